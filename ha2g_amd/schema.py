@@ -1,0 +1,136 @@
+"""state_dict schemas (key -> shape) of the four hot-path modules, exactly as the reference registers
+them (verified against the reference modules in tests/golden/gen_golden.py).
+Reference checkpoints (`gen_dict_1..3`, `dis_dict`, `audio_dict`, `text_dict`, scripts/train.py:233-237)
+therefore load into the modules of this package unchanged.
+"""
+
+
+def text_encoder_schema(n_words, hidden, n_layers, embed=300, p=''):
+    s = {p + 'embedding.weight': (n_words, embed)}
+    for i in range(n_layers):
+        cin = embed if i == 0 else hidden
+        for conv, alias, c_in in (('conv1', 'net.0', cin), ('conv2', 'net.4', hidden)):
+            for name in (conv, alias):       # TemporalBlock registers every conv twice (tcn.py:19,25,31)
+                q = '%stcn.network.%d.%s.' % (p, i, name)
+                s[q + 'bias'] = (hidden,)
+                s[q + 'weight_g'] = (hidden, 1, 1)
+                s[q + 'weight_v'] = (hidden, c_in, 2)
+        if cin != hidden:
+            s['%stcn.network.%d.downsample.weight' % (p, i)] = (hidden, cin, 1)
+            s['%stcn.network.%d.downsample.bias' % (p, i)] = (hidden,)
+    s[p + 'decoder.weight'] = (32, hidden)
+    s[p + 'decoder.bias'] = (32,)
+    return s
+
+
+def gru_schema(in_size, hidden, n_layers, p=''):
+    s = {}
+    for l in range(n_layers):
+        k = in_size if l == 0 else 2 * hidden
+        for suf in ('', '_reverse'):
+            s['%sweight_ih_l%d%s' % (p, l, suf)] = (3 * hidden, k)
+            s['%sweight_hh_l%d%s' % (p, l, suf)] = (3 * hidden, hidden)
+            s['%sbias_ih_l%d%s' % (p, l, suf)] = (3 * hidden,)
+            s['%sbias_hh_l%d%s' % (p, l, suf)] = (3 * hidden,)
+    return s
+
+
+def generator_schema(pose_dim, n_words, n_spk, hidden, n_layers, p=''):
+    s = text_encoder_schema(n_words, hidden, n_layers, p=p + 'text_encoder.')
+    s[p + 'speaker_embedding.0.weight'] = (n_spk, 16)
+    for name in ('speaker_embedding.1', 'speaker_mu', 'speaker_logvar'):
+        s[p + name + '.weight'] = (16, 16)
+        s[p + name + '.bias'] = (16,)
+    s.update(gru_schema(32 + 32 + pose_dim + 1 + 16, hidden, n_layers, p + 'gru.'))
+    s[p + 'out.0.weight'] = (hidden // 2, hidden)
+    s[p + 'out.0.bias'] = (hidden // 2,)
+    s[p + 'out.2.weight'] = (pose_dim, hidden // 2)
+    s[p + 'out.2.bias'] = (pose_dim,)
+    return s
+
+
+def _bn(s, q, c):
+    s[q + 'weight'] = (c,)
+    s[q + 'bias'] = (c,)
+    s[q + 'running_mean'] = (c,)
+    s[q + 'running_var'] = (c,)
+    s[q + 'num_batches_tracked'] = ()
+
+
+def discriminator_schema(pose_dim, p=''):
+    s = {}
+    for idx, (co, ci) in ((0, (16, pose_dim)), (3, (8, 16)), (6, (8, 8))):
+        s['%spre_conv.%d.weight' % (p, idx)] = (co, ci, 3)
+        s['%spre_conv.%d.bias' % (p, idx)] = (co,)
+    _bn(s, p + 'pre_conv.1.', 16)
+    _bn(s, p + 'pre_conv.4.', 8)
+    s.update(gru_schema(8, 64, 4, p + 'gru.'))
+    s[p + 'out.weight'] = (1, 64)
+    s[p + 'out.bias'] = (1,)
+    s[p + 'out2.weight'] = (1, 28)
+    s[p + 'out2.bias'] = (1,)
+    return s
+
+
+WAV_LAYERS = (3, 4, 6, 3)
+WAV_FILTERS = (32, 64, 128, 256)
+
+
+def wav_encoder_schema(n_spk, pose_level, p=''):
+    q = p + 'feat_extractor.'
+    s = {q + 'conv1.weight': (32, 1, 3, 3), q + 'conv1.bias': (32,)}
+    _bn(s, q + 'bn1.', 32)
+    for name, c, k, h in (('low', 64, 2, 63), ('mid', 32, 3, 62), ('high', 16, 3, 62)):
+        s[q + 'conv_%s.weight' % name] = (c, c, k, k)
+        s[q + 'conv_%s.bias' % name] = (c,)
+        _bn(s, q + 'bn_%s.' % name, c)
+        s[q + 'fc_%s.weight' % name] = (32, h * c)
+        s[q + 'fc_%s.bias' % name] = (32,)
+    cin = 32
+    for li, (nblk, c) in enumerate(zip(WAV_LAYERS, WAV_FILTERS)):
+        for j in range(nblk):
+            b = '%slayer%d.%d.' % (q, li + 1, j)
+            s[b + 'conv1.weight'] = (c, cin if j == 0 else c, 3, 3)
+            _bn(s, b + 'bn1.', c)
+            s[b + 'conv2.weight'] = (c, c, 3, 3)
+            _bn(s, b + 'bn2.', c)
+            s[b + 'se.fc.0.weight'] = (c // 8, c)
+            s[b + 'se.fc.0.bias'] = (c // 8,)
+            s[b + 'se.fc.2.weight'] = (c, c // 8)
+            s[b + 'se.fc.2.bias'] = (c,)
+            if j == 0 and li > 0:
+                s[b + 'downsample.0.weight'] = (c, cin, 1, 1)
+                _bn(s, b + 'downsample.1.', c)
+        cin = c
+    s[q + 'speaker_embedding.0.weight'] = (n_spk, 16)
+    s[q + 'speaker_embedding.1.weight'] = (16, 16)
+    s[q + 'speaker_embedding.1.bias'] = (16,)
+    s[q + 'fc1.weight'] = (32, 16)
+    s[q + 'fc1.bias'] = (32,)
+    s[q + 'fc2.weight'] = (3 * pose_level, 32)
+    s[q + 'fc2.bias'] = (3 * pose_level,)
+    return s
+
+
+GESTURE_POSE_DIMS = (15, 21, 27)
+EXPRESSIVE_POSE_DIMS = (24, 30, 36, 66, 96, 126)
+
+
+def step_schema(case_or_dims, n_words, n_spk, hidden, n_layers):
+    """All modules of one train step keyed by role prefix ('g1.', ..., 'dis.', 'audio.', 'text.')."""
+    dims = tuple(case_or_dims)
+    s = {}
+    for i, pd in enumerate(dims):
+        s.update(generator_schema(pd, n_words, n_spk, hidden, n_layers, 'g%d.' % (i + 1)))
+    s.update(discriminator_schema(dims[-1], 'dis.'))
+    s.update(wav_encoder_schema(n_spk, len(dims), 'audio.'))
+    s.update(text_encoder_schema(n_words, hidden, n_layers, p='text.'))
+    return s
+
+
+def procedural_state(schema, seed):
+    """Materialise a schema with ha2g_amd.procedural values as torch CPU tensors."""
+    import torch
+    from . import procedural as proc
+    return {k: torch.from_numpy(proc.tensor_for(k, shp, seed)) if shp != () else
+            torch.tensor(int(proc.tensor_for(k, (1,), seed)[0])) for k, shp in schema.items()}

@@ -1,0 +1,133 @@
+"""Shared parity-test helpers: procedural state/batches and the golden-fixture tolerance policy.
+
+Tolerance policy (DESIGN.md "Parity"): an fp32 implementation passes on array X when
+    max|X - truth64| <= 1e-4 * max|truth64| + 4 * noise32(X) + tiny,
+where truth64 / noise32 come from the reference's own float64 / float32 runs stored in tests/golden.
+A float64 implementation must hit 1e-9.
+"""
+import numpy as np
+import torch
+
+from . import procedural as proc
+from . import schema
+
+
+def state_for(case, dt=torch.float32, dims=schema.GESTURE_POSE_DIMS):
+    sch = schema.step_schema(dims, case['n_words'], case['n_spk'], case['hidden_size'], case['n_layers'])
+    sd = schema.procedural_state(sch, case['seed'])
+    return {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def batch_for(case, dt=torch.float32, P=27):
+    text, spec, target, vid = map(torch.from_numpy,
+                                  proc.make_batch(case['B'], P, case['n_words'], case['n_spk'], case['seed']))
+    return text, spec.to(dt), target.to(dt), vid
+
+
+def wproc(name, t, seed):
+    w = proc.tensor_for('w.' + name, (2,) + tuple(t.shape), seed)[0] * t[0].numel() ** 0.5
+    return torch.from_numpy(w).to(device=t.device, dtype=t.dtype)
+
+
+def leaf_params(sd, role):
+    ps = {k: v for k, v in sd.items() if k.startswith(role + '.') and v.is_floating_point()
+          and not k.endswith(('running_mean', 'running_var')) and '.net.' not in k}
+    for v in ps.values():
+        v.requires_grad_(True)
+    return ps
+
+
+def _np(t):
+    if isinstance(t, torch.Tensor):
+        t = t.detach().double().cpu().numpy()
+    return np.asarray(t, np.float64)
+
+
+class Checker:
+    def __init__(self, g, dt=torch.float32, rtol=1e-4, noise_mult=4.0):
+        self.g = g
+        self.f64 = dt == torch.float64
+        self.rtol = 1e-9 if self.f64 else rtol
+        self.nm = 0.0 if self.f64 else noise_mult
+        self.worst = 0.0
+
+    def _tol(self, key, scale):
+        return self.rtol * scale + self.nm * float(self.g[key + '@noise']) + 1e-12 + (0 if self.f64 else 1e-7 * scale)
+
+    def close(self, got, key):
+        ref = self.g[key]
+        got = _np(got).reshape(ref.shape)
+        scale = max(np.abs(ref).max(), 1e-30)
+        err = np.abs(got - ref).max()
+        tol = self._tol(key, scale)
+        self.worst = max(self.worst, err / scale)
+        assert err <= tol, '%s: max err %.3e > tol %.3e (scale %.3e, ref fp32 noise %.3e)' % (
+            key, err, tol, scale, float(self.g[key + '@noise']))
+
+    def digest(self, got, key, norms_only=False):
+        """Compare (norm, strided sample) digests of a large tensor."""
+        a = _np(got).reshape(-1)
+        stride = max(1, a.size // 64)
+        smp = a[::stride][:64]
+        nrm = np.sqrt((a * a).sum())
+        rn = float(self.g[key + '/norm'])
+        tol = self._tol(key + '/norm', max(rn, 1e-30))
+        assert abs(nrm - rn) <= tol, '%s/norm: %.9e vs %.9e (tol %.2e)' % (key, nrm, rn, tol)
+        ref = self.g[key + '/sample']
+        # elementwise: scale by the tensor's rms-ish magnitude so tiny sampled entries are not over-weighted
+        scale = max(np.abs(ref).max(), rn / max(np.sqrt(a.size), 1.0), 1e-30)
+        err = np.abs(smp - ref).max()
+        tol = self._tol(key + '/sample', scale)
+        assert err <= tol, '%s/sample: max err %.3e > tol %.3e (scale %.3e)' % (key, err, tol, scale)
+
+    def grads(self, prefix, role, params, grads):
+        for (k, _), gr in zip(params.items(), grads):
+            self.digest(gr, '%s/%s' % (prefix, k[len(role) + 1:]))
+
+    def step(self, si, ret, grads, sd, lr=5e-4):
+        g = self.g
+        pre = 'step%d/' % si
+        if si > 0 and not self.f64:
+            # The 2nd step runs on Adam-updated weights: sign flips of noise-level gradients feed back into
+            # every tensor, so two fp32 runs of the REFERENCE itself scatter at the 1e-3 level here (B=3..4).
+            # The exact state logic (Adam moments, D-phase ordering, grad accumulation on D) is pinned by the
+            # float64 run; in fp32 only the loss dict and gradient norms are checked, loosely.
+            relaxed = Checker(g, torch.float32, rtol=2e-3, noise_mult=self.nm * 4)
+            return relaxed._step(si, ret, grads, sd, lr, norms_only=True)
+        return self._step(si, ret, grads, sd, lr)
+
+    def _step(self, si, ret, grads, sd, lr, norms_only=False):
+        g = self.g
+        pre = 'step%d/' % si
+        ref_keys = sorted(k[len(pre) + 4:] for k in g.files if k.startswith(pre + 'ret/') and '@' not in k)
+        assert sorted(ret) == ref_keys, (sorted(ret), ref_keys)
+        for k, v in ret.items():
+            r = float(g[pre + 'ret/' + k])
+            tol = self._tol(pre + 'ret/' + k, max(abs(r), 1e-3))
+            assert abs(v - r) <= tol, (si, k, v, r, tol)
+        for k in g.files:
+            if '@' in k or not k.startswith(pre) or not k.endswith('/norm'):
+                continue
+            kind, pk = k[len(pre):-5].split('/', 1)
+            if '.net.' in pk:
+                continue
+            if norms_only:
+                if kind == 'grad':
+                    nrm = float(np.sqrt((_np(grads[pk]) ** 2).sum()))
+                    rn = float(g[k])
+                    assert abs(nrm - rn) <= 2e-2 * rn + 4 * float(g[k + '@noise']) + 1e-9, (si, pk, nrm, rn)
+                continue
+            if kind == 'grad':
+                self.digest(grads[pk], k[:-5])
+            elif kind == 'buf':
+                self.digest(sd[pk], k[:-5])
+            elif kind == 'param':
+                if self.f64:
+                    self.digest(sd[pk], k[:-5])
+                else:
+                    # Adam's first steps move every weight by ~lr whatever |g| is, and flip with the sign of
+                    # noise-level gradients: compare within 2 % of the accumulated step size instead.
+                    a = _np(sd[pk]).reshape(-1)
+                    smp = a[::max(1, a.size // 64)][:64]
+                    err = np.abs(smp - g[k[:-5] + '/sample']).max()
+                    assert err <= 0.02 * lr * (si + 1) + 4 * float(g[k[:-5] + '/sample@noise']), (si, pk, err)

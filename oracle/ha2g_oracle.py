@@ -1,0 +1,375 @@
+"""CPU ORACLE for the HA2G hierarchy train step -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A from-scratch functional restatement (torch CPU fp32 primitives over plain dicts of tensors) of the
+reference algorithm on the hot path.  Only tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg may import it; nothing under ha2g_amd/ does.
+
+Parity status: PINNED.  Every function here is checked in tests/test_oracle_golden.py against the
+fixtures tests/golden/*.npz, which were produced by importing and running the reference itself
+(tests/golden/gen_golden.py) -- module outputs, gradients, two full train steps (warm-up phase and
+GAN phase) incl. Adam updates and BatchNorm running statistics, Gesture and Expressive variants.
+
+State is a flat dict  name -> tensor  using the reference's state_dict keys
+prefixed by the module's role: 'g1.'..'g6.', 'dis.', 'audio.', 'text.'.
+
+Reference citations are relative to /root/reference/scripts/.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------------------------
+# primitives
+# ----------------------------------------------------------------------------------------------
+
+
+def batch_norm_train(x, sd, p, momentum=0.1, eps=1e-5, update=True):
+    """Train-mode BatchNorm over all dims but channel (dim 1): biased batch variance to normalise,
+    unbiased variance into running_var, momentum 0.1 (torch semantics).  Uses the
+    fused torch primitive so that the float32 backward has the same (analytic) form as the reference's."""
+    rm = sd[p + 'running_mean'] if update else None
+    rv = sd[p + 'running_var'] if update else None
+    if update:
+        sd[p + 'num_batches_tracked'].add_(1)
+    return F.batch_norm(x, rm, rv, sd[p + 'weight'], sd[p + 'bias'], True, momentum, eps)
+
+
+def gru_bidir(x, sd, p, n_layers, H, masks=None):
+    """Stacked bidirectional GRU, batch_first, h0 = 0 (torch.nn.GRU semantics).
+    gates ordered (r,z,n); n = tanh(gi_n + r*(W_hn h + b_hn)); h' = (1-z)*n + z*h.
+    `masks[l]` (already scaled by 1/(1-p)) multiplies the output of layer l < last (dropout)."""
+    B, T, _ = x.shape
+    inp = x
+    for l in range(n_layers):
+        outs = []
+        for suffix, order in (('', range(T)), ('_reverse', range(T - 1, -1, -1))):
+            w_ih, w_hh = sd['%sweight_ih_l%d%s' % (p, l, suffix)], sd['%sweight_hh_l%d%s' % (p, l, suffix)]
+            b_ih, b_hh = sd['%sbias_ih_l%d%s' % (p, l, suffix)], sd['%sbias_hh_l%d%s' % (p, l, suffix)]
+            gi_all = inp @ w_ih.t() + b_ih
+            h = x.new_zeros(B, H)
+            ys = [None] * T
+            for t in order:
+                gi = gi_all[:, t]
+                gh = h @ w_hh.t() + b_hh
+                r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+                z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+                n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+                h = (1 - z) * n + z * h
+                ys[t] = h
+            outs.append(torch.stack(ys, 1))
+        inp = torch.cat(outs, 2)
+        if masks is not None and l < n_layers - 1:
+            inp = inp * masks[l]
+    return inp
+
+
+def weight_norm(g, v):
+    """w = g * v / ||v||, norm over (in, k) per output channel (tcn.py:19 via torch weight_norm)."""
+    return g * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
+
+
+# ----------------------------------------------------------------------------------------------
+# modules
+# ----------------------------------------------------------------------------------------------
+
+
+def text_encoder_tcn(tokens, sd, p, n_layers, drop=None):
+    """model/hierarchy_net.py:48-52 + model/tcn.py:16-64: embedding -> n_layers x [2 x (causal dilated
+    conv k=2 -> ReLU)] + identity residual -> ReLU -> Linear(->32).  `drop` = optional dict of
+    pre-scaled dropout masks {'emb', (i,0), (i,1)}."""
+    x = F.embedding(tokens, sd[p + 'embedding.weight'])
+    if drop:
+        x = x * drop['emb']
+    x = x.transpose(1, 2)                                            # (B, C, T)
+    for i in range(n_layers):
+        dil = 2 ** i
+        res = x
+        y = x
+        for j, c in enumerate(('conv1', 'conv2')):
+            q = '%stcn.network.%d.%s.' % (p, i, c)
+            w = weight_norm(sd[q + 'weight_g'], sd[q + 'weight_v'])
+            y = F.conv1d(F.pad(y, (dil, 0)), w, sd[q + 'bias'], dilation=dil)   # left pad == pad+chomp
+            y = torch.relu(y)
+            if drop:
+                y = y * drop[(i, j)]
+        if (p + 'tcn.network.%d.downsample.weight' % i) in sd:
+            res = F.conv1d(res, sd[p + 'tcn.network.%d.downsample.weight' % i], sd[p + 'tcn.network.%d.downsample.bias' % i])
+        x = torch.relu(y + res)
+    return F.linear(x.transpose(1, 2), sd[p + 'decoder.weight'], sd[p + 'decoder.bias'])
+
+
+def _se_block(x, sd, p, stride, has_down, update_bn):
+    """model/ResNetBlocks.py:21-37: conv -> ReLU -> BN -> conv -> BN -> SE -> (+residual) -> ReLU."""
+    out = F.conv2d(x, sd[p + 'conv1.weight'], None, stride=stride, padding=1)
+    out = batch_norm_train(torch.relu(out), sd, p + 'bn1.', update=update_bn)
+    out = F.conv2d(out, sd[p + 'conv2.weight'], None, padding=1)
+    out = batch_norm_train(out, sd, p + 'bn2.', update=update_bn)
+    y = out.mean((2, 3))                                             # ResNetBlocks.py:91-95
+    y = torch.relu(F.linear(y, sd[p + 'se.fc.0.weight'], sd[p + 'se.fc.0.bias']))
+    y = torch.sigmoid(F.linear(y, sd[p + 'se.fc.2.weight'], sd[p + 'se.fc.2.bias']))
+    out = out * y[:, :, None, None]
+    if has_down:
+        x = F.conv2d(x, sd[p + 'downsample.0.weight'], None, stride=stride)
+        x = batch_norm_train(x, sd, p + 'downsample.1.', update=update_bn)
+    return torch.relu(out + x)
+
+
+def wav_encoder(spec, vid, sd, p, pose_level, update_bn=True):
+    """model/hierarchy_net.py:16-19 -> model/ResNetSE34V2.py:118-218.  Returns
+    (weight (B,3,L), feat_low, feat_mid, feat_high (B,T,32), [blend_i (B,T,32)] * L)."""
+    q = p + 'feat_extractor.'
+    B = spec.shape[0]
+    x = F.conv2d(spec.unsqueeze(1), sd[q + 'conv1.weight'], sd[q + 'conv1.bias'], padding=1)
+    x = batch_norm_train(torch.relu(x), sd, q + 'bn1.', update=update_bn)
+    feats = []
+    for li, nblk in enumerate((3, 4, 6, 3)):
+        for j in range(nblk):
+            first = j == 0 and li > 0
+            x = _se_block(x, sd, '%slayer%d.%d.' % (q, li + 1, j), 2 if first else 1, first, update_bn)
+        feats.append(x)
+
+    def tap(f, name, shuffle):
+        if shuffle > 1:
+            f = F.pixel_shuffle(f, shuffle)
+        f = F.conv2d(f, sd[q + 'conv_%s.weight' % name], sd[q + 'conv_%s.bias' % name])
+        f = batch_norm_train(torch.relu(f), sd, q + 'bn_%s.' % name, update=update_bn)
+        f = f.reshape(B, -1, f.shape[-1]).transpose(1, 2)            # (B, W, C*H), K index = c*H + h
+        return F.linear(f, sd[q + 'fc_%s.weight' % name], sd[q + 'fc_%s.bias' % name])
+
+    low = tap(feats[1], 'low', 1)
+    mid = tap(feats[2], 'mid', 2)
+    high = tap(feats[3], 'high', 4)
+    z = F.embedding(vid, sd[q + 'speaker_embedding.0.weight'])
+    z = F.linear(z, sd[q + 'speaker_embedding.1.weight'], sd[q + 'speaker_embedding.1.bias'])
+    h = F.elu(F.linear(F.elu(z), sd[q + 'fc1.weight'], sd[q + 'fc1.bias']))
+    w = F.linear(h, sd[q + 'fc2.weight'], sd[q + 'fc2.bias']).reshape(B, 3, pose_level).softmax(1)
+    blend = [low * w[:, 0, i, None, None] + mid * w[:, 1, i, None, None] + high * w[:, 2, i, None, None]
+             for i in range(pose_level)]
+    return w, low, mid, high, blend
+
+
+def pose_generator(pre_seq, tokens, audio_feat, vid, sd, p, n_layers, H, eps, drop=None):
+    """model/hierarchy_net.py:99-149.  eps: (B,16) reparameterisation noise.  drop: optional dict with
+    'text' (text-encoder masks) and 'gru' (list of layer masks)."""
+    text = text_encoder_tcn(tokens, sd, p + 'text_encoder.', n_layers, drop['text'] if drop else None)
+    z = F.embedding(vid, sd[p + 'speaker_embedding.0.weight'])
+    z = F.linear(z, sd[p + 'speaker_embedding.1.weight'], sd[p + 'speaker_embedding.1.bias'])
+    mu = F.linear(z, sd[p + 'speaker_mu.weight'], sd[p + 'speaker_mu.bias'])
+    logvar = F.linear(z, sd[p + 'speaker_logvar.weight'], sd[p + 'speaker_logvar.bias'])
+    zc = mu + eps * torch.exp(0.5 * logvar)                          # embedding_net.py:10-13
+    x = torch.cat((pre_seq, audio_feat, text, zc.unsqueeze(1).expand(-1, pre_seq.shape[1], -1)), 2)
+    y = gru_bidir(x, sd, p + 'gru.', n_layers, H, drop['gru'] if drop else None)
+    y = y[:, :, :H] + y[:, :, H:]
+    y = F.linear(y, sd[p + 'out.0.weight'], sd[p + 'out.0.bias'])
+    y = F.leaky_relu(y, 0.01)
+    y = F.linear(y, sd[p + 'out.2.weight'], sd[p + 'out.2.bias'])
+    return y, zc, mu, logvar
+
+
+def conv_discriminator(poses, sd, p, update_bn=True, gru_masks=None):
+    """model/hierarchy_net.py:222-242: 3 x Conv1d(k=3) (+BN+LeakyReLU on the first two) -> bi-GRU(8->64,
+    4 layers) -> direction sum -> Linear(64,1) per frame -> Linear(T-6,1) -> sigmoid."""
+    x = poses.transpose(1, 2)
+    x = F.conv1d(x, sd[p + 'pre_conv.0.weight'], sd[p + 'pre_conv.0.bias'])
+    x = F.leaky_relu(batch_norm_train(x, sd, p + 'pre_conv.1.', update=update_bn), 0.01)
+    x = F.conv1d(x, sd[p + 'pre_conv.3.weight'], sd[p + 'pre_conv.3.bias'])
+    x = F.leaky_relu(batch_norm_train(x, sd, p + 'pre_conv.4.', update=update_bn), 0.01)
+    x = F.conv1d(x, sd[p + 'pre_conv.6.weight'], sd[p + 'pre_conv.6.bias']).transpose(1, 2)
+    y = gru_bidir(x, sd, p + 'gru.', 4, 64, gru_masks)
+    y = y[:, :, :64] + y[:, :, 64:]
+    y = F.linear(y, sd[p + 'out.weight'], sd[p + 'out.bias']).squeeze(2)
+    return torch.sigmoid(F.linear(y, sd[p + 'out2.weight'], sd[p + 'out2.bias']))
+
+
+# ----------------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------------
+
+
+def contrastive_ce(a, b, expressive=False, chunk=1024):
+    """train_eval/train_hierarchy.py:54-68 (Gesture: +1e-8, clamp) and
+    train_hierarchy_expressive.py:107-121 (no eps, no clamp).  dist[i,j] = ||a_i - b_j||, rows = a.
+    Computed in row chunks (same arithmetic; avoids the N x N x 32 intermediate of the reference)."""
+    a = F.normalize(a, p=2, dim=1)
+    b = F.normalize(b, p=2, dim=1)
+    N = a.shape[0]
+    total = a.new_zeros(())
+    for s in range(0, N, chunk):
+        d = (a[s:s + chunk, None, :] - b[None, :, :]).norm(p=2, dim=2)
+        logits = 1.0 / d if expressive else torch.clamp(1.0 / (d + 1e-8), min=1e-8)
+        total = total + F.cross_entropy(logits, torch.arange(s, min(s + chunk, N)), reduction='sum')
+    return total / N
+
+
+def huber(x, y, beta, reduction='mean'):
+    """smooth_l1_loss(x/beta, y/beta) * beta == Huber(delta=beta) (train_hierarchy.py:173-176)."""
+    d = (x - y).abs()
+    v = torch.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta)
+    return v.mean() if reduction == 'mean' else v
+
+
+GESTURE_PAIRS = ((3, 4), (4, 5), (6, 7), (7, 8))
+
+
+def physical_prior(out, mean_dir_vec, pairs, avg, var, palm=False):
+    """train_hierarchy.py:242-262 / train_hierarchy_expressive.py:421-447."""
+    raw = out + mean_dir_vec.view(1, 1, -1)
+    v = F.normalize(raw.reshape(raw.shape[0] * raw.shape[1], -1, 3), dim=-1)
+    if palm:
+        left = F.normalize(torch.cross(v[:, 11], v[:, 17], dim=1), dim=-1)
+        right = F.normalize(torch.cross(v[:, 28], v[:, 34], dim=1), dim=-1)
+        v = torch.cat((v, left.unsqueeze(1), right.unsqueeze(1)), 1)
+    total = 0
+    for i, (a, b) in enumerate(pairs):
+        ip = torch.clamp((v[:, a] * v[:, b]).sum(1), -1 + 1e-7, 1 - 1e-7)
+        ang = torch.acos(ip) / math.pi
+        total = total + torch.mean((ang - avg[i]) ** 2 / (2 * var[i]))
+    return total
+
+
+# ----------------------------------------------------------------------------------------------
+# hierarchy tables
+# ----------------------------------------------------------------------------------------------
+
+# Gesture: columns of the 27-d target that make each level's target (train_hierarchy.py:86-88)
+GESTURE_LEVEL_COLS = (
+    list(range(0, 12)) + list(range(18, 21)),
+    list(range(0, 15)) + list(range(18, 24)),
+    list(range(0, 27)),
+)
+# (dst column range in pre_seq_{k+1}, src column range in out_k) (train_hierarchy.py:161-162,168-169)
+GESTURE_SCATTER = (
+    (((0, 12), (0, 12)), ((15, 18), (12, 15))),
+    (((0, 15), (0, 15)), ((18, 24), (15, 21))),
+)
+
+
+def _adam(params, grads, state, lr, step, b1=0.5, b2=0.999, eps=1e-8):
+    """torch.optim.Adam semantics (no weight decay, no amsgrad): train.py:155-170."""
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    with torch.no_grad():
+        for k, p in params.items():
+            g = grads.get(k)
+            if g is None:
+                continue
+            m, v = state.setdefault(k, (torch.zeros_like(p), torch.zeros_like(p)))
+            m.mul_(b1).add_(g, alpha=1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            p.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)
+
+
+class OracleTrainer:
+    """Holds the state dict, Adam states and step counters of the six (nine) modules and runs
+    train_iter_hierarchy (train_eval/train_hierarchy.py:71-293) on CPU."""
+
+    def __init__(self, sd, args, n_levels=3):
+        self.sd = sd
+        self.args = args
+        self.L = n_levels
+        self.roles = ['g%d' % (i + 1) for i in range(n_levels)] + ['dis', 'audio', 'text']
+        self.adam = {r: {} for r in self.roles}
+        self.steps = {r: 0 for r in self.roles}
+        self.grads = {}                                              # name -> accumulated .grad (dis keeps across phases)
+        if n_levels != 3:
+            raise NotImplementedError('the 6-level expressive step is not restated yet (parity for it: unpinned)')
+
+    def params(self, role):
+        return {k: v for k, v in self.sd.items() if k.startswith(role + '.') and v.is_floating_point()
+                and not k.endswith(('running_mean', 'running_var')) and '.net.' not in k}
+
+    def _chain(self, tokens, target_lv, blend, vid, eps_fn, grad):
+        a = self.args
+        outs = []
+        last = None
+        ctx = torch.enable_grad() if grad else torch.no_grad()
+        with ctx:
+            for k in range(3):
+                tk = target_lv[k]
+                pre = tk.new_zeros(tk.shape[0], tk.shape[1], tk.shape[2] + 1)
+                pre[:, :a.n_pre_poses, :-1] = tk[:, :a.n_pre_poses]
+                pre[:, :a.n_pre_poses, -1] = 1
+                if k > 0:                                            # coarse output -> finer pre_seq, differentiable
+                    for (d0, d1), (s0, s1) in GESTURE_SCATTER[k - 1]:
+                        pre[:, a.n_pre_poses:, d0:d1] = outs[-1][:, a.n_pre_poses:, s0:s1]
+                o, z, mu, lv = pose_generator(pre, tokens, blend[k], vid, self.sd, 'g%d.' % (k + 1), a.n_layers,
+                                              a.hidden_size, eps_fn((tk.shape[0], 16)))
+                outs.append(o)
+                last = (z, mu, lv)
+        return outs, last
+
+    def train_iter(self, epoch, tokens, spec, target, vid, eps_fn, rand_perm):
+        a = self.args
+        sd = self.sd
+        for r in self.roles:
+            for k, p in self.params(r).items():
+                p.requires_grad_(True)
+        _, low, mid, high, blend = wav_encoder(spec, vid, sd, 'audio.', 3)
+        text_feat = text_encoder_tcn(tokens, sd, 'text.', a.n_layers)
+        tl = [target[:, :, c] for c in GESTURE_LEVEL_COLS]
+        ret = {}
+        gan = epoch > a.loss_warmup and a.loss_gan_weight > 0.0
+        dis_error = None
+        if gan:
+            for k in self.params('dis'):
+                self.grads.pop(k, None)
+            outs, _ = self._chain(tokens, tl, [b.detach() for b in blend], vid, eps_fn, grad=False)
+            real = conv_discriminator(target, sd, 'dis.')
+            fake = conv_discriminator(outs[2].detach(), sd, 'dis.')
+            dis_error = -torch.mean(torch.log(real + 1e-8) + torch.log(1 - fake + 1e-8))
+            dp = self.params('dis')
+            gs = torch.autograd.grad(dis_error, list(dp.values()), allow_unused=True)
+            for (k, _), g in zip(dp.items(), gs):
+                if g is not None:
+                    self.grads[k] = g.clone()
+            self.steps['dis'] += 1
+            _adam(dp, self.grads, self.adam['dis'], a.learning_rate * a.discriminator_lr_weight, self.steps['dis'])
+        for r in self.roles:
+            if r != 'dis':
+                for k in self.params(r):
+                    self.grads.pop(k, None)
+        N = text_feat.shape[0] * text_feat.shape[1]
+        c_pos = contrastive_ce(text_feat.reshape(N, -1), high.reshape(N, -1))
+        c_neg = -contrastive_ce(text_feat.reshape(N, -1), low.reshape(N, -1))
+        outs, (z, mu, logvar) = self._chain(tokens, tl, blend, vid, eps_fn, grad=True)
+        hub = sum(huber(o, t, 0.1) for o, t in zip(outs, tl))
+        dis_out = conv_discriminator(outs[2], sd, 'dis.')
+        gen_error = -torch.mean(torch.log(dis_out + 1e-8))
+        rvid = vid[rand_perm]
+        routs, (rz, _, _) = self._chain(tokens, tl, [b.detach() for b in blend], rvid, eps_fn, grad=False)
+        pose_l1 = huber(outs[2], routs[2].detach(), 0.05, 'none').sum((1, 2))
+        z_l1 = (z.detach() - rz.detach()).abs().mean(1)
+        div_reg = torch.clamp(-(pose_l1 / (z_l1 + 1e-5)), min=-1000).mean()
+        kld = -0.5 * torch.mean(1 + logvar - mu.pow(2) - logvar.exp())
+        loss = a.loss_regression_weight * hub + a.loss_kld_weight * kld + a.loss_reg_weight * div_reg
+        if epoch > a.loss_warmup:
+            loss = loss + a.loss_gan_weight * gen_error
+        loss = loss + a.loss_contrastive_pos_weight * c_pos + a.loss_contrastive_neg_weight * c_neg
+        from ha2g_amd.config import PHYS_GESTURE
+        mdv = torch.tensor(a.mean_dir_vec).squeeze(1)
+        phy = physical_prior(outs[2], mdv, GESTURE_PAIRS, PHYS_GESTURE[0], PHYS_GESTURE[1])
+        loss = loss + a.loss_physical_weight * phy
+        allp = {}
+        for r in self.roles:
+            allp.update(self.params(r))
+        gs = torch.autograd.grad(loss, list(allp.values()), allow_unused=True)
+        for (k, _), g in zip(allp.items(), gs):
+            if g is not None:
+                self.grads[k] = self.grads[k] + g if k in self.grads else g.clone()
+        for r in self.roles:
+            if r == 'dis':
+                continue
+            self.steps[r] += 1
+            _adam(self.params(r), self.grads, self.adam[r], a.learning_rate, self.steps[r])
+        ret['loss'] = a.loss_regression_weight * hub.item()
+        if kld.item():
+            ret['KLD'] = a.loss_kld_weight * kld.item()
+        if div_reg.item():
+            ret['DIV_REG'] = a.loss_reg_weight * div_reg.item()
+        if gan:
+            ret['gen'] = a.loss_gan_weight * gen_error.item()
+            ret['dis'] = dis_error.item()
+        ret['c_pos'] = a.loss_contrastive_pos_weight * c_pos.item()
+        ret['c_neg'] = a.loss_contrastive_neg_weight * c_neg.item()
+        ret['phy'] = a.loss_physical_weight * phy.item()
+        return ret

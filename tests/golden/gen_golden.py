@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Generate the parity fixtures in tests/golden/*.npz by running the REFERENCE itself on CPU.
+
+Runs only in the build container (needs /root/reference, read-only); the fixtures it writes are
+data (expected outputs), never reference source.  Parameters and inputs are NOT stored: they are
+regenerated on both sides from ha2g_amd/procedural.py.
+
+Import recipe: stub `fasttext`, put /root/reference/scripts on sys.path, no bytecode.
+Determinism: dropout p=0 everywhere, reparameterize() fed from procedural.EpsStream, torch.randperm
+replaced by procedural.fixed_perm; BatchNorm stays in train mode.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.modules.setdefault('fasttext', types.ModuleType('fasttext'))
+sys.path.insert(0, '/root/reference/scripts')
+
+import numpy as np
+import torch
+
+import model.embedding_net as ref_embedding_net
+from model import vocab as ref_vocab
+from model.hierarchy_net import (Hierarchical_ConvDiscriminator, Hierarchical_PoseGenerator,
+                                 Hierarchical_WavEncoder, TextEncoderTCN)
+from train_eval.train_hierarchy import SoftmaxContrastiveLoss, train_iter_hierarchy
+import train_eval.train_hierarchy_expressive as ref_expr
+
+from ha2g_amd import procedural as proc
+from ha2g_amd.config import CASES, make_args, MEAN_DIR_VEC_EXPRESSIVE  # noqa: F401
+
+torch.set_num_threads(8)
+
+
+def speaker_vocab(n_spk):
+    v = ref_vocab.Vocab('vid', insert_default_tokens=False)
+    while v.n_words < n_spk:
+        v.index_word('spk%d' % v.n_words)
+    return v
+
+
+class Lang:
+    def __init__(self, n_words):
+        self.n_words = n_words
+        self.word_embedding_weights = None
+
+
+def no_dropout(m):
+    for sub in m.modules():
+        if isinstance(sub, torch.nn.Dropout):
+            sub.p = 0.0
+        if isinstance(sub, torch.nn.GRU):
+            sub.dropout = 0.0
+    return m
+
+
+def build(case, pose_dims, pose_level, dt=torch.float32):
+    args = make_args(case)
+    spk = speaker_vocab(case['n_spk'])
+    lang = Lang(case['n_words'])
+    gens = []
+    for i, pd in enumerate(pose_dims):
+        g = Hierarchical_PoseGenerator(args, n_words=lang.n_words, word_embed_size=300, word_embeddings=None,
+                                       z_obj=spk, pose_dim=pd)
+        gens.append(no_dropout(proc.fill_module(g, case['seed'], 'g%d.' % (i + 1))))
+    dis = no_dropout(proc.fill_module(Hierarchical_ConvDiscriminator(pose_dims[-1]), case['seed'], 'dis.'))
+    aud = no_dropout(proc.fill_module(Hierarchical_WavEncoder(args, z_obj=spk, pose_level=pose_level, nOut=32),
+                                      case['seed'], 'audio.'))
+    txt = no_dropout(proc.fill_module(TextEncoderTCN(args, lang.n_words, 300, pre_trained_embedding=None,
+                                                     dropout=args.dropout_prob), case['seed'], 'text.'))
+    gens = [g.to(dt) for g in gens]
+    return args, gens, dis.to(dt), aud.to(dt), txt.to(dt)
+
+
+def digest(out, name, t):
+    a = t.detach().double().numpy().reshape(-1)
+    stride = max(1, a.size // 64)
+    out[name + '/norm'] = np.float64(np.sqrt((a * a).sum()))
+    out[name + '/sample'] = a[::stride][:64].copy()
+
+
+def module_goldens(case, out, dt):
+    """Per-module forward outputs + gradient digests under loss = sum(out * w_proc)."""
+    args, gens, dis, aud, txt = build(case, (15, 21, 27), 3, dt)
+    B = case['B']
+    text, spec, target, vid = proc.make_batch(B, 27, case['n_words'], case['n_spk'], case['seed'])
+    text_t, spec_t, tgt_t, vid_t = map(torch.from_numpy, (text, spec, target, vid))
+    spec_t, tgt_t = spec_t.to(dt), tgt_t.to(dt)
+
+    def wproc(name, t):
+        return torch.from_numpy(proc.tensor_for('w.' + name, (2,) + tuple(t.shape), case['seed'])[0] * t[0].numel() ** 0.5).to(dt)
+
+    # text encoder
+    y = txt(text_t)
+    out['text/out'] = y.detach().double().numpy()
+    (y * wproc('text', y)).sum().backward()
+    for k, p in txt.named_parameters():
+        digest(out, 'text/grad/' + k, p.grad)
+
+    # audio encoder
+    w, lo, mid, hi, blend = aud(spec_t, vid_t)
+    out['audio/weight'] = w.detach().double().numpy()
+    out['audio/low'] = lo.detach().double().numpy()
+    out['audio/mid'] = mid.detach().double().numpy()
+    out['audio/high'] = hi.detach().double().numpy()
+    for i, bl in enumerate(blend):
+        out['audio/blend%d' % i] = bl.detach().double().numpy()
+    loss = sum((bl * wproc('blend%d' % i, bl)).sum() for i, bl in enumerate(blend)) + (hi * wproc('hi', hi)).sum() \
+        + (lo * wproc('lo', lo)).sum()
+    loss.backward()
+    for k, p in aud.named_parameters():
+        digest(out, 'audio/grad/' + k, p.grad)
+    for k, b in aud.named_buffers():
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            digest(out, 'audio/buf/' + k, b)
+
+    # generator g3 (pose_dim 27)
+    eps = proc.EpsStream(case['seed'])
+    ref_embedding_net.reparameterize = lambda mu, logvar: mu + torch.from_numpy(eps(mu.shape)).to(mu.dtype) * torch.exp(0.5 * logvar)
+    pre = torch.zeros(B, 34, 28, dtype=dt)
+    pre[:, :4, :-1] = tgt_t[:, :4]
+    pre[:, :4, -1] = 1
+    pre.requires_grad_(True)
+    afeat = torch.from_numpy(proc.tensor_for('in.afeat', (B, 34, 32), case['seed']) * 10).to(dt).requires_grad_(True)
+    o, z, mu, lv = gens[2](pre, text_t, afeat, vid_t)
+    out['gen/out'] = o.detach().double().numpy()
+    out['gen/z'] = z.detach().double().numpy()
+    out['gen/mu'] = mu.detach().double().numpy()
+    out['gen/logvar'] = lv.detach().double().numpy()
+    ((o * wproc('gen', o)).sum() + (z * wproc('z', z)).sum() + (mu * lv).sum()).backward()
+    for k, p in gens[2].named_parameters():
+        digest(out, 'gen/grad/' + k, p.grad)
+    out['gen/grad_pre'] = pre.grad.double().numpy()
+    out['gen/grad_afeat'] = afeat.grad.double().numpy()
+
+    # discriminator
+    x = tgt_t.clone().requires_grad_(True)
+    d = dis(x)
+    out['dis/out'] = d.detach().double().numpy()
+    (d * wproc('dis', d)).sum().backward()
+    for k, p in dis.named_parameters():
+        digest(out, 'dis/grad/' + k, p.grad)
+    out['dis/grad_in'] = x.grad.double().numpy()
+    for k, b in dis.named_buffers():
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            out['dis/buf/' + k] = b.double().numpy().copy()
+
+    # contrastive loss (both variants), N = B*34 rows of dim 32
+    a = torch.from_numpy(proc.tensor_for('in.ca', (B * 34, 32), case['seed']) * 6).to(dt).requires_grad_(True)
+    b = torch.from_numpy(proc.tensor_for('in.cb', (B * 34, 32), case['seed']) * 6).to(dt).requires_grad_(True)
+    l = SoftmaxContrastiveLoss()(a, b)
+    l.backward()
+    out['contrastive/loss'] = l.detach().double().numpy()
+    out['contrastive/grad_a'] = a.grad.double().numpy().copy()
+    out['contrastive/grad_b'] = b.grad.double().numpy().copy()
+    a.grad = b.grad = None
+    l = ref_expr.SoftmaxContrastiveLoss()(a, b)
+    l.backward()
+    out['contrastive_expr/loss'] = l.detach().double().numpy()
+    out['contrastive_expr/grad_a'] = a.grad.double().numpy().copy()
+    out['contrastive_expr/grad_b'] = b.grad.double().numpy().copy()
+
+
+def step_goldens(case, out, dt, expressive=False):
+    """Two consecutive train steps (epoch 0 = warm-up phase, epoch 11 = GAN phase) through the reference."""
+    pose_dims = (24, 30, 36, 66, 96, 126) if expressive else (15, 21, 27)
+    args, gens, dis, aud, txt = build(case, pose_dims, len(pose_dims), dt)
+    B = case['B']
+    P = pose_dims[-1]
+    text, spec, target, vid = proc.make_batch(B, P, case['n_words'], case['n_spk'], case['seed'])
+    text_t, spec_t, tgt_t, vid_t = map(torch.from_numpy, (text, spec, target, vid))
+    spec_t, tgt_t = spec_t.to(dt), tgt_t.to(dt)
+    eps = proc.EpsStream(case['seed'])
+    ref_embedding_net.reparameterize = lambda mu, logvar: mu + torch.from_numpy(eps(mu.shape)).to(mu.dtype) * torch.exp(0.5 * logvar)
+    perm = torch.from_numpy(proc.fixed_perm(B, case['seed']))
+    orig_randperm = torch.randperm
+    torch.randperm = lambda n, *a, **k: perm.clone()
+    lr = float(args.learning_rate)
+    opts = [torch.optim.Adam(g.parameters(), lr=lr, betas=(0.5, 0.999)) for g in gens]
+    dis_opt = torch.optim.Adam(dis.parameters(), lr=lr * args.discriminator_lr_weight, betas=(0.5, 0.999))
+    aud_opt = torch.optim.Adam(aud.parameters(), lr=lr, betas=(0.5, 0.999))
+    txt_opt = torch.optim.Adam(txt.parameters(), lr=lr, betas=(0.5, 0.999))
+    mods = {('g%d' % (i + 1)): g for i, g in enumerate(gens)}
+    mods.update(dis=dis, audio=aud, text=txt)
+    try:
+        for si, epoch in enumerate((0, 11)):
+            if expressive:
+                ret = ref_expr.train_iter_hierarchy_expressive(args, epoch, text_t, spec_t, tgt_t, vid_t, *gens, dis, aud,
+                                                               txt, *opts, dis_opt, aud_opt, txt_opt)
+            else:
+                ret = train_iter_hierarchy(args, epoch, text_t, spec_t, tgt_t, vid_t, *gens, dis, aud, txt,
+                                           *opts, dis_opt, aud_opt, txt_opt)
+            for k, v in ret.items():
+                out['step%d/ret/%s' % (si, k)] = np.float64(v)
+            for mn, m in mods.items():
+                for k, p in m.named_parameters():
+                    if p.grad is not None:
+                        digest(out, 'step%d/grad/%s.%s' % (si, mn, k), p.grad)
+                    digest(out, 'step%d/param/%s.%s' % (si, mn, k), p)
+                for k, b in m.named_buffers():
+                    if k.endswith('running_mean') or k.endswith('running_var'):
+                        digest(out, 'step%d/buf/%s.%s' % (si, mn, k), b)
+            print('   step', si, 'epoch', epoch, {k: round(float(v), 6) for k, v in ret.items()})
+    finally:
+        torch.randperm = orig_randperm
+
+
+def main():
+    only = sys.argv[1:]
+    for name, case in CASES.items():
+        if only and name not in only:
+            continue
+        print('case', name, case)
+        runs = {}
+        for dt in (torch.float64, torch.float32):
+            o = runs[dt] = {}
+            if case.get('expressive'):
+                step_goldens(case, o, dt, expressive=True)
+            else:
+                module_goldens(case, o, dt)
+                step_goldens(case, o, dt)
+        # truth = the reference in float64; '@noise' = how far the reference's own float32 run is from it
+        out = {}
+        for k, v in runs[torch.float64].items():
+            v = np.asarray(v, np.float64)
+            out[k] = v
+            out[k + '@noise'] = np.float64(np.abs(np.asarray(runs[torch.float32][k], np.float64) - v).max())
+        path = os.path.join(HERE, name + '.npz')
+        np.savez_compressed(path, **out)
+        print('  wrote', path, os.path.getsize(path) // 1024, 'KiB,', len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    main()
