@@ -1,0 +1,447 @@
+// fp32 MFMA GEMM family for gfx950 (MI355X): dense GEMM (NT / NN / TN) and NHWC implicit-GEMM
+// convolution (forward, data-gradient, weight-gradient) share one LDS-tiled kernel.
+//
+//   C[M,N] = act(alpha * A[M,K] * B[K,N] + beta * C + bias[n])
+//
+// Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles / SIMD).  A block is 4 waves (WMxWN);
+// each wave owns an (32*MI) x (32*NI) output tile; K advances 16 per LDS stage.  LDS tiles are k-major
+// (As[k][m], Bs[k][n]) so an MFMA operand read is 32 consecutive floats per half-wave (conflict free).
+// Global->LDS staging goes through registers (double-buffered LDS, one barrier per K-step).
+//
+// Operand addressing modes:
+//   A: KC  a(m,k) = A[m*lda + k]            (activations, row-major)
+//      MC  a(m,k) = A[k*lda + m]            (transposed: dY^T in weight gradients)
+//      IM  a(m,k) = gather from an NHWC tensor; m = (img, oy, ox), k = (kh, kw, c)   (conv fwd / dgrad)
+//   B: NC  b(k,n) = B[k*ldb + n]
+//      KC  b(k,n) = B[n*ldb + k]            (torch Linear weight [N,K]; conv weight [co][(kh,kw,ci)])
+//      IM  b(k,n) = gather from NHWC x; k = output pixel, n = (kh, kw, ci)           (conv wgrad)
+// Split-K (grid.z): partial tiles go to a caller-provided workspace and ha2g reduce kernel applies
+// the epilogue -- deterministic (no float atomics).
+#include "common.h"
+
+namespace {
+
+enum { A_KC = 0, A_MC = 1, A_IM = 2 };
+enum { B_NC = 0, B_KC = 1, B_IM = 2 };
+
+struct ConvGeom {
+    int GH, GW, GC;   // gathered tensor: height, width, channels (NHWC)
+    int OH, OW;       // output pixel grid the GEMM rows (A_IM) / K index (B_IM) run over
+    int KH, KW, stride, pad;
+    int transposed;   // A_IM only: 1 = data-gradient gather (oy + pad - kh must be divisible by stride)
+};
+
+struct GemmP {
+    int M, N, K;
+    const float* A; long lda;
+    const float* B; long ldb;
+    float* C; long ldc;
+    float alpha, beta;
+    const float* bias;
+    int act;          // 0 none, 1 relu, 2 leaky-relu(0.01), 3 sigmoid
+    int splits, kchunk;
+    float* ws;        // [splits][M][N] when splits > 1
+    ConvGeom g;
+};
+
+constexpr int BK = 16;
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return v > 0.f ? v : 0.01f * v;
+    if (act == 3) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+template <bool VEC>
+__device__ __forceinline__ float4 ld4_guard(const float* p, int valid) {   // valid = number of in-range elements (<=4)
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid >= 4) {
+        if (VEC) return *reinterpret_cast<const float4*>(p);
+        v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];
+        return v;
+    }
+    if (valid > 0) v.x = p[0];
+    if (valid > 1) v.y = p[1];
+    if (valid > 2) v.z = p[2];
+    return v;
+}
+
+template <int MI, int NI, int WM, int WN, int AMODE, int BMODE, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+    constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr bool A_KCONT = (AMODE != A_MC);          // staged float4 spans 4 consecutive k
+    constexpr bool B_KCONT = (BMODE == B_KC);
+    constexpr int NA = (BM * 4 + 255) / 256, NB = (BN * 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+    float* As = smem;                      // [2][BK][LDA]
+    float* Bs = smem + 2 * BK * LDA;       // [2][BK][LDB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const ConvGeom g = p.g;
+
+    // ---- per-thread staging slots ----
+    int a_r[NA], a_c[NA];   // KCONT: r = tile row (m), c = k offset (0,4,8,12);  MCONT: r = k row, c = m offset
+    bool a_on[NA];
+    int a_oy[NA], a_ox[NA]; long a_img[NA];   // A_IM
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        int s = tid + i * 256;
+        a_on[i] = s < BM * 4;
+        if (A_KCONT) { a_r[i] = s >> 2; a_c[i] = (s & 3) * 4; }
+        else { a_r[i] = s / (BM / 4); a_c[i] = (s % (BM / 4)) * 4; }
+        if (AMODE == A_IM) {
+            int m = m0 + a_r[i];
+            a_on[i] = a_on[i] && m < p.M;
+            int mm = a_on[i] ? m : 0;
+            int ox = mm % g.OW; int t = mm / g.OW; int oy = t % g.OH; int img = t / g.OH;
+            a_oy[i] = oy; a_ox[i] = ox; a_img[i] = (long)img * g.GH * g.GW;
+        }
+    }
+    int b_r[NB], b_c[NB];
+    bool b_on[NB];
+    int b_kh[NB], b_kw[NB], b_ci[NB];   // B_IM
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        int s = tid + i * 256;
+        b_on[i] = s < BN * 4;
+        if (B_KCONT) { b_r[i] = s >> 2; b_c[i] = (s & 3) * 4; }
+        else { b_r[i] = s / (BN / 4); b_c[i] = (s % (BN / 4)) * 4; }
+        if (BMODE == B_IM) {
+            int n = n0 + b_c[i];
+            b_on[i] = b_on[i] && n < p.N;
+            int nn = b_on[i] ? n : 0;
+            int tap = nn / g.GC;
+            b_ci[i] = nn % g.GC; b_kh[i] = tap / g.KW; b_kw[i] = tap % g.KW;
+        }
+    }
+
+    float4 ra[NA], rb[NB];
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kbeg + kt * BK;
+        // ---- A ----
+        if (AMODE == A_IM) {
+            const int tap = k0 / g.GC, c0 = k0 % g.GC;     // a 16-wide k tile never straddles a tap (GC % 16 == 0)
+            const int kh = tap / g.KW, kw = tap % g.KW;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a_on[i] && k0 + a_c[i] < kend) {
+                    int iy, ix; bool ok;
+                    if (!g.transposed) {
+                        iy = a_oy[i] * g.stride - g.pad + kh; ix = a_ox[i] * g.stride - g.pad + kw;
+                        ok = iy >= 0 && iy < g.GH && ix >= 0 && ix < g.GW;
+                    } else {
+                        int ty = a_oy[i] + g.pad - kh, tx = a_ox[i] + g.pad - kw;
+                        ok = ty >= 0 && tx >= 0;
+                        if (g.stride == 2) { ok = ok && !((ty | tx) & 1); iy = ty >> 1; ix = tx >> 1; }
+                        else { iy = ty; ix = tx; }
+                        ok = ok && iy < g.GH && ix < g.GW;
+                    }
+                    if (ok) v = *reinterpret_cast<const float4*>(p.A + ((a_img[i] + (long)iy * g.GW + ix) * g.GC + c0 + a_c[i]));
+                }
+                ra[i] = v;
+            }
+        } else if (AMODE == A_KC) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                int m = m0 + a_r[i], k = k0 + a_c[i];
+                int valid = (a_on[i] && m < p.M) ? (kend - k) : 0;
+                ra[i] = ld4_guard<VEC>(p.A + (long)m * p.lda + k, valid);
+            }
+        } else {   // A_MC
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                int k = k0 + a_r[i], m = m0 + a_c[i];
+                int valid = (a_on[i] && k < kend) ? (p.M - m) : 0;
+                ra[i] = ld4_guard<VEC>(p.A + (long)k * p.lda + m, valid);
+            }
+        }
+        // ---- B ----
+        if (BMODE == B_IM) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                int pix = k0 + b_r[i];
+                if (b_on[i] && pix < kend) {
+                    int ox = pix % g.OW; int t = pix / g.OW; int oy = t % g.OH; int img = t / g.OH;
+                    int iy = oy * g.stride - g.pad + b_kh[i], ix = ox * g.stride - g.pad + b_kw[i];
+                    if (iy >= 0 && iy < g.GH && ix >= 0 && ix < g.GW)
+                        v = *reinterpret_cast<const float4*>(p.B + (((long)img * g.GH + iy) * g.GW + ix) * g.GC + b_ci[i]);
+                }
+                rb[i] = v;
+            }
+        } else if (BMODE == B_KC) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                int n = n0 + b_r[i], k = k0 + b_c[i];
+                int valid = (b_on[i] && n < p.N) ? (kend - k) : 0;
+                rb[i] = ld4_guard<VEC>(p.B + (long)n * p.ldb + k, valid);
+            }
+        } else {   // B_NC
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                int k = k0 + b_r[i], n = n0 + b_c[i];
+                int valid = (b_on[i] && k < kend) ? (p.N - n) : 0;
+                rb[i] = ld4_guard<VEC>(p.B + (long)k * p.ldb + n, valid);
+            }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float* as = As + buf * BK * LDA;
+        float* bs = Bs + buf * BK * LDB;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (!(tid + i * 256 < BM * 4)) continue;
+            if (A_KCONT) {
+                float* d = as + a_c[i] * LDA + a_r[i];
+                d[0] = ra[i].x; d[LDA] = ra[i].y; d[2 * LDA] = ra[i].z; d[3 * LDA] = ra[i].w;
+            } else {
+                *reinterpret_cast<float4*>(as + a_r[i] * LDA + a_c[i]) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (!(tid + i * 256 < BN * 4)) continue;
+            if (B_KCONT) {
+                float* d = bs + b_c[i] * LDB + b_r[i];
+                d[0] = rb[i].x; d[LDB] = rb[i].y; d[2 * LDB] = rb[i].z; d[3 * LDB] = rb[i].w;
+            } else {
+                *reinterpret_cast<float4*>(bs + b_r[i] * LDB + b_c[i]) = rb[i];
+            }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    const int l31 = lane & 31, lhi = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const float* as = As + cur * BK * LDA + wm * (32 * MI) + l31;
+        const float* bs = Bs + cur * BK * LDB + wn * (32 * NI) + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = as[(2 * kk + lhi) * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = bs[(2 * kk + lhi) * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    const bool partial = p.splits > 1;
+    float* out = partial ? p.ws + (long)blockIdx.z * p.M * p.N : p.C;
+    const long ldo = partial ? p.N : p.ldc;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + wn * (32 * NI) + j * 32 + l31;
+            if (col >= p.N) continue;
+            const float bv = (!partial && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r];
+                float* dst = out + (long)row * ldo + col;
+                if (!partial) {
+                    v = p.alpha * v + bv;
+                    if (p.beta != 0.f) v += p.beta * *dst;
+                    v = apply_act(v, p.act);
+                }
+                *dst = v;
+            }
+        }
+}
+
+__global__ void splitk_reduce_kernel(const float* ws, int splits, long MN, int N, float* C, long ldc, float alpha,
+                                     float beta, const float* bias, int act) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= MN) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += ws[(long)z * MN + i];
+    int col = (int)(i % N);
+    long row = i / N;
+    float v = alpha * s + (bias ? bias[col] : 0.f);
+    float* dst = C + row * ldc + col;
+    if (beta != 0.f) v += beta * *dst;
+    *dst = apply_act(v, act);
+}
+
+template <int MI, int NI, int WM, int WN, int AMODE, int BMODE, bool VEC>
+int launch(const GemmP& p, hipStream_t st) {
+    constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
+    dim3 grid(ceil_div(p.M, BM), ceil_div(p.N, BN), p.splits);
+    hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC>), grid, dim3(256), 0, st, p);
+    HA2G_CHECK_LAUNCH("gemm");
+    if (p.splits > 1) {
+        long MN = (long)p.M * p.N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(MN, 256)), dim3(256), 0, st, p.ws, p.splits, MN, p.N, p.C,
+                           p.ldc, p.alpha, p.beta, p.bias, p.act);
+        HA2G_CHECK_LAUNCH("splitk_reduce");
+    }
+    return 0;
+}
+
+// Pick split-K so that a launch has enough workgroups to fill 256 CUs; returns splits and sets kchunk.
+int choose_splits(int M, int N, int K, int BM, int BN, long ws_floats, int* kchunk) {
+    long tiles = (long)ceil_div(M, BM) * ceil_div(N, BN);
+    int splits = 1;
+    if (tiles < 192 && K >= 512) {
+        splits = (int)((512 + tiles - 1) / tiles);
+        int maxs = K / 128;
+        if (splits > maxs) splits = maxs;
+        if (splits < 1) splits = 1;
+        while (splits > 1 && (long)splits * M * N > ws_floats) --splits;
+    }
+    int kc = ceil_div(K, splits);
+    kc = ceil_div(kc, BK) * BK;
+    splits = ceil_div(K, kc);
+    *kchunk = kc;
+    return splits;
+}
+
+template <int AMODE, int BMODE, bool VEC>
+int dispatch_tile(GemmP& p, long ws_floats, hipStream_t st) {
+    // tile shape by problem shape: skinny-N problems use 4x1 waves of 32-wide tiles
+    if (p.N <= 32) {
+        p.splits = choose_splits(p.M, p.N, p.K, 128, 32, ws_floats, &p.kchunk);
+        return launch<1, 1, 4, 1, AMODE, BMODE, VEC>(p, st);
+    }
+    if (p.N <= 64 || (long)ceil_div(p.M, 128) * ceil_div(p.N, 128) < 128) {
+        p.splits = choose_splits(p.M, p.N, p.K, 64, 64, ws_floats, &p.kchunk);
+        return launch<1, 1, 2, 2, AMODE, BMODE, VEC>(p, st);
+    }
+    p.splits = choose_splits(p.M, p.N, p.K, 128, 128, ws_floats, &p.kchunk);
+    return launch<2, 2, 2, 2, AMODE, BMODE, VEC>(p, st);
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+// Dense GEMM, row-major.  transa/transb follow BLAS meaning on row-major storage:
+//   transa = 0: A is [M,K] (lda >= K);  1: A is stored [K,M] (lda >= M)
+//   transb = 0: B is [K,N] (ldb >= N);  1: B is stored [N,K] (ldb >= K)   <- torch Linear weights
+// ws / ws_bytes: optional split-K workspace (may be null: no split-K).
+int ha2g_gemm_f32(int transa, int transb, int M, int N, int K, float alpha, const float* A, long lda, const float* B,
+                  long ldb, float beta, float* C, long ldc, const float* bias, int act, float* ws, long ws_bytes,
+                  void* stream) {
+    HA2G_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
+    if (M == 0 || N == 0) return 0;
+    GemmP p{};
+    p.M = M; p.N = N; p.K = K; p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+    p.alpha = alpha; p.beta = beta; p.bias = bias; p.act = act; p.ws = ws; p.splits = 1; p.kchunk = K;
+    hipStream_t st = (hipStream_t)stream;
+    long wsf = ws ? ws_bytes / 4 : 0;
+    // vector path needs 16-byte aligned rows along the contiguous dimension of both operands
+    bool va = aligned16(A) && (lda % 4 == 0) && ((transa ? M : K) % 4 == 0);
+    bool vb = aligned16(B) && (ldb % 4 == 0) && ((transb ? K : N) % 4 == 0);
+    bool vec = va && vb;
+    if (!transa && transb) return vec ? dispatch_tile<A_KC, B_KC, true>(p, wsf, st) : dispatch_tile<A_KC, B_KC, false>(p, wsf, st);
+    if (!transa && !transb) return vec ? dispatch_tile<A_KC, B_NC, true>(p, wsf, st) : dispatch_tile<A_KC, B_NC, false>(p, wsf, st);
+    if (transa && !transb) return vec ? dispatch_tile<A_MC, B_NC, true>(p, wsf, st) : dispatch_tile<A_MC, B_NC, false>(p, wsf, st);
+    return ha2g_set_error(-1, "gemm: transa=1,transb=1 is not used on this path");
+}
+
+// NHWC convolution as implicit GEMM.  x [N,H,W,Cin], w [Cout][KH][KW][Cin] (torch channels_last weight),
+// y [N,OH,OW,Cout].  Cin % 16 == 0 (the 1-channel stem has its own kernel in conv_misc.hip).
+int ha2g_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin,
+                        int Cout, int KH, int KW, int stride, int pad, int act, void* stream) {
+    HA2G_REQUIRE(Cin % 16 == 0, "conv2d_fwd: Cin=%d must be a multiple of 16", Cin);
+    int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    GemmP p{};
+    p.M = N * OH * OW; p.N = Cout; p.K = KH * KW * Cin;
+    p.A = x; p.B = w; p.ldb = p.K; p.C = y; p.ldc = Cout; p.alpha = 1.f; p.beta = 0.f; p.bias = bias; p.act = act;
+    p.splits = 1; p.kchunk = p.K;
+    p.g = ConvGeom{H, W, Cin, OH, OW, KH, KW, stride, pad, 0};
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout <= 32) return launch<2, 1, 4, 1, A_IM, B_KC, true>(p, st);
+    if (Cout <= 64) return launch<1, 2, 4, 1, A_IM, B_KC, true>(p, st);
+    return launch<2, 2, 2, 2, A_IM, B_KC, true>(p, st);
+}
+
+// Data gradient: dx [N,H,W,Cin] = conv_transpose(dy [N,OH,OW,Cout], w).  wt is the weight permuted to
+// [Cin][KH][KW][Cout] (ha2g_conv2d_weight_ohwi_to_ihwo).  Cout % 16 == 0.
+int ha2g_conv2d_dgrad_f32(const float* dy, const float* wt, float* dx, int N, int H, int W, int Cin, int Cout, int KH,
+                          int KW, int stride, int pad, float beta, void* stream) {
+    HA2G_REQUIRE(Cout % 16 == 0, "conv2d_dgrad: Cout=%d must be a multiple of 16", Cout);
+    HA2G_REQUIRE(stride == 1 || stride == 2, "conv2d_dgrad: stride must be 1 or 2");
+    int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    GemmP p{};
+    p.M = N * H * W; p.N = Cin; p.K = KH * KW * Cout;
+    p.A = dy; p.B = wt; p.ldb = p.K; p.C = dx; p.ldc = Cin; p.alpha = 1.f; p.beta = beta; p.bias = nullptr; p.act = 0;
+    p.splits = 1; p.kchunk = p.K;
+    p.g = ConvGeom{OH, OW, Cout, H, W, KH, KW, stride, pad, 1};
+    hipStream_t st = (hipStream_t)stream;
+    if (Cin <= 32) return launch<2, 1, 4, 1, A_IM, B_KC, true>(p, st);
+    if (Cin <= 64) return launch<1, 2, 4, 1, A_IM, B_KC, true>(p, st);
+    return launch<2, 2, 2, 2, A_IM, B_KC, true>(p, st);
+}
+
+// Weight gradient: dw [Cout][KH][KW][Cin] (+)= dy^T * im2col(x); K = N*OH*OW output pixels, split over grid.z.
+// ws must hold splits*Cout*KH*KW*Cin floats (query with ha2g_conv2d_wgrad_workspace_bytes).
+long ha2g_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    long K = (long)N * OH * OW, MN = (long)Cout * KH * KW * Cin;
+    int BM = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
+    long tiles = (long)ceil_div(Cout, BM) * ceil_div(KH * KW * Cin, 128);
+    long splits = (1024 + tiles - 1) / tiles;
+    if (splits > K / 256) splits = K / 256;
+    if (splits < 1) splits = 1;
+    return splits * MN * 4;
+}
+
+int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout, int KH,
+                          int KW, int stride, int pad, float beta, float* ws, long ws_bytes, void* stream) {
+    HA2G_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "conv2d_wgrad: channels must be multiples of 4");
+    int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    GemmP p{};
+    p.M = Cout; p.N = KH * KW * Cin; p.K = N * OH * OW;
+    p.A = dy; p.lda = Cout; p.B = x; p.C = dw; p.ldc = p.N; p.alpha = 1.f; p.beta = beta; p.bias = nullptr; p.act = 0;
+    p.g = ConvGeom{H, W, Cin, OH, OW, KH, KW, stride, pad, 0};
+    long need = ha2g_conv2d_wgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad);
+    long MN = (long)p.M * p.N;
+    int splits = (int)(need / (MN * 4));
+    HA2G_REQUIRE(splits == 1 || (ws && ws_bytes >= need), "conv2d_wgrad: workspace too small (%ld < %ld)", ws_bytes, need);
+    int kc = ceil_div(p.K, splits);
+    kc = ceil_div(kc, BK) * BK;
+    p.kchunk = kc; p.splits = ceil_div(p.K, kc); p.ws = ws;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout <= 32) return launch<1, 1, 1, 4, A_MC, B_IM, true>(p, st);
+    if (Cout <= 64) return launch<2, 1, 1, 4, A_MC, B_IM, true>(p, st);
+    return launch<2, 2, 2, 2, A_MC, B_IM, true>(p, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,311 @@
+// Bidirectional GRU layer: persistent recurrent kernels (forward and BPTT) for gfx950.
+//
+// torch.nn.GRU semantics (reference: scripts/model/hierarchy_net.py:87-88,144 / :213,232):
+//   gi = x W_ih^T + b_ih (done by ha2g_gemm_f32 for all T at once), gh = h W_hh^T + b_hh,
+//   r = sig(gi_r + gh_r), z = sig(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1-z) n + z h, h0 = 0.
+//
+// Decomposition: grid = (ceil(B/16), 2 directions).  A workgroup owns 16 batch rows of one direction for
+// all T steps, so there is NO cross-workgroup synchronisation inside the recurrence.  Per step it computes
+// gh^T[3H x 16] = W_hh[3H x H] * h^T[H x 16] with v_mfma_f32_16x16x4_f32 (exact fp32):
+//   * A operand = W_hh, pre-packed once per call into MFMA fragment order (1 KiB contiguous per wave load,
+//     streamed from L2 every step; 1.08 MB at H=300 stays L2-resident),
+//   * B operand = h^T, 16 x H, exchanged between the 4 waves through LDS and then held in VGPRs,
+//   * the three gate accumulators of a hidden unit land in the same lane, so the gate math is in-register;
+//     h_prev for the blend is the lane's own B-operand register (same (batch, unit) mapping).
+// K order inside a 16-wide k block is permuted (lane group g takes k = 16m + 4g + u) so both operands are
+// float4 loads; a sum is order-independent up to rounding.
+#include "common.h"
+
+namespace {
+
+template <int H> struct GruCfg {
+    static constexpr int NJT = (H + 15) / 16;      // 16-wide tiles over hidden units (and over k)
+    static constexpr int HP = NJT * 16;            // padded hidden size
+    static constexpr int LDH = HP + 4;             // LDS row stride of the 16 x HP hidden-state tile
+};
+
+// ---- weight packing ---------------------------------------------------------------------------------
+// fwd fragment (jt, gate, m):  lane (i = l&15, g = l>>4), u:  W_hh[gate*H + 16jt + i][16m + 4g + u]
+// bwd fragment (kt, gate, jt): lane (i, g), u:               W_hh[gate*H + 16jt + 4g + u][16kt + i]
+template <int H>
+__global__ void gru_pack_kernel(const float* __restrict__ whh, float* __restrict__ pf, float* __restrict__ pb) {
+    constexpr int NJT = GruCfg<H>::NJT;
+    const int frag = blockIdx.x;                     // (a*3 + gate)*NJT + c
+    const int c = frag % NJT, gate = (frag / NJT) % 3, a = frag / (3 * NJT);
+    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+    float4 f, b;
+    float* fp = &f.x; float* bp = &b.x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        int row = 16 * a + i, k = 16 * c + 4 * g + u;                 // fwd: a = jt, c = m
+        fp[u] = (row < H && k < H) ? whh[(long)(gate * H + row) * H + k] : 0.f;
+        int j = 16 * c + 4 * g + u, kk = 16 * a + i;                  // bwd: a = kt, c = jt
+        bp[u] = (j < H && kk < H) ? whh[(long)(gate * H + j) * H + kk] : 0.f;
+    }
+    reinterpret_cast<float4*>(pf)[(long)frag * 64 + lane] = f;
+    reinterpret_cast<float4*>(pb)[(long)frag * 64 + lane] = b;
+}
+
+// ---- forward ------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ gi,      // [B][T][2][3H]
+                                                      const float* __restrict__ wp,      // [2][NJT*3*NJT][64][4]
+                                                      const float* __restrict__ bhh0, const float* __restrict__ bhh1,
+                                                      float* __restrict__ y,             // [B][T][2H]
+                                                      float* __restrict__ rs,            // [B][T][2][4][H] or null
+                                                      int B, int T) {
+    using C = GruCfg<H>;
+    constexpr int NJT = C::NJT, LDH = C::LDH;
+    __shared__ __attribute__((aligned(16))) float hs[2][16 * LDH];
+    const int dir = blockIdx.y, b0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lb = lane & 15, g = lane >> 4;
+    const int b = b0 + lb;
+    const bool bok = b < B;
+    const float4* wpd = reinterpret_cast<const float4*>(wp) + (long)dir * (NJT * 3 * NJT) * 64 + lane;
+    const float* bhh = dir ? bhh1 : bhh0;
+
+    for (int i = tid; i < 16 * LDH; i += 256) hs[0][i] = 0.f;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? T - 1 - s : s;
+        const int cur = s & 1;
+        float4 hb[NJT];                                   // B operand: h[b][16m + 4g + u]
+#pragma unroll
+        for (int m = 0; m < NJT; ++m) hb[m] = *reinterpret_cast<const float4*>(&hs[cur][lb * LDH + 16 * m + 4 * g]);
+
+        for (int jt = wave; jt < NJT; jt += 4) {
+            f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
+            const float4* w = wpd + (long)(jt * 3) * NJT * 64;
+            const int j = 16 * jt + 4 * g;
+            const bool ok = bok && j < H;
+            // issue the step's gi loads early; they are consumed after the MFMA chain
+            float4 gir = make_float4(0.f, 0.f, 0.f, 0.f), giz = gir, gin = gir;
+            if (ok) {
+                const float* gp = gi + ((long)(b * T + t) * 2 + dir) * 3 * H + j;
+                gir = *reinterpret_cast<const float4*>(gp);
+                giz = *reinterpret_cast<const float4*>(gp + H);
+                gin = *reinterpret_cast<const float4*>(gp + 2 * H);
+            }
+#pragma unroll
+            for (int m = 0; m < NJT; ++m) {
+                const float4 wr = w[m * 64], wz = w[(NJT + m) * 64], wn = w[(2 * NJT + m) * 64];
+                const float* pr = &wr.x; const float* pz = &wz.x; const float* pn = &wn.x; const float* ph = &hb[m].x;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ar = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[u], ph[u], ar, 0, 0, 0);
+                    az = __builtin_amdgcn_mfma_f32_16x16x4f32(pz[u], ph[u], az, 0, 0, 0);
+                    an = __builtin_amdgcn_mfma_f32_16x16x4f32(pn[u], ph[u], an, 0, 0, 0);
+                }
+            }
+            // C/D layout 16x16: col (batch) = lane&15, row (unit within tile) = 4*(lane>>4) + reg
+            float4 hn4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const float4 br = *reinterpret_cast<const float4*>(bhh + j);
+                const float4 bz = *reinterpret_cast<const float4*>(bhh + H + j);
+                const float4 bn = *reinterpret_cast<const float4*>(bhh + 2 * H + j);
+                const float4 hprev = *reinterpret_cast<const float4*>(&hs[cur][lb * LDH + j]);   // == hb[jt], re-read (static indexing)
+                const float* hp = &hprev.x;
+                float4 r4, z4, n4, q4;
+                float* pr = &r4.x; float* pz = &z4.x; float* pn = &n4.x; float* pq = &q4.x; float* ph = &hn4.x;
+                const float* gr = &gir.x; const float* gz = &giz.x; const float* gn = &gin.x;
+                const float* cbr = &br.x; const float* cbz = &bz.x; const float* cbn = &bn.x;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float r = sigmoidf_(gr[u] + ar[u] + cbr[u]);
+                    const float z = sigmoidf_(gz[u] + az[u] + cbz[u]);
+                    const float q = an[u] + cbn[u];                  // W_hn h + b_hn
+                    const float n = tanhf_(gn[u] + r * q);
+                    pr[u] = r; pz[u] = z; pn[u] = n; pq[u] = q;
+                    ph[u] = (1.f - z) * n + z * hp[u];
+                }
+                *reinterpret_cast<float4*>(y + (long)(b * T + t) * 2 * H + dir * H + j) = hn4;
+                if (rs) {
+                    float* rp = rs + ((long)(b * T + t) * 2 + dir) * 4 * H + j;
+                    *reinterpret_cast<float4*>(rp) = r4;
+                    *reinterpret_cast<float4*>(rp + H) = z4;
+                    *reinterpret_cast<float4*>(rp + 2 * H) = n4;
+                    *reinterpret_cast<float4*>(rp + 3 * H) = q4;
+                }
+            }
+            *reinterpret_cast<float4*>(&hs[cur ^ 1][lb * LDH + j]) = hn4;    // zeros in the padding
+        }
+        __syncthreads();
+    }
+}
+
+// ---- backward (BPTT) ----------------------------------------------------------------------------------
+// Per step (reverse of the forward order):  dh = dy_t + carry;
+//   dn = dh (1-z), dz = dh (h_prev - n), da_n = dn (1-n^2), da_z = dz z (1-z), da_r = da_n hn r (1-r)
+//   dg[b][t][dir] = [da_r | da_z | da_n | da_n r]   (first three = d gi, [0,1,3] = d gh)
+//   carry' = dh z + [da_r, da_z, da_n r] * W_hh      (MFMA, K = 3H)
+template <int H>
+__global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ dy,      // [B][T][2H]
+                                                      const float* __restrict__ y,       // [B][T][2H]
+                                                      const float* __restrict__ rs,      // [B][T][2][4][H]
+                                                      const float* __restrict__ wpt,     // [2][NJT*3*NJT][64][4]
+                                                      float* __restrict__ dg,            // [B][T][2][4H]
+                                                      int B, int T) {
+    using C = GruCfg<H>;
+    constexpr int NJT = C::NJT, HP = C::HP, LDH = C::LDH, LDG = 3 * HP + 4;
+    __shared__ __attribute__((aligned(16))) float sg[16 * LDG];      // d gh tile  [16][3*HP]
+    __shared__ __attribute__((aligned(16))) float sc[16 * LDH];      // dh carry   [16][HP]
+    const int dir = blockIdx.y, b0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lb = lane & 15, g = lane >> 4;
+    const float4* wpd = reinterpret_cast<const float4*>(wpt) + (long)dir * (NJT * 3 * NJT) * 64 + lane;
+
+    for (int i = tid; i < 16 * LDH; i += 256) sc[i] = 0.f;
+    for (int i = tid; i < 16 * LDG; i += 256) sg[i] = 0.f;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? s : T - 1 - s;
+        const int tp = dir ? t + 1 : t - 1;              // time index of h_prev
+        const bool has_prev = tp >= 0 && tp < T;
+        // ---- phase 1: gate gradients (elementwise over 16 x H) ----
+        for (int idx = tid; idx < 16 * (H / 4); idx += 256) {
+            const int bb = idx / (H / 4), j = (idx % (H / 4)) * 4;
+            const int b = b0 + bb;
+            float4 dar = make_float4(0.f, 0.f, 0.f, 0.f), daz = dar, dghn = dar, dhz = dar;
+            if (b < B) {
+                const long bt = (long)b * T + t;
+                const float4 dy4 = *reinterpret_cast<const float4*>(dy + bt * 2 * H + dir * H + j);
+                const float* rp = rs + (bt * 2 + dir) * 4 * H + j;
+                const float4 r4 = *reinterpret_cast<const float4*>(rp);
+                const float4 z4 = *reinterpret_cast<const float4*>(rp + H);
+                const float4 n4 = *reinterpret_cast<const float4*>(rp + 2 * H);
+                const float4 q4 = *reinterpret_cast<const float4*>(rp + 3 * H);
+                float4 hp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (has_prev) hp4 = *reinterpret_cast<const float4*>(y + ((long)b * T + tp) * 2 * H + dir * H + j);
+                const float4 c4 = *reinterpret_cast<const float4*>(&sc[bb * LDH + j]);
+                float4 dan;
+                const float* pdy = &dy4.x; const float* pr = &r4.x; const float* pz = &z4.x; const float* pn = &n4.x;
+                const float* pq = &q4.x; const float* php = &hp4.x; const float* pc = &c4.x;
+                float* o_r = &dar.x; float* o_z = &daz.x; float* o_n = &dan.x; float* o_q = &dghn.x; float* o_c = &dhz.x;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float dh = pdy[u] + pc[u];
+                    const float dn = dh * (1.f - pz[u]);
+                    const float dz = dh * (php[u] - pn[u]);
+                    const float a_n = dn * (1.f - pn[u] * pn[u]);
+                    o_n[u] = a_n;
+                    o_z[u] = dz * pz[u] * (1.f - pz[u]);
+                    o_r[u] = a_n * pq[u] * pr[u] * (1.f - pr[u]);
+                    o_q[u] = a_n * pr[u];
+                    o_c[u] = dh * pz[u];
+                }
+                float* gp = dg + (bt * 2 + dir) * 4 * H + j;
+                *reinterpret_cast<float4*>(gp) = dar;
+                *reinterpret_cast<float4*>(gp + H) = daz;
+                *reinterpret_cast<float4*>(gp + 2 * H) = dan;
+                *reinterpret_cast<float4*>(gp + 3 * H) = dghn;
+            }
+            *reinterpret_cast<float4*>(&sg[bb * LDG + j]) = dar;
+            *reinterpret_cast<float4*>(&sg[bb * LDG + HP + j]) = daz;
+            *reinterpret_cast<float4*>(&sg[bb * LDG + 2 * HP + j]) = dghn;
+            *reinterpret_cast<float4*>(&sc[bb * LDH + j]) = dhz;
+        }
+        __syncthreads();
+        // ---- phase 2: carry[b][k] += sum_{gate,j} dgh[b][gate,j] * W_hh[gate*H + j][k] ----
+        if (s + 1 < T) {
+            for (int kt = wave; kt < NJT; kt += 4) {
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+                const float4* w = wpd + (long)(kt * 3) * NJT * 64;
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    const float4 w0 = w[jt * 64], w1 = w[(NJT + jt) * 64], w2 = w[(2 * NJT + jt) * 64];
+                    const float4 d0 = *reinterpret_cast<const float4*>(&sg[lb * LDG + 16 * jt + 4 * g]);
+                    const float4 d1 = *reinterpret_cast<const float4*>(&sg[lb * LDG + HP + 16 * jt + 4 * g]);
+                    const float4 d2 = *reinterpret_cast<const float4*>(&sg[lb * LDG + 2 * HP + 16 * jt + 4 * g]);
+                    const float* pw0 = &w0.x; const float* pw1 = &w1.x; const float* pw2 = &w2.x;
+                    const float* pd0 = &d0.x; const float* pd1 = &d1.x; const float* pd2 = &d2.x;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pw0[u], pd0[u], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pw1[u], pd1[u], a1, 0, 0, 0);
+                        a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pw2[u], pd2[u], a2, 0, 0, 0);
+                    }
+                }
+                float* cp = &sc[lb * LDH + 16 * kt + 4 * g];
+                float4 c4 = *reinterpret_cast<float4*>(cp);
+                c4.x += a0[0] + a1[0] + a2[0];
+                c4.y += a0[1] + a1[1] + a2[1];
+                c4.z += a0[2] + a1[2] + a2[2];
+                c4.w += a0[3] + a1[3] + a2[3];
+                *reinterpret_cast<float4*>(cp) = c4;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int H>
+int run_pack(const float* whh, float* pf, float* pb, hipStream_t st) {
+    constexpr int NJT = GruCfg<H>::NJT;
+    hipLaunchKernelGGL(gru_pack_kernel<H>, dim3(NJT * 3 * NJT), dim3(64), 0, st, whh, pf, pb);
+    HA2G_CHECK_LAUNCH("gru_pack");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// floats per direction of one packed W_hh image (forward or backward form)
+long ha2g_gru_packed_floats(int H) {
+    long njt = (H + 15) / 16;
+    return njt * 3 * njt * 64 * 4;
+}
+
+int ha2g_gru_supported_hidden(int H) { return H == 300 || H == 64 || H == 32; }
+
+// Pack one direction's W_hh [3H][H] into the forward (pf) and BPTT (pb) fragment images.
+int ha2g_gru_pack_whh(const float* whh, float* pf, float* pb, int H, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (H) {
+        case 300: return run_pack<300>(whh, pf, pb, st);
+        case 64: return run_pack<64>(whh, pf, pb, st);
+        case 32: return run_pack<32>(whh, pf, pb, st);
+    }
+    return ha2g_set_error(-1, "gru: hidden size %d not instantiated (300, 64, 32)", H);
+}
+
+// One bidirectional layer, all T steps.  gi [B][T][2][3H] already holds x W_ih^T + b_ih of both directions;
+// wp = packed forward images of (fwd dir, reverse dir) back to back; y [B][T][2H]; rs (optional reserve for
+// backward) [B][T][2][4][H] = r, z, n, (W_hn h + b_hn).
+int ha2g_gru_layer_fwd(const float* gi, const float* wp, const float* bhh_fwd, const float* bhh_rev, float* y, float* rs,
+                       int B, int T, int H, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0 || T == 0) return 0;
+    dim3 grid(ceil_div(B, 16), 2), block(256);
+    switch (H) {
+        case 300: hipLaunchKernelGGL(gru_fwd_kernel<300>, grid, block, 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, B, T); break;
+        case 64: hipLaunchKernelGGL(gru_fwd_kernel<64>, grid, block, 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, B, T); break;
+        case 32: hipLaunchKernelGGL(gru_fwd_kernel<32>, grid, block, 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, B, T); break;
+        default: return ha2g_set_error(-1, "gru: hidden size %d not instantiated (300, 64, 32)", H);
+    }
+    HA2G_CHECK_LAUNCH("gru_layer_fwd");
+    return 0;
+}
+
+// BPTT of one bidirectional layer.  dy/y [B][T][2H], rs from the forward, wpt = packed backward images of both
+// directions; writes dg [B][T][2][4H] = (d gi_r, d gi_z, d gi_n, d gh_n).  Weight/bias/input gradients are
+// batched GEMMs / column sums over dg done by the caller.
+int ha2g_gru_layer_bwd(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, int B, int T, int H,
+                       void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0 || T == 0) return 0;
+    dim3 grid(ceil_div(B, 16), 2), block(256);
+    switch (H) {
+        case 300: hipLaunchKernelGGL(gru_bwd_kernel<300>, grid, block, 0, st, dy, y, rs, wpt, dg, B, T); break;
+        case 64: hipLaunchKernelGGL(gru_bwd_kernel<64>, grid, block, 0, st, dy, y, rs, wpt, dg, B, T); break;
+        case 32: hipLaunchKernelGGL(gru_bwd_kernel<32>, grid, block, 0, st, dy, y, rs, wpt, dg, B, T); break;
+        default: return ha2g_set_error(-1, "gru: hidden size %d not instantiated (300, 64, 32)", H);
+    }
+    HA2G_CHECK_LAUNCH("gru_layer_bwd");
+    return 0;
+}
+
+}  // extern "C"
