@@ -1,33 +1,39 @@
 """ctypes binding of libha2g_hip.so -- the C-ABI library of hand-written gfx950 kernels.
 
-The library is the product path: there is no fallback.  If it is missing or a symbol is absent the import
-fails loudly (build with `python -c "import __graft_entry__ as g; g.build()"` or `make -C ha2g_amd/csrc`).
-Prototypes mirror include/ha2g_hip.h ('p' = device pointer, 'i' = int, 'l' = long, 'f' = float).
+The library is the product path: there is no fallback.  If it is missing, or any symbol declared in
+include/ha2g_hip.h is absent, the import fails loudly (build with __graft_entry__.build() or
+`make -C ha2g_amd/csrc`).  Prototypes are parsed from the header so Python and C cannot drift apart.
 """
 import ctypes
 import os
+import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libha2g_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'ha2g_hip.h')
 
-_T = {'p': ctypes.c_void_p, 'i': ctypes.c_int, 'l': ctypes.c_long, 'f': ctypes.c_float}
+_SCALARS = {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'unsigned': ctypes.c_uint}
 
-# name -> argument kinds (return type is int unless listed in _RET)
-SIGNATURES = {
-    'ha2g_abi_version': '',
-    'ha2g_gemm_f32': 'iiiiifplplfplpipl' + 'p',
-    'ha2g_colsum_f32': 'pllipf' + 'p',
-    'ha2g_conv2d_fwd_f32': 'pppp' + 'iiiiiiiii' + 'i' + 'p',
-    'ha2g_conv2d_dgrad_f32': 'ppp' + 'iiiiiiiii' + 'f' + 'p',
-    'ha2g_conv2d_wgrad_workspace_bytes': 'iiiiiiiii',
-    'ha2g_conv2d_wgrad_f32': 'ppp' + 'iiiiiiiii' + 'f' + 'pl' + 'p',
-    'ha2g_gru_packed_floats': 'i',
-    'ha2g_gru_supported_hidden': 'i',
-    'ha2g_gru_pack_whh': 'pppi' + 'p',
-    'ha2g_gru_layer_fwd': 'pppppp' + 'iii' + 'p',
-    'ha2g_gru_layer_bwd': 'ppppp' + 'iii' + 'p',
-}
-_RET = {'ha2g_conv2d_wgrad_workspace_bytes': ctypes.c_long, 'ha2g_gru_packed_floats': ctypes.c_long}
+
+def parse_header(path=HEADER_PATH):
+    """-> {name: (restype, [argtypes])} for every prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
+    src = re.sub(r'//[^\n]*', ' ', src)
+    protos = {}
+    for m in re.finditer(r'\b(const\s+char\s*\*|int|long)\s+(ha2g_\w+)\s*\(([^)]*)\)\s*;', src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        restype = ctypes.c_char_p if '*' in ret else _SCALARS[ret]
+        argtypes = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                if '*' in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    argtypes.append(_SCALARS[a.replace('const ', '').split()[0]])
+        protos[name] = (restype, argtypes)
+    return protos
 
 
 class Ha2gError(RuntimeError):
@@ -39,15 +45,14 @@ def _load():
         raise ImportError('ha2g_amd: %s not found -- the HIP extension is required (no CPU/torch fallback). '
                           'Build it with `make -C ha2g_amd/csrc` or __graft_entry__.build().' % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
-    lib.ha2g_last_error.restype = ctypes.c_char_p
-    lib.ha2g_last_error.argtypes = []
-    for name, kinds in SIGNATURES.items():
+    for name, (restype, argtypes) in parse_header().items():
         try:
             fn = getattr(lib, name)
         except AttributeError:
-            raise ImportError('ha2g_amd: symbol %s missing from %s (stale build?)' % (name, LIB_PATH))
-        fn.argtypes = [_T[k] for k in kinds]
-        fn.restype = _RET.get(name, ctypes.c_int)
+            raise ImportError('ha2g_amd: symbol %s (declared in include/ha2g_hip.h) missing from %s -- stale build?'
+                              % (name, LIB_PATH))
+        fn.restype = restype
+        fn.argtypes = argtypes
     return lib
 
 

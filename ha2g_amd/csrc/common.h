@@ -27,9 +27,11 @@ int ha2g_set_error(int code, const char* fmt, ...);
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device helpers ----
-// Gate non-linearities: the accurate libm forms (gate math is <1% of the recurrent kernels' time).
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
+// Gate non-linearities on the hardware exp2/rcp units (v_exp_f32 / v_rcp_f32, ~1 ulp each): absolute error
+// ~2e-7 on values in (0,1) / (-1,1), far inside the 1e-4 parity budget, and ~10x fewer VALU slots than libm's
+// expf/tanhf in the recurrent kernels' serial epilogue.  Saturate cleanly: exp -> inf gives rcp -> 0.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1,0 +1,403 @@
+// Memory-bound glue kernels of the HA2G step: embedding gather / deterministic scatter-add, 1-D im2col /
+// col2im for the TCN and discriminator convolutions, weight-norm, pointwise ops, Philox dropout, pixel
+// shuffle, speaker-softmax blending.  All are HBM-bound: float4 accesses, grid-stride loops, no atomics
+// on floats (reductions are fixed-order => bitwise reproducible).
+#include "common.h"
+
+namespace {
+
+constexpr int EB = 256;
+inline int grid_for(long n, int per = 1) { long g = (n + (long)EB * per - 1) / ((long)EB * per); return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+// ---------------------------------------------------------------- embedding ---------------------------
+__global__ void embedding_fwd_kernel(const long* __restrict__ tok, const float* __restrict__ W, float* __restrict__ out,
+                                     long n, int C4) {
+    long total = n * C4;
+    for (long i = (long)blockIdx.x * EB + threadIdx.x; i < total; i += (long)gridDim.x * EB) {
+        long r = i / C4; int c = (int)(i % C4);
+        reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(W + tok[r] * (long)C4 * 4)[c];
+    }
+}
+
+// dW[tok] += sum over positions carrying tok.  grid = (n positions, column chunks of 64); the block of the FIRST
+// occurrence of a token sums all its occurrences in ascending position order (4 waves take positions round-robin,
+// then a fixed-order LDS combine) -> deterministic, no atomics.  Token lists are short (n <= ~13k).
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const long* __restrict__ tok, const float* __restrict__ dY,
+                                                            float* __restrict__ dW, int n, int C) {
+    __shared__ float part[4][64];
+    __shared__ int first;
+    const int p = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long t = tok[p];
+    if (threadIdx.x == 0) first = 1;
+    __syncthreads();
+    for (int q = threadIdx.x; q < p; q += 256)
+        if (tok[q] == t) first = 0;
+    __syncthreads();
+    if (!first) return;
+    const int c = blockIdx.y * 64 + lane;
+    float s = 0.f;
+    int k = 0;                                            // running index among matches
+    for (int q0 = p; q0 < n; q0 += 64) {
+        int q = q0 + lane;
+        unsigned long long m = __ballot(q < n && tok[q] == t);
+        while (m) {
+            int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if ((k & 3) == w && c < C) s += dY[(long)(q0 + b) * C + c];
+            ++k;
+        }
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < C) dW[t * C + c] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+// ---------------------------------------------------------------- 1-D im2col --------------------------
+// x [B][T][C] -> col [B][To][C*k], col[b][t][c*k + kk] = x[b][t - pad_left + kk*dil][c] (0 outside).
+__global__ void im2col1d_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int T, int C, int k, int dil,
+                                int pad_left, int To) {
+    long total = (long)B * To * C * k;
+    for (long i = (long)blockIdx.x * EB + threadIdx.x; i < total; i += (long)gridDim.x * EB) {
+        int kk = (int)(i % k); long r = i / k; int c = (int)(r % C); r /= C; int t = (int)(r % To); int b = (int)(r / To);
+        int ts = t - pad_left + kk * dil;
+        col[i] = (ts >= 0 && ts < T) ? x[((long)b * T + ts) * C + c] : 0.f;
+    }
+}
+// dx[b][ts][c] = sum_kk dcol[b][ts + pad_left - kk*dil][c*k + kk]
+__global__ void col2im1d_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B, int T, int C, int k, int dil,
+                                int pad_left, int To) {
+    long total = (long)B * T * C;
+    for (long i = (long)blockIdx.x * EB + threadIdx.x; i < total; i += (long)gridDim.x * EB) {
+        int c = (int)(i % C); long r = i / C; int ts = (int)(r % T); int b = (int)(r / T);
+        float s = 0.f;
+        for (int kk = 0; kk < k; ++kk) {
+            int t = ts + pad_left - kk * dil;
+            if (t >= 0 && t < To) s += dcol[(((long)b * To + t) * C + c) * k + kk];
+        }
+        dx[i] = s;
+    }
+}
+
+// ---------------------------------------------------------------- weight norm --------------------------
+// w[o][:] = g[o] * v[o][:] / ||v[o]||   (one block per output channel; n = in*k elements per row)
+__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                              float* __restrict__ w, float* __restrict__ norm, int n) {
+    __shared__ float red[16];
+    const int o = blockIdx.x;
+    const float* vr = v + (long)o * n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += vr[i] * vr[i];
+    s = block_sum(s, red);
+    const float nr = sqrtf(s);
+    if (threadIdx.x == 0) norm[o] = nr;
+    const float sc = g[o] / nr;
+    for (int i = threadIdx.x; i < n; i += 256) w[(long)o * n + i] = vr[i] * sc;
+}
+// dg[o] = <dw, v>/||v||;  dv = g/||v|| * (dw - v <dw,v>/||v||^2)
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ g,
+                                                              const float* __restrict__ v, const float* __restrict__ norm,
+                                                              float* __restrict__ dg, float* __restrict__ dv, int n) {
+    __shared__ float red[16];
+    const int o = blockIdx.x;
+    const float* vr = v + (long)o * n;
+    const float* dr = dw + (long)o * n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += dr[i] * vr[i];
+    s = block_sum(s, red);
+    const float nr = norm[o];
+    if (threadIdx.x == 0) dg[o] = s / nr;
+    const float a = g[o] / nr, bq = s / (nr * nr);
+    for (int i = threadIdx.x; i < n; i += 256) dv[(long)o * n + i] = a * (dr[i] - vr[i] * bq);
+}
+
+// ---------------------------------------------------------------- pointwise ---------------------------
+enum EltOp {
+    OP_ADD = 0, OP_MUL = 1, OP_ADD_RELU = 2, OP_RELU_BWD = 3, OP_LEAKY_BWD = 4, OP_SIGMOID_BWD = 5, OP_ELU = 6,
+    OP_ELU_BWD = 7, OP_REPARAM = 8, OP_REPARAM_BWD_LOGVAR = 9, OP_AXPBY = 10, OP_LEAKY = 11, OP_RELU = 12, OP_SCALE = 13, OP_MUL_SCALAR = 14,
+};
+
+__device__ __forceinline__ float elt(int op, float a, float b, float c, float alpha, float beta) {
+    switch (op) {
+        case OP_ADD: return a + b;
+        case OP_MUL: return a * b;
+        case OP_ADD_RELU: return fmaxf(a + b, 0.f);
+        case OP_RELU_BWD: return b > 0.f ? a : 0.f;                       // a = dy, b = y
+        case OP_LEAKY_BWD: return b > 0.f ? a : 0.01f * a;
+        case OP_SIGMOID_BWD: return a * b * (1.f - b);                     // b = sigmoid output
+        case OP_ELU: return a > 0.f ? a : expm1f(a);
+        case OP_ELU_BWD: return b > 0.f ? a : a * (b + 1.f);              // b = elu output
+        case OP_REPARAM: return a + c * expf(0.5f * b);                    // a = mu, b = logvar, c = eps
+        case OP_REPARAM_BWD_LOGVAR: return a * c * 0.5f * expf(0.5f * b);  // a = dz
+        case OP_AXPBY: return alpha * a + beta * b;
+        case OP_LEAKY: return a > 0.f ? a : 0.01f * a;
+        case OP_RELU: return fmaxf(a, 0.f);
+        case OP_SCALE: return alpha * a;
+    }
+    return 0.f;
+}
+
+__global__ void eltwise_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                               float* __restrict__ out, long n, float alpha, float beta, int vec) {
+    const long n4 = vec ? (n >> 2) : 0;
+    if (op == OP_MUL_SCALAR) {          // out = a * b[0], b = device scalar (upstream gradient of a loss term)
+        const float sc = b[0] * alpha;
+        for (long i = (long)blockIdx.x * EB + threadIdx.x; i < n; i += (long)gridDim.x * EB) out[i] = a[i] * sc;
+        return;
+    }
+    for (long i = (long)blockIdx.x * EB + threadIdx.x; i < n4; i += (long)gridDim.x * EB) {
+        float4 va = reinterpret_cast<const float4*>(a)[i];
+        float4 vb = b ? reinterpret_cast<const float4*>(b)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 vc = c ? reinterpret_cast<const float4*>(c)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 r;
+        r.x = elt(op, va.x, vb.x, vc.x, alpha, beta); r.y = elt(op, va.y, vb.y, vc.y, alpha, beta);
+        r.z = elt(op, va.z, vb.z, vc.z, alpha, beta); r.w = elt(op, va.w, vb.w, vc.w, alpha, beta);
+        reinterpret_cast<float4*>(out)[i] = r;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * EB + threadIdx.x; i < n; i += (long)gridDim.x * EB)
+        out[i] = elt(op, a[i], b ? b[i] : 0.f, c ? c[i] : 0.f, alpha, beta);
+}
+
+// ---------------------------------------------------------------- bidirectional sum --------------------
+// out[r][h] = y[r][h] + y[r][H+h]  (model/hierarchy_net.py:145);  inverse: dy[r][h] -> dout[r][h], dout[r][H+h]
+__global__ void dirsum_kernel(const float* __restrict__ y, float* __restrict__ out, long rows, int H4, int inverse) {
+    const long total = rows * H4;
+    for (long i = (long)blockIdx.x * EB + threadIdx.x; i < total; i += (long)gridDim.x * EB) {
+        long r = i / H4; int h = (int)(i % H4);
+        if (!inverse) {
+            float4 a = reinterpret_cast<const float4*>(y)[r * 2 * H4 + h], b = reinterpret_cast<const float4*>(y)[r * 2 * H4 + H4 + h];
+            reinterpret_cast<float4*>(out)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        } else {
+            float4 d = reinterpret_cast<const float4*>(y)[i];
+            reinterpret_cast<float4*>(out)[r * 2 * H4 + h] = d;
+            reinterpret_cast<float4*>(out)[r * 2 * H4 + H4 + h] = d;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- dropout (Philox4x32-10) -------------
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t h0 = __umulhi(M0, c0), l0 = M0 * c0, h1 = __umulhi(M1, c2), l1 = M1 * c2;
+    uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+// mask[i] = keep ? 1/(1-p) : 0 ; out = x * mask.  state = {seed, step} lives in device memory so a captured
+// hipGraph draws fresh masks on every replay; `stream_id` separates call sites within a step.
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ out, float* __restrict__ mask, long n, float p,
+                               const unsigned long long* __restrict__ state, unsigned stream_id) {
+    const unsigned long long seed = state[0], step = state[1];
+    const float scale = 1.f / (1.f - p);
+    const long n4 = (n + 3) >> 2;
+    for (long i = (long)blockIdx.x * EB + threadIdx.x; i < n4; i += (long)gridDim.x * EB) {
+        uint32_t c0 = (uint32_t)i, c1 = (uint32_t)(i >> 32) ^ stream_id, c2 = (uint32_t)step, c3 = (uint32_t)(step >> 32);
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        uint32_t rr[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            long e = i * 4 + j;
+            if (e < n) {
+                float u = (rr[j] >> 8) * (1.0f / 16777216.0f);
+                float m = u >= p ? scale : 0.f;
+                if (mask) mask[e] = m;
+                if (out) out[e] = x[e] * m;
+            }
+        }
+    }
+}
+__global__ void rng_advance_kernel(unsigned long long* state) { state[1] += 1ull; }
+
+// ---------------------------------------------------------------- pixel shuffle (NHWC) ----------------
+// torch.nn.PixelShuffle(r) on logical NCHW: out[n, c, h*r+i, w*r+j] = in[n, c*r*r + i*r + j, h, w].
+// Physical layout here is NHWC on both sides.
+__global__ void pixel_shuffle_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int Cout, int r,
+                                     int inverse) {
+    long total = (long)N * H * r * W * r * Cout;
+    const int Cin = Cout * r * r;
+    for (long o = (long)blockIdx.x * EB + threadIdx.x; o < total; o += (long)gridDim.x * EB) {
+        int c = (int)(o % Cout); long t = o / Cout; int ox = (int)(t % (W * r)); t /= (W * r); int oy = (int)(t % (H * r)); int n = (int)(t / (H * r));
+        int h = oy / r, i = oy % r, w = ox / r, j = ox % r;
+        long src = (((long)n * H + h) * W + w) * Cin + c * r * r + i * r + j;
+        if (!inverse) out[o] = in[src]; else out[src] = in[o];     // inverse: `in` is the shuffled-layout gradient
+    }
+}
+
+// ---------------------------------------------------------------- tap flatten --------------------------
+// [N][H][W][C] -> [N][W][C][H]: row (n,w) of the tap FC input with K index c*H + h, exactly the reference's
+// reshape(B, C*H, W).transpose(1,2) of an NCHW tensor (model/ResNetSE34V2.py:160-162).  inverse=1 maps back.
+__global__ void nhwc_to_nwch_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C, int inverse) {
+    const long total = (long)N * H * W * C;
+    for (long o = (long)blockIdx.x * EB + threadIdx.x; o < total; o += (long)gridDim.x * EB) {
+        int h = (int)(o % H); long t = o / H; int c = (int)(t % C); t /= C; int w = (int)(t % W); int n = (int)(t / W);
+        long src = (((long)n * H + h) * W + w) * C + c;
+        if (!inverse) out[o] = in[src]; else out[src] = in[o];
+    }
+}
+
+// ---------------------------------------------------------------- speaker-softmax blending -------------
+// logits [B][3][L] -> w = softmax over the 3 granularities; blend_i[b,t,:] = sum_g feat_g[b,t,:] * w[b,g,i]
+// (reference: scripts/model/ResNetSE34V2.py:202-212).  feats are [B][T*F] rows.
+__global__ void blend_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ f0, const float* __restrict__ f1,
+                                 const float* __restrict__ f2, float* __restrict__ wout, float* __restrict__ blend, int B,
+                                 int L, int TF) {
+    const int b = blockIdx.x;
+    __shared__ float w[3 * 8];
+    if (threadIdx.x < L) {
+        int i = threadIdx.x;
+        float a0 = logits[(b * 3 + 0) * L + i], a1 = logits[(b * 3 + 1) * L + i], a2 = logits[(b * 3 + 2) * L + i];
+        float m = fmaxf(a0, fmaxf(a1, a2));
+        float e0 = expf(a0 - m), e1 = expf(a1 - m), e2 = expf(a2 - m), s = e0 + e1 + e2;
+        w[0 * L + i] = e0 / s; w[1 * L + i] = e1 / s; w[2 * L + i] = e2 / s;
+        wout[(b * 3 + 0) * L + i] = e0 / s; wout[(b * 3 + 1) * L + i] = e1 / s; wout[(b * 3 + 2) * L + i] = e2 / s;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < TF; e += blockDim.x) {
+        float x0 = f0[(long)b * TF + e], x1 = f1[(long)b * TF + e], x2 = f2[(long)b * TF + e];
+        for (int i = 0; i < L; ++i) blend[((long)i * B + b) * TF + e] = x0 * w[i] + x1 * w[L + i] + x2 * w[2 * L + i];
+    }
+}
+// inputs: dblend [L][B][TF], dw_ext [B][3][L] (gradient flowing into the returned `weight`, may be null);
+// outputs: df_g (+= into provided buffers, which the caller pre-fills with the direct feat gradients or zeros),
+// dlogits [B][3][L].
+__global__ __launch_bounds__(256) void blend_bwd_kernel(const float* __restrict__ dblend, const float* __restrict__ dw_ext,
+                                                        const float* __restrict__ w, const float* __restrict__ f0,
+                                                        const float* __restrict__ f1, const float* __restrict__ f2,
+                                                        float* __restrict__ df0, float* __restrict__ df1, float* __restrict__ df2,
+                                                        float* __restrict__ dlogits, int B, int L, int TF) {
+    const int b = blockIdx.x;
+    __shared__ float red[16];
+    __shared__ float dw[3 * 8];
+    float acc[3 * 8];
+    for (int i = 0; i < 3 * L; ++i) acc[i] = 0.f;
+    for (int e = threadIdx.x; e < TF; e += 256) {
+        float x0 = f0[(long)b * TF + e], x1 = f1[(long)b * TF + e], x2 = f2[(long)b * TF + e];
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        for (int i = 0; i < L; ++i) {
+            float d = dblend[((long)i * B + b) * TF + e];
+            g0 += d * w[(b * 3 + 0) * L + i]; g1 += d * w[(b * 3 + 1) * L + i]; g2 += d * w[(b * 3 + 2) * L + i];
+            acc[i] += d * x0; acc[L + i] += d * x1; acc[2 * L + i] += d * x2;
+        }
+        df0[(long)b * TF + e] += g0; df1[(long)b * TF + e] += g1; df2[(long)b * TF + e] += g2;
+    }
+    for (int i = 0; i < 3 * L; ++i) {
+        float s = block_sum(acc[i], red);
+        if (threadIdx.x == 0) dw[i] = s + (dw_ext ? dw_ext[b * 3 * L + i] : 0.f);
+    }
+    __syncthreads();
+    if (threadIdx.x < L) {           // softmax backward over g for level i
+        int i = threadIdx.x;
+        float w0 = w[(b * 3 + 0) * L + i], w1 = w[(b * 3 + 1) * L + i], w2 = w[(b * 3 + 2) * L + i];
+        float dot = dw[i] * w0 + dw[L + i] * w1 + dw[2 * L + i] * w2;
+        dlogits[(b * 3 + 0) * L + i] = w0 * (dw[i] - dot);
+        dlogits[(b * 3 + 1) * L + i] = w1 * (dw[L + i] - dot);
+        dlogits[(b * 3 + 2) * L + i] = w2 * (dw[2 * L + i] - dot);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ha2g_embedding_fwd_f32(const long* tok, const float* W, float* out, long n, int C, void* stream) {
+    HA2G_REQUIRE(C % 4 == 0, "embedding: width %d must be a multiple of 4", C);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_for(n * (C / 4))), dim3(EB), 0, (hipStream_t)stream, tok, W, out, n, C / 4);
+    HA2G_CHECK_LAUNCH("embedding_fwd");
+    return 0;
+}
+int ha2g_embedding_bwd_f32(const long* tok, const float* dY, float* dW, int n, int C, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(n, ceil_div(C, 64)), dim3(256), 0, (hipStream_t)stream, tok, dY, dW, n, C);
+    HA2G_CHECK_LAUNCH("embedding_bwd");
+    return 0;
+}
+int ha2g_im2col1d_f32(const float* x, float* col, int B, int T, int C, int k, int dil, int pad_left, int To, void* stream) {
+    long total = (long)B * To * C * k;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(im2col1d_kernel, dim3(grid_for(total)), dim3(EB), 0, (hipStream_t)stream, x, col, B, T, C, k, dil, pad_left, To);
+    HA2G_CHECK_LAUNCH("im2col1d");
+    return 0;
+}
+int ha2g_col2im1d_f32(const float* dcol, float* dx, int B, int T, int C, int k, int dil, int pad_left, int To, void* stream) {
+    long total = (long)B * T * C;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(col2im1d_kernel, dim3(grid_for(total)), dim3(EB), 0, (hipStream_t)stream, dcol, dx, B, T, C, k, dil, pad_left, To);
+    HA2G_CHECK_LAUNCH("col2im1d");
+    return 0;
+}
+int ha2g_weight_norm_fwd_f32(const float* g, const float* v, float* w, float* norm, int Cout, int n, void* stream) {
+    hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, g, v, w, norm, n);
+    HA2G_CHECK_LAUNCH("weight_norm_fwd");
+    return 0;
+}
+int ha2g_weight_norm_bwd_f32(const float* dw, const float* g, const float* v, const float* norm, float* dg, float* dv, int Cout,
+                             int n, void* stream) {
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, dw, g, v, norm, dg, dv, n);
+    HA2G_CHECK_LAUNCH("weight_norm_bwd");
+    return 0;
+}
+// out = op(a, b, c); b / c may be null for unary ops (float4 path when every pointer is 16-byte aligned).
+int ha2g_eltwise_f32(int op, const float* a, const float* b, const float* c, float* out, long n, float alpha, float beta,
+                     void* stream) {
+    if (n == 0) return 0;
+    HA2G_REQUIRE(op >= 0 && op <= OP_MUL_SCALAR, "eltwise: unknown op %d", op);
+    int vec = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) & 15) == 0 && op != OP_MUL_SCALAR;
+    hipLaunchKernelGGL(eltwise_kernel, dim3(grid_for(n, 4)), dim3(EB), 0, (hipStream_t)stream, op, a, b, c, out, n, alpha, beta, vec);
+    HA2G_CHECK_LAUNCH("eltwise");
+    return 0;
+}
+// state: device uint64[2] = {seed, step}.  out and/or mask may be null.
+int ha2g_dropout_f32(const float* x, float* out, float* mask, long n, float p, const void* state, unsigned stream_id, void* stream) {
+    if (n == 0) return 0;
+    HA2G_REQUIRE(p >= 0.f && p < 1.f, "dropout: p=%f out of range", p);
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n, 4)), dim3(EB), 0, (hipStream_t)stream, x, out, mask, n, p,
+                       (const unsigned long long*)state, stream_id);
+    HA2G_CHECK_LAUNCH("dropout");
+    return 0;
+}
+int ha2g_dirsum_f32(const float* y, float* out, long rows, int H, int inverse, void* stream) {
+    HA2G_REQUIRE(H % 4 == 0, "dirsum: H %% 4");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(dirsum_kernel, dim3(grid_for(rows * (H / 4))), dim3(EB), 0, (hipStream_t)stream, y, out, rows, H / 4, inverse);
+    HA2G_CHECK_LAUNCH("dirsum");
+    return 0;
+}
+int ha2g_rng_advance(void* state, void* stream) {
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)state);
+    HA2G_CHECK_LAUNCH("rng_advance");
+    return 0;
+}
+// NHWC pixel shuffle; in [N,H,W,Cout*r*r] -> out [N,H*r,W*r,Cout].  inverse=1: `in` is the gradient in the
+// shuffled layout and `out` receives the gradient in the unshuffled layout.
+int ha2g_pixel_shuffle_f32(const float* in, float* out, int N, int H, int W, int Cout, int r, int inverse, void* stream) {
+    long total = (long)N * H * r * W * r * Cout;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid_for(total)), dim3(EB), 0, (hipStream_t)stream, in, out, N, H, W, Cout, r, inverse);
+    HA2G_CHECK_LAUNCH("pixel_shuffle");
+    return 0;
+}
+int ha2g_nhwc_to_nwch_f32(const float* in, float* out, int N, int H, int W, int C, int inverse, void* stream) {
+    long total = (long)N * H * W * C;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(nhwc_to_nwch_kernel, dim3(grid_for(total)), dim3(EB), 0, (hipStream_t)stream, in, out, N, H, W, C, inverse);
+    HA2G_CHECK_LAUNCH("nhwc_to_nwch");
+    return 0;
+}
+int ha2g_blend_fwd_f32(const float* logits, const float* f0, const float* f1, const float* f2, float* w, float* blend, int B, int L,
+                       int TF, void* stream) {
+    HA2G_REQUIRE(L <= 8, "blend: pose_level %d > 8", L);
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, f0, f1, f2, w, blend, B, L, TF);
+    HA2G_CHECK_LAUNCH("blend_fwd");
+    return 0;
+}
+int ha2g_blend_bwd_f32(const float* dblend, const float* dw_ext, const float* w, const float* f0, const float* f1, const float* f2,
+                       float* df0, float* df1, float* df2, float* dlogits, int B, int L, int TF, void* stream) {
+    HA2G_REQUIRE(L <= 8, "blend: pose_level %d > 8", L);
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dblend, dw_ext, w, f0, f1, f2, df0, df1, df2,
+                       dlogits, B, L, TF);
+    HA2G_CHECK_LAUNCH("blend_bwd");
+    return 0;
+}
+
+}  // extern "C"

@@ -18,6 +18,10 @@
 
 namespace {
 
+constexpr int NT = 512;        // 8 waves = 2 per SIMD: one wave's W_hh loads overlap its partner's MFMAs
+constexpr int NW = NT / 64;
+constexpr int PF = 8;          // W_hh fragments (1 KiB per wave each) kept in flight per wave
+
 template <int H> struct GruCfg {
     static constexpr int NJT = (H + 15) / 16;      // 16-wide tiles over hidden units (and over k)
     static constexpr int HP = NJT * 16;            // padded hidden size
@@ -48,7 +52,7 @@ __global__ void gru_pack_kernel(const float* __restrict__ whh, float* __restrict
 
 // ---- forward ------------------------------------------------------------------------------------------
 template <int H>
-__global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ gi,      // [B][T][2][3H]
+__global__ __launch_bounds__(NT) void gru_fwd_kernel(const float* __restrict__ gi,      // [B][T][2][3H]
                                                       const float* __restrict__ wp,      // [2][NJT*3*NJT][64][4]
                                                       const float* __restrict__ bhh0, const float* __restrict__ bhh1,
                                                       float* __restrict__ y,             // [B][T][2H]
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
     const float4* wpd = reinterpret_cast<const float4*>(wp) + (long)dir * (NJT * 3 * NJT) * 64 + lane;
     const float* bhh = dir ? bhh1 : bhh0;
 
-    for (int i = tid; i < 16 * LDH; i += 256) hs[0][i] = 0.f;
+    for (int i = tid; i < 16 * LDH; i += NT) hs[0][i] = 0.f;
     __syncthreads();
 
     for (int s = 0; s < T; ++s) {
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
 #pragma unroll
         for (int m = 0; m < NJT; ++m) hb[m] = *reinterpret_cast<const float4*>(&hs[cur][lb * LDH + 16 * m + 4 * g]);
 
-        for (int jt = wave; jt < NJT; jt += 4) {
+        for (int jt = wave; jt < NJT; jt += NW) {
             f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
             const float4* w = wpd + (long)(jt * 3) * NJT * 64;
             const int j = 16 * jt + 4 * g;
@@ -88,15 +92,27 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
                 giz = *reinterpret_cast<const float4*>(gp + H);
                 gin = *reinterpret_cast<const float4*>(gp + 2 * H);
             }
+            // W_hh fragment stream of this j-tile, order f = 3*m + gate, kept PF fragments ahead of the MFMAs
+            // (one wave alone cannot hide the ~500-cycle L2 latency otherwise; hipcc keeps <=2 loads in flight).
+            constexpr int NF = 3 * NJT;
+            float4 ring[PF];
 #pragma unroll
-            for (int m = 0; m < NJT; ++m) {
-                const float4 wr = w[m * 64], wz = w[(NJT + m) * 64], wn = w[(2 * NJT + m) * 64];
-                const float* pr = &wr.x; const float* pz = &wz.x; const float* pn = &wn.x; const float* ph = &hb[m].x;
+            for (int f = 0; f < PF && f < NF; ++f) ring[f] = w[((f % 3) * NJT + f / 3) * 64];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    ar = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[u], ph[u], ar, 0, 0, 0);
-                    az = __builtin_amdgcn_mfma_f32_16x16x4f32(pz[u], ph[u], az, 0, 0, 0);
-                    an = __builtin_amdgcn_mfma_f32_16x16x4f32(pn[u], ph[u], an, 0, 0, 0);
+            for (int f = 0; f < NF; ++f) {
+                const float4 wv = ring[f % PF];
+                if (f + PF < NF) ring[f % PF] = w[(((f + PF) % 3) * NJT + (f + PF) / 3) * 64];
+                __builtin_amdgcn_sched_barrier(0);      // keep the refill load ahead of the MFMAs (hipcc sinks it otherwise)
+                const float* pw = &wv.x; const float* ph = &hb[f / 3].x;
+                if (f % 3 == 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ar = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[u], ph[u], ar, 0, 0, 0);
+                } else if (f % 3 == 1) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) az = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[u], ph[u], az, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) an = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[u], ph[u], an, 0, 0, 0);
                 }
             }
             // C/D layout 16x16: col (batch) = lane&15, row (unit within tile) = 4*(lane>>4) + reg
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
 //   dg[b][t][dir] = [da_r | da_z | da_n | da_n r]   (first three = d gi, [0,1,3] = d gh)
 //   carry' = dh z + [da_r, da_z, da_n r] * W_hh      (MFMA, K = 3H)
 template <int H>
-__global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ dy,      // [B][T][2H]
+__global__ __launch_bounds__(NT) void gru_bwd_kernel(const float* __restrict__ dy,      // [B][T][2H]
                                                       const float* __restrict__ y,       // [B][T][2H]
                                                       const float* __restrict__ rs,      // [B][T][2][4][H]
                                                       const float* __restrict__ wpt,     // [2][NJT*3*NJT][64][4]
@@ -156,8 +172,8 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
     const int lb = lane & 15, g = lane >> 4;
     const float4* wpd = reinterpret_cast<const float4*>(wpt) + (long)dir * (NJT * 3 * NJT) * 64 + lane;
 
-    for (int i = tid; i < 16 * LDH; i += 256) sc[i] = 0.f;
-    for (int i = tid; i < 16 * LDG; i += 256) sg[i] = 0.f;
+    for (int i = tid; i < 16 * LDH; i += NT) sc[i] = 0.f;
+    for (int i = tid; i < 16 * LDG; i += NT) sg[i] = 0.f;
     __syncthreads();
 
     for (int s = 0; s < T; ++s) {
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
         const int tp = dir ? t + 1 : t - 1;              // time index of h_prev
         const bool has_prev = tp >= 0 && tp < T;
         // ---- phase 1: gate gradients (elementwise over 16 x H) ----
-        for (int idx = tid; idx < 16 * (H / 4); idx += 256) {
+        for (int idx = tid; idx < 16 * (H / 4); idx += NT) {
             const int bb = idx / (H / 4), j = (idx % (H / 4)) * 4;
             const int b = b0 + bb;
             float4 dar = make_float4(0.f, 0.f, 0.f, 0.f), daz = dar, dghn = dar, dhz = dar;
@@ -210,22 +226,31 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
         __syncthreads();
         // ---- phase 2: carry[b][k] += sum_{gate,j} dgh[b][gate,j] * W_hh[gate*H + j][k] ----
         if (s + 1 < T) {
-            for (int kt = wave; kt < NJT; kt += 4) {
+            for (int kt = wave; kt < NJT; kt += NW) {
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
                 const float4* w = wpd + (long)(kt * 3) * NJT * 64;
+                constexpr int NF = 3 * NJT;       // f = 3*jt + gate
+                float4 ring[PF];
 #pragma unroll
-                for (int jt = 0; jt < NJT; ++jt) {
-                    const float4 w0 = w[jt * 64], w1 = w[(NJT + jt) * 64], w2 = w[(2 * NJT + jt) * 64];
-                    const float4 d0 = *reinterpret_cast<const float4*>(&sg[lb * LDG + 16 * jt + 4 * g]);
-                    const float4 d1 = *reinterpret_cast<const float4*>(&sg[lb * LDG + HP + 16 * jt + 4 * g]);
-                    const float4 d2 = *reinterpret_cast<const float4*>(&sg[lb * LDG + 2 * HP + 16 * jt + 4 * g]);
-                    const float* pw0 = &w0.x; const float* pw1 = &w1.x; const float* pw2 = &w2.x;
-                    const float* pd0 = &d0.x; const float* pd1 = &d1.x; const float* pd2 = &d2.x;
+                for (int f = 0; f < PF && f < NF; ++f) ring[f] = w[((f % 3) * NJT + f / 3) * 64];
+                float4 dnext = *reinterpret_cast<const float4*>(&sg[lb * LDG + 4 * g]);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pw0[u], pd0[u], a0, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pw1[u], pd1[u], a1, 0, 0, 0);
-                        a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pw2[u], pd2[u], a2, 0, 0, 0);
+                for (int f = 0; f < NF; ++f) {
+                    const float4 wv = ring[f % PF];
+                    const float4 dv = dnext;
+                    if (f + PF < NF) ring[f % PF] = w[(((f + PF) % 3) * NJT + (f + PF) / 3) * 64];
+                    if (f + 1 < NF) dnext = *reinterpret_cast<const float4*>(&sg[lb * LDG + ((f + 1) % 3) * HP + 16 * ((f + 1) / 3) + 4 * g]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float* pw = &wv.x; const float* pd = &dv.x;
+                    if (f % 3 == 0) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[u], pd[u], a0, 0, 0, 0);
+                    } else if (f % 3 == 1) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[u], pd[u], a1, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[u], pd[u], a2, 0, 0, 0);
                     }
                 }
                 float* cp = &sc[lb * LDH + 16 * kt + 4 * g];
@@ -279,7 +304,7 @@ int ha2g_gru_layer_fwd(const float* gi, const float* wp, const float* bhh_fwd, c
                        int B, int T, int H, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (B == 0 || T == 0) return 0;
-    dim3 grid(ceil_div(B, 16), 2), block(256);
+    dim3 grid(ceil_div(B, 16), 2), block(NT);
     switch (H) {
         case 300: hipLaunchKernelGGL(gru_fwd_kernel<300>, grid, block, 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, B, T); break;
         case 64: hipLaunchKernelGGL(gru_fwd_kernel<64>, grid, block, 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, B, T); break;
@@ -297,7 +322,7 @@ int ha2g_gru_layer_bwd(const float* dy, const float* y, const float* rs, const f
                        void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (B == 0 || T == 0) return 0;
-    dim3 grid(ceil_div(B, 16), 2), block(256);
+    dim3 grid(ceil_div(B, 16), 2), block(NT);
     switch (H) {
         case 300: hipLaunchKernelGGL(gru_bwd_kernel<300>, grid, block, 0, st, dy, y, rs, wpt, dg, B, T); break;
         case 64: hipLaunchKernelGGL(gru_bwd_kernel<64>, grid, block, 0, st, dy, y, rs, wpt, dg, B, T); break;

@@ -1,0 +1,333 @@
+// Loss terms of train_iter_hierarchy (reference scripts/train_eval/train_hierarchy.py:54-68,173-262).
+// Every kernel produces the scalar term AND the unit gradient w.r.t. its differentiable inputs in one go
+// (the autograd wrapper only rescales by the upstream scalar), reductions are fixed-order (deterministic).
+#include "common.h"
+
+namespace {
+
+// deterministic sum of n floats (n up to a few 100k) by ONE block: out = scale * sum(x) (+ out if accumulate)
+__global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, long n, float* __restrict__ out, float scale,
+                                                   int accumulate) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) s += x[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *out = (accumulate ? *out : 0.f) + scale * s;
+}
+
+// ---- Huber: smooth_l1(x/beta, y/beta)*beta == 0.5 d^2/beta (|d|<beta) else |d| - beta/2 ------------------
+__global__ __launch_bounds__(256) void huber_kernel(const float* __restrict__ x, const float* __restrict__ y, long n, float beta,
+                                                    float gscale, float* __restrict__ part, float* __restrict__ dx) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float d = x[i] - y[i], ad = fabsf(d);
+        bool q = ad < beta;
+        s += q ? 0.5f * d * d / beta : ad - 0.5f * beta;
+        if (dx) dx[i] = gscale * (q ? d / beta : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// ---- KLD = -0.5 * mean(1 + lv - mu^2 - exp(lv)) ---------------------------------------------------------
+__global__ __launch_bounds__(256) void kld_kernel(const float* __restrict__ mu, const float* __restrict__ lv, int n,
+                                                  float* __restrict__ loss, float* __restrict__ dmu, float* __restrict__ dlv) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const float inv = 1.f / (float)n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float m = mu[i], l = lv[i], e = expf(l);
+        s += 1.f + l - m * m - e;
+        dmu[i] = m * inv;
+        dlv[i] = -0.5f * (1.f - e) * inv;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *loss = -0.5f * s * inv;
+}
+
+// ---- diversity regulariser (train_hierarchy.py:213-222): one block per sample --------------------------
+__global__ __launch_bounds__(256) void divreg_kernel(const float* __restrict__ out, const float* __restrict__ rnd,
+                                                     const float* __restrict__ z, const float* __restrict__ zr, int B, int TP,
+                                                     int Z, float beta, float* __restrict__ per_sample, float* __restrict__ dout) {
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    const float* o = out + (long)b * TP;
+    const float* r = rnd + (long)b * TP;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < TP; i += 256) {
+        float d = o[i] - r[i], ad = fabsf(d);
+        s += ad < beta ? 0.5f * d * d / beta : ad - 0.5f * beta;
+    }
+    const float pose = block_sum(s, red);
+    float zs = 0.f;
+    for (int i = threadIdx.x; i < Z; i += 256) zs += fabsf(z[b * Z + i] - zr[b * Z + i]);
+    const float zl1 = block_sum(zs, red) / (float)Z;
+    const float v = -(pose / (zl1 + 1.0e-5f));
+    const bool live = v >= -1000.f;                           // clamp(min=-1000) passes gradient on its boundary
+    if (threadIdx.x == 0) per_sample[b] = live ? v : -1000.f;
+    const float g = live ? -1.f / ((zl1 + 1.0e-5f) * (float)B) : 0.f;
+    for (int i = threadIdx.x; i < TP; i += 256) {
+        float d = o[i] - r[i], ad = fabsf(d);
+        dout[(long)b * TP + i] = g * (ad < beta ? d / beta : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)));
+    }
+}
+
+// ---- physical angle prior (train_hierarchy.py:242-262): one thread per (b,t) row -------------------------
+constexpr int MAXV = 48;     // bones (+2 palm normals for the expressive skeleton)
+__global__ __launch_bounds__(64) void phys_kernel(const float* __restrict__ out, const float* __restrict__ mean_dir, int rows,
+                                                  int nb, const int* __restrict__ pairs, int npairs, const float* __restrict__ avg,
+                                                  const float* __restrict__ var, float* __restrict__ per_row, float* __restrict__ dout) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= rows) return;
+    const int P = nb * 3;
+    const float* o = out + (long)r * P;
+    float* g = dout + (long)r * P;
+    for (int i = 0; i < P; ++i) g[i] = 0.f;
+    float total = 0.f;
+    const float inv_rows = 1.f / (float)rows, PI = 3.14159265358979323846f;
+    for (int k = 0; k < npairs; ++k) {
+        const int a = pairs[2 * k], b = pairs[2 * k + 1];
+        float va[3], vb[3];
+        for (int c = 0; c < 3; ++c) { va[c] = o[a * 3 + c] + mean_dir[a * 3 + c]; vb[c] = o[b * 3 + c] + mean_dir[b * 3 + c]; }
+        float na = sqrtf(va[0] * va[0] + va[1] * va[1] + va[2] * va[2]), nbn = sqrtf(vb[0] * vb[0] + vb[1] * vb[1] + vb[2] * vb[2]);
+        float da = fmaxf(na, 1e-12f), db = fmaxf(nbn, 1e-12f);
+        float ua[3], ub[3];
+        for (int c = 0; c < 3; ++c) { ua[c] = va[c] / da; ub[c] = vb[c] / db; }
+        float ip = ua[0] * ub[0] + ua[1] * ub[1] + ua[2] * ub[2];
+        const float lo = -1.f + 1e-7f, hi = 1.f - 1e-7f;
+        const bool inside = ip >= lo && ip <= hi;
+        float ipc = fminf(fmaxf(ip, lo), hi);
+        float ang = acosf(ipc) / PI;
+        float diff = ang - avg[k];
+        total += diff * diff / (2.f * var[k]);
+        // d/d ip
+        float gip = inside ? (diff / var[k]) * (-1.f / (PI * sqrtf(1.f - ipc * ipc))) * inv_rows : 0.f;
+        // through the two normalisations: d v = (d u - u (u . d u)) / |v|
+        float dua[3] = {gip * ub[0], gip * ub[1], gip * ub[2]}, dub[3] = {gip * ua[0], gip * ua[1], gip * ua[2]};
+        float pa = ua[0] * dua[0] + ua[1] * dua[1] + ua[2] * dua[2], pb = ub[0] * dub[0] + ub[1] * dub[1] + ub[2] * dub[2];
+        for (int c = 0; c < 3; ++c) {
+            if (na > 1e-12f) g[a * 3 + c] += (dua[c] - ua[c] * pa) / da; else g[a * 3 + c] += dua[c] / da;
+            if (nbn > 1e-12f) g[b * 3 + c] += (dub[c] - ub[c] * pb) / db; else g[b * 3 + c] += dub[c] / db;
+        }
+    }
+    per_row[r] = total * inv_rows;
+}
+
+// ---- GAN terms: mode 0  gen = -mean(log(d+1e-8));  mode 1  dis = -mean(log(real+1e-8) + log(1-fake+1e-8)) ----
+__global__ __launch_bounds__(256) void gan_kernel(int mode, const float* __restrict__ a, const float* __restrict__ b, int n,
+                                                  float* __restrict__ loss, float* __restrict__ da, float* __restrict__ db) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const float inv = 1.f / (float)n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        if (mode == 0) {
+            s += logf(a[i] + 1e-8f);
+            da[i] = -inv / (a[i] + 1e-8f);
+        } else {
+            s += logf(a[i] + 1e-8f) + logf(1.f - b[i] + 1e-8f);
+            da[i] = -inv / (a[i] + 1e-8f);
+            db[i] = inv / (1.f - b[i] + 1e-8f);
+        }
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *loss = -s * inv;
+}
+
+// ---- softmax contrastive loss (train_hierarchy.py:54-68; expressive variant :107-121) -------------------
+constexpr int CD = 32;      // feature width of text / audio features
+constexpr int CT = 64;      // rows of the opposite side staged in LDS per tile
+
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, float* __restrict__ xn, float* __restrict__ nrm, int N) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float s = 0.f, v[CD];
+    for (int d = 0; d < CD; ++d) { v[d] = x[(long)i * CD + d]; s += v[d] * v[d]; }
+    float n = fmaxf(sqrtf(s), 1e-12f);
+    nrm[i] = n;
+    for (int d = 0; d < CD; ++d) xn[(long)i * CD + d] = v[d] / n;
+}
+
+__device__ __forceinline__ float logit_of(float dist, int expressive) {
+    return expressive ? 1.0f / dist : fmaxf(1.0f / (dist + 1e-8f), 1e-8f);
+}
+// d logit / d dist
+__device__ __forceinline__ float dlogit_of(float dist, float l, int expressive) {
+    if (expressive) return -l * l;
+    return (1.0f / (dist + 1e-8f) > 1e-8f) ? -l * l : 0.f;
+}
+
+// thread per row i of a: sweep 1 -> running max / sum-exp over all j and the diagonal logit; sweep 2 -> d a_i.
+__global__ __launch_bounds__(64) void contrastive_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, int N,
+                                                              int expressive, float* __restrict__ rmax, float* __restrict__ rsum,
+                                                              float* __restrict__ loss_i, float* __restrict__ dan) {
+    __shared__ float tb[CT * CD];
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const bool on = i < N;
+    float ai[CD];
+    for (int d = 0; d < CD; ++d) ai[d] = on ? a[(long)i * CD + d] : 0.f;
+    float m = -INFINITY, z = 0.f, lii = 0.f;
+    for (int j0 = 0; j0 < N; j0 += CT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < CT * CD; e += 64) tb[e] = (j0 + e / CD < N) ? b[(long)j0 * CD + e] : 0.f;
+        __syncthreads();
+        const int jn = min(CT, N - j0);
+        for (int j = 0; j < jn; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < CD; ++d) { float t = ai[d] - tb[j * CD + d]; s += t * t; }
+            float l = logit_of(sqrtf(s), expressive);
+            if (j0 + j == i) lii = l;
+            if (l > m) { z = z * expf(m - l) + 1.f; m = l; } else z += expf(l - m);
+        }
+    }
+    if (on) { rmax[i] = m; rsum[i] = z; loss_i[i] = (m + logf(z)) - lii; }
+    const float invN = 1.f / (float)N;
+    float acc[CD], csum = 0.f;
+    for (int d = 0; d < CD; ++d) acc[d] = 0.f;
+    for (int j0 = 0; j0 < N; j0 += CT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < CT * CD; e += 64) tb[e] = (j0 + e / CD < N) ? b[(long)j0 * CD + e] : 0.f;
+        __syncthreads();
+        const int jn = min(CT, N - j0);
+        for (int j = 0; j < jn; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < CD; ++d) { float t = ai[d] - tb[j * CD + d]; s += t * t; }
+            float dist = sqrtf(s);
+            float l = logit_of(dist, expressive);
+            float p = expf(l - m) / z - ((j0 + j == i) ? 1.f : 0.f);
+            float c = dist > 0.f ? p * dlogit_of(dist, l, expressive) / dist * invN : 0.f;    // norm backward: 0 at dist = 0
+            csum += c;
+#pragma unroll
+            for (int d = 0; d < CD; ++d) acc[d] += c * tb[j * CD + d];
+        }
+    }
+    if (on)
+        for (int d = 0; d < CD; ++d) dan[(long)i * CD + d] = ai[d] * csum - acc[d];
+}
+
+// thread per row j of b: d b_j = sum_i c_ij (b_j - a_i)
+__global__ __launch_bounds__(64) void contrastive_cols_kernel(const float* __restrict__ a, const float* __restrict__ b, int N,
+                                                              int expressive, const float* __restrict__ rmax,
+                                                              const float* __restrict__ rsum, float* __restrict__ dbn) {
+    __shared__ float ta[CT * CD];
+    __shared__ float tm[CT], tz[CT];
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const bool on = j < N;
+    float bj[CD], acc[CD], csum = 0.f;
+    for (int d = 0; d < CD; ++d) { bj[d] = on ? b[(long)j * CD + d] : 0.f; acc[d] = 0.f; }
+    const float invN = 1.f / (float)N;
+    for (int i0 = 0; i0 < N; i0 += CT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < CT * CD; e += 64) ta[e] = (i0 + e / CD < N) ? a[(long)i0 * CD + e] : 0.f;
+        if (threadIdx.x < CT) { int i = i0 + threadIdx.x; tm[threadIdx.x] = i < N ? rmax[i] : 0.f; tz[threadIdx.x] = i < N ? rsum[i] : 1.f; }
+        __syncthreads();
+        const int in = min(CT, N - i0);
+        for (int i = 0; i < in; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < CD; ++d) { float t = ta[i * CD + d] - bj[d]; s += t * t; }
+            float dist = sqrtf(s);
+            float l = logit_of(dist, expressive);
+            float p = expf(l - tm[i]) / tz[i] - ((i0 + i == j) ? 1.f : 0.f);
+            float c = dist > 0.f ? p * dlogit_of(dist, l, expressive) / dist * invN : 0.f;
+            csum += c;
+#pragma unroll
+            for (int d = 0; d < CD; ++d) acc[d] += c * ta[i * CD + d];
+        }
+    }
+    if (on)
+        for (int d = 0; d < CD; ++d) dbn[(long)j * CD + d] = bj[d] * csum - acc[d];
+}
+
+// gradient through x / max(|x|, 1e-12): dx = (dn - n (n . dn)) / |x|
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restrict__ xn, const float* __restrict__ nrm,
+                                                          const float* __restrict__ dn, float* __restrict__ dx, int N) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float p = 0.f;
+    for (int d = 0; d < CD; ++d) p += xn[(long)i * CD + d] * dn[(long)i * CD + d];
+    float n = nrm[i];
+    for (int d = 0; d < CD; ++d) {
+        float g = dn[(long)i * CD + d];
+        dx[(long)i * CD + d] = (n > 1e-12f ? g - xn[(long)i * CD + d] * p : g) / n;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ha2g_sum_f32(const float* x, long n, float* out, float scale, int accumulate, void* stream) {
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out, scale, accumulate);
+    HA2G_CHECK_LAUNCH("sum");
+    return 0;
+}
+
+// loss = mean Huber_beta(x - y); dx (nullable) = d loss / d x.  ws: >= 1024 floats.
+int ha2g_huber_f32(const float* x, const float* y, long n, float beta, float* loss, float* dx, float* ws, void* stream) {
+    HA2G_REQUIRE(n > 0, "huber: empty input");
+    hipStream_t st = (hipStream_t)stream;
+    int nb = (int)((n + 4095) / 4096);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(huber_kernel, dim3(nb), dim3(256), 0, st, x, y, n, beta, 1.f / (float)n, ws, dx);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, ws, (long)nb, loss, 1.f / (float)n, 0);
+    HA2G_CHECK_LAUNCH("huber");
+    return 0;
+}
+
+int ha2g_kld_f32(const float* mu, const float* logvar, int n, float* loss, float* dmu, float* dlogvar, void* stream) {
+    hipLaunchKernelGGL(kld_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mu, logvar, n, loss, dmu, dlogvar);
+    HA2G_CHECK_LAUNCH("kld");
+    return 0;
+}
+
+// out/rnd [B][TP], z/zr [B][Z]; loss = mean_b clamp(-(huber_sum_b)/(mean|z-zr| + 1e-5), min=-1000); ws >= B floats
+int ha2g_divreg_f32(const float* out, const float* rnd, const float* z, const float* zr, int B, int TP, int Z, float beta,
+                    float* loss, float* dout, float* ws, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(divreg_kernel, dim3(B), dim3(256), 0, st, out, rnd, z, zr, B, TP, Z, beta, ws, dout);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, ws, (long)B, loss, 1.f / (float)B, 0);
+    HA2G_CHECK_LAUNCH("divreg");
+    return 0;
+}
+
+// out [rows][nb*3]; pairs int32 [npairs][2]; avg/var [npairs]; ws >= rows floats
+int ha2g_phys_angle_f32(const float* out, const float* mean_dir, int rows, int nb, const int* pairs, int npairs, const float* avg,
+                        const float* var, float* loss, float* dout, float* ws, void* stream) {
+    HA2G_REQUIRE(nb <= MAXV, "phys: too many bones (%d)", nb);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(phys_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, out, mean_dir, rows, nb, pairs, npairs, avg, var, ws, dout);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, ws, (long)rows, loss, 1.f, 0);
+    HA2G_CHECK_LAUNCH("phys");
+    return 0;
+}
+
+int ha2g_gan_loss_f32(int mode, const float* a, const float* b, int n, float* loss, float* da, float* db, void* stream) {
+    hipLaunchKernelGGL(gan_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mode, a, b, n, loss, da, db);
+    HA2G_CHECK_LAUNCH("gan_loss");
+    return 0;
+}
+
+// a, b [N][32] raw features (rows = first argument of the reference's criterion = text); loss scalar;
+// da, db unit gradients w.r.t. the raw inputs.  ws >= N*(2*32 + 2*32 + 5) floats.
+long ha2g_contrastive_workspace_floats(int N) { return (long)N * (4 * CD + 5); }
+int ha2g_contrastive_f32(const float* a, const float* b, int N, int expressive, float* loss, float* da, float* db, float* ws,
+                         void* stream) {
+    HA2G_REQUIRE(N > 0, "contrastive: empty input");
+    hipStream_t st = (hipStream_t)stream;
+    float* an = ws; float* bn = an + (long)N * CD; float* dan = bn + (long)N * CD; float* dbn = dan + (long)N * CD;
+    float* na = dbn + (long)N * CD; float* nbv = na + N; float* rmax = nbv + N; float* rsum = rmax + N; float* li = rsum + N;
+    hipLaunchKernelGGL(rownorm_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, a, an, na, N);
+    hipLaunchKernelGGL(rownorm_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, b, bn, nbv, N);
+    hipLaunchKernelGGL(contrastive_rows_kernel, dim3(ceil_div(N, 64)), dim3(64), 0, st, an, bn, N, expressive, rmax, rsum, li, dan);
+    hipLaunchKernelGGL(contrastive_cols_kernel, dim3(ceil_div(N, 64)), dim3(64), 0, st, an, bn, N, expressive, rmax, rsum, dbn);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, li, (long)N, loss, 1.f / (float)N, 0);
+    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, an, na, dan, da, N);
+    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, bn, nbv, dbn, db, N);
+    HA2G_CHECK_LAUNCH("contrastive");
+    return 0;
+}
+
+}  // extern "C"

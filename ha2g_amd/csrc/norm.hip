@@ -1,0 +1,295 @@
+// Train-mode BatchNorm (2-D and 1-D share one [rows][C] channels-last form) and the squeeze-excite
+// pointwise pieces of the SE-ResNet audio encoder.  HBM-bound kernels: float4 lanes over channels,
+// per-block partial column sums + a tiny fixed-order final reduction in double (deterministic).
+//
+// BatchNorm semantics = torch (reference scripts/model/ResNetBlocks.py:24-30, ResNetSE34V2.py:127-129):
+// normalise with the biased batch variance, update running_var with the unbiased one, momentum 0.1.
+#include "common.h"
+
+namespace {
+
+constexpr int NB_MAX = 1024;   // max row-chunk blocks of a partial reduction
+
+// thread layout shared by the column reductions: C4 = C/4 float4 lanes per row, 256 % C4 == 0
+struct ColMap {
+    int c4, r0, rstep;
+    __device__ ColMap(int C4) { c4 = threadIdx.x % C4; r0 = threadIdx.x / C4; rstep = 256 / C4; }
+};
+
+struct d4 { double x, y, z, w; };
+__device__ __forceinline__ d4 d4zero() { d4 r; r.x = r.y = r.z = r.w = 0.0; return r; }
+
+// combine the per-thread double partials of threads sharing c4, write [blk][which][C] (double)
+__device__ __forceinline__ void block_col_reduce(d4 a, d4 b, int C4, double* __restrict__ part, int C, d4* lds) {
+    // lds: [2][256] d4
+    lds[threadIdx.x] = a;
+    lds[256 + threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        d4 sa = d4zero(), sb = d4zero();
+        for (int t = threadIdx.x; t < 256; t += C4) {
+            d4 x = lds[t], y = lds[256 + t];
+            sa.x += x.x; sa.y += x.y; sa.z += x.z; sa.w += x.w;
+            sb.x += y.x; sb.y += y.y; sb.z += y.z; sb.w += y.w;
+        }
+        double* p0 = part + ((long)blockIdx.x * 2 + 0) * C + threadIdx.x * 4;
+        double* p1 = part + ((long)blockIdx.x * 2 + 1) * C + threadIdx.x * 4;
+        p0[0] = sa.x; p0[1] = sa.y; p0[2] = sa.z; p0[3] = sa.w;
+        p1[0] = sb.x; p1[1] = sb.y; p1[2] = sb.z; p1[3] = sb.w;
+    }
+}
+
+// mode 0: (x - K, (x-K)^2) with K = row 0 (shift against cancellation); mode 1: (dy, dy * xhat).
+// Sums are carried in double (torch's CPU batch-norm accumulates in double too; the kernel is HBM-bound, the
+// fp64 adds are free) -- nearly-dead post-ReLU channels make sum(dy*xhat) cancel by 1e3..1e4.
+template <int MODE>
+__global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          long rows, int C, double* __restrict__ part) {
+    __shared__ d4 lds[512];
+    const int C4 = C >> 2;
+    ColMap m(C4);
+    const long rows_per = (rows + gridDim.x - 1) / gridDim.x;
+    const long rbeg = (long)blockIdx.x * rows_per, rend = min(rows, rbeg + rows_per);
+    d4 a = d4zero(), b = d4zero();
+    float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), is4 = k4;
+    if (MODE == 0) k4 = reinterpret_cast<const float4*>(x)[m.c4];
+    else { k4 = reinterpret_cast<const float4*>(mean)[m.c4]; is4 = reinterpret_cast<const float4*>(invstd)[m.c4]; }
+    for (long r = rbeg + m.r0; r < rend; r += m.rstep) {
+        float4 v = reinterpret_cast<const float4*>(x + r * C)[m.c4];
+        if (MODE == 0) {
+            double vx = (double)v.x - k4.x, vy = (double)v.y - k4.y, vz = (double)v.z - k4.z, vw = (double)v.w - k4.w;
+            a.x += vx; a.y += vy; a.z += vz; a.w += vw;
+            b.x += vx * vx; b.y += vy * vy; b.z += vz * vz; b.w += vw * vw;
+        } else {
+            float4 d = reinterpret_cast<const float4*>(dy + r * C)[m.c4];
+            a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+            b.x += (double)d.x * (((double)v.x - k4.x) * is4.x); b.y += (double)d.y * (((double)v.y - k4.y) * is4.y);
+            b.z += (double)d.z * (((double)v.z - k4.z) * is4.z); b.w += (double)d.w * (((double)v.w - k4.w) * is4.w);
+        }
+    }
+    block_col_reduce(a, b, C4, part, C, lds);
+}
+
+__global__ void bn_stats_final_kernel(const double* __restrict__ part, int nblk, long rows, int C, const float* __restrict__ x,
+                                      float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rmean,
+                                      float* __restrict__ rvar, float momentum, float eps) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) { s1 += part[((long)b * 2) * C + c]; s2 += part[((long)b * 2 + 1) * C + c]; }
+    double n = (double)rows, m1 = s1 / n;
+    double var = s2 / n - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    double mu = (double)x[c] + m1;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mu;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * n / (n > 1.0 ? n - 1.0 : 1.0));
+    }
+}
+
+__global__ void pair_final_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ out0, float* __restrict__ out1) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) { s1 += part[((long)b * 2) * C + c]; s2 += part[((long)b * 2 + 1) * C + c]; }
+    out0[c] = (float)s1;
+    out1[c] = (float)s2;
+}
+
+// y = (x - mean) * invstd * gamma + beta ; act: 0 none, 2 leaky-relu(0.01)
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, long rows,
+                                int C, int act) {
+    const int C4 = C >> 2;
+    const long total = rows * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c4 = (int)(i % C4);
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        float4 mu = reinterpret_cast<const float4*>(mean)[c4], is = reinterpret_cast<const float4*>(invstd)[c4];
+        float4 g = reinterpret_cast<const float4*>(gamma)[c4], b = reinterpret_cast<const float4*>(beta)[c4];
+        float4 r;
+        r.x = (v.x - mu.x) * is.x * g.x + b.x; r.y = (v.y - mu.y) * is.y * g.y + b.y;
+        r.z = (v.z - mu.z) * is.z * g.z + b.z; r.w = (v.w - mu.w) * is.w * g.w + b.w;
+        if (act == 2) {
+            r.x = r.x > 0.f ? r.x : 0.01f * r.x; r.y = r.y > 0.f ? r.y : 0.01f * r.y;
+            r.z = r.z > 0.f ? r.z : 0.01f * r.z; r.w = r.w > 0.f ? r.w : 0.01f * r.w;
+        }
+        reinterpret_cast<float4*>(y)[i] = r;
+    }
+}
+
+// dx = gamma * invstd * (dy - sum_dy/N - xhat * sum_dy_xhat/N)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, float* __restrict__ dx,
+                                    long rows, int C) {
+    const int C4 = C >> 2;
+    const long total = rows * C4;
+    const float invn = 1.f / (float)rows;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c4 = (int)(i % C4);
+        float4 d = reinterpret_cast<const float4*>(dy)[i], v = reinterpret_cast<const float4*>(x)[i];
+        float4 mu = reinterpret_cast<const float4*>(mean)[c4], is = reinterpret_cast<const float4*>(invstd)[c4];
+        float4 g = reinterpret_cast<const float4*>(gamma)[c4];
+        float4 s1 = reinterpret_cast<const float4*>(sum_dy)[c4], s2 = reinterpret_cast<const float4*>(sum_dy_xhat)[c4];
+        float4 r;
+        const double dn = (double)invn;
+        r.x = (float)((double)g.x * is.x * ((double)d.x - s1.x * dn - ((double)v.x - mu.x) * is.x * (s2.x * dn)));
+        r.y = (float)((double)g.y * is.y * ((double)d.y - s1.y * dn - ((double)v.y - mu.y) * is.y * (s2.y * dn)));
+        r.z = (float)((double)g.z * is.z * ((double)d.z - s1.z * dn - ((double)v.z - mu.z) * is.z * (s2.z * dn)));
+        r.w = (float)((double)g.w * is.w * ((double)d.w - s1.w * dn - ((double)v.w - mu.w) * is.w * (s2.w * dn)));
+        reinterpret_cast<float4*>(dx)[i] = r;
+    }
+}
+
+// ---- squeeze-excite pieces; x is [N][HW][C] -------------------------------------------------------------
+// per-image column mean (MODE 0) or per-image sum of a*b (MODE 1: ds[n,c] = sum_hw dpre*b2 with dpre = dout*(out>0))
+template <int MODE>
+__global__ __launch_bounds__(256) void image_col_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                        const float* __restrict__ outp, int HW, int C, float* __restrict__ res,
+                                                        float scale) {
+    __shared__ d4 lds[256];
+    const int C4 = C >> 2;
+    ColMap m(C4);
+    const long base = (long)blockIdx.x * HW * C;
+    d4 a = d4zero();
+    for (int r = m.r0; r < HW; r += m.rstep) {
+        float4 v = reinterpret_cast<const float4*>(x + base + (long)r * C)[m.c4];
+        if (MODE == 1) {
+            float4 d = reinterpret_cast<const float4*>(dout + base + (long)r * C)[m.c4];
+            float4 o = reinterpret_cast<const float4*>(outp + base + (long)r * C)[m.c4];
+            a.x += o.x > 0.f ? (double)v.x * d.x : 0.0; a.y += o.y > 0.f ? (double)v.y * d.y : 0.0;
+            a.z += o.z > 0.f ? (double)v.z * d.z : 0.0; a.w += o.w > 0.f ? (double)v.w * d.w : 0.0;
+        } else {
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    lds[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        d4 s = d4zero();
+        for (int t = threadIdx.x; t < 256; t += C4) { d4 v = lds[t]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        float4 o = make_float4((float)(s.x * scale), (float)(s.y * scale), (float)(s.z * scale), (float)(s.w * scale));
+        reinterpret_cast<float4*>(res + (long)blockIdx.x * C)[threadIdx.x] = o;
+    }
+}
+
+// out = relu(x * s[n,c] + res)
+__global__ void se_scale_add_relu_kernel(const float* __restrict__ x, const float* __restrict__ s, const float* __restrict__ res,
+                                         float* __restrict__ out, long N, int HW, int C) {
+    const int C4 = C >> 2;
+    const long per = (long)HW * C4, total = N * per;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long n = i / per; int c4 = (int)(i % C4);
+        float4 v = reinterpret_cast<const float4*>(x)[i], r = reinterpret_cast<const float4*>(res)[i];
+        float4 sc = reinterpret_cast<const float4*>(s + n * C)[c4];
+        float4 o;
+        o.x = fmaxf(v.x * sc.x + r.x, 0.f); o.y = fmaxf(v.y * sc.y + r.y, 0.f);
+        o.z = fmaxf(v.z * sc.z + r.z, 0.f); o.w = fmaxf(v.w * sc.w + r.w, 0.f);
+        reinterpret_cast<float4*>(out)[i] = o;
+    }
+}
+// dpre = dout * (out > 0); dres = dpre; dx = dpre * s[n,c] + dpool[n,c]   (dpool already divided by HW)
+__global__ void se_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ outp, const float* __restrict__ s,
+                                    const float* __restrict__ dpool, float* __restrict__ dres, float* __restrict__ dx, long N,
+                                    int HW, int C) {
+    const int C4 = C >> 2;
+    const long per = (long)HW * C4, total = N * per;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long n = i / per; int c4 = (int)(i % C4);
+        float4 d = reinterpret_cast<const float4*>(dout)[i], o = reinterpret_cast<const float4*>(outp)[i];
+        float4 sc = reinterpret_cast<const float4*>(s + n * C)[c4], dp = reinterpret_cast<const float4*>(dpool + n * C)[c4];
+        float4 p;
+        p.x = o.x > 0.f ? d.x : 0.f; p.y = o.y > 0.f ? d.y : 0.f; p.z = o.z > 0.f ? d.z : 0.f; p.w = o.w > 0.f ? d.w : 0.f;
+        reinterpret_cast<float4*>(dres)[i] = p;
+        float4 q;
+        q.x = p.x * sc.x + dp.x; q.y = p.y * sc.y + dp.y; q.z = p.z * sc.z + dp.z; q.w = p.w * sc.w + dp.w;
+        reinterpret_cast<float4*>(dx)[i] = q;
+    }
+}
+
+inline int chunk_blocks(long rows) {
+    long b = rows / 512;
+    if (b < 1) b = 1;
+    if (b > NB_MAX) b = NB_MAX;
+    return (int)b;
+}
+inline int flat_grid(long n) { long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+inline bool okC(int C) { return C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+// floats of scratch needed by the column reductions below
+long ha2g_bn_workspace_floats(int C) { return (long)NB_MAX * 2 * C * 2; }   /* partials are doubles */
+
+// mean/invstd [C] out; running_mean/var updated in place when non-null.  x is [rows][C], C in {4,8,...,1024} with 256 % (C/4) == 0.
+int ha2g_bn_stats_f32(const float* x, long rows, int C, float* mean, float* invstd, float* running_mean, float* running_var,
+                      float momentum, float eps, float* ws, void* stream) {
+    HA2G_REQUIRE(okC(C), "bn: unsupported channel count %d", C);
+    HA2G_REQUIRE(rows > 0, "bn: empty batch");
+    hipStream_t st = (hipStream_t)stream;
+    int nb = chunk_blocks(rows);
+    hipLaunchKernelGGL(col_partial_kernel<0>, dim3(nb), dim3(256), 0, st, x, nullptr, nullptr, nullptr, rows, C, (double*)ws);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, (const double*)ws, nb, rows, C, x, mean, invstd, running_mean,
+                       running_var, momentum, eps);
+    HA2G_CHECK_LAUNCH("bn_stats");
+    return 0;
+}
+int ha2g_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y,
+                      long rows, int C, int act, void* stream) {
+    HA2G_REQUIRE(C % 4 == 0, "bn: C %% 4");
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta,
+                       y, rows, C, act);
+    HA2G_CHECK_LAUNCH("bn_apply");
+    return 0;
+}
+// dgamma = sum dy*xhat, dbeta = sum dy, dx as torch's batch-norm backward (train mode)
+int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx,
+                    float* dgamma, float* dbeta, long rows, int C, float* ws, void* stream) {
+    HA2G_REQUIRE(okC(C), "bn: unsupported channel count %d", C);
+    hipStream_t st = (hipStream_t)stream;
+    int nb = chunk_blocks(rows);
+    hipLaunchKernelGGL(col_partial_kernel<1>, dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
+    hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, (const double*)ws, nb, C, dbeta, dgamma);
+    if (dx)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, st, dy, x, mean, invstd, gamma, dbeta,
+                           dgamma, dx, rows, C);
+    HA2G_CHECK_LAUNCH("bn_bwd");
+    return 0;
+}
+// out[n][c] = mean over HW of x[n][hw][c]
+int ha2g_hw_mean_f32(const float* x, float* out, int N, int HW, int C, void* stream) {
+    HA2G_REQUIRE(okC(C), "hw_mean: unsupported channel count %d", C);
+    hipLaunchKernelGGL(image_col_kernel<0>, dim3(N), dim3(256), 0, (hipStream_t)stream, x, nullptr, nullptr, HW, C, out, 1.f / (float)HW);
+    HA2G_CHECK_LAUNCH("hw_mean");
+    return 0;
+}
+int ha2g_se_scale_add_relu_f32(const float* x, const float* s, const float* res, float* out, int N, int HW, int C, void* stream) {
+    HA2G_REQUIRE(C % 4 == 0, "se: C %% 4");
+    hipLaunchKernelGGL(se_scale_add_relu_kernel, dim3(flat_grid((long)N * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, s, res,
+                       out, (long)N, HW, C);
+    HA2G_CHECK_LAUNCH("se_scale_add_relu");
+    return 0;
+}
+// ds[n][c] = sum_hw dout*(out>0)*x
+int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, float* ds, int N, int HW, int C, void* stream) {
+    HA2G_REQUIRE(okC(C), "se: unsupported channel count %d", C);
+    hipLaunchKernelGGL(image_col_kernel<1>, dim3(N), dim3(256), 0, (hipStream_t)stream, x, dout, out, HW, C, ds, 1.f);
+    HA2G_CHECK_LAUNCH("se_bwd_scale");
+    return 0;
+}
+int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, const float* dpool, float* dres, float* dx, int N,
+                          int HW, int C, void* stream) {
+    HA2G_REQUIRE(C % 4 == 0, "se: C %% 4");
+    hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(flat_grid((long)N * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, dout, out, s,
+                       dpool, dres, dx, (long)N, HW, C);
+    HA2G_CHECK_LAUNCH("se_bwd_apply");
+    return 0;
+}
+
+}  // extern "C"

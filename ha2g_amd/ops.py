@@ -1,14 +1,17 @@
 """Python face of the HIP kernels: thin functional wrappers (raw pointers + current stream through the C-ABI)
 and the torch.autograd.Function classes that make `loss.backward()` at the reference's call sites run the
-hand-written backward kernels.  torch is used for device memory, streams and autograd bookkeeping only.
+hand-written backward kernels.  torch is used for device memory, streams and autograd bookkeeping only;
+there is no fallback path -- every op here ends in a libha2g_hip.so call.
 """
 import torch
 
 from ._lib import check, lib
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
+(OP_ADD, OP_MUL, OP_ADD_RELU, OP_RELU_BWD, OP_LEAKY_BWD, OP_SIGMOID_BWD, OP_ELU, OP_ELU_BWD, OP_REPARAM,
+ OP_REPARAM_BWD_LOGVAR, OP_AXPBY, OP_LEAKY, OP_RELU, OP_SCALE, OP_MUL_SCALAR) = range(15)
 
-_WS_BYTES = 96 << 20
+_WS_BYTES = 160 << 20
 _ws = {}
 
 
@@ -17,7 +20,8 @@ def _stream():
 
 
 def workspace(device):
-    """One persistent split-K / scratch workspace per device (all ops of a step run on one stream)."""
+    """One persistent scratch buffer per device (split-K partials, reduction partials).  All ops of a step are
+    enqueued on one stream, so sharing it is safe; it is allocated once, outside any graph capture."""
     key = (device.type, device.index)
     if key not in _ws:
         _ws[key] = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
@@ -28,9 +32,22 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+def _f32c(t):
+    assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous(), (t.dtype, t.device, t.stride())
+    return t
+
+
 def _chk2d(t):
     assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32 and t.is_cuda, (t.shape, t.stride(), t.dtype)
 
+
+def empty(*shape, like):
+    return torch.empty(*shape, dtype=torch.float32, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------------
+# raw wrappers
+# ------------------------------------------------------------------------------------------------
 
 def gemm(a, b, transa=False, transb=False, out=None, alpha=1.0, beta=0.0, bias=None, act=ACT_NONE):
     """out[M,N] = act(alpha * op(a) @ op(b) + beta*out + bias).  a, b, out: 2-D fp32 CUDA tensors with unit
@@ -59,6 +76,348 @@ def colsum(x, out=None, beta=0.0):
     return out
 
 
+def eltwise(op, a, b=None, c=None, out=None, alpha=1.0, beta=0.0):
+    a = _f32c(a)
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.ha2g_eltwise_f32(op, a.data_ptr(), _p(b), _p(c), out.data_ptr(), a.numel(), alpha, beta, _stream()))
+    return out
+
+
+def act_bwd(dy, y, act):
+    dy = dy.contiguous()
+    if act == ACT_NONE:
+        return dy
+    op = {ACT_RELU: OP_RELU_BWD, ACT_LEAKY: OP_LEAKY_BWD, ACT_SIGMOID: OP_SIGMOID_BWD}[act]
+    return eltwise(op, dy, y)
+
+
+# ------------------------------------------------------------------------------------------------
+# RNG (dropout) -- device-resident Philox state so a captured graph draws new masks on each replay
+# ------------------------------------------------------------------------------------------------
+
+class Rng:
+    def __init__(self):
+        self.state = None
+        self.call = 0
+
+    def seed(self, device, seed):
+        self.state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+        self.call = 0
+
+    def begin_step(self):
+        self.call = 0
+
+    def end_step(self):
+        if self.state is not None:
+            check(lib.ha2g_rng_advance(self.state.data_ptr(), _stream()))
+
+    def next_id(self):
+        self.call += 1
+        return self.call
+
+
+rng = Rng()
+
+
+class DropoutFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        x = _f32c(x.contiguous())
+        if rng.state is None or rng.state.device != x.device:
+            rng.seed(x.device, 0x5EED)
+        out, mask = torch.empty_like(x), torch.empty_like(x)
+        check(lib.ha2g_dropout_f32(x.data_ptr(), out.data_ptr(), mask.data_ptr(), x.numel(), p, rng.state.data_ptr(),
+                                   rng.next_id(), _stream()))
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return eltwise(OP_MUL, dy.contiguous(), ctx.saved_tensors[0]), None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    return DropoutFunction.apply(x, p)
+
+
+def dropout_mask(shape, p, device):
+    """Pre-scaled keep mask only (used for the GRU inter-layer dropout)."""
+    if rng.state is None or rng.state.device != device:
+        rng.seed(device, 0x5EED)
+    mask = torch.empty(shape, dtype=torch.float32, device=device)
+    check(lib.ha2g_dropout_f32(0, 0, mask.data_ptr(), mask.numel(), p, rng.state.data_ptr(), rng.next_id(), _stream()))
+    return mask
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear / embedding / pointwise
+# ------------------------------------------------------------------------------------------------
+
+class LinearFunction(torch.autograd.Function):
+    """y = act(x W^T + b); x [..., K], W [N, K] (nn.Linear layout)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        w = w.contiguous()
+        y = gemm(x2, w, transb=True, bias=b, act=act)
+        ctx.act = act
+        ctx.xshape = x.shape
+        ctx.has_b = b is not None
+        ctx.save_for_backward(x2, w, y if act != ACT_NONE else None)
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        dy2 = act_bwd(dy.reshape(-1, dy.shape[-1]), y, ctx.act)
+        if dy2.stride(1) != 1:
+            dy2 = dy2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(dy2, w).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = gemm(dy2, x2, transa=True)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = colsum(dy2)
+        return dx, dw, db, None
+
+
+def linear(x, w, b=None, act=ACT_NONE):
+    return LinearFunction.apply(x, w, b, act)
+
+
+class EmbeddingFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, w):
+        tok = tok.contiguous()
+        out = torch.empty(*tok.shape, w.shape[1], dtype=torch.float32, device=w.device)
+        check(lib.ha2g_embedding_fwd_f32(tok.data_ptr(), w.data_ptr(), out.data_ptr(), tok.numel(), w.shape[1], _stream()))
+        ctx.save_for_backward(tok)
+        ctx.wshape = w.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (tok,) = ctx.saved_tensors
+        dw = torch.zeros(ctx.wshape, dtype=torch.float32, device=dy.device)
+        dy = dy.contiguous()
+        check(lib.ha2g_embedding_bwd_f32(tok.data_ptr(), dy.data_ptr(), dw.data_ptr(), tok.numel(), ctx.wshape[1], _stream()))
+        return None, dw
+
+
+def embedding(tok, w):
+    return EmbeddingFunction.apply(tok, w)
+
+
+class EltUnary(torch.autograd.Function):
+    """ELU (alpha = 1) -- the only standalone unary activation on the path (ResNetSE34V2.py:200-201)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = eltwise(OP_ELU, x.contiguous())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return eltwise(OP_ELU_BWD, dy.contiguous(), ctx.saved_tensors[0])
+
+
+def elu(x):
+    return EltUnary.apply(x)
+
+
+class AddReluFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        y = eltwise(OP_ADD_RELU, a.contiguous(), b.contiguous())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = eltwise(OP_RELU_BWD, dy.contiguous(), ctx.saved_tensors[0])
+        return g, g
+
+
+def add_relu(a, b):
+    return AddReluFunction.apply(a, b)
+
+
+class ReparamFunction(torch.autograd.Function):
+    """z = mu + eps * exp(0.5 logvar)  (model/embedding_net.py:10-13)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        mu, logvar, eps = mu.contiguous(), logvar.contiguous(), eps.contiguous()
+        ctx.save_for_backward(logvar, eps)
+        return eltwise(OP_REPARAM, mu, logvar, eps)
+
+    @staticmethod
+    def backward(ctx, dz):
+        logvar, eps = ctx.saved_tensors
+        dz = dz.contiguous()
+        return dz, eltwise(OP_REPARAM_BWD_LOGVAR, dz, logvar, eps), None
+
+
+def reparameterize(mu, logvar, eps):
+    return ReparamFunction.apply(mu, logvar, eps)
+
+
+class DirSumFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y):
+        y = _f32c(y.contiguous())
+        H = y.shape[-1] // 2
+        rows = y.numel() // (2 * H)
+        out = torch.empty(*y.shape[:-1], H, dtype=torch.float32, device=y.device)
+        check(lib.ha2g_dirsum_f32(y.data_ptr(), out.data_ptr(), rows, H, 0, _stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = _f32c(d.contiguous())
+        H = d.shape[-1]
+        out = torch.empty(*d.shape[:-1], 2 * H, dtype=torch.float32, device=d.device)
+        check(lib.ha2g_dirsum_f32(d.data_ptr(), out.data_ptr(), d.numel() // H, H, 1, _stream()))
+        return out
+
+
+def dirsum(y):
+    return DirSumFunction.apply(y)
+
+
+# ------------------------------------------------------------------------------------------------
+# 1-D convolutions (TCN causal dilated k=2; discriminator valid k=3) as im2col + GEMM, weight norm
+# ------------------------------------------------------------------------------------------------
+
+class WeightNormFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, v):
+        g, v = g.contiguous(), v.contiguous()
+        cout, n = v.shape[0], v[0].numel()
+        w, norm = torch.empty_like(v), torch.empty(cout, dtype=torch.float32, device=v.device)
+        check(lib.ha2g_weight_norm_fwd_f32(g.data_ptr(), v.data_ptr(), w.data_ptr(), norm.data_ptr(), cout, n, _stream()))
+        ctx.save_for_backward(g, v, norm)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        g, v, norm = ctx.saved_tensors
+        dw = dw.contiguous()
+        dg, dv = torch.empty_like(g), torch.empty_like(v)
+        check(lib.ha2g_weight_norm_bwd_f32(dw.data_ptr(), g.data_ptr(), v.data_ptr(), norm.data_ptr(), dg.data_ptr(), dv.data_ptr(),
+                                           v.shape[0], v[0].numel(), _stream()))
+        return dg, dv
+
+
+def weight_norm(g, v):
+    return WeightNormFunction.apply(g, v)
+
+
+class Conv1dFunction(torch.autograd.Function):
+    """x [B,T,Cin] (time-major rows), w [Cout,Cin,k] (nn.Conv1d layout), out [B,To,Cout].
+    out[b,t] = sum_kk W[:,:,kk] x[b, t - pad_left + kk*dil]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, dil, pad_left, To, act):
+        x = _f32c(x.contiguous())
+        w = w.contiguous()
+        B, T, C = x.shape
+        cout, _, k = w.shape
+        col = torch.empty(B * To, C * k, dtype=torch.float32, device=x.device)
+        check(lib.ha2g_im2col1d_f32(x.data_ptr(), col.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
+        y = gemm(col, w.view(cout, C * k), transb=True, bias=b, act=act)
+        ctx.geom = (B, T, C, k, dil, pad_left, To, act)
+        ctx.has_b = b is not None
+        ctx.save_for_backward(col, w, y if act != ACT_NONE else None)
+        return y.view(B, To, cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        col, w, y = ctx.saved_tensors
+        B, T, C, k, dil, pad_left, To, act = ctx.geom
+        cout = w.shape[0]
+        dy2 = act_bwd(dy.reshape(B * To, cout), y, act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dcol = gemm(dy2, w.view(cout, C * k))
+            dx = torch.empty(B, T, C, dtype=torch.float32, device=dy.device)
+            check(lib.ha2g_col2im1d_f32(dcol.data_ptr(), dx.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
+        if ctx.needs_input_grad[1]:
+            dw = gemm(dy2, col, transa=True).view(cout, C, k)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = colsum(dy2)
+        return dx, dw, db, None, None, None, None
+
+
+def conv1d_tm(x, w, b, dil=1, pad_left=0, To=None, act=ACT_NONE):
+    if To is None:
+        To = x.shape[1] + pad_left - (w.shape[2] - 1) * dil
+    return Conv1dFunction.apply(x, w, b, dil, pad_left, To, act)
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm over [rows, C]
+# ------------------------------------------------------------------------------------------------
+
+def bn_stats(x2, running_mean, running_var, momentum, eps):
+    rows, C = x2.shape
+    mean, invstd = empty(C, like=x2), empty(C, like=x2)
+    check(lib.ha2g_bn_stats_f32(x2.data_ptr(), rows, C, mean.data_ptr(), invstd.data_ptr(), _p(running_mean), _p(running_var),
+                                momentum, eps, workspace(x2.device).data_ptr(), _stream()))
+    return mean, invstd
+
+
+def bn_apply(x2, mean, invstd, gamma, beta, act=ACT_NONE, out=None):
+    rows, C = x2.shape
+    if out is None:
+        out = torch.empty_like(x2)
+    check(lib.ha2g_bn_apply_f32(x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                rows, C, act, _stream()))
+    return out
+
+
+def bn_bwd(dy2, x2, mean, invstd, gamma, need_dx=True):
+    rows, C = x2.shape
+    dx = torch.empty_like(x2) if need_dx else None
+    dgamma, dbeta = empty(C, like=x2), empty(C, like=x2)
+    check(lib.ha2g_bn_bwd_f32(dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dx),
+                              dgamma.data_ptr(), dbeta.data_ptr(), rows, C, workspace(x2.device).data_ptr(), _stream()))
+    return dx, dgamma, dbeta
+
+
+class BatchNormFunction(torch.autograd.Function):
+    """Train-mode BatchNorm over the last dim of a contiguous [..., C] tensor, optional fused LeakyReLU."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, act):
+        x = _f32c(x.contiguous())
+        x2 = x.view(-1, x.shape[-1])
+        mean, invstd = bn_stats(x2, running_mean, running_var, momentum, eps)
+        y = bn_apply(x2, mean, invstd, gamma, beta, act)
+        ctx.act = act
+        ctx.save_for_backward(x2, mean, invstd, gamma, y if act != ACT_NONE else None)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, invstd, gamma, y = ctx.saved_tensors
+        dy2 = act_bwd(dy.reshape(x2.shape), y, ctx.act)
+        dx, dg, db = bn_bwd(dy2, x2, mean, invstd, gamma)
+        return dx.view(dy.shape), dg, db, None, None, None, None, None
+
+
+def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, act=ACT_NONE):
+    return BatchNormFunction.apply(x, gamma, beta, running_mean, running_var, momentum, eps, act)
+
+
 # ------------------------------------------------------------------------------------------------
 # bidirectional multi-layer GRU
 # ------------------------------------------------------------------------------------------------
@@ -84,7 +443,7 @@ class BiGRUFunction(torch.autograd.Function):
         inp = x.contiguous()
         packs = []
         for l in range(L):
-            w = weights[8 * l:8 * l + 8]
+            w = [t.contiguous() for t in weights[8 * l:8 * l + 8]]
             K = inp.shape[2]
             gi = torch.empty(B * T, 6 * H, dtype=torch.float32, device=dev)
             x2 = inp.view(B * T, K)
@@ -101,7 +460,7 @@ class BiGRUFunction(torch.autograd.Function):
             packs.append(pk)
             inp = y
             if masks is not None and l < L - 1 and masks[l] is not None:
-                inp = y * masks[l]
+                inp = eltwise(OP_MUL, y, masks[l])
         ctx.H, ctx.L, ctx.masks = H, L, masks
         ctx.saved_bufs = saved
         ctx.packs = packs
@@ -121,7 +480,7 @@ class BiGRUFunction(torch.autograd.Function):
             inp, y, rs = ctx.saved_bufs[l]
             w = weights[8 * l:8 * l + 8]
             if masks is not None and l < L - 1 and masks[l] is not None:
-                dy = dy * masks[l]
+                dy = eltwise(OP_MUL, dy, masks[l])
             dg = torch.empty(B * T, 8 * H, dtype=torch.float32, device=dev)        # [dir][r z n hn]
             check(lib.ha2g_gru_layer_bwd(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), ctx.packs[l][2].data_ptr(), dg.data_ptr(),
                                          B, T, H, st))
@@ -132,12 +491,14 @@ class BiGRUFunction(torch.autograd.Function):
             hp[:, 1:, :H] = y[:, :-1, :H]
             hp[:, :-1, H:] = y[:, 1:, H:]
             hp2 = hp.view(B * T, 2 * H)
-            dx = torch.empty(B * T, K, dtype=torch.float32, device=dev)
+            need_dx = l > 0 or ctx.needs_input_grad[0]
+            dx = torch.empty(B * T, K, dtype=torch.float32, device=dev) if need_dx else None
             for d in range(2):
                 o = 4 * H * d
                 dgi = dg[:, o:o + 3 * H]
                 w_ih = w[4 * d]
-                gemm(dgi, w_ih, out=dx, beta=float(d))                              # dX (+)= dgi W_ih
+                if need_dx:
+                    gemm(dgi, w_ih, out=dx, beta=float(d))                          # dX (+)= dgi W_ih
                 grads[8 * l + 4 * d + 0] = gemm(dgi, x2, transa=True)               # dW_ih = dgi^T X
                 dwhh = torch.empty(3 * H, H, dtype=torch.float32, device=dev)
                 hpd = hp2[:, d * H:(d + 1) * H]
@@ -149,10 +510,155 @@ class BiGRUFunction(torch.autograd.Function):
                 colsum(dg[:, o:o + 2 * H], out=dbhh[:2 * H])
                 colsum(dg[:, o + 3 * H:o + 4 * H], out=dbhh[2 * H:])
                 grads[8 * l + 4 * d + 3] = dbhh
-            dy = dx.view(B, T, K)
+            dy = dx.view(B, T, K) if need_dx else None
         ctx.saved_bufs = None
         return (dy, None, None) + tuple(grads)
 
 
 def bigru(x, weights, H, masks=None):
     return BiGRUFunction.apply(x, masks, H, *weights)
+
+
+# ------------------------------------------------------------------------------------------------
+# loss terms: value + unit gradient computed in forward; backward = scale by the upstream scalar
+# ------------------------------------------------------------------------------------------------
+
+def _scale_by(g_unit, gout, sign=1.0):
+    return eltwise(OP_MUL_SCALAR, g_unit, gout.contiguous(), alpha=sign)
+
+
+class HuberFunction(torch.autograd.Function):
+    """mean Huber_beta(x - y) == smooth_l1_loss(x/beta, y/beta) * beta  (train_hierarchy.py:173-176)."""
+
+    @staticmethod
+    def forward(ctx, x, y, beta):
+        x, y = _f32c(x.contiguous()), _f32c(y.contiguous())
+        loss, dx = empty((), like=x), torch.empty_like(x)
+        check(lib.ha2g_huber_f32(x.data_ptr(), y.data_ptr(), x.numel(), beta, loss.data_ptr(), dx.data_ptr(),
+                                 workspace(x.device).data_ptr(), _stream()))
+        ctx.save_for_backward(dx)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return _scale_by(ctx.saved_tensors[0], g), None, None
+
+
+def huber(x, y, beta):
+    return HuberFunction.apply(x, y, beta)
+
+
+class KLDFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        mu, logvar = _f32c(mu.contiguous()), _f32c(logvar.contiguous())
+        loss, dmu, dlv = empty((), like=mu), torch.empty_like(mu), torch.empty_like(mu)
+        check(lib.ha2g_kld_f32(mu.data_ptr(), logvar.data_ptr(), mu.numel(), loss.data_ptr(), dmu.data_ptr(), dlv.data_ptr(), _stream()))
+        ctx.save_for_backward(dmu, dlv)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dmu, dlv = ctx.saved_tensors
+        return _scale_by(dmu, g), _scale_by(dlv, g)
+
+
+def kld(mu, logvar):
+    return KLDFunction.apply(mu, logvar)
+
+
+class DivRegFunction(torch.autograd.Function):
+    """train_hierarchy.py:213-222; gradient flows into `out` only (everything else is detached there)."""
+
+    @staticmethod
+    def forward(ctx, out, rnd, z, zr, beta):
+        out, rnd, z, zr = (_f32c(t.contiguous()) for t in (out, rnd, z, zr))
+        B = out.shape[0]
+        loss, dout = empty((), like=out), torch.empty_like(out)
+        check(lib.ha2g_divreg_f32(out.data_ptr(), rnd.data_ptr(), z.data_ptr(), zr.data_ptr(), B, out[0].numel(), z.shape[1], beta,
+                                  loss.data_ptr(), dout.data_ptr(), workspace(out.device).data_ptr(), _stream()))
+        ctx.save_for_backward(dout)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return _scale_by(ctx.saved_tensors[0], g), None, None, None, None
+
+
+def div_reg(out, rnd, z, zr, beta=0.05):
+    return DivRegFunction.apply(out, rnd, z, zr, beta)
+
+
+class PhysAngleFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, mean_dir, pairs, avg, var):
+        out = _f32c(out.contiguous())
+        P = out.shape[-1]
+        rows = out.numel() // P
+        loss, dout = empty((), like=out), torch.empty_like(out)
+        check(lib.ha2g_phys_angle_f32(out.data_ptr(), mean_dir.data_ptr(), rows, P // 3, pairs.data_ptr(), pairs.shape[0],
+                                      avg.data_ptr(), var.data_ptr(), loss.data_ptr(), dout.data_ptr(),
+                                      workspace(out.device).data_ptr(), _stream()))
+        ctx.save_for_backward(dout)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return _scale_by(ctx.saved_tensors[0], g), None, None, None, None
+
+
+def phys_angle(out, mean_dir, pairs, avg, var):
+    return PhysAngleFunction.apply(out, mean_dir, pairs, avg, var)
+
+
+class GanLossFunction(torch.autograd.Function):
+    """mode 0: -mean(log(a + 1e-8)); mode 1: -mean(log(a + 1e-8) + log(1 - b + 1e-8))  (train_hierarchy.py:128,180)."""
+
+    @staticmethod
+    def forward(ctx, mode, a, b):
+        a = _f32c(a.contiguous())
+        b = _f32c(b.contiguous()) if b is not None else None
+        loss, da = empty((), like=a), torch.empty_like(a)
+        db = torch.empty_like(a) if b is not None else None
+        check(lib.ha2g_gan_loss_f32(mode, a.data_ptr(), _p(b), a.numel(), loss.data_ptr(), da.data_ptr(), _p(db), _stream()))
+        ctx.save_for_backward(da, db)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        da, db = ctx.saved_tensors
+        return None, _scale_by(da, g), (_scale_by(db, g) if db is not None else None)
+
+
+def gen_loss(d_out):
+    return GanLossFunction.apply(0, d_out, None)
+
+
+def dis_loss(real, fake):
+    return GanLossFunction.apply(1, real, fake)
+
+
+class ContrastiveFunction(torch.autograd.Function):
+    """SoftmaxContrastiveLoss (train_hierarchy.py:54-68 / train_hierarchy_expressive.py:107-121); a, b [N,32]."""
+
+    @staticmethod
+    def forward(ctx, a, b, expressive):
+        a, b = _f32c(a.contiguous()), _f32c(b.contiguous())
+        N = a.shape[0]
+        assert a.shape == b.shape and a.shape[1] == 32
+        ws = workspace(a.device)
+        assert lib.ha2g_contrastive_workspace_floats(N) <= ws.numel()
+        loss, da, db = empty((), like=a), torch.empty_like(a), torch.empty_like(b)
+        check(lib.ha2g_contrastive_f32(a.data_ptr(), b.data_ptr(), N, int(expressive), loss.data_ptr(), da.data_ptr(), db.data_ptr(),
+                                       ws.data_ptr(), _stream()))
+        ctx.save_for_backward(da, db)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        da, db = ctx.saved_tensors
+        return _scale_by(da, g), _scale_by(db, g), None
+
+
+def contrastive(a, b, expressive=False):
+    return ContrastiveFunction.apply(a, b, expressive)

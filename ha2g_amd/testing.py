@@ -131,3 +131,48 @@ class Checker:
                     smp = a[::max(1, a.size // 64)][:64]
                     err = np.abs(smp - g[k[:-5] + '/sample']).max()
                     assert err <= 0.02 * lr * (si + 1) + 4 * float(g[k[:-5] + '/sample@noise']), (si, pk, err)
+
+
+# ---- module construction helpers shared by GPU tests, smoke() and bench.py -------------------------------
+
+class SpeakerVocab:
+    """Stand-in for the reference's vocab.Vocab used as z_obj: only .n_words is read on the hot path."""
+
+    def __init__(self, n_words):
+        self.n_words = n_words
+
+
+def no_dropout(m):
+    from .hierarchy_net import BiGRU, TemporalBlock
+    for sub in m.modules():
+        if isinstance(sub, torch.nn.Dropout):
+            sub.p = 0.0
+        if isinstance(sub, BiGRU):
+            sub.dropout = 0.0
+        if isinstance(sub, TemporalBlock):
+            sub.p = 0.0
+    return m
+
+
+def load_role(module, state, role):
+    """Load the `role.`-prefixed entries of a step state dict into one module."""
+    sub = {k[len(role) + 1:]: v for k, v in state.items() if k.startswith(role + '.')}
+    module.load_state_dict(sub)
+    return module
+
+
+def build_modules(case, device, dims=schema.GESTURE_POSE_DIMS, state=None):
+    """(args, [g1..], dis, audio, text) with procedural parameters of `case`, dropout disabled."""
+    from .config import make_args
+    from . import hierarchy_net as hn
+    args = make_args(case)
+    spk = SpeakerVocab(case['n_spk'])
+    state = state if state is not None else state_for(case, torch.float32, dims)
+    gens = []
+    for i, pd in enumerate(dims):
+        g = hn.Hierarchical_PoseGenerator(args, pd, case['n_words'], 300, None, z_obj=spk)
+        gens.append(no_dropout(load_role(g, state, 'g%d' % (i + 1))).to(device))
+    dis = no_dropout(load_role(hn.Hierarchical_ConvDiscriminator(dims[-1]), state, 'dis')).to(device)
+    aud = no_dropout(load_role(hn.Hierarchical_WavEncoder(args, spk, len(dims), 32), state, 'audio')).to(device)
+    txt = no_dropout(load_role(hn.TextEncoderTCN(args, case['n_words'], 300, None, dropout=args.dropout_prob), state, 'text')).to(device)
+    return args, gens, dis, aud, txt

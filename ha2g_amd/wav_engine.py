@@ -1,0 +1,331 @@
+"""SE-ResNet34 audio encoder (Hierarchical_WavEncoder) forward/backward orchestration over the HIP kernels.
+
+Reference: scripts/model/ResNetSE34V2.py:118-218 (forward), scripts/model/ResNetBlocks.py:21-37,81-95
+(SEBasicBlock / SELayer).  Activations are NHWC in HBM (channels contiguous = the K axis of the implicit
+GEMM); conv weights are kept physically [Cout][KH][KW][Cin] (torch channels_last parameters with the
+reference's logical OIHW shape).  The whole module is ONE autograd node: backward is written out by hand
+below instead of being traced.
+"""
+import torch
+
+from . import ops
+from ._lib import check, lib
+from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, _p, _stream, empty, workspace
+
+LAYERS = (3, 4, 6, 3)
+FILTERS = (32, 64, 128, 256)
+TAPS = (('low', 64, 2, 1), ('mid', 32, 3, 2), ('high', 16, 3, 4))      # name, channels, kernel, pixel-shuffle factor
+
+
+def param_names(pose_level):
+    """Flat, ordered list of parameter/buffer keys (relative to feat_extractor.) the engine consumes."""
+    names = ['conv1.weight', 'conv1.bias', 'bn1']
+    for li, nblk in enumerate(LAYERS):
+        for j in range(nblk):
+            b = 'layer%d.%d.' % (li + 1, j)
+            names += [b + 'conv1.weight', b + 'bn1', b + 'conv2.weight', b + 'bn2', b + 'se.fc.0.weight', b + 'se.fc.0.bias',
+                      b + 'se.fc.2.weight', b + 'se.fc.2.bias']
+            if j == 0 and li > 0:
+                names += [b + 'downsample.0.weight', b + 'downsample.1']
+    for t, _, _, _ in TAPS:
+        names += ['conv_%s.weight' % t, 'conv_%s.bias' % t, 'bn_%s' % t, 'fc_%s.weight' % t, 'fc_%s.bias' % t]
+    names += ['speaker_embedding.0.weight', 'speaker_embedding.1.weight', 'speaker_embedding.1.bias', 'fc1.weight', 'fc1.bias',
+              'fc2.weight', 'fc2.bias']
+    return names
+
+
+# ---- raw conv wrappers (NHWC tensors [N,H,W,C]; weights physical OHWI) --------------------------------------
+
+def _ohwi(w):
+    """Physical [Cout,KH,KW,Cin] view of a logical OIHW conv weight (no copy when it is channels_last)."""
+    wp = w.permute(0, 2, 3, 1)
+    return wp if wp.is_contiguous() else wp.contiguous()
+
+
+def conv_fwd(x, w_ohwi, bias, stride, pad, act):
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w_ohwi.shape
+    OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    y = empty(N, OH, OW, Cout, like=x)
+    check(lib.ha2g_conv2d_fwd_f32(x.data_ptr(), w_ohwi.data_ptr(), _p(bias), y.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                  act, _stream()))
+    return y
+
+
+def conv_dgrad(dy, w_ohwi, xshape, stride, pad, out=None, beta=0.0):
+    N, H, W, Cin = xshape
+    Cout, KH, KW, _ = w_ohwi.shape
+    wt = empty(Cin, KH, KW, Cout, like=dy)
+    check(lib.ha2g_conv2d_weight_ohwi_to_ihwo_f32(w_ohwi.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, _stream()))
+    if out is None:
+        out = empty(N, H, W, Cin, like=dy)
+    check(lib.ha2g_conv2d_dgrad_f32(dy.data_ptr(), wt.data_ptr(), out.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad, beta,
+                                    _stream()))
+    return out
+
+
+def conv_wgrad(x, dy, w_ohwi, stride, pad):
+    """-> gradient as a logical OIHW tensor with channels_last (OHWI) memory, matching the parameter."""
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w_ohwi.shape
+    dw = empty(Cout, KH, KW, Cin, like=x)
+    ws = workspace(x.device)
+    need = lib.ha2g_conv2d_wgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
+    assert need <= ws.numel() * 4, 'wgrad workspace %d > %d' % (need, ws.numel() * 4)
+    check(lib.ha2g_conv2d_wgrad_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad, 0.0,
+                                    ws.data_ptr(), ws.numel() * 4, _stream()))
+    return dw.permute(0, 3, 1, 2)
+
+
+def _rows(t):
+    return t.view(-1, t.shape[-1])
+
+
+class _BN:
+    """Parameters of one BatchNorm2d: (gamma, beta, running_mean, running_var, num_batches_tracked)."""
+    __slots__ = ('gamma', 'beta', 'rm', 'rv', 'nbt')
+
+    def __init__(self, gamma, beta, rm, rv, nbt):
+        self.gamma, self.beta, self.rm, self.rv, self.nbt = gamma, beta, rm, rv, nbt
+
+
+def _bn_fwd(x, bn, training_stats=True):
+    x2 = _rows(x)
+    mean, invstd = ops.bn_stats(x2, bn.rm, bn.rv, 0.1, 1e-5)
+    if bn.nbt is not None:
+        bn.nbt.add_(1)
+    y = ops.bn_apply(x2, mean, invstd, bn.gamma, bn.beta).view(x.shape)
+    return y, mean, invstd
+
+
+def _pixel_shuffle(x, r, inverse=False, shape=None):
+    if not inverse:
+        N, H, W, C = x.shape
+        out = empty(N, H * r, W * r, C // (r * r), like=x)
+        check(lib.ha2g_pixel_shuffle_f32(x.data_ptr(), out.data_ptr(), N, H, W, C // (r * r), r, 0, _stream()))
+        return out
+    N, H, W, C = shape                                   # unshuffled shape
+    out = empty(N, H, W, C, like=x)
+    check(lib.ha2g_pixel_shuffle_f32(x.data_ptr(), out.data_ptr(), N, H, W, C // (r * r), r, 1, _stream()))
+    return out
+
+
+def _tap_pack(x, inverse=False, shape=None):
+    if not inverse:
+        N, H, W, C = x.shape
+        out = empty(N * W, C * H, like=x)
+        check(lib.ha2g_nhwc_to_nwch_f32(x.data_ptr(), out.data_ptr(), N, H, W, C, 0, _stream()))
+        return out
+    N, H, W, C = shape
+    out = empty(N, H, W, C, like=x)
+    check(lib.ha2g_nhwc_to_nwch_f32(x.data_ptr(), out.data_ptr(), N, H, W, C, 1, _stream()))
+    return out
+
+
+class WavEncoderFunction(torch.autograd.Function):
+    """apply(spec [B,128,W], vid [B], pose_level, names, bufs, *tensors) -> (weight, low, mid, high, blend_0..L-1).
+    `tensors` follow param_names(): a BatchNorm entry contributes 2 tensors (gamma, beta); its buffers
+    (running_mean, running_var, num_batches_tracked) come from the non-differentiable dict `bufs`."""
+
+    @staticmethod
+    def forward(ctx, spec, vid, L, names, bufs, *tensors):
+        P = {}
+        it = iter(range(len(tensors)))
+        flat_index = {}
+        for n in names:
+            if n.split('.')[-1].startswith('bn') or n.endswith('downsample.1'):
+                idx = [next(it) for _ in range(2)]
+                P[n] = _BN(tensors[idx[0]], tensors[idx[1]], *bufs[n])
+                flat_index[n] = idx
+            else:
+                i = next(it)
+                P[n] = tensors[i]
+                flat_index[n] = i
+        spec = spec.contiguous().float()
+        B, H0, W0 = spec.shape
+        S = {}                                            # saved activations for backward
+        # ---- stem: conv(1->32) + ReLU, then BN ----
+        w1 = P['conv1.weight'].contiguous()
+        c0 = empty(B, H0, W0, 32, like=spec)
+        check(lib.ha2g_stem_conv_fwd_f32(spec.data_ptr(), w1.data_ptr(), P['conv1.bias'].data_ptr(), c0.data_ptr(), B, H0, W0, _stream()))
+        x, m, s = _bn_fwd(c0, P['bn1'])
+        S['stem'] = (spec, c0, m, s)
+        feats = []
+        cin = 32
+        for li, nblk in enumerate(LAYERS):
+            for j in range(nblk):
+                b = 'layer%d.%d.' % (li + 1, j)
+                first = j == 0 and li > 0
+                stride = 2 if first else 1
+                wa, wb = _ohwi(P[b + 'conv1.weight']), _ohwi(P[b + 'conv2.weight'])
+                c1 = conv_fwd(x, wa, None, stride, 1, ACT_RELU)                     # relu(conv1)
+                a1, m1, s1 = _bn_fwd(c1, P[b + 'bn1'])
+                c2 = conv_fwd(a1, wb, None, 1, 1, ACT_NONE)
+                b2, m2, s2 = _bn_fwd(c2, P[b + 'bn2'])
+                N, OH, OW, C = b2.shape
+                pooled = empty(N, C, like=x)
+                check(lib.ha2g_hw_mean_f32(b2.data_ptr(), pooled.data_ptr(), N, OH * OW, C, _stream()))
+                h1 = ops.gemm(pooled, P[b + 'se.fc.0.weight'], transb=True, bias=P[b + 'se.fc.0.bias'], act=ACT_RELU)
+                sc = ops.gemm(h1, P[b + 'se.fc.2.weight'], transb=True, bias=P[b + 'se.fc.2.bias'], act=ACT_SIGMOID)
+                if first:
+                    wd = _ohwi(P[b + 'downsample.0.weight'])
+                    cd = conv_fwd(x, wd, None, 2, 0, ACT_NONE)
+                    res, md, sd = _bn_fwd(cd, P[b + 'downsample.1'])
+                else:
+                    res, cd, md, sd = x, None, None, None
+                out = torch.empty_like(b2)
+                check(lib.ha2g_se_scale_add_relu_f32(b2.data_ptr(), sc.data_ptr(), res.data_ptr(), out.data_ptr(), N, OH * OW, C, _stream()))
+                S[b] = (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, cd, md, sd, out, stride)
+                x = out
+            feats.append(x)
+            cin = FILTERS[li]
+        # ---- taps ----
+        tap_out = []
+        for (t, C, k, r), f in zip(TAPS, feats[1:]):
+            fin = _pixel_shuffle(f, r) if r > 1 else f
+            wt = _ohwi(P['conv_%s.weight' % t])
+            ct = conv_fwd(fin, wt, P['conv_%s.bias' % t], 1, 0, ACT_RELU)
+            at, mt, st = _bn_fwd(ct, P['bn_%s' % t])
+            packed = _tap_pack(at)                                                  # [B*Wt, C*Ht]
+            y = ops.gemm(packed, P['fc_%s.weight' % t], transb=True, bias=P['fc_%s.bias' % t])
+            Wt = at.shape[2]
+            S['tap_' + t] = (f.shape, fin, ct, mt, st, at.shape, packed)
+            tap_out.append(y.view(B, Wt, 32))
+        low, mid, high = tap_out
+        # ---- speaker-conditioned softmax blending ----
+        vid = vid.contiguous()
+        ze = empty(B, 16, like=spec)
+        check(lib.ha2g_embedding_fwd_f32(vid.data_ptr(), P['speaker_embedding.0.weight'].data_ptr(), ze.data_ptr(), B, 16, _stream()))
+        z = ops.gemm(ze, P['speaker_embedding.1.weight'], transb=True, bias=P['speaker_embedding.1.bias'])
+        e0 = ops.eltwise(ops.OP_ELU, z)
+        f1 = ops.gemm(e0, P['fc1.weight'], transb=True, bias=P['fc1.bias'])
+        e1 = ops.eltwise(ops.OP_ELU, f1)
+        logits = ops.gemm(e1, P['fc2.weight'], transb=True, bias=P['fc2.bias'])    # [B, 3*L] == (B,3,L)
+        T = low.shape[1]
+        wsm = empty(B, 3, L, like=spec)
+        blend = empty(L, B, T, 32, like=spec)
+        check(lib.ha2g_blend_fwd_f32(logits.data_ptr(), low.data_ptr(), mid.data_ptr(), high.data_ptr(), wsm.data_ptr(), blend.data_ptr(),
+                                     B, L, T * 32, _stream()))
+        S['spk'] = (vid, ze, e0, e1, wsm)
+        S['feats'] = (low, mid, high)
+        ctx.S, ctx.P, ctx.L, ctx.names, ctx.flat_index, ctx.n_tensors = S, P, L, names, flat_index, len(tensors)
+        return (wsm, low, mid, high) + tuple(blend[i] for i in range(L))
+
+    @staticmethod
+    def backward(ctx, dw_ext, dlow, dmid, dhigh, *dblend):
+        S, P, L = ctx.S, ctx.P, ctx.L
+        G = {}                                            # name -> grad (BN: (dgamma, dbeta))
+        low, mid, high = S['feats']
+        B, T, _ = low.shape
+        dev = low.device
+
+        def z_or(t, like):
+            return t.contiguous().clone() if t is not None else torch.zeros_like(like)
+
+        df = [z_or(dlow, low), z_or(dmid, mid), z_or(dhigh, high)]
+        vid, ze, e0, e1, wsm = S['spk']
+        if any(d is not None for d in dblend) or dw_ext is not None:
+            db = torch.stack([d if d is not None else torch.zeros_like(low) for d in dblend]).contiguous()
+            dlogits = empty(B, 3 * L, like=low)
+            dwe = dw_ext.contiguous() if dw_ext is not None else None
+            check(lib.ha2g_blend_bwd_f32(db.data_ptr(), _p(dwe), wsm.data_ptr(), low.data_ptr(), mid.data_ptr(), high.data_ptr(),
+                                         df[0].data_ptr(), df[1].data_ptr(), df[2].data_ptr(), dlogits.data_ptr(), B, L, T * 32, _stream()))
+            # speaker MLP backward
+            G['fc2.weight'] = ops.gemm(dlogits, e1, transa=True)
+            G['fc2.bias'] = ops.colsum(dlogits)
+            de1 = ops.gemm(dlogits, P['fc2.weight'])
+            df1 = ops.eltwise(ops.OP_ELU_BWD, de1, e1)
+            G['fc1.weight'] = ops.gemm(df1, e0, transa=True)
+            G['fc1.bias'] = ops.colsum(df1)
+            de0 = ops.gemm(df1, P['fc1.weight'])
+            dz = ops.eltwise(ops.OP_ELU_BWD, de0, e0)
+            G['speaker_embedding.1.weight'] = ops.gemm(dz, ze, transa=True)
+            G['speaker_embedding.1.bias'] = ops.colsum(dz)
+            dze = ops.gemm(dz, P['speaker_embedding.1.weight'])
+            demb = torch.zeros_like(P['speaker_embedding.0.weight'])
+            check(lib.ha2g_embedding_bwd_f32(vid.data_ptr(), dze.data_ptr(), demb.data_ptr(), B, 16, _stream()))
+            G['speaker_embedding.0.weight'] = demb
+        # ---- taps backward -> gradient w.r.t. the three trunk features ----
+        dfeat = [None, None, None, None]
+        for ti, (t, C, k, r) in enumerate(TAPS):
+            fshape, fin, ct, mt, st, ashape, packed = S['tap_' + t]
+            dy = df[ti].view(B * ashape[2], 32)
+            G['fc_%s.weight' % t] = ops.gemm(dy, packed, transa=True)
+            G['fc_%s.bias' % t] = ops.colsum(dy)
+            dpacked = ops.gemm(dy, P['fc_%s.weight' % t])
+            dat = _tap_pack(dpacked, inverse=True, shape=ashape)
+            bn = P['bn_%s' % t]
+            dct, dg, dbt = ops.bn_bwd(_rows(dat), _rows(ct), mt, st, bn.gamma)
+            G['bn_%s' % t] = (dg, dbt)
+            dct = ops.eltwise(ops.OP_RELU_BWD, dct, _rows(ct)).view(ct.shape)
+            wt = _ohwi(P['conv_%s.weight' % t])
+            G['conv_%s.weight' % t] = conv_wgrad(fin, dct, wt, 1, 0)
+            G['conv_%s.bias' % t] = ops.colsum(_rows(dct))
+            dfin = conv_dgrad(dct, wt, fin.shape, 1, 0)
+            dfeat[ti + 1] = _pixel_shuffle(dfin, r, inverse=True, shape=fshape) if r > 1 else dfin
+        # ---- trunk backward ----
+        dx = None
+        for li in range(len(LAYERS) - 1, -1, -1):
+            if dfeat[li] is not None:
+                dx = dfeat[li] if dx is None else ops.eltwise(ops.OP_ADD, dx, dfeat[li])
+            for j in range(LAYERS[li] - 1, -1, -1):
+                b = 'layer%d.%d.' % (li + 1, j)
+                (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, cd, md, sd, out, stride) = S[b]
+                N, OH, OW, C = b2.shape
+                HW = OH * OW
+                dout = dx.contiguous()
+                ds = empty(N, C, like=b2)
+                check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, _stream()))
+                dsc = ops.eltwise(ops.OP_SIGMOID_BWD, ds, sc)
+                G[b + 'se.fc.2.weight'] = ops.gemm(dsc, h1, transa=True)
+                G[b + 'se.fc.2.bias'] = ops.colsum(dsc)
+                dh1 = ops.eltwise(ops.OP_RELU_BWD, ops.gemm(dsc, P[b + 'se.fc.2.weight']), h1)
+                G[b + 'se.fc.0.weight'] = ops.gemm(dh1, pooled, transa=True)
+                G[b + 'se.fc.0.bias'] = ops.colsum(dh1)
+                dpool = ops.gemm(dh1, P[b + 'se.fc.0.weight'], alpha=1.0 / HW)
+                dres, db2 = torch.empty_like(b2), torch.empty_like(b2)
+                check(lib.ha2g_se_bwd_apply_f32(dout.data_ptr(), out.data_ptr(), sc.data_ptr(), dpool.data_ptr(), dres.data_ptr(),
+                                                db2.data_ptr(), N, HW, C, _stream()))
+                dc2, dg2, dbb2 = ops.bn_bwd(_rows(db2), _rows(c2), m2, s2, P[b + 'bn2'].gamma)
+                G[b + 'bn2'] = (dg2, dbb2)
+                dc2 = dc2.view(c2.shape)
+                wb = _ohwi(P[b + 'conv2.weight'])
+                G[b + 'conv2.weight'] = conv_wgrad(a1, dc2, wb, 1, 1)
+                da1 = conv_dgrad(dc2, wb, a1.shape, 1, 1)
+                dc1, dg1, dbb1 = ops.bn_bwd(_rows(da1), _rows(c1), m1, s1, P[b + 'bn1'].gamma)
+                G[b + 'bn1'] = (dg1, dbb1)
+                dc1 = ops.eltwise(ops.OP_RELU_BWD, dc1, _rows(c1)).view(c1.shape)
+                wa = _ohwi(P[b + 'conv1.weight'])
+                G[b + 'conv1.weight'] = conv_wgrad(x, dc1, wa, stride, 1)
+                dxin = conv_dgrad(dc1, wa, x.shape, stride, 1)
+                if cd is not None:
+                    dcd, dgd, dbd = ops.bn_bwd(_rows(dres), _rows(cd), md, sd, P[b + 'downsample.1'].gamma)
+                    G[b + 'downsample.1'] = (dgd, dbd)
+                    dcd = dcd.view(cd.shape)
+                    wd = _ohwi(P[b + 'downsample.0.weight'])
+                    G[b + 'downsample.0.weight'] = conv_wgrad(x, dcd, wd, 2, 0)
+                    conv_dgrad(dcd, wd, x.shape, 2, 0, out=dxin, beta=1.0)
+                    dx = dxin
+                else:
+                    dx = ops.eltwise(ops.OP_ADD, dxin, dres)
+        # ---- stem backward ----
+        spec, c0, m0, s0 = S['stem']
+        dc0, dg0, db0 = ops.bn_bwd(_rows(dx), _rows(c0), m0, s0, P['bn1'].gamma)
+        G['bn1'] = (dg0, db0)
+        dc0 = ops.eltwise(ops.OP_RELU_BWD, dc0, _rows(c0))
+        dw1, dbias1 = torch.empty_like(P['conv1.weight'].contiguous()), torch.empty_like(P['conv1.bias'])
+        Bn, H0, W0 = spec.shape
+        check(lib.ha2g_stem_conv_wgrad_f32(spec.data_ptr(), dc0.data_ptr(), dw1.data_ptr(), dbias1.data_ptr(), Bn, H0, W0, 0.0,
+                                           workspace(dev).data_ptr(), _stream()))
+        G['conv1.weight'], G['conv1.bias'] = dw1, dbias1
+        # ---- scatter into the flat gradient tuple ----
+        grads = [None] * ctx.n_tensors
+        for n, idx in ctx.flat_index.items():
+            if n not in G:
+                continue
+            if isinstance(idx, list):
+                grads[idx[0]], grads[idx[1]] = G[n]
+            else:
+                grads[idx] = G[n]
+        ctx.S = None
+        return (None, None, None, None, None) + tuple(grads)

@@ -1,0 +1,131 @@
+/* libha2g_hip.so -- C ABI of the hand-written gfx950 (MI355X / CDNA4) kernels behind the HA2G hierarchy
+ * train step.
+ *
+ * The reference (alvinliu0/HA2G) has no FFI: its hot path is Python/torch modules.  Each entry point below
+ * replaces the torch operator(s) the reference reaches through the cited lines (paths relative to the
+ * reference's scripts/ directory); the Python mirror of the reference interface (ha2g_amd/*.py) binds them
+ * with ctypes, and INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only (no torch types); all pointers are DEVICE pointers to fp32
+ * (or int64/int32 where typed) unless noted; outputs and workspaces are caller-allocated; no allocation,
+ * no implicit synchronisation; every call enqueues on `stream` (a hipStream_t passed as void*) and is safe
+ * to capture into a hipGraph; re-entrant across streams.  Return 0 on success, negative on error with the
+ * message available from ha2g_last_error() (thread-local).
+ */
+#ifndef HA2G_HIP_H
+#define HA2G_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int ha2g_abi_version(void);
+const char* ha2g_last_error(void);
+
+/* ---- dense fp32 GEMM on MFMA (v_mfma_f32_32x32x2_f32) -------------------------------------------------
+ * C[M,N] = act(alpha*op(A)*op(B) + beta*C + bias[n]);  row-major; transa=1: A stored [K,M]; transb=1: B stored [N,K].
+ * act: 0 none, 1 relu, 2 leaky-relu(0.01), 3 sigmoid.  ws/ws_bytes: optional split-K scratch.
+ * Replaces nn.Linear / addmm everywhere on the path: GRU input projections (model/hierarchy_net.py:87-88,144),
+ * generator head :89-93,146, TCN convs as im2col GEMMs (model/tcn.py:19-31), tap FCs
+ * (model/ResNetSE34V2.py:36,40,44,163,174,185), speaker MLPs (:194-202), SE FCs (model/ResNetBlocks.py:84-89). */
+int ha2g_gemm_f32(int transa, int transb, int M, int N, int K, float alpha, const float* A, long lda, const float* B,
+                  long ldb, float beta, float* C, long ldc, const float* bias, int act, float* ws, long ws_bytes,
+                  void* stream);
+/* out[c] = beta*out[c] + sum_r X[r*ld + c]  (bias gradients) */
+int ha2g_colsum_f32(const float* X, long ld, long rows, int cols, float* out, float beta, void* stream);
+
+/* ---- NHWC convolution as implicit GEMM (audio encoder: model/ResNetSE34V2.py:27-42,96-116,
+ *      model/ResNetBlocks.py:12-15,24-29).  x [N,H,W,Cin], w [Cout][KH][KW][Cin], y [N,OH,OW,Cout]. ---- */
+int ha2g_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin,
+                        int Cout, int KH, int KW, int stride, int pad, int act, void* stream);
+/* wt = weight permuted to [Cin][KH][KW][Cout] by ha2g_conv2d_weight_ohwi_to_ihwo_f32; dx = beta*dx + ... */
+int ha2g_conv2d_dgrad_f32(const float* dy, const float* wt, float* dx, int N, int H, int W, int Cin, int Cout, int KH,
+                          int KW, int stride, int pad, float beta, void* stream);
+long ha2g_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout, int KH,
+                          int KW, int stride, int pad, float beta, float* ws, long ws_bytes, void* stream);
+int ha2g_conv2d_weight_ohwi_to_ihwo_f32(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
+/* stem Conv2d(1->32, 3x3, pad 1) + bias + ReLU (model/ResNetSE34V2.py:27,127-128); x [N,H,W], y [N,H,W,32] */
+int ha2g_stem_conv_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, void* stream);
+int ha2g_stem_conv_wgrad_f32(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, float beta,
+                             float* ws, void* stream);
+/* NHWC PixelShuffle(r) (model/ResNetSE34V2.py:166-167,177-178); inverse=1 routes the gradient back */
+int ha2g_pixel_shuffle_f32(const float* in, float* out, int N, int H, int W, int Cout, int r, int inverse, void* stream);
+
+/* [N][H][W][C] -> [N][W][C][H]: tap-FC input rows with K index c*H+h (model/ResNetSE34V2.py:160-162); inverse=1 maps back */
+int ha2g_nhwc_to_nwch_f32(const float* in, float* out, int N, int H, int W, int C, int inverse, void* stream);
+
+/* ---- bidirectional GRU layer (nn.GRU: model/hierarchy_net.py:87-88,144 generator; :213,232 discriminator) ---- */
+long ha2g_gru_packed_floats(int H);           /* floats of one packed W_hh image (per direction, per form) */
+int ha2g_gru_supported_hidden(int H);         /* 300, 64, 32 are instantiated */
+int ha2g_gru_pack_whh(const float* whh, float* packed_fwd, float* packed_bwd, int H, void* stream);
+/* gi [B][T][2][3H] = x W_ih^T + b_ih (both directions); wp = packed_fwd images (dir 0, dir 1) back to back;
+ * y [B][T][2H]; rs (nullable reserve) [B][T][2][4][H] */
+int ha2g_gru_layer_fwd(const float* gi, const float* wp, const float* bhh_fwd, const float* bhh_rev, float* y,
+                       float* rs, int B, int T, int H, void* stream);
+/* dg [B][T][2][4H] = (d gi_r, d gi_z, d gi_n, d gh_n); wpt = packed_bwd images (dir 0, dir 1) */
+int ha2g_gru_layer_bwd(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, int B, int T,
+                       int H, void* stream);
+
+/* ---- BatchNorm (train mode) over [rows][C] channels-last data (nn.BatchNorm2d: model/ResNetBlocks.py:13,15,
+ *      ResNetSE34V2.py:29,35,39,43,103; nn.BatchNorm1d: model/hierarchy_net.py:205,208) ---- */
+long ha2g_bn_workspace_floats(int C);
+int ha2g_bn_stats_f32(const float* x, long rows, int C, float* mean, float* invstd, float* running_mean,
+                      float* running_var, float momentum, float eps, float* ws, void* stream);
+int ha2g_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      float* y, long rows, int C, int act, void* stream);
+int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma,
+                    float* dx, float* dgamma, float* dbeta, long rows, int C, float* ws, void* stream);
+/* ---- squeeze-excite pointwise pieces (model/ResNetBlocks.py:81-95 and the residual tail :33-36) ---- */
+int ha2g_hw_mean_f32(const float* x, float* out, int N, int HW, int C, void* stream);
+int ha2g_se_scale_add_relu_f32(const float* x, const float* s, const float* res, float* out, int N, int HW, int C, void* stream);
+int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, float* ds, int N, int HW, int C, void* stream);
+int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, const float* dpool, float* dres,
+                          float* dx, int N, int HW, int C, void* stream);
+/* speaker-softmax blending of the three audio taps (model/ResNetSE34V2.py:202-212) */
+int ha2g_blend_fwd_f32(const float* logits, const float* f0, const float* f1, const float* f2, float* w, float* blend,
+                       int B, int L, int TF, void* stream);
+int ha2g_blend_bwd_f32(const float* dblend, const float* dw_ext, const float* w, const float* f0, const float* f1,
+                       const float* f2, float* df0, float* df1, float* df2, float* dlogits, int B, int L, int TF, void* stream);
+
+/* ---- text encoder pieces (model/hierarchy_net.py:48-52, model/tcn.py:16-46, torch weight_norm) ---- */
+int ha2g_embedding_fwd_f32(const long* tok, const float* W, float* out, long n, int C, void* stream);
+int ha2g_embedding_bwd_f32(const long* tok, const float* dY, float* dW, int n, int C, void* stream);   /* dW += */
+int ha2g_im2col1d_f32(const float* x, float* col, int B, int T, int C, int k, int dil, int pad_left, int To, void* stream);
+int ha2g_col2im1d_f32(const float* dcol, float* dx, int B, int T, int C, int k, int dil, int pad_left, int To, void* stream);
+int ha2g_weight_norm_fwd_f32(const float* g, const float* v, float* w, float* norm, int Cout, int n, void* stream);
+int ha2g_weight_norm_bwd_f32(const float* dw, const float* g, const float* v, const float* norm, float* dg, float* dv,
+                             int Cout, int n, void* stream);
+
+/* ---- pointwise / RNG ---- */
+/* op: 0 a+b, 1 a*b, 2 relu(a+b), 3 relu', 4 leaky', 5 sigmoid', 6 elu, 7 elu', 8 reparam (model/embedding_net.py:10-13),
+ *     9 reparam d/dlogvar, 10 alpha*a+beta*b, 11 leaky, 12 relu, 13 alpha*a, 14 a*b[0]*alpha (b = device scalar) */
+int ha2g_eltwise_f32(int op, const float* a, const float* b, const float* c, float* out, long n, float alpha, float beta, void* stream);
+/* out[r][h] = y[r][h] + y[r][H+h] (sum of the two GRU directions, model/hierarchy_net.py:145); inverse=1: gradient fan-out */
+int ha2g_dirsum_f32(const float* y, float* out, long rows, int H, int inverse, void* stream);
+/* Philox4x32-10 dropout; state = device uint64[2] {seed, step}; out and/or mask (pre-scaled keep mask) may be null */
+int ha2g_dropout_f32(const float* x, float* out, float* mask, long n, float p, const void* state, unsigned stream_id, void* stream);
+int ha2g_rng_advance(void* state, void* stream);
+
+/* ---- loss terms (train_eval/train_hierarchy.py): value + unit gradient in one pass ---- */
+int ha2g_sum_f32(const float* x, long n, float* out, float scale, int accumulate, void* stream);
+int ha2g_huber_f32(const float* x, const float* y, long n, float beta, float* loss, float* dx, float* ws, void* stream);      /* :173-176 */
+int ha2g_kld_f32(const float* mu, const float* logvar, int n, float* loss, float* dmu, float* dlogvar, void* stream);          /* :226 */
+int ha2g_divreg_f32(const float* out, const float* rnd, const float* z, const float* zr, int B, int TP, int Z, float beta,
+                    float* loss, float* dout, float* ws, void* stream);                                                          /* :213-222 */
+int ha2g_phys_angle_f32(const float* out, const float* mean_dir, int rows, int nb, const int* pairs, int npairs,
+                        const float* avg, const float* var, float* loss, float* dout, float* ws, void* stream);                  /* :242-262 */
+int ha2g_gan_loss_f32(int mode, const float* a, const float* b, int n, float* loss, float* da, float* db, void* stream);       /* :128,180 */
+long ha2g_contrastive_workspace_floats(int N);
+int ha2g_contrastive_f32(const float* a, const float* b, int N, int expressive, float* loss, float* da, float* db, float* ws,
+                         void* stream);                                                                                          /* :54-68 */
+
+/* ---- optimizer (torch.optim.Adam as set up in train.py:155-170) ---- */
+int ha2g_adam_step_inc(int* step, void* stream);
+int ha2g_adam_f32(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                  const int* step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

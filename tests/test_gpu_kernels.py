@@ -119,3 +119,92 @@ def test_bigru_fwd_bwd(case):
     assert relerr(y, y64.detach()) < 2e-5
     for name, a, b in zip(['x'] + flat, gg, g64):
         assert relerr(a, b) < 1e-4, name
+
+
+CONV_CASES = [
+    # (N, H, W, Cin, Cout, k, stride, pad, bias)
+    (2, 16, 9, 256, 256, 3, 1, 1, False),
+    (3, 32, 18, 128, 256, 3, 2, 1, False),
+    (2, 32, 18, 128, 256, 1, 2, 0, False),
+    (2, 64, 35, 64, 64, 2, 1, 0, True),
+    (2, 64, 36, 16, 16, 3, 1, 0, True),
+    (2, 40, 22, 32, 32, 3, 1, 1, False),
+    (2, 41, 23, 32, 64, 3, 2, 1, False),
+    (1, 128, 70, 32, 64, 1, 2, 0, False),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(case):
+    """Implicit-GEMM NHWC conv kernels vs torch CPU float64 conv2d autograd."""
+    import torch.nn.functional as F
+    from ha2g_amd import wav_engine as we
+    N, H, W, Cin, Cout, k, stride, pad, use_bias = case
+    dev = _dev()
+    x = rnd((N, Cin, H, W), 11)
+    w = rnd((Cout, Cin, k, k), 12, 1.0 / (Cin * k * k) ** 0.5)
+    b = rnd((Cout,), 13) if use_bias else None
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, None if b is None else b.double(), stride=stride, padding=pad)
+    gy = rnd(tuple(y64.shape), 14)
+    gx64, gw64 = torch.autograd.grad((y64 * gy.double()).sum(), [x64, w64])
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev)                      # NHWC
+    wg = w.permute(0, 2, 3, 1).contiguous().to(dev)                      # OHWI
+    y = we.conv_fwd(xg, wg, None if b is None else b.to(dev), stride, pad, 0)
+    assert relerr(y.permute(0, 3, 1, 2), y64.detach()) < 1e-5
+    gyg = gy.permute(0, 2, 3, 1).contiguous().to(dev)
+    dx = we.conv_dgrad(gyg, wg, xg.shape, stride, pad)
+    assert relerr(dx.permute(0, 3, 1, 2), gx64) < 1e-5
+    dw = we.conv_wgrad(xg, gyg, wg, stride, pad)
+    assert dw.shape == w.shape
+    assert relerr(dw, gw64) < 2e-5
+
+
+def test_stem_conv():
+    import torch.nn.functional as F
+    from ha2g_amd._lib import lib, check
+    from ha2g_amd import ops
+    dev = _dev()
+    N, H, W = 3, 128, 70
+    x = rnd((N, H, W), 21, 30.0)
+    w = rnd((32, 1, 3, 3), 22, 0.3)
+    b = rnd((32,), 23)
+    x64, w64, b64 = x.double(), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    pre = F.conv2d(x64.unsqueeze(1), w64, b64, padding=1)
+    gy = rnd(tuple(pre.shape), 24)
+    gw64, gb64 = torch.autograd.grad((pre * gy.double()).sum(), [w64, b64])
+    y = torch.empty(N, H, W, 32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    xg, wg, bg = x.to(dev), w.to(dev), b.to(dev)
+    check(lib.ha2g_stem_conv_fwd_f32(xg.data_ptr(), wg.data_ptr(), bg.data_ptr(), y.data_ptr(), N, H, W, st))
+    assert relerr(y.permute(0, 3, 1, 2), pre.detach().clamp_min(0)) < 1e-5
+    dw, db = torch.empty(32, 1, 3, 3, device=dev), torch.empty(32, device=dev)
+    gyg = gy.permute(0, 2, 3, 1).contiguous().to(dev)
+    check(lib.ha2g_stem_conv_wgrad_f32(xg.data_ptr(), gyg.data_ptr(), dw.data_ptr(), db.data_ptr(), N, H, W, 0.0,
+                                       ops.workspace(xg.device).data_ptr(), st))
+    assert relerr(dw, gw64) < 2e-5
+    assert relerr(db, gb64) < 2e-5
+
+
+@pytest.mark.parametrize('shape', [(5000, 32), (96, 16), (1200, 256), (84, 8)])
+def test_batchnorm_fwd_bwd(shape):
+    import torch.nn.functional as F
+    from ha2g_amd import ops
+    dev = _dev()
+    rows, C = shape
+    x = rnd((rows, C), 31, 3.0) + 5.0                                    # mean >> 0: exercises the shifted variance
+    g, b = rnd((C,), 32) + 1.5, rnd((C,), 33)
+    rm, rv = rnd((C,), 34), rnd((C,), 35).abs() + 0.5
+    wy = rnd((rows, C), 36)
+    x64, g64, b64 = x.double().requires_grad_(True), g.double().requires_grad_(True), b.double().requires_grad_(True)
+    rm64, rv64 = rm.double().clone(), rv.double().clone()
+    y64 = F.batch_norm(x64, rm64, rv64, g64, b64, True, 0.1, 1e-5)
+    gr = torch.autograd.grad((y64 * wy.double()).sum(), [x64, g64, b64])
+    xg, gg, bg = x.to(dev).requires_grad_(True), g.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    rmg, rvg = rm.to(dev), rv.to(dev)
+    y = ops.batch_norm_train(xg, gg, bg, rmg, rvg)
+    (y * wy.to(dev)).sum().backward()
+    assert relerr(y, y64.detach()) < 1e-5
+    assert relerr(rmg, rm64) < 1e-5 and relerr(rvg, rv64) < 1e-5
+    assert relerr(xg.grad, gr[0]) < 2e-5
+    assert relerr(gg.grad, gr[1]) < 2e-5 and relerr(bg.grad, gr[2]) < 2e-5
