@@ -287,8 +287,9 @@ __global__ void splitk_reduce_kernel(const float* ws, int splits, long MN, int N
                                      float beta, const float* bias, int act) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= MN) return;
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += ws[(long)z * MN + i];
+    double sd = 0.0;
+    for (int z = 0; z < splits; ++z) sd += (double)ws[(long)z * MN + i];
+    const float s = (float)sd;
     int col = (int)(i % N);
     long row = i / N;
     float v = alpha * s + (bias ? bias[col] : 0.f);

@@ -22,10 +22,10 @@ namespace {
 // LDS combine (deterministic).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ld, long rows, int cols,
                                                      float* __restrict__ out, float beta) {
-    __shared__ float part[4][64];
+    __shared__ double part[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;      // HBM-bound: double accumulation is free and keeps bias grads exact
     if (c < cols) {
         long r = w;
         for (; r + 12 < rows; r += 16) {
@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     part[w][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (w == 0 && c < cols) {
-        float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-        out[c] = (beta != 0.f ? beta * out[c] : 0.f) + s;
+        double s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)s;
     }
 }
 

@@ -1,0 +1,77 @@
+"""Fused Adam over flat parameter/gradient buffers (HIP kernel ha2g_adam_f32) with torch.optim.Adam semantics as the
+reference sets it up (scripts/train.py:155-170: one optimizer per module, lr 5e-4 (D: x0.2), betas (0.5, 0.999)).
+
+Construction re-points every parameter's storage into one flat fp32 buffer (layout-preserving, so channels_last conv
+weights stay OHWI) and installs `.grad` views into a matching flat gradient buffer: the optimizer step is then ONE
+HBM-streaming kernel, and data-parallel gradient exchange is ONE RCCL all-reduce per module (ha2g_amd/ddp.py).
+"""
+import torch
+
+from ._lib import check, lib
+from .ops import _stream
+
+
+def _storage_span(p):
+    """Number of elements of the dense memory block a (possibly permuted-contiguous) parameter occupies."""
+    return p.numel()
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=5e-4, betas=(0.5, 0.999), eps=1e-8):
+        params = [p for p in params]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        ps = [p for p in self.param_groups[0]['params'] if p.requires_grad]
+        assert ps, 'no trainable parameters'
+        dev = ps[0].device
+        assert all(p.dtype == torch.float32 and p.device == dev for p in ps)
+        offs, total = [], 0
+        for p in ps:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4                     # keep every tensor 16-byte aligned
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._views = []
+        with torch.no_grad():
+            for p, o in zip(ps, offs):
+                dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+                src = p.data if dense else p.data.contiguous()
+                pv = torch.as_strided(self.flat_p, src.shape, src.stride(), o)
+                pv.copy_(src)
+                p.data = pv
+                gv = torch.as_strided(self.flat_g, src.shape, src.stride(), o)
+                p.grad = gv
+                self._views.append((p, gv))
+        self.total = total
+
+    def zero_grad(self, set_to_none=False):
+        """Gradients live in the flat buffer: zero it in place and keep the views installed."""
+        self.flat_g.zero_()
+        for p, gv in self._views:
+            if p.grad is not gv:
+                p.grad = gv
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        for p, gv in self._views:                                 # a foreign tensor installed as .grad: fold it back
+            if p.grad is not gv:
+                if p.grad is not None:
+                    gv.copy_(p.grad)
+                p.grad = gv
+        st = _stream()
+        check(lib.ha2g_adam_step_inc(self.step_t.data_ptr(), st))
+        check(lib.ha2g_adam_f32(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
+                                self.total, float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
+                                self.step_t.data_ptr(), st))
+
+    def allreduce_grads(self, group=None, async_op=False):
+        """Data-parallel: average the flat gradient buffer over ranks (one RCCL all-reduce over xGMI)."""
+        import torch.distributed as dist
+        ws = dist.get_world_size(group)
+        if ws == 1:
+            return None
+        self.flat_g.div_(ws)
+        return dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group, async_op=async_op)

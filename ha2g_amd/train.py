@@ -1,0 +1,62 @@
+"""Driver-side surface the train step sits behind: init_model() and the optimizer set-up of the reference's
+scripts/train.py:50-88,114-170, plus a minimal batch loop (:254-316) for synthetic / in-memory data.
+Dataset building, evaluation (FGD), checkpoint I/O and video synthesis are out of scope."""
+import torch
+
+from .hierarchy_net import (Hierarchical_ConvDiscriminator, Hierarchical_PoseGenerator, Hierarchical_WavEncoder,
+                            TextEncoderTCN)
+from .optim import FusedAdam
+from .train_hierarchy import train_iter_hierarchy
+
+
+def init_model(args, lang_model, speaker_model, pose_dim, _device=None):
+    """reference scripts/train.py:50-88 (only `args.model == 'hierarchy'` is on the hot path)."""
+    generator = discriminator = audio_encoder = text_encoder = loss_fn = None
+    if args.model == 'hierarchy':
+        generator = Hierarchical_PoseGenerator(args, n_words=lang_model.n_words, word_embed_size=args.wordembed_dim,
+                                               word_embeddings=lang_model.word_embedding_weights, z_obj=speaker_model,
+                                               pose_dim=pose_dim)
+        discriminator = Hierarchical_ConvDiscriminator(pose_dim)
+        audio_encoder = Hierarchical_WavEncoder(args, z_obj=speaker_model, pose_level=3, nOut=32)
+        text_encoder = TextEncoderTCN(args, lang_model.n_words, args.wordembed_dim,
+                                      pre_trained_embedding=lang_model.word_embedding_weights, dropout=args.dropout_prob)
+    else:
+        raise NotImplementedError('ha2g_amd implements the `hierarchy` model family only (got %r)' % args.model)
+    return generator, discriminator, audio_encoder, text_encoder, loss_fn
+
+
+class HierarchyTrainer:
+    """Everything train_epochs() builds before its batch loop (reference scripts/train.py:114-170)."""
+
+    def __init__(self, args, lang_model, speaker_model, pose_dim, device, pose_dims=(15, 21, 27)):
+        self.args, self.device = args, device
+        _, self.discriminator, self.audio_encoder, self.text_encoder, _ = init_model(args, lang_model, speaker_model, pose_dim, device)
+        self.gens = [init_model(args, lang_model, speaker_model, pd, device)[0] for pd in pose_dims]
+        for m in self.modules():
+            m.to(device)
+        self.make_optimizers()
+
+    def modules(self):
+        return list(self.gens) + [self.discriminator, self.audio_encoder, self.text_encoder]
+
+    def make_optimizers(self):
+        a = self.args
+        lr = float(a.learning_rate)
+        self.gen_opts = [FusedAdam(g.parameters(), lr=lr, betas=(0.5, 0.999)) for g in self.gens]
+        self.audio_opt = FusedAdam(self.audio_encoder.parameters(), lr=lr, betas=(0.5, 0.999))
+        self.text_opt = FusedAdam(self.text_encoder.parameters(), lr=lr, betas=(0.5, 0.999))
+        self.dis_opt = FusedAdam(self.discriminator.parameters(), lr=lr * a.discriminator_lr_weight, betas=(0.5, 0.999))
+
+    def broadcast_parameters(self, src=0):
+        """DDP start-up: every rank adopts rank `src`'s parameters and buffers."""
+        import torch.distributed as dist
+        for o in self.gen_opts + [self.audio_opt, self.text_opt, self.dis_opt]:
+            dist.broadcast(o.flat_p, src)
+        for m in self.modules():
+            for b in m.buffers():
+                dist.broadcast(b, src)
+
+    def train_iter(self, epoch, in_text_padded, in_spec, target, vid_indices, **kw):
+        return train_iter_hierarchy(self.args, epoch, in_text_padded, in_spec, target, vid_indices, *self.gens,
+                                    self.discriminator, self.audio_encoder, self.text_encoder, *self.gen_opts, self.dis_opt,
+                                    self.audio_opt, self.text_opt, **kw)

@@ -166,7 +166,8 @@ class WavEncoderFunction(torch.autograd.Function):
                 pooled = empty(N, C, like=x)
                 check(lib.ha2g_hw_mean_f32(b2.data_ptr(), pooled.data_ptr(), N, OH * OW, C, _stream()))
                 h1 = ops.gemm(pooled, P[b + 'se.fc.0.weight'], transb=True, bias=P[b + 'se.fc.0.bias'], act=ACT_RELU)
-                sc = ops.gemm(h1, P[b + 'se.fc.2.weight'], transb=True, bias=P[b + 'se.fc.2.bias'], act=ACT_SIGMOID)
+                su = ops.gemm(h1, P[b + 'se.fc.2.weight'], transb=True, bias=P[b + 'se.fc.2.bias'])      # gate pre-activation
+                sc = ops.eltwise(ops.OP_SIGMOID, su)
                 if first:
                     wd = _ohwi(P[b + 'downsample.0.weight'])
                     cd = conv_fwd(x, wd, None, 2, 0, ACT_NONE)
@@ -175,7 +176,7 @@ class WavEncoderFunction(torch.autograd.Function):
                     res, cd, md, sd = x, None, None, None
                 out = torch.empty_like(b2)
                 check(lib.ha2g_se_scale_add_relu_f32(b2.data_ptr(), sc.data_ptr(), res.data_ptr(), out.data_ptr(), N, OH * OW, C, _stream()))
-                S[b] = (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, cd, md, sd, out, stride)
+                S[b] = (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride)
                 x = out
             feats.append(x)
             cin = FILTERS[li]
@@ -270,13 +271,13 @@ class WavEncoderFunction(torch.autograd.Function):
                 dx = dfeat[li] if dx is None else ops.eltwise(ops.OP_ADD, dx, dfeat[li])
             for j in range(LAYERS[li] - 1, -1, -1):
                 b = 'layer%d.%d.' % (li + 1, j)
-                (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, cd, md, sd, out, stride) = S[b]
+                (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride) = S[b]
                 N, OH, OW, C = b2.shape
                 HW = OH * OW
                 dout = dx.contiguous()
                 ds = empty(N, C, like=b2)
                 check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, _stream()))
-                dsc = ops.eltwise(ops.OP_SIGMOID_BWD, ds, sc)
+                dsc = ops.eltwise(ops.OP_SIGMOID_BWD_PRE, ds, su)
                 G[b + 'se.fc.2.weight'] = ops.gemm(dsc, h1, transa=True)
                 G[b + 'se.fc.2.bias'] = ops.colsum(dsc)
                 dh1 = ops.eltwise(ops.OP_RELU_BWD, ops.gemm(dsc, P[b + 'se.fc.2.weight']), h1)

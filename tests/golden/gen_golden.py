@@ -78,6 +78,17 @@ def build(case, pose_dims, pose_level, dt=torch.float32):
     return args, gens, dis.to(dt), aud.to(dt), txt.to(dt)
 
 
+PERTURB_DRAW = 0
+
+
+def perturbed(t, rel, salt):
+    """t * (1 + rel * N(0,1)): an ulp-scale relative perturbation of a float input (conditioning probe)."""
+    if not rel:
+        return t
+    r = np.random.Generator(np.random.PCG64([4242, salt, PERTURB_DRAW])).standard_normal(tuple(t.shape))
+    return t * (1.0 + rel * torch.from_numpy(r).to(t.dtype))
+
+
 def digest(out, name, t):
     a = t.detach().double().numpy().reshape(-1)
     stride = max(1, a.size // 64)
@@ -85,13 +96,13 @@ def digest(out, name, t):
     out[name + '/sample'] = a[::stride][:64].copy()
 
 
-def module_goldens(case, out, dt):
+def module_goldens(case, out, dt, perturb=0.0):
     """Per-module forward outputs + gradient digests under loss = sum(out * w_proc)."""
     args, gens, dis, aud, txt = build(case, (15, 21, 27), 3, dt)
     B = case['B']
     text, spec, target, vid = proc.make_batch(B, 27, case['n_words'], case['n_spk'], case['seed'])
     text_t, spec_t, tgt_t, vid_t = map(torch.from_numpy, (text, spec, target, vid))
-    spec_t, tgt_t = spec_t.to(dt), tgt_t.to(dt)
+    spec_t, tgt_t = perturbed(spec_t.to(dt), perturb, 1), perturbed(tgt_t.to(dt), perturb, 2)
 
     def wproc(name, t):
         return torch.from_numpy(proc.tensor_for('w.' + name, (2,) + tuple(t.shape), case['seed'])[0] * t[0].numel() ** 0.5).to(dt)
@@ -167,7 +178,7 @@ def module_goldens(case, out, dt):
     out['contrastive_expr/grad_b'] = b.grad.double().numpy().copy()
 
 
-def step_goldens(case, out, dt, expressive=False):
+def step_goldens(case, out, dt, expressive=False, perturb=0.0):
     """Two consecutive train steps (epoch 0 = warm-up phase, epoch 11 = GAN phase) through the reference."""
     pose_dims = (24, 30, 36, 66, 96, 126) if expressive else (15, 21, 27)
     args, gens, dis, aud, txt = build(case, pose_dims, len(pose_dims), dt)
@@ -175,7 +186,7 @@ def step_goldens(case, out, dt, expressive=False):
     P = pose_dims[-1]
     text, spec, target, vid = proc.make_batch(B, P, case['n_words'], case['n_spk'], case['seed'])
     text_t, spec_t, tgt_t, vid_t = map(torch.from_numpy, (text, spec, target, vid))
-    spec_t, tgt_t = spec_t.to(dt), tgt_t.to(dt)
+    spec_t, tgt_t = perturbed(spec_t.to(dt), perturb, 1), perturbed(tgt_t.to(dt), perturb, 2)
     eps = proc.EpsStream(case['seed'])
     ref_embedding_net.reparameterize = lambda mu, logvar: mu + torch.from_numpy(eps(mu.shape)).to(mu.dtype) * torch.exp(0.5 * logvar)
     perm = torch.from_numpy(proc.fixed_perm(B, case['seed']))
@@ -218,19 +229,29 @@ def main():
             continue
         print('case', name, case)
         runs = {}
-        for dt in (torch.float64, torch.float32):
-            o = runs[dt] = {}
+        global PERTURB_DRAW
+        plan = [('f64', torch.float64, 0.0, 0), ('f32', torch.float32, 0.0, 0), ('cond', torch.float64, 6e-8, 0),
+                ('f32p0', torch.float32, 6e-8, 1), ('f32p1', torch.float32, 6e-8, 2), ('f32p2', torch.float32, 6e-8, 3)]
+        for tag, dt, pert, draw in plan:
+            PERTURB_DRAW = draw
+            o = runs[tag] = {}
             if case.get('expressive'):
-                step_goldens(case, o, dt, expressive=True)
+                step_goldens(case, o, dt, expressive=True, perturb=pert)
             else:
-                module_goldens(case, o, dt)
-                step_goldens(case, o, dt)
-        # truth = the reference in float64; '@noise' = how far the reference's own float32 run is from it
+                module_goldens(case, o, dt, perturb=pert)
+                step_goldens(case, o, dt, perturb=pert)
+        # truth  = the reference in float64;
+        # @noise = the reference's own float32 scatter around it: max deviation over four float32 runs (the plain one and
+        #          three whose float inputs are perturbed by one float32 ulp, 6e-8 relative -- that changes every rounding
+        #          decision downstream, so it samples the chaotic fp32 noise of the deep BatchNorm'ed net, not only one draw);
+        # @cond  = how far the float64 result moves under the same one-ulp input perturbation (pure conditioning).
         out = {}
-        for k, v in runs[torch.float64].items():
+        f32runs = ('f32', 'f32p0', 'f32p1', 'f32p2')
+        for k, v in runs['f64'].items():
             v = np.asarray(v, np.float64)
             out[k] = v
-            out[k + '@noise'] = np.float64(np.abs(np.asarray(runs[torch.float32][k], np.float64) - v).max())
+            out[k + '@noise'] = np.float64(max(np.abs(np.asarray(runs[r][k], np.float64) - v).max() for r in f32runs))
+            out[k + '@cond'] = np.float64(np.abs(np.asarray(runs['cond'][k], np.float64) - v).max())
         path = os.path.join(HERE, name + '.npz')
         np.savez_compressed(path, **out)
         print('  wrote', path, os.path.getsize(path) // 1024, 'KiB,', len(out), 'arrays')

@@ -1,5 +1,5 @@
 """GPU parity of the module mirrors (HIP forward + hand-written backward) against the reference-generated
-fixtures, with the tolerance policy of ha2g_amd/testing.py (1e-4 rel + 4x the reference's own fp32 noise)."""
+fixtures, with the tolerance policy of ha2g_amd/testing.py (1e-4 rel + 3x the reference's own fp32 scatter)."""
 import numpy as np
 import pytest
 import torch

@@ -1,0 +1,42 @@
+"""Full train_iter_hierarchy on the GPU vs the reference-generated step fixtures: two consecutive steps
+(epoch 0 = warm-up phase, epoch 11 = GAN phase) -- loss dict, accumulated gradients, Adam-updated parameters,
+BatchNorm running statistics -- for the fused-chain schedule and the literal three-pass schedule."""
+import pytest
+import torch
+
+from ha2g_amd import procedural as proc
+from ha2g_amd import train_hierarchy as th
+from ha2g_amd.config import CASES
+from ha2g_amd.optim import FusedAdam
+from ha2g_amd.testing import Checker, EpsInjector, batch_for, build_modules, named_state
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.mark.parametrize('fuse', [True, False])
+@pytest.mark.parametrize('name', ['small', 'cfg1'])
+def test_train_step(golden, name, fuse):
+    case, g = CASES[name], golden(name)
+    ck = Checker(g)
+    args, gens, dis, aud, txt = build_modules(case, DEV)
+    text, spec, target, vid = (t.to(DEV) for t in batch_for(case))
+    lr = float(args.learning_rate)
+    g_opts = [FusedAdam(m.parameters(), lr=lr) for m in gens]
+    dis_opt = FusedAdam(dis.parameters(), lr=lr * args.discriminator_lr_weight)
+    aud_opt, txt_opt = FusedAdam(aud.parameters(), lr=lr), FusedAdam(txt.parameters(), lr=lr)
+    EpsInjector(gens, case['seed'], case['B'])
+    perm = torch.from_numpy(proc.fixed_perm(case['B'], case['seed'])).to(DEV)
+    mods = dict(g1=gens[0], g2=gens[1], g3=gens[2], dis=dis, audio=aud, text=txt)
+    old = th.FUSE_CHAINS, th.randperm_source
+    th.FUSE_CHAINS, th.randperm_source = fuse, (lambda n, device: perm)
+    try:
+        for si, epoch in enumerate((0, 11)):
+            ret = th.train_iter_hierarchy(args, epoch, text, spec, target, vid, *gens, dis, aud, txt, *g_opts, dis_opt,
+                                          aud_opt, txt_opt)
+            sd, grads = named_state(mods)
+            if epoch == 0:                      # the reference's D has .grad None during warm-up (never backpropagated)
+                grads = {k: v for k, v in grads.items() if not k.startswith('dis.')}
+            ck.step(si, ret, grads, sd)
+    finally:
+        th.FUSE_CHAINS, th.randperm_source = old
