@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pose-frames/sec of the HA2G hierarchy train step (config/hierarchy.yml shapes, B=128 per GPU,
+T=34, 27-d pose, fp32, GAN phase = epoch > loss_warmup) on N MI355X, synthetic data, random-init weights.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `value` = B*T*N / max-over-ranks step time; `roofline` = the bi-GRU forward kernel timed
+with HIP events on its launch stream inside the timed region; `cpu_baseline` = the CPU oracle (a port of the reference's
+step) timed on a bounded sample on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+class Vocab:
+    def __init__(self, n_words, weights=None):
+        self.n_words = n_words
+        self.word_embedding_weights = weights
+
+
+def cpu_baseline(B, epoch, n_words, n_spk):
+    """Time the CPU oracle's train step (oracle/ha2g_oracle.py, parity-pinned port of the reference) on one batch."""
+    from ha2g_amd import procedural as proc, schema
+    from ha2g_amd.config import hierarchy_args
+    from oracle import ha2g_oracle as O
+    args = hierarchy_args(dropout_prob=0.0)
+    sch = schema.step_schema(schema.GESTURE_POSE_DIMS, n_words, n_spk, args.hidden_size, args.n_layers)
+    sd = schema.procedural_state(sch, 3)
+    tr = O.OracleTrainer(sd, args)
+    text, spec, target, vid = map(torch.from_numpy, proc.make_batch(B, 27, n_words, n_spk, 4321))
+    eps = lambda shp: torch.randn(shp)
+    perm = torch.randperm(B)
+    small = [t[:2] for t in (text, spec, target, vid)]
+    tr.train_iter(epoch, *small, eps, torch.randperm(2))                    # warm the thread pool / allocator
+    t0 = time.time()
+    tr.train_iter(epoch, text, spec, target, vid, eps, perm)
+    dt = time.time() - t0
+    return dict(value=B * 34 / dt, unit='pose-frames/s', cores=torch.get_num_threads(), kind='port',
+                sample='1 train step (epoch %d) of B=%d, T=34 on the CPU oracle: %.1f s' % (epoch, B, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=128, help='per-GPU batch (weak scaling)')
+    ap.add_argument('--epoch', type=int, default=11, help='> loss_warmup (10) = GAN phase; 0 = warm-up phase')
+    ap.add_argument('--n-words', type=int, default=20000)
+    ap.add_argument('--n-spk', type=int, default=1371)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=64)
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    from ha2g_amd import ops, procedural as proc
+    from ha2g_amd.config import hierarchy_args
+    from ha2g_amd.train import HierarchyTrainer
+
+    torch.manual_seed(0)
+    args = hierarchy_args()                                   # config/hierarchy.yml, dropout 0.3
+    tr = HierarchyTrainer(args, Vocab(a.n_words), Vocab(a.n_spk), 27, dev)
+    if world > 1:
+        tr.broadcast_parameters(0)
+    ops.rng.seed(dev, 1234 + rank)
+    text, spec, target, vid = (torch.from_numpy(x).to(dev) for x in proc.make_batch(a.batch, 27, a.n_words, a.n_spk, 1234 + rank))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        tr.train_iter(a.epoch, text, spec, target, vid)
+    ops.ktimer.enabled = True
+    ops.ktimer.reset()
+    sync()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(a.steps):
+        last = tr.train_iter(a.epoch, text, spec, target, vid)
+    sync()
+    dt = time.perf_counter() - t0
+    ops.ktimer.enabled = False
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ms = dt / a.steps * 1e3
+    value = a.batch * 34 * world / (dt / a.steps)
+
+    if rank == 0:
+        # ---- roofline of the named kernel: bi-GRU layer forward (ha2g_gru_layer_fwd, H=300, layers 1..3: in = 600) ----
+        H, T = args.hidden_size, 34
+        kt = ops.ktimer.summary()
+        roof = None
+        if 'gru_layer_fwd' in kt:
+            n, mean_us, rows = kt['gru_layer_fwd']                       # rows = batch rows per launch (3B in the GAN phase)
+            flops = 2.0 * rows * T * 2 * 3 * H * H + 12.0 * rows * T * 2 * H   # recurrent matmul + gate math per launch
+            bytes_ = (rows * T * 2 * 3 * H + rows * T * 2 * H + rows * T * 2 * 4 * H + 2 * 3 * H * H) * 4.0   # gi + y + reserve + W_hh
+            ach = flops / (mean_us * 1e-6) / 1e12
+            roof = dict(kernel='gru_fwd_kernel<300> (ha2g_gru_layer_fwd)', bound='mfma', achieved=round(ach, 3), peak=157.3,
+                        unit='TFLOP/s', frac=round(ach / 157.3, 4), traffic=None, launches=n, mean_us=round(mean_us, 1),
+                        batch_rows=rows, hbm_GBps_algorithmic=round(bytes_ / (mean_us * 1e-6) / 1e9, 1),
+                        hbm_frac_of_8TBps=round(bytes_ / (mean_us * 1e-6) / 8e12, 4))
+        out = dict(metric='pose-frames/sec (train step) for hierarchy.yml B=128 T=34', value=round(value, 1), unit='pose-frames/s',
+                   n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling='weak',
+                   vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload='config/hierarchy.yml TED-Gesture hierarchy train step, B=%d per GPU, T=34, 27-d pose, '
+                                        'spec (128,70), n_words=%d, n_spk=%d, dropout 0.3, %s' % (
+                                            a.batch, a.n_words, a.n_spk, 'GAN phase (epoch %d > loss_warmup)' % a.epoch
+                                            if a.epoch > args.loss_warmup else 'warm-up phase (epoch %d)' % a.epoch),
+                               global_batch=a.batch * world, parallelism='dp%d' % world),
+                   roofline=roof, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(a.cpu_batch, a.epoch, a.n_words, a.n_spk)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

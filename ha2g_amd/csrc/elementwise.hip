@@ -19,15 +19,39 @@ __global__ void embedding_fwd_kernel(const long* __restrict__ tok, const float* 
     }
 }
 
-// dW[tok] += sum over positions carrying tok.  grid = (n positions, column chunks of 64); the block of the FIRST
-// occurrence of a token sums all its occurrences in ascending position order (4 waves take positions round-robin,
-// then a fixed-order LDS combine) -> deterministic, no atomics.  Token lists are short (n <= ~13k).
+// dW[tok] += sum over positions carrying tok, deterministic and atomic-free:
+//  * the padding id (token `heavy`, ~80 % of all positions: in_text_padded is zero except at word onsets, reference
+//    data_loader/lmdb_data_loader.py:116-141) is a masked column sum done in two fixed-order levels;
+//  * every other token: the block of its FIRST occurrence sums all its occurrences in ascending position order
+//    (4 waves take matches round-robin, fixed-order LDS combine).
+__global__ __launch_bounds__(256) void embedding_bwd_heavy_partial(const long* __restrict__ tok, const float* __restrict__ dY,
+                                                                   double* __restrict__ part, int n, int C, long heavy) {
+    __shared__ double sh[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int per = (n + gridDim.y - 1) / gridDim.y;
+    const int pbeg = blockIdx.y * per, pend = min(n, pbeg + per);
+    double s = 0.0;
+    for (int p = pbeg + w; p < pend; p += 4)
+        if (tok[p] == heavy && c < C) s += dY[(long)p * C + c];
+    sh[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < C) part[(long)blockIdx.y * C + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+__global__ void embedding_bwd_heavy_final(const double* __restrict__ part, int nchunk, int C, float* __restrict__ dW, long heavy) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < nchunk; ++k) s += part[(long)k * C + c];
+    dW[heavy * C + c] += (float)s;
+}
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const long* __restrict__ tok, const float* __restrict__ dY,
-                                                            float* __restrict__ dW, int n, int C) {
+                                                            float* __restrict__ dW, int n, int C, long heavy) {
     __shared__ float part[4][64];
     __shared__ int first;
     const int p = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long t = tok[p];
+    if (t == heavy) return;
     if (threadIdx.x == 0) first = 1;
     __syncthreads();
     for (int q = threadIdx.x; q < p; q += 256)
@@ -309,9 +333,16 @@ int ha2g_embedding_fwd_f32(const long* tok, const float* W, float* out, long n, 
     HA2G_CHECK_LAUNCH("embedding_fwd");
     return 0;
 }
-int ha2g_embedding_bwd_f32(const long* tok, const float* dY, float* dW, int n, int C, void* stream) {
+// dW [V][C] += scatter of dY [n][C] by tok [n]; `heavy` = the most frequent id (padding, 0); ws >= 64*C doubles
+int ha2g_embedding_bwd_f32(const long* tok, const float* dY, float* dW, int n, int C, long heavy, float* ws, void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(n, ceil_div(C, 64)), dim3(256), 0, (hipStream_t)stream, tok, dY, dW, n, C);
+    hipStream_t st = (hipStream_t)stream;
+    int nchunk = n / 128 < 1 ? 1 : (n / 128 > 64 ? 64 : n / 128);
+    if (heavy >= 0) {
+        hipLaunchKernelGGL(embedding_bwd_heavy_partial, dim3(ceil_div(C, 64), nchunk), dim3(256), 0, st, tok, dY, (double*)ws, n, C, heavy);
+        hipLaunchKernelGGL(embedding_bwd_heavy_final, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const double*)ws, nchunk, C, dW, heavy);
+    }
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(n, ceil_div(C, 64)), dim3(256), 0, st, tok, dY, dW, n, C, heavy);
     HA2G_CHECK_LAUNCH("embedding_bwd");
     return 0;
 }

@@ -157,87 +157,120 @@ __device__ __forceinline__ float dlogit_of(float dist, float l, int expressive) 
     return (1.0f / (dist + 1e-8f) > 1e-8f) ? -l * l : 0.f;
 }
 
-// thread per row i of a: sweep 1 -> running max / sum-exp over all j and the diagonal logit; sweep 2 -> d a_i.
-__global__ __launch_bounds__(64) void contrastive_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, int N,
-                                                              int expressive, float* __restrict__ rmax, float* __restrict__ rsum,
-                                                              float* __restrict__ loss_i, float* __restrict__ dan) {
-    __shared__ float tb[CT * CD];
-    const int i = blockIdx.x * 64 + threadIdx.x;
+// Pair kernels.  A block owns 16 rows of one side; its 256 threads are 16 row slots x 16 lanes that split the opposite
+// side's rows (staged through LDS in tiles of CT rows, row stride CD+1 so the 16 lanes of a slot hit distinct banks).
+// Per-row reductions (online log-sum-exp, gradient sums) are combined across the 16 lanes with xor shuffles in a fixed
+// order => deterministic.  O(N^2 * 32) flops on ~N/16 blocks instead of the N x N x 32 tensor the reference materialises.
+constexpr int LDT = CD + 1;
+
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void contrastive_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, int N,
+                                                               int expressive, float* __restrict__ rmax, float* __restrict__ rsum,
+                                                               float* __restrict__ loss_i, float* __restrict__ dan) {
+    __shared__ float tb[CT * LDT];
+    const int slot = threadIdx.x >> 4, jl = threadIdx.x & 15;
+    const int i = blockIdx.x * 16 + slot;
     const bool on = i < N;
     float ai[CD];
+#pragma unroll
     for (int d = 0; d < CD; ++d) ai[d] = on ? a[(long)i * CD + d] : 0.f;
     float m = -INFINITY, z = 0.f, lii = 0.f;
     for (int j0 = 0; j0 < N; j0 += CT) {
         __syncthreads();
-        for (int e = threadIdx.x; e < CT * CD; e += 64) tb[e] = (j0 + e / CD < N) ? b[(long)j0 * CD + e] : 0.f;
+        for (int e = threadIdx.x; e < CT * CD; e += 256) { int r = e / CD, d = e % CD; tb[r * LDT + d] = (j0 + r < N) ? b[(long)(j0 + r) * CD + d] : 0.f; }
         __syncthreads();
-        const int jn = min(CT, N - j0);
-        for (int j = 0; j < jn; ++j) {
+        for (int j = jl; j < CT && j0 + j < N; j += 16) {
             float s = 0.f;
 #pragma unroll
-            for (int d = 0; d < CD; ++d) { float t = ai[d] - tb[j * CD + d]; s += t * t; }
+            for (int d = 0; d < CD; ++d) { float t = ai[d] - tb[j * LDT + d]; s += t * t; }
             float l = logit_of(sqrtf(s), expressive);
             if (j0 + j == i) lii = l;
             if (l > m) { z = z * expf(m - l) + 1.f; m = l; } else z += expf(l - m);
         }
     }
-    if (on) { rmax[i] = m; rsum[i] = z; loss_i[i] = (m + logf(z)) - lii; }
+    // combine the 16 lanes' (m, z): fixed xor tree
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        float m2 = __shfl_xor(m, o, 64), z2 = __shfl_xor(z, o, 64);
+        float mm = fmaxf(m, m2);
+        float za = (m == -INFINITY) ? 0.f : z * expf(m - mm), zb = (m2 == -INFINITY) ? 0.f : z2 * expf(m2 - mm);
+        // order the two operands by lane parity so both partners compute the identical sum
+        const bool low = ((threadIdx.x & o) == 0);
+        z = low ? za + zb : zb + za;
+        m = mm;
+    }
+    lii = group16_sum(lii);
+    if (on && jl == 0) { rmax[i] = m; rsum[i] = z; loss_i[i] = (m + logf(z)) - lii; }
     const float invN = 1.f / (float)N;
     float acc[CD], csum = 0.f;
+#pragma unroll
     for (int d = 0; d < CD; ++d) acc[d] = 0.f;
     for (int j0 = 0; j0 < N; j0 += CT) {
         __syncthreads();
-        for (int e = threadIdx.x; e < CT * CD; e += 64) tb[e] = (j0 + e / CD < N) ? b[(long)j0 * CD + e] : 0.f;
+        for (int e = threadIdx.x; e < CT * CD; e += 256) { int r = e / CD, d = e % CD; tb[r * LDT + d] = (j0 + r < N) ? b[(long)(j0 + r) * CD + d] : 0.f; }
         __syncthreads();
-        const int jn = min(CT, N - j0);
-        for (int j = 0; j < jn; ++j) {
+        for (int j = jl; j < CT && j0 + j < N; j += 16) {
             float s = 0.f;
 #pragma unroll
-            for (int d = 0; d < CD; ++d) { float t = ai[d] - tb[j * CD + d]; s += t * t; }
+            for (int d = 0; d < CD; ++d) { float t = ai[d] - tb[j * LDT + d]; s += t * t; }
             float dist = sqrtf(s);
             float l = logit_of(dist, expressive);
             float p = expf(l - m) / z - ((j0 + j == i) ? 1.f : 0.f);
             float c = dist > 0.f ? p * dlogit_of(dist, l, expressive) / dist * invN : 0.f;    // norm backward: 0 at dist = 0
             csum += c;
 #pragma unroll
-            for (int d = 0; d < CD; ++d) acc[d] += c * tb[j * CD + d];
+            for (int d = 0; d < CD; ++d) acc[d] += c * tb[j * LDT + d];
         }
     }
-    if (on)
+    csum = group16_sum(csum);
+#pragma unroll
+    for (int d = 0; d < CD; ++d) acc[d] = group16_sum(acc[d]);
+    if (on && jl == 0)
+#pragma unroll
         for (int d = 0; d < CD; ++d) dan[(long)i * CD + d] = ai[d] * csum - acc[d];
 }
 
-// thread per row j of b: d b_j = sum_i c_ij (b_j - a_i)
-__global__ __launch_bounds__(64) void contrastive_cols_kernel(const float* __restrict__ a, const float* __restrict__ b, int N,
-                                                              int expressive, const float* __restrict__ rmax,
-                                                              const float* __restrict__ rsum, float* __restrict__ dbn) {
-    __shared__ float ta[CT * CD];
+// 16 rows j of b per block: d b_j = sum_i c_ij (b_j - a_i)
+__global__ __launch_bounds__(256) void contrastive_cols_kernel(const float* __restrict__ a, const float* __restrict__ b, int N,
+                                                               int expressive, const float* __restrict__ rmax,
+                                                               const float* __restrict__ rsum, float* __restrict__ dbn) {
+    __shared__ float ta[CT * LDT];
     __shared__ float tm[CT], tz[CT];
-    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int slot = threadIdx.x >> 4, il = threadIdx.x & 15;
+    const int j = blockIdx.x * 16 + slot;
     const bool on = j < N;
     float bj[CD], acc[CD], csum = 0.f;
+#pragma unroll
     for (int d = 0; d < CD; ++d) { bj[d] = on ? b[(long)j * CD + d] : 0.f; acc[d] = 0.f; }
     const float invN = 1.f / (float)N;
     for (int i0 = 0; i0 < N; i0 += CT) {
         __syncthreads();
-        for (int e = threadIdx.x; e < CT * CD; e += 64) ta[e] = (i0 + e / CD < N) ? a[(long)i0 * CD + e] : 0.f;
+        for (int e = threadIdx.x; e < CT * CD; e += 256) { int r = e / CD, d = e % CD; ta[r * LDT + d] = (i0 + r < N) ? a[(long)(i0 + r) * CD + d] : 0.f; }
         if (threadIdx.x < CT) { int i = i0 + threadIdx.x; tm[threadIdx.x] = i < N ? rmax[i] : 0.f; tz[threadIdx.x] = i < N ? rsum[i] : 1.f; }
         __syncthreads();
-        const int in = min(CT, N - i0);
-        for (int i = 0; i < in; ++i) {
+        for (int i = il; i < CT && i0 + i < N; i += 16) {
             float s = 0.f;
 #pragma unroll
-            for (int d = 0; d < CD; ++d) { float t = ta[i * CD + d] - bj[d]; s += t * t; }
+            for (int d = 0; d < CD; ++d) { float t = ta[i * LDT + d] - bj[d]; s += t * t; }
             float dist = sqrtf(s);
             float l = logit_of(dist, expressive);
             float p = expf(l - tm[i]) / tz[i] - ((i0 + i == j) ? 1.f : 0.f);
             float c = dist > 0.f ? p * dlogit_of(dist, l, expressive) / dist * invN : 0.f;
             csum += c;
 #pragma unroll
-            for (int d = 0; d < CD; ++d) acc[d] += c * ta[i * CD + d];
+            for (int d = 0; d < CD; ++d) acc[d] += c * ta[i * LDT + d];
         }
     }
-    if (on)
+    csum = group16_sum(csum);
+#pragma unroll
+    for (int d = 0; d < CD; ++d) acc[d] = group16_sum(acc[d]);
+    if (on && il == 0)
+#pragma unroll
         for (int d = 0; d < CD; ++d) dbn[(long)j * CD + d] = bj[d] * csum - acc[d];
 }
 
@@ -321,8 +354,8 @@ int ha2g_contrastive_f32(const float* a, const float* b, int N, int expressive, 
     float* na = dbn + (long)N * CD; float* nbv = na + N; float* rmax = nbv + N; float* rsum = rmax + N; float* li = rsum + N;
     hipLaunchKernelGGL(rownorm_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, a, an, na, N);
     hipLaunchKernelGGL(rownorm_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, b, bn, nbv, N);
-    hipLaunchKernelGGL(contrastive_rows_kernel, dim3(ceil_div(N, 64)), dim3(64), 0, st, an, bn, N, expressive, rmax, rsum, li, dan);
-    hipLaunchKernelGGL(contrastive_cols_kernel, dim3(ceil_div(N, 64)), dim3(64), 0, st, an, bn, N, expressive, rmax, rsum, dbn);
+    hipLaunchKernelGGL(contrastive_rows_kernel, dim3(ceil_div(N, 16)), dim3(256), 0, st, an, bn, N, expressive, rmax, rsum, li, dan);
+    hipLaunchKernelGGL(contrastive_cols_kernel, dim3(ceil_div(N, 16)), dim3(256), 0, st, an, bn, N, expressive, rmax, rsum, dbn);
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, li, (long)N, loss, 1.f / (float)N, 0);
     hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, an, na, dan, da, N);
     hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, bn, nbv, dbn, db, N);

@@ -18,34 +18,50 @@ extern "C" int ha2g_abi_version(void) { return 1; }
 
 namespace {
 
-// out[c] = beta*out[c] + sum_r X[r*ld + c]; one block per 64 columns, 4 waves stride the rows, fixed-order
-// LDS combine (deterministic).
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ld, long rows, int cols,
-                                                     float* __restrict__ out, float beta) {
-    __shared__ double part[4][64];
+// out[c] = beta*out[c] + sum_r X[r*ld + c].  Two levels, both fixed-order (deterministic): grid (col chunks of 64,
+// row chunks); each block's 4 waves stride its row chunk with double accumulators, combine through LDS and write one
+// partial per (row chunk, column); a second kernel adds the row-chunk partials per column in ascending order.
+constexpr int CS_MAXCHUNK = 256;
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long ld, long rows, int cols,
+                                                             double* __restrict__ part) {
+    __shared__ double sh[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;      // HBM-bound: double accumulation is free and keeps bias grads exact
+    const long per = (rows + gridDim.y - 1) / gridDim.y;
+    const long rbeg = (long)blockIdx.y * per, rend = min(rows, rbeg + per);
+    double s0 = 0.0, s1 = 0.0;
     if (c < cols) {
-        long r = w;
-        for (; r + 12 < rows; r += 16) {
-            s0 += X[r * ld + c]; s1 += X[(r + 4) * ld + c]; s2 += X[(r + 8) * ld + c]; s3 += X[(r + 12) * ld + c];
-        }
-        for (; r < rows; r += 4) s0 += X[r * ld + c];
+        long r = rbeg + w;
+        for (; r + 4 < rend; r += 8) { s0 += X[r * ld + c]; s1 += X[(r + 4) * ld + c]; }
+        for (; r < rend; r += 4) s0 += X[r * ld + c];
     }
-    part[w][lane] = (s0 + s1) + (s2 + s3);
+    sh[w][lane] = s0 + s1;
     __syncthreads();
-    if (w == 0 && c < cols) {
-        double s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-        out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)s;
-    }
+    if (w == 0 && c < cols) part[(long)blockIdx.y * cols + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+__global__ void colsum_final_kernel(const double* __restrict__ part, int nchunk, int cols, float* __restrict__ out, float beta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    double s = 0.0;
+    for (int k = 0; k < nchunk; ++k) s += part[(long)k * cols + c];
+    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)s;
 }
 
 }  // namespace
 
-extern "C" int ha2g_colsum_f32(const float* X, long ld, long rows, int cols, float* out, float beta, void* stream) {
+// ws: >= CS_MAXCHUNK*cols doubles of scratch (ha2g_colsum_workspace_bytes)
+extern "C" long ha2g_colsum_workspace_bytes(int cols) { return (long)CS_MAXCHUNK * cols * 8; }
+extern "C" int ha2g_colsum_f32(const float* X, long ld, long rows, int cols, float* out, float beta, float* ws, void* stream) {
     if (cols <= 0) return 0;
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0, (hipStream_t)stream, X, ld, rows, cols, out, beta);
+    HA2G_REQUIRE(ws != nullptr, "colsum: workspace required");
+    hipStream_t st = (hipStream_t)stream;
+    int cchunks = ceil_div(cols, 64);
+    long want = rows / 64;                                // >= 64 rows per block
+    int nchunk = (int)(want < 1 ? 1 : (want > CS_MAXCHUNK ? CS_MAXCHUNK : want));
+    while (nchunk > 1 && (long)nchunk * cchunks > 2048) nchunk /= 2;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cchunks, nchunk), dim3(256), 0, st, X, ld, rows, cols, (double*)ws);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, st, (const double*)ws, nchunk, cols, out, beta);
     HA2G_CHECK_LAUNCH("colsum");
     return 0;
 }

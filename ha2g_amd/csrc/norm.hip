@@ -71,13 +71,22 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
     block_col_reduce(a, b, C4, part, C, lds);
 }
 
-__global__ void bn_stats_final_kernel(const double* __restrict__ part, int nblk, long rows, int C, const float* __restrict__ x,
-                                      float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rmean,
-                                      float* __restrict__ rvar, float momentum, float eps) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+// final reductions: one wave per column; lanes stride the block partials, fixed-order shuffle tree (deterministic)
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ part, int nblk, long rows, int C,
+                                                             const float* __restrict__ x, float* __restrict__ mean,
+                                                             float* __restrict__ invstd, float* __restrict__ rmean,
+                                                             float* __restrict__ rvar, float momentum, float eps) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) { s1 += part[((long)b * 2) * C + c]; s2 += part[((long)b * 2 + 1) * C + c]; }
+    for (int b = lane; b < nblk; b += 64) { s1 += part[((long)b * 2) * C + c]; s2 += part[((long)b * 2 + 1) * C + c]; }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if (lane != 0) return;
     double n = (double)rows, m1 = s1 / n;
     double var = s2 / n - m1 * m1;
     if (var < 0.0) var = 0.0;
@@ -90,13 +99,14 @@ __global__ void bn_stats_final_kernel(const double* __restrict__ part, int nblk,
     }
 }
 
-__global__ void pair_final_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ out0, float* __restrict__ out1) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void pair_final_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ out0,
+                                                         float* __restrict__ out1) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) { s1 += part[((long)b * 2) * C + c]; s2 += part[((long)b * 2 + 1) * C + c]; }
-    out0[c] = (float)s1;
-    out1[c] = (float)s2;
+    for (int b = lane; b < nblk; b += 64) { s1 += part[((long)b * 2) * C + c]; s2 += part[((long)b * 2 + 1) * C + c]; }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if (lane == 0) { out0[c] = (float)s1; out1[c] = (float)s2; }
 }
 
 // y = (x - mean) * invstd * gamma + beta ; act: 0 none, 2 leaky-relu(0.01)
@@ -235,7 +245,7 @@ int ha2g_bn_stats_f32(const float* x, long rows, int C, float* mean, float* invs
     hipStream_t st = (hipStream_t)stream;
     int nb = chunk_blocks(rows);
     hipLaunchKernelGGL(col_partial_kernel<0>, dim3(nb), dim3(256), 0, st, x, nullptr, nullptr, nullptr, rows, C, (double*)ws);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, (const double*)ws, nb, rows, C, x, mean, invstd, running_mean,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, rows, C, x, mean, invstd, running_mean,
                        running_var, momentum, eps);
     HA2G_CHECK_LAUNCH("bn_stats");
     return 0;
@@ -255,7 +265,7 @@ int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const fl
     hipStream_t st = (hipStream_t)stream;
     int nb = chunk_blocks(rows);
     hipLaunchKernelGGL(col_partial_kernel<1>, dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
-    hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, (const double*)ws, nb, C, dbeta, dgamma);
+    hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, C, dbeta, dgamma);
     if (dx)
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, st, dy, x, mean, invstd, gamma, dbeta,
                            dgamma, dx, rows, C);

@@ -155,6 +155,7 @@ class BiGRU(nn.Module):
         if not ops.gru_supported(hidden_size):
             raise ValueError('ha2g_amd: GRU hidden size %d has no HIP instantiation (300, 64, 32)' % hidden_size)
         self.input_size, self.hidden_size, self.num_layers, self.dropout = input_size, hidden_size, num_layers, dropout
+        self.grad_slice = None        # (first_row, n_rows) hint set by the fused-chain train step
         self._names = []
         k = 1.0 / math.sqrt(hidden_size)
         for l in range(num_layers):
@@ -175,7 +176,7 @@ class BiGRU(nn.Module):
         if self.training and self.dropout > 0 and self.num_layers > 1:
             masks = [ops.dropout_mask((x.shape[0], x.shape[1], 2 * self.hidden_size), self.dropout, x.device)
                      for _ in range(self.num_layers - 1)]
-        y = ops.bigru(x, [getattr(self, n) for n in self._names], self.hidden_size, masks)
+        y = ops.bigru(x, [getattr(self, n) for n in self._names], self.hidden_size, masks, self.grad_slice)
         return y, None
 
 

@@ -28,6 +28,38 @@ def workspace(device):
     return _ws[key]
 
 
+class KernelTimer:
+    """HIP-event timing of selected kernel launches on the stream they are launched on (bench.py's roofline leg)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.recs = {}
+
+    def reset(self):
+        self.recs = {}
+
+    def launch(self, name, fn, meta=0):
+        if not self.enabled:
+            return fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = fn()
+        e.record()
+        self.recs.setdefault(name, []).append((s, e, meta))
+        return r
+
+    def summary(self):
+        """{name: (launches, mean microseconds, meta of the last launch)}; call after a device synchronize."""
+        out = {}
+        for k, v in self.recs.items():
+            us = [s.elapsed_time(e) * 1e3 for s, e, _ in v]
+            out[k] = (len(us), sum(us) / len(us), v[-1][2])
+        return out
+
+
+ktimer = KernelTimer()
+
+
 def _p(t):
     return 0 if t is None else t.data_ptr()
 
@@ -72,7 +104,8 @@ def colsum(x, out=None, beta=0.0):
     _chk2d(x)
     if out is None:
         out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
-    check(lib.ha2g_colsum_f32(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], out.data_ptr(), beta, _stream()))
+    check(lib.ha2g_colsum_f32(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], out.data_ptr(), beta,
+                              workspace(x.device).data_ptr(), _stream()))
     return out
 
 
@@ -207,7 +240,8 @@ class EmbeddingFunction(torch.autograd.Function):
         (tok,) = ctx.saved_tensors
         dw = torch.zeros(ctx.wshape, dtype=torch.float32, device=dy.device)
         dy = dy.contiguous()
-        check(lib.ha2g_embedding_bwd_f32(tok.data_ptr(), dy.data_ptr(), dw.data_ptr(), tok.numel(), ctx.wshape[1], _stream()))
+        check(lib.ha2g_embedding_bwd_f32(tok.data_ptr(), dy.data_ptr(), dw.data_ptr(), tok.numel(), ctx.wshape[1], 0,
+                                         workspace(dy.device).data_ptr(), _stream()))
         return None, dw
 
 
@@ -427,12 +461,14 @@ def gru_supported(H):
 
 
 class BiGRUFunction(torch.autograd.Function):
-    """Stacked bidirectional GRU (batch_first, h0 = 0).  forward(x, masks, H, *weights): weights in torch
+    """Stacked bidirectional GRU (batch_first, h0 = 0).  forward(x, masks, H, grad_slice, *weights): weights in torch
     `_flat_weights` order (per layer, per direction: w_ih, w_hh, b_ih, b_hh); masks = tuple of pre-scaled
-    dropout masks for the outputs of layers 0..L-2 (or None)."""
+    dropout masks for the outputs of layers 0..L-2 (or None); grad_slice = (first_row, n_rows) promises that only
+    those batch rows receive a non-zero output gradient (fused-chain step), so BPTT and the weight-gradient GEMMs
+    run on that slice alone."""
 
     @staticmethod
-    def forward(ctx, x, masks, H, *weights):
+    def forward(ctx, x, masks, H, grad_slice, *weights):
         B, T, _ = x.shape
         L = len(weights) // 8
         dev = x.device
@@ -454,14 +490,15 @@ class BiGRUFunction(torch.autograd.Function):
             check(lib.ha2g_gru_pack_whh(w[5].data_ptr(), pk[1].data_ptr(), pk[3].data_ptr(), H, st))
             y = torch.empty(B, T, 2 * H, dtype=torch.float32, device=dev)
             rs = torch.empty(B, T, 2, 4, H, dtype=torch.float32, device=dev) if need_grad else None
-            check(lib.ha2g_gru_layer_fwd(gi.data_ptr(), pk.data_ptr(), w[3].data_ptr(), w[7].data_ptr(), y.data_ptr(), _p(rs),
-                                         B, T, H, st))
+            ktimer.launch('gru_layer_fwd' if (H == 300 and l > 0) else 'gru_layer_fwd_other',
+                          lambda: check(lib.ha2g_gru_layer_fwd(gi.data_ptr(), pk.data_ptr(), w[3].data_ptr(), w[7].data_ptr(),
+                                                               y.data_ptr(), _p(rs), B, T, H, st)), B)
             saved.append((inp, y, rs))
             packs.append(pk)
             inp = y
             if masks is not None and l < L - 1 and masks[l] is not None:
                 inp = eltwise(OP_MUL, y, masks[l])
-        ctx.H, ctx.L, ctx.masks = H, L, masks
+        ctx.H, ctx.L, ctx.masks, ctx.grad_slice = H, L, masks, grad_slice
         ctx.saved_bufs = saved
         ctx.packs = packs
         ctx.save_for_backward(*weights)
@@ -473,17 +510,23 @@ class BiGRUFunction(torch.autograd.Function):
         weights = ctx.saved_tensors
         st = _stream()
         dy = dy.contiguous()
+        Bfull = dy.shape[0]
+        sl = slice(None)
+        if ctx.grad_slice is not None and ctx.grad_slice[1] < Bfull:
+            sl = slice(ctx.grad_slice[0], ctx.grad_slice[0] + ctx.grad_slice[1])
+            dy = dy[sl]                                   # leading-dim slice: still contiguous
         B, T, _ = dy.shape
         dev = dy.device
         grads = [None] * (8 * L)
         for l in range(L - 1, -1, -1):
-            inp, y, rs = ctx.saved_bufs[l]
+            inp, y, rs = (t[sl] for t in ctx.saved_bufs[l])
             w = weights[8 * l:8 * l + 8]
             if masks is not None and l < L - 1 and masks[l] is not None:
-                dy = eltwise(OP_MUL, dy, masks[l])
+                dy = eltwise(OP_MUL, dy, masks[l][sl])
             dg = torch.empty(B * T, 8 * H, dtype=torch.float32, device=dev)        # [dir][r z n hn]
-            check(lib.ha2g_gru_layer_bwd(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), ctx.packs[l][2].data_ptr(), dg.data_ptr(),
-                                         B, T, H, st))
+            ktimer.launch('gru_layer_bwd' if H == 300 else 'gru_layer_bwd_other',
+                          lambda: check(lib.ha2g_gru_layer_bwd(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), ctx.packs[l][2].data_ptr(),
+                                                               dg.data_ptr(), B, T, H, st)), B)
             K = inp.shape[2]
             x2 = inp.view(B * T, K)
             # h_prev per direction: forward dir sees y[t-1], reverse dir sees y[t+1]; zero at the sequence ends
@@ -511,12 +554,16 @@ class BiGRUFunction(torch.autograd.Function):
                 colsum(dg[:, o + 3 * H:o + 4 * H], out=dbhh[2 * H:])
                 grads[8 * l + 4 * d + 3] = dbhh
             dy = dx.view(B, T, K) if need_dx else None
+        if dy is not None and B != Bfull:
+            full = torch.zeros(Bfull, T, dy.shape[2], dtype=torch.float32, device=dev)
+            full[sl] = dy
+            dy = full
         ctx.saved_bufs = None
-        return (dy, None, None) + tuple(grads)
+        return (dy, None, None, None) + tuple(grads)
 
 
-def bigru(x, weights, H, masks=None):
-    return BiGRUFunction.apply(x, masks, H, *weights)
+def bigru(x, weights, H, masks=None, grad_slice=None):
+    return BiGRUFunction.apply(x, masks, H, grad_slice, *weights)
 
 
 # ------------------------------------------------------------------------------------------------

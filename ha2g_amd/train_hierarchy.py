@@ -110,7 +110,14 @@ def train_iter_hierarchy(args, epoch, in_text_padded, in_spec, target, vid_indic
         for lvl in range(3):
             f = linear_blend_feat[lvl]
             blend_all.append(torch.cat([f if b == 'main' else f.detach() for b in blocks]) if k > 1 else f)
-        outs_all, z_all, mu_all, lv_all = _chain(args, gens, [rep(t) for t in targets], rep(in_text_padded), blend_all, vids_all)
+        main_at = blocks.index('main')
+        for g in gens:                                   # only the main block's rows carry gradient through the GRUs
+            g.gru.grad_slice = (main_at * B, B) if k > 1 else None
+        try:
+            outs_all, z_all, mu_all, lv_all = _chain(args, gens, [rep(t) for t in targets], rep(in_text_padded), blend_all, vids_all)
+        finally:
+            for g in gens:
+                g.gru.grad_slice = None
         fused = {}
         for i, b in enumerate(blocks):
             sl = slice(i * B, (i + 1) * B)

@@ -244,7 +244,7 @@ class WavEncoderFunction(torch.autograd.Function):
             G['speaker_embedding.1.bias'] = ops.colsum(dz)
             dze = ops.gemm(dz, P['speaker_embedding.1.weight'])
             demb = torch.zeros_like(P['speaker_embedding.0.weight'])
-            check(lib.ha2g_embedding_bwd_f32(vid.data_ptr(), dze.data_ptr(), demb.data_ptr(), B, 16, _stream()))
+            check(lib.ha2g_embedding_bwd_f32(vid.data_ptr(), dze.data_ptr(), demb.data_ptr(), B, 16, -1, workspace(dev).data_ptr(), _stream()))
             G['speaker_embedding.0.weight'] = demb
         # ---- taps backward -> gradient w.r.t. the three trunk features ----
         dfeat = [None, None, None, None]

@@ -31,8 +31,9 @@ const char* ha2g_last_error(void);
 int ha2g_gemm_f32(int transa, int transb, int M, int N, int K, float alpha, const float* A, long lda, const float* B,
                   long ldb, float beta, float* C, long ldc, const float* bias, int act, float* ws, long ws_bytes,
                   void* stream);
-/* out[c] = beta*out[c] + sum_r X[r*ld + c]  (bias gradients) */
-int ha2g_colsum_f32(const float* X, long ld, long rows, int cols, float* out, float beta, void* stream);
+/* out[c] = beta*out[c] + sum_r X[r*ld + c]  (bias gradients); ws >= ha2g_colsum_workspace_bytes(cols) */
+long ha2g_colsum_workspace_bytes(int cols);
+int ha2g_colsum_f32(const float* X, long ld, long rows, int cols, float* out, float beta, float* ws, void* stream);
 
 /* ---- NHWC convolution as implicit GEMM (audio encoder: model/ResNetSE34V2.py:27-42,96-116,
  *      model/ResNetBlocks.py:12-15,24-29).  x [N,H,W,Cin], w [Cout][KH][KW][Cin], y [N,OH,OW,Cout]. ---- */
@@ -90,7 +91,8 @@ int ha2g_blend_bwd_f32(const float* dblend, const float* dw_ext, const float* w,
 
 /* ---- text encoder pieces (model/hierarchy_net.py:48-52, model/tcn.py:16-46, torch weight_norm) ---- */
 int ha2g_embedding_fwd_f32(const long* tok, const float* W, float* out, long n, int C, void* stream);
-int ha2g_embedding_bwd_f32(const long* tok, const float* dY, float* dW, int n, int C, void* stream);   /* dW += */
+/* dW += ; heavy = most frequent id (the padding id 0), summed by a 2-level masked column sum; ws >= 64*C doubles */
+int ha2g_embedding_bwd_f32(const long* tok, const float* dY, float* dW, int n, int C, long heavy, float* ws, void* stream);
 int ha2g_im2col1d_f32(const float* x, float* col, int B, int T, int C, int k, int dil, int pad_left, int To, void* stream);
 int ha2g_col2im1d_f32(const float* dcol, float* dx, int B, int T, int C, int k, int dil, int pad_left, int To, void* stream);
 int ha2g_weight_norm_fwd_f32(const float* g, const float* v, float* w, float* norm, int Cout, int n, void* stream);
