@@ -40,12 +40,16 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     __syncthreads();
     if (w == 0 && c < cols) part[(long)blockIdx.y * cols + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
-__global__ void colsum_final_kernel(const double* __restrict__ part, int nchunk, int cols, float* __restrict__ out, float beta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per column: lanes stride the row-chunk partials, fixed xor tree
+__global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ part, int nchunk, int cols, float* __restrict__ out,
+                                                           float beta) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= cols) return;
     double s = 0.0;
-    for (int k = 0; k < nchunk; ++k) s += part[(long)k * cols + c];
-    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)s;
+    for (int k = lane; k < nchunk; k += 64) s += part[(long)k * cols + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) out[c] = (beta != 0.f ? beta * out[c] : 0.f) + (float)s;
 }
 
 }  // namespace
@@ -61,7 +65,7 @@ extern "C" int ha2g_colsum_f32(const float* X, long ld, long rows, int cols, flo
     int nchunk = (int)(want < 1 ? 1 : (want > CS_MAXCHUNK ? CS_MAXCHUNK : want));
     while (nchunk > 1 && (long)nchunk * cchunks > 2048) nchunk /= 2;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(cchunks, nchunk), dim3(256), 0, st, X, ld, rows, cols, (double*)ws);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, st, (const double*)ws, nchunk, cols, out, beta);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 4)), dim3(256), 0, st, (const double*)ws, nchunk, cols, out, beta);
     HA2G_CHECK_LAUNCH("colsum");
     return 0;
 }

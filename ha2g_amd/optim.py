@@ -69,9 +69,5 @@ class FusedAdam(torch.optim.Optimizer):
 
     def allreduce_grads(self, group=None, async_op=False):
         """Data-parallel: average the flat gradient buffer over ranks (one RCCL all-reduce over xGMI)."""
-        import torch.distributed as dist
-        ws = dist.get_world_size(group)
-        if ws == 1:
-            return None
-        self.flat_g.div_(ws)
-        return dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        from . import ddp
+        return ddp.average_(self.flat_g, group, async_op)

@@ -60,17 +60,8 @@ def _chain(args, gens, targets, in_text, blend, vids):
 
 
 def _allreduce(optimizers):
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        for o in optimizers:
-            if hasattr(o, 'allreduce_grads'):
-                o.allreduce_grads()
-            else:
-                for grp in o.param_groups:
-                    for p in grp['params']:
-                        if p.grad is not None:
-                            p.grad.div_(dist.get_world_size())
-                            dist.all_reduce(p.grad)
+    from . import ddp
+    ddp.average_module_grads_(optimizers)
 
 
 def train_iter_hierarchy(args, epoch, in_text_padded, in_spec, target, vid_indices,
