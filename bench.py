@@ -58,6 +58,7 @@ def main():
     ap.add_argument('--epoch', type=int, default=11, help='> loss_warmup (10) = GAN phase; 0 = warm-up phase')
     ap.add_argument('--n-words', type=int, default=20000)
     ap.add_argument('--n-spk', type=int, default=1371)
+    ap.add_argument('--expressive', action='store_true', help='config_expressive/hierarchy.yml: 6 levels, 126-d pose (BASELINE config 3)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=64)
     a = ap.parse_args()
@@ -77,12 +78,15 @@ def main():
     from ha2g_amd.train import HierarchyTrainer
 
     torch.manual_seed(0)
-    args = hierarchy_args()                                   # config/hierarchy.yml, dropout 0.3
-    tr = HierarchyTrainer(args, Vocab(a.n_words), Vocab(a.n_spk), 27, dev)
+    from ha2g_amd import schema
+    P = 126 if a.expressive else 27
+    args = hierarchy_args(expressive=a.expressive)            # config[_expressive]/hierarchy.yml, dropout 0.3
+    tr = HierarchyTrainer(args, Vocab(a.n_words), Vocab(a.n_spk), P, dev,
+                          pose_dims=schema.EXPRESSIVE_POSE_DIMS if a.expressive else schema.GESTURE_POSE_DIMS)
     if world > 1:
         tr.broadcast_parameters(0)
     ops.rng.seed(dev, 1234 + rank)
-    text, spec, target, vid = (torch.from_numpy(x).to(dev) for x in proc.make_batch(a.batch, 27, a.n_words, a.n_spk, 1234 + rank))
+    text, spec, target, vid = (torch.from_numpy(x).to(dev) for x in proc.make_batch(a.batch, P, a.n_words, a.n_spk, 1234 + rank))
 
     def sync():
         if world > 1:
@@ -125,13 +129,13 @@ def main():
         out = dict(metric='pose-frames/sec (train step) for hierarchy.yml B=128 T=34', value=round(value, 1), unit='pose-frames/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload='config/hierarchy.yml TED-Gesture hierarchy train step, B=%d per GPU, T=34, 27-d pose, '
+                   config=dict(workload='%s hierarchy train step, B=%d per GPU, T=34, %d-d pose, '
                                         'spec (128,70), n_words=%d, n_spk=%d, dropout 0.3, %s' % (
-                                            a.batch, a.n_words, a.n_spk, 'GAN phase (epoch %d > loss_warmup)' % a.epoch
+                                            'config_expressive/hierarchy.yml TED-Expressive' if a.expressive else 'config/hierarchy.yml TED-Gesture', a.batch, P, a.n_words, a.n_spk, 'GAN phase (epoch %d > loss_warmup)' % a.epoch
                                             if a.epoch > args.loss_warmup else 'warm-up phase (epoch %d)' % a.epoch),
                                global_batch=a.batch * world, parallelism='dp%d' % world),
                    roofline=roof, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not a.expressive:
             out['cpu_baseline'] = cpu_baseline(a.cpu_batch, a.epoch, a.n_words, a.n_spk)
         print(json.dumps(out))
     if world > 1:

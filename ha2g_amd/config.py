@@ -77,3 +77,89 @@ PHYS_GESTURE = (
     (0.0018439559498801827, 0.013570506125688553, 0.0017794054001569748, 0.013684595935046673),
 )
 PHYS_GESTURE_PAIRS = ((3, 4), (4, 5), (6, 7), (7, 8))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Hierarchy tables, restated as data.  Column units; `dst` slices index the (P_k + 1)-wide pre_seq of
+# level k, `src` slices the P_{k-1}-wide output of level k-1 -- python slice semantics, negative values included, which
+# is what reproduces the expressive step's one-column shift of the 15 head values
+# (train_hierarchy_expressive.py:164,172,180,196,212: `pre_seq_k[:, 4:, -15:] = out[:, 4:, -15:]`).
+# ----------------------------------------------------------------------------------------------------------------------
+
+def _cols(*ranges):
+    out = []
+    for a, b in ranges:
+        out += list(range(a, b))
+    return out
+
+
+GESTURE_SPEC = dict(
+    name='gesture', pose_dims=(15, 21, 27), contrastive_expressive=False,
+    # train_eval/train_hierarchy.py:86-88
+    level_cols=(_cols((0, 12), (18, 21)), _cols((0, 15), (18, 24)), _cols((0, 27))),
+    # train_eval/train_hierarchy.py:161-162,168-169
+    scatter=((), ((slice(0, 12), slice(0, 12)), (slice(15, 18), slice(12, 15))),
+             ((slice(0, 15), slice(0, 15)), (slice(18, 24), slice(15, 21)))),
+    phys_pairs=PHYS_GESTURE_PAIRS, phys_avg=PHYS_GESTURE[0], phys_var=PHYS_GESTURE[1], palm=(),
+)
+
+_HEAD = 126 - 15
+# physical prior of the 42-bone skeleton + two palm normals (indices 42, 43): train_hierarchy_expressive.py:9-70,429-447
+PHYS_EXPRESSIVE_PAIRS = (
+    (0, 1), (0, 2), (1, 3), (3, 4), (5, 6), (6, 7), (8, 9), (9, 10), (11, 12), (12, 13), (14, 15), (15, 16),
+    (17, 18), (18, 19), (17, 5), (5, 8), (8, 14), (14, 11), (2, 20), (20, 21), (22, 23), (23, 24), (25, 26),
+    (26, 27), (28, 29), (29, 30), (31, 32), (32, 33), (34, 35), (35, 36), (34, 22), (22, 25), (25, 31), (31,
+    28), (0, 37), (37, 38), (37, 39), (38, 40), (39, 41), (4, 42), (21, 43)
+)
+PHYS_EXPRESSIVE_AVG = (
+    0.5969760417938232, 0.572796642780304, 0.348366379737854, 0.5536502599716187, 0.13027764856815338,
+    0.2801012694835663, 0.21510013937950134, 0.2457924336194992, 0.25812962651252747, 0.1696397364139557,
+    0.22138600051403046, 0.2232128530740738, 0.10013844072818756, 0.13465291261672974, 0.15643933415412903,
+    0.0757620558142662, 0.08111366629600525, 0.07266224175691605, 0.28242993354797363, 0.5088332295417786,
+    0.13428474962711334, 0.31135401129722595, 0.21646016836166382, 0.26498687267303467, 0.2691807448863983,
+    0.18528689444065094, 0.23011097311973572, 0.23511438071727753, 0.08650383353233337, 0.11938644200563431,
+    0.16712385416030884, 0.07711927592754364, 0.08256717771291733, 0.07396762818098068, 0.2504960894584656,
+    0.508758008480072, 0.4859846234321594, 0.30816879868507385, 0.2943730056285858, 0.572842538356781,
+    0.4471983015537262
+)
+PHYS_EXPRESSIVE_VAR = (
+    0.00028363385354168713, 0.00029294739942997694, 0.001516797230578959, 0.010948357172310352,
+    0.0025349585339426994, 0.009562775492668152, 0.008637933991849422, 0.008715483359992504,
+    0.012276478111743927, 0.005242602434009314, 0.008161756210029125, 0.007505195681005716,
+    0.002306767040863633, 0.0008198867435567081, 9.477637649979442e-05, 4.9160284106619656e-05,
+    5.3111481975065544e-05, 4.9043188482755795e-05, 0.0013721085852012038, 0.010581498965620995,
+    0.00196851696819067, 0.006986899301409721, 0.006110062822699547, 0.0074407304637134075,
+    0.010817521251738071, 0.005984380841255188, 0.006697201170027256, 0.00707469554618001,
+    0.0020931533072143793, 0.0006661304505541921, 9.530011448077857e-05, 4.7486370021943e-05,
+    5.157381747267209e-05, 4.733635432785377e-05, 0.00095974380383268, 0.00023575413797516376,
+    0.0002760167117230594, 2.6063793484354392e-05, 2.591621523606591e-05, 0.01612936705350876,
+    0.013571133837103844
+)
+
+EXPRESSIVE_SPEC = dict(
+    name='expressive', pose_dims=(24, 30, 36, 66, 96, 126), contrastive_expressive=True,
+    # train_eval/train_hierarchy_expressive.py:140-145
+    level_cols=(
+        _cols((0, 9), (_HEAD, 126)),
+        _cols((0, 12), (60, 63), (_HEAD, 126)),
+        _cols((0, 15), (60, 66), (_HEAD, 126)),
+        _cols((0, 18), (24, 27), (33, 36), (42, 45), (51, 54), (60, 69), (75, 78), (84, 87), (93, 96), (102, 105), (_HEAD, 126)),
+        _cols((0, 21), (24, 30), (33, 39), (42, 48), (51, 57), (60, 72), (75, 81), (84, 90), (93, 99), (102, 108), (_HEAD, 126)),
+        _cols((0, 126)),
+    ),
+    # train_eval/train_hierarchy_expressive.py:163-164,170-172,178-180,186-196,202-212
+    scatter=(
+        (),
+        ((slice(0, 9), slice(0, 9)), (slice(-15, None), slice(-15, None))),
+        ((slice(0, 12), slice(0, 12)), (slice(15, 18), slice(12, 15)), (slice(-15, None), slice(-15, None))),
+        ((slice(0, 15), slice(0, 15)), (slice(30, 36), slice(15, 21)), (slice(-15, None), slice(-15, None))),
+        ((slice(0, 18), slice(0, 18)), (slice(21, 24), slice(18, 21)), (slice(27, 30), slice(21, 24)), (slice(33, 36), slice(24, 27)),
+         (slice(39, 42), slice(27, 30)), (slice(45, 54), slice(30, 39)), (slice(57, 60), slice(39, 42)), (slice(63, 66), slice(42, 45)),
+         (slice(69, 72), slice(45, 48)), (slice(75, 78), slice(48, 51)), (slice(-15, None), slice(-15, None))),
+        ((slice(0, 21), slice(0, 21)), (slice(24, 30), slice(21, 27)), (slice(33, 39), slice(27, 33)), (slice(42, 48), slice(33, 39)),
+         (slice(51, 57), slice(39, 45)), (slice(60, 72), slice(45, 57)), (slice(75, 81), slice(57, 63)), (slice(84, 90), slice(63, 69)),
+         (slice(93, 99), slice(69, 75)), (slice(102, 108), slice(75, 81)), (slice(-15, None), slice(-15, None))),
+    ),
+    phys_pairs=PHYS_EXPRESSIVE_PAIRS, phys_avg=PHYS_EXPRESSIVE_AVG, phys_var=PHYS_EXPRESSIVE_VAR,
+    palm=((11, 17), (28, 34)),          # synthetic bones 42, 43 = cross products of these raw direction vectors
+)

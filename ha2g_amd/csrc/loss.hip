@@ -73,11 +73,39 @@ __global__ __launch_bounds__(256) void divreg_kernel(const float* __restrict__ o
     }
 }
 
-// ---- physical angle prior (train_hierarchy.py:242-262): one thread per (b,t) row -------------------------
-constexpr int MAXV = 48;     // bones (+2 palm normals for the expressive skeleton)
+// ---- physical angle prior (train_hierarchy.py:242-262; expressive :421-447): one thread per (b,t) row ------------
+// Bones >= nb are synthetic "palm normals": cross products of two raw (un-normalised) bone vectors, appended before
+// the normalisation exactly as the reference concatenates them (train_hierarchy_expressive.py:430-432).
+constexpr int MAXV = 48;
+struct PalmSpec { int n; int a[4]; int b[4]; };
+
+__device__ __forceinline__ void phys_vec(const float* o, const float* md, int nb, const PalmSpec& pm, int idx, float* v) {
+    if (idx < nb) {
+        for (int c = 0; c < 3; ++c) v[c] = o[idx * 3 + c] + md[idx * 3 + c];
+    } else {
+        const int pa = pm.a[idx - nb], pb = pm.b[idx - nb];
+        float u[3], w[3];
+        for (int c = 0; c < 3; ++c) { u[c] = o[pa * 3 + c] + md[pa * 3 + c]; w[c] = o[pb * 3 + c] + md[pb * 3 + c]; }
+        v[0] = u[1] * w[2] - u[2] * w[1]; v[1] = u[2] * w[0] - u[0] * w[2]; v[2] = u[0] * w[1] - u[1] * w[0];
+    }
+}
+// scatter d L / d v (v = raw vector of bone idx) into the pose gradient; c = u x w  =>  dL/du = w x g, dL/dw = g x u
+__device__ __forceinline__ void phys_grad(const float* o, const float* md, int nb, const PalmSpec& pm, int idx, const float* gv, float* g) {
+    if (idx < nb) {
+        for (int c = 0; c < 3; ++c) g[idx * 3 + c] += gv[c];
+    } else {
+        const int pa = pm.a[idx - nb], pb = pm.b[idx - nb];
+        float u[3], w[3];
+        for (int c = 0; c < 3; ++c) { u[c] = o[pa * 3 + c] + md[pa * 3 + c]; w[c] = o[pb * 3 + c] + md[pb * 3 + c]; }
+        g[pa * 3 + 0] += w[1] * gv[2] - w[2] * gv[1]; g[pa * 3 + 1] += w[2] * gv[0] - w[0] * gv[2]; g[pa * 3 + 2] += w[0] * gv[1] - w[1] * gv[0];
+        g[pb * 3 + 0] += gv[1] * u[2] - gv[2] * u[1]; g[pb * 3 + 1] += gv[2] * u[0] - gv[0] * u[2]; g[pb * 3 + 2] += gv[0] * u[1] - gv[1] * u[0];
+    }
+}
+
 __global__ __launch_bounds__(64) void phys_kernel(const float* __restrict__ out, const float* __restrict__ mean_dir, int rows,
-                                                  int nb, const int* __restrict__ pairs, int npairs, const float* __restrict__ avg,
-                                                  const float* __restrict__ var, float* __restrict__ per_row, float* __restrict__ dout) {
+                                                  int nb, PalmSpec pm, const int* __restrict__ pairs, int npairs,
+                                                  const float* __restrict__ avg, const float* __restrict__ var,
+                                                  float* __restrict__ per_row, float* __restrict__ dout) {
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= rows) return;
     const int P = nb * 3;
@@ -89,7 +117,8 @@ __global__ __launch_bounds__(64) void phys_kernel(const float* __restrict__ out,
     for (int k = 0; k < npairs; ++k) {
         const int a = pairs[2 * k], b = pairs[2 * k + 1];
         float va[3], vb[3];
-        for (int c = 0; c < 3; ++c) { va[c] = o[a * 3 + c] + mean_dir[a * 3 + c]; vb[c] = o[b * 3 + c] + mean_dir[b * 3 + c]; }
+        phys_vec(o, mean_dir, nb, pm, a, va);
+        phys_vec(o, mean_dir, nb, pm, b, vb);
         float na = sqrtf(va[0] * va[0] + va[1] * va[1] + va[2] * va[2]), nbn = sqrtf(vb[0] * vb[0] + vb[1] * vb[1] + vb[2] * vb[2]);
         float da = fmaxf(na, 1e-12f), db = fmaxf(nbn, 1e-12f);
         float ua[3], ub[3];
@@ -101,15 +130,17 @@ __global__ __launch_bounds__(64) void phys_kernel(const float* __restrict__ out,
         float ang = acosf(ipc) / PI;
         float diff = ang - avg[k];
         total += diff * diff / (2.f * var[k]);
-        // d/d ip
         float gip = inside ? (diff / var[k]) * (-1.f / (PI * sqrtf(1.f - ipc * ipc))) * inv_rows : 0.f;
         // through the two normalisations: d v = (d u - u (u . d u)) / |v|
         float dua[3] = {gip * ub[0], gip * ub[1], gip * ub[2]}, dub[3] = {gip * ua[0], gip * ua[1], gip * ua[2]};
         float pa = ua[0] * dua[0] + ua[1] * dua[1] + ua[2] * dua[2], pb = ub[0] * dub[0] + ub[1] * dub[1] + ub[2] * dub[2];
+        float gva[3], gvb[3];
         for (int c = 0; c < 3; ++c) {
-            if (na > 1e-12f) g[a * 3 + c] += (dua[c] - ua[c] * pa) / da; else g[a * 3 + c] += dua[c] / da;
-            if (nbn > 1e-12f) g[b * 3 + c] += (dub[c] - ub[c] * pb) / db; else g[b * 3 + c] += dub[c] / db;
+            gva[c] = (na > 1e-12f ? dua[c] - ua[c] * pa : dua[c]) / da;
+            gvb[c] = (nbn > 1e-12f ? dub[c] - ub[c] * pb : dub[c]) / db;
         }
+        phys_grad(o, mean_dir, nb, pm, a, gva, g);
+        phys_grad(o, mean_dir, nb, pm, b, gvb, g);
     }
     per_row[r] = total * inv_rows;
 }
@@ -326,12 +357,17 @@ int ha2g_divreg_f32(const float* out, const float* rnd, const float* z, const fl
     return 0;
 }
 
-// out [rows][nb*3]; pairs int32 [npairs][2]; avg/var [npairs]; ws >= rows floats
+// out [rows][nb*3]; pairs int32 [npairs][2] (indices >= nb address the palm normals); palm: host int32 [npalm][2]
+// (bone pairs whose raw cross product forms synthetic bone nb+i), npalm <= 4; avg/var [npairs]; ws >= rows floats
 int ha2g_phys_angle_f32(const float* out, const float* mean_dir, int rows, int nb, const int* pairs, int npairs, const float* avg,
-                        const float* var, float* loss, float* dout, float* ws, void* stream) {
+                        const float* var, const int* palm_host, int npalm, float* loss, float* dout, float* ws, void* stream) {
     HA2G_REQUIRE(nb <= MAXV, "phys: too many bones (%d)", nb);
+    HA2G_REQUIRE(npalm >= 0 && npalm <= 4, "phys: at most 4 palm normals");
+    PalmSpec pm{};
+    pm.n = npalm;
+    for (int i = 0; i < npalm; ++i) { pm.a[i] = palm_host[2 * i]; pm.b[i] = palm_host[2 * i + 1]; }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(phys_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, out, mean_dir, rows, nb, pairs, npairs, avg, var, ws, dout);
+    hipLaunchKernelGGL(phys_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, out, mean_dir, rows, nb, pm, pairs, npairs, avg, var, ws, dout);
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, ws, (long)rows, loss, 1.f, 0);
     HA2G_CHECK_LAUNCH("phys");
     return 0;

@@ -638,24 +638,27 @@ def div_reg(out, rnd, z, zr, beta=0.05):
 
 class PhysAngleFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, out, mean_dir, pairs, avg, var):
+    def forward(ctx, out, mean_dir, pairs, avg, var, palm):
+        import ctypes
         out = _f32c(out.contiguous())
         P = out.shape[-1]
         rows = out.numel() // P
         loss, dout = empty((), like=out), torch.empty_like(out)
+        flat = [int(v) for pr in palm for v in pr]
+        parr = (ctypes.c_int * max(len(flat), 1))(*flat)
         check(lib.ha2g_phys_angle_f32(out.data_ptr(), mean_dir.data_ptr(), rows, P // 3, pairs.data_ptr(), pairs.shape[0],
-                                      avg.data_ptr(), var.data_ptr(), loss.data_ptr(), dout.data_ptr(),
-                                      workspace(out.device).data_ptr(), _stream()))
+                                      avg.data_ptr(), var.data_ptr(), ctypes.cast(parr, ctypes.c_void_p), len(palm),
+                                      loss.data_ptr(), dout.data_ptr(), workspace(out.device).data_ptr(), _stream()))
         ctx.save_for_backward(dout)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        return _scale_by(ctx.saved_tensors[0], g), None, None, None, None
+        return _scale_by(ctx.saved_tensors[0], g), None, None, None, None, None
 
 
-def phys_angle(out, mean_dir, pairs, avg, var):
-    return PhysAngleFunction.apply(out, mean_dir, pairs, avg, var)
+def phys_angle(out, mean_dir, pairs, avg, var, palm=()):
+    return PhysAngleFunction.apply(out, mean_dir, pairs, avg, var, tuple(palm))
 
 
 class GanLossFunction(torch.autograd.Function):

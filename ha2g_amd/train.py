@@ -6,18 +6,19 @@ import torch
 from .hierarchy_net import (Hierarchical_ConvDiscriminator, Hierarchical_PoseGenerator, Hierarchical_WavEncoder,
                             TextEncoderTCN)
 from .optim import FusedAdam
-from .train_hierarchy import train_iter_hierarchy
+from .train_hierarchy import train_iter_hierarchy, train_iter_hierarchy_expressive
 
 
-def init_model(args, lang_model, speaker_model, pose_dim, _device=None):
-    """reference scripts/train.py:50-88 (only `args.model == 'hierarchy'` is on the hot path)."""
+def init_model(args, lang_model, speaker_model, pose_dim, _device=None, pose_level=3):
+    """reference scripts/train.py:50-88 (only `args.model == 'hierarchy'` is on the hot path); train_expressive.py:95-133
+    is the same with pose_level=6 for the audio encoder."""
     generator = discriminator = audio_encoder = text_encoder = loss_fn = None
     if args.model == 'hierarchy':
         generator = Hierarchical_PoseGenerator(args, n_words=lang_model.n_words, word_embed_size=args.wordembed_dim,
                                                word_embeddings=lang_model.word_embedding_weights, z_obj=speaker_model,
                                                pose_dim=pose_dim)
         discriminator = Hierarchical_ConvDiscriminator(pose_dim)
-        audio_encoder = Hierarchical_WavEncoder(args, z_obj=speaker_model, pose_level=3, nOut=32)
+        audio_encoder = Hierarchical_WavEncoder(args, z_obj=speaker_model, pose_level=pose_level, nOut=32)
         text_encoder = TextEncoderTCN(args, lang_model.n_words, args.wordembed_dim,
                                       pre_trained_embedding=lang_model.word_embedding_weights, dropout=args.dropout_prob)
     else:
@@ -30,7 +31,9 @@ class HierarchyTrainer:
 
     def __init__(self, args, lang_model, speaker_model, pose_dim, device, pose_dims=(15, 21, 27)):
         self.args, self.device = args, device
-        _, self.discriminator, self.audio_encoder, self.text_encoder, _ = init_model(args, lang_model, speaker_model, pose_dim, device)
+        self.expressive = len(pose_dims) == 6        # scripts/train_expressive.py:160-168: six generators 24/30/36/66/96/126
+        _, self.discriminator, self.audio_encoder, self.text_encoder, _ = init_model(args, lang_model, speaker_model, pose_dim, device,
+                                                                                     pose_level=len(pose_dims))
         self.gens = [init_model(args, lang_model, speaker_model, pd, device)[0] for pd in pose_dims]
         for m in self.modules():
             m.to(device)
@@ -57,6 +60,6 @@ class HierarchyTrainer:
                 dist.broadcast(b, src)
 
     def train_iter(self, epoch, in_text_padded, in_spec, target, vid_indices, **kw):
-        return train_iter_hierarchy(self.args, epoch, in_text_padded, in_spec, target, vid_indices, *self.gens,
-                                    self.discriminator, self.audio_encoder, self.text_encoder, *self.gen_opts, self.dis_opt,
-                                    self.audio_opt, self.text_opt, **kw)
+        fn = train_iter_hierarchy_expressive if self.expressive else train_iter_hierarchy
+        return fn(self.args, epoch, in_text_padded, in_spec, target, vid_indices, *self.gens, self.discriminator, self.audio_encoder,
+                  self.text_encoder, *self.gen_opts, self.dis_opt, self.audio_opt, self.text_opt, **kw)

@@ -15,7 +15,7 @@ import math
 import torch
 
 from . import ops
-from .config import PHYS_GESTURE, PHYS_GESTURE_PAIRS
+from .config import EXPRESSIVE_SPEC, GESTURE_SPEC
 
 FUSE_CHAINS = True            # False = literal three-pass ordering of the reference (used as a cross-check in tests)
 randperm_source = None        # tests inject a fixed permutation: callable(n, device) -> LongTensor
@@ -23,14 +23,15 @@ randperm_source = None        # tests inject a fixed permutation: callable(n, de
 _const_cache = {}
 
 
-def _consts(args, device):
-    key = (id(args), str(device))
+def _consts(spec, args, device):
+    key = (spec['name'], id(args), str(device))
     c = _const_cache.get(key)
     if c is None:
         c = dict(mean_dir=torch.tensor(args.mean_dir_vec, dtype=torch.float32).squeeze(1).to(device),
-                 pairs=torch.tensor(PHYS_GESTURE_PAIRS, dtype=torch.int32, device=device),
-                 avg=torch.tensor(PHYS_GESTURE[0], dtype=torch.float32, device=device),
-                 var=torch.tensor(PHYS_GESTURE[1], dtype=torch.float32, device=device))
+                 pairs=torch.tensor(spec['phys_pairs'], dtype=torch.int32, device=device),
+                 avg=torch.tensor(spec['phys_avg'], dtype=torch.float32, device=device),
+                 var=torch.tensor(spec['phys_var'], dtype=torch.float32, device=device),
+                 cols=[torch.tensor(c, dtype=torch.long, device=device) for c in spec['level_cols']])
         _const_cache[key] = c
     return c
 
@@ -42,21 +43,20 @@ def _pre_seq(target_k, n_pre):
     return pre
 
 
-def _chain(args, gens, targets, in_text, blend, vids):
-    """coarse-to-fine decode g1 -> g2 -> g3 (reference :153-170).  All inputs may carry a multiple of B rows."""
+def _chain(spec, args, gens, targets, in_text, blend, vids):
+    """coarse-to-fine decode g1 -> ... -> gL (reference train_hierarchy.py:153-170 / train_hierarchy_expressive.py:272-316).
+    Level k's frames n_pre.. are seeded with level k-1's output through spec['scatter'] (differentiable slice writes).
+    All inputs may carry a multiple of B rows."""
     n = args.n_pre_poses
-    g1, g2, g3 = gens
-    pre1 = _pre_seq(targets[0], n)
-    out1, *_ = g1(pre1, in_text, blend[0], vids)
-    pre2 = _pre_seq(targets[1], n)
-    pre2[:, n:, :4 * 3] = out1[:, n:, :4 * 3]
-    pre2[:, n:, 5 * 3:6 * 3] = out1[:, n:, 4 * 3:5 * 3]
-    out2, *_ = g2(pre2, in_text, blend[1], vids)
-    pre3 = _pre_seq(targets[2], n)
-    pre3[:, n:, :5 * 3] = out2[:, n:, :5 * 3]
-    pre3[:, n:, 6 * 3:8 * 3] = out2[:, n:, 5 * 3:7 * 3]
-    out3, z, mu, logvar = g3(pre3, in_text, blend[2], vids)
-    return (out1, out2, out3), z, mu, logvar
+    outs, last = [], None
+    for k, g in enumerate(gens):
+        pre = _pre_seq(targets[k], n)
+        for dst, src in spec['scatter'][k]:
+            pre[:, n:, dst] = outs[-1][:, n:, src]
+        o, z, mu, logvar = g(pre, in_text, blend[k], vids)
+        outs.append(o)
+        last = (z, mu, logvar)
+    return outs, last[0], last[1], last[2]
 
 
 def _allreduce(optimizers):
@@ -68,19 +68,38 @@ def train_iter_hierarchy(args, epoch, in_text_padded, in_spec, target, vid_indic
                          g1, g2, g3, discriminator, audio_encoder, text_encoder,
                          gen_optimizer_1, gen_optimizer_2, gen_optimizer_3, dis_optimizer,
                          audio_optimizer, text_optimizer, return_tensors=False):
+    """TED-Gesture (3 levels, 27-d pose): drop-in for scripts/train_eval/train_hierarchy.py:71-74."""
+    return _train_iter(GESTURE_SPEC, args, epoch, in_text_padded, in_spec, target, vid_indices, (g1, g2, g3), discriminator,
+                       audio_encoder, text_encoder, (gen_optimizer_1, gen_optimizer_2, gen_optimizer_3), dis_optimizer,
+                       audio_optimizer, text_optimizer, return_tensors)
+
+
+def train_iter_hierarchy_expressive(args, epoch, in_text_padded, in_spec, target, vid_indices,
+                                    g1, g2, g3, g4, g5, g6, discriminator, audio_encoder, text_encoder,
+                                    gen_optimizer_1, gen_optimizer_2, gen_optimizer_3,
+                                    gen_optimizer_4, gen_optimizer_5, gen_optimizer_6, dis_optimizer,
+                                    audio_optimizer, text_optimizer, return_tensors=False):
+    """TED-Expressive (6 levels, 126-d pose): drop-in for scripts/train_eval/train_hierarchy_expressive.py:124-128."""
+    return _train_iter(EXPRESSIVE_SPEC, args, epoch, in_text_padded, in_spec, target, vid_indices, (g1, g2, g3, g4, g5, g6),
+                       discriminator, audio_encoder, text_encoder,
+                       (gen_optimizer_1, gen_optimizer_2, gen_optimizer_3, gen_optimizer_4, gen_optimizer_5, gen_optimizer_6),
+                       dis_optimizer, audio_optimizer, text_optimizer, return_tensors)
+
+
+def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices, gens, discriminator, audio_encoder, text_encoder,
+                gen_optimizers, dis_optimizer, audio_optimizer, text_optimizer, return_tensors=False):
     warm_up_epochs = args.loss_warmup
     dev = target.device
     B = target.shape[0]
     ops.rng.begin_step()
-    gens = (g1, g2, g3)
+    L = len(gens)
+    consts = _consts(spec, args, dev)
 
     weight, feat_low, feat_mid, feat_high, linear_blend_feat = audio_encoder(in_spec, vid_indices)
     text_feat = text_encoder(in_text_padded)
 
-    target_1 = torch.cat((target[:, :, :4 * 3], target[:, :, 6 * 3:7 * 3]), dim=2)
-    target_2 = torch.cat((target[:, :, :5 * 3], target[:, :, 6 * 3:8 * 3]), dim=2)
-    target_3 = target
-    targets = (target_1, target_2, target_3)
+    # per-level targets = column subsets of the full pose (train_hierarchy.py:86-88 / expressive :140-145)
+    targets = [target if len(c) == target.shape[2] else target.index_select(2, c) for c in consts['cols']]
 
     gan = epoch > warm_up_epochs and args.loss_gan_weight > 0.0
     use_div = (args.z_type == 'speaker' or args.z_type == 'random') and args.loss_reg_weight > 0.0
@@ -98,14 +117,14 @@ def train_iter_hierarchy(args, epoch, in_text_padded, in_spec, target, vid_indic
         rep = lambda t: t.repeat(*([k] + [1] * (t.dim() - 1))) if k > 1 else t
         vids_all = torch.cat([rand_vids if b == 'rand' else vid_indices for b in blocks]) if k > 1 else vid_indices
         blend_all = []
-        for lvl in range(3):
+        for lvl in range(L):
             f = linear_blend_feat[lvl]
             blend_all.append(torch.cat([f if b == 'main' else f.detach() for b in blocks]) if k > 1 else f)
         main_at = blocks.index('main')
         for g in gens:                                   # only the main block's rows carry gradient through the GRUs
             g.gru.grad_slice = (main_at * B, B) if k > 1 else None
         try:
-            outs_all, z_all, mu_all, lv_all = _chain(args, gens, [rep(t) for t in targets], rep(in_text_padded), blend_all, vids_all)
+            outs_all, z_all, mu_all, lv_all = _chain(spec, args, gens, [rep(t) for t in targets], rep(in_text_padded), blend_all, vids_all)
         finally:
             for g in gens:
                 g.gru.grad_slice = None
@@ -120,9 +139,10 @@ def train_iter_hierarchy(args, epoch, in_text_padded, in_spec, target, vid_indic
     if gan:
         dis_optimizer.zero_grad()
         if fused is not None:
-            out_dir_vec_d = fused['dis'][0][2]
+            out_dir_vec_d = fused['dis'][0][-1]
         else:
-            (_, _, out_dir_vec_d), *_ = _chain(args, gens, targets, in_text_padded, linear_blend_feat, vid_indices)
+            outs_d, *_ = _chain(spec, args, gens, targets, in_text_padded, linear_blend_feat, vid_indices)
+            out_dir_vec_d = outs_d[-1]
         dis_real = discriminator(target, in_text_padded)
         dis_fake = discriminator(out_dir_vec_d.detach(), in_text_padded)
         dis_error = ops.dis_loss(dis_real, dis_fake)                      # ns-gan
@@ -132,35 +152,37 @@ def train_iter_hierarchy(args, epoch, in_text_padded, in_spec, target, vid_indic
 
     ###########################################################################################
     # train G   (reference :135-274)
-    for o in (gen_optimizer_1, gen_optimizer_2, gen_optimizer_3, audio_optimizer, text_optimizer):
+    for o in tuple(gen_optimizers) + (audio_optimizer, text_optimizer):
         o.zero_grad()
 
     N = text_feat.shape[0] * text_feat.shape[1]
     if args.loss_contrastive_pos_weight > 0.0:
-        text_high_contrastive = ops.contrastive(text_feat.reshape(N, -1), feat_high.reshape(N, -1), False)
+        text_high_contrastive = ops.contrastive(text_feat.reshape(N, -1), feat_high.reshape(N, -1), spec['contrastive_expressive'])
     if args.loss_contrastive_neg_weight > 0.0:
-        text_low_contrastive = -ops.contrastive(text_feat.reshape(N, -1), feat_low.reshape(N, -1), False)
+        text_low_contrastive = -ops.contrastive(text_feat.reshape(N, -1), feat_low.reshape(N, -1), spec['contrastive_expressive'])
 
     if fused is not None:
-        (out_dir_vec_1, out_dir_vec_2, out_dir_vec), z_context, z_mu, z_logvar = fused['main']
+        outs_main, z_context, z_mu, z_logvar = fused['main']
     else:
-        (out_dir_vec_1, out_dir_vec_2, out_dir_vec), z_context, z_mu, z_logvar = _chain(
-            args, gens, targets, in_text_padded, linear_blend_feat, vid_indices)
+        outs_main, z_context, z_mu, z_logvar = _chain(spec, args, gens, targets, in_text_padded, linear_blend_feat, vid_indices)
+    out_dir_vec = outs_main[-1]
 
     beta = 0.1
-    h3 = ops.huber(out_dir_vec, target_3, beta)
-    huber_loss = ops.huber(out_dir_vec_1, target_1, beta) + ops.huber(out_dir_vec_2, target_2, beta) + h3
+    huber_loss = ops.huber(outs_main[0], targets[0], beta)
+    for o_k, t_k in zip(outs_main[1:], targets[1:]):
+        huber_loss = huber_loss + ops.huber(o_k, t_k, beta)
     dis_output = discriminator(out_dir_vec, in_text_padded)              # always executed, as in the reference (:179)
     gen_error = ops.gen_loss(dis_output)
     kld = div_reg = None
 
     if use_div:
         if fused is not None:
-            (_, _, out_dir_vec_rand_vid), z_context_rand, _, _ = fused['rand']
+            outs_rand, z_context_rand, _, _ = fused['rand']
         else:
             with torch.no_grad():
-                (_, _, out_dir_vec_rand_vid), z_context_rand, _, _ = _chain(
-                    args, gens, targets, in_text_padded, [f.detach() for f in linear_blend_feat], rand_vids)
+                outs_rand, z_context_rand, _, _ = _chain(spec, args, gens, targets, in_text_padded,
+                                                         [f.detach() for f in linear_blend_feat], rand_vids)
+        out_dir_vec_rand_vid = outs_rand[-1]
         div_reg = ops.div_reg(out_dir_vec, out_dir_vec_rand_vid.detach(), z_context.detach(), z_context_rand.detach(), 0.05)
         if args.z_type == 'speaker':
             kld = ops.kld(z_mu, z_logvar)
@@ -177,12 +199,11 @@ def train_iter_hierarchy(args, epoch, in_text_padded, in_spec, target, vid_indic
     if args.loss_contrastive_neg_weight > 0.0:
         loss = loss + args.loss_contrastive_neg_weight * text_low_contrastive
     if args.loss_physical_weight > 0.0:
-        c = _consts(args, dev)
-        physical_loss = ops.phys_angle(out_dir_vec, c['mean_dir'], c['pairs'], c['avg'], c['var'])
+        physical_loss = ops.phys_angle(out_dir_vec, consts['mean_dir'], consts['pairs'], consts['avg'], consts['var'], spec['palm'])
         loss = loss + args.loss_physical_weight * physical_loss
 
     loss.backward()
-    g_opts = (gen_optimizer_1, gen_optimizer_2, gen_optimizer_3, audio_optimizer, text_optimizer)
+    g_opts = tuple(gen_optimizers) + (audio_optimizer, text_optimizer)
     _allreduce(g_opts)
     for o in g_opts:
         o.step()

@@ -116,8 +116,10 @@ int ha2g_huber_f32(const float* x, const float* y, long n, float beta, float* lo
 int ha2g_kld_f32(const float* mu, const float* logvar, int n, float* loss, float* dmu, float* dlogvar, void* stream);          /* :226 */
 int ha2g_divreg_f32(const float* out, const float* rnd, const float* z, const float* zr, int B, int TP, int Z, float beta,
                     float* loss, float* dout, float* ws, void* stream);                                                          /* :213-222 */
+/* palm_host: HOST int32 [npalm][2] bone pairs whose raw cross products are appended as bones nb, nb+1, ... (expressive :430-432) */
 int ha2g_phys_angle_f32(const float* out, const float* mean_dir, int rows, int nb, const int* pairs, int npairs,
-                        const float* avg, const float* var, float* loss, float* dout, float* ws, void* stream);                  /* :242-262 */
+                        const float* avg, const float* var, const int* palm_host, int npalm, float* loss, float* dout,
+                        float* ws, void* stream);                                                                                /* :242-262 */
 int ha2g_gan_loss_f32(int mode, const float* a, const float* b, int n, float* loss, float* da, float* db, void* stream);       /* :128,180 */
 long ha2g_contrastive_workspace_floats(int N);
 int ha2g_contrastive_f32(const float* a, const float* b, int N, int expressive, float* loss, float* da, float* db, float* ws,

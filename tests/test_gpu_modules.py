@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from ha2g_amd import procedural as proc
-from ha2g_amd.config import CASES
+from ha2g_amd.config import CASES, EXPRESSIVE_SPEC, MEAN_DIR_VEC_EXPRESSIVE
 from ha2g_amd.testing import Checker, batch_for, build_modules, wproc
 
 pytestmark = pytest.mark.gpu
@@ -113,7 +113,7 @@ def test_contrastive(golden, name, expr):
 def test_losses_vs_torch():
     """Small loss kernels against the oracle's float64 formulas (value and gradient)."""
     from ha2g_amd import ops
-    from ha2g_amd.config import PHYS_GESTURE, PHYS_GESTURE_PAIRS, MEAN_DIR_VEC_GESTURE
+    from ha2g_amd.config import PHYS_GESTURE, PHYS_GESTURE_PAIRS, MEAN_DIR_VEC_GESTURE, EXPRESSIVE_SPEC, MEAN_DIR_VEC_EXPRESSIVE
     from oracle import ha2g_oracle as O
     r = np.random.Generator(np.random.PCG64(5))
     B, T, P = 6, 34, 27
@@ -158,3 +158,23 @@ def test_losses_vs_torch():
     for got, r64 in zip([o.grad, m.grad, l.grad, d1.grad, d2.grad], g64):
         err = float((got.double().cpu() - r64).abs().max() / r64.abs().max())
         assert err < 5e-5, err
+
+
+def test_phys_angle_expressive_palm():
+    """41 angle pairs over 42 bones + two palm normals (cross products) vs the oracle's float64 formula."""
+    from ha2g_amd import ops
+    from oracle import ha2g_oracle as O
+    sp = EXPRESSIVE_SPEC
+    r = np.random.Generator(np.random.PCG64(9))
+    out = torch.from_numpy((0.3 * r.standard_normal((5, 34, 126))).astype(np.float32))
+    mdv = torch.tensor(MEAN_DIR_VEC_EXPRESSIVE)
+    o64 = out.double().requires_grad_(True)
+    l64 = O.physical_prior(o64, mdv.double(), sp['phys_pairs'], sp['phys_avg'], sp['phys_var'], sp['palm'])
+    g64, = torch.autograd.grad(l64, o64)
+    o = out.to(DEV).requires_grad_(True)
+    l = ops.phys_angle(o, mdv.to(DEV), torch.tensor(sp['phys_pairs'], dtype=torch.int32, device=DEV),
+                       torch.tensor(sp['phys_avg'], device=DEV), torch.tensor(sp['phys_var'], device=DEV), sp['palm'])
+    (2.0 * l).backward()
+    assert abs(float(l) - float(l64)) <= 2e-5 * abs(float(l64))
+    err = float((o.grad.double().cpu() - 2.0 * g64).abs().max() / (2.0 * g64).abs().max())
+    assert err < 5e-5, err

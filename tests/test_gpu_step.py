@@ -40,3 +40,35 @@ def test_train_step(golden, name, fuse):
             ck.step(si, ret, grads, sd)
     finally:
         th.FUSE_CHAINS, th.randperm_source = old
+
+
+@pytest.mark.parametrize('fuse', [True, False])
+def test_train_step_expressive(golden, fuse):
+    """6-level TED-Expressive twin (train_hierarchy_expressive.py:124-483): P=126, off-by-one head scatter, palm normals,
+    eps-free contrastive, 9 modules / 9 optimizers."""
+    from ha2g_amd import schema
+    case, g = CASES['expr_small'], golden('expr_small')
+    ck = Checker(g)
+    dims = schema.EXPRESSIVE_POSE_DIMS
+    args, gens, dis, aud, txt = build_modules(case, DEV, dims)
+    text, spec, target, vid = (t.to(DEV) for t in batch_for(case, P=126))
+    lr = float(args.learning_rate)
+    g_opts = [FusedAdam(m.parameters(), lr=lr) for m in gens]
+    dis_opt = FusedAdam(dis.parameters(), lr=lr * args.discriminator_lr_weight)
+    aud_opt, txt_opt = FusedAdam(aud.parameters(), lr=lr), FusedAdam(txt.parameters(), lr=lr)
+    EpsInjector(gens, case['seed'], case['B'])
+    perm = torch.from_numpy(proc.fixed_perm(case['B'], case['seed'])).to(DEV)
+    mods = {'g%d' % (i + 1): m for i, m in enumerate(gens)}
+    mods.update(dis=dis, audio=aud, text=txt)
+    old = th.FUSE_CHAINS, th.randperm_source
+    th.FUSE_CHAINS, th.randperm_source = fuse, (lambda n, device: perm)
+    try:
+        for si, epoch in enumerate((0, 11)):
+            ret = th.train_iter_hierarchy_expressive(args, epoch, text, spec, target, vid, *gens, dis, aud, txt, *g_opts, dis_opt,
+                                                     aud_opt, txt_opt)
+            sd, grads = named_state(mods)
+            if epoch == 0:
+                grads = {k: v for k, v in grads.items() if not k.startswith('dis.')}
+            ck.step(si, ret, grads, sd)
+    finally:
+        th.FUSE_CHAINS, th.randperm_source = old

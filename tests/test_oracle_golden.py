@@ -132,3 +132,20 @@ def test_train_step(golden, name, dt):
     for si, epoch in enumerate((0, 11)):
         ret = tr.train_iter(epoch, text, spec, target, vid, lambda shp: torch.from_numpy(es(shp)).to(dt), perm)
         ck.step(si, ret, tr.grads, sd)
+
+
+@pytest.mark.parametrize('dt', DTS)
+def test_train_step_expressive(golden, dt):
+    """6-level TED-Expressive twin (train_hierarchy_expressive.py): off-by-one head scatter, palm normals, eps-free contrastive."""
+    from ha2g_amd.config import EXPRESSIVE_SPEC
+    case, g = CASES['expr_small'], golden('expr_small')
+    ck = Checker(g, dt)
+    sd = state_for(case, dt, schema.EXPRESSIVE_POSE_DIMS)
+    text, spec, target, vid = batch_for(case, dt, P=126)
+    args = make_args(case)
+    tr = O.OracleTrainer(sd, args, EXPRESSIVE_SPEC)
+    es = proc.EpsStream(case['seed'])
+    perm = torch.from_numpy(proc.fixed_perm(case['B'], case['seed']))
+    for si, epoch in enumerate((0, 11)):
+        ret = tr.train_iter(epoch, text, spec, target, vid, lambda shp: torch.from_numpy(es(shp)).to(dt), perm)
+        ck.step(si, ret, tr.grads, sd)
