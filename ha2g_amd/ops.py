@@ -460,6 +460,32 @@ def gru_supported(H):
     return bool(lib.ha2g_gru_supported_hidden(H))
 
 
+USE_GRU_CLUSTER = True        # H = 300 forward recurrence on the 5-workgroup-cluster kernel (gru_cluster.hip)
+_cluster_bufs = {}
+
+
+def _cluster_scratch(device):
+    key = (device.type, device.index)
+    if key not in _cluster_bufs:
+        n = lib.ha2g_gru_cluster_workspace_bytes()
+        _cluster_bufs[key] = (torch.zeros(n // 8 + 8, dtype=torch.int64, device=device), torch.zeros(1, dtype=torch.int32, device=device))
+    return _cluster_bufs[key]
+
+
+def gru_cluster_error(device):
+    """1 if any cluster hand-off timed out since start-up (synchronises; tests only)."""
+    return int(_cluster_scratch(device)[1].item())
+
+
+def _gru_layer_fwd(gi, pk, bf, br, y, rs, B, T, H, st, device):
+    if USE_GRU_CLUSTER and lib.ha2g_gru_cluster_supported(H):
+        xch, err = _cluster_scratch(device)
+        check(lib.ha2g_gru_layer_fwd_cluster(gi.data_ptr(), pk.data_ptr(), bf.data_ptr(), br.data_ptr(), y.data_ptr(), _p(rs),
+                                             xch.data_ptr(), err.data_ptr(), B, T, H, st))
+    else:
+        check(lib.ha2g_gru_layer_fwd(gi.data_ptr(), pk.data_ptr(), bf.data_ptr(), br.data_ptr(), y.data_ptr(), _p(rs), B, T, H, st))
+
+
 class BiGRUFunction(torch.autograd.Function):
     """Stacked bidirectional GRU (batch_first, h0 = 0).  forward(x, masks, H, grad_slice, *weights): weights in torch
     `_flat_weights` order (per layer, per direction: w_ih, w_hh, b_ih, b_hh); masks = tuple of pre-scaled
@@ -491,8 +517,7 @@ class BiGRUFunction(torch.autograd.Function):
             y = torch.empty(B, T, 2 * H, dtype=torch.float32, device=dev)
             rs = torch.empty(B, T, 2, 4, H, dtype=torch.float32, device=dev) if need_grad else None
             ktimer.launch('gru_layer_fwd' if (H == 300 and l > 0) else 'gru_layer_fwd_other',
-                          lambda: check(lib.ha2g_gru_layer_fwd(gi.data_ptr(), pk.data_ptr(), w[3].data_ptr(), w[7].data_ptr(),
-                                                               y.data_ptr(), _p(rs), B, T, H, st)), B)
+                          lambda: _gru_layer_fwd(gi, pk, w[3], w[7], y, rs, B, T, H, st, dev), B)
             saved.append((inp, y, rs))
             packs.append(pk)
             inp = y

@@ -64,6 +64,13 @@ int ha2g_gru_pack_whh(const float* whh, float* packed_fwd, float* packed_bwd, in
  * y [B][T][2H]; rs (nullable reserve) [B][T][2][4][H] */
 int ha2g_gru_layer_fwd(const float* gi, const float* wp, const float* bhh_fwd, const float* bhh_rev, float* y,
                        float* rs, int B, int T, int H, void* stream);
+/* Workgroup-cluster form of the forward recurrence (H = 300): 5 workgroups per (16-row tile, direction) keep their slice
+ * of W_hh in registers and all-gather h every step through 8-byte {tag,value} granules.  xch: scratch of
+ * ha2g_gru_cluster_workspace_bytes(); err: device int32, set to 1 if a hand-off timed out. */
+long ha2g_gru_cluster_workspace_bytes(void);
+int ha2g_gru_cluster_supported(int H);
+int ha2g_gru_layer_fwd_cluster(const float* gi, const float* wp, const float* bhh_fwd, const float* bhh_rev, float* y,
+                               float* rs, void* xch, int* err, int B, int T, int H, void* stream);
 /* dg [B][T][2][4H] = (d gi_r, d gi_z, d gi_n, d gh_n); wpt = packed_bwd images (dir 0, dir 1) */
 int ha2g_gru_layer_bwd(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, int B, int T,
                        int H, void* stream);

@@ -208,3 +208,28 @@ def test_batchnorm_fwd_bwd(shape):
     assert relerr(rmg, rm64) < 1e-5 and relerr(rvg, rv64) < 1e-5
     assert relerr(xg.grad, gr[0]) < 2e-5
     assert relerr(gg.grad, gr[1]) < 2e-5 and relerr(bg.grad, gr[2]) < 2e-5
+
+
+@pytest.mark.parametrize('B', [5, 40, 384, 400])
+def test_gru_cluster_matches_single_workgroup_kernel(B):
+    """The 5-workgroup-cluster forward (weights in registers, per-step granule all-gather) must reproduce the
+    single-workgroup kernel bit for bit (same MFMA order per output), for ragged, full and multi-launch batches."""
+    from ha2g_amd import ops
+    dev = _dev()
+    H, T, In, L = 300, 34, 108, 2
+    flat = []
+    for l in range(L):
+        k = In if l == 0 else 2 * H
+        for suf in range(2):
+            for shp in ((3 * H, k), (3 * H, H), (3 * H,), (3 * H,)):
+                flat.append(rnd(shp, 100 + len(flat), 1.0 / H ** 0.5).to(dev))
+    x = rnd((B, T, In), 7).to(dev)
+    outs = []
+    for use in (False, True):
+        ops.USE_GRU_CLUSTER = use
+        try:
+            outs.append(ops.bigru(x, flat, H))
+        finally:
+            ops.USE_GRU_CLUSTER = True
+    assert ops.gru_cluster_error(dev) == 0
+    assert torch.equal(outs[0], outs[1])

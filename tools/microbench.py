@@ -46,9 +46,14 @@ def bench_gru(B, T=34, H=300):
                                                     rs.data_ptr(), B, T, H, st)))
     b = timeit(lambda: check(lib.ha2g_gru_layer_bwd(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pk[2].data_ptr(), dg.data_ptr(),
                                                     B, T, H, st)))
+    fc = None
+    if lib.ha2g_gru_cluster_supported(H):
+        xch, err = ops._cluster_scratch(dev)
+        fc = timeit(lambda: check(lib.ha2g_gru_layer_fwd_cluster(gi.data_ptr(), pk.data_ptr(), bhh.data_ptr(), bhh.data_ptr(), y.data_ptr(),
+                                                                 rs.data_ptr(), xch.data_ptr(), err.data_ptr(), B, T, H, st)))
     fl = 2.0 * B * T * 2 * 3 * H * H
     print('gru layer B=%d T=%d H=%d: fwd %.1f us (%.2f us/step, %.1f TFLOP/s)  bwd %.1f us (%.1f TFLOP/s)' % (
-        B, T, H, f, f / T, fl / f / 1e6, b, fl / b / 1e6))
+        B, T, H, f, f / T, fl / f / 1e6, b, fl / b / 1e6) + ('' if fc is None else '  | cluster fwd %.1f us (%.2f us/step, %.1f TFLOP/s) err=%d' % (fc, fc / T, fl / fc / 1e6, ops.gru_cluster_error(dev))))
 
 
 if __name__ == '__main__':
