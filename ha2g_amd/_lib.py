@@ -21,9 +21,9 @@ def parse_header(path=HEADER_PATH):
     src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
     src = re.sub(r'//[^\n]*', ' ', src)
     protos = {}
-    for m in re.finditer(r'\b(const\s+char\s*\*|int|long)\s+(ha2g_\w+)\s*\(([^)]*)\)\s*;', src):
+    for m in re.finditer(r'\b(const\s+char\s*\*|int|long|void)\s+(ha2g_\w+)\s*\(([^)]*)\)\s*;', src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
-        restype = ctypes.c_char_p if '*' in ret else _SCALARS[ret]
+        restype = ctypes.c_char_p if '*' in ret else (None if ret == 'void' else _SCALARS[ret])
         argtypes = []
         if args and args != 'void':
             for a in args.split(','):

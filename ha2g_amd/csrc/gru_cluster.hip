@@ -190,13 +190,181 @@ __global__ __launch_bounds__(NT, 1) void gru_fwd_cluster_kernel(const float* __r
     }
 }
 
+
+// ---- backward (BPTT), cluster form -------------------------------------------------------------------------------------
+// Member q owns hidden units [64q, 64q+64).  Per step (reverse of the forward order):
+//   phase 1  gate gradients of the OWN units (one (row, 4-unit) group per thread): dg -> HBM, d gh -> LDS, dh*z kept in regs;
+//   phase 2  partial[b][k] = sum_{gate, j in own} dgh[b][gate,j] * W_hh[gate*H+j][k] for ALL k on MFMA, with the member's
+//            slice of W_hh (the same 192 rows as in the forward) resident in registers as 60 transposed fragments per wave;
+//   exchange the 64-column block of `partial` that belongs to member p is sent to p (granule pairs, 16-byte sc1 stores);
+//            every member adds the five blocks of its own columns in member order (fixed => deterministic):
+//            carry' = dh*z + sum_src partial_src.   The carry never leaves the owning thread's registers.
+constexpr int LDG = 3 * 64 + 4;      // LDS row stride of the own d gh tile [16][3][64]
+constexpr int LDP = 64 + 4;
+
+__global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __restrict__ dy,      // [B][T][2H]
+                                                                const float* __restrict__ y,       // [B][T][2H]
+                                                                const float* __restrict__ rs,      // [B][T][2][4][H]
+                                                                const float* __restrict__ wpt,     // packed bwd images, 2 dirs
+                                                                float* __restrict__ dg,            // [B][T][2][4H]
+                                                                u64* __restrict__ xch, int* __restrict__ err, int B, int T,
+                                                                int tile0, int nclusters, int dbg) {
+    __shared__ __attribute__((aligned(16))) float sg[16 * LDG];
+    __shared__ __attribute__((aligned(16))) float sp[16 * LDP];
+    const int id = blockIdx.x, xcd = id & 7, r = id >> 3;
+    const int q = r % G, c = (r / G) * 8 + xcd;
+    if (c >= nclusters) return;
+    const int dir = c & 1, b0 = (tile0 + (c >> 1)) * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lb = lane & 15, g = lane >> 4;
+    const int k0 = q * 64;                                  // first own unit
+    // phase-1 / gather ownership: thread -> (batch row bb, units k0 + jl4 .. +3)
+    const int bb = tid >> 4, jl4 = (tid & 15) * 4;
+    const int jo = k0 + jl4, bo = b0 + bb;
+    const bool own_ok = jo < H && bo < B;
+
+    // ---- resident transposed W_hh fragments: wave w serves k-tiles w, w+4, ... ; own j-tiles jt0..jt0+3 ----
+    constexpr int NKW = (NJT + TPW - 1) / TPW;             // k-tiles per wave (5)
+    float4 wf[NKW * 3 * TPW];
+    {
+        const float4* base = reinterpret_cast<const float4*>(wpt) + (long)dir * (NJT * 3 * NJT) * 64 + lane;
+#pragma unroll
+        for (int kk = 0; kk < NKW; ++kk)
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+                for (int jl = 0; jl < TPW; ++jl) {
+                    const int kt = wave + kk * TPW, jt = q * TPW + jl;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (kt < NJT && jt < NJT) v = base[((long)(kt * 3 + gate) * NJT + jt) * 64];
+                    wf[(kk * 3 + gate) * TPW + jl] = v;
+                }
+    }
+    for (int i = tid; i < 16 * LDG; i += NT) sg[i] = 0.f;
+    for (int i = tid; i < 16 * LDP; i += NT) sp[i] = 0.f;
+    u64* xc = xch + (long)c * 2 * G * G * 16 * 64;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xc, 0, 2 * G * G * 16 * 64 * 8, 0x00020000);
+    float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? s : T - 1 - s;
+        const int tp = dir ? t + 1 : t - 1;
+        const bool has_prev = tp >= 0 && tp < T;
+        // ---- phase 1 ----
+        float4 dar = make_float4(0.f, 0.f, 0.f, 0.f), daz = dar, dghn = dar, dhz = dar;
+        if (own_ok) {
+            const long bt = (long)bo * T + t;
+            const float4 dy4 = *reinterpret_cast<const float4*>(dy + bt * 2 * H + dir * H + jo);
+            const float* rp = rs + (bt * 2 + dir) * 4 * H + jo;
+            const float4 r4 = *reinterpret_cast<const float4*>(rp);
+            const float4 z4 = *reinterpret_cast<const float4*>(rp + H);
+            const float4 n4 = *reinterpret_cast<const float4*>(rp + 2 * H);
+            const float4 q4 = *reinterpret_cast<const float4*>(rp + 3 * H);
+            float4 hp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (has_prev) hp4 = *reinterpret_cast<const float4*>(y + ((long)bo * T + tp) * 2 * H + dir * H + jo);
+            float4 dan;
+            const float* pdy = &dy4.x; const float* pr = &r4.x; const float* pz = &z4.x; const float* pn = &n4.x;
+            const float* pq = &q4.x; const float* php = &hp4.x; const float* pc = &carry.x;
+            float* o_r = &dar.x; float* o_z = &daz.x; float* o_n = &dan.x; float* o_q = &dghn.x; float* o_c = &dhz.x;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float dh = pdy[u] + pc[u];
+                const float dn = dh * (1.f - pz[u]);
+                const float dz = dh * (php[u] - pn[u]);
+                const float a_n = dn * (1.f - pn[u] * pn[u]);
+                o_n[u] = a_n;
+                o_z[u] = dz * pz[u] * (1.f - pz[u]);
+                o_r[u] = a_n * pq[u] * pr[u] * (1.f - pr[u]);
+                o_q[u] = a_n * pr[u];
+                o_c[u] = dh * pz[u];
+            }
+            float* gp = dg + (bt * 2 + dir) * 4 * H + jo;
+            *reinterpret_cast<float4*>(gp) = dar;
+            *reinterpret_cast<float4*>(gp + H) = daz;
+            *reinterpret_cast<float4*>(gp + 2 * H) = dan;
+            *reinterpret_cast<float4*>(gp + 3 * H) = dghn;
+        }
+        if (s + 1 == T) break;                              // the carry out of the last step is never used (h0 is constant)
+        *reinterpret_cast<float4*>(&sg[bb * LDG + jl4]) = dar;
+        *reinterpret_cast<float4*>(&sg[bb * LDG + 64 + jl4]) = daz;
+        *reinterpret_cast<float4*>(&sg[bb * LDG + 128 + jl4]) = dghn;
+        __syncthreads();
+        // ---- phase 2: partial sums for all k from the own units ----
+        float4 bop[3 * TPW];
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+            for (int jl = 0; jl < TPW; ++jl) bop[gate * TPW + jl] = *reinterpret_cast<const float4*>(&sg[lb * LDG + gate * 64 + 16 * jl + 4 * g]);
+        const unsigned tag = (unsigned)(s + 1);
+#pragma unroll
+        for (int kk = 0; kk < NKW; ++kk) {
+            const int kt = wave + kk * TPW;
+            if (kt >= NJT) continue;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+#pragma unroll
+            for (int jl = 0; jl < TPW; ++jl) {
+                const float* w0 = &wf[(kk * 3 + 0) * TPW + jl].x; const float* w1 = &wf[(kk * 3 + 1) * TPW + jl].x;
+                const float* w2 = &wf[(kk * 3 + 2) * TPW + jl].x;
+                const float* d0 = &bop[jl].x; const float* d1 = &bop[TPW + jl].x; const float* d2 = &bop[2 * TPW + jl].x;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[u], d0[u], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[u], d1[u], a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[u], d2[u], a2, 0, 0, 0);
+                }
+            }
+            const float p0 = a0[0] + a1[0] + a2[0], p1 = a0[1] + a1[1] + a2[1], p2 = a0[2] + a1[2] + a2[2], p3 = a0[3] + a1[3] + a2[3];
+            const int dst = kt / TPW, kl = 16 * (kt % TPW) + 4 * g;      // owner of these columns, column within its block
+            if (dst == q) {
+                *reinterpret_cast<float4*>(&sp[lb * LDP + kl]) = make_float4(p0, p1, p2, p3);
+            } else if (dbg != 2) {
+                const int go = (((((s & 1) * G + dst) * G + q) * 16 + lb) * 64 + kl) * 8;
+                store_granule_pair(xr, go, tag, p0, p1);
+                store_granule_pair(xr, go + 16, tag, p2, p3);
+            }
+        }
+        __syncthreads();
+        // ---- gather: carry' = dh*z + sum over members (ascending) of their partial for my 4 units ----
+        float4 part[G];                                      // statically indexed only (member q's slot stays unused)
+        const float4 own_part = *reinterpret_cast<const float4*>(&sp[bb * LDP + jl4]);
+        if (dbg != 2) {
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int src = 0; src < G; ++src) {
+                    // columns >= H (the padding of the last member's block) are never published: do not wait for them
+                    if (src == q || jo >= H) { part[src] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+                    const int go = (((((s & 1) * G + q) * G + src) * 16 + bb) * 64 + jl4) * 8;
+                    const u32x4 x0 = load_granule_pair(xr, go), x1 = load_granule_pair(xr, go + 16);
+                    part[src] = make_float4(__uint_as_float(x0[0]), __uint_as_float(x0[2]), __uint_as_float(x1[0]), __uint_as_float(x1[2]));
+                    ok = ok && x0[1] == tag && x0[3] == tag && x1[1] == tag && x1[3] == tag;
+                }
+                if (__all(ok) || dbg == 1) break;
+                if (spins > SPIN_LIMIT) { if (lane == 0) atomicExch(err, 1); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        } else {
+#pragma unroll
+            for (int src = 0; src < G; ++src) part[src] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        carry = dhz;
+#pragma unroll
+        for (int src = 0; src < G; ++src) {
+            const float4 p = (src == q) ? own_part : part[src];
+            carry.x += p.x; carry.y += p.y; carry.z += p.z; carry.w += p.w;
+        }
+        if (!own_ok) carry = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 }  // namespace
 
 static int g_dbg = 0;
 extern "C" {
 
 void ha2g_gru_cluster_debug(int m) { g_dbg = m; }
-long ha2g_gru_cluster_workspace_bytes(void) { return (long)MAX_TILES * 2 * 2 * 16 * HP * 8 + 64; }
+long ha2g_gru_cluster_workspace_bytes(void) { return (long)MAX_TILES * 2 * 2 * G * G * 16 * 64 * 8 + 64; }   /* sized for the backward's per-pair slots */
 int ha2g_gru_cluster_supported(int H_) { return H_ == H; }
 
 // Same contract as ha2g_gru_layer_fwd (H = 300 only) plus: xch = scratch of ha2g_gru_cluster_workspace_bytes() bytes,
@@ -216,6 +384,25 @@ int ha2g_gru_layer_fwd_cluster(const float* gi, const float* wp, const float* bh
         hipLaunchKernelGGL(gru_fwd_cluster_kernel, dim3(grid), dim3(NT), 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, (u64*)xch, err, B, T,
                            t0, nclusters, g_dbg);
         HA2G_CHECK_LAUNCH("gru_layer_fwd_cluster");
+    }
+    return 0;
+}
+
+// BPTT counterpart (same contract as ha2g_gru_layer_bwd, H = 300 only); wpt = packed backward images of both directions.
+int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, void* xch, int* err,
+                               int B, int T, int H_, void* stream) {
+    HA2G_REQUIRE(H_ == H, "gru cluster kernel: H=%d not instantiated (300)", H_);
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0 || T == 0) return 0;
+    const int tiles = ceil_div(B, 16);
+    for (int t0 = 0; t0 < tiles; t0 += MAX_TILES) {
+        const int nt = tiles - t0 < MAX_TILES ? tiles - t0 : MAX_TILES;
+        const int nclusters = nt * 2;
+        hipError_t e = hipMemsetAsync(xch, 0, (size_t)nclusters * 2 * G * G * 16 * 64 * 8, st);
+        if (e != hipSuccess) return ha2g_set_error(-2, "gru cluster: memset failed: %s", hipGetErrorString(e));
+        const int grid = ceil_div(nclusters, 8) * 8 * G;
+        hipLaunchKernelGGL(gru_bwd_cluster_kernel, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, (u64*)xch, err, B, T, t0, nclusters, g_dbg);
+        HA2G_CHECK_LAUNCH("gru_layer_bwd_cluster");
     }
     return 0;
 }

@@ -477,6 +477,15 @@ def gru_cluster_error(device):
     return int(_cluster_scratch(device)[1].item())
 
 
+def _gru_layer_bwd(dy, y, rs, pkt, dg, B, T, H, st, device):
+    if USE_GRU_CLUSTER and lib.ha2g_gru_cluster_supported(H):
+        xch, err = _cluster_scratch(device)
+        check(lib.ha2g_gru_layer_bwd_cluster(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pkt.data_ptr(), dg.data_ptr(), xch.data_ptr(),
+                                             err.data_ptr(), B, T, H, st))
+    else:
+        check(lib.ha2g_gru_layer_bwd(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pkt.data_ptr(), dg.data_ptr(), B, T, H, st))
+
+
 def _gru_layer_fwd(gi, pk, bf, br, y, rs, B, T, H, st, device):
     if USE_GRU_CLUSTER and lib.ha2g_gru_cluster_supported(H):
         xch, err = _cluster_scratch(device)
@@ -550,8 +559,7 @@ class BiGRUFunction(torch.autograd.Function):
                 dy = eltwise(OP_MUL, dy, masks[l][sl])
             dg = torch.empty(B * T, 8 * H, dtype=torch.float32, device=dev)        # [dir][r z n hn]
             ktimer.launch('gru_layer_bwd' if H == 300 else 'gru_layer_bwd_other',
-                          lambda: check(lib.ha2g_gru_layer_bwd(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), ctx.packs[l][2].data_ptr(),
-                                                               dg.data_ptr(), B, T, H, st)), B)
+                          lambda: _gru_layer_bwd(dy, y, rs, ctx.packs[l][2], dg, B, T, H, st, dev), B)
             K = inp.shape[2]
             x2 = inp.view(B * T, K)
             # h_prev per direction: forward dir sees y[t-1], reverse dir sees y[t+1]; zero at the sequence ends

@@ -71,6 +71,9 @@ long ha2g_gru_cluster_workspace_bytes(void);
 int ha2g_gru_cluster_supported(int H);
 int ha2g_gru_layer_fwd_cluster(const float* gi, const float* wp, const float* bhh_fwd, const float* bhh_rev, float* y,
                                float* rs, void* xch, int* err, int B, int T, int H, void* stream);
+int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, void* xch,
+                               int* err, int B, int T, int H, void* stream);
+void ha2g_gru_cluster_debug(int mode);   /* ablation switch for tools/dbg_cluster.py: 0 normal, 1 no wait, 2 no exchange */
 /* dg [B][T][2][4H] = (d gi_r, d gi_z, d gi_n, d gh_n); wpt = packed_bwd images (dir 0, dir 1) */
 int ha2g_gru_layer_bwd(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, int B, int T,
                        int H, void* stream);

@@ -233,3 +233,32 @@ def test_gru_cluster_matches_single_workgroup_kernel(B):
             ops.USE_GRU_CLUSTER = True
     assert ops.gru_cluster_error(dev) == 0
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('B', [5, 40, 130])
+def test_gru_cluster_backward_matches(B):
+    """Cluster BPTT vs the single-workgroup BPTT: same math, different (fixed) summation order of the five partial sums."""
+    from ha2g_amd import ops
+    dev = _dev()
+    H, T, In, L = 300, 34, 108, 2
+    ws = []
+    for l in range(L):
+        k = In if l == 0 else 2 * H
+        for suf in range(2):
+            for shp in ((3 * H, k), (3 * H, H), (3 * H,), (3 * H,)):
+                ws.append(rnd(shp, 300 + len(ws), 1.0 / H ** 0.5).to(dev))
+    x0 = rnd((B, T, In), 9).to(dev)
+    wy = rnd((B, T, 2 * H), 10).to(dev)
+    res = []
+    for use in (False, True):
+        ops.USE_GRU_CLUSTER = use
+        try:
+            x = x0.clone().requires_grad_(True)
+            flat = [w.clone().requires_grad_(True) for w in ws]
+            yy = ops.bigru(x, flat, H)
+            res.append(torch.autograd.grad((yy * wy).sum(), [x] + flat))
+        finally:
+            ops.USE_GRU_CLUSTER = True
+    assert ops.gru_cluster_error(dev) == 0
+    for a, b in zip(*res):
+        assert relerr(a, b.cpu()) < 2e-5

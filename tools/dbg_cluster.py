@@ -24,3 +24,11 @@ for mode, name in ((0, 'normal'), (1, 'publish+one gather pass, no wait'), (2, '
     us = timeit(lambda: check(lib.ha2g_gru_layer_fwd_cluster(gi.data_ptr(), pk.data_ptr(), bhh.data_ptr(), bhh.data_ptr(), y.data_ptr(), rs.data_ptr(), xch.data_ptr(), err.data_ptr(), B, T, H, st)))
     print('%-40s %.1f us  %.2f us/step' % (name, us, us / T))
 raw.ha2g_gru_cluster_debug(0)
+dg = torch.empty(B * T, 8 * H, device=dev); dy = torch.randn(B, T, 2 * H, device=dev)
+for Bb in (128, 384):
+    for mode, name in ((0, 'bwd normal'), (1, 'bwd no wait'), (2, 'bwd no exchange')):
+        raw.ha2g_gru_cluster_debug(mode)
+        us = timeit(lambda: check(lib.ha2g_gru_layer_bwd_cluster(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pk[2].data_ptr(), dg.data_ptr(), xch.data_ptr(), err.data_ptr(), Bb, T, H, st)))
+        print('B=%d %-30s %.1f us  %.2f us/step' % (Bb, name, us, us / T))
+raw.ha2g_gru_cluster_debug(0)
+print('err', ops.gru_cluster_error(dev))
