@@ -44,7 +44,6 @@ struct GemmP {
     ConvGeom g;
 };
 
-constexpr int BK = 16;
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
@@ -67,23 +66,25 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int valid) {   // va
     return v;
 }
 
-template <int MI, int NI, int WM, int WN, int AMODE, int BMODE, bool VEC>
+template <int MI, int NI, int WM, int WN, int AMODE, int BMODE, bool VEC, int BKT>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr bool A_KCONT = (AMODE != A_MC);          // staged float4 spans 4 consecutive k
     constexpr bool B_KCONT = (BMODE == B_KC);
-    constexpr int NA = (BM * 4 + 255) / 256, NB = (BN * 4 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
-    float* As = smem;                      // [2][BK][LDA]
-    float* Bs = smem + 2 * BK * LDA;       // [2][BK][LDB]
+    constexpr int KQ = BKT / 4;                        // float4 quads per tile row along k
+    constexpr int SA = BM * KQ, SB = BN * KQ;          // staging slots (float4) of the A / B tile
+    constexpr int NA = (SA + 255) / 256, NB = (SB + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BKT * (LDA + LDB)];
+    float* As = smem;                      // [2][BKT][LDA]
+    float* Bs = smem + 2 * BKT * LDA;      // [2][BKT][LDB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int kbeg = blockIdx.z * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
-    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int nk = (kend - kbeg + BKT - 1) / BKT;
     const ConvGeom g = p.g;
 
     // ---- per-thread staging slots ----
@@ -93,8 +94,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         int s = tid + i * 256;
-        a_on[i] = s < BM * 4;
-        if (A_KCONT) { a_r[i] = s >> 2; a_c[i] = (s & 3) * 4; }
+        a_on[i] = s < SA;
+        if (A_KCONT) { a_r[i] = s / KQ; a_c[i] = (s % KQ) * 4; }
         else { a_r[i] = s / (BM / 4); a_c[i] = (s % (BM / 4)) * 4; }
         if (AMODE == A_IM) {
             int m = m0 + a_r[i];
@@ -110,8 +111,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         int s = tid + i * 256;
-        b_on[i] = s < BN * 4;
-        if (B_KCONT) { b_r[i] = s >> 2; b_c[i] = (s & 3) * 4; }
+        b_on[i] = s < SB;
+        if (B_KCONT) { b_r[i] = s / KQ; b_c[i] = (s % KQ) * 4; }
         else { b_r[i] = s / (BN / 4); b_c[i] = (s % (BN / 4)) * 4; }
         if (BMODE == B_IM) {
             int n = n0 + b_c[i];
@@ -125,10 +126,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     float4 ra[NA], rb[NB];
 
     auto load_tile = [&](int kt) {
-        const int k0 = kbeg + kt * BK;
+        const int k0 = kbeg + kt * BKT;
         // ---- A ----
         if (AMODE == A_IM) {
-            const int tap = k0 / g.GC, c0 = k0 % g.GC;     // a 16-wide k tile never straddles a tap (GC % 16 == 0)
+            const int tap = k0 / g.GC, c0 = k0 % g.GC;     // a BKT-wide k tile never straddles a tap (GC % BKT == 0)
             const int kh = tap / g.KW, kw = tap % g.KW;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
@@ -196,11 +197,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     };
 
     auto store_tile = [&](int buf) {
-        float* as = As + buf * BK * LDA;
-        float* bs = Bs + buf * BK * LDB;
+        float* as = As + buf * BKT * LDA;
+        float* bs = Bs + buf * BKT * LDB;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            if (!(tid + i * 256 < BM * 4)) continue;
+            if (!(tid + i * 256 < SA)) continue;
             if (A_KCONT) {
                 float* d = as + a_c[i] * LDA + a_r[i];
                 d[0] = ra[i].x; d[LDA] = ra[i].y; d[2 * LDA] = ra[i].z; d[3 * LDA] = ra[i].w;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            if (!(tid + i * 256 < BN * 4)) continue;
+            if (!(tid + i * 256 < SB)) continue;
             if (B_KCONT) {
                 float* d = bs + b_c[i] * LDB + b_r[i];
                 d[0] = rb[i].x; d[LDB] = rb[i].y; d[2 * LDB] = rb[i].z; d[3 * LDB] = rb[i].w;
@@ -237,10 +238,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) load_tile(kt + 1);
-        const float* as = As + cur * BK * LDA + wm * (32 * MI) + l31;
-        const float* bs = Bs + cur * BK * LDB + wn * (32 * NI) + l31;
+        const float* as = As + cur * BKT * LDA + wm * (32 * MI) + l31;
+        const float* bs = Bs + cur * BKT * LDB + wn * (32 * NI) + l31;
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
+        for (int kk = 0; kk < BKT / 2; ++kk) {
             float a[MI], b[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) a[i] = as[(2 * kk + lhi) * LDA + i * 32];
@@ -283,6 +284,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         }
 }
 
+static int g_bk32 = 0;   // BKT = 32 measured 5-20 % SLOWER on MI355X (fewer resident blocks, more staging registers): off
+
 __global__ void splitk_reduce_kernel(const float* ws, int splits, long MN, int N, float* C, long ldc, float alpha,
                                      float beta, const float* bias, int act) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -302,7 +305,10 @@ template <int MI, int NI, int WM, int WN, int AMODE, int BMODE, bool VEC>
 int launch(const GemmP& p, hipStream_t st) {
     constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
     dim3 grid(ceil_div(p.M, BM), ceil_div(p.N, BN), p.splits);
-    hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC>), grid, dim3(256), 0, st, p);
+    // deep tiles (BKT = 32) halve the barriers per MFMA; the im2col A loader needs a tile inside one filter tap
+    const bool deep = g_bk32 && p.kchunk >= 64 && (AMODE != A_IM || p.g.GC % 32 == 0);
+    if (deep) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 32>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16>), grid, dim3(256), 0, st, p);
     HA2G_CHECK_LAUNCH("gemm");
     if (p.splits > 1) {
         long MN = (long)p.M * p.N;
@@ -325,7 +331,7 @@ int choose_splits(int M, int N, int K, int BM, int BN, long ws_floats, int* kchu
         while (splits > 1 && (long)splits * M * N > ws_floats) --splits;
     }
     int kc = ceil_div(K, splits);
-    kc = ceil_div(kc, BK) * BK;
+    kc = ceil_div(kc, 32) * 32;
     splits = ceil_div(K, kc);
     *kchunk = kc;
     return splits;
@@ -350,7 +356,41 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
+static int g_conv_cfg = -1;     // -1 = heuristic; 0: 256x32, 1: 128x64, 2: 128x128, 3: 64x64, 4: 64x128   (tools/conv_bench.py)
+
+template <int AMODE, int BMODE>
+static int launch_conv_cfg(int cfg, const GemmP& p, hipStream_t st) {
+    switch (cfg) {
+        case 0: return launch<2, 1, 4, 1, AMODE, BMODE, true>(p, st);
+        case 1: return launch<1, 2, 4, 1, AMODE, BMODE, true>(p, st);
+        case 2: return launch<2, 2, 2, 2, AMODE, BMODE, true>(p, st);
+        case 3: return launch<1, 1, 2, 2, AMODE, BMODE, true>(p, st);
+        default: return launch<1, 2, 2, 2, AMODE, BMODE, true>(p, st);
+    }
+}
+
+// workgroups a CU can hold at once are limited, and every CU shares one MFMA pipe per SIMD: a launch runs as long as
+// its most loaded CU.  Pick the tile whose (estimated per-tile efficiency x load balance over 256 CUs) is best.
+static int pick_conv_cfg(int M, int N) {
+    if (g_conv_cfg >= 0) return g_conv_cfg;
+    static const int bm[5] = {256, 128, 128, 64, 64}, bn[5] = {32, 64, 128, 64, 128};
+    static const double eff[5] = {0.70, 0.95, 0.90, 0.95, 1.00};    // measured on the four trunk shapes (tools/conv_bench.py)
+    int best = 2; double bs = -1.0;
+    for (int c = 0; c < 5; ++c) {
+        if (bn[c] > 32 && N <= 32 && c != 0) continue;
+        long tiles = (long)ceil_div(M, bm[c]) * ceil_div(N, bn[c]);
+        double waste_n = (double)N / (ceil_div(N, bn[c]) * bn[c]);
+        double per_cu = (double)tiles / 256.0;
+        double balance = per_cu / (double)((tiles + 255) / 256);
+        double score = eff[c] * balance * waste_n;
+        if (score > bs) { bs = score; best = c; }
+    }
+    return best;
+}
+
 extern "C" {
+
+void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 100) g_bk32 = cfg - 100; else g_conv_cfg = cfg; }   /* 100/101: tile depth 16/32 */
 
 // Dense GEMM, row-major.  transa/transb follow BLAS meaning on row-major storage:
 //   transa = 0: A is [M,K] (lda >= K);  1: A is stored [K,M] (lda >= M)
@@ -388,9 +428,7 @@ int ha2g_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float
     p.splits = 1; p.kchunk = p.K;
     p.g = ConvGeom{H, W, Cin, OH, OW, KH, KW, stride, pad, 0};
     hipStream_t st = (hipStream_t)stream;
-    if (Cout <= 32) return launch<2, 1, 4, 1, A_IM, B_KC, true>(p, st);
-    if (Cout <= 64) return launch<1, 2, 4, 1, A_IM, B_KC, true>(p, st);
-    return launch<2, 2, 2, 2, A_IM, B_KC, true>(p, st);
+    return launch_conv_cfg<A_IM, B_KC>(pick_conv_cfg(p.M, p.N), p, st);
 }
 
 // Data gradient: dx [N,H,W,Cin] = conv_transpose(dy [N,OH,OW,Cout], w).  wt is the weight permuted to
@@ -406,9 +444,7 @@ int ha2g_conv2d_dgrad_f32(const float* dy, const float* wt, float* dx, int N, in
     p.splits = 1; p.kchunk = p.K;
     p.g = ConvGeom{OH, OW, Cout, H, W, KH, KW, stride, pad, 1};
     hipStream_t st = (hipStream_t)stream;
-    if (Cin <= 32) return launch<2, 1, 4, 1, A_IM, B_KC, true>(p, st);
-    if (Cin <= 64) return launch<1, 2, 4, 1, A_IM, B_KC, true>(p, st);
-    return launch<2, 2, 2, 2, A_IM, B_KC, true>(p, st);
+    return launch_conv_cfg<A_IM, B_KC>(pick_conv_cfg(p.M, p.N), p, st);
 }
 
 // Weight gradient: dw [Cout][KH][KW][Cin] (+)= dy^T * im2col(x); K = N*OH*OW output pixels, split over grid.z.
@@ -437,7 +473,7 @@ int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int
     int splits = (int)(need / (MN * 4));
     HA2G_REQUIRE(splits == 1 || (ws && ws_bytes >= need), "conv2d_wgrad: workspace too small (%ld < %ld)", ws_bytes, need);
     int kc = ceil_div(p.K, splits);
-    kc = ceil_div(kc, BK) * BK;
+    kc = ceil_div(kc, 32) * 32;
     p.kchunk = kc; p.splits = ceil_div(p.K, kc); p.ws = ws;
     hipStream_t st = (hipStream_t)stream;
     if (Cout <= 32) return launch<1, 1, 1, 4, A_MC, B_IM, true>(p, st);

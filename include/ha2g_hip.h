@@ -46,6 +46,7 @@ long ha2g_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, i
 int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout, int KH,
                           int KW, int stride, int pad, float beta, float* ws, long ws_bytes, void* stream);
 int ha2g_conv2d_weight_ohwi_to_ihwo_f32(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
+void ha2g_conv_debug_cfg(int cfg);   /* tile-shape override for tools/conv_bench.py (-1 = heuristic) */
 /* stem Conv2d(1->32, 3x3, pad 1) + bias + ReLU (model/ResNetSE34V2.py:27,127-128); x [N,H,W], y [N,H,W,32] */
 int ha2g_stem_conv_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, void* stream);
 int ha2g_stem_conv_wgrad_f32(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, float beta,
