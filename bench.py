@@ -122,8 +122,15 @@ def main():
             flops = 2.0 * rows * T * 2 * 3 * H * H + 12.0 * rows * T * 2 * H   # recurrent matmul + gate math per launch
             bytes_ = (rows * T * 2 * 3 * H + rows * T * 2 * H + rows * T * 2 * 4 * H + 2 * 3 * H * H) * 4.0   # gi + y + reserve + W_hh
             ach = flops / (mean_us * 1e-6) / 1e12
+            traffic, tsrc = None, None
+            pj = os.path.join(ROOT, 'profiles', 'r01_pmc_gru_fwd.json')
+            if os.path.exists(pj):                         # HBM bytes per launch from separate rocprofv3 --pmc passes (same workload)
+                pm = json.load(open(pj))
+                if pm.get('batch_rows') == rows:
+                    traffic, tsrc = pm['hbm_bytes_per_launch'], 'profiles/r01_pmc_gru_fwd.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)'
             roof = dict(kernel='gru_fwd_cluster_kernel (ha2g_gru_layer_fwd_cluster, H=300)', bound='mfma', achieved=round(ach, 3), peak=157.3,
-                        unit='TFLOP/s', frac=round(ach / 157.3, 4), traffic=None, launches=n, mean_us=round(mean_us, 1),
+                        unit='TFLOP/s', frac=round(ach / 157.3, 4), traffic=traffic, traffic_source=tsrc,
+                        algorithmic_bytes=bytes_, launches=n, mean_us=round(mean_us, 1),
                         batch_rows=rows, hbm_GBps_algorithmic=round(bytes_ / (mean_us * 1e-6) / 1e9, 1),
                         hbm_frac_of_8TBps=round(bytes_ / (mean_us * 1e-6) / 8e12, 4))
         out = dict(metric='pose-frames/sec (train step) for hierarchy.yml B=128 T=34', value=round(value, 1), unit='pose-frames/s',
