@@ -105,6 +105,16 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     ops.ktimer.enabled = False
+    # secondary number: warm-up phase (epoch <= loss_warmup, no D update / no D-phase chain), a third of the timed steps
+    k2 = max(2, a.steps // 3)
+    for _ in range(2):
+        tr.train_iter(0, text, spec, target, vid)
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(k2):
+        tr.train_iter(0, text, spec, target, vid)
+    sync()
+    ms_warm = (time.perf_counter() - t1) / k2 * 1e3
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -136,12 +146,13 @@ def main():
         out = dict(metric='pose-frames/sec (train step) for hierarchy.yml B=128 T=34', value=round(value, 1), unit='pose-frames/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype='f32', data='synthetic',
+                   warmup_phase=dict(ms_per_step=round(ms_warm, 3), value=round(a.batch * 34 * world / (ms_warm * 1e-3), 1)),
                    config=dict(workload='%s hierarchy train step, B=%d per GPU, T=34, %d-d pose, '
                                         'spec (128,70), n_words=%d, n_spk=%d, dropout 0.3, %s' % (
                                             'config_expressive/hierarchy.yml TED-Expressive' if a.expressive else 'config/hierarchy.yml TED-Gesture', a.batch, P, a.n_words, a.n_spk, 'GAN phase (epoch %d > loss_warmup)' % a.epoch
                                             if a.epoch > args.loss_warmup else 'warm-up phase (epoch %d)' % a.epoch),
                                global_batch=a.batch * world, parallelism='dp%d' % world),
-                   roofline=roof, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
+                   gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
         if world == 1 and not a.no_cpu_baseline and not a.expressive:
             out['cpu_baseline'] = cpu_baseline(a.cpu_batch, a.epoch, a.n_words, a.n_spk)
         print(json.dumps(out))
