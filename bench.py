@@ -74,6 +74,9 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     from ha2g_amd import ops, procedural as proc
+    if os.environ.get('HA2G_DEBUG_CFG'):
+        from ha2g_amd._lib import lib as _l
+        _l.ha2g_conv_debug_cfg(int(os.environ['HA2G_DEBUG_CFG']))
     from ha2g_amd.config import hierarchy_args
     from ha2g_amd.train import HierarchyTrainer
 

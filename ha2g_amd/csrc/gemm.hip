@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         }
 }
 
+static int g_split_tiles = 192;   // swept on the full step: <=100 is 5-30 % slower, >=192 flat
 static int g_bk32 = 0;   // BKT = 32 measured 5-20 % SLOWER on MI355X (fewer resident blocks, more staging registers): off
 
 __global__ void splitk_reduce_kernel(const float* ws, int splits, long MN, int N, float* C, long ldc, float alpha,
@@ -321,9 +322,11 @@ int launch(const GemmP& p, hipStream_t st) {
 
 // Pick split-K so that a launch has enough workgroups to fill 256 CUs; returns splits and sets kchunk.
 int choose_splits(int M, int N, int K, int BM, int BN, long ws_floats, int* kchunk) {
+    // Split K when the tile grid cannot fill the 256 CUs a couple of times over (measured on the whole train step:
+    // splitting below 192 tiles is worth 5-30 % of the step; the workspace round trip + reduce launch is cheap).
     long tiles = (long)ceil_div(M, BM) * ceil_div(N, BN);
     int splits = 1;
-    if (tiles < 192 && K >= 512) {
+    if (tiles < g_split_tiles && K >= 512) {
         splits = (int)((512 + tiles - 1) / tiles);
         int maxs = K / 128;
         if (splits > maxs) splits = maxs;
@@ -390,7 +393,7 @@ static int pick_conv_cfg(int M, int N) {
 
 extern "C" {
 
-void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 100) g_bk32 = cfg - 100; else g_conv_cfg = cfg; }   /* 100/101: tile depth 16/32 */
+void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 1000) g_split_tiles = cfg - 1000; else if (cfg >= 100) g_bk32 = cfg - 100; else g_conv_cfg = cfg; }   /* 100/101: tile depth 16/32; 1000+n: split-K tile threshold n */
 
 // Dense GEMM, row-major.  transa/transb follow BLAS meaning on row-major storage:
 //   transa = 0: A is [M,K] (lda >= K);  1: A is stored [K,M] (lda >= M)
