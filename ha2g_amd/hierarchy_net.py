@@ -59,6 +59,8 @@ class BatchNormParams(nn.Module):
 
     def forward(self, x, act=ACT_NONE):
         """x: contiguous [..., C] (channels last)."""
+        if not self.training:
+            return ops.batch_norm_eval(x, self.weight, self.bias, self.running_mean, self.running_var, 1e-5, act)
         self.num_batches_tracked.add_(1)
         return ops.batch_norm_train(x, self.weight, self.bias, self.running_mean, self.running_var, 0.1, 1e-5, act)
 
@@ -385,7 +387,7 @@ class ResNetSE(nn.Module):
                 bufs[n] = (obj.running_mean, obj.running_var, obj.num_batches_tracked)
             else:
                 tensors.append(obj)
-        outs = wav_engine.WavEncoderFunction.apply(x, vid_indices, self.pose_level, self._names, bufs, *tensors)
+        outs = wav_engine.WavEncoderFunction.apply(x, vid_indices, self.pose_level, self._names, (bufs, self.training), *tensors)
         weight, low, mid, high = outs[:4]
         return weight, low, mid, high, list(outs[4:])
 

@@ -9,7 +9,7 @@ from ._lib import check, lib
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 (OP_ADD, OP_MUL, OP_ADD_RELU, OP_RELU_BWD, OP_LEAKY_BWD, OP_SIGMOID_BWD, OP_ELU, OP_ELU_BWD, OP_REPARAM,
- OP_REPARAM_BWD_LOGVAR, OP_AXPBY, OP_LEAKY, OP_RELU, OP_SCALE, OP_MUL_SCALAR, OP_SIGMOID, OP_SIGMOID_BWD_PRE) = range(17)
+ OP_REPARAM_BWD_LOGVAR, OP_AXPBY, OP_LEAKY, OP_RELU, OP_SCALE, OP_MUL_SCALAR, OP_SIGMOID, OP_SIGMOID_BWD_PRE, OP_RSQRT_EPS) = range(18)
 
 _WS_BYTES = 160 << 20
 _ws = {}
@@ -450,6 +450,15 @@ class BatchNormFunction(torch.autograd.Function):
 
 def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, act=ACT_NONE):
     return BatchNormFunction.apply(x, gamma, beta, running_mean, running_var, momentum, eps, act)
+
+
+def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, act=ACT_NONE):
+    """Inference BatchNorm (module.eval()): normalise with the running statistics; forward only."""
+    if torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad and False):
+        raise NotImplementedError('ha2g_amd: eval-mode BatchNorm is forward-only; wrap inference in torch.no_grad()')
+    x = _f32c(x.contiguous())
+    invstd = eltwise(OP_RSQRT_EPS, running_var, alpha=eps)
+    return bn_apply(x.view(-1, x.shape[-1]), running_mean, invstd, gamma, beta, act).view(x.shape)
 
 
 # ------------------------------------------------------------------------------------------------

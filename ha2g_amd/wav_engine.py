@@ -89,8 +89,14 @@ class _BN:
         self.gamma, self.beta, self.rm, self.rv, self.nbt = gamma, beta, rm, rv, nbt
 
 
-def _bn_fwd(x, bn, training_stats=True):
+_TRAINING = [True]
+
+
+def _bn_fwd(x, bn):
     x2 = _rows(x)
+    if not _TRAINING[0]:                                    # module.eval(): running statistics, no update
+        invstd = ops.eltwise(ops.OP_RSQRT_EPS, bn.rv, alpha=1e-5)
+        return ops.bn_apply(x2, bn.rm, invstd, bn.gamma, bn.beta).view(x.shape), bn.rm, invstd
     mean, invstd = ops.bn_stats(x2, bn.rm, bn.rv, 0.1, 1e-5)
     if bn.nbt is not None:
         bn.nbt.add_(1)
@@ -129,6 +135,10 @@ class WavEncoderFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, vid, L, names, bufs, *tensors):
+        bufs, training = bufs
+        if not training and torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+            raise NotImplementedError('ha2g_amd: the eval-mode audio encoder is forward-only; wrap inference in torch.no_grad()')
+        _TRAINING[0] = training
         P = {}
         it = iter(range(len(tensors)))
         flat_index = {}

@@ -113,7 +113,8 @@ int ha2g_weight_norm_bwd_f32(const float* dw, const float* g, const float* v, co
 /* ---- pointwise / RNG ---- */
 /* op: 0 a+b, 1 a*b, 2 relu(a+b), 3 relu', 4 leaky', 5 sigmoid', 6 elu, 7 elu', 8 reparam (model/embedding_net.py:10-13),
  *     9 reparam d/dlogvar, 10 alpha*a+beta*b, 11 leaky, 12 relu, 13 alpha*a, 14 a*b[0]*alpha (b = device scalar),
- *     15 sigmoid(a), 16 a*sigmoid(b)*sigmoid(-b) (sigmoid' from the pre-activation b) */
+ *     15 sigmoid(a), 16 a*sigmoid(b)*sigmoid(-b) (sigmoid' from the pre-activation b),
+ *     17 1/sqrt(a+alpha) */
 int ha2g_eltwise_f32(int op, const float* a, const float* b, const float* c, float* out, long n, float alpha, float beta, void* stream);
 /* out[r][h] = y[r][h] + y[r][H+h] (sum of the two GRU directions, model/hierarchy_net.py:145); inverse=1: gradient fan-out */
 int ha2g_dirsum_f32(const float* y, float* out, long rows, int H, int inverse, void* stream);

@@ -28,6 +28,8 @@ def batch_norm_train(x, sd, p, momentum=0.1, eps=1e-5, update=True):
     """Train-mode BatchNorm over all dims but channel (dim 1): biased batch variance to normalise,
     unbiased variance into running_var, momentum 0.1 (torch semantics).  Uses the
     fused torch primitive so that the float32 backward has the same (analytic) form as the reference's."""
+    if update == 'eval':                                             # inference: normalise with the running statistics
+        return F.batch_norm(x, sd[p + 'running_mean'], sd[p + 'running_var'], sd[p + 'weight'], sd[p + 'bias'], False, momentum, eps)
     rm = sd[p + 'running_mean'] if update else None
     rv = sd[p + 'running_var'] if update else None
     if update:

@@ -177,6 +177,24 @@ def module_goldens(case, out, dt, perturb=0.0):
     out['contrastive_expr/grad_a'] = a.grad.double().numpy().copy()
     out['contrastive_expr/grad_b'] = b.grad.double().numpy().copy()
 
+    # ---- inference path: .eval() modules (BatchNorm running statistics, no dropout), fresh procedural state ----
+    args, gens, dis, aud, txt = build(case, (15, 21, 27), 3, dt)
+    for m in gens + [dis, aud, txt]:
+        m.eval()
+    with torch.no_grad():
+        w, lo, mid, hi, blend = aud(spec_t, vid_t)
+        out['eval/audio/low'] = lo.double().numpy()
+        out['eval/audio/high'] = hi.double().numpy()
+        out['eval/audio/blend2'] = blend[2].double().numpy()
+        out['eval/dis/out'] = dis(tgt_t).double().numpy()
+        eps2 = proc.EpsStream(case['seed'])
+        ref_embedding_net.reparameterize = lambda mu, logvar: mu + torch.from_numpy(eps2(mu.shape)).to(mu.dtype) * torch.exp(0.5 * logvar)
+        pre = torch.zeros(B, 34, 28, dtype=dt)
+        pre[:, :4, :-1] = tgt_t[:, :4]
+        pre[:, :4, -1] = 1
+        o, *_ = gens[2](pre, text_t, blend[2], vid_t)
+        out['eval/gen/out'] = o.double().numpy()
+
 
 def step_goldens(case, out, dt, expressive=False, perturb=0.0):
     """Two consecutive train steps (epoch 0 = warm-up phase, epoch 11 = GAN phase) through the reference."""

@@ -178,3 +178,32 @@ def test_phys_angle_expressive_palm():
     assert abs(float(l) - float(l64)) <= 2e-5 * abs(float(l64))
     err = float((o.grad.double().cpu() - 2.0 * g64).abs().max() / (2.0 * g64).abs().max())
     assert err < 5e-5, err
+
+
+@pytest.mark.parametrize('name', ['small', 'cfg1'])
+def test_eval_mode_inference(golden, name):
+    """module.eval() forward (BatchNorm running statistics, no dropout) = the path evaluate_testset / synthesis use
+    (reference scripts/train.py:376-417)."""
+    case, ck = CASES[name], Checker(golden(name))
+    _, gens, dis, aud, _ = build_modules(case, DEV)
+    for m in gens + [dis, aud]:
+        m.eval()
+    text, spec, target, vid = (t.to(DEV) for t in batch_for(case))
+    B = case['B']
+    eps = torch.from_numpy(proc.EpsStream(case['seed'])((B, 16))).to(DEV)
+    gens[2].eps_source = lambda shape, device: eps
+    with torch.no_grad():
+        w, lo, mid, hi, blend = aud(spec, vid)
+        ck.close(lo, 'eval/audio/low')
+        ck.close(hi, 'eval/audio/high')
+        ck.close(blend[2], 'eval/audio/blend2')
+        ck.close(dis(target), 'eval/dis/out')
+        pre = torch.zeros(B, 34, 28, device=DEV)
+        pre[:, :4, :-1] = target[:, :4]
+        pre[:, :4, -1] = 1
+        o, *_ = gens[2](pre, text, blend[2], vid)
+        ck.close(o, 'eval/gen/out')
+    for k, b in aud.named_buffers():                      # eval must not touch the running statistics
+        if k.endswith('running_mean'):
+            ref = torch.from_numpy(proc.tensor_for('audio.' + k, b.shape, case['seed']))
+            assert torch.equal(b.cpu(), ref)

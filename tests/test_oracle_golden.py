@@ -149,3 +149,25 @@ def test_train_step_expressive(golden, dt):
     for si, epoch in enumerate((0, 11)):
         ret = tr.train_iter(epoch, text, spec, target, vid, lambda shp: torch.from_numpy(es(shp)).to(dt), perm)
         ck.step(si, ret, tr.grads, sd)
+
+
+@pytest.mark.parametrize('dt', DTS)
+@pytest.mark.parametrize('name', ['small', 'cfg1'])
+def test_eval_mode_inference(golden, name, dt):
+    """Inference path (module.eval(): BatchNorm running statistics) of audio encoder, discriminator and generator."""
+    case, ck = CASES[name], Checker(golden(name), dt)
+    sd = state_for(case, dt)
+    text, spec, target, vid = batch_for(case, dt)
+    B = case['B']
+    with torch.no_grad():
+        w, lo, mid, hi, blend = O.wav_encoder(spec, vid, sd, 'audio.', 3, update_bn='eval')
+        ck.close(lo, 'eval/audio/low')
+        ck.close(hi, 'eval/audio/high')
+        ck.close(blend[2], 'eval/audio/blend2')
+        ck.close(O.conv_discriminator(target, sd, 'dis.', update_bn='eval'), 'eval/dis/out')
+        eps = torch.from_numpy(proc.EpsStream(case['seed'])((B, 16))).to(dt)
+        pre = torch.zeros(B, 34, 28, dtype=dt)
+        pre[:, :4, :-1] = target[:, :4]
+        pre[:, :4, -1] = 1
+        o, *_ = O.pose_generator(pre, text, blend[2], vid, sd, 'g3.', case['n_layers'], case['hidden_size'], eps)
+        ck.close(o, 'eval/gen/out')
