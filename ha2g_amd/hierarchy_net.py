@@ -219,18 +219,50 @@ class Hierarchical_PoseGenerator(nn.Module):
         self.do_flatten_parameters = False
         self.eps_source = default_eps                            # injectable reparameterisation noise (parity tests)
 
+    def _row_split(self, fn, *tensors):
+        """Row-wise sub-networks (no BatchNorm in the generator => rows are independent) are evaluated separately on the
+        rows that will receive gradient and, under no_grad, on the rest, so their backward touches only the former.
+        Active when the fused-chain train step set `gru.grad_slice`; otherwise a plain call."""
+        gs = self.gru.grad_slice
+        if gs is None or not torch.is_grad_enabled():
+            return fn(*tensors)
+        s0, cnt = gs
+        B = tensors[0].shape[0]
+        parts = []
+        for a, b, grad in ((0, s0, False), (s0, s0 + cnt, True), (s0 + cnt, B, False)):
+            if b <= a:
+                continue
+            sl = [t[a:b] for t in tensors]
+            if grad:
+                parts.append(fn(*sl))
+            else:
+                with torch.no_grad():
+                    parts.append(fn(*sl))
+        if isinstance(parts[0], tuple):
+            return tuple(torch.cat([p[i] for p in parts]) for i in range(len(parts[0])))
+        return torch.cat(parts)
+
+    def _speaker(self, vid_indices, eps):
+        z_context = self.speaker_embedding(vid_indices)
+        z_mu = self.speaker_mu(z_context)
+        z_logvar = self.speaker_logvar(z_context)
+        return ops.reparameterize(z_mu, z_logvar, eps), z_mu, z_logvar
+
+    def _head(self, gru_out):
+        output = ops.dirsum(gru_out)                               # sum bidirectional outputs
+        h = self.out[0](output.reshape(-1, output.shape[2]), act=ACT_LEAKY)
+        return self.out[2](h).reshape(gru_out.shape[0], gru_out.shape[1], -1)
+
     def forward(self, pre_seq, in_text, audio_feat_seq=None, vid_indices=None):
         text_feat_seq = None
         if self.input_context != 'none':
-            text_feat_seq = self.text_encoder(in_text)
+            text_feat_seq = self._row_split(self.text_encoder, in_text)
             assert audio_feat_seq.shape[1] == text_feat_seq.shape[1]
         if self.z_obj:
             if self.speaker_embedding:
                 assert vid_indices is not None
-                z_context = self.speaker_embedding(vid_indices)
-                z_mu = self.speaker_mu(z_context)
-                z_logvar = self.speaker_logvar(z_context)
-                z_context = ops.reparameterize(z_mu, z_logvar, self.eps_source(z_mu.shape, z_mu.device))
+                eps = self.eps_source((vid_indices.shape[0], self.z_size), vid_indices.device)
+                z_context, z_mu, z_logvar = self._row_split(self._speaker, vid_indices, eps)
             else:
                 z_mu = z_logvar = None
                 z_context = torch.randn(audio_feat_seq.shape[0], self.z_size, device=audio_feat_seq.device)
@@ -250,10 +282,7 @@ class Hierarchical_PoseGenerator(nn.Module):
             parts.append(z_context.unsqueeze(1).expand(-1, pre_seq.shape[1], -1))
         in_data = torch.cat(parts, dim=2)                          # layout plumbing (cat / expand) stays in torch
         output, _ = self.gru(in_data, None)
-        output = ops.dirsum(output)                                # sum bidirectional outputs
-        h = self.out[0](output.reshape(-1, output.shape[2]), act=ACT_LEAKY)
-        output = self.out[2](h)
-        decoder_outputs = output.reshape(in_data.shape[0], in_data.shape[1], -1)
+        decoder_outputs = self._row_split(self._head, output)
         return decoder_outputs, z_context, z_mu, z_logvar
 
 

@@ -20,12 +20,48 @@ def _stream():
 
 
 def workspace(device):
-    """One persistent scratch buffer per device (split-K partials, reduction partials).  All ops of a step are
-    enqueued on one stream, so sharing it is safe; it is allocated once, outside any graph capture."""
-    key = (device.type, device.index)
+    """One persistent scratch buffer per (device, stream) (split-K partials, reduction partials).  Kernels of one stream
+    run in order, so they can share it; the weight-gradient side stream gets its own.  Allocated once, outside capture."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _ws:
         _ws[key] = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
     return _ws[key]
+
+
+class SideStream:
+    """Fork/join helper: weight / bias gradients are off the critical path of back-propagation (only the optimizer needs
+    them), so backward functions enqueue them on a second HIP stream where they overlap with the data-gradient chain and
+    fill CUs that latency-bound kernels (GRU clusters, small GEMMs) leave idle.
+        with side.section(x.device):   # side stream waits for everything enqueued so far on the main stream
+            dw = gemm(...)
+        ...
+        side.join(x.device)            # main stream waits for the side stream (before the results are handed to autograd)
+    Tensors touched by side-stream kernels must stay referenced until join()."""
+
+    def __init__(self):
+        self.enabled = True
+        self._streams = {}
+
+    def stream(self, device):
+        key = (device.type, device.index)
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device)
+        return self._streams[key]
+
+    def section(self, device):
+        import contextlib
+        if not self.enabled:
+            return contextlib.nullcontext()
+        s = self.stream(device)
+        s.wait_stream(torch.cuda.current_stream(device))
+        return torch.cuda.stream(s)
+
+    def join(self, device):
+        if self.enabled:
+            torch.cuda.current_stream(device).wait_stream(self.stream(device))
+
+
+side = SideStream()
 
 
 class KernelTimer:
@@ -189,6 +225,11 @@ def dropout_mask(shape, p, device):
 # Linear / embedding / pointwise
 # ------------------------------------------------------------------------------------------------
 
+def _null():
+    import contextlib
+    return contextlib.nullcontext()
+
+
 class LinearFunction(torch.autograd.Function):
     """y = act(x W^T + b); x [..., K], W [N, K] (nn.Linear layout)."""
 
@@ -212,12 +253,16 @@ class LinearFunction(torch.autograd.Function):
         if dy2.stride(1) != 1:
             dy2 = dy2.contiguous()
         dx = dw = db = None
+        big = dy2.shape[0] >= 1024                       # tiny layers: the fork/join costs more than it hides
+        with (side.section(dy2.device) if big else _null()):
+            if ctx.needs_input_grad[1]:
+                dw = gemm(dy2, x2, transa=True)
+            if ctx.has_b and ctx.needs_input_grad[2]:
+                db = colsum(dy2)
         if ctx.needs_input_grad[0]:
             dx = gemm(dy2, w).view(ctx.xshape)
-        if ctx.needs_input_grad[1]:
-            dw = gemm(dy2, x2, transa=True)
-        if ctx.has_b and ctx.needs_input_grad[2]:
-            db = colsum(dy2)
+        if big:
+            side.join(dy2.device)
         return dx, dw, db, None
 
 
@@ -380,14 +425,16 @@ class Conv1dFunction(torch.autograd.Function):
         cout = w.shape[0]
         dy2 = act_bwd(dy.reshape(B * To, cout), y, act)
         dx = dw = db = None
+        with side.section(dy2.device):
+            if ctx.needs_input_grad[1]:
+                dw = gemm(dy2, col, transa=True).view(cout, C, k)
+            if ctx.has_b and ctx.needs_input_grad[2]:
+                db = colsum(dy2)
         if ctx.needs_input_grad[0]:
             dcol = gemm(dy2, w.view(cout, C * k))
             dx = torch.empty(B, T, C, dtype=torch.float32, device=dy.device)
             check(lib.ha2g_col2im1d_f32(dcol.data_ptr(), dx.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
-        if ctx.needs_input_grad[1]:
-            dw = gemm(dy2, col, transa=True).view(cout, C, k)
-        if ctx.has_b and ctx.needs_input_grad[2]:
-            db = colsum(dy2)
+        side.join(dy2.device)
         return dx, dw, db, None, None, None, None
 
 
@@ -561,6 +608,7 @@ class BiGRUFunction(torch.autograd.Function):
         B, T, _ = dy.shape
         dev = dy.device
         grads = [None] * (8 * L)
+        keep = []
         for l in range(L - 1, -1, -1):
             inp, y, rs = (t[sl] for t in ctx.saved_bufs[l])
             w = weights[8 * l:8 * l + 8]
@@ -578,24 +626,27 @@ class BiGRUFunction(torch.autograd.Function):
             hp2 = hp.view(B * T, 2 * H)
             need_dx = l > 0 or ctx.needs_input_grad[0]
             dx = torch.empty(B * T, K, dtype=torch.float32, device=dev) if need_dx else None
-            for d in range(2):
-                o = 4 * H * d
-                dgi = dg[:, o:o + 3 * H]
-                w_ih = w[4 * d]
-                if need_dx:
-                    gemm(dgi, w_ih, out=dx, beta=float(d))                          # dX (+)= dgi W_ih
-                grads[8 * l + 4 * d + 0] = gemm(dgi, x2, transa=True)               # dW_ih = dgi^T X
-                dwhh = torch.empty(3 * H, H, dtype=torch.float32, device=dev)
-                hpd = hp2[:, d * H:(d + 1) * H]
-                gemm(dg[:, o:o + 2 * H], hpd, transa=True, out=dwhh[:2 * H])        # rows r,z
-                gemm(dg[:, o + 3 * H:o + 4 * H], hpd, transa=True, out=dwhh[2 * H:])  # rows n (d gh_n)
-                grads[8 * l + 4 * d + 1] = dwhh
-                grads[8 * l + 4 * d + 2] = colsum(dgi)
-                dbhh = torch.empty(3 * H, dtype=torch.float32, device=dev)
-                colsum(dg[:, o:o + 2 * H], out=dbhh[:2 * H])
-                colsum(dg[:, o + 3 * H:o + 4 * H], out=dbhh[2 * H:])
-                grads[8 * l + 4 * d + 3] = dbhh
+            keep.append((dg, hp, x2, y, dy))                                        # side-stream readers: alive until join
+            with side.section(dev):                                                 # weight / bias gradients: off the critical path
+                for d in range(2):
+                    o = 4 * H * d
+                    dgi = dg[:, o:o + 3 * H]
+                    grads[8 * l + 4 * d + 0] = gemm(dgi, x2, transa=True)           # dW_ih = dgi^T X
+                    dwhh = torch.empty(3 * H, H, dtype=torch.float32, device=dev)
+                    hpd = hp2[:, d * H:(d + 1) * H]
+                    gemm(dg[:, o:o + 2 * H], hpd, transa=True, out=dwhh[:2 * H])    # rows r,z
+                    gemm(dg[:, o + 3 * H:o + 4 * H], hpd, transa=True, out=dwhh[2 * H:])  # rows n (d gh_n)
+                    grads[8 * l + 4 * d + 1] = dwhh
+                    grads[8 * l + 4 * d + 2] = colsum(dgi)
+                    dbhh = torch.empty(3 * H, dtype=torch.float32, device=dev)
+                    colsum(dg[:, o:o + 2 * H], out=dbhh[:2 * H])
+                    colsum(dg[:, o + 3 * H:o + 4 * H], out=dbhh[2 * H:])
+                    grads[8 * l + 4 * d + 3] = dbhh
+            if need_dx:
+                for d in range(2):                                                  # critical path: dX (+)= dgi W_ih
+                    gemm(dg[:, 4 * H * d:4 * H * d + 3 * H], w[4 * d], out=dx, beta=float(d))
             dy = dx.view(B, T, K) if need_dx else None
+        side.join(dev)
         if dy is not None and B != Bfull:
             full = torch.zeros(Bfull, T, dy.shape[2], dtype=torch.float32, device=dev)
             full[sl] = dy
