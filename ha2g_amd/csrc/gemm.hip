@@ -285,7 +285,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 }
 
 static int g_split_tiles = 192;   // swept on the full step: <=100 is 5-30 % slower, >=192 flat
-static int g_bk32 = 0;   // BKT = 32 measured 5-20 % SLOWER on MI355X (fewer resident blocks, more staging registers): off
 
 __global__ void splitk_reduce_kernel(const float* ws, int splits, long MN, int N, float* C, long ldc, float alpha,
                                      float beta, const float* bias, int act) {
@@ -306,10 +305,9 @@ template <int MI, int NI, int WM, int WN, int AMODE, int BMODE, bool VEC>
 int launch(const GemmP& p, hipStream_t st) {
     constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
     dim3 grid(ceil_div(p.M, BM), ceil_div(p.N, BN), p.splits);
-    // deep tiles (BKT = 32) halve the barriers per MFMA; the im2col A loader needs a tile inside one filter tap
-    const bool deep = g_bk32 && p.kchunk >= 64 && (AMODE != A_IM || p.g.GC % 32 == 0);
-    if (deep) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 32>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16>), grid, dim3(256), 0, st, p);
+    // tile depth BKT = 16.  (BKT = 32 was measured 5-20 % slower on MI355X: fewer resident blocks per CU, more staging
+    // registers; the template parameter stays for future tuning.)
+    hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16>), grid, dim3(256), 0, st, p);
     HA2G_CHECK_LAUNCH("gemm");
     if (p.splits > 1) {
         long MN = (long)p.M * p.N;
@@ -342,17 +340,27 @@ int choose_splits(int M, int N, int K, int BM, int BN, long ws_floats, int* kchu
 
 template <int AMODE, int BMODE, bool VEC>
 int dispatch_tile(GemmP& p, long ws_floats, hipStream_t st) {
-    // tile shape by problem shape: skinny-N problems use 4x1 waves of 32-wide tiles
-    if (p.N <= 32) {
-        p.splits = choose_splits(p.M, p.N, p.K, 128, 32, ws_floats, &p.kchunk);
-        return launch<1, 1, 4, 1, AMODE, BMODE, VEC>(p, st);
+    // Tile shape by problem shape.  Every CU's SIMDs share one MFMA pipe, so a launch lasts as long as its most loaded
+    // CU: score = per-tile efficiency x useful fraction of the padded tiles x load balance over 256 CUs (split-K fills
+    // the chip when the grid is small, so small grids are scored as balanced).
+    static const int bm[5] = {128, 64, 128, 64, 128}, bn[5] = {128, 128, 64, 64, 32};
+    static const double eff[5] = {1.00, 0.97, 0.93, 0.88, 0.70};
+    int best = 0; double bs = -1.0;
+    for (int c = 0; c < 5; ++c) {
+        long tm = ceil_div(p.M, bm[c]), tn = ceil_div(p.N, bn[c]), tiles = tm * tn;
+        double useful = ((double)p.M * p.N) / ((double)tiles * bm[c] * bn[c]);
+        double balance = tiles >= g_split_tiles ? ((double)tiles / 256.0) / (double)((tiles + 255) / 256) : 0.95;
+        double score = eff[c] * useful * balance;
+        if (score > bs) { bs = score; best = c; }
     }
-    if (p.N <= 64 || (long)ceil_div(p.M, 128) * ceil_div(p.N, 128) < 128) {
-        p.splits = choose_splits(p.M, p.N, p.K, 64, 64, ws_floats, &p.kchunk);
-        return launch<1, 1, 2, 2, AMODE, BMODE, VEC>(p, st);
+    p.splits = choose_splits(p.M, p.N, p.K, bm[best], bn[best], ws_floats, &p.kchunk);
+    switch (best) {
+        case 0: return launch<2, 2, 2, 2, AMODE, BMODE, VEC>(p, st);
+        case 1: return launch<1, 2, 2, 2, AMODE, BMODE, VEC>(p, st);
+        case 2: return launch<1, 2, 4, 1, AMODE, BMODE, VEC>(p, st);
+        case 3: return launch<1, 1, 2, 2, AMODE, BMODE, VEC>(p, st);
+        default: return launch<1, 1, 4, 1, AMODE, BMODE, VEC>(p, st);
     }
-    p.splits = choose_splits(p.M, p.N, p.K, 128, 128, ws_floats, &p.kchunk);
-    return launch<2, 2, 2, 2, AMODE, BMODE, VEC>(p, st);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -393,7 +401,7 @@ static int pick_conv_cfg(int M, int N) {
 
 extern "C" {
 
-void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 1000) g_split_tiles = cfg - 1000; else if (cfg >= 100) g_bk32 = cfg - 100; else g_conv_cfg = cfg; }   /* 100/101: tile depth 16/32; 1000+n: split-K tile threshold n */
+void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 1000) g_split_tiles = cfg - 1000; else g_conv_cfg = cfg; }   /* 1000+n: split-K tile threshold n */
 
 // Dense GEMM, row-major.  transa/transb follow BLAS meaning on row-major storage:
 //   transa = 0: A is [M,K] (lda >= K);  1: A is stored [K,M] (lda >= M)

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Group a tools/rocpd_stats.py summary into kernel families (per-step numbers).  usage: profile_categories.py stats.txt n_steps"""
+import re
+import sys
+rows = []
+for l in open(sys.argv[1]).read().splitlines()[2:]:
+    m = re.match(r'(\S+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)%', l)
+    if m:
+        rows.append((m.group(1), int(m.group(2)), float(m.group(3))))
+steps = int(sys.argv[2])
+def cat(n):
+    if 'gemm_kernel' in n:
+        mm = re.search(r'ILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)', n)
+        am, bm = int(mm.group(5)), int(mm.group(6))
+        return 'conv fwd/dgrad (implicit GEMM)' if am == 2 else ('conv wgrad (implicit GEMM)' if bm == 2 else 'dense GEMM')
+    for key, name in (('gru_', 'GRU recurrences'), ('splitk', 'split-K reduce'), ('colsum', 'bias-grad column sums'),
+                      ('col_partial', 'BatchNorm'), ('bn_', 'BatchNorm'), ('pair_final', 'BatchNorm'),
+                      ('image_col', 'SE pointwise'), ('se_scale', 'SE pointwise'), ('se_bwd', 'SE pointwise'),
+                      ('contrastive', 'contrastive loss'), ('rownorm', 'contrastive loss'), ('at6native', 'torch plumbing (add/fill/copy/cat)'),
+                      ('rocclr', 'torch plumbing (add/fill/copy/cat)'), ('eltwise', 'pointwise (act bwd, adds, masks)'),
+                      ('dropout', 'dropout'), ('im2col', 'im2col/col2im'), ('col2im', 'im2col/col2im'), ('embedding', 'embedding'),
+                      ('adam', 'Adam'), ('stem_', 'stem conv'), ('pixel_shuffle', 'layout (shuffle/pack/permute)'),
+                      ('nhwc_to', 'layout (shuffle/pack/permute)'), ('ohwi', 'layout (shuffle/pack/permute)'), ('weight_norm', 'weight norm'),
+                      ('dirsum', 'pointwise (act bwd, adds, masks)'), ('blend', 'blend'), ('huber', 'small losses'), ('sum_kernel', 'small losses'),
+                      ('phys', 'small losses'), ('kld', 'small losses'), ('divreg', 'small losses'), ('gan_', 'small losses')):
+        if key in n:
+            return name
+    return 'other: ' + n[:40]
+agg = {}
+for n, c, ms in rows:
+    a = agg.setdefault(cat(n), [0, 0.0])
+    a[0] += c
+    a[1] += ms
+tot = sum(v[1] for v in agg.values())
+print('%-40s %10s %12s %7s' % ('family', 'launches', 'ms/step', 'share'))
+for k, (c, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print('%-40s %10d %12.2f %6.1f%%' % (k, c // steps, ms / steps, 100 * ms / tot))
+print('%-40s %10d %12.2f' % ('total', sum(v[0] for v in agg.values()) // steps, tot / steps))
