@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         }
 }
 
+static int g_wgrad_blocks = 1024;
 static int g_split_tiles = 192;   // swept on the full step: <=100 is 5-30 % slower, >=192 flat
 
 __global__ void splitk_reduce_kernel(const float* ws, int splits, long MN, int N, float* C, long ldc, float alpha,
@@ -401,7 +402,7 @@ static int pick_conv_cfg(int M, int N) {
 
 extern "C" {
 
-void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 1000) g_split_tiles = cfg - 1000; else g_conv_cfg = cfg; }   /* 1000+n: split-K tile threshold n */
+void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 10000) g_wgrad_blocks = cfg - 10000; else if (cfg >= 1000) g_split_tiles = cfg - 1000; else g_conv_cfg = cfg; }   /* 1000+n: split-K tile threshold n; 10000+n: wgrad block target n */
 
 // Dense GEMM, row-major.  transa/transb follow BLAS meaning on row-major storage:
 //   transa = 0: A is [M,K] (lda >= K);  1: A is stored [K,M] (lda >= M)
@@ -465,7 +466,7 @@ long ha2g_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, i
     long K = (long)N * OH * OW, MN = (long)Cout * KH * KW * Cin;
     int BM = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
     long tiles = (long)ceil_div(Cout, BM) * ceil_div(KH * KW * Cin, 128);
-    long splits = (1024 + tiles - 1) / tiles;
+    long splits = (g_wgrad_blocks + tiles - 1) / tiles;
     if (splits > K / 256) splits = K / 256;
     if (splits < 1) splits = 1;
     return splits * MN * 4;

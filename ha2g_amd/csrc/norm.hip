@@ -135,7 +135,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, float* __restrict__ dx,
-                                    long rows, int C) {
+                                    long rows, int C, int relu_mask) {
     const int C4 = C >> 2;
     const long total = rows * C4;
     const float invn = 1.f / (float)rows;
@@ -151,6 +151,9 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
         r.y = (float)((double)g.y * is.y * ((double)d.y - s1.y * dn - ((double)v.y - mu.y) * is.y * (s2.y * dn)));
         r.z = (float)((double)g.z * is.z * ((double)d.z - s1.z * dn - ((double)v.z - mu.z) * is.z * (s2.z * dn)));
         r.w = (float)((double)g.w * is.w * ((double)d.w - s1.w * dn - ((double)v.w - mu.w) * is.w * (s2.w * dn)));
+        if (relu_mask) {          // x is a ReLU output (conv -> ReLU -> BN): chain the ReLU derivative, mask = (x > 0)
+            r.x = v.x > 0.f ? r.x : 0.f; r.y = v.y > 0.f ? r.y : 0.f; r.z = v.z > 0.f ? r.z : 0.f; r.w = v.w > 0.f ? r.w : 0.f;
+        }
         reinterpret_cast<float4*>(dx)[i] = r;
     }
 }
@@ -259,8 +262,9 @@ int ha2g_bn_apply_f32(const float* x, const float* mean, const float* invstd, co
     return 0;
 }
 // dgamma = sum dy*xhat, dbeta = sum dy, dx as torch's batch-norm backward (train mode)
+// relu_mask = 1: x is the output of a ReLU that precedes the BatchNorm; dx then is the gradient w.r.t. the ReLU's INPUT
 int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx,
-                    float* dgamma, float* dbeta, long rows, int C, float* ws, void* stream) {
+                    float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* ws, void* stream) {
     HA2G_REQUIRE(okC(C), "bn: unsupported channel count %d", C);
     hipStream_t st = (hipStream_t)stream;
     int nb = chunk_blocks(rows);
@@ -268,7 +272,7 @@ int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const fl
     hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, C, dbeta, dgamma);
     if (dx)
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, st, dy, x, mean, invstd, gamma, dbeta,
-                           dgamma, dx, rows, C);
+                           dgamma, dx, rows, C, relu_mask);
     HA2G_CHECK_LAUNCH("bn_bwd");
     return 0;
 }

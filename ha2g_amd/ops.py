@@ -465,12 +465,12 @@ def bn_apply(x2, mean, invstd, gamma, beta, act=ACT_NONE, out=None):
     return out
 
 
-def bn_bwd(dy2, x2, mean, invstd, gamma, need_dx=True):
+def bn_bwd(dy2, x2, mean, invstd, gamma, need_dx=True, relu_mask=False):
     rows, C = x2.shape
     dx = torch.empty_like(x2) if need_dx else None
     dgamma, dbeta = empty(C, like=x2), empty(C, like=x2)
     check(lib.ha2g_bn_bwd_f32(dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dx),
-                              dgamma.data_ptr(), dbeta.data_ptr(), rows, C, workspace(x2.device).data_ptr(), _stream()))
+                              dgamma.data_ptr(), dbeta.data_ptr(), rows, C, int(relu_mask), workspace(x2.device).data_ptr(), _stream()))
     return dx, dgamma, dbeta
 
 

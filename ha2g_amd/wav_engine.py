@@ -266,9 +266,9 @@ class WavEncoderFunction(torch.autograd.Function):
             dpacked = ops.gemm(dy, P['fc_%s.weight' % t])
             dat = _tap_pack(dpacked, inverse=True, shape=ashape)
             bn = P['bn_%s' % t]
-            dct, dg, dbt = ops.bn_bwd(_rows(dat), _rows(ct), mt, st, bn.gamma)
+            dct, dg, dbt = ops.bn_bwd(_rows(dat), _rows(ct), mt, st, bn.gamma, relu_mask=True)     # BN' and ReLU' in one pass
             G['bn_%s' % t] = (dg, dbt)
-            dct = ops.eltwise(ops.OP_RELU_BWD, dct, _rows(ct)).view(ct.shape)
+            dct = dct.view(ct.shape)
             wt = _ohwi(P['conv_%s.weight' % t])
             G['conv_%s.weight' % t] = conv_wgrad(fin, dct, wt, 1, 0)
             G['conv_%s.bias' % t] = ops.colsum(_rows(dct))
@@ -303,11 +303,14 @@ class WavEncoderFunction(torch.autograd.Function):
                 wb = _ohwi(P[b + 'conv2.weight'])
                 G[b + 'conv2.weight'] = conv_wgrad(a1, dc2, wb, 1, 1)
                 da1 = conv_dgrad(dc2, wb, a1.shape, 1, 1)
-                dc1, dg1, dbb1 = ops.bn_bwd(_rows(da1), _rows(c1), m1, s1, P[b + 'bn1'].gamma)
+                dc1, dg1, dbb1 = ops.bn_bwd(_rows(da1), _rows(c1), m1, s1, P[b + 'bn1'].gamma, relu_mask=True)
                 G[b + 'bn1'] = (dg1, dbb1)
-                dc1 = ops.eltwise(ops.OP_RELU_BWD, dc1, _rows(c1)).view(c1.shape)
+                dc1 = dc1.view(c1.shape)
                 wa = _ohwi(P[b + 'conv1.weight'])
                 G[b + 'conv1.weight'] = conv_wgrad(x, dc1, wa, stride, 1)
+                if cd is None:
+                    dx = conv_dgrad(dc1, wa, x.shape, stride, 1, out=dres, beta=1.0)      # identity shortcut: accumulate onto d(residual)
+                    continue
                 dxin = conv_dgrad(dc1, wa, x.shape, stride, 1)
                 if cd is not None:
                     dcd, dgd, dbd = ops.bn_bwd(_rows(dres), _rows(cd), md, sd, P[b + 'downsample.1'].gamma)
@@ -321,9 +324,8 @@ class WavEncoderFunction(torch.autograd.Function):
                     dx = ops.eltwise(ops.OP_ADD, dxin, dres)
         # ---- stem backward ----
         spec, c0, m0, s0 = S['stem']
-        dc0, dg0, db0 = ops.bn_bwd(_rows(dx), _rows(c0), m0, s0, P['bn1'].gamma)
+        dc0, dg0, db0 = ops.bn_bwd(_rows(dx), _rows(c0), m0, s0, P['bn1'].gamma, relu_mask=True)
         G['bn1'] = (dg0, db0)
-        dc0 = ops.eltwise(ops.OP_RELU_BWD, dc0, _rows(c0))
         dw1, dbias1 = torch.empty_like(P['conv1.weight'].contiguous()), torch.empty_like(P['conv1.bias'])
         Bn, H0, W0 = spec.shape
         check(lib.ha2g_stem_conv_wgrad_f32(spec.data_ptr(), dc0.data_ptr(), dw1.data_ptr(), dbias1.data_ptr(), Bn, H0, W0, 0.0,
