@@ -100,13 +100,17 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __res
 }
 
 __global__ __launch_bounds__(256) void pair_final_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ out0,
-                                                         float* __restrict__ out1) {
+                                                         float* __restrict__ out1, float* __restrict__ acc0, float* __restrict__ acc1) {
     const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
     for (int b = lane; b < nblk; b += 64) { s1 += part[((long)b * 2) * C + c]; s2 += part[((long)b * 2 + 1) * C + c]; }
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-    if (lane == 0) { out0[c] = (float)s1; out1[c] = (float)s2; }
+    if (lane == 0) {
+        out0[c] = (float)s1; out1[c] = (float)s2;
+        if (acc0) acc0[c] += (float)s1;                  // optional: accumulate straight into the parameters' .grad buffers
+        if (acc1) acc1[c] += (float)s2;
+    }
 }
 
 // y = (x - mean) * invstd * gamma + beta ; act: 0 none, 2 leaky-relu(0.01)
@@ -264,12 +268,13 @@ int ha2g_bn_apply_f32(const float* x, const float* mean, const float* invstd, co
 // dgamma = sum dy*xhat, dbeta = sum dy, dx as torch's batch-norm backward (train mode)
 // relu_mask = 1: x is the output of a ReLU that precedes the BatchNorm; dx then is the gradient w.r.t. the ReLU's INPUT
 int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx,
-                    float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* ws, void* stream) {
+                    float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta, float* ws,
+                    void* stream) {
     HA2G_REQUIRE(okC(C), "bn: unsupported channel count %d", C);
     hipStream_t st = (hipStream_t)stream;
     int nb = chunk_blocks(rows);
     hipLaunchKernelGGL(col_partial_kernel<1>, dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
-    hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, C, dbeta, dgamma);
+    hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, C, dbeta, dgamma, acc_dbeta, acc_dgamma);
     if (dx)
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, st, dy, x, mean, invstd, gamma, dbeta,
                            dgamma, dx, rows, C, relu_mask);

@@ -230,6 +230,18 @@ def _null():
     return contextlib.nullcontext()
 
 
+DIRECT_GRAD = True     # accumulate weight gradients straight into an existing `.grad` buffer (beta = 1 epilogues) instead of
+                       # returning a temporary that autograd then adds with its own kernel (one at::add per parameter)
+
+
+def _grad_target(param):
+    """The parameter's installed gradient buffer if a kernel may accumulate into it directly, else None."""
+    g = param.grad if DIRECT_GRAD and param.is_leaf else None
+    if g is None or g.shape != param.shape or g.dtype != torch.float32 or g.stride() != param.stride():
+        return None
+    return g
+
+
 class LinearFunction(torch.autograd.Function):
     """y = act(x W^T + b); x [..., K], W [N, K] (nn.Linear layout)."""
 
@@ -238,11 +250,14 @@ class LinearFunction(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         if x2.stride(1) != 1:
             x2 = x2.contiguous()
+        w_in = w
         w = w.contiguous()
         y = gemm(x2, w, transb=True, bias=b, act=act)
         ctx.act = act
         ctx.xshape = x.shape
         ctx.has_b = b is not None
+        ctx.bias_ref = b
+        ctx.wref = w_in
         ctx.save_for_backward(x2, w, y if act != ACT_NONE else None)
         return y.view(*x.shape[:-1], w.shape[0])
 
@@ -256,9 +271,17 @@ class LinearFunction(torch.autograd.Function):
         big = dy2.shape[0] >= 1024                       # tiny layers: the fork/join costs more than it hides
         with (side.section(dy2.device) if big else _null()):
             if ctx.needs_input_grad[1]:
-                dw = gemm(dy2, x2, transa=True)
+                tgt = _grad_target(ctx.wref)
+                if tgt is not None and tgt.is_contiguous():
+                    gemm(dy2, x2, transa=True, out=tgt, beta=1.0)
+                else:
+                    dw = gemm(dy2, x2, transa=True)
             if ctx.has_b and ctx.needs_input_grad[2]:
-                db = colsum(dy2)
+                tgt = _grad_target(ctx.bias_ref) if ctx.bias_ref is not None else None
+                if tgt is not None:
+                    colsum(dy2, out=tgt, beta=1.0)
+                else:
+                    db = colsum(dy2)
         if ctx.needs_input_grad[0]:
             dx = gemm(dy2, w).view(ctx.xshape)
         if big:
@@ -278,16 +301,19 @@ class EmbeddingFunction(torch.autograd.Function):
         check(lib.ha2g_embedding_fwd_f32(tok.data_ptr(), w.data_ptr(), out.data_ptr(), tok.numel(), w.shape[1], _stream()))
         ctx.save_for_backward(tok)
         ctx.wshape = w.shape
+        ctx.wref = w
         return out
 
     @staticmethod
     def backward(ctx, dy):
         (tok,) = ctx.saved_tensors
-        dw = torch.zeros(ctx.wshape, dtype=torch.float32, device=dy.device)
+        tgt = _grad_target(ctx.wref)
+        direct = tgt is not None and tgt.is_contiguous()
+        dw = tgt if direct else torch.zeros(ctx.wshape, dtype=torch.float32, device=dy.device)
         dy = dy.contiguous()
         check(lib.ha2g_embedding_bwd_f32(tok.data_ptr(), dy.data_ptr(), dw.data_ptr(), tok.numel(), ctx.wshape[1], 0,
-                                         workspace(dy.device).data_ptr(), _stream()))
-        return None, dw
+                                         workspace(dy.device).data_ptr(), _stream()))          # the kernel accumulates (dW +=)
+        return None, (None if direct else dw)
 
 
 def embedding(tok, w):
@@ -465,12 +491,15 @@ def bn_apply(x2, mean, invstd, gamma, beta, act=ACT_NONE, out=None):
     return out
 
 
-def bn_bwd(dy2, x2, mean, invstd, gamma, need_dx=True, relu_mask=False):
+def bn_bwd(dy2, x2, mean, invstd, gamma, need_dx=True, relu_mask=False, acc=None):
+    """acc = (gamma.grad, beta.grad) buffers to accumulate into directly (the returned dgamma/dbeta are the fresh sums)."""
     rows, C = x2.shape
     dx = torch.empty_like(x2) if need_dx else None
     dgamma, dbeta = empty(C, like=x2), empty(C, like=x2)
+    ag, ab = acc if acc is not None else (None, None)
     check(lib.ha2g_bn_bwd_f32(dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dx),
-                              dgamma.data_ptr(), dbeta.data_ptr(), rows, C, int(relu_mask), workspace(x2.device).data_ptr(), _stream()))
+                              dgamma.data_ptr(), dbeta.data_ptr(), rows, C, int(relu_mask), _p(ag), _p(ab),
+                              workspace(x2.device).data_ptr(), _stream()))
     return dx, dgamma, dbeta
 
 
@@ -631,17 +660,29 @@ class BiGRUFunction(torch.autograd.Function):
                 for d in range(2):
                     o = 4 * H * d
                     dgi = dg[:, o:o + 3 * H]
-                    grads[8 * l + 4 * d + 0] = gemm(dgi, x2, transa=True)           # dW_ih = dgi^T X
-                    dwhh = torch.empty(3 * H, H, dtype=torch.float32, device=dev)
+                    tg = [_grad_target(w[4 * d + i]) for i in range(4)]
+                    tg = [t if (t is not None and t.is_contiguous()) else None for t in tg]
+                    if tg[0] is not None:
+                        gemm(dgi, x2, transa=True, out=tg[0], beta=1.0)             # dW_ih += dgi^T X, straight into .grad
+                    else:
+                        grads[8 * l + 4 * d + 0] = gemm(dgi, x2, transa=True)
+                    bt = 1.0 if tg[1] is not None else 0.0
+                    dwhh = tg[1] if tg[1] is not None else torch.empty(3 * H, H, dtype=torch.float32, device=dev)
                     hpd = hp2[:, d * H:(d + 1) * H]
-                    gemm(dg[:, o:o + 2 * H], hpd, transa=True, out=dwhh[:2 * H])    # rows r,z
-                    gemm(dg[:, o + 3 * H:o + 4 * H], hpd, transa=True, out=dwhh[2 * H:])  # rows n (d gh_n)
-                    grads[8 * l + 4 * d + 1] = dwhh
-                    grads[8 * l + 4 * d + 2] = colsum(dgi)
-                    dbhh = torch.empty(3 * H, dtype=torch.float32, device=dev)
-                    colsum(dg[:, o:o + 2 * H], out=dbhh[:2 * H])
-                    colsum(dg[:, o + 3 * H:o + 4 * H], out=dbhh[2 * H:])
-                    grads[8 * l + 4 * d + 3] = dbhh
+                    gemm(dg[:, o:o + 2 * H], hpd, transa=True, out=dwhh[:2 * H], beta=bt)    # rows r,z
+                    gemm(dg[:, o + 3 * H:o + 4 * H], hpd, transa=True, out=dwhh[2 * H:], beta=bt)  # rows n (d gh_n)
+                    if tg[1] is None:
+                        grads[8 * l + 4 * d + 1] = dwhh
+                    if tg[2] is not None:
+                        colsum(dgi, out=tg[2], beta=1.0)
+                    else:
+                        grads[8 * l + 4 * d + 2] = colsum(dgi)
+                    bt = 1.0 if tg[3] is not None else 0.0
+                    dbhh = tg[3] if tg[3] is not None else torch.empty(3 * H, dtype=torch.float32, device=dev)
+                    colsum(dg[:, o:o + 2 * H], out=dbhh[:2 * H], beta=bt)
+                    colsum(dg[:, o + 3 * H:o + 4 * H], out=dbhh[2 * H:], beta=bt)
+                    if tg[3] is None:
+                        grads[8 * l + 4 * d + 3] = dbhh
             if need_dx:
                 for d in range(2):                                                  # critical path: dX (+)= dgi W_ih
                     gemm(dg[:, 4 * H * d:4 * H * d + 3 * H], w[4 * d], out=dx, beta=float(d))

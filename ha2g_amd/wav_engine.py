@@ -64,17 +64,26 @@ def conv_dgrad(dy, w_ohwi, xshape, stride, pad, out=None, beta=0.0):
     return out
 
 
-def conv_wgrad(x, dy, w_ohwi, stride, pad):
-    """-> gradient as a logical OIHW tensor with channels_last (OHWI) memory, matching the parameter."""
+def conv_wgrad(x, dy, w_ohwi, stride, pad, into=None):
+    """-> gradient as a logical OIHW tensor with channels_last (OHWI) memory, matching the parameter.
+    into = the parameter's .grad (logical OIHW, physical OHWI): accumulate there (beta = 1) and return None."""
     N, H, W, Cin = x.shape
     Cout, KH, KW, _ = w_ohwi.shape
-    dw = empty(Cout, KH, KW, Cin, like=x)
+    beta = 0.0
+    if into is not None:
+        dwp = into.permute(0, 2, 3, 1)
+        if dwp.is_contiguous():
+            dw, beta = dwp, 1.0
+        else:
+            into = None
+    if into is None:
+        dw = empty(Cout, KH, KW, Cin, like=x)
     ws = workspace(x.device)
     need = lib.ha2g_conv2d_wgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad)
     assert need <= ws.numel() * 4, 'wgrad workspace %d > %d' % (need, ws.numel() * 4)
-    check(lib.ha2g_conv2d_wgrad_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad, 0.0,
+    check(lib.ha2g_conv2d_wgrad_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad, beta,
                                     ws.data_ptr(), ws.numel() * 4, _stream()))
-    return dw.permute(0, 3, 1, 2)
+    return None if into is not None else dw.permute(0, 3, 1, 2)
 
 
 def _rows(t):
@@ -225,7 +234,39 @@ class WavEncoderFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dw_ext, dlow, dmid, dhigh, *dblend):
         S, P, L = ctx.S, ctx.P, ctx.L
-        G = {}                                            # name -> grad (BN: (dgamma, dbeta))
+        G = {}                                            # name -> grad (BN: (dgamma, dbeta)); None = accumulated in place
+
+        def tgt(t):                                       # a parameter's installed .grad buffer, if kernels may add into it
+            g = ops._grad_target(t)
+            return g if (g is not None and (g.is_contiguous() or g.dim() == 4)) else None
+
+        def gw(name, a, b_):                              # dW (+)= a^T b_
+            t = tgt(P[name])
+            if t is not None and t.is_contiguous():
+                ops.gemm(a, b_, transa=True, out=t, beta=1.0)
+            else:
+                G[name] = ops.gemm(a, b_, transa=True)
+
+        def gb(name, a):                                  # db (+)= column sums of a
+            t = tgt(P[name])
+            if t is not None:
+                ops.colsum(a, out=t, beta=1.0)
+            else:
+                G[name] = ops.colsum(a)
+
+        def gconv(name, xin, dyc, w_ohwi, stride, pad):
+            r = conv_wgrad(xin, dyc, w_ohwi, stride, pad, into=tgt(P[name]))
+            if r is not None:
+                G[name] = r
+
+        def gbn(name, dy2, x2, mean, invstd, relu_mask=False):
+            bn = P[name]
+            tg_, tb_ = tgt(bn.gamma), tgt(bn.beta)
+            acc = (tg_, tb_) if (tg_ is not None and tb_ is not None) else None
+            dx_, dg_, db_ = ops.bn_bwd(dy2, x2, mean, invstd, bn.gamma, relu_mask=relu_mask, acc=acc)
+            if acc is None:
+                G[name] = (dg_, db_)
+            return dx_
         low, mid, high = S['feats']
         B, T, _ = low.shape
         dev = low.device
@@ -242,16 +283,16 @@ class WavEncoderFunction(torch.autograd.Function):
             check(lib.ha2g_blend_bwd_f32(db.data_ptr(), _p(dwe), wsm.data_ptr(), low.data_ptr(), mid.data_ptr(), high.data_ptr(),
                                          df[0].data_ptr(), df[1].data_ptr(), df[2].data_ptr(), dlogits.data_ptr(), B, L, T * 32, _stream()))
             # speaker MLP backward
-            G['fc2.weight'] = ops.gemm(dlogits, e1, transa=True)
-            G['fc2.bias'] = ops.colsum(dlogits)
+            gw('fc2.weight', dlogits, e1)
+            gb('fc2.bias', dlogits)
             de1 = ops.gemm(dlogits, P['fc2.weight'])
             df1 = ops.eltwise(ops.OP_ELU_BWD, de1, e1)
-            G['fc1.weight'] = ops.gemm(df1, e0, transa=True)
-            G['fc1.bias'] = ops.colsum(df1)
+            gw('fc1.weight', df1, e0)
+            gb('fc1.bias', df1)
             de0 = ops.gemm(df1, P['fc1.weight'])
             dz = ops.eltwise(ops.OP_ELU_BWD, de0, e0)
-            G['speaker_embedding.1.weight'] = ops.gemm(dz, ze, transa=True)
-            G['speaker_embedding.1.bias'] = ops.colsum(dz)
+            gw('speaker_embedding.1.weight', dz, ze)
+            gb('speaker_embedding.1.bias', dz)
             dze = ops.gemm(dz, P['speaker_embedding.1.weight'])
             demb = torch.zeros_like(P['speaker_embedding.0.weight'])
             check(lib.ha2g_embedding_bwd_f32(vid.data_ptr(), dze.data_ptr(), demb.data_ptr(), B, 16, -1, workspace(dev).data_ptr(), _stream()))
@@ -261,17 +302,14 @@ class WavEncoderFunction(torch.autograd.Function):
         for ti, (t, C, k, r) in enumerate(TAPS):
             fshape, fin, ct, mt, st, ashape, packed = S['tap_' + t]
             dy = df[ti].view(B * ashape[2], 32)
-            G['fc_%s.weight' % t] = ops.gemm(dy, packed, transa=True)
-            G['fc_%s.bias' % t] = ops.colsum(dy)
+            gw('fc_%s.weight' % t, dy, packed)
+            gb('fc_%s.bias' % t, dy)
             dpacked = ops.gemm(dy, P['fc_%s.weight' % t])
             dat = _tap_pack(dpacked, inverse=True, shape=ashape)
-            bn = P['bn_%s' % t]
-            dct, dg, dbt = ops.bn_bwd(_rows(dat), _rows(ct), mt, st, bn.gamma, relu_mask=True)     # BN' and ReLU' in one pass
-            G['bn_%s' % t] = (dg, dbt)
-            dct = dct.view(ct.shape)
+            dct = gbn('bn_%s' % t, _rows(dat), _rows(ct), mt, st, relu_mask=True).view(ct.shape)     # BN' and ReLU' in one pass
             wt = _ohwi(P['conv_%s.weight' % t])
-            G['conv_%s.weight' % t] = conv_wgrad(fin, dct, wt, 1, 0)
-            G['conv_%s.bias' % t] = ops.colsum(_rows(dct))
+            gconv('conv_%s.weight' % t, fin, dct, wt, 1, 0)
+            gb('conv_%s.bias' % t, _rows(dct))
             dfin = conv_dgrad(dct, wt, fin.shape, 1, 0)
             dfeat[ti + 1] = _pixel_shuffle(dfin, r, inverse=True, shape=fshape) if r > 1 else dfin
         # ---- trunk backward ----
@@ -288,44 +326,37 @@ class WavEncoderFunction(torch.autograd.Function):
                 ds = empty(N, C, like=b2)
                 check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, _stream()))
                 dsc = ops.eltwise(ops.OP_SIGMOID_BWD_PRE, ds, su)
-                G[b + 'se.fc.2.weight'] = ops.gemm(dsc, h1, transa=True)
-                G[b + 'se.fc.2.bias'] = ops.colsum(dsc)
+                gw(b + 'se.fc.2.weight', dsc, h1)
+                gb(b + 'se.fc.2.bias', dsc)
                 dh1 = ops.eltwise(ops.OP_RELU_BWD, ops.gemm(dsc, P[b + 'se.fc.2.weight']), h1)
-                G[b + 'se.fc.0.weight'] = ops.gemm(dh1, pooled, transa=True)
-                G[b + 'se.fc.0.bias'] = ops.colsum(dh1)
+                gw(b + 'se.fc.0.weight', dh1, pooled)
+                gb(b + 'se.fc.0.bias', dh1)
                 dpool = ops.gemm(dh1, P[b + 'se.fc.0.weight'], alpha=1.0 / HW)
                 dres, db2 = torch.empty_like(b2), torch.empty_like(b2)
                 check(lib.ha2g_se_bwd_apply_f32(dout.data_ptr(), out.data_ptr(), sc.data_ptr(), dpool.data_ptr(), dres.data_ptr(),
                                                 db2.data_ptr(), N, HW, C, _stream()))
-                dc2, dg2, dbb2 = ops.bn_bwd(_rows(db2), _rows(c2), m2, s2, P[b + 'bn2'].gamma)
-                G[b + 'bn2'] = (dg2, dbb2)
-                dc2 = dc2.view(c2.shape)
+                dc2 = gbn(b + 'bn2', _rows(db2), _rows(c2), m2, s2).view(c2.shape)
                 wb = _ohwi(P[b + 'conv2.weight'])
-                G[b + 'conv2.weight'] = conv_wgrad(a1, dc2, wb, 1, 1)
+                gconv(b + 'conv2.weight', a1, dc2, wb, 1, 1)
                 da1 = conv_dgrad(dc2, wb, a1.shape, 1, 1)
-                dc1, dg1, dbb1 = ops.bn_bwd(_rows(da1), _rows(c1), m1, s1, P[b + 'bn1'].gamma, relu_mask=True)
-                G[b + 'bn1'] = (dg1, dbb1)
-                dc1 = dc1.view(c1.shape)
+                dc1 = gbn(b + 'bn1', _rows(da1), _rows(c1), m1, s1, relu_mask=True).view(c1.shape)
                 wa = _ohwi(P[b + 'conv1.weight'])
-                G[b + 'conv1.weight'] = conv_wgrad(x, dc1, wa, stride, 1)
+                gconv(b + 'conv1.weight', x, dc1, wa, stride, 1)
                 if cd is None:
                     dx = conv_dgrad(dc1, wa, x.shape, stride, 1, out=dres, beta=1.0)      # identity shortcut: accumulate onto d(residual)
                     continue
                 dxin = conv_dgrad(dc1, wa, x.shape, stride, 1)
                 if cd is not None:
-                    dcd, dgd, dbd = ops.bn_bwd(_rows(dres), _rows(cd), md, sd, P[b + 'downsample.1'].gamma)
-                    G[b + 'downsample.1'] = (dgd, dbd)
-                    dcd = dcd.view(cd.shape)
+                    dcd = gbn(b + 'downsample.1', _rows(dres), _rows(cd), md, sd).view(cd.shape)
                     wd = _ohwi(P[b + 'downsample.0.weight'])
-                    G[b + 'downsample.0.weight'] = conv_wgrad(x, dcd, wd, 2, 0)
+                    gconv(b + 'downsample.0.weight', x, dcd, wd, 2, 0)
                     conv_dgrad(dcd, wd, x.shape, 2, 0, out=dxin, beta=1.0)
                     dx = dxin
                 else:
                     dx = ops.eltwise(ops.OP_ADD, dxin, dres)
         # ---- stem backward ----
         spec, c0, m0, s0 = S['stem']
-        dc0, dg0, db0 = ops.bn_bwd(_rows(dx), _rows(c0), m0, s0, P['bn1'].gamma, relu_mask=True)
-        G['bn1'] = (dg0, db0)
+        dc0 = gbn('bn1', _rows(dx), _rows(c0), m0, s0, relu_mask=True)
         dw1, dbias1 = torch.empty_like(P['conv1.weight'].contiguous()), torch.empty_like(P['conv1.bias'])
         Bn, H0, W0 = spec.shape
         check(lib.ha2g_stem_conv_wgrad_f32(spec.data_ptr(), dc0.data_ptr(), dw1.data_ptr(), dbias1.data_ptr(), Bn, H0, W0, 0.0,

@@ -88,7 +88,8 @@ int ha2g_bn_apply_f32(const float* x, const float* mean, const float* invstd, co
                       float* y, long rows, int C, int act, void* stream);
 /* relu_mask = 1: x is a ReLU output feeding the BatchNorm (conv -> ReLU -> BN, ResNetBlocks.py:24-26); dx is then masked by x > 0 */
 int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma,
-                    float* dx, float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* ws, void* stream);
+                    float* dx, float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma /*nullable: += */,
+                    float* acc_dbeta /*nullable: += */, float* ws, void* stream);
 /* ---- squeeze-excite pointwise pieces (model/ResNetBlocks.py:81-95 and the residual tail :33-36) ---- */
 int ha2g_hw_mean_f32(const float* x, float* out, int N, int HW, int C, void* stream);
 int ha2g_se_scale_add_relu_f32(const float* x, const float* s, const float* res, float* out, int N, int HW, int C, void* stream);
