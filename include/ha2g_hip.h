@@ -46,6 +46,9 @@ long ha2g_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, i
 int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout, int KH,
                           int KW, int stride, int pad, float beta, float* ws, long ws_bytes, void* stream);
 int ha2g_conv2d_weight_ohwi_to_ihwo_f32(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
+/* 0 (default): exact fp32 MFMA everywhere.  1 (opt-in): GEMMs/convolutions whose operands stage along k run on the
+ * split-bf16 core (3 x bf16 MFMA, fp32 accumulate): 1.5-2.5x faster, ~4e-6 rms-rel per GEMM instead of ~4e-7 */
+void ha2g_gemm_set_mode(int x3);
 void ha2g_conv_debug_cfg(int cfg);   /* tile-shape override for tools/conv_bench.py (-1 = heuristic) */
 /* stem Conv2d(1->32, 3x3, pad 1) + bias + ReLU (model/ResNetSE34V2.py:27,127-128); x [N,H,W], y [N,H,W,32] */
 int ha2g_stem_conv_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, void* stream);

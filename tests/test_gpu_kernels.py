@@ -262,3 +262,22 @@ def test_gru_cluster_backward_matches(B):
     assert ops.gru_cluster_error(dev) == 0
     for a, b in zip(*res):
         assert relerr(a, b.cpu()) < 2e-5
+
+
+def test_split_bf16_core_opt_in():
+    """The opt-in bf16x3 matrix core (3 x bf16 MFMA, fp32 accumulate) stays within 1e-5 rel of float64 on a GEMM and a conv."""
+    import torch.nn.functional as F
+    from ha2g_amd import ops, wav_engine as we
+    from ha2g_amd._lib import lib
+    dev = _dev()
+    a, b = rnd((1000, 600), 41), rnd((300, 600), 42)
+    x = rnd((2, 64, 20, 12), 43)
+    w = rnd((64, 64, 3, 3), 44, 0.05)
+    lib.ha2g_gemm_set_mode(1)
+    try:
+        c = ops.gemm(a.to(dev), b.to(dev), transb=True)
+        y = we.conv_fwd(x.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), None, 1, 1, 0)
+    finally:
+        lib.ha2g_gemm_set_mode(0)
+    assert relerr(c, a.double() @ b.double().t()) < 1e-5
+    assert relerr(y.permute(0, 3, 1, 2), F.conv2d(x.double(), w.double(), padding=1)) < 1e-5
