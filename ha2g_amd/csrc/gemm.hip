@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     }
     int b_r[NB], b_c[NB];
     bool b_on[NB];
-    int b_kh[NB], b_kw[NB], b_ci[NB];   // B_IM
+    int b_kh[NB], b_kw[NB], b_ci[NB];   // B_IM: filter tap / channel of the slot's columns (fixed for the block)
+    int b_ox[NB], b_oy[NB], b_img[NB];  // B_IM: pixel coordinates of the slot's current k row, advanced incrementally
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         int s = tid + i * 256;
@@ -120,6 +121,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
             int nn = b_on[i] ? n : 0;
             int tap = nn / g.GC;
             b_ci[i] = nn % g.GC; b_kh[i] = tap / g.KW; b_kw[i] = tap % g.KW;
+            int pix = kbeg + b_r[i];                         // one division per block; load_tile steps by BKT afterwards
+            b_ox[i] = pix % g.OW; int t = pix / g.OW; b_oy[i] = t % g.OH; b_img[i] = t / g.OH;
         }
     }
 
@@ -172,12 +175,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 int pix = k0 + b_r[i];
                 if (b_on[i] && pix < kend) {
-                    int ox = pix % g.OW; int t = pix / g.OW; int oy = t % g.OH; int img = t / g.OH;
-                    int iy = oy * g.stride - g.pad + b_kh[i], ix = ox * g.stride - g.pad + b_kw[i];
+                    int iy = b_oy[i] * g.stride - g.pad + b_kh[i], ix = b_ox[i] * g.stride - g.pad + b_kw[i];
                     if (iy >= 0 && iy < g.GH && ix >= 0 && ix < g.GW)
-                        v = *reinterpret_cast<const float4*>(p.B + (((long)img * g.GH + iy) * g.GW + ix) * g.GC + b_ci[i]);
+                        v = *reinterpret_cast<const float4*>(p.B + (((long)b_img[i] * g.GH + iy) * g.GW + ix) * g.GC + b_ci[i]);
                 }
                 rb[i] = v;
+                // advance this slot's pixel by one tile depth (tiles are visited in order): no div/mod in the loop
+                b_ox[i] += BKT;
+                while (b_ox[i] >= g.OW) { b_ox[i] -= g.OW; if (++b_oy[i] == g.OH) { b_oy[i] = 0; ++b_img[i]; } }
             }
         } else if (BMODE == B_KC) {
 #pragma unroll
@@ -503,6 +508,28 @@ __global__ void splitk_reduce_kernel(const float* ws, int splits, long MN, int N
     *dst = apply_act(v, act);
 }
 
+// Many splits over a small output (weight gradients of the 32/64-channel convolutions: up to ~340 partials of 9-37 k
+// floats): one block per 64 outputs, its 4 waves stride the partials, fixed-order LDS combine (deterministic).
+__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* ws, int splits, long MN, int N, float* C, long ldc,
+                                                                 float alpha, float beta, const float* bias, int act) {
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + lane;
+    double sd = 0.0;
+    if (i < MN)
+        for (int z = w; z < splits; z += 4) sd += (double)ws[(long)z * MN + i];
+    part[w][lane] = sd;
+    __syncthreads();
+    if (w != 0 || i >= MN) return;
+    const float s = (float)((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    int col = (int)(i % N);
+    long row = i / N;
+    float v = alpha * s + (bias ? bias[col] : 0.f);
+    float* dst = C + row * ldc + col;
+    if (beta != 0.f) v += beta * *dst;
+    *dst = apply_act(v, act);
+}
+
 template <int MI, int NI, int WM, int WN, int AMODE, int BMODE, bool VEC>
 int launch(const GemmP& p, hipStream_t st) {
     constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
@@ -519,8 +546,12 @@ int launch(const GemmP& p, hipStream_t st) {
     HA2G_CHECK_LAUNCH("gemm");
     if (p.splits > 1) {
         long MN = (long)p.M * p.N;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(MN, 256)), dim3(256), 0, st, p.ws, p.splits, MN, p.N, p.C,
-                           p.ldc, p.alpha, p.beta, p.bias, p.act);
+        if (p.splits >= 16 && MN <= (1 << 20))
+            hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(ceil_div(MN, 64)), dim3(256), 0, st, p.ws, p.splits, MN, p.N, p.C,
+                               p.ldc, p.alpha, p.beta, p.bias, p.act);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(MN, 256)), dim3(256), 0, st, p.ws, p.splits, MN, p.N, p.C,
+                               p.ldc, p.alpha, p.beta, p.bias, p.act);
         HA2G_CHECK_LAUNCH("splitk_reduce");
     }
     return 0;
