@@ -72,3 +72,39 @@ def test_train_step_expressive(golden, fuse):
             ck.step(si, ret, grads, sd)
     finally:
         th.FUSE_CHAINS, th.randperm_source = old
+
+
+def test_training_loop_reduces_loss_and_is_deterministic():
+    """A few real optimisation steps (dropout on, default init, HierarchyTrainer = the reference's train_epochs set-up):
+    losses stay finite, the regression loss falls on a fixed batch, memory does not grow, no GRU hand-off times out,
+    and two identically seeded runs are bitwise equal (no float atomics anywhere on the path)."""
+    from ha2g_amd import ops
+    from ha2g_amd.config import hierarchy_args
+    from ha2g_amd.testing import SpeakerVocab
+    from ha2g_amd.train import HierarchyTrainer
+
+    class Lang:
+        n_words, word_embedding_weights = 300, None
+
+    def run():
+        torch.manual_seed(3)
+        ops.rng.seed(torch.device(DEV), 99)
+        args = hierarchy_args()
+        tr = HierarchyTrainer(args, Lang(), SpeakerVocab(20), 27, torch.device(DEV))
+        text, spec, target, vid = (torch.from_numpy(x).to(DEV) for x in proc.make_batch(16, 27, 300, 20, 5))
+        hist, mem = [], []
+        for i in range(14):
+            r = tr.train_iter(0 if i < 4 else 11, text, spec, target, vid)
+            assert all(v == v and abs(v) < 1e6 for v in r.values()), r
+            hist.append(r)
+            mem.append(torch.cuda.memory_allocated())
+        return hist, mem, tr.gens[2].out[2].weight.detach().clone()
+
+    h1, m1, w1 = run()
+    assert h1[-1]['loss'] < 0.95 * h1[0]['loss'], (h1[0], h1[-1])
+    assert set(h1[0]) == {'loss', 'KLD', 'DIV_REG', 'c_pos', 'c_neg', 'phy'} and 'gen' in h1[-1] and 'dis' in h1[-1]
+    assert abs(h1[-1]['dis'] - 1.386) < 0.1                       # 2 ln 2 early in GAN training (reference log line 209)
+    assert m1[-1] <= m1[6] * 1.05 + (1 << 20)
+    assert ops.gru_cluster_error(torch.device(DEV)) == 0
+    h2, _, w2 = run()
+    assert h1 == h2 and torch.equal(w1, w2)
