@@ -52,6 +52,31 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split_bf16x2(float a, float b, unsigned& hi, unsigned& lo) {
+    f32x2_t v = {a, b};
+    bf16x2_t h = __builtin_convertvector(v, bf16x2_t);                 // v_cvt_pk_bf16_f32, round-to-nearest-even
+    hi = __builtin_bit_cast(unsigned, h);
+    f32x2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+    bf16x2_t l = __builtin_convertvector(r, bf16x2_t);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+// one fp32 value -> a 32-bit word {hi bf16 | lo bf16}: hi = bf16(x) in the upper half, lo = bf16(x - hi) in the lower half
+__device__ __forceinline__ float4 pack_hilo4(float4 v) {
+    unsigned h0, l0, h1, l1;
+    split_bf16x2(v.x, v.y, h0, l0); split_bf16x2(v.z, v.w, h1, l1);
+    float4 r;
+    r.x = __uint_as_float((h0 << 16) | (l0 & 0xffffu));
+    r.y = __uint_as_float((h0 & 0xffff0000u) | (l0 >> 16));
+    r.z = __uint_as_float((h1 << 16) | (l1 & 0xffffu));
+    r.w = __uint_as_float((h1 & 0xffff0000u) | (l1 >> 16));
+    return r;
+}
+
 template <bool VEC>
 __device__ __forceinline__ float4 ld4_guard(const float* p, int valid) {   // valid = number of in-range elements (<=4)
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -66,7 +91,11 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int valid) {   // va
     return v;
 }
 
-template <int MI, int NI, int WM, int WN, int AMODE, int BMODE, bool VEC, int BKT>
+// SPLIT = true: the LDS tiles hold {hi|lo} bf16 pairs instead of fp32 and the inner product runs as three bf16 MFMAs
+// (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulate) -- same staging, same tile shapes, every loader mode; 4e-6 rms-rel
+// per GEMM instead of 4e-7.  Used (by default) only for WEIGHT gradients, whose error goes straight to the optimizer and
+// does not compound through the network.
+template <int MI, int NI, int WM, int WN, int AMODE, int BMODE, bool VEC, int BKT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -204,6 +233,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     auto store_tile = [&](int buf) {
         float* as = As + buf * BKT * LDA;
         float* bs = Bs + buf * BKT * LDB;
+        if (SPLIT) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = pack_hilo4(ra[i]);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[i] = pack_hilo4(rb[i]);
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (!(tid + i * 256 < SA)) continue;
@@ -245,18 +280,54 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         if (kt + 1 < nk) load_tile(kt + 1);
         const float* as = As + cur * BKT * LDA + wm * (32 * MI) + l31;
         const float* bs = Bs + cur * BKT * LDB + wn * (32 * NI) + l31;
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int kk = 0; kk < BKT / 2; ++kk) {
-            float a[MI], b[NI];
+            for (int kk = 0; kk < BKT / 2; ++kk) {
+                float a[MI], b[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = as[(2 * kk + lhi) * LDA + i * 32];
+                for (int i = 0; i < MI; ++i) a[i] = as[(2 * kk + lhi) * LDA + i * 32];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) b[j] = bs[(2 * kk + lhi) * LDB + j * 32];
+                for (int j = 0; j < NI; ++j) b[j] = bs[(2 * kk + lhi) * LDB + j * 32];
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // v_mfma_f32_32x32x16_bf16: lane (row = l&31, half = l>>5) supplies k = 8*half .. 8*half+7 of a 16-deep chunk
+#pragma unroll
+            for (int kc = 0; kc < BKT / 16; ++kc) {
+                bf16x8_t ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    unsigned w[8], hi[4], lo[4];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] = __float_as_uint(as[(kc * 16 + 8 * lhi + e) * LDA + i * 32]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { hi[q] = (w[2 * q] >> 16) | (w[2 * q + 1] & 0xffff0000u); lo[q] = (w[2 * q] & 0xffffu) | (w[2 * q + 1] << 16); }
+                    ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<uint4*>(hi));
+                    al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<uint4*>(lo));
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    unsigned w[8], hi[4], lo[4];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] = __float_as_uint(bs[(kc * 16 + 8 * lhi + e) * LDB + j * 32]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { hi[q] = (w[2 * q] >> 16) | (w[2 * q + 1] & 0xffff0000u); lo[q] = (w[2 * q] & 0xffffu) | (w[2 * q + 1] << 16); }
+                    bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<uint4*>(hi));
+                    bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<uint4*>(lo));
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
         }
         if (kt + 1 < nk) store_tile(cur ^ 1);
         __syncthreads();
@@ -299,18 +370,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 // (typ. 4e-6), the same class as the rounding of a K ~ 1e3 fp32 accumulation chain -- parity tests use unchanged tolerances.
 // Operands whose staged float4 runs along k only: A = KC or IM (im2col), B = KC.  LDS tiles are [row][k] bf16 with an
 // 80-byte row stride (16 consecutive rows hit 16 distinct 16-byte slots: conflict-free ds_read_b128 fragment loads).
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void split_bf16x2(float a, float b, unsigned& hi, unsigned& lo) {
-    f32x2_t v = {a, b};
-    bf16x2_t h = __builtin_convertvector(v, bf16x2_t);                 // v_cvt_pk_bf16_f32, round-to-nearest-even
-    hi = __builtin_bit_cast(unsigned, h);
-    f32x2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
-    bf16x2_t l = __builtin_convertvector(r, bf16x2_t);
-    lo = __builtin_bit_cast(unsigned, l);
-}
 
 constexpr int X3_BK = 32;          // k per LDS stage
 constexpr int X3_LDK = 40;         // bf16 elements per LDS row (80 bytes)
@@ -486,6 +545,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmP p) {
         }
 }
 
+static int g_split_wgrad = 1;   // weight-gradient GEMMs / convolutions on the split-bf16 inner product (ha2g_gemm_set_mode bit 1)
 static int g_x3 = 0;      // split-bf16 core: OPT-IN (ha2g_gemm_set_mode(1)).  It is 1.5-2.5x faster on K-contiguous GEMMs / convs
                           // with >= 64 channels but ~10x noisier than the fp32 MFMA chain (4e-6 vs 4e-7 rms-rel per GEMM), which the
                           // reference-derived parity tolerances of the deep audio encoder do not absorb -> exact fp32 is the default.
@@ -542,7 +602,14 @@ int launch(const GemmP& p, hipStream_t st) {
     if constexpr (X3_SHAPE) {
         if (use_x3) hipLaunchKernelGGL((gemm_x3_kernel<MI, NI, WM, WN, AMODE>), grid, dim3(256), 0, st, p);
     }
-    if (!use_x3) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16>), grid, dim3(256), 0, st, p);
+    // transposed-A shapes are the weight gradients (dW = dY^T X, conv wgrad): split-bf16 inner product by default
+    constexpr bool WGRAD_SHAPE = AMODE == A_MC && VEC;
+    bool use_split = false;
+    if constexpr (WGRAD_SHAPE) use_split = g_split_wgrad && p.kchunk >= 64;
+    if constexpr (WGRAD_SHAPE) {
+        if (use_split) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, true>), grid, dim3(256), 0, st, p);
+    }
+    if (!use_x3 && !use_split) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16>), grid, dim3(256), 0, st, p);
     HA2G_CHECK_LAUNCH("gemm");
     if (p.splits > 1) {
         long MN = (long)p.M * p.N;
@@ -640,7 +707,9 @@ static int pick_conv_cfg(int M, int N) {
 
 extern "C" {
 
-void ha2g_gemm_set_mode(int x3) { g_x3 = x3; }   /* 1 = split-bf16 (bf16x3) matrix core where supported, 0 = exact fp32 MFMA */
+/* bit 0: forward / data-gradient GEMMs with k-contiguous operands on the split-bf16 core (default 0 = exact fp32);
+   bit 1: weight-gradient GEMMs on the split-bf16 inner product (default 1) */
+void ha2g_gemm_set_mode(int mode) { g_x3 = mode & 1; g_split_wgrad = (mode >> 1) & 1; }
 void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 10000) g_wgrad_blocks = cfg - 10000; else if (cfg >= 1000) g_split_tiles = cfg - 1000; else g_conv_cfg = cfg; }   /* 1000+n: split-K tile threshold n; 10000+n: wgrad block target n */
 
 // Dense GEMM, row-major.  transa/transb follow BLAS meaning on row-major storage:
