@@ -545,6 +545,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmP p) {
         }
 }
 
+static int g_split_dgrad = 1;   // data-gradient GEMMs / convolutions on the split-bf16 inner product (bit 2)
 static int g_split_wgrad = 1;   // weight-gradient GEMMs / convolutions on the split-bf16 inner product (ha2g_gemm_set_mode bit 1)
 static int g_x3 = 0;      // split-bf16 core: OPT-IN (ha2g_gemm_set_mode(1)).  It is 1.5-2.5x faster on K-contiguous GEMMs / convs
                           // with >= 64 channels but ~10x noisier than the fp32 MFMA chain (4e-6 vs 4e-7 rms-rel per GEMM), which the
@@ -602,12 +603,18 @@ int launch(const GemmP& p, hipStream_t st) {
     if constexpr (X3_SHAPE) {
         if (use_x3) hipLaunchKernelGGL((gemm_x3_kernel<MI, NI, WM, WN, AMODE>), grid, dim3(256), 0, st, p);
     }
-    // transposed-A shapes are the weight gradients (dW = dY^T X, conv wgrad): split-bf16 inner product by default
-    constexpr bool WGRAD_SHAPE = AMODE == A_MC && VEC;
+    // split-bf16 inner product by role: transposed-A shapes are the weight gradients (dW = dY^T X, conv wgrad; default on),
+    // n-contiguous B / the transposed conv gather are the data gradients (mode bit 2)
     bool use_split = false;
-    if constexpr (WGRAD_SHAPE) use_split = g_split_wgrad && p.kchunk >= 64;
-    if constexpr (WGRAD_SHAPE) {
-        if (use_split) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, true>), grid, dim3(256), 0, st, p);
+    if constexpr (VEC) {
+        constexpr bool WGRAD_SHAPE = AMODE == A_MC;
+        constexpr bool DGRAD_DENSE = AMODE == A_KC && BMODE == B_NC;
+        bool dgrad_conv = AMODE == A_IM && p.g.transposed;
+        use_split = !use_x3 && p.kchunk >= 64 &&
+                    ((WGRAD_SHAPE && g_split_wgrad) || ((DGRAD_DENSE || dgrad_conv) && g_split_dgrad));
+        if constexpr (WGRAD_SHAPE || DGRAD_DENSE || AMODE == A_IM) {
+            if (use_split) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, true>), grid, dim3(256), 0, st, p);
+        }
     }
     if (!use_x3 && !use_split) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16>), grid, dim3(256), 0, st, p);
     HA2G_CHECK_LAUNCH("gemm");
@@ -707,9 +714,10 @@ static int pick_conv_cfg(int M, int N) {
 
 extern "C" {
 
-/* bit 0: forward / data-gradient GEMMs with k-contiguous operands on the split-bf16 core (default 0 = exact fp32);
-   bit 1: weight-gradient GEMMs on the split-bf16 inner product (default 1) */
-void ha2g_gemm_set_mode(int mode) { g_x3 = mode & 1; g_split_wgrad = (mode >> 1) & 1; }
+/* bit 0: forward GEMMs / convolutions on the split-bf16 core (default 0 = exact fp32: the error compounds through 34 layers
+   and breaks parity); bit 1: weight gradients, bit 2: data gradients on the split-bf16 inner product (default 1: the parity
+   margins of the full step are unchanged, see tools/margins.py) */
+void ha2g_gemm_set_mode(int mode) { g_x3 = mode & 1; g_split_wgrad = (mode >> 1) & 1; g_split_dgrad = (mode >> 2) & 1; }
 void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 10000) g_wgrad_blocks = cfg - 10000; else if (cfg >= 1000) g_split_tiles = cfg - 1000; else g_conv_cfg = cfg; }   /* 1000+n: split-K tile threshold n; 10000+n: wgrad block target n */
 
 // Dense GEMM, row-major.  transa/transb follow BLAS meaning on row-major storage:

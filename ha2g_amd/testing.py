@@ -49,6 +49,8 @@ def _np(t):
 
 
 class Checker:
+    margins = []   # (error / tolerance, key) of every comparison made, for tools/margins.py
+
     def __init__(self, g, dt=torch.float32, rtol=1e-4, noise_mult=3.0):
         self.g = g
         self.f64 = dt == torch.float64
@@ -103,6 +105,7 @@ class Checker:
         err = np.abs(got - ref).max()
         tol = self._tol(key, scale)
         self.worst = max(self.worst, err / scale)
+        Checker.margins.append((float(err / tol), key))
         assert err <= tol, '%s: max err %.3e > tol %.3e (scale %.3e, ref fp32 noise %.3e)' % (
             key, err, tol, scale, float(self.g[key + '@noise']))
 
@@ -117,6 +120,7 @@ class Checker:
         # (a norm's own noise sample can be accidentally tiny when d happens to be orthogonal to g).
         gfl = self._group_rel_floor(key + '/sample')
         tol = self._tol(key + '/norm', max(rn, 1e-30)) + self.nm * self._floor(key + '/sample') * np.sqrt(a.size) + self.nm * gfl * rn
+        Checker.margins.append((float(abs(nrm - rn) / tol), key + '/norm'))
         assert abs(nrm - rn) <= tol, '%s/norm: %.9e vs %.9e (tol %.2e)' % (key, nrm, rn, tol)
         ref = self.g[key + '/sample']
         # elementwise: scale by the tensor's rms-ish magnitude so tiny sampled entries are not over-weighted
@@ -125,6 +129,7 @@ class Checker:
         # + rtol of the module's typical gradient magnitude: a tensor whose gradient is itself the residue of heavy
         # cancellation (e.g. an SE gate's  sum_hw dout*bn(x)  ~1e-3 of its terms) is judged on the module's scale.
         tol = self._tol(key + '/sample', scale) + self.nm * gfl * scale + (0 if self.f64 else self.rtol * self._group_stats(key + '/sample')[1])
+        Checker.margins.append((float(err / tol), key + '/sample'))
         assert err <= tol, '%s/sample: max err %.3e > tol %.3e (scale %.3e)' % (key, err, tol, scale)
 
     def grads(self, prefix, role, params, grads):

@@ -273,11 +273,11 @@ def test_split_bf16_core_opt_in():
     a, b = rnd((1000, 600), 41), rnd((300, 600), 42)
     x = rnd((2, 64, 20, 12), 43)
     w = rnd((64, 64, 3, 3), 44, 0.05)
-    lib.ha2g_gemm_set_mode(3)
+    lib.ha2g_gemm_set_mode(7)
     try:
         c = ops.gemm(a.to(dev), b.to(dev), transb=True)
         y = we.conv_fwd(x.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), None, 1, 1, 0)
     finally:
-        lib.ha2g_gemm_set_mode(2)
+        lib.ha2g_gemm_set_mode(6)
     assert relerr(c, a.double() @ b.double().t()) < 1e-5
     assert relerr(y.permute(0, 3, 1, 2), F.conv2d(x.double(), w.double(), padding=1)) < 1e-5

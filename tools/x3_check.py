@@ -40,4 +40,4 @@ for H, W, C in ((128, 70, 32), (64, 35, 64), (32, 18, 128), (16, 9, 256)):
     print('conv C=%d %dx%d: fp32 %.0fus %.0fTF | x3 %.0fus %.0fTF | x3 vs fp32 max-rel %.1e rms-rel %.1e' % (
         C, H, W, res[0][1], fl / res[0][1] / 1e6, res[1][1], fl / res[1][1] / 1e6, float(d.abs().max() / res[0][0].abs().max()),
         float((d ** 2).mean().sqrt() / (res[0][0].double() ** 2).mean().sqrt())))
-lib.ha2g_gemm_set_mode(2)
+lib.ha2g_gemm_set_mode(6)
