@@ -60,6 +60,7 @@ def main():
     ap.add_argument('--n-spk', type=int, default=1371)
     ap.add_argument('--expressive', action='store_true', help='config_expressive/hierarchy.yml: 6 levels, 126-d pose (BASELINE config 3)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--primary-only', action='store_true', help='skip the secondary timings (warm-up phase, exact-fp32 mode): for profiling')
     ap.add_argument('--cpu-batch', type=int, default=64)
     a = ap.parse_args()
 
@@ -109,15 +110,28 @@ def main():
     dt = time.perf_counter() - t0
     ops.ktimer.enabled = False
     # secondary number: warm-up phase (epoch <= loss_warmup, no D update / no D-phase chain), a third of the timed steps
-    k2 = max(2, a.steps // 3)
-    for _ in range(2):
+    k2 = max(2, a.steps // 3) if not a.primary_only else 0
+    for _ in range(2 if k2 else 0):
         tr.train_iter(0, text, spec, target, vid)
     sync()
     t1 = time.perf_counter()
     for _ in range(k2):
         tr.train_iter(0, text, spec, target, vid)
     sync()
-    ms_warm = (time.perf_counter() - t1) / k2 * 1e3
+    ms_warm = (time.perf_counter() - t1) / max(k2, 1) * 1e3 if k2 else float('nan')
+    # disclosure: the same step with EVERY matrix product on the exact fp32 MFMA (ha2g_gemm_set_mode(0)); the default runs the
+    # backward GEMMs/convolutions as split-bf16 (hi+lo halves, 3 bf16 MFMAs, fp32 accumulate), parity margins unchanged
+    from ha2g_amd._lib import lib as _lib
+    _lib.ha2g_gemm_set_mode(0)
+    for _ in range(2 if k2 else 0):
+        tr.train_iter(a.epoch, text, spec, target, vid)
+    sync()
+    t2 = time.perf_counter()
+    for _ in range(k2):
+        tr.train_iter(a.epoch, text, spec, target, vid)
+    sync()
+    ms_exact = (time.perf_counter() - t2) / max(k2, 1) * 1e3 if k2 else float('nan')
+    _lib.ha2g_gemm_set_mode(int(os.environ.get('HA2G_GEMM_MODE', '6')))
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -149,6 +163,8 @@ def main():
         out = dict(metric='pose-frames/sec (train step) for hierarchy.yml B=128 T=34', value=round(value, 1), unit='pose-frames/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype='f32', data='synthetic',
+                   matrix_core='forward: fp32 MFMA; backward GEMMs/convs: split-bf16 x3 MFMA with fp32 accumulate (fp32-class, same parity bar)',
+                   exact_fp32_matrix_core=dict(ms_per_step=round(ms_exact, 3), value=round(a.batch * 34 * world / (ms_exact * 1e-3), 1)),
                    warmup_phase=dict(ms_per_step=round(ms_warm, 3), value=round(a.batch * 34 * world / (ms_warm * 1e-3), 1)),
                    config=dict(workload='%s hierarchy train step, B=%d per GPU, T=34, %d-d pose, '
                                         'spec (128,70), n_words=%d, n_spk=%d, dropout 0.3, %s' % (

@@ -63,6 +63,6 @@ def check(rc):
     if rc != 0:
         raise Ha2gError('ha2g kernel call failed (%d): %s' % (rc, lib.ha2g_last_error().decode()))
 
-# matrix-core mode (see ha2g_gemm_set_mode in include/ha2g_hip.h); HA2G_GEMM_MODE overrides the library default (2)
+# matrix-core mode (see ha2g_gemm_set_mode in include/ha2g_hip.h); HA2G_GEMM_MODE overrides the library default (6)
 if os.environ.get("HA2G_GEMM_MODE"):
     lib.ha2g_gemm_set_mode(int(os.environ["HA2G_GEMM_MODE"]))

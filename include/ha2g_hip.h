@@ -53,8 +53,12 @@ int ha2g_conv2d_weight_ohwi_to_ihwo_f32(const float* w, float* wt, int Cout, int
  *                parity checks does not move (0.698 -> 0.699, tools/margins.py);
  *   bit 0 (off): forward GEMMs / convolutions too (another 1.5-2.5x on those, but the error compounds through the
  *                34-layer audio tower and the step no longer meets the 1e-4 parity bar).
+ *   bit 3 (off): forward GEMMs / convolutions on the 3-piece split (6 bf16 MFMAs): as accurate as the fp32 MFMA chain
+ *                (3.7e-7 vs 4.4e-7 rms-rel), 1.1-1.45x faster per GEMM, ~1.4 % of the step.
  * 0 = exact fp32 MFMA everywhere. */
 void ha2g_gemm_set_mode(int mode);
+/* tuning aid: forward GEMMs narrower than n columns stay on the fp32 MFMA */
+void ha2g_gemm_debug_x6_min_n(int n);
 void ha2g_conv_debug_cfg(int cfg);   /* tile-shape override for tools/conv_bench.py (-1 = heuristic) */
 /* stem Conv2d(1->32, 3x3, pad 1) + bias + ReLU (model/ResNetSE34V2.py:27,127-128); x [N,H,W], y [N,H,W,32] */
 int ha2g_stem_conv_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, void* stream);

@@ -281,3 +281,29 @@ def test_split_bf16_core_opt_in():
         lib.ha2g_gemm_set_mode(6)
     assert relerr(c, a.double() @ b.double().t()) < 1e-5
     assert relerr(y.permute(0, 3, 1, 2), F.conv2d(x.double(), w.double(), padding=1)) < 1e-5
+
+
+def test_three_piece_split_core_is_fp32_accurate():
+    """The opt-in 3-piece forward matrix core (3 bf16 pieces per operand, 6 MFMAs, fp32 accumulate) is as accurate as the fp32 MFMA
+    chain: against float64, its error is within 1.5x of the exact-fp32 mode's on a GEMM (ragged K) and a convolution."""
+    import torch.nn.functional as F
+    from ha2g_amd import ops, wav_engine as we
+    from ha2g_amd._lib import lib
+    dev = _dev()
+    a, b = rnd((1000, 348), 51), rnd((300, 348), 52)
+    x = rnd((2, 64, 20, 12), 53)
+    w = rnd((96, 64, 3, 3), 54, 0.05)
+    ref_c = a.double() @ b.double().t()
+    ref_y = F.conv2d(x.double(), w.double(), padding=1)
+    out = {}
+    try:
+        for mode in (0, 14):
+            lib.ha2g_gemm_set_mode(mode)
+            c = ops.gemm(a.to(dev), b.to(dev), transb=True)
+            y = we.conv_fwd(x.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), None, 1, 1, 0)
+            rms = lambda g, r: float(((g.double().cpu() - r) ** 2).mean().sqrt() / (r ** 2).mean().sqrt())
+            out[mode] = (rms(c, ref_c), rms(y.permute(0, 3, 1, 2), ref_y))
+    finally:
+        lib.ha2g_gemm_set_mode(6)
+    assert out[14][0] <= 1.5 * out[0][0] + 1e-8 and out[14][0] < 5e-7, out
+    assert out[14][1] <= 1.5 * out[0][1] + 1e-8 and out[14][1] < 5e-7, out
