@@ -2,6 +2,7 @@
 // Every kernel produces the scalar term AND the unit gradient w.r.t. its differentiable inputs in one go
 // (the autograd wrapper only rescales by the upstream scalar), reductions are fixed-order (deterministic).
 #include "common.h"
+#include "../../include/ha2g_hip.h"   // ha2g_gemm_f32 / ha2g_colsum_f32 used by the contrastive loss
 
 namespace {
 
@@ -167,7 +168,6 @@ __global__ __launch_bounds__(256) void gan_kernel(int mode, const float* __restr
 
 // ---- softmax contrastive loss (train_hierarchy.py:54-68; expressive variant :107-121) -------------------
 constexpr int CD = 32;      // feature width of text / audio features
-constexpr int CT = 64;      // rows of the opposite side staged in LDS per tile
 
 __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, float* __restrict__ xn, float* __restrict__ nrm, int N) {
     int i = blockIdx.x * 256 + threadIdx.x;
@@ -188,133 +188,107 @@ __device__ __forceinline__ float dlogit_of(float dist, float l, int expressive) 
     return (1.0f / (dist + 1e-8f) > 1e-8f) ? -l * l : 0.f;
 }
 
-// Pair kernels.  A block owns 16 rows of one side; its 256 threads are 16 row slots x 16 lanes that split the opposite
-// side's rows (staged through LDS in tiles of CT rows, row stride CD+1 so the 16 lanes of a slot hit distinct banks).
-// Per-row reductions (online log-sum-exp, gradient sums) are combined across the 16 lanes with xor shuffles in a fixed
-// order => deterministic.  O(N^2 * 32) flops on ~N/16 blocks instead of the N x N x 32 tensor the reference materialises.
+// Pair work, three stages per block of R rows (R x N floats of scratch, R chosen to fit the workspace):
+//   1. contrastive_dist_kernel   D[i][j] = |a_i - b_j|  -- 64x64 tile per block, 4x4 pairs per thread out of LDS (VALU-bound,
+//                                N^2/4096 blocks fill the chip; the reference materialises an N x N x 32 tensor instead);
+//   2. contrastive_row_kernel    one wave per row: online log-sum-exp of the logits, loss_i, then the row of coefficients
+//                                c_ij = d loss / d dist_ij / dist_ij  written over D, plus its row sum;
+//   3. MFMA GEMMs                d a_i = a_i * sum_j c_ij - (C b)_i ,   d b_j = b_j * sum_i c_ij - (C^T a)_j
+//                                (ha2g_gemm_f32; column sums by ha2g_colsum_f32).
+// Every reduction has a fixed order => deterministic.
 constexpr int LDT = CD + 1;
 
-__device__ __forceinline__ float group16_sum(float v) {
+__global__ __launch_bounds__(256) void contrastive_dist_kernel(const float* __restrict__ a, const float* __restrict__ b, int N,
+                                                               int r0, int R, float* __restrict__ D) {
+    __shared__ float ta[64 * LDT], tb[64 * LDT];
+    const int i0 = r0 + blockIdx.x * 64, j0 = blockIdx.y * 64;
+    for (int e = threadIdx.x; e < 64 * CD; e += 256) {
+        const int r = e / CD, d = e % CD;
+        ta[r * LDT + d] = (i0 + r < r0 + R) ? a[(long)(i0 + r) * CD + d] : 0.f;
+        tb[r * LDT + d] = (j0 + r < N) ? b[(long)(j0 + r) * CD + d] : 0.f;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // rows ty + 16*r, columns tx + 16*c
+    float s[4][4];
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-__global__ __launch_bounds__(256) void contrastive_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, int N,
-                                                               int expressive, float* __restrict__ rmax, float* __restrict__ rsum,
-                                                               float* __restrict__ loss_i, float* __restrict__ dan) {
-    __shared__ float tb[CT * LDT];
-    const int slot = threadIdx.x >> 4, jl = threadIdx.x & 15;
-    const int i = blockIdx.x * 16 + slot;
-    const bool on = i < N;
-    float ai[CD];
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int d = 0; d < CD; ++d) ai[d] = on ? a[(long)i * CD + d] : 0.f;
-    float m = -INFINITY, z = 0.f, lii = 0.f;
-    for (int j0 = 0; j0 < N; j0 += CT) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < CT * CD; e += 256) { int r = e / CD, d = e % CD; tb[r * LDT + d] = (j0 + r < N) ? b[(long)(j0 + r) * CD + d] : 0.f; }
-        __syncthreads();
-        for (int j = jl; j < CT && j0 + j < N; j += 16) {
-            float s = 0.f;
+        for (int c = 0; c < 4; ++c) s[r][c] = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < CD; ++d) {
+        float av[4], bv[4];
 #pragma unroll
-            for (int d = 0; d < CD; ++d) { float t = ai[d] - tb[j * LDT + d]; s += t * t; }
-            float l = logit_of(sqrtf(s), expressive);
-            if (j0 + j == i) lii = l;
-            if (l > m) { z = z * expf(m - l) + 1.f; m = l; } else z += expf(l - m);
+        for (int r = 0; r < 4; ++r) av[r] = ta[(ty + 16 * r) * LDT + d];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bv[c] = tb[(tx + 16 * c) * LDT + d];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float t = av[r] - bv[c]; s[r][c] += t * t; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty + 16 * r;
+        if (i >= r0 + R) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = j0 + tx + 16 * c;
+            if (j < N) D[(long)(i - r0) * N + j] = sqrtf(s[r][c]);
         }
     }
-    // combine the 16 lanes' (m, z): fixed xor tree
+}
+
+__global__ __launch_bounds__(256) void contrastive_row_kernel(float* __restrict__ D, const float* __restrict__ an, int N, int r0, int R,
+                                                              int expressive, float* __restrict__ loss_i, float* __restrict__ dan) {
+    const int lane = threadIdx.x & 63, il = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (il >= R) return;
+    const int i = r0 + il;
+    float* row = D + (long)il * N;
+    float m = -INFINITY, z = 0.f, lii = 0.f;
+    for (int j = lane; j < N; j += 64) {
+        const float l = logit_of(row[j], expressive);
+        if (j == i) lii = l;
+        if (l > m) { z = z * expf(m - l) + 1.f; m = l; } else z += expf(l - m);
+    }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-        float m2 = __shfl_xor(m, o, 64), z2 = __shfl_xor(z, o, 64);
-        float mm = fmaxf(m, m2);
-        float za = (m == -INFINITY) ? 0.f : z * expf(m - mm), zb = (m2 == -INFINITY) ? 0.f : z2 * expf(m2 - mm);
-        // order the two operands by lane parity so both partners compute the identical sum
-        const bool low = ((threadIdx.x & o) == 0);
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), z2 = __shfl_xor(z, o, 64);
+        const float mm = fmaxf(m, m2);
+        const float za = (m == -INFINITY) ? 0.f : z * expf(m - mm), zb = (m2 == -INFINITY) ? 0.f : z2 * expf(m2 - mm);
+        const bool low = ((lane & o) == 0);               // both partners add in the same order
         z = low ? za + zb : zb + za;
         m = mm;
+        lii += __shfl_xor(lii, o, 64);
     }
-    lii = group16_sum(lii);
-    if (on && jl == 0) { rmax[i] = m; rsum[i] = z; loss_i[i] = (m + logf(z)) - lii; }
-    const float invN = 1.f / (float)N;
-    float acc[CD], csum = 0.f;
-#pragma unroll
-    for (int d = 0; d < CD; ++d) acc[d] = 0.f;
-    for (int j0 = 0; j0 < N; j0 += CT) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < CT * CD; e += 256) { int r = e / CD, d = e % CD; tb[r * LDT + d] = (j0 + r < N) ? b[(long)(j0 + r) * CD + d] : 0.f; }
-        __syncthreads();
-        for (int j = jl; j < CT && j0 + j < N; j += 16) {
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < CD; ++d) { float t = ai[d] - tb[j * LDT + d]; s += t * t; }
-            float dist = sqrtf(s);
-            float l = logit_of(dist, expressive);
-            float p = expf(l - m) / z - ((j0 + j == i) ? 1.f : 0.f);
-            float c = dist > 0.f ? p * dlogit_of(dist, l, expressive) / dist * invN : 0.f;    // norm backward: 0 at dist = 0
-            csum += c;
-#pragma unroll
-            for (int d = 0; d < CD; ++d) acc[d] += c * tb[j * LDT + d];
-        }
+    if (lane == 0) loss_i[i] = (m + logf(z)) - lii;
+    const float invN = 1.f / (float)N, invz = 1.f / z;
+    float csum = 0.f;
+    for (int j = lane; j < N; j += 64) {
+        const float dist = row[j];
+        const float l = logit_of(dist, expressive);
+        const float p = expf(l - m) * invz - ((j == i) ? 1.f : 0.f);
+        const float c = dist > 0.f ? p * dlogit_of(dist, l, expressive) / dist * invN : 0.f;    // norm backward: 0 at dist = 0
+        row[j] = c;
+        csum += c;
     }
-    csum = group16_sum(csum);
 #pragma unroll
-    for (int d = 0; d < CD; ++d) acc[d] = group16_sum(acc[d]);
-    if (on && jl == 0)
-#pragma unroll
-        for (int d = 0; d < CD; ++d) dan[(long)i * CD + d] = ai[d] * csum - acc[d];
-}
-
-// 16 rows j of b per block: d b_j = sum_i c_ij (b_j - a_i)
-__global__ __launch_bounds__(256) void contrastive_cols_kernel(const float* __restrict__ a, const float* __restrict__ b, int N,
-                                                               int expressive, const float* __restrict__ rmax,
-                                                               const float* __restrict__ rsum, float* __restrict__ dbn) {
-    __shared__ float ta[CT * LDT];
-    __shared__ float tm[CT], tz[CT];
-    const int slot = threadIdx.x >> 4, il = threadIdx.x & 15;
-    const int j = blockIdx.x * 16 + slot;
-    const bool on = j < N;
-    float bj[CD], acc[CD], csum = 0.f;
-#pragma unroll
-    for (int d = 0; d < CD; ++d) { bj[d] = on ? b[(long)j * CD + d] : 0.f; acc[d] = 0.f; }
-    const float invN = 1.f / (float)N;
-    for (int i0 = 0; i0 < N; i0 += CT) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < CT * CD; e += 256) { int r = e / CD, d = e % CD; ta[r * LDT + d] = (i0 + r < N) ? a[(long)(i0 + r) * CD + d] : 0.f; }
-        if (threadIdx.x < CT) { int i = i0 + threadIdx.x; tm[threadIdx.x] = i < N ? rmax[i] : 0.f; tz[threadIdx.x] = i < N ? rsum[i] : 1.f; }
-        __syncthreads();
-        for (int i = il; i < CT && i0 + i < N; i += 16) {
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < CD; ++d) { float t = ta[i * LDT + d] - bj[d]; s += t * t; }
-            float dist = sqrtf(s);
-            float l = logit_of(dist, expressive);
-            float p = expf(l - tm[i]) / tz[i] - ((i0 + i == j) ? 1.f : 0.f);
-            float c = dist > 0.f ? p * dlogit_of(dist, l, expressive) / dist * invN : 0.f;
-            csum += c;
-#pragma unroll
-            for (int d = 0; d < CD; ++d) acc[d] += c * ta[i * LDT + d];
-        }
-    }
-    csum = group16_sum(csum);
-#pragma unroll
-    for (int d = 0; d < CD; ++d) acc[d] = group16_sum(acc[d]);
-    if (on && il == 0)
-#pragma unroll
-        for (int d = 0; d < CD; ++d) dbn[(long)j * CD + d] = bj[d] * csum - acc[d];
+    for (int o = 32; o > 0; o >>= 1) csum += __shfl_xor(csum, o, 64);
+    if (lane < CD) dan[(long)i * CD + lane] = an[(long)i * CD + lane] * csum;
 }
 
 // gradient through x / max(|x|, 1e-12): dx = (dn - n (n . dn)) / |x|
+// cs (nullable): the gradient w.r.t. the normalised row is dn + xn * cs[i]
 __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restrict__ xn, const float* __restrict__ nrm,
-                                                          const float* __restrict__ dn, float* __restrict__ dx, int N) {
+                                                          const float* __restrict__ dn, const float* __restrict__ cs,
+                                                          float* __restrict__ dx, int N) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
+    const float c = cs ? cs[i] : 0.f;
     float p = 0.f;
-    for (int d = 0; d < CD; ++d) p += xn[(long)i * CD + d] * dn[(long)i * CD + d];
+    for (int d = 0; d < CD; ++d) p += xn[(long)i * CD + d] * (dn[(long)i * CD + d] + xn[(long)i * CD + d] * c);
     float n = nrm[i];
     for (int d = 0; d < CD; ++d) {
-        float g = dn[(long)i * CD + d];
+        float g = dn[(long)i * CD + d] + xn[(long)i * CD + d] * c;
         dx[(long)i * CD + d] = (n > 1e-12f ? g - xn[(long)i * CD + d] * p : g) / n;
     }
 }
@@ -380,21 +354,53 @@ int ha2g_gan_loss_f32(int mode, const float* a, const float* b, int n, float* lo
 }
 
 // a, b [N][32] raw features (rows = first argument of the reference's criterion = text); loss scalar;
-// da, db unit gradients w.r.t. the raw inputs.  ws >= N*(2*32 + 2*32 + 5) floats.
-long ha2g_contrastive_workspace_floats(int N) { return (long)N * (4 * CD + 5); }
+// da, db unit gradients w.r.t. the raw inputs.  ws >= ha2g_contrastive_workspace_floats(N) floats: per-row vectors, the
+// split-K / column-sum scratch of the inner GEMMs and an R x N block of the pair matrix (R = N when it fits in 80 MB,
+// else the rows are processed in blocks -- same arithmetic, fixed order).
+static int contrastive_rows_per_block(int N) {
+    long r = (80L << 20) / (4L * N);
+    r = r / 64 * 64;
+    if (r < 64) r = 64;
+    return (int)(r > N ? N : r);
+}
+static long contrastive_gemm_ws_floats(int N) { return 40L * N * CD + 64; }                  // <= 40 split-K partials of [N][32]
+long ha2g_contrastive_workspace_floats(int N) {
+    return (long)N * (4 * CD + 6) + contrastive_gemm_ws_floats(N) + ha2g_colsum_workspace_bytes(N) / 4 +
+           (long)contrastive_rows_per_block(N) * N + 64;
+}
 int ha2g_contrastive_f32(const float* a, const float* b, int N, int expressive, float* loss, float* da, float* db, float* ws,
                          void* stream) {
     HA2G_REQUIRE(N > 0, "contrastive: empty input");
     hipStream_t st = (hipStream_t)stream;
     float* an = ws; float* bn = an + (long)N * CD; float* dan = bn + (long)N * CD; float* dbn = dan + (long)N * CD;
-    float* na = dbn + (long)N * CD; float* nbv = na + N; float* rmax = nbv + N; float* rsum = rmax + N; float* li = rsum + N;
+    float* na = dbn + (long)N * CD; float* nbv = na + N; float* li = nbv + N; float* cs = li + N;
+    float* gws = cs + 3 * N;                                   // (keeps 16-byte alignment: N*(4*32+6) floats so far)
+    gws += (4 - ((gws - ws) & 3)) & 3;
+    const long gws_floats = contrastive_gemm_ws_floats(N);
+    float* cws = gws + gws_floats;
+    cws += ((cws - ws) & 1);                                   // doubles
+    float* D = cws + ha2g_colsum_workspace_bytes(N) / 4;
+    D += (4 - ((D - ws) & 3)) & 3;
+    const int RB = contrastive_rows_per_block(N);
     hipLaunchKernelGGL(rownorm_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, a, an, na, N);
     hipLaunchKernelGGL(rownorm_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, b, bn, nbv, N);
-    hipLaunchKernelGGL(contrastive_rows_kernel, dim3(ceil_div(N, 16)), dim3(256), 0, st, an, bn, N, expressive, rmax, rsum, li, dan);
-    hipLaunchKernelGGL(contrastive_cols_kernel, dim3(ceil_div(N, 16)), dim3(256), 0, st, an, bn, N, expressive, rmax, rsum, dbn);
+    for (int r0 = 0; r0 < N; r0 += RB) {
+        const int R = min(RB, N - r0);
+        const float acc = r0 == 0 ? 0.f : 1.f;
+        hipLaunchKernelGGL(contrastive_dist_kernel, dim3(ceil_div(R, 64), ceil_div(N, 64)), dim3(256), 0, st, an, bn, N, r0, R, D);
+        hipLaunchKernelGGL(contrastive_row_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, st, D, an, N, r0, R, expressive, li, dan);
+        HA2G_CHECK_LAUNCH("contrastive");
+        // d an[r0:r0+R] = an * rowsum(C) - C bn ;  d bn (+)= - C^T an[r0:r0+R] ;  cs (+)= colsum(C)
+        int rc = ha2g_gemm_f32(0, 0, R, CD, N, -1.f, D, N, bn, CD, 1.f, dan + (long)r0 * CD, CD, nullptr, 0, gws, gws_floats * 4, stream);
+        if (rc) return rc;
+        rc = ha2g_gemm_f32(1, 0, N, CD, R, -1.f, D, N, an + (long)r0 * CD, CD, acc, dbn, CD, nullptr, 0, gws, gws_floats * 4, stream);
+        if (rc) return rc;
+        rc = ha2g_colsum_f32(D, N, R, N, cs, acc, cws, stream);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, li, (long)N, loss, 1.f / (float)N, 0);
-    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, an, na, dan, da, N);
-    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, bn, nbv, dbn, db, N);
+    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, an, na, dan, (const float*)nullptr, da, N);
+    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, bn, nbv, dbn, (const float*)cs, db, N);
     HA2G_CHECK_LAUNCH("contrastive");
     return 0;
 }

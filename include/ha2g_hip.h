@@ -3,7 +3,7 @@
  *
  * The reference (alvinliu0/HA2G) has no FFI: its hot path is Python/torch modules.  Each entry point below
  * replaces the torch operator(s) the reference reaches through the cited lines (paths relative to the
- * reference's scripts/ directory); the Python mirror of the reference interface (ha2g_amd/*.py) binds them
+ * reference's scripts/ directory); the Python mirror of the reference interface (the ha2g_amd package) binds them
  * with ctypes, and INTEGRATION.md shows the stub a reference maintainer would add.
  *
  * Conventions: plain pointers and sizes only (no torch types); all pointers are DEVICE pointers to fp32
