@@ -97,6 +97,14 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
 
     weight, feat_low, feat_mid, feat_high, linear_blend_feat = audio_encoder(in_spec, vid_indices)
     text_feat = text_encoder(in_text_padded)
+    # Cut the autograd graph at the encoders' outputs: the backward runs in two stages (generators + losses, then the
+    # encoders), so that under data parallelism the generators' gradient all-reduce is in flight while the audio tower --
+    # the longest part of the backward -- is still back-propagating (BASELINE north_star: "all-reduce overlapped with
+    # backward").  Same arithmetic: the encoders receive exactly the gradients accumulated on the cut tensors.
+    enc_outs = [weight, feat_low, feat_mid, feat_high, text_feat] + list(linear_blend_feat)
+    enc_cut = [t.detach().requires_grad_(True) if (torch.is_tensor(t) and t.requires_grad) else t for t in enc_outs]
+    weight, feat_low, feat_mid, feat_high, text_feat = enc_cut[:5]
+    linear_blend_feat = enc_cut[5:]
 
     # per-level targets = column subsets of the full pose (train_hierarchy.py:86-88 / expressive :140-145)
     targets = [target if len(c) == target.shape[2] else target.index_select(2, c) for c in consts['cols']]
@@ -202,9 +210,20 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
         physical_loss = ops.phys_angle(out_dir_vec, consts['mean_dir'], consts['pairs'], consts['avg'], consts['var'], spec['palm'])
         loss = loss + args.loss_physical_weight * physical_loss
 
-    loss.backward()
+    from . import ddp
+    loss.backward()                                      # stage 1: losses, discriminator, generators (down to the cut)
+    works = []
+    if ddp.active():
+        works = [ddp.average_(o.flat_g, async_op=True) if hasattr(o, 'flat_g') else ddp.average_module_grads_([o])
+                 for o in gen_optimizers]
+    pairs = [(o, c.grad) for o, c in zip(enc_outs, enc_cut) if c is not o and c.grad is not None]
+    if pairs:                                            # stage 2: audio + text encoders, overlapping the collectives above
+        torch.autograd.backward([p[0] for p in pairs], [p[1] for p in pairs])
+    _allreduce((audio_optimizer, text_optimizer))
+    for w in works:
+        if w is not None:
+            w.wait()
     g_opts = tuple(gen_optimizers) + (audio_optimizer, text_optimizer)
-    _allreduce(g_opts)
     for o in g_opts:
         o.step()
     ops.rng.end_step()
