@@ -157,6 +157,21 @@ int ha2g_adam_step_inc(int* step, void* stream);
 int ha2g_adam_f32(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                   const int* step, void* stream);
 
+/* ---- log-mel front-end on the GPU: replaces the offline librosa step
+ *      scripts/utils/data_utils.py:34-38 extract_melspectrogram / dataset_script/script/make_ted_dataset.py:121-123:
+ *      melspectrogram(y, sr=16000, n_fft=1024, hop_length=512, power=2) -> power_to_db(ref=max over the clip) -> float16.
+ *      STFT = fp32 MFMA GEMM of the centre-padded clip (lda = 512: overlapping frames, nothing materialised) against a
+ *      Hann-windowed DFT basis; 128 Slaney mel filters = second GEMM.  PARITY UNPINNED (librosa is not vendored by the
+ *      reference and absent here): checked against oracle/logmel_oracle.py, a restatement of librosa's published defaults. ---- */
+long ha2g_logmel_tables_floats(void);                      /* DFT basis [1026][1024] + mel filters [128][516] */
+int ha2g_logmel_frames(long n_samples);                    /* 1 + n / 512 (center=True) */
+int ha2g_logmel_init_f32(float* tables, int sr, void* stream);
+long ha2g_logmel_workspace_floats(int B, long n_samples);
+/* y [B][n] -> out [B][128][frames] dB in [-80, 0]; pad_reflect: 1 = librosa <= 0.9 default ('reflect'), 0 = zeros (>= 0.10);
+ * round_f16: 1 = round through float16 like the reference's stored arrays */
+int ha2g_logmel_f32(const float* y, int B, long n_samples, int pad_reflect, const float* tables, int round_f16, float* out,
+                    float* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -307,3 +307,32 @@ def test_three_piece_split_core_is_fp32_accurate():
         lib.ha2g_gemm_set_mode(6)
     assert out[14][0] <= 1.5 * out[0][0] + 1e-8 and out[14][0] < 5e-7, out
     assert out[14][1] <= 1.5 * out[0][1] + 1e-8 and out[14][1] < 5e-7, out
+
+
+def test_log_mel_frontend():
+    """On-GPU log-mel (ha2g_logmel_f32) vs the NumPy restatement of librosa's defaults (oracle/logmel_oracle.py; parity
+    unpinned: librosa absent).  Clips of the length the loader uses (34 frames at 15 fps = 36 267 samples -> 71 columns,
+    cropped to 70), tones + noise at different levels, both padding modes; tolerance 0.05 dB before float16 rounding
+    (float16 spacing at -64..-80 dB is 0.0625), at most one float16 ulp after."""
+    import numpy as np
+    from ha2g_amd import audio_frontend as fe
+    from oracle import logmel_oracle as L
+    dev = _dev()
+    n = 36267
+    t = np.arange(n) / 16000.0
+    r = np.random.Generator(np.random.PCG64(11))
+    clips = np.stack([0.3 * np.sin(2 * np.pi * 440 * t) + 0.02 * r.standard_normal(n),
+                      0.05 * np.sin(2 * np.pi * 3000 * t + 1.0) * np.exp(-3 * t) + 1e-3 * r.standard_normal(n),
+                      0.5 * r.standard_normal(n) * (t > 1.0)]).astype(np.float32)
+    for mode in ('reflect', 'constant'):
+        got = fe.batch_log_mel(torch.from_numpy(clips).to(dev), pad_mode=mode, f16=False).cpu().numpy()
+        got16 = fe.batch_log_mel(torch.from_numpy(clips).to(dev), pad_mode=mode, f16=True).cpu().numpy()
+        assert got.shape == (3, 128, 71)
+        for b in range(3):
+            ref = L.extract_melspectrogram(clips[b].astype(np.float64), pad_mode=mode, f16=False)
+            assert np.abs(got[b] - ref).max() < 0.05, (mode, b, float(np.abs(got[b] - ref).max()))
+            ref16 = ref.astype(np.float16).astype(np.float32)
+            assert np.abs(got16[b] - ref16).max() <= 0.0626, (mode, b)
+            assert float(got[b].max()) == 0.0 and float(got[b].min()) >= -80.0
+    one = fe.extract_melspectrogram(clips[0])
+    assert one.dtype == torch.float16 and tuple(one.shape) == (128, 71)
