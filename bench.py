@@ -145,7 +145,7 @@ def main():
         kt = ops.ktimer.summary()
         roof = None
         if 'gru_layer_fwd' in kt:
-            n, mean_us, rows = kt['gru_layer_fwd']                       # rows = batch rows per launch (3B in the GAN phase)
+            n, mean_us, rows = kt['gru_layer_fwd'][:3]                       # rows = batch rows per launch (3B in the GAN phase)
             flops = 2.0 * rows * T * 2 * 3 * H * H + 12.0 * rows * T * 2 * H   # recurrent matmul + gate math per launch
             bytes_ = (rows * T * 2 * 3 * H + rows * T * 2 * H + rows * T * 2 * 4 * H + 2 * 3 * H * H) * 4.0   # gi + y + reserve + W_hh
             ach = flops / (mean_us * 1e-6) / 1e12
@@ -160,6 +160,13 @@ def main():
                         algorithmic_bytes=bytes_, launches=n, mean_us=round(mean_us, 1),
                         batch_rows=rows, hbm_GBps_algorithmic=round(bytes_ / (mean_us * 1e-6) / 1e9, 1),
                         hbm_frac_of_8TBps=round(bytes_ / (mean_us * 1e-6) / 8e12, 4))
+        roof_conv = None
+        if 'conv2d_fwd' in kt:                     # the largest kernel family by time: implicit-GEMM convolutions of the audio tower (forward, fp32 MFMA)
+            n, mean_us, _, flops = kt['conv2d_fwd']
+            ach = flops / (n * mean_us * 1e-6) / 1e12
+            roof_conv = dict(kernel='gemm_kernel<A_IM,B_KC> (ha2g_conv2d_fwd_f32, all SE-ResNet34 forward convolutions)', bound='mfma',
+                             achieved=round(ach, 2), peak=157.3, unit='TFLOP/s', frac=round(ach / 157.3, 4), launches=n,
+                             mean_us=round(mean_us, 1), traffic=None)
         out = dict(metric='pose-frames/sec (train step) for hierarchy.yml B=128 T=34', value=round(value, 1), unit='pose-frames/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype='f32', data='synthetic',
@@ -171,7 +178,7 @@ def main():
                                             'config_expressive/hierarchy.yml TED-Expressive' if a.expressive else 'config/hierarchy.yml TED-Gesture', a.batch, P, a.n_words, a.n_spk, 'GAN phase (epoch %d > loss_warmup)' % a.epoch
                                             if a.epoch > args.loss_warmup else 'warm-up phase (epoch %d)' % a.epoch),
                                global_batch=a.batch * world, parallelism='dp%d' % world),
-                   gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
+                   gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, roofline_conv=roof_conv, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
         if world == 1 and not a.no_cpu_baseline and not a.expressive:
             out['cpu_baseline'] = cpu_baseline(a.cpu_batch, a.epoch, a.n_words, a.n_spk)
         print(json.dumps(out))

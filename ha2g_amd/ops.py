@@ -85,11 +85,11 @@ class KernelTimer:
         return r
 
     def summary(self):
-        """{name: (launches, mean microseconds, meta of the last launch)}; call after a device synchronize."""
+        """{name: (launches, mean microseconds, meta of the last launch, sum of metas)}; call after a device synchronize."""
         out = {}
         for k, v in self.recs.items():
             us = [s.elapsed_time(e) * 1e3 for s, e, _ in v]
-            out[k] = (len(us), sum(us) / len(us), v[-1][2])
+            out[k] = (len(us), sum(us) / len(us), v[-1][2], sum(m for _, _, m in v))
         return out
 
 

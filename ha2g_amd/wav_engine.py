@@ -47,8 +47,9 @@ def conv_fwd(x, w_ohwi, bias, stride, pad, act):
     Cout, KH, KW, _ = w_ohwi.shape
     OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     y = empty(N, OH, OW, Cout, like=x)
-    check(lib.ha2g_conv2d_fwd_f32(x.data_ptr(), w_ohwi.data_ptr(), _p(bias), y.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad,
-                                  act, _stream()))
+    ops.ktimer.launch('conv2d_fwd', lambda: check(lib.ha2g_conv2d_fwd_f32(
+        x.data_ptr(), w_ohwi.data_ptr(), _p(bias), y.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad, act, _stream())),
+        2.0 * N * OH * OW * Cout * KH * KW * Cin)
     return y
 
 
