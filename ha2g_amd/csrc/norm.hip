@@ -135,6 +135,51 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     }
 }
 
+
+// BatchNorm apply fused with the squeeze of the SE layer that follows it (ResNetBlocks.py:24-36,81-83): writes y = bn(x) and
+// per-(image, channel) sums of y in the same pass (the separate hw-mean kernel re-read the whole tensor).  grid (chunks, N):
+// a block owns a row chunk of ONE image; per-thread double partials, block combine through LDS, one partial per
+// (image, chunk, channel); pool_final adds the chunks in ascending order (deterministic).
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y, int HW, int C,
+                                                            double* __restrict__ part) {
+    __shared__ d4 lds[256];
+    const int C4 = C >> 2;
+    ColMap m(C4);
+    const int nchunk = gridDim.x;
+    const int per = (HW + nchunk - 1) / nchunk;
+    const int rbeg = blockIdx.x * per, rend = min(HW, rbeg + per);
+    const long base = (long)blockIdx.y * HW * C;
+    const float4 mu = reinterpret_cast<const float4*>(mean)[m.c4], is = reinterpret_cast<const float4*>(invstd)[m.c4];
+    const float4 g = reinterpret_cast<const float4*>(gamma)[m.c4], b = reinterpret_cast<const float4*>(beta)[m.c4];
+    d4 a = d4zero();
+    for (int r = rbeg + m.r0; r < rend; r += m.rstep) {
+        const float4 v = reinterpret_cast<const float4*>(x + base + (long)r * C)[m.c4];
+        float4 o;
+        o.x = (v.x - mu.x) * is.x * g.x + b.x; o.y = (v.y - mu.y) * is.y * g.y + b.y;
+        o.z = (v.z - mu.z) * is.z * g.z + b.z; o.w = (v.w - mu.w) * is.w * g.w + b.w;
+        reinterpret_cast<float4*>(y + base + (long)r * C)[m.c4] = o;
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+    }
+    lds[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        d4 s = d4zero();
+        for (int t = threadIdx.x; t < 256; t += C4) { d4 v = lds[t]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        double* p = part + ((long)blockIdx.y * nchunk + blockIdx.x) * C + threadIdx.x * 4;
+        p[0] = s.x; p[1] = s.y; p[2] = s.z; p[3] = s.w;
+    }
+}
+__global__ void pool_final_kernel(const double* __restrict__ part, int nchunk, int C, long NC, float scale, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= NC) return;
+    const long n = i / C; const int c = (int)(i % C);
+    double s = 0.0;
+    for (int k = 0; k < nchunk; ++k) s += part[(n * nchunk + k) * C + c];
+    out[i] = (float)(s * scale);
+}
+
 // dx = gamma * invstd * (dy - sum_dy/N - xhat * sum_dy_xhat/N)
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -263,6 +308,26 @@ int ha2g_bn_apply_f32(const float* x, const float* mean, const float* invstd, co
     hipLaunchKernelGGL(bn_apply_kernel, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta,
                        y, rows, C, act);
     HA2G_CHECK_LAUNCH("bn_apply");
+    return 0;
+}
+// y = bn(x) for x [N][HW][C] AND pooled[n][c] = mean over HW of y (the SE squeeze) in one pass over the tensor.
+// ws: >= ha2g_bn_apply_pool_workspace_floats(N, HW, C) floats.
+static int pool_chunks(int N, int HW) {
+    int c = 2048 / (N < 1 ? 1 : N);                      // ~2k blocks per launch
+    int cap = HW / 64;                                   // >= 64 rows per block
+    if (c > cap) c = cap;
+    return c < 1 ? 1 : c;
+}
+long ha2g_bn_apply_pool_workspace_floats(int N, int HW, int C) { return (long)N * pool_chunks(N, HW) * C * 2; }
+int ha2g_bn_apply_pool_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y,
+                           int N, int HW, int C, float* pooled, float* ws, void* stream) {
+    HA2G_REQUIRE(okC(C), "bn_apply_pool: unsupported channel count %d", C);
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = pool_chunks(N, HW);
+    hipLaunchKernelGGL(bn_apply_pool_kernel, dim3(nchunk, N), dim3(256), 0, st, x, mean, invstd, gamma, beta, y, HW, C, (double*)ws);
+    hipLaunchKernelGGL(pool_final_kernel, dim3(ceil_div((long)N * C, 256)), dim3(256), 0, st, (const double*)ws, nchunk, C, (long)N * C,
+                       1.f / (float)HW, pooled);
+    HA2G_CHECK_LAUNCH("bn_apply_pool");
     return 0;
 }
 // dgamma = sum dy*xhat, dbeta = sum dy, dx as torch's batch-norm backward (train mode)

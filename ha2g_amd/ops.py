@@ -491,6 +491,17 @@ def bn_apply(x2, mean, invstd, gamma, beta, act=ACT_NONE, out=None):
     return out
 
 
+def bn_apply_pool(x, mean, invstd, gamma, beta):
+    """x [N,H,W,C] -> (bn(x), mean over H*W of bn(x) [N,C]) in one pass (BatchNorm apply + SE squeeze)."""
+    N, H, W, C = x.shape
+    y, pooled = torch.empty_like(x), empty(N, C, like=x)
+    ws = workspace(x.device)
+    assert lib.ha2g_bn_apply_pool_workspace_floats(N, H * W, C) <= ws.numel()
+    check(lib.ha2g_bn_apply_pool_f32(x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                     N, H * W, C, pooled.data_ptr(), ws.data_ptr(), _stream()))
+    return y, pooled
+
+
 def bn_bwd(dy2, x2, mean, invstd, gamma, need_dx=True, relu_mask=False, acc=None):
     """acc = (gamma.grad, beta.grad) buffers to accumulate into directly (the returned dgamma/dbeta are the fresh sums)."""
     rows, C = x2.shape

@@ -102,14 +102,18 @@ class _BN:
 _TRAINING = [True]
 
 
-def _bn_fwd(x, bn):
+def _bn_fwd(x, bn, pool=False):
+    """BatchNorm forward; pool=True also returns the per-image channel means of the output (the SE squeeze), fused."""
     x2 = _rows(x)
     if not _TRAINING[0]:                                    # module.eval(): running statistics, no update
-        invstd = ops.eltwise(ops.OP_RSQRT_EPS, bn.rv, alpha=1e-5)
-        return ops.bn_apply(x2, bn.rm, invstd, bn.gamma, bn.beta).view(x.shape), bn.rm, invstd
-    mean, invstd = ops.bn_stats(x2, bn.rm, bn.rv, 0.1, 1e-5)
-    if bn.nbt is not None:
-        bn.nbt.add_(1)
+        mean, invstd = bn.rm, ops.eltwise(ops.OP_RSQRT_EPS, bn.rv, alpha=1e-5)
+    else:
+        mean, invstd = ops.bn_stats(x2, bn.rm, bn.rv, 0.1, 1e-5)
+        if bn.nbt is not None:
+            bn.nbt.add_(1)
+    if pool:
+        y, pooled = ops.bn_apply_pool(x, mean, invstd, bn.gamma, bn.beta)
+        return y, mean, invstd, pooled
     y = ops.bn_apply(x2, mean, invstd, bn.gamma, bn.beta).view(x.shape)
     return y, mean, invstd
 
@@ -181,10 +185,8 @@ class WavEncoderFunction(torch.autograd.Function):
                 c1 = conv_fwd(x, wa, None, stride, 1, ACT_RELU)                     # relu(conv1)
                 a1, m1, s1 = _bn_fwd(c1, P[b + 'bn1'])
                 c2 = conv_fwd(a1, wb, None, 1, 1, ACT_NONE)
-                b2, m2, s2 = _bn_fwd(c2, P[b + 'bn2'])
+                b2, m2, s2, pooled = _bn_fwd(c2, P[b + 'bn2'], pool=True)         # bn2 + SE squeeze in one pass
                 N, OH, OW, C = b2.shape
-                pooled = empty(N, C, like=x)
-                check(lib.ha2g_hw_mean_f32(b2.data_ptr(), pooled.data_ptr(), N, OH * OW, C, _stream()))
                 h1 = ops.gemm(pooled, P[b + 'se.fc.0.weight'], transb=True, bias=P[b + 'se.fc.0.bias'], act=ACT_RELU)
                 su = ops.gemm(h1, P[b + 'se.fc.2.weight'], transb=True, bias=P[b + 'se.fc.2.bias'])      # gate pre-activation
                 sc = ops.eltwise(ops.OP_SIGMOID, su)

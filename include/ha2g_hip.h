@@ -99,6 +99,11 @@ int ha2g_bn_stats_f32(const float* x, long rows, int C, float* mean, float* invs
                       float* running_var, float momentum, float eps, float* ws, void* stream);
 int ha2g_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                       float* y, long rows, int C, int act, void* stream);
+/* BatchNorm apply fused with the SE squeeze that follows bn2 (model/ResNetBlocks.py:29-36,81-83): y = bn(x) for x [N][HW][C]
+ * and pooled[n][c] = mean_hw y in ONE pass over the tensor.  ws >= ha2g_bn_apply_pool_workspace_floats(N, HW, C). */
+long ha2g_bn_apply_pool_workspace_floats(int N, int HW, int C);
+int ha2g_bn_apply_pool_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y,
+                           int N, int HW, int C, float* pooled, float* ws, void* stream);
 /* relu_mask = 1: x is a ReLU output feeding the BatchNorm (conv -> ReLU -> BN, ResNetBlocks.py:24-26); dx is then masked by x > 0 */
 int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma,
                     float* dx, float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma /*nullable: += */,
