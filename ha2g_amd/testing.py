@@ -242,11 +242,12 @@ def build_modules(case, device, dims=schema.GESTURE_POSE_DIMS, state=None):
 class EpsInjector:
     """Feeds the reference's reparameterisation-noise sequence to the generators.  The reference draws one (B,16)
     tensor per generator call in the order [chain][g1,g2,g3]; the fused step calls each generator once with k*B rows
-    (row block i = chain i), so generator j receives stream entries base + 3*i + j for i = 0..k-1."""
+    (row block p = chain eps_block_order[p]), so generator j receives stream entries base + 3*i + j for i = 0..k-1."""
 
     def __init__(self, gens, seed, B):
         self.B, self.base, self.seed = B, 0, seed
         self.n_gen = len(gens)
+        self.gens = list(gens)
         for j, g in enumerate(gens):
             g.eps_source = (lambda shape, device, j=j: self(j, shape, device))
 
@@ -256,7 +257,9 @@ class EpsInjector:
 
     def __call__(self, j, shape, device):
         k = shape[0] // self.B
-        eps = np.concatenate([self._draw(self.base + self.n_gen * i + j) for i in range(k)], 0)
+        # physical row block p holds the reference's pass number order[p] (the step puts the gradient-carrying block last)
+        order = getattr(self.gens[j], 'eps_block_order', None) or list(range(k))
+        eps = np.concatenate([self._draw(self.base + self.n_gen * order[p] + j) for p in range(k)], 0)
         if j == self.n_gen - 1:
             self.base += self.n_gen * k
         return torch.from_numpy(eps).to(device)

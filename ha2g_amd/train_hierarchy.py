@@ -121,23 +121,28 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
         # row blocks: [D-phase chain (GAN phase only) | main chain | random-speaker chain]; eps is drawn block by block
         # in that order, which is the order the reference's three passes consume it.
         blocks = (['dis'] if gan else []) + ['main'] + (['rand'] if use_div else [])
-        k = len(blocks)
+        # physical row order: the gradient-carrying main block LAST, so that the rows evaluated under no_grad (row-wise
+        # sub-networks, see Hierarchical_PoseGenerator._row_split) form ONE contiguous range = one fuller launch per op
+        phys = [b for b in blocks if b != 'main'] + ['main']
+        k = len(phys)
         rep = lambda t: t.repeat(*([k] + [1] * (t.dim() - 1))) if k > 1 else t
-        vids_all = torch.cat([rand_vids if b == 'rand' else vid_indices for b in blocks]) if k > 1 else vid_indices
+        vids_all = torch.cat([rand_vids if b == 'rand' else vid_indices for b in phys]) if k > 1 else vid_indices
         blend_all = []
         for lvl in range(L):
             f = linear_blend_feat[lvl]
-            blend_all.append(torch.cat([f if b == 'main' else f.detach() for b in blocks]) if k > 1 else f)
-        main_at = blocks.index('main')
+            blend_all.append(torch.cat([f if b == 'main' else f.detach() for b in phys]) if k > 1 else f)
+        main_at = phys.index('main')
         for g in gens:                                   # only the main block's rows carry gradient through the GRUs
             g.gru.grad_slice = (main_at * B, B) if k > 1 else None
+            g.eps_block_order = [blocks.index(b) for b in phys]       # logical (reference pass) index of each physical block
         try:
             outs_all, z_all, mu_all, lv_all = _chain(spec, args, gens, [rep(t) for t in targets], rep(in_text_padded), blend_all, vids_all)
         finally:
             for g in gens:
                 g.gru.grad_slice = None
+                g.eps_block_order = None
         fused = {}
-        for i, b in enumerate(blocks):
+        for i, b in enumerate(phys):
             sl = slice(i * B, (i + 1) * B)
             fused[b] = ([o[sl] for o in outs_all], z_all[sl], mu_all[sl], lv_all[sl])
 
