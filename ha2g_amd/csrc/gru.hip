@@ -276,6 +276,22 @@ int run_pack(const float* whh, float* pf, float* pb, hipStream_t st) {
 
 }  // namespace
 
+namespace {
+// Bias gradients of one bidirectional layer from ONE column sum of the gate-gradient buffer dg [rows][2 dirs][r z n_i n_h]:
+//   d b_ih = (r, z, n_i)      d b_hh = (r, z, n_h)      (nn.GRU keeps b_ih and b_hh separate; r and z gradients coincide)
+__global__ void gru_bias_grads_kernel(const float* __restrict__ cs, float* __restrict__ bih0, float* __restrict__ bhh0,
+                                      float* __restrict__ bih1, float* __restrict__ bhh1, int H, float beta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 6 * H) return;
+    const int d = i / (3 * H), j = i % (3 * H);
+    const float* t = cs + 4 * H * d;
+    float* bi = d ? bih1 : bih0; float* bh = d ? bhh1 : bhh0;
+    const float vi = t[j], vh = j < 2 * H ? t[j] : t[j + H];
+    bi[j] = (beta != 0.f ? beta * bi[j] : 0.f) + vi;
+    bh[j] = (beta != 0.f ? beta * bh[j] : 0.f) + vh;
+}
+}  // namespace
+
 extern "C" {
 
 // floats per direction of one packed W_hh image (forward or backward form)
@@ -333,4 +349,13 @@ int ha2g_gru_layer_bwd(const float* dy, const float* y, const float* rs, const f
     return 0;
 }
 
+
+// colsums [8H] = column sums of dg [rows][8H]; writes (beta = 0) or accumulates (beta = 1) the four bias gradients of the layer
+int ha2g_gru_bias_grads_f32(const float* colsums, float* dbih_fwd, float* dbhh_fwd, float* dbih_rev, float* dbhh_rev, int H, float beta,
+                            void* stream) {
+    hipLaunchKernelGGL(gru_bias_grads_kernel, dim3((6 * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, colsums, dbih_fwd, dbhh_fwd,
+                       dbih_rev, dbhh_rev, H, beta);
+    HA2G_CHECK_LAUNCH("gru_bias_grads");
+    return 0;
+}
 }  // extern "C"

@@ -668,6 +668,7 @@ class BiGRUFunction(torch.autograd.Function):
             dx = torch.empty(B * T, K, dtype=torch.float32, device=dev) if need_dx else None
             keep.append((dg, hp, x2, y, dy))                                        # side-stream readers: alive until join
             with side.section(dev):                                                 # weight / bias gradients: off the critical path
+                tgs = []
                 for d in range(2):
                     o = 4 * H * d
                     dgi = dg[:, o:o + 3 * H]
@@ -684,16 +685,18 @@ class BiGRUFunction(torch.autograd.Function):
                     gemm(dg[:, o + 3 * H:o + 4 * H], hpd, transa=True, out=dwhh[2 * H:], beta=bt)  # rows n (d gh_n)
                     if tg[1] is None:
                         grads[8 * l + 4 * d + 1] = dwhh
-                    if tg[2] is not None:
-                        colsum(dgi, out=tg[2], beta=1.0)
-                    else:
-                        grads[8 * l + 4 * d + 2] = colsum(dgi)
-                    bt = 1.0 if tg[3] is not None else 0.0
-                    dbhh = tg[3] if tg[3] is not None else torch.empty(3 * H, dtype=torch.float32, device=dev)
-                    colsum(dg[:, o:o + 2 * H], out=dbhh[:2 * H], beta=bt)
-                    colsum(dg[:, o + 3 * H:o + 4 * H], out=dbhh[2 * H:], beta=bt)
-                    if tg[3] is None:
-                        grads[8 * l + 4 * d + 3] = dbhh
+                    tgs.append(tg)
+                # the four bias gradients of the layer from ONE column sum over all 8H gate-gradient columns
+                cs = colsum(dg)
+                direct = all(t[2] is not None and t[3] is not None for t in tgs)
+                outs = [(tgs[d][2], tgs[d][3]) if direct else (torch.empty(3 * H, dtype=torch.float32, device=dev),
+                                                                torch.empty(3 * H, dtype=torch.float32, device=dev)) for d in range(2)]
+                check(lib.ha2g_gru_bias_grads_f32(cs.data_ptr(), outs[0][0].data_ptr(), outs[0][1].data_ptr(), outs[1][0].data_ptr(),
+                                                  outs[1][1].data_ptr(), H, 1.0 if direct else 0.0, _stream()))
+                keep.append(cs)
+                if not direct:
+                    for d in range(2):
+                        grads[8 * l + 4 * d + 2], grads[8 * l + 4 * d + 3] = outs[d]
             if need_dx:
                 for d in range(2):                                                  # critical path: dX (+)= dgi W_ih
                     gemm(dg[:, 4 * H * d:4 * H * d + 3 * H], w[4 * d], out=dx, beta=float(d))

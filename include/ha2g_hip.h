@@ -74,6 +74,10 @@ int ha2g_nhwc_to_nwch_f32(const float* in, float* out, int N, int H, int W, int 
 long ha2g_gru_packed_floats(int H);           /* floats of one packed W_hh image (per direction, per form) */
 int ha2g_gru_supported_hidden(int H);         /* 300, 64, 32 are instantiated */
 int ha2g_gru_pack_whh(const float* whh, float* packed_fwd, float* packed_bwd, int H, void* stream);
+/* the layer's four bias gradients from ONE column sum (ha2g_colsum_f32) of dg [rows][2][r z n_i n_h]: d b_ih = (r,z,n_i),
+ * d b_hh = (r,z,n_h); beta = 1 accumulates into the destinations */
+int ha2g_gru_bias_grads_f32(const float* colsums, float* dbih_fwd, float* dbhh_fwd, float* dbih_rev, float* dbhh_rev, int H,
+                            float beta, void* stream);
 /* gi [B][T][2][3H] = x W_ih^T + b_ih (both directions); wp = packed_fwd images (dir 0, dir 1) back to back;
  * y [B][T][2H]; rs (nullable reserve) [B][T][2][4][H] */
 int ha2g_gru_layer_fwd(const float* gi, const float* wp, const float* bhh_fwd, const float* bhh_rev, float* y,
