@@ -100,6 +100,7 @@ class _BN:
 
 
 _TRAINING = [True]
+_NBT_PENDING = []
 
 
 def _bn_fwd(x, bn, pool=False):
@@ -110,7 +111,7 @@ def _bn_fwd(x, bn, pool=False):
     else:
         mean, invstd = ops.bn_stats(x2, bn.rm, bn.rv, 0.1, 1e-5)
         if bn.nbt is not None:
-            bn.nbt.add_(1)
+            _NBT_PENDING.append(bn.nbt)                    # num_batches_tracked += 1, batched into one launch per forward
     if pool:
         y, pooled = ops.bn_apply_pool(x, mean, invstd, bn.gamma, bn.beta)
         return y, mean, invstd, pooled
@@ -153,6 +154,7 @@ class WavEncoderFunction(torch.autograd.Function):
         if not training and torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
             raise NotImplementedError('ha2g_amd: the eval-mode audio encoder is forward-only; wrap inference in torch.no_grad()')
         _TRAINING[0] = training
+        _NBT_PENDING.clear()
         P = {}
         it = iter(range(len(tensors)))
         flat_index = {}
@@ -215,6 +217,9 @@ class WavEncoderFunction(torch.autograd.Function):
             S['tap_' + t] = (f.shape, fin, ct, mt, st, at.shape, packed)
             tap_out.append(y.view(B, Wt, 32))
         low, mid, high = tap_out
+        if _NBT_PENDING:
+            torch._foreach_add_(_NBT_PENDING, 1)
+            _NBT_PENDING.clear()
         # ---- speaker-conditioned softmax blending ----
         vid = vid.contiguous()
         ze = empty(B, 16, like=spec)
