@@ -1,0 +1,188 @@
+// Direct 3x3 / stride 1 / pad 1 convolution for 32 -> 32 channels (the six layer1 convolutions of the SE-ResNet34 and their
+// data gradients: 19 % of the tower's flops at the largest spatial size, 128 x 70).  With N = 32 output channels the
+// implicit-GEMM kernel re-stages every input value 9 times through the loader for only 32 columns of reuse and stays at
+// ~65 TFLOP/s; here
+//   * a tile is 256 CONSECUTIVE pixels of one image (8 MFMA row blocks, one per wave), whose input patch -- the 4-5 image rows
+//     they span plus one halo row above and below, full width plus a zero column left and right -- is ONE contiguous range
+//     of the NHWC tensor: it is copied to LDS once (16-byte loads/stores, pixel stride 36 floats => conflict-free b128
+//     fragment reads) and every tap of every pixel reads it there; padding is zeros in LDS, so the inner loop has no masks;
+//   * the whole 32 x 288 filter lives in REGISTERS (144 per lane) in MFMA B-fragment order, loaded once per workgroup;
+//     workgroups are persistent (one 8-wave workgroup per CU) and loop over tiles with the patch DOUBLE-BUFFERED: the next
+//     tile's patch is fetched one 16-byte slot per thread per filter tap while the current tile is on the matrix cores;
+//   * inner loop per (row block, tap): 4 ds_read_b128 -> 16 v_mfma_f32_32x32x2_f32 (k order chosen so that one 16-byte read
+//     feeds 4 MFMAs: MFMA j of channel group q uses channels 8q + j (lanes 0-31) and 8q + 4 + j (lanes 32-63)).
+// The data gradient is the same kernel on dy with the [ci][kh][kw][co] weight image and the taps flipped.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int CH = 32, CS = 36, TP = 256, NT = 512;
+
+struct Tile { int img, p0, r0, rows; };
+
+__device__ __forceinline__ Tile tile_of(long tile, int tpi, int HW, int W) {
+    Tile t;
+    t.img = (int)(tile / tpi); t.p0 = (int)(tile % tpi) * TP;
+    const int pend = min(t.p0 + TP, HW);
+    t.r0 = t.p0 / W;
+    t.rows = (pend - 1) / W - t.r0 + 3;                                  // + halo row above and below
+    return t;
+}
+
+// Cursor over one thread's 8 patch slots of a tile (slot t = 16 bytes: padded pixel (tid >> 3) + 64 t of the patch, channel
+// quad tid & 7).  Successive slots are 64 padded pixels apart, i.e. at most one row wrap (W + 2 > 64 is checked by the host):
+// no divisions or multiplications per slot.
+struct SlotCursor {
+    int pr, px;          // patch row / padded column of the current slot
+    long g;              // element offset of the source pixel's channel quad in x (valid only when the slot is inside the image)
+    int lo;              // LDS float offset of the slot
+    __device__ __forceinline__ void init(const Tile& t, int tid, int H, int W, int HW) {
+        const int PW = W + 2, pi = tid >> 3, c4 = tid & 7;
+        pr = pi / PW; px = pi - pr * PW;
+        g = ((long)t.img * HW + (long)(t.r0 - 1 + pr) * W + (px - 1)) * CH + 4 * c4;
+        lo = (pr * PW + px) * CS + 4 * c4;
+    }
+    __device__ __forceinline__ void advance(int W) {
+        const int PW = W + 2;
+        px += 64; g += 64 * CH; lo += 64 * CS;
+        if (px >= PW) { px -= PW; ++pr; g -= 2 * CH; }                   // the LDS offset is linear in the padded pixel index
+    }
+    // loads the slot (zeros outside the image); returns its LDS offset or -1 past the tile's patch rows
+    __device__ __forceinline__ int load(const float* __restrict__ x, const Tile& t, int H, int W, float4& v) const {
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pr >= t.rows) return -1;
+        const int gy = t.r0 - 1 + pr;
+        if (gy >= 0 && gy < H && px >= 1 && px <= W) v = *reinterpret_cast<const float4*>(x + g);
+        return lo;
+    }
+};
+
+// 512 threads = 8 waves, one 32-pixel row block each; persistent over tiles; the patch is double-buffered in LDS and the next
+// tile's patch is fetched one slot per filter tap while the current tile is on the matrix cores.
+__global__ __launch_bounds__(NT, 1) void conv3x3_c32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ y, int N, int H, int W, int flip, int act,
+                                                            float beta, int patch_floats, unsigned row_magic) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // 2 x [rows_max][W + 2][CS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int HW = H * W, PW = W + 2;
+    const int tpi = (HW + TP - 1) / TP;
+    const long tiles = (long)N * tpi;
+
+    // ---- filter -> registers: breg[t][q] holds w[n = l31][tap t][channels 8q + 4*lhi .. +3] ----
+    float4 breg[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tt = flip ? 8 - t : t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) breg[t][q] = *reinterpret_cast<const float4*>(w + ((long)l31 * 9 + tt) * CH + 8 * q + 4 * lhi);
+    }
+
+    long tile = blockIdx.x;
+    if (tile >= tiles) return;
+    Tile cur = tile_of(tile, tpi, HW, W);
+    // prologue: first patch straight into buffer 0
+    {
+        SlotCursor c; c.init(cur, tid, H, W, HW);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float4 v;
+            const int off = c.load(x, cur, H, W, v);
+            if (off >= 0) *reinterpret_cast<float4*>(lds + off) = v;
+            c.advance(W);
+        }
+    }
+    __syncthreads();
+    int buf = 0;
+    for (;; ) {
+        const long ntile = tile + gridDim.x;
+        const bool has_next = ntile < tiles;
+        Tile nxt = cur;
+        if (has_next) nxt = tile_of(ntile, tpi, HW, W);
+        const float* patch = lds + buf * patch_floats;
+        float* npatch = lds + (buf ^ 1) * patch_floats;
+
+        int p = cur.p0 + 32 * wave + l31;
+        if (p >= HW) p = HW - 1;                                         // clamp: stays inside the patch, result discarded
+        const int py = p / W, px = p - py * W;
+        const int a0 = ((py - cur.r0) * PW + px) * CS + 4 * lhi;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // next tile's patch: slot t is fetched at tap t and stored to the other LDS buffer DEPTH taps later (global latency is
+        // ~2 taps of MFMA time); the last DEPTH slots are stored after the tap loop
+        constexpr int DEPTH = 3;
+        SlotCursor nc; nc.init(nxt, tid, H, W, HW);
+        float4 nv[DEPTH];
+        int noff[DEPTH];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) noff[i] = -1;
+        // fragment reads run one (tap, channel-group) step ahead of the MFMAs that consume them
+        float4 av = *reinterpret_cast<const float4*>(patch + a0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t >= DEPTH && noff[t % DEPTH] >= 0) *reinterpret_cast<float4*>(npatch + noff[t % DEPTH]) = nv[t % DEPTH];
+            noff[t % DEPTH] = -1;
+            if (has_next && t < 8 && !(act & 0x20)) { noff[t % DEPTH] = nc.load(x, nxt, H, W, nv[t % DEPTH]); nc.advance(W); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 cur_a = av;
+                const int step = 4 * t + q + 1;                            // next step's fragment
+                if (step < 36) {
+                    const int nt = step / 4, nq = step % 4;
+                    av = *reinterpret_cast<const float4*>(patch + a0 + ((nt / 3) * PW + (nt % 3)) * CS + 8 * nq);
+                }
+                const float* pa = &cur_a.x; const float* pb = &breg[t][q].x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[j], pb[j], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i)
+            if (noff[i] >= 0) *reinterpret_cast<float4*>(npatch + noff[i]) = nv[i];
+        // ---- epilogue: C/D layout row = (r&3) + 8*(r>>2) + 4*lhi (pixel), col = l31 (channel) ----
+        float* yout = y + (long)cur.img * HW * CH;
+        const int pb0 = cur.p0 + 32 * wave;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pp = pb0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (pp >= HW || (act & 0x10)) continue;
+            float v = acc[r];
+            float* d = yout + (long)pp * CH + l31;
+            if (beta != 0.f) v += beta * *d;
+            if ((act & 15) == 1) v = fmaxf(v, 0.f);
+            *d = v;
+        }
+        if (!has_next) break;
+        // next patch complete, current patch no longer read.  LDS-only barrier: __syncthreads() would also wait for this tile's
+        // output stores to drain (s_waitcnt vmcnt(0)), ~1-2 us of idle matrix cores per tile
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        tile = ntile; cur = nxt; buf ^= 1;
+    }
+}
+
+}  // namespace
+
+// x [N][H][W][32], w [32][3][3][32] (n, tap, k), y [N][H][W][32] = act(beta*y + conv3x3(x, w)); flip = 1 visits the taps in
+// reverse (data gradient).  Returns -100 if the shape does not fit the LDS budget (caller falls back to the implicit GEMM).
+int conv3x3_c32_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta,
+                              hipStream_t st) {
+    const int rows_max = (TP + W - 2) / W + 1 + 2;
+    const int patch_floats = rows_max * (W + 2) * CS;
+    const size_t lds = (size_t)2 * patch_floats * sizeof(float);
+    if (lds > 150 * 1024 || (long)H * W < TP || rows_max * (W + 2) * 8 > 8 * NT || W + 2 <= 64) return -100;   // one workgroup per CU, 8 slots per thread
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return ha2g_set_error(-2, "conv3x3_c32: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    const long tiles = (long)N * (((long)H * W + TP - 1) / TP);
+    const int grid = (int)(tiles < 256 ? tiles : 256);
+    const unsigned row_slots = (unsigned)(W + 2) * 8;
+    const unsigned row_magic = (unsigned)((0x100000000ULL + row_slots - 1) / row_slots);    // s / row_slots = umulhi(s, magic), s < 2^16
+    hipLaunchKernelGGL(conv3x3_c32_kernel, dim3(grid), dim3(NT), lds, st, x, w, y, N, H, W, flip, act, beta, patch_floats, row_magic);
+    HA2G_CHECK_LAUNCH("conv3x3_c32");
+    return 0;
+}

@@ -59,6 +59,9 @@ int ha2g_conv2d_weight_ohwi_to_ihwo_f32(const float* w, float* wt, int Cout, int
 void ha2g_gemm_set_mode(int mode);
 /* tuning aid: forward GEMMs narrower than n columns stay on the fp32 MFMA */
 void ha2g_gemm_debug_x6_min_n(int n);
+/* bit 0 (default 0, opt-in): forward 32->32 channel 3x3 convolutions on the direct LDS-patch kernel conv_c32.hip (else implicit GEMM);
+ * bit 1 (default 0): their data gradients too (fp32; the split-bf16 implicit GEMM is faster); bits 4-5: timing ablations */
+void ha2g_conv_debug_direct_c32(int on);
 void ha2g_conv_debug_cfg(int cfg);   /* tile-shape override for tools/conv_bench.py (-1 = heuristic) */
 /* stem Conv2d(1->32, 3x3, pad 1) + bias + ReLU (model/ResNetSE34V2.py:27,127-128); x [N,H,W], y [N,H,W,32] */
 int ha2g_stem_conv_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, void* stream);

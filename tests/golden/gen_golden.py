@@ -248,8 +248,9 @@ def main():
         print('case', name, case)
         runs = {}
         global PERTURB_DRAW
-        plan = [('f64', torch.float64, 0.0, 0), ('f32', torch.float32, 0.0, 0), ('cond', torch.float64, 6e-8, 0),
-                ('f32p0', torch.float32, 6e-8, 1), ('f32p1', torch.float32, 6e-8, 2), ('f32p2', torch.float32, 6e-8, 3)]
+        NPERT = 8                               # float32 runs with one-ulp input perturbations (plus the plain float32 run)
+        plan = [('f64', torch.float64, 0.0, 0), ('f32', torch.float32, 0.0, 0), ('cond', torch.float64, 6e-8, 0)]
+        plan += [('f32p%d' % i, torch.float32, 6e-8, i + 1) for i in range(NPERT)]
         for tag, dt, pert, draw in plan:
             PERTURB_DRAW = draw
             o = runs[tag] = {}
@@ -259,12 +260,12 @@ def main():
                 module_goldens(case, o, dt, perturb=pert)
                 step_goldens(case, o, dt, perturb=pert)
         # truth  = the reference in float64;
-        # @noise = the reference's own float32 scatter around it: max deviation over four float32 runs (the plain one and
-        #          three whose float inputs are perturbed by one float32 ulp, 6e-8 relative -- that changes every rounding
+        # @noise = the reference's own float32 scatter around it: max deviation over NINE float32 runs (the plain one and
+        #          eight whose float inputs are perturbed by one float32 ulp, 6e-8 relative -- that changes every rounding
         #          decision downstream, so it samples the chaotic fp32 noise of the deep BatchNorm'ed net, not only one draw);
         # @cond  = how far the float64 result moves under the same one-ulp input perturbation (pure conditioning).
         out = {}
-        f32runs = ('f32', 'f32p0', 'f32p1', 'f32p2')
+        f32runs = ('f32',) + tuple('f32p%d' % i for i in range(NPERT))
         for k, v in runs['f64'].items():
             v = np.asarray(v, np.float64)
             out[k] = v

@@ -336,3 +336,35 @@ def test_log_mel_frontend():
             assert float(got[b].max()) == 0.0 and float(got[b].min()) >= -80.0
     one = fe.extract_melspectrogram(clips[0])
     assert one.dtype == torch.float16 and tuple(one.shape) == (128, 71)
+
+
+@pytest.mark.parametrize('shape', [(3, 20, 14), (2, 128, 70), (1, 16, 16), (2, 9, 37)])
+def test_direct_conv3x3_c32(shape):
+    """The direct LDS-patch kernel for the 32->32 channel 3x3 convolutions (layer1 of the audio tower; conv_c32.hip), forward
+    (+ReLU) and data gradient (accumulating), against float64 torch and against the implicit-GEMM path it replaces.  Shapes:
+    ragged last tile, the real 128x70 map, exactly one tile, a width that makes tiles straddle many rows."""
+    import torch.nn.functional as F
+    from ha2g_amd import wav_engine as we
+    from ha2g_amd._lib import lib
+    dev = _dev()
+    N, H, W = shape
+    x = rnd((N, 32, H, W), 61)
+    w = rnd((32, 32, 3, 3), 62, 0.08)
+    dy = rnd((N, 32, H, W), 63)
+    base = rnd((N, 32, H, W), 64)
+    xg, dyg, wg = (t.permute(0, 2, 3, 1).contiguous().to(dev) for t in (x, dy, w))
+    ref_y = F.relu(F.conv2d(x.double(), w.double(), padding=1))
+    ref_dx = base.double() + F.conv_transpose2d(dy.double(), w.double(), padding=1)
+    outs = {}
+    try:
+        for direct in (1, 0):
+            lib.ha2g_conv_debug_direct_c32(3 if direct else 0)
+            y = we.conv_fwd(xg, wg, None, 1, 1, we.ACT_RELU)
+            acc = base.permute(0, 2, 3, 1).contiguous().to(dev)
+            dx = we.conv_dgrad(dyg, wg, (N, H, W, 32), 1, 1, out=acc, beta=1.0)
+            outs[direct] = (y.permute(0, 3, 1, 2), dx.permute(0, 3, 1, 2))
+    finally:
+        lib.ha2g_conv_debug_direct_c32(0)
+    assert relerr(outs[1][0], ref_y) < 2e-6
+    assert relerr(outs[1][1], ref_dx) < 2e-5          # the data gradient of the implicit-GEMM path is split-bf16; the direct kernel is fp32
+    assert relerr(outs[0][0], ref_y) < 2e-6 and relerr(outs[0][1], ref_dx) < 2e-5

@@ -9,6 +9,6 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
   i=$((i+1)); rm -rf /tmp/pmc$i
   rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc$i -o p -- python3 tools/conv_vs_gemm.py > /tmp/pmc$i.log 2>&1
   db=$(find /tmp/pmc$i -name "*.db" | head -1)
-  python tools/rocpd_pmc.py $db gemm_kernel >> $out 2>&1
+  python tools/rocpd_pmc.py $db ${PMC_FILTER:-gemm_kernel} >> $out 2>&1
 done
 cat $out | cut -c1-150
