@@ -865,7 +865,11 @@ int ha2g_conv2d_dgrad_f32(const float* dy, const float* wt, float* dx, int N, in
     p.splits = 1; p.kchunk = p.K;
     p.g = ConvGeom{OH, OW, Cout, H, W, KH, KW, stride, pad, 1};
     hipStream_t st = (hipStream_t)stream;
-    return launch_conv_cfg<A_IM, B_KC>(pick_conv_cfg(p.M, p.N), p, st);
+    int cfg = pick_conv_cfg(p.M, p.N);
+    // the plane-based split-bf16 kernel is staging-bound, not MFMA-bound: its best tiles differ from the fp32 kernel's
+    // (tools/x3_cfg_sweep.py: 64-channel layers 64x64 141 vs 170 us, 256-channel layers 128x128 141 vs 151 us)
+    if (g_conv_cfg < 0 && g_split_dgrad && p.N > 32 && Cout % 32 == 0) cfg = p.N <= 64 ? 3 : (p.N >= 256 ? 2 : cfg);
+    return launch_conv_cfg<A_IM, B_KC>(cfg, p, st);
 }
 
 // Weight gradient: dw [Cout][KH][KW][Cin] (+)= dy^T * im2col(x); K = N*OH*OW output pixels, split over grid.z.
