@@ -623,7 +623,7 @@ static int g_x3 = 0;      // split-bf16 core: OPT-IN (ha2g_gemm_set_mode(1)).  I
                           // with >= 64 channels but ~10x noisier than the fp32 MFMA chain (4e-6 vs 4e-7 rms-rel per GEMM), which the
                           // reference-derived parity tolerances of the deep audio encoder do not absorb -> exact fp32 is the default.
 
-static int g_wgrad_blocks = 1024;
+static int g_wgrad_blocks = 0;      // 0 = per-shape default (see ha2g_conv2d_wgrad_workspace_bytes); else forced target
 static int g_split_tiles = 192;   // swept on the full step: <=100 is 5-30 % slower, >=192 flat
 
 __global__ void splitk_reduce_kernel(const float* ws, int splits, long MN, int N, float* C, long ldc, float alpha,
@@ -879,7 +879,10 @@ long ha2g_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, i
     long K = (long)N * OH * OW, MN = (long)Cout * KH * KW * Cin;
     int BM = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
     long tiles = (long)ceil_div(Cout, BM) * ceil_div(KH * KW * Cin, 128);
-    long splits = (g_wgrad_blocks + tiles - 1) / tiles;
+    // target workgroups per launch, swept with the split-bf16 inner product (tools/wgrad_sweep.py): many small chunks for the
+    // 32-channel layer (huge K, tiny output), fewer for the wide layers whose partial tiles are large
+    const long target = g_wgrad_blocks > 0 ? g_wgrad_blocks : (Cout <= 32 ? 1536 : (Cout <= 64 ? 1024 : 768));
+    long splits = (target + tiles - 1) / tiles;
     if (splits > K / 256) splits = K / 256;
     if (splits < 1) splits = 1;
     return splits * MN * 4;
