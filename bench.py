@@ -60,6 +60,7 @@ def main():
     ap.add_argument('--n-spk', type=int, default=1371)
     ap.add_argument('--expressive', action='store_true', help='config_expressive/hierarchy.yml: 6 levels, 126-d pose (BASELINE config 3)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='time hipGraph replays of the captured step instead of eager launches (no per-kernel HIP events => roofline objects are null)')
     ap.add_argument('--primary-only', action='store_true', help='skip the secondary timings (warm-up phase, exact-fp32 mode): for profiling')
     ap.add_argument('--cpu-batch', type=int, default=64)
     a = ap.parse_args()
@@ -99,16 +100,28 @@ def main():
 
     for _ in range(a.warmup):
         tr.train_iter(a.epoch, text, spec, target, vid)
-    ops.ktimer.enabled = True
-    ops.ktimer.reset()
-    sync()
-    t0 = time.perf_counter()
     last = None
-    for _ in range(a.steps):
-        last = tr.train_iter(a.epoch, text, spec, target, vid)
-    sync()
-    dt = time.perf_counter() - t0
-    ops.ktimer.enabled = False
+    if a.graph:                                      # whole step as one hipGraph (same kernels, launch overhead removed)
+        from ha2g_amd.train_hierarchy import _ret_dict
+        graph, gnames, gpacked = tr.capture_step(a.epoch, text, spec, target, vid)
+        ops.ktimer.reset()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            graph.replay()
+        sync()
+        dt = time.perf_counter() - t0
+        last = _ret_dict(args, gnames, gpacked.tolist())
+    else:
+        ops.ktimer.enabled = True
+        ops.ktimer.reset()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            last = tr.train_iter(a.epoch, text, spec, target, vid)
+        sync()
+        dt = time.perf_counter() - t0
+        ops.ktimer.enabled = False
     # secondary number: warm-up phase (epoch <= loss_warmup, no D update / no D-phase chain), a third of the timed steps
     k2 = max(2, a.steps // 3) if not a.primary_only else 0
     for _ in range(2 if k2 else 0):
@@ -169,7 +182,7 @@ def main():
                              mean_us=round(mean_us, 1), traffic=None)
         out = dict(metric='pose-frames/sec (train step) for hierarchy.yml B=128 T=34', value=round(value, 1), unit='pose-frames/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling='weak',
-                   vs_baseline=None, dtype='f32', data='synthetic',
+                   vs_baseline=None, dtype='f32', data='synthetic', launch='hipGraph replay' if a.graph else 'eager',
                    matrix_core='forward: fp32 MFMA; backward GEMMs/convs: split-bf16 x3 MFMA with fp32 accumulate (fp32-class, same parity bar)',
                    exact_fp32_matrix_core=dict(ms_per_step=round(ms_exact, 3), value=round(a.batch * 34 * world / (ms_exact * 1e-3), 1)),
                    warmup_phase=dict(ms_per_step=round(ms_warm, 3), value=round(a.batch * 34 * world / (ms_warm * 1e-3), 1)),

@@ -59,6 +59,22 @@ class HierarchyTrainer:
             for b in m.buffers():
                 dist.broadcast(b, src)
 
+    def capture_step(self, epoch, in_text_padded, in_spec, target, vid_indices, warmup=2):
+        """Capture one whole train step on these (static) input tensors into a hipGraph.  Returns (graph, names, packed):
+        `graph.replay()` runs the step (fresh dropout masks / noise per replay, device-side Adam counters), `packed` then holds
+        the logged scalars in `names` order.  Update the input tensors in place to feed new batches."""
+        s = torch.cuda.Stream(self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):                   # allocations / workspaces of the capture stream are created outside capture
+            for _ in range(warmup):
+                self.train_iter(epoch, in_text_padded, in_spec, target, vid_indices, return_tensors=True)
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            names, packed = self.train_iter(epoch, in_text_padded, in_spec, target, vid_indices, return_tensors=True)
+        return graph, names, packed
+
     def train_iter(self, epoch, in_text_padded, in_spec, target, vid_indices, **kw):
         fn = train_iter_hierarchy_expressive if self.expressive else train_iter_hierarchy
         return fn(self.args, epoch, in_text_padded, in_spec, target, vid_indices, *self.gens, self.discriminator, self.audio_encoder,
