@@ -60,6 +60,7 @@ def main():
     ap.add_argument('--n-spk', type=int, default=1371)
     ap.add_argument('--expressive', action='store_true', help='config_expressive/hierarchy.yml: 6 levels, 126-d pose (BASELINE config 3)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--bf16', action='store_true', help='BASELINE config 5 style: every vectorisable GEMM / convolution with plain bf16 operands (fp32 accumulate, fp32 storage / master weights); reported with dtype "bf16", never the default')
     ap.add_argument('--graph', action='store_true', help='time hipGraph replays of the captured step instead of eager launches (no per-kernel HIP events => roofline objects are null)')
     ap.add_argument('--primary-only', action='store_true', help='skip the secondary timings (warm-up phase, exact-fp32 mode): for profiling')
     ap.add_argument('--cpu-batch', type=int, default=64)
@@ -84,6 +85,9 @@ def main():
 
     torch.manual_seed(0)
     from ha2g_amd import schema
+    from ha2g_amd._lib import lib as _lib0
+    default_mode = int(os.environ.get('HA2G_GEMM_MODE', '22' if a.bf16 else '6'))
+    _lib0.ha2g_gemm_set_mode(default_mode)
     P = 126 if a.expressive else 27
     args = hierarchy_args(expressive=a.expressive)            # config[_expressive]/hierarchy.yml, dropout 0.3
     tr = HierarchyTrainer(args, Vocab(a.n_words), Vocab(a.n_spk), P, dev,
@@ -144,7 +148,7 @@ def main():
         tr.train_iter(a.epoch, text, spec, target, vid)
     sync()
     ms_exact = (time.perf_counter() - t2) / max(k2, 1) * 1e3 if k2 else float('nan')
-    _lib.ha2g_gemm_set_mode(int(os.environ.get('HA2G_GEMM_MODE', '6')))
+    _lib.ha2g_gemm_set_mode(default_mode)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -182,8 +186,9 @@ def main():
                              mean_us=round(mean_us, 1), traffic=None)
         out = dict(metric='pose-frames/sec (train step) for hierarchy.yml B=128 T=34', value=round(value, 1), unit='pose-frames/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling='weak',
-                   vs_baseline=None, dtype='f32', data='synthetic', launch='hipGraph replay' if a.graph else 'eager',
-                   matrix_core='forward: fp32 MFMA; backward GEMMs/convs: split-bf16 x3 MFMA with fp32 accumulate (fp32-class, same parity bar)',
+                   vs_baseline=None, dtype='bf16' if a.bf16 else 'f32', data='synthetic', launch='hipGraph replay' if a.graph else 'eager',
+                   matrix_core=('bf16 operands (1 MFMA per product), fp32 accumulate, fp32 storage and master weights; GRU recurrences fp32' if a.bf16 else
+                                'forward: fp32 MFMA; backward GEMMs/convs: split-bf16 x3 MFMA with fp32 accumulate (fp32-class, same parity bar)'),
                    exact_fp32_matrix_core=dict(ms_per_step=round(ms_exact, 3), value=round(a.batch * 34 * world / (ms_exact * 1e-3), 1)),
                    warmup_phase=dict(ms_per_step=round(ms_warm, 3), value=round(a.batch * 34 * world / (ms_warm * 1e-3), 1)),
                    config=dict(workload='%s hierarchy train step, B=%d per GPU, T=34, %d-d pose, '

@@ -55,6 +55,8 @@ int ha2g_conv2d_weight_ohwi_to_ihwo_f32(const float* w, float* wt, int Cout, int
  *                34-layer audio tower and the step no longer meets the 1e-4 parity bar).
  *   bit 3 (off): forward GEMMs / convolutions on the 3-piece split (6 bf16 MFMAs): as accurate as the fp32 MFMA chain
  *                (3.7e-7 vs 4.4e-7 rms-rel), 1.1-1.45x faster per GEMM, ~1.4 % of the step.
+ *   bit 4 (off): every vectorisable GEMM / convolution with PLAIN bf16 operands (one bf16 MFMA per product, fp32 accumulate,
+ *                fp32 storage) -- reduced precision (2^-9 per operand), for BASELINE config 5 / `bench.py --bf16` only.
  * 0 = exact fp32 MFMA everywhere. */
 void ha2g_gemm_set_mode(int mode);
 /* tuning aid: forward GEMMs narrower than n columns stay on the fp32 MFMA */

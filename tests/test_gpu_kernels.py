@@ -368,3 +368,36 @@ def test_direct_conv3x3_c32(shape):
     assert relerr(outs[1][0], ref_y) < 2e-6
     assert relerr(outs[1][1], ref_dx) < 2e-5          # the data gradient of the implicit-GEMM path is split-bf16; the direct kernel is fp32
     assert relerr(outs[0][0], ref_y) < 2e-6 and relerr(outs[0][1], ref_dx) < 2e-5
+
+
+def test_plain_bf16_mode_is_bf16_accurate():
+    """Mode bit 4 (bench --bf16, BASELINE config 5): GEMMs / convolutions with plain bf16 operands and fp32 accumulation are
+    within bf16 rounding (2^-9 per operand -> ~3e-3 rms) of float64 for every loader mode; never enabled by default."""
+    import torch.nn.functional as F
+    from ha2g_amd import ops, wav_engine as we
+    from ha2g_amd._lib import lib
+    dev = _dev()
+    a, b = rnd((1000, 600), 71), rnd((300, 600), 72)
+    b2 = rnd((600, 300), 73)
+    x = rnd((2, 64, 20, 12), 74)
+    w = rnd((64, 64, 3, 3), 75, 0.05)
+    dy = rnd((2, 64, 20, 12), 76)
+    rms = lambda g, r: float(((g.double().cpu() - r) ** 2).mean().sqrt() / (r ** 2).mean().sqrt())
+    lib.ha2g_gemm_set_mode(22)
+    try:
+        c_nt = ops.gemm(a.to(dev), b.to(dev), transb=True)
+        c_nn = ops.gemm(a.to(dev), b2.to(dev))
+        c_tn = ops.gemm(a.to(dev), a.to(dev)[:, :300].contiguous(), transa=True)
+        xg, wg, dyg = (t.permute(0, 2, 3, 1).contiguous().to(dev) for t in (x, w, dy))
+        y = we.conv_fwd(xg, wg, None, 1, 1, 0)
+        dx = we.conv_dgrad(dyg, wg, (2, 20, 12, 64), 1, 1)
+        dw = we.conv_wgrad(xg, dyg, wg, 1, 1)
+    finally:
+        lib.ha2g_gemm_set_mode(6)
+    refs = [(c_nt, a.double() @ b.double().t()), (c_nn, a.double() @ b2.double()), (c_tn, a.double().t() @ a.double()[:, :300]),
+            (y.permute(0, 3, 1, 2), F.conv2d(x.double(), w.double(), padding=1)),
+            (dx.permute(0, 3, 1, 2), F.conv_transpose2d(dy.double(), w.double(), padding=1)),
+            (dw, torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=1))]
+    for i, (got, ref) in enumerate(refs):
+        e = rms(got, ref)
+        assert 1e-4 < e < 6e-3, (i, e)          # bf16-level error: not fp32 (would be < 1e-6), not broken
