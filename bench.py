@@ -175,7 +175,7 @@ def main():
             roof = dict(kernel='gru_fwd_cluster_kernel (ha2g_gru_layer_fwd_cluster, H=300)', bound='mfma', achieved=round(ach, 3), peak=157.3,
                         unit='TFLOP/s', frac=round(ach / 157.3, 4), traffic=traffic, traffic_source=tsrc,
                         algorithmic_bytes=bytes_, launches=n, mean_us=round(mean_us, 1),
-                        batch_rows=rows, hbm_GBps_algorithmic=round(bytes_ / (mean_us * 1e-6) / 1e9, 1),
+                        batch_rows=rows, us_per_timestep=round(mean_us / T, 2), hbm_GBps_algorithmic=round(bytes_ / (mean_us * 1e-6) / 1e9, 1),
                         hbm_frac_of_8TBps=round(bytes_ / (mean_us * 1e-6) / 8e12, 4))
         roof_conv = None
         if 'conv2d_fwd' in kt:                     # the largest kernel family by time: implicit-GEMM convolutions of the audio tower (forward, fp32 MFMA)
