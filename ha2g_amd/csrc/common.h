@@ -27,6 +27,8 @@ int ha2g_set_error(int code, const char* fmt, ...);
 // internal (not part of the C ABI): direct 32->32 channel 3x3 convolution, conv_c32.hip
 int conv3x3_c32_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta,
                               hipStream_t st);
+int conv3x3_c32_x3_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta,
+                          hipStream_t st);
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -36,16 +36,18 @@ __device__ __forceinline__ Tile tile_of(long tile, int tpi, int HW, int W) {
 struct SlotCursor {
     int pr, px;          // patch row / padded column of the current slot
     long g;              // element offset of the source pixel's channel quad in x (valid only when the slot is inside the image)
-    int lo;              // LDS float offset of the slot
+    int lo;              // LDS float offset of the slot (fp32 patch)
+    int pp;              // padded pixel index pr * (W + 2) + px (bf16-plane patch)
     __device__ __forceinline__ void init(const Tile& t, int tid, int H, int W, int HW) {
         const int PW = W + 2, pi = tid >> 3, c4 = tid & 7;
         pr = pi / PW; px = pi - pr * PW;
         g = ((long)t.img * HW + (long)(t.r0 - 1 + pr) * W + (px - 1)) * CH + 4 * c4;
         lo = (pr * PW + px) * CS + 4 * c4;
+        pp = pr * PW + px;
     }
     __device__ __forceinline__ void advance(int W) {
         const int PW = W + 2;
-        px += 64; g += 64 * CH; lo += 64 * CS;
+        px += 64; g += 64 * CH; lo += 64 * CS; pp += 64;
         if (px >= PW) { px -= PW; ++pr; g -= 2 * CH; }                   // the LDS offset is linear in the padded pixel index
     }
     // loads the slot (zeros outside the image); returns its LDS offset or -1 past the tile's patch rows
@@ -162,6 +164,103 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c32_kernel(const float* __restr
     }
 }
 
+
+// ---- split-bf16 variant (data gradient) --------------------------------------------------------------------------------------
+// Same tiling; the patch is stored as two bf16 planes (hi = bf16(x), lo = bf16(x - hi); pixel stride 40 bf16 = 80 bytes =>
+// conflict-free b128 fragment reads), the filter as hi / lo B fragments in registers (144 per lane as before), and every
+// (pixel block, tap, 16-channel chunk) is a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_32x32x16_bf16: 54 MFMAs of 8 passes
+// per wave and tile instead of 144 of 16 passes.  Single-buffered patch (two planes of 7 x 72 pixels = 80.6 KB).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int CSH = 40;
+
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    f32x2_t v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+    f32x2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+}
+
+__global__ __launch_bounds__(NT, 1) void conv3x3_c32_x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               float* __restrict__ y, int N, int H, int W, int flip, int act,
+                                                               float beta, int plane_elems) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short pl[];  // [2 planes][rows_max][W + 2][CSH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int HW = H * W, PW = W + 2;
+    const int tpi = (HW + TP - 1) / TP;
+    const long tiles = (long)N * tpi;
+
+    // filter -> registers: for tap t and 16-channel chunk c, lane (n = l31, half = lhi) holds channels 16c + 8*half .. +7 of row n
+    bf16x8_t bh[9][2], bl[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tt = flip ? 8 - t : t;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float4 u0 = *reinterpret_cast<const float4*>(w + ((long)l31 * 9 + tt) * CH + 16 * c + 8 * lhi);
+            const float4 u1 = *reinterpret_cast<const float4*>(w + ((long)l31 * 9 + tt) * CH + 16 * c + 8 * lhi + 4);
+            uint4 h, l;
+            split2(u0.x, u0.y, h.x, l.x); split2(u0.z, u0.w, h.y, l.y); split2(u1.x, u1.y, h.z, l.z); split2(u1.z, u1.w, h.w, l.w);
+            bh[t][c] = __builtin_bit_cast(bf16x8_t, h);
+            bl[t][c] = __builtin_bit_cast(bf16x8_t, l);
+        }
+    }
+    unsigned short* phi = pl;
+    unsigned short* plo = pl + plane_elems;
+    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const Tile cur = tile_of(tile, tpi, HW, W);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // previous tile's fragment reads are done
+        {
+            SlotCursor c; c.init(cur, tid, H, W, HW);
+            float4 v[8]; int off[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { off[i] = c.load(x, cur, H, W, v[i]) >= 0 ? c.pp * CSH + 4 * (tid & 7) : -1; c.advance(W); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (off[i] >= 0) {
+                    uint2 h, l;
+                    split2(v[i].x, v[i].y, h.x, l.x); split2(v[i].z, v[i].w, h.y, l.y);
+                    *reinterpret_cast<uint2*>(phi + off[i]) = h;
+                    *reinterpret_cast<uint2*>(plo + off[i]) = l;
+                }
+        }
+        __syncthreads();
+        int p = cur.p0 + 32 * wave + l31;
+        if (p >= HW) p = HW - 1;
+        const int py = p / W, px = p - py * W;
+        const int a0 = ((py - cur.r0) * PW + px) * CSH + 8 * lhi;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * PW + (t % 3)) * CSH;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(phi + a0 + toff + 16 * c);
+                const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(plo + a0 + toff + 16 * c);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t][c], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t][c], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t][c], acc, 0, 0, 0);
+            }
+        }
+        float* yout = y + (long)cur.img * HW * CH;
+        const int pb0 = cur.p0 + 32 * wave;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pp = pb0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (pp >= HW) continue;
+            float v = acc[r];
+            float* d = yout + (long)pp * CH + l31;
+            if (beta != 0.f) v += beta * *d;
+            if ((act & 15) == 1) v = fmaxf(v, 0.f);
+            *d = v;
+        }
+    }
+}
+
 }  // namespace
 
 // x [N][H][W][32], w [32][3][3][32] (n, tap, k), y [N][H][W][32] = act(beta*y + conv3x3(x, w)); flip = 1 visits the taps in
@@ -184,5 +283,24 @@ int conv3x3_c32_launch(const float* x, const float* w, float* y, int N, int H, i
     const unsigned row_magic = (unsigned)((0x100000000ULL + row_slots - 1) / row_slots);    // s / row_slots = umulhi(s, magic), s < 2^16
     hipLaunchKernelGGL(conv3x3_c32_kernel, dim3(grid), dim3(NT), lds, st, x, w, y, N, H, W, flip, act, beta, patch_floats, row_magic);
     HA2G_CHECK_LAUNCH("conv3x3_c32");
+    return 0;
+}
+
+// split-bf16 variant (used for the data gradient); same contract
+int conv3x3_c32_x3_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st) {
+    const int rows_max = (TP + W - 2) / W + 1 + 2;
+    const int plane_elems = rows_max * (W + 2) * CSH;
+    const size_t lds = (size_t)2 * plane_elems * sizeof(unsigned short);
+    if (lds > 150 * 1024 || (long)H * W < TP || rows_max * (W + 2) * 8 > 8 * NT || W + 2 <= 64) return -100;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return ha2g_set_error(-2, "conv3x3_c32_x3: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    const long tiles = (long)N * (((long)H * W + TP - 1) / TP);
+    const int grid = (int)(tiles < 256 ? tiles : 256);
+    hipLaunchKernelGGL(conv3x3_c32_x3_kernel, dim3(grid), dim3(NT), lds, st, x, w, y, N, H, W, flip, act, beta, plane_elems);
+    HA2G_CHECK_LAUNCH("conv3x3_c32_x3");
     return 0;
 }

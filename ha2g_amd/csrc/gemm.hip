@@ -614,6 +614,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmP p) {
 
 static int g_c32_dbg = 0;
 static int g_direct_c32_dgrad = 0;
+static int g_direct_c32_x3 = 1;  // data gradient of the 32->32 channel 3x3 convolutions on the split-bf16 direct kernel (debug bit 2 = off)
 static int g_direct_c32 = 0;     // 32->32 channel 3x3 stride-1 forward convolutions on the direct LDS-patch kernel (conv_c32.hip): OPT-IN.
                                  // 231 vs 312 us per convolution (-0.5 ms/step) and exact to 2e-6 vs float64, but its different fp32
                                  // summation order moves the chaotic B=4 BatchNorm case (cfg1) to 1.04x its tolerance (3x the
@@ -812,7 +813,7 @@ extern "C" {
    margins of the full step are unchanged, see tools/margins.py) */
 void ha2g_gemm_set_mode(int mode) { g_x3 = mode & 1; g_split_wgrad = (mode >> 1) & 1; g_split_dgrad = (mode >> 2) & 1; g_x6 = (mode >> 3) & 1; g_bf16 = (mode >> 4) & 1; }
 void ha2g_gemm_debug_x6_min_n(int n) { g_x6_min_n = n; }
-void ha2g_conv_debug_direct_c32(int on) { g_direct_c32 = on & 1; g_direct_c32_dgrad = (on >> 1) & 1; g_c32_dbg = on & 0x30; }
+void ha2g_conv_debug_direct_c32(int on) { g_direct_c32 = on & 1; g_direct_c32_dgrad = (on >> 1) & 1; g_direct_c32_x3 = !((on >> 2) & 1); g_c32_dbg = on & 0x30; }
 void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 10000) g_wgrad_blocks = cfg - 10000; else if (cfg >= 1000) g_split_tiles = cfg - 1000; else g_conv_cfg = cfg; }   /* 1000+n: split-K tile threshold n; 10000+n: wgrad block target n */
 
 // Dense GEMM, row-major.  transa/transb follow BLAS meaning on row-major storage:
@@ -867,9 +868,11 @@ int ha2g_conv2d_dgrad_f32(const float* dy, const float* wt, float* dx, int N, in
     HA2G_REQUIRE(stride == 1 || stride == 2, "conv2d_dgrad: stride must be 1 or 2");
     HA2G_REQUIRE(KH * KW <= 32, "conv2d_dgrad: at most 32 filter taps");
     int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
-    // (the fp32 direct kernel is slower than the split-bf16 implicit GEMM for the data gradient: 235 vs 207 us; bit 1 of the debug knob)
-    if (g_direct_c32_dgrad && Cin == 32 && Cout == 32 && KH == 3 && KW == 3 && stride == 1 && pad == 1) {
-        int rc = conv3x3_c32_launch(dy, wt, dx, N, H, W, 1, 0, beta, (hipStream_t)stream);   // wt = [ci][kh][kw][co], taps flipped
+    if (Cin == 32 && Cout == 32 && KH == 3 && KW == 3 && stride == 1 && pad == 1) {
+        // direct LDS-patch kernels (conv_c32.hip): split-bf16 by default like every other data gradient; fp32 form = debug bit 1
+        int rc = -100;
+        if (g_direct_c32_dgrad) rc = conv3x3_c32_launch(dy, wt, dx, N, H, W, 1, 0, beta, (hipStream_t)stream);
+        else if (g_split_dgrad && g_direct_c32_x3) rc = conv3x3_c32_x3_launch(dy, wt, dx, N, H, W, 1, 0, beta, (hipStream_t)stream);
         if (rc != -100) return rc;
     }
     GemmP p{};

@@ -62,7 +62,8 @@ void ha2g_gemm_set_mode(int mode);
 /* tuning aid: forward GEMMs narrower than n columns stay on the fp32 MFMA */
 void ha2g_gemm_debug_x6_min_n(int n);
 /* bit 0 (default 0, opt-in): forward 32->32 channel 3x3 convolutions on the direct LDS-patch kernel conv_c32.hip (else implicit GEMM);
- * bit 1 (default 0): their data gradients too (fp32; the split-bf16 implicit GEMM is faster); bits 4-5: timing ablations */
+ * bit 1 (default 0): their data gradients on the fp32 direct kernel; bit 2 (default 0): 1 = take their data gradients OFF the
+ * split-bf16 direct kernel (default path, 121 vs 227 us) back to the implicit GEMM; bits 4-5: timing ablations */
 void ha2g_conv_debug_direct_c32(int on);
 void ha2g_conv_debug_cfg(int cfg);   /* tile-shape override for tools/conv_bench.py (-1 = heuristic) */
 /* stem Conv2d(1->32, 3x3, pad 1) + bias + ReLU (model/ResNetSE34V2.py:27,127-128); x [N,H,W], y [N,H,W,32] */

@@ -357,17 +357,20 @@ def test_direct_conv3x3_c32(shape):
     ref_dx = base.double() + F.conv_transpose2d(dy.double(), w.double(), padding=1)
     outs = {}
     try:
-        for direct in (1, 0):
-            lib.ha2g_conv_debug_direct_c32(3 if direct else 0)
+        # 3: fp32 direct kernel for forward and data gradient; 0 (default): forward implicit GEMM, data gradient on the
+        # split-bf16 direct kernel; 4: everything on the implicit GEMM
+        for mode in (3, 0, 4):
+            lib.ha2g_conv_debug_direct_c32(mode)
             y = we.conv_fwd(xg, wg, None, 1, 1, we.ACT_RELU)
             acc = base.permute(0, 2, 3, 1).contiguous().to(dev)
             dx = we.conv_dgrad(dyg, wg, (N, H, W, 32), 1, 1, out=acc, beta=1.0)
-            outs[direct] = (y.permute(0, 3, 1, 2), dx.permute(0, 3, 1, 2))
+            outs[mode] = (y.permute(0, 3, 1, 2), dx.permute(0, 3, 1, 2))
     finally:
         lib.ha2g_conv_debug_direct_c32(0)
-    assert relerr(outs[1][0], ref_y) < 2e-6
-    assert relerr(outs[1][1], ref_dx) < 2e-5          # the data gradient of the implicit-GEMM path is split-bf16; the direct kernel is fp32
-    assert relerr(outs[0][0], ref_y) < 2e-6 and relerr(outs[0][1], ref_dx) < 2e-5
+    for mode in (3, 0, 4):
+        assert relerr(outs[mode][0], ref_y) < 2e-6, mode
+        # split-bf16 data gradients: ~4e-6 rms; the direct kernels need W + 2 > 64, narrower maps fall back to the split GEMM
+        assert relerr(outs[mode][1], ref_dx) < (2e-6 if (mode == 3 and W > 62) else 2e-5), mode
 
 
 def test_plain_bf16_mode_is_bf16_accurate():
