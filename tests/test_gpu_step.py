@@ -244,3 +244,35 @@ def test_full_size_schedule_and_precision_invariants():
     for k in g_f:
         d = float((g_f[k] - g_x[k]).norm() / g_x[k].norm())
         assert d < 1e-4, ('split-bf16 vs fp32 backward', k, d)
+
+
+@pytest.mark.parametrize('B', [1, 5, 17])
+def test_ragged_batch_sizes_vs_oracle(B):
+    """Batch sizes that are not multiples of any tile (GRU 16-row tiles, 32-pixel conv blocks, 64-row reduction chunks): one
+    GAN-phase step on the GPU against the CPU oracle run in-test on the same seeded inputs (loss dict to 1e-4 rel, like
+    __graft_entry__.smoke), B = 1 included (a single sample per BatchNorm batch, a 1-element permutation)."""
+    from ha2g_amd.config import make_args
+    from ha2g_amd.testing import state_for
+    from oracle import ha2g_oracle as O
+    case = dict(CASES['small'], B=B)
+    args, gens, dis, aud, txt = build_modules(case, DEV)
+    text, spec, target, vid = batch_for(case)
+    lr = float(args.learning_rate)
+    opts = [FusedAdam(m.parameters(), lr=lr) for m in gens]
+    dis_opt = FusedAdam(dis.parameters(), lr=lr * args.discriminator_lr_weight)
+    aud_opt, txt_opt = FusedAdam(aud.parameters(), lr=lr), FusedAdam(txt.parameters(), lr=lr)
+    EpsInjector(gens, case['seed'], B)
+    perm = torch.from_numpy(proc.fixed_perm(B, case['seed']))
+    old = th.randperm_source
+    th.randperm_source = lambda n, device: perm.to(device)
+    try:
+        ret = th.train_iter_hierarchy(args, 11, text.to(DEV), spec.to(DEV), target.to(DEV), vid.to(DEV), *gens, dis, aud, txt,
+                                      *opts, dis_opt, aud_opt, txt_opt)
+    finally:
+        th.randperm_source = old
+    tr = O.OracleTrainer(state_for(case), make_args(case))
+    es = proc.EpsStream(case['seed'])
+    ref = tr.train_iter(11, text, spec, target, vid, lambda shp: torch.from_numpy(es(shp)), perm)
+    assert sorted(ret) == sorted(ref), (ret, ref)
+    for k in ref:
+        assert abs(ret[k] - ref[k]) <= 1e-4 * max(abs(ref[k]), 1e-3), (B, k, ret[k], ref[k])
