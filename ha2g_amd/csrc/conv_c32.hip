@@ -165,15 +165,17 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c32_kernel(const float* __restr
 }
 
 
-// ---- split-bf16 variant (data gradient) --------------------------------------------------------------------------------------
-// Same tiling; the patch is stored as two bf16 planes (hi = bf16(x), lo = bf16(x - hi); pixel stride 40 bf16 = 80 bytes =>
-// conflict-free b128 fragment reads), the filter as hi / lo B fragments in registers (144 per lane as before), and every
-// (pixel block, tap, 16-channel chunk) is a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_32x32x16_bf16: 54 MFMAs of 8 passes
-// per wave and tile instead of 144 of 16 passes.  Single-buffered patch (two planes of 7 x 72 pixels = 80.6 KB).
+// ---- split-bf16 variant (data gradient), C = 32 and C = 64 ----------------------------------------------------------------
+// Same tiling; the patch is stored as two bf16 planes (hi = bf16(x), lo = bf16(x - hi); pixel stride C + 8 bf16 => conflict-free
+// b128 fragment reads), the filter as hi / lo B fragments in registers, and every (pixel block, tap, 16-channel chunk) is
+// a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_32x32x16_bf16 (8 passes each instead of 8 fp32 MFMAs of 16 passes).
+//   C = 32: 8 waves, one 32-pixel block each, all 32 output channels (144 filter registers per lane);
+//   C = 64 (template path, NOT dispatched): 4 waves, two pixel blocks each, 32 of the 64 output channels per workgroup (288
+//           filter registers per lane, a tile is visited twice) -- measured 141 us = no faster than the split implicit GEMM.
+// Single-buffered patch (two planes: 80.6 KB at 70-wide maps / C = 32, 117 KB at 35-wide maps / C = 64).
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-constexpr int CSH = 40;
 
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
     f32x2_t v = {a, b};
@@ -182,25 +184,40 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
 }
 
-__global__ __launch_bounds__(NT, 1) void conv3x3_c32_x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                               float* __restrict__ y, int N, int H, int W, int flip, int act,
-                                                               float beta, int plane_elems) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short pl[];  // [2 planes][rows_max][W + 2][CSH]
+template <int C> struct X3Geo {
+    static constexpr int THREADS = C == 32 ? 512 : 256;      // 8 waves x 1 block, or 4 waves x 2 blocks of 32 pixels
+    static constexpr int MB = C == 32 ? 1 : 2;               // pixel blocks per wave
+    static constexpr int NH = C / 32;                        // 32-channel output halves
+    static constexpr int CHUNKS = C / 16;
+    static constexpr int CSX = C + 8;                        // bf16 per pixel in a plane
+    static constexpr int QP = C / 4;                         // float4 quads per pixel
+    static constexpr int PSTEP = THREADS / QP;               // padded pixels between a thread's consecutive slots
+};
+
+template <int C>
+__global__ __launch_bounds__(X3Geo<C>::THREADS, 1) void conv3x3_x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                         float* __restrict__ y, int N, int H, int W, int flip,
+                                                                         int act, float beta, int plane_elems) {
+    using G = X3Geo<C>;
+    extern __shared__ __attribute__((aligned(16))) unsigned short pl[];  // [2 planes][rows_max][W + 2][CSX]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int HW = H * W, PW = W + 2;
     const int tpi = (HW + TP - 1) / TP;
     const long tiles = (long)N * tpi;
+    const int nh = G::NH == 1 ? 0 : (blockIdx.x % G::NH);              // output-channel half of this workgroup
+    const int nout = nh * 32 + l31;
 
-    // filter -> registers: for tap t and 16-channel chunk c, lane (n = l31, half = lhi) holds channels 16c + 8*half .. +7 of row n
-    bf16x8_t bh[9][2], bl[9][2];
+    // filter -> registers: for tap t and 16-channel chunk c, lane (n = nout, half = lhi) holds channels 16c + 8*half .. +7 of row n
+    bf16x8_t bh[9][G::CHUNKS], bl[9][G::CHUNKS];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int tt = flip ? 8 - t : t;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const float4 u0 = *reinterpret_cast<const float4*>(w + ((long)l31 * 9 + tt) * CH + 16 * c + 8 * lhi);
-            const float4 u1 = *reinterpret_cast<const float4*>(w + ((long)l31 * 9 + tt) * CH + 16 * c + 8 * lhi + 4);
+        for (int c = 0; c < G::CHUNKS; ++c) {
+            const float* src = w + ((long)nout * 9 + tt) * C + 16 * c + 8 * lhi;
+            const float4 u0 = *reinterpret_cast<const float4*>(src);
+            const float4 u1 = *reinterpret_cast<const float4*>(src + 4);
             uint4 h, l;
             split2(u0.x, u0.y, h.x, l.x); split2(u0.z, u0.w, h.y, l.y); split2(u1.x, u1.y, h.z, l.z); split2(u1.z, u1.w, h.w, l.w);
             bh[t][c] = __builtin_bit_cast(bf16x8_t, h);
@@ -209,54 +226,82 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c32_x3_kernel(const float* __re
     }
     unsigned short* phi = pl;
     unsigned short* plo = pl + plane_elems;
-    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for (long tile = blockIdx.x / G::NH; tile < tiles; tile += gridDim.x / G::NH) {
         const Tile cur = tile_of(tile, tpi, HW, W);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // previous tile's fragment reads are done
         {
-            SlotCursor c; c.init(cur, tid, H, W, HW);
-            float4 v[8]; int off[8];
+            // patch fill: slot = (padded pixel, 4-channel quad); a thread's slots are PSTEP padded pixels apart
+            const int c4 = tid % G::QP;
+            int pp = tid / G::QP;
+            int pr = pp / PW, px = pp - pr * PW;
+            long g = ((long)cur.img * HW + (long)(cur.r0 - 1 + pr) * W + (px - 1)) * C + 4 * c4;
+            while (pr < cur.rows) {
+                constexpr int NS = 8;
+                float4 v[NS]; int off[NS];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { off[i] = c.load(x, cur, H, W, v[i]) >= 0 ? c.pp * CSH + 4 * (tid & 7) : -1; c.advance(W); }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (off[i] >= 0) {
-                    uint2 h, l;
-                    split2(v[i].x, v[i].y, h.x, l.x); split2(v[i].z, v[i].w, h.y, l.y);
-                    *reinterpret_cast<uint2*>(phi + off[i]) = h;
-                    *reinterpret_cast<uint2*>(plo + off[i]) = l;
+                for (int i = 0; i < NS; ++i) {
+                    off[i] = -1;
+                    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (pr < cur.rows) {
+                        const int gy = cur.r0 - 1 + pr;
+                        if (gy >= 0 && gy < H && px >= 1 && px <= W) v[i] = *reinterpret_cast<const float4*>(x + g);
+                        off[i] = pp * G::CSX + 4 * c4;
+                    }
+                    pp += G::PSTEP; px += G::PSTEP; g += (long)G::PSTEP * C;
+                    while (px >= PW) { px -= PW; ++pr; g -= 2 * C; }
                 }
-        }
-        __syncthreads();
-        int p = cur.p0 + 32 * wave + l31;
-        if (p >= HW) p = HW - 1;
-        const int py = p / W, px = p - py * W;
-        const int a0 = ((py - cur.r0) * PW + px) * CSH + 8 * lhi;
-        f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int toff = ((t / 3) * PW + (t % 3)) * CSH;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(phi + a0 + toff + 16 * c);
-                const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(plo + a0 + toff + 16 * c);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t][c], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t][c], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t][c], acc, 0, 0, 0);
+                for (int i = 0; i < NS; ++i)
+                    if (off[i] >= 0) {
+                        uint2 h, l;
+                        split2(v[i].x, v[i].y, h.x, l.x); split2(v[i].z, v[i].w, h.y, l.y);
+                        *reinterpret_cast<uint2*>(phi + off[i]) = h;
+                        *reinterpret_cast<uint2*>(plo + off[i]) = l;
+                    }
             }
         }
-        float* yout = y + (long)cur.img * HW * CH;
-        const int pb0 = cur.p0 + 32 * wave;
+        __syncthreads();
+        int a0[G::MB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int pp = pb0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            if (pp >= HW) continue;
-            float v = acc[r];
-            float* d = yout + (long)pp * CH + l31;
-            if (beta != 0.f) v += beta * *d;
-            if ((act & 15) == 1) v = fmaxf(v, 0.f);
-            *d = v;
+        for (int b = 0; b < G::MB; ++b) {
+            int p = cur.p0 + 32 * (G::MB * wave + b) + l31;
+            if (p >= HW) p = HW - 1;                                     // clamp: stays inside the patch, result discarded
+            const int py = p / W, px = p - py * W;
+            a0[b] = ((py - cur.r0) * PW + px) * G::CSX + 8 * lhi;
+        }
+        f32x16 acc[G::MB];
+#pragma unroll
+        for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * PW + (t % 3)) * G::CSX;
+#pragma unroll
+            for (int c = 0; c < G::CHUNKS; ++c)
+#pragma unroll
+                for (int b = 0; b < G::MB; ++b) {
+                    const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(phi + a0[b] + toff + 16 * c);
+                    const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(plo + a0[b] + toff + 16 * c);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t][c], acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t][c], acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t][c], acc[b], 0, 0, 0);
+                }
+        }
+        float* yout = y + (long)cur.img * HW * C;
+#pragma unroll
+        for (int b = 0; b < G::MB; ++b) {
+            const int pb0 = cur.p0 + 32 * (G::MB * wave + b);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pp = pb0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (pp >= HW) continue;
+                float v = acc[b][r];
+                float* d = yout + (long)pp * C + nout;
+                if (beta != 0.f) v += beta * *d;
+                if ((act & 15) == 1) v = fmaxf(v, 0.f);
+                *d = v;
+            }
         }
     }
 }
@@ -286,21 +331,28 @@ int conv3x3_c32_launch(const float* x, const float* w, float* y, int N, int H, i
     return 0;
 }
 
-// split-bf16 variant (used for the data gradient); same contract
-int conv3x3_c32_x3_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st) {
+// split-bf16 variants (used for the data gradient); C = 32 or 64 channels in and out; same contract
+template <int C>
+static int conv3x3_x3_launch_t(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st) {
+    using G = X3Geo<C>;
     const int rows_max = (TP + W - 2) / W + 1 + 2;
-    const int plane_elems = rows_max * (W + 2) * CSH;
+    const int plane_elems = rows_max * (W + 2) * G::CSX;
     const size_t lds = (size_t)2 * plane_elems * sizeof(unsigned short);
-    if (lds > 150 * 1024 || (long)H * W < TP || rows_max * (W + 2) * 8 > 8 * NT || W + 2 <= 64) return -100;
+    if (lds > 150 * 1024 || (long)H * W < TP || W + 2 <= G::PSTEP) return -100;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-            return ha2g_set_error(-2, "conv3x3_c32_x3: cannot raise the dynamic LDS limit");
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return ha2g_set_error(-2, "conv3x3_x3: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
-    const long tiles = (long)N * (((long)H * W + TP - 1) / TP);
-    const int grid = (int)(tiles < 256 ? tiles : 256);
-    hipLaunchKernelGGL(conv3x3_c32_x3_kernel, dim3(grid), dim3(NT), lds, st, x, w, y, N, H, W, flip, act, beta, plane_elems);
-    HA2G_CHECK_LAUNCH("conv3x3_c32_x3");
+    const long items = (long)N * (((long)H * W + TP - 1) / TP) * G::NH;
+    int grid = (int)(items < 256 ? items : 256);
+    grid = grid / G::NH * G::NH;                         // workgroup parity = output-channel half
+    if (grid < G::NH) return -100;
+    hipLaunchKernelGGL(conv3x3_x3_kernel<C>, dim3(grid), dim3(G::THREADS), lds, st, x, w, y, N, H, W, flip, act, beta, plane_elems);
+    HA2G_CHECK_LAUNCH("conv3x3_x3");
     return 0;
+}
+int conv3x3_c32_x3_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st) {
+    return conv3x3_x3_launch_t<32>(x, w, y, N, H, W, flip, act, beta, st);
 }
