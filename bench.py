@@ -28,25 +28,85 @@ class Vocab:
         self.word_embedding_weights = weights
 
 
-def cpu_baseline(B, epoch, n_words, n_spk):
-    """Time the CPU oracle's train step (oracle/ha2g_oracle.py, parity-pinned port of the reference) on one batch."""
+def host_cpu():
+    """(model name, physical cores of one socket) from /proc/cpuinfo; falls back to os.cpu_count()."""
+    model, cores = 'unknown', set()
+    try:
+        phys = None
+        for line in open('/proc/cpuinfo'):
+            k, _, v = line.partition(':')
+            k, v = k.strip(), v.strip()
+            if k == 'model name':
+                model = v
+            elif k == 'physical id':
+                phys = v
+            elif k == 'core id' and phys is not None:
+                cores.add((phys, v))
+        sockets = {p_ for p_, _ in cores}
+        n = len([c for c in cores if c[0] == min(sockets)]) if cores else 0
+    except OSError:
+        n = 0
+    return model, (n or os.cpu_count() or 1)
+
+
+def cpu_baseline(epoch, n_words, n_spk, budget_s=60.0):
+    """The CPU oracle's train step (oracle/ha2g_oracle.py, parity-pinned port of the reference) timed on this box's host cores:
+    threads = physical cores of one socket (SURVEY 8d / BASELINE.md 3).  B=4 (BASELINE config 1): 1 warm-up + 3 timed steps
+    per phase; B=128 (the headline batch): 1 warm-up step at B=4 to spin up the thread pool, then up to 3 timed GAN-phase
+    steps, bounded by `budget_s` of CPU time (one step is ~20-40 s)."""
     from ha2g_amd import procedural as proc, schema
     from ha2g_amd.config import hierarchy_args
     from oracle import ha2g_oracle as O
+    model, ncores = host_cpu()
+    torch.set_num_threads(ncores)
     args = hierarchy_args(dropout_prob=0.0)
     sch = schema.step_schema(schema.GESTURE_POSE_DIMS, n_words, n_spk, args.hidden_size, args.n_layers)
     sd = schema.procedural_state(sch, 3)
     tr = O.OracleTrainer(sd, args)
-    text, spec, target, vid = map(torch.from_numpy, proc.make_batch(B, 27, n_words, n_spk, 4321))
     eps = lambda shp: torch.randn(shp)
-    perm = torch.randperm(B)
-    small = [t[:2] for t in (text, spec, target, vid)]
-    tr.train_iter(epoch, *small, eps, torch.randperm(2))                    # warm the thread pool / allocator
-    t0 = time.time()
-    tr.train_iter(epoch, text, spec, target, vid, eps, perm)
-    dt = time.time() - t0
-    return dict(value=B * 34 / dt, unit='pose-frames/s', cores=torch.get_num_threads(), kind='port',
-                sample='1 train step (epoch %d) of B=%d, T=34 on the CPU oracle: %.1f s' % (epoch, B, dt))
+
+    def batch(B):
+        return tuple(map(torch.from_numpy, proc.make_batch(B, 27, n_words, n_spk, 4321)))
+
+    def timed(B, ep, nmax, budget):
+        data, times = batch(B), []
+        while len(times) < nmax and (not times or sum(times) + times[-1] < budget):
+            t0 = time.time()
+            tr.train_iter(ep, *data, eps, torch.randperm(B))
+            times.append(time.time() - t0)
+        return times
+
+    tr.train_iter(epoch, *batch(4), eps, torch.randperm(4))               # warm-up (thread pool, allocator)
+    b4 = {}
+    for name, ep in (('gan_phase', epoch), ('warmup_phase', 0)):
+        ts = timed(4, ep, 3, 30.0)
+        b4[name] = dict(steps=len(ts), s_per_step=round(sum(ts) / len(ts), 3), value=round(4 * 34 * len(ts) / sum(ts), 1))
+    ts = timed(128, epoch, 3, budget_s)
+    dt = sum(ts) / len(ts)
+    return dict(value=round(128 * 34 / dt, 1), unit='pose-frames/s', cores=ncores, cpu_model=model, kind='port',
+                sample='%d timed train step(s) (epoch %d, GAN phase) of B=128, T=34 on the CPU oracle after a warm-up step: %.1f s/step; '
+                       'B=4 (BASELINE config 1): 1 warm-up + 3 timed steps per phase' % (len(ts), epoch, dt),
+                b128=dict(steps=len(ts), s_per_step=round(dt, 2)), b4=b4)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, RCCL rendezvous on
+    127.0.0.1) BEFORE this process touches the GPU, stream rank 0's JSON line through, exit with the worst return code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p_ in procs:
+        rc = max(rc, abs(p_.wait()))
+    sys.exit(rc)
 
 
 def main():
@@ -63,9 +123,10 @@ def main():
     ap.add_argument('--bf16', action='store_true', help='BASELINE config 5 style: every vectorisable GEMM / convolution with plain bf16 operands (fp32 accumulate, fp32 storage / master weights); reported with dtype "bf16", never the default')
     ap.add_argument('--graph', action='store_true', help='time hipGraph replays of the captured step instead of eager launches (no per-kernel HIP events => roofline objects are null)')
     ap.add_argument('--primary-only', action='store_true', help='skip the secondary timings (warm-up phase, exact-fp32 mode): for profiling')
-    ap.add_argument('--cpu-batch', type=int, default=64)
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        spawn_ranks(a.gpus)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -198,7 +259,7 @@ def main():
                                global_batch=a.batch * world, parallelism='dp%d' % world),
                    gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, roofline_conv=roof_conv, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
         if world == 1 and not a.no_cpu_baseline and not a.expressive:
-            out['cpu_baseline'] = cpu_baseline(a.cpu_batch, a.epoch, a.n_words, a.n_spk)
+            out['cpu_baseline'] = cpu_baseline(a.epoch, a.n_words, a.n_spk)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

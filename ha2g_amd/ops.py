@@ -573,6 +573,17 @@ def gru_cluster_error(device):
     return int(_cluster_scratch(device)[1].item())
 
 
+def gru_cluster_error_tensor(device):
+    """The device int32 error word of the cluster GRU kernels (None while no cluster launch has happened on `device`):
+    the train step appends it to its packed scalar read-back and raises when it is non-zero."""
+    b = _cluster_bufs.get((device.type, device.index))
+    return None if b is None else b[1]
+
+
+class Ha2gClusterError(RuntimeError):
+    pass
+
+
 def _gru_layer_bwd(dy, y, rs, pkt, dg, B, T, H, st, device):
     if USE_GRU_CLUSTER and lib.ha2g_gru_cluster_supported(H):
         xch, err = _cluster_scratch(device)

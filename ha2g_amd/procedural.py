@@ -51,6 +51,12 @@ def tensor_for(key, shape, seed=0):
     return (0.1 * (2.0 * r.random(shape) - 1.0)).astype(np.float32)   # biases, BN beta
 
 
+def block_input(key, shape, seed=0):
+    """A post-ReLU-like feature map (what an SEBasicBlock / tap of the audio tower sees): relu(N(0.3, 1)) in NCHW order."""
+    r = _rng(key, seed)
+    return np.maximum(r.standard_normal(tuple(shape)) + 0.3, 0.0).astype(np.float32)
+
+
 def fill_module(module, seed=0, prefix=''):
     """Overwrite every parameter/buffer of a torch module in place (same keys on both sides)."""
     import torch

@@ -112,6 +112,22 @@ def wav_encoder_schema(n_spk, pose_level, p=''):
     return s
 
 
+def se_block_schema(cin, c, first, p=''):
+    """One SEBasicBlock (model/ResNetBlocks.py:7-37,81-95), optionally with the stride-2 1x1 downsample branch."""
+    s = {p + 'conv1.weight': (c, cin, 3, 3)}
+    _bn(s, p + 'bn1.', c)
+    s[p + 'conv2.weight'] = (c, c, 3, 3)
+    _bn(s, p + 'bn2.', c)
+    s[p + 'se.fc.0.weight'] = (c // 8, c)
+    s[p + 'se.fc.0.bias'] = (c // 8,)
+    s[p + 'se.fc.2.weight'] = (c, c // 8)
+    s[p + 'se.fc.2.bias'] = (c,)
+    if first:
+        s[p + 'downsample.0.weight'] = (c, cin, 1, 1)
+        _bn(s, p + 'downsample.1.', c)
+    return s
+
+
 GESTURE_POSE_DIMS = (15, 21, 27)
 EXPRESSIVE_POSE_DIMS = (24, 30, 36, 66, 96, 126)
 

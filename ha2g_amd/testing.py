@@ -276,3 +276,97 @@ def named_state(mods):
         for k, b in m.named_buffers():
             sd['%s.%s' % (role, k)] = b
     return sd, grads
+
+
+# ---- round 2: audio-tower fixtures (tests/golden/blocks.npz, blocksfull.npz, enc16.npz) -------------------------------------
+
+class DigestChecker:
+    """Checks (norm, strided sample) digests written by gen_golden.digest_n:
+        |x - truth| <= rtol * scale + noise_mult * max(@noise, @cond)      (float64: 1e-9 * scale)
+    `shares` records, per comparison, which fraction of the tolerance the reference's own fp32 scatter contributes --
+    on the strict fixtures (blocks.npz) it must stay below 10 %, i.e. rtol = 1e-4 is the operative bound."""
+
+    def __init__(self, g, dt=torch.float32, rtol=1e-4, noise_mult=1.0):
+        self.g = g
+        self.f64 = dt == torch.float64
+        self.rtol = 1e-9 if self.f64 else rtol
+        self.nm = 0.0 if self.f64 else noise_mult
+        self.shares, self.errs = [], []
+
+    def floor(self, key):
+        return max(float(self.g[key + '@noise']), float(self.g[key + '@cond']))
+
+    def check(self, got, key):
+        g = self.g
+        a = _np(got).reshape(-1)
+        ref = g[key + '/sample']
+        smp = a if a.size <= 4096 else a[::max(1, a.size // ref.size)][:ref.size]
+        assert smp.shape == ref.shape, (key, smp.shape, ref.shape)
+        rn = float(g[key + '/norm'])
+        nrm = float(np.sqrt((a * a).sum()))
+        ntol = self.rtol * max(rn, 1e-30) + self.nm * self.floor(key + '/norm') + self.nm * self.floor(key + '/sample') * np.sqrt(a.size)
+        assert abs(nrm - rn) <= ntol, '%s/norm: %.9e vs %.9e (tol %.2e)' % (key, nrm, rn, ntol)
+        scale = max(np.abs(ref).max(), rn / max(np.sqrt(a.size), 1.0), 1e-30)
+        fl = self.nm * self.floor(key + '/sample')
+        tol = self.rtol * scale + fl + 1e-12
+        err = np.abs(smp - ref).max()
+        self.shares.append((fl / tol, key))
+        self.errs.append((err / scale, key))
+        assert err <= tol, '%s/sample: max err %.3e > tol %.3e (scale %.3e, rel %.2e)' % (key, err, tol, scale, err / scale)
+
+
+def block_state(name, geom, seed, dt=torch.float32):
+    """Procedural state dict {key: tensor} of one SEBasicBlock fixture (keys as the reference registers them)."""
+    cin, c, h, w, first = geom
+    sch = schema.se_block_schema(cin, c, first, 'blk.%s.' % name)
+    sd = schema.procedural_state(sch, seed)
+    return {k[len('blk.%s.' % name):]: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def block_io(name, geom, B, seed, dt=torch.float32):
+    """(x NCHW, loss weights NCHW for out) of a block fixture."""
+    cin, c, h, w, first = geom
+    x = torch.from_numpy(proc.block_input('blk.%s.x' % name, (B, cin, h, w), seed)).to(dt)
+    oh, ow = ((h + 1) // 2, (w + 1) // 2) if first else (h, w)
+    wl = torch.from_numpy(proc.tensor_for('w.blk.%s' % name, (2, B, c, oh, ow), seed)[0] * (c * oh * ow) ** 0.5).to(dt)
+    return x, wl
+
+
+def engine_P(sd, device):
+    """name -> tensor / wav_engine._BN on `device` from a flat state dict with the reference's key names
+    (BatchNorm entries 'x.weight/.bias/.running_mean/.running_var/.num_batches_tracked' fold into one _BN under 'x')."""
+    from .wav_engine import _BN
+    P = {}
+    for k, v in sd.items():
+        if k.endswith('.running_mean'):
+            q = k[:-len('running_mean')]
+            P[q[:-1]] = _BN(*(sd[q + n].clone().to(device) for n in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked')))
+    for k, v in sd.items():
+        base = k.rsplit('.', 1)[0]
+        if base in P:
+            continue
+        t = v.clone().to(device)
+        if t.dim() == 4:
+            t = t.contiguous(memory_format=torch.channels_last)
+        P[k] = t
+    return P
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2)
+
+
+def taps_inputs(case, seed, dt=torch.float32):
+    B, W3 = case['B'], case['W3']
+    shapes = dict(layer2=(B, 64, 64, 4 * W3 - 1), layer3=(B, 128, 32, 2 * W3), layer4=(B, 256, 16, W3))
+    feats = {k: torch.from_numpy(proc.block_input('taps.' + k, shp, seed)).to(dt) for k, shp in shapes.items()}
+    vid = torch.from_numpy(np.arange(B, dtype=np.int64) % (case['n_spk'] - 1) + 1)
+    return feats, vid
+
+
+def taps_w(name, t, seed):
+    return torch.from_numpy(proc.tensor_for('w.taps.' + name, (2,) + tuple(t.shape), seed)[0] * t[0].numel() ** 0.5).to(device=t.device, dtype=t.dtype)

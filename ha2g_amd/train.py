@@ -56,6 +56,9 @@ class HierarchyTrainer:
         for o in self.gen_opts + [self.audio_opt, self.text_opt, self.dis_opt]:
             dist.broadcast(o.flat_p, src)
         for m in self.modules():
+            for p in m.parameters():
+                if not p.requires_grad:                      # frozen parameters (freeze_wordembed) live outside the flat buffers
+                    dist.broadcast(p.data, src)
             for b in m.buffers():
                 dist.broadcast(b, src)
 
@@ -71,7 +74,7 @@ class HierarchyTrainer:
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, stream=s):      # same stream as the warm-up: its workspace exists already, outside the capture
             names, packed = self.train_iter(epoch, in_text_padded, in_spec, target, vid_indices, return_tensors=True)
         return graph, names, packed
 

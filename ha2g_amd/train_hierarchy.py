@@ -247,6 +247,9 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
         names.append('c_neg'); vals.append(text_low_contrastive.detach())
     if args.loss_physical_weight > 0.0:
         names.append('phy'); vals.append(physical_loss.detach())
+    err = ops.gru_cluster_error_tensor(dev)
+    if err is not None:                                  # cluster-GRU hand-off time-out flag rides along in the same D2H copy
+        names.append('_cluster_err'); vals.append(err[0].to(torch.float32))
     packed = torch.stack(vals)
     if return_tensors:                                   # graph-captured steps read the packed buffer after replay
         return names, packed
@@ -259,6 +262,11 @@ def _ret_dict(args, names, vals):
          'c_neg': args.loss_contrastive_neg_weight, 'phy': args.loss_physical_weight}
     ret = {}
     for n, v in zip(names, vals):
+        if n == '_cluster_err':
+            if v:
+                raise ops.Ha2gClusterError('ha2g_amd: a GRU cluster hand-off timed out (gru_cluster.hip): this step\'s GRU outputs '
+                                           'and gradients are invalid -- the device cannot co-schedule the cluster\'s workgroups')
+            continue
         if n in ('KLD', 'DIV_REG') and not v:            # reference: `if kld:` / `if div_reg:` (train_hierarchy.py:277-280)
             continue
         ret[n] = w[n] * v

@@ -143,6 +143,184 @@ def _tap_pack(x, inverse=False, shape=None):
     return out
 
 
+class GradSink:
+    """Where the backward kernels put parameter gradients: straight into a parameter's installed `.grad` buffer when
+    there is one (beta = 1 epilogues), else into the dict G (name -> grad; BatchNorm: (dgamma, dbeta))."""
+
+    def __init__(self, P):
+        self.P, self.G = P, {}
+
+    @staticmethod
+    def tgt(t):                                           # a parameter's installed .grad buffer, if kernels may add into it
+        g = ops._grad_target(t)
+        return g if (g is not None and (g.is_contiguous() or g.dim() == 4)) else None
+
+    def gw(self, name, a, b_):                            # dW (+)= a^T b_
+        t = self.tgt(self.P[name])
+        if t is not None and t.is_contiguous():
+            ops.gemm(a, b_, transa=True, out=t, beta=1.0)
+        else:
+            self.G[name] = ops.gemm(a, b_, transa=True)
+
+    def gb(self, name, a):                                # db (+)= column sums of a
+        t = self.tgt(self.P[name])
+        if t is not None:
+            ops.colsum(a, out=t, beta=1.0)
+        else:
+            self.G[name] = ops.colsum(a)
+
+    def gconv(self, name, xin, dyc, w_ohwi, stride, pad):
+        r = conv_wgrad(xin, dyc, w_ohwi, stride, pad, into=self.tgt(self.P[name]))
+        if r is not None:
+            self.G[name] = r
+
+    def gbn(self, name, dy2, x2, mean, invstd, relu_mask=False):
+        bn = self.P[name]
+        tg_, tb_ = self.tgt(bn.gamma), self.tgt(bn.beta)
+        acc = (tg_, tb_) if (tg_ is not None and tb_ is not None) else None
+        dx_, dg_, db_ = ops.bn_bwd(dy2, x2, mean, invstd, bn.gamma, relu_mask=relu_mask, acc=acc)
+        if acc is None:
+            self.G[name] = (dg_, db_)
+        return dx_
+
+
+# ---- one SEBasicBlock (ResNetBlocks.py:21-37,81-95): conv -> ReLU -> BN -> conv -> BN -> SE -> (+ residual) -> ReLU --------
+
+def block_fwd(x, P, b, first):
+    """x NHWC; P: name -> tensor / _BN with keys prefixed by `b`; first = stride-2 block with the 1x1 downsample branch.
+    Returns (out NHWC, saved tuple for block_bwd)."""
+    stride = 2 if first else 1
+    wa, wb = _ohwi(P[b + 'conv1.weight']), _ohwi(P[b + 'conv2.weight'])
+    c1 = conv_fwd(x, wa, None, stride, 1, ACT_RELU)                     # relu(conv1)
+    a1, m1, s1 = _bn_fwd(c1, P[b + 'bn1'])
+    c2 = conv_fwd(a1, wb, None, 1, 1, ACT_NONE)
+    b2, m2, s2, pooled = _bn_fwd(c2, P[b + 'bn2'], pool=True)         # bn2 + SE squeeze in one pass
+    N, OH, OW, C = b2.shape
+    h1 = ops.gemm(pooled, P[b + 'se.fc.0.weight'], transb=True, bias=P[b + 'se.fc.0.bias'], act=ACT_RELU)
+    su = ops.gemm(h1, P[b + 'se.fc.2.weight'], transb=True, bias=P[b + 'se.fc.2.bias'])      # gate pre-activation
+    sc = ops.eltwise(ops.OP_SIGMOID, su)
+    if first:
+        wd = _ohwi(P[b + 'downsample.0.weight'])
+        cd = conv_fwd(x, wd, None, 2, 0, ACT_NONE)
+        res, md, sd = _bn_fwd(cd, P[b + 'downsample.1'])
+    else:
+        res, cd, md, sd = x, None, None, None
+    out = torch.empty_like(b2)
+    check(lib.ha2g_se_scale_add_relu_f32(b2.data_ptr(), sc.data_ptr(), res.data_ptr(), out.data_ptr(), N, OH * OW, C, _stream()))
+    return out, (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride)
+
+
+def block_bwd(dx, saved, P, b, sink):
+    """dx = d(out) NHWC -> d(x) NHWC; parameter gradients go to `sink` (GradSink)."""
+    (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride) = saved
+    N, OH, OW, C = b2.shape
+    HW = OH * OW
+    dout = dx.contiguous()
+    ds = empty(N, C, like=b2)
+    check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, _stream()))
+    dsc = ops.eltwise(ops.OP_SIGMOID_BWD_PRE, ds, su)
+    sink.gw(b + 'se.fc.2.weight', dsc, h1)
+    sink.gb(b + 'se.fc.2.bias', dsc)
+    dh1 = ops.eltwise(ops.OP_RELU_BWD, ops.gemm(dsc, P[b + 'se.fc.2.weight']), h1)
+    sink.gw(b + 'se.fc.0.weight', dh1, pooled)
+    sink.gb(b + 'se.fc.0.bias', dh1)
+    dpool = ops.gemm(dh1, P[b + 'se.fc.0.weight'], alpha=1.0 / HW)
+    dres, db2 = torch.empty_like(b2), torch.empty_like(b2)
+    check(lib.ha2g_se_bwd_apply_f32(dout.data_ptr(), out.data_ptr(), sc.data_ptr(), dpool.data_ptr(), dres.data_ptr(),
+                                    db2.data_ptr(), N, HW, C, _stream()))
+    dc2 = sink.gbn(b + 'bn2', _rows(db2), _rows(c2), m2, s2).view(c2.shape)
+    wb = _ohwi(P[b + 'conv2.weight'])
+    sink.gconv(b + 'conv2.weight', a1, dc2, wb, 1, 1)
+    da1 = conv_dgrad(dc2, wb, a1.shape, 1, 1)
+    dc1 = sink.gbn(b + 'bn1', _rows(da1), _rows(c1), m1, s1, relu_mask=True).view(c1.shape)
+    wa = _ohwi(P[b + 'conv1.weight'])
+    sink.gconv(b + 'conv1.weight', x, dc1, wa, stride, 1)
+    if cd is None:
+        return conv_dgrad(dc1, wa, x.shape, stride, 1, out=dres, beta=1.0)      # identity shortcut: accumulate onto d(residual)
+    dxin = conv_dgrad(dc1, wa, x.shape, stride, 1)
+    dcd = sink.gbn(b + 'downsample.1', _rows(dres), _rows(cd), md, sd).view(cd.shape)
+    wd = _ohwi(P[b + 'downsample.0.weight'])
+    sink.gconv(b + 'downsample.0.weight', x, dcd, wd, 2, 0)
+    conv_dgrad(dcd, wd, x.shape, 2, 0, out=dxin, beta=1.0)
+    return dxin
+
+
+# ---- one tap (ResNetSE34V2.py:157-212): [PixelShuffle] -> conv -> ReLU -> BN -> flatten (B, W, C*H) -> FC -----------------
+
+def tap_fwd(f, P, t, r):
+    fin = _pixel_shuffle(f, r) if r > 1 else f
+    wt = _ohwi(P['conv_%s.weight' % t])
+    ct = conv_fwd(fin, wt, P['conv_%s.bias' % t], 1, 0, ACT_RELU)
+    at, mt, st = _bn_fwd(ct, P['bn_%s' % t])
+    packed = _tap_pack(at)                                                  # [B*Wt, C*Ht]
+    y = ops.gemm(packed, P['fc_%s.weight' % t], transb=True, bias=P['fc_%s.bias' % t])
+    return y.view(f.shape[0], at.shape[2], 32), (f.shape, fin, ct, mt, st, at.shape, packed)
+
+
+def tap_bwd(dy, saved, P, t, r, sink):
+    """dy [B, Wt, 32] -> gradient w.r.t. the trunk feature the tap reads (NHWC)."""
+    fshape, fin, ct, mt, st, ashape, packed = saved
+    dy = dy.view(fshape[0] * ashape[2], 32)
+    sink.gw('fc_%s.weight' % t, dy, packed)
+    sink.gb('fc_%s.bias' % t, dy)
+    dpacked = ops.gemm(dy, P['fc_%s.weight' % t])
+    dat = _tap_pack(dpacked, inverse=True, shape=ashape)
+    dct = sink.gbn('bn_%s' % t, _rows(dat), _rows(ct), mt, st, relu_mask=True).view(ct.shape)     # BN' and ReLU' in one pass
+    wt = _ohwi(P['conv_%s.weight' % t])
+    sink.gconv('conv_%s.weight' % t, fin, dct, wt, 1, 0)
+    sink.gb('conv_%s.bias' % t, _rows(dct))
+    dfin = conv_dgrad(dct, wt, fin.shape, 1, 0)
+    return _pixel_shuffle(dfin, r, inverse=True, shape=fshape) if r > 1 else dfin
+
+
+# ---- speaker-conditioned softmax blending (ResNetSE34V2.py:196-216) ----------------------------------------------------------
+
+def blend_fwd(vid, low, mid, high, P, L):
+    B, T, _ = low.shape
+    vid = vid.contiguous()
+    ze = empty(B, 16, like=low)
+    check(lib.ha2g_embedding_fwd_f32(vid.data_ptr(), P['speaker_embedding.0.weight'].data_ptr(), ze.data_ptr(), B, 16, _stream()))
+    z = ops.gemm(ze, P['speaker_embedding.1.weight'], transb=True, bias=P['speaker_embedding.1.bias'])
+    e0 = ops.eltwise(ops.OP_ELU, z)
+    f1 = ops.gemm(e0, P['fc1.weight'], transb=True, bias=P['fc1.bias'])
+    e1 = ops.eltwise(ops.OP_ELU, f1)
+    logits = ops.gemm(e1, P['fc2.weight'], transb=True, bias=P['fc2.bias'])    # [B, 3*L] == (B,3,L)
+    wsm = empty(B, 3, L, like=low)
+    blend = empty(L, B, T, 32, like=low)
+    check(lib.ha2g_blend_fwd_f32(logits.data_ptr(), low.data_ptr(), mid.data_ptr(), high.data_ptr(), wsm.data_ptr(), blend.data_ptr(),
+                                 B, L, T * 32, _stream()))
+    return wsm, blend, (vid, ze, e0, e1, wsm)
+
+
+def blend_bwd(dw_ext, dblend, df, saved, feats, P, L, sink):
+    """dblend: tuple of L gradients (or None) of the blended features, dw_ext: gradient of the softmax weights (or None);
+    df = [dlow, dmid, dhigh] buffers the blend's contribution is ADDED to."""
+    vid, ze, e0, e1, wsm = saved
+    low, mid, high = feats
+    B, T, _ = low.shape
+    dev = low.device
+    db = torch.stack([d if d is not None else torch.zeros_like(low) for d in dblend]).contiguous()
+    dlogits = empty(B, 3 * L, like=low)
+    dwe = dw_ext.contiguous() if dw_ext is not None else None
+    check(lib.ha2g_blend_bwd_f32(db.data_ptr(), _p(dwe), wsm.data_ptr(), low.data_ptr(), mid.data_ptr(), high.data_ptr(),
+                                 df[0].data_ptr(), df[1].data_ptr(), df[2].data_ptr(), dlogits.data_ptr(), B, L, T * 32, _stream()))
+    # speaker MLP backward
+    sink.gw('fc2.weight', dlogits, e1)
+    sink.gb('fc2.bias', dlogits)
+    de1 = ops.gemm(dlogits, P['fc2.weight'])
+    df1 = ops.eltwise(ops.OP_ELU_BWD, de1, e1)
+    sink.gw('fc1.weight', df1, e0)
+    sink.gb('fc1.bias', df1)
+    de0 = ops.gemm(df1, P['fc1.weight'])
+    dz = ops.eltwise(ops.OP_ELU_BWD, de0, e0)
+    sink.gw('speaker_embedding.1.weight', dz, ze)
+    sink.gb('speaker_embedding.1.bias', dz)
+    dze = ops.gemm(dz, P['speaker_embedding.1.weight'])
+    demb = torch.zeros_like(P['speaker_embedding.0.weight'])
+    check(lib.ha2g_embedding_bwd_f32(vid.data_ptr(), dze.data_ptr(), demb.data_ptr(), B, 16, -1, workspace(dev).data_ptr(), _stream()))
+    sink.G['speaker_embedding.0.weight'] = demb
+
+
 class WavEncoderFunction(torch.autograd.Function):
     """apply(spec [B,128,W], vid [B], pose_level, names, bufs, *tensors) -> (weight, low, mid, high, blend_0..L-1).
     `tensors` follow param_names(): a BatchNorm entry contributes 2 tensors (gamma, beta); its buffers
@@ -177,64 +355,21 @@ class WavEncoderFunction(torch.autograd.Function):
         x, m, s = _bn_fwd(c0, P['bn1'])
         S['stem'] = (spec, c0, m, s)
         feats = []
-        cin = 32
         for li, nblk in enumerate(LAYERS):
             for j in range(nblk):
                 b = 'layer%d.%d.' % (li + 1, j)
-                first = j == 0 and li > 0
-                stride = 2 if first else 1
-                wa, wb = _ohwi(P[b + 'conv1.weight']), _ohwi(P[b + 'conv2.weight'])
-                c1 = conv_fwd(x, wa, None, stride, 1, ACT_RELU)                     # relu(conv1)
-                a1, m1, s1 = _bn_fwd(c1, P[b + 'bn1'])
-                c2 = conv_fwd(a1, wb, None, 1, 1, ACT_NONE)
-                b2, m2, s2, pooled = _bn_fwd(c2, P[b + 'bn2'], pool=True)         # bn2 + SE squeeze in one pass
-                N, OH, OW, C = b2.shape
-                h1 = ops.gemm(pooled, P[b + 'se.fc.0.weight'], transb=True, bias=P[b + 'se.fc.0.bias'], act=ACT_RELU)
-                su = ops.gemm(h1, P[b + 'se.fc.2.weight'], transb=True, bias=P[b + 'se.fc.2.bias'])      # gate pre-activation
-                sc = ops.eltwise(ops.OP_SIGMOID, su)
-                if first:
-                    wd = _ohwi(P[b + 'downsample.0.weight'])
-                    cd = conv_fwd(x, wd, None, 2, 0, ACT_NONE)
-                    res, md, sd = _bn_fwd(cd, P[b + 'downsample.1'])
-                else:
-                    res, cd, md, sd = x, None, None, None
-                out = torch.empty_like(b2)
-                check(lib.ha2g_se_scale_add_relu_f32(b2.data_ptr(), sc.data_ptr(), res.data_ptr(), out.data_ptr(), N, OH * OW, C, _stream()))
-                S[b] = (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride)
-                x = out
+                x, S[b] = block_fwd(x, P, b, j == 0 and li > 0)
             feats.append(x)
-            cin = FILTERS[li]
         # ---- taps ----
         tap_out = []
         for (t, C, k, r), f in zip(TAPS, feats[1:]):
-            fin = _pixel_shuffle(f, r) if r > 1 else f
-            wt = _ohwi(P['conv_%s.weight' % t])
-            ct = conv_fwd(fin, wt, P['conv_%s.bias' % t], 1, 0, ACT_RELU)
-            at, mt, st = _bn_fwd(ct, P['bn_%s' % t])
-            packed = _tap_pack(at)                                                  # [B*Wt, C*Ht]
-            y = ops.gemm(packed, P['fc_%s.weight' % t], transb=True, bias=P['fc_%s.bias' % t])
-            Wt = at.shape[2]
-            S['tap_' + t] = (f.shape, fin, ct, mt, st, at.shape, packed)
-            tap_out.append(y.view(B, Wt, 32))
+            y, S['tap_' + t] = tap_fwd(f, P, t, r)
+            tap_out.append(y)
         low, mid, high = tap_out
         if _NBT_PENDING:
             torch._foreach_add_(_NBT_PENDING, 1)
             _NBT_PENDING.clear()
-        # ---- speaker-conditioned softmax blending ----
-        vid = vid.contiguous()
-        ze = empty(B, 16, like=spec)
-        check(lib.ha2g_embedding_fwd_f32(vid.data_ptr(), P['speaker_embedding.0.weight'].data_ptr(), ze.data_ptr(), B, 16, _stream()))
-        z = ops.gemm(ze, P['speaker_embedding.1.weight'], transb=True, bias=P['speaker_embedding.1.bias'])
-        e0 = ops.eltwise(ops.OP_ELU, z)
-        f1 = ops.gemm(e0, P['fc1.weight'], transb=True, bias=P['fc1.bias'])
-        e1 = ops.eltwise(ops.OP_ELU, f1)
-        logits = ops.gemm(e1, P['fc2.weight'], transb=True, bias=P['fc2.bias'])    # [B, 3*L] == (B,3,L)
-        T = low.shape[1]
-        wsm = empty(B, 3, L, like=spec)
-        blend = empty(L, B, T, 32, like=spec)
-        check(lib.ha2g_blend_fwd_f32(logits.data_ptr(), low.data_ptr(), mid.data_ptr(), high.data_ptr(), wsm.data_ptr(), blend.data_ptr(),
-                                     B, L, T * 32, _stream()))
-        S['spk'] = (vid, ze, e0, e1, wsm)
+        wsm, blend, S['spk'] = blend_fwd(vid, low, mid, high, P, L)
         S['feats'] = (low, mid, high)
         ctx.S, ctx.P, ctx.L, ctx.names, ctx.flat_index, ctx.n_tensors = S, P, L, names, flat_index, len(tensors)
         return (wsm, low, mid, high) + tuple(blend[i] for i in range(L))
@@ -242,84 +377,21 @@ class WavEncoderFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dw_ext, dlow, dmid, dhigh, *dblend):
         S, P, L = ctx.S, ctx.P, ctx.L
-        G = {}                                            # name -> grad (BN: (dgamma, dbeta)); None = accumulated in place
-
-        def tgt(t):                                       # a parameter's installed .grad buffer, if kernels may add into it
-            g = ops._grad_target(t)
-            return g if (g is not None and (g.is_contiguous() or g.dim() == 4)) else None
-
-        def gw(name, a, b_):                              # dW (+)= a^T b_
-            t = tgt(P[name])
-            if t is not None and t.is_contiguous():
-                ops.gemm(a, b_, transa=True, out=t, beta=1.0)
-            else:
-                G[name] = ops.gemm(a, b_, transa=True)
-
-        def gb(name, a):                                  # db (+)= column sums of a
-            t = tgt(P[name])
-            if t is not None:
-                ops.colsum(a, out=t, beta=1.0)
-            else:
-                G[name] = ops.colsum(a)
-
-        def gconv(name, xin, dyc, w_ohwi, stride, pad):
-            r = conv_wgrad(xin, dyc, w_ohwi, stride, pad, into=tgt(P[name]))
-            if r is not None:
-                G[name] = r
-
-        def gbn(name, dy2, x2, mean, invstd, relu_mask=False):
-            bn = P[name]
-            tg_, tb_ = tgt(bn.gamma), tgt(bn.beta)
-            acc = (tg_, tb_) if (tg_ is not None and tb_ is not None) else None
-            dx_, dg_, db_ = ops.bn_bwd(dy2, x2, mean, invstd, bn.gamma, relu_mask=relu_mask, acc=acc)
-            if acc is None:
-                G[name] = (dg_, db_)
-            return dx_
+        sink = GradSink(P)
+        G = sink.G
         low, mid, high = S['feats']
-        B, T, _ = low.shape
         dev = low.device
 
         def z_or(t, like):
             return t.contiguous().clone() if t is not None else torch.zeros_like(like)
 
         df = [z_or(dlow, low), z_or(dmid, mid), z_or(dhigh, high)]
-        vid, ze, e0, e1, wsm = S['spk']
         if any(d is not None for d in dblend) or dw_ext is not None:
-            db = torch.stack([d if d is not None else torch.zeros_like(low) for d in dblend]).contiguous()
-            dlogits = empty(B, 3 * L, like=low)
-            dwe = dw_ext.contiguous() if dw_ext is not None else None
-            check(lib.ha2g_blend_bwd_f32(db.data_ptr(), _p(dwe), wsm.data_ptr(), low.data_ptr(), mid.data_ptr(), high.data_ptr(),
-                                         df[0].data_ptr(), df[1].data_ptr(), df[2].data_ptr(), dlogits.data_ptr(), B, L, T * 32, _stream()))
-            # speaker MLP backward
-            gw('fc2.weight', dlogits, e1)
-            gb('fc2.bias', dlogits)
-            de1 = ops.gemm(dlogits, P['fc2.weight'])
-            df1 = ops.eltwise(ops.OP_ELU_BWD, de1, e1)
-            gw('fc1.weight', df1, e0)
-            gb('fc1.bias', df1)
-            de0 = ops.gemm(df1, P['fc1.weight'])
-            dz = ops.eltwise(ops.OP_ELU_BWD, de0, e0)
-            gw('speaker_embedding.1.weight', dz, ze)
-            gb('speaker_embedding.1.bias', dz)
-            dze = ops.gemm(dz, P['speaker_embedding.1.weight'])
-            demb = torch.zeros_like(P['speaker_embedding.0.weight'])
-            check(lib.ha2g_embedding_bwd_f32(vid.data_ptr(), dze.data_ptr(), demb.data_ptr(), B, 16, -1, workspace(dev).data_ptr(), _stream()))
-            G['speaker_embedding.0.weight'] = demb
+            blend_bwd(dw_ext, dblend, df, S['spk'], S['feats'], P, L, sink)
         # ---- taps backward -> gradient w.r.t. the three trunk features ----
         dfeat = [None, None, None, None]
         for ti, (t, C, k, r) in enumerate(TAPS):
-            fshape, fin, ct, mt, st, ashape, packed = S['tap_' + t]
-            dy = df[ti].view(B * ashape[2], 32)
-            gw('fc_%s.weight' % t, dy, packed)
-            gb('fc_%s.bias' % t, dy)
-            dpacked = ops.gemm(dy, P['fc_%s.weight' % t])
-            dat = _tap_pack(dpacked, inverse=True, shape=ashape)
-            dct = gbn('bn_%s' % t, _rows(dat), _rows(ct), mt, st, relu_mask=True).view(ct.shape)     # BN' and ReLU' in one pass
-            wt = _ohwi(P['conv_%s.weight' % t])
-            gconv('conv_%s.weight' % t, fin, dct, wt, 1, 0)
-            gb('conv_%s.bias' % t, _rows(dct))
-            dfin = conv_dgrad(dct, wt, fin.shape, 1, 0)
-            dfeat[ti + 1] = _pixel_shuffle(dfin, r, inverse=True, shape=fshape) if r > 1 else dfin
+            dfeat[ti + 1] = tap_bwd(df[ti], S['tap_' + t], P, t, r, sink)
         # ---- trunk backward ----
         dx = None
         for li in range(len(LAYERS) - 1, -1, -1):
@@ -327,44 +399,10 @@ class WavEncoderFunction(torch.autograd.Function):
                 dx = dfeat[li] if dx is None else ops.eltwise(ops.OP_ADD, dx, dfeat[li])
             for j in range(LAYERS[li] - 1, -1, -1):
                 b = 'layer%d.%d.' % (li + 1, j)
-                (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride) = S[b]
-                N, OH, OW, C = b2.shape
-                HW = OH * OW
-                dout = dx.contiguous()
-                ds = empty(N, C, like=b2)
-                check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, _stream()))
-                dsc = ops.eltwise(ops.OP_SIGMOID_BWD_PRE, ds, su)
-                gw(b + 'se.fc.2.weight', dsc, h1)
-                gb(b + 'se.fc.2.bias', dsc)
-                dh1 = ops.eltwise(ops.OP_RELU_BWD, ops.gemm(dsc, P[b + 'se.fc.2.weight']), h1)
-                gw(b + 'se.fc.0.weight', dh1, pooled)
-                gb(b + 'se.fc.0.bias', dh1)
-                dpool = ops.gemm(dh1, P[b + 'se.fc.0.weight'], alpha=1.0 / HW)
-                dres, db2 = torch.empty_like(b2), torch.empty_like(b2)
-                check(lib.ha2g_se_bwd_apply_f32(dout.data_ptr(), out.data_ptr(), sc.data_ptr(), dpool.data_ptr(), dres.data_ptr(),
-                                                db2.data_ptr(), N, HW, C, _stream()))
-                dc2 = gbn(b + 'bn2', _rows(db2), _rows(c2), m2, s2).view(c2.shape)
-                wb = _ohwi(P[b + 'conv2.weight'])
-                gconv(b + 'conv2.weight', a1, dc2, wb, 1, 1)
-                da1 = conv_dgrad(dc2, wb, a1.shape, 1, 1)
-                dc1 = gbn(b + 'bn1', _rows(da1), _rows(c1), m1, s1, relu_mask=True).view(c1.shape)
-                wa = _ohwi(P[b + 'conv1.weight'])
-                gconv(b + 'conv1.weight', x, dc1, wa, stride, 1)
-                if cd is None:
-                    dx = conv_dgrad(dc1, wa, x.shape, stride, 1, out=dres, beta=1.0)      # identity shortcut: accumulate onto d(residual)
-                    continue
-                dxin = conv_dgrad(dc1, wa, x.shape, stride, 1)
-                if cd is not None:
-                    dcd = gbn(b + 'downsample.1', _rows(dres), _rows(cd), md, sd).view(cd.shape)
-                    wd = _ohwi(P[b + 'downsample.0.weight'])
-                    gconv(b + 'downsample.0.weight', x, dcd, wd, 2, 0)
-                    conv_dgrad(dcd, wd, x.shape, 2, 0, out=dxin, beta=1.0)
-                    dx = dxin
-                else:
-                    dx = ops.eltwise(ops.OP_ADD, dxin, dres)
+                dx = block_bwd(dx, S[b], P, b, sink)
         # ---- stem backward ----
         spec, c0, m0, s0 = S['stem']
-        dc0 = gbn('bn1', _rows(dx), _rows(c0), m0, s0, relu_mask=True)
+        dc0 = sink.gbn('bn1', _rows(dx), _rows(c0), m0, s0, relu_mask=True)
         dw1, dbias1 = torch.empty_like(P['conv1.weight'].contiguous()), torch.empty_like(P['conv1.bias'])
         Bn, H0, W0 = spec.shape
         check(lib.ha2g_stem_conv_wgrad_f32(spec.data_ptr(), dc0.data_ptr(), dw1.data_ptr(), dbias1.data_ptr(), Bn, H0, W0, 0.0,

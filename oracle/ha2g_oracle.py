@@ -101,7 +101,7 @@ def text_encoder_tcn(tokens, sd, p, n_layers, drop=None):
     return F.linear(x.transpose(1, 2), sd[p + 'decoder.weight'], sd[p + 'decoder.bias'])
 
 
-def _se_block(x, sd, p, stride, has_down, update_bn):
+def se_block(x, sd, p, stride, has_down, update_bn=True):
     """model/ResNetBlocks.py:21-37: conv -> ReLU -> BN -> conv -> BN -> SE -> (+residual) -> ReLU."""
     out = F.conv2d(x, sd[p + 'conv1.weight'], None, stride=stride, padding=1)
     out = batch_norm_train(torch.relu(out), sd, p + 'bn1.', update=update_bn)
@@ -128,27 +128,38 @@ def wav_encoder(spec, vid, sd, p, pose_level, update_bn=True):
     for li, nblk in enumerate((3, 4, 6, 3)):
         for j in range(nblk):
             first = j == 0 and li > 0
-            x = _se_block(x, sd, '%slayer%d.%d.' % (q, li + 1, j), 2 if first else 1, first, update_bn)
+            x = se_block(x, sd, '%slayer%d.%d.' % (q, li + 1, j), 2 if first else 1, first, update_bn)
         feats.append(x)
 
-    def tap(f, name, shuffle):
-        if shuffle > 1:
-            f = F.pixel_shuffle(f, shuffle)
-        f = F.conv2d(f, sd[q + 'conv_%s.weight' % name], sd[q + 'conv_%s.bias' % name])
-        f = batch_norm_train(torch.relu(f), sd, q + 'bn_%s.' % name, update=update_bn)
-        f = f.reshape(B, -1, f.shape[-1]).transpose(1, 2)            # (B, W, C*H), K index = c*H + h
-        return F.linear(f, sd[q + 'fc_%s.weight' % name], sd[q + 'fc_%s.bias' % name])
+    low = wav_tap(feats[1], sd, q, 'low', 1, update_bn)
+    mid = wav_tap(feats[2], sd, q, 'mid', 2, update_bn)
+    high = wav_tap(feats[3], sd, q, 'high', 4, update_bn)
+    w, blend = wav_blend(vid, low, mid, high, sd, q, pose_level)
+    return w, low, mid, high, blend
 
-    low = tap(feats[1], 'low', 1)
-    mid = tap(feats[2], 'mid', 2)
-    high = tap(feats[3], 'high', 4)
+
+def wav_tap(f, sd, q, name, shuffle, update_bn=True):
+    """One tap of ResNetSE.forward (model/ResNetSE34V2.py:157-192): [PixelShuffle] -> conv -> ReLU -> BN ->
+    (B, C*H, W) -> transpose -> Linear; the FC's K index is c*H + h, its row index the time column w."""
+    B = f.shape[0]
+    if shuffle > 1:
+        f = F.pixel_shuffle(f, shuffle)
+    f = F.conv2d(f, sd[q + 'conv_%s.weight' % name], sd[q + 'conv_%s.bias' % name])
+    f = batch_norm_train(torch.relu(f), sd, q + 'bn_%s.' % name, update=update_bn)
+    f = f.reshape(B, -1, f.shape[-1]).transpose(1, 2)            # (B, W, C*H)
+    return F.linear(f, sd[q + 'fc_%s.weight' % name], sd[q + 'fc_%s.bias' % name])
+
+
+def wav_blend(vid, low, mid, high, sd, q, pose_level):
+    """Speaker-conditioned softmax blending of the three taps (model/ResNetSE34V2.py:194-214)."""
+    B = low.shape[0]
     z = F.embedding(vid, sd[q + 'speaker_embedding.0.weight'])
     z = F.linear(z, sd[q + 'speaker_embedding.1.weight'], sd[q + 'speaker_embedding.1.bias'])
     h = F.elu(F.linear(F.elu(z), sd[q + 'fc1.weight'], sd[q + 'fc1.bias']))
     w = F.linear(h, sd[q + 'fc2.weight'], sd[q + 'fc2.bias']).reshape(B, 3, pose_level).softmax(1)
     blend = [low * w[:, 0, i, None, None] + mid * w[:, 1, i, None, None] + high * w[:, 2, i, None, None]
              for i in range(pose_level)]
-    return w, low, mid, high, blend
+    return w, blend
 
 
 def pose_generator(pre_seq, tokens, audio_feat, vid, sd, p, n_layers, H, eps, drop=None):

@@ -79,3 +79,52 @@ def test_single_process_is_inactive():
     from ha2g_amd import ddp
     assert not ddp.active()
     assert ddp.rank_seed(10, 3) == 13
+
+
+def _flat_worker(rank, world, port, out):
+    """Real FusedAdam flat-buffer layout on CPU tensors (only .step() needs the GPU): gradients land in the flat views through
+    autograd, ddp.average_module_grads_ / FusedAdam.allreduce_grads average them with ONE collective per optimizer."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ha2g_amd import ddp
+    from ha2g_amd.optim import FusedAdam
+    torch.manual_seed(3)                                          # identical replicas
+    net_a = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    net_b = torch.nn.Conv2d(2, 3, 3).to(memory_format=torch.channels_last)
+    frozen = torch.nn.Parameter(torch.full((4,), float(rank)), requires_grad=False)
+    opts = [FusedAdam(net_a.parameters()), FusedAdam(list(net_b.parameters()))]
+    assert all(p.grad.data_ptr() >= o.flat_g.data_ptr() for o in opts for p in o.param_groups[0]['params'])
+    g = torch.Generator().manual_seed(100 + rank)                 # per-rank shard
+    x, img = torch.randn(6, 7, generator=g), torch.randn(2, 2, 5, 5, generator=g)
+    for o in opts:
+        o.zero_grad()
+    (net_a(x).pow(2).mean() + net_b(img).pow(2).mean()).backward()
+    local = [o.flat_g.clone() for o in opts]
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **k: (calls.append(t.numel()), orig(t, *a, **k))[1]
+    ddp.average_module_grads_(opts[:1])
+    w = opts[1].allreduce_grads(async_op=True)
+    w.wait()
+    dist.all_reduce = orig
+    assert calls == [opts[0].total, opts[1].total]                # one collective per module, on the whole flat buffer
+    # the parameter's .grad views see the averaged values (they alias the flat buffer)
+    assert torch.equal(net_a[0].weight.grad.reshape(-1), opts[0].flat_g[:35])
+    ddp.broadcast_([frozen.data], 0)
+    gathered = [[torch.empty_like(l) for _ in range(world)] for l in local]
+    for l, gl in zip(local, gathered):
+        dist.all_gather(gl, l)
+    if rank == 0:
+        torch.save({'avg': [o.flat_g for o in opts], 'locals': gathered, 'frozen': frozen.data}, out)
+    else:
+        assert float(frozen.sum()) == 0.0                          # adopted rank 0's frozen parameter
+    dist.destroy_process_group()
+
+
+def test_flat_buffer_average_two_ranks(tmp_path):
+    out = str(tmp_path / 'flat.pt')
+    mp.spawn(_flat_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    for avg, (l0, l1) in zip(res['avg'], res['locals']):
+        assert not torch.equal(l0, l1)
+        assert torch.allclose(avg, (l0 + l1) / 2, rtol=1e-6, atol=1e-9)

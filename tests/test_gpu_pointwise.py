@@ -1,0 +1,233 @@
+"""Direct float64 checks of the HIP kernels that the whole-module fixtures only reach indirectly: the SE tail
+(forward, squeeze gradient, apply gradient), PixelShuffle (both directions), the tap flatten, the speaker-softmax blend,
+the embedding gradient, weight_norm, Adam, and the Philox dropout (keep rate, scaling, mask placement)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def rnd(shape, seed, scale=1.0):
+    r = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((scale * r.standard_normal(shape)).astype(np.float32))
+
+
+def relerr(got, ref):
+    ref = ref.double()
+    return float((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize('shape', [(3, 35, 32), (2, 576, 64), (5, 40, 128), (1, 144, 256), (4, 8960, 32)])
+def test_se_tail_fwd_bwd(shape):
+    """out = relu(x * s[n,c] + res) (ResNetBlocks.py:33-36,91-95); ds = sum_hw dout*(out>0)*x; dres, dx (with the
+    squeeze's gradient dpool folded in)."""
+    from ha2g_amd._lib import check, lib
+    from ha2g_amd.ops import _stream
+    N, HW, C = shape
+    x, res, dout = rnd((N, HW, C), 1), rnd((N, HW, C), 2), rnd((N, HW, C), 3)
+    s = torch.sigmoid(rnd((N, C), 4))
+    dpool = rnd((N, C), 5, 0.1)
+    xd, rd, sd_, dd = x.double().requires_grad_(True), res.double().requires_grad_(True), s.double().requires_grad_(True), dout.double()
+    out64 = torch.relu(xd * sd_[:, None, :] + rd)
+    gx, gr, gs = torch.autograd.grad((out64 * dd).sum(), [xd, rd, sd_])
+    gx = gx + dpool.double()[:, None, :]
+    xg, rg, sg, dg, pg = (t.to(DEV).contiguous() for t in (x, res, s, dout, dpool))
+    out, ds = torch.empty_like(xg), torch.empty(N, C, device=DEV)
+    dres, dx = torch.empty_like(xg), torch.empty_like(xg)
+    check(lib.ha2g_se_scale_add_relu_f32(xg.data_ptr(), sg.data_ptr(), rg.data_ptr(), out.data_ptr(), N, HW, C, _stream()))
+    check(lib.ha2g_se_bwd_scale_f32(dg.data_ptr(), out.data_ptr(), xg.data_ptr(), ds.data_ptr(), N, HW, C, _stream()))
+    check(lib.ha2g_se_bwd_apply_f32(dg.data_ptr(), out.data_ptr(), sg.data_ptr(), pg.data_ptr(), dres.data_ptr(), dx.data_ptr(), N, HW, C, _stream()))
+    assert relerr(out, out64.detach()) < 2e-7
+    assert relerr(ds, gs) < 2e-6
+    assert relerr(dres, gr) < 2e-7
+    assert relerr(dx, gx) < 2e-7
+
+
+@pytest.mark.parametrize('case', [(2, 32, 18, 128, 2), (3, 16, 9, 256, 4), (1, 5, 3, 64, 2)])
+def test_pixel_shuffle_both_directions(case):
+    from ha2g_amd import wav_engine as we
+    N, H, W, C, r = case
+    x = rnd((N, C, H, W), 7)
+    ref = F.pixel_shuffle(x, r)
+    got = we._pixel_shuffle(x.permute(0, 2, 3, 1).contiguous().to(DEV), r)
+    assert torch.equal(got.permute(0, 3, 1, 2).cpu(), ref)
+    dy = rnd(tuple(ref.shape), 8)
+    back = we._pixel_shuffle(dy.permute(0, 2, 3, 1).contiguous().to(DEV), r, inverse=True, shape=(N, H, W, C))
+    assert torch.equal(back.permute(0, 3, 1, 2).cpu(), F.pixel_unshuffle(dy, r))
+
+
+@pytest.mark.parametrize('case', [(2, 63, 34, 64), (3, 62, 6, 32), (1, 62, 34, 16), (2, 5, 3, 8)])
+def test_tap_flatten_both_directions(case):
+    """[N,H,W,C] -> rows (n,w), K index c*H+h == reshape(B, C*H, W).transpose(1,2) of the reference (ResNetSE34V2.py:160-162)."""
+    from ha2g_amd import wav_engine as we
+    N, H, W, C = case
+    x = rnd((N, C, H, W), 9)
+    ref = x.reshape(N, C * H, W).transpose(1, 2).reshape(N * W, C * H)
+    got = we._tap_pack(x.permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert torch.equal(got.cpu(), ref)
+    d = rnd((N * W, C * H), 10)
+    back = we._tap_pack(d.to(DEV), inverse=True, shape=(N, H, W, C))
+    assert torch.equal(back.permute(0, 3, 1, 2).cpu(), d.view(N, W, C * H).transpose(1, 2).reshape(N, C, H, W))
+
+
+@pytest.mark.parametrize('L', [3, 6])
+def test_blend_fwd_bwd(L):
+    from ha2g_amd._lib import check, lib
+    from ha2g_amd.ops import _stream
+    B, T = 5, 34
+    logits = rnd((B, 3 * L), 11)
+    f = [rnd((B, T, 32), 12 + i) for i in range(3)]
+    dbl, dw_ext = rnd((L, B, T, 32), 20), rnd((B, 3, L), 21)
+    df0 = [rnd((B, T, 32), 30 + i) for i in range(3)]
+    lg = logits.double().requires_grad_(True)
+    fd = [t.double().requires_grad_(True) for t in f]
+    w64 = lg.view(B, 3, L).softmax(1)
+    bl64 = torch.stack([fd[0] * w64[:, 0, i, None, None] + fd[1] * w64[:, 1, i, None, None] + fd[2] * w64[:, 2, i, None, None] for i in range(L)])
+    g = torch.autograd.grad((bl64 * dbl.double()).sum() + (w64 * dw_ext.double()).sum(), [lg] + fd)
+    lgg = logits.to(DEV)
+    fg = [t.to(DEV) for t in f]
+    w, bl = torch.empty(B, 3, L, device=DEV), torch.empty(L, B, T, 32, device=DEV)
+    check(lib.ha2g_blend_fwd_f32(lgg.data_ptr(), fg[0].data_ptr(), fg[1].data_ptr(), fg[2].data_ptr(), w.data_ptr(), bl.data_ptr(), B, L, T * 32, _stream()))
+    assert relerr(w, w64.detach()) < 5e-7 and relerr(bl, bl64.detach()) < 5e-7
+    df = [t.to(DEV).clone() for t in df0]
+    dlog = torch.empty(B, 3 * L, device=DEV)
+    check(lib.ha2g_blend_bwd_f32(dbl.to(DEV).data_ptr(), dw_ext.to(DEV).data_ptr(), w.data_ptr(), fg[0].data_ptr(), fg[1].data_ptr(), fg[2].data_ptr(),
+                                 df[0].data_ptr(), df[1].data_ptr(), df[2].data_ptr(), dlog.data_ptr(), B, L, T * 32, _stream()))
+    assert relerr(dlog, g[0]) < 5e-6
+    for i in range(3):                                       # the kernel ADDS the blend's share onto the incoming tap gradients
+        assert relerr(df[i], g[1 + i] + df0[i].double()) < 1e-6
+
+
+def test_embedding_bwd_duplicates_and_padding():
+    from ha2g_amd import ops
+    V, C, B, T = 50, 300, 9, 34
+    r = np.random.Generator(np.random.PCG64(3))
+    tok = np.zeros((B, T), np.int64)
+    for b in range(B):
+        pos = r.choice(T, size=7, replace=False)
+        tok[b, pos] = r.integers(1, 6, size=7)                # few distinct ids => many duplicates
+    tok[0, :] = 7                                             # one id 34 times in a row
+    w = rnd((V, C), 4).to(DEV).requires_grad_(True)
+    dy = rnd((B, T, C), 5)
+    out = ops.embedding(torch.from_numpy(tok).to(DEV), w)
+    assert torch.equal(out.detach().cpu(), w.detach().cpu()[torch.from_numpy(tok)])
+    out.backward(dy.to(DEV))
+    ref = torch.zeros(V, C, dtype=torch.float64).index_add_(0, torch.from_numpy(tok).reshape(-1), dy.double().reshape(-1, C))
+    assert relerr(w.grad, ref) < 1e-6
+    assert float(w.grad[8:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('shape', [(300, 300, 2), (16, 27, 3), (5, 3, 1)])
+def test_weight_norm_fwd_bwd(shape):
+    from ha2g_amd import ops
+    v = rnd(shape, 6, 0.01)
+    g = (0.5 + torch.rand(shape[0], 1, 1, generator=torch.Generator().manual_seed(1)))
+    dw = rnd(shape, 7)
+    vd, gd = v.double().requires_grad_(True), g.double().requires_grad_(True)
+    w64 = gd * vd / vd.flatten(1).norm(dim=1).view(-1, 1, 1)
+    gg, gv = torch.autograd.grad((w64 * dw.double()).sum(), [gd, vd])
+    vg, ggpu = v.to(DEV).requires_grad_(True), g.to(DEV).requires_grad_(True)
+    w = ops.weight_norm(ggpu, vg)
+    w.backward(dw.to(DEV))
+    assert relerr(w, w64.detach()) < 5e-7
+    assert relerr(ggpu.grad, gg) < 5e-6
+    assert relerr(vg.grad, gv) < 5e-6
+
+
+def test_adam_matches_torch_adam_fp64():
+    """Five steps of ha2g_adam_f32 (through FusedAdam) against torch.optim.Adam in float64 (train.py:155-170 settings),
+    odd element counts (scalar tail) and a zero-gradient tensor (moments decay, parameter unchanged)."""
+    from ha2g_amd.optim import FusedAdam
+    shapes = [(37, 5), (1,), (300, 300, 2), (7,)]
+    ps = [torch.nn.Parameter(rnd(s, 40 + i).to(DEV)) for i, s in enumerate(shapes)]
+    ref = [torch.nn.Parameter(p.detach().double().cpu()) for p in ps]
+    opt = FusedAdam(ps, lr=5e-4, betas=(0.5, 0.999))
+    ropt = torch.optim.Adam(ref, lr=5e-4, betas=(0.5, 0.999))
+    for step in range(5):
+        opt.zero_grad()
+        for i, (p, q) in enumerate(zip(ps, ref)):
+            g = rnd(tuple(p.shape), 100 * step + i) if i != 3 else torch.zeros(p.shape)
+            p.grad.copy_(g.to(DEV))
+            q.grad = g.double()
+        opt.step()
+        ropt.step()
+        for p, q in zip(ps, ref):
+            # one update is lr-sized (5e-4) on O(1) parameters: compare the accumulated displacement, not the parameter
+            assert float((p.detach().double().cpu() - q.detach()).abs().max()) < 2e-6 * 5e-4 * (step + 1) + 1e-7 * float(q.abs().max())
+    assert torch.equal(ps[3].detach().cpu(), rnd((7,), 43))
+
+
+def test_dropout_kernel_statistics_and_masks():
+    """Philox dropout: keep rate within 4 sigma of 1-p, kept values scaled by exactly 1/(1-p), backward uses the forward's
+    mask, masks differ between call sites, steps and seeds (= ranks), and are reproducible for equal (seed, step, site)."""
+    from ha2g_amd import ops
+    n = 1 << 20
+    x = (rnd((n,), 1).abs() + 0.5).to(DEV)
+    for p in (0.1, 0.3):
+        ops.rng.seed(torch.device(DEV), 77)
+        ops.rng.begin_step()
+        xr = x.clone().requires_grad_(True)
+        y = ops.dropout(xr, p, True)
+        keep = y != 0
+        rate = float(keep.float().mean())
+        assert abs(rate - (1 - p)) < 4 * np.sqrt(p * (1 - p) / n), (p, rate)
+        assert torch.equal(y[keep], (x * np.float32(1.0 / (1.0 - np.float32(p))))[keep])            # exact 1/(1-p) scaling
+        y.backward(torch.ones_like(y))
+        assert torch.equal(xr.grad != 0, keep)                                                  # same mask in backward
+        assert torch.allclose(xr.grad[keep], torch.full_like(xr.grad[keep], 1.0 / (1.0 - p)))
+        y2 = ops.dropout(x, p, True)                                                            # next call site, same step
+        assert float(((y2 != 0) == keep).float().mean()) < 1 - 2 * p * (1 - p) + 0.01
+        ops.rng.end_step()
+        ops.rng.begin_step()
+        y3 = ops.dropout(x, p, True)                                                            # same site, next step
+        assert float(((y3 != 0) == keep).float().mean()) < 1 - 2 * p * (1 - p) + 0.01
+        ops.rng.seed(torch.device(DEV), 78)                                                     # another rank's seed
+        y4 = ops.dropout(x, p, True)
+        assert float(((y4 != 0) == keep).float().mean()) < 1 - 2 * p * (1 - p) + 0.01
+        ops.rng.seed(torch.device(DEV), 77)                                                     # replay: identical
+        assert torch.equal(ops.dropout(x, p, True), y)
+    assert ops.dropout(x, 0.3, False) is x and ops.dropout(x, 0.0, True) is x
+    ops.rng.seed(torch.device(DEV), 0x5EED)
+
+
+def test_dropout_placement_matches_reference_sites():
+    """Where masks are drawn (reference: embedding dropout 0.1 hierarchy_net.py:40,50; TCN Dropout(0.3) after each of the
+    two ReLUs of every TemporalBlock tcn.py:23,29; nn.GRU inter-layer dropout on the outputs of layers 0..L-2 only
+    hierarchy_net.py:88,213) and that eval() draws none.  Counted through the Philox call-site counter."""
+    from ha2g_amd import hierarchy_net as hn, ops
+    from ha2g_amd.config import hierarchy_args
+    from ha2g_amd.testing import SpeakerVocab
+    args = hierarchy_args(hidden_size=32, n_layers=2)
+    dev = torch.device(DEV)
+    txt = hn.TextEncoderTCN(args, 40, 300, None, dropout=args.dropout_prob).to(dev)
+    tok = torch.randint(0, 40, (3, 34), device=dev)
+    ops.rng.seed(dev, 5)
+    ops.rng.begin_step()
+    txt(tok)
+    assert ops.rng.call == 1 + 2 * args.n_layers                 # embedding + two per TemporalBlock
+    assert txt.drop.p == 0.1 and all(b.p == 0.3 for b in txt.tcn.network)
+    ops.rng.begin_step()
+    txt.eval()
+    txt(tok)
+    assert ops.rng.call == 0
+    gru = hn.BiGRU(8, 64, 4, dropout=0.3).to(dev)
+    ops.rng.begin_step()
+    x = torch.randn(3, 28, 8, device=dev)
+    y, _ = gru(x)
+    assert ops.rng.call == 3                                       # layers 0..2, not after the last layer
+    # the last layer's output carries no mask: no exact zeros, and it equals a no-dropout run fed the same masked inputs
+    assert float((y == 0).float().mean()) == 0.0
+    # inter-layer mask really is applied: with p -> 0 masks the result changes
+    gru.dropout = 0.0
+    ops.rng.begin_step()
+    y0, _ = gru(x)
+    assert ops.rng.call == 0 and not torch.equal(y0, y)
+    g1 = hn.Hierarchical_PoseGenerator(args, 27, 40, 300, None, z_obj=SpeakerVocab(6)).to(dev)
+    ops.rng.begin_step()
+    pre = torch.zeros(3, 34, 28, device=dev)
+    g1(pre, tok, torch.randn(3, 34, 32, device=dev), torch.randint(1, 6, (3,), device=dev))
+    assert ops.rng.call == (1 + 2 * args.n_layers) + (args.n_layers - 1)
+    ops.rng.seed(dev, 0x5EED)

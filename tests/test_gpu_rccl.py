@@ -38,6 +38,76 @@ print('RCCL_OK')
 '''
 
 
+CHILD_FORCED = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+torch.cuda.set_device(0)
+dev = torch.device('cuda', 0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+from bench import Vocab
+from ha2g_amd import ddp, ops, procedural as proc, train_hierarchy as th
+from ha2g_amd.config import hierarchy_args
+from ha2g_amd.testing import no_dropout
+from ha2g_amd.train import HierarchyTrainer
+B = 3
+text, spec, target, vid = (torch.from_numpy(x).to(dev) for x in proc.make_batch(B, 27, 50, 7, 5))
+eps_const = torch.from_numpy(proc.tensor_for('in.eps', (3 * B, 16), 11)).to(dev)
+perm = torch.from_numpy(proc.fixed_perm(B, 11)).to(dev)
+th.randperm_source = lambda n, device: perm
+calls = []
+orig_all_reduce = dist.all_reduce
+def counting_all_reduce(t, *a, **k):
+    calls.append((t.numel(), bool(k.get('async_op'))))
+    return orig_all_reduce(t, *a, **k)
+dist.all_reduce = counting_all_reduce
+def run(forced):
+    torch.manual_seed(5)
+    ops.rng.seed(dev, 77)
+    tr = HierarchyTrainer(hierarchy_args(hidden_size=32, n_layers=2), Vocab(50), Vocab(7), 27, dev)
+    for m in tr.modules():
+        no_dropout(m)
+    for g in tr.gens:
+        g.eps_source = lambda shape, device: eps_const[:shape[0]]
+    ddp.FORCE_ACTIVE = forced
+    if forced:
+        tr.broadcast_parameters(0)
+    rets = [tr.train_iter(e, text, spec, target, vid) for e in (0, 11, 11)]
+    ddp.FORCE_ACTIVE = False
+    torch.cuda.synchronize()
+    flat = torch.cat([o.flat_p for o in tr.gen_opts + [tr.audio_opt, tr.text_opt, tr.dis_opt]])
+    return rets, flat.clone()
+r_plain, p_plain = run(False)
+assert not calls, calls
+r_ddp, p_ddp = run(True)
+# the in-step collective branch ran: per step 3 async all-reduces (generators, overlapping the encoders' backward) + audio +
+# text, and one for the discriminator in each GAN-phase step
+assert len(calls) == 3 * 5 + 2, calls
+assert sum(1 for _, a in calls if a) == 9, calls
+assert r_plain == r_ddp, (r_plain, r_ddp)
+assert torch.equal(p_plain, p_ddp)                 # a world of one: averaging is the identity, bit for bit
+dist.destroy_process_group()
+print('RCCL_FORCED_OK')
+'''
+
+
+def _run_child(code):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    return subprocess.run([sys.executable, '-c', code % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=900)
+
+
+def test_in_step_collective_branch_equals_plain_step():
+    """Forces the data-parallel branch of the train step (async RCCL all-reduce of the three generators' flat gradient
+    buffers issued after backward stage 1, stage-2 backward of the encoders, the encoders' all-reduces, wait, Adam; the
+    discriminator's all-reduce inside the D phase) in a world of ONE rank and checks three steps equal the plain path bit
+    for bit (loss dicts and every parameter)."""
+    p = _run_child(CHILD_FORCED)
+    assert p.returncode == 0 and 'RCCL_FORCED_OK' in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+
+
 def test_single_rank_rccl_group():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))

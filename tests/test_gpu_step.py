@@ -156,7 +156,7 @@ def test_whole_step_hipgraph_capture_matches_eager():
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, stream=s):                      # capture on the warm-up stream (its workspace already exists)
             gnames, gpacked = tr_g.train_iter(11, text, spec, target, vid, return_tensors=True)
         replays = []
         for _ in range(2):                                           # the capture itself does not execute: steps 3 and 4 are replays

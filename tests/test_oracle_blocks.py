@@ -1,0 +1,137 @@
+"""Pin the oracle's SEBasicBlock / tap / blend restatements (and the whole encoder at B=16) to the round-2 audio-tower
+fixtures produced by the reference itself (tests/golden/gen_golden.py: blocks.npz, blocksfull.npz, enc16.npz).  CPU only.
+
+blocks.npz is the STRICT set: reduced spatial sizes with the seed searched so that no ReLU input lies within 1.5e-5 of
+zero; float32 rounding cannot flip a ReLU decision, so the reference's own fp32 scatter is ~1e-6 and rtol = 1e-4 is the
+operative bound on every gradient tensor of the block (test_strict_fixture_floors pins that property of the data)."""
+import numpy as np
+import pytest
+import torch
+
+from ha2g_amd import procedural as proc
+from ha2g_amd import schema
+from ha2g_amd.config import BLOCK_B, BLOCK_CASES, BLOCKFULL_B, BLOCKFULL_CASES, ENC_CASE, TAPS_CASE, TAPSFULL_CASE
+from ha2g_amd.testing import DigestChecker, block_io, block_state, taps_inputs, taps_w
+from oracle import ha2g_oracle as O
+
+DTS = [torch.float64, torch.float32]
+
+
+def test_strict_fixture_floors(golden):
+    """Every tensor of the strict fixtures is well conditioned: reference fp32 scatter / scale <= 1e-5."""
+    g = golden('blocks')
+    worst = 0.0
+    for k in g.files:
+        if k.endswith('/sample'):
+            scale = max(np.abs(g[k]).max(), float(g[k[:-7] + '/norm']) / max(1.0, np.sqrt(g[k].size)))
+            fl = max(float(g[k + '@noise']), float(g[k + '@cond']))
+            worst = max(worst, fl / scale)
+            assert fl <= 1e-5 * scale, (k, fl / scale)
+    assert worst > 0
+
+
+def run_block(ck, name, geom, B, seed, dt, fn_block):
+    sd = block_state(name, geom, seed, dt)
+    x, wl = block_io(name, geom, B, seed, dt)
+    x.requires_grad_(True)
+    ps = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not k.endswith(('running_mean', 'running_var'))}
+    y = fn_block(x, sd, '', 2 if geom[4] else 1, geom[4])
+    grads = torch.autograd.grad((y * wl).sum(), [x] + list(ps.values()))
+    q = 'blk/%s/' % name
+    ck.check(y, q + 'out')
+    ck.check(grads[0], q + 'grad_x')
+    for k, gr in zip(ps, grads[1:]):
+        ck.check(gr, q + 'grad/' + k)
+    for k, v in sd.items():
+        if k.endswith(('running_mean', 'running_var')):
+            ck.check(v, q + 'buf/' + k)
+
+
+@pytest.mark.parametrize('dt', DTS)
+@pytest.mark.parametrize('name', list(BLOCK_CASES))
+def test_se_block_strict(golden, name, dt):
+    g = golden('blocks')
+    ck = DigestChecker(g, dt)
+    run_block(ck, name, BLOCK_CASES[name], BLOCK_B, int(g['blk/%s/seed' % name]), dt, O.se_block)
+    assert dt == torch.float64 or max(s for s, _ in ck.shares) < 0.1
+
+
+@pytest.mark.parametrize('dt', DTS)
+@pytest.mark.parametrize('name', ['l1', 'l3d', 'l4'])
+def test_se_block_full_size(golden, name, dt):
+    g = golden('blocksfull')
+    ck = DigestChecker(g, dt, noise_mult=3.0)
+    run_block(ck, name, BLOCKFULL_CASES[name], BLOCKFULL_B, int(g['blk/%s/seed' % name]), dt, O.se_block)
+
+
+def run_taps(ck, case, seed, dt):
+    sch = schema.wav_encoder_schema(case['n_spk'], case['L'], 'audio.')
+    sd = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in schema.procedural_state(sch, seed).items()}
+    q = 'audio.feat_extractor.'
+    feats, vid = taps_inputs(case, seed, dt)
+    for f in feats.values():
+        f.requires_grad_(True)
+    names = [k for k in sd if k[len(q):].startswith(('conv_', 'bn_', 'fc_', 'fc1', 'fc2', 'speaker_embedding')) and sd[k].is_floating_point()
+             and not k.endswith(('running_mean', 'running_var'))]
+    for k in names:
+        sd[k].requires_grad_(True)
+    lo = O.wav_tap(feats['layer2'], sd, q, 'low', 1)
+    mid = O.wav_tap(feats['layer3'], sd, q, 'mid', 2)
+    hi = O.wav_tap(feats['layer4'], sd, q, 'high', 4)
+    w, blend = O.wav_blend(vid, lo, mid, hi, sd, q, case['L'])
+    loss = sum((bl * taps_w('blend%d' % i, bl, seed)).sum() for i, bl in enumerate(blend)) + (lo * taps_w('lo', lo, seed)).sum() \
+        + (mid * taps_w('mid', mid, seed)).sum() + (hi * taps_w('hi', hi, seed)).sum() + (w * taps_w('w', w, seed)).sum()
+    grads = torch.autograd.grad(loss, list(feats.values()) + [sd[k] for k in names])
+    ck.check(w, 'taps/weight'); ck.check(lo, 'taps/low'); ck.check(mid, 'taps/mid'); ck.check(hi, 'taps/high')
+    for i, bl in enumerate(blend):
+        ck.check(bl, 'taps/blend%d' % i)
+    for k, gr in zip(list(feats) + names, grads):
+        ck.check(gr, 'taps/grad_' + k if k in feats else 'taps/grad/' + k[len(q):])
+    for k in sd:
+        if k[len(q):].startswith('bn_') and k.endswith(('running_mean', 'running_var')):
+            ck.check(sd[k], 'taps/buf/' + k[len(q):])
+
+
+@pytest.mark.parametrize('dt', DTS)
+def test_taps_and_blend_strict(golden, dt):
+    g = golden('blocks')
+    ck = DigestChecker(g, dt)
+    run_taps(ck, TAPS_CASE, int(g['taps/seed']), dt)
+    assert dt == torch.float64 or max(s for s, _ in ck.shares) < 0.1
+
+
+@pytest.mark.parametrize('dt', DTS)
+def test_taps_and_blend_full_size(golden, dt):
+    g = golden('blocksfull')
+    run_taps(DigestChecker(g, dt, noise_mult=3.0), TAPSFULL_CASE, int(g['taps/seed']), dt)
+
+
+@pytest.mark.parametrize('dt', DTS)
+def test_whole_encoder_b16(golden, dt):
+    """Whole Hierarchical_WavEncoder at B=16.  The reference's own fp32 gradients scatter at the 1e-3 level here too
+    (~2e8 ReLU inputs: some always sit within rounding of zero, and one flipped decision moves a weight gradient by
+    ~1/sqrt(elements)); batch size does not cure it, which is why the strict per-block fixtures exist."""
+    case = ENC_CASE
+    g = golden('enc16')
+    ck = DigestChecker(g, dt, noise_mult=3.0)
+    sch = schema.wav_encoder_schema(case['n_spk'], 3, 'audio.')
+    sd = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in schema.procedural_state(sch, case['seed']).items()}
+    _, spec, _, vid = proc.make_batch(case['B'], 27, 40, case['n_spk'], case['seed'])
+    names = [k for k in sd if sd[k].is_floating_point() and not k.endswith(('running_mean', 'running_var'))]
+    for k in names:
+        sd[k].requires_grad_(True)
+    w, lo, mid, hi, blend = O.wav_encoder(torch.from_numpy(spec).to(dt), torch.from_numpy(vid), sd, 'audio.', 3)
+    s = case['seed']
+
+    def wp(name, t):
+        return torch.from_numpy(proc.tensor_for('w.' + name, (2,) + tuple(t.shape), s)[0] * t[0].numel() ** 0.5).to(dt)
+    loss = sum((bl * wp('blend%d' % i, bl)).sum() for i, bl in enumerate(blend)) + (hi * wp('hi', hi)).sum() + (lo * wp('lo', lo)).sum()
+    grads = torch.autograd.grad(loss, [sd[k] for k in names])
+    ck.check(w, 'enc/weight'); ck.check(lo, 'enc/low'); ck.check(mid, 'enc/mid'); ck.check(hi, 'enc/high')
+    for i, bl in enumerate(blend):
+        ck.check(bl, 'enc/blend%d' % i)
+    for k, gr in zip(names, grads):
+        ck.check(gr, 'enc/grad/' + k[6:])
+    for k in sd:
+        if k.endswith(('running_mean', 'running_var')):
+            ck.check(sd[k], 'enc/buf/' + k[6:])
