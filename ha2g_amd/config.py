@@ -63,6 +63,8 @@ CASES = {
     'cfg1': dict(B=4, hidden_size=300, n_layers=4, n_words=60, n_spk=8, seed=12),
     # TED-Expressive twin (6 levels, P=126), step only
     'expr_small': dict(B=3, hidden_size=32, n_layers=2, n_words=40, n_spk=6, seed=13, expressive=True),
+    # config 3 of BASELINE.json at full width (H=300 cluster GRU, 4 layers, GRU input widths 105..207), B=4, step only
+    'expr_cfg1': dict(B=4, hidden_size=300, n_layers=4, n_words=60, n_spk=8, seed=15, expressive=True),
 }
 
 

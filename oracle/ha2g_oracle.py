@@ -200,19 +200,25 @@ def conv_discriminator(poses, sd, p, update_bn=True, gru_masks=None):
 # ----------------------------------------------------------------------------------------------
 
 
+def contrastive_ce_rows(a, b, s, e, expressive=False):
+    """Rows s..e-1 of the loss below, already divided by N: sum_i CE(logits[i, :], i) / N (so that row blocks can be
+    back-propagated one at a time at N = 8704, where the whole N x N x 32 graph would not fit in memory)."""
+    an = F.normalize(a, p=2, dim=1)
+    bn = F.normalize(b, p=2, dim=1)
+    d = (an[s:e, None, :] - bn[None, :, :]).norm(p=2, dim=2)
+    logits = 1.0 / d if expressive else torch.clamp(1.0 / (d + 1e-8), min=1e-8)
+    return F.cross_entropy(logits, torch.arange(s, e), reduction='sum') / a.shape[0]
+
+
 def contrastive_ce(a, b, expressive=False, chunk=1024):
     """train_eval/train_hierarchy.py:54-68 (Gesture: +1e-8, clamp) and
     train_hierarchy_expressive.py:107-121 (no eps, no clamp).  dist[i,j] = ||a_i - b_j||, rows = a.
     Computed in row chunks (same arithmetic; avoids the N x N x 32 intermediate of the reference)."""
-    a = F.normalize(a, p=2, dim=1)
-    b = F.normalize(b, p=2, dim=1)
     N = a.shape[0]
     total = a.new_zeros(())
     for s in range(0, N, chunk):
-        d = (a[s:s + chunk, None, :] - b[None, :, :]).norm(p=2, dim=2)
-        logits = 1.0 / d if expressive else torch.clamp(1.0 / (d + 1e-8), min=1e-8)
-        total = total + F.cross_entropy(logits, torch.arange(s, min(s + chunk, N)), reduction='sum')
-    return total / N
+        total = total + contrastive_ce_rows(a, b, s, min(s + chunk, N), expressive)
+    return total
 
 
 def huber(x, y, beta, reduction='mean'):

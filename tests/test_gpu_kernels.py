@@ -404,3 +404,27 @@ def test_plain_bf16_mode_is_bf16_accurate():
     for i, (got, ref) in enumerate(refs):
         e = rms(got, ref)
         assert 1e-4 < e < 6e-3, (i, e)          # bf16-level error: not fp32 (would be < 1e-6), not broken
+
+
+@pytest.mark.parametrize('expr', [False, True])
+@pytest.mark.parametrize('N', [4352, 8704])
+def test_contrastive_full_size_vs_oracle(N, expr):
+    """SoftmaxContrastiveLoss at the headline sizes -- N = B*34 = 4352 (B=128) and 8704 (B=256: the row-blocked branch
+    above 80 MB of pair matrix) -- against the oracle's float64 loss (train_hierarchy.py:54-68 / expressive :107-121),
+    back-propagated one 128-row block at a time on the host."""
+    from ha2g_amd import ops
+    from oracle import ha2g_oracle as O
+    torch.set_num_threads(max(1, min(64, (torch.get_num_threads() or 8))))
+    a, b = rnd((N, 32), 31, 1.0), rnd((N, 32), 32, 1.0)
+    b[: N // 2] = a[: N // 2] + 0.3 * b[: N // 2]                   # correlated pairs: the diagonal logits matter
+    a64, b64 = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    loss64 = 0.0
+    for s in range(0, N, 128):
+        l = O.contrastive_ce_rows(a64, b64, s, min(s + 128, N), expr)
+        l.backward()
+        loss64 += float(l)
+    ag, bg = a.to(_dev()).requires_grad_(True), b.to(_dev()).requires_grad_(True)
+    loss = ops.contrastive(ag, bg, expr)
+    loss.backward()
+    assert abs(float(loss) - loss64) <= 2e-5 * abs(loss64), (float(loss), loss64)
+    assert relerr(ag.grad, a64.grad) < 1e-4 and relerr(bg.grad, b64.grad) < 1e-4, (relerr(ag.grad, a64.grad), relerr(bg.grad, b64.grad))

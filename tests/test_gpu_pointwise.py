@@ -155,8 +155,15 @@ def test_adam_matches_torch_adam_fp64():
         opt.step()
         ropt.step()
         for p, q in zip(ps, ref):
-            # one update is lr-sized (5e-4) on O(1) parameters: compare the accumulated displacement, not the parameter
-            assert float((p.detach().double().cpu() - q.detach()).abs().max()) < 2e-6 * 5e-4 * (step + 1) + 1e-7 * float(q.abs().max())
+            # O(1) parameters move by lr = 5e-4 per step: the fp32 parameter's own rounding (half an ulp per update) dominates
+            assert float((p.detach().double().cpu() - q.detach()).abs().max()) < (1.2e-7 * float(q.abs().max()) + 1e-3 * 5e-4) * (step + 1)
+        off = 0
+        for q in ref:                                             # the moments are the sharper check of the update arithmetic
+            st = ropt.state[q]
+            n = q.numel()
+            assert relerr(opt.flat_m[off:off + n], st['exp_avg'].reshape(-1)) < 2e-6
+            assert relerr(opt.flat_v[off:off + n], st['exp_avg_sq'].reshape(-1)) < 2e-6
+            off += (n + 3) // 4 * 4
     assert torch.equal(ps[3].detach().cpu(), rnd((7,), 43))
 
 

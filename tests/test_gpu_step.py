@@ -43,11 +43,13 @@ def test_train_step(golden, name, fuse):
 
 
 @pytest.mark.parametrize('fuse', [True, False])
-def test_train_step_expressive(golden, fuse):
+@pytest.mark.parametrize('name', ['expr_small', 'expr_cfg1'])
+def test_train_step_expressive(golden, name, fuse):
     """6-level TED-Expressive twin (train_hierarchy_expressive.py:124-483): P=126, off-by-one head scatter, palm normals,
-    eps-free contrastive, 9 modules / 9 optimizers."""
+    eps-free contrastive, 9 modules / 9 optimizers.  expr_cfg1 = full width (H=300 cluster GRU, 4 layers, GRU input
+    widths 105..207) at B=4."""
     from ha2g_amd import schema
-    case, g = CASES['expr_small'], golden('expr_small')
+    case, g = CASES[name], golden(name)
     ck = Checker(g)
     dims = schema.EXPRESSIVE_POSE_DIMS
     args, gens, dis, aud, txt = build_modules(case, DEV, dims)
@@ -171,16 +173,9 @@ def test_whole_step_hipgraph_capture_matches_eager():
     assert ops.gru_cluster_error(dev) == 0
 
 
-def test_full_size_schedule_and_precision_invariants():
-    """BASELINE's full-size configuration (B=128, T=34, 27-d pose, spec (128,70), 20 000 words, 1 371 speakers, H=300, 4
-    layers): no reference fixture exists at this size (the CPU reference needs minutes per step), so the step is checked
-    through size-independent invariants, with the random draws pinned:
-      * the fused 3-chain schedule and the literal three-pass schedule of the reference give the same loss terms and the
-        same gradient for every module;
-      * the default matrix-core mode (split-bf16 backward GEMMs / convolutions) and the exact-fp32 mode give identical
-        losses (the forward is untouched) and gradients that agree to 1e-4 of each module's gradient norm;
-      * running the same step twice from the same state is bitwise reproducible."""
-    from ha2g_amd import ops
+def _full_size_step(expressive, B, fuse, mode, seed=21):
+    """One GAN-phase step of a freshly built full-size trainer with every random draw pinned; returns (loss dict, flat grads)."""
+    from ha2g_amd import ops, schema
     from ha2g_amd._lib import lib
     from ha2g_amd.config import hierarchy_args
     from ha2g_amd.testing import SpeakerVocab, no_dropout
@@ -190,48 +185,61 @@ def test_full_size_schedule_and_precision_invariants():
     class Lang:
         n_words, word_embedding_weights = 20000, None
 
+    P = 126 if expressive else 27
+    text, spec, target, vid = (torch.from_numpy(x).to(DEV) for x in proc.make_batch(B, P, 20000, 1371, 1234))
+    eps_const = torch.from_numpy(proc.tensor_for('in.eps', (3 * B, 16), seed)).to(DEV)
+    perm = torch.from_numpy(proc.fixed_perm(B, seed)).to(DEV)
+    torch.manual_seed(9)
+    ops.rng.seed(dev, 5)
+    tr = HierarchyTrainer(hierarchy_args(expressive=expressive), Lang(), SpeakerVocab(1371), P, dev,
+                          pose_dims=schema.EXPRESSIVE_POSE_DIMS if expressive else schema.GESTURE_POSE_DIMS)
+    for m in tr.modules():
+        no_dropout(m)
+    for g in tr.gens:
+        # the fused pass asks for k*B rows (block p = pass eps_block_order[p]); the literal passes ask for B rows each.
+        # A constant per-pass slice keyed by the logical pass makes both schedules consume the same noise.
+        g._pass = 0
+
+        def src(shape, device, g=g):
+            k = shape[0] // B
+            order = getattr(g, 'eps_block_order', None) or list(range(k))
+            if k == 1:
+                out = eps_const[g._pass * B:(g._pass + 1) * B]
+                g._pass += 1
+                return out
+            return torch.cat([eps_const[o * B:(o + 1) * B] for o in order])
+        g.eps_source = src
+    old = th.FUSE_CHAINS, th.randperm_source
+    th.FUSE_CHAINS, th.randperm_source = fuse, (lambda n, device: perm)
+    lib.ha2g_gemm_set_mode(mode)
+    try:
+        ret = tr.train_iter(11, text, spec, target, vid)
+    finally:
+        th.FUSE_CHAINS, th.randperm_source = old
+        lib.ha2g_gemm_set_mode(6)
+    names = ['g%d' % (i + 1) for i in range(len(tr.gens))] + ['audio', 'text']
+    grads = {n: o.flat_g.clone() for n, o in zip(names, tr.gen_opts + [tr.audio_opt, tr.text_opt])}
+    assert ops.gru_cluster_error(dev) == 0
+    del tr
+    torch.cuda.empty_cache()
+    return ret, grads
+
+
+@pytest.mark.parametrize('expressive', [False, True])
+def test_full_size_schedule_and_precision_invariants(expressive):
+    """BASELINE's full-size configurations (config 2: B=128, T=34, 27-d pose; config 3: the 6-level 126-d expressive twin; spec
+    (128,70), 20 000 words, 1 371 speakers, H=300, 4 layers): no reference fixture exists at this size (the CPU reference needs
+    minutes per step), so the step is checked through size-independent invariants, with the random draws pinned:
+      * the fused 3-chain schedule and the literal three-pass schedule of the reference give the same loss terms and the
+        same gradient for every module;
+      * the default matrix-core mode (split-bf16 backward GEMMs / convolutions) and the exact-fp32 mode give identical
+        losses (the forward is untouched) and gradients that agree to 1e-4 of each module's gradient norm;
+      * running the same step twice from the same state is bitwise reproducible."""
     B = 128
-    text, spec, target, vid = (torch.from_numpy(x).to(DEV) for x in proc.make_batch(B, 27, 20000, 1371, 1234))
-    eps_const = torch.from_numpy(proc.tensor_for('in.eps', (3 * B, 16), 21)).to(DEV)
-    perm = torch.from_numpy(proc.fixed_perm(B, 21)).to(DEV)
-
-    def one_step(fuse, mode):
-        torch.manual_seed(9)
-        ops.rng.seed(dev, 5)
-        tr = HierarchyTrainer(hierarchy_args(), Lang(), SpeakerVocab(1371), 27, dev)
-        for m in tr.modules():
-            no_dropout(m)
-        for g in tr.gens:
-            # the fused pass asks for k*B rows (block p = pass eps_block_order[p]); the literal passes ask for B rows each.
-            # A constant per-pass slice keyed by the logical pass makes both schedules consume the same noise.
-            g._pass = 0
-
-            def src(shape, device, g=g):
-                k = shape[0] // B
-                order = getattr(g, 'eps_block_order', None) or list(range(k))
-                if k == 1:
-                    out = eps_const[g._pass * B:(g._pass + 1) * B]
-                    g._pass += 1
-                    return out
-                return torch.cat([eps_const[o * B:(o + 1) * B] for o in order])
-            g.eps_source = src
-        old = th.FUSE_CHAINS, th.randperm_source
-        th.FUSE_CHAINS, th.randperm_source = fuse, (lambda n, device: perm)
-        lib.ha2g_gemm_set_mode(mode)
-        try:
-            ret = tr.train_iter(11, text, spec, target, vid)
-        finally:
-            th.FUSE_CHAINS, th.randperm_source = old
-            lib.ha2g_gemm_set_mode(6)
-        norms = {}
-        for name, o in zip(['g1', 'g2', 'g3', 'audio', 'text'], tr.gen_opts + [tr.audio_opt, tr.text_opt]):
-            norms[name] = o.flat_g.clone()
-        return ret, norms
-
-    r_f, g_f = one_step(True, 6)
-    r_l, g_l = one_step(False, 6)
-    r_x, g_x = one_step(True, 0)
-    r_f2, g_f2 = one_step(True, 6)
+    r_f, g_f = _full_size_step(expressive, B, True, 6)
+    r_l, g_l = _full_size_step(expressive, B, False, 6)
+    r_x, g_x = _full_size_step(expressive, B, True, 0)
+    r_f2, g_f2 = _full_size_step(expressive, B, True, 6)
     assert r_f == r_f2 and all(torch.equal(g_f[k], g_f2[k]) for k in g_f)                      # reproducible
     for k in r_f:                                                                              # schedules agree
         assert abs(r_f[k] - r_l[k]) <= 2e-5 * max(abs(r_l[k]), 1e-3), (k, r_f[k], r_l[k])
@@ -244,6 +252,26 @@ def test_full_size_schedule_and_precision_invariants():
     for k in g_f:
         d = float((g_f[k] - g_x[k]).norm() / g_x[k].norm())
         assert d < 1e-4, ('split-bf16 vs fp32 backward', k, d)
+
+
+def test_config5_bf16_step_b256():
+    """BASELINE config 5: the expressive step with the contrastive terms at B=256 (N = 8704 contrastive rows: the
+    row-blocked >80 MB branch) with PLAIN bf16 GEMM / convolution operands (`bench.py --bf16`, mode 22) against the fp32-class
+    default on the same pinned draws: every loss term within 2e-3 relative, every module's gradient within 5 % in norm and
+    at cosine > 0.98 of the fp32-class gradient.  (bf16 operands: 2^-9 relative rounding per product term.)"""
+    r32, g32 = _full_size_step(True, 256, True, 6)
+    r16, g16 = _full_size_step(True, 256, True, 22)
+    assert sorted(r16) == sorted(r32)
+    for k in r32:
+        assert abs(r16[k] - r32[k]) <= 2e-3 * max(abs(r32[k]), 1e-3), (k, r16[k], r32[k])
+    report = {}
+    for k in g32:
+        ratio = float(g16[k].norm() / g32[k].norm())
+        cos = float(torch.dot(g16[k], g32[k]) / (g16[k].norm() * g32[k].norm()))
+        report[k] = (round(ratio, 4), round(cos, 5))
+    print('config5 bf16 vs fp32-class (norm ratio, cosine):', report)
+    for k, (ratio, cos) in report.items():
+        assert abs(ratio - 1) < 0.05 and cos > 0.98, report
 
 
 @pytest.mark.parametrize('B', [1, 5, 17])

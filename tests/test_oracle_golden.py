@@ -135,10 +135,11 @@ def test_train_step(golden, name, dt):
 
 
 @pytest.mark.parametrize('dt', DTS)
-def test_train_step_expressive(golden, dt):
+@pytest.mark.parametrize('name', ['expr_small', 'expr_cfg1'])
+def test_train_step_expressive(golden, name, dt):
     """6-level TED-Expressive twin (train_hierarchy_expressive.py): off-by-one head scatter, palm normals, eps-free contrastive."""
     from ha2g_amd.config import EXPRESSIVE_SPEC
-    case, g = CASES['expr_small'], golden('expr_small')
+    case, g = CASES[name], golden(name)
     ck = Checker(g, dt)
     sd = state_for(case, dt, schema.EXPRESSIVE_POSE_DIMS)
     text, spec, target, vid = batch_for(case, dt, P=126)
