@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libha2g_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'ha2g_hip.h')
 
-_SCALARS = {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'unsigned': ctypes.c_uint}
+_SCALARS = {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'double': ctypes.c_double, 'unsigned': ctypes.c_uint}
 
 
 def parse_header(path=HEADER_PATH):

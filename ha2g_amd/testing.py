@@ -370,3 +370,33 @@ def taps_inputs(case, seed, dt=torch.float32):
 
 def taps_w(name, t, seed):
     return torch.from_numpy(proc.tensor_for('w.taps.' + name, (2,) + tuple(t.shape), seed)[0] * t[0].numel() ** 0.5).to(device=t.device, dtype=t.dtype)
+
+
+def tcn_relu_margin(case):
+    """Smallest non-zero |ReLU input| (relative to the tensor's max) over the text encoders of a step case, from the
+    procedural state in float64 (torch CPU conv1d; test-side helper).  The token inputs are integers, so the reference's
+    nine perturbed fp32 runs never re-roll these decisions: a pre-activation within fp32 rounding of zero would be an
+    un-measured coin flip of any fp32 implementation.  Step fixtures are generated from seeds where this margin is safe."""
+    import torch.nn.functional as F
+    dims = schema.EXPRESSIVE_POSE_DIMS if case.get('expressive') else schema.GESTURE_POSE_DIMS
+    sd = state_for(case, torch.float64, dims)
+    text = torch.from_numpy(proc.make_batch(case['B'], dims[-1], case['n_words'], case['n_spk'], case['seed'])[0])
+    worst = 1.0
+    for role in ['g%d.text_encoder.' % (i + 1) for i in range(len(dims))] + ['text.']:
+        x = F.embedding(text, sd[role + 'embedding.weight']).transpose(1, 2)
+        for i in range(case['n_layers']):
+            dil, y = 2 ** i, x
+            for c in ('conv1', 'conv2'):
+                q = '%stcn.network.%d.%s.' % (role, i, c)
+                v = sd[q + 'weight_v']
+                w = sd[q + 'weight_g'] * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
+                y = F.conv1d(F.pad(y, (dil, 0)), w, sd[q + 'bias'], dilation=dil)
+                a = y.abs()
+                worst = min(worst, float(a[a > 0].min() / a.max()))
+                y = torch.relu(y)
+            dk = '%stcn.network.%d.downsample.weight' % (role, i)
+            res = F.conv1d(x, sd[dk], sd[dk[:-6] + 'bias']) if dk in sd else x
+            s = (y + res).abs()
+            worst = min(worst, float(s[s > 0].min() / s.max()))
+            x = torch.relu(y + res)
+    return worst

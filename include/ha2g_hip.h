@@ -169,7 +169,9 @@ int ha2g_contrastive_f32(const float* a, const float* b, int N, int expressive, 
 
 /* ---- optimizer (torch.optim.Adam as set up in train.py:155-170) ---- */
 int ha2g_adam_step_inc(int* step, void* stream);
-int ha2g_adam_f32(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+/* lr, betas, eps are doubles like torch's Python scalars: 1 - beta, the bias corrections 1 - beta^step and lr / bc1 are formed
+ * in double (in fp32, 1 - 0.999 alone is off by 1.3e-5 relative), the per-element update runs in fp32 */
+int ha2g_adam_f32(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
                   const int* step, void* stream);
 
 /* ---- log-mel front-end on the GPU: replaces the offline librosa step

@@ -135,3 +135,14 @@ def test_whole_encoder_b16(golden, dt):
     for k in sd:
         if k.endswith(('running_mean', 'running_var')):
             ck.check(sd[k], 'enc/buf/' + k[6:])
+
+
+def test_step_fixture_tcn_relu_margins():
+    """The text encoders' inputs are integer tokens: the reference's one-ulp input perturbations never reach them, so a TCN
+    pre-activation within fp32 rounding of zero would be an unmeasured coin flip.  Pin the margins the step cases were
+    chosen for (relative to the layer's largest pre-activation, float64)."""
+    from ha2g_amd.config import CASES
+    from ha2g_amd.testing import tcn_relu_margin
+    assert tcn_relu_margin(CASES['expr_cfg1']) > 5e-7
+    assert tcn_relu_margin(CASES['cfg1']) > 5e-8
+    assert tcn_relu_margin(CASES['small']) > 1e-6
