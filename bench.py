@@ -218,26 +218,43 @@ def main():
     value = a.batch * 34 * world / (dt / a.steps)
 
     if rank == 0:
-        # ---- roofline of the named kernel: bi-GRU layer forward (ha2g_gru_layer_fwd, H=300, layers 1..3: in = 600) ----
+        # ---- roofline of the named kernel: bi-GRU layer forward (ha2g_gru_layer_fwd_cluster, H=300, layers 1..3: in = 600) and its BPTT twin ----
         H, T = args.hidden_size, 34
         kt = ops.ktimer.summary()
-        roof = None
-        if 'gru_layer_fwd' in kt:
-            n, mean_us, rows = kt['gru_layer_fwd'][:3]                       # rows = batch rows per launch (3B in the GAN phase)
+        import hashlib
+        src_sha = hashlib.sha256(open(os.path.join(ROOT, 'ha2g_amd', 'csrc', 'gru_cluster.hip'), 'rb').read()).hexdigest()
+
+        def gru_roof(key, kernel, pmc_name, bwd):
+            if key not in kt:
+                return None
+            n, mean_us, rows = kt[key][:3]                                     # rows = batch rows per launch
             flops = 2.0 * rows * T * 2 * 3 * H * H + 12.0 * rows * T * 2 * H   # recurrent matmul + gate math per launch
-            bytes_ = (rows * T * 2 * 3 * H + rows * T * 2 * H + rows * T * 2 * 4 * H + 2 * 3 * H * H) * 4.0   # gi + y + reserve + W_hh
+            if bwd:       # dy + y + reserve (4 planes) read, dg (4 planes) written, W_hh once
+                bytes_ = (rows * T * 2 * H * 2 + rows * T * 2 * 4 * H * 2 + 2 * 3 * H * H) * 4.0
+            else:         # gi read, y + reserve written, W_hh once
+                bytes_ = (rows * T * 2 * 3 * H + rows * T * 2 * H + rows * T * 2 * 4 * H + 2 * 3 * H * H) * 4.0
             ach = flops / (mean_us * 1e-6) / 1e12
-            traffic, tsrc = None, None
-            pj = os.path.join(ROOT, 'profiles', 'r01_pmc_gru_fwd.json')
+            traffic = tsrc = stale = None
+            pj = os.path.join(ROOT, 'profiles', pmc_name)
             if os.path.exists(pj):                         # HBM bytes per launch from separate rocprofv3 --pmc passes (same workload)
                 pm = json.load(open(pj))
                 if pm.get('batch_rows') == rows:
-                    traffic, tsrc = pm['hbm_bytes_per_launch'], 'profiles/r01_pmc_gru_fwd.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)'
-            roof = dict(kernel='gru_fwd_cluster_kernel (ha2g_gru_layer_fwd_cluster, H=300)', bound='mfma', achieved=round(ach, 3), peak=157.3,
-                        unit='TFLOP/s', frac=round(ach / 157.3, 4), traffic=traffic, traffic_source=tsrc,
-                        algorithmic_bytes=bytes_, launches=n, mean_us=round(mean_us, 1),
+                    traffic, tsrc = pm['hbm_bytes_per_launch'], 'profiles/%s (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)' % pmc_name
+                    stale = pm.get('source_sha256') != src_sha     # the kernel source changed since the counters were collected
+            return dict(kernel=kernel, bound='mfma', achieved=round(ach, 3), peak=157.3, unit='TFLOP/s', frac=round(ach / 157.3, 4),
+                        traffic=traffic, traffic_source=tsrc, traffic_stale=stale, algorithmic_bytes=bytes_,
+                        traffic_over_algorithmic=(round(traffic / bytes_, 3) if traffic else None), launches=n, mean_us=round(mean_us, 1),
                         batch_rows=rows, us_per_timestep=round(mean_us / T, 2), hbm_GBps_algorithmic=round(bytes_ / (mean_us * 1e-6) / 1e9, 1),
                         hbm_frac_of_8TBps=round(bytes_ / (mean_us * 1e-6) / 8e12, 4))
+        roof = gru_roof('gru_layer_fwd', 'gru_fwd_cluster_kernel (ha2g_gru_layer_fwd_cluster, H=300)', 'r02_pmc_gru_fwd.json', False)
+        roof_bwd = gru_roof('gru_layer_bwd', 'gru_bwd_cluster_kernel (ha2g_gru_layer_bwd_cluster, H=300)', 'r02_pmc_gru_bwd.json', True)
+        roof_gemm = None
+        if 'gemm_gi' in kt:                        # dominant dense-GEMM shape: the GRU input projections (rows x 600) . (600 x 900)^T, fp32 MFMA
+            n, mean_us, _, flops = kt['gemm_gi']
+            ach = flops / (n * mean_us * 1e-6) / 1e12
+            roof_gemm = dict(kernel='gemm_kernel<A_KC,B_KC> (ha2g_gemm_f32: GRU input projections [rows,600]x[900,600]^T)', bound='mfma',
+                             achieved=round(ach, 2), peak=157.3, unit='TFLOP/s', frac=round(ach / 157.3, 4), launches=n, mean_us=round(mean_us, 1),
+                             traffic=None)
         roof_conv = None
         if 'conv2d_fwd' in kt:                     # the largest kernel family by time: implicit-GEMM convolutions of the audio tower (forward, fp32 MFMA)
             n, mean_us, _, flops = kt['conv2d_fwd']
@@ -257,7 +274,7 @@ def main():
                                             'config_expressive/hierarchy.yml TED-Expressive' if a.expressive else 'config/hierarchy.yml TED-Gesture', a.batch, P, a.n_words, a.n_spk, 'GAN phase (epoch %d > loss_warmup)' % a.epoch
                                             if a.epoch > args.loss_warmup else 'warm-up phase (epoch %d)' % a.epoch),
                                global_batch=a.batch * world, parallelism='dp%d' % world),
-                   gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, roofline_conv=roof_conv, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
+                   gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, roofline_bwd=roof_bwd, roofline_gemm=roof_gemm, roofline_conv=roof_conv, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
         if world == 1 and not a.no_cpu_baseline and not a.expressive:
             out['cpu_baseline'] = cpu_baseline(a.epoch, a.n_words, a.n_spk)
         print(json.dumps(out))

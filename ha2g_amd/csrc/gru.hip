@@ -75,10 +75,6 @@ __global__ __launch_bounds__(NT) void gru_fwd_kernel(const float* __restrict__ g
     for (int s = 0; s < T; ++s) {
         const int t = dir ? T - 1 - s : s;
         const int cur = s & 1;
-        float4 hb[NJT];                                   // B operand: h[b][16m + 4g + u]
-#pragma unroll
-        for (int m = 0; m < NJT; ++m) hb[m] = *reinterpret_cast<const float4*>(&hs[cur][lb * LDH + 16 * m + 4 * g]);
-
         for (int jt = wave; jt < NJT; jt += NW) {
             f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
             const float4* w = wpd + (long)(jt * 3) * NJT * 64;
@@ -92,18 +88,25 @@ __global__ __launch_bounds__(NT) void gru_fwd_kernel(const float* __restrict__ g
                 giz = *reinterpret_cast<const float4*>(gp + H);
                 gin = *reinterpret_cast<const float4*>(gp + 2 * H);
             }
-            // W_hh fragment stream of this j-tile, order f = 3*m + gate, kept PF fragments ahead of the MFMAs
+            // k-block order of this j-tile: rotated to start at the blocks of the 4-tile group the tile belongs to,
+            // m_i = (4 (jt / 4) + i) mod NJT -- the order in which the cluster kernel (gru_cluster.hip) consumes the hidden
+            // state (own member's columns first, then the other members' as they arrive), so that both kernels produce
+            // the same bits.  (NJT <= 4: the identity.)
+            const int rot = 4 * (jt / 4);
+            // W_hh fragment stream of this j-tile, order f = 3*i + gate, kept PF fragments ahead of the MFMAs
             // (one wave alone cannot hide the ~500-cycle L2 latency otherwise; hipcc keeps <=2 loads in flight).
             constexpr int NF = 3 * NJT;
             float4 ring[PF];
 #pragma unroll
-            for (int f = 0; f < PF && f < NF; ++f) ring[f] = w[((f % 3) * NJT + f / 3) * 64];
+            for (int f = 0; f < PF && f < NF; ++f) ring[f] = w[((f % 3) * NJT + (rot + f / 3) % NJT) * 64];
+            float4 hbv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 const float4 wv = ring[f % PF];
-                if (f + PF < NF) ring[f % PF] = w[(((f + PF) % 3) * NJT + (f + PF) / 3) * 64];
+                if (f + PF < NF) ring[f % PF] = w[(((f + PF) % 3) * NJT + (rot + (f + PF) / 3) % NJT) * 64];
+                if (f % 3 == 0) hbv = *reinterpret_cast<const float4*>(&hs[cur][lb * LDH + 16 * ((rot + f / 3) % NJT) + 4 * g]);   // B operand: h[b][16m + 4g + u]
                 __builtin_amdgcn_sched_barrier(0);      // keep the refill load ahead of the MFMAs (hipcc sinks it otherwise)
-                const float* pw = &wv.x; const float* ph = &hb[f / 3].x;
+                const float* pw = &wv.x; const float* ph = &hbv.x;
                 if (f % 3 == 0) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) ar = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[u], ph[u], ar, 0, 0, 0);

@@ -1,4 +1,4 @@
-// Bidirectional GRU layer forward, "workgroup cluster" form for H = 300 on gfx950.
+// Bidirectional GRU layer forward + BPTT, "workgroup cluster" form for H = 300 on gfx950.
 //
 // gru.hip's kernel gives one workgroup 16 batch rows x ALL 3H gate rows: 48 workgroups at B = 384, each issuing 15 us of
 // fp32 MFMA per step while streaming the whole 1.08 MB W_hh from L2.  Here a (16-row batch tile, direction) pair is served
@@ -9,12 +9,28 @@
 //   * 240 of the 256 CUs work on the recurrence instead of 48.
 // The price is an all-gather of the new hidden state inside the cluster every step.  It uses the placement-independent
 // "data is the flag" hand-off of the CDNA4 guide (cdna_hip_programming.md G16, recipe R2): every float travels as one
-// naturally aligned 8-byte {tag = step + 1, value} granule written with ONE agent-scope (sc1, write-through) store and
-// read with agent-scope loads until its tag matches; no fences, no flags, correct for any workgroup->XCD placement.
-// Slots are double-buffered by step parity; the buffer is zeroed by a memset node before every launch; spins are bounded
-// (a timeout sets *err and lets the kernel finish with garbage rather than hang the device).
-// All workgroups of a launch must be co-resident: the host wrapper caps a launch at 24 batch tiles (240 workgroups of
-// 256 threads, one per CU) and loops over larger batches.
+// naturally aligned 8-byte {value, tag} granule (two per 16-byte store) and is re-read with agent-scope loads until its
+// tag matches; no fences, no flags, correct for any workgroup->XCD placement.
+//
+// Round 2 -- the step is software-pipelined around the hand-off instead of waiting for it:
+//   * PER-SOURCE STAGING: the 19 k-blocks of the chain are consumed member by member, the member's OWN 64 columns first
+//     (they are in LDS already), then the other four members' blocks in ring order; the poll loads of source i+1 are in
+//     flight while the 48 MFMAs of source i issue, so only the first arrival is exposed (order m_i = (4q + i) mod 19 --
+//     gru.hip uses the same order, the two kernels agree bit for bit);
+//   * barriers wait for LDS only (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() also drains vmcnt, i.e. waited for
+//     the HBM acknowledgement of every y / reserve store and for the prefetched polls, twice per step;
+//   * y / reserve stores of step s and the gi loads of step s+2 are issued AFTER the last poll of step s+1, so no poll
+//     (whose result wait is a vmcnt(0) on gfx9 once loads and stores are mixed) ever queues behind HBM traffic;
+//   * tags carry a device-side launch epoch (tag = epoch * 64 + step + 1): no memset of the exchange buffer per launch,
+//     and a captured hipGraph still gets fresh tags on every replay;
+//   * when the five members of a cluster report the same XCC id (one handshake through the write-through path at kernel
+//     start) the granules are published with plain stores: they stay in that XCD's L2, where the members' sc1 loads
+//     read them, instead of being written through to HBM; any other placement keeps the write-through (sc1) form.
+// Spins are bounded: a lost hand-off sets *err and lets the kernel finish with garbage rather than hang the device; the
+// train step reads *err back with its loss scalars and raises.
+// All workgroups of a launch must be co-resident: the host wrapper caps a launch at CUs / (2 G) batch tiles (24 on the
+// 256-CU MI355X: 240 workgroups of 256 threads, one per CU), loops over larger batches, and reports "unsupported" (the
+// caller then uses gru.hip) on a device or partition with fewer than 2 G compute units.
 #include "common.h"
 
 namespace {
@@ -27,44 +43,117 @@ constexpr int TPW = 4;               // tiles (= waves) per workgroup
 constexpr int G = (NJT + TPW - 1) / TPW;   // 5 workgroups per cluster
 constexpr int NT = 64 * TPW;
 constexpr int MAX_TILES = 24;        // 24 tiles x 2 directions x 5 = 240 workgroups <= 256 CUs
+constexpr int MAX_STEPS = 62;        // tag = epoch * 64 + step + 1 (63 = the placement handshake)
+constexpr unsigned EPOCH_WRAP = 1u << 26;
 constexpr unsigned SPIN_LIMIT = 1u << 18;
 
 typedef unsigned long long u64;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// Two {value, tag} granules travel in ONE 16-byte write-through (sc1) store / agent-scope (sc1) load: each 8-byte half
-// validates itself, so a torn 16-byte access cannot pair a new tag with stale data, and the fabric sees half as many
-// (and 2.7x cheaper per byte) writes as with scalar 8-byte granule stores (MI355X_MICROARCH.md, hand-off price list).
+// exchange-buffer geometry (granules of 8 bytes).  One cluster region serves either kernel; the last 16 granules are the
+// placement handshake slots.
+// forward region: [parity][row][unit] = 2 * 16 * HP granules (fits inside the backward geometry below)
+constexpr long BWD_GRAN = 2L * G * G * 16 * 64;          // [parity][dst][src][row][64 units]
+constexpr long CL_GRAN = BWD_GRAN + 16;
+constexpr long XCH_BYTES = (long)MAX_TILES * 2 * CL_GRAN * 8;
+
+// Two {value, tag} granules travel in ONE 16-byte store / agent-scope (sc1) load: each 8-byte half validates itself, so a
+// torn 16-byte access cannot pair a new tag with stale data.  AUX = 16 (sc1): write-through, visible to every XCD;
+// AUX = 0: plain store, visible in the issuing XCD's L2 (used only when the whole cluster sits on one XCD).
+template <int AUX>
 __device__ __forceinline__ void store_granule_pair(__amdgpu_buffer_rsrc_t r, int byte_off, unsigned tag, float v0, float v1) {
     u32x4 d = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
-    __builtin_amdgcn_raw_buffer_store_b128(d, r, byte_off, 0, /*aux = sc1*/ 16);
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, byte_off, 0, AUX);
 }
 __device__ __forceinline__ u32x4 load_granule_pair(__amdgpu_buffer_rsrc_t r, int byte_off) {
-    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, /*aux = sc1*/ 16);
+    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, /*aux = sc1: bypass this CU's L1*/ 16);
+}
+// workgroup barrier that waits for this wave's LDS traffic only; global loads / stores stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // vmcnt(63) expcnt(7) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
-__global__ __launch_bounds__(NT, 1) void gru_fwd_cluster_kernel(const float* __restrict__ gi,      // [B][T][2][3H]
-                                                                const float* __restrict__ wp,      // packed fwd images, 2 dirs
-                                                                const float* __restrict__ bhh0, const float* __restrict__ bhh1,
-                                                                float* __restrict__ y,             // [B][T][2H]
-                                                                float* __restrict__ rs,            // [B][T][2][4][H] or null
-                                                                u64* __restrict__ xch,             // [clusters][2][16][HP] granules
-                                                                int* __restrict__ err, int B, int T, int tile0, int nclusters, int dbg) {
-    __shared__ __attribute__((aligned(16))) float hs[16 * LDH];
-    // block -> (cluster, member): the G members of a cluster share blockIdx % 8, i.e. (observed) one XCD -- speed only
-    const int id = blockIdx.x, xcd = id & 7, r = id >> 3;
-    const int q = r % G, c = (r / G) * 8 + xcd;
-    if (c >= nclusters) return;
-    const int dir = c & 1, b0 = (tile0 + (c >> 1)) * 16;
+// Placement handshake: every member publishes its XCC id (write-through), reads the other four; returns 1 when all five
+// agree.  Doubles as the first rendezvous of the launch: a cluster that is not co-resident times out here.
+__device__ __forceinline__ int cluster_same_xcd(__amdgpu_buffer_rsrc_t xr, int hdr_byte_off, int q, unsigned tag, int* err, int* sh) {
+    const int tid = threadIdx.x;
+    if (tid < G) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;     // HW_REG_XCC_ID[3:0]
+        if (tid == q) store_granule_pair<16>(xr, hdr_byte_off + 16 * q, tag, __uint_as_float(xcc), __uint_as_float(xcc));
+        unsigned got = 0xffffffffu;
+        for (unsigned spins = 0;; ++spins) {
+            const u32x4 x = load_granule_pair(xr, hdr_byte_off + 16 * tid);
+            if (x[1] == tag && x[3] == tag) { got = x[0]; break; }
+            if (spins > SPIN_LIMIT) { atomicExch(err, 1); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        sh[tid] = (int)got;
+    }
+    __syncthreads();
+    int same = 1;
+#pragma unroll
+    for (int p = 1; p < G; ++p) same &= (sh[p] == sh[0]) & (sh[p] >= 0);
+    return same;
+}
+
+// 12 MFMAs per 16-wide k-block: gh^T[3 x 16 units][16 rows] += W_hh[.., 16m..16m+15] * h^T
+#define HA2G_FWD_BLOCKS(M0, NB)                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < (NB); ++i_) {                                                         \
+        const float4 hb_ = *reinterpret_cast<const float4*>(&hs[lb * LDH + 16 * ((M0) + i_) + 4 * g]);           \
+        const float* ph_ = &hb_.x;                                                                                \
+        const float* pr_ = &wf[(M0) + i_].x; const float* pz_ = &wf[NJT + (M0) + i_].x;                          \
+        const float* pn_ = &wf[2 * NJT + (M0) + i_].x;                                                            \
+        _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                        \
+            ar = __builtin_amdgcn_mfma_f32_16x16x4f32(pr_[u_], ph_[u_], ar, 0, 0, 0);                             \
+            az = __builtin_amdgcn_mfma_f32_16x16x4f32(pz_[u_], ph_[u_], az, 0, 0, 0);                             \
+            an = __builtin_amdgcn_mfma_f32_16x16x4f32(pn_[u_], ph_[u_], an, 0, 0, 0);                             \
+        }                                                                                                         \
+    }
+
+// poll loads of source slot I (P = the member it reads): two granule pairs per thread
+#define HA2G_POLL_ISSUE(I, P)                                                                                     \
+    if (64 * (P) + pc < H) {                                                                                      \
+        const int off_ = (sbase + pr * HP + 64 * (P) + pc) * 8;                                                   \
+        pa##I = load_granule_pair(xr, off_); pb##I = load_granule_pair(xr, off_ + 16);                            \
+    }
+
+// wait until this thread's two granule pairs of source P carry `tag`, then stage the four floats into the LDS tile
+#define HA2G_POLL_WAIT_STAGE(I, P)                                                                                \
+    {                                                                                                             \
+        const bool act_ = 64 * (P) + pc < H;                                                                      \
+        for (unsigned spins_ = 0;; ++spins_) {                                                                    \
+            const bool ok_ = !act_ || (pa##I[1] == tag && pa##I[3] == tag && pb##I[1] == tag && pb##I[3] == tag); \
+            if (__all(ok_) || (dbg & 1)) break;                                                                   \
+            if (spins_ > SPIN_LIMIT) { if (lane == 0) atomicExch(err, 1); break; }                                \
+            __builtin_amdgcn_s_sleep(1);                                                                          \
+            HA2G_POLL_ISSUE(I, P)                                                                                 \
+        }                                                                                                         \
+        if (act_) *reinterpret_cast<float4*>(&hs[pr * LDH + 64 * (P) + pc]) =                                     \
+            make_float4(__uint_as_float(pa##I[0]), __uint_as_float(pa##I[2]), __uint_as_float(pb##I[0]), __uint_as_float(pb##I[2])); \
+    }
+
+// Member Q of a cluster, all T steps.  Q is a template parameter so that the rotated k-block order indexes the register-
+// resident W_hh slice statically.
+template <int Q, int PA>
+__device__ __forceinline__ void gru_fwd_member(const float* __restrict__ gi, const float* __restrict__ wp, const float* __restrict__ bhh,
+                                               float* __restrict__ y, float* __restrict__ rs, const __amdgpu_buffer_rsrc_t xr,
+                                               int* __restrict__ err, const int B, const int T, const int dir, const int b0,
+                                               const unsigned tag0, const int fast, const int dbg, float* __restrict__ hs) {
+    constexpr int NOWN = (Q == G - 1) ? NJT - TPW * (G - 1) : TPW;       // k-blocks / unit tiles of this member: 4 4 4 4 3
+    constexpr int P1 = (Q + 1) % G, P2 = (Q + 2) % G, P3 = (Q + 3) % G, P4 = (Q + 4) % G;
+#define HA2G_NB(P) ((P) == G - 1 ? NJT - TPW * (G - 1) : TPW)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lb = lane & 15, g = lane >> 4;
     const int b = b0 + lb;
     const bool bok = b < B;
-    const int jt = q * TPW + wave;
-    const bool tile_on = jt < NJT;
+    const bool tile_on = wave < NOWN;
+    const int jt = Q * TPW + wave;
     const int j = 16 * jt + 4 * g;                       // first of this lane's 4 hidden units
     const bool jok = tile_on && j < H;
-    const float* bhh = dir ? bhh1 : bhh0;
+    const int pr = tid >> 4, pc = (tid & 15) * 4;        // gather ownership: LDS row, column inside a member's 64-column block
 
     // ---- this wave's slice of W_hh: 3 gates x 19 k-blocks, resident in registers for the whole sequence ----
     float4 wf[3 * NJT];
@@ -81,48 +170,79 @@ __global__ __launch_bounds__(NT, 1) void gru_fwd_cluster_kernel(const float* __r
     }
     for (int i = tid; i < 16 * LDH; i += NT) hs[i] = 0.f;
 
-    // own / foreign column ranges of the gathered hidden state
-    const int k0 = q * TPW * 16, k1 = min(H, k0 + TPW * 16), nown = k1 - k0, nother = H - nown;
-    u64* xc = xch + (long)c * 2 * 16 * HP;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xc, 0, 2 * 16 * HP * 8, 0x00020000);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gir = zero4, giz = zero4, gin = zero4;        // gi of the step whose gates run next
+    float4 gir_n = zero4, giz_n = zero4, gin_n = zero4;  // ... of the step after (prefetched)
+    float4 d_h = zero4, d_r = zero4, d_z = zero4, d_n = zero4, d_q = zero4;   // deferred y / reserve stores of the previous step
+    long d_bt = -1;
+    if (jok && bok) {
+        const float* gp = gi + ((long)(b * T + (dir ? T - 1 : 0)) * 2 + dir) * 3 * H + j;
+        gir = *reinterpret_cast<const float4*>(gp);
+        giz = *reinterpret_cast<const float4*>(gp + H);
+        gin = *reinterpret_cast<const float4*>(gp + 2 * H);
+    }
+    u32x4 pa1 = {0u, 0u, 0u, 0u}, pb1 = pa1, pa2 = pa1, pb2 = pa1, pa3 = pa1, pb3 = pa1, pa4 = pa1, pb4 = pa1;
+
+    // the point of a step after which no poll is outstanding: fetch the NEXT step's gi, flush the PREVIOUS step's outputs
+#define HA2G_FWD_PREFETCH_FLUSH(S)                                                                                \
+    {                                                                                                             \
+        if ((S) + 1 < T && jok && bok) {                                                                          \
+            const int tn_ = dir ? T - 2 - (S) : (S) + 1;                                                          \
+            const float* gp_ = gi + ((long)(b * T + tn_) * 2 + dir) * 3 * H + j;                                  \
+            gir_n = *reinterpret_cast<const float4*>(gp_);                                                        \
+            giz_n = *reinterpret_cast<const float4*>(gp_ + H);                                                    \
+            gin_n = *reinterpret_cast<const float4*>(gp_ + 2 * H);                                                \
+        }                                                                                                         \
+        if (d_bt >= 0) {                                                                                          \
+            *reinterpret_cast<float4*>(y + d_bt * 2 * H + dir * H + j) = d_h;                                     \
+            if (rs) {                                                                                             \
+                float* rp_ = rs + (d_bt * 2 + dir) * 4 * H + j;                                                   \
+                *reinterpret_cast<float4*>(rp_) = d_r;                                                            \
+                *reinterpret_cast<float4*>(rp_ + H) = d_z;                                                        \
+                *reinterpret_cast<float4*>(rp_ + 2 * H) = d_n;                                                    \
+                *reinterpret_cast<float4*>(rp_ + 3 * H) = d_q;                                                    \
+            }                                                                                                     \
+            d_bt = -1;                                                                                            \
+        }                                                                                                         \
+    }
 
     for (int s = 0; s < T; ++s) {
         const int t = dir ? T - 1 - s : s;
-        __syncthreads();                                  // A: hs holds the complete h_s
-        float4 hb[NJT];
-#pragma unroll
-        for (int m = 0; m < NJT; ++m) hb[m] = *reinterpret_cast<const float4*>(&hs[lb * LDH + 16 * m + 4 * g]);
-        float4 gir = make_float4(0.f, 0.f, 0.f, 0.f), giz = gir, gin = gir;
-        if (jok && bok) {
-            const float* gp = gi + ((long)(b * T + t) * 2 + dir) * 3 * H + j;
-            gir = *reinterpret_cast<const float4*>(gp);
-            giz = *reinterpret_cast<const float4*>(gp + H);
-            gin = *reinterpret_cast<const float4*>(gp + 2 * H);
-        }
-        __syncthreads();                                  // B: every wave has its B operand; hs may be overwritten
         f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
-        if (tile_on) {
-#pragma unroll
-            for (int m = 0; m < NJT; ++m) {
-                const float* ph = &hb[m].x;
-                const float* pr = &wf[m].x; const float* pz = &wf[NJT + m].x; const float* pn = &wf[2 * NJT + m].x;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    ar = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[u], ph[u], ar, 0, 0, 0);
-                    az = __builtin_amdgcn_mfma_f32_16x16x4f32(pz[u], ph[u], az, 0, 0, 0);
-                    an = __builtin_amdgcn_mfma_f32_16x16x4f32(pn[u], ph[u], an, 0, 0, 0);
-                }
+        if (s == 0) {
+            HA2G_FWD_PREFETCH_FLUSH(0)                                    // h_0 = 0: no recurrent product, nothing to gather
+            lds_barrier();
+        } else if (dbg & 2) {                                             // ablation: no exchange (stale foreign columns)
+            lds_barrier();
+            if (tile_on) { HA2G_FWD_BLOCKS(0, NJT) }
+            HA2G_FWD_PREFETCH_FLUSH(s)
+            lds_barrier();
+        } else {
+            const unsigned tag = tag0 + (unsigned)s;                      // h_s was published at the end of step s-1
+            const int sbase = ((s - 1) & 1) * 16 * HP;
+            lds_barrier();                                                // every wave's own columns of h_s are in the tile
+            // own member's blocks first; the polls of all four foreign members are issued after PA of them -- late enough that
+            // the granules published at the end of the previous step have reached L2, early enough to return under the rest
+            constexpr int PA_ = PA < NOWN ? PA : NOWN;
+            if (tile_on) { HA2G_FWD_BLOCKS(TPW * Q, PA_) }
+            HA2G_POLL_ISSUE(1, P1) HA2G_POLL_ISSUE(2, P2) HA2G_POLL_ISSUE(3, P3) HA2G_POLL_ISSUE(4, P4)
+            if (tile_on) { HA2G_FWD_BLOCKS(TPW * Q + PA_, NOWN - PA_) }
+            HA2G_POLL_WAIT_STAGE(1, P1) HA2G_POLL_WAIT_STAGE(2, P2) HA2G_POLL_WAIT_STAGE(3, P3) HA2G_POLL_WAIT_STAGE(4, P4)
+            HA2G_FWD_PREFETCH_FLUSH(s)
+            lds_barrier();
+            if (tile_on) {
+                HA2G_FWD_BLOCKS(TPW * P1, HA2G_NB(P1)) HA2G_FWD_BLOCKS(TPW * P2, HA2G_NB(P2))
+                HA2G_FWD_BLOCKS(TPW * P3, HA2G_NB(P3)) HA2G_FWD_BLOCKS(TPW * P4, HA2G_NB(P4))
             }
         }
         // ---- gates (C/D layout: col = batch lane&15, row = 4*(lane>>4) + reg) ----
-        float4 hn4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 hn4 = zero4;
         if (jok) {
             if (bok) {
-                // h_prev of this lane's units: the wave's own columns of hs (only this wave ever writes them, later in this step)
+                // h_prev of this lane's units: the wave's own columns of the tile (only this wave ever writes them, below)
                 const float4 hprev = *reinterpret_cast<const float4*>(&hs[lb * LDH + j]);
                 const float* hpp = &hprev.x;
-                float4 r4, z4, n4, q4;
-                float* pr = &r4.x; float* pz = &z4.x; float* pn = &n4.x; float* pq = &q4.x; float* ph = &hn4.x;
+                float* pr4 = &d_r.x; float* pz4 = &d_z.x; float* pn4 = &d_n.x; float* pq4 = &d_q.x; float* ph = &hn4.x;
                 const float* gr = &gir.x; const float* gz = &giz.x; const float* gn = &gin.x;
                 const float* cbr = &br.x; const float* cbz = &bz.x; const float* cbn = &bn.x;
 #pragma unroll
@@ -131,100 +251,92 @@ __global__ __launch_bounds__(NT, 1) void gru_fwd_cluster_kernel(const float* __r
                     const float zz = sigmoidf_(gz[u] + az[u] + cbz[u]);
                     const float qq = an[u] + cbn[u];
                     const float nn = tanhf_(gn[u] + rr * qq);
-                    pr[u] = rr; pz[u] = zz; pn[u] = nn; pq[u] = qq;
+                    pr4[u] = rr; pz4[u] = zz; pn4[u] = nn; pq4[u] = qq;
                     ph[u] = (1.f - zz) * nn + zz * hpp[u];
                 }
-                *reinterpret_cast<float4*>(y + (long)(b * T + t) * 2 * H + dir * H + j) = hn4;
-                if (rs) {
-                    float* rp = rs + ((long)(b * T + t) * 2 + dir) * 4 * H + j;
-                    *reinterpret_cast<float4*>(rp) = r4;
-                    *reinterpret_cast<float4*>(rp + H) = z4;
-                    *reinterpret_cast<float4*>(rp + 2 * H) = n4;
-                    *reinterpret_cast<float4*>(rp + 3 * H) = q4;
-                }
+                d_h = hn4;
+                d_bt = (long)b * T + t;                                   // stored after the next step's last poll
             }
-            *reinterpret_cast<float4*>(&hs[lb * LDH + j]) = hn4;       // own columns of h_{s+1} (zeros for padded batch rows)
-            if (s + 1 < T && dbg != 2) {                               // publish: 4 floats = 2 granule pairs = 2 x 16 B
+            if (s + 1 < T && !(dbg & 2)) {                                // publish first: 4 floats = 2 granule pairs = 2 x 16 B
                 const int go = (((s & 1) * 16 + lb) * HP + j) * 8;
-                const unsigned tag = (unsigned)(s + 1);
-                store_granule_pair(xr, go, tag, hn4.x, hn4.y);
-                store_granule_pair(xr, go + 16, tag, hn4.z, hn4.w);
-            }
-        }
-        // ---- gather the other members' columns of h_{s+1} ----
-        if (s + 1 < T && dbg != 2) {
-            const unsigned tag = (unsigned)(s + 1);
-            const int sbase = (s & 1) * 16 * HP;                      // granule index of this parity's slot
-            constexpr int NPMAX = (16 * (H - 32) / 2 + NT - 1) / NT;  // granule PAIRS per thread (upper bound)
-            const int npair = nother / 2;                             // own / foreign ranges are multiples of 4 units
-            int off[NPMAX];                                           // granule index (b * HP + k) of the pair's first float
-#pragma unroll
-            for (int i = 0; i < NPMAX; ++i) {
-                const int p = tid + i * NT;
-                if (p < 16 * npair) {
-                    const int bb = p / npair, kk = (p % npair) * 2;
-                    off[i] = bb * HP + (kk < k0 ? kk : kk + nown);
-                } else off[i] = -1;
-            }
-            float v0[NPMAX], v1[NPMAX];
-            for (unsigned spins = 0;; ++spins) {
-                bool ok = true;
-#pragma unroll
-                for (int i = 0; i < NPMAX; ++i)
-                    if (off[i] >= 0) {
-                        const u32x4 x = load_granule_pair(xr, (sbase + off[i]) * 8);
-                        v0[i] = __uint_as_float(x[0]); v1[i] = __uint_as_float(x[2]);
-                        ok = ok && x[1] == tag && x[3] == tag;
-                    }
-                if (__all(ok) || dbg == 1) break;
-                if (spins > SPIN_LIMIT) { if (lane == 0) atomicExch(err, 1); break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-#pragma unroll
-            for (int i = 0; i < NPMAX; ++i)
-                if (off[i] >= 0) {
-                    float* d = &hs[(off[i] / HP) * LDH + (off[i] % HP)];
-                    d[0] = v0[i]; d[1] = v1[i];
+                const unsigned ptag = tag0 + (unsigned)(s + 1);
+                if (fast) {
+                    store_granule_pair<0>(xr, go, ptag, hn4.x, hn4.y);
+                    store_granule_pair<0>(xr, go + 16, ptag, hn4.z, hn4.w);
+                } else {
+                    store_granule_pair<16>(xr, go, ptag, hn4.x, hn4.y);
+                    store_granule_pair<16>(xr, go + 16, ptag, hn4.z, hn4.w);
                 }
+            }
         }
+        if (tile_on) *reinterpret_cast<float4*>(&hs[lb * LDH + j]) = hn4;        // own columns of h_{s+1} (zeros for padded rows / units)
+        gir = gir_n; giz = giz_n; gin = gin_n;
     }
+    HA2G_FWD_PREFETCH_FLUSH(T)                                            // the last step's outputs
+#undef HA2G_NB
+}
+
+__global__ __launch_bounds__(NT, 1) void gru_fwd_cluster_kernel(const float* __restrict__ gi,      // [B][T][2][3H]
+                                                                const float* __restrict__ wp,      // packed fwd images, 2 dirs
+                                                                const float* __restrict__ bhh0, const float* __restrict__ bhh1,
+                                                                float* __restrict__ y,             // [B][T][2H]
+                                                                float* __restrict__ rs,            // [B][T][2][4][H] or null
+                                                                u64* __restrict__ xch, const unsigned* __restrict__ epoch,
+                                                                int* __restrict__ err, int B, int T, int tile0, int nclusters, int dbg) {
+    __shared__ __attribute__((aligned(16))) float hs[16 * LDH];
+    __shared__ int sh[8];
+    // block -> (cluster, member): the G members of a cluster share blockIdx % 8, i.e. (observed) one XCD -- speed only
+    const int id = blockIdx.x, xcd = id & 7, r = id >> 3;
+    const int q = r % G, c = (r / G) * 8 + xcd;
+    if (c >= nclusters) return;
+    const int dir = c & 1, b0 = (tile0 + (c >> 1)) * 16;
+    u64* xc = xch + (long)c * CL_GRAN;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xc, 0, (int)(CL_GRAN * 8), 0x00020000);
+    const unsigned tag0 = *epoch * 64u;
+    int fast = cluster_same_xcd(xr, (int)(BWD_GRAN * 8), q, tag0 + 63u, err, sh);
+    if (dbg & 4) fast = 0;
+    const float* bhh = dir ? bhh1 : bhh0;
+#define HA2G_FWD_CALL(QQ, PP) gru_fwd_member<QQ, PP>(gi, wp, bhh, y, rs, xr, err, B, T, dir, b0, tag0, fast, dbg, hs)
+#define HA2G_FWD_SWITCH(PP)                                                                                       \
+    switch (q) {                                                                                                  \
+        case 0: HA2G_FWD_CALL(0, PP); break; case 1: HA2G_FWD_CALL(1, PP); break; case 2: HA2G_FWD_CALL(2, PP); break; \
+        case 3: HA2G_FWD_CALL(3, PP); break; default: HA2G_FWD_CALL(4, PP); break;                                \
+    }
+    // polls issued after ALL own blocks (PA = 4): measured 6.16 us/step vs 6.53 / 6.39 / 6.26 for PA = 2 / 1 / 3 -- an earlier poll mostly
+    // returns the previous step's granules (publish -> L2-visible takes longer than the 0.77 us of own-block MFMAs) and the re-poll costs more
+    HA2G_FWD_SWITCH(4)
 }
 
 
 // ---- backward (BPTT), cluster form -------------------------------------------------------------------------------------
 // Member q owns hidden units [64q, 64q+64).  Per step (reverse of the forward order):
 //   phase 1  gate gradients of the OWN units (one (row, 4-unit) group per thread): dg -> HBM, d gh -> LDS, dh*z kept in regs;
-//   phase 2  partial[b][k] = sum_{gate, j in own} dgh[b][gate,j] * W_hh[gate*H+j][k] for ALL k on MFMA, with the member's
+//            its operands (dy, the four reserve planes, h_prev) are prefetched one step ahead;
+//   phase 2  partial[b][k] = sum_{gate, j in own} dgh[b][gate,j] * W_hh[gate*H + j][k] for ALL k on MFMA, with the member's
 //            slice of W_hh (the same 192 rows as in the forward) resident in registers as 60 transposed fragments per wave;
-//   exchange the 64-column block of `partial` that belongs to member p is sent to p (granule pairs, 16-byte sc1 stores);
-//            every member adds the five blocks of its own columns in member order (fixed => deterministic):
+//            the 64-column blocks that belong to the OTHER members are computed and published first (ring order), the own
+//            block last, so the granules travel while the own block's MFMAs issue;
+//   exchange every member adds the five blocks of its own columns in member order (fixed => deterministic):
 //            carry' = dh*z + sum_src partial_src.   The carry never leaves the owning thread's registers.
 constexpr int LDG = 3 * 64 + 4;      // LDS row stride of the own d gh tile [16][3][64]
 constexpr int LDP = 64 + 4;
+constexpr int NKW = (NJT + TPW - 1) / TPW;             // k-tiles per wave (5): wave w serves k-tiles w, w+4, ... = one per member
 
-__global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __restrict__ dy,      // [B][T][2H]
-                                                                const float* __restrict__ y,       // [B][T][2H]
-                                                                const float* __restrict__ rs,      // [B][T][2][4][H]
-                                                                const float* __restrict__ wpt,     // packed bwd images, 2 dirs
-                                                                float* __restrict__ dg,            // [B][T][2][4H]
-                                                                u64* __restrict__ xch, int* __restrict__ err, int B, int T,
-                                                                int tile0, int nclusters, int dbg) {
-    __shared__ __attribute__((aligned(16))) float sg[16 * LDG];
-    __shared__ __attribute__((aligned(16))) float sp[16 * LDP];
-    const int id = blockIdx.x, xcd = id & 7, r = id >> 3;
-    const int q = r % G, c = (r / G) * 8 + xcd;
-    if (c >= nclusters) return;
-    const int dir = c & 1, b0 = (tile0 + (c >> 1)) * 16;
+template <int Q, int PB>
+__device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ rs,
+                                               const float* __restrict__ wpt, float* __restrict__ dg, const __amdgpu_buffer_rsrc_t xr,
+                                               int* __restrict__ err, const int B, const int T, const int dir, const int b0,
+                                               const unsigned tag0, const int fast, const int dbg, float* __restrict__ sg,
+                                               float* __restrict__ sp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lb = lane & 15, g = lane >> 4;
-    const int k0 = q * 64;                                  // first own unit
+    constexpr int k0 = Q * 64;                              // first own unit
     // phase-1 / gather ownership: thread -> (batch row bb, units k0 + jl4 .. +3)
     const int bb = tid >> 4, jl4 = (tid & 15) * 4;
     const int jo = k0 + jl4, bo = b0 + bb;
     const bool own_ok = jo < H && bo < B;
 
-    // ---- resident transposed W_hh fragments: wave w serves k-tiles w, w+4, ... ; own j-tiles jt0..jt0+3 ----
-    constexpr int NKW = (NJT + TPW - 1) / TPW;             // k-tiles per wave (5)
+    // ---- resident transposed W_hh fragments: wave w serves k-tiles w, w+4, ... ; own j-tiles 4Q..4Q+3 ----
     float4 wf[NKW * 3 * TPW];
     {
         const float4* base = reinterpret_cast<const float4*>(wpt) + (long)dir * (NJT * 3 * NJT) * 64 + lane;
@@ -234,7 +346,7 @@ __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __r
             for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
                 for (int jl = 0; jl < TPW; ++jl) {
-                    const int kt = wave + kk * TPW, jt = q * TPW + jl;
+                    const int kt = wave + kk * TPW, jt = Q * TPW + jl;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (kt < NJT && jt < NJT) v = base[((long)(kt * 3 + gate) * NJT + jt) * 64];
                     wf[(kk * 3 + gate) * TPW + jl] = v;
@@ -242,30 +354,61 @@ __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __r
     }
     for (int i = tid; i < 16 * LDG; i += NT) sg[i] = 0.f;
     for (int i = tid; i < 16 * LDP; i += NT) sp[i] = 0.f;
-    u64* xc = xch + (long)c * 2 * G * G * 16 * 64;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xc, 0, 2 * G * G * 16 * 64 * 8, 0x00020000);
-    float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 carry = zero4;
+
+    // operands of the step whose gate gradients run next (prefetched during the previous step's MFMA phase)
+    float4 n_dy = zero4, n_r = zero4, n_z = zero4, n_n = zero4, n_q = zero4, n_hp = zero4;
+#define HA2G_BWD_LOAD(S)                                                                                          \
+    if (own_ok && (S) < T) {                                                                                      \
+        const int t_ = dir ? (S) : T - 1 - (S);                                                                   \
+        const int tp_ = dir ? t_ + 1 : t_ - 1;                                                                    \
+        const long bt_ = (long)bo * T + t_;                                                                       \
+        n_dy = *reinterpret_cast<const float4*>(dy + bt_ * 2 * H + dir * H + jo);                                 \
+        const float* rp_ = rs + (bt_ * 2 + dir) * 4 * H + jo;                                                     \
+        n_r = *reinterpret_cast<const float4*>(rp_);                                                              \
+        n_z = *reinterpret_cast<const float4*>(rp_ + H);                                                          \
+        n_n = *reinterpret_cast<const float4*>(rp_ + 2 * H);                                                      \
+        n_q = *reinterpret_cast<const float4*>(rp_ + 3 * H);                                                      \
+        n_hp = (tp_ >= 0 && tp_ < T) ? *reinterpret_cast<const float4*>(y + ((long)bo * T + tp_) * 2 * H + dir * H + jo) : zero4; \
+    }
+    HA2G_BWD_LOAD(0)
+    lds_barrier();
+
+    // one k-tile (destination member KK) of the partial product; published unless it is the own block
+#define HA2G_BWD_KTILE(KK)                                                                                        \
+    if (wave + (KK) * TPW < NJT) {                                                                                \
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;                                                        \
+        _Pragma("unroll") for (int jl = 0; jl < TPW; ++jl) {                                                      \
+            const float* w0 = &wf[((KK) * 3 + 0) * TPW + jl].x; const float* w1 = &wf[((KK) * 3 + 1) * TPW + jl].x; \
+            const float* w2 = &wf[((KK) * 3 + 2) * TPW + jl].x;                                                   \
+            const float* d0 = &bop[jl].x; const float* d1 = &bop[TPW + jl].x; const float* d2 = &bop[2 * TPW + jl].x; \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                       \
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[u], d0[u], a0, 0, 0, 0);                             \
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[u], d1[u], a1, 0, 0, 0);                             \
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[u], d2[u], a2, 0, 0, 0);                             \
+            }                                                                                                     \
+        }                                                                                                         \
+        const float p0 = a0[0] + a1[0] + a2[0], p1 = a0[1] + a1[1] + a2[1], p2 = a0[2] + a1[2] + a2[2], p3 = a0[3] + a1[3] + a2[3]; \
+        const int kl = 16 * wave + 4 * g;                        /* column within the destination's 64-column block */ \
+        if ((KK) == Q) {                                                                                          \
+            *reinterpret_cast<float4*>(&sp[lb * LDP + kl]) = make_float4(p0, p1, p2, p3);                         \
+        } else if (!(dbg & 2)) {                                                                                  \
+            const int go = (((((s & 1) * G + (KK)) * G + Q) * 16 + lb) * 64 + kl) * 8;                            \
+            if (fast) { store_granule_pair<0>(xr, go, tag, p0, p1); store_granule_pair<0>(xr, go + 16, tag, p2, p3); } \
+            else { store_granule_pair<16>(xr, go, tag, p0, p1); store_granule_pair<16>(xr, go + 16, tag, p2, p3); } \
+        }                                                                                                         \
+    }
 
     for (int s = 0; s < T; ++s) {
         const int t = dir ? s : T - 1 - s;
-        const int tp = dir ? t + 1 : t - 1;
-        const bool has_prev = tp >= 0 && tp < T;
         // ---- phase 1 ----
-        float4 dar = make_float4(0.f, 0.f, 0.f, 0.f), daz = dar, dghn = dar, dhz = dar;
+        float4 dar = zero4, daz = zero4, dghn = zero4, dhz = zero4;
         if (own_ok) {
             const long bt = (long)bo * T + t;
-            const float4 dy4 = *reinterpret_cast<const float4*>(dy + bt * 2 * H + dir * H + jo);
-            const float* rp = rs + (bt * 2 + dir) * 4 * H + jo;
-            const float4 r4 = *reinterpret_cast<const float4*>(rp);
-            const float4 z4 = *reinterpret_cast<const float4*>(rp + H);
-            const float4 n4 = *reinterpret_cast<const float4*>(rp + 2 * H);
-            const float4 q4 = *reinterpret_cast<const float4*>(rp + 3 * H);
-            float4 hp4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (has_prev) hp4 = *reinterpret_cast<const float4*>(y + ((long)bo * T + tp) * 2 * H + dir * H + jo);
             float4 dan;
-            const float* pdy = &dy4.x; const float* pr = &r4.x; const float* pz = &z4.x; const float* pn = &n4.x;
-            const float* pq = &q4.x; const float* php = &hp4.x; const float* pc = &carry.x;
+            const float* pdy = &n_dy.x; const float* pr = &n_r.x; const float* pz = &n_z.x; const float* pn = &n_n.x;
+            const float* pq = &n_q.x; const float* php = &n_hp.x; const float* pc = &carry.x;
             float* o_r = &dar.x; float* o_z = &daz.x; float* o_n = &dan.x; float* o_q = &dghn.x; float* o_c = &dhz.x;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -289,23 +432,35 @@ __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __r
         *reinterpret_cast<float4*>(&sg[bb * LDG + jl4]) = dar;
         *reinterpret_cast<float4*>(&sg[bb * LDG + 64 + jl4]) = daz;
         *reinterpret_cast<float4*>(&sg[bb * LDG + 128 + jl4]) = dghn;
-        __syncthreads();
-        // ---- phase 2: partial sums for all k from the own units ----
+        lds_barrier();
+        HA2G_BWD_LOAD(s + 1)                                // next step's operands: in flight during the MFMA phase
+        // ---- phase 2: partial sums for all k from the own units; foreign destinations first ----
         float4 bop[3 * TPW];
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
             for (int jl = 0; jl < TPW; ++jl) bop[gate * TPW + jl] = *reinterpret_cast<const float4*>(&sg[lb * LDG + gate * 64 + 16 * jl + 4 * g]);
-        const unsigned tag = (unsigned)(s + 1);
+        const unsigned tag = tag0 + (unsigned)(s + 1);
+        HA2G_BWD_KTILE((Q + 1) % G)
+        HA2G_BWD_KTILE((Q + 2) % G)
+        HA2G_BWD_KTILE((Q + 3) % G)
+        HA2G_BWD_KTILE((Q + 4) % G)
+        // own block last: the four foreign blocks are travelling; the gather loads are issued after PB of its 4 j-tiles
+        u32x4 gx0[G], gx1[G];                                // statically indexed only (member Q's slot stays unused)
+#define HA2G_BWD_GATHER_ISSUE                                                                                     \
+        _Pragma("unroll") for (int src = 0; src < G; ++src) {                                                     \
+            if (src == Q || jo >= H || (dbg & 2)) continue;      /* columns >= H (padding of the last block) are never published */ \
+            const int go_ = (((((s & 1) * G + Q) * G + src) * 16 + bb) * 64 + jl4) * 8;                           \
+            gx0[src] = load_granule_pair(xr, go_); gx1[src] = load_granule_pair(xr, go_ + 16);                    \
+        }
 #pragma unroll
-        for (int kk = 0; kk < NKW; ++kk) {
-            const int kt = wave + kk * TPW;
-            if (kt >= NJT) continue;
+        for (int src = 0; src < G; ++src) { gx0[src] = u32x4{0u, 0u, 0u, 0u}; gx1[src] = gx0[src]; }
+        if (wave + Q * TPW < NJT) {
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
 #pragma unroll
             for (int jl = 0; jl < TPW; ++jl) {
-                const float* w0 = &wf[(kk * 3 + 0) * TPW + jl].x; const float* w1 = &wf[(kk * 3 + 1) * TPW + jl].x;
-                const float* w2 = &wf[(kk * 3 + 2) * TPW + jl].x;
+                const float* w0 = &wf[(Q * 3 + 0) * TPW + jl].x; const float* w1 = &wf[(Q * 3 + 1) * TPW + jl].x;
+                const float* w2 = &wf[(Q * 3 + 2) * TPW + jl].x;
                 const float* d0 = &bop[jl].x; const float* d1 = &bop[TPW + jl].x; const float* d2 = &bop[2 * TPW + jl].x;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -313,49 +468,100 @@ __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __r
                     a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[u], d1[u], a1, 0, 0, 0);
                     a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[u], d2[u], a2, 0, 0, 0);
                 }
+                if (jl == PB - 1) { HA2G_BWD_GATHER_ISSUE }
             }
-            const float p0 = a0[0] + a1[0] + a2[0], p1 = a0[1] + a1[1] + a2[1], p2 = a0[2] + a1[2] + a2[2], p3 = a0[3] + a1[3] + a2[3];
-            const int dst = kt / TPW, kl = 16 * (kt % TPW) + 4 * g;      // owner of these columns, column within its block
-            if (dst == q) {
-                *reinterpret_cast<float4*>(&sp[lb * LDP + kl]) = make_float4(p0, p1, p2, p3);
-            } else if (dbg != 2) {
-                const int go = (((((s & 1) * G + dst) * G + q) * 16 + lb) * 64 + kl) * 8;
-                store_granule_pair(xr, go, tag, p0, p1);
-                store_granule_pair(xr, go + 16, tag, p2, p3);
-            }
+            *reinterpret_cast<float4*>(&sp[lb * LDP + 16 * wave + 4 * g]) =
+                make_float4(a0[0] + a1[0] + a2[0], a0[1] + a1[1] + a2[1], a0[2] + a1[2] + a2[2], a0[3] + a1[3] + a2[3]);
+        } else {
+            HA2G_BWD_GATHER_ISSUE
         }
-        __syncthreads();
+        lds_barrier();
         // ---- gather: carry' = dh*z + sum over members (ascending) of their partial for my 4 units ----
-        float4 part[G];                                      // statically indexed only (member q's slot stays unused)
+        float4 part[G];
         const float4 own_part = *reinterpret_cast<const float4*>(&sp[bb * LDP + jl4]);
-        if (dbg != 2) {
+        if (!(dbg & 2)) {
             for (unsigned spins = 0;; ++spins) {
                 bool ok = true;
 #pragma unroll
                 for (int src = 0; src < G; ++src) {
-                    // columns >= H (the padding of the last member's block) are never published: do not wait for them
-                    if (src == q || jo >= H) { part[src] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
-                    const int go = (((((s & 1) * G + q) * G + src) * 16 + bb) * 64 + jl4) * 8;
-                    const u32x4 x0 = load_granule_pair(xr, go), x1 = load_granule_pair(xr, go + 16);
+                    if (src == Q || jo >= H) { part[src] = zero4; continue; }
+                    const u32x4 x0 = gx0[src], x1 = gx1[src];
                     part[src] = make_float4(__uint_as_float(x0[0]), __uint_as_float(x0[2]), __uint_as_float(x1[0]), __uint_as_float(x1[2]));
                     ok = ok && x0[1] == tag && x0[3] == tag && x1[1] == tag && x1[3] == tag;
                 }
-                if (__all(ok) || dbg == 1) break;
+                if (__all(ok) || (dbg & 1)) break;
                 if (spins > SPIN_LIMIT) { if (lane == 0) atomicExch(err, 1); break; }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
+                HA2G_BWD_GATHER_ISSUE
             }
         } else {
 #pragma unroll
-            for (int src = 0; src < G; ++src) part[src] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int src = 0; src < G; ++src) part[src] = zero4;
         }
         carry = dhz;
 #pragma unroll
         for (int src = 0; src < G; ++src) {
-            const float4 p = (src == q) ? own_part : part[src];
+            const float4 p = (src == Q) ? own_part : part[src];
             carry.x += p.x; carry.y += p.y; carry.z += p.z; carry.w += p.w;
         }
-        if (!own_ok) carry = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!own_ok) carry = zero4;
     }
+}
+
+__global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __restrict__ dy,      // [B][T][2H]
+                                                                const float* __restrict__ y,       // [B][T][2H]
+                                                                const float* __restrict__ rs,      // [B][T][2][4][H]
+                                                                const float* __restrict__ wpt,     // packed bwd images, 2 dirs
+                                                                float* __restrict__ dg,            // [B][T][2][4H]
+                                                                u64* __restrict__ xch, const unsigned* __restrict__ epoch,
+                                                                int* __restrict__ err, int B, int T, int tile0, int nclusters, int dbg) {
+    __shared__ __attribute__((aligned(16))) float sg[16 * LDG];
+    __shared__ __attribute__((aligned(16))) float sp[16 * LDP];
+    __shared__ int sh[8];
+    const int id = blockIdx.x, xcd = id & 7, r = id >> 3;
+    const int q = r % G, c = (r / G) * 8 + xcd;
+    if (c >= nclusters) return;
+    const int dir = c & 1, b0 = (tile0 + (c >> 1)) * 16;
+    u64* xc = xch + (long)c * CL_GRAN;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xc, 0, (int)(CL_GRAN * 8), 0x00020000);
+    const unsigned tag0 = *epoch * 64u;
+    int fast = cluster_same_xcd(xr, (int)(BWD_GRAN * 8), q, tag0 + 63u, err, sh);
+    if (dbg & 4) fast = 0;
+#define HA2G_BWD_CALL(QQ, PP) gru_bwd_member<QQ, PP>(dy, y, rs, wpt, dg, xr, err, B, T, dir, b0, tag0, fast, dbg, sg, sp)
+#define HA2G_BWD_SWITCH(PP)                                                                                       \
+    switch (q) {                                                                                                  \
+        case 0: HA2G_BWD_CALL(0, PP); break; case 1: HA2G_BWD_CALL(1, PP); break; case 2: HA2G_BWD_CALL(2, PP); break; \
+        case 3: HA2G_BWD_CALL(3, PP); break; default: HA2G_BWD_CALL(4, PP); break;                                \
+    }
+    HA2G_BWD_SWITCH(4)                                       // gather loads after the own block (5.81 vs 5.86-5.93 us/step for earlier issue)
+}
+
+// Launch epoch in device memory (a captured hipGraph must draw a new one on every replay).  On the (practically never
+// reached) wrap the single block also clears every tag, so an old launch's granules cannot alias a new epoch.
+__global__ __launch_bounds__(1024) void cluster_epoch_kernel(unsigned* __restrict__ epoch, u64* __restrict__ xch) {
+    __shared__ unsigned e;
+    if (threadIdx.x == 0) e = *epoch + 1u;
+    __syncthreads();
+    if (e >= EPOCH_WRAP) {
+        for (long i = threadIdx.x; i < XCH_BYTES / 8; i += 1024) xch[i] = 0ull;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) e = 1u;
+    }
+    if (threadIdx.x == 0) *epoch = e;
+}
+
+int device_tile_cap() {
+    static int cap[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cap[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        int t = cus / (2 * G);
+        cap[dev] = t > MAX_TILES ? MAX_TILES : (t < 1 ? -1 : t);
+    }
+    return cap[dev] < 0 ? 0 : cap[dev];
 }
 
 }  // namespace
@@ -364,24 +570,30 @@ static int g_dbg = 0;
 extern "C" {
 
 void ha2g_gru_cluster_debug(int m) { g_dbg = m; }
-long ha2g_gru_cluster_workspace_bytes(void) { return (long)MAX_TILES * 2 * 2 * G * G * 16 * 64 * 8 + 64; }   /* sized for the backward's per-pair slots */
-int ha2g_gru_cluster_supported(int H_) { return H_ == H; }
+/* exchange granules of 48 clusters + the device-side launch epoch (last 64 bytes); must be zero-initialised ONCE by the caller */
+long ha2g_gru_cluster_workspace_bytes(void) { return XCH_BYTES + 64; }
+int ha2g_gru_cluster_max_steps(void) { return MAX_STEPS; }
+/* H = 300 and a device (partition) with at least 2 G = 10 compute units: every workgroup of a launch must be co-resident */
+int ha2g_gru_cluster_supported(int H_) { return H_ == H && device_tile_cap() >= 1; }
 
-// Same contract as ha2g_gru_layer_fwd (H = 300 only) plus: xch = scratch of ha2g_gru_cluster_workspace_bytes() bytes,
-// err = device int32 set to 1 if a hand-off timed out (results are then invalid; the kernel still terminates).
+// Same contract as ha2g_gru_layer_fwd (H = 300, T <= 62) plus: xch = scratch of ha2g_gru_cluster_workspace_bytes() bytes, zeroed
+// once at allocation; err = device int32 set to 1 if a hand-off timed out (results are then invalid; the kernel still terminates).
 int ha2g_gru_layer_fwd_cluster(const float* gi, const float* wp, const float* bhh_fwd, const float* bhh_rev, float* y, float* rs,
                                void* xch, int* err, int B, int T, int H_, void* stream) {
     HA2G_REQUIRE(H_ == H, "gru cluster kernel: H=%d not instantiated (300)", H_);
+    HA2G_REQUIRE(T <= MAX_STEPS, "gru cluster kernel: T=%d > %d steps", T, MAX_STEPS);
+    const int cap = device_tile_cap();
+    HA2G_REQUIRE(cap >= 1, "gru cluster kernel: the device has fewer than %d compute units", 2 * G);
     hipStream_t st = (hipStream_t)stream;
     if (B == 0 || T == 0) return 0;
+    unsigned* epoch = (unsigned*)((char*)xch + XCH_BYTES);
     const int tiles = ceil_div(B, 16);
-    for (int t0 = 0; t0 < tiles; t0 += MAX_TILES) {
-        const int nt = tiles - t0 < MAX_TILES ? tiles - t0 : MAX_TILES;
+    for (int t0 = 0; t0 < tiles; t0 += cap) {
+        const int nt = tiles - t0 < cap ? tiles - t0 : cap;
         const int nclusters = nt * 2;
-        hipError_t e = hipMemsetAsync(xch, 0, (size_t)nclusters * 2 * 16 * HP * 8, st);
-        if (e != hipSuccess) return ha2g_set_error(-2, "gru cluster: memset failed: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(cluster_epoch_kernel, dim3(1), dim3(1024), 0, st, epoch, (u64*)xch);
         const int grid = ceil_div(nclusters, 8) * 8 * G;
-        hipLaunchKernelGGL(gru_fwd_cluster_kernel, dim3(grid), dim3(NT), 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, (u64*)xch, err, B, T,
+        hipLaunchKernelGGL(gru_fwd_cluster_kernel, dim3(grid), dim3(NT), 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, (u64*)xch, epoch, err, B, T,
                            t0, nclusters, g_dbg);
         HA2G_CHECK_LAUNCH("gru_layer_fwd_cluster");
     }
@@ -392,16 +604,19 @@ int ha2g_gru_layer_fwd_cluster(const float* gi, const float* wp, const float* bh
 int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, void* xch, int* err,
                                int B, int T, int H_, void* stream) {
     HA2G_REQUIRE(H_ == H, "gru cluster kernel: H=%d not instantiated (300)", H_);
+    HA2G_REQUIRE(T <= MAX_STEPS, "gru cluster kernel: T=%d > %d steps", T, MAX_STEPS);
+    const int cap = device_tile_cap();
+    HA2G_REQUIRE(cap >= 1, "gru cluster kernel: the device has fewer than %d compute units", 2 * G);
     hipStream_t st = (hipStream_t)stream;
     if (B == 0 || T == 0) return 0;
+    unsigned* epoch = (unsigned*)((char*)xch + XCH_BYTES);
     const int tiles = ceil_div(B, 16);
-    for (int t0 = 0; t0 < tiles; t0 += MAX_TILES) {
-        const int nt = tiles - t0 < MAX_TILES ? tiles - t0 : MAX_TILES;
+    for (int t0 = 0; t0 < tiles; t0 += cap) {
+        const int nt = tiles - t0 < cap ? tiles - t0 : cap;
         const int nclusters = nt * 2;
-        hipError_t e = hipMemsetAsync(xch, 0, (size_t)nclusters * 2 * G * G * 16 * 64 * 8, st);
-        if (e != hipSuccess) return ha2g_set_error(-2, "gru cluster: memset failed: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(cluster_epoch_kernel, dim3(1), dim3(1024), 0, st, epoch, (u64*)xch);
         const int grid = ceil_div(nclusters, 8) * 8 * G;
-        hipLaunchKernelGGL(gru_bwd_cluster_kernel, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, (u64*)xch, err, B, T, t0, nclusters, g_dbg);
+        hipLaunchKernelGGL(gru_bwd_cluster_kernel, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, (u64*)xch, epoch, err, B, T, t0, nclusters, g_dbg);
         HA2G_CHECK_LAUNCH("gru_layer_bwd_cluster");
     }
     return 0;

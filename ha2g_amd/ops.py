@@ -585,7 +585,7 @@ class Ha2gClusterError(RuntimeError):
 
 
 def _gru_layer_bwd(dy, y, rs, pkt, dg, B, T, H, st, device):
-    if USE_GRU_CLUSTER and lib.ha2g_gru_cluster_supported(H):
+    if USE_GRU_CLUSTER and lib.ha2g_gru_cluster_supported(H) and T <= lib.ha2g_gru_cluster_max_steps():
         xch, err = _cluster_scratch(device)
         check(lib.ha2g_gru_layer_bwd_cluster(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pkt.data_ptr(), dg.data_ptr(), xch.data_ptr(),
                                              err.data_ptr(), B, T, H, st))
@@ -594,7 +594,7 @@ def _gru_layer_bwd(dy, y, rs, pkt, dg, B, T, H, st, device):
 
 
 def _gru_layer_fwd(gi, pk, bf, br, y, rs, B, T, H, st, device):
-    if USE_GRU_CLUSTER and lib.ha2g_gru_cluster_supported(H):
+    if USE_GRU_CLUSTER and lib.ha2g_gru_cluster_supported(H) and T <= lib.ha2g_gru_cluster_max_steps():
         xch, err = _cluster_scratch(device)
         check(lib.ha2g_gru_layer_fwd_cluster(gi.data_ptr(), pk.data_ptr(), bf.data_ptr(), br.data_ptr(), y.data_ptr(), _p(rs),
                                              xch.data_ptr(), err.data_ptr(), B, T, H, st))
@@ -625,8 +625,10 @@ class BiGRUFunction(torch.autograd.Function):
             K = inp.shape[2]
             gi = torch.empty(B * T, 6 * H, dtype=torch.float32, device=dev)
             x2 = inp.view(B * T, K)
-            gemm(x2, w[0], transb=True, out=gi[:, :3 * H], bias=w[2])
-            gemm(x2, w[4], transb=True, out=gi[:, 3 * H:], bias=w[6])
+            tkey = 'gemm_gi' if (H == 300 and l > 0) else 'gemm_gi_other'
+            fl = 2.0 * B * T * K * 3 * H
+            ktimer.launch(tkey, lambda: gemm(x2, w[0], transb=True, out=gi[:, :3 * H], bias=w[2]), fl)
+            ktimer.launch(tkey, lambda: gemm(x2, w[4], transb=True, out=gi[:, 3 * H:], bias=w[6]), fl)
             pk = torch.empty(4, npk, dtype=torch.float32, device=dev)     # [fwd-form f, r | bwd-form f, r]
             check(lib.ha2g_gru_pack_whh(w[1].data_ptr(), pk[0].data_ptr(), pk[2].data_ptr(), H, st))
             check(lib.ha2g_gru_pack_whh(w[5].data_ptr(), pk[1].data_ptr(), pk[3].data_ptr(), H, st))

@@ -88,16 +88,23 @@ int ha2g_gru_bias_grads_f32(const float* colsums, float* dbih_fwd, float* dbhh_f
  * y [B][T][2H]; rs (nullable reserve) [B][T][2][4][H] */
 int ha2g_gru_layer_fwd(const float* gi, const float* wp, const float* bhh_fwd, const float* bhh_rev, float* y,
                        float* rs, int B, int T, int H, void* stream);
-/* Workgroup-cluster form of the forward recurrence (H = 300): 5 workgroups per (16-row tile, direction) keep their slice
- * of W_hh in registers and all-gather h every step through 8-byte {tag,value} granules.  xch: scratch of
- * ha2g_gru_cluster_workspace_bytes(); err: device int32, set to 1 if a hand-off timed out. */
+/* Workgroup-cluster form of the recurrence (H = 300, T <= ha2g_gru_cluster_max_steps()): 5 workgroups per (16-row tile,
+ * direction) keep their slice of W_hh in registers and all-gather h every step through 8-byte {value, tag} granules; the k-blocks
+ * of the MFMA chain are consumed member by member while the next member's granules are still in flight.
+ * xch: scratch of ha2g_gru_cluster_workspace_bytes(), ZEROED ONCE at allocation (its tail holds the device-side launch epoch that
+ * stamps the tags, so no per-launch clearing and hipGraph replays stay correct); err: device int32, set to 1 if a hand-off timed
+ * out (the step's results are then invalid).  ha2g_gru_cluster_supported(H): H == 300 AND the current device has >= 10 compute
+ * units (every workgroup of a launch must be co-resident; a launch takes CUs/10 batch tiles, at most 24) -- otherwise use
+ * ha2g_gru_layer_fwd / _bwd. */
 long ha2g_gru_cluster_workspace_bytes(void);
+int ha2g_gru_cluster_max_steps(void);
 int ha2g_gru_cluster_supported(int H);
 int ha2g_gru_layer_fwd_cluster(const float* gi, const float* wp, const float* bhh_fwd, const float* bhh_rev, float* y,
                                float* rs, void* xch, int* err, int B, int T, int H, void* stream);
 int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, void* xch,
                                int* err, int B, int T, int H, void* stream);
-void ha2g_gru_cluster_debug(int mode);   /* ablation switch for tools/dbg_cluster.py: 0 normal, 1 no wait, 2 no exchange */
+/* ablation bits for tools/dbg_cluster.py: 1 no wait, 2 no exchange, 4 force the write-through publish */
+void ha2g_gru_cluster_debug(int mode);
 /* dg [B][T][2][4H] = (d gi_r, d gi_z, d gi_n, d gh_n); wpt = packed_bwd images (dir 0, dir 1) */
 int ha2g_gru_layer_bwd(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, int B, int T,
                        int H, void* stream);
