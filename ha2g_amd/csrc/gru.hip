@@ -165,6 +165,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_kernel(const float* __restrict__ d
                                                       const float* __restrict__ rs,      // [B][T][2][4][H]
                                                       const float* __restrict__ wpt,     // [2][NJT*3*NJT][64][4]
                                                       float* __restrict__ dg,            // [B][T][2][4H]
+                                                      float* __restrict__ hpo,           // [B][T][2H] h_prev per step (nullable)
                                                       int B, int T) {
     using C = GruCfg<H>;
     constexpr int NJT = C::NJT, HP = C::HP, LDH = C::LDH, LDG = 3 * HP + 4;
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_kernel(const float* __restrict__ d
                 *reinterpret_cast<float4*>(gp + H) = daz;
                 *reinterpret_cast<float4*>(gp + 2 * H) = dan;
                 *reinterpret_cast<float4*>(gp + 3 * H) = dghn;
+                if (hpo) *reinterpret_cast<float4*>(hpo + bt * 2 * H + dir * H + j) = hp4;
             }
             *reinterpret_cast<float4*>(&sg[bb * LDG + j]) = dar;
             *reinterpret_cast<float4*>(&sg[bb * LDG + HP + j]) = daz;
@@ -337,15 +339,15 @@ int ha2g_gru_layer_fwd(const float* gi, const float* wp, const float* bhh_fwd, c
 // BPTT of one bidirectional layer.  dy/y [B][T][2H], rs from the forward, wpt = packed backward images of both
 // directions; writes dg [B][T][2][4H] = (d gi_r, d gi_z, d gi_n, d gh_n).  Weight/bias/input gradients are
 // batched GEMMs / column sums over dg done by the caller.
-int ha2g_gru_layer_bwd(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, int B, int T, int H,
+int ha2g_gru_layer_bwd(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, float* hp, int B, int T, int H,
                        void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (B == 0 || T == 0) return 0;
     dim3 grid(ceil_div(B, 16), 2), block(NT);
     switch (H) {
-        case 300: hipLaunchKernelGGL(gru_bwd_kernel<300>, grid, block, 0, st, dy, y, rs, wpt, dg, B, T); break;
-        case 64: hipLaunchKernelGGL(gru_bwd_kernel<64>, grid, block, 0, st, dy, y, rs, wpt, dg, B, T); break;
-        case 32: hipLaunchKernelGGL(gru_bwd_kernel<32>, grid, block, 0, st, dy, y, rs, wpt, dg, B, T); break;
+        case 300: hipLaunchKernelGGL(gru_bwd_kernel<300>, grid, block, 0, st, dy, y, rs, wpt, dg, hp, B, T); break;
+        case 64: hipLaunchKernelGGL(gru_bwd_kernel<64>, grid, block, 0, st, dy, y, rs, wpt, dg, hp, B, T); break;
+        case 32: hipLaunchKernelGGL(gru_bwd_kernel<32>, grid, block, 0, st, dy, y, rs, wpt, dg, hp, B, T); break;
         default: return ha2g_set_error(-1, "gru: hidden size %d not instantiated (300, 64, 32)", H);
     }
     HA2G_CHECK_LAUNCH("gru_layer_bwd");

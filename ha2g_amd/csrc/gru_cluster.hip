@@ -324,7 +324,7 @@ constexpr int NKW = (NJT + TPW - 1) / TPW;             // k-tiles per wave (5): 
 
 template <int Q, int PB>
 __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ rs,
-                                               const float* __restrict__ wpt, float* __restrict__ dg, const __amdgpu_buffer_rsrc_t xr,
+                                               const float* __restrict__ wpt, float* __restrict__ dg, float* __restrict__ hpo, const __amdgpu_buffer_rsrc_t xr,
                                                int* __restrict__ err, const int B, const int T, const int dir, const int b0,
                                                const unsigned tag0, const int fast, const int dbg, float* __restrict__ sg,
                                                float* __restrict__ sp) {
@@ -427,6 +427,7 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
             *reinterpret_cast<float4*>(gp + H) = daz;
             *reinterpret_cast<float4*>(gp + 2 * H) = dan;
             *reinterpret_cast<float4*>(gp + 3 * H) = dghn;
+            if (hpo) *reinterpret_cast<float4*>(hpo + bt * 2 * H + dir * H + jo) = n_hp;      // h_prev of this step: the dW_hh GEMM's operand
         }
         if (s + 1 == T) break;                              // the carry out of the last step is never used (h0 is constant)
         *reinterpret_cast<float4*>(&sg[bb * LDG + jl4]) = dar;
@@ -513,6 +514,7 @@ __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __r
                                                                 const float* __restrict__ rs,      // [B][T][2][4][H]
                                                                 const float* __restrict__ wpt,     // packed bwd images, 2 dirs
                                                                 float* __restrict__ dg,            // [B][T][2][4H]
+                                                                float* __restrict__ hpo,           // [B][T][2H] h_prev per step (nullable)
                                                                 u64* __restrict__ xch, const unsigned* __restrict__ epoch,
                                                                 int* __restrict__ err, int B, int T, int tile0, int nclusters, int dbg) {
     __shared__ __attribute__((aligned(16))) float sg[16 * LDG];
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __r
     const unsigned tag0 = *epoch * 64u;
     int fast = cluster_same_xcd(xr, (int)(BWD_GRAN * 8), q, tag0 + 63u, err, sh);
     if (dbg & 4) fast = 0;
-#define HA2G_BWD_CALL(QQ, PP) gru_bwd_member<QQ, PP>(dy, y, rs, wpt, dg, xr, err, B, T, dir, b0, tag0, fast, dbg, sg, sp)
+#define HA2G_BWD_CALL(QQ, PP) gru_bwd_member<QQ, PP>(dy, y, rs, wpt, dg, hpo, xr, err, B, T, dir, b0, tag0, fast, dbg, sg, sp)
 #define HA2G_BWD_SWITCH(PP)                                                                                       \
     switch (q) {                                                                                                  \
         case 0: HA2G_BWD_CALL(0, PP); break; case 1: HA2G_BWD_CALL(1, PP); break; case 2: HA2G_BWD_CALL(2, PP); break; \
@@ -601,7 +603,7 @@ int ha2g_gru_layer_fwd_cluster(const float* gi, const float* wp, const float* bh
 }
 
 // BPTT counterpart (same contract as ha2g_gru_layer_bwd, H = 300 only); wpt = packed backward images of both directions.
-int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, void* xch, int* err,
+int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, float* hp, void* xch, int* err,
                                int B, int T, int H_, void* stream) {
     HA2G_REQUIRE(H_ == H, "gru cluster kernel: H=%d not instantiated (300)", H_);
     HA2G_REQUIRE(T <= MAX_STEPS, "gru cluster kernel: T=%d > %d steps", T, MAX_STEPS);
@@ -616,7 +618,7 @@ int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs,
         const int nclusters = nt * 2;
         hipLaunchKernelGGL(cluster_epoch_kernel, dim3(1), dim3(1024), 0, st, epoch, (u64*)xch);
         const int grid = ceil_div(nclusters, 8) * 8 * G;
-        hipLaunchKernelGGL(gru_bwd_cluster_kernel, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, (u64*)xch, epoch, err, B, T, t0, nclusters, g_dbg);
+        hipLaunchKernelGGL(gru_bwd_cluster_kernel, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, err, B, T, t0, nclusters, g_dbg);
         HA2G_CHECK_LAUNCH("gru_layer_bwd_cluster");
     }
     return 0;

@@ -268,6 +268,10 @@ class Hierarchical_PoseGenerator(nn.Module):
                 z_context = torch.randn(audio_feat_seq.shape[0], self.z_size, device=audio_feat_seq.device)
         else:
             z_mu = z_logvar = z_context = None
+        if self.input_context == 'both' and z_context is not None and pre_seq.is_cuda:
+            # the configuration hierarchy.yml runs: [pre_seq | audio | text | z over time] in one pack kernel
+            output, _ = self.gru(ops.gen_concat(pre_seq, audio_feat_seq, text_feat_seq, z_context), None)
+            return self._row_split(self._head, output), z_context, z_mu, z_logvar
         if self.input_context == 'both':
             parts = [pre_seq, audio_feat_seq, text_feat_seq]
         elif self.input_context == 'audio':

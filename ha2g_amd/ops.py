@@ -584,13 +584,13 @@ class Ha2gClusterError(RuntimeError):
     pass
 
 
-def _gru_layer_bwd(dy, y, rs, pkt, dg, B, T, H, st, device):
+def _gru_layer_bwd(dy, y, rs, pkt, dg, hp, B, T, H, st, device):
     if USE_GRU_CLUSTER and lib.ha2g_gru_cluster_supported(H) and T <= lib.ha2g_gru_cluster_max_steps():
         xch, err = _cluster_scratch(device)
-        check(lib.ha2g_gru_layer_bwd_cluster(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pkt.data_ptr(), dg.data_ptr(), xch.data_ptr(),
+        check(lib.ha2g_gru_layer_bwd_cluster(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pkt.data_ptr(), dg.data_ptr(), hp.data_ptr(), xch.data_ptr(),
                                              err.data_ptr(), B, T, H, st))
     else:
-        check(lib.ha2g_gru_layer_bwd(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pkt.data_ptr(), dg.data_ptr(), B, T, H, st))
+        check(lib.ha2g_gru_layer_bwd(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pkt.data_ptr(), dg.data_ptr(), hp.data_ptr(), B, T, H, st))
 
 
 def _gru_layer_fwd(gi, pk, bf, br, y, rs, B, T, H, st, device):
@@ -668,14 +668,12 @@ class BiGRUFunction(torch.autograd.Function):
             if masks is not None and l < L - 1 and masks[l] is not None:
                 dy = eltwise(OP_MUL, dy, masks[l][sl])
             dg = torch.empty(B * T, 8 * H, dtype=torch.float32, device=dev)        # [dir][r z n hn]
+            # h_prev per direction (forward dir: y[t-1], reverse dir: y[t+1], zero at the sequence ends) is written by the BPTT kernel
+            hp = torch.empty(B, T, 2 * H, dtype=torch.float32, device=dev)
             ktimer.launch('gru_layer_bwd' if H == 300 else 'gru_layer_bwd_other',
-                          lambda: _gru_layer_bwd(dy, y, rs, ctx.packs[l][2], dg, B, T, H, st, dev), B)
+                          lambda: _gru_layer_bwd(dy, y, rs, ctx.packs[l][2], dg, hp, B, T, H, st, dev), B)
             K = inp.shape[2]
             x2 = inp.view(B * T, K)
-            # h_prev per direction: forward dir sees y[t-1], reverse dir sees y[t+1]; zero at the sequence ends
-            hp = torch.zeros(B, T, 2 * H, dtype=torch.float32, device=dev)
-            hp[:, 1:, :H] = y[:, :-1, :H]
-            hp[:, :-1, H:] = y[:, 1:, H:]
             hp2 = hp.view(B * T, 2 * H)
             need_dx = l > 0 or ctx.needs_input_grad[0]
             dx = torch.empty(B * T, K, dtype=torch.float32, device=dev) if need_dx else None
@@ -873,3 +871,115 @@ class ContrastiveFunction(torch.autograd.Function):
 
 def contrastive(a, b, expressive=False):
     return ContrastiveFunction.apply(a, b, expressive)
+
+
+# ------------------------------------------------------------------------------------------------
+# generator input pack / hierarchy scatter / loss assembly (csrc/pack.hip)
+# ------------------------------------------------------------------------------------------------
+
+def scatter_tables(P, Pprev, scatter, device):
+    """(map[P+1], inv[Pprev][2]) int32 device tables of one hierarchy level from the reference's slice assignments
+    `pre_seq_k[:, n:, dst] = out_{k-1}[:, n:, src]` applied in order on the (P+1)-wide pre_seq (python slice semantics, negative
+    bounds included: that is what reproduces the expressive step's one-column shift; a later assignment overwrites an earlier one)."""
+    import numpy as np
+    m = -np.ones(P + 1, np.int32)
+    for dst, src in scatter:
+        m[dst] = np.arange(Pprev, dtype=np.int32)[src]
+    inv = -np.ones((max(Pprev, 1), 2), np.int32)
+    for c, j in enumerate(m):
+        if j >= 0:
+            slot = 0 if inv[j, 0] < 0 else 1
+            assert inv[j, slot] < 0, 'an output column feeds more than two pre_seq columns'
+            inv[j, slot] = c
+    return torch.from_numpy(m).to(device), torch.from_numpy(inv).to(device)
+
+
+class PreSeqFunction(torch.autograd.Function):
+    """pre_seq of one level (train_hierarchy.py:153-169): frames < n_pre carry (target, 1), later frames the coarser level's
+    output through the scatter map; differentiable w.r.t. that output."""
+
+    @staticmethod
+    def forward(ctx, target_k, prev, tables, n_pre):
+        target_k = _f32c(target_k.contiguous())
+        R, T, P = target_k.shape
+        out = torch.empty(R, T, P + 1, dtype=torch.float32, device=target_k.device)
+        Pprev = 0
+        if prev is not None:
+            prev = _f32c(prev.contiguous())
+            Pprev = prev.shape[2]
+        check(lib.ha2g_pre_seq_fwd_f32(target_k.data_ptr(), _p(prev), _p(tables[0]) if prev is not None else 0, out.data_ptr(), R, T, P, Pprev,
+                                       n_pre, _stream()))
+        ctx.geom, ctx.tables = (R, T, P, Pprev, n_pre), tables
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        R, T, P, Pprev, n_pre = ctx.geom
+        if Pprev == 0 or not ctx.needs_input_grad[1]:
+            return None, None, None, None
+        d = _f32c(d.contiguous())
+        dprev = torch.empty(R, T, Pprev, dtype=torch.float32, device=d.device)
+        check(lib.ha2g_pre_seq_bwd_f32(d.data_ptr(), ctx.tables[1].data_ptr(), dprev.data_ptr(), R, T, P, Pprev, n_pre, _stream()))
+        return None, dprev, None, None
+
+
+def pre_seq(target_k, prev, tables, n_pre):
+    return PreSeqFunction.apply(target_k, prev, tables, n_pre)
+
+
+class GenConcatFunction(torch.autograd.Function):
+    """in_data = cat(pre_seq, audio_feat, text_feat, z expanded over time) (model/hierarchy_net.py:121-141, input_context 'both')."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, z):
+        a, b, c, z = (_f32c(t.contiguous()) for t in (a, b, c, z))
+        R, T, Wa = a.shape
+        Wb, Wc, Wz = b.shape[2], c.shape[2], z.shape[1]
+        assert b.shape[:2] == (R, T) and c.shape[:2] == (R, T) and z.shape[0] == R
+        out = torch.empty(R, T, Wa + Wb + Wc + Wz, dtype=torch.float32, device=a.device)
+        check(lib.ha2g_gen_concat_fwd_f32(a.data_ptr(), b.data_ptr(), c.data_ptr(), z.data_ptr(), out.data_ptr(), R, T, Wa, Wb, Wc, Wz, _stream()))
+        ctx.geom = (R, T, Wa, Wb, Wc, Wz)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        R, T, Wa, Wb, Wc, Wz = ctx.geom
+        d = _f32c(d.contiguous())
+        need = ctx.needs_input_grad
+        mk = lambda ok, *shape: torch.empty(*shape, dtype=torch.float32, device=d.device) if ok else None
+        da, db, dc, dz = mk(need[0], R, T, Wa), mk(need[1], R, T, Wb), mk(need[2], R, T, Wc), mk(need[3], R, Wz)
+        check(lib.ha2g_gen_concat_bwd_f32(d.data_ptr(), _p(da), _p(db), _p(dc), _p(dz), R, T, Wa, Wb, Wc, Wz, _stream()))
+        return da, db, dc, dz
+
+
+def gen_concat(a, b, c, z):
+    return GenConcatFunction.apply(a, b, c, z)
+
+
+class WeightedSumFunction(torch.autograd.Function):
+    """sum_i w_i * term_i over 0-dim loss tensors in one launch (train_hierarchy.py:226-262); backward = one launch too."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        import ctypes
+        n = len(terms)
+        terms = [_f32c(t) for t in terms]
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in terms])
+        ws = (ctypes.c_float * n)(*[float(w) for w in weights])
+        out = torch.empty((), dtype=torch.float32, device=terms[0].device)
+        check(lib.ha2g_weighted_sum_f32(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(ws, ctypes.c_void_p), n, out.data_ptr(), _stream()))
+        ctx.weights = [float(w) for w in weights]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        n = len(ctx.weights)
+        ws = (ctypes.c_float * n)(*ctx.weights)
+        out = torch.empty(n, dtype=torch.float32, device=g.device)
+        check(lib.ha2g_weighted_sum_bwd_f32(ctypes.cast(ws, ctypes.c_void_p), n, g.contiguous().data_ptr(), out.data_ptr(), _stream()))
+        return (None,) + tuple(out[i] for i in range(n))
+
+
+def weighted_sum(terms, weights):
+    return WeightedSumFunction.apply(tuple(weights), *terms)

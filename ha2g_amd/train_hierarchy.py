@@ -31,7 +31,10 @@ def _consts(spec, args, device):
                  pairs=torch.tensor(spec['phys_pairs'], dtype=torch.int32, device=device),
                  avg=torch.tensor(spec['phys_avg'], dtype=torch.float32, device=device),
                  var=torch.tensor(spec['phys_var'], dtype=torch.float32, device=device),
-                 cols=[torch.tensor(c, dtype=torch.long, device=device) for c in spec['level_cols']])
+                 cols=[torch.tensor(c, dtype=torch.long, device=device) for c in spec['level_cols']],
+                 # per-level scatter tables of the pre_seq pack kernel (csrc/pack.hip)
+                 tables=[ops.scatter_tables(P, spec['pose_dims'][k - 1] if k else 0, spec['scatter'][k], device)
+                         for k, P in enumerate(spec['pose_dims'])])
         _const_cache[key] = c
     return c
 
@@ -136,7 +139,7 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
             g.gru.grad_slice = (main_at * B, B) if k > 1 else None
             g.eps_block_order = [blocks.index(b) for b in phys]       # logical (reference pass) index of each physical block
         try:
-            outs_all, z_all, mu_all, lv_all = _chain(spec, args, gens, [rep(t) for t in targets], rep(in_text_padded), blend_all, vids_all)
+            outs_all, z_all, mu_all, lv_all = _chain(spec, args, gens, [rep(t) for t in targets], rep(in_text_padded), blend_all, vids_all, consts['tables'])
         finally:
             for g in gens:
                 g.gru.grad_slice = None
@@ -154,7 +157,7 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
         if fused is not None:
             out_dir_vec_d = fused['dis'][0][-1]
         else:
-            outs_d, *_ = _chain(spec, args, gens, targets, in_text_padded, linear_blend_feat, vid_indices)
+            outs_d, *_ = _chain(spec, args, gens, targets, in_text_padded, linear_blend_feat, vid_indices, consts['tables'])
             out_dir_vec_d = outs_d[-1]
         dis_real = discriminator(target, in_text_padded)
         dis_fake = discriminator(out_dir_vec_d.detach(), in_text_padded)
@@ -171,49 +174,46 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
     N = text_feat.shape[0] * text_feat.shape[1]
     if args.loss_contrastive_pos_weight > 0.0:
         text_high_contrastive = ops.contrastive(text_feat.reshape(N, -1), feat_high.reshape(N, -1), spec['contrastive_expressive'])
-    if args.loss_contrastive_neg_weight > 0.0:
-        text_low_contrastive = -ops.contrastive(text_feat.reshape(N, -1), feat_low.reshape(N, -1), spec['contrastive_expressive'])
+    if args.loss_contrastive_neg_weight > 0.0:                # reference: text_low_contrastive = -contrastive(text, low); the sign rides in the weight
+        text_low_pos = ops.contrastive(text_feat.reshape(N, -1), feat_low.reshape(N, -1), spec['contrastive_expressive'])
 
     if fused is not None:
         outs_main, z_context, z_mu, z_logvar = fused['main']
     else:
-        outs_main, z_context, z_mu, z_logvar = _chain(spec, args, gens, targets, in_text_padded, linear_blend_feat, vid_indices)
+        outs_main, z_context, z_mu, z_logvar = _chain(spec, args, gens, targets, in_text_padded, linear_blend_feat, vid_indices, consts['tables'])
     out_dir_vec = outs_main[-1]
 
     beta = 0.1
-    huber_loss = ops.huber(outs_main[0], targets[0], beta)
-    for o_k, t_k in zip(outs_main[1:], targets[1:]):
-        huber_loss = huber_loss + ops.huber(o_k, t_k, beta)
+    hubers = [ops.huber(o_k, t_k, beta) for o_k, t_k in zip(outs_main, targets)]
     dis_output = discriminator(out_dir_vec, in_text_padded)              # always executed, as in the reference (:179)
     gen_error = ops.gen_loss(dis_output)
     kld = div_reg = None
 
+    # total loss = one weighted sum over the scalar terms (reference :226-262; same terms, same weights)
+    terms, weights = list(hubers), [args.loss_regression_weight] * len(hubers)
     if use_div:
         if fused is not None:
             outs_rand, z_context_rand, _, _ = fused['rand']
         else:
             with torch.no_grad():
                 outs_rand, z_context_rand, _, _ = _chain(spec, args, gens, targets, in_text_padded,
-                                                         [f.detach() for f in linear_blend_feat], rand_vids)
+                                                         [f.detach() for f in linear_blend_feat], rand_vids, consts['tables'])
         out_dir_vec_rand_vid = outs_rand[-1]
         div_reg = ops.div_reg(out_dir_vec, out_dir_vec_rand_vid.detach(), z_context.detach(), z_context_rand.detach(), 0.05)
         if args.z_type == 'speaker':
             kld = ops.kld(z_mu, z_logvar)
-            loss = args.loss_regression_weight * huber_loss + args.loss_kld_weight * kld + args.loss_reg_weight * div_reg
-        else:
-            loss = args.loss_regression_weight * huber_loss + args.loss_reg_weight * div_reg
-    else:
-        loss = args.loss_regression_weight * huber_loss
-
+            terms.append(kld); weights.append(args.loss_kld_weight)
+        terms.append(div_reg); weights.append(args.loss_reg_weight)
     if epoch > warm_up_epochs:
-        loss = loss + args.loss_gan_weight * gen_error
+        terms.append(gen_error); weights.append(args.loss_gan_weight)
     if args.loss_contrastive_pos_weight > 0.0:
-        loss = loss + args.loss_contrastive_pos_weight * text_high_contrastive
+        terms.append(text_high_contrastive); weights.append(args.loss_contrastive_pos_weight)
     if args.loss_contrastive_neg_weight > 0.0:
-        loss = loss + args.loss_contrastive_neg_weight * text_low_contrastive
+        terms.append(text_low_pos); weights.append(-args.loss_contrastive_neg_weight)
     if args.loss_physical_weight > 0.0:
         physical_loss = ops.phys_angle(out_dir_vec, consts['mean_dir'], consts['pairs'], consts['avg'], consts['var'], spec['palm'])
-        loss = loss + args.loss_physical_weight * physical_loss
+        terms.append(physical_loss); weights.append(args.loss_physical_weight)
+    loss = ops.weighted_sum(terms, weights)
 
     from . import ddp
     loss.backward()                                      # stage 1: losses, discriminator, generators (down to the cut)
@@ -234,7 +234,11 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
     ops.rng.end_step()
 
     # ---- one packed device->host transfer of the logged scalars ----
-    names, vals = ['loss'], [huber_loss.detach()]
+    # 'loss' = the sum of the per-level Huber terms (added on the host in fp32, left to right like the reference's
+    # `huber_loss = h1 + h2 + ...`); 'c_neg' is logged with the reference's sign (it holds -contrastive(text, low))
+    names, vals = [], []
+    for i, h in enumerate(hubers):
+        names.append('loss' if i == 0 else '+loss'); vals.append(h.detach())
     if kld is not None:
         names.append('KLD'); vals.append(kld.detach())
     if div_reg is not None:
@@ -244,7 +248,7 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
     if args.loss_contrastive_pos_weight > 0.0:
         names.append('c_pos'); vals.append(text_high_contrastive.detach())
     if args.loss_contrastive_neg_weight > 0.0:
-        names.append('c_neg'); vals.append(text_low_contrastive.detach())
+        names.append('-c_neg'); vals.append(text_low_pos.detach())
     if args.loss_physical_weight > 0.0:
         names.append('phy'); vals.append(physical_loss.detach())
     err = ops.gru_cluster_error_tensor(dev)
@@ -261,7 +265,16 @@ def _ret_dict(args, names, vals):
          'gen': args.loss_gan_weight, 'dis': 1.0, 'c_pos': args.loss_contrastive_pos_weight,
          'c_neg': args.loss_contrastive_neg_weight, 'phy': args.loss_physical_weight}
     ret = {}
-    for n, v in zip(names, vals):
+    import numpy as np
+    merged = []
+    for n, v in zip(names, vals):                        # '+x' adds to the previous entry in fp32, '-x' negates
+        if n.startswith('+'):
+            merged[-1][1] = float(np.float32(merged[-1][1]) + np.float32(v))
+        elif n.startswith('-'):
+            merged.append([n[1:], -v])
+        else:
+            merged.append([n, v])
+    for n, v in merged:
         if n == '_cluster_err':
             if v:
                 raise ops.Ha2gClusterError('ha2g_amd: a GRU cluster hand-off timed out (gru_cluster.hip): this step\'s GRU outputs '

@@ -101,12 +101,13 @@ int ha2g_gru_cluster_max_steps(void);
 int ha2g_gru_cluster_supported(int H);
 int ha2g_gru_layer_fwd_cluster(const float* gi, const float* wp, const float* bhh_fwd, const float* bhh_rev, float* y,
                                float* rs, void* xch, int* err, int B, int T, int H, void* stream);
-int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, void* xch,
+int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, float* hp, void* xch,
                                int* err, int B, int T, int H, void* stream);
 /* ablation bits for tools/dbg_cluster.py: 1 no wait, 2 no exchange, 4 force the write-through publish */
 void ha2g_gru_cluster_debug(int mode);
-/* dg [B][T][2][4H] = (d gi_r, d gi_z, d gi_n, d gh_n); wpt = packed_bwd images (dir 0, dir 1) */
-int ha2g_gru_layer_bwd(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, int B, int T,
+/* dg [B][T][2][4H] = (d gi_r, d gi_z, d gi_n, d gh_n); wpt = packed_bwd images (dir 0, dir 1); hp (nullable) [B][T][2H] receives
+ * the h_prev each step used (y shifted by one step per direction, zero at the sequence ends) = the dW_hh GEMM's operand */
+int ha2g_gru_layer_bwd(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, float* hp, int B, int T,
                        int H, void* stream);
 
 /* ---- BatchNorm (train mode) over [rows][C] channels-last data (nn.BatchNorm2d: model/ResNetBlocks.py:13,15,
@@ -158,6 +159,25 @@ int ha2g_dirsum_f32(const float* y, float* out, long rows, int H, int inverse, v
 /* Philox4x32-10 dropout; state = device uint64[2] {seed, step}; out and/or mask (pre-scaled keep mask) may be null */
 int ha2g_dropout_f32(const float* x, float* out, float* mask, long n, float p, const void* state, unsigned stream_id, void* stream);
 int ha2g_rng_advance(void* state, void* stream);
+
+/* ---- generator input pack + hierarchy scatter (train_eval/train_hierarchy.py:153-169, expressive :163-212;
+ *      model/hierarchy_net.py:121-141) ----
+ * pre_seq [rows][T][P+1]: frames < n_pre = (target frame, constraint bit 1); frames >= n_pre = columns of the coarser level's
+ * output `prev` [rows][T][Pprev] through map[P+1] (int32, -1 = stays 0; built from the reference's slice assignments in order,
+ * so the expressive step's one-column shift of the head values is reproduced).  prev/map may be null (first level).
+ * Backward: inv[Pprev][2] = the (at most two) pre_seq columns each output column feeds (-1 = none). */
+int ha2g_pre_seq_fwd_f32(const float* target, const float* prev, const int* map, float* out, long rows, int T, int P, int Pprev,
+                         int n_pre, void* stream);
+int ha2g_pre_seq_bwd_f32(const float* dpre, const int* inv, float* dprev, long rows, int T, int P, int Pprev, int n_pre, void* stream);
+/* in_data [rows][T][Wa+Wb+Wc+Wz] = [a | b | c | z[row] expanded over T]; backward splits the gradient (da/db/dc/dz nullable) */
+int ha2g_gen_concat_fwd_f32(const float* a, const float* b, const float* c, const float* z, float* out, long rows, int T, int Wa, int Wb,
+                            int Wc, int Wz, void* stream);
+int ha2g_gen_concat_bwd_f32(const float* d, float* da, float* db, float* dc, float* dz, long rows, int T, int Wa, int Wb, int Wc, int Wz,
+                            void* stream);
+/* total loss = sum_i w_i * term_i (train_hierarchy.py:226-262) in one launch, left-to-right fp32 like the Python expression.
+ * terms_host / weights_host are HOST arrays (n <= 24) of device scalar pointers / weights, read at call time. */
+int ha2g_weighted_sum_f32(const void* const* terms_host, const float* weights_host, int n, float* out, void* stream);
+int ha2g_weighted_sum_bwd_f32(const float* weights_host, int n, const float* g, float* out, void* stream);
 
 /* ---- loss terms (train_eval/train_hierarchy.py): value + unit gradient in one pass ---- */
 int ha2g_sum_f32(const float* x, long n, float* out, float scale, int accumulate, void* stream);

@@ -238,3 +238,68 @@ def test_dropout_placement_matches_reference_sites():
     g1(pre, tok, torch.randn(3, 34, 32, device=dev), torch.randint(1, 6, (3,), device=dev))
     assert ops.rng.call == (1 + 2 * args.n_layers) + (args.n_layers - 1)
     ops.rng.seed(dev, 0x5EED)
+
+
+@pytest.mark.parametrize('specname', ['gesture', 'expressive'])
+def test_pre_seq_pack_and_scatter_match_reference_slice_writes(specname):
+    """ha2g_pre_seq_* (csrc/pack.hip) against the reference's literal construction -- zeros, `pre[:, :n, :-1] = target`,
+    `pre[:, :n, -1] = 1`, then the level's slice assignments `pre[:, n:, dst] = out[:, n:, src]` in order (incl. the
+    expressive off-by-one head scatter that overwrites the constraint-bit column) -- forward bit for bit, and the gradient
+    w.r.t. the coarser level's output against torch autograd of those slice writes."""
+    from ha2g_amd import ops
+    from ha2g_amd.config import EXPRESSIVE_SPEC, GESTURE_SPEC
+    spec = GESTURE_SPEC if specname == 'gesture' else EXPRESSIVE_SPEC
+    dims, n, R, T = spec['pose_dims'], 4, 5, 34
+    for k, P in enumerate(dims):
+        Pprev = dims[k - 1] if k else 0
+        tgt = rnd((R, T, P), 50 + k)
+        prev = rnd((R, T, Pprev), 60 + k) if k else None
+        w = rnd((R, T, P + 1), 70 + k)
+        # reference construction on CPU (train_hierarchy.py:153-169 / train_hierarchy_expressive.py:163-212)
+        pv = prev.clone().requires_grad_(True) if k else None
+        pre = tgt.new_zeros((R, T, P + 1))
+        pre[:, 0:n, :-1] = tgt[:, 0:n]
+        pre[:, 0:n, -1] = 1
+        for dst, src in spec['scatter'][k]:
+            pre[:, n:, dst] = pv[:, n:, src]
+        tables = ops.scatter_tables(P, Pprev, spec['scatter'][k], torch.device(DEV))
+        pg = prev.to(DEV).requires_grad_(True) if k else None
+        got = ops.pre_seq(tgt.to(DEV), pg, tables, n)
+        assert torch.equal(got.detach().cpu(), pre.detach()), (specname, k)
+        if k:
+            (pre * w).sum().backward()
+            (got * w.to(DEV)).sum().backward()
+            assert torch.equal(pg.grad.cpu(), pv.grad), (specname, k)
+
+
+def test_gen_concat_matches_torch_cat():
+    from ha2g_amd import ops
+    R, T = 7, 34
+    for Wa in (16, 28, 127):
+        a, b, c, z = rnd((R, T, Wa), 1), rnd((R, T, 32), 2), rnd((R, T, 32), 3), rnd((R, 16), 4)
+        w = rnd((R, T, Wa + 80), 5)
+        cpu = [t.clone().requires_grad_(True) for t in (a, b, c, z)]
+        ref = torch.cat((cpu[0], cpu[1], cpu[2], cpu[3].unsqueeze(1).expand(-1, T, -1)), dim=2)      # hierarchy_net.py:121-141
+        (ref * w).sum().backward()
+        gpu = [t.to(DEV).requires_grad_(True) for t in (a, b, c, z)]
+        got = ops.gen_concat(*gpu)
+        assert torch.equal(got.detach().cpu(), ref.detach())
+        (got * w.to(DEV)).sum().backward()
+        for g_, c_ in zip(gpu[:3], cpu[:3]):
+            assert torch.equal(g_.grad.cpu(), c_.grad)
+        assert relerr(gpu[3].grad, cpu[3].grad) < 1e-6                 # sum over 34 frames: order of additions may differ
+
+
+def test_weighted_sum_loss_assembly():
+    from ha2g_amd import ops
+    vals = [0.31, 1.7, -2.5, 0.004, 12.0]
+    ws = [70.0, 0.1, 0.05, -0.005, 0.01]
+    ts = [torch.tensor(v, device=DEV, requires_grad=True) for v in vals]
+    tot = ops.weighted_sum(ts, ws)
+    ref = np.float32(0)
+    for v, w_ in zip(vals, ws):
+        ref = np.float32(ref + np.float32(w_) * np.float32(v))
+    assert abs(float(tot) - float(ref)) <= 1e-6 * abs(float(ref))
+    (3.0 * tot).backward()
+    for t, w_ in zip(ts, ws):
+        assert abs(float(t.grad) - 3.0 * w_) <= 1e-6 * abs(3.0 * w_)

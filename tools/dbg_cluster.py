@@ -28,7 +28,7 @@ dg = torch.empty(B * T, 8 * H, device=dev); dy = torch.randn(B, T, 2 * H, device
 for Bb in (128, 384):
     for mode, name in ((0, 'bwd normal'), (4, 'bwd write-through forced'), (1, 'bwd no wait'), (2, 'bwd no exchange')):
         raw.ha2g_gru_cluster_debug(mode)
-        us = timeit(lambda: check(lib.ha2g_gru_layer_bwd_cluster(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pk[2].data_ptr(), dg.data_ptr(), xch.data_ptr(), err.data_ptr(), Bb, T, H, st)))
+        us = timeit(lambda: check(lib.ha2g_gru_layer_bwd_cluster(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pk[2].data_ptr(), dg.data_ptr(), 0, xch.data_ptr(), err.data_ptr(), Bb, T, H, st)))
         print('B=%d %-55s %.1f us  %.2f us/step' % (Bb, name, us, us / T))
 raw.ha2g_gru_cluster_debug(0)
 print('err', ops.gru_cluster_error(dev))

@@ -45,7 +45,7 @@ def bench_gru(B, T=34, H=300):
     f = timeit(lambda: check(lib.ha2g_gru_layer_fwd(gi.data_ptr(), pk.data_ptr(), bhh.data_ptr(), bhh.data_ptr(), y.data_ptr(),
                                                     rs.data_ptr(), B, T, H, st)))
     b = timeit(lambda: check(lib.ha2g_gru_layer_bwd(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pk[2].data_ptr(), dg.data_ptr(),
-                                                    B, T, H, st)))
+                                                    0, B, T, H, st)))
     fc = None
     if lib.ha2g_gru_cluster_supported(H):
         xch, err = ops._cluster_scratch(dev)
