@@ -39,23 +39,15 @@ def _consts(spec, args, device):
     return c
 
 
-def _pre_seq(target_k, n_pre):
-    pre = target_k.new_zeros((target_k.shape[0], target_k.shape[1], target_k.shape[2] + 1))
-    pre[:, 0:n_pre, :-1] = target_k[:, 0:n_pre, :]
-    pre[:, 0:n_pre, -1] = 1                                    # indicating bit for constraints
-    return pre
-
-
-def _chain(spec, args, gens, targets, in_text, blend, vids):
+def _chain(spec, args, gens, targets, in_text, blend, vids, tables):
     """coarse-to-fine decode g1 -> ... -> gL (reference train_hierarchy.py:153-170 / train_hierarchy_expressive.py:272-316).
-    Level k's frames n_pre.. are seeded with level k-1's output through spec['scatter'] (differentiable slice writes).
-    All inputs may carry a multiple of B rows."""
+    Level k's pre_seq = (target frames, constraint bit) for the first n_pre frames; its later frames are seeded with level
+    k-1's output through spec['scatter'][k] -- one pack kernel per level (differentiable w.r.t. the coarser output) instead
+    of the reference's zeros + slice writes.  All inputs may carry a multiple of B rows."""
     n = args.n_pre_poses
     outs, last = [], None
     for k, g in enumerate(gens):
-        pre = _pre_seq(targets[k], n)
-        for dst, src in spec['scatter'][k]:
-            pre[:, n:, dst] = outs[-1][:, n:, src]
+        pre = ops.pre_seq(targets[k], outs[-1] if k else None, tables[k], n)
         o, z, mu, logvar = g(pre, in_text, blend[k], vids)
         outs.append(o)
         last = (z, mu, logvar)
