@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __res
 // dg[o] = <dw, v>/||v||;  dv = g/||v|| * (dw - v <dw,v>/||v||^2)
 __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ g,
                                                               const float* __restrict__ v, const float* __restrict__ norm,
-                                                              float* __restrict__ dg, float* __restrict__ dv, int n) {
+                                                              float* __restrict__ dg, float* __restrict__ dv, int n, float beta) {
     __shared__ float red[16];
     const int o = blockIdx.x;
     const float* vr = v + (long)o * n;
@@ -129,9 +129,12 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __res
     for (int i = threadIdx.x; i < n; i += 256) s += dr[i] * vr[i];
     s = block_sum(s, red);
     const float nr = norm[o];
-    if (threadIdx.x == 0) dg[o] = s / nr;
+    if (threadIdx.x == 0) dg[o] = (beta != 0.f ? beta * dg[o] : 0.f) + s / nr;
     const float a = g[o] / nr, bq = s / (nr * nr);
-    for (int i = threadIdx.x; i < n; i += 256) dv[(long)o * n + i] = a * (dr[i] - vr[i] * bq);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float* d = dv + (long)o * n + i;
+        *d = (beta != 0.f ? beta * *d : 0.f) + a * (dr[i] - vr[i] * bq);
+    }
 }
 
 // ---------------------------------------------------------------- pointwise ---------------------------
@@ -367,8 +370,8 @@ int ha2g_weight_norm_fwd_f32(const float* g, const float* v, float* w, float* no
     return 0;
 }
 int ha2g_weight_norm_bwd_f32(const float* dw, const float* g, const float* v, const float* norm, float* dg, float* dv, int Cout,
-                             int n, void* stream) {
-    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, dw, g, v, norm, dg, dv, n);
+                             int n, float beta, void* stream) {
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, dw, g, v, norm, dg, dv, n, beta);
     HA2G_CHECK_LAUNCH("weight_norm_bwd");
     return 0;
 }

@@ -405,20 +405,27 @@ def dirsum(y):
 class WeightNormFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g, v):
+        g_in, v_in = g, v
         g, v = g.contiguous(), v.contiguous()
         cout, n = v.shape[0], v[0].numel()
         w, norm = torch.empty_like(v), torch.empty(cout, dtype=torch.float32, device=v.device)
         check(lib.ha2g_weight_norm_fwd_f32(g.data_ptr(), v.data_ptr(), w.data_ptr(), norm.data_ptr(), cout, n, _stream()))
         ctx.save_for_backward(g, v, norm)
+        ctx.refs = (g_in, v_in)
         return w
 
     @staticmethod
     def backward(ctx, dw):
         g, v, norm = ctx.saved_tensors
         dw = dw.contiguous()
+        tg, tv = _grad_target(ctx.refs[0]), _grad_target(ctx.refs[1])
+        if tg is not None and tv is not None and tg.is_contiguous() and tv.is_contiguous():     # straight into the flat .grad buffers
+            check(lib.ha2g_weight_norm_bwd_f32(dw.data_ptr(), g.data_ptr(), v.data_ptr(), norm.data_ptr(), tg.data_ptr(), tv.data_ptr(),
+                                               v.shape[0], v[0].numel(), 1.0, _stream()))
+            return None, None
         dg, dv = torch.empty_like(g), torch.empty_like(v)
         check(lib.ha2g_weight_norm_bwd_f32(dw.data_ptr(), g.data_ptr(), v.data_ptr(), norm.data_ptr(), dg.data_ptr(), dv.data_ptr(),
-                                           v.shape[0], v[0].numel(), _stream()))
+                                           v.shape[0], v[0].numel(), 0.0, _stream()))
         return dg, dv
 
 
@@ -433,6 +440,7 @@ class Conv1dFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, dil, pad_left, To, act):
         x = _f32c(x.contiguous())
+        ctx.refs = (w, b)
         w = w.contiguous()
         B, T, C = x.shape
         cout, _, k = w.shape
@@ -453,9 +461,17 @@ class Conv1dFunction(torch.autograd.Function):
         dx = dw = db = None
         with side.section(dy2.device):
             if ctx.needs_input_grad[1]:
-                dw = gemm(dy2, col, transa=True).view(cout, C, k)
+                tw = _grad_target(ctx.refs[0])
+                if tw is not None and tw.is_contiguous():             # a leaf weight (discriminator convs): dW += straight into .grad
+                    gemm(dy2, col, transa=True, out=tw.view(cout, C * k), beta=1.0)
+                else:                                                 # weight-normalised TCN convs: dw feeds weight_norm's backward
+                    dw = gemm(dy2, col, transa=True).view(cout, C, k)
             if ctx.has_b and ctx.needs_input_grad[2]:
-                db = colsum(dy2)
+                tb = _grad_target(ctx.refs[1])
+                if tb is not None:
+                    colsum(dy2, out=tb, beta=1.0)
+                else:
+                    db = colsum(dy2)
         if ctx.needs_input_grad[0]:
             dcol = gemm(dy2, w.view(cout, C * k))
             dx = torch.empty(B, T, C, dtype=torch.float32, device=dy.device)

@@ -145,8 +145,9 @@ int ha2g_embedding_bwd_f32(const long* tok, const float* dY, float* dW, int n, i
 int ha2g_im2col1d_f32(const float* x, float* col, int B, int T, int C, int k, int dil, int pad_left, int To, void* stream);
 int ha2g_col2im1d_f32(const float* dcol, float* dx, int B, int T, int C, int k, int dil, int pad_left, int To, void* stream);
 int ha2g_weight_norm_fwd_f32(const float* g, const float* v, float* w, float* norm, int Cout, int n, void* stream);
+/* dg / dv = beta * (old) + gradient: beta = 1 accumulates straight into the parameters' gradient buffers */
 int ha2g_weight_norm_bwd_f32(const float* dw, const float* g, const float* v, const float* norm, float* dg, float* dv,
-                             int Cout, int n, void* stream);
+                             int Cout, int n, float beta, void* stream);
 
 /* ---- pointwise / RNG ---- */
 /* op: 0 a+b, 1 a*b, 2 relu(a+b), 3 relu', 4 leaky', 5 sigmoid', 6 elu, 7 elu', 8 reparam (model/embedding_net.py:10-13),
