@@ -95,6 +95,10 @@ TAPSFULL_CASE = dict(tag='taps', B=4, n_spk=8, seed=22, L=3, W3=9)        # real
 ENC_CASE = dict(B=16, n_spk=8, seed=14)
 
 
+# sliding-window synthesis fixture (tests/golden/synth.npz): 9 s clip -> 5 windows of 34 frames, `small` case modules
+SYNTH_CASE = dict(clip_seconds=9.0, n_words=18, seed=31, vid=3)
+
+
 def make_args(case):
     return hierarchy_args(expressive=bool(case.get('expressive')), hidden_size=case['hidden_size'],
                           n_layers=case['n_layers'], dropout_prob=0.0)

@@ -87,6 +87,19 @@ __global__ void gen_concat_bwd_kernel(const float* __restrict__ d, float* __rest
     }
 }
 
+// Sliding-window synthesis (scripts/synthesize_hierarchy.py:150-161): window i covers frames [i*(T-n), i*(T-n)+T); its first n frames
+// overlap the previous window's last n and are cross-faded  out[j] = prev[j]*(n-j)/(n+1) + next[j]*(j+1)/(n+1)  -- same operation
+// order in fp32 as the reference's numpy expression -- the rest is copied.
+__global__ void window_blend_kernel(const float* __restrict__ win, float* __restrict__ out, int first, int T, int n, int P) {
+    const int total = T * P;
+    for (int i = blockIdx.x * EB + threadIdx.x; i < total; i += gridDim.x * EB) {
+        const int j = i / P;
+        float v = win[i];
+        if (!first && j < n) v = out[i] * (float)(n - j) / (float)(n + 1) + v * (float)(j + 1) / (float)(n + 1);
+        out[i] = v;
+    }
+}
+
 constexpr int MAXTERMS = 24;
 struct Terms { const float* p[MAXTERMS]; float w[MAXTERMS]; int n; };
 // out[0] = sum_i w_i * *p_i, accumulated left to right in fp32 (the order the reference's Python expression adds them)
@@ -137,6 +150,14 @@ int ha2g_gen_concat_bwd_f32(const float* d, float* da, float* db, float* dc, flo
     hipLaunchKernelGGL(gen_concat_bwd_kernel, dim3(grid_for(rows * T * (Wa + Wb + Wc) + rows * Wz)), dim3(EB), 0, (hipStream_t)stream, d, da,
                        db, dc, dz, rows, T, Wa, Wb, Wc, Wz);
     HA2G_CHECK_LAUNCH("gen_concat_bwd");
+    return 0;
+}
+/* out_all [frames][P] with frames >= index*(T-n_pre)+T: blend window `index` ([T][P]) into the running sequence */
+int ha2g_window_blend_f32(const float* win, float* out_all, int index, int T, int n_pre, int P, void* stream) {
+    HA2G_REQUIRE(index >= 0 && n_pre >= 0 && n_pre < T, "window_blend: bad geometry");
+    hipLaunchKernelGGL(window_blend_kernel, dim3(grid_for((long)T * P)), dim3(EB), 0, (hipStream_t)stream, win,
+                       out_all + (long)index * (T - n_pre) * P, index == 0, T, n_pre, P);
+    HA2G_CHECK_LAUNCH("window_blend");
     return 0;
 }
 /* terms_host: HOST array of n device pointers to fp32 scalars; weights_host: HOST array of n weights (both read at call time) */

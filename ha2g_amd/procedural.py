@@ -103,3 +103,16 @@ def sample_of(t, n=64):
     a = np.asarray(t, dtype=np.float64).reshape(-1)
     stride = max(1, a.size // n)
     return np.float64(np.sqrt((a * a).sum())), a[::stride][:n].astype(np.float32)
+
+
+def synth_spectrogram(n_audio, seed):
+    """(128, 1 + n_audio // 512) log-mel-like array in [-80, 0] dB for the synthesis fixture."""
+    r = np.random.Generator(np.random.PCG64([seed, 55]))
+    return (-80.0 * r.random((128, 1 + n_audio // 512))).astype(np.float32)
+
+
+def synth_words(clip_seconds, n, seed):
+    """[(text 'w<k>', start_s, end_s)] sorted by onset: the word list a transcript aligner would hand to the synthesis loop."""
+    r = np.random.Generator(np.random.PCG64([seed, 56]))
+    starts = np.sort(r.random(n) * (clip_seconds - 0.5))
+    return [('w%d' % int(r.integers(0, 30)), float(s), float(s + 0.1 + 0.3 * r.random())) for s in starts]

@@ -175,6 +175,10 @@ int ha2g_gen_concat_fwd_f32(const float* a, const float* b, const float* c, cons
                             int Wc, int Wz, void* stream);
 int ha2g_gen_concat_bwd_f32(const float* d, float* da, float* db, float* dc, float* dz, long rows, int T, int Wa, int Wb, int Wc, int Wz,
                             void* stream);
+/* sliding-window synthesis, smoothing of the motion transition (scripts/synthesize_hierarchy.py:150-161): window `index` ([T][P]) is
+ * written into out_all [frames][P] at frame index*(T-n_pre); its first n_pre frames are cross-faded with what the previous window left
+ * there:  out = prev*(n-j)/(n+1) + next*(j+1)/(n+1), j = 0..n-1 */
+int ha2g_window_blend_f32(const float* win, float* out_all, int index, int T, int n_pre, int P, void* stream);
 /* total loss = sum_i w_i * term_i (train_hierarchy.py:226-262) in one launch, left-to-right fp32 like the Python expression.
  * terms_host / weights_host are HOST arrays (n <= 24) of device scalar pointers / weights, read at call time. */
 int ha2g_weighted_sum_f32(const void* const* terms_host, const float* weights_host, int n, float* out, void* stream);

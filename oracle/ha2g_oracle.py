@@ -378,3 +378,55 @@ class OracleTrainer:
         ret['c_neg'] = a.loss_contrastive_neg_weight * c_neg.item()
         ret['phy'] = a.loss_physical_weight * phy.item()
         return ret
+
+
+# ----------------------------------------------------------------------------------------------
+# sliding-window synthesis (scripts/synthesize_hierarchy.py:36-215), hierarchy model, eval-mode modules
+# ----------------------------------------------------------------------------------------------
+
+
+def synthesize_windows(args, sd, spec, lang_model, n_audio, words, spectrogram, vid, eps_fn, audio_sr=16000):
+    """generate_gestures_hierarchy restated over the oracle's functional modules: windows of n_poses frames every
+    n_poses - n_pre_poses frames, the first n_pre_poses of a window seeded with the previous window's last ones (per level),
+    overlap cross-faded prev*(n-j)/(n+1) + next*(j+1)/(n+1) in float32 numpy (:150-161).  -> numpy [frames, P]."""
+    import numpy as np
+    from ha2g_amd.synthesize import calc_spectrogram_length_from_motion_length, frame_tokens, plan_windows
+    n_frames, n_pre = args.n_poses, args.n_pre_poses
+    clip_length = n_audio / audio_sr
+    unit_time, stride_time, num_sub = plan_windows(clip_length, n_frames, n_pre, args.motion_resampling_framerate)
+    spec_len = calc_spectrogram_length_from_motion_length(n_frames, args.motion_resampling_framerate)
+    dims = spec['pose_dims']
+    dt = spectrogram.dtype
+    targets = [torch.zeros(1, n_frames, P, dtype=dt) for P in dims]
+    vid_t = torch.LongTensor([vid])
+    out_list, out_dir_vec = [], None
+    with torch.no_grad():
+        for i in range(num_sub):
+            start_time = i * stride_time
+            a0 = math.floor(start_time / clip_length * spectrogram.shape[0])      # the reference's shape[0] (mel bins) quirk
+            in_spec = spectrogram[:, a0:a0 + spec_len].unsqueeze(0)
+            tokens = frame_tokens(lang_model, words, start_time, start_time + unit_time, n_frames)
+            if i > 0:
+                for k, c in enumerate(spec['level_cols']):
+                    targets[k][:, :n_pre] = out_dir_vec[:, -n_pre:][:, :, c]
+            _, _, _, _, blend = wav_encoder(in_spec, vid_t, sd, 'audio.', len(dims), update_bn='eval')
+            prev = None
+            for k in range(len(dims)):
+                tk = targets[k]
+                pre = tk.new_zeros(1, n_frames, dims[k] + 1)
+                pre[:, :n_pre, :-1] = tk[:, :n_pre]
+                pre[:, :n_pre, -1] = 1
+                for dst, src in spec['scatter'][k]:
+                    pre[:, n_pre:, dst] = prev[:, n_pre:, src]
+                prev, _, _, _ = pose_generator(pre, tokens, blend[k], vid_t, sd, 'g%d.' % (k + 1), args.n_layers, args.hidden_size,
+                                               eps_fn((1, 16)))
+            out_dir_vec = prev
+            out_seq = out_dir_vec[0].numpy().copy()
+            if out_list:
+                last_poses = out_list[-1][-n_pre:]
+                out_list[-1] = out_list[-1][:-n_pre]
+                n = len(last_poses)
+                for j in range(n):
+                    out_seq[j] = last_poses[j] * (n - j) / (n + 1) + out_seq[j] * (j + 1) / (n + 1)
+            out_list.append(out_seq)
+    return np.vstack(out_list)

@@ -424,6 +424,87 @@ def encoder_goldens(out, dt, perturb=0.0):
             digest_n(out, 'enc/buf/' + k, b, n=128)
 
 
+def _stub_io_modules():
+    """scripts/synthesize_hierarchy.py, train.py and utils/train_utils.py import I/O packages that are absent here (librosa, soundfile,
+    lmdb, configargparse, umap, tensorboard).  Empty stand-in MODULES satisfy those import statements (the SURVEY 8c recipe for
+    fasttext, extended); none of their functionality is used by the functions the fixtures run."""
+    import importlib
+    for n in ('librosa', 'librosa.display', 'soundfile', 'lmdb', 'configargparse', 'umap'):
+        try:
+            importlib.import_module(n)
+        except Exception:
+            sys.modules[n] = types.ModuleType(n)
+    sys.modules['librosa'].display = sys.modules['librosa.display']
+    tb = types.ModuleType('torch.utils.tensorboard')
+    tb.SummaryWriter = object
+    sys.modules['torch.utils.tensorboard'] = tb
+
+
+class SynthLang:
+    """lang_model of the synthesis fixture: word 'w<k>' -> index 4 + k."""
+    SOS_token, EOS_token = 1, 2
+
+    def get_word_index(self, word):
+        return 4 + int(word[1:])
+
+
+def synth_goldens(out, dt, perturb=0.0):
+    """scripts/synthesize_hierarchy.py:36-215 generate_gestures_hierarchy run by the reference itself on a 9 s synthetic clip (5 windows):
+    eval-mode modules with the `small` case's procedural weights, procedural spectrogram / word timings, injected reparameterisation
+    noise.  The function casts its inputs to float32 itself, so only float32 runs exist: `truth` = the plain float32 run."""
+    _stub_io_modules()
+    import synthesize_hierarchy as S
+    from ha2g_amd.config import SYNTH_CASE as sc
+    case = CASES['small']
+    args, gens, dis, aud, txt = build(case, (15, 21, 27), 3, torch.float32)
+    for m in gens + [aud]:
+        m.eval()
+    n_audio = int(sc['clip_seconds'] * 16000)
+    spectro = proc.synth_spectrogram(n_audio, sc['seed'])
+    if perturb:
+        r = np.random.Generator(np.random.PCG64([4242, 31, PERTURB_DRAW])).standard_normal(spectro.shape)
+        spectro = (spectro * (1.0 + perturb * r)).astype(np.float32)
+    words = proc.synth_words(sc['clip_seconds'], sc['n_words'], sc['seed'])
+    eps = proc.EpsStream(sc['seed'])
+    ref_embedding_net.reparameterize = lambda mu, logvar: mu + torch.from_numpy(eps(mu.shape)).to(mu.dtype) * torch.exp(0.5 * logvar)
+    S.extract_melspectrogram = lambda audio, sr: spectro                     # the librosa front-end is outside this fixture (f3)
+    tg = [torch.zeros(1, 34, P) for P in (15, 21, 27)]
+    res = S.generate_gestures_hierarchy(args, *gens, aud, SynthLang(), np.zeros(n_audio, np.float32), words, *tg, vid=sc['vid'])
+    out['synth/out'] = np.asarray(res, np.float64)
+
+
+def write_fixture32(name, runs, NPERT):
+    """fixtures whose reference only runs in float32: truth = the plain run, @noise = scatter of the perturbed runs around it"""
+    out = {}
+    for k, v in runs['f32'].items():
+        v = np.asarray(v, np.float64)
+        out[k] = v
+        out[k + '@noise'] = np.float64(max(np.abs(np.asarray(runs['f32p%d' % i][k], np.float64) - v).max() for i in range(NPERT)))
+        out[k + '@cond'] = np.float64(0.0)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('  wrote', path, os.path.getsize(path) // 1024, 'KiB,', len(out), 'arrays')
+
+
+EXTRA32 = {'synth': (synth_goldens,)}
+
+
+def main_extra32(only):
+    global PERTURB_DRAW
+    for name, fns in EXTRA32.items():
+        if only and name not in only:
+            continue
+        print('fixture', name)
+        NPERT = 8
+        runs = {}
+        for tag, pert, draw in [('f32', 0.0, 0)] + [('f32p%d' % i, 6e-8, i + 1) for i in range(NPERT)]:
+            PERTURB_DRAW = draw
+            o = runs[tag] = {}
+            for fn in fns:
+                fn(o, torch.float32, perturb=pert)
+        write_fixture32(name, runs, NPERT)
+
+
 EXTRA = {'blocks': (block_goldens, taps_goldens), 'blocksfull': (blockfull_goldens, tapsfull_goldens), 'enc16': (encoder_goldens,)}
 
 
@@ -462,6 +543,7 @@ def main_extra(only):
 def main():
     only = sys.argv[1:]
     main_extra(only)
+    main_extra32(only)
     for name, case in CASES.items():
         if only and name not in only:
             continue
