@@ -95,6 +95,8 @@ TAPSFULL_CASE = dict(tag='taps', B=4, n_spk=8, seed=22, L=3, W3=9)        # real
 ENC_CASE = dict(B=16, n_spk=8, seed=14)
 
 
+# FGD evaluator fixture (tests/golden/fgd.npz): 3 batches of 48 (generated, real) windows through the reference's EmbeddingSpaceEvaluator
+FGD_CASE = dict(B=48, batches=3, seed=41)
 # sliding-window synthesis fixture (tests/golden/synth.npz): 9 s clip -> 5 windows of 34 frames, `small` case modules
 SYNTH_CASE = dict(clip_seconds=9.0, n_words=18, seed=31, vid=3)
 

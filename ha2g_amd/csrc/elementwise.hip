@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __res
 // ---------------------------------------------------------------- pointwise ---------------------------
 enum EltOp {
     OP_ADD = 0, OP_MUL = 1, OP_ADD_RELU = 2, OP_RELU_BWD = 3, OP_LEAKY_BWD = 4, OP_SIGMOID_BWD = 5, OP_ELU = 6,
-    OP_ELU_BWD = 7, OP_REPARAM = 8, OP_REPARAM_BWD_LOGVAR = 9, OP_AXPBY = 10, OP_LEAKY = 11, OP_RELU = 12, OP_SCALE = 13, OP_MUL_SCALAR = 14, OP_SIGMOID = 15, OP_SIGMOID_BWD_PRE = 16, OP_RSQRT_EPS = 17,
+    OP_ELU_BWD = 7, OP_REPARAM = 8, OP_REPARAM_BWD_LOGVAR = 9, OP_AXPBY = 10, OP_LEAKY = 11, OP_RELU = 12, OP_SCALE = 13, OP_MUL_SCALAR = 14, OP_SIGMOID = 15, OP_SIGMOID_BWD_PRE = 16, OP_RSQRT_EPS = 17, OP_LEAKY_A = 18,
 };
 
 __device__ __forceinline__ float elt(int op, float a, float b, float c, float alpha, float beta) {
@@ -162,6 +162,7 @@ __device__ __forceinline__ float elt(int op, float a, float b, float c, float al
         case OP_SIGMOID: return 1.f / (1.f + expf(-a));
         // a = dy, b = pre-activation: s(1-s) as sigma(b)*sigma(-b) -- no cancellation when the gate saturates
         case OP_RSQRT_EPS: return 1.f / sqrtf(a + alpha);           // inference BatchNorm: invstd from running_var
+        case OP_LEAKY_A: return a > 0.f ? a : alpha * a;             // LeakyReLU(alpha): 0.2 in the FGD auto-encoder
         case OP_SIGMOID_BWD_PRE: return a * (1.f / (1.f + expf(-b))) * (1.f / (1.f + expf(b)));
     }
     return 0.f;
@@ -379,7 +380,7 @@ int ha2g_weight_norm_bwd_f32(const float* dw, const float* g, const float* v, co
 int ha2g_eltwise_f32(int op, const float* a, const float* b, const float* c, float* out, long n, float alpha, float beta,
                      void* stream) {
     if (n == 0) return 0;
-    HA2G_REQUIRE(op >= 0 && op <= OP_RSQRT_EPS, "eltwise: unknown op %d", op);
+    HA2G_REQUIRE(op >= 0 && op <= OP_LEAKY_A, "eltwise: unknown op %d", op);
     int vec = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) & 15) == 0 && op != OP_MUL_SCALAR;
     hipLaunchKernelGGL(eltwise_kernel, dim3(grid_for(n, 4)), dim3(EB), 0, (hipStream_t)stream, op, a, b, c, out, n, alpha, beta, vec);
     HA2G_CHECK_LAUNCH("eltwise");

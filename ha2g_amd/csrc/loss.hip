@@ -406,3 +406,93 @@ int ha2g_contrastive_f32(const float* a, const float* b, int N, int expressive, 
 }
 
 }  // extern "C"
+
+// ---- FGD evaluator statistics (model/embedding_space_evaluator.py), float64 accumulation, single-launch, deterministic ----
+namespace {
+__global__ __launch_bounds__(1024) void feat_stats_kernel(const float* __restrict__ f, int N, int D, double* __restrict__ sum, double* __restrict__ outer) {
+    for (int e = threadIdx.x; e < D * D + D; e += 1024) {
+        double s = 0.0;
+        if (e < D * D) {
+            const int i = e / D, j = e % D;
+            for (int n = 0; n < N; ++n) s += (double)f[(long)n * D + i] * (double)f[(long)n * D + j];
+            outer[e] += s;
+        } else {
+            const int i = e - D * D;
+            for (int n = 0; n < N; ++n) s += (double)f[(long)n * D + i];
+            sum[i] += s;
+        }
+    }
+}
+__global__ __launch_bounds__(1024) void l1_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, double* __restrict__ out) {
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) s += fabs((double)a[i] - (double)b[i]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] += red[0];
+}
+// one block per sample; per-sample values are combined in sample order by the last step (single extra block: blockIdx 0 after a second launch)
+__global__ __launch_bounds__(256) void recon_metrics_partial(const float* __restrict__ r, const float* __restrict__ p, int T, int P, double* __restrict__ part) {
+    __shared__ double red[3][256];
+    const int b = blockIdx.x;
+    const float* rb = r + (long)b * T * P;
+    const float* pb = p + (long)b * T * P;
+    double l1 = 0.0, dl1 = 0.0, cs = 0.0;
+    for (int i = threadIdx.x; i < T * P; i += 256) {
+        l1 += fabs((double)rb[i] - (double)pb[i]);
+        if (i < (T - 1) * P) dl1 += fabs(((double)rb[i + P] - (double)rb[i]) - ((double)pb[i + P] - (double)pb[i]));
+    }
+    const int nb = P / 3;
+    for (int i = threadIdx.x; i < T * nb; i += 256) {
+        const float* x = rb + (long)i * 3; const float* y = pb + (long)i * 3;
+        const double dot = (double)x[0] * y[0] + (double)x[1] * y[1] + (double)x[2] * y[2];
+        const double nx = sqrt((double)x[0] * x[0] + (double)x[1] * x[1] + (double)x[2] * x[2]);
+        const double ny = sqrt((double)y[0] * y[0] + (double)y[1] * y[1] + (double)y[2] * y[2]);
+        cs += 1.0 - dot / (fmax(nx, 1e-8) * fmax(ny, 1e-8));
+    }
+    red[0][threadIdx.x] = l1; red[1][threadIdx.x] = dl1; red[2][threadIdx.x] = cs;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; red[2][threadIdx.x] += red[2][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[2 * b] = red[0][0] / (double)(T * P) + red[1][0] / (double)((T - 1) * P);
+        part[2 * b + 1] = red[2][0];
+    }
+}
+__global__ void recon_metrics_final(const double* __restrict__ part, int B, double* __restrict__ out) {
+    if (threadIdx.x < 2) {
+        double s = 0.0;
+        for (int b = 0; b < B; ++b) s += part[2 * b + threadIdx.x];
+        out[threadIdx.x] += s;
+    }
+}
+}  // namespace
+
+extern "C" {
+int ha2g_feat_stats_f64(const float* f, int N, int D, double* sum, double* outer, void* stream) {
+    HA2G_REQUIRE(D >= 1 && D <= 128, "feat_stats: D=%d out of range", D);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(feat_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, f, N, D, sum, outer);
+    HA2G_CHECK_LAUNCH("feat_stats");
+    return 0;
+}
+int ha2g_l1_rows_f64(const float* a, const float* b, long n, double* out, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(l1_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, n, out);
+    HA2G_CHECK_LAUNCH("l1_rows");
+    return 0;
+}
+/* out[0..1] += ; the first 2*B doubles after out[2] are scratch: out must hold 2 + 2*B doubles */
+int ha2g_recon_metrics_f64(const float* recon, const float* poses, int B, int T, int P, double* out, void* stream) {
+    HA2G_REQUIRE(P % 3 == 0 && T >= 2, "recon_metrics: P %% 3 == 0 and T >= 2");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(recon_metrics_partial, dim3(B), dim3(256), 0, (hipStream_t)stream, recon, poses, T, P, out + 2);
+    hipLaunchKernelGGL(recon_metrics_final, dim3(1), dim3(64), 0, (hipStream_t)stream, out + 2, B, out);
+    HA2G_CHECK_LAUNCH("recon_metrics");
+    return 0;
+}
+}  // extern "C"
+

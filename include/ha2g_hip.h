@@ -153,7 +153,7 @@ int ha2g_weight_norm_bwd_f32(const float* dw, const float* g, const float* v, co
 /* op: 0 a+b, 1 a*b, 2 relu(a+b), 3 relu', 4 leaky', 5 sigmoid', 6 elu, 7 elu', 8 reparam (model/embedding_net.py:10-13),
  *     9 reparam d/dlogvar, 10 alpha*a+beta*b, 11 leaky, 12 relu, 13 alpha*a, 14 a*b[0]*alpha (b = device scalar),
  *     15 sigmoid(a), 16 a*sigmoid(b)*sigmoid(-b) (sigmoid' from the pre-activation b),
- *     17 1/sqrt(a+alpha) */
+ *     17 1/sqrt(a+alpha), 18 leaky-relu with slope alpha */
 int ha2g_eltwise_f32(int op, const float* a, const float* b, const float* c, float* out, long n, float alpha, float beta, void* stream);
 /* out[r][h] = y[r][h] + y[r][H+h] (sum of the two GRU directions, model/hierarchy_net.py:145); inverse=1: gradient fan-out */
 int ha2g_dirsum_f32(const float* y, float* out, long rows, int H, int inverse, void* stream);
@@ -198,6 +198,15 @@ int ha2g_gan_loss_f32(int mode, const float* a, const float* b, int n, float* lo
 long ha2g_contrastive_workspace_floats(int N);
 int ha2g_contrastive_f32(const float* a, const float* b, int N, int expressive, float* loss, float* da, float* db, float* ws,
                          void* stream);                                                                                          /* :54-68 */
+
+/* ---- FGD evaluator statistics (model/embedding_space_evaluator.py:57-154), accumulated on the device in float64 ----
+ * feat_stats: sum[D] += sum_n f[n][:], outer[D][D] += sum_n f[n] f[n]^T (D <= 128): mean / covariance of the latent features (np.mean, np.cov);
+ * l1_rows: out[0] += sum_n sum_d |a[n][d] - b[n][d]| (feat_dist :139-144, diversity :112-123);
+ * recon_metrics: out[0] += sum_b ( mean_{t,d}|r-p| + mean_{t<T-1,d}|(r[t+1]-r[t]) - (p[t+1]-p[t])| ), out[1] += sum_{b,t,bone} (1 - cos(r_bone, p_bone))
+ *                (:78-103; poses [B][T][P], P = 3 * bones, cosine_similarity eps 1e-8) */
+int ha2g_feat_stats_f64(const float* f, int N, int D, double* sum, double* outer, void* stream);
+int ha2g_l1_rows_f64(const float* a, const float* b, long n, double* out, void* stream);
+int ha2g_recon_metrics_f64(const float* recon, const float* poses, int B, int T, int P, double* out /* 2 + 2*B doubles: [0..1] accumulators, rest scratch */, void* stream);
 
 /* ---- optimizer (torch.optim.Adam as set up in train.py:155-170) ---- */
 int ha2g_adam_step_inc(int* step, void* stream);

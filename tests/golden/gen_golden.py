@@ -473,6 +473,35 @@ def synth_goldens(out, dt, perturb=0.0):
     out['synth/out'] = np.asarray(res, np.float64)
 
 
+def fgd_goldens(out, dt, perturb=0.0):
+    """model/embedding_space_evaluator.py:57-154 run by the reference's own EmbeddingSpaceEvaluator (TED-Gesture branch: EmbeddingNet in
+    'pose' mode, model/embedding_net.py) on three batches of procedural (generated, real) pose windows; the checkpoint it loads is written
+    here from procedural parameters.  Stored: latent features, reconstruction / cosine diagnostics per batch, FGD, feature distance."""
+    _stub_io_modules()
+    import tempfile
+    from model.embedding_net import EmbeddingNet
+    from model.embedding_space_evaluator import EmbeddingSpaceEvaluator
+    from ha2g_amd.config import FGD_CASE as fc, hierarchy_args
+    args = hierarchy_args()
+    net = proc.fill_module(EmbeddingNet(args, 27, 34, 10, 300, None, 'pose'), fc['seed'], 'fgd.')
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, 'ae.bin')
+        torch.save({'pose_dim': 27, 'gen_dict': net.state_dict()}, path)
+        ev = EmbeddingSpaceEvaluator(args, path, Lang(10), torch.device('cpu'))
+    ev.net.to(dt)
+    for i in range(fc['batches']):
+        real, gen = proc.fgd_batch(fc['B'], i, fc['seed'])
+        real_t, gen_t = perturbed(torch.from_numpy(real).to(dt), perturb, 40 + i), perturbed(torch.from_numpy(gen).to(dt), perturb, 50 + i)
+        ev.push_samples(None, None, gen_t, real_t)
+        out['fgd/real_feat%d' % i] = np.asarray(ev.real_feat_list[-1], np.float64)
+        out['fgd/gen_feat%d' % i] = np.asarray(ev.generated_feat_list[-1], np.float64)
+        out['fgd/recon_err_diff%d' % i] = np.float64(ev.recon_err_diff[-1])
+        out['fgd/cos_err_diff%d' % i] = np.float64(ev.cos_err_diff[-1])
+    fd, feat_dist = ev.get_scores()
+    out['fgd/frechet'] = np.float64(fd)
+    out['fgd/feat_dist'] = np.float64(feat_dist)
+
+
 def write_fixture32(name, runs, NPERT):
     """fixtures whose reference only runs in float32: truth = the plain run, @noise = scatter of the perturbed runs around it"""
     out = {}
@@ -505,7 +534,7 @@ def main_extra32(only):
         write_fixture32(name, runs, NPERT)
 
 
-EXTRA = {'blocks': (block_goldens, taps_goldens), 'blocksfull': (blockfull_goldens, tapsfull_goldens), 'enc16': (encoder_goldens,)}
+EXTRA = {'fgd': (fgd_goldens,), 'blocks': (block_goldens, taps_goldens), 'blocksfull': (blockfull_goldens, tapsfull_goldens), 'enc16': (encoder_goldens,)}
 
 
 def write_fixture(name, runs, NPERT):
