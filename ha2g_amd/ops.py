@@ -298,6 +298,19 @@ class EmbeddingFunction(torch.autograd.Function):
     def forward(ctx, tok, w):
         tok = tok.contiguous()
         out = torch.empty(*tok.shape, w.shape[1], dtype=torch.float32, device=w.device)
+        st = getattr(w, '_ha2g_sparse', None)
+        ctx.sparse = st
+        if st is not None:
+            # row-wise (sparse) table: compact the batch's ids, replay the zero-gradient Adam updates those rows missed since they were
+            # last touched (dense Adam moves every row every step), THEN read them
+            n = tok.numel()
+            uniq = torch.empty(n + 1, dtype=torch.int64, device=w.device)
+            remap = torch.empty(n, dtype=torch.int64, device=w.device)
+            cpos = torch.empty(n, dtype=torch.int32, device=w.device)
+            count = torch.empty(1, dtype=torch.int32, device=w.device)
+            check(lib.ha2g_unique_tokens(tok.data_ptr(), n, st.map.data_ptr(), cpos.data_ptr(), uniq.data_ptr(), remap.data_ptr(), count.data_ptr(), _stream()))
+            st.catch_up(uniq, count, n + 1)
+            ctx.compact = (uniq, remap, count)
         check(lib.ha2g_embedding_fwd_f32(tok.data_ptr(), w.data_ptr(), out.data_ptr(), tok.numel(), w.shape[1], _stream()))
         ctx.save_for_backward(tok)
         ctx.wshape = w.shape
@@ -307,10 +320,17 @@ class EmbeddingFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (tok,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.sparse is not None:                       # compact gradient: one summed row per distinct id, handed to the optimizer
+            uniq, remap, count = ctx.compact
+            n, C = tok.numel(), ctx.wshape[1]
+            vals = torch.zeros(n + 1, C, dtype=torch.float32, device=dy.device)
+            check(lib.ha2g_embedding_bwd_f32(remap.data_ptr(), dy.data_ptr(), vals.data_ptr(), n, C, 0, workspace(dy.device).data_ptr(), _stream()))
+            ctx.sparse.pending.append((uniq, count, vals))
+            return None, None
         tgt = _grad_target(ctx.wref)
         direct = tgt is not None and tgt.is_contiguous()
         dw = tgt if direct else torch.zeros(ctx.wshape, dtype=torch.float32, device=dy.device)
-        dy = dy.contiguous()
         check(lib.ha2g_embedding_bwd_f32(tok.data_ptr(), dy.data_ptr(), dw.data_ptr(), tok.numel(), ctx.wshape[1], 0,
                                          workspace(dy.device).data_ptr(), _stream()))          # the kernel accumulates (dW +=)
         return None, (None if direct else dw)
@@ -999,3 +1019,71 @@ class WeightedSumFunction(torch.autograd.Function):
 
 def weighted_sum(terms, weights):
     return WeightedSumFunction.apply(tuple(weights), *terms)
+
+
+# ------------------------------------------------------------------------------------------------
+# sparse embedding tables (csrc/sparse.hip): compact row gradients + lazy row-wise Adam
+# ------------------------------------------------------------------------------------------------
+
+class SparseTable:
+    """Optimizer-side state of one embedding table [n_rows, C] that is updated row-wise (ha2g_amd.optim.FusedAdam(sparse=...)).
+    `pending` collects this step's compact gradients (uniq ids, device count, summed rows) from EmbeddingFunction.backward."""
+
+    def __init__(self, weight, opt):
+        V, C = weight.shape
+        dev = weight.device
+        self.weight, self.opt = weight, opt
+        self.m = torch.zeros(V, C, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(V, C, dtype=torch.float32, device=dev)
+        self.last = torch.zeros(V, dtype=torch.int32, device=dev)                    # optimizer step each row is up to date with
+        self.map = torch.full((V,), 2 ** 31 - 1, dtype=torch.int32, device=dev)      # scratch of ha2g_unique_tokens
+        self.pending = []
+
+    def _run(self, ids, count, max_rows, vals):
+        g = self.opt.param_groups[0]
+        w = self.weight.data
+        check(lib.ha2g_sparse_adam_f32(w.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.last.data_ptr(), ids.data_ptr(), count.data_ptr(),
+                                       max_rows, _p(vals), self.opt.table.data_ptr(), self.opt.step_t.data_ptr(), w.shape[1],
+                                       float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), _stream()))
+
+    def catch_up(self, ids, count, max_rows):
+        self._run(ids, count, max_rows, None)
+
+    def merged(self):
+        """This step's compact gradient as ONE (ids, count, rows) list with distinct ids (several backward passes / ranks are merged
+        by running the id lists through the same compaction + deterministic row summation the embedding backward uses)."""
+        if len(self.pending) == 1:
+            return self.pending[0]
+        ids = torch.cat([torch.where(torch.arange(u.numel(), device=u.device) < c, u, torch.zeros_like(u)) for u, c, _ in self.pending])
+        rows = torch.cat([v * (torch.arange(v.shape[0], device=v.device) < c).unsqueeze(1) for _, c, v in self.pending])
+        return merge_rows(ids, rows, self.map)
+
+    def step(self):
+        if not self.pending:
+            return
+        ids, count, vals = self.merged()
+        self._run(ids, count, ids.numel(), vals)
+        self.pending = []
+
+    def sync(self):
+        """Bring EVERY row up to date (before reading the table outside the embedding forward: checkpoints, evaluation dumps)."""
+        V = self.weight.shape[0]
+        ids = torch.empty(V, dtype=torch.int64, device=self.weight.device)
+        count = torch.empty(1, dtype=torch.int32, device=self.weight.device)
+        check(lib.ha2g_iota_ids(ids.data_ptr(), count.data_ptr(), V, _stream()))
+        self.catch_up(ids, count, V)
+
+
+def merge_rows(ids, rows, map_scratch):
+    """(ids [n] with repeats -- entries that carry nothing must be id 0 with a zero row --, rows [n, C]) -> (uniq, count, summed rows)."""
+    n, C = rows.shape
+    dev = rows.device
+    ids = ids.contiguous()
+    uniq = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    remap = torch.empty(n, dtype=torch.int64, device=dev)
+    cpos = torch.empty(n, dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    check(lib.ha2g_unique_tokens(ids.data_ptr(), n, map_scratch.data_ptr(), cpos.data_ptr(), uniq.data_ptr(), remap.data_ptr(), count.data_ptr(), _stream()))
+    vals = torch.zeros(n + 1, C, dtype=torch.float32, device=dev)
+    check(lib.ha2g_embedding_bwd_f32(remap.data_ptr(), rows.contiguous().data_ptr(), vals.data_ptr(), n, C, 0, workspace(dev).data_ptr(), _stream()))
+    return uniq, count, vals

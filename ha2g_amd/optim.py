@@ -17,10 +17,15 @@ def _storage_span(p):
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=5e-4, betas=(0.5, 0.999), eps=1e-8):
+    TABLE_STEPS = 1 << 20         # per-step Adam scalars kept for the lazy row updates of sparse tables (8 MB)
+
+    def __init__(self, params, lr=5e-4, betas=(0.5, 0.999), eps=1e-8, sparse=()):
+        """sparse: embedding tables (subset of params) updated ROW-WISE from compact gradients (ha2g_amd.ops.SparseTable, csrc/sparse.hip):
+        they stay out of the flat buffers; results are bit-identical to the dense update (tests/test_gpu_sparse.py)."""
         params = [p for p in params]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
-        ps = [p for p in self.param_groups[0]['params'] if p.requires_grad]
+        sparse_ids = {id(p) for p in sparse if p.requires_grad}
+        ps = [p for p in self.param_groups[0]['params'] if p.requires_grad and id(p) not in sparse_ids]
         assert ps, 'no trainable parameters'
         dev = ps[0].device
         assert all(p.dtype == torch.float32 and p.device == dev for p in ps)
@@ -45,6 +50,16 @@ class FusedAdam(torch.optim.Optimizer):
                 p.grad = gv
                 self._views.append((p, gv))
         self.total = total
+        self.sparse_tables = []
+        if sparse_ids:
+            from .ops import SparseTable
+            self.table = torch.zeros(self.TABLE_STEPS, 2, dtype=torch.float32, device=dev)
+            self._host_step = 0
+            for p in self.param_groups[0]['params']:
+                if id(p) in sparse_ids:
+                    st = SparseTable(p, self)
+                    p._ha2g_sparse = st
+                    self.sparse_tables.append(st)
 
     def zero_grad(self, set_to_none=False):
         """Gradients live in the flat buffer: zero it in place and keep the views installed."""
@@ -52,6 +67,8 @@ class FusedAdam(torch.optim.Optimizer):
         for p, gv in self._views:
             if p.grad is not gv:
                 p.grad = gv
+        for st in self.sparse_tables:
+            st.pending = []
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -66,8 +83,22 @@ class FusedAdam(torch.optim.Optimizer):
         check(lib.ha2g_adam_f32(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
                                 self.total, float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
                                 self.step_t.data_ptr(), st))
+        if self.sparse_tables:
+            self._host_step += 1
+            assert self._host_step < self.TABLE_STEPS - 1, 'FusedAdam: per-step scalar table exhausted'
+            check(lib.ha2g_adam_scalars(self.step_t.data_ptr(), float(g['lr']), float(g['betas'][0]), float(g['betas'][1]),
+                                        self.table.data_ptr(), self.TABLE_STEPS, st))
+            for tb in self.sparse_tables:
+                tb.step()
+
+    def sync_sparse(self):
+        """Replay the pending zero-gradient updates of every row of the sparse tables (call before saving / exporting their weights)."""
+        for tb in self.sparse_tables:
+            tb.sync()
 
     def allreduce_grads(self, group=None, async_op=False):
         """Data-parallel: average the flat gradient buffer over ranks (one RCCL all-reduce over xGMI)."""
         from . import ddp
+        for tb in self.sparse_tables:
+            ddp.exchange_sparse_(tb, group)
         return ddp.average_(self.flat_g, group, async_op)

@@ -29,8 +29,11 @@ def init_model(args, lang_model, speaker_model, pose_dim, _device=None, pose_lev
 class HierarchyTrainer:
     """Everything train_epochs() builds before its batch loop (reference scripts/train.py:114-170)."""
 
-    def __init__(self, args, lang_model, speaker_model, pose_dim, device, pose_dims=(15, 21, 27)):
+    def __init__(self, args, lang_model, speaker_model, pose_dim, device, pose_dims=(15, 21, 27), sparse_embeddings=False):
+        """sparse_embeddings: update the word-embedding tables row-wise from compact gradients (bit-identical to the dense update,
+        see ha2g_amd.optim.FusedAdam); call sync_sparse() before reading those tables outside the step (checkpoints)."""
         self.args, self.device = args, device
+        self.sparse_embeddings = sparse_embeddings
         self.expressive = len(pose_dims) == 6        # scripts/train_expressive.py:160-168: six generators 24/30/36/66/96/126
         _, self.discriminator, self.audio_encoder, self.text_encoder, _ = init_model(args, lang_model, speaker_model, pose_dim, device,
                                                                                      pose_level=len(pose_dims))
@@ -45,10 +48,15 @@ class HierarchyTrainer:
     def make_optimizers(self):
         a = self.args
         lr = float(a.learning_rate)
-        self.gen_opts = [FusedAdam(g.parameters(), lr=lr, betas=(0.5, 0.999)) for g in self.gens]
+        sp = (lambda enc: [enc.embedding.weight]) if self.sparse_embeddings else (lambda enc: [])
+        self.gen_opts = [FusedAdam(g.parameters(), lr=lr, betas=(0.5, 0.999), sparse=sp(g.text_encoder)) for g in self.gens]
         self.audio_opt = FusedAdam(self.audio_encoder.parameters(), lr=lr, betas=(0.5, 0.999))
-        self.text_opt = FusedAdam(self.text_encoder.parameters(), lr=lr, betas=(0.5, 0.999))
+        self.text_opt = FusedAdam(self.text_encoder.parameters(), lr=lr, betas=(0.5, 0.999), sparse=sp(self.text_encoder))
         self.dis_opt = FusedAdam(self.discriminator.parameters(), lr=lr * a.discriminator_lr_weight, betas=(0.5, 0.999))
+
+    def sync_sparse(self):
+        for o in self.gen_opts + [self.text_opt]:
+            o.sync_sparse()
 
     def broadcast_parameters(self, src=0):
         """DDP start-up: every rank adopts rank `src`'s parameters and buffers."""
@@ -57,7 +65,7 @@ class HierarchyTrainer:
             dist.broadcast(o.flat_p, src)
         for m in self.modules():
             for p in m.parameters():
-                if not p.requires_grad:                      # frozen parameters (freeze_wordembed) live outside the flat buffers
+                if not p.requires_grad or getattr(p, '_ha2g_sparse', None) is not None:      # frozen / row-wise tables live outside the flat buffers
                     dist.broadcast(p.data, src)
             for b in m.buffers():
                 dist.broadcast(b, src)

@@ -211,6 +211,9 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
     loss.backward()                                      # stage 1: losses, discriminator, generators (down to the cut)
     works = []
     if ddp.active():
+        for o in gen_optimizers:
+            for tb in getattr(o, 'sparse_tables', ()):
+                ddp.exchange_sparse_(tb)
         works = [ddp.average_(o.flat_g, async_op=True) if hasattr(o, 'flat_g') else ddp.average_module_grads_([o])
                  for o in gen_optimizers]
     pairs = [(o, c.grad) for o, c in zip(enc_outs, enc_cut) if c is not o and c.grad is not None]

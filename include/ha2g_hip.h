@@ -215,6 +215,20 @@ int ha2g_adam_step_inc(int* step, void* stream);
 int ha2g_adam_f32(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
                   const int* step, void* stream);
 
+/* ---- sparse embedding gradients + lazy row-wise Adam (tables: model/hierarchy_net.py:31-34, optimizer train.py:155-170) ----
+ * unique_tokens: tok [n] int64 -> uniq (slot 0 = the padding id 0, then distinct ids in order of first occurrence), remap [n] (slot of each
+ *   position), count (device int32); map = int32 [n_rows] scratch that is INT_MAX on entry and exit, cpos = int32 [n] scratch.  The compact row
+ *   gradient is then ha2g_embedding_bwd_f32(remap, dY, vals [count][C], heavy = 0).
+ * adam_scalars: table[*step] = {lr/(1-b1^t), 1/sqrt(1-b2^t)} exactly as ha2g_adam_f32's prologue computes them (float2 table of `cap` entries).
+ * sparse_adam: for the `*count` distinct rows `ids` (grid = max_rows): replay the zero-gradient Adam updates the row missed since last[row]
+ *   (dense Adam moves EVERY row every step), then, when vals != NULL, apply step *step with gradient row vals[r]; vals == NULL = catch-up only
+ *   (before an embedding read).  Bit-identical to ha2g_adam_f32 on a dense gradient with zeros elsewhere. */
+int ha2g_unique_tokens(const long* tok, int n, int* map, int* cpos, long* uniq, long* remap, int* count, void* stream);
+int ha2g_adam_scalars(const int* step, double lr, double b1, double b2, void* table, int cap, void* stream);
+int ha2g_sparse_adam_f32(float* W, float* M, float* V, int* last, const long* ids, const int* count, int max_rows, const float* vals,
+                         const void* table, const int* step, int C, double b1, double b2, double eps, void* stream);
+int ha2g_iota_ids(long* ids, int* count, int n, void* stream);
+
 /* ---- log-mel front-end on the GPU: replaces the offline librosa step
  *      scripts/utils/data_utils.py:34-38 extract_melspectrogram / dataset_script/script/make_ted_dataset.py:121-123:
  *      melspectrogram(y, sr=16000, n_fft=1024, hop_length=512, power=2) -> power_to_db(ref=max over the clip) -> float16.

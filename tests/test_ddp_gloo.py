@@ -128,3 +128,32 @@ def test_flat_buffer_average_two_ranks(tmp_path):
     for avg, (l0, l1) in zip(res['avg'], res['locals']):
         assert not torch.equal(l0, l1)
         assert torch.allclose(avg, (l0 + l1) / 2, rtol=1e-6, atol=1e-9)
+
+
+def _sparse_worker(rank, world, port, out):
+    """ddp.gather_sparse_rows on CPU tensors: only max-count rows travel, invalid tail entries come back as (id 0, zero row), rows pre-scaled."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ha2g_amd import ddp
+    g = torch.Generator().manual_seed(50 + rank)
+    cap, C = 16, 12
+    n = 5 if rank == 0 else 9                                   # ranks hold different numbers of distinct rows
+    ids = torch.zeros(cap, dtype=torch.int64)
+    ids[1:n] = torch.randperm(30, generator=g)[:n - 1] + 1      # slot 0 = padding id 0
+    rows = torch.randn(cap, C, generator=g)
+    rows[n:] = 7.0                                              # garbage past the count must not travel
+    ids_all, rows_all = ddp.gather_sparse_rows(ids, torch.tensor([n], dtype=torch.int32), rows)
+    assert ids_all.shape == (2 * 9,) and rows_all.shape == (2 * 9, C)
+    if rank == 0:
+        torch.save({'ids_all': ids_all, 'rows_all': rows_all, 'ids0': ids, 'rows0': rows}, out)
+    dist.destroy_process_group()
+
+
+def test_sparse_row_gather_two_ranks(tmp_path):
+    out = str(tmp_path / 'sp.pt')
+    mp.spawn(_sparse_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    ids_all, rows_all = res['ids_all'], res['rows_all']
+    assert torch.equal(ids_all[:5], res['ids0'][:5]) and int(ids_all[5:9].abs().sum()) == 0      # rank 0's block: 5 valid, 4 padded
+    assert torch.allclose(rows_all[:5], res['rows0'][:5] * 0.5) and float(rows_all[5:9].abs().sum()) == 0.0
+    assert int((ids_all[9:] != 0).sum()) == 8                                                     # rank 1: 9 valid (slot 0 + 8 ids)
