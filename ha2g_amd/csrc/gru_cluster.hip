@@ -99,17 +99,27 @@ __device__ __forceinline__ int cluster_same_xcd(__amdgpu_buffer_rsrc_t xr, int h
     return same;
 }
 
-// 12 MFMAs per 16-wide k-block: gh^T[3 x 16 units][16 rows] += W_hh[.., 16m..16m+15] * h^T
-#define HA2G_FWD_BLOCKS(M0, NB)                                                                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < (NB); ++i_) {                                                         \
-        const float4 hb_ = *reinterpret_cast<const float4*>(&hs[lb * LDH + 16 * ((M0) + i_) + 4 * g]);           \
-        const float* ph_ = &hb_.x;                                                                                \
-        const float* pr_ = &wf[(M0) + i_].x; const float* pz_ = &wf[NJT + (M0) + i_].x;                          \
-        const float* pn_ = &wf[2 * NJT + (M0) + i_].x;                                                            \
-        _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                        \
-            ar = __builtin_amdgcn_mfma_f32_16x16x4f32(pr_[u_], ph_[u_], ar, 0, 0, 0);                             \
-            az = __builtin_amdgcn_mfma_f32_16x16x4f32(pz_[u_], ph_[u_], az, 0, 0, 0);                             \
-            an = __builtin_amdgcn_mfma_f32_16x16x4f32(pn_[u_], ph_[u_], an, 0, 0, 0);                             \
+// 12 MFMAs per 16-wide k-block: gh^T[3 x 16 units][16 rows] += W_hh[.., 16m..16m+15] * h^T, for the chain positions I0 .. I1-1 of the
+// member's rotated order m_i = (4Q + i) mod 19.  The B operand (h, from the LDS tile) of position i+1 is fetched BEFORE the MFMAs of
+// position i issue: with a single operand register set hipcc put every ds_read_b128 right in front of its first MFMA, i.e. 19 exposed
+// LDS round trips (~1.1 us) per step.
+#define HA2G_MI(i) ((TPW * Q + (i)) % NJT)
+#define HA2G_FWD_CHAIN(I0, I1)                                                                                    \
+    if ((I0) < (I1)) {                                                                                            \
+        float4 hb_ = *reinterpret_cast<const float4*>(&hs[lb * LDH + 16 * HA2G_MI(I0) + 4 * g]);                 \
+        _Pragma("unroll") for (int i_ = (I0); i_ < (I1); ++i_) {                                                  \
+            float4 hn_ = hb_;                                                                                     \
+            if (i_ + 1 < (I1)) hn_ = *reinterpret_cast<const float4*>(&hs[lb * LDH + 16 * HA2G_MI(i_ + 1) + 4 * g]); \
+            __builtin_amdgcn_sched_barrier(0);          /* keep the prefetch ahead of this position's MFMAs (hipcc sinks it otherwise) */ \
+            const float* ph_ = &hb_.x;                                                                            \
+            const float* pr_ = &wf[HA2G_MI(i_)].x; const float* pz_ = &wf[NJT + HA2G_MI(i_)].x;                   \
+            const float* pn_ = &wf[2 * NJT + HA2G_MI(i_)].x;                                                      \
+            _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                    \
+                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(pr_[u_], ph_[u_], ar, 0, 0, 0);                         \
+                az = __builtin_amdgcn_mfma_f32_16x16x4f32(pz_[u_], ph_[u_], az, 0, 0, 0);                         \
+                an = __builtin_amdgcn_mfma_f32_16x16x4f32(pn_[u_], ph_[u_], an, 0, 0, 0);                         \
+            }                                                                                                     \
+            hb_ = hn_;                                                                                            \
         }                                                                                                         \
     }
 
@@ -174,7 +184,7 @@ __device__ __forceinline__ void gru_fwd_member(const float* __restrict__ gi, con
     float4 gir = zero4, giz = zero4, gin = zero4;        // gi of the step whose gates run next
     float4 gir_n = zero4, giz_n = zero4, gin_n = zero4;  // ... of the step after (prefetched)
     float4 d_h = zero4, d_r = zero4, d_z = zero4, d_n = zero4, d_q = zero4;   // deferred y / reserve stores of the previous step
-    long d_bt = -1;
+    int d_bt = -1;
     if (jok && bok) {
         const float* gp = gi + ((long)(b * T + (dir ? T - 1 : 0)) * 2 + dir) * 3 * H + j;
         gir = *reinterpret_cast<const float4*>(gp);
@@ -183,38 +193,42 @@ __device__ __forceinline__ void gru_fwd_member(const float* __restrict__ gi, con
     }
     u32x4 pa1 = {0u, 0u, 0u, 0u}, pb1 = pa1, pa2 = pa1, pb2 = pa1, pa3 = pa1, pb3 = pa1, pa4 = pa1, pb4 = pa1;
 
-    // the point of a step after which no poll is outstanding: fetch the NEXT step's gi, flush the PREVIOUS step's outputs
-#define HA2G_FWD_PREFETCH_FLUSH(S)                                                                                \
-    {                                                                                                             \
-        if ((S) + 1 < T && jok && bok) {                                                                          \
-            const int tn_ = dir ? T - 2 - (S) : (S) + 1;                                                          \
-            const float* gp_ = gi + ((long)(b * T + tn_) * 2 + dir) * 3 * H + j;                                  \
-            gir_n = *reinterpret_cast<const float4*>(gp_);                                                        \
-            giz_n = *reinterpret_cast<const float4*>(gp_ + H);                                                    \
-            gin_n = *reinterpret_cast<const float4*>(gp_ + 2 * H);                                                \
-        }                                                                                                         \
-        if (d_bt >= 0) {                                                                                          \
-            *reinterpret_cast<float4*>(y + d_bt * 2 * H + dir * H + j) = d_h;                                     \
-            if (rs) {                                                                                             \
-                float* rp_ = rs + (d_bt * 2 + dir) * 4 * H + j;                                                   \
-                *reinterpret_cast<float4*>(rp_) = d_r;                                                            \
-                *reinterpret_cast<float4*>(rp_ + H) = d_z;                                                        \
-                *reinterpret_cast<float4*>(rp_ + 2 * H) = d_n;                                                    \
-                *reinterpret_cast<float4*>(rp_ + 3 * H) = d_q;                                                    \
-            }                                                                                                     \
-            d_bt = -1;                                                                                            \
-        }                                                                                                         \
+    // running per-lane pointers (advanced by one time step per iteration: no 64-bit index arithmetic in the loop)
+    const long tstep = dir ? -1 : 1;
+    const float* gi_next = gi + ((long)(b * (long)T + (dir ? T - 2 : 1)) * 2 + dir) * 3 * H + j;      // gi row of the step after the current one
+    float* y_cur = y + ((long)b * T + (dir ? T - 1 : 0)) * 2 * H + dir * H + j;                      // outputs of the current step
+    float* rs_cur = rs ? rs + (((long)b * T + (dir ? T - 1 : 0)) * 2 + dir) * 4 * H + j : nullptr;
+    float* y_def = nullptr; float* rs_def = nullptr;                                                 // ... of the previous step (deferred)
+    // (1) while the polls are in flight: fetch the NEXT step's gi (loads only: the polls' vmcnt wait stays exact)
+#define HA2G_FWD_PREFETCH(S)                                                                                      \
+    if ((S) + 1 < T && jok && bok) {                                                                              \
+        gir_n = *reinterpret_cast<const float4*>(gi_next);                                                        \
+        giz_n = *reinterpret_cast<const float4*>(gi_next + H);                                                    \
+        gin_n = *reinterpret_cast<const float4*>(gi_next + 2 * H);                                                \
     }
+    // (2) after the last poll of the step: flush the PREVIOUS step's outputs (stores never sit in front of a poll)
+#define HA2G_FWD_FLUSH                                                                                            \
+    if (d_bt >= 0) {                                                                                              \
+        *reinterpret_cast<float4*>(y_def) = d_h;                                                                  \
+        if (rs) {                                                                                                 \
+            *reinterpret_cast<float4*>(rs_def) = d_r;                                                             \
+            *reinterpret_cast<float4*>(rs_def + H) = d_z;                                                         \
+            *reinterpret_cast<float4*>(rs_def + 2 * H) = d_n;                                                     \
+            *reinterpret_cast<float4*>(rs_def + 3 * H) = d_q;                                                     \
+        }                                                                                                         \
+        d_bt = -1;                                                                                                \
+    }
+#define HA2G_FWD_PREFETCH_FLUSH(S) { HA2G_FWD_PREFETCH(S) HA2G_FWD_FLUSH }
 
     for (int s = 0; s < T; ++s) {
-        const int t = dir ? T - 1 - s : s;
+        // time index of step s: dir ? T - 1 - s : s (carried by the running pointers)
         f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
         if (s == 0) {
             HA2G_FWD_PREFETCH_FLUSH(0)                                    // h_0 = 0: no recurrent product, nothing to gather
             lds_barrier();
         } else if (dbg & 2) {                                             // ablation: no exchange (stale foreign columns)
             lds_barrier();
-            if (tile_on) { HA2G_FWD_BLOCKS(0, NJT) }
+            if (tile_on) { HA2G_FWD_CHAIN(0, NJT) }
             HA2G_FWD_PREFETCH_FLUSH(s)
             lds_barrier();
         } else {
@@ -224,16 +238,14 @@ __device__ __forceinline__ void gru_fwd_member(const float* __restrict__ gi, con
             // own member's blocks first; the polls of all four foreign members are issued after PA of them -- late enough that
             // the granules published at the end of the previous step have reached L2, early enough to return under the rest
             constexpr int PA_ = PA < NOWN ? PA : NOWN;
-            if (tile_on) { HA2G_FWD_BLOCKS(TPW * Q, PA_) }
+            if (tile_on) { HA2G_FWD_CHAIN(0, PA_) }
             HA2G_POLL_ISSUE(1, P1) HA2G_POLL_ISSUE(2, P2) HA2G_POLL_ISSUE(3, P3) HA2G_POLL_ISSUE(4, P4)
-            if (tile_on) { HA2G_FWD_BLOCKS(TPW * Q + PA_, NOWN - PA_) }
+            if (tile_on) { HA2G_FWD_CHAIN(PA_, NOWN) }
+            HA2G_FWD_PREFETCH(s)                                          // issues under the polls' round trip
             HA2G_POLL_WAIT_STAGE(1, P1) HA2G_POLL_WAIT_STAGE(2, P2) HA2G_POLL_WAIT_STAGE(3, P3) HA2G_POLL_WAIT_STAGE(4, P4)
-            HA2G_FWD_PREFETCH_FLUSH(s)
+            HA2G_FWD_FLUSH
             lds_barrier();
-            if (tile_on) {
-                HA2G_FWD_BLOCKS(TPW * P1, HA2G_NB(P1)) HA2G_FWD_BLOCKS(TPW * P2, HA2G_NB(P2))
-                HA2G_FWD_BLOCKS(TPW * P3, HA2G_NB(P3)) HA2G_FWD_BLOCKS(TPW * P4, HA2G_NB(P4))
-            }
+            if (tile_on) { HA2G_FWD_CHAIN(NOWN, NJT) }                     // the other four members' blocks, ring order
         }
         // ---- gates (C/D layout: col = batch lane&15, row = 4*(lane>>4) + reg) ----
         float4 hn4 = zero4;
@@ -255,7 +267,8 @@ __device__ __forceinline__ void gru_fwd_member(const float* __restrict__ gi, con
                     ph[u] = (1.f - zz) * nn + zz * hpp[u];
                 }
                 d_h = hn4;
-                d_bt = (long)b * T + t;                                   // stored after the next step's last poll
+                d_bt = 1;                                                 // stored after the next step's last poll
+                y_def = y_cur; rs_def = rs_cur;
             }
             if (s + 1 < T && !(dbg & 2)) {                                // publish first: 4 floats = 2 granule pairs = 2 x 16 B
                 const int go = (((s & 1) * 16 + lb) * HP + j) * 8;
@@ -271,8 +284,10 @@ __device__ __forceinline__ void gru_fwd_member(const float* __restrict__ gi, con
         }
         if (tile_on) *reinterpret_cast<float4*>(&hs[lb * LDH + j]) = hn4;        // own columns of h_{s+1} (zeros for padded rows / units)
         gir = gir_n; giz = giz_n; gin = gin_n;
+        gi_next += tstep * 6 * H; y_cur += tstep * 2 * H;
+        if (rs) rs_cur += tstep * 8 * H;
     }
-    HA2G_FWD_PREFETCH_FLUSH(T)                                            // the last step's outputs
+    HA2G_FWD_FLUSH                                                        // the last step's outputs
 #undef HA2G_NB
 }
 
