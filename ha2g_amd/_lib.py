@@ -63,6 +63,9 @@ def check(rc):
     if rc != 0:
         raise Ha2gError('ha2g kernel call failed (%d): %s' % (rc, lib.ha2g_last_error().decode()))
 
-# matrix-core mode (see ha2g_gemm_set_mode in include/ha2g_hip.h); HA2G_GEMM_MODE overrides the library default (6)
-if os.environ.get("HA2G_GEMM_MODE"):
-    lib.ha2g_gemm_set_mode(int(os.environ["HA2G_GEMM_MODE"]))
+# matrix-core mode (see ha2g_gemm_set_mode in include/ha2g_hip.h) and direct-convolution switches; the HA2G_GEMM_MODE / HA2G_DIRECT_C32
+# environment variables override the library defaults (tests restore THESE values after toggling modes)
+DEFAULT_GEMM_MODE = int(os.environ.get("HA2G_GEMM_MODE", "14"))
+DEFAULT_DIRECT_C32 = int(os.environ.get("HA2G_DIRECT_C32", "1"))
+lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
+lib.ha2g_conv_debug_direct_c32(DEFAULT_DIRECT_C32)

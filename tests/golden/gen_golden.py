@@ -579,7 +579,11 @@ def main():
         print('case', name, case)
         runs = {}
         global PERTURB_DRAW
-        NPERT = 8                               # float32 runs with one-ulp input perturbations (plus the plain float32 run)
+        # float32 runs with one-ulp input perturbations (plus the plain float32 run).  24 since round 2 (8 before): the scatter of the
+        # SE-ResNet's gradients at B = 3..4 is driven by rare ReLU-decision flips (heavy-tailed), and the maximum over 9 runs
+        # under-estimated it -- a second valid fp32 summation order of the forward convolutions landed at 1.04-1.10x of 3 x that
+        # maximum on one of ~1000 tensors.  The float64 truth is unchanged; only @noise can grow.
+        NPERT = 24
         plan = [('f64', torch.float64, 0.0, 0), ('f32', torch.float32, 0.0, 0), ('cond', torch.float64, 6e-8, 0)]
         plan += [('f32p%d' % i, torch.float32, 6e-8, i + 1) for i in range(NPERT)]
         for tag, dt, pert, draw in plan:

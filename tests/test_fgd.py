@@ -86,6 +86,6 @@ def test_gpu_fgd_evaluator_matches_reference(golden):
     fd, dist = ev.get_scores()
     _close(fd, g, 'fgd/frechet', 1e-4, scale=_trace_scale(g))
     _close(dist, g, 'fgd/feat_dist', 1e-4)
-    assert ev.get_diversity_scores() > 0
+    assert ev.get_diversity_scores() >= 0          # a random re-pairing of 3 batches can be the identity
     ev.reset()
     assert ev.get_no_of_samples() == 0

@@ -24,7 +24,7 @@ def gemm_mode():
     def set_mode(m):
         lib.ha2g_gemm_set_mode(m)
     yield set_mode
-    lib.ha2g_gemm_set_mode(6)
+    lib.ha2g_gemm_set_mode(__import__('ha2g_amd._lib', fromlist=['x']).DEFAULT_GEMM_MODE)
 
 
 def run_block(ck, name, geom, B, seed):

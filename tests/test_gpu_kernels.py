@@ -278,7 +278,7 @@ def test_split_bf16_core_opt_in():
         c = ops.gemm(a.to(dev), b.to(dev), transb=True)
         y = we.conv_fwd(x.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), None, 1, 1, 0)
     finally:
-        lib.ha2g_gemm_set_mode(6)
+        lib.ha2g_gemm_set_mode(__import__('ha2g_amd._lib', fromlist=['x']).DEFAULT_GEMM_MODE)
     assert relerr(c, a.double() @ b.double().t()) < 1e-5
     assert relerr(y.permute(0, 3, 1, 2), F.conv2d(x.double(), w.double(), padding=1)) < 1e-5
 
@@ -304,7 +304,7 @@ def test_three_piece_split_core_is_fp32_accurate():
             rms = lambda g, r: float(((g.double().cpu() - r) ** 2).mean().sqrt() / (r ** 2).mean().sqrt())
             out[mode] = (rms(c, ref_c), rms(y.permute(0, 3, 1, 2), ref_y))
     finally:
-        lib.ha2g_gemm_set_mode(6)
+        lib.ha2g_gemm_set_mode(__import__('ha2g_amd._lib', fromlist=['x']).DEFAULT_GEMM_MODE)
     assert out[14][0] <= 1.5 * out[0][0] + 1e-8 and out[14][0] < 5e-7, out
     assert out[14][1] <= 1.5 * out[0][1] + 1e-8 and out[14][1] < 5e-7, out
 
@@ -366,7 +366,7 @@ def test_direct_conv3x3_c32(shape):
             dx = we.conv_dgrad(dyg, wg, (N, H, W, 32), 1, 1, out=acc, beta=1.0)
             outs[mode] = (y.permute(0, 3, 1, 2), dx.permute(0, 3, 1, 2))
     finally:
-        lib.ha2g_conv_debug_direct_c32(0)
+        lib.ha2g_conv_debug_direct_c32(__import__('ha2g_amd._lib', fromlist=['x']).DEFAULT_DIRECT_C32)
     for mode in (3, 0, 4):
         assert relerr(outs[mode][0], ref_y) < 2e-6, mode
         # split-bf16 data gradients: ~4e-6 rms; the direct kernels need W + 2 > 64, narrower maps fall back to the split GEMM
@@ -396,7 +396,7 @@ def test_plain_bf16_mode_is_bf16_accurate():
         dx = we.conv_dgrad(dyg, wg, (2, 20, 12, 64), 1, 1)
         dw = we.conv_wgrad(xg, dyg, wg, 1, 1)
     finally:
-        lib.ha2g_gemm_set_mode(6)
+        lib.ha2g_gemm_set_mode(__import__('ha2g_amd._lib', fromlist=['x']).DEFAULT_GEMM_MODE)
     refs = [(c_nt, a.double() @ b.double().t()), (c_nn, a.double() @ b2.double()), (c_tn, a.double().t() @ a.double()[:, :300]),
             (y.permute(0, 3, 1, 2), F.conv2d(x.double(), w.double(), padding=1)),
             (dx.permute(0, 3, 1, 2), F.conv_transpose2d(dy.double(), w.double(), padding=1)),

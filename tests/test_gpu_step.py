@@ -216,7 +216,7 @@ def _full_size_step(expressive, B, fuse, mode, seed=21):
         ret = tr.train_iter(11, text, spec, target, vid)
     finally:
         th.FUSE_CHAINS, th.randperm_source = old
-        lib.ha2g_gemm_set_mode(6)
+        lib.ha2g_gemm_set_mode(__import__('ha2g_amd._lib', fromlist=['x']).DEFAULT_GEMM_MODE)
     names = ['g%d' % (i + 1) for i in range(len(tr.gens))] + ['audio', 'text']
     grads = {n: o.flat_g.clone() for n, o in zip(names, tr.gen_opts + [tr.audio_opt, tr.text_opt])}
     assert ops.gru_cluster_error(dev) == 0
