@@ -148,7 +148,7 @@ def main():
     torch.manual_seed(0)
     from ha2g_amd import schema
     from ha2g_amd._lib import lib as _lib0
-    default_mode = int(os.environ.get('HA2G_GEMM_MODE', '22' if a.bf16 else '14'))
+    default_mode = int(os.environ.get('HA2G_GEMM_MODE', '22' if a.bf16 else '6'))
     _lib0.ha2g_gemm_set_mode(default_mode)
     P = 126 if a.expressive else 27
     args = hierarchy_args(expressive=a.expressive)            # config[_expressive]/hierarchy.yml, dropout 0.3
@@ -268,7 +268,7 @@ def main():
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype='bf16' if a.bf16 else 'f32', data='synthetic', launch='hipGraph replay' if a.graph else 'eager',
                    matrix_core=('bf16 operands (1 MFMA per product), fp32 accumulate, fp32 storage and master weights; GRU recurrences fp32' if a.bf16 else
-                                'forward GEMMs/convs: 3-piece bf16 split (6 MFMA, fp32-accurate: 3.7e-7 rms-rel) / fp32 MFMA; backward: 2-piece split (3 MFMA, 4e-6 rms-rel); fp32 storage and accumulation; GRU recurrences fp32 MFMA'),
+                                'forward: fp32 MFMA; backward GEMMs/convs: split-bf16 x3 MFMA with fp32 accumulate (fp32-class, same parity bar)'),
                    exact_fp32_matrix_core=dict(ms_per_step=round(ms_exact, 3), value=round(a.batch * 34 * world / (ms_exact * 1e-3), 1)),
                    warmup_phase=dict(ms_per_step=round(ms_warm, 3), value=round(a.batch * 34 * world / (ms_warm * 1e-3), 1)),
                    config=dict(workload='%s hierarchy train step, B=%d per GPU, T=34, %d-d pose, '

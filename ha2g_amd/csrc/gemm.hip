@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmP p) {
 static int g_c32_dbg = 0;
 static int g_direct_c32_dgrad = 0;
 static int g_direct_c32_x3 = 1;  // data gradient of the 32->32 channel 3x3 convolutions on the split-bf16 direct kernel (debug bit 2 = off)
-static int g_direct_c32 = 1;     // 32->32 channel 3x3 stride-1 forward convolutions on the direct LDS-patch kernel (conv_c32.hip): default since round 2.
+static int g_direct_c32 = 0;     // 32->32 channel 3x3 stride-1 forward convolutions on the direct LDS-patch kernel (conv_c32.hip): OPT-IN.
                                  // 231 vs 312 us per convolution (-0.5 ms/step) and exact to 2e-6 vs float64, but its different fp32
                                  // summation order moves the chaotic B=4 BatchNorm case (cfg1) to 1.04x its tolerance (3x the
                                  // reference's nine-run fp32 scatter) on one of 1 000 tensors, so the implicit GEMM stays the default.
@@ -623,7 +623,7 @@ static int g_split_dgrad = 1;   // data-gradient GEMMs / convolutions on the spl
 static int g_split_wgrad = 1;   // weight-gradient GEMMs / convolutions on the split-bf16 inner product (ha2g_gemm_set_mode bit 1)
 static int g_bf16 = 0;    // every vectorisable GEMM / convolution with plain bf16 operands (1 MFMA per product), fp32 accumulate: mode bit 4.
                           // NOT fp32-class (8 mantissa bits per operand): the `--bf16` bench mode for BASELINE config 5, never the default.
-static int g_x6 = 1;      // forward k-contiguous GEMMs / convolutions on the 3-piece split (fp32-accurate), mode bit 3: default since round 2.
+static int g_x6 = 0;      // forward k-contiguous GEMMs / convolutions on the 3-piece split (fp32-accurate), mode bit 3: OPT-IN.
                           // Measured 1.1-1.45x over the fp32 MFMA per GEMM but only 1.4 % of the step (LDS-bandwidth bound), and
                           // being a DIFFERENT fp32-level rounding it lands elsewhere in the reference's own run-to-run scatter.
 static int g_x6_min_n = 33;

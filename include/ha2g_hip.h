@@ -46,14 +46,14 @@ long ha2g_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, i
 int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout, int KH,
                           int KW, int stride, int pad, float beta, float* ws, long ws_bytes, void* stream);
 int ha2g_conv2d_weight_ohwi_to_ihwo_f32(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
-/* Matrix-core mode bits; default 14 (bits 1, 2, 3) since round 2 (6 in round 1).  The split-bf16 inner product writes each fp32 operand as hi + lo bf16 halves and
+/* Matrix-core mode bits; default 6.  The split-bf16 inner product writes each fp32 operand as hi + lo bf16 halves and
  * runs a_lo*b_hi + a_hi*b_lo + a_hi*b_hi as three bf16 MFMAs with fp32 accumulation (~4e-6 rms-rel per GEMM vs 4e-7).
  *   bit 1 (on):  WEIGHT gradients (dW = dY^T X, conv wgrad) -- the error goes straight to the optimizer;
  *   bit 2 (on):  DATA gradients (dX = dY W, conv dgrad) -- measured: the worst error/tolerance ratio of the whole-step
  *                parity checks does not move (0.698 -> 0.699, tools/margins.py);
  *   bit 0 (off): forward GEMMs / convolutions too (another 1.5-2.5x on those, but the error compounds through the
  *                34-layer audio tower and the step no longer meets the 1e-4 parity bar).
- *   bit 3 (on):  forward GEMMs / convolutions on the 3-piece split (6 bf16 MFMAs): as accurate as the fp32 MFMA chain
+ *   bit 3 (off): forward GEMMs / convolutions on the 3-piece split (6 bf16 MFMAs): as accurate as the fp32 MFMA chain
  *                (3.7e-7 vs 4.4e-7 rms-rel), 1.1-1.45x faster per GEMM, ~1.4 % of the step.
  *   bit 4 (off): every vectorisable GEMM / convolution with PLAIN bf16 operands (one bf16 MFMA per product, fp32 accumulate,
  *                fp32 storage) -- reduced precision (2^-9 per operand), for BASELINE config 5 / `bench.py --bf16` only.
@@ -61,7 +61,7 @@ int ha2g_conv2d_weight_ohwi_to_ihwo_f32(const float* w, float* wt, int Cout, int
 void ha2g_gemm_set_mode(int mode);
 /* tuning aid: forward GEMMs narrower than n columns stay on the fp32 MFMA */
 void ha2g_gemm_debug_x6_min_n(int n);
-/* bit 0 (default 1 since round 2): forward 32->32 channel 3x3 convolutions on the direct LDS-patch kernel conv_c32.hip (else implicit GEMM);
+/* bit 0 (default 0, opt-in): forward 32->32 channel 3x3 convolutions on the direct LDS-patch kernel conv_c32.hip (else implicit GEMM);
  * bit 1 (default 0): their data gradients on the fp32 direct kernel; bit 2 (default 0): 1 = take their data gradients OFF the
  * split-bf16 direct kernel (default path, 121 vs 227 us) back to the implicit GEMM; bits 4-5: timing ablations */
 void ha2g_conv_debug_direct_c32(int on);
