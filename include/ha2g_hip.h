@@ -57,6 +57,10 @@ int ha2g_conv2d_weight_ohwi_to_ihwo_f32(const float* w, float* wt, int Cout, int
  *                (3.7e-7 vs 4.4e-7 rms-rel), 1.1-1.45x faster per GEMM, ~1.4 % of the step.
  *   bit 4 (off): every vectorisable GEMM / convolution with PLAIN bf16 operands (one bf16 MFMA per product, fp32 accumulate,
  *                fp32 storage) -- reduced precision (2^-9 per operand), for BASELINE config 5 / `bench.py --bf16` only.
+ *   bit 5 (off): the 3-piece split of bit 3 for forward DENSE GEMMs only (GRU input projections, TCN / discriminator im2col GEMMs,
+ *                generator head): fp32-accurate; the convolutions and the audio tower's own (narrow) GEMMs stay on the fp32 MFMA, so the tower's
+ *                forward arithmetic is bit-identical with and without it (tests/test_gpu_kernels.py).  Measured slower on the whole step (60.1 vs 58.0 ms:
+ *                the skinny-K projections are LDS-bound on the split kernel), kept opt-in.
  * 0 = exact fp32 MFMA everywhere. */
 void ha2g_gemm_set_mode(int mode);
 /* tuning aid: forward GEMMs narrower than n columns stay on the fp32 MFMA */

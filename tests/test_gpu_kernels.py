@@ -428,3 +428,31 @@ def test_contrastive_full_size_vs_oracle(N, expr):
     loss.backward()
     assert abs(float(loss) - loss64) <= 2e-5 * abs(loss64), (float(loss), loss64)
     assert relerr(ag.grad, a64.grad) < 1e-4 and relerr(bg.grad, b64.grad) < 1e-4, (relerr(ag.grad, a64.grad), relerr(bg.grad, b64.grad))
+
+
+def test_dense_forward_split_leaves_the_audio_tower_bits_unchanged():
+    """Mode bit 5 (3-piece forward split for dense GEMMs) must not touch the audio encoder: its forward arithmetic is frozen.
+    Same outputs bit for bit with the bit on and off; a generator-sized GEMM does change (and stays fp32-accurate)."""
+    from ha2g_amd import ops, procedural as proc
+    from ha2g_amd._lib import DEFAULT_GEMM_MODE, lib
+    from ha2g_amd.config import CASES
+    from ha2g_amd.testing import batch_for, build_modules
+    dev = _dev()
+    case = CASES['small']
+    _, _, _, aud, _ = build_modules(case, dev)
+    _, spec, _, vid = batch_for(case)
+    a, b = rnd((4352, 600), 3).to(dev), rnd((900, 600), 4, 600 ** -0.5).to(dev)
+    outs = {}
+    try:
+        for mode in (6, 38):
+            lib.ha2g_gemm_set_mode(mode)
+            with torch.no_grad():
+                w, lo, mid, hi, blend = aud(spec.to(dev), vid.to(dev))
+            outs[mode] = (torch.cat([lo.reshape(-1), mid.reshape(-1), hi.reshape(-1), w.reshape(-1)] + [t.reshape(-1) for t in blend]),
+                          ops.gemm(a, b, transb=True))
+    finally:
+        lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
+    assert torch.equal(outs[6][0], outs[38][0])
+    assert not torch.equal(outs[6][1], outs[38][1])
+    ref = a.double().cpu() @ b.double().cpu().t()
+    assert relerr(outs[38][1], ref) < 2e-6 and relerr(outs[6][1], ref) < 2e-6
