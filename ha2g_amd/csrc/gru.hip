@@ -271,6 +271,224 @@ __global__ __launch_bounds__(NT) void gru_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// ---- small hidden sizes (H <= 64: the discriminator's GRU(8->64, 4 layers), model/hierarchy_net.py:213,232) --------------------
+// The generic kernels above re-stream W_hh from L2 every step and load the step's operands from HBM when they need them: fine when a
+// step carries 15 us of MFMA work (H = 300), but at H = 64 a step is 48 MFMAs per wave (0.64 us) and the launch was pure latency
+// (3.3 us per step).  Here one wave owns one 16-unit tile: its 3 x NJT weight fragments stay in registers for the whole sequence
+// (12 float4 at H = 64), the step's gi / gate operands are prefetched two steps ahead, barriers wait for LDS only, and the hidden
+// state ping-pongs between two LDS tiles (one barrier per step).  Same MFMA order per accumulator as the generic kernel => same bits.
+__device__ __forceinline__ void lds_only_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // vmcnt(63) expcnt(7) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int H>
+__global__ __launch_bounds__(64 * GruCfg<H>::NJT) void gru_fwd_small_kernel(const float* __restrict__ gi, const float* __restrict__ wp,
+                                                                            const float* __restrict__ bhh0, const float* __restrict__ bhh1,
+                                                                            float* __restrict__ y, float* __restrict__ rs, int B, int T) {
+    using C = GruCfg<H>;
+    constexpr int NJT = C::NJT, LDH = C::LDH, NTS = 64 * NJT;
+    __shared__ __attribute__((aligned(16))) float hs[2][16 * LDH];
+    const int dir = blockIdx.y, b0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, lane = tid & 63, jt = tid >> 6;
+    const int lb = lane & 15, g = lane >> 4;
+    const int b = b0 + lb;
+    const int j = 16 * jt + 4 * g;
+    const bool ok = b < B && j < H;
+    const float* bhh = dir ? bhh1 : bhh0;
+    float4 wf[3 * NJT];                                   // [gate][m]
+    {
+        const float4* w = reinterpret_cast<const float4*>(wp) + ((long)dir * (NJT * 3 * NJT) + (long)jt * 3 * NJT) * 64 + lane;
+#pragma unroll
+        for (int f = 0; f < 3 * NJT; ++f) wf[f] = w[f * 64];
+    }
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 br = zero4, bz = zero4, bn = zero4;
+    if (ok) {
+        br = *reinterpret_cast<const float4*>(bhh + j);
+        bz = *reinterpret_cast<const float4*>(bhh + H + j);
+        bn = *reinterpret_cast<const float4*>(bhh + 2 * H + j);
+    }
+    for (int i = tid; i < 2 * 16 * LDH; i += NTS) (&hs[0][0])[i] = 0.f;
+    // gi of the current step in registers; the next step's is requested right AFTER this step's stores: on gfx9 a wave that has loads
+    // and stores in flight can only wait with vmcnt(0), so a load issued before the gates would be waited for by the gates themselves
+    const long tstep = dir ? -1 : 1;
+    const float* gp = gi + ((long)(b * (long)T + (dir ? T - 1 : 0)) * 2 + dir) * 3 * H + j;
+    float4 c_r = zero4, c_z = zero4, c_n = zero4;
+    if (ok) { c_r = *reinterpret_cast<const float4*>(gp); c_z = *reinterpret_cast<const float4*>(gp + H); c_n = *reinterpret_cast<const float4*>(gp + 2 * H); }
+    float* yp = y + ((long)b * T + (dir ? T - 1 : 0)) * 2 * H + dir * H + j;
+    float* rp = rs ? rs + (((long)b * T + (dir ? T - 1 : 0)) * 2 + dir) * 4 * H + j : nullptr;
+    lds_only_barrier();
+
+    for (int s = 0; s < T; ++s) {
+        const int cur = s & 1;
+        float4 hb[NJT];
+#pragma unroll
+        for (int m = 0; m < NJT; ++m) hb[m] = *reinterpret_cast<const float4*>(&hs[cur][lb * LDH + 16 * m + 4 * g]);
+        f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
+        if (s > 0) {                                      // h_0 = 0: nothing to multiply in the first step
+#pragma unroll
+            for (int m = 0; m < NJT; ++m) {
+                const float* ph = &hb[m].x;
+                const float* pr = &wf[m].x; const float* pz = &wf[NJT + m].x; const float* pn = &wf[2 * NJT + m].x;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ar = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[u], ph[u], ar, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) az = __builtin_amdgcn_mfma_f32_16x16x4f32(pz[u], ph[u], az, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) an = __builtin_amdgcn_mfma_f32_16x16x4f32(pn[u], ph[u], an, 0, 0, 0);
+            }
+        }
+        float4 hn4 = zero4;
+        if (ok) {
+            const float* hp = &hb[0].x + 0;               // h_prev of this lane's units = hb[jt] (statically indexed below)
+            float4 hprev = hb[0];
+#pragma unroll
+            for (int m = 1; m < NJT; ++m) if (m == jt) hprev = hb[m];
+            (void)hp;
+            const float* hpp = &hprev.x;
+            float4 r4, z4, n4, q4;
+            float* pr = &r4.x; float* pz = &z4.x; float* pn = &n4.x; float* pq = &q4.x; float* ph = &hn4.x;
+            const float* gr = &c_r.x; const float* gz = &c_z.x; const float* gn = &c_n.x;
+            const float* cbr = &br.x; const float* cbz = &bz.x; const float* cbn = &bn.x;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float r = sigmoidf_(gr[u] + ar[u] + cbr[u]);
+                const float z = sigmoidf_(gz[u] + az[u] + cbz[u]);
+                const float q = an[u] + cbn[u];
+                const float n = tanhf_(gn[u] + r * q);
+                pr[u] = r; pz[u] = z; pn[u] = n; pq[u] = q;
+                ph[u] = (1.f - z) * n + z * hpp[u];
+            }
+            *reinterpret_cast<float4*>(yp) = hn4;
+            if (rs) {
+                *reinterpret_cast<float4*>(rp) = r4;
+                *reinterpret_cast<float4*>(rp + H) = z4;
+                *reinterpret_cast<float4*>(rp + 2 * H) = n4;
+                *reinterpret_cast<float4*>(rp + 3 * H) = q4;
+            }
+        }
+        *reinterpret_cast<float4*>(&hs[cur ^ 1][lb * LDH + j]) = hn4;    // zeros in the padding
+        gp += tstep * 6 * H; yp += tstep * 2 * H;
+        if (ok && s + 1 < T) { c_r = *reinterpret_cast<const float4*>(gp); c_z = *reinterpret_cast<const float4*>(gp + H); c_n = *reinterpret_cast<const float4*>(gp + 2 * H); }
+        if (rs) rp += tstep * 8 * H;
+        lds_only_barrier();
+    }
+}
+
+// BPTT twin: thread -> (batch row, 4 units) for the gate gradients (operands prefetched one step ahead), wave kt -> k-tile of
+// carry[b][k] += dgh * W_hh with its 3 x NJT transposed fragments resident; the carry lives in LDS (the two phases own it differently).
+template <int H>
+__global__ __launch_bounds__(64 * GruCfg<H>::NJT) void gru_bwd_small_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                            const float* __restrict__ rs, const float* __restrict__ wpt,
+                                                                            float* __restrict__ dg, float* __restrict__ hpo, int B, int T) {
+    using C = GruCfg<H>;
+    constexpr int NJT = C::NJT, HP = C::HP, LDH = C::LDH, LDG = 3 * HP + 4, NTS = 64 * NJT;
+    static_assert(16 * (H / 4) <= NTS, "one (row, 4-unit) item per thread");
+    __shared__ __attribute__((aligned(16))) float sg[16 * LDG];
+    __shared__ __attribute__((aligned(16))) float sc[16 * LDH];
+    const int dir = blockIdx.y, b0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, lane = tid & 63, kt = tid >> 6;
+    const int lb = lane & 15, g = lane >> 4;
+    const int bb = tid / (H / 4), j = (tid % (H / 4)) * 4;
+    const int b = b0 + bb;
+    const bool item = tid < 16 * (H / 4), own = item && b < B;
+    float4 wf[3 * NJT];                                   // [gate][jt] of k-tile kt
+    {
+        const float4* w = reinterpret_cast<const float4*>(wpt) + ((long)dir * (NJT * 3 * NJT) + (long)(kt * 3) * NJT) * 64 + lane;
+#pragma unroll
+        for (int f = 0; f < 3 * NJT; ++f) wf[f] = w[f * 64];
+    }
+    for (int i = tid; i < 16 * LDH; i += NTS) sc[i] = 0.f;
+    for (int i = tid; i < 16 * LDG; i += NTS) sg[i] = 0.f;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 n_dy = zero4, n_r = zero4, n_z = zero4, n_n = zero4, n_q = zero4, n_hp = zero4;
+#define HA2G_SMALL_BWD_LOAD(S)                                                                                    \
+    if (own && (S) < T) {                                                                                         \
+        const int t_ = dir ? (S) : T - 1 - (S);                                                                   \
+        const int tp_ = dir ? t_ + 1 : t_ - 1;                                                                    \
+        const long bt_ = (long)b * T + t_;                                                                        \
+        n_dy = *reinterpret_cast<const float4*>(dy + bt_ * 2 * H + dir * H + j);                                  \
+        const float* rp_ = rs + (bt_ * 2 + dir) * 4 * H + j;                                                      \
+        n_r = *reinterpret_cast<const float4*>(rp_);                                                              \
+        n_z = *reinterpret_cast<const float4*>(rp_ + H);                                                          \
+        n_n = *reinterpret_cast<const float4*>(rp_ + 2 * H);                                                      \
+        n_q = *reinterpret_cast<const float4*>(rp_ + 3 * H);                                                      \
+        n_hp = (tp_ >= 0 && tp_ < T) ? *reinterpret_cast<const float4*>(y + ((long)b * T + tp_) * 2 * H + dir * H + j) : zero4; \
+    }
+    HA2G_SMALL_BWD_LOAD(0)
+    lds_only_barrier();
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? s : T - 1 - s;
+        // ---- phase 1: gate gradients ----
+        if (item) {
+            float4 dar = zero4, daz = zero4, dghn = zero4, dhz = zero4;
+            if (own) {
+                const long bt = (long)b * T + t;
+                const float4 c4 = *reinterpret_cast<const float4*>(&sc[bb * LDH + j]);
+                float4 dan;
+                const float* pdy = &n_dy.x; const float* pr = &n_r.x; const float* pz = &n_z.x; const float* pn = &n_n.x;
+                const float* pq = &n_q.x; const float* php = &n_hp.x; const float* pc = &c4.x;
+                float* o_r = &dar.x; float* o_z = &daz.x; float* o_n = &dan.x; float* o_q = &dghn.x; float* o_c = &dhz.x;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float dh = pdy[u] + pc[u];
+                    const float dn = dh * (1.f - pz[u]);
+                    const float dz = dh * (php[u] - pn[u]);
+                    const float a_n = dn * (1.f - pn[u] * pn[u]);
+                    o_n[u] = a_n;
+                    o_z[u] = dz * pz[u] * (1.f - pz[u]);
+                    o_r[u] = a_n * pq[u] * pr[u] * (1.f - pr[u]);
+                    o_q[u] = a_n * pr[u];
+                    o_c[u] = dh * pz[u];
+                }
+                float* gp = dg + (bt * 2 + dir) * 4 * H + j;
+                *reinterpret_cast<float4*>(gp) = dar;
+                *reinterpret_cast<float4*>(gp + H) = daz;
+                *reinterpret_cast<float4*>(gp + 2 * H) = dan;
+                *reinterpret_cast<float4*>(gp + 3 * H) = dghn;
+                if (hpo) *reinterpret_cast<float4*>(hpo + bt * 2 * H + dir * H + j) = n_hp;
+            }
+            *reinterpret_cast<float4*>(&sg[bb * LDG + j]) = dar;
+            *reinterpret_cast<float4*>(&sg[bb * LDG + HP + j]) = daz;
+            *reinterpret_cast<float4*>(&sg[bb * LDG + 2 * HP + j]) = dghn;
+            *reinterpret_cast<float4*>(&sc[bb * LDH + j]) = dhz;
+        }
+        if (s + 1 == T) break;
+        lds_only_barrier();
+        HA2G_SMALL_BWD_LOAD(s + 1)
+        // ---- phase 2: carry[b][16 kt ..] += sum_{gate, jt} dgh[b][gate, jt] * W_hh[gate*H + 16 jt ..][16 kt ..] ----
+        {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+#pragma unroll
+            for (int jq = 0; jq < NJT; ++jq) {
+                const float4 d0 = *reinterpret_cast<const float4*>(&sg[lb * LDG + 0 * HP + 16 * jq + 4 * g]);
+                const float4 d1 = *reinterpret_cast<const float4*>(&sg[lb * LDG + 1 * HP + 16 * jq + 4 * g]);
+                const float4 d2 = *reinterpret_cast<const float4*>(&sg[lb * LDG + 2 * HP + 16 * jq + 4 * g]);
+                const float* w0 = &wf[0 * NJT + jq].x; const float* w1 = &wf[1 * NJT + jq].x; const float* w2 = &wf[2 * NJT + jq].x;
+                const float* p0 = &d0.x; const float* p1 = &d1.x; const float* p2 = &d2.x;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[u], p0[u], a0, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[u], p1[u], a1, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[u], p2[u], a2, 0, 0, 0);
+            }
+            float* cp = &sc[lb * LDH + 16 * kt + 4 * g];
+            float4 c4 = *reinterpret_cast<float4*>(cp);
+            c4.x += a0[0] + a1[0] + a2[0];
+            c4.y += a0[1] + a1[1] + a2[1];
+            c4.z += a0[2] + a1[2] + a2[2];
+            c4.w += a0[3] + a1[3] + a2[3];
+            *reinterpret_cast<float4*>(cp) = c4;
+        }
+        lds_only_barrier();
+    }
+#undef HA2G_SMALL_BWD_LOAD
+}
+
 template <int H>
 int run_pack(const float* whh, float* pf, float* pb, hipStream_t st) {
     constexpr int NJT = GruCfg<H>::NJT;
@@ -328,8 +546,8 @@ int ha2g_gru_layer_fwd(const float* gi, const float* wp, const float* bhh_fwd, c
     dim3 grid(ceil_div(B, 16), 2), block(NT);
     switch (H) {
         case 300: hipLaunchKernelGGL(gru_fwd_kernel<300>, grid, block, 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, B, T); break;
-        case 64: hipLaunchKernelGGL(gru_fwd_kernel<64>, grid, block, 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, B, T); break;
-        case 32: hipLaunchKernelGGL(gru_fwd_kernel<32>, grid, block, 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, B, T); break;
+        case 64: hipLaunchKernelGGL(gru_fwd_small_kernel<64>, grid, dim3(64 * GruCfg<64>::NJT), 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, B, T); break;
+        case 32: hipLaunchKernelGGL(gru_fwd_small_kernel<32>, grid, dim3(64 * GruCfg<32>::NJT), 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, B, T); break;
         default: return ha2g_set_error(-1, "gru: hidden size %d not instantiated (300, 64, 32)", H);
     }
     HA2G_CHECK_LAUNCH("gru_layer_fwd");
@@ -346,8 +564,8 @@ int ha2g_gru_layer_bwd(const float* dy, const float* y, const float* rs, const f
     dim3 grid(ceil_div(B, 16), 2), block(NT);
     switch (H) {
         case 300: hipLaunchKernelGGL(gru_bwd_kernel<300>, grid, block, 0, st, dy, y, rs, wpt, dg, hp, B, T); break;
-        case 64: hipLaunchKernelGGL(gru_bwd_kernel<64>, grid, block, 0, st, dy, y, rs, wpt, dg, hp, B, T); break;
-        case 32: hipLaunchKernelGGL(gru_bwd_kernel<32>, grid, block, 0, st, dy, y, rs, wpt, dg, hp, B, T); break;
+        case 64: hipLaunchKernelGGL(gru_bwd_small_kernel<64>, grid, dim3(64 * GruCfg<64>::NJT), 0, st, dy, y, rs, wpt, dg, hp, B, T); break;
+        case 32: hipLaunchKernelGGL(gru_bwd_small_kernel<32>, grid, dim3(64 * GruCfg<32>::NJT), 0, st, dy, y, rs, wpt, dg, hp, B, T); break;
         default: return ha2g_set_error(-1, "gru: hidden size %d not instantiated (300, 64, 32)", H);
     }
     HA2G_CHECK_LAUNCH("gru_layer_bwd");
