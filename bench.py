@@ -123,6 +123,7 @@ def main():
     ap.add_argument('--bf16', action='store_true', help='BASELINE config 5 style: every vectorisable GEMM / convolution with plain bf16 operands (fp32 accumulate, fp32 storage / master weights); reported with dtype "bf16", never the default')
     ap.add_argument('--graph', action='store_true', help='time hipGraph replays of the captured step instead of eager launches (no per-kernel HIP events => roofline objects are null)')
     ap.add_argument('--sparse-embeddings', action='store_true', help='compact row gradients + lazy row-wise Adam for the word-embedding tables (bit-identical to the dense default; -45 %% gradient-exchange bytes under data parallelism, +0.4 ms of small kernels on one GPU)')
+    ap.add_argument('--dry-run', action='store_true', help='only exercise the rank launch: every rank prints its RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* and exits (no GPU)')
     ap.add_argument('--primary-only', action='store_true', help='skip the secondary timings (warm-up phase, exact-fp32 mode): for profiling')
     a = ap.parse_args()
 
@@ -131,6 +132,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if a.dry_run:
+        print(json.dumps(dict(dry_run=True, rank=rank, local_rank=local, world=world, master='%s:%s' % (os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT')),
+                              ipc_legacy=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))), flush=True)
+        return
     assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)

@@ -93,3 +93,20 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
         assert 'no CPU/torch fallback' in str(e)
     else:
         raise AssertionError('loading without the HIP library must fail')
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher starts N rank processes (fresh children, rendezvous on 127.0.0.1) before the parent
+    touches the GPU; under torchrun-style environments it does not re-spawn.  --dry-run makes every rank report its environment."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '3', '--dry-run'], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    recs = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
+    assert sorted(r['rank'] for r in recs) == [0, 1, 2] and all(r['world'] == 3 and r['local_rank'] == r['rank'] for r in recs)
+    assert len({r['master'] for r in recs}) == 1 and recs[0]['master'].startswith('127.0.0.1:') and all(r['ipc_legacy'] == '0' for r in recs)
+    env2 = dict(env, RANK='1', LOCAL_RANK='1', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29999')      # launched by torchrun: no re-spawn
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run'], env=env2, capture_output=True, text=True, timeout=300)
+    recs = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
+    assert p.returncode == 0 and len(recs) == 1 and recs[0]['rank'] == 1 and recs[0]['world'] == 2
