@@ -21,8 +21,8 @@
 //     the HBM acknowledgement of every y / reserve store and for the prefetched polls, twice per step;
 //   * y / reserve stores of step s and the gi loads of step s+2 are issued AFTER the last poll of step s+1, so no poll
 //     (whose result wait is a vmcnt(0) on gfx9 once loads and stores are mixed) ever queues behind HBM traffic;
-//   * tags carry a device-side launch epoch (tag = epoch * 64 + step + 1): no memset of the exchange buffer per launch,
-//     and a captured hipGraph still gets fresh tags on every replay;
+//   * tags carry a launch epoch (tag = epoch * 64 + step + 1; eager: a host counter, under hipGraph capture: a device-side counter so
+//     that every replay stamps fresh tags -- disjoint namespaces): no memset of the exchange buffer per launch;
 //   * when the five members of a cluster report the same XCC id (one handshake through the write-through path at kernel
 //     start) the granules are published with plain stores: they stay in that XCD's L2, where the members' sc1 loads
 //     read them, instead of being written through to HBM; any other placement keeps the write-through (sc1) form.
@@ -44,7 +44,7 @@ constexpr int G = (NJT + TPW - 1) / TPW;   // 5 workgroups per cluster
 constexpr int NT = 64 * TPW;
 constexpr int MAX_TILES = 24;        // 24 tiles x 2 directions x 5 = 240 workgroups <= 256 CUs
 constexpr int MAX_STEPS = 62;        // tag = epoch * 64 + step + 1 (63 = the placement handshake)
-constexpr unsigned EPOCH_WRAP = 1u << 26;
+constexpr unsigned EPOCH_WRAP = 1u << 25;     // tag = [bit 31: device-epoch namespace][25 bits epoch][6 bits step + 1]
 constexpr unsigned SPIN_LIMIT = 1u << 18;
 
 typedef unsigned long long u64;
@@ -76,13 +76,18 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// Placement handshake: every member publishes its XCC id (write-through), reads the other four; returns 1 when all five
-// agree.  Doubles as the first rendezvous of the launch: a cluster that is not co-resident times out here.
-__device__ __forceinline__ int cluster_same_xcd(__amdgpu_buffer_rsrc_t xr, int hdr_byte_off, int q, unsigned tag, int* err, int* sh) {
+// Placement handshake: every member publishes its XCC id (write-through) BEFORE it loads its weight slice and reads the other four ids
+// AFTER -- the publish -> visible latency hides under the weight loads; returns 1 when all five agree.  Doubles as the first rendezvous of
+// the launch: a cluster that is not co-resident times out here.
+__device__ __forceinline__ void cluster_publish_xcd(__amdgpu_buffer_rsrc_t xr, int hdr_byte_off, int q, unsigned tag) {
+    if ((int)threadIdx.x == q) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;     // HW_REG_XCC_ID[3:0]
+        store_granule_pair<16>(xr, hdr_byte_off + 16 * q, tag, __uint_as_float(xcc), __uint_as_float(xcc));
+    }
+}
+__device__ __forceinline__ int cluster_same_xcd(__amdgpu_buffer_rsrc_t xr, int hdr_byte_off, unsigned tag, int* err, int* sh) {
     const int tid = threadIdx.x;
     if (tid < G) {
-        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;     // HW_REG_XCC_ID[3:0]
-        if (tid == q) store_granule_pair<16>(xr, hdr_byte_off + 16 * q, tag, __uint_as_float(xcc), __uint_as_float(xcc));
         unsigned got = 0xffffffffu;
         for (unsigned spins = 0;; ++spins) {
             const u32x4 x = load_granule_pair(xr, hdr_byte_off + 16 * tid);
@@ -110,7 +115,7 @@ __device__ __forceinline__ int cluster_same_xcd(__amdgpu_buffer_rsrc_t xr, int h
         _Pragma("unroll") for (int i_ = (I0); i_ < (I1); ++i_) {                                                  \
             float4 hn_ = hb_;                                                                                     \
             if (i_ + 1 < (I1)) hn_ = *reinterpret_cast<const float4*>(&hs[lb * LDH + 16 * HA2G_MI(i_ + 1) + 4 * g]); \
-            __builtin_amdgcn_sched_barrier(0);          /* keep the prefetch ahead of this position's MFMAs (hipcc sinks it otherwise) */ \
+            __builtin_amdgcn_sched_barrier(0x16);       /* MFMA and LDS ops are pinned, VALU/SALU/VMEM may cross: keeps the prefetch ahead of this position's MFMAs (hipcc sinks it otherwise) */ \
             const float* ph_ = &hb_.x;                                                                            \
             const float* pr_ = &wf[HA2G_MI(i_)].x; const float* pz_ = &wf[NJT + HA2G_MI(i_)].x;                   \
             const float* pn_ = &wf[2 * NJT + HA2G_MI(i_)].x;                                                      \
@@ -130,19 +135,23 @@ __device__ __forceinline__ int cluster_same_xcd(__amdgpu_buffer_rsrc_t xr, int h
         pa##I = load_granule_pair(xr, off_); pb##I = load_granule_pair(xr, off_ + 16);                            \
     }
 
-// wait until this thread's two granule pairs of source P carry `tag`, then stage the four floats into the LDS tile
-#define HA2G_POLL_WAIT_STAGE(I, P)                                                                                \
+// tag check / LDS staging of one source slot
+#define HA2G_POLL_OK(I, P) (!(64 * (P) + pc < H) || (((pa##I[1] ^ tag) | (pa##I[3] ^ tag) | (pb##I[1] ^ tag) | (pb##I[3] ^ tag)) == 0u))
+#define HA2G_POLL_STAGE(I, P)                                                                                     \
+    if (64 * (P) + pc < H) *reinterpret_cast<float4*>(&hs[pr * LDH + 64 * (P) + pc]) =                            \
+        make_float4(__uint_as_float(pa##I[0]), __uint_as_float(pa##I[2]), __uint_as_float(pb##I[0]), __uint_as_float(pb##I[2]));
+// wait until this thread's granule pairs of ALL FOUR foreign members carry `tag` (one loop: the members publish in lock-step), then
+// stage the sixteen floats into the LDS tile
+#define HA2G_POLL_WAIT_STAGE_ALL                                                                                  \
     {                                                                                                             \
-        const bool act_ = 64 * (P) + pc < H;                                                                      \
         for (unsigned spins_ = 0;; ++spins_) {                                                                    \
-            const bool ok_ = !act_ || (pa##I[1] == tag && pa##I[3] == tag && pb##I[1] == tag && pb##I[3] == tag); \
+            const bool ok_ = HA2G_POLL_OK(1, P1) && HA2G_POLL_OK(2, P2) && HA2G_POLL_OK(3, P3) && HA2G_POLL_OK(4, P4); \
             if (__all(ok_) || (dbg & 1)) break;                                                                   \
             if (spins_ > SPIN_LIMIT) { if (lane == 0) atomicExch(err, 1); break; }                                \
             __builtin_amdgcn_s_sleep(1);                                                                          \
-            HA2G_POLL_ISSUE(I, P)                                                                                 \
+            HA2G_POLL_ISSUE(1, P1) HA2G_POLL_ISSUE(2, P2) HA2G_POLL_ISSUE(3, P3) HA2G_POLL_ISSUE(4, P4)           \
         }                                                                                                         \
-        if (act_) *reinterpret_cast<float4*>(&hs[pr * LDH + 64 * (P) + pc]) =                                     \
-            make_float4(__uint_as_float(pa##I[0]), __uint_as_float(pa##I[2]), __uint_as_float(pb##I[0]), __uint_as_float(pb##I[2])); \
+        HA2G_POLL_STAGE(1, P1) HA2G_POLL_STAGE(2, P2) HA2G_POLL_STAGE(3, P3) HA2G_POLL_STAGE(4, P4)               \
     }
 
 // Member Q of a cluster, all T steps.  Q is a template parameter so that the rotated k-block order indexes the register-
@@ -151,7 +160,7 @@ template <int Q, int PA>
 __device__ __forceinline__ void gru_fwd_member(const float* __restrict__ gi, const float* __restrict__ wp, const float* __restrict__ bhh,
                                                float* __restrict__ y, float* __restrict__ rs, const __amdgpu_buffer_rsrc_t xr,
                                                int* __restrict__ err, const int B, const int T, const int dir, const int b0,
-                                               const unsigned tag0, const int fast, const int dbg, float* __restrict__ hs) {
+                                               const unsigned tag0, int* __restrict__ sh, const int dbg, float* __restrict__ hs) {
     constexpr int NOWN = (Q == G - 1) ? NJT - TPW * (G - 1) : TPW;       // k-blocks / unit tiles of this member: 4 4 4 4 3
     constexpr int P1 = (Q + 1) % G, P2 = (Q + 2) % G, P3 = (Q + 3) % G, P4 = (Q + 4) % G;
 #define HA2G_NB(P) ((P) == G - 1 ? NJT - TPW * (G - 1) : TPW)
@@ -166,12 +175,14 @@ __device__ __forceinline__ void gru_fwd_member(const float* __restrict__ gi, con
     const int pr = tid >> 4, pc = (tid & 15) * 4;        // gather ownership: LDS row, column inside a member's 64-column block
 
     // ---- this wave's slice of W_hh: 3 gates x 19 k-blocks, resident in registers for the whole sequence ----
+    cluster_publish_xcd(xr, (int)(BWD_GRAN * 8), Q, tag0 + 63u);
     float4 wf[3 * NJT];
     {
         const float4* wsrc = reinterpret_cast<const float4*>(wp) + ((long)dir * (NJT * 3 * NJT) + (long)(tile_on ? jt : 0) * 3 * NJT) * 64 + lane;
 #pragma unroll
         for (int f = 0; f < 3 * NJT; ++f) wf[f] = wsrc[f * 64];
     }
+    const int fast = (dbg & 4) ? (cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh), 0) : cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh);
     float4 br = make_float4(0.f, 0.f, 0.f, 0.f), bz = br, bn = br;
     if (jok) {
         br = *reinterpret_cast<const float4*>(bhh + j);
@@ -242,7 +253,7 @@ __device__ __forceinline__ void gru_fwd_member(const float* __restrict__ gi, con
             HA2G_POLL_ISSUE(1, P1) HA2G_POLL_ISSUE(2, P2) HA2G_POLL_ISSUE(3, P3) HA2G_POLL_ISSUE(4, P4)
             if (tile_on) { HA2G_FWD_CHAIN(PA_, NOWN) }
             HA2G_FWD_PREFETCH(s)                                          // issues under the polls' round trip
-            HA2G_POLL_WAIT_STAGE(1, P1) HA2G_POLL_WAIT_STAGE(2, P2) HA2G_POLL_WAIT_STAGE(3, P3) HA2G_POLL_WAIT_STAGE(4, P4)
+            HA2G_POLL_WAIT_STAGE_ALL
             HA2G_FWD_FLUSH
             lds_barrier();
             if (tile_on) { HA2G_FWD_CHAIN(NOWN, NJT) }                     // the other four members' blocks, ring order
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(NT, 1) void gru_fwd_cluster_kernel(const float* __r
                                                                 const float* __restrict__ bhh0, const float* __restrict__ bhh1,
                                                                 float* __restrict__ y,             // [B][T][2H]
                                                                 float* __restrict__ rs,            // [B][T][2][4][H] or null
-                                                                u64* __restrict__ xch, const unsigned* __restrict__ epoch,
+                                                                u64* __restrict__ xch, const unsigned* __restrict__ epoch, unsigned host_tag0,
                                                                 int* __restrict__ err, int B, int T, int tile0, int nclusters, int dbg) {
     __shared__ __attribute__((aligned(16))) float hs[16 * LDH];
     __shared__ int sh[8];
@@ -307,11 +318,10 @@ __global__ __launch_bounds__(NT, 1) void gru_fwd_cluster_kernel(const float* __r
     const int dir = c & 1, b0 = (tile0 + (c >> 1)) * 16;
     u64* xc = xch + (long)c * CL_GRAN;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xc, 0, (int)(CL_GRAN * 8), 0x00020000);
-    const unsigned tag0 = *epoch * 64u;
-    int fast = cluster_same_xcd(xr, (int)(BWD_GRAN * 8), q, tag0 + 63u, err, sh);
-    if (dbg & 4) fast = 0;
+    // launch tag base: the device-side epoch while a hipGraph is being captured (a replay must draw fresh tags), else the host's launch counter
+    const unsigned tag0 = epoch ? (0x80000000u | (*epoch << 6)) : host_tag0;
     const float* bhh = dir ? bhh1 : bhh0;
-#define HA2G_FWD_CALL(QQ, PP) gru_fwd_member<QQ, PP>(gi, wp, bhh, y, rs, xr, err, B, T, dir, b0, tag0, fast, dbg, hs)
+#define HA2G_FWD_CALL(QQ, PP) gru_fwd_member<QQ, PP>(gi, wp, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, hs)
 #define HA2G_FWD_SWITCH(PP)                                                                                       \
     switch (q) {                                                                                                  \
         case 0: HA2G_FWD_CALL(0, PP); break; case 1: HA2G_FWD_CALL(1, PP); break; case 2: HA2G_FWD_CALL(2, PP); break; \
@@ -341,7 +351,7 @@ template <int Q, int PB>
 __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ rs,
                                                const float* __restrict__ wpt, float* __restrict__ dg, float* __restrict__ hpo, const __amdgpu_buffer_rsrc_t xr,
                                                int* __restrict__ err, const int B, const int T, const int dir, const int b0,
-                                               const unsigned tag0, const int fast, const int dbg, float* __restrict__ sg,
+                                               const unsigned tag0, int* __restrict__ sh, const int dbg, float* __restrict__ sg,
                                                float* __restrict__ sp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lb = lane & 15, g = lane >> 4;
@@ -352,6 +362,7 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
     const bool own_ok = jo < H && bo < B;
 
     // ---- resident transposed W_hh fragments: wave w serves k-tiles w, w+4, ... ; own j-tiles 4Q..4Q+3 ----
+    cluster_publish_xcd(xr, (int)(BWD_GRAN * 8), Q, tag0 + 63u);
     float4 wf[NKW * 3 * TPW];
     {
         const float4* base = reinterpret_cast<const float4*>(wpt) + (long)dir * (NJT * 3 * NJT) * 64 + lane;
@@ -367,6 +378,7 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
                     wf[(kk * 3 + gate) * TPW + jl] = v;
                 }
     }
+    const int fast = (dbg & 4) ? (cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh), 0) : cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh);
     for (int i = tid; i < 16 * LDG; i += NT) sg[i] = 0.f;
     for (int i = tid; i < 16 * LDP; i += NT) sp[i] = 0.f;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -530,7 +542,7 @@ __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __r
                                                                 const float* __restrict__ wpt,     // packed bwd images, 2 dirs
                                                                 float* __restrict__ dg,            // [B][T][2][4H]
                                                                 float* __restrict__ hpo,           // [B][T][2H] h_prev per step (nullable)
-                                                                u64* __restrict__ xch, const unsigned* __restrict__ epoch,
+                                                                u64* __restrict__ xch, const unsigned* __restrict__ epoch, unsigned host_tag0,
                                                                 int* __restrict__ err, int B, int T, int tile0, int nclusters, int dbg) {
     __shared__ __attribute__((aligned(16))) float sg[16 * LDG];
     __shared__ __attribute__((aligned(16))) float sp[16 * LDP];
@@ -541,10 +553,8 @@ __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __r
     const int dir = c & 1, b0 = (tile0 + (c >> 1)) * 16;
     u64* xc = xch + (long)c * CL_GRAN;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xc, 0, (int)(CL_GRAN * 8), 0x00020000);
-    const unsigned tag0 = *epoch * 64u;
-    int fast = cluster_same_xcd(xr, (int)(BWD_GRAN * 8), q, tag0 + 63u, err, sh);
-    if (dbg & 4) fast = 0;
-#define HA2G_BWD_CALL(QQ, PP) gru_bwd_member<QQ, PP>(dy, y, rs, wpt, dg, hpo, xr, err, B, T, dir, b0, tag0, fast, dbg, sg, sp)
+    const unsigned tag0 = epoch ? (0x80000000u | (*epoch << 6)) : host_tag0;
+#define HA2G_BWD_CALL(QQ, PP) gru_bwd_member<QQ, PP>(dy, y, rs, wpt, dg, hpo, xr, err, B, T, dir, b0, tag0, sh, dbg, sg, sp)
 #define HA2G_BWD_SWITCH(PP)                                                                                       \
     switch (q) {                                                                                                  \
         case 0: HA2G_BWD_CALL(0, PP); break; case 1: HA2G_BWD_CALL(1, PP); break; case 2: HA2G_BWD_CALL(2, PP); break; \
@@ -566,6 +576,26 @@ __global__ __launch_bounds__(1024) void cluster_epoch_kernel(unsigned* __restric
         if (threadIdx.x == 0) e = 1u;
     }
     if (threadIdx.x == 0) *epoch = e;
+}
+
+// Tag base of one launch.  Eager launches draw it from a host counter (no extra kernel); under stream capture the launch reads the
+// device-side epoch, bumped by cluster_epoch_kernel in front of it, so that every replay of the graph stamps new tags.  The two
+// sequences live in disjoint tag namespaces (bit 31).  Returns the device epoch pointer to pass (nullptr = use *host_tag0).
+const unsigned* launch_tag_base(void* xch, hipStream_t st, unsigned* host_tag0) {
+    static unsigned host_epoch = 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        unsigned* epoch = (unsigned*)((char*)xch + XCH_BYTES);
+        hipLaunchKernelGGL(cluster_epoch_kernel, dim3(1), dim3(1024), 0, st, epoch, (u64*)xch);
+        *host_tag0 = 0;
+        return epoch;
+    }
+    if (++host_epoch >= EPOCH_WRAP) {                    // ~33 M launches: clear every tag once, restart the sequence
+        (void)hipMemsetAsync(xch, 0, XCH_BYTES, st);
+        host_epoch = 1;
+    }
+    *host_tag0 = host_epoch << 6;
+    return nullptr;
 }
 
 int device_tile_cap() {
@@ -603,14 +633,14 @@ int ha2g_gru_layer_fwd_cluster(const float* gi, const float* wp, const float* bh
     HA2G_REQUIRE(cap >= 1, "gru cluster kernel: the device has fewer than %d compute units", 2 * G);
     hipStream_t st = (hipStream_t)stream;
     if (B == 0 || T == 0) return 0;
-    unsigned* epoch = (unsigned*)((char*)xch + XCH_BYTES);
     const int tiles = ceil_div(B, 16);
     for (int t0 = 0; t0 < tiles; t0 += cap) {
         const int nt = tiles - t0 < cap ? tiles - t0 : cap;
         const int nclusters = nt * 2;
-        hipLaunchKernelGGL(cluster_epoch_kernel, dim3(1), dim3(1024), 0, st, epoch, (u64*)xch);
+        unsigned host_tag0 = 0;
+        const unsigned* epoch = launch_tag_base(xch, st, &host_tag0);
         const int grid = ceil_div(nclusters, 8) * 8 * G;
-        hipLaunchKernelGGL(gru_fwd_cluster_kernel, dim3(grid), dim3(NT), 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, (u64*)xch, epoch, err, B, T,
+        hipLaunchKernelGGL(gru_fwd_cluster_kernel, dim3(grid), dim3(NT), 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, (u64*)xch, epoch, host_tag0, err, B, T,
                            t0, nclusters, g_dbg);
         HA2G_CHECK_LAUNCH("gru_layer_fwd_cluster");
     }
@@ -626,14 +656,14 @@ int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs,
     HA2G_REQUIRE(cap >= 1, "gru cluster kernel: the device has fewer than %d compute units", 2 * G);
     hipStream_t st = (hipStream_t)stream;
     if (B == 0 || T == 0) return 0;
-    unsigned* epoch = (unsigned*)((char*)xch + XCH_BYTES);
     const int tiles = ceil_div(B, 16);
     for (int t0 = 0; t0 < tiles; t0 += cap) {
         const int nt = tiles - t0 < cap ? tiles - t0 : cap;
         const int nclusters = nt * 2;
-        hipLaunchKernelGGL(cluster_epoch_kernel, dim3(1), dim3(1024), 0, st, epoch, (u64*)xch);
+        unsigned host_tag0 = 0;
+        const unsigned* epoch = launch_tag_base(xch, st, &host_tag0);
         const int grid = ceil_div(nclusters, 8) * 8 * G;
-        hipLaunchKernelGGL(gru_bwd_cluster_kernel, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, err, B, T, t0, nclusters, g_dbg);
+        hipLaunchKernelGGL(gru_bwd_cluster_kernel, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg);
         HA2G_CHECK_LAUNCH("gru_layer_bwd_cluster");
     }
     return 0;
