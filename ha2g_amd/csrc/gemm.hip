@@ -728,7 +728,22 @@ int launch(const GemmP& p, hipStream_t st) {
     return 0;
 }
 
-// Pick split-K so that a launch has enough workgroups to fill 256 CUs; returns splits and sets kchunk.
+// Compute units of the current device (256 on an unpartitioned MI355X; fewer under CPX/DPX partitioning or CU masking), queried once per
+// device: the tile / split-K heuristics balance work over THIS many CUs.  The arithmetic a shape runs is therefore a function of the CU
+// count: the parity fixtures and the bitwise run-to-run guarantees are stated for one device configuration.
+static int cu_count() {
+    static int n[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (n[dev] == 0) {
+        int c = 0;
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        n[dev] = c;
+    }
+    return n[dev];
+}
+
+// Pick split-K so that a launch has enough workgroups to fill the CUs; returns splits and sets kchunk.
 int choose_splits(int M, int N, int K, int BM, int BN, long ws_floats, int* kchunk) {
     // Split K when the tile grid cannot fill the 256 CUs a couple of times over (measured on the whole train step:
     // splitting below 192 tiles is worth 5-30 % of the step; the workspace round trip + reduce launch is cheap).
@@ -759,7 +774,8 @@ int dispatch_tile(GemmP& p, long ws_floats, hipStream_t st) {
     for (int c = 0; c < 5; ++c) {
         long tm = ceil_div(p.M, bm[c]), tn = ceil_div(p.N, bn[c]), tiles = tm * tn;
         double useful = ((double)p.M * p.N) / ((double)tiles * bm[c] * bn[c]);
-        double balance = tiles >= g_split_tiles ? ((double)tiles / 256.0) / (double)((tiles + 255) / 256) : 0.95;
+        const int ncu = cu_count();
+        double balance = tiles >= g_split_tiles ? ((double)tiles / ncu) / (double)((tiles + ncu - 1) / ncu) : 0.95;
         double score = eff[c] * useful * balance;
         if (score > bs) { bs = score; best = c; }
     }
@@ -801,8 +817,9 @@ static int pick_conv_cfg(int M, int N) {
         if (bn[c] > 32 && N <= 32 && c != 0) continue;
         long tiles = (long)ceil_div(M, bm[c]) * ceil_div(N, bn[c]);
         double waste_n = (double)N / (ceil_div(N, bn[c]) * bn[c]);
-        double per_cu = (double)tiles / 256.0;
-        double balance = per_cu / (double)((tiles + 255) / 256);
+        const int ncu = cu_count();
+        double per_cu = (double)tiles / ncu;
+        double balance = per_cu / (double)((tiles + ncu - 1) / ncu);
         double score = eff[c] * balance * waste_n;
         if (score > bs) { bs = score; best = c; }
     }

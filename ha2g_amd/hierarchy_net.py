@@ -314,19 +314,34 @@ class Hierarchical_ConvDiscriminator(nn.Module):
         self.out2 = Linear(28, 1)
         self.do_flatten_parameters = False
 
-    def forward(self, poses, in_text=None):
+    def _features(self, poses):
+        """pre_conv stack: Conv1d -> BatchNorm1d (train: statistics of THIS call's batch) -> LeakyReLU, twice, then Conv1d"""
         pc = self.pre_conv
         x = ops.conv1d_tm(poses, pc[0].weight, pc[0].bias)                    # [B, T-2, 16]
         x = pc[1](x, act=ACT_LEAKY)
         x = ops.conv1d_tm(x, pc[3].weight, pc[3].bias)
         x = pc[4](x, act=ACT_LEAKY)
-        feat = ops.conv1d_tm(x, pc[6].weight, pc[6].bias)                     # [B, T-6, 8]
+        return ops.conv1d_tm(x, pc[6].weight, pc[6].bias)                     # [B, T-6, 8]
+
+    def _classify(self, feat):
         output, _ = self.gru(feat, None)
         output = ops.dirsum(output)
-        batch_size = poses.shape[0]
+        batch_size = feat.shape[0]
         output = self.out(output.reshape(-1, output.shape[2]))
         output = output.view(batch_size, -1)
         return self.out2(output, act=ACT_SIGMOID)
+
+    def forward(self, poses, in_text=None):
+        return self._classify(self._features(poses))
+
+    def forward_pair(self, real, fake, in_text=None):
+        """D(real), D(fake) of the discriminator update (train_hierarchy.py:121-128) in one pass through the row-wise part: the two
+        pre_conv stacks run separately and in the reference's order (train-mode BatchNorm normalises each call with its own batch
+        statistics and updates the running ones), the latency-bound 4-layer GRU and the two Linear heads -- independent per sample --
+        see both batches at once (one set of 4 + 4 layer launches instead of two)."""
+        feat = torch.cat([self._features(real), self._features(fake)])
+        out = self._classify(feat)
+        return out[:real.shape[0]], out[real.shape[0]:]
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -151,8 +151,11 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
         else:
             outs_d, *_ = _chain(spec, args, gens, targets, in_text_padded, linear_blend_feat, vid_indices, consts['tables'])
             out_dir_vec_d = outs_d[-1]
-        dis_real = discriminator(target, in_text_padded)
-        dis_fake = discriminator(out_dir_vec_d.detach(), in_text_padded)
+        if FUSE_CHAINS and hasattr(discriminator, 'forward_pair'):
+            dis_real, dis_fake = discriminator.forward_pair(target, out_dir_vec_d.detach(), in_text_padded)
+        else:
+            dis_real = discriminator(target, in_text_padded)
+            dis_fake = discriminator(out_dir_vec_d.detach(), in_text_padded)
         dis_error = ops.dis_loss(dis_real, dis_fake)                      # ns-gan
         dis_error.backward()
         _allreduce([dis_optimizer])

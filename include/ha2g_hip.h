@@ -11,6 +11,9 @@
  * no implicit synchronisation; every call enqueues on `stream` (a hipStream_t passed as void*) and is safe
  * to capture into a hipGraph; re-entrant across streams.  Return 0 on success, negative on error with the
  * message available from ha2g_last_error() (thread-local).
+ * The ha2g_*_set_mode / ha2g_*_debug_* switches are PROCESS-GLOBAL configuration (which arithmetic variant the GEMM / convolution entry
+ * points dispatch to): set them before enqueueing work, not concurrently with launches from another thread.  Tile and split-K choices
+ * (hence the fp32 summation order of a shape) depend on the device's compute-unit count, queried once per device.
  */
 #ifndef HA2G_HIP_H
 #define HA2G_HIP_H
