@@ -118,9 +118,9 @@ def synth_words(clip_seconds, n, seed):
     return [('w%d' % int(r.integers(0, 30)), float(s), float(s + 0.1 + 0.3 * r.random())) for s in starts]
 
 
-def fgd_batch(B, i, seed):
-    """(real, generated) pose windows [B, 34, 27] of batch i for the FGD fixture: smooth random walks; `generated` = a noisier, biased copy."""
-    r = np.random.Generator(np.random.PCG64([seed, 61, i]))
-    real = np.cumsum(0.05 * r.standard_normal((B, 34, 27)), axis=1) + 0.3 * r.standard_normal((B, 1, 27))
-    gen = 0.8 * real + 0.1 * r.standard_normal((B, 34, 27)) + 0.05
+def fgd_batch(B, i, seed, P=27):
+    """(real, generated) pose windows [B, 34, P] of batch i for the FGD fixture: smooth random walks; `generated` = a noisier, biased copy."""
+    r = np.random.Generator(np.random.PCG64([seed, 61, i] if P == 27 else [seed, 61, i, P]))
+    real = np.cumsum(0.05 * r.standard_normal((B, 34, P)), axis=1) + 0.3 * r.standard_normal((B, 1, P))
+    gen = 0.8 * real + 0.1 * r.standard_normal((B, 34, P)) + 0.05
     return real.astype(np.float32), gen.astype(np.float32)

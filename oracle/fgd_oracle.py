@@ -43,14 +43,16 @@ def recon_metrics(recon, poses):
 
 
 class Evaluator:
-    def __init__(self, sd):
-        self.sd = sd
+    def __init__(self, sd, enc='pose_encoder.', dec='decoder.', mu='pose_encoder.fc_mu.'):
+        """defaults = EmbeddingNet 'pose' mode (TED-Gesture); MotionAE (TED-Expressive, model/motion_ae.py): enc='encoder.', mu=None"""
+        self.sd, self.names = sd, (enc, dec, mu)
         self.real, self.gen, self.recon_err_diff, self.cos_err_diff = [], [], [], []
 
     def push_samples(self, generated, real):
+        enc, dec, mu = self.names
         with torch.no_grad():
-            rf, gf = encode(real, self.sd), encode(generated, self.sd)
-            rr, gr = decode(rf, self.sd), decode(gf, self.sd)
+            rf, gf = encode(real, self.sd, enc, mu), encode(generated, self.sd, enc, mu)
+            rr, gr = decode(rf, self.sd, dec), decode(gf, self.sd, dec)
             a, b = recon_metrics(rr, real), recon_metrics(gr, generated)
         self.real.append(rf.numpy()); self.gen.append(gf.numpy())
         self.recon_err_diff.append(float(b[0] - a[0])); self.cos_err_diff.append(float(b[1] - a[1]))

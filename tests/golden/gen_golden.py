@@ -502,6 +502,58 @@ def fgd_goldens(out, dt, perturb=0.0):
     out['fgd/feat_dist'] = np.float64(feat_dist)
 
 
+def fgd126_goldens(out, dt, perturb=0.0):
+    """The TED-Expressive branch of the evaluator (model/embedding_space_evaluator.py:33-36,71-73): MotionAE(126, 128) from model/motion_ae.py."""
+    _stub_io_modules()
+    import tempfile
+    from model.motion_ae import MotionAE
+    from model.embedding_space_evaluator import EmbeddingSpaceEvaluator
+    from ha2g_amd.config import FGD_CASE as fc, hierarchy_args
+    args = hierarchy_args(expressive=True)
+    net = proc.fill_module(MotionAE(126, 128), fc['seed'], 'fgd126.')
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, 'ae.bin')
+        torch.save({'pose_dim': 126, 'latent_dim': 128, 'motion_ae': net.state_dict()}, path)
+        ev = EmbeddingSpaceEvaluator(args, path, Lang(10), torch.device('cpu'))
+    ev.net.to(dt)
+    for i in range(fc['batches']):
+        real, gen = proc.fgd_batch(fc['B'], i, fc['seed'], P=126)
+        real_t, gen_t = perturbed(torch.from_numpy(real).to(dt), perturb, 40 + i), perturbed(torch.from_numpy(gen).to(dt), perturb, 50 + i)
+        ev.push_samples(None, None, gen_t, real_t)
+        out['fgd126/real_feat%d' % i] = np.asarray(ev.real_feat_list[-1], np.float64)
+        out['fgd126/gen_feat%d' % i] = np.asarray(ev.generated_feat_list[-1], np.float64)
+        out['fgd126/recon_err_diff%d' % i] = np.float64(ev.recon_err_diff[-1])
+        out['fgd126/cos_err_diff%d' % i] = np.float64(ev.cos_err_diff[-1])
+    fd, feat_dist = ev.get_scores()
+    out['fgd126/frechet'] = np.float64(fd)
+    out['fgd126/feat_dist'] = np.float64(feat_dist)
+
+
+def synth_expr_goldens(out, dt, perturb=0.0):
+    """scripts/synthesize_expressive_hierarchy.py:36-258 generate_gestures_hierarchy (six levels, 126-d) run by the reference itself:
+    `expr_small` case modules, the same synthetic 9 s clip as synth_goldens."""
+    _stub_io_modules()
+    import synthesize_expressive_hierarchy as S
+    from ha2g_amd.config import SYNTH_CASE as sc
+    case = CASES['expr_small']
+    dims = (24, 30, 36, 66, 96, 126)
+    args, gens, dis, aud, txt = build(case, dims, 6, torch.float32)
+    for m in gens + [aud]:
+        m.eval()
+    n_audio = int(sc['clip_seconds'] * 16000)
+    spectro = proc.synth_spectrogram(n_audio, sc['seed'])
+    if perturb:
+        r = np.random.Generator(np.random.PCG64([4242, 31, PERTURB_DRAW])).standard_normal(spectro.shape)
+        spectro = (spectro * (1.0 + perturb * r)).astype(np.float32)
+    words = proc.synth_words(sc['clip_seconds'], sc['n_words'], sc['seed'])
+    eps = proc.EpsStream(sc['seed'])
+    ref_embedding_net.reparameterize = lambda mu, logvar: mu + torch.from_numpy(eps(mu.shape)).to(mu.dtype) * torch.exp(0.5 * logvar)
+    S.extract_melspectrogram = lambda audio, sr: spectro
+    tg = [torch.zeros(1, 34, P) for P in dims]
+    res = S.generate_gestures_hierarchy(args, *gens, aud, SynthLang(), np.zeros(n_audio, np.float32), words, *tg, vid=sc['vid'])
+    out['synth_expr/out'] = np.asarray(res, np.float64)
+
+
 def write_fixture32(name, runs, NPERT):
     """fixtures whose reference only runs in float32: truth = the plain run, @noise = scatter of the perturbed runs around it"""
     out = {}
@@ -515,7 +567,7 @@ def write_fixture32(name, runs, NPERT):
     print('  wrote', path, os.path.getsize(path) // 1024, 'KiB,', len(out), 'arrays')
 
 
-EXTRA32 = {'synth': (synth_goldens,)}
+EXTRA32 = {'synth': (synth_goldens, synth_expr_goldens)}
 
 
 def main_extra32(only):
@@ -534,7 +586,7 @@ def main_extra32(only):
         write_fixture32(name, runs, NPERT)
 
 
-EXTRA = {'fgd': (fgd_goldens,), 'blocks': (block_goldens, taps_goldens), 'blocksfull': (blockfull_goldens, tapsfull_goldens), 'enc16': (encoder_goldens,)}
+EXTRA = {'fgd': (fgd_goldens, fgd126_goldens), 'blocks': (block_goldens, taps_goldens), 'blocksfull': (blockfull_goldens, tapsfull_goldens), 'enc16': (encoder_goldens,)}
 
 
 def write_fixture(name, runs, NPERT):
