@@ -97,6 +97,8 @@ ENC_CASE = dict(B=16, n_spk=8, seed=14)
 
 # FGD evaluator fixture (tests/golden/fgd.npz): 3 batches of 48 (generated, real) windows through the reference's EmbeddingSpaceEvaluator
 FGD_CASE = dict(B=48, batches=3, seed=41)
+# evaluate_testset fixture (tests/golden/evalset.npz): two loader batches of 6 through the reference's validation loop
+EVAL_CASE = dict(B=6, batches=2, seed=51)
 # sliding-window synthesis fixture (tests/golden/synth.npz): 9 s clip -> 5 windows of 34 frames, `small` case modules
 SYNTH_CASE = dict(clip_seconds=9.0, n_words=18, seed=31, vid=3)
 

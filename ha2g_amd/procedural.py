@@ -124,3 +124,9 @@ def fgd_batch(B, i, seed, P=27):
     real = np.cumsum(0.05 * r.standard_normal((B, 34, P)), axis=1) + 0.3 * r.standard_normal((B, 1, P))
     gen = 0.8 * real + 0.1 * r.standard_normal((B, 34, P)) + 0.05
     return real.astype(np.float32), gen.astype(np.float32)
+
+
+def eval_speakers(n, n_spk, seed):
+    """Deterministic stand-in for the validation loop's random speaker draws (ids 1 .. n_spk-1)."""
+    r = np.random.Generator(np.random.PCG64([seed, 81]))
+    return [int(v) for v in r.integers(1, n_spk, size=n)]

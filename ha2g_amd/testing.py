@@ -197,10 +197,12 @@ class Checker:
 # ---- module construction helpers shared by GPU tests, smoke() and bench.py -------------------------------
 
 class SpeakerVocab:
-    """Stand-in for the reference's vocab.Vocab used as z_obj: only .n_words is read on the hot path."""
+    """Stand-in for the reference's vocab.Vocab used as z_obj: .n_words is read on the hot path, .word2index by the validation loop's
+    random speaker draw (scripts/train.py:365)."""
 
     def __init__(self, n_words):
         self.n_words = n_words
+        self.word2index = {'spk%d' % i: i for i in range(n_words)}
 
 
 def no_dropout(m):

@@ -554,6 +554,62 @@ def synth_expr_goldens(out, dt, perturb=0.0):
     out['synth_expr/out'] = np.asarray(res, np.float64)
 
 
+def _evalset(out, tag, expressive, perturb):
+    _stub_io_modules()
+    import random as _random
+    import tempfile
+    from model.embedding_space_evaluator import EmbeddingSpaceEvaluator
+    from ha2g_amd.config import EVAL_CASE as ec, FGD_CASE as fc, hierarchy_args
+    if expressive:
+        import train_expressive as ref_train
+        from model.motion_ae import MotionAE
+        case, dims, P = CASES['expr_small'], (24, 30, 36, 66, 96, 126), 126
+        net = proc.fill_module(MotionAE(126, 128), fc['seed'], 'fgd126.')
+        ckpt = {'pose_dim': 126, 'latent_dim': 128, 'motion_ae': net.state_dict()}
+    else:
+        import train as ref_train
+        from model.embedding_net import EmbeddingNet
+        case, dims, P = CASES['small'], (15, 21, 27), 27
+        net = proc.fill_module(EmbeddingNet(hierarchy_args(), 27, 34, 10, 300, None, 'pose'), fc['seed'], 'fgd.')
+        ckpt = {'pose_dim': 27, 'gen_dict': net.state_dict()}
+    args, gens, dis, aud, txt = build(case, dims, len(dims), torch.float32)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, 'ae.bin')
+        torch.save(ckpt, path)
+        ev = EmbeddingSpaceEvaluator(hierarchy_args(expressive=expressive), path, Lang(10), torch.device('cpu'))
+    batches = []
+    for i in range(ec['batches']):
+        text, spec, target, vid = proc.make_batch(ec['B'], P, case['n_words'], case['n_spk'], ec['seed'] + i)
+        if perturb:
+            r = np.random.Generator(np.random.PCG64([4242, 71 + i, PERTURB_DRAW])).standard_normal(spec.shape)
+            spec = (spec * (1.0 + perturb * r)).astype(np.float32)
+        z = torch.zeros(1)
+        batches.append((z, z, torch.from_numpy(text), z, torch.from_numpy(target), torch.zeros(ec['B'], 1), torch.from_numpy(spec), None))
+    eps = proc.EpsStream(ec['seed'])
+    ref_embedding_net.reparameterize = lambda mu, logvar: mu + torch.from_numpy(eps(mu.shape)).to(mu.dtype) * torch.exp(0.5 * logvar)
+    draws = iter(proc.eval_speakers(ec['B'] * ec['batches'], case['n_spk'], ec['seed']))
+    orig_choice, orig_perm = _random.choice, torch.randperm
+    _random.choice = lambda seq: next(draws)
+    torch.randperm = lambda n, *a, **k: torch.arange(n - 1, -1, -1)
+    try:
+        ret = ref_train.evaluate_testset(batches, None, *gens, aud, None, ev, args)
+    finally:
+        _random.choice, torch.randperm = orig_choice, orig_perm
+    for k in ('loss', 'joint_mae', 'frechet', 'feat_dist', 'diversity'):
+        out[tag + '/' + k] = np.float64(ret[k])
+
+
+def evalset_goldens(out, dt, perturb=0.0):
+    """scripts/train.py:326-500 evaluate_testset run by the reference itself (hierarchy branch): `small` case modules in eval mode, two
+    synthetic loader batches, the FGD evaluator of fgd_goldens, deterministic speaker draws; float32 only (the function casts)."""
+    _evalset(out, 'evalset', False, perturb)
+
+
+def evalset_expr_goldens(out, dt, perturb=0.0):
+    """scripts/train_expressive.py:394-626 evaluate_testset (six levels, MotionAE evaluator) run by the reference itself on `expr_small`."""
+    _evalset(out, 'evalset_expr', True, perturb)
+
+
 def write_fixture32(name, runs, NPERT):
     """fixtures whose reference only runs in float32: truth = the plain run, @noise = scatter of the perturbed runs around it"""
     out = {}
@@ -567,7 +623,7 @@ def write_fixture32(name, runs, NPERT):
     print('  wrote', path, os.path.getsize(path) // 1024, 'KiB,', len(out), 'arrays')
 
 
-EXTRA32 = {'synth': (synth_goldens, synth_expr_goldens)}
+EXTRA32 = {'synth': (synth_goldens, synth_expr_goldens), 'evalset': (evalset_goldens, evalset_expr_goldens)}
 
 
 def main_extra32(only):
