@@ -15,6 +15,7 @@ import torch
 
 from . import procedural as proc
 from . import schema
+from .config import FGD_CASE
 
 
 def state_for(case, dt=torch.float32, dims=schema.GESTURE_POSE_DIMS):
@@ -402,3 +403,37 @@ def tcn_relu_margin(case):
             worst = min(worst, float(s[s > 0].min() / s.max()))
             x = torch.relu(y + res)
     return worst
+
+
+def fgd_ae_state(dt=torch.float32, P=27):
+    """Procedural state dict of the reference's EmbeddingNet(mode='pose') (P=27; keys/shapes restated from model/embedding_net.py:42-82,
+    156-218) or MotionAE(126, 128) (P=126; model/motion_ae.py:33-131)."""
+    sch = {}
+    latent = 32 if P == 27 else 128
+
+    def bn(p, c):
+        for k in ('weight', 'bias', 'running_mean', 'running_var'):
+            sch[p + k] = (c,)
+        sch[p + 'num_batches_tracked'] = ()
+    e, d = ('pose_encoder.' if P == 27 else 'encoder.'), 'decoder.'
+    for i, (co, ci, k) in enumerate(((32, P, 3), (64, 32, 3), (64, 64, 4))):
+        sch['%snet.%d.0.weight' % (e, i)] = (co, ci, k); sch['%snet.%d.0.bias' % (e, i)] = (co,); bn('%snet.%d.1.' % (e, i), co)
+    sch[e + 'net.3.weight'] = (32, 64, 3); sch[e + 'net.3.bias'] = (32,)
+    for i, (co, ci) in ((0, (256, 384)), (3, (128, 256)), (6, (latent, 128))):
+        sch['%sout_net.%d.weight' % (e, i)] = (co, ci); sch['%sout_net.%d.bias' % (e, i)] = (co,)
+    bn(e + 'out_net.1.', 256); bn(e + 'out_net.4.', 128)
+    if P == 27:
+        for k in ('fc_mu', 'fc_logvar'):
+            sch[e + k + '.weight'] = (32, 32); sch[e + k + '.bias'] = (32,)
+    sch[d + 'pre_net.0.weight'] = (64, latent); sch[d + 'pre_net.0.bias'] = (64,); bn(d + 'pre_net.1.', 64)
+    sch[d + 'pre_net.3.weight'] = (136, 64); sch[d + 'pre_net.3.bias'] = (136,)
+    sch[d + 'net.0.weight'] = (4, 32, 3); sch[d + 'net.0.bias'] = (32,); bn(d + 'net.1.', 32)
+    sch[d + 'net.3.weight'] = (32, 32, 3); sch[d + 'net.3.bias'] = (32,); bn(d + 'net.4.', 32)
+    sch[d + 'net.6.weight'] = (32, 32, 3); sch[d + 'net.6.bias'] = (32,)
+    sch[d + 'net.7.weight'] = (P, 32, 3); sch[d + 'net.7.bias'] = (P,)
+    sd = {}
+    for k, shp in sch.items():
+        v = proc.tensor_for(('fgd.' if P == 27 else 'fgd126.') + k, shp if shp else (1,), FGD_CASE['seed'])
+        t = torch.from_numpy(np.asarray(v)).reshape(shp)
+        sd[k] = t.to(dt) if t.is_floating_point() else t
+    return sd
