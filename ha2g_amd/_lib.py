@@ -69,3 +69,6 @@ DEFAULT_GEMM_MODE = int(os.environ.get("HA2G_GEMM_MODE", "6"))
 DEFAULT_DIRECT_C32 = int(os.environ.get("HA2G_DIRECT_C32", "0"))
 lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
 lib.ha2g_conv_debug_direct_c32(DEFAULT_DIRECT_C32)
+# dense tile rule (tuning aid): HA2G_GEMM_TILE=-2 selects round 1's tile rule, 0..8 forces one tile shape (bit-identical results either way)
+if "HA2G_GEMM_TILE" in os.environ:
+    lib.ha2g_gemm_debug_tile(int(os.environ["HA2G_GEMM_TILE"]), 0)

@@ -763,30 +763,70 @@ int choose_splits(int M, int N, int K, int BM, int BN, long ws_floats, int* kchu
     return splits;
 }
 
+// Dense tile shapes.  0-4 serve every operand layout; 5-8 (wider / 96- and 160-column tiles) only the 16-byte-aligned (VEC) paths.
+// The arithmetic of one output element does not depend on the tile shape (same k order, same MFMA chain per accumulator), only on the
+// split-K count: the split decision below is the round-1 rule (so results are bit-identical to round 1's), the tile shape of the
+// k-contiguous-A GEMMs (forward and data-gradient products) is then picked by a time model fitted to tools/gemm_tile_sweep.py on MI355X
+// (profiles/r02_gemm_tile_sweep.txt): launch time = (most loaded CU's block count) x block time / latency-hiding factor, where the
+// factor drops when a CU holds only one or two blocks (nothing to overlap the tile loads with).
+static const int kTileBM[9] = {128, 64, 128, 64, 128, 128, 128, 64, 128}, kTileBN[9] = {128, 128, 64, 64, 32, 192, 160, 192, 96};
+static const double kTileEff[5] = {1.00, 0.97, 0.93, 0.88, 0.70};
+struct TileModel { double kov, f1s, f2s, f1b, f2b, eff[9]; };
+static const TileModel kModelF32   = {0.0,  0.67, 0.88, 0.84, 0.98, {0.71, 0.77, 0.85, 0.83, 0.71, 0.73, 0.71, 0.76, 0.80}};   // fp32 MFMA inner product
+static const TileModel kModelSplit = {44.0, 0.69, 0.82, 0.59, 0.97, {1.34, 1.27, 1.33, 1.16, 0.96, 1.49, 1.35, 1.30, 1.31}};   // split-bf16 inner product
+static int g_tile_force = -1, g_splits_force = 0;      // ha2g_gemm_debug_tile: tools/gemm_tile_sweep.py
+static int g_tile_model = 1;                           // ha2g_gemm_debug_tile(-2, 0) = round-1 tile rule
+
 template <int AMODE, int BMODE, bool VEC>
 int dispatch_tile(GemmP& p, long ws_floats, hipStream_t st) {
-    // Tile shape by problem shape.  Every CU's SIMDs share one MFMA pipe, so a launch lasts as long as its most loaded
-    // CU: score = per-tile efficiency x useful fraction of the padded tiles x load balance over 256 CUs (split-K fills
-    // the chip when the grid is small, so small grids are scored as balanced).
-    static const int bm[5] = {128, 64, 128, 64, 128}, bn[5] = {128, 128, 64, 64, 32};
-    static const double eff[5] = {1.00, 0.97, 0.93, 0.88, 0.70};
+    // Round-1 rule: every CU's SIMDs share one MFMA pipe, so a launch lasts as long as its most loaded CU: score = per-tile
+    // efficiency x useful fraction of the padded tiles x load balance over the CUs (split-K fills the chip when the grid is small,
+    // so small grids are scored as balanced).  It still fixes the split-K count.
     int best = 0; double bs = -1.0;
+    const int ncu = cu_count();
     for (int c = 0; c < 5; ++c) {
-        long tm = ceil_div(p.M, bm[c]), tn = ceil_div(p.N, bn[c]), tiles = tm * tn;
-        double useful = ((double)p.M * p.N) / ((double)tiles * bm[c] * bn[c]);
-        const int ncu = cu_count();
+        long tm = ceil_div(p.M, kTileBM[c]), tn = ceil_div(p.N, kTileBN[c]), tiles = tm * tn;
+        double useful = ((double)p.M * p.N) / ((double)tiles * kTileBM[c] * kTileBN[c]);
         double balance = tiles >= g_split_tiles ? ((double)tiles / ncu) / (double)((tiles + ncu - 1) / ncu) : 0.95;
-        double score = eff[c] * useful * balance;
+        double score = kTileEff[c] * useful * balance;
         if (score > bs) { bs = score; best = c; }
     }
-    p.splits = choose_splits(p.M, p.N, p.K, bm[best], bn[best], ws_floats, &p.kchunk);
+    p.splits = choose_splits(p.M, p.N, p.K, kTileBM[best], kTileBN[best], ws_floats, &p.kchunk);
+    constexpr int NC = VEC ? 9 : 5;
+    if (VEC && AMODE == A_KC && g_tile_model && !g_bf16 && !g_x3 && !g_x6 && !g_x6_dense) {
+        const TileModel& m = (BMODE == B_NC && g_split_dgrad && p.kchunk >= 64) ? kModelSplit : kModelF32;
+        double bt = 1e300;
+        for (int c = 0; c < NC; ++c) {
+            long tiles = (long)ceil_div(p.M, kTileBM[c]) * ceil_div(p.N, kTileBN[c]);
+            long load = (tiles * p.splits + ncu - 1) / ncu;
+            const bool big = kTileBM[c] * kTileBN[c] >= 128 * 96;
+            double occ = load >= 3 ? 1.0 : (load == 2 ? (big ? m.f2b : m.f2s) : (big ? m.f1b : m.f1s));
+            double t = (double)load * kTileBM[c] * kTileBN[c] * (p.kchunk + m.kov) / (m.eff[c] * occ);
+            if (t < bt) { bt = t; best = c; }
+        }
+    }
+    if (g_tile_force >= 0 && g_tile_force < NC) best = g_tile_force;
+    if (g_splits_force > 0 && (long)g_splits_force * p.M * p.N <= ws_floats) {
+        int kc = ceil_div(ceil_div(p.K, g_splits_force), 32) * 32;
+        p.splits = ceil_div(p.K, kc); p.kchunk = kc;
+    }
     switch (best) {
         case 0: return launch<2, 2, 2, 2, AMODE, BMODE, VEC>(p, st);
         case 1: return launch<1, 2, 2, 2, AMODE, BMODE, VEC>(p, st);
         case 2: return launch<1, 2, 4, 1, AMODE, BMODE, VEC>(p, st);
         case 3: return launch<1, 1, 2, 2, AMODE, BMODE, VEC>(p, st);
-        default: return launch<1, 1, 4, 1, AMODE, BMODE, VEC>(p, st);
+        case 4: return launch<1, 1, 4, 1, AMODE, BMODE, VEC>(p, st);
+        default: break;
     }
+    if constexpr (VEC && AMODE == A_KC) {
+        switch (best) {
+            case 5: return launch<2, 3, 2, 2, AMODE, BMODE, VEC>(p, st);
+            case 6: return launch<1, 5, 4, 1, AMODE, BMODE, VEC>(p, st);
+            case 7: return launch<1, 3, 2, 2, AMODE, BMODE, VEC>(p, st);
+            default: return launch<1, 3, 4, 1, AMODE, BMODE, VEC>(p, st);
+        }
+    }
+    return launch<2, 2, 2, 2, AMODE, BMODE, VEC>(p, st);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -833,6 +873,7 @@ extern "C" {
    margins of the full step are unchanged, see tools/margins.py) */
 void ha2g_gemm_set_mode(int mode) { g_x3 = mode & 1; g_split_wgrad = (mode >> 1) & 1; g_split_dgrad = (mode >> 2) & 1; g_x6 = (mode >> 3) & 1; g_bf16 = (mode >> 4) & 1; g_x6_dense = (mode >> 5) & 1; }
 void ha2g_gemm_debug_x6_min_n(int n) { g_x6_min_n = n; }
+void ha2g_gemm_debug_tile(int cfg, int splits) { g_tile_model = cfg != -2; g_tile_force = cfg == -2 ? -1 : cfg; g_splits_force = splits; }
 void ha2g_conv_debug_direct_c32(int on) { g_direct_c32 = on & 1; g_direct_c32_dgrad = (on >> 1) & 1; g_direct_c32_x3 = !((on >> 2) & 1); g_c32_dbg = on & 0x30; }
 void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 10000) g_wgrad_blocks = cfg - 10000; else if (cfg >= 1000) g_split_tiles = cfg - 1000; else g_conv_cfg = cfg; }   /* 1000+n: split-K tile threshold n; 10000+n: wgrad block target n */
 

@@ -68,6 +68,10 @@ int ha2g_conv2d_weight_ohwi_to_ihwo_f32(const float* w, float* wt, int Cout, int
 void ha2g_gemm_set_mode(int mode);
 /* tuning aid: forward GEMMs narrower than n columns stay on the fp32 MFMA */
 void ha2g_gemm_debug_x6_min_n(int n);
+/* tuning aid (tools/gemm_tile_sweep.py): force the dense tile shape (0-8, see kTileBM/kTileBN in csrc/gemm.hip; -1 = default rule,
+ * -2 = round 1's tile rule; results are bit-identical under every tile shape) and the split-K
+ * count (0 = heuristic) of every following ha2g_gemm_f32 call */
+void ha2g_gemm_debug_tile(int cfg, int splits);
 /* bit 0 (default 0, opt-in): forward 32->32 channel 3x3 convolutions on the direct LDS-patch kernel conv_c32.hip (else implicit GEMM);
  * bit 1 (default 0): their data gradients on the fp32 direct kernel; bit 2 (default 0): 1 = take their data gradients OFF the
  * split-bf16 direct kernel (default path, 121 vs 227 us) back to the implicit GEMM; bits 4-5: timing ablations */

@@ -456,3 +456,29 @@ def test_dense_forward_split_leaves_the_audio_tower_bits_unchanged():
     assert not torch.equal(outs[6][1], outs[38][1])
     ref = a.double().cpu() @ b.double().cpu().t()
     assert relerr(outs[38][1], ref) < 2e-6 and relerr(outs[6][1], ref) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(4352, 600, 300, False, False), (1000, 300, 600, False, True), (136, 900, 600, False, True),
+                                   (4352, 600, 900, False, False), (2176, 300, 150, False, False)])
+def test_dense_tile_shape_does_not_change_bits(shape):
+    """The tile shape of a dense GEMM (nine shapes, picked per problem by a fitted time model in round 2) is a pure speed choice: for a fixed
+    split-K count -- still decided by round 1's rule -- every output element runs the same MFMA chain over k in the same order."""
+    import ctypes
+    from ha2g_amd import ops
+    from ha2g_amd._lib import lib
+    lib.ha2g_gemm_debug_tile.argtypes = [ctypes.c_int, ctypes.c_int]
+    M, N, K, ta, tb = shape
+    g = torch.Generator(device='cuda:0').manual_seed(M + N)
+    a = torch.randn((K, M) if ta else (M, K), device='cuda:0', generator=g)
+    b = torch.randn((N, K) if tb else (K, N), device='cuda:0', generator=g)
+    try:
+        lib.ha2g_gemm_debug_tile(-2, 0)                                    # round 1's tile rule
+        ref = ops.gemm(a, b, transa=ta, transb=tb).clone()
+        for cfg in [-1] + list(range(9)):
+            lib.ha2g_gemm_debug_tile(cfg, 0)
+            assert torch.equal(ops.gemm(a, b, transa=ta, transb=tb), ref), cfg
+    finally:
+        lib.ha2g_gemm_debug_tile(-1, 0)
+    ref64 = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    assert float((ref.double() - ref64).abs().max() / ref64.abs().max()) < 2e-5
