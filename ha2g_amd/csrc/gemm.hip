@@ -42,6 +42,9 @@ struct GemmP {
     int splits, kchunk;
     float* ws;        // [splits][M][N] when splits > 1
     ConvGeom g;
+    // A_MC (weight-gradient shape, A = dY stored [K][M]) only: csum[m] = csum_beta * csum[m] + sum_k A[k][m] -- the bias gradient of the
+    // layer from the dY tiles this launch stages anyway.  Partials of a split-K launch go to ws + splits*M*N as [splits][M].
+    float* csum; float csum_beta;
 };
 
 
@@ -207,6 +210,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     }
 
     float4 ra[NA], rb[NB];
+    float4 bsum[NA];                          // A_MC + p.csum: this thread's column sums of the A tiles (k rows a_r + 16 j)
+    const bool csum_on = AMODE == A_MC && p.csum != nullptr && blockIdx.y == 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     auto load_tile = [&](int kt) {
         const int k0 = kbeg + kt * BKT;
@@ -274,6 +281,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     auto store_tile = [&](int buf) {
         float* as = As + buf * BKT * LDA;
         float* bs = Bs + buf * BKT * LDB;
+        if (AMODE == A_MC && csum_on) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) { bsum[i].x += ra[i].x; bsum[i].y += ra[i].y; bsum[i].z += ra[i].z; bsum[i].w += ra[i].w; }
+        }
         if (SPLIT) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) ra[i] = pack_hilo4(ra[i]);
@@ -401,6 +412,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 *dst = v;
             }
         }
+    if constexpr (AMODE == A_MC) {
+        if (csum_on) {                                   // block-uniform: combine the 16 k-row slots per column through LDS, fixed order
+            float* red = smem;                           // [BKT][BM]; the tiles are dead (last loop iteration ended with a barrier)
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                if (tid + i * 256 < SA) *reinterpret_cast<float4*>(red + a_r[i] * BM + a_c[i]) = bsum[i];
+            __syncthreads();
+            if (tid < BM && m0 + tid < p.M) {
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < BKT; ++r) t += red[r * BM + tid];
+                if (partial) p.ws[(long)p.splits * p.M * p.N + (long)blockIdx.z * p.M + m0 + tid] = t;
+                else p.csum[m0 + tid] = (p.csum_beta != 0.f ? p.csum_beta * p.csum[m0 + tid] : 0.f) + t;
+            }
+        }
+    }
 }
 
 
@@ -638,9 +665,17 @@ static int g_wgrad_blocks = 0;      // 0 = per-shape default (see ha2g_conv2d_wg
 static int g_split_tiles = 192;   // swept on the full step: <=100 is 5-30 % slower, >=192 flat
 
 __global__ void splitk_reduce_kernel(const float* ws, int splits, long MN, int N, float* C, long ldc, float alpha,
-                                     float beta, const float* bias, int act) {
+                                     float beta, const float* bias, int act, float* csum, float csum_beta, int M) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= MN) return;
+    if (i >= MN) {                                        // the fused bias gradient's partials: [splits][M] behind the slabs
+        const long m = i - MN;
+        if (csum == nullptr || m >= M) return;
+        const float* wb = ws + (long)splits * MN;
+        double sd = 0.0;
+        for (int z = 0; z < splits; ++z) sd += (double)wb[(long)z * M + m];
+        csum[m] = (csum_beta != 0.f ? csum_beta * csum[m] : 0.f) + (float)sd;
+        return;
+    }
     double sd = 0.0;
     for (int z = 0; z < splits; ++z) sd += (double)ws[(long)z * MN + i];
     const float s = (float)sd;
@@ -655,17 +690,23 @@ __global__ void splitk_reduce_kernel(const float* ws, int splits, long MN, int N
 // Many splits over a small output (weight gradients of the 32/64-channel convolutions: up to ~340 partials of 9-37 k
 // floats): one block per 64 outputs, its 4 waves stride the partials, fixed-order LDS combine (deterministic).
 __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* ws, int splits, long MN, int N, float* C, long ldc,
-                                                                 float alpha, float beta, const float* bias, int act) {
+                                                                 float alpha, float beta, const float* bias, int act, float* csum,
+                                                                 float csum_beta, int M) {
     __shared__ double part[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long i = (long)blockIdx.x * 64 + lane;
+    const long nmain = (MN + 63) / 64;                    // blocks past the output tiles reduce the fused bias gradient's partials
+    const bool tail = blockIdx.x >= nmain;
+    const long i = tail ? (long)(blockIdx.x - nmain) * 64 + lane : (long)blockIdx.x * 64 + lane;
+    const long cnt = tail ? M : MN;
+    const float* src = tail ? ws + (long)splits * MN : ws;
     double sd = 0.0;
-    if (i < MN)
-        for (int z = w; z < splits; z += 4) sd += (double)ws[(long)z * MN + i];
+    if (i < cnt)
+        for (int z = w; z < splits; z += 4) sd += (double)src[(long)z * cnt + i];
     part[w][lane] = sd;
     __syncthreads();
-    if (w != 0 || i >= MN) return;
+    if (w != 0 || i >= cnt) return;
     const float s = (float)((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    if (tail) { csum[i] = (csum_beta != 0.f ? csum_beta * csum[i] : 0.f) + s; return; }
     int col = (int)(i % N);
     long row = i / N;
     float v = alpha * s + (bias ? bias[col] : 0.f);
@@ -717,12 +758,13 @@ int launch(const GemmP& p, hipStream_t st) {
     HA2G_CHECK_LAUNCH("gemm");
     if (p.splits > 1) {
         long MN = (long)p.M * p.N;
+        float* cs = AMODE == A_MC ? p.csum : nullptr;
         if (p.splits >= 16 && MN <= (1 << 20))
-            hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(ceil_div(MN, 64)), dim3(256), 0, st, p.ws, p.splits, MN, p.N, p.C,
-                               p.ldc, p.alpha, p.beta, p.bias, p.act);
+            hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(ceil_div(MN, 64) + (cs ? ceil_div(p.M, 64) : 0)), dim3(256), 0, st, p.ws, p.splits,
+                               MN, p.N, p.C, p.ldc, p.alpha, p.beta, p.bias, p.act, cs, p.csum_beta, p.M);
         else
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(MN, 256)), dim3(256), 0, st, p.ws, p.splits, MN, p.N, p.C,
-                               p.ldc, p.alpha, p.beta, p.bias, p.act);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(MN + (cs ? p.M : 0), 256)), dim3(256), 0, st, p.ws, p.splits, MN, p.N, p.C,
+                               p.ldc, p.alpha, p.beta, p.bias, p.act, cs, p.csum_beta, p.M);
         HA2G_CHECK_LAUNCH("splitk_reduce");
     }
     return 0;
@@ -754,7 +796,7 @@ int choose_splits(int M, int N, int K, int BM, int BN, long ws_floats, int* kchu
         int maxs = K / 128;
         if (splits > maxs) splits = maxs;
         if (splits < 1) splits = 1;
-        while (splits > 1 && (long)splits * M * N > ws_floats) --splits;
+        while (splits > 1 && (long)splits * M * (N + 1) > ws_floats) --splits;
     }
     int kc = ceil_div(K, splits);
     kc = ceil_div(kc, 32) * 32;
@@ -806,7 +848,7 @@ int dispatch_tile(GemmP& p, long ws_floats, hipStream_t st) {
         }
     }
     if (g_tile_force >= 0 && g_tile_force < NC) best = g_tile_force;
-    if (g_splits_force > 0 && (long)g_splits_force * p.M * p.N <= ws_floats) {
+    if (g_splits_force > 0 && (long)g_splits_force * p.M * (p.N + 1) <= ws_floats) {
         int kc = ceil_div(ceil_div(p.K, g_splits_force), 32) * 32;
         p.splits = ceil_div(p.K, kc); p.kchunk = kc;
     }
@@ -899,6 +941,24 @@ int ha2g_gemm_f32(int transa, int transb, int M, int N, int K, float alpha, cons
     if (!transa && !transb) return vec ? dispatch_tile<A_KC, B_NC, true>(p, wsf, st) : dispatch_tile<A_KC, B_NC, false>(p, wsf, st);
     if (transa && !transb) return vec ? dispatch_tile<A_MC, B_NC, true>(p, wsf, st) : dispatch_tile<A_MC, B_NC, false>(p, wsf, st);
     return ha2g_set_error(-1, "gemm: transa=1,transb=1 is not used on this path");
+}
+
+// Weight and bias gradient of a linear layer in one launch: dW[M,N] = beta*dW + dY^T X and db[M] = bias_beta*db + column sums of dY,
+// dY stored [K][M] (rows = samples), X [K][N].  The bias sums ride on the dY tiles the GEMM stages anyway (fp32 per block, double across
+// split-K partials in the reduce launch).
+int ha2g_gemm_wgrad_bias_f32(int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float beta, float* dW, long ldw,
+                             float bias_beta, float* db, float* ws, long ws_bytes, void* stream) {
+    HA2G_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_wgrad_bias: negative dimension");
+    HA2G_REQUIRE(db != nullptr, "gemm_wgrad_bias: null bias gradient");
+    if (M == 0 || N == 0) return 0;
+    GemmP p{};
+    p.M = M; p.N = N; p.K = K; p.A = dY; p.lda = ldy; p.B = X; p.ldb = ldx; p.C = dW; p.ldc = ldw;
+    p.alpha = 1.f; p.beta = beta; p.bias = nullptr; p.act = 0; p.ws = ws; p.splits = 1; p.kchunk = K;
+    p.csum = db; p.csum_beta = bias_beta;
+    hipStream_t st = (hipStream_t)stream;
+    long wsf = ws ? ws_bytes / 4 : 0;
+    bool vec = aligned16(dY) && (ldy % 4 == 0) && (M % 4 == 0) && aligned16(X) && (ldx % 4 == 0) && (N % 4 == 0);
+    return vec ? dispatch_tile<A_MC, B_NC, true>(p, wsf, st) : dispatch_tile<A_MC, B_NC, false>(p, wsf, st);
 }
 
 // NHWC convolution as implicit GEMM.  x [N,H,W,Cin], w [Cout][KH][KW][Cin] (torch channels_last weight),

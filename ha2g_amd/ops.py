@@ -3,6 +3,8 @@ and the torch.autograd.Function classes that make `loss.backward()` at the refer
 hand-written backward kernels.  torch is used for device memory, streams and autograd bookkeeping only;
 there is no fallback path -- every op here ends in a libha2g_hip.so call.
 """
+import os
+
 import torch
 
 from ._lib import check, lib
@@ -117,9 +119,11 @@ def empty(*shape, like):
 # raw wrappers
 # ------------------------------------------------------------------------------------------------
 
-def gemm(a, b, transa=False, transb=False, out=None, alpha=1.0, beta=0.0, bias=None, act=ACT_NONE):
+def gemm(a, b, transa=False, transb=False, out=None, alpha=1.0, beta=0.0, bias=None, act=ACT_NONE, colsum_out=None, colsum_beta=0.0):
     """out[M,N] = act(alpha * op(a) @ op(b) + beta*out + bias).  a, b, out: 2-D fp32 CUDA tensors with unit
-    inner stride (row stride free, so column slices of wider buffers work)."""
+    inner stride (row stride free, so column slices of wider buffers work).
+    colsum_out [M] (weight-gradient shape only: transa, not transb): also colsum_out = colsum_beta*colsum_out + a.sum(0), the layer's bias
+    gradient, from the same launch."""
     _chk2d(a)
     _chk2d(b)
     M, K = (a.shape[1], a.shape[0]) if transa else a.shape
@@ -131,6 +135,12 @@ def gemm(a, b, transa=False, transb=False, out=None, alpha=1.0, beta=0.0, bias=N
     _chk2d(out)
     assert out.shape == (M, N)
     ws = workspace(a.device)
+    if colsum_out is not None:
+        assert transa and not transb and alpha == 1.0 and bias is None and act == ACT_NONE
+        assert colsum_out.shape == (M,) and colsum_out.is_contiguous() and colsum_out.dtype == torch.float32
+        check(lib.ha2g_gemm_wgrad_bias_f32(M, N, K, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), beta, out.data_ptr(), out.stride(0),
+                                           colsum_beta, colsum_out.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream()))
+        return out
     check(lib.ha2g_gemm_f32(int(transa), int(transb), M, N, K, alpha, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
                             beta, out.data_ptr(), out.stride(0), _p(bias), act, ws.data_ptr(), ws.numel() * 4, _stream()))
     return out
@@ -234,6 +244,9 @@ DIRECT_GRAD = True     # accumulate weight gradients straight into an existing `
                        # returning a temporary that autograd then adds with its own kernel (one at::add per parameter)
 
 
+FUSE_BIAS_GRAD = os.environ.get("HA2G_FUSE_BIAS_GRAD", "1") != "0"     # Linear / Conv1d: bias gradient = column sums taken by the weight-gradient GEMM (ha2g_gemm_wgrad_bias_f32)
+
+
 def _grad_target(param):
     """The parameter's installed gradient buffer if a kernel may accumulate into it directly, else None."""
     g = param.grad if DIRECT_GRAD and param.is_leaf else None
@@ -270,16 +283,21 @@ class LinearFunction(torch.autograd.Function):
         dx = dw = db = None
         big = dy2.shape[0] >= 1024                       # tiny layers: the fork/join costs more than it hides
         with (side.section(dy2.device) if big else _null()):
+            want_b = ctx.has_b and ctx.needs_input_grad[2]
+            tb = _grad_target(ctx.bias_ref) if (want_b and ctx.bias_ref is not None) else None
+            fuse_b = want_b and ctx.needs_input_grad[1] and FUSE_BIAS_GRAD        # bias gradient from the weight-gradient launch
+            if fuse_b and tb is None:
+                db = torch.empty(dy2.shape[1], dtype=torch.float32, device=dy2.device)
+            cs = dict(colsum_out=tb if tb is not None else db, colsum_beta=1.0 if tb is not None else 0.0) if fuse_b else {}
             if ctx.needs_input_grad[1]:
                 tgt = _grad_target(ctx.wref)
                 if tgt is not None and tgt.is_contiguous():
-                    gemm(dy2, x2, transa=True, out=tgt, beta=1.0)
+                    gemm(dy2, x2, transa=True, out=tgt, beta=1.0, **cs)
                 else:
-                    dw = gemm(dy2, x2, transa=True)
-            if ctx.has_b and ctx.needs_input_grad[2]:
-                tgt = _grad_target(ctx.bias_ref) if ctx.bias_ref is not None else None
-                if tgt is not None:
-                    colsum(dy2, out=tgt, beta=1.0)
+                    dw = gemm(dy2, x2, transa=True, **cs)
+            if want_b and not fuse_b:
+                if tb is not None:
+                    colsum(dy2, out=tb, beta=1.0)
                 else:
                     db = colsum(dy2)
         if ctx.needs_input_grad[0]:
@@ -480,14 +498,19 @@ class Conv1dFunction(torch.autograd.Function):
         dy2 = act_bwd(dy.reshape(B * To, cout), y, act)
         dx = dw = db = None
         with side.section(dy2.device):
+            want_b = ctx.has_b and ctx.needs_input_grad[2]
+            tb = _grad_target(ctx.refs[1]) if want_b else None
+            fuse_b = want_b and ctx.needs_input_grad[1] and FUSE_BIAS_GRAD        # bias gradient from the weight-gradient launch
+            if fuse_b and tb is None:
+                db = torch.empty(cout, dtype=torch.float32, device=dy2.device)
+            cs = dict(colsum_out=tb if tb is not None else db, colsum_beta=1.0 if tb is not None else 0.0) if fuse_b else {}
             if ctx.needs_input_grad[1]:
                 tw = _grad_target(ctx.refs[0])
                 if tw is not None and tw.is_contiguous():             # a leaf weight (discriminator convs): dW += straight into .grad
-                    gemm(dy2, col, transa=True, out=tw.view(cout, C * k), beta=1.0)
+                    gemm(dy2, col, transa=True, out=tw.view(cout, C * k), beta=1.0, **cs)
                 else:                                                 # weight-normalised TCN convs: dw feeds weight_norm's backward
-                    dw = gemm(dy2, col, transa=True).view(cout, C, k)
-            if ctx.has_b and ctx.needs_input_grad[2]:
-                tb = _grad_target(ctx.refs[1])
+                    dw = gemm(dy2, col, transa=True, **cs).view(cout, C, k)
+            if want_b and not fuse_b:
                 if tb is not None:
                     colsum(dy2, out=tb, beta=1.0)
                 else:
@@ -698,6 +721,7 @@ class BiGRUFunction(torch.autograd.Function):
         dev = dy.device
         grads = [None] * (8 * L)
         keep = []
+        fused_b = []
         for l in range(L - 1, -1, -1):
             inp, y, rs = (t[sl] for t in ctx.saved_bufs[l])
             w = weights[8 * l:8 * l + 8]
@@ -721,29 +745,36 @@ class BiGRUFunction(torch.autograd.Function):
                     dgi = dg[:, o:o + 3 * H]
                     tg = [_grad_target(w[4 * d + i]) for i in range(4)]
                     tg = [t if (t is not None and t.is_contiguous()) else None for t in tg]
+                    # bias gradients ride on the weight-gradient launches when every target is an installed .grad buffer:
+                    # b_ih <- columns [r z n] of dgi, b_hh <- columns [r z] and [hn] (the same dY tiles the three GEMMs stage)
+                    fb = FUSE_BIAS_GRAD and all(t is not None for t in tg)
+                    cs3 = [dict(colsum_out=c, colsum_beta=1.0) for c in (tg[2], tg[3][:2 * H], tg[3][2 * H:])] if fb else [{}, {}, {}]
+                    fused_b.append(fb)
                     if tg[0] is not None:
-                        gemm(dgi, x2, transa=True, out=tg[0], beta=1.0)             # dW_ih += dgi^T X, straight into .grad
+                        gemm(dgi, x2, transa=True, out=tg[0], beta=1.0, **cs3[0])   # dW_ih += dgi^T X, straight into .grad
                     else:
                         grads[8 * l + 4 * d + 0] = gemm(dgi, x2, transa=True)
                     bt = 1.0 if tg[1] is not None else 0.0
                     dwhh = tg[1] if tg[1] is not None else torch.empty(3 * H, H, dtype=torch.float32, device=dev)
                     hpd = hp2[:, d * H:(d + 1) * H]
-                    gemm(dg[:, o:o + 2 * H], hpd, transa=True, out=dwhh[:2 * H], beta=bt)    # rows r,z
-                    gemm(dg[:, o + 3 * H:o + 4 * H], hpd, transa=True, out=dwhh[2 * H:], beta=bt)  # rows n (d gh_n)
+                    gemm(dg[:, o:o + 2 * H], hpd, transa=True, out=dwhh[:2 * H], beta=bt, **cs3[1])    # rows r,z
+                    gemm(dg[:, o + 3 * H:o + 4 * H], hpd, transa=True, out=dwhh[2 * H:], beta=bt, **cs3[2])  # rows n (d gh_n)
                     if tg[1] is None:
                         grads[8 * l + 4 * d + 1] = dwhh
                     tgs.append(tg)
-                # the four bias gradients of the layer from ONE column sum over all 8H gate-gradient columns
-                cs = colsum(dg)
-                direct = all(t[2] is not None and t[3] is not None for t in tgs)
-                outs = [(tgs[d][2], tgs[d][3]) if direct else (torch.empty(3 * H, dtype=torch.float32, device=dev),
-                                                                torch.empty(3 * H, dtype=torch.float32, device=dev)) for d in range(2)]
-                check(lib.ha2g_gru_bias_grads_f32(cs.data_ptr(), outs[0][0].data_ptr(), outs[0][1].data_ptr(), outs[1][0].data_ptr(),
-                                                  outs[1][1].data_ptr(), H, 1.0 if direct else 0.0, _stream()))
-                keep.append(cs)
-                if not direct:
-                    for d in range(2):
-                        grads[8 * l + 4 * d + 2], grads[8 * l + 4 * d + 3] = outs[d]
+                if not all(fused_b[-2:]):
+                    assert not any(fused_b[-2:]), 'both directions of a layer share one gradient-buffer state'
+                    # the four bias gradients of the layer from ONE column sum over all 8H gate-gradient columns
+                    cs = colsum(dg)
+                    direct = all(t[2] is not None and t[3] is not None for t in tgs)
+                    outs = [(tgs[d][2], tgs[d][3]) if direct else (torch.empty(3 * H, dtype=torch.float32, device=dev),
+                                                                    torch.empty(3 * H, dtype=torch.float32, device=dev)) for d in range(2)]
+                    check(lib.ha2g_gru_bias_grads_f32(cs.data_ptr(), outs[0][0].data_ptr(), outs[0][1].data_ptr(), outs[1][0].data_ptr(),
+                                                      outs[1][1].data_ptr(), H, 1.0 if direct else 0.0, _stream()))
+                    keep.append(cs)
+                    if not direct:
+                        for d in range(2):
+                            grads[8 * l + 4 * d + 2], grads[8 * l + 4 * d + 3] = outs[d]
             if need_dx:
                 for d in range(2):                                                  # critical path: dX (+)= dgi W_ih
                     gemm(dg[:, 4 * H * d:4 * H * d + 3 * H], w[4 * d], out=dx, beta=float(d))

@@ -34,6 +34,11 @@ const char* ha2g_last_error(void);
 int ha2g_gemm_f32(int transa, int transb, int M, int N, int K, float alpha, const float* A, long lda, const float* B,
                   long ldb, float beta, float* C, long ldc, const float* bias, int act, float* ws, long ws_bytes,
                   void* stream);
+/* dW[M,N] = beta*dW + dY^T X  and  db[M] = bias_beta*db + column sums of dY  in one launch (+ the split-K reduce launch it needs anyway);
+ * dY stored [K][M] (K = samples), X [K][N].  The weight and bias gradients of nn.Linear / nn.Conv1d (autograd's addmm backward + sum(0):
+ * model/hierarchy_net.py:87-93, model/tcn.py:19-31, model/ResNetSE34V2.py:163-202) without a separate pass over dY. */
+int ha2g_gemm_wgrad_bias_f32(int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float beta, float* dW, long ldw,
+                             float bias_beta, float* db, float* ws, long ws_bytes, void* stream);
 /* out[c] = beta*out[c] + sum_r X[r*ld + c]  (bias gradients); ws >= ha2g_colsum_workspace_bytes(cols) */
 long ha2g_colsum_workspace_bytes(int cols);
 int ha2g_colsum_f32(const float* X, long ld, long rows, int cols, float* out, float beta, float* ws, void* stream);

@@ -482,3 +482,47 @@ def test_dense_tile_shape_does_not_change_bits(shape):
         lib.ha2g_gemm_debug_tile(-1, 0)
     ref64 = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
     assert float((ref.double() - ref64).abs().max() / ref64.abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(300, 600, 4352), (900, 600, 4352), (150, 300, 4352), (27, 150, 4352), (64, 16, 128), (300, 300, 136),
+                                   (129, 77, 1000), (16, 128, 7168)])
+@pytest.mark.parametrize('acc', [False, True])
+def test_wgrad_gemm_with_fused_bias_gradient(shape, acc):
+    """ha2g_gemm_wgrad_bias_f32: the weight gradient is bit-identical to the plain GEMM's, the bias gradient equals the float64 column sums of dY
+    (split-K and single-pass launches, 16-byte-aligned and ragged shapes, overwrite and accumulate)."""
+    from ha2g_amd import ops
+    M, N, K = shape
+    g = torch.Generator(device='cuda:0').manual_seed(M * 7 + N)
+    dy = torch.randn(K, M, device='cuda:0', generator=g) + 0.25
+    x = torch.randn(K, N, device='cuda:0', generator=g)
+    w0 = torch.randn(M, N, device='cuda:0', generator=g) if acc else torch.zeros(M, N, device='cuda:0')
+    b0 = torch.randn(M, device='cuda:0', generator=g) if acc else torch.full((M,), float('nan'), device='cuda:0')
+    ref_w = ops.gemm(dy, x, transa=True, out=w0.clone(), beta=1.0 if acc else 0.0)
+    got_w, got_b = w0.clone(), b0.clone()
+    ops.gemm(dy, x, transa=True, out=got_w, beta=1.0 if acc else 0.0, colsum_out=got_b, colsum_beta=1.0 if acc else 0.0)
+    assert torch.equal(got_w, ref_w)
+    ref_b = dy.double().sum(0) + (b0.double() if acc else 0.0)
+    scale = float(dy.double().abs().sum(0).max())
+    assert float((got_b.double() - ref_b).abs().max()) <= 2e-6 * scale
+
+
+@pytest.mark.gpu
+def test_linear_and_conv1d_bias_gradients_fused_equal_unfused():
+    from ha2g_amd import ops
+    g = torch.Generator(device='cuda:0').manual_seed(11)
+    x = torch.randn(64, 34, 48, device='cuda:0', generator=g, requires_grad=True)
+    w = torch.randn(40, 48, device='cuda:0', generator=g, requires_grad=True)
+    b = torch.randn(40, device='cuda:0', generator=g, requires_grad=True)
+    wc = torch.randn(40, 48, 2, device='cuda:0', generator=g, requires_grad=True)
+    res = {}
+    for fuse in (True, False):
+        ops.FUSE_BIAS_GRAD = fuse
+        try:
+            y = ops.linear(x, w, b, ops.ACT_LEAKY) .sum() + (ops.conv1d_tm(x, wc, b, 2, 2, 34, ops.ACT_RELU) ** 2).sum()
+            res[fuse] = torch.autograd.grad(y, (x, w, b, wc))
+        finally:
+            ops.FUSE_BIAS_GRAD = True
+    for a_, b_ in zip(res[True], res[False]):
+        assert float((a_ - b_).abs().max()) <= 2e-6 * float(b_.abs().max())
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][3], res[False][3])
