@@ -66,7 +66,7 @@ def check(rc):
 # matrix-core mode (see ha2g_gemm_set_mode in include/ha2g_hip.h) and direct-convolution switches; the HA2G_GEMM_MODE / HA2G_DIRECT_C32
 # environment variables override the library defaults (tests restore THESE values after toggling modes)
 DEFAULT_GEMM_MODE = int(os.environ.get("HA2G_GEMM_MODE", "6"))
-DEFAULT_DIRECT_C32 = int(os.environ.get("HA2G_DIRECT_C32", "0"))
+DEFAULT_DIRECT_C32 = int(os.environ.get("HA2G_DIRECT_C32", "1"))
 lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
 lib.ha2g_conv_debug_direct_c32(DEFAULT_DIRECT_C32)
 # dense tile rule (tuning aid): HA2G_GEMM_TILE=-2 selects round 1's tile rule, 0..8 forces one tile shape (bit-identical results either way)

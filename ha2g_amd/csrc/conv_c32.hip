@@ -9,8 +9,12 @@
 //   * the whole 32 x 288 filter lives in REGISTERS (144 per lane) in MFMA B-fragment order, loaded once per workgroup;
 //     workgroups are persistent (one 8-wave workgroup per CU) and loop over tiles with the patch DOUBLE-BUFFERED: the next
 //     tile's patch is fetched one 16-byte slot per thread per filter tap while the current tile is on the matrix cores;
-//   * inner loop per (row block, tap): 4 ds_read_b128 -> 16 v_mfma_f32_32x32x2_f32 (k order chosen so that one 16-byte read
-//     feeds 4 MFMAs: MFMA j of channel group q uses channels 8q + j (lanes 0-31) and 8q + 4 + j (lanes 32-63)).
+//   * inner loop per (row block, tap): 4 ds_read_b128 -> 16 v_mfma_f32_32x32x2_f32.  One 16-byte read feeds 4 MFMAs AND the k order
+//     is the implicit GEMM's (k = tap * 32 + channel ascending, lanes 0-31 the even k of a pair, lanes 32-63 the odd one): the patch is
+//     stored with the channels of every 8-group interleaved as [0 2 4 6 | 1 3 5 7], so the 16 bytes a lane of half h reads are channels
+//     8q + h, 8q + 2 + h, 8q + 4 + h, 8q + 6 + h and MFMA j consumes the pair (8q + 2j, 8q + 2j + 1).  Every accumulator therefore runs the
+//     same MFMA chain on the same operands as gemm.hip's A_IM kernel: the two kernels are BIT-IDENTICAL (tests/test_gpu_kernels.py), which is
+//     what lets the forward pass use this one by default without touching the parity fixtures.
 // The data gradient is the same kernel on dy with the [ci][kh][kw][co] weight image and the taps flipped.
 #include "common.h"
 
@@ -31,7 +35,7 @@ __device__ __forceinline__ Tile tile_of(long tile, int tpi, int HW, int W) {
 }
 
 // Cursor over one thread's 8 patch slots of a tile (slot t = 16 bytes: padded pixel (tid >> 3) + 64 t of the patch, channel
-// quad tid & 7).  Successive slots are 64 padded pixels apart, i.e. at most one row wrap (W + 2 > 64 is checked by the host):
+// quad c4 = a permutation of tid & 7).  Successive slots are 64 padded pixels apart, i.e. at most one row wrap (W + 2 > 64 is checked by the host):
 // no divisions or multiplications per slot.
 struct SlotCursor {
     int pr, px;          // patch row / padded column of the current slot
@@ -39,7 +43,7 @@ struct SlotCursor {
     int lo;              // LDS float offset of the slot (fp32 patch)
     int pp;              // padded pixel index pr * (W + 2) + px (bf16-plane patch)
     __device__ __forceinline__ void init(const Tile& t, int tid, int H, int W, int HW) {
-        const int PW = W + 2, pi = tid >> 3, c4 = tid & 7;
+        const int PW = W + 2, pi = tid >> 3, c4 = ((tid >> 2) & 1) | ((tid & 3) << 1);   // quad parity = lane bit 2 (see interleave_slot)
         pr = pi / PW; px = pi - pr * PW;
         g = ((long)t.img * HW + (long)(t.r0 - 1 + pr) * W + (px - 1)) * CH + 4 * c4;
         lo = (pr * PW + px) * CS + 4 * c4;
@@ -60,6 +64,23 @@ struct SlotCursor {
     }
 };
 
+// Channel interleave of the patch (see header).  Lanes l and l ^ 4 hold the two channel quads 8q..8q+3 / 8q+4..8q+7 of one pixel (slot
+// mapping in SlotCursor::init: the quad's parity is bit 2 of the lane) and must store [0 2 4 6] / [1 3 5 7].  Four DPP moves do it with
+// no selects and no LDS traffic: the bank mask (groups of 4 lanes) writes the neighbour's value only into the lanes of one parity, the
+// others keep their own value, so the patch is still written with one 16-byte store per slot.  Called by all lanes.
+__device__ __forceinline__ float dpp_keep(float keep, float src, bool from_above) {
+    // from_above: even-parity lanes (banks 0, 2) take src of lane + 4 (row_shl:4); else odd-parity lanes (banks 1, 3) take src of lane - 4
+    return from_above ? __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(src), 0x104, 0xF, 0x5, false))
+                      : __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(src), 0x114, 0xF, 0xA, false));
+}
+__device__ __forceinline__ float4 interleave_slot(const float4& v) {
+    return make_float4(dpp_keep(v.x, v.y, false),      // even: ch0 (own x)        odd: ch1 (neighbour's y)
+                       dpp_keep(v.z, v.w, false),      // even: ch2 (own z)        odd: ch3 (neighbour's w)
+                       dpp_keep(v.y, v.x, true),       // even: ch4 (neighbour's x) odd: ch5 (own y)
+                       dpp_keep(v.w, v.z, true));      // even: ch6 (neighbour's z) odd: ch7 (own w)
+}
+__device__ __forceinline__ void store_slot(float* lds, int off, const float4& v) { *reinterpret_cast<float4*>(lds + off) = v; }
+
 // 512 threads = 8 waves, one 32-pixel row block each; persistent over tiles; the patch is double-buffered in LDS and the next
 // tile's patch is fetched one slot per filter tap while the current tile is on the matrix cores.
 __global__ __launch_bounds__(NT, 1) void conv3x3_c32_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -72,13 +93,17 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c32_kernel(const float* __restr
     const int tpi = (HW + TP - 1) / TP;
     const long tiles = (long)N * tpi;
 
-    // ---- filter -> registers: breg[t][q] holds w[n = l31][tap t][channels 8q + 4*lhi .. +3] ----
+    // ---- filter -> registers: breg[t][q] holds w[n = l31][tap t][channels 8q + lhi, 8q + 2 + lhi, 8q + 4 + lhi, 8q + 6 + lhi] ----
     float4 breg[9][4];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int tt = flip ? 8 - t : t;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) breg[t][q] = *reinterpret_cast<const float4*>(w + ((long)l31 * 9 + tt) * CH + 8 * q + 4 * lhi);
+        for (int q = 0; q < 4; ++q) {
+            const float4 f0 = *reinterpret_cast<const float4*>(w + ((long)l31 * 9 + tt) * CH + 8 * q);
+            const float4 f1 = *reinterpret_cast<const float4*>(w + ((long)l31 * 9 + tt) * CH + 8 * q + 4);
+            breg[t][q] = lhi ? make_float4(f0.y, f0.w, f1.y, f1.w) : make_float4(f0.x, f0.z, f1.x, f1.z);
+        }
     }
 
     long tile = blockIdx.x;
@@ -91,7 +116,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c32_kernel(const float* __restr
         for (int i = 0; i < 8; ++i) {
             float4 v;
             const int off = c.load(x, cur, H, W, v);
-            if (off >= 0) *reinterpret_cast<float4*>(lds + off) = v;
+            v = interleave_slot(v);
+            if (off >= 0) store_slot(lds, off, v);
             c.advance(W);
         }
     }
@@ -117,6 +143,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c32_kernel(const float* __restr
         constexpr int DEPTH = 3;
         SlotCursor nc; nc.init(nxt, tid, H, W, HW);
         float4 nv[DEPTH];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) nv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         int noff[DEPTH];
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) noff[i] = -1;
@@ -124,9 +152,12 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c32_kernel(const float* __restr
         float4 av = *reinterpret_cast<const float4*>(patch + a0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            if (t >= DEPTH && noff[t % DEPTH] >= 0) *reinterpret_cast<float4*>(npatch + noff[t % DEPTH]) = nv[t % DEPTH];
+            if (t >= DEPTH) {                                              // block-uniform condition: every lane takes part in the swap
+                const float4 sv = interleave_slot(nv[t % DEPTH]);
+                if (noff[t % DEPTH] >= 0) store_slot(npatch, noff[t % DEPTH], sv);
+            }
             noff[t % DEPTH] = -1;
-            if (has_next && t < 8 && !(act & 0x20)) { noff[t % DEPTH] = nc.load(x, nxt, H, W, nv[t % DEPTH]); nc.advance(W); }
+            if (has_next && t < 8 && !(act & 0x20)) { noff[t % DEPTH] = nc.load(x, nxt, H, W, nv[t % DEPTH]); nc.advance(W); }   /* interleaved at store time */
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 cur_a = av;
@@ -141,8 +172,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_c32_kernel(const float* __restr
             }
         }
 #pragma unroll
-        for (int i = 0; i < DEPTH; ++i)
-            if (noff[i] >= 0) *reinterpret_cast<float4*>(npatch + noff[i]) = nv[i];
+        for (int i = 0; i < DEPTH; ++i) {
+            const float4 sv = interleave_slot(nv[i]);
+            if (noff[i] >= 0) store_slot(npatch, noff[i], sv);
+        }
         // ---- epilogue: C/D layout row = (r&3) + 8*(r>>2) + 4*lhi (pixel), col = l31 (channel) ----
         float* yout = y + (long)cur.img * HW * CH;
         const int pb0 = cur.p0 + 32 * wave;

@@ -77,7 +77,8 @@ void ha2g_gemm_debug_x6_min_n(int n);
  * -2 = round 1's tile rule; results are bit-identical under every tile shape) and the split-K
  * count (0 = heuristic) of every following ha2g_gemm_f32 call */
 void ha2g_gemm_debug_tile(int cfg, int splits);
-/* bit 0 (default 0, opt-in): forward 32->32 channel 3x3 convolutions on the direct LDS-patch kernel conv_c32.hip (else implicit GEMM);
+/* bit 0 (default 1): forward 32->32 channel 3x3 convolutions on the direct LDS-patch kernel conv_c32.hip (else implicit GEMM; the two are
+ * bit-identical: same MFMA chain per accumulator);
  * bit 1 (default 0): their data gradients on the fp32 direct kernel; bit 2 (default 0): 1 = take their data gradients OFF the
  * split-bf16 direct kernel (default path, 121 vs 227 us) back to the implicit GEMM; bits 4-5: timing ablations */
 void ha2g_conv_debug_direct_c32(int on);

@@ -19,3 +19,4 @@ xz = torch.zeros_like(x)
 lib.ha2g_conv_debug_direct_c32(1)
 print('zeros input', '%.0f us' % timeit(lambda: we.conv_fwd(xz, w, None, 1, 1, 0)))
 lib.ha2g_conv_debug_direct_c32(0)
+print('implicit GEMM', '%.0f us' % timeit(lambda: we.conv_fwd(x, w, None, 1, 1, 0)))
