@@ -52,8 +52,12 @@ __global__ __launch_bounds__(256) void stem_wgrad_partial_kernel(const float* __
     float acc[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+    // pixel coordinates advance incrementally (the 64-bit divisions of pix were most of this kernel's instructions); unrolled so that the
+    // next pixels' dy / x loads are issued before this pixel's FMAs retire.  The accumulation order over pixels is unchanged.
+    int ox, oy; long n;
+    { const long p0 = pbeg + pl; ox = (int)(p0 % W); const long t = p0 / W; oy = (int)(t % H); n = t / H; }
+#pragma unroll 4
     for (long pix = pbeg + pl; pix < pend; pix += 8) {
-        const int ox = (int)(pix % W); long t = pix / W; const int oy = (int)(t % H); const long n = t / H;
         const float d = dy[pix * SC + co];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
@@ -64,6 +68,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_partial_kernel(const float* __
                 acc[kh * 3 + kw] += d * xv;
             }
         acc[9] += d;
+        ox += 8;
+        while (ox >= W) { ox -= W; if (++oy == H) { oy = 0; ++n; } }
     }
 #pragma unroll
     for (int k = 0; k < 10; ++k) red[pl][co][k] = acc[k];
@@ -80,7 +86,15 @@ __global__ void stem_wgrad_final_kernel(const float* __restrict__ part, int nblk
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= SC * 10) return;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += part[(long)b * SC * 10 + e];
+    int b = 0;
+    for (; b + 7 < nblk; b += 8) {                     // eight partials in flight, added in block order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = part[(long)(b + j) * SC * 10 + e];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; b < nblk; ++b) s += part[(long)b * SC * 10 + e];
     int c = e / 10, k = e % 10;
     if (k < 9) dw[c * 9 + k] = (beta != 0.f ? beta * dw[c * 9 + k] : 0.f) + (float)s;
     else db[c] = (beta != 0.f ? beta * db[c] : 0.f) + (float)s;

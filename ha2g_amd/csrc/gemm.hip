@@ -664,6 +664,22 @@ static int g_x3 = 0;      // split-bf16 core: OPT-IN (ha2g_gemm_set_mode(1)).  I
 static int g_wgrad_blocks = 0;      // 0 = per-shape default (see ha2g_conv2d_wgrad_workspace_bytes); else forced target
 static int g_split_tiles = 192;   // swept on the full step: <=100 is 5-30 % slower, >=192 flat
 
+// sum of p[z * stride] for z = z0, z0 + step, ... < n, accumulated in double IN THAT ORDER; eight loads are issued before the first add (the
+// plain loop compiles to load -> s_waitcnt vmcnt(0) -> add per partial: one full memory latency per split)
+__device__ __forceinline__ double ordered_sum(const float* __restrict__ p, long stride, int z0, int n, int step) {
+    double sd = 0.0;
+    int z = z0;
+    for (; z + 7 * step < n; z += 8 * step) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[(long)(z + j * step) * stride];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sd += (double)v[j];
+    }
+    for (; z < n; z += step) sd += (double)p[(long)z * stride];
+    return sd;
+}
+
 __global__ void splitk_reduce_kernel(const float* ws, int splits, long MN, int N, float* C, long ldc, float alpha,
                                      float beta, const float* bias, int act, float* csum, float csum_beta, int M) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -671,13 +687,11 @@ __global__ void splitk_reduce_kernel(const float* ws, int splits, long MN, int N
         const long m = i - MN;
         if (csum == nullptr || m >= M) return;
         const float* wb = ws + (long)splits * MN;
-        double sd = 0.0;
-        for (int z = 0; z < splits; ++z) sd += (double)wb[(long)z * M + m];
+        const double sd = ordered_sum(wb + m, M, 0, splits, 1);
         csum[m] = (csum_beta != 0.f ? csum_beta * csum[m] : 0.f) + (float)sd;
         return;
     }
-    double sd = 0.0;
-    for (int z = 0; z < splits; ++z) sd += (double)ws[(long)z * MN + i];
+    const double sd = ordered_sum(ws + i, MN, 0, splits, 1);
     const float s = (float)sd;
     int col = (int)(i % N);
     long row = i / N;
@@ -700,8 +714,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* ws
     const long cnt = tail ? M : MN;
     const float* src = tail ? ws + (long)splits * MN : ws;
     double sd = 0.0;
-    if (i < cnt)
-        for (int z = w; z < splits; z += 4) sd += (double)src[(long)z * cnt + i];
+    if (i < cnt) sd = ordered_sum(src + i, cnt, w, splits, 4);
     part[w][lane] = sd;
     __syncthreads();
     if (w != 0 || i >= cnt) return;

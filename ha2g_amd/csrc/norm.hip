@@ -55,18 +55,35 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
     float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), is4 = k4;
     if (MODE == 0) k4 = reinterpret_cast<const float4*>(x)[m.c4];
     else { k4 = reinterpret_cast<const float4*>(mean)[m.c4]; is4 = reinterpret_cast<const float4*>(invstd)[m.c4]; }
-    for (long r = rbeg + m.r0; r < rend; r += m.rstep) {
-        float4 v = reinterpret_cast<const float4*>(x + r * C)[m.c4];
+    // four rows per trip: the loads are issued together (one row per trip is load -> wait -> add, a single 16-byte request in flight per
+    // wave: ~2.7 TB/s measured), the adds keep the row order, so the sums are bit-identical to the one-row loop's
+    auto accum = [&](const float4& v, const float4& d) {
         if (MODE == 0) {
             double vx = (double)v.x - k4.x, vy = (double)v.y - k4.y, vz = (double)v.z - k4.z, vw = (double)v.w - k4.w;
             a.x += vx; a.y += vy; a.z += vz; a.w += vw;
             b.x += vx * vx; b.y += vy * vy; b.z += vz * vz; b.w += vw * vw;
         } else {
-            float4 d = reinterpret_cast<const float4*>(dy + r * C)[m.c4];
             a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
             b.x += (double)d.x * (((double)v.x - k4.x) * is4.x); b.y += (double)d.y * (((double)v.y - k4.y) * is4.y);
             b.z += (double)d.z * (((double)v.z - k4.z) * is4.z); b.w += (double)d.w * (((double)v.w - k4.w) * is4.w);
         }
+    };
+    long r = rbeg + m.r0;
+    for (; r + 3 * m.rstep < rend; r += 4 * m.rstep) {
+        float4 v[4], d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = reinterpret_cast<const float4*>(x + (r + (long)j * m.rstep) * C)[m.c4];
+            d[j] = v[j];
+            if (MODE == 1) d[j] = reinterpret_cast<const float4*>(dy + (r + (long)j * m.rstep) * C)[m.c4];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accum(v[j], d[j]);
+    }
+    for (; r < rend; r += m.rstep) {
+        float4 v = reinterpret_cast<const float4*>(x + r * C)[m.c4], d = v;
+        if (MODE == 1) d = reinterpret_cast<const float4*>(dy + r * C)[m.c4];
+        accum(v, d);
     }
     block_col_reduce(a, b, C4, part, C, lds);
 }
@@ -84,7 +101,17 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __res
     const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = lane; b < nblk; b += 64) { s1 += part[((long)b * 2) * C + c]; s2 += part[((long)b * 2 + 1) * C + c]; }
+    {   // partials in fixed order, four pairs of loads per trip in flight
+        int b = lane;
+        for (; b + 192 < nblk; b += 256) {
+            double p1[4], p2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { p1[j] = part[((long)(b + 64 * j) * 2) * C + c]; p2[j] = part[((long)(b + 64 * j) * 2 + 1) * C + c]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1 += p1[j]; s2 += p2[j]; }
+        }
+        for (; b < nblk; b += 64) { s1 += part[((long)b * 2) * C + c]; s2 += part[((long)b * 2 + 1) * C + c]; }
+    }
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
     if (lane != 0) return;
     double n = (double)rows, m1 = s1 / n;
@@ -104,7 +131,17 @@ __global__ __launch_bounds__(256) void pair_final_kernel(const double* __restric
     const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = lane; b < nblk; b += 64) { s1 += part[((long)b * 2) * C + c]; s2 += part[((long)b * 2 + 1) * C + c]; }
+    {   // partials in fixed order, four pairs of loads per trip in flight
+        int b = lane;
+        for (; b + 192 < nblk; b += 256) {
+            double p1[4], p2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { p1[j] = part[((long)(b + 64 * j) * 2) * C + c]; p2[j] = part[((long)(b + 64 * j) * 2 + 1) * C + c]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1 += p1[j]; s2 += p2[j]; }
+        }
+        for (; b < nblk; b += 64) { s1 += part[((long)b * 2) * C + c]; s2 += part[((long)b * 2 + 1) * C + c]; }
+    }
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
     if (lane == 0) {
         out0[c] = (float)s1; out1[c] = (float)s2;
@@ -154,14 +191,22 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restr
     const float4 mu = reinterpret_cast<const float4*>(mean)[m.c4], is = reinterpret_cast<const float4*>(invstd)[m.c4];
     const float4 g = reinterpret_cast<const float4*>(gamma)[m.c4], b = reinterpret_cast<const float4*>(beta)[m.c4];
     d4 a = d4zero();
-    for (int r = rbeg + m.r0; r < rend; r += m.rstep) {
-        const float4 v = reinterpret_cast<const float4*>(x + base + (long)r * C)[m.c4];
+    auto row = [&](const float4& v, int r) {
         float4 o;
         o.x = (v.x - mu.x) * is.x * g.x + b.x; o.y = (v.y - mu.y) * is.y * g.y + b.y;
         o.z = (v.z - mu.z) * is.z * g.z + b.z; o.w = (v.w - mu.w) * is.w * g.w + b.w;
         reinterpret_cast<float4*>(y + base + (long)r * C)[m.c4] = o;
         a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+    };
+    int r = rbeg + m.r0;
+    for (; r + 3 * m.rstep < rend; r += 4 * m.rstep) {           // four loads in flight per wave, rows consumed in order
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = reinterpret_cast<const float4*>(x + base + (long)(r + j * m.rstep) * C)[m.c4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) row(v[j], r + j * m.rstep);
     }
+    for (; r < rend; r += m.rstep) row(reinterpret_cast<const float4*>(x + base + (long)r * C)[m.c4], r);
     lds[threadIdx.x] = a;
     __syncthreads();
     if (threadIdx.x < C4) {
@@ -218,16 +263,34 @@ __global__ __launch_bounds__(256) void image_col_kernel(const float* __restrict_
     ColMap m(C4);
     const long base = (long)blockIdx.x * HW * C;
     d4 a = d4zero();
-    for (int r = m.r0; r < HW; r += m.rstep) {
-        float4 v = reinterpret_cast<const float4*>(x + base + (long)r * C)[m.c4];
+    // one block per image: four rows per trip so that 4 (MODE 0) / 12 (MODE 1) 16-byte loads are in flight per wave; the adds keep the row
+    // order of the one-row loop (bit-identical sums)
+    auto accum = [&](const float4& v, const float4& d, const float4& o) {
         if (MODE == 1) {
-            float4 d = reinterpret_cast<const float4*>(dout + base + (long)r * C)[m.c4];
-            float4 o = reinterpret_cast<const float4*>(outp + base + (long)r * C)[m.c4];
             a.x += o.x > 0.f ? (double)v.x * d.x : 0.0; a.y += o.y > 0.f ? (double)v.y * d.y : 0.0;
             a.z += o.z > 0.f ? (double)v.z * d.z : 0.0; a.w += o.w > 0.f ? (double)v.w * d.w : 0.0;
         } else {
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
+    };
+    int r = m.r0;
+    for (; r + 3 * m.rstep < HW; r += 4 * m.rstep) {
+        float4 v[4], d[4], o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long off = base + (long)(r + j * m.rstep) * C;
+            v[j] = reinterpret_cast<const float4*>(x + off)[m.c4];
+            d[j] = v[j]; o[j] = v[j];
+            if (MODE == 1) { d[j] = reinterpret_cast<const float4*>(dout + off)[m.c4]; o[j] = reinterpret_cast<const float4*>(outp + off)[m.c4]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accum(v[j], d[j], o[j]);
+    }
+    for (; r < HW; r += m.rstep) {
+        const long off = base + (long)r * C;
+        float4 v = reinterpret_cast<const float4*>(x + off)[m.c4], d = v, o = v;
+        if (MODE == 1) { d = reinterpret_cast<const float4*>(dout + off)[m.c4]; o = reinterpret_cast<const float4*>(outp + off)[m.c4]; }
+        accum(v, d, o);
     }
     lds[threadIdx.x] = a;
     __syncthreads();
