@@ -257,11 +257,15 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
 template <int MODE>
 __global__ __launch_bounds__(256) void image_col_kernel(const float* __restrict__ x, const float* __restrict__ dout,
                                                         const float* __restrict__ outp, int HW, int C, float* __restrict__ res,
-                                                        float scale) {
+                                                        float scale, double* __restrict__ part) {
+    // grid (nchunk, N): block (k, n) sums rows [k*per, (k+1)*per) of image n; part == nullptr (nchunk = 1): final floats to res, else
+    // double partials [n][k][C] for pool_final_kernel (more blocks than images: a 128-image batch alone fills half the CUs)
     __shared__ d4 lds[256];
     const int C4 = C >> 2;
     ColMap m(C4);
-    const long base = (long)blockIdx.x * HW * C;
+    const int nchunk = gridDim.x, per = (HW + nchunk - 1) / nchunk;
+    const int rbeg = blockIdx.x * per, rend = min(HW, rbeg + per);
+    const long base = (long)blockIdx.y * HW * C;
     d4 a = d4zero();
     // one block per image: four rows per trip so that 4 (MODE 0) / 12 (MODE 1) 16-byte loads are in flight per wave; the adds keep the row
     // order of the one-row loop (bit-identical sums)
@@ -273,8 +277,8 @@ __global__ __launch_bounds__(256) void image_col_kernel(const float* __restrict_
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
     };
-    int r = m.r0;
-    for (; r + 3 * m.rstep < HW; r += 4 * m.rstep) {
+    int r = rbeg + m.r0;
+    for (; r + 3 * m.rstep < rend; r += 4 * m.rstep) {
         float4 v[4], d[4], o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256) void image_col_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) accum(v[j], d[j], o[j]);
     }
-    for (; r < HW; r += m.rstep) {
+    for (; r < rend; r += m.rstep) {
         const long off = base + (long)r * C;
         float4 v = reinterpret_cast<const float4*>(x + off)[m.c4], d = v, o = v;
         if (MODE == 1) { d = reinterpret_cast<const float4*>(dout + off)[m.c4]; o = reinterpret_cast<const float4*>(outp + off)[m.c4]; }
@@ -297,8 +301,13 @@ __global__ __launch_bounds__(256) void image_col_kernel(const float* __restrict_
     if (threadIdx.x < C4) {
         d4 s = d4zero();
         for (int t = threadIdx.x; t < 256; t += C4) { d4 v = lds[t]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-        float4 o = make_float4((float)(s.x * scale), (float)(s.y * scale), (float)(s.z * scale), (float)(s.w * scale));
-        reinterpret_cast<float4*>(res + (long)blockIdx.x * C)[threadIdx.x] = o;
+        if (part) {
+            double* p = part + ((long)blockIdx.y * nchunk + blockIdx.x) * C + threadIdx.x * 4;
+            p[0] = s.x; p[1] = s.y; p[2] = s.z; p[3] = s.w;
+        } else {
+            float4 o = make_float4((float)(s.x * scale), (float)(s.y * scale), (float)(s.z * scale), (float)(s.w * scale));
+            reinterpret_cast<float4*>(res + (long)blockIdx.y * C)[threadIdx.x] = o;
+        }
     }
 }
 
@@ -412,7 +421,7 @@ int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const fl
 // out[n][c] = mean over HW of x[n][hw][c]
 int ha2g_hw_mean_f32(const float* x, float* out, int N, int HW, int C, void* stream) {
     HA2G_REQUIRE(okC(C), "hw_mean: unsupported channel count %d", C);
-    hipLaunchKernelGGL(image_col_kernel<0>, dim3(N), dim3(256), 0, (hipStream_t)stream, x, nullptr, nullptr, HW, C, out, 1.f / (float)HW);
+    hipLaunchKernelGGL(image_col_kernel<0>, dim3(1, N), dim3(256), 0, (hipStream_t)stream, x, nullptr, nullptr, HW, C, out, 1.f / (float)HW, nullptr);
     HA2G_CHECK_LAUNCH("hw_mean");
     return 0;
 }
@@ -424,9 +433,16 @@ int ha2g_se_scale_add_relu_f32(const float* x, const float* s, const float* res,
     return 0;
 }
 // ds[n][c] = sum_hw dout*(out>0)*x
-int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, float* ds, int N, int HW, int C, void* stream) {
+int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, float* ds, int N, int HW, int C, float* ws, void* stream) {
     HA2G_REQUIRE(okC(C), "se: unsupported channel count %d", C);
-    hipLaunchKernelGGL(image_col_kernel<1>, dim3(N), dim3(256), 0, (hipStream_t)stream, x, dout, out, HW, C, ds, 1.f);
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = ws ? pool_chunks(N, HW) : 1;          // ws: ha2g_bn_apply_pool_workspace_floats(N, HW, C) floats, or null
+    if (nchunk > 1) {
+        hipLaunchKernelGGL(image_col_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, ds, 1.f, (double*)ws);
+        hipLaunchKernelGGL(pool_final_kernel, dim3(ceil_div((long)N * C, 256)), dim3(256), 0, st, (const double*)ws, nchunk, C, (long)N * C, 1.f, ds);
+    } else {
+        hipLaunchKernelGGL(image_col_kernel<1>, dim3(1, N), dim3(256), 0, st, x, dout, out, HW, C, ds, 1.f, nullptr);
+    }
     HA2G_CHECK_LAUNCH("se_bwd_scale");
     return 0;
 }

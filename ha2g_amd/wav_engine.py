@@ -217,7 +217,7 @@ def block_bwd(dx, saved, P, b, sink):
     HW = OH * OW
     dout = dx.contiguous()
     ds = empty(N, C, like=b2)
-    check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, _stream()))
+    check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, ops.workspace(dout.device).data_ptr(), _stream()))
     dsc = ops.eltwise(ops.OP_SIGMOID_BWD_PRE, ds, su)
     sink.gw(b + 'se.fc.2.weight', dsc, h1)
     sink.gb(b + 'se.fc.2.bias', dsc)
