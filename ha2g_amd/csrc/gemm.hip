@@ -661,6 +661,7 @@ static int g_x3 = 0;      // split-bf16 core: OPT-IN (ha2g_gemm_set_mode(1)).  I
                           // with >= 64 channels but ~10x noisier than the fp32 MFMA chain (4e-6 vs 4e-7 rms-rel per GEMM), which the
                           // reference-derived parity tolerances of the deep audio encoder do not absorb -> exact fp32 is the default.
 
+static int g_wgrad_wide = 1;        // Cout <= 32 weight gradients: one 32 x 384 tile spans all 9*Cin columns (dy tile staged once instead of 3 times)
 static int g_wgrad_blocks = 0;      // 0 = per-shape default (see ha2g_conv2d_wgrad_workspace_bytes); else forced target
 static int g_split_tiles = 192;   // swept on the full step: <=100 is 5-30 % slower, >=192 flat
 
@@ -930,7 +931,7 @@ void ha2g_gemm_set_mode(int mode) { g_x3 = mode & 1; g_split_wgrad = (mode >> 1)
 void ha2g_gemm_debug_x6_min_n(int n) { g_x6_min_n = n; }
 void ha2g_gemm_debug_tile(int cfg, int splits) { g_tile_model = cfg != -2; g_tile_force = cfg == -2 ? -1 : cfg; g_splits_force = splits; }
 void ha2g_conv_debug_direct_c32(int on) { g_direct_c32 = on & 1; g_direct_c32_dgrad = (on >> 1) & 1; g_direct_c32_x3 = !((on >> 2) & 1); g_c32_dbg = on & 0x30; }
-void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 10000) g_wgrad_blocks = cfg - 10000; else if (cfg >= 1000) g_split_tiles = cfg - 1000; else g_conv_cfg = cfg; }   /* 1000+n: split-K tile threshold n; 10000+n: wgrad block target n */
+void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 20000) g_wgrad_wide = cfg - 20000; else if (cfg >= 10000) g_wgrad_blocks = cfg - 10000; else if (cfg >= 1000) g_split_tiles = cfg - 1000; else g_conv_cfg = cfg; }   /* 1000+n: split-K tile threshold n; 10000+n: wgrad block target n */
 
 // Dense GEMM, row-major.  transa/transb follow BLAS meaning on row-major storage:
 //   transa = 0: A is [M,K] (lda >= K);  1: A is stored [K,M] (lda >= M)
@@ -1028,10 +1029,11 @@ long ha2g_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, i
     int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     long K = (long)N * OH * OW, MN = (long)Cout * KH * KW * Cin;
     int BM = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
-    long tiles = (long)ceil_div(Cout, BM) * ceil_div(KH * KW * Cin, 128);
+    const bool wide = g_wgrad_wide && Cout <= 32 && KH * KW * Cin <= 384;
+    long tiles = (long)ceil_div(Cout, BM) * ceil_div(KH * KW * Cin, wide ? 384 : 128);
     // target workgroups per launch, swept with the split-bf16 inner product (tools/wgrad_sweep.py): many small chunks for the
     // 32-channel layer (huge K, tiny output), fewer for the wide layers whose partial tiles are large
-    const long target = g_wgrad_blocks > 0 ? g_wgrad_blocks : (Cout <= 32 ? 1536 : (Cout <= 64 ? 1024 : 768));
+    const long target = g_wgrad_blocks > 0 ? g_wgrad_blocks : (wide ? 512 : (Cout <= 32 ? 1536 : (Cout <= 64 ? 1024 : 768)));
     long splits = (target + tiles - 1) / tiles;
     if (splits > K / 256) splits = K / 256;
     if (splits < 1) splits = 1;
@@ -1054,6 +1056,7 @@ int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int
     kc = ceil_div(kc, 32) * 32;
     p.kchunk = kc; p.splits = ceil_div(p.K, kc); p.ws = ws;
     hipStream_t st = (hipStream_t)stream;
+    if (g_wgrad_wide && Cout <= 32 && p.N <= 384) return launch<1, 3, 1, 4, A_MC, B_IM, true>(p, st);
     if (Cout <= 32) return launch<1, 1, 1, 4, A_MC, B_IM, true>(p, st);
     if (Cout <= 64) return launch<2, 1, 1, 4, A_MC, B_IM, true>(p, st);
     return launch<2, 2, 2, 2, A_MC, B_IM, true>(p, st);
