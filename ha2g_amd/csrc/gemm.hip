@@ -45,6 +45,10 @@ struct GemmP {
     // A_MC (weight-gradient shape, A = dY stored [K][M]) only: csum[m] = csum_beta * csum[m] + sum_k A[k][m] -- the bias gradient of the
     // layer from the dY tiles this launch stages anyway.  Partials of a split-K launch go to ws + splits*M*N as [splits][M].
     float* csum; float csum_beta;
+    // Grouped launch (gemm_kernel only): `groups` independent problems of one shape, group = blockIdx.z / splits.  Per-group base pointers
+    // (stacked operands: base + g * stride, or separate tensors); split-K slabs [group][split][M][N], then the bias partials [group][split][M].
+    int groups;
+    const float* Ag[8]; const float* Bg[8]; float* Cg[8]; const float* biasg[8]; float* csumg[8];
 };
 
 
@@ -164,7 +168,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int kbeg = blockIdx.z * p.kchunk;
+    // grouped launch: this block's problem and split; gA .. gcsum are that problem's operands (plain launch: group 0 = the GemmP fields)
+    const bool grouped = p.groups > 1;
+    const int grp = grouped ? (int)blockIdx.z / p.splits : 0;
+    const int zsp = grouped ? (int)blockIdx.z - grp * p.splits : (int)blockIdx.z;
+    const float* __restrict__ gA = grouped ? p.Ag[grp] : p.A;
+    const float* __restrict__ gB = grouped ? p.Bg[grp] : p.B;
+    float* __restrict__ gC = grouped ? p.Cg[grp] : p.C;
+    const float* __restrict__ gbias = grouped ? p.biasg[grp] : p.bias;
+    float* __restrict__ gcsum = grouped ? p.csumg[grp] : p.csum;
+    const long gMN = (long)p.M * p.N;
+    float* gws = p.ws + (long)grp * p.splits * gMN;                                                      // this group's slabs
+    float* gwsb = p.ws + (long)(grouped ? p.groups : 1) * p.splits * gMN + (long)grp * p.splits * p.M;    // its bias partials
+    const int kbeg = zsp * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int nk = (kend - kbeg + BKT - 1) / BKT;
     const ConvGeom g = p.g;
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
     float4 ra[NA], rb[NB];
     float4 bsum[NA];                          // A_MC + p.csum: this thread's column sums of the A tiles (k rows a_r + 16 j)
-    const bool csum_on = AMODE == A_MC && p.csum != nullptr && blockIdx.y == 0;
+    const bool csum_on = AMODE == A_MC && gcsum != nullptr && blockIdx.y == 0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -226,7 +242,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((a_im[i].mask & bit) && k0 + a_c[i] < kend) v = *reinterpret_cast<const float4*>(p.A + (a_im[i].base + koff));
+                if ((a_im[i].mask & bit) && k0 + a_c[i] < kend) v = *reinterpret_cast<const float4*>(gA + (a_im[i].base + koff));
                 ra[i] = v;
             }
             a_cur.advance(g, BKT);
@@ -235,14 +251,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
             for (int i = 0; i < NA; ++i) {
                 int m = m0 + a_r[i], k = k0 + a_c[i];
                 int valid = (a_on[i] && m < p.M) ? (kend - k) : 0;
-                ra[i] = ld4_guard<VEC>(p.A + (long)m * p.lda + k, valid);
+                ra[i] = ld4_guard<VEC>(gA + (long)m * p.lda + k, valid);
             }
         } else {   // A_MC
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 int k = k0 + a_r[i], m = m0 + a_c[i];
                 int valid = (a_on[i] && k < kend) ? (p.M - m) : 0;
-                ra[i] = ld4_guard<VEC>(p.A + (long)k * p.lda + m, valid);
+                ra[i] = ld4_guard<VEC>(gA + (long)k * p.lda + m, valid);
             }
         }
         // ---- B ----
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 if (b_on[i] && pix < kend) {
                     int iy = b_oy[i] * g.stride - g.pad + b_kh[i], ix = b_ox[i] * g.stride - g.pad + b_kw[i];
                     if (iy >= 0 && iy < g.GH && ix >= 0 && ix < g.GW)
-                        v = *reinterpret_cast<const float4*>(p.B + (((long)b_img[i] * g.GH + iy) * g.GW + ix) * g.GC + b_ci[i]);
+                        v = *reinterpret_cast<const float4*>(gB + (((long)b_img[i] * g.GH + iy) * g.GW + ix) * g.GC + b_ci[i]);
                 }
                 rb[i] = v;
                 // advance this slot's pixel by one tile depth (tiles are visited in order): no div/mod in the loop
@@ -266,14 +282,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
             for (int i = 0; i < NB; ++i) {
                 int n = n0 + b_r[i], k = k0 + b_c[i];
                 int valid = (b_on[i] && n < p.N) ? (kend - k) : 0;
-                rb[i] = ld4_guard<VEC>(p.B + (long)n * p.ldb + k, valid);
+                rb[i] = ld4_guard<VEC>(gB + (long)n * p.ldb + k, valid);
             }
         } else {   // B_NC
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 int k = k0 + b_r[i], n = n0 + b_c[i];
                 int valid = (b_on[i] && k < kend) ? (p.N - n) : 0;
-                rb[i] = ld4_guard<VEC>(p.B + (long)k * p.ldb + n, valid);
+                rb[i] = ld4_guard<VEC>(gB + (long)k * p.ldb + n, valid);
             }
         }
     };
@@ -389,7 +405,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
     // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
     const bool partial = p.splits > 1;
-    float* out = partial ? p.ws + (long)blockIdx.z * p.M * p.N : p.C;
+    float* out = partial ? gws + (long)zsp * gMN : gC;
     const long ldo = partial ? p.N : p.ldc;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -397,7 +413,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         for (int j = 0; j < NI; ++j) {
             const int col = n0 + wn * (32 * NI) + j * 32 + l31;
             if (col >= p.N) continue;
-            const float bv = (!partial && p.bias) ? p.bias[col] : 0.f;
+            const float bv = (!partial && gbias) ? gbias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -423,8 +439,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 float t = 0.f;
 #pragma unroll
                 for (int r = 0; r < BKT; ++r) t += red[r * BM + tid];
-                if (partial) p.ws[(long)p.splits * p.M * p.N + (long)blockIdx.z * p.M + m0 + tid] = t;
-                else p.csum[m0 + tid] = (p.csum_beta != 0.f ? p.csum_beta * p.csum[m0 + tid] : 0.f) + t;
+                if (partial) gwsb[(long)zsp * p.M + m0 + tid] = t;
+                else gcsum[m0 + tid] = (p.csum_beta != 0.f ? p.csum_beta * gcsum[m0 + tid] : 0.f) + t;
             }
         }
     }
@@ -681,18 +697,24 @@ __device__ __forceinline__ double ordered_sum(const float* __restrict__ p, long 
     return sd;
 }
 
-__global__ void splitk_reduce_kernel(const float* ws, int splits, long MN, int N, float* C, long ldc, float alpha,
-                                     float beta, const float* bias, int act, float* csum, float csum_beta, int M) {
+// per-group outputs of a (possibly grouped, grid.y = group) reduce launch
+struct ReduceOut { float* C[8]; const float* bias[8]; float* csum[8]; int groups; };
+
+__global__ void splitk_reduce_kernel(const float* ws, int splits, long MN, int N, ReduceOut ro, long ldc, float alpha,
+                                     float beta, int act, float csum_beta, int M) {
+    const int grp = blockIdx.y;
+    float* C = ro.C[grp]; const float* bias = ro.bias[grp]; float* csum = ro.csum[grp];
+    const float* wg = ws + (long)grp * splits * MN;
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= MN) {                                        // the fused bias gradient's partials: [splits][M] behind the slabs
+    if (i >= MN) {                                        // the fused bias gradient's partials: [group][splits][M] behind the slabs
         const long m = i - MN;
         if (csum == nullptr || m >= M) return;
-        const float* wb = ws + (long)splits * MN;
+        const float* wb = ws + (long)ro.groups * splits * MN + (long)grp * splits * M;
         const double sd = ordered_sum(wb + m, M, 0, splits, 1);
         csum[m] = (csum_beta != 0.f ? csum_beta * csum[m] : 0.f) + (float)sd;
         return;
     }
-    const double sd = ordered_sum(ws + i, MN, 0, splits, 1);
+    const double sd = ordered_sum(wg + i, MN, 0, splits, 1);
     const float s = (float)sd;
     int col = (int)(i % N);
     long row = i / N;
@@ -704,16 +726,17 @@ __global__ void splitk_reduce_kernel(const float* ws, int splits, long MN, int N
 
 // Many splits over a small output (weight gradients of the 32/64-channel convolutions: up to ~340 partials of 9-37 k
 // floats): one block per 64 outputs, its 4 waves stride the partials, fixed-order LDS combine (deterministic).
-__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* ws, int splits, long MN, int N, float* C, long ldc,
-                                                                 float alpha, float beta, const float* bias, int act, float* csum,
-                                                                 float csum_beta, int M) {
+__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* ws, int splits, long MN, int N, ReduceOut ro, long ldc,
+                                                                 float alpha, float beta, int act, float csum_beta, int M) {
     __shared__ double part[4][64];
+    const int grp = blockIdx.y;
+    float* C = ro.C[grp]; const float* bias = ro.bias[grp]; float* csum = ro.csum[grp];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long nmain = (MN + 63) / 64;                    // blocks past the output tiles reduce the fused bias gradient's partials
     const bool tail = blockIdx.x >= nmain;
     const long i = tail ? (long)(blockIdx.x - nmain) * 64 + lane : (long)blockIdx.x * 64 + lane;
     const long cnt = tail ? M : MN;
-    const float* src = tail ? ws + (long)splits * MN : ws;
+    const float* src = tail ? ws + (long)ro.groups * splits * MN + (long)grp * splits * M : ws + (long)grp * splits * MN;
     double sd = 0.0;
     if (i < cnt) sd = ordered_sum(src + i, cnt, w, splits, 4);
     part[w][lane] = sd;
@@ -732,12 +755,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* ws
 template <int MI, int NI, int WM, int WN, int AMODE, int BMODE, bool VEC>
 int launch(const GemmP& p, hipStream_t st) {
     constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
-    dim3 grid(ceil_div(p.M, BM), ceil_div(p.N, BN), p.splits);
+    const int groups = p.groups > 1 ? p.groups : 1;
+    dim3 grid(ceil_div(p.M, BM), ceil_div(p.N, BN), p.splits * groups);
     // tile depth BKT = 16.  (BKT = 32 was measured 5-20 % slower on MI355X: fewer resident blocks per CU, more staging
     // registers; the template parameter stays for future tuning.)
     constexpr bool X3_SHAPE = (AMODE == A_KC || AMODE == A_IM) && BMODE == B_KC && VEC;
     bool use_x3 = false;
-    if constexpr (X3_SHAPE) {
+    if constexpr (X3_SHAPE) if (groups == 1) {
         const bool bwd = AMODE == A_IM && p.g.transposed;       // conv data gradient: handled by the split-bf16 inner product below
         // two-piece planes (b128 fragment reads): opt-in for forward work, DEFAULT for the conv data gradient (1.4x faster there
         // than the packed-word inner product below, same 3-MFMA arithmetic)
@@ -772,13 +796,20 @@ int launch(const GemmP& p, hipStream_t st) {
     HA2G_CHECK_LAUNCH("gemm");
     if (p.splits > 1) {
         long MN = (long)p.M * p.N;
-        float* cs = AMODE == A_MC ? p.csum : nullptr;
+        ReduceOut ro{};
+        ro.groups = groups;
+        bool cs = false;
+        for (int g = 0; g < groups; ++g) {
+            ro.C[g] = groups > 1 ? p.Cg[g] : p.C; ro.bias[g] = groups > 1 ? p.biasg[g] : p.bias;
+            ro.csum[g] = AMODE == A_MC ? (groups > 1 ? p.csumg[g] : p.csum) : nullptr;
+            cs = cs || ro.csum[g] != nullptr;
+        }
         if (p.splits >= 16 && MN <= (1 << 20))
-            hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(ceil_div(MN, 64) + (cs ? ceil_div(p.M, 64) : 0)), dim3(256), 0, st, p.ws, p.splits,
-                               MN, p.N, p.C, p.ldc, p.alpha, p.beta, p.bias, p.act, cs, p.csum_beta, p.M);
+            hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(ceil_div(MN, 64) + (cs ? ceil_div(p.M, 64) : 0), groups), dim3(256), 0, st, p.ws,
+                               p.splits, MN, p.N, ro, p.ldc, p.alpha, p.beta, p.act, p.csum_beta, p.M);
         else
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(MN + (cs ? p.M : 0), 256)), dim3(256), 0, st, p.ws, p.splits, MN, p.N, p.C,
-                               p.ldc, p.alpha, p.beta, p.bias, p.act, cs, p.csum_beta, p.M);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(MN + (cs ? p.M : 0), 256), groups), dim3(256), 0, st, p.ws, p.splits, MN, p.N,
+                               ro, p.ldc, p.alpha, p.beta, p.act, p.csum_beta, p.M);
         HA2G_CHECK_LAUNCH("splitk_reduce");
     }
     return 0;
@@ -800,17 +831,17 @@ static int cu_count() {
 }
 
 // Pick split-K so that a launch has enough workgroups to fill the CUs; returns splits and sets kchunk.
-int choose_splits(int M, int N, int K, int BM, int BN, long ws_floats, int* kchunk) {
+int choose_splits(int M, int N, int K, int BM, int BN, long ws_floats, int* kchunk, int groups = 1) {
     // Split K when the tile grid cannot fill the 256 CUs a couple of times over (measured on the whole train step:
     // splitting below 192 tiles is worth 5-30 % of the step; the workspace round trip + reduce launch is cheap).
-    long tiles = (long)ceil_div(M, BM) * ceil_div(N, BN);
+    long tiles = (long)ceil_div(M, BM) * ceil_div(N, BN) * groups;
     int splits = 1;
     if (tiles < g_split_tiles && K >= 512) {
         splits = (int)((512 + tiles - 1) / tiles);
         int maxs = K / 128;
         if (splits > maxs) splits = maxs;
         if (splits < 1) splits = 1;
-        while (splits > 1 && (long)splits * M * (N + 1) > ws_floats) --splits;
+        while (splits > 1 && (long)groups * splits * M * (N + 1) > ws_floats) --splits;
     }
     int kc = ceil_div(K, splits);
     kc = ceil_div(kc, 32) * 32;
@@ -840,20 +871,21 @@ int dispatch_tile(GemmP& p, long ws_floats, hipStream_t st) {
     // so small grids are scored as balanced).  It still fixes the split-K count.
     int best = 0; double bs = -1.0;
     const int ncu = cu_count();
+    const int groups = p.groups > 1 ? p.groups : 1;          // a grouped launch fills the chip with groups x tiles workgroups
     for (int c = 0; c < 5; ++c) {
-        long tm = ceil_div(p.M, kTileBM[c]), tn = ceil_div(p.N, kTileBN[c]), tiles = tm * tn;
-        double useful = ((double)p.M * p.N) / ((double)tiles * kTileBM[c] * kTileBN[c]);
+        long tm = ceil_div(p.M, kTileBM[c]), tn = ceil_div(p.N, kTileBN[c]), tiles = tm * tn * groups;
+        double useful = ((double)p.M * p.N * groups) / ((double)tiles * kTileBM[c] * kTileBN[c]);
         double balance = tiles >= g_split_tiles ? ((double)tiles / ncu) / (double)((tiles + ncu - 1) / ncu) : 0.95;
         double score = kTileEff[c] * useful * balance;
         if (score > bs) { bs = score; best = c; }
     }
-    p.splits = choose_splits(p.M, p.N, p.K, kTileBM[best], kTileBN[best], ws_floats, &p.kchunk);
+    p.splits = choose_splits(p.M, p.N, p.K, kTileBM[best], kTileBN[best], ws_floats, &p.kchunk, groups);
     constexpr int NC = VEC ? 9 : 5;
     if (VEC && AMODE == A_KC && g_tile_model && !g_bf16 && !g_x3 && !g_x6 && !g_x6_dense) {
         const TileModel& m = (BMODE == B_NC && g_split_dgrad && p.kchunk >= 64) ? kModelSplit : kModelF32;
         double bt = 1e300;
         for (int c = 0; c < NC; ++c) {
-            long tiles = (long)ceil_div(p.M, kTileBM[c]) * ceil_div(p.N, kTileBN[c]);
+            long tiles = (long)ceil_div(p.M, kTileBM[c]) * ceil_div(p.N, kTileBN[c]) * groups;
             long load = (tiles * p.splits + ncu - 1) / ncu;
             const bool big = kTileBM[c] * kTileBN[c] >= 128 * 96;
             double occ = load >= 3 ? 1.0 : (load == 2 ? (big ? m.f2b : m.f2s) : (big ? m.f1b : m.f1s));
@@ -862,7 +894,7 @@ int dispatch_tile(GemmP& p, long ws_floats, hipStream_t st) {
         }
     }
     if (g_tile_force >= 0 && g_tile_force < NC) best = g_tile_force;
-    if (g_splits_force > 0 && (long)g_splits_force * p.M * (p.N + 1) <= ws_floats) {
+    if (g_splits_force > 0 && (long)groups * g_splits_force * p.M * (p.N + 1) <= ws_floats) {
         int kc = ceil_div(ceil_div(p.K, g_splits_force), 32) * 32;
         p.splits = ceil_div(p.K, kc); p.kchunk = kc;
     }
@@ -972,6 +1004,35 @@ int ha2g_gemm_wgrad_bias_f32(int M, int N, int K, const float* dY, long ldy, con
     hipStream_t st = (hipStream_t)stream;
     long wsf = ws ? ws_bytes / 4 : 0;
     bool vec = aligned16(dY) && (ldy % 4 == 0) && (M % 4 == 0) && aligned16(X) && (ldx % 4 == 0) && (N % 4 == 0);
+    return vec ? dispatch_tile<A_MC, B_NC, true>(p, wsf, st) : dispatch_tile<A_MC, B_NC, false>(p, wsf, st);
+}
+
+// `groups` (<= 8) independent GEMMs of ONE shape in one launch (+ one reduce launch when split-K is used): the same layer of several
+// networks with their own weights -- the three / six generators' text encoders run in lockstep.  Semantics per group g as ha2g_gemm_f32 /
+// ha2g_gemm_wgrad_bias_f32 with A = Ag[g] etc.; bias / csum arrays (or their entries) may be null; csum only with transa = 1, transb = 0.
+int ha2g_gemm_grouped_f32(int groups, int transa, int transb, int M, int N, int K, float alpha, const float* const* Ag, long lda,
+                          const float* const* Bg, long ldb, float beta, float* const* Cg, long ldc, const float* const* biasg, int act,
+                          float* const* csumg, float csum_beta, float* ws, long ws_bytes, void* stream) {
+    HA2G_REQUIRE(groups >= 1 && groups <= 8, "gemm_grouped: 1..8 groups, got %d", groups);
+    HA2G_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm_grouped: negative dimension");
+    HA2G_REQUIRE(!(transa && transb), "gemm_grouped: transa=1,transb=1 is not used on this path");
+    HA2G_REQUIRE(csumg == nullptr || (transa && !transb), "gemm_grouped: column sums ride on the weight-gradient shape only");
+    if (M == 0 || N == 0) return 0;
+    GemmP p{};
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.alpha = alpha; p.beta = beta; p.act = act; p.ws = ws; p.splits = 1; p.kchunk = K; p.csum_beta = csum_beta;
+    p.groups = groups;
+    bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && ((transa ? M : K) % 4 == 0) && ((transb ? K : N) % 4 == 0);
+    for (int g = 0; g < groups; ++g) {
+        p.Ag[g] = Ag[g]; p.Bg[g] = Bg[g]; p.Cg[g] = Cg[g];
+        p.biasg[g] = biasg ? biasg[g] : nullptr; p.csumg[g] = csumg ? csumg[g] : nullptr;
+        vec = vec && aligned16(Ag[g]) && aligned16(Bg[g]);
+    }
+    p.A = p.Ag[0]; p.B = p.Bg[0]; p.C = p.Cg[0]; p.bias = p.biasg[0]; p.csum = p.csumg[0];     // groups == 1 degenerates to the plain launch
+    hipStream_t st = (hipStream_t)stream;
+    long wsf = ws ? ws_bytes / 4 : 0;
+    if (!transa && transb) return vec ? dispatch_tile<A_KC, B_KC, true>(p, wsf, st) : dispatch_tile<A_KC, B_KC, false>(p, wsf, st);
+    if (!transa && !transb) return vec ? dispatch_tile<A_KC, B_NC, true>(p, wsf, st) : dispatch_tile<A_KC, B_NC, false>(p, wsf, st);
     return vec ? dispatch_tile<A_MC, B_NC, true>(p, wsf, st) : dispatch_tile<A_MC, B_NC, false>(p, wsf, st);
 }
 

@@ -146,6 +146,47 @@ def gemm(a, b, transa=False, transb=False, out=None, alpha=1.0, beta=0.0, bias=N
     return out
 
 
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def gemm_grouped(a, b, transa=False, transb=False, out=None, alpha=1.0, beta=0.0, bias=None, act=ACT_NONE, colsum_out=None, colsum_beta=0.0):
+    """G independent GEMMs of one shape in one launch (ha2g_gemm_grouped_f32).  a, b, out, bias, colsum_out: lists of G tensors, or ONE
+    stacked tensor with a leading group dimension ([G, rows, cols] operands / outputs, [G, N] bias, [G, M] column sums); per group the
+    semantics of gemm()."""
+    def parts(t, nd):
+        if t is None or isinstance(t, (list, tuple)):
+            return t
+        assert t.dim() == nd + 1
+        return [t[g] for g in range(t.shape[0])]
+    A, Bm = parts(a, 2), parts(b, 2)
+    G = len(A)
+    assert len(Bm) == G and 1 <= G <= 8
+    for t in A + Bm:
+        _chk2d(t)
+    M, K = (A[0].shape[1], A[0].shape[0]) if transa else A[0].shape
+    Kb, N = (Bm[0].shape[1], Bm[0].shape[0]) if transb else Bm[0].shape
+    assert K == Kb
+    assert all(t.shape == A[0].shape and t.stride(0) == A[0].stride(0) for t in A) and all(t.shape == Bm[0].shape and t.stride(0) == Bm[0].stride(0) for t in Bm)
+    ret = out
+    if out is None:
+        assert beta == 0.0
+        ret = out = torch.empty(G, M, N, dtype=torch.float32, device=A[0].device)
+    C = parts(out, 2)
+    assert len(C) == G and all(t.shape == (M, N) and t.stride(0) == C[0].stride(0) and t.stride(1) == 1 for t in C)
+    bias_l = parts(bias, 1)
+    cs_l = parts(colsum_out, 1)
+    if cs_l is not None:
+        assert transa and not transb and all(t is None or (t.shape == (M,) and t.is_contiguous()) for t in cs_l)
+    ws = workspace(A[0].device)
+    keep = (_ptr_array(A), _ptr_array(Bm), _ptr_array(C), _ptr_array(bias_l) if bias_l is not None else None,
+            _ptr_array(cs_l) if cs_l is not None else None)
+    check(lib.ha2g_gemm_grouped_f32(G, int(transa), int(transb), M, N, K, alpha, keep[0], A[0].stride(0), keep[1], Bm[0].stride(0), beta,
+                                    keep[2], C[0].stride(0), keep[3], act, keep[4], colsum_beta, ws.data_ptr(), ws.numel() * 4, _stream()))
+    return ret
+
+
 def colsum(x, out=None, beta=0.0):
     _chk2d(x)
     if out is None:

@@ -39,6 +39,14 @@ int ha2g_gemm_f32(int transa, int transb, int M, int N, int K, float alpha, cons
  * model/hierarchy_net.py:87-93, model/tcn.py:19-31, model/ResNetSE34V2.py:163-202) without a separate pass over dY. */
 int ha2g_gemm_wgrad_bias_f32(int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float beta, float* dW, long ldw,
                              float bias_beta, float* db, float* ws, long ws_bytes, void* stream);
+/* `groups` (1..8) independent GEMMs of one shape in ONE launch: per group g the semantics of ha2g_gemm_f32 (and, with csumg on the
+ * weight-gradient shape transa=1/transb=0, of ha2g_gemm_wgrad_bias_f32) on Ag[g], Bg[g], Cg[g], biasg[g], csumg[g] (host arrays of device
+ * pointers; biasg / csumg or their entries may be null).  The same layer of the three (TED-Gesture) or six (TED-Expressive) generators'
+ * text encoders -- separate nn.Module instances in the reference (model/hierarchy_net.py:66-70) -- fills the chip as one grid instead of
+ * three under-filled ones. */
+int ha2g_gemm_grouped_f32(int groups, int transa, int transb, int M, int N, int K, float alpha, const float* const* Ag, long lda,
+                          const float* const* Bg, long ldb, float beta, float* const* Cg, long ldc, const float* const* biasg, int act,
+                          float* const* csumg, float csum_beta, float* ws, long ws_bytes, void* stream);
 /* out[c] = beta*out[c] + sum_r X[r*ld + c]  (bias gradients); ws >= ha2g_colsum_workspace_bytes(cols) */
 long ha2g_colsum_workspace_bytes(int cols);
 int ha2g_colsum_f32(const float* X, long ld, long rows, int cols, float* out, float beta, float* ws, void* stream);

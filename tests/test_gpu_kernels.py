@@ -528,3 +528,39 @@ def test_linear_and_conv1d_bias_gradients_fused_equal_unfused():
     for a_, b_ in zip(res[True], res[False]):
         assert float((a_ - b_).abs().max()) <= 2e-6 * float(b_.abs().max())
     assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][3], res[False][3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(3, 4352, 300, 600, False, True), (3, 4352, 600, 300, False, False), (3, 300, 600, 4352, True, False),
+                                  (6, 136, 32, 300, False, True), (2, 129, 77, 1000, True, False), (3, 8704, 300, 600, False, True),
+                                  (1, 300, 300, 4352, True, False)])
+def test_grouped_gemm_matches_per_group_launches(case):
+    """ha2g_gemm_grouped_f32: G problems of one shape in one launch == G plain launches (forward with bias + activation, data-gradient and
+    weight-gradient shapes with the fused bias gradient; stacked and separate operands; accumulate)."""
+    from ha2g_amd import ops
+    G, M, N, K, ta, tb = case
+    gen = torch.Generator(device='cuda:0').manual_seed(G * 1000 + M)
+    a = torch.randn(G, *((K, M) if ta else (M, K)), device='cuda:0', generator=gen)
+    b = [torch.randn((N, K) if tb else (K, N), device='cuda:0', generator=gen) for _ in range(G)]         # separate tensors (weights)
+    c0 = torch.randn(G, M, N, device='cuda:0', generator=gen)
+    wgrad = ta and not tb
+    bias = None if wgrad else torch.randn(G, N, device='cuda:0', generator=gen)
+    cs0 = torch.randn(G, M, device='cuda:0', generator=gen) if wgrad else None
+    act = ops.ACT_NONE if wgrad else ops.ACT_RELU
+    got, got_cs = c0.clone(), (cs0.clone() if wgrad else None)
+    ops.gemm_grouped(a, b, transa=ta, transb=tb, out=got, beta=1.0, bias=bias, act=act, colsum_out=got_cs, colsum_beta=1.0)
+    for g in range(G):
+        ref = a[g].double().t() @ b[g].double() if ta else a[g].double() @ (b[g].double().t() if tb else b[g].double())
+        ref = ref + c0[g].double() + (bias[g].double() if bias is not None else 0.0)
+        if act == ops.ACT_RELU:
+            ref = ref.clamp_min(0)
+        scale = float(ref.abs().max())
+        assert float((got[g].double() - ref).abs().max()) <= 3e-5 * scale, g                 # split-bf16 class on the gradient shapes
+        if wgrad:
+            refb = a[g].double().sum(0) + cs0[g].double()
+            assert float((got_cs[g].double() - refb).abs().max()) <= 2e-6 * float(a[g].double().abs().sum(0).max()), g
+    if G == 1:                                                                             # degenerate group count == the plain launch, bit for bit
+        one, one_cs = c0[0].clone(), (cs0[0].clone() if wgrad else None)
+        ops.gemm(a[0], b[0], transa=ta, transb=tb, out=one, beta=1.0, bias=None if bias is None else bias[0], act=act,
+                 **(dict(colsum_out=one_cs, colsum_beta=1.0) if wgrad else {}))
+        assert torch.equal(one, got[0])
