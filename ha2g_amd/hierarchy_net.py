@@ -147,6 +147,43 @@ class TextEncoderTCN(nn.Module):
         return self.decoder(y).contiguous()
 
 
+def text_encoders_groupable(encs):
+    """True when the encoders are same-shape TextEncoderTCN modules without residual down-sampling (embed size == hidden size, the
+    hierarchy.yml configuration): their layers can then run as grouped launches."""
+    if len(encs) < 2 or len(encs) > 8 or not all(isinstance(e, TextEncoderTCN) for e in encs):
+        return False
+    e0 = encs[0]
+    sig = lambda e: (tuple(e.embedding.weight.shape), len(e.tcn.network), e.drop.p, e.training,
+                     tuple((tuple(b.conv1.weight_v.shape), tuple(b.conv2.weight_v.shape), b.dilation, b.p, b.downsample is None) for b in e.tcn.network),
+                     tuple(e.decoder.weight.shape))
+    return all(sig(e) == sig(e0) for e in encs) and all(b.downsample is None for b in e0.tcn.network)
+
+
+def grouped_text_encoders(encs, in_text):
+    """The G generators' text encoders (separate modules in the reference, model/hierarchy_net.py:66-70, each called inside its generator's
+    forward :121-123) evaluated in lockstep: every layer is ONE launch over the stacked [G*B, T, C] activations and one grouped GEMM with the
+    G weight sets, instead of G under-filled launches.  Same arithmetic per encoder; returns [G, B, T, 32]."""
+    G = len(encs)
+    B, T = in_text.shape
+    e0 = encs[0]
+    x = torch.stack([e.embedding(in_text) for e in encs])                  # [G, B, T, E]: each encoder has its own table
+    E = x.shape[3]
+    x = ops.dropout(x.view(G * B, T, E), e0.drop.p, e0.training)
+    for lvl in range(len(e0.tcn.network)):
+        blocks = [e.tcn.network[lvl] for e in encs]
+        d, p = blocks[0].dilation, blocks[0].p
+        y = x
+        for name in ('conv1', 'conv2'):
+            convs = [getattr(b, name) for b in blocks]
+            ws = [ops.weight_norm(c.weight_g, c.weight_v) for c in convs]
+            y = ops.grouped_conv1d_tm(y.view(G, B, T, y.shape[2]), ws, [c.bias for c in convs], dil=d, pad_left=d * (ws[0].shape[2] - 1), To=T,
+                                      act=ACT_RELU).view(G * B, T, -1)
+            y = ops.dropout(y, p, e0.training)
+        x = ops.add_relu(y, x)
+    out = ops.grouped_linear(x.view(G, B * T, x.shape[2]), [e.decoder.weight for e in encs], [e.decoder.bias for e in encs])
+    return out.view(G, B, T, -1)
+
+
 # ---------------------------------------------------------------------------------------------------
 # bidirectional GRU parameters (torch.nn.GRU names / init)
 # ---------------------------------------------------------------------------------------------------
@@ -253,10 +290,14 @@ class Hierarchical_PoseGenerator(nn.Module):
         h = self.out[0](output.reshape(-1, output.shape[2]), act=ACT_LEAKY)
         return self.out[2](h).reshape(gru_out.shape[0], gru_out.shape[1], -1)
 
-    def forward(self, pre_seq, in_text, audio_feat_seq=None, vid_indices=None):
-        text_feat_seq = None
-        if self.input_context != 'none':
-            text_feat_seq = self._row_split(self.text_encoder, in_text)
+    def forward(self, pre_seq, in_text, audio_feat_seq=None, vid_indices=None, text_feat_seq=None):
+        # text_feat_seq: this generator's text features when the caller evaluated all generators' text encoders together
+        # (grouped_text_encoders); None = run the own encoder here, as the reference does
+        if self.input_context == 'none':
+            text_feat_seq = None
+        else:
+            if text_feat_seq is None:
+                text_feat_seq = self._row_split(self.text_encoder, in_text)
             assert audio_feat_seq.shape[1] == text_feat_seq.shape[1]
         if self.z_obj:
             if self.speaker_embedding:

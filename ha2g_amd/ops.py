@@ -569,6 +569,97 @@ def conv1d_tm(x, w, b, dil=1, pad_left=0, To=None, act=ACT_NONE):
         To = x.shape[1] + pad_left - (w.shape[2] - 1) * dil
     return Conv1dFunction.apply(x, w, b, dil, pad_left, To, act)
 
+# ------------------------------------------------------------------------------------------------
+# grouped layers: the same layer of G networks (own weights) as one launch per GEMM (ha2g_gemm_grouped_f32)
+# ------------------------------------------------------------------------------------------------
+
+class GroupedLinearFunction(torch.autograd.Function):
+    """y[g] = act(x[g] W_g^T + b_g); x [G, R, K] stacked, W_g [N, K] and b_g [N] separate tensors (G parameters of G modules)."""
+
+    @staticmethod
+    def forward(ctx, x, act, G, *wb):
+        ws, bs = list(wb[:G]), list(wb[G:])
+        has_b = bs[0] is not None
+        x = _f32c(x.contiguous())
+        wc = [w.contiguous() for w in ws]
+        y = gemm_grouped(x, wc, transb=True, bias=bs if has_b else None, act=act)
+        ctx.act, ctx.G, ctx.has_b = act, G, has_b
+        ctx.refs = (ws, bs)
+        ctx.save_for_backward(x, y if act != ACT_NONE else None, *wc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, *wc = ctx.saved_tensors
+        G = ctx.G
+        ws, bs = ctx.refs
+        dy2 = act_bwd(dy, y, ctx.act)
+        N, K = wc[0].shape
+        dx = None
+        dws, dbs = [None] * G, [None] * G
+        need_w, need_b = ctx.needs_input_grad[3], ctx.has_b and ctx.needs_input_grad[3 + G]
+        with side.section(dy2.device):
+            if need_w:
+                tw = [_grad_target(w) for w in ws]
+                direct_w = all(t is not None and t.is_contiguous() for t in tw)
+                tb = [_grad_target(b) for b in bs] if need_b else None
+                direct_b = need_b and all(t is not None for t in tb)
+                if need_b and not direct_b:
+                    tb = torch.empty(G, N, dtype=torch.float32, device=dy2.device)
+                    dbs = [tb[g] for g in range(G)]
+                if direct_w:
+                    out = [t.view(N, K) for t in tw]
+                else:
+                    out = torch.empty(G, N, K, dtype=torch.float32, device=dy2.device)
+                    dws = [out[g].view(ws[g].shape) for g in range(G)]
+                gemm_grouped(dy2, x, transa=True, out=out, beta=1.0 if direct_w else 0.0,
+                             colsum_out=tb if need_b else None, colsum_beta=1.0 if direct_b else 0.0)
+            elif need_b:
+                for g in range(G):
+                    dbs[g] = colsum(dy2[g])
+        if ctx.needs_input_grad[0]:
+            dx = gemm_grouped(dy2, wc)
+        side.join(dy2.device)
+        return (dx, None, None) + tuple(dws) + tuple(dbs)
+
+
+def grouped_linear(x, ws, bs=None, act=ACT_NONE):
+    G = len(ws)
+    return GroupedLinearFunction.apply(x, act, G, *ws, *(bs if bs is not None else [None] * G))
+
+
+class Im2col1dFunction(torch.autograd.Function):
+    """x [B, T, C] -> columns [B*To, C*k] of a dilated causal 1-D convolution (the GEMM operand of Conv1dFunction); backward = col2im."""
+
+    @staticmethod
+    def forward(ctx, x, k, dil, pad_left, To):
+        x = _f32c(x.contiguous())
+        B, T, C = x.shape
+        col = torch.empty(B * To, C * k, dtype=torch.float32, device=x.device)
+        check(lib.ha2g_im2col1d_f32(x.data_ptr(), col.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
+        ctx.geom = (B, T, C, k, dil, pad_left, To)
+        return col
+
+    @staticmethod
+    def backward(ctx, dcol):
+        B, T, C, k, dil, pad_left, To = ctx.geom
+        dcol = dcol.contiguous()
+        dx = torch.empty(B, T, C, dtype=torch.float32, device=dcol.device)
+        check(lib.ha2g_col2im1d_f32(dcol.data_ptr(), dx.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
+        return dx, None, None, None, None
+
+
+def grouped_conv1d_tm(x, ws, bs, dil=1, pad_left=0, To=None, act=ACT_NONE):
+    """x [G, B, T, C] (the inputs of G same-shape convolutions), ws: G weights [Cout, C, k], bs: G biases -> [G, B, To, Cout]."""
+    G, B, T, C = x.shape
+    cout, _, k = ws[0].shape
+    if To is None:
+        To = T + pad_left - (k - 1) * dil
+    col = Im2col1dFunction.apply(x.reshape(G * B, T, C), k, dil, pad_left, To)
+    y = grouped_linear(col.view(G, B * To, C * k), [w.reshape(cout, C * k) for w in ws], bs, act)
+    return y.view(G, B, To, cout)
+
+
 
 # ------------------------------------------------------------------------------------------------
 # BatchNorm over [rows, C]

@@ -12,6 +12,8 @@ truthiness quirk that drops KLD / DIV_REG when exactly 0).  Differences are pure
 """
 import math
 
+import os
+
 import torch
 
 from . import ops
@@ -46,12 +48,43 @@ def _chain(spec, args, gens, targets, in_text, blend, vids, tables):
     of the reference's zeros + slice writes.  All inputs may carry a multiple of B rows."""
     n = args.n_pre_poses
     outs, last = [], None
+    text_feats = _grouped_text_features(gens, in_text)
     for k, g in enumerate(gens):
         pre = ops.pre_seq(targets[k], outs[-1] if k else None, tables[k], n)
-        o, z, mu, logvar = g(pre, in_text, blend[k], vids)
+        o, z, mu, logvar = g(pre, in_text, blend[k], vids, **({} if text_feats is None else {'text_feat_seq': text_feats[k]}))
         outs.append(o)
         last = (z, mu, logvar)
     return outs, last[0], last[1], last[2]
+
+
+FUSE_TEXT = os.environ.get('HA2G_FUSE_TEXT', '1') != '0'     # the generators' text encoders as grouped launches (hierarchy_net.grouped_text_encoders)
+
+
+def _grouped_text_features(gens, in_text):
+    """Per-generator text features from ONE lockstep pass over all generators' text encoders, or None when they cannot be grouped.
+    Honours the fused-chain row split (hierarchy_net._row_split): rows that receive no gradient are evaluated under no_grad."""
+    from .hierarchy_net import grouped_text_encoders, text_encoders_groupable
+    mods = [g.module if hasattr(g, 'module') else g for g in gens]
+    if not FUSE_TEXT or not in_text.is_cuda or any(m.input_context == 'none' for m in mods):
+        return None
+    encs = [m.text_encoder for m in mods]
+    if not text_encoders_groupable(encs):
+        return None
+    gs = mods[0].gru.grad_slice
+    if gs is None or not torch.is_grad_enabled():
+        return grouped_text_encoders(encs, in_text)
+    s0, cnt = gs
+    B = in_text.shape[0]
+    parts = []
+    for a, b, grad in ((0, s0, False), (s0, s0 + cnt, True), (s0 + cnt, B, False)):
+        if b <= a:
+            continue
+        if grad:
+            parts.append(grouped_text_encoders(encs, in_text[a:b]))
+        else:
+            with torch.no_grad():
+                parts.append(grouped_text_encoders(encs, in_text[a:b]))
+    return torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
 
 
 def _allreduce(optimizers):

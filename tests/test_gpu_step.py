@@ -173,7 +173,7 @@ def test_whole_step_hipgraph_capture_matches_eager():
     assert ops.gru_cluster_error(dev) == 0
 
 
-def _full_size_step(expressive, B, fuse, mode, seed=21):
+def _full_size_step(expressive, B, fuse, mode, seed=21, fuse_text=True):
     """One GAN-phase step of a freshly built full-size trainer with every random draw pinned; returns (loss dict, flat grads)."""
     from ha2g_amd import ops, schema
     from ha2g_amd._lib import lib
@@ -209,13 +209,13 @@ def _full_size_step(expressive, B, fuse, mode, seed=21):
                 return out
             return torch.cat([eps_const[o * B:(o + 1) * B] for o in order])
         g.eps_source = src
-    old = th.FUSE_CHAINS, th.randperm_source
-    th.FUSE_CHAINS, th.randperm_source = fuse, (lambda n, device: perm)
+    old = th.FUSE_CHAINS, th.randperm_source, th.FUSE_TEXT
+    th.FUSE_CHAINS, th.randperm_source, th.FUSE_TEXT = fuse, (lambda n, device: perm), fuse_text
     lib.ha2g_gemm_set_mode(mode)
     try:
         ret = tr.train_iter(11, text, spec, target, vid)
     finally:
-        th.FUSE_CHAINS, th.randperm_source = old
+        th.FUSE_CHAINS, th.randperm_source, th.FUSE_TEXT = old
         lib.ha2g_gemm_set_mode(__import__('ha2g_amd._lib', fromlist=['x']).DEFAULT_GEMM_MODE)
     names = ['g%d' % (i + 1) for i in range(len(tr.gens))] + ['audio', 'text']
     grads = {n: o.flat_g.clone() for n, o in zip(names, tr.gen_opts + [tr.audio_opt, tr.text_opt])}
@@ -252,6 +252,21 @@ def test_full_size_schedule_and_precision_invariants(expressive):
     for k in g_f:
         d = float((g_f[k] - g_x[k]).norm() / g_x[k].norm())
         assert d < 1e-4, ('split-bf16 vs fp32 backward', k, d)
+
+
+@pytest.mark.parametrize('expressive,fuse', [(False, True), (False, False), (True, True)])
+def test_grouped_text_encoders_match_the_per_generator_encoders(expressive, fuse):
+    """The generators' text encoders evaluated in lockstep as grouped launches (hierarchy_net.grouped_text_encoders, the default) against
+    each generator running its own encoder inside its forward (the reference's structure): same loss terms, same gradients for every module,
+    under the fused-chain and the literal schedule, three and six generators."""
+    B = 128
+    r_g, g_g = _full_size_step(expressive, B, fuse, 6, fuse_text=True)
+    r_s, g_s = _full_size_step(expressive, B, fuse, 6, fuse_text=False)
+    for k in r_g:
+        assert abs(r_g[k] - r_s[k]) <= 2e-5 * max(abs(r_s[k]), 1e-3), (k, r_g[k], r_s[k])
+    for k in g_g:
+        d = float((g_g[k] - g_s[k]).norm() / g_s[k].norm())
+        assert d < 2e-4, ('grouped vs per-generator text encoders', k, d)
 
 
 def test_config5_bf16_step_b256():
