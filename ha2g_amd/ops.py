@@ -285,6 +285,7 @@ DIRECT_GRAD = True     # accumulate weight gradients straight into an existing `
                        # returning a temporary that autograd then adds with its own kernel (one at::add per parameter)
 
 
+GROUP_GRU_WGRAD = os.environ.get("HA2G_GROUP_GRU_WGRAD", "1") != "0"   # the two directions' weight gradients of a GRU layer as grouped launches
 FUSE_BIAS_GRAD = os.environ.get("HA2G_FUSE_BIAS_GRAD", "1") != "0"     # Linear / Conv1d: bias gradient = column sums taken by the weight-gradient GEMM (ha2g_gemm_wgrad_bias_f32)
 
 
@@ -873,27 +874,40 @@ class BiGRUFunction(torch.autograd.Function):
             with side.section(dev):                                                 # weight / bias gradients: off the critical path
                 tgs = []
                 for d in range(2):
-                    o = 4 * H * d
-                    dgi = dg[:, o:o + 3 * H]
                     tg = [_grad_target(w[4 * d + i]) for i in range(4)]
-                    tg = [t if (t is not None and t.is_contiguous()) else None for t in tg]
-                    # bias gradients ride on the weight-gradient launches when every target is an installed .grad buffer:
-                    # b_ih <- columns [r z n] of dgi, b_hh <- columns [r z] and [hn] (the same dY tiles the three GEMMs stage)
-                    fb = FUSE_BIAS_GRAD and all(t is not None for t in tg)
-                    cs3 = [dict(colsum_out=c, colsum_beta=1.0) for c in (tg[2], tg[3][:2 * H], tg[3][2 * H:])] if fb else [{}, {}, {}]
-                    fused_b.append(fb)
-                    if tg[0] is not None:
-                        gemm(dgi, x2, transa=True, out=tg[0], beta=1.0, **cs3[0])   # dW_ih += dgi^T X, straight into .grad
-                    else:
-                        grads[8 * l + 4 * d + 0] = gemm(dgi, x2, transa=True)
-                    bt = 1.0 if tg[1] is not None else 0.0
-                    dwhh = tg[1] if tg[1] is not None else torch.empty(3 * H, H, dtype=torch.float32, device=dev)
-                    hpd = hp2[:, d * H:(d + 1) * H]
-                    gemm(dg[:, o:o + 2 * H], hpd, transa=True, out=dwhh[:2 * H], beta=bt, **cs3[1])    # rows r,z
-                    gemm(dg[:, o + 3 * H:o + 4 * H], hpd, transa=True, out=dwhh[2 * H:], beta=bt, **cs3[2])  # rows n (d gh_n)
-                    if tg[1] is None:
-                        grads[8 * l + 4 * d + 1] = dwhh
-                    tgs.append(tg)
+                    tgs.append([t if (t is not None and t.is_contiguous()) else None for t in tg])
+                if FUSE_BIAS_GRAD and GROUP_GRU_WGRAD and all(t is not None for tg in tgs for t in tg):
+                    # every target is an installed .grad buffer: the two directions' weight-gradient GEMMs have one shape each -> three grouped
+                    # launches (dW_ih, dW_hh rows r z, dW_hh rows n) instead of six, bias gradients riding on them
+                    A = [[dg[:, 4 * H * d:4 * H * d + 3 * H] for d in range(2)], [dg[:, 4 * H * d:4 * H * d + 2 * H] for d in range(2)],
+                         [dg[:, 4 * H * d + 3 * H:4 * H * d + 4 * H] for d in range(2)]]
+                    Bm = [[x2, x2], [hp2[:, d * H:(d + 1) * H] for d in range(2)], [hp2[:, d * H:(d + 1) * H] for d in range(2)]]
+                    Cm = [[tgs[d][0] for d in range(2)], [tgs[d][1][:2 * H] for d in range(2)], [tgs[d][1][2 * H:] for d in range(2)]]
+                    cs = [[tgs[d][2] for d in range(2)], [tgs[d][3][:2 * H] for d in range(2)], [tgs[d][3][2 * H:] for d in range(2)]]
+                    for i in range(3):
+                        gemm_grouped(A[i], Bm[i], transa=True, out=Cm[i], beta=1.0, colsum_out=cs[i], colsum_beta=1.0)
+                    fused_b += [True, True]
+                else:
+                    for d in range(2):
+                        o = 4 * H * d
+                        dgi = dg[:, o:o + 3 * H]
+                        tg = tgs[d]
+                        # bias gradients ride on the weight-gradient launches when every target is an installed .grad buffer:
+                        # b_ih <- columns [r z n] of dgi, b_hh <- columns [r z] and [hn] (the same dY tiles the three GEMMs stage)
+                        fb = FUSE_BIAS_GRAD and all(t is not None for t in tg)
+                        cs3 = [dict(colsum_out=c, colsum_beta=1.0) for c in (tg[2], tg[3][:2 * H], tg[3][2 * H:])] if fb else [{}, {}, {}]
+                        fused_b.append(fb)
+                        if tg[0] is not None:
+                            gemm(dgi, x2, transa=True, out=tg[0], beta=1.0, **cs3[0])   # dW_ih += dgi^T X, straight into .grad
+                        else:
+                            grads[8 * l + 4 * d + 0] = gemm(dgi, x2, transa=True)
+                        bt = 1.0 if tg[1] is not None else 0.0
+                        dwhh = tg[1] if tg[1] is not None else torch.empty(3 * H, H, dtype=torch.float32, device=dev)
+                        hpd = hp2[:, d * H:(d + 1) * H]
+                        gemm(dg[:, o:o + 2 * H], hpd, transa=True, out=dwhh[:2 * H], beta=bt, **cs3[1])    # rows r,z
+                        gemm(dg[:, o + 3 * H:o + 4 * H], hpd, transa=True, out=dwhh[2 * H:], beta=bt, **cs3[2])  # rows n (d gh_n)
+                        if tg[1] is None:
+                            grads[8 * l + 4 * d + 1] = dwhh
                 if not all(fused_b[-2:]):
                     assert not any(fused_b[-2:]), 'both directions of a layer share one gradient-buffer state'
                     # the four bias gradients of the layer from ONE column sum over all 8H gate-gradient columns
