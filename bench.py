@@ -194,6 +194,7 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         ops.ktimer.enabled = False
+        tr.sync()                                    # outside the timed region: raises if a cluster-GRU hand-off of any step timed out
     # secondary number: warm-up phase (epoch <= loss_warmup, no D update / no D-phase chain), a third of the timed steps
     k2 = max(2, a.steps // 3) if not a.primary_only else 0
     for _ in range(2 if k2 else 0):

@@ -54,6 +54,14 @@ class HierarchyTrainer:
         self.text_opt = FusedAdam(self.text_encoder.parameters(), lr=lr, betas=(0.5, 0.999), sparse=sp(self.text_encoder))
         self.dis_opt = FusedAdam(self.discriminator.parameters(), lr=lr * a.discriminator_lr_weight, betas=(0.5, 0.999))
 
+    def sync(self):
+        """Waits for the device and raises if a cluster-GRU hand-off of an earlier step timed out.  train_iter returns as soon as the
+        step's losses have reached the host (they exist before the backward); the backward / optimizer kernels may still be running."""
+        import torch
+        from .train_hierarchy import drain_cluster_errors
+        torch.cuda.synchronize(self.device)
+        drain_cluster_errors(block=True)
+
     def sync_sparse(self):
         for o in self.gen_opts + [self.text_opt]:
             o.sync_sparse()

@@ -87,6 +87,48 @@ def _grouped_text_features(gens, in_text):
     return torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
 
 
+_pinned_bufs = {}
+_err_watch = []          # (event, pinned int32 word, device): end-of-step copies of the cluster error word not yet looked at
+_err_free = []
+
+
+def _pinned(dev, slot, n):
+    key = (dev.index, slot)
+    b = _pinned_bufs.get(key)
+    if b is None or b.numel() < n:
+        b = _pinned_bufs[key] = torch.empty(max(n, 32), dtype=torch.float32, pin_memory=True)
+    return b[:n]
+
+
+def _watch_cluster_errors(dev):
+    """Asynchronous copy of the cluster-GRU error word at the end of a step (it then covers the step's BPTT launches)."""
+    err = ops.gru_cluster_error_tensor(dev)
+    if err is None:
+        return
+    word = _err_free.pop() if _err_free else torch.empty(1, dtype=torch.int32, pin_memory=True)
+    word.copy_(err[:1], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _err_watch.append((ev, word, dev))
+
+
+def drain_cluster_errors(block=False):
+    """Looks at the end-of-step error words whose copies have completed (block=True: waits for all of them) and raises
+    Ha2gClusterError when one is set.  Called at the start of every train step and by HierarchyTrainer.sync()."""
+    bad = False
+    while _err_watch and (block or _err_watch[0][0].query()):
+        ev, word, dev = _err_watch.pop(0)
+        ev.synchronize()
+        bad = bad or int(word[0]) != 0
+        _err_free.append(word)
+    if bad:
+        raise ops.Ha2gClusterError(_CLUSTER_MSG)
+
+
+_CLUSTER_MSG = ('ha2g_amd: a GRU cluster hand-off timed out (gru_cluster.hip): that step\'s GRU outputs and gradients are invalid -- '
+                'the device cannot co-schedule the cluster\'s workgroups')
+
+
 def _allreduce(optimizers):
     from . import ddp
     ddp.average_module_grads_(optimizers)
@@ -119,6 +161,7 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
     warm_up_epochs = args.loss_warmup
     dev = target.device
     B = target.shape[0]
+    drain_cluster_errors()                               # BPTT time-outs of earlier steps whose read-back has arrived
     ops.rng.begin_step()
     L = len(gens)
     consts = _consts(spec, args, dev)
@@ -243,6 +286,39 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
         terms.append(physical_loss); weights.append(args.loss_physical_weight)
     loss = ops.weighted_sum(terms, weights)
 
+    # ---- one packed device->host transfer of the logged scalars, issued as soon as they exist ----
+    # 'loss' = the sum of the per-level Huber terms (added on the host in fp32, left to right like the reference's
+    # `huber_loss = h1 + h2 + ...`); 'c_neg' is logged with the reference's sign (it holds -contrastive(text, low)).
+    # Every logged scalar is a forward quantity, so the copy is enqueued BEFORE the backward: train_iter returns when the copy's event
+    # has fired instead of draining the device (the reference's `.item()` calls wait for backward + optimizer too: 1.2 ms of idle
+    # matrix cores per step, the host re-starts every step with an empty launch queue).  The values are the same.
+    names, vals = [], []
+    for i, h in enumerate(hubers):
+        names.append('loss' if i == 0 else '+loss'); vals.append(h.detach())
+    if kld is not None:
+        names.append('KLD'); vals.append(kld.detach())
+    if div_reg is not None:
+        names.append('DIV_REG'); vals.append(div_reg.detach())
+    if gan:
+        names += ['gen', 'dis']; vals += [gen_error.detach(), dis_error.detach()]
+    if args.loss_contrastive_pos_weight > 0.0:
+        names.append('c_pos'); vals.append(text_high_contrastive.detach())
+    if args.loss_contrastive_neg_weight > 0.0:
+        names.append('-c_neg'); vals.append(text_low_pos.detach())
+    if args.loss_physical_weight > 0.0:
+        names.append('phy'); vals.append(physical_loss.detach())
+    err = ops.gru_cluster_error_tensor(dev)
+    if err is not None:                                  # cluster-GRU hand-off time-out flag (forward launches so far) rides along
+        names.append('_cluster_err'); vals.append(err[0].to(torch.float32))
+    packed = torch.stack(vals)
+    readback = None
+    if not return_tensors:
+        host = _pinned(dev, 'loss', packed.numel())
+        host.copy_(packed, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        readback = (host, ev)
+
     from . import ddp
     loss.backward()                                      # stage 1: losses, discriminator, generators (down to the cut)
     works = []
@@ -264,31 +340,18 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
         o.step()
     ops.rng.end_step()
 
-    # ---- one packed device->host transfer of the logged scalars ----
-    # 'loss' = the sum of the per-level Huber terms (added on the host in fp32, left to right like the reference's
-    # `huber_loss = h1 + h2 + ...`); 'c_neg' is logged with the reference's sign (it holds -contrastive(text, low))
-    names, vals = [], []
-    for i, h in enumerate(hubers):
-        names.append('loss' if i == 0 else '+loss'); vals.append(h.detach())
-    if kld is not None:
-        names.append('KLD'); vals.append(kld.detach())
-    if div_reg is not None:
-        names.append('DIV_REG'); vals.append(div_reg.detach())
-    if gan:
-        names += ['gen', 'dis']; vals += [gen_error.detach(), dis_error.detach()]
-    if args.loss_contrastive_pos_weight > 0.0:
-        names.append('c_pos'); vals.append(text_high_contrastive.detach())
-    if args.loss_contrastive_neg_weight > 0.0:
-        names.append('-c_neg'); vals.append(text_low_pos.detach())
-    if args.loss_physical_weight > 0.0:
-        names.append('phy'); vals.append(physical_loss.detach())
-    err = ops.gru_cluster_error_tensor(dev)
-    if err is not None:                                  # cluster-GRU hand-off time-out flag rides along in the same D2H copy
-        names.append('_cluster_err'); vals.append(err[0].to(torch.float32))
-    packed = torch.stack(vals)
     if return_tensors:                                   # graph-captured steps read the packed buffer after replay
+        err = ops.gru_cluster_error_tensor(dev)
+        if err is not None:                              # the error word as it stands at the END of the step (BPTT launches included)
+            if names[-1] == '_cluster_err':
+                packed = packed[:-1]
+            else:
+                names.append('_cluster_err')
+            packed = torch.cat([packed, err[:1].to(torch.float32)])
         return names, packed
-    return _ret_dict(args, names, packed.tolist())
+    _watch_cluster_errors(dev)                            # BPTT hand-off time-outs: checked without blocking (see drain_cluster_errors)
+    readback[1].synchronize()                            # the losses left the device before the backward started: no device-wide sync here
+    return _ret_dict(args, names, readback[0].tolist())
 
 
 def _ret_dict(args, names, vals):
@@ -308,8 +371,7 @@ def _ret_dict(args, names, vals):
     for n, v in merged:
         if n == '_cluster_err':
             if v:
-                raise ops.Ha2gClusterError('ha2g_amd: a GRU cluster hand-off timed out (gru_cluster.hip): this step\'s GRU outputs '
-                                           'and gradients are invalid -- the device cannot co-schedule the cluster\'s workgroups')
+                raise ops.Ha2gClusterError(_CLUSTER_MSG)
             continue
         if n in ('KLD', 'DIV_REG') and not v:            # reference: `if kld:` / `if div_reg:` (train_hierarchy.py:277-280)
             continue

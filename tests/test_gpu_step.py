@@ -1,6 +1,7 @@
 """Full train_iter_hierarchy on the GPU vs the reference-generated step fixtures: two consecutive steps
 (epoch 0 = warm-up phase, epoch 11 = GAN phase) -- loss dict, accumulated gradients, Adam-updated parameters,
 BatchNorm running statistics -- for the fused-chain schedule and the literal three-pass schedule."""
+import numpy as np
 import pytest
 import torch
 
@@ -320,3 +321,39 @@ def test_ragged_batch_sizes_vs_oracle(B):
     assert sorted(ret) == sorted(ref), (ret, ref)
     for k in ref:
         assert abs(ret[k] - ref[k]) <= 1e-4 * max(abs(ref[k]), 1e-3), (B, k, ret[k], ref[k])
+
+
+def test_loss_readback_is_early_and_cluster_errors_are_still_raised():
+    """train_iter copies the logged scalars to the host before the backward is enqueued and returns when THAT copy has landed (no
+    device-wide sync per step).  The cluster-GRU error word still fails loudly: the forward launches' word rides in the same copy (raised by
+    the same call), the end-of-step word (BPTT launches) is copied asynchronously and raised by the next step / HierarchyTrainer.sync()."""
+    from ha2g_amd import ops, train_hierarchy as th
+    from ha2g_amd.config import hierarchy_args
+    from ha2g_amd.testing import SpeakerVocab
+    from ha2g_amd.train import HierarchyTrainer
+    dev = torch.device(DEV)
+    args = hierarchy_args()
+    class Lang:
+        n_words, word_embedding_weights = 500, None
+    tr = HierarchyTrainer(args, Lang(), SpeakerVocab(40), 27, dev)
+    text, spec, target, vid = (torch.from_numpy(x).to(dev) for x in proc.make_batch(16, 27, 500, 40, 5))
+    a = tr.train_iter(11, text, spec, target, vid)
+    tr.sync()
+    assert all(np.isfinite(v) for v in a.values()) and not th._err_watch
+    word = ops.gru_cluster_error_tensor(dev)
+    try:
+        word.fill_(1)                                            # as if a hand-off had timed out
+        with pytest.raises(ops.Ha2gClusterError):
+            tr.train_iter(11, text, spec, target, vid)           # the forward-time copy carries the word: same call raises
+        torch.cuda.synchronize()
+        th._err_watch.clear()
+        th._watch_cluster_errors(dev)                            # the end-of-step copy path
+        with pytest.raises(ops.Ha2gClusterError):
+            tr.sync()
+    finally:
+        word.zero_()
+        torch.cuda.synchronize()
+        th._err_watch.clear()
+    b = tr.train_iter(11, text, spec, target, vid)
+    tr.sync()
+    assert set(b) == set(a)
