@@ -110,3 +110,23 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run'], env=env2, capture_output=True, text=True, timeout=300)
     recs = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
     assert p.returncode == 0 and len(recs) == 1 and recs[0]['rank'] == 1 and recs[0]['world'] == 2
+
+
+def test_fastcall_binding_covers_the_header_and_converts_like_ctypes():
+    """ha2g_amd/_ha2g_fastcall (generated from include/ha2g_hip.h by csrc/gen_fastcall.py) exports one METH_FASTCALL wrapper per entry point;
+    pointer arguments accept ints, None, ctypes pointer objects (their VALUE) and ctypes arrays (their storage), as ctypes' c_void_p does."""
+    import ctypes
+    from ha2g_amd import _lib
+    from ha2g_amd import _ha2g_fastcall as fc
+    assert _lib.lib.fastcall
+    for name in _lib.parse_header():
+        assert hasattr(fc, name), name
+    assert fc.ha2g_abi_version() == _lib._clib.ha2g_abi_version()
+    arr = (ctypes.c_float * 4)(1, 2, 3, 4)
+    for ptr in (None, 0, ctypes.addressof(arr), arr, ctypes.cast(arr, ctypes.c_void_p)):
+        # M = 0: returns before touching any operand, after every argument has been converted
+        assert fc.ha2g_gemm_f32(0, 1, 0, 0, 0, 1.0, ptr, 0, ptr, 0, 0, ptr, 0, None, 0, None, 0, None) == 0
+    with pytest.raises(TypeError):
+        fc.ha2g_gemm_f32(0, 1, 0)
+    with pytest.raises(TypeError):
+        fc.ha2g_gemm_f32(0, 1, 0, 0, 0, 1.0, 'x', 0, None, 0, 0, None, 0, None, 0, None, 0, None)

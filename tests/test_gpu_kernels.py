@@ -469,7 +469,6 @@ def test_dense_tile_shape_does_not_change_bits(shape):
     import ctypes
     from ha2g_amd import ops
     from ha2g_amd._lib import lib
-    lib.ha2g_gemm_debug_tile.argtypes = [ctypes.c_int, ctypes.c_int]
     M, N, K, ta, tb = shape
     g = torch.Generator(device='cuda:0').manual_seed(M + N)
     a = torch.randn((K, M) if ta else (M, K), device='cuda:0', generator=g)

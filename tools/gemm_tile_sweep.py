@@ -5,7 +5,6 @@ sys.path.insert(0, '.')
 from ha2g_amd import ops
 from ha2g_amd._lib import lib
 dev = torch.device('cuda:0')
-lib.ha2g_gemm_debug_tile.argtypes = [__import__('ctypes').c_int] * 2
 SHAPES = [  # calls, M, N, K, ta, tb
     (18, 13056, 900, 600, 0, 1), (24, 8704, 300, 600, 0, 1), (32, 4352, 600, 300, 0, 0), (32, 4352, 300, 600, 0, 1),
     (18, 900, 600, 4352, 1, 0), (32, 300, 600, 4352, 1, 0), (18, 4352, 600, 900, 0, 0), (24, 600, 300, 4352, 1, 0),
