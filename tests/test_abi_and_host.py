@@ -1,5 +1,6 @@
 """CPU-side checks: the C-ABI library loads and exports every symbol include/ha2g_hip.h declares (no compute calls),
 state_dict schemas, the returned-dict conventions of the train step, procedural determinism."""
+import pytest
 import ctypes
 import os
 import re
