@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) w[e] = __float_as_uint(as[(kc * 16 + 8 * lhi + e) * LDA + i * 32]);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { hi[q] = (w[2 * q] >> 16) | (w[2 * q + 1] & 0xffff0000u); lo[q] = (w[2 * q] & 0xffffu) | (w[2 * q + 1] << 16); }
+                    for (int q = 0; q < 4; ++q) { hi[q] = __builtin_amdgcn_perm(w[2 * q + 1], w[2 * q], 0x07060302u); lo[q] = __builtin_amdgcn_perm(w[2 * q + 1], w[2 * q], 0x05040100u); }   /* v_perm_b32: the two upper / lower halves in one op each */
                     ah[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<uint4*>(hi));
                     al[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<uint4*>(lo));
                 }
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) w[e] = __float_as_uint(bs[(kc * 16 + 8 * lhi + e) * LDB + j * 32]);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { hi[q] = (w[2 * q] >> 16) | (w[2 * q + 1] & 0xffff0000u); lo[q] = (w[2 * q] & 0xffffu) | (w[2 * q + 1] << 16); }
+                    for (int q = 0; q < 4; ++q) { hi[q] = __builtin_amdgcn_perm(w[2 * q + 1], w[2 * q], 0x07060302u); lo[q] = __builtin_amdgcn_perm(w[2 * q + 1], w[2 * q], 0x05040100u); }   /* v_perm_b32: the two upper / lower halves in one op each */
                     bh[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<uint4*>(hi));
                     bl[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<uint4*>(lo));
                 }
