@@ -77,10 +77,10 @@ __device__ __forceinline__ float4 pack_hilo4(float4 v) {
     unsigned h0, l0, h1, l1;
     split_bf16x2(v.x, v.y, h0, l0); split_bf16x2(v.z, v.w, h1, l1);
     float4 r;
-    r.x = __uint_as_float((h0 << 16) | (l0 & 0xffffu));
-    r.y = __uint_as_float((h0 & 0xffff0000u) | (l0 >> 16));
-    r.z = __uint_as_float((h1 << 16) | (l1 & 0xffffu));
-    r.w = __uint_as_float((h1 & 0xffff0000u) | (l1 >> 16));
+    r.x = __uint_as_float(__builtin_amdgcn_perm(h0, l0, 0x05040100u));      // {hi.lower | lo.lower}   (v_perm_b32: one op per word)
+    r.y = __uint_as_float(__builtin_amdgcn_perm(h0, l0, 0x07060302u));      // {hi.upper | lo.upper}
+    r.z = __uint_as_float(__builtin_amdgcn_perm(h1, l1, 0x05040100u));
+    r.w = __uint_as_float(__builtin_amdgcn_perm(h1, l1, 0x07060302u));
     return r;
 }
 
