@@ -161,7 +161,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     constexpr int KQ = BKT / 4;                        // float4 quads per tile row along k
     constexpr int SA = BM * KQ, SB = BN * KQ;          // staging slots (float4) of the A / B tile
     constexpr int NA = (SA + 255) / 256, NB = (SB + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float smem[2 * BKT * (LDA + LDB)];
+    // SPLIT = 3 (weight-gradient shapes: both operands arrive with k as the SLOW dimension): the tile is stored as bf16 hi / lo PLANES
+    // [k][m] (a staged float4 = four consecutive m -> one 8-byte store per plane) and the MFMA fragments -- 8 consecutive k per lane --
+    // come from the gfx950 transpose read ds_read_b64_tr_b16: a 16-lane group reads a [4 k][16 m] block row-major and every lane
+    // receives one column (probed on hardware: out[lane i][elem j] = in[lane 4j + i/4][elem i%4], tools/probe/tr_probe.hip).  Two such
+    // reads form a 32x32x16 operand with no VALU at all; SPLIT = 1 rebuilt every fragment from packed {hi|lo} words with 8 ds_read_b32
+    // and 8 v_perm_b32 per fragment, in every wave that needed it -- those kernels were VALU-bound.  Same hi / lo values, same MFMA
+    // order: bit-identical to SPLIT = 1.  Plane row strides are = 32 (mod 64) bf16 so that the four k rows of a read hit disjoint banks.
+    constexpr bool PLANES = SPLIT == 3;
+    static_assert(!PLANES || (AMODE == A_MC && BMODE != B_KC && BKT == 16), "plane staging serves the k-slow operand layouts");
+    constexpr int LDPA = (BM % 64 == 0) ? BM + 32 : BM, LDPB = (BN % 64 == 0) ? BN + 32 : BN;      // bf16 elements
+    constexpr int PL_BUF = 2 * BKT * (LDPA + LDPB);                                                // per buffer: A hi, A lo, B hi, B lo
+    constexpr int SMEM_F32 = 2 * BKT * (LDA + LDB), SMEM_PL = (2 * PL_BUF + 1) / 2;
+    __shared__ __attribute__((aligned(16))) float smem[PLANES ? (SMEM_PL > 16 * BM ? SMEM_PL : 16 * BM) : SMEM_F32];
     float* As = smem;                      // [2][BKT][LDA]
     float* Bs = smem + 2 * BKT * LDA;      // [2][BKT][LDB]
 
@@ -301,6 +313,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) { bsum[i].x += ra[i].x; bsum[i].y += ra[i].y; bsum[i].z += ra[i].z; bsum[i].w += ra[i].w; }
         }
+        if constexpr (PLANES) {
+            unsigned short* pl = reinterpret_cast<unsigned short*>(smem) + buf * PL_BUF;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                if (!(tid + i * 256 < SA)) continue;
+                uint2 h, l;
+                split_bf16x2(ra[i].x, ra[i].y, h.x, l.x); split_bf16x2(ra[i].z, ra[i].w, h.y, l.y);
+                unsigned short* d = pl + a_r[i] * LDPA + a_c[i];
+                *reinterpret_cast<uint2*>(d) = h;
+                *reinterpret_cast<uint2*>(d + BKT * LDPA) = l;
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (!(tid + i * 256 < SB)) continue;
+                uint2 h, l;
+                split_bf16x2(rb[i].x, rb[i].y, h.x, l.x); split_bf16x2(rb[i].z, rb[i].w, h.y, l.y);
+                unsigned short* d = pl + 2 * BKT * LDPA + b_r[i] * LDPB + b_c[i];
+                *reinterpret_cast<uint2*>(d) = h;
+                *reinterpret_cast<uint2*>(d + BKT * LDPB) = l;
+            }
+            return;
+        }
         if (SPLIT) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) ra[i] = pack_hilo4(ra[i]);
@@ -348,7 +382,38 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         if (kt + 1 < nk) load_tile(kt + 1);
         const float* as = As + cur * BKT * LDA + wm * (32 * MI) + l31;
         const float* bs = Bs + cur * BKT * LDB + wn * (32 * NI) + l31;
-        if constexpr (!SPLIT) {
+        if constexpr (PLANES) {
+            typedef short s16x4_t __attribute__((ext_vector_type(4)));
+            typedef short s16x8_t __attribute__((ext_vector_type(8)));
+            typedef __attribute__((address_space(3))) s16x4_t* lds4_t;
+            const int g4 = lane >> 4, q16 = lane & 15;
+            const int krow = 8 * (g4 >> 1) + (q16 >> 2), moff = 16 * (g4 & 1) + 4 * (q16 & 3);
+            const unsigned short* pl = reinterpret_cast<const unsigned short*>(smem) + cur * PL_BUF;
+            auto frag = [&](const unsigned short* ptr, int ld) {      // k rows krow .. krow+3 and krow+4 .. krow+7 of this lane's k half
+                const s16x4_t f0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(__attribute__((address_space(3))) const unsigned short*)ptr);
+                const s16x4_t f1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(__attribute__((address_space(3))) const unsigned short*)(ptr + 4 * ld));
+                return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(f0, f1, 0, 1, 2, 3, 4, 5, 6, 7));
+            };
+            bf16x8_t ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const unsigned short* pa = pl + krow * LDPA + wm * (32 * MI) + i * 32 + moff;
+                ah[i] = frag(pa, LDPA); al[i] = frag(pa + BKT * LDPA, LDPA);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const unsigned short* pb = pl + 2 * BKT * LDPA + krow * LDPB + wn * (32 * NI) + j * 32 + moff;
+                bh[j] = frag(pb, LDPB); bl[j] = frag(pb + BKT * LDPB, LDPB);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        } else if constexpr (!SPLIT) {
 #pragma unroll
             for (int kk = 0; kk < BKT / 2; ++kk) {
                 float a[MI], b[NI];
@@ -677,6 +742,7 @@ static int g_x3 = 0;      // split-bf16 core: OPT-IN (ha2g_gemm_set_mode(1)).  I
                           // with >= 64 channels but ~10x noisier than the fp32 MFMA chain (4e-6 vs 4e-7 rms-rel per GEMM), which the
                           // reference-derived parity tolerances of the deep audio encoder do not absorb -> exact fp32 is the default.
 
+static int g_wgrad_planes = 1;      // weight-gradient shapes: bf16 planes + transpose reads (SPLIT = 3) instead of packed words (SPLIT = 1); bit-identical
 static int g_wgrad_wide = 1;        // Cout <= 32 weight gradients: one 32 x 384 tile spans all 9*Cin columns (dy tile staged once instead of 3 times)
 static int g_wgrad_blocks = 0;      // 0 = per-shape default (see ha2g_conv2d_wgrad_workspace_bytes); else forced target
 static int g_split_tiles = 192;   // swept on the full step: <=100 is 5-30 % slower, >=192 flat
@@ -788,7 +854,12 @@ int launch(const GemmP& p, hipStream_t st) {
         if (g_bf16 && !use_x3 && p.kchunk >= 32) {
             hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 2>), grid, dim3(256), 0, st, p);
             use_split = true;
-        } else if constexpr (WGRAD_SHAPE || DGRAD_DENSE || AMODE == A_IM) {
+        } else if constexpr (WGRAD_SHAPE) {
+            if (use_split) {
+                if (g_wgrad_planes) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 3>), grid, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 1>), grid, dim3(256), 0, st, p);
+            }
+        } else if constexpr (DGRAD_DENSE || AMODE == A_IM) {
             if (use_split) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 1>), grid, dim3(256), 0, st, p);
         }
     }
@@ -963,7 +1034,7 @@ void ha2g_gemm_set_mode(int mode) { g_x3 = mode & 1; g_split_wgrad = (mode >> 1)
 void ha2g_gemm_debug_x6_min_n(int n) { g_x6_min_n = n; }
 void ha2g_gemm_debug_tile(int cfg, int splits) { g_tile_model = cfg != -2; g_tile_force = cfg == -2 ? -1 : cfg; g_splits_force = splits; }
 void ha2g_conv_debug_direct_c32(int on) { g_direct_c32 = on & 1; g_direct_c32_dgrad = (on >> 1) & 1; g_direct_c32_x3 = !((on >> 2) & 1); g_c32_dbg = on & 0x30; }
-void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 20000) g_wgrad_wide = cfg - 20000; else if (cfg >= 10000) g_wgrad_blocks = cfg - 10000; else if (cfg >= 1000) g_split_tiles = cfg - 1000; else g_conv_cfg = cfg; }   /* 1000+n: split-K tile threshold n; 10000+n: wgrad block target n */
+void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 30000) g_wgrad_planes = cfg - 30000; else if (cfg >= 20000) g_wgrad_wide = cfg - 20000; else if (cfg >= 10000) g_wgrad_blocks = cfg - 10000; else if (cfg >= 1000) g_split_tiles = cfg - 1000; else g_conv_cfg = cfg; }   /* 1000+n: split-K tile threshold n; 10000+n: wgrad block target n */
 
 // Dense GEMM, row-major.  transa/transb follow BLAS meaning on row-major storage:
 //   transa = 0: A is [M,K] (lda >= K);  1: A is stored [K,M] (lda >= M)

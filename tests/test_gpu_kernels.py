@@ -563,3 +563,49 @@ def test_grouped_gemm_matches_per_group_launches(case):
         ops.gemm(a[0], b[0], transa=ta, transb=tb, out=one, beta=1.0, bias=None if bias is None else bias[0], act=act,
                  **(dict(colsum_out=one_cs, colsum_beta=1.0) if wgrad else {}))
         assert torch.equal(one, got[0])
+
+
+@pytest.mark.gpu
+def test_plane_staged_weight_gradients_are_bit_identical_to_the_packed_word_kernel():
+    """SPLIT = 3 (bf16 hi / lo planes + ds_read_b64_tr_b16 transpose reads, the default for weight-gradient shapes) against SPLIT = 1 (packed
+    {hi|lo} words rebuilt into fragments with VALU ops): same split values, same MFMA order -> torch.equal; dense (every tile shape the rule
+    can pick, with the fused bias gradient), grouped, and the implicit-GEMM convolution weight gradients of every channel width."""
+    from ha2g_amd import ops, wav_engine as we
+    from ha2g_amd._lib import lib
+    g = torch.Generator(device='cuda:0').manual_seed(77)
+
+    def both(fn):
+        out = []
+        for planes in (0, 1):
+            lib.ha2g_conv_debug_cfg(30000 + planes)
+            out.append(fn())
+        lib.ha2g_conv_debug_cfg(30001)
+        return out
+    try:
+        for (M, N, K) in [(300, 600, 4352), (900, 600, 4352), (150, 300, 4352), (64, 16, 1000), (32, 288, 2048), (600, 300, 13056), (27, 150, 4352)]:
+            dy, x = torch.randn(K, M, device='cuda:0', generator=g), torch.randn(K, N, device='cuda:0', generator=g)
+
+            def run():
+                w, b = torch.zeros(M, N, device='cuda:0'), torch.zeros(M, device='cuda:0')
+                if M % 4 == 0:
+                    ops.gemm(dy, x, transa=True, out=w, colsum_out=b)
+                else:
+                    ops.gemm(dy, x, transa=True, out=w)
+                return w, b
+            (w0, b0), (w1, b1) = both(run)
+            assert torch.equal(w0, w1) and torch.equal(b0, b1), (M, N, K)
+            ref = dy.double().t() @ x.double()
+            assert float((w1.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+        a = torch.randn(3, 4352, 300, device='cuda:0', generator=g); b = torch.randn(3, 4352, 600, device='cuda:0', generator=g)
+        o0, o1 = both(lambda: ops.gemm_grouped(a, b, transa=True))
+        assert torch.equal(o0, o1)
+        for (N, H, W, Cin, Cout, stride) in [(4, 128, 70, 32, 32, 1), (4, 64, 35, 64, 64, 1), (4, 32, 18, 128, 128, 1), (4, 16, 9, 256, 256, 1),
+                                             (4, 128, 70, 32, 64, 2)]:
+            x = torch.randn(N, H, W, Cin, device='cuda:0', generator=g)
+            OH, OW = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+            dy = torch.randn(N, OH, OW, Cout, device='cuda:0', generator=g)
+            w0 = torch.empty(Cout, 3, 3, Cin, device='cuda:0')
+            d0, d1 = both(lambda: we.conv_wgrad(x, dy, w0, stride, 1).clone())
+            assert torch.equal(d0, d1), (Cin, Cout, stride)
+    finally:
+        lib.ha2g_conv_debug_cfg(30001)
