@@ -169,9 +169,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     // and 8 v_perm_b32 per fragment, in every wave that needed it -- those kernels were VALU-bound.  Same hi / lo values, same MFMA
     // order: bit-identical to SPLIT = 1.  Plane row strides are = 32 (mod 64) bf16 so that the four k rows of a read hit disjoint banks.
     constexpr bool PLANES = SPLIT == 3;
-    static_assert(!PLANES || (AMODE == A_MC && BMODE != B_KC && BKT == 16), "plane staging serves the k-slow operand layouts");
+    // A k-contiguous operand (A_KC: the dense data gradients dX = dY W) keeps [m][k] planes read with plain 16-byte loads (row stride 24
+    // bf16: 16 consecutive rows hit 16 distinct 16-byte slots); its n-contiguous B goes through the transpose reads like above.
+    static_assert(!PLANES || (AMODE != A_IM && BMODE != B_KC && BKT == 16), "plane staging: A_MC / A_KC with a k-slow B operand");
     constexpr int LDPA = (BM % 64 == 0) ? BM + 32 : BM, LDPB = (BN % 64 == 0) ? BN + 32 : BN;      // bf16 elements
-    constexpr int PL_BUF = 2 * BKT * (LDPA + LDPB);                                                // per buffer: A hi, A lo, B hi, B lo
+    constexpr int LDKA = BKT + 8;                                                                  // A_KC: [m][k] plane row
+    constexpr int PLA = AMODE == A_MC ? BKT * LDPA : BM * LDKA;                                    // one A plane
+    constexpr int PL_BUF = 2 * PLA + 2 * BKT * LDPB;                                               // per buffer: A hi, A lo, B hi, B lo
     constexpr int SMEM_F32 = 2 * BKT * (LDA + LDB), SMEM_PL = (2 * PL_BUF + 1) / 2;
     __shared__ __attribute__((aligned(16))) float smem[PLANES ? (SMEM_PL > 16 * BM ? SMEM_PL : 16 * BM) : SMEM_F32];
     float* As = smem;                      // [2][BKT][LDA]
@@ -320,16 +324,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 if (!(tid + i * 256 < SA)) continue;
                 uint2 h, l;
                 split_bf16x2(ra[i].x, ra[i].y, h.x, l.x); split_bf16x2(ra[i].z, ra[i].w, h.y, l.y);
-                unsigned short* d = pl + a_r[i] * LDPA + a_c[i];
+                unsigned short* d = pl + (AMODE == A_MC ? a_r[i] * LDPA + a_c[i] : a_r[i] * LDKA + a_c[i]);    // A_KC: four consecutive k of row a_r
                 *reinterpret_cast<uint2*>(d) = h;
-                *reinterpret_cast<uint2*>(d + BKT * LDPA) = l;
+                *reinterpret_cast<uint2*>(d + PLA) = l;
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 if (!(tid + i * 256 < SB)) continue;
                 uint2 h, l;
                 split_bf16x2(rb[i].x, rb[i].y, h.x, l.x); split_bf16x2(rb[i].z, rb[i].w, h.y, l.y);
-                unsigned short* d = pl + 2 * BKT * LDPA + b_r[i] * LDPB + b_c[i];
+                unsigned short* d = pl + 2 * PLA + b_r[i] * LDPB + b_c[i];
                 *reinterpret_cast<uint2*>(d) = h;
                 *reinterpret_cast<uint2*>(d + BKT * LDPB) = l;
             }
@@ -397,12 +401,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
             bf16x8_t ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const unsigned short* pa = pl + krow * LDPA + wm * (32 * MI) + i * 32 + moff;
-                ah[i] = frag(pa, LDPA); al[i] = frag(pa + BKT * LDPA, LDPA);
+                if constexpr (AMODE == A_MC) {
+                    const unsigned short* pa = pl + krow * LDPA + wm * (32 * MI) + i * 32 + moff;
+                    ah[i] = frag(pa, LDPA); al[i] = frag(pa + PLA, LDPA);
+                } else {
+                    const unsigned short* pa = pl + (wm * (32 * MI) + i * 32 + l31) * LDKA + 8 * lhi;
+                    ah[i] = *reinterpret_cast<const bf16x8_t*>(pa); al[i] = *reinterpret_cast<const bf16x8_t*>(pa + PLA);
+                }
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                const unsigned short* pb = pl + 2 * BKT * LDPA + krow * LDPB + wn * (32 * NI) + j * 32 + moff;
+                const unsigned short* pb = pl + 2 * PLA + krow * LDPB + wn * (32 * NI) + j * 32 + moff;
                 bh[j] = frag(pb, LDPB); bl[j] = frag(pb + BKT * LDPB, LDPB);
             }
 #pragma unroll
@@ -859,7 +868,12 @@ int launch(const GemmP& p, hipStream_t st) {
                 if (g_wgrad_planes) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 3>), grid, dim3(256), 0, st, p);
                 else hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 1>), grid, dim3(256), 0, st, p);
             }
-        } else if constexpr (DGRAD_DENSE || AMODE == A_IM) {
+        } else if constexpr (DGRAD_DENSE) {
+            if (use_split) {
+                if (g_wgrad_planes) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 3>), grid, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 1>), grid, dim3(256), 0, st, p);
+            }
+        } else if constexpr (AMODE == A_IM) {
             if (use_split) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 1>), grid, dim3(256), 0, st, p);
         }
     }

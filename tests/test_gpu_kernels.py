@@ -599,6 +599,16 @@ def test_plane_staged_weight_gradients_are_bit_identical_to_the_packed_word_kern
         a = torch.randn(3, 4352, 300, device='cuda:0', generator=g); b = torch.randn(3, 4352, 600, device='cuda:0', generator=g)
         o0, o1 = both(lambda: ops.gemm_grouped(a, b, transa=True))
         assert torch.equal(o0, o1)
+        # dense data gradients dX = dY W (k-contiguous A in [m][k] planes with plain 16-byte reads, n-contiguous B through the transpose reads)
+        for (M, N, K) in [(4352, 600, 900), (4352, 600, 300), (7168, 128, 192), (1000, 300, 152), (136, 900, 600), (4352, 32, 300)]:
+            dy, w = torch.randn(M, K, device='cuda:0', generator=g), torch.randn(K, N, device='cuda:0', generator=g)
+            d0, d1 = both(lambda: ops.gemm(dy, w))
+            assert torch.equal(d0, d1), (M, N, K)
+            ref = dy.double() @ w.double()
+            assert float((d1.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+        w3 = [torch.randn(300, 600, device='cuda:0', generator=g) for _ in range(3)]
+        o0, o1 = both(lambda: ops.gemm_grouped(a, w3))
+        assert torch.equal(o0, o1)
         for (N, H, W, Cin, Cout, stride) in [(4, 128, 70, 32, 32, 1), (4, 64, 35, 64, 64, 1), (4, 32, 18, 128, 128, 1), (4, 16, 9, 256, 256, 1),
                                              (4, 128, 70, 32, 64, 2)]:
             x = torch.randn(N, H, W, Cin, device='cuda:0', generator=g)
