@@ -339,6 +339,141 @@ __global__ __launch_bounds__(X3Geo<C>::THREADS, 1) void conv3x3_x3_kernel(const 
     }
 }
 
+
+// ---- direct weight gradient, 32 -> 32 channels, 3x3 / stride 1 / pad 1 (split-bf16) ---------------------------------------------------
+// dW[co][tap][ci] = sum over pixels of dy[p][co] * x[p + tap][ci].  The implicit GEMM stages the im2col gather of x -- the same patch nine
+// times, for only 32 rows of reuse -- and is bound by that staging (237 us at B = 128).  Here a tile is 128 consecutive pixels of one image:
+// its x patch (rows + halo, zero padding) and its dy strip are stored ONCE as bf16 hi / lo planes [pixel][32 channels], and every fragment
+// is a pair of transpose reads (ds_read_b64_tr_b16, see gemm.hip SPLIT = 3): the dy fragment (A: co x 16 pixels) is shared by the nine
+// taps, the x fragment of tap t is the same read at a row offset of (kh * PW + kw) patch pixels.  Each wave owns 32 pixels of the tile and
+// nine 32 x 32 accumulators (144 AGPRs) that live across all tiles of its persistent workgroup; at the end the four waves are added in
+// wave order through LDS and the workgroup writes ONE partial [32][9][32]; gemm.hip's wide split-K reduce adds the partials in double.
+constexpr int WG_TP = 128, WG_NT = 256;
+
+__global__ __launch_bounds__(WG_NT, 2) void conv3x3_c32_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                     float* __restrict__ part, int N, int H, int W, int plane_elems) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short wpl[];        // [x hi][x lo][dy hi][dy lo]
+    typedef short s16x4_t __attribute__((ext_vector_type(4)));
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) s16x4_t* lds4_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5, g4 = lane >> 4, q16 = lane & 15;
+    const int krow = 8 * (g4 >> 1) + (q16 >> 2), moff = 16 * (g4 & 1) + 4 * (q16 & 3);
+    const int HW = H * W, PW = W + 2;
+    const int tpi = (HW + WG_TP - 1) / WG_TP;
+    const long tiles = (long)N * tpi;
+    unsigned short* xh = wpl;
+    unsigned short* xl = wpl + plane_elems;
+    unsigned short* dh = wpl + 2 * plane_elems;
+    unsigned short* dl = dh + WG_TP * CH;
+    auto tr = [](const unsigned short* ptr) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(__attribute__((address_space(3))) const unsigned short*)ptr);
+    };
+    auto frag = [&](const unsigned short* p0, const unsigned short* p1) {      // k rows krow..krow+3 (p0) and krow+4..krow+7 (p1)
+        return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(tr(p0), tr(p1), 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        Tile cur;
+        cur.img = (int)(tile / tpi); cur.p0 = (int)(tile % tpi) * WG_TP;
+        const int pend = min(cur.p0 + WG_TP, HW);
+        cur.r0 = cur.p0 / W;
+        cur.rows = (pend - 1) / W - cur.r0 + 3;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // the previous tile's fragment reads are done
+        {   // x patch: slot = (padded pixel, channel quad); a thread's slots are 32 padded pixels apart
+            const int c4 = tid & 7;
+            int pp = tid >> 3;
+            int pr = pp / PW, px = pp - pr * PW;
+            long g = ((long)cur.img * HW + (long)(cur.r0 - 1 + pr) * W + (px - 1)) * CH + 4 * c4;
+            while (pr < cur.rows) {
+                constexpr int NS = 4;
+                float4 v[NS]; int off[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    off[i] = -1;
+                    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (pr < cur.rows) {
+                        const int gy = cur.r0 - 1 + pr;
+                        if (gy >= 0 && gy < H && px >= 1 && px <= W) v[i] = *reinterpret_cast<const float4*>(x + g);
+                        off[i] = pp * CH + 4 * c4;
+                    }
+                    pp += 32; px += 32; g += 32L * CH;
+                    while (px >= PW) { px -= PW; ++pr; g -= 2 * CH; }
+                }
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+                    if (off[i] >= 0) {
+                        uint2 h, l;
+                        split2(v[i].x, v[i].y, h.x, l.x); split2(v[i].z, v[i].w, h.y, l.y);
+                        *reinterpret_cast<uint2*>(xh + off[i]) = h;
+                        *reinterpret_cast<uint2*>(xl + off[i]) = l;
+                    }
+            }
+            // dy strip: 128 pixels x 8 quads = 4 slots per thread; rows past the image end are zeros (their products vanish)
+            float4 d[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pix = (tid >> 3) + 32 * i, p = cur.p0 + pix;
+                d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < HW) d[i] = *reinterpret_cast<const float4*>(dy + ((long)cur.img * HW + p) * CH + 4 * c4);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = ((tid >> 3) + 32 * i) * CH + 4 * c4;
+                uint2 h, l;
+                split2(d[i].x, d[i].y, h.x, l.x); split2(d[i].z, d[i].w, h.y, l.y);
+                *reinterpret_cast<uint2*>(dh + o) = h;
+                *reinterpret_cast<uint2*>(dl + o) = l;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int pb = 32 * wave + 16 * ch + krow;                           // this lane's two tile-local pixels: pb and pb + 4
+            const bf16x8_t ah = frag(dh + pb * CH + moff, dh + (pb + 4) * CH + moff);
+            const bf16x8_t al = frag(dl + pb * CH + moff, dl + (pb + 4) * CH + moff);
+            int p0 = cur.p0 + pb, p1 = p0 + 4;
+            if (p0 >= HW) p0 = HW - 1;                                           // clamp: stays inside the patch; dy is zero there
+            if (p1 >= HW) p1 = HW - 1;
+            const int y0 = p0 / W, y1 = p1 / W;
+            const int r0 = ((y0 - cur.r0) * PW + (p0 - y0 * W)) * CH + moff;     // tap (0,0) = the pixel above-left (halo included)
+            const int r1 = ((y1 - cur.r0) * PW + (p1 - y1 * W)) * CH + moff;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int toff = ((t / 3) * PW + (t % 3)) * CH;
+                const bf16x8_t bh = frag(xh + r0 + toff, xh + r1 + toff);
+                const bf16x8_t bl = frag(xl + r0 + toff, xl + r1 + toff);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the four waves' accumulators, added in wave order through LDS; one partial [co][tap][ci] per workgroup ----
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(wpl);                                  // 9216 floats
+    for (int w = 0; w < WG_NT / 64; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    float* d = red + (co * 9 + t) * CH + l31;
+                    *d = (w == 0 ? 0.f : *d) + acc[t][r];
+                }
+        }
+        __syncthreads();
+    }
+    float* out = part + (long)blockIdx.x * 9 * CH * CH;
+    for (int e = tid; e < 9 * CH * CH / 4; e += WG_NT) reinterpret_cast<float4*>(out)[e] = reinterpret_cast<const float4*>(red)[e];
+}
+
 }  // namespace
 
 // x [N][H][W][32], w [32][3][3][32] (n, tap, k), y [N][H][W][32] = act(beta*y + conv3x3(x, w)); flip = 1 visits the taps in
@@ -388,4 +523,31 @@ static int conv3x3_x3_launch_t(const float* x, const float* w, float* y, int N, 
 }
 int conv3x3_c32_x3_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st) {
     return conv3x3_x3_launch_t<32>(x, w, y, N, H, W, flip, act, beta, st);
+}
+
+// dW partials of the direct 32-channel weight gradient: returns the number of partial [32][9][32] blocks written to `part` (the caller
+// reduces them), -100 when the shape does not fit (caller falls back to the implicit GEMM), < 0 on error.
+int conv3x3_c32_wgrad_blocks(int N, int H, int W) {
+    const long tiles = (long)N * (((long)H * W + WG_TP - 1) / WG_TP);
+    int cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) { int c = 0; if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) cus = c; }
+    return (int)(tiles < 2L * cus ? tiles : 2L * cus);
+}
+int conv3x3_c32_wgrad_launch(const float* x, const float* dy, float* part, int N, int H, int W, hipStream_t st) {
+    const int rows_max = (WG_TP + W - 2) / W + 1 + 2;
+    const int plane_elems = rows_max * (W + 2) * CH;
+    size_t lds = ((size_t)2 * plane_elems + 2 * WG_TP * CH) * sizeof(unsigned short);
+    if (lds < 9 * CH * CH * sizeof(float)) lds = 9 * CH * CH * sizeof(float);
+    if (lds > 78 * 1024 || (long)H * W < WG_TP || W + 2 <= 32) return -100;           // two workgroups per CU; 32 padded pixels between a thread's slots
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 78 * 1024) != hipSuccess)
+            return ha2g_set_error(-2, "conv3x3_c32_wgrad: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    const int grid = conv3x3_c32_wgrad_blocks(N, H, W);
+    hipLaunchKernelGGL(conv3x3_c32_wgrad_kernel, dim3(grid), dim3(WG_NT), lds, st, x, dy, part, N, H, W, plane_elems);
+    HA2G_CHECK_LAUNCH("conv3x3_c32_wgrad");
+    return grid;
 }

@@ -751,6 +751,7 @@ static int g_x3 = 0;      // split-bf16 core: OPT-IN (ha2g_gemm_set_mode(1)).  I
                           // with >= 64 channels but ~10x noisier than the fp32 MFMA chain (4e-6 vs 4e-7 rms-rel per GEMM), which the
                           // reference-derived parity tolerances of the deep audio encoder do not absorb -> exact fp32 is the default.
 
+static int g_direct_c32_wgrad = 1;  // 32 -> 32 channel 3x3 weight gradients on the direct transpose-read kernel (conv_c32.hip); ha2g_conv_debug_cfg(40000) = off
 static int g_wgrad_planes = 1;      // weight-gradient shapes: bf16 planes + transpose reads (SPLIT = 3) instead of packed words (SPLIT = 1); bit-identical
 static int g_wgrad_wide = 1;        // Cout <= 32 weight gradients: one 32 x 384 tile spans all 9*Cin columns (dy tile staged once instead of 3 times)
 static int g_wgrad_blocks = 0;      // 0 = per-shape default (see ha2g_conv2d_wgrad_workspace_bytes); else forced target
@@ -1048,7 +1049,7 @@ void ha2g_gemm_set_mode(int mode) { g_x3 = mode & 1; g_split_wgrad = (mode >> 1)
 void ha2g_gemm_debug_x6_min_n(int n) { g_x6_min_n = n; }
 void ha2g_gemm_debug_tile(int cfg, int splits) { g_tile_model = cfg != -2; g_tile_force = cfg == -2 ? -1 : cfg; g_splits_force = splits; }
 void ha2g_conv_debug_direct_c32(int on) { g_direct_c32 = on & 1; g_direct_c32_dgrad = (on >> 1) & 1; g_direct_c32_x3 = !((on >> 2) & 1); g_c32_dbg = on & 0x30; }
-void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 30000) g_wgrad_planes = cfg - 30000; else if (cfg >= 20000) g_wgrad_wide = cfg - 20000; else if (cfg >= 10000) g_wgrad_blocks = cfg - 10000; else if (cfg >= 1000) g_split_tiles = cfg - 1000; else g_conv_cfg = cfg; }   /* 1000+n: split-K tile threshold n; 10000+n: wgrad block target n */
+void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 40000) g_direct_c32_wgrad = cfg - 40000; else if (cfg >= 30000) g_wgrad_planes = cfg - 30000; else if (cfg >= 20000) g_wgrad_wide = cfg - 20000; else if (cfg >= 10000) g_wgrad_blocks = cfg - 10000; else if (cfg >= 1000) g_split_tiles = cfg - 1000; else g_conv_cfg = cfg; }   /* 1000+n: split-K tile threshold n; 10000+n: wgrad block target n */
 
 // Dense GEMM, row-major.  transa/transb follow BLAS meaning on row-major storage:
 //   transa = 0: A is [M,K] (lda >= K);  1: A is stored [K,M] (lda >= M)
@@ -1183,7 +1184,12 @@ long ha2g_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, i
     long splits = (target + tiles - 1) / tiles;
     if (splits > K / 256) splits = K / 256;
     if (splits < 1) splits = 1;
-    return splits * MN * 4;
+    long bytes = splits * MN * 4;
+    if (Cin == 32 && Cout == 32 && KH == 3 && KW == 3 && stride == 1 && pad == 1) {          // direct kernel: one partial per workgroup
+        const long direct = (long)conv3x3_c32_wgrad_blocks(N, H, W) * MN * 4;
+        if (direct > bytes) bytes = direct;
+    }
+    return bytes;
 }
 
 int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout, int KH,
@@ -1196,6 +1202,30 @@ int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int
     p.g = ConvGeom{H, W, Cin, OH, OW, KH, KW, stride, pad, 0};
     long need = ha2g_conv2d_wgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad);
     long MN = (long)p.M * p.N;
+    hipStream_t st0 = (hipStream_t)stream;
+    if (g_direct_c32_wgrad && g_split_wgrad && !g_bf16 && Cin == 32 && Cout == 32 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && ws &&
+        ws_bytes >= need) {
+        const int nblk = conv3x3_c32_wgrad_launch(x, dy, ws, N, H, W, st0);
+        if (nblk != -100) {
+            if (nblk < 0) return nblk;
+            ReduceOut ro{};
+            ro.groups = 1; ro.C[0] = dw;
+            hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(ceil_div(MN, 64), 1), dim3(256), 0, st0, ws, nblk, MN, p.N, ro, p.ldc, 1.f, beta, 0, 0.f,
+                               p.M);
+            HA2G_CHECK_LAUNCH("conv3x3_c32_wgrad reduce");
+            return 0;
+        }
+    }
+    {   // the implicit GEMM's own split count (the direct kernel may have asked for a larger workspace)
+        int BM = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
+        const bool wide = g_wgrad_wide && Cout <= 32 && KH * KW * Cin <= 384;
+        long tiles = (long)ceil_div(Cout, BM) * ceil_div(KH * KW * Cin, wide ? 384 : 128);
+        const long target = g_wgrad_blocks > 0 ? g_wgrad_blocks : (wide ? 512 : (Cout <= 32 ? 1536 : (Cout <= 64 ? 1024 : 768)));
+        long sp = (target + tiles - 1) / tiles;
+        if (sp > (long)p.K / 256) sp = p.K / 256;
+        if (sp < 1) sp = 1;
+        need = sp * MN * 4;
+    }
     int splits = (int)(need / (MN * 4));
     HA2G_REQUIRE(splits == 1 || (ws && ws_bytes >= need), "conv2d_wgrad: workspace too small (%ld < %ld)", ws_bytes, need);
     int kc = ceil_div(p.K, splits);

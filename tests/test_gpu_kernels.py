@@ -619,3 +619,37 @@ def test_plane_staged_weight_gradients_are_bit_identical_to_the_packed_word_kern
             assert torch.equal(d0, d1), (Cin, Cout, stride)
     finally:
         lib.ha2g_conv_debug_cfg(30001)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(4, 128, 70), (3, 13, 70), (2, 16, 64), (1, 9, 35), (5, 64, 35)])
+def test_direct_c32_weight_gradient(shape):
+    """conv_c32.hip's direct 32-channel weight gradient (patch + dy strip as bf16 planes, transpose-read fragments, nine taps share one dy
+    fragment) against float64 autograd and against the implicit GEMM it replaces; ragged last tile, tiles that straddle many image rows, a map
+    too small for the kernel (falls back), accumulation into an existing gradient."""
+    import torch.nn.functional as F
+    from ha2g_amd import wav_engine as we
+    from ha2g_amd._lib import lib
+    N, H, W = shape
+    g = torch.Generator(device='cuda:0').manual_seed(H * W)
+    x = torch.randn(N, H, W, 32, device='cuda:0', generator=g)
+    dy = torch.randn(N, H, W, 32, device='cuda:0', generator=g)
+    w0 = torch.empty(32, 3, 3, 32, device='cuda:0')
+    xd = x.permute(0, 3, 1, 2).double()
+    wd = torch.zeros(32, 32, 3, 3, dtype=torch.float64, device='cuda:0', requires_grad=True)
+    (F.conv2d(xd, wd, padding=1) * dy.permute(0, 3, 1, 2).double()).sum().backward()
+    ref = wd.grad
+    outs = {}
+    try:
+        for direct in (1, 0):
+            lib.ha2g_conv_debug_cfg(40000 + direct)
+            outs[direct] = we.conv_wgrad(x, dy, w0, 1, 1).clone()
+    finally:
+        lib.ha2g_conv_debug_cfg(40001)
+    scale = float(ref.abs().max())
+    for direct in (1, 0):
+        assert float((outs[direct].double() - ref).abs().max()) <= 2e-5 * scale, direct
+    acc = torch.randn(32, 32, 3, 3, device='cuda:0', generator=g).contiguous(memory_format=torch.channels_last)
+    base = acc.clone()
+    we.conv_wgrad(x, dy, w0, 1, 1, into=acc)
+    assert float((acc.double() - (base.double() + ref)).abs().max()) <= 2e-5 * scale

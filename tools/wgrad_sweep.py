@@ -18,7 +18,7 @@ for H, W, C in ((128, 70, 32), (64, 35, 64), (32, 18, 128), (16, 9, 256)):
     dy = torch.randn(B, H, W, C, device=dev)
     fl = 2.0 * B * H * W * C * C * 9
     row = []
-    for nb in (384, 512, 768, 1024, 1536, 2048):
+    for nb in (0, 256, 384, 512, 768, 1024, 1536, 2048):
         lib.ha2g_conv_debug_cfg(10000 + nb)
         try:
             t = timeit(lambda: we.conv_wgrad(x, dy, w, 1, 1))
