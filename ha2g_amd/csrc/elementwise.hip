@@ -216,7 +216,7 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
 // mask[i] = keep ? 1/(1-p) : 0 ; out = x * mask.  state = {seed, step} lives in device memory so a captured
 // hipGraph draws fresh masks on every replay; `stream_id` separates call sites within a step.
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ out, float* __restrict__ mask, long n, float p,
-                               const unsigned long long* __restrict__ state, unsigned stream_id) {
+                               const unsigned long long* __restrict__ state, unsigned stream_id, int vec) {
     const unsigned long long seed = state[0], step = state[1];
     const float scale = 1.f / (1.f - p);
     const long n4 = (n + 3) >> 2;
@@ -226,14 +226,23 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
         uint32_t rr[4] = {c0, c1, c2, c3};
+        float m[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            long e = i * 4 + j;
-            if (e < n) {
-                float u = (rr[j] >> 8) * (1.0f / 16777216.0f);
-                float m = u >= p ? scale : 0.f;
-                if (mask) mask[e] = m;
-                if (out) out[e] = x[e] * m;
+        for (int j = 0; j < 4; ++j) m[j] = ((rr[j] >> 8) * (1.0f / 16777216.0f)) >= p ? scale : 0.f;
+        if (vec && i * 4 + 3 < n) {                        // 16-byte accesses when the buffers allow it (the common case)
+            if (mask) reinterpret_cast<float4*>(mask)[i] = make_float4(m[0], m[1], m[2], m[3]);
+            if (out) {
+                const float4 v = reinterpret_cast<const float4*>(x)[i];
+                reinterpret_cast<float4*>(out)[i] = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                long e = i * 4 + j;
+                if (e < n) {
+                    if (mask) mask[e] = m[j];
+                    if (out) out[e] = x[e] * m[j];
+                }
             }
         }
     }
@@ -401,8 +410,9 @@ int ha2g_eltwise_f32(int op, const float* a, const float* b, const float* c, flo
 int ha2g_dropout_f32(const float* x, float* out, float* mask, long n, float p, const void* state, unsigned stream_id, void* stream) {
     if (n == 0) return 0;
     HA2G_REQUIRE(p >= 0.f && p < 1.f, "dropout: p=%f out of range", p);
+    const int vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(mask)) & 15) == 0;
     hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n, 4)), dim3(EB), 0, (hipStream_t)stream, x, out, mask, n, p,
-                       (const unsigned long long*)state, stream_id);
+                       (const unsigned long long*)state, stream_id, vec);
     HA2G_CHECK_LAUNCH("dropout");
     return 0;
 }

@@ -220,10 +220,12 @@ class Rng:
     def __init__(self):
         self.state = None
         self.call = 0
+        self.step_token = 0          # host-side count of end_step() / seed() calls: dropout backward checks it re-draws in the same step
 
     def seed(self, device, seed):
         self.state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
         self.call = 0
+        self.step_token += 1
 
     def begin_step(self):
         self.call = 0
@@ -231,6 +233,7 @@ class Rng:
     def end_step(self):
         if self.state is not None:
             check(lib.ha2g_rng_advance(self.state.data_ptr(), _stream()))
+            self.step_token += 1
 
     def next_id(self):
         self.call += 1
@@ -241,20 +244,29 @@ rng = Rng()
 
 
 class DropoutFunction(torch.autograd.Function):
+    """out = x * mask, mask = keep / (1 - p) drawn from the device-resident Philox state keyed by (seed, step, call id, element).  The mask is
+    NOT stored: the backward re-draws it by running the same kernel on dy with the same call id (the state only advances at the end of the
+    step) -- one tensor less written in the forward and read in the backward.  A backward issued after the step counter moved would silently
+    draw a different mask, so that is an error."""
+
     @staticmethod
     def forward(ctx, x, p):
         x = _f32c(x.contiguous())
         if rng.state is None or rng.state.device != x.device:
             rng.seed(x.device, 0x5EED)
-        out, mask = torch.empty_like(x), torch.empty_like(x)
-        check(lib.ha2g_dropout_f32(x.data_ptr(), out.data_ptr(), mask.data_ptr(), x.numel(), p, rng.state.data_ptr(),
-                                   rng.next_id(), _stream()))
-        ctx.save_for_backward(mask)
+        out = torch.empty_like(x)
+        ctx.p, ctx.call, ctx.step_token = p, rng.next_id(), rng.step_token
+        check(lib.ha2g_dropout_f32(x.data_ptr(), out.data_ptr(), None, x.numel(), p, rng.state.data_ptr(), ctx.call, _stream()))
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        return eltwise(OP_MUL, dy.contiguous(), ctx.saved_tensors[0]), None
+        if ctx.step_token != rng.step_token:
+            raise RuntimeError('ha2g_amd dropout: backward after the RNG step advanced (rng.end_step()): the mask cannot be re-drawn')
+        dy = _f32c(dy.contiguous())
+        dx = torch.empty_like(dy)
+        check(lib.ha2g_dropout_f32(dy.data_ptr(), dx.data_ptr(), None, dy.numel(), ctx.p, rng.state.data_ptr(), ctx.call, _stream()))
+        return dx, None
 
 
 def dropout(x, p, training):

@@ -201,6 +201,13 @@ def test_dropout_kernel_statistics_and_masks():
         ops.rng.seed(torch.device(DEV), 77)                                                     # replay: identical
         assert torch.equal(ops.dropout(x, p, True), y)
     assert ops.dropout(x, 0.3, False) is x and ops.dropout(x, 0.0, True) is x
+    # the mask is re-drawn in the backward (not stored): a backward issued after the step counter advanced must fail loudly
+    ops.rng.begin_step()
+    xr = x.clone().requires_grad_(True)
+    y5 = ops.dropout(xr, 0.3, True)
+    ops.rng.end_step()
+    with pytest.raises(RuntimeError):
+        y5.backward(torch.ones_like(y5))
     ops.rng.seed(torch.device(DEV), 0x5EED)
 
 
