@@ -256,6 +256,8 @@ def main():
                         hbm_frac_of_8TBps=round(bytes_ / (mean_us * 1e-6) / 8e12, 4))
         roof = gru_roof('gru_layer_fwd', 'gru_fwd_cluster_kernel (ha2g_gru_layer_fwd_cluster, H=300)', 'r02_pmc_gru_fwd.json', False)
         roof_bwd = gru_roof('gru_layer_bwd', 'gru_bwd_cluster_kernel (ha2g_gru_layer_bwd_cluster, H=300)', 'r02_pmc_gru_bwd.json', True)
+        if roof_bwd is not None:     # the BPTT chain runs on the split-bf16 inner product in the default mode (3 bf16 MFMAs per product term, fp32 accumulate);
+            roof_bwd['arithmetic'] = 'fp32 MFMA' if a.bf16 else 'split-bf16 x3 (fp32-class; frac is still priced against the fp32 MFMA peak)'
         roof_gemm = None
         if 'gemm_gi' in kt:                        # dominant dense-GEMM shape: the GRU input projections (rows x 600) . (600 x 900)^T, fp32 MFMA
             n, mean_us, _, flops = kt['gemm_gi']

@@ -1060,6 +1060,8 @@ static int pick_conv_cfg(int M, int N) {
     return best;
 }
 
+int ha2g_split_dgrad_enabled() { return g_split_dgrad && !g_bf16; }
+
 extern "C" {
 
 /* bit 0: forward GEMMs / convolutions on the split-bf16 core (default 0 = exact fp32: the error compounds through 34 layers

@@ -347,7 +347,32 @@ constexpr int LDG = 3 * 64 + 4;      // LDS row stride of the own d gh tile [16]
 constexpr int LDP = 64 + 4;
 constexpr int NKW = (NJT + TPW - 1) / TPW;             // k-tiles per wave (5): wave w serves k-tiles w, w+4, ... = one per member
 
-template <int Q, int PB>
+// ---- split-bf16 BPTT (ha2g_gemm_set_mode bit 2, the data-gradient class) ------------------------------------------------------------------
+// The 16x16x4 fp32 chain of a k-tile -- for every j-tile four MFMAs whose lanes hold k = 16 jl + 4 g + u, i.e. the lane's float4 -- is the
+// same contraction as ONE v_mfma_f32_16x16x16_bf16 on that float4 as four bf16 (lane (row, g) supplies k = 4 g .. 4 g + 3).  With each
+// fp32 value split into hi = bf16(x), lo = bf16(x - hi) the product runs as w_lo*d_hi + w_hi*d_lo + w_hi*d_hi (fp32 accumulate): 3 x 16
+// cycles instead of 4 x 32 per (gate, j-tile).  The resident weight fragments are split once per launch in place ({hi01, hi23, lo01,
+// lo23} in the four words of the float4: no extra registers), the gate-gradient operands once per step.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bfx2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 split_pack4(const float4 v) {
+    const f32x2_t a = {v.x, v.y}, b = {v.z, v.w};
+    const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bfx2_t)), h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bfx2_t));
+    const f32x2_t ra = {v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u)};
+    const f32x2_t rb = {v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u)};
+    const unsigned l0 = __builtin_bit_cast(unsigned, __builtin_convertvector(ra, bfx2_t)), l1 = __builtin_bit_cast(unsigned, __builtin_convertvector(rb, bfx2_t));
+    return make_float4(__uint_as_float(h0), __uint_as_float(h1), __uint_as_float(l0), __uint_as_float(l1));
+}
+__device__ __forceinline__ s16x4_t hi_of(const float4& p) { return __builtin_bit_cast(s16x4_t, make_float2(p.x, p.y)); }
+__device__ __forceinline__ s16x4_t lo_of(const float4& p) { return __builtin_bit_cast(s16x4_t, make_float2(p.z, p.w)); }
+__device__ __forceinline__ f32x4 mfma3_bf16(const float4& w, const float4& d, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(lo_of(w), hi_of(d), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi_of(w), lo_of(d), acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi_of(w), hi_of(d), acc, 0, 0, 0);
+}
+
+template <int Q, int PB, bool SPL>
 __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ rs,
                                                const float* __restrict__ wpt, float* __restrict__ dg, float* __restrict__ hpo, const __amdgpu_buffer_rsrc_t xr,
                                                int* __restrict__ err, const int B, const int T, const int dir, const int b0,
@@ -375,7 +400,7 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
                     const int kt = wave + kk * TPW, jt = Q * TPW + jl;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (kt < NJT && jt < NJT) v = base[((long)(kt * 3 + gate) * NJT + jt) * 64];
-                    wf[(kk * 3 + gate) * TPW + jl] = v;
+                    wf[(kk * 3 + gate) * TPW + jl] = SPL ? split_pack4(v) : v;
                 }
     }
     const int fast = (dbg & 4) ? (cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh), 0) : cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh);
@@ -410,10 +435,16 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
             const float* w0 = &wf[((KK) * 3 + 0) * TPW + jl].x; const float* w1 = &wf[((KK) * 3 + 1) * TPW + jl].x; \
             const float* w2 = &wf[((KK) * 3 + 2) * TPW + jl].x;                                                   \
             const float* d0 = &bop[jl].x; const float* d1 = &bop[TPW + jl].x; const float* d2 = &bop[2 * TPW + jl].x; \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                       \
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[u], d0[u], a0, 0, 0, 0);                             \
-                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[u], d1[u], a1, 0, 0, 0);                             \
-                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[u], d2[u], a2, 0, 0, 0);                             \
+            if constexpr (SPL) {                                                                                  \
+                a0 = mfma3_bf16(wf[((KK) * 3 + 0) * TPW + jl], bop[jl], a0);                                      \
+                a1 = mfma3_bf16(wf[((KK) * 3 + 1) * TPW + jl], bop[TPW + jl], a1);                                \
+                a2 = mfma3_bf16(wf[((KK) * 3 + 2) * TPW + jl], bop[2 * TPW + jl], a2);                            \
+            } else {                                                                                              \
+                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                   \
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[u], d0[u], a0, 0, 0, 0);                         \
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[u], d1[u], a1, 0, 0, 0);                         \
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[u], d2[u], a2, 0, 0, 0);                         \
+                }                                                                                                 \
             }                                                                                                     \
         }                                                                                                         \
         const float p0 = a0[0] + a1[0] + a2[0], p1 = a0[1] + a1[1] + a2[1], p2 = a0[2] + a1[2] + a2[2], p3 = a0[3] + a1[3] + a2[3]; \
@@ -467,7 +498,10 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
-            for (int jl = 0; jl < TPW; ++jl) bop[gate * TPW + jl] = *reinterpret_cast<const float4*>(&sg[lb * LDG + gate * 64 + 16 * jl + 4 * g]);
+            for (int jl = 0; jl < TPW; ++jl) {
+                const float4 v = *reinterpret_cast<const float4*>(&sg[lb * LDG + gate * 64 + 16 * jl + 4 * g]);
+                bop[gate * TPW + jl] = SPL ? split_pack4(v) : v;
+            }
         const unsigned tag = tag0 + (unsigned)(s + 1);
         HA2G_BWD_KTILE((Q + 1) % G)
         HA2G_BWD_KTILE((Q + 2) % G)
@@ -490,11 +524,17 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
                 const float* w0 = &wf[(Q * 3 + 0) * TPW + jl].x; const float* w1 = &wf[(Q * 3 + 1) * TPW + jl].x;
                 const float* w2 = &wf[(Q * 3 + 2) * TPW + jl].x;
                 const float* d0 = &bop[jl].x; const float* d1 = &bop[TPW + jl].x; const float* d2 = &bop[2 * TPW + jl].x;
+                if constexpr (SPL) {
+                    a0 = mfma3_bf16(wf[(Q * 3 + 0) * TPW + jl], bop[jl], a0);
+                    a1 = mfma3_bf16(wf[(Q * 3 + 1) * TPW + jl], bop[TPW + jl], a1);
+                    a2 = mfma3_bf16(wf[(Q * 3 + 2) * TPW + jl], bop[2 * TPW + jl], a2);
+                } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[u], d0[u], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[u], d1[u], a1, 0, 0, 0);
-                    a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[u], d2[u], a2, 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) {
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[u], d0[u], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[u], d1[u], a1, 0, 0, 0);
+                        a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[u], d2[u], a2, 0, 0, 0);
+                    }
                 }
                 if (jl == PB - 1) { HA2G_BWD_GATHER_ISSUE }
             }
@@ -536,6 +576,7 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
     }
 }
 
+template <bool SPL>
 __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __restrict__ dy,      // [B][T][2H]
                                                                 const float* __restrict__ y,       // [B][T][2H]
                                                                 const float* __restrict__ rs,      // [B][T][2][4][H]
@@ -554,7 +595,7 @@ __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __r
     u64* xc = xch + (long)c * CL_GRAN;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xc, 0, (int)(CL_GRAN * 8), 0x00020000);
     const unsigned tag0 = epoch ? (0x80000000u | (*epoch << 6)) : host_tag0;
-#define HA2G_BWD_CALL(QQ, PP) gru_bwd_member<QQ, PP>(dy, y, rs, wpt, dg, hpo, xr, err, B, T, dir, b0, tag0, sh, dbg, sg, sp)
+#define HA2G_BWD_CALL(QQ, PP) gru_bwd_member<QQ, PP, SPL>(dy, y, rs, wpt, dg, hpo, xr, err, B, T, dir, b0, tag0, sh, dbg, sg, sp)
 #define HA2G_BWD_SWITCH(PP)                                                                                       \
     switch (q) {                                                                                                  \
         case 0: HA2G_BWD_CALL(0, PP); break; case 1: HA2G_BWD_CALL(1, PP); break; case 2: HA2G_BWD_CALL(2, PP); break; \
@@ -663,7 +704,10 @@ int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs,
         unsigned host_tag0 = 0;
         const unsigned* epoch = launch_tag_base(xch, st, &host_tag0);
         const int grid = ceil_div(nclusters, 8) * 8 * G;
-        hipLaunchKernelGGL(gru_bwd_cluster_kernel, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg);
+        if (ha2g_split_dgrad_enabled())     // data-gradient class of ha2g_gemm_set_mode: split-bf16 inner product (exact fp32 in mode 0)
+            hipLaunchKernelGGL(gru_bwd_cluster_kernel<true>, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg);
+        else
+            hipLaunchKernelGGL(gru_bwd_cluster_kernel<false>, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg);
         HA2G_CHECK_LAUNCH("gru_layer_bwd_cluster");
     }
     return 0;
