@@ -29,7 +29,7 @@ int conv3x3_c32_launch(const float* x, const float* w, float* y, int N, int H, i
                               hipStream_t st);
 int conv3x3_c32_x3_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta,
                           hipStream_t st);
-int ha2g_split_dgrad_enabled();      // gemm.hip: ha2g_gemm_set_mode bit 2 (and not the plain-bf16 mode)
+int gemm_split_dgrad_enabled();      // gemm.hip: ha2g_gemm_set_mode bit 2 (and not the plain-bf16 mode)
 int conv3x3_c32_wgrad_blocks(int N, int H, int W);
 int conv3x3_c32_wgrad_launch(const float* x, const float* dy, float* part, int N, int H, int W, hipStream_t st);
 

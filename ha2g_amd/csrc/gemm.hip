@@ -1060,7 +1060,7 @@ static int pick_conv_cfg(int M, int N) {
     return best;
 }
 
-int ha2g_split_dgrad_enabled() { return g_split_dgrad && !g_bf16; }
+int gemm_split_dgrad_enabled() { return g_split_dgrad && !g_bf16; }
 
 extern "C" {
 
