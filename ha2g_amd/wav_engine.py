@@ -162,6 +162,18 @@ class GradSink:
         else:
             self.G[name] = ops.gemm(a, b_, transa=True)
 
+    def gwb(self, wname, bname, a, b_):                   # dW (+)= a^T b_ and db (+)= column sums of a, one launch (ha2g_gemm_wgrad_bias_f32)
+        tw, tb = self.tgt(self.P[wname]), self.tgt(self.P[bname])
+        if ops.FUSE_BIAS_GRAD and tw is not None and tw.is_contiguous() and tb is not None:
+            ops.gemm(a, b_, transa=True, out=tw, beta=1.0, colsum_out=tb, colsum_beta=1.0)
+        elif ops.FUSE_BIAS_GRAD and tw is None and tb is None:
+            db = torch.empty(a.shape[1], dtype=torch.float32, device=a.device)
+            self.G[wname] = ops.gemm(a, b_, transa=True, colsum_out=db)
+            self.G[bname] = db
+        else:
+            self.gw(wname, a, b_)
+            self.gb(bname, a)
+
     def gb(self, name, a):                                # db (+)= column sums of a
         t = self.tgt(self.P[name])
         if t is not None:
@@ -219,11 +231,9 @@ def block_bwd(dx, saved, P, b, sink):
     ds = empty(N, C, like=b2)
     check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, ops.workspace(dout.device).data_ptr(), _stream()))
     dsc = ops.eltwise(ops.OP_SIGMOID_BWD_PRE, ds, su)
-    sink.gw(b + 'se.fc.2.weight', dsc, h1)
-    sink.gb(b + 'se.fc.2.bias', dsc)
+    sink.gwb(b + 'se.fc.2.weight', b + 'se.fc.2.bias', dsc, h1)
     dh1 = ops.eltwise(ops.OP_RELU_BWD, ops.gemm(dsc, P[b + 'se.fc.2.weight']), h1)
-    sink.gw(b + 'se.fc.0.weight', dh1, pooled)
-    sink.gb(b + 'se.fc.0.bias', dh1)
+    sink.gwb(b + 'se.fc.0.weight', b + 'se.fc.0.bias', dh1, pooled)
     dpool = ops.gemm(dh1, P[b + 'se.fc.0.weight'], alpha=1.0 / HW)
     dres, db2 = torch.empty_like(b2), torch.empty_like(b2)
     check(lib.ha2g_se_bwd_apply_f32(dout.data_ptr(), out.data_ptr(), sc.data_ptr(), dpool.data_ptr(), dres.data_ptr(),
@@ -261,8 +271,7 @@ def tap_bwd(dy, saved, P, t, r, sink):
     """dy [B, Wt, 32] -> gradient w.r.t. the trunk feature the tap reads (NHWC)."""
     fshape, fin, ct, mt, st, ashape, packed = saved
     dy = dy.view(fshape[0] * ashape[2], 32)
-    sink.gw('fc_%s.weight' % t, dy, packed)
-    sink.gb('fc_%s.bias' % t, dy)
+    sink.gwb('fc_%s.weight' % t, 'fc_%s.bias' % t, dy, packed)
     dpacked = ops.gemm(dy, P['fc_%s.weight' % t])
     dat = _tap_pack(dpacked, inverse=True, shape=ashape)
     dct = sink.gbn('bn_%s' % t, _rows(dat), _rows(ct), mt, st, relu_mask=True).view(ct.shape)     # BN' and ReLU' in one pass
@@ -305,16 +314,13 @@ def blend_bwd(dw_ext, dblend, df, saved, feats, P, L, sink):
     check(lib.ha2g_blend_bwd_f32(db.data_ptr(), _p(dwe), wsm.data_ptr(), low.data_ptr(), mid.data_ptr(), high.data_ptr(),
                                  df[0].data_ptr(), df[1].data_ptr(), df[2].data_ptr(), dlogits.data_ptr(), B, L, T * 32, _stream()))
     # speaker MLP backward
-    sink.gw('fc2.weight', dlogits, e1)
-    sink.gb('fc2.bias', dlogits)
+    sink.gwb('fc2.weight', 'fc2.bias', dlogits, e1)
     de1 = ops.gemm(dlogits, P['fc2.weight'])
     df1 = ops.eltwise(ops.OP_ELU_BWD, de1, e1)
-    sink.gw('fc1.weight', df1, e0)
-    sink.gb('fc1.bias', df1)
+    sink.gwb('fc1.weight', 'fc1.bias', df1, e0)
     de0 = ops.gemm(df1, P['fc1.weight'])
     dz = ops.eltwise(ops.OP_ELU_BWD, de0, e0)
-    sink.gw('speaker_embedding.1.weight', dz, ze)
-    sink.gb('speaker_embedding.1.bias', dz)
+    sink.gwb('speaker_embedding.1.weight', 'speaker_embedding.1.bias', dz, ze)
     dze = ops.gemm(dz, P['speaker_embedding.1.weight'])
     demb = torch.zeros_like(P['speaker_embedding.0.weight'])
     check(lib.ha2g_embedding_bwd_f32(vid.data_ptr(), dze.data_ptr(), demb.data_ptr(), B, 16, -1, workspace(dev).data_ptr(), _stream()))
