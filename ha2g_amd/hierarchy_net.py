@@ -159,13 +159,23 @@ def text_encoders_groupable(encs):
     return all(sig(e) == sig(e0) for e in encs) and all(b.downsample is None for b in e0.tcn.network)
 
 
-def grouped_text_encoders(encs, in_text):
+def grouped_conv_weights(encs):
+    """The weight-normalised convolution weights of every TCN layer of every encoder: [level][conv 0/1][encoder].  They depend on the
+    parameters only, so a train step computes them ONCE and shares them between the no-grad and the gradient-carrying row blocks."""
+    return [[[ops.weight_norm(getattr(e.tcn.network[lvl], name).weight_g, getattr(e.tcn.network[lvl], name).weight_v) for e in encs]
+             for name in ('conv1', 'conv2')] for lvl in range(len(encs[0].tcn.network))]
+
+
+def grouped_text_encoders(encs, in_text, wn=None):
     """The G generators' text encoders (separate modules in the reference, model/hierarchy_net.py:66-70, each called inside its generator's
     forward :121-123) evaluated in lockstep: every layer is ONE launch over the stacked [G*B, T, C] activations and one grouped GEMM with the
-    G weight sets, instead of G under-filled launches.  Same arithmetic per encoder; returns [G, B, T, 32]."""
+    G weight sets, instead of G under-filled launches.  Same arithmetic per encoder; returns [G, B, T, 32].  wn: grouped_conv_weights(encs)
+    when the caller evaluates several row blocks with the same parameters."""
     G = len(encs)
     B, T = in_text.shape
     e0 = encs[0]
+    if wn is None:
+        wn = grouped_conv_weights(encs)
     x = torch.stack([e.embedding(in_text) for e in encs])                  # [G, B, T, E]: each encoder has its own table
     E = x.shape[3]
     x = ops.dropout(x.view(G * B, T, E), e0.drop.p, e0.training)
@@ -173,9 +183,9 @@ def grouped_text_encoders(encs, in_text):
         blocks = [e.tcn.network[lvl] for e in encs]
         d, p = blocks[0].dilation, blocks[0].p
         y = x
-        for name in ('conv1', 'conv2'):
+        for ci, name in enumerate(('conv1', 'conv2')):
             convs = [getattr(b, name) for b in blocks]
-            ws = [ops.weight_norm(c.weight_g, c.weight_v) for c in convs]
+            ws = wn[lvl][ci]
             y = ops.grouped_conv1d_tm(y.view(G, B, T, y.shape[2]), ws, [c.bias for c in convs], dil=d, pad_left=d * (ws[0].shape[2] - 1), To=T,
                                       act=ACT_RELU).view(G * B, T, -1)
             y = ops.dropout(y, p, e0.training)

@@ -63,7 +63,7 @@ FUSE_TEXT = os.environ.get('HA2G_FUSE_TEXT', '1') != '0'     # the generators' t
 def _grouped_text_features(gens, in_text):
     """Per-generator text features from ONE lockstep pass over all generators' text encoders, or None when they cannot be grouped.
     Honours the fused-chain row split (hierarchy_net._row_split): rows that receive no gradient are evaluated under no_grad."""
-    from .hierarchy_net import grouped_text_encoders, text_encoders_groupable
+    from .hierarchy_net import grouped_conv_weights, grouped_text_encoders, text_encoders_groupable
     mods = [g.module if hasattr(g, 'module') else g for g in gens]
     if not FUSE_TEXT or not in_text.is_cuda or any(m.input_context == 'none' for m in mods):
         return None
@@ -76,14 +76,15 @@ def _grouped_text_features(gens, in_text):
     s0, cnt = gs
     B = in_text.shape[0]
     parts = []
+    wn = grouped_conv_weights(encs)                      # once per step, shared by the row blocks
     for a, b, grad in ((0, s0, False), (s0, s0 + cnt, True), (s0 + cnt, B, False)):
         if b <= a:
             continue
         if grad:
-            parts.append(grouped_text_encoders(encs, in_text[a:b]))
+            parts.append(grouped_text_encoders(encs, in_text[a:b], wn))
         else:
             with torch.no_grad():
-                parts.append(grouped_text_encoders(encs, in_text[a:b]))
+                parts.append(grouped_text_encoders(encs, in_text[a:b], wn))
     return torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
 
 

@@ -209,8 +209,10 @@ def block_fwd(x, P, b, first):
     b2, m2, s2, pooled = _bn_fwd(c2, P[b + 'bn2'], pool=True)         # bn2 + SE squeeze in one pass
     N, OH, OW, C = b2.shape
     h1 = ops.gemm(pooled, P[b + 'se.fc.0.weight'], transb=True, bias=P[b + 'se.fc.0.bias'], act=ACT_RELU)
-    su = ops.gemm(h1, P[b + 'se.fc.2.weight'], transb=True, bias=P[b + 'se.fc.2.bias'])      # gate pre-activation
-    sc = ops.eltwise(ops.OP_SIGMOID, su)
+    # the gate straight out of the GEMM's sigmoid epilogue (the same 1 / (1 + expf(-v)) on the same v as a separate pointwise launch:
+    # bit-identical forward); the backward takes sigma' = s (1 - s) from the stored gate
+    sc = ops.gemm(h1, P[b + 'se.fc.2.weight'], transb=True, bias=P[b + 'se.fc.2.bias'], act=ACT_SIGMOID)
+    su = None
     if first:
         wd = _ohwi(P[b + 'downsample.0.weight'])
         cd = conv_fwd(x, wd, None, 2, 0, ACT_NONE)
@@ -230,7 +232,7 @@ def block_bwd(dx, saved, P, b, sink):
     dout = dx.contiguous()
     ds = empty(N, C, like=b2)
     check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, ops.workspace(dout.device).data_ptr(), _stream()))
-    dsc = ops.eltwise(ops.OP_SIGMOID_BWD_PRE, ds, su)
+    dsc = ops.eltwise(ops.OP_SIGMOID_BWD, ds, sc)
     sink.gwb(b + 'se.fc.2.weight', b + 'se.fc.2.bias', dsc, h1)
     dh1 = ops.eltwise(ops.OP_RELU_BWD, ops.gemm(dsc, P[b + 'se.fc.2.weight']), h1)
     sink.gwb(b + 'se.fc.0.weight', b + 'se.fc.0.bias', dh1, pooled)
