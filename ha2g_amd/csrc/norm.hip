@@ -216,13 +216,17 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restr
         p[0] = s.x; p[1] = s.y; p[2] = s.z; p[3] = s.w;
     }
 }
-__global__ void pool_final_kernel(const double* __restrict__ part, int nchunk, int C, long NC, float scale, float* __restrict__ out) {
+// gate (nullable): out = sum * scale * g (1 - g) -- the SE backward's sigmoid' factor, so that no separate pointwise launch follows
+__global__ void pool_final_kernel(const double* __restrict__ part, int nchunk, int C, long NC, float scale, float* __restrict__ out,
+                                  const float* __restrict__ gate) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= NC) return;
     const long n = i / C; const int c = (int)(i % C);
     double s = 0.0;
     for (int k = 0; k < nchunk; ++k) s += part[(n * nchunk + k) * C + c];
-    out[i] = (float)(s * scale);
+    float v = (float)(s * scale);
+    if (gate) { const float g = gate[i]; v = v * g * (1.f - g); }
+    out[i] = v;
 }
 
 // dx = gamma * invstd * (dy - sum_dy/N - xhat * sum_dy_xhat/N)
@@ -257,7 +261,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
 template <int MODE>
 __global__ __launch_bounds__(256) void image_col_kernel(const float* __restrict__ x, const float* __restrict__ dout,
                                                         const float* __restrict__ outp, int HW, int C, float* __restrict__ res,
-                                                        float scale, double* __restrict__ part) {
+                                                        float scale, double* __restrict__ part, const float* __restrict__ gate) {
     // grid (nchunk, N): block (k, n) sums rows [k*per, (k+1)*per) of image n; part == nullptr (nchunk = 1): final floats to res, else
     // double partials [n][k][C] for pool_final_kernel (more blocks than images: a 128-image batch alone fills half the CUs)
     __shared__ d4 lds[256];
@@ -306,6 +310,10 @@ __global__ __launch_bounds__(256) void image_col_kernel(const float* __restrict_
             p[0] = s.x; p[1] = s.y; p[2] = s.z; p[3] = s.w;
         } else {
             float4 o = make_float4((float)(s.x * scale), (float)(s.y * scale), (float)(s.z * scale), (float)(s.w * scale));
+            if (gate) {
+                const float4 g = reinterpret_cast<const float4*>(gate + (long)blockIdx.y * C)[threadIdx.x];
+                o.x = o.x * g.x * (1.f - g.x); o.y = o.y * g.y * (1.f - g.y); o.z = o.z * g.z * (1.f - g.z); o.w = o.w * g.w * (1.f - g.w);
+            }
             reinterpret_cast<float4*>(res + (long)blockIdx.y * C)[threadIdx.x] = o;
         }
     }
@@ -398,7 +406,7 @@ int ha2g_bn_apply_pool_f32(const float* x, const float* mean, const float* invst
     const int nchunk = pool_chunks(N, HW);
     hipLaunchKernelGGL(bn_apply_pool_kernel, dim3(nchunk, N), dim3(256), 0, st, x, mean, invstd, gamma, beta, y, HW, C, (double*)ws);
     hipLaunchKernelGGL(pool_final_kernel, dim3(ceil_div((long)N * C, 256)), dim3(256), 0, st, (const double*)ws, nchunk, C, (long)N * C,
-                       1.f / (float)HW, pooled);
+                       1.f / (float)HW, pooled, nullptr);
     HA2G_CHECK_LAUNCH("bn_apply_pool");
     return 0;
 }
@@ -421,7 +429,7 @@ int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const fl
 // out[n][c] = mean over HW of x[n][hw][c]
 int ha2g_hw_mean_f32(const float* x, float* out, int N, int HW, int C, void* stream) {
     HA2G_REQUIRE(okC(C), "hw_mean: unsupported channel count %d", C);
-    hipLaunchKernelGGL(image_col_kernel<0>, dim3(1, N), dim3(256), 0, (hipStream_t)stream, x, nullptr, nullptr, HW, C, out, 1.f / (float)HW, nullptr);
+    hipLaunchKernelGGL(image_col_kernel<0>, dim3(1, N), dim3(256), 0, (hipStream_t)stream, x, nullptr, nullptr, HW, C, out, 1.f / (float)HW, nullptr, nullptr);
     HA2G_CHECK_LAUNCH("hw_mean");
     return 0;
 }
@@ -433,15 +441,17 @@ int ha2g_se_scale_add_relu_f32(const float* x, const float* s, const float* res,
     return 0;
 }
 // ds[n][c] = sum_hw dout*(out>0)*x
-int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, float* ds, int N, int HW, int C, float* ws, void* stream) {
+int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, float* ds, int N, int HW, int C, const float* gate, float* ws,
+                          void* stream) {
     HA2G_REQUIRE(okC(C), "se: unsupported channel count %d", C);
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = ws ? pool_chunks(N, HW) : 1;          // ws: ha2g_bn_apply_pool_workspace_floats(N, HW, C) floats, or null
     if (nchunk > 1) {
-        hipLaunchKernelGGL(image_col_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, ds, 1.f, (double*)ws);
-        hipLaunchKernelGGL(pool_final_kernel, dim3(ceil_div((long)N * C, 256)), dim3(256), 0, st, (const double*)ws, nchunk, C, (long)N * C, 1.f, ds);
+        hipLaunchKernelGGL(image_col_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, ds, 1.f, (double*)ws, (const float*)nullptr);
+        hipLaunchKernelGGL(pool_final_kernel, dim3(ceil_div((long)N * C, 256)), dim3(256), 0, st, (const double*)ws, nchunk, C, (long)N * C, 1.f, ds,
+                           gate);
     } else {
-        hipLaunchKernelGGL(image_col_kernel<1>, dim3(1, N), dim3(256), 0, st, x, dout, out, HW, C, ds, 1.f, nullptr);
+        hipLaunchKernelGGL(image_col_kernel<1>, dim3(1, N), dim3(256), 0, st, x, dout, out, HW, C, ds, 1.f, (double*)nullptr, gate);
     }
     HA2G_CHECK_LAUNCH("se_bwd_scale");
     return 0;

@@ -231,8 +231,9 @@ def block_bwd(dx, saved, P, b, sink):
     HW = OH * OW
     dout = dx.contiguous()
     ds = empty(N, C, like=b2)
-    check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, ops.workspace(dout.device).data_ptr(), _stream()))
-    dsc = ops.eltwise(ops.OP_SIGMOID_BWD, ds, sc)
+    check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, sc.data_ptr(),
+                                    ops.workspace(dout.device).data_ptr(), _stream()))
+    dsc = ds                                            # already times the gate's sigmoid' (folded into the reduction's final pass)
     sink.gwb(b + 'se.fc.2.weight', b + 'se.fc.2.bias', dsc, h1)
     dh1 = ops.eltwise(ops.OP_RELU_BWD, ops.gemm(dsc, P[b + 'se.fc.2.weight']), h1)
     sink.gwb(b + 'se.fc.0.weight', b + 'se.fc.0.bias', dh1, pooled)

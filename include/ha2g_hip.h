@@ -154,7 +154,9 @@ int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const fl
 /* ---- squeeze-excite pointwise pieces (model/ResNetBlocks.py:81-95 and the residual tail :33-36) ---- */
 int ha2g_hw_mean_f32(const float* x, float* out, int N, int HW, int C, void* stream);
 int ha2g_se_scale_add_relu_f32(const float* x, const float* s, const float* res, float* out, int N, int HW, int C, void* stream);
-int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, float* ds, int N, int HW, int C, float* ws, void* stream);   /* ws: ha2g_bn_apply_pool_workspace_floats(N, HW, C) floats (row-chunked partials) or null (one block per image) */
+int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, float* ds, int N, int HW, int C, const float* gate, float* ws,
+                          void* stream);   /* gate (nullable) [N][C]: ds is multiplied by gate * (1 - gate), the sigmoid derivative of the SE gate; */
+     /* ws: ha2g_bn_apply_pool_workspace_floats(N, HW, C) floats (row-chunked partials) or null (one block per image) */
 int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, const float* dpool, float* dres,
                           float* dx, int N, int HW, int C, void* stream);
 /* speaker-softmax blending of the three audio taps (model/ResNetSE34V2.py:202-212) */

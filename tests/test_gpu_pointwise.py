@@ -39,10 +39,14 @@ def test_se_tail_fwd_bwd(shape):
     dres, dx = torch.empty_like(xg), torch.empty_like(xg)
     check(lib.ha2g_se_scale_add_relu_f32(xg.data_ptr(), sg.data_ptr(), rg.data_ptr(), out.data_ptr(), N, HW, C, _stream()))
     from ha2g_amd import ops as _ops
-    check(lib.ha2g_se_bwd_scale_f32(dg.data_ptr(), out.data_ptr(), xg.data_ptr(), ds.data_ptr(), N, HW, C, _ops.workspace(xg.device).data_ptr(), _stream()))
+    check(lib.ha2g_se_bwd_scale_f32(dg.data_ptr(), out.data_ptr(), xg.data_ptr(), ds.data_ptr(), N, HW, C, None, _ops.workspace(xg.device).data_ptr(), _stream()))
     ds1 = torch.empty_like(ds)
-    check(lib.ha2g_se_bwd_scale_f32(dg.data_ptr(), out.data_ptr(), xg.data_ptr(), ds1.data_ptr(), N, HW, C, None, _stream()))       # one block per image
+    check(lib.ha2g_se_bwd_scale_f32(dg.data_ptr(), out.data_ptr(), xg.data_ptr(), ds1.data_ptr(), N, HW, C, None, None, _stream()))       # one block per image
     assert relerr(ds1, gs) < 2e-6
+    for ws_ in (_ops.workspace(xg.device).data_ptr(), None):                                     # gate folded in: ds * s (1 - s)
+        dsg = torch.empty_like(ds)
+        check(lib.ha2g_se_bwd_scale_f32(dg.data_ptr(), out.data_ptr(), xg.data_ptr(), dsg.data_ptr(), N, HW, C, sg.data_ptr(), ws_, _stream()))
+        assert relerr(dsg, gs * sd_.detach() * (1 - sd_.detach())) < 2e-6
     check(lib.ha2g_se_bwd_apply_f32(dg.data_ptr(), out.data_ptr(), sg.data_ptr(), pg.data_ptr(), dres.data_ptr(), dx.data_ptr(), N, HW, C, _stream()))
     assert relerr(out, out64.detach()) < 2e-7
     assert relerr(ds, gs) < 2e-6
