@@ -143,9 +143,14 @@ def _tap_pack(x, inverse=False, shape=None):
     return out
 
 
+import os as _os
+SIDE_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_WGRAD', '1') != '0'
+
+
 class GradSink:
     """Where the backward kernels put parameter gradients: straight into a parameter's installed `.grad` buffer when
-    there is one (beta = 1 epilogues), else into the dict G (name -> grad; BatchNorm: (dgamma, dbeta))."""
+    there is one (beta = 1 epilogues), else into the dict G (name -> grad; BatchNorm: (dgamma, dbeta)).  The convolution weight
+    gradients are enqueued on ops.side's stream: call join(device) before reading any gradient."""
 
     def __init__(self, P):
         self.P, self.G = P, {}
@@ -182,9 +187,26 @@ class GradSink:
             self.G[name] = ops.colsum(a)
 
     def gconv(self, name, xin, dyc, w_ohwi, stride, pad):
-        r = conv_wgrad(xin, dyc, w_ohwi, stride, pad, into=self.tgt(self.P[name]))
+        # the convolution weight gradients only feed the optimizer: on the side stream they overlap the data-gradient chain -- MFMA work
+        # beside the bandwidth-bound BatchNorm / SE passes of the main stream.  The operands are handed to the side stream's allocator
+        # bookkeeping (record_stream) because the caller drops them before the join at the end of the tower's backward.
+        if SIDE_WGRAD and ops.side.enabled and xin.is_cuda:
+            with ops.side.section(xin.device):
+                st = torch.cuda.current_stream(xin.device)
+                xin.record_stream(st); dyc.record_stream(st)
+                r = conv_wgrad(xin, dyc, w_ohwi, stride, pad, into=self.tgt(self.P[name]))
+                if r is not None:
+                    r.record_stream(torch.cuda.default_stream(xin.device))
+            self.forked = True
+        else:
+            r = conv_wgrad(xin, dyc, w_ohwi, stride, pad, into=self.tgt(self.P[name]))
         if r is not None:
             self.G[name] = r
+
+    def join(self, device):
+        if getattr(self, 'forked', False):
+            ops.side.join(device)
+            self.forked = False
 
     def gbn(self, name, dy2, x2, mean, invstd, relu_mask=False):
         bn = self.P[name]
@@ -417,6 +439,7 @@ class WavEncoderFunction(torch.autograd.Function):
         check(lib.ha2g_stem_conv_wgrad_f32(spec.data_ptr(), dc0.data_ptr(), dw1.data_ptr(), dbias1.data_ptr(), Bn, H0, W0, 0.0,
                                            workspace(dev).data_ptr(), _stream()))
         G['conv1.weight'], G['conv1.bias'] = dw1, dbias1
+        sink.join(dev)                                   # the side stream's weight gradients are complete before autograd sees them
         # ---- scatter into the flat gradient tuple ----
         grads = [None] * ctx.n_tensors
         for n, idx in ctx.flat_index.items():

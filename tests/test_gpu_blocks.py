@@ -36,6 +36,7 @@ def run_block(ck, name, geom, B, seed):
     out, saved = we.block_fwd(nhwc(x.to(DEV)), P, '', geom[4])
     sink = we.GradSink(P)
     dx = we.block_bwd(nhwc(wl.to(DEV)), saved, P, '', sink)
+    sink.join(torch.device(DEV))                              # the convolution weight gradients run on the side stream
     q = 'blk/%s/' % name
     ck.check(nchw(out), q + 'out')
     ck.check(nchw(dx), q + 'grad_x')
@@ -96,6 +97,7 @@ def run_taps(ck, case, seed):
     we.blend_bwd(taps_w('w', wsm, seed), tuple(taps_w('blend%d' % i, blend[i], seed) for i in range(L)), df, spk, (low, mid, high), P, L, sink)
     for ti, ((t, C, k, r), lname) in enumerate(zip(we.TAPS, ('layer2', 'layer3', 'layer4'))):
         ck.check(nchw(we.tap_bwd(df[ti], saves[ti], P, t, r, sink)), 'taps/grad_' + lname)
+    sink.join(torch.device(DEV))
     n = 0
     for k, gr in sink.G.items():
         if isinstance(gr, tuple):
