@@ -157,3 +157,32 @@ def test_whole_encoder_b16(golden):
     for k, b in aud.named_buffers():
         if k.endswith(('running_mean', 'running_var')):
             ck.check(b, 'enc/buf/' + k)
+
+
+def test_tower_side_stream_weight_gradients_equal_inline():
+    """The tower's convolution / FC weight gradients run on ops.side's stream beside the data-gradient chain (wav_engine.GradSink.gconv / gwb);
+    same kernels, same operands: every parameter gradient must equal the in-line schedule bit for bit."""
+    from ha2g_amd import hierarchy_net as hn, wav_engine as we
+    from ha2g_amd.config import make_args
+    from ha2g_amd.testing import SpeakerVocab, no_dropout
+    case = ENC_CASE
+    args = make_args(dict(hidden_size=32, n_layers=2))
+    _, spec, _, vid = proc.make_batch(case['B'], 27, 40, case['n_spk'], case['seed'])
+    spec, vid = torch.from_numpy(spec).to(DEV), torch.from_numpy(vid).to(DEV)
+    grads = {}
+    old = we.SIDE_WGRAD, we.SIDE_FC_WGRAD
+    try:
+        for side in (True, False):
+            we.SIDE_WGRAD = we.SIDE_FC_WGRAD = side
+            aud = hn.Hierarchical_WavEncoder(args, SpeakerVocab(case['n_spk']), 3, 32)
+            proc.fill_module(aud, case['seed'], 'audio.')
+            aud = no_dropout(aud).to(DEV)
+            w, lo, mid, hi, blend = aud(spec, vid)
+            (sum((bl * bl).sum() for bl in blend) + (hi * lo.mean()).sum() + w.sum()).backward()
+            torch.cuda.synchronize()
+            grads[side] = {k: p_.grad.clone() for k, p_ in aud.named_parameters()}
+    finally:
+        we.SIDE_WGRAD, we.SIDE_FC_WGRAD = old
+    assert set(grads[True]) == set(grads[False]) and len(grads[True]) > 100
+    for k in grads[True]:
+        assert torch.equal(grads[True][k], grads[False][k]), k
