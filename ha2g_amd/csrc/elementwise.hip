@@ -137,6 +137,37 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __res
     }
 }
 
+// Many weight-norm layers of ONE row length in one launch (grid.y = layer): the 24 (48) convolutions of the generators' text encoders are
+// parameters-only work that otherwise costs one tiny launch each at the head of every step.  Same per-row arithmetic as the single kernels.
+struct WnMulti { const float* g[32]; const float* v[32]; float* w[32]; float* norm[32]; const float* dw[32]; float* dg[32]; float* dv[32]; };
+__global__ __launch_bounds__(256) void weight_norm_multi_fwd_kernel(WnMulti m, int n) {
+    __shared__ float red[16];
+    const int o = blockIdx.x, t = blockIdx.y;
+    const float* vr = m.v[t] + (long)o * n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += vr[i] * vr[i];
+    s = block_sum(s, red);
+    const float nr = sqrtf(s);
+    if (threadIdx.x == 0) m.norm[t][o] = nr;
+    const float sc = m.g[t][o] / nr;
+    float* wr = m.w[t] + (long)o * n;
+    for (int i = threadIdx.x; i < n; i += 256) wr[i] = vr[i] * sc;
+}
+__global__ __launch_bounds__(256) void weight_norm_multi_bwd_kernel(WnMulti m, int n, float beta) {
+    __shared__ float red[16];
+    const int o = blockIdx.x, t = blockIdx.y;
+    const float* vr = m.v[t] + (long)o * n;
+    const float* dr = m.dw[t] + (long)o * n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += dr[i] * vr[i];
+    s = block_sum(s, red);
+    const float nr = m.norm[t][o];
+    if (threadIdx.x == 0) m.dg[t][o] = (beta != 0.f ? beta * m.dg[t][o] : 0.f) + s / nr;
+    const float a = m.g[t][o] / nr, bq = s / (nr * nr);
+    float* dvr = m.dv[t] + (long)o * n;
+    for (int i = threadIdx.x; i < n; i += 256) dvr[i] = (beta != 0.f ? beta * dvr[i] : 0.f) + a * (dr[i] - vr[i] * bq);
+}
+
 // ---------------------------------------------------------------- pointwise ---------------------------
 enum EltOp {
     OP_ADD = 0, OP_MUL = 1, OP_ADD_RELU = 2, OP_RELU_BWD = 3, OP_LEAKY_BWD = 4, OP_SIGMOID_BWD = 5, OP_ELU = 6,
@@ -394,6 +425,25 @@ int ha2g_weight_norm_bwd_f32(const float* dw, const float* g, const float* v, co
                              int n, float beta, void* stream) {
     hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, dw, g, v, norm, dg, dv, n, beta);
     HA2G_CHECK_LAUNCH("weight_norm_bwd");
+    return 0;
+}
+// `count` (<= 32) weight-norm layers with the same [Cout][n] shape in one launch; host arrays of device pointers
+int ha2g_weight_norm_multi_fwd_f32(int count, const float* const* g, const float* const* v, float* const* w, float* const* norm, int Cout, int n,
+                                   void* stream) {
+    HA2G_REQUIRE(count >= 1 && count <= 32, "weight_norm_multi: 1..32 layers, got %d", count);
+    WnMulti m{};
+    for (int t = 0; t < count; ++t) { m.g[t] = g[t]; m.v[t] = v[t]; m.w[t] = w[t]; m.norm[t] = norm[t]; }
+    hipLaunchKernelGGL(weight_norm_multi_fwd_kernel, dim3(Cout, count), dim3(256), 0, (hipStream_t)stream, m, n);
+    HA2G_CHECK_LAUNCH("weight_norm_multi_fwd");
+    return 0;
+}
+int ha2g_weight_norm_multi_bwd_f32(int count, const float* const* dw, const float* const* g, const float* const* v, const float* const* norm,
+                                   float* const* dg, float* const* dv, int Cout, int n, float beta, void* stream) {
+    HA2G_REQUIRE(count >= 1 && count <= 32, "weight_norm_multi: 1..32 layers, got %d", count);
+    WnMulti m{};
+    for (int t = 0; t < count; ++t) { m.dw[t] = dw[t]; m.g[t] = g[t]; m.v[t] = v[t]; m.norm[t] = const_cast<float*>(norm[t]); m.dg[t] = dg[t]; m.dv[t] = dv[t]; }
+    hipLaunchKernelGGL(weight_norm_multi_bwd_kernel, dim3(Cout, count), dim3(256), 0, (hipStream_t)stream, m, n, beta);
+    HA2G_CHECK_LAUNCH("weight_norm_multi_bwd");
     return 0;
 }
 // out = op(a, b, c); b / c may be null for unary ops (float4 path when every pointer is 16-byte aligned).

@@ -162,8 +162,13 @@ def text_encoders_groupable(encs):
 def grouped_conv_weights(encs):
     """The weight-normalised convolution weights of every TCN layer of every encoder: [level][conv 0/1][encoder].  They depend on the
     parameters only, so a train step computes them ONCE and shares them between the no-grad and the gradient-carrying row blocks."""
-    return [[[ops.weight_norm(getattr(e.tcn.network[lvl], name).weight_g, getattr(e.tcn.network[lvl], name).weight_v) for e in encs]
-             for name in ('conv1', 'conv2')] for lvl in range(len(encs[0].tcn.network))]
+    convs = [[[getattr(e.tcn.network[lvl], name) for e in encs] for name in ('conv1', 'conv2')] for lvl in range(len(encs[0].tcn.network))]
+    flat = [c for lv in convs for pair in lv for c in pair]
+    if len({tuple(c.weight_v.shape) for c in flat}) == 1 and flat[0].weight_v.is_cuda:          # one launch for all of them (32 per launch)
+        ws = ops.weight_norm_multi([c.weight_g for c in flat], [c.weight_v for c in flat])
+        it = iter(ws)
+        return [[[next(it) for _ in pair] for pair in lv] for lv in convs]
+    return [[[ops.weight_norm(c.weight_g, c.weight_v) for c in pair] for pair in lv] for lv in convs]
 
 
 def grouped_text_encoders(encs, in_text, wn=None):

@@ -525,6 +525,51 @@ def weight_norm(g, v):
     return WeightNormFunction.apply(g, v)
 
 
+class MultiWeightNormFunction(torch.autograd.Function):
+    """n weight-norm layers of one shape (n <= 32) as one launch forward and one backward: apply(n, g_0..g_{n-1}, v_0..v_{n-1}) -> n weights."""
+
+    @staticmethod
+    def forward(ctx, n, *gv):
+        gs_in, vs_in = gv[:n], gv[n:]
+        gs, vs = [g.contiguous() for g in gs_in], [v.contiguous() for v in vs_in]
+        cout, rl = vs[0].shape[0], vs[0][0].numel()
+        assert all(v.shape == vs[0].shape for v in vs)
+        ws = [torch.empty_like(v) for v in vs]
+        norms = torch.empty(n, cout, dtype=torch.float32, device=vs[0].device)
+        check(lib.ha2g_weight_norm_multi_fwd_f32(n, _ptr_array(gs), _ptr_array(vs), _ptr_array(ws), _ptr_array([norms[i] for i in range(n)]), cout, rl,
+                                                 _stream()))
+        ctx.n, ctx.refs = n, (gs_in, vs_in)
+        ctx.save_for_backward(norms, *gs, *vs)
+        return tuple(ws)
+
+    @staticmethod
+    def backward(ctx, *dws):
+        n = ctx.n
+        norms, *gv = ctx.saved_tensors
+        gs, vs = gv[:n], gv[n:]
+        cout, rl = vs[0].shape[0], vs[0][0].numel()
+        dws = [(d.contiguous() if d is not None else torch.zeros_like(vs[i])) for i, d in enumerate(dws)]
+        tg = [_grad_target(t) for t in ctx.refs[0]]
+        tv = [_grad_target(t) for t in ctx.refs[1]]
+        direct = all(t is not None and t.is_contiguous() for t in tg + tv)
+        if not direct:
+            tg, tv = [torch.empty_like(g) for g in gs], [torch.empty_like(v) for v in vs]
+        check(lib.ha2g_weight_norm_multi_bwd_f32(n, _ptr_array(dws), _ptr_array(gs), _ptr_array(vs), _ptr_array([norms[i] for i in range(n)]),
+                                                 _ptr_array(tg), _ptr_array(tv), cout, rl, 1.0 if direct else 0.0, _stream()))
+        if direct:
+            return (None,) * (1 + 2 * n)
+        return (None,) + tuple(tg) + tuple(tv)
+
+
+def weight_norm_multi(gs, vs):
+    """[weight_norm(g, v) for g, v in zip(gs, vs)] for same-shape layers, 32 per launch."""
+    out = []
+    for a in range(0, len(gs), 32):
+        g_, v_ = list(gs[a:a + 32]), list(vs[a:a + 32])
+        out += list(MultiWeightNormFunction.apply(len(g_), *g_, *v_))
+    return out
+
+
 class Conv1dFunction(torch.autograd.Function):
     """x [B,T,Cin] (time-major rows), w [Cout,Cin,k] (nn.Conv1d layout), out [B,To,Cout].
     out[b,t] = sum_kk W[:,:,kk] x[b, t - pad_left + kk*dil]."""

@@ -175,6 +175,12 @@ int ha2g_weight_norm_fwd_f32(const float* g, const float* v, float* w, float* no
 /* dg / dv = beta * (old) + gradient: beta = 1 accumulates straight into the parameters' gradient buffers */
 int ha2g_weight_norm_bwd_f32(const float* dw, const float* g, const float* v, const float* norm, float* dg, float* dv,
                              int Cout, int n, float beta, void* stream);
+/* up to 32 weight-norm layers of one [Cout][n] shape in one launch (host arrays of device pointers): the convolutions of the generators'
+ * text encoders (model/tcn.py:19-31, one torch.nn.utils.weight_norm per conv) are parameters-only work at the head of every step */
+int ha2g_weight_norm_multi_fwd_f32(int count, const float* const* g, const float* const* v, float* const* w, float* const* norm, int Cout, int n,
+                                   void* stream);
+int ha2g_weight_norm_multi_bwd_f32(int count, const float* const* dw, const float* const* g, const float* const* v, const float* const* norm,
+                                   float* const* dg, float* const* dv, int Cout, int n, float beta, void* stream);
 
 /* ---- pointwise / RNG ---- */
 /* op: 0 a+b, 1 a*b, 2 relu(a+b), 3 relu', 4 leaky', 5 sigmoid', 6 elu, 7 elu', 8 reparam (model/embedding_net.py:10-13),

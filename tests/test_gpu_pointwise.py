@@ -318,3 +318,25 @@ def test_weighted_sum_loss_assembly():
     (3.0 * tot).backward()
     for t, w_ in zip(ts, ws):
         assert abs(float(t.grad) - 3.0 * w_) <= 1e-6 * abs(3.0 * w_)
+
+
+@pytest.mark.gpu
+def test_multi_weight_norm_equals_per_layer_launches():
+    """ha2g_weight_norm_multi_{fwd,bwd}_f32: many same-shape weight-norm layers in one launch == the per-layer kernels, bit for bit (weights and
+    both parameter gradients, returned and accumulated)."""
+    from ha2g_amd import ops
+    n = 35                                                               # crosses the 32-per-launch chunk
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    gs = [torch.rand(40, 1, 1, device=DEV, generator=gen).add_(0.5).requires_grad_(True) for _ in range(n)]
+    vs = [torch.randn(40, 24, 2, device=DEV, generator=gen).requires_grad_(True) for _ in range(n)]
+    cot = [torch.randn(40, 24, 2, device=DEV, generator=gen) for _ in range(n)]
+    w_multi = ops.weight_norm_multi(gs, vs)
+    g_multi = torch.autograd.grad(sum((w * c).sum() for w, c in zip(w_multi, cot)), gs + vs)
+    w_one = [ops.weight_norm(g, v) for g, v in zip(gs, vs)]
+    g_one = torch.autograd.grad(sum((w * c).sum() for w, c in zip(w_one, cot)), gs + vs)
+    for a, b in zip(w_multi, w_one):
+        assert torch.equal(a, b)
+    for a, b in zip(g_multi, g_one):
+        assert torch.equal(a, b)
+    ref = vs[0].double() * (gs[0].double() / vs[0].double().flatten(1).norm(dim=1).view(-1, 1, 1))
+    assert relerr(w_multi[0].detach(), ref.detach().cpu()) < 1e-6
