@@ -94,12 +94,13 @@ class TemporalBlock(nn.Module):
             self.downsample.bias = nn.Parameter(_uniform(torch.empty(n_outputs), 1.0 / math.sqrt(n_inputs)))
         self.dilation, self.p = dilation, dropout
 
-    def forward(self, x):
-        """x: [B, T, C] time-major (the reference carries [B, C, T]; same math)."""
+    def forward(self, x, ws=None):
+        """x: [B, T, C] time-major (the reference carries [B, C, T]; same math).  ws: the two weight-normalised conv weights when the caller
+        computed all of the network's weight norms in one launch."""
         d = self.dilation
         y = x
-        for conv in (self.conv1, self.conv2):
-            w = ops.weight_norm(conv.weight_g, conv.weight_v)
+        for ci, conv in enumerate((self.conv1, self.conv2)):
+            w = ws[ci] if ws is not None else ops.weight_norm(conv.weight_g, conv.weight_v)
             y = ops.conv1d_tm(y, w, conv.bias, dil=d, pad_left=d * (w.shape[2] - 1), To=x.shape[1], act=ACT_RELU)
             y = ops.dropout(y, self.p, self.training)
         res = x if self.downsample is None else ops.conv1d_tm(x, self.downsample.weight, self.downsample.bias)
@@ -116,6 +117,12 @@ class TemporalConvNet(nn.Module):
         self.network = nn.Sequential(*layers)
 
     def forward(self, x):
+        convs = [c for b in self.network for c in (b.conv1, b.conv2)]
+        if x.is_cuda and len({tuple(c.weight_v.shape) for c in convs}) == 1:          # every weight norm of the stack in one launch
+            ws = ops.weight_norm_multi([c.weight_g for c in convs], [c.weight_v for c in convs])
+            for i, b in enumerate(self.network):
+                x = b(x, ws[2 * i:2 * i + 2])
+            return x
         return self.network(x)
 
 
