@@ -169,17 +169,16 @@ class GradSink:
             self.G[name] = ops.gemm(a, b_, transa=True)
 
     def gwb(self, wname, bname, a, b_):                   # dW (+)= a^T b_ and db (+)= column sums of a, one launch (ha2g_gemm_wgrad_bias_f32)
-        if SIDE_FC_WGRAD and SIDE_WGRAD and ops.side.enabled and a.is_cuda and not getattr(self, '_in_side', False):
+        if SIDE_FC_WGRAD and SIDE_WGRAD and ops.side.enabled and a.is_cuda:
             with ops.side.section(a.device):              # off the data-gradient chain, like the convolution weight gradients
                 st = torch.cuda.current_stream(a.device)
                 a.record_stream(st); b_.record_stream(st)
-                self._in_side = True
-                try:
-                    self.gwb(wname, bname, a, b_)
-                finally:
-                    self._in_side = False
+                self._gwb(wname, bname, a, b_)
             self.forked = True
-            return
+        else:
+            self._gwb(wname, bname, a, b_)
+
+    def _gwb(self, wname, bname, a, b_):
         tw, tb = self.tgt(self.P[wname]), self.tgt(self.P[bname])
         if ops.FUSE_BIAS_GRAD and tw is not None and tw.is_contiguous() and tb is not None:
             ops.gemm(a, b_, transa=True, out=tw, beta=1.0, colsum_out=tb, colsum_beta=1.0)
