@@ -121,11 +121,15 @@ def main():
     ap.add_argument('--expressive', action='store_true', help='config_expressive/hierarchy.yml: 6 levels, 126-d pose (BASELINE config 3)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--bf16', action='store_true', help='BASELINE config 5 style: every vectorisable GEMM / convolution with plain bf16 operands (fp32 accumulate, fp32 storage / master weights); reported with dtype "bf16", never the default')
-    ap.add_argument('--graph', action='store_true', help='time hipGraph replays of the captured step instead of eager launches (no per-kernel HIP events => roofline objects are null)')
+    ap.add_argument('--launch', choices=('auto', 'graph', 'eager'), default='auto', help='what `value` times: hipGraph replays of the captured step (auto: when N = 1) or eager launches (auto: when N > 1); the eager number is always reported next to it')
+    ap.add_argument('--graph', action='store_true', help='same as --launch graph')
+    ap.add_argument('--no-roofline', action='store_true', help='with --primary-only: skip the per-launch HIP-event pass as well (profiling runs)')
     ap.add_argument('--sparse-embeddings', action='store_true', help='compact row gradients + lazy row-wise Adam for the word-embedding tables (bit-identical to the dense default; -45 %% gradient-exchange bytes under data parallelism, +0.4 ms of small kernels on one GPU)')
     ap.add_argument('--dry-run', action='store_true', help='only exercise the rank launch: every rank prints its RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* and exits (no GPU)')
     ap.add_argument('--primary-only', action='store_true', help='skip the secondary timings (warm-up phase, exact-fp32 mode): for profiling')
     a = ap.parse_args()
+    if a.graph:
+        a.launch = 'graph'
 
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         spawn_ranks(a.gpus)
@@ -170,54 +174,90 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        tr.train_iter(a.epoch, text, spec, target, vid)
-    last = None
-    if a.graph:                                      # whole step as one hipGraph (same kernels, launch overhead removed)
-        from ha2g_amd.train_hierarchy import _ret_dict
-        graph, gnames, gpacked = tr.capture_step(a.epoch, text, spec, target, vid)
-        ops.ktimer.reset()
+    rccl_world = 1
+    if world > 1:                                    # what RCCL itself sees: SUM all-reduce of one 1 per rank
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_world = int(ones.item())
+
+    from ha2g_amd import train_hierarchy as th
+    from ha2g_amd.train_hierarchy import _ret_dict
+    from ha2g_amd._lib import lib as _lib
+
+    def timed_eager(epoch, steps, clock=None):
+        """`steps` eager train steps between barriers + device syncs -> (seconds, last loss dict)."""
+        last_ = None
+        sync()
+        th.host_clock = clock
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last_ = tr.train_iter(epoch, text, spec, target, vid)
+        sync()
+        dt_ = time.perf_counter() - t0
+        th.host_clock = None
+        tr.sync()                                    # outside the timed region: raises if a cluster-GRU hand-off of any step timed out
+        return dt_, last_
+
+    def timed_graph(epoch, steps):
+        """The whole step captured into ONE hipGraph (same kernels, both streams, fresh dropout / noise / Adam counters per replay),
+        `steps` replays between barriers + device syncs -> (seconds, last loss dict).  The capture's memory pool is released afterwards."""
+        graph, gnames, gpacked = tr.capture_step(epoch, text, spec, target, vid)
+        graph.replay()                               # one untimed replay: first-launch upload of the executable graph
         sync()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
+        for _ in range(steps):
             graph.replay()
         sync()
-        dt = time.perf_counter() - t0
-        last = _ret_dict(args, gnames, gpacked.tolist())
-    else:
-        ops.ktimer.enabled = True
-        ops.ktimer.reset()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            last = tr.train_iter(a.epoch, text, spec, target, vid)
-        sync()
-        dt = time.perf_counter() - t0
-        ops.ktimer.enabled = False
-        tr.sync()                                    # outside the timed region: raises if a cluster-GRU hand-off of any step timed out
-    # secondary number: warm-up phase (epoch <= loss_warmup, no D update / no D-phase chain), a third of the timed steps
-    k2 = max(2, a.steps // 3) if not a.primary_only else 0
-    for _ in range(2 if k2 else 0):
-        tr.train_iter(0, text, spec, target, vid)
-    sync()
-    t1 = time.perf_counter()
-    for _ in range(k2):
-        tr.train_iter(0, text, spec, target, vid)
-    sync()
-    ms_warm = (time.perf_counter() - t1) / max(k2, 1) * 1e3 if k2 else float('nan')
-    # disclosure: the same step with EVERY matrix product on the exact fp32 MFMA (ha2g_gemm_set_mode(0)); the default runs the
-    # backward GEMMs/convolutions as split-bf16 (hi+lo halves, 3 bf16 MFMAs, fp32 accumulate), parity margins unchanged
-    from ha2g_amd._lib import lib as _lib
-    _lib.ha2g_gemm_set_mode(0)
-    for _ in range(2 if k2 else 0):
+        dt_ = time.perf_counter() - t0
+        last_ = _ret_dict(args, gnames, gpacked.tolist())
+        del graph, gpacked
+        torch.cuda.empty_cache()
+        return dt_, last_
+
+    for _ in range(a.warmup):
+        tr.train_iter(a.epoch, text, spec, target, vid)
+    # ---- headline: GPU-bound number = hipGraph replays of the captured step (N = 1); eager launches are timed next to it.  With more than one
+    # rank the timed path is the eager one (RCCL collectives inside a capture have never run on this pool: an exception could be caught, a hang not).
+    use_graph = a.launch == 'graph' or (a.launch == 'auto' and world == 1)
+    launch, graph_note = 'eager', None
+    dt = None
+    if use_graph:
+        try:
+            dt, last = timed_graph(a.epoch, a.steps)
+            launch = 'hipGraph replay'
+        except Exception as e:                       # fail over to the eager path, loudly, instead of losing the bench line
+            graph_note = 'graph capture failed (%s: %s); value is the eager number' % (type(e).__name__, str(e)[:200])
+            torch.cuda.synchronize()
+    clock = dict(busy=0.0, steps=0)
+    dt_eager, last_eager = timed_eager(a.epoch, a.steps, clock)
+    if dt is None:
+        dt, last = dt_eager, last_eager
+    eager = dict(ms_per_step=round(dt_eager / a.steps * 1e3, 3), value=round(a.batch * 34 * world / (dt_eager / a.steps), 1),
+                 host_ms_per_step=round(clock['busy'] / max(clock['steps'], 1) * 1e3, 3),
+                 note='host_ms_per_step = wall time inside train_iter minus the final wait for the loss read-back (python + autograd walk + launches)')
+    # ---- roofline leg: a SEPARATE, untimed pass of eager steps with HIP events around the individual launches (on their launch stream)
+    k_roof = 0 if a.primary_only and a.no_roofline else max(2, min(a.steps, 10))
+    ops.ktimer.enabled = True
+    ops.ktimer.reset()
+    for _ in range(k_roof):
         tr.train_iter(a.epoch, text, spec, target, vid)
     sync()
-    t2 = time.perf_counter()
-    for _ in range(k2):
-        tr.train_iter(a.epoch, text, spec, target, vid)
-    sync()
-    ms_exact = (time.perf_counter() - t2) / max(k2, 1) * 1e3 if k2 else float('nan')
-    _lib.ha2g_gemm_set_mode(default_mode)
+    ops.ktimer.enabled = False
+    tr.sync()
+    # ---- secondary numbers, timed like the primary over the same number of steps: warm-up phase (epoch <= loss_warmup: no D update / no D-phase
+    # chain) and the same GAN-phase step with EVERY matrix product on the exact fp32 MFMA (ha2g_gemm_set_mode(0)) -- the default runs the backward
+    # GEMMs / convolutions on the 2-piece split-bf16 product (hi + lo = 16 operand mantissa bits, 3 bf16 MFMAs, fp32 accumulate)
+    timed = (lambda ep, n: timed_graph(ep, n)) if launch != 'eager' else (lambda ep, n: timed_eager(ep, n))
+    ms_warm = ms_exact = float('nan')
+    if not a.primary_only:
+        for _ in range(2):
+            tr.train_iter(0, text, spec, target, vid)
+        ms_warm = timed(0, a.steps)[0] / a.steps * 1e3
+        _lib.ha2g_gemm_set_mode(0)
+        for _ in range(2):
+            tr.train_iter(a.epoch, text, spec, target, vid)
+        ms_exact = timed(a.epoch, a.steps)[0] / a.steps * 1e3
+        _lib.ha2g_gemm_set_mode(default_mode)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -274,18 +314,23 @@ def main():
                              mean_us=round(mean_us, 1), traffic=None)
         out = dict(metric='pose-frames/sec (train step) for hierarchy.yml B=128 T=34', value=round(value, 1), unit='pose-frames/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling='weak',
-                   vs_baseline=None, dtype='bf16' if a.bf16 else 'f32', data='synthetic', launch='hipGraph replay' if a.graph else 'eager',
+                   vs_baseline=None,
+                   dtype=('bf16 (operands; fp32 accumulate, fp32 storage and master weights)' if a.bf16 else
+                          'f32 (storage, accumulation, forward products: fp32 MFMA; backward products: bf16x2 split = 16-bit operand mantissa, fp32 accumulate)'),
+                   data='synthetic', launch=launch, launch_note=graph_note, rccl_world=rccl_world, eager=eager,
                    matrix_core=('bf16 operands (1 MFMA per product), fp32 accumulate, fp32 storage and master weights; GRU recurrences fp32' if a.bf16 else
-                                'forward: fp32 MFMA; backward GEMMs/convs: split-bf16 x3 MFMA with fp32 accumulate (fp32-class, same parity bar)'),
-                   exact_fp32_matrix_core=dict(ms_per_step=round(ms_exact, 3), value=round(a.batch * 34 * world / (ms_exact * 1e-3), 1)),
-                   warmup_phase=dict(ms_per_step=round(ms_warm, 3), value=round(a.batch * 34 * world / (ms_warm * 1e-3), 1)),
+                                'forward: fp32 MFMA; backward GEMMs/convs/BPTT: 2-piece split-bf16 (hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; 4e-6 rms-rel per GEMM vs 4e-7 for fp32 MFMA); '
+                                'the fp32-arithmetic number is exact_fp32_matrix_core'),
+                   exact_fp32_matrix_core=dict(ms_per_step=round(ms_exact, 3), value=round(a.batch * 34 * world / (ms_exact * 1e-3), 1), steps=a.steps, launch=launch,
+                                               arithmetic='every matrix product on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 (exact fp32, the reference\'s arithmetic class)'),
+                   warmup_phase=dict(ms_per_step=round(ms_warm, 3), value=round(a.batch * 34 * world / (ms_warm * 1e-3), 1), steps=a.steps, launch=launch),
                    config=dict(workload='%s hierarchy train step, B=%d per GPU, T=34, %d-d pose, '
                                         'spec (128,70), n_words=%d, n_spk=%d, dropout 0.3, %s' % (
                                             'config_expressive/hierarchy.yml TED-Expressive' if a.expressive else 'config/hierarchy.yml TED-Gesture', a.batch, P, a.n_words, a.n_spk, 'GAN phase (epoch %d > loss_warmup)' % a.epoch
                                             if a.epoch > args.loss_warmup else 'warm-up phase (epoch %d)' % a.epoch),
                                global_batch=a.batch * world, parallelism='dp%d' % world,
                                word_embedding_updates='row-wise (compact gradients, lazy Adam; bit-identical to dense)' if a.sparse_embeddings else 'dense'),
-                   gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, roofline_bwd=roof_bwd, roofline_gemm=roof_gemm, roofline_conv=roof_conv, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
+                   gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, roofline_bwd=roof_bwd, roofline_gemm=roof_gemm, roofline_conv=roof_conv, roofline_pass='separate untimed pass of %d eager steps, HIP events around each launch on its launch stream' % k_roof, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
         if world == 1 and not a.no_cpu_baseline and not a.expressive:
             out['cpu_baseline'] = cpu_baseline(a.epoch, a.n_words, a.n_spk)
         print(json.dumps(out))

@@ -71,6 +71,18 @@ CASES = {
 }
 
 
+# Headline-size step fixtures (round 3; tests/golden/cfg2_b128.npz, cfg3_b128.npz): BASELINE configs 2 and 3 run through the
+# reference's own train_iter_hierarchy[_expressive] at B=128, H=300, 4 layers, 20 000 words, 1 371 speakers, spec (128,70) --
+# loss dicts, per-tensor gradient / parameter / BatchNorm-buffer digests of two consecutive steps (epoch 0, epoch 11).  Step-only,
+# GPU-side tests only (the CPU oracle is pinned by CASES; a B=128 float64 oracle step needs ~40 GB and minutes).  At this size
+# some text-encoder ReLU input always sits within fp32 rounding of zero, so the generator's perturbed runs also perturb the word
+# embedding tables by one fp32 ulp (`perturb_text`): the integer tokens would otherwise never re-roll those decisions.
+BIG_CASES = {
+    'cfg2_b128': dict(B=128, hidden_size=300, n_layers=4, n_words=20000, n_spk=1371, seed=128),
+    'cfg3_b128': dict(B=128, hidden_size=300, n_layers=4, n_words=20000, n_spk=1371, seed=129, expressive=True),
+}
+
+
 # Audio-tower fixtures of round 2.  name: (C_in, C, H_in, W_in, first = stride-2 block with the 1x1 downsample branch)
 # * BLOCK_CASES / TAPS_CASE (tests/golden/blocks.npz): every distinct SEBasicBlock geometry and the three taps + blend at a
 #   REDUCED spatial size, with the seed searched by the generator so that no ReLU input lies within 1.5e-5 (relative) of

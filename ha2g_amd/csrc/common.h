@@ -36,6 +36,18 @@ int conv3x3_c32_wgrad_launch(const float* x, const float* dy, float* part, int N
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device helpers ----
+// The two-piece bf16 split of the split-bf16 inner product (gemm.hip, conv_planes.hip): hi = bf16(x) round-to-nearest-even (v_cvt_pk_bf16_f32),
+// lo = bf16(x - hi); two values per call, packed {b | a} like the MFMA operand words.  Producers that write pre-split planes and consumers
+// that split at staging time must use THIS function: the bit-identity of the plane-based kernels rests on it.
+typedef __bf16 ha2g_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float ha2g_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_bf16(float a, float b, unsigned& hi, unsigned& lo) {
+    ha2g_f32x2_t v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, ha2g_bf16x2_t));
+    ha2g_f32x2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, ha2g_bf16x2_t));
+}
+
 // Gate non-linearities on the hardware exp2/rcp units (v_exp_f32 / v_rcp_f32, ~1 ulp each): absolute error
 // ~2e-7 on values in (0,1) / (-1,1), far inside the 1e-4 parity budget, and ~10x fewer VALU slots than libm's
 // expf/tanhf in the recurrent kernels' serial epilogue.  Saturate cleanly: exp -> inf gives rcp -> 0.

@@ -32,6 +32,8 @@
 // 256-CU MI355X: 240 workgroups of 256 threads, one per CU), loops over larger batches, and reports "unsupported" (the
 // caller then uses gru.hip) on a device or partition with fewer than 2 G compute units.
 #include "common.h"
+#include <mutex>
+#include <unordered_map>
 
 namespace {
 
@@ -622,8 +624,13 @@ __global__ __launch_bounds__(1024) void cluster_epoch_kernel(unsigned* __restric
 // Tag base of one launch.  Eager launches draw it from a host counter (no extra kernel); under stream capture the launch reads the
 // device-side epoch, bumped by cluster_epoch_kernel in front of it, so that every replay of the graph stamps new tags.  The two
 // sequences live in disjoint tag namespaces (bit 31).  Returns the device epoch pointer to pass (nullptr = use *host_tag0).
+// The host sequence is kept PER EXCHANGE BUFFER (one per device in ha2g_amd.ops) under a mutex: both Python bindings release the GIL, and a
+// process-wide counter would, on its wrap, clear only the buffer of the device that happened to launch -- another device's buffer would keep
+// old tags that the restarted sequence could meet again.  A buffer re-allocated at the same address (zeroed by the caller) simply continues
+// its sequence: tags stay unique per buffer over time.
 const unsigned* launch_tag_base(void* xch, hipStream_t st, unsigned* host_tag0) {
-    static unsigned host_epoch = 0;
+    static std::mutex mu;
+    static std::unordered_map<void*, unsigned> epochs;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
         unsigned* epoch = (unsigned*)((char*)xch + XCH_BYTES);
@@ -631,7 +638,9 @@ const unsigned* launch_tag_base(void* xch, hipStream_t st, unsigned* host_tag0) 
         *host_tag0 = 0;
         return epoch;
     }
-    if (++host_epoch >= EPOCH_WRAP) {                    // ~33 M launches: clear every tag once, restart the sequence
+    std::lock_guard<std::mutex> lock(mu);
+    unsigned& host_epoch = epochs[xch];
+    if (++host_epoch >= EPOCH_WRAP) {                    // ~33 M launches on this buffer: clear its tags once, restart its sequence
         (void)hipMemsetAsync(xch, 0, XCH_BYTES, st);
         host_epoch = 1;
     }

@@ -69,3 +69,27 @@ extern "C" int ha2g_colsum_f32(const float* X, long ld, long rows, int cols, flo
     HA2G_CHECK_LAUNCH("colsum");
     return 0;
 }
+
+
+// ---- test aid: hold compute units for a while (tests/test_gpu_ddp2.py: the cluster GRU under foreign co-resident work) ----
+namespace {
+// One 256-thread workgroup that owns its CU's whole LDS (no other LDS-using workgroup fits beside it) and spins on the 100 MHz wall clock.
+__global__ __launch_bounds__(256) void occupy_kernel(long ticks, int* __restrict__ sink) {
+    __shared__ int hog[(160 * 1024 - 64) / 4];
+    hog[threadIdx.x] = (int)threadIdx.x;
+    __syncthreads();
+    const long t0 = wall_clock64();
+    int v = 0;
+    while (wall_clock64() - t0 < ticks) { v += hog[(threadIdx.x + v) & 255]; __builtin_amdgcn_s_sleep(8); }
+    if (v == 0x7fffffff) *sink = v;                    // keeps the LDS reads alive
+}
+}  // namespace
+
+/* `blocks` workgroups, each monopolising one compute unit's LDS for `microseconds` (a stand-in for a foreign kernel, e.g. an RCCL
+ * collective, resident while a cluster GRU launch needs its 240 workgroups co-resident).  sink: any device int. */
+extern "C" int ha2g_debug_occupy(int blocks, long microseconds, int* sink, void* stream) {
+    HA2G_REQUIRE(blocks >= 1 && blocks <= 256 && microseconds >= 0, "debug_occupy: 1..256 blocks");
+    hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, microseconds * 100, sink);
+    HA2G_CHECK_LAUNCH("debug_occupy");
+    return 0;
+}

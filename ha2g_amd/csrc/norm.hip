@@ -230,10 +230,14 @@ __global__ void pool_final_kernel(const double* __restrict__ part, int nchunk, i
 }
 
 // dx = gamma * invstd * (dy - sum_dy/N - xhat * sum_dy_xhat/N)
+// PL = 1: dx is ALSO (or, with dx == nullptr, ONLY) written as two bf16 planes  hi = bf16(dx), lo = bf16(dx - hi)  -- the operand format of the
+// plane-based split-bf16 consumers (conv_planes.hip): this pass is HBM-bound, the split rides in its shadow, and the convolution data /
+// weight gradients that read the tensor no longer split it once per consumer tile.
+template <int PL>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, float* __restrict__ dx,
-                                    long rows, int C, int relu_mask) {
+                                    long rows, int C, int relu_mask, unsigned short* __restrict__ dx_hi, unsigned short* __restrict__ dx_lo) {
     const int C4 = C >> 2;
     const long total = rows * C4;
     const float invn = 1.f / (float)rows;
@@ -252,7 +256,13 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
         if (relu_mask) {          // x is a ReLU output (conv -> ReLU -> BN): chain the ReLU derivative, mask = (x > 0)
             r.x = v.x > 0.f ? r.x : 0.f; r.y = v.y > 0.f ? r.y : 0.f; r.z = v.z > 0.f ? r.z : 0.f; r.w = v.w > 0.f ? r.w : 0.f;
         }
-        reinterpret_cast<float4*>(dx)[i] = r;
+        if (!PL || dx != nullptr) reinterpret_cast<float4*>(dx)[i] = r;
+        if (PL) {
+            uint2 h, l;
+            split2_bf16(r.x, r.y, h.x, l.x); split2_bf16(r.z, r.w, h.y, l.y);
+            reinterpret_cast<uint2*>(dx_hi)[i] = h;
+            reinterpret_cast<uint2*>(dx_lo)[i] = l;
+        }
     }
 }
 
@@ -421,9 +431,24 @@ int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const fl
     hipLaunchKernelGGL(col_partial_kernel<1>, dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
     hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, C, dbeta, dgamma, acc_dbeta, acc_dgamma);
     if (dx)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, st, dy, x, mean, invstd, gamma, dbeta,
-                           dgamma, dx, rows, C, relu_mask);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, st, dy, x, mean, invstd, gamma, dbeta,
+                           dgamma, dx, rows, C, relu_mask, (unsigned short*)nullptr, (unsigned short*)nullptr);
     HA2G_CHECK_LAUNCH("bn_bwd");
+    return 0;
+}
+// ha2g_bn_bwd_f32 whose dx goes out as bf16 planes dx_hi / dx_lo [rows][C] (and, when dx != NULL, in fp32 as well)
+int ha2g_bn_bwd_planes_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx, void* dx_hi,
+                           void* dx_lo, float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta,
+                           float* ws, void* stream) {
+    HA2G_REQUIRE(okC(C), "bn: unsupported channel count %d", C);
+    HA2G_REQUIRE(dx_hi != nullptr && dx_lo != nullptr, "bn_bwd_planes: null plane");
+    hipStream_t st = (hipStream_t)stream;
+    int nb = chunk_blocks(rows);
+    hipLaunchKernelGGL(col_partial_kernel<1>, dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
+    hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, C, dbeta, dgamma, acc_dbeta, acc_dgamma);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, st, dy, x, mean, invstd, gamma, dbeta, dgamma, dx,
+                       rows, C, relu_mask, (unsigned short*)dx_hi, (unsigned short*)dx_lo);
+    HA2G_CHECK_LAUNCH("bn_bwd_planes");
     return 0;
 }
 // out[n][c] = mean over HW of x[n][hw][c]

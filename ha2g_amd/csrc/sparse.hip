@@ -53,24 +53,31 @@ __global__ void adam_scalars_kernel(const int* __restrict__ step, double lr, dou
 __global__ __launch_bounds__(128) void sparse_adam_kernel(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V, int* __restrict__ last,
                                                           const long* __restrict__ ids, const int* __restrict__ count, const float* __restrict__ vals,
                                                           const float2* __restrict__ table, const int* __restrict__ step, int C, float b1, float b2,
-                                                          float omb1, float omb2, float eps) {
+                                                          float omb1, float omb2, float eps, int cap, double lr_d, double b1_d, double b2_d) {
     const int r = blockIdx.x;
     if (r >= *count) return;
     const long row = ids[r];
     const int t = *step, t0 = last[row];
     const int zero_to = vals ? t - 1 : t;                      // last step replayed with a zero gradient
     const bool fresh = t0 == 0;                                // never updated: m = v = 0, zero-gradient steps are exact no-ops
+    // per-step scalars: the device table up to `cap` steps (adam_scalars_kernel stops writing there: a captured graph can replay past any
+    // host-side count), beyond it the same double-precision prologue recomputed in place -- same values, never an out-of-bounds read
+    auto scalars = [&](int s) -> float2 {
+        if (s < cap) return table[s];
+        const double bc1 = 1.0 - pow(b1_d, (double)s), bc2 = 1.0 - pow(b2_d, (double)s);
+        return make_float2((float)(lr_d / bc1), (float)(1.0 / sqrt(bc2)));
+    };
     for (int c = threadIdx.x; c < C; c += 128) {
         const long o = row * C + c;
         float p = W[o], m = M[o], v = V[o];
         if (!fresh)
             for (int s = t0 + 1; s <= zero_to; ++s) {
-                const float2 sc = table[s];
+                const float2 sc = scalars(s);
                 m = b1 * m; v = b2 * v;
                 p -= sc.x * m / (sqrtf(v) * sc.y + eps);
             }
         if (vals) {
-            const float2 sc = table[t];
+            const float2 sc = scalars(t);
             const float g = vals[(long)r * C + c];
             m = b1 * m + omb1 * g; v = b2 * v + omb2 * g * g;
             p -= sc.x * m / (sqrtf(v) * sc.y + eps);
@@ -101,10 +108,11 @@ int ha2g_adam_scalars(const int* step, double lr, double b1, double b2, void* ta
     return 0;
 }
 int ha2g_sparse_adam_f32(float* W, float* M, float* V, int* last, const long* ids, const int* count, int max_rows, const float* vals,
-                         const void* table, const int* step, int C, double b1, double b2, double eps, void* stream) {
+                         const void* table, const int* step, int C, double b1, double b2, double eps, int table_steps, double lr, void* stream) {
     if (max_rows <= 0) return 0;
+    HA2G_REQUIRE(table_steps >= 1, "sparse_adam: empty scalar table");
     hipLaunchKernelGGL(sparse_adam_kernel, dim3(max_rows), dim3(128), 0, (hipStream_t)stream, W, M, V, last, ids, count, vals,
-                       (const float2*)table, step, C, (float)b1, (float)b2, (float)(1.0 - b1), (float)(1.0 - b2), (float)eps);
+                       (const float2*)table, step, C, (float)b1, (float)b2, (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, table_steps, lr, b1, b2);
     HA2G_CHECK_LAUNCH("sparse_adam");
     return 0;
 }

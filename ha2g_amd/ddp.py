@@ -9,12 +9,54 @@ import torch.distributed as dist
 
 
 FORCE_ACTIVE = False      # tests: take the collective code path even in a world of one rank (the arithmetic is then the identity)
+DISABLED = False          # tests: a rank of an initialised world computes its purely local step (reference value of the averaged one)
 
 
 def active(group=None):
-    if not (dist.is_available() and dist.is_initialized()):
+    if DISABLED or not (dist.is_available() and dist.is_initialized()):
         return False
     return FORCE_ACTIVE or dist.get_world_size(group) > 1
+
+
+class _Done:
+    """Work handle of a collective that was completed synchronously (host-staged gloo path)."""
+
+    def wait(self):
+        return True
+
+
+def _host_staged(t, group):
+    """gloo with device tensors (the world-size-2 hardware test: two processes on ONE GPU, where RCCL refuses duplicate devices): gloo's
+    device-tensor support differs per collective and per build, so device tensors are staged through the host.  Never taken under RCCL."""
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def all_reduce_(t, group=None, async_op=False):
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return _Done() if async_op else None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def all_gather_(outs, t, group=None):
+    if _host_staged(t, group):
+        hs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        dist.all_gather(hs, t.cpu(), group=group)
+        for o, h in zip(outs, hs):
+            o.copy_(h)
+        return
+    dist.all_gather(outs, t, group=group)
+
+
+def broadcast_one_(t, src=0, group=None):
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src, group=group)
+        t.copy_(h)
+        return
+    dist.broadcast(t, src, group=group)
 
 
 def average_(flat, group=None, async_op=False):
@@ -23,12 +65,38 @@ def average_(flat, group=None, async_op=False):
     if ws == 1 and not FORCE_ACTIVE:
         return None
     flat.mul_(1.0 / ws)
-    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return all_reduce_(flat, group, async_op)
 
 
 def broadcast_(tensors, src=0, group=None):
     for t in tensors:
-        dist.broadcast(t, src, group=group)
+        broadcast_one_(t, src, group)
+
+
+def bn_buffers(modules):
+    """The BatchNorm running statistics (running_mean / running_var buffers) of a list of modules, in registration order."""
+    return [b for m in modules for k, b in m.named_buffers() if k.endswith(('running_mean', 'running_var'))]
+
+
+def sync_bn_stats_(modules, mode='mean', group=None):
+    """BatchNorm running statistics are rank-local under data parallelism (each rank normalises its own shard).  Before a checkpoint
+    or an evaluation pass make them identical on every rank: mode 'mean' = average over ranks (ONE all-reduce over the concatenated buffers),
+    'rank0' = adopt rank 0's (what torch DDP's broadcast_buffers does).  num_batches_tracked is equal on every rank by construction."""
+    bufs = bn_buffers(modules)
+    if not bufs or not active(group):
+        return 0
+    flat = torch.cat([b.reshape(-1) for b in bufs])
+    if mode == 'mean':
+        average_(flat, group)
+    elif mode == 'rank0':
+        broadcast_one_(flat, 0, group)
+    else:
+        raise ValueError('sync_bn_stats_: mode must be "mean" or "rank0", got %r' % (mode,))
+    o = 0
+    for b in bufs:
+        b.copy_(flat[o:o + b.numel()].view_as(b))
+        o += b.numel()
+    return len(bufs)
 
 
 def rank_seed(base, rank=None):
@@ -46,27 +114,38 @@ def gather_sparse_rows(ids, count, rows, group=None):
     ws = dist.get_world_size(group)
     cnt = count.to(torch.int64).reshape(1)
     counts = [torch.empty_like(cnt) for _ in range(ws)]
-    dist.all_gather(counts, cnt, group=group)
-    mx = int(torch.stack(counts).max().item())
+    all_gather_(counts, cnt, group)
+    mx = max(int(torch.stack(counts).max().item()), 1)       # never an empty collective
+    if ids.shape[0] < mx:                                  # a rank whose own list is shorter than the longest one (e.g. nothing pending)
+        ids = torch.cat([ids, ids.new_zeros(mx - ids.shape[0])])
+        rows = torch.cat([rows, rows.new_zeros(mx - rows.shape[0], rows.shape[1])])
     valid = torch.arange(mx, device=ids.device) < cnt
     ids_s = torch.where(valid, ids[:mx], torch.zeros_like(ids[:mx])).contiguous()
     rows_s = (rows[:mx] * valid.unsqueeze(1) * (1.0 / ws)).contiguous()
     ids_all = [torch.empty_like(ids_s) for _ in range(ws)]
     rows_all = [torch.empty_like(rows_s) for _ in range(ws)]
-    dist.all_gather(ids_all, ids_s, group=group)
-    dist.all_gather(rows_all, rows_s, group=group)
+    all_gather_(ids_all, ids_s, group)
+    all_gather_(rows_all, rows_s, group)
     return torch.cat(ids_all), torch.cat(rows_all)
 
 
 def exchange_sparse_(table, group=None):
     """Data-parallel mean of one sparse table's compact gradient: gather every rank's rows, merge repeated ids (deterministic row
     sums in rank order) -- replaces the dense n_words x 300 all-reduce."""
-    if not active(group) or not table.pending:
+    if not active(group):
         return
     from . import ops
-    ids, count, rows = table.merged()
+    # EVERY rank takes part in the three all-gathers, whatever its local state: a rank with nothing pending (a skipped backward, a
+    # non-finite-loss skip on that rank only) contributes count 0 -- an early return here would leave the other ranks' collectives hanging
+    if table.pending:
+        ids, count, rows = table.merged()
+    else:
+        w = table.weight
+        ids = torch.zeros(1, dtype=torch.int64, device=w.device)
+        count = torch.zeros(1, dtype=torch.int32, device=w.device)
+        rows = torch.zeros(1, w.shape[1], dtype=torch.float32, device=w.device)
     ids_all, rows_all = gather_sparse_rows(ids, count, rows, group)
-    table.pending = [ops.merge_rows(ids_all, rows_all, table.map)]
+    table.pending = [ops.merge_rows(ids_all, rows_all, table.map)] if ids_all.numel() else []
 
 
 def average_module_grads_(optimizers, group=None):

@@ -141,6 +141,8 @@ class EmbeddingSpaceEvaluator:
         feat1 = torch.cat(self.generated_feat_list[:500])
         random_idx = torch.randperm(len(self.generated_feat_list))[:500]
         feat2 = torch.cat([self.generated_feat_list[int(x)] for x in random_idx])
+        if feat1.shape != feat2.shape:                   # > 500 pushed batches with a ragged last one: the reference's numpy expression raises here too
+            raise ValueError('get_diversity_scores: operands could not be broadcast together with shapes %s %s' % (tuple(feat1.shape), tuple(feat2.shape)))
         acc = torch.zeros(1, dtype=torch.float64, device=self.device)
         check(lib.ha2g_l1_rows_f64(feat1.data_ptr(), feat2.data_ptr(), feat1.numel(), acc.data_ptr(), _st()))
         return float(acc.item()) / feat1.shape[0]

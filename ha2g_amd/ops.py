@@ -751,16 +751,33 @@ def bn_apply_pool(x, mean, invstd, gamma, beta):
     return y, pooled
 
 
-def bn_bwd(dy2, x2, mean, invstd, gamma, need_dx=True, relu_mask=False, acc=None):
-    """acc = (gamma.grad, beta.grad) buffers to accumulate into directly (the returned dgamma/dbeta are the fresh sums)."""
+def bn_bwd(dy2, x2, mean, invstd, gamma, need_dx=True, relu_mask=False, acc=None, planes=False):
+    """acc = (gamma.grad, beta.grad) buffers to accumulate into directly (the returned dgamma/dbeta are the fresh sums).
+    planes: dx is also written as (hi, lo) bf16 planes for the plane-based split-bf16 consumers (csrc/conv_planes.hip) and the return value
+    grows to (dx, dgamma, dbeta, (hi, lo)); with need_dx=False ONLY the planes are written (dx is None)."""
     rows, C = x2.shape
     dx = torch.empty_like(x2) if need_dx else None
     dgamma, dbeta = empty(C, like=x2), empty(C, like=x2)
     ag, ab = acc if acc is not None else (None, None)
+    if planes:
+        hi = torch.empty(rows, C, dtype=torch.bfloat16, device=x2.device)
+        lo = torch.empty(rows, C, dtype=torch.bfloat16, device=x2.device)
+        check(lib.ha2g_bn_bwd_planes_f32(dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dx), hi.data_ptr(),
+                                         lo.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, C, int(relu_mask), _p(ag), _p(ab),
+                                         workspace(x2.device).data_ptr(), _stream()))
+        return dx, dgamma, dbeta, (hi, lo)
     check(lib.ha2g_bn_bwd_f32(dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dx),
                               dgamma.data_ptr(), dbeta.data_ptr(), rows, C, int(relu_mask), _p(ag), _p(ab),
                               workspace(x2.device).data_ptr(), _stream()))
     return dx, dgamma, dbeta
+
+
+def to_planes(x):
+    """fp32 tensor -> (hi, lo) bf16 planes of the same shape: hi = bf16(x), lo = bf16(x - hi) (the operand split of the split-bf16 product)."""
+    x = _f32c(x)
+    hi, lo = torch.empty_like(x, dtype=torch.bfloat16), torch.empty_like(x, dtype=torch.bfloat16)
+    check(lib.ha2g_f32_to_planes(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), x.numel(), _stream()))
+    return hi, lo
 
 
 class BatchNormFunction(torch.autograd.Function):
@@ -1278,7 +1295,7 @@ class SparseTable:
         w = self.weight.data
         check(lib.ha2g_sparse_adam_f32(w.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.last.data_ptr(), ids.data_ptr(), count.data_ptr(),
                                        max_rows, _p(vals), self.opt.table.data_ptr(), self.opt.step_t.data_ptr(), w.shape[1],
-                                       float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), _stream()))
+                                       float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), self.opt.TABLE_STEPS, float(g['lr']), _stream()))
 
     def catch_up(self, ids, count, max_rows):
         self._run(ids, count, max_rows, None)

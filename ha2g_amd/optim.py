@@ -84,8 +84,7 @@ class FusedAdam(torch.optim.Optimizer):
                                 self.total, float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
                                 self.step_t.data_ptr(), st))
         if self.sparse_tables:
-            self._host_step += 1
-            assert self._host_step < self.TABLE_STEPS - 1, 'FusedAdam: per-step scalar table exhausted'
+            self._host_step += 1        # informational; past TABLE_STEPS the row kernel recomputes the scalars itself (sparse.hip)
             check(lib.ha2g_adam_scalars(self.step_t.data_ptr(), float(g['lr']), float(g['betas'][0]), float(g['betas'][1]),
                                         self.table.data_ptr(), self.TABLE_STEPS, st))
             for tb in self.sparse_tables:

@@ -68,15 +68,21 @@ class HierarchyTrainer:
 
     def broadcast_parameters(self, src=0):
         """DDP start-up: every rank adopts rank `src`'s parameters and buffers."""
-        import torch.distributed as dist
+        from . import ddp
         for o in self.gen_opts + [self.audio_opt, self.text_opt, self.dis_opt]:
-            dist.broadcast(o.flat_p, src)
+            ddp.broadcast_one_(o.flat_p, src)
         for m in self.modules():
             for p in m.parameters():
                 if not p.requires_grad or getattr(p, '_ha2g_sparse', None) is not None:      # frozen / row-wise tables live outside the flat buffers
-                    dist.broadcast(p.data, src)
+                    ddp.broadcast_one_(p.data, src)
             for b in m.buffers():
-                dist.broadcast(b, src)
+                ddp.broadcast_one_(b, src)
+
+    def sync_bn_stats(self, mode='mean'):
+        """Call before a checkpoint / validation pass under data parallelism: the BatchNorm running statistics of the audio encoder and the
+        discriminator are rank-local during training (ha2g_amd.ddp.sync_bn_stats_); afterwards every rank would save the same state_dict."""
+        from . import ddp
+        return ddp.sync_bn_stats_(self.modules(), mode)
 
     def capture_step(self, epoch, in_text_padded, in_spec, target, vid_indices, warmup=2):
         """Capture one whole train step on these (static) input tensors into a hipGraph.  Returns (graph, names, packed):
@@ -89,6 +95,8 @@ class HierarchyTrainer:
                 self.train_iter(epoch, in_text_padded, in_spec, target, vid_indices, return_tensors=True)
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
+        from .train_hierarchy import drain_cluster_errors
+        drain_cluster_errors(block=True)             # error words of earlier eager steps are looked at (and raised) BEFORE the capture starts
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=s):      # same stream as the warm-up: its workspace exists already, outside the capture
             names, packed = self.train_iter(epoch, in_text_padded, in_spec, target, vid_indices, return_tensors=True)

@@ -11,8 +11,8 @@ truthiness quirk that drops KLD / DIV_REG when exactly 0).  Differences are pure
   * the <= 8 logged scalars come back in a single device->host copy instead of ~9 .item() syncs.
 """
 import math
-
 import os
+import time
 
 import torch
 
@@ -89,6 +89,7 @@ def _grouped_text_features(gens, in_text):
 
 
 _pinned_bufs = {}
+host_clock = None        # bench.py: {'busy': s, 'steps': n} -- host time spent inside train_iter excluding the final wait for the loss read-back
 _err_watch = []          # (event, pinned int32 word, device): end-of-step copies of the cluster error word not yet looked at
 _err_free = []
 
@@ -162,7 +163,9 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
     warm_up_epochs = args.loss_warmup
     dev = target.device
     B = target.shape[0]
-    drain_cluster_errors()                               # BPTT time-outs of earlier steps whose read-back has arrived
+    t_host0 = time.perf_counter() if host_clock is not None else 0.0
+    if not (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
+        drain_cluster_errors()                           # BPTT time-outs of earlier steps whose read-back has arrived (never inside a capture)
     ops.rng.begin_step()
     L = len(gens)
     consts = _consts(spec, args, dev)
@@ -351,6 +354,9 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
             packed = torch.cat([packed, err[:1].to(torch.float32)])
         return names, packed
     _watch_cluster_errors(dev)                            # BPTT hand-off time-outs: checked without blocking (see drain_cluster_errors)
+    if host_clock is not None:
+        host_clock['busy'] += time.perf_counter() - t_host0
+        host_clock['steps'] += 1
     readback[1].synchronize()                            # the losses left the device before the backward started: no device-wide sync here
     return _ret_dict(args, names, readback[0].tolist())
 

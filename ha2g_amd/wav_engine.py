@@ -65,6 +65,27 @@ def conv_dgrad(dy, w_ohwi, xshape, stride, pad, out=None, beta=0.0):
     return out
 
 
+def dgrad_planes_ok(w_ohwi, stride, pad):
+    Cout, KH, KW, Cin = w_ohwi.shape
+    return PLANES and bool(lib.ha2g_conv2d_dgrad_planes_supported(Cin, Cout, KH, KW, stride, pad))
+
+
+def conv_dgrad_planes(dy_planes, w_ohwi, xshape, stride, pad, out=None, beta=0.0):
+    """conv_dgrad on the pre-split bf16 planes of dy (ops.bn_bwd(..., planes=True)): the weight goes through one re-layout + split launch,
+    the data gradient through the DMA-staged kernel of csrc/conv_planes.hip.  Bit-identical to conv_dgrad() in the default arithmetic mode."""
+    N, H, W, Cin = xshape
+    Cout, KH, KW, _ = w_ohwi.shape
+    hi, lo = dy_planes
+    wh = torch.empty(Cin, KH, KW, Cout, dtype=torch.bfloat16, device=hi.device)
+    wl = torch.empty_like(wh)
+    check(lib.ha2g_conv2d_weight_ihwo_planes(w_ohwi.data_ptr(), wh.data_ptr(), wl.data_ptr(), Cout, KH, KW, Cin, _stream()))
+    if out is None:
+        out = torch.empty(N, H, W, Cin, dtype=torch.float32, device=hi.device)
+    check(lib.ha2g_conv2d_dgrad_planes_f32(hi.data_ptr(), lo.data_ptr(), wh.data_ptr(), wl.data_ptr(), out.data_ptr(), N, H, W, Cin, Cout, KH, KW,
+                                           stride, pad, beta, _stream()))
+    return out
+
+
 def conv_wgrad(x, dy, w_ohwi, stride, pad, into=None):
     """-> gradient as a logical OIHW tensor with channels_last (OHWI) memory, matching the parameter.
     into = the parameter's .grad (logical OIHW, physical OHWI): accumulate there (beta = 1) and return None."""
@@ -144,6 +165,7 @@ def _tap_pack(x, inverse=False, shape=None):
 
 
 import os as _os
+PLANES = _os.environ.get('HA2G_PLANES', '1') != '0'       # producer-side bf16 hi / lo planes for the backward convolutions (round 3; bit-identical A/B switch)
 SIDE_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_WGRAD', '1') != '0'
 SIDE_FC_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_FC', '1') != '0'
 
@@ -219,14 +241,15 @@ class GradSink:
             ops.side.join(device)
             self.forked = False
 
-    def gbn(self, name, dy2, x2, mean, invstd, relu_mask=False):
+    def gbn(self, name, dy2, x2, mean, invstd, relu_mask=False, planes=False):
+        """planes=True: -> (dx fp32, (hi, lo) bf16 planes of dx)"""
         bn = self.P[name]
         tg_, tb_ = self.tgt(bn.gamma), self.tgt(bn.beta)
         acc = (tg_, tb_) if (tg_ is not None and tb_ is not None) else None
-        dx_, dg_, db_ = ops.bn_bwd(dy2, x2, mean, invstd, bn.gamma, relu_mask=relu_mask, acc=acc)
+        r = ops.bn_bwd(dy2, x2, mean, invstd, bn.gamma, relu_mask=relu_mask, acc=acc, planes=planes)
         if acc is None:
-            self.G[name] = (dg_, db_)
-        return dx_
+            self.G[name] = (r[1], r[2])
+        return (r[0], r[3]) if planes else r[0]
 
 
 # ---- one SEBasicBlock (ResNetBlocks.py:21-37,81-95): conv -> ReLU -> BN -> conv -> BN -> SE -> (+ residual) -> ReLU --------
@@ -274,15 +297,22 @@ def block_bwd(dx, saved, P, b, sink):
     dres, db2 = torch.empty_like(b2), torch.empty_like(b2)
     check(lib.ha2g_se_bwd_apply_f32(dout.data_ptr(), out.data_ptr(), sc.data_ptr(), dpool.data_ptr(), dres.data_ptr(),
                                     db2.data_ptr(), N, HW, C, _stream()))
-    dc2 = sink.gbn(b + 'bn2', _rows(db2), _rows(c2), m2, s2).view(c2.shape)
     wb = _ohwi(P[b + 'conv2.weight'])
-    sink.gconv(b + 'conv2.weight', a1, dc2, wb, 1, 1)
-    da1 = conv_dgrad(dc2, wb, a1.shape, 1, 1)
-    dc1 = sink.gbn(b + 'bn1', _rows(da1), _rows(c1), m1, s1, relu_mask=True).view(c1.shape)
     wa = _ohwi(P[b + 'conv1.weight'])
+    # the BatchNorm-backward apply pass is the PRODUCER of the convolutions' dy: where the plane-based data gradient serves the geometry it
+    # also writes dy as bf16 hi / lo planes (same values the consumer tiles used to split out of the fp32 tensor, once instead of per tile)
+    p2, p1 = dgrad_planes_ok(wb, 1, 1), dgrad_planes_ok(wa, stride, 1)
+    dc2 = sink.gbn(b + 'bn2', _rows(db2), _rows(c2), m2, s2, planes=p2)
+    dc2, dc2p = (dc2[0].view(c2.shape), dc2[1]) if p2 else (dc2.view(c2.shape), None)
+    sink.gconv(b + 'conv2.weight', a1, dc2, wb, 1, 1)
+    da1 = conv_dgrad_planes(dc2p, wb, a1.shape, 1, 1) if p2 else conv_dgrad(dc2, wb, a1.shape, 1, 1)
+    dc1 = sink.gbn(b + 'bn1', _rows(da1), _rows(c1), m1, s1, relu_mask=True, planes=p1)
+    dc1, dc1p = (dc1[0].view(c1.shape), dc1[1]) if p1 else (dc1.view(c1.shape), None)
     sink.gconv(b + 'conv1.weight', x, dc1, wa, stride, 1)
-    if cd is None:
-        return conv_dgrad(dc1, wa, x.shape, stride, 1, out=dres, beta=1.0)      # identity shortcut: accumulate onto d(residual)
+    if cd is None:                                                              # identity shortcut: accumulate onto d(residual)
+        if p1:
+            return conv_dgrad_planes(dc1p, wa, x.shape, stride, 1, out=dres, beta=1.0)
+        return conv_dgrad(dc1, wa, x.shape, stride, 1, out=dres, beta=1.0)
     dxin = conv_dgrad(dc1, wa, x.shape, stride, 1)
     dcd = sink.gbn(b + 'downsample.1', _rows(dres), _rows(cd), md, sd).view(cd.shape)
     wd = _ohwi(P[b + 'downsample.0.weight'])

@@ -62,6 +62,17 @@ long ha2g_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, i
 int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout, int KH,
                           int KW, int stride, int pad, float beta, float* ws, long ws_bytes, void* stream);
 int ha2g_conv2d_weight_ohwi_to_ihwo_f32(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream);
+/* ---- plane-based split-bf16 products (round 3; csrc/conv_planes.hip): the operands arrive PRE-SPLIT as two bf16 planes (hi = bf16(x),
+ *      lo = bf16(x - hi)) written once by their producer (ha2g_bn_bwd_planes_f32, the weight re-layout below) and go global -> LDS by DMA; the
+ *      same three-MFMA product, k order and accumulation as the kernels behind ha2g_conv2d_dgrad_f32 in the default mode: bit-identical results.
+ *      Autograd's conv2d backward w.r.t. the input (model/ResNetBlocks.py:24-29 under loss.backward(), train_eval/train_hierarchy.py:264). ---- */
+void ha2g_conv_planes_enable(int on);
+void ha2g_conv_planes_debug(int bits);     /* timing ablations only: 1 = no DMA after the first k tile, 2 = no MFMA (results are then meaningless) */
+int ha2g_f32_to_planes(const float* x, void* hi, void* lo, long n, void* stream);
+int ha2g_conv2d_weight_ihwo_planes(const float* w, void* wt_hi, void* wt_lo, int Cout, int KH, int KW, int Cin, void* stream);
+int ha2g_conv2d_dgrad_planes_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
+int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N, int H, int W,
+                                 int Cin, int Cout, int KH, int KW, int stride, int pad, float beta, void* stream);
 /* Matrix-core mode bits; default 6.  The split-bf16 inner product writes each fp32 operand as hi + lo bf16 halves and
  * runs a_lo*b_hi + a_hi*b_lo + a_hi*b_hi as three bf16 MFMAs with fp32 accumulation (~4e-6 rms-rel per GEMM vs 4e-7).
  *   bit 1 (on):  WEIGHT gradients (dW = dY^T X, conv wgrad) -- the error goes straight to the optimizer;
@@ -130,6 +141,10 @@ int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs,
                                int* err, int B, int T, int H, void* stream);
 /* ablation bits for tools/dbg_cluster.py: 1 no wait, 2 no exchange, 4 force the write-through publish */
 void ha2g_gru_cluster_debug(int mode);
+/* test aid: `blocks` (1..256) workgroups that each hold one compute unit's whole LDS for `microseconds` on `stream` -- a stand-in for a foreign
+ * kernel (an RCCL collective of the data-parallel step, scripts/train.py:133-143 replaced by ha2g_amd/ddp.py) that is resident while a cluster
+ * GRU launch needs its workgroups co-resident; the launch must then complete or set its error word, never hang.  sink: any device int. */
+int ha2g_debug_occupy(int blocks, long microseconds, int* sink, void* stream);
 /* dg [B][T][2][4H] = (d gi_r, d gi_z, d gi_n, d gh_n); wpt = packed_bwd images (dir 0, dir 1); hp (nullable) [B][T][2H] receives
  * the h_prev each step used (y shifted by one step per direction, zero at the sequence ends) = the dW_hh GEMM's operand */
 int ha2g_gru_layer_bwd(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, float* hp, int B, int T,
@@ -151,6 +166,11 @@ int ha2g_bn_apply_pool_f32(const float* x, const float* mean, const float* invst
 int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma,
                     float* dx, float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma /*nullable: += */,
                     float* acc_dbeta /*nullable: += */, float* ws, void* stream);
+/* the same with dx written as two bf16 planes dx_hi / dx_lo [rows][C] (hi = bf16(dx), lo = bf16(dx - hi)) for the plane-based split-bf16
+ * convolution gradients below; dx (fp32) may be NULL when every consumer reads the planes */
+int ha2g_bn_bwd_planes_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx, void* dx_hi,
+                           void* dx_lo, float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta,
+                           float* ws, void* stream);
 /* ---- squeeze-excite pointwise pieces (model/ResNetBlocks.py:81-95 and the residual tail :33-36) ---- */
 int ha2g_hw_mean_f32(const float* x, float* out, int N, int HW, int C, void* stream);
 int ha2g_se_scale_add_relu_f32(const float* x, const float* s, const float* res, float* out, int N, int HW, int C, void* stream);
@@ -255,11 +275,13 @@ int ha2g_adam_f32(float* p, const float* g, float* m, float* v, long n, double l
  * adam_scalars: table[*step] = {lr/(1-b1^t), 1/sqrt(1-b2^t)} exactly as ha2g_adam_f32's prologue computes them (float2 table of `cap` entries).
  * sparse_adam: for the `*count` distinct rows `ids` (grid = max_rows): replay the zero-gradient Adam updates the row missed since last[row]
  *   (dense Adam moves EVERY row every step), then, when vals != NULL, apply step *step with gradient row vals[r]; vals == NULL = catch-up only
- *   (before an embedding read).  Bit-identical to ha2g_adam_f32 on a dense gradient with zeros elsewhere. */
+ *   (before an embedding read).  Bit-identical to ha2g_adam_f32 on a dense gradient with zeros elsewhere.  Steps >= table_steps (a captured
+ *   graph replays past any host-side count) take their scalars from the same double-precision formula with `lr` instead of the table; the
+ *   catch-up of a row is one serial chain over every step it missed (dense-Adam semantics), i.e. O(steps since the row was last touched). */
 int ha2g_unique_tokens(const long* tok, int n, int* map, int* cpos, long* uniq, long* remap, int* count, void* stream);
 int ha2g_adam_scalars(const int* step, double lr, double b1, double b2, void* table, int cap, void* stream);
 int ha2g_sparse_adam_f32(float* W, float* M, float* V, int* last, const long* ids, const int* count, int max_rows, const float* vals,
-                         const void* table, const int* step, int C, double b1, double b2, double eps, void* stream);
+                         const void* table, const int* step, int C, double b1, double b2, double eps, int table_steps, double lr, void* stream);
 int ha2g_iota_ids(long* ids, int* count, int n, void* stream);
 
 /* ---- log-mel front-end on the GPU: replaces the offline librosa step

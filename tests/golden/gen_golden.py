@@ -196,10 +196,17 @@ def module_goldens(case, out, dt, perturb=0.0):
         out['eval/gen/out'] = o.double().numpy()
 
 
-def step_goldens(case, out, dt, expressive=False, perturb=0.0):
-    """Two consecutive train steps (epoch 0 = warm-up phase, epoch 11 = GAN phase) through the reference."""
+def step_goldens(case, out, dt, expressive=False, perturb=0.0, perturb_text=False):
+    """Two consecutive train steps (epoch 0 = warm-up phase, epoch 11 = GAN phase) through the reference.
+    perturb_text: the perturbed runs also move the word-embedding tables by `perturb` (one fp32 ulp) -- the tokens are integers,
+    so nothing else would re-roll the text encoders' rounding / ReLU decisions (BIG_CASES)."""
     pose_dims = (24, 30, 36, 66, 96, 126) if expressive else (15, 21, 27)
     args, gens, dis, aud, txt = build(case, pose_dims, len(pose_dims), dt)
+    if perturb and perturb_text:
+        with torch.no_grad():
+            for i, m in enumerate(gens + [txt]):
+                emb = m.text_encoder.embedding if hasattr(m, 'text_encoder') else m.embedding
+                emb.weight.copy_(perturbed(emb.weight, perturb, 100 + i))
     B = case['B']
     P = pose_dims[-1]
     text, spec, target, vid = proc.make_batch(B, P, case['n_words'], case['n_spk'], case['seed'])
@@ -677,8 +684,33 @@ def main_extra(only):
         write_fixture(name, runs, NPERT)
 
 
+def main_big(only):
+    """Headline-size step fixtures (config.BIG_CASES): float64 truth, the plain float32 run, the float64 conditioning run and
+    NPERT one-ulp-perturbed float32 runs of the reference at B=128 (each run = 2 steps; ~21 GB in float32, ~42 GB in float64).
+    Only generated when named on the command line."""
+    global PERTURB_DRAW
+    from ha2g_amd.config import BIG_CASES
+    import time
+    for name, case in BIG_CASES.items():
+        if name not in only:
+            continue
+        print('case', name, case, flush=True)
+        NPERT = 4
+        plan = [('f64', torch.float64, 0.0, 0), ('f32', torch.float32, 0.0, 0), ('cond', torch.float64, 6e-8, 0)]
+        plan += [('f32p%d' % i, torch.float32, 6e-8, i + 1) for i in range(NPERT)]
+        runs = {}
+        for tag, dt, pert, draw in plan:
+            PERTURB_DRAW = draw
+            o = runs[tag] = {}
+            t0 = time.time()
+            step_goldens(case, o, dt, expressive=bool(case.get('expressive')), perturb=pert, perturb_text=True)
+            print('   run', tag, 'done in %.0f s' % (time.time() - t0), flush=True)
+        write_fixture(name, runs, NPERT)
+
+
 def main():
     only = sys.argv[1:]
+    main_big(only)
     main_extra(only)
     main_extra32(only)
     for name, case in CASES.items():

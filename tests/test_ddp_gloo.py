@@ -157,3 +157,79 @@ def test_sparse_row_gather_two_ranks(tmp_path):
     assert torch.equal(ids_all[:5], res['ids0'][:5]) and int(ids_all[5:9].abs().sum()) == 0      # rank 0's block: 5 valid, 4 padded
     assert torch.allclose(rows_all[:5], res['rows0'][:5] * 0.5) and float(rows_all[5:9].abs().sum()) == 0.0
     assert int((ids_all[9:] != 0).sum()) == 8                                                     # rank 1: 9 valid (slot 0 + 8 ids)
+
+
+def _bn_worker(rank, world, port, out):
+    """ddp.sync_bn_stats_: BatchNorm running statistics diverge per rank during data-parallel training (each rank normalises its own shard);
+    'mean' averages them with ONE collective, 'rank0' adopts rank 0's; num_batches_tracked and the affine parameters are not touched."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ha2g_amd import ddp
+    torch.manual_seed(1)
+    mods = [torch.nn.Sequential(torch.nn.Conv1d(3, 4, 3), torch.nn.BatchNorm1d(4)), torch.nn.BatchNorm2d(5)]
+    g = torch.Generator().manual_seed(10 + rank)
+    mods[0].train(); mods[1].train()
+    mods[0](torch.randn(6, 3, 9, generator=g) * (1 + rank))      # per-rank shards -> per-rank running statistics
+    mods[1](torch.randn(2, 5, 4, 4, generator=g) + rank)
+    local = [b.clone() for b in ddp.bn_buffers(mods)]
+    assert len(local) == 4
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **k: (calls.append(t.numel()), orig(t, *a, **k))[1]
+    n = ddp.sync_bn_stats_(mods, 'mean')
+    dist.all_reduce = orig
+    assert n == 4 and calls == [4 + 4 + 5 + 5]                   # one collective over the concatenated buffers
+    mean = [b.clone() for b in ddp.bn_buffers(mods)]
+    for b, l in zip(ddp.bn_buffers(mods), local):                # restore, then the rank-0 mode
+        b.copy_(l)
+    ddp.sync_bn_stats_(mods, 'rank0')
+    r0 = [b.clone() for b in ddp.bn_buffers(mods)]
+    gathered = [[torch.empty_like(l) for _ in range(world)] for l in local]
+    for l, gl in zip(local, gathered):
+        dist.all_gather(gl, l)
+    assert int(mods[1].num_batches_tracked) == 1
+    if rank == 0:
+        torch.save({'locals': gathered, 'mean': mean, 'rank0': r0}, out)
+    else:
+        torch.save({'mean': mean, 'rank0': r0}, out + '.r1')
+    dist.destroy_process_group()
+
+
+def test_bn_running_stats_sync_two_ranks(tmp_path):
+    out = str(tmp_path / 'bn.pt')
+    mp.spawn(_bn_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out), torch.load(out + '.r1')
+    for (l0, l1), m0, m1, a0, a1 in zip(r0['locals'], r0['mean'], r1['mean'], r0['rank0'], r1['rank0']):
+        assert not torch.equal(l0, l1)                            # the ranks really diverged
+        assert torch.allclose(m0, (l0 + l1) / 2, rtol=1e-6, atol=1e-9) and torch.equal(m0, m1)
+        assert torch.equal(a0, l0) and torch.equal(a1, l0)
+
+
+def _sparse_empty_worker(rank, world, port, out):
+    """A rank with NOTHING pending (count 0, a 1-entry dummy list) still takes part in every collective of the sparse row exchange."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ha2g_amd import ddp
+    C = 6
+    if rank == 0:
+        ids = torch.tensor([0, 7, 3, 9], dtype=torch.int64)
+        rows = torch.arange(4 * C, dtype=torch.float32).view(4, C)
+        cnt = torch.tensor([4], dtype=torch.int32)
+    else:
+        ids, rows, cnt = torch.zeros(1, dtype=torch.int64), torch.zeros(1, C), torch.zeros(1, dtype=torch.int32)
+    ids_all, rows_all = ddp.gather_sparse_rows(ids, cnt, rows)
+    assert ids_all.shape == (8,) and rows_all.shape == (8, C)
+    assert ids_all[:4].tolist() == [0, 7, 3, 9] and int(ids_all[4:].abs().sum()) == 0 and float(rows_all[4:].abs().sum()) == 0.0
+    assert torch.allclose(rows_all[:4], torch.arange(4 * C, dtype=torch.float32).view(4, C) * 0.5)
+    # both ranks empty: still one (dummy) entry per rank travels, never an empty collective
+    e = ddp.gather_sparse_rows(torch.zeros(1, dtype=torch.int64), torch.zeros(1, dtype=torch.int32), torch.zeros(1, C))
+    assert e[0].shape == (2,) and float(e[1].abs().sum()) == 0.0
+    if rank == 0:
+        torch.save({'ok': True}, out)
+    dist.destroy_process_group()
+
+
+def test_sparse_row_gather_with_an_idle_rank(tmp_path):
+    out = str(tmp_path / 'spe.pt')
+    mp.spawn(_sparse_empty_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert torch.load(out)['ok']

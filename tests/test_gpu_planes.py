@@ -1,0 +1,108 @@
+"""Plane-based split-bf16 products (csrc/conv_planes.hip, round 3): operands pre-split into bf16 hi / lo planes by their producer, moved
+global -> LDS by DMA.  Every kernel here must be BIT-IDENTICAL to the round-2 kernel it replaces (same hi / lo values, same three-MFMA product,
+same k order), so the reference-derived parity fixtures cannot move: the tests compare with torch.equal.  (Replaces autograd's conv2d
+backward, model/ResNetBlocks.py:24-29 under train_eval/train_hierarchy.py:264.)"""
+import pytest
+import torch
+
+from ha2g_amd import ops, procedural as proc, wav_engine as we
+from ha2g_amd._lib import DEFAULT_GEMM_MODE, lib
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def test_to_planes_is_the_two_piece_bf16_split():
+    torch.manual_seed(0)
+    x = torch.randn(1 << 16, device=DEV) * torch.logspace(-6, 6, 1 << 16, device=DEV)
+    hi, lo = ops.to_planes(x)
+    assert torch.equal(hi, x.bfloat16())                                       # round-to-nearest-even
+    assert torch.equal(lo, (x - hi.float()).bfloat16())
+    err = (x.double() - hi.double() - lo.double()).abs() / x.double().abs()
+    assert float(err.max()) <= 2.0 ** -16                                      # 16 operand mantissa bits survive
+
+
+@pytest.mark.parametrize('relu_mask', [False, True])
+def test_bn_bwd_planes_equal_the_split_of_the_fp32_output(relu_mask):
+    torch.manual_seed(1)
+    rows, C = 4 * 32 * 18, 128
+    x = torch.relu(torch.randn(rows, C, device=DEV) + 0.2) if relu_mask else torch.randn(rows, C, device=DEV)
+    dy = torch.randn(rows, C, device=DEV)
+    mean, invstd = ops.bn_stats(x, None, None, 0.1, 1e-5)
+    gamma = torch.rand(C, device=DEV) + 0.5
+    dx0, dg0, db0 = ops.bn_bwd(dy, x, mean, invstd, gamma, relu_mask=relu_mask)
+    dx1, dg1, db1, (hi, lo) = ops.bn_bwd(dy, x, mean, invstd, gamma, relu_mask=relu_mask, planes=True)
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    h2, l2 = ops.to_planes(dx0)
+    assert torch.equal(hi, h2) and torch.equal(lo, l2)
+    _, _, _, (hi3, lo3) = ops.bn_bwd(dy, x, mean, invstd, gamma, need_dx=False, relu_mask=relu_mask, planes=True)     # planes only
+    assert torch.equal(hi3, hi) and torch.equal(lo3, lo)
+
+
+@pytest.mark.parametrize('B,H,W,C', [(4, 64, 35, 64), (3, 64, 35, 64), (4, 32, 18, 128), (5, 16, 9, 256), (1, 7, 5, 64), (128, 32, 18, 128)])
+def test_dgrad_planes_bit_identical_to_the_split_implicit_gemm(B, H, W, C):
+    """3x3 stride-1 data gradient of every trunk width the kernel serves (layers 2-4), tile-aligned and ragged pixel counts, borders smaller than
+    a tile, beta = 0 and the accumulate-onto-the-residual-gradient form (beta = 1) of the identity blocks."""
+    torch.manual_seed(2)
+    dy = torch.randn(B, H, W, C, device=DEV)
+    w = torch.randn(C, 3, 3, C, device=DEV) * 0.05                             # OHWI
+    assert we.dgrad_planes_ok(w, 1, 1)
+    ref = we.conv_dgrad(dy, w, (B, H, W, C), 1, 1)
+    got = we.conv_dgrad_planes(ops.to_planes(dy), w, (B, H, W, C), 1, 1)
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    base = torch.randn(B, H, W, C, device=DEV)
+    ref1 = we.conv_dgrad(dy, w, (B, H, W, C), 1, 1, out=base.clone(), beta=1.0)
+    got1 = we.conv_dgrad_planes(ops.to_planes(dy), w, (B, H, W, C), 1, 1, out=base.clone(), beta=1.0)
+    assert torch.equal(got1, ref1)
+    # and it IS the split-bf16 product, not something looser: within the split's error of the float64 result
+    x64 = torch.nn.functional.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    rel = float((got.double() - x64).abs().max() / x64.abs().max())
+    assert rel < 3e-5, rel
+
+
+def test_planes_are_only_used_in_the_split_mode_and_can_be_switched_off():
+    w = torch.zeros(64, 3, 3, 64, device=DEV)
+    assert we.dgrad_planes_ok(w, 1, 1)
+    assert not we.dgrad_planes_ok(w, 2, 1)                                     # stride-2 blocks keep the implicit GEMM
+    assert not we.dgrad_planes_ok(torch.zeros(32, 3, 3, 32, device=DEV), 1, 1)  # layer1 has its direct LDS-patch kernels
+    try:
+        lib.ha2g_gemm_set_mode(0)                                              # exact-fp32 mode: no split product anywhere
+        assert not we.dgrad_planes_ok(w, 1, 1)
+    finally:
+        lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
+    try:
+        lib.ha2g_conv_planes_enable(0)
+        assert not we.dgrad_planes_ok(w, 1, 1)
+    finally:
+        lib.ha2g_conv_planes_enable(1)
+
+
+def test_train_step_is_bitwise_unchanged_by_the_plane_path():
+    """One GAN-phase step of a trainer (full SE-ResNet34 audio tower, B = 4) with the plane path on and off: every gradient bit-equal."""
+    from ha2g_amd.config import hierarchy_args
+    from ha2g_amd.testing import SpeakerVocab
+    from ha2g_amd.train import HierarchyTrainer
+    dev = torch.device(DEV)
+
+    class Lang:
+        n_words, word_embedding_weights = 200, None
+
+    text, spec, target, vid = (torch.from_numpy(x).to(DEV) for x in proc.make_batch(4, 27, 200, 12, 9))
+
+    def run(planes):
+        old = we.PLANES
+        we.PLANES = planes
+        try:
+            torch.manual_seed(4)
+            ops.rng.seed(dev, 11)
+            tr = HierarchyTrainer(hierarchy_args(hidden_size=32, n_layers=2), Lang(), SpeakerVocab(12), 27, dev)
+            ret = tr.train_iter(11, text, spec, target, vid)
+            tr.sync()
+            return ret, [o.flat_g.clone() for o in tr.gen_opts + [tr.audio_opt, tr.text_opt, tr.dis_opt]]
+        finally:
+            we.PLANES = old
+    r0, g0 = run(False)
+    r1, g1 = run(True)
+    assert r0 == r1
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)

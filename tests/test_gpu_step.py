@@ -77,6 +77,55 @@ def test_train_step_expressive(golden, name, fuse):
         th.FUSE_CHAINS, th.randperm_source = old
 
 
+@pytest.mark.parametrize('mode', [6, 0])
+@pytest.mark.parametrize('name', ['cfg2_b128', 'cfg3_b128'])
+def test_train_step_headline_size_vs_reference(golden, name, mode):
+    """BASELINE configs 2 / 3 at FULL size -- B=128, T=34, H=300, 4 layers, 20 000 words, 1 371 speakers, spec (128,70); 27-d pose / the 6-level
+    126-d expressive twin -- against fixtures produced by the reference's own train_iter_hierarchy[_expressive] (train_eval/train_hierarchy.py:
+    71-293, train_hierarchy_expressive.py:124-483) on the same procedural parameters and batch: two consecutive steps (epoch 0, epoch 11), loss
+    dict, every tensor's gradient digest, BatchNorm running statistics, Adam-updated parameters.  mode 6 = the default arithmetic (split-bf16
+    backward products), mode 0 = every product on the fp32 MFMA.  Tolerance = Checker: 1e-4 of the tensor's scale + 3 x the reference's own
+    measured fp32 scatter / conditioning (4 one-ulp-perturbed fp32 runs + the float64 conditioning run, tests/golden/gen_golden.py main_big)."""
+    import os
+    from ha2g_amd import schema
+    from ha2g_amd._lib import DEFAULT_GEMM_MODE, lib
+    from ha2g_amd.config import BIG_CASES
+    from tests.conftest import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, name + '.npz')):
+        pytest.skip('fixture %s.npz not generated (tests/golden/gen_golden.py %s)' % (name, name))
+    case, g = BIG_CASES[name], golden(name)
+    expressive = bool(case.get('expressive'))
+    dims = schema.EXPRESSIVE_POSE_DIMS if expressive else schema.GESTURE_POSE_DIMS
+    ck = Checker(g)
+    args, gens, dis, aud, txt = build_modules(case, DEV, dims)
+    text, spec, target, vid = (t.to(DEV) for t in batch_for(case, P=dims[-1]))
+    lr = float(args.learning_rate)
+    g_opts = [FusedAdam(m.parameters(), lr=lr) for m in gens]
+    dis_opt = FusedAdam(dis.parameters(), lr=lr * args.discriminator_lr_weight)
+    aud_opt, txt_opt = FusedAdam(aud.parameters(), lr=lr), FusedAdam(txt.parameters(), lr=lr)
+    EpsInjector(gens, case['seed'], case['B'])
+    perm = torch.from_numpy(proc.fixed_perm(case['B'], case['seed'])).to(DEV)
+    mods = {'g%d' % (i + 1): m for i, m in enumerate(gens)}
+    mods.update(dis=dis, audio=aud, text=txt)
+    fn = th.train_iter_hierarchy_expressive if expressive else th.train_iter_hierarchy
+    old = th.randperm_source
+    th.randperm_source = lambda n, device: perm
+    lib.ha2g_gemm_set_mode(mode)
+    try:
+        for si, epoch in enumerate((0, 11)):
+            ret = fn(args, epoch, text, spec, target, vid, *gens, dis, aud, txt, *g_opts, dis_opt, aud_opt, txt_opt)
+            sd, grads = named_state(mods)
+            if epoch == 0:
+                grads = {k: v for k, v in grads.items() if not k.startswith('dis.')}
+            ck.step(si, ret, grads, sd)
+    finally:
+        th.randperm_source = old
+        lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
+    from ha2g_amd import ops
+    assert ops.gru_cluster_error(torch.device(DEV)) == 0
+    print('%s mode %d: worst relative deviation from the reference %.2e' % (name, mode, ck.worst))
+
+
 def test_training_loop_reduces_loss_and_is_deterministic():
     """A few real optimisation steps (dropout on, default init, HierarchyTrainer = the reference's train_epochs set-up):
     losses stay finite, the regression loss falls on a fixed batch, memory does not grow, no GRU hand-off times out,

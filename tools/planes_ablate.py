@@ -1,0 +1,41 @@
+"""Timing ablations of the plane-based data-gradient kernel (ha2g_conv_planes_debug): full / no DMA / no MFMA / neither, at the trunk shapes
+(B = 128) and at 4x the pixels (tile quantisation removed).  usage: python tools/planes_ablate.py"""
+import sys
+import torch
+sys.path.insert(0, '.')
+from ha2g_amd import ops, wav_engine as we
+from ha2g_amd._lib import lib
+
+dev = torch.device('cuda:0')
+
+
+def t_us(fn, iters=10):
+    fn(); fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+print('%-26s %9s %9s %9s %9s   %s' % ('shape', 'full', 'no DMA', 'no MFMA', 'neither', 'TF(f32eq) full'))
+for B in (128, 512):
+    for H, W, C in ((64, 35, 64), (32, 18, 128), (16, 9, 256)):
+        dy = torch.randn(B, H, W, C, device=dev)
+        w = torch.randn(C, 3, 3, C, device=dev) * 0.05
+        pl = ops.to_planes(dy)
+        wh = torch.empty(C, 3, 3, C, dtype=torch.bfloat16, device=dev); wl = torch.empty_like(wh)
+        lib.ha2g_conv2d_weight_ihwo_planes(w.data_ptr(), wh.data_ptr(), wl.data_ptr(), C, 3, 3, C, 0)
+        out = torch.empty(B, H, W, C, device=dev)
+        fn = lambda: lib.ha2g_conv2d_dgrad_planes_f32(pl[0].data_ptr(), pl[1].data_ptr(), wh.data_ptr(), wl.data_ptr(), out.data_ptr(), B, H, W, C, C, 3, 3,
+                                                      1, 1, 0.0, torch.cuda.current_stream().cuda_stream)
+        ts = []
+        for bits in (0, 1, 2, 3):
+            lib.ha2g_conv_planes_debug(bits)
+            ts.append(t_us(fn))
+        lib.ha2g_conv_planes_debug(0)
+        fl = 2.0 * B * H * W * C * C * 9
+        print('B=%-3d C=%-3d %3dx%-3d        %9.1f %9.1f %9.1f %9.1f   %.1f' % (B, C, H, W, ts[0], ts[1], ts[2], ts[3], fl / ts[0] / 1e6))

@@ -1,0 +1,40 @@
+"""A/B of the plane-based data gradient (csrc/conv_planes.hip) against the round-2 split implicit GEMM, per trunk shape at B = 128, in one
+process, interleaved rounds (guide 5.4 rule 24).  usage: python tools/planes_bench.py [rounds]"""
+import sys
+import torch
+sys.path.insert(0, '.')
+from ha2g_amd import ops, wav_engine as we
+
+dev = torch.device('cuda:0')
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+B = 128
+
+
+def t_us(fn, iters=10):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+print('%-28s %10s %10s %8s %10s %8s' % ('shape', 'old us', 'planes us', 'ratio', 'TF(f32eq)', 'of 833'))
+for H, W, C in ((64, 35, 64), (32, 18, 128), (16, 9, 256)):
+    dy = torch.randn(B, H, W, C, device=dev)
+    w = torch.randn(C, 3, 3, C, device=dev) * 0.05
+    pl = ops.to_planes(dy)
+    shp = (B, H, W, C)
+    old = lambda: we.conv_dgrad(dy, w, shp, 1, 1)
+    new = lambda: we.conv_dgrad_planes(pl, w, shp, 1, 1)
+    for f in (old, new):
+        f(); f()
+    torch.cuda.synchronize()
+    to, tn = [], []
+    for _ in range(rounds):
+        to.append(t_us(old)); tn.append(t_us(new))
+    to.sort(); tn.sort()
+    mo, mn = to[len(to) // 2], tn[len(tn) // 2]
+    fl = 2.0 * B * H * W * C * C * 9
+    print('dgrad C=%-3d %3dx%-3d          %10.1f %10.1f %8.2f %10.1f %8.3f' % (C, H, W, mo, mn, mo / mn, fl / mn / 1e6, fl / mn / 1e6 / 833.0))

@@ -13,7 +13,14 @@ def cat(n):
         mm = re.search(r'ILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)', n)
         am, bm = int(mm.group(5)), int(mm.group(6))
         return 'conv fwd/dgrad (implicit GEMM)' if am == 2 else ('conv wgrad (implicit GEMM)' if bm == 2 else 'dense GEMM')
-    for key, name in (('gru_', 'GRU recurrences'), ('splitk', 'split-K reduce'), ('colsum', 'bias-grad column sums'),
+    if 'gemm_x3_kernel' in n:
+        mm = re.search(r'ILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)', n)
+        return 'conv dgrad (split implicit GEMM, gemm_x3)' if int(mm.group(5)) == 2 else 'dense GEMM'
+    for key, name in (('pconv_dgrad', 'conv dgrad (planes, DMA-staged)'), ('pconv_wgrad', 'conv wgrad (planes, DMA-staged)'),
+                      ('weight_ihwo_planes', 'layout (shuffle/pack/permute)'), ('f32_to_planes', 'layout (shuffle/pack/permute)'),
+                      ('conv3x3_c32_wgrad', 'conv 32ch direct (fwd / dgrad / wgrad)'), ('conv3x3_c32_kernel', 'conv 32ch direct (fwd / dgrad / wgrad)'),
+                      ('conv3x3_x3_kernel', 'conv 32ch direct (fwd / dgrad / wgrad)'), ('pool_final', 'SE pointwise'), ('transpose_batched', 'layout (shuffle/pack/permute)'),
+                      ('gru_', 'GRU recurrences'), ('splitk', 'split-K reduce'), ('colsum', 'bias-grad column sums'),
                       ('col_partial', 'BatchNorm'), ('bn_', 'BatchNorm'), ('pair_final', 'BatchNorm'),
                       ('image_col', 'SE pointwise'), ('se_scale', 'SE pointwise'), ('se_bwd', 'SE pointwise'),
                       ('contrastive', 'contrastive loss'), ('rownorm', 'contrastive loss'), ('at6native', 'torch plumbing (add/fill/copy/cat)'),
