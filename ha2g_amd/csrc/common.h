@@ -32,6 +32,11 @@ int conv3x3_c32_x3_launch(const float* x, const float* w, float* y, int N, int H
 int gemm_split_dgrad_enabled();      // gemm.hip: ha2g_gemm_set_mode bit 2 (and not the plain-bf16 mode)
 int conv3x3_c32_wgrad_blocks(int N, int H, int W);
 int conv3x3_c32_wgrad_launch(const float* x, const float* dy, float* part, int N, int H, int W, hipStream_t st);
+// internal: plane-based 3x3 weight gradient, conv_planes.hip (the wide split-K reduce that follows lives in gemm.hip)
+int pconv_wgrad_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+long pconv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int pconv_wgrad_launch(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* part, int N, int H, int W, int Cin, int Cout,
+                       hipStream_t st);
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 

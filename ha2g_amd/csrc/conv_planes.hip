@@ -219,10 +219,229 @@ __global__ __launch_bounds__(256) void pconv_dgrad_kernel(PConvP p) {
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a 3x3 / stride-1 / pad-1 convolution from planes:  dW[co][tap][ci] = sum over pixels p of dy[p][co] * x[p + tap][ci].
+// The implicit GEMM (gemm.hip, A_MC x B_IM) stages the im2col gather of x -- the same pixels nine times -- and both operands once per
+// 128-wide output tile; rocprofv3 puts it at 15 VALU per MFMA (split + gather arithmetic) and, in the step, bound by L2 -> LDS traffic beside
+// the data-gradient stream.  Here a workgroup owns a 64 (co) x 64 (ci) block of dW for ALL nine taps (each wave a 32 x 32 corner = nine
+// accumulators, 144 AGPRs, as in conv3x3_c32_wgrad_kernel) and walks a range of 64-pixel tiles: per tile the dy strip [64 px][64 co] and the
+// x patch [(rows + halo) x (W + 2) px][64 ci] go global -> LDS ONCE, by DMA, as bf16 hi / lo planes (zero padding = the zero page), and every
+// MFMA operand is a pair of transpose reads (ds_read_b64_tr_b16: k = pixel is the slow index of both operands); the x fragment of tap
+// (kh, kw) is the same read kh (W + 2) + kw patch rows further down.  128-byte LDS rows; the two 64-byte halves of a row are swapped on
+// rows with bit 1 set so that the four pixel rows of a transpose read cover all 64 banks (the swap is applied to the DMA's source address).
+// Tiles are double-buffered: tile i + 1 streams in while tile i's 108 MFMAs per wave run.  Each workgroup writes ONE partial block into its
+// chunk's dW-shaped slab; gemm.hip's wide reduce adds the chunks in double.
+struct PWgradP {
+    const unsigned short* x_hi; const unsigned short* x_lo;
+    const unsigned short* dy_hi; const unsigned short* dy_lo;
+    float* part;                        // [nchunks][Cout][9][Cin]
+    int N, H, W, Cin, Cout;
+    int tpi, tiles_per_chunk, patch_rows;      // tiles per image; consecutive tiles per workgroup; LDS rows reserved for one patch plane (multiple of 8)
+    int dbg;                            // timing ablation (ha2g_conv_planes_debug): 1 = no DMA after the first tile (a branch around the MFMAs would
+                                        // split the basic block the read / MFMA interleave is scheduled in)
+};
+
+// WT = pixels per tile (k of one stage): 64, or 48 where the image has a multiple of 48 but not of 64 pixels (layer 4: 16 x 9 = 144).
+// LDS image of one tile (64 KB, two of them): [dy hi | dy lo | x hi | x lo], every plane as TWO sub-planes of 32 channels with 64-byte rows
+// ([half][pixel][32 ch]): a wave works on one half of dy (its 32 co) and one half of x (its 32 ci), the four pixel rows of a transpose read are
+// then 256 contiguous bytes -- conflict-free with NO swizzle, so a fragment address is lane base + tap offset (one add; the first version's
+// XOR-swizzled 128-byte rows cost ~7 VALU per MFMA in address arithmetic and the kernel was instruction-issue bound at 3x the MFMA floor).
+constexpr int PW_ROWS = 192;                                   // patch rows reserved per sub-plane (>= rows * (W + 2); checked by the host)
+constexpr int X_SUB = PW_ROWS * 64;                            // bytes of one x sub-plane
+
+// Twelve waves: wave = corner (32 co x 32 ci of the 64 x 64 block) + 4 * tap row (kh = 0, 1, 2: three taps each).  Three waves per SIMD share
+// the matrix pipe.  (Four waves with all nine taps each = 144 accumulator registers: rocprofv3 showed the pipe 36 % busy, a third of the wave's
+// time parked at the tile boundary with nothing else to issue from.)  Every wave issues a FIXED number of DMA instructions per tile (one
+// 16-row piece of the patch in its four sub-planes, two pieces of the dy strip): with a data-dependent count hipcc put s_waitcnt vmcnt(0) in
+// front of every fragment read, i.e. waited for the NEXT tile's DMA before computing on this one.
+template <int WT>
+__global__ __launch_bounds__(768) void pconv_wgrad_kernel(PWgradP p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char wsm[];
+    typedef short s16x4_t __attribute__((ext_vector_type(4)));
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) s16x4_t* lds4_t;
+    constexpr int NKC = WT / 16;
+    constexpr int DY_SUB = ((WT + 15) / 16) * 1024;            // bytes of one dy sub-plane (WT rows of 64 bytes, in 16-row DMA pieces)
+    constexpr int DY_ALL = 4 * DY_SUB, BUF = DY_ALL + 4 * X_SUB;
+    constexpr int NDY = 4 * (WT / 16);                         // dy DMA pieces per tile: 16 (WT = 64) or 12 (WT = 48)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 1) & 1, wn = wave & 1, kh = wave >> 2;                // corner, tap row
+    const int l31 = lane & 31, lhi = lane >> 5, g4 = lane >> 4, q16 = lane & 15;
+    const int krow = 8 * (g4 >> 1) + (q16 >> 2), moff = 16 * (g4 & 1) + 4 * (q16 & 3);
+    const int HW = p.H * p.W, PW = p.W + 2;
+    const int ncit = p.Cin >> 6;
+    const int co0 = ((int)blockIdx.y / ncit) << 6, ci0 = ((int)blockIdx.y % ncit) << 6;
+    const int tiles = p.N * p.tpi;
+    const int t_beg = (int)blockIdx.x * p.tiles_per_chunk;
+    const int t_end = t_beg + p.tiles_per_chunk < tiles ? t_beg + p.tiles_per_chunk : tiles;
+    const unsigned short* zero = g_zero_page;
+
+    auto tr = [](const unsigned char* ptr) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(__attribute__((address_space(3))) const unsigned char*)ptr);
+    };
+    auto frag = [&](const unsigned char* q0, const unsigned char* q1) {          // k rows krow .. +3 (q0) and krow + 4 .. + 7 (q1)
+        return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(tr(q0), tr(q1), 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    const int drow = lane >> 2, dpc = lane & 3;                                   // DMA: 16 rows x 4 sixteen-byte pieces per wave instruction
+    // this lane's patch pixel: piece `wave`, row drow -> padded coordinates (fixed for every tile: the patch geometry depends on W only)
+    const int pp = wave * 16 + drow;
+    const int ppr = pp / PW, ppx = pp - ppr * PW;
+    auto stage = [&](int tile, int buf) {
+        const int img = tile / p.tpi, p0 = (tile - img * p.tpi) * WT;
+        const int pend = p0 + WT < HW ? p0 + WT : HW;
+        const int r0 = p0 / p.W, rows = (pend - 1) / p.W - r0 + 3;              // + the halo row above and below
+        unsigned char* dst = wsm + buf * BUF;
+        // dy strip: NDY pieces = (plane, half, 16 pixels); wave w stages pieces w and w + 12 (WT = 64; the waves past the end repeat their first)
+#pragma unroll
+        for (int i = 0; i < (NDY + 11) / 12; ++i) {
+            const int q = (wave + 12 * i) < NDY ? wave + 12 * i : wave;           // = sub * (WT / 16) + piece, sub = plane * 2 + half
+            const int sub = q / (WT / 16), piece = q - sub * (WT / 16);
+            const int pix = p0 + piece * 16 + drow;
+            const bool on = pix < HW;
+            const long o = ((long)img * HW + pix) * p.Cout + co0 + (sub & 1) * 32 + dpc * 8;
+            const unsigned short* g = on ? ((sub >> 1) ? p.dy_lo : p.dy_hi) + o : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lds_ptr_t)(dst + sub * DY_SUB + piece * 1024), 16, 0, 0);
+        }
+        // x patch: piece `wave` (16 padded pixels) in its four sub-planes; pieces past rows * PW carry zeros (never read)
+        {
+            const int gy = r0 - 1 + ppr;
+            const bool on = ppr < rows && gy >= 0 && gy < p.H && ppx >= 1 && ppx <= p.W;
+            const long o = (((long)img * p.H + gy) * p.W + (ppx - 1)) * p.Cin + ci0 + dpc * 8;
+            unsigned char* d = dst + DY_ALL + wave * 1024;
+            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.x_hi + o : zero), (lds_ptr_t)(d), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.x_hi + o + 32 : zero), (lds_ptr_t)(d + X_SUB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.x_lo + o : zero), (lds_ptr_t)(d + 2 * X_SUB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.x_lo + o + 32 : zero), (lds_ptr_t)(d + 3 * X_SUB), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // fragment sets of one 16-pixel k chunk: the dy fragment (hi, lo) and this wave's three taps' x fragments (hi, lo).  Two sets: chunk kc + 1 is
+    // read from LDS while chunk kc's 9 MFMAs run.
+    struct FragSet { bf16x8_t ah, al, bh[3], bl[3]; };
+    const int a_lane = wm * DY_SUB + 2 * moff;                                    // this wave's dy half + this lane's channel offset
+    const int b_lane = DY_ALL + wn * X_SUB + 2 * moff + kh * PW * 64;             // its x half, channel offset and tap row
+    auto load_set = [&](FragSet& f, int cur, int p0, int r0, int kc) {
+        const unsigned char* base = wsm + cur * BUF;
+        const int k0 = 16 * kc + krow, k1 = k0 + 4;                               // this lane's two tile-local pixels
+        const unsigned char* a0 = base + a_lane + k0 * 64;
+        const unsigned char* a1 = base + a_lane + k1 * 64;
+        f.ah = frag(a0, a1);
+        f.al = frag(a0 + 2 * DY_SUB, a1 + 2 * DY_SUB);
+        int q0 = p0 + k0, q1 = p0 + k1;
+        if (q0 >= HW) q0 = HW - 1;                                                 // clamp: stays inside the patch; dy is zero there
+        if (q1 >= HW) q1 = HW - 1;
+        const int y0 = q0 / p.W, y1 = q1 / p.W;
+        const unsigned char* b0 = base + b_lane + ((y0 - r0) * PW + (q0 - y0 * p.W)) * 64;   // patch row of tap (kh, 0)
+        const unsigned char* b1 = base + b_lane + ((y1 - r0) * PW + (q1 - y1 * p.W)) * 64;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            f.bh[t] = frag(b0 + t * 64, b1 + t * 64);
+            f.bl[t] = frag(b0 + t * 64 + 2 * X_SUB, b1 + t * 64 + 2 * X_SUB);
+        }
+    };
+    // three passes over the taps (lo*hi, hi*lo, hi*hi): consecutive MFMAs go to DIFFERENT accumulators; each accumulator still sees its
+    // products in the same order
+    auto mfma_set = [&](const FragSet& f) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bl[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bh[t], acc[t], 0, 0, 0);
+    };
+
+    if (t_beg < t_end) stage(t_beg, 0);
+    __syncthreads();
+    FragSet fs0, fs1;
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        const int cur = (tile - t_beg) & 1;
+        if (tile + 1 < t_end && !(p.dbg & 1)) stage(tile + 1, cur ^ 1);
+        const int p0 = (tile % p.tpi) * WT;
+        const int r0 = p0 / p.W;
+        load_set(fs0, cur, p0, r0, 0);
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            FragSet& use = (kc & 1) ? fs1 : fs0;
+            FragSet& nxt = (kc & 1) ? fs0 : fs1;
+            if (kc + 1 < NKC) load_set(nxt, cur, p0, r0, kc + 1);
+            mfma_set(use);
+        }
+        __syncthreads();                 // the next tile has landed (vmcnt(0) rides on the fence) and every wave is done with this one
+    }
+    // ---- this wave's three taps of its corner of the chunk's slab: part[chunk][co][tap][ci] ----
+    float* out = p.part + (long)blockIdx.x * p.Cout * 9 * p.Cin;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            out[((long)co * 9 + kh * 3 + t) * p.Cin + ci0 + wn * 32 + l31] = acc[t][r];
+        }
+}
+
 static int g_pdbg = 0;
 static int g_planes = 1;         // ha2g_conv_planes_enable: 0 = callers keep the round-2 kernels (A/B switch, HA2G_PLANES=0)
 
 }  // namespace
+
+// Partials of the plane-based weight gradient: returns the number of dW-shaped slabs written to `part` (the caller reduces them),
+// -100 when the geometry is not served (caller keeps the implicit GEMM), < 0 on error.
+static int pwgrad_tile(int HW) { return (HW % 64 != 0 && HW % 48 == 0) ? 48 : 64; }
+int pconv_wgrad_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (!(g_planes && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0 && (long)H * W >= 16)) return 0;
+    const int wt = pwgrad_tile(H * W);
+    return ((wt + W - 2) / W + 1 + 2) * (W + 2) <= PW_ROWS;
+}
+long pconv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+    const int wt = pwgrad_tile(H * W);
+    const long tiles = (long)N * (((long)H * W + wt - 1) / wt);
+    const int npairs = (Cin / 64) * (Cout / 64);
+    long nchunks = 256 / npairs < 1 ? 1 : 256 / npairs;
+    if (nchunks > tiles) nchunks = tiles;
+    return nchunks * (long)Cout * 9 * Cin * 4;
+}
+int pconv_wgrad_launch(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* part, int N, int H, int W, int Cin, int Cout,
+                       hipStream_t st) {
+    PWgradP p{};
+    p.x_hi = (const unsigned short*)x_hi; p.x_lo = (const unsigned short*)x_lo;
+    p.dy_hi = (const unsigned short*)dy_hi; p.dy_lo = (const unsigned short*)dy_lo;
+    p.part = part; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.dbg = g_pdbg;
+    const int HW = H * W, wt = pwgrad_tile(HW);
+    p.tpi = (HW + wt - 1) / wt;
+    const long tiles = (long)N * p.tpi;
+    const int npairs = (Cin / 64) * (Cout / 64);
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) { int c = 0; if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) cus = c; }
+    if (cus > 256) cus = 256;                                   // the workspace query assumes at most 256 chunks x pairs
+    long nchunks = cus / npairs < 1 ? 1 : cus / npairs;
+    if (nchunks > tiles) nchunks = tiles;
+    p.tiles_per_chunk = (int)((tiles + nchunks - 1) / nchunks);
+    nchunks = (tiles + p.tiles_per_chunk - 1) / p.tiles_per_chunk;
+    const int rows_max = (wt + W - 2) / W + 1 + 2;
+    p.patch_rows = rows_max * (W + 2);
+    if (p.patch_rows > PW_ROWS) return -100;                     // the patch does not fit the reserved sub-planes
+    const size_t lds = (size_t)2 * (4 * (size_t)((wt + 15) / 16) * 1024 + 4 * (size_t)X_SUB);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_wgrad_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_wgrad_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
+            return ha2g_set_error(-2, "pconv_wgrad: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    if (wt == 64) hipLaunchKernelGGL(pconv_wgrad_kernel<64>, dim3((unsigned)nchunks, npairs), dim3(768), lds, st, p);
+    else hipLaunchKernelGGL(pconv_wgrad_kernel<48>, dim3((unsigned)nchunks, npairs), dim3(768), lds, st, p);
+    HA2G_CHECK_LAUNCH("pconv_wgrad");
+    return (int)nchunks;
+}
 
 extern "C" {
 

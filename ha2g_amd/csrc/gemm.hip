@@ -1260,4 +1260,28 @@ int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int
     return launch<2, 2, 2, 2, A_MC, B_IM, true>(p, st);
 }
 
+
+// Plane-based weight gradient (conv_planes.hip): x and dy arrive as bf16 hi / lo planes; one DMA-staged launch writes `chunks` dW-shaped
+// partial slabs into ws, the wide reduce adds them in double.  3x3 / stride 1 / pad 1, channels multiples of 64.
+int ha2g_conv2d_wgrad_planes_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    return g_split_wgrad && !g_bf16 && pconv_wgrad_supported(H, W, Cin, Cout, KH, KW, stride, pad);
+}
+long ha2g_conv2d_wgrad_planes_workspace_bytes(int N, int H, int W, int Cin, int Cout) { return pconv_wgrad_workspace_bytes(N, H, W, Cin, Cout); }
+int ha2g_conv2d_wgrad_planes_f32(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, int N, int H, int W, int Cin,
+                                 int Cout, int KH, int KW, int stride, int pad, float beta, float* ws, long ws_bytes, void* stream) {
+    HA2G_REQUIRE(ha2g_conv2d_wgrad_planes_supported(H, W, Cin, Cout, KH, KW, stride, pad), "conv2d_wgrad_planes: unsupported geometry / mode");
+    HA2G_REQUIRE(ws && ws_bytes >= pconv_wgrad_workspace_bytes(N, H, W, Cin, Cout), "conv2d_wgrad_planes: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = pconv_wgrad_launch(x_hi, x_lo, dy_hi, dy_lo, ws, N, H, W, Cin, Cout, st);
+    if (chunks == -100) return ha2g_set_error(-1, "conv2d_wgrad_planes: the patch does not fit the LDS (W = %d)", W);
+    if (chunks < 0) return chunks;
+    const long MN = (long)Cout * KH * KW * Cin;
+    ReduceOut ro{};
+    ro.groups = 1; ro.C[0] = dw;
+    hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(ceil_div(MN, 64), 1), dim3(256), 0, st, ws, chunks, MN, KH * KW * Cin, ro, (long)KH * KW * Cin, 1.f,
+                       beta, 0, 0.f, Cout);
+    HA2G_CHECK_LAUNCH("conv2d_wgrad_planes reduce");
+    return 0;
+}
+
 }  // extern "C"

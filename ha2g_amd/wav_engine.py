@@ -67,7 +67,7 @@ def conv_dgrad(dy, w_ohwi, xshape, stride, pad, out=None, beta=0.0):
 
 def dgrad_planes_ok(w_ohwi, stride, pad):
     Cout, KH, KW, Cin = w_ohwi.shape
-    return PLANES and bool(lib.ha2g_conv2d_dgrad_planes_supported(Cin, Cout, KH, KW, stride, pad))
+    return bool(PLANES & 1) and bool(lib.ha2g_conv2d_dgrad_planes_supported(Cin, Cout, KH, KW, stride, pad))
 
 
 def conv_dgrad_planes(dy_planes, w_ohwi, xshape, stride, pad, out=None, beta=0.0):
@@ -105,6 +105,31 @@ def conv_wgrad(x, dy, w_ohwi, stride, pad, into=None):
     assert need <= ws.numel() * 4, 'wgrad workspace %d > %d' % (need, ws.numel() * 4)
     check(lib.ha2g_conv2d_wgrad_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad, beta,
                                     ws.data_ptr(), ws.numel() * 4, _stream()))
+    return None if into is not None else dw.permute(0, 3, 1, 2)
+
+
+def wgrad_planes_ok(x, w_ohwi, stride, pad):
+    Cout, KH, KW, Cin = w_ohwi.shape
+    return bool(PLANES & 2) and bool(lib.ha2g_conv2d_wgrad_planes_supported(x.shape[1], x.shape[2], Cin, Cout, KH, KW, stride, pad))
+
+
+def conv_wgrad_planes(x_planes, dy_planes, w_ohwi, xshape, into=None):
+    """conv_wgrad (3x3 / stride 1 / pad 1) on the bf16 planes of x and dy: one DMA-staged launch + the wide reduce (csrc/conv_planes.hip)."""
+    N, H, W, Cin = xshape
+    Cout, KH, KW, _ = w_ohwi.shape
+    beta = 0.0
+    if into is not None:
+        dwp = into.permute(0, 2, 3, 1)
+        if dwp.is_contiguous():
+            dw, beta = dwp, 1.0
+        else:
+            into = None
+    if into is None:
+        dw = torch.empty(Cout, KH, KW, Cin, dtype=torch.float32, device=x_planes[0].device)
+    ws = workspace(x_planes[0].device)
+    assert lib.ha2g_conv2d_wgrad_planes_workspace_bytes(N, H, W, Cin, Cout) <= ws.numel() * 4
+    check(lib.ha2g_conv2d_wgrad_planes_f32(x_planes[0].data_ptr(), x_planes[1].data_ptr(), dy_planes[0].data_ptr(), dy_planes[1].data_ptr(),
+                                           dw.data_ptr(), N, H, W, Cin, Cout, KH, KW, 1, 1, beta, ws.data_ptr(), ws.numel() * 4, _stream()))
     return None if into is not None else dw.permute(0, 3, 1, 2)
 
 
@@ -165,7 +190,9 @@ def _tap_pack(x, inverse=False, shape=None):
 
 
 import os as _os
-PLANES = _os.environ.get('HA2G_PLANES', '1') != '0'       # producer-side bf16 hi / lo planes for the backward convolutions (round 3; bit-identical A/B switch)
+# producer-side bf16 hi / lo planes for the backward convolutions (round 3).  bit 0: data gradients (bit-identical to the round-2 kernels),
+# bit 1: weight gradients (same products, different fp32 summation order); HA2G_PLANES=0 is the round-2 path
+PLANES = int(_os.environ.get('HA2G_PLANES', '3'))
 SIDE_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_WGRAD', '1') != '0'
 SIDE_FC_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_FC', '1') != '0'
 
@@ -219,7 +246,30 @@ class GradSink:
         else:
             self.G[name] = ops.colsum(a)
 
-    def gconv(self, name, xin, dyc, w_ohwi, stride, pad):
+    def gconv(self, name, xin, dyc, w_ohwi, stride, pad, dy_planes=None):
+        """dy_planes: the (hi, lo) planes of dyc when its producer wrote them -- the plane-based weight gradient then splits x once (a
+        streaming pass on the side stream) instead of once per consumer tile and tap."""
+        if dy_planes is not None and wgrad_planes_ok(xin, w_ohwi, stride, pad):
+            return self._gconv_planes(name, xin, dy_planes, w_ohwi)
+        return self._gconv(name, xin, dyc, w_ohwi, stride, pad)
+
+    def _gconv_planes(self, name, xin, dy_planes, w_ohwi):
+        side_on = SIDE_WGRAD and ops.side.enabled and xin.is_cuda
+        ctx = ops.side.section(xin.device) if side_on else ops._null()
+        with ctx:
+            if side_on:
+                st = torch.cuda.current_stream(xin.device)
+                xin.record_stream(st); dy_planes[0].record_stream(st); dy_planes[1].record_stream(st)
+            xp = ops.to_planes(xin)
+            r = conv_wgrad_planes(xp, dy_planes, w_ohwi, xin.shape, into=self.tgt(self.P[name]))
+            if r is not None and side_on:
+                r.record_stream(torch.cuda.default_stream(xin.device))
+        if side_on:
+            self.forked = True
+        if r is not None:
+            self.G[name] = r
+
+    def _gconv(self, name, xin, dyc, w_ohwi, stride, pad):
         # the convolution weight gradients only feed the optimizer: on the side stream they overlap the data-gradient chain -- MFMA work
         # beside the bandwidth-bound BatchNorm / SE passes of the main stream.  The operands are handed to the side stream's allocator
         # bookkeeping (record_stream) because the caller drops them before the join at the end of the tower's backward.
@@ -241,12 +291,12 @@ class GradSink:
             ops.side.join(device)
             self.forked = False
 
-    def gbn(self, name, dy2, x2, mean, invstd, relu_mask=False, planes=False):
-        """planes=True: -> (dx fp32, (hi, lo) bf16 planes of dx)"""
+    def gbn(self, name, dy2, x2, mean, invstd, relu_mask=False, planes=False, need_dx=True):
+        """planes=True: -> (dx fp32 or None (need_dx=False: every consumer reads the planes), (hi, lo) bf16 planes of dx)"""
         bn = self.P[name]
         tg_, tb_ = self.tgt(bn.gamma), self.tgt(bn.beta)
         acc = (tg_, tb_) if (tg_ is not None and tb_ is not None) else None
-        r = ops.bn_bwd(dy2, x2, mean, invstd, bn.gamma, relu_mask=relu_mask, acc=acc, planes=planes)
+        r = ops.bn_bwd(dy2, x2, mean, invstd, bn.gamma, need_dx=need_dx or not planes, relu_mask=relu_mask, acc=acc, planes=planes)
         if acc is None:
             self.G[name] = (r[1], r[2])
         return (r[0], r[3]) if planes else r[0]
@@ -302,13 +352,15 @@ def block_bwd(dx, saved, P, b, sink):
     # the BatchNorm-backward apply pass is the PRODUCER of the convolutions' dy: where the plane-based data gradient serves the geometry it
     # also writes dy as bf16 hi / lo planes (same values the consumer tiles used to split out of the fp32 tensor, once instead of per tile)
     p2, p1 = dgrad_planes_ok(wb, 1, 1), dgrad_planes_ok(wa, stride, 1)
-    dc2 = sink.gbn(b + 'bn2', _rows(db2), _rows(c2), m2, s2, planes=p2)
-    dc2, dc2p = (dc2[0].view(c2.shape), dc2[1]) if p2 else (dc2.view(c2.shape), None)
-    sink.gconv(b + 'conv2.weight', a1, dc2, wb, 1, 1)
+    f2 = not (p2 and wgrad_planes_ok(a1, wb, 1, 1))                           # someone still reads the fp32 tensor
+    f1 = not (p1 and wgrad_planes_ok(x, wa, stride, 1))
+    dc2 = sink.gbn(b + 'bn2', _rows(db2), _rows(c2), m2, s2, planes=p2, need_dx=f2)
+    dc2, dc2p = ((dc2[0].view(c2.shape) if f2 else None), dc2[1]) if p2 else (dc2.view(c2.shape), None)
+    sink.gconv(b + 'conv2.weight', a1, dc2, wb, 1, 1, dy_planes=dc2p)
     da1 = conv_dgrad_planes(dc2p, wb, a1.shape, 1, 1) if p2 else conv_dgrad(dc2, wb, a1.shape, 1, 1)
-    dc1 = sink.gbn(b + 'bn1', _rows(da1), _rows(c1), m1, s1, relu_mask=True, planes=p1)
-    dc1, dc1p = (dc1[0].view(c1.shape), dc1[1]) if p1 else (dc1.view(c1.shape), None)
-    sink.gconv(b + 'conv1.weight', x, dc1, wa, stride, 1)
+    dc1 = sink.gbn(b + 'bn1', _rows(da1), _rows(c1), m1, s1, relu_mask=True, planes=p1, need_dx=f1)
+    dc1, dc1p = ((dc1[0].view(c1.shape) if f1 else None), dc1[1]) if p1 else (dc1.view(c1.shape), None)
+    sink.gconv(b + 'conv1.weight', x, dc1, wa, stride, 1, dy_planes=dc1p)
     if cd is None:                                                              # identity shortcut: accumulate onto d(residual)
         if p1:
             return conv_dgrad_planes(dc1p, wa, x.shape, stride, 1, out=dres, beta=1.0)

@@ -73,6 +73,14 @@ int ha2g_conv2d_weight_ihwo_planes(const float* w, void* wt_hi, void* wt_lo, int
 int ha2g_conv2d_dgrad_planes_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
 int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N, int H, int W,
                                  int Cin, int Cout, int KH, int KW, int stride, int pad, float beta, void* stream);
+/* dw [Cout][KH][KW][Cin] = beta*dw + dy^T im2col(x) from the planes of x [N,H,W,Cin] and dy [N,H,W,Cout] (3x3 / stride 1 / pad 1, channels
+ * multiples of 64): every pixel of x and dy goes global -> LDS once per 64 x 64 block of dW (the nine taps share the staged patch); fp32
+ * accumulation per workgroup, the workgroups' partial slabs (ws >= ..._workspace_bytes) are added in double.  Autograd's conv2d backward w.r.t.
+ * the weight (model/ResNetBlocks.py:24-29). */
+int ha2g_conv2d_wgrad_planes_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+long ha2g_conv2d_wgrad_planes_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int ha2g_conv2d_wgrad_planes_f32(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, int N, int H, int W, int Cin,
+                                 int Cout, int KH, int KW, int stride, int pad, float beta, float* ws, long ws_bytes, void* stream);
 /* Matrix-core mode bits; default 6.  The split-bf16 inner product writes each fp32 operand as hi + lo bf16 halves and
  * runs a_lo*b_hi + a_hi*b_lo + a_hi*b_hi as three bf16 MFMAs with fp32 accumulation (~4e-6 rms-rel per GEMM vs 4e-7).
  *   bit 1 (on):  WEIGHT gradients (dW = dY^T X, conv wgrad) -- the error goes straight to the optimizer;

@@ -77,8 +77,35 @@ def test_planes_are_only_used_in_the_split_mode_and_can_be_switched_off():
         lib.ha2g_conv_planes_enable(1)
 
 
-def test_train_step_is_bitwise_unchanged_by_the_plane_path():
-    """One GAN-phase step of a trainer (full SE-ResNet34 audio tower, B = 4) with the plane path on and off: every gradient bit-equal."""
+@pytest.mark.parametrize('B,H,W,C', [(4, 64, 35, 64), (3, 32, 18, 128), (5, 16, 9, 256), (2, 7, 5, 64), (1, 4, 4, 128), (128, 32, 18, 128)])
+def test_wgrad_planes_vs_float64_and_the_implicit_gemm(B, H, W, C):
+    """3x3 / stride-1 / pad-1 weight gradient from planes: every trunk width, tile-aligned (35 and 9 tiles per image) and ragged (144 and 35
+    pixels per image, an image smaller than one tile) pixel counts, accumulate-into-.grad form.  Same products as the round-2 kernel in a
+    different fp32 summation order: both must sit at the split product's error (2e-5) from autograd in float64."""
+    torch.manual_seed(3)
+    x = torch.randn(B, H, W, C, device=DEV)
+    dy = torch.randn(B, H, W, C, device=DEV)
+    w = torch.zeros(C, 3, 3, C, device=DEV)
+    assert we.wgrad_planes_ok(x, w, 1, 1)
+    got = we.conv_wgrad_planes(ops.to_planes(x), ops.to_planes(dy), w, x.shape)             # logical OIHW
+    old = we.conv_wgrad(x, dy, w, 1, 1)
+    xx = x.double().permute(0, 3, 1, 2).requires_grad_(False)
+    ww = torch.zeros(C, C, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
+    y = torch.nn.functional.conv2d(xx, ww, padding=1)
+    (gref,) = torch.autograd.grad(y, ww, dy.double().permute(0, 3, 1, 2))
+    scale = float(gref.abs().max())
+    e_new, e_old = float((got.double() - gref).abs().max()) / scale, float((old.double() - gref).abs().max()) / scale
+    assert e_new < 2e-5 and e_old < 2e-5, (e_new, e_old)
+    # accumulate form (beta = 1 into an installed channels_last .grad)
+    base = torch.randn(C, C, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)
+    tgt = base.clone(memory_format=torch.channels_last)
+    assert we.conv_wgrad_planes(ops.to_planes(x), ops.to_planes(dy), w, x.shape, into=tgt) is None
+    assert float((tgt.double() - base.double() - gref).abs().max()) / scale < 2e-5
+
+
+def test_train_step_is_bitwise_unchanged_by_the_plane_data_gradients_and_close_with_the_plane_weight_gradients():
+    """One GAN-phase step of a trainer (full SE-ResNet34 audio tower, B = 4): plane-based DATA gradients leave every gradient bit-equal to the
+    round-2 path; adding the plane-based WEIGHT gradients (another fp32 summation order of the same products) moves them by < 1e-5 of the norm."""
     from ha2g_amd.config import hierarchy_args
     from ha2g_amd.testing import SpeakerVocab
     from ha2g_amd.train import HierarchyTrainer
@@ -101,8 +128,10 @@ def test_train_step_is_bitwise_unchanged_by_the_plane_path():
             return ret, [o.flat_g.clone() for o in tr.gen_opts + [tr.audio_opt, tr.text_opt, tr.dis_opt]]
         finally:
             we.PLANES = old
-    r0, g0 = run(False)
-    r1, g1 = run(True)
-    assert r0 == r1
-    for a, b in zip(g0, g1):
+    r0, g0 = run(0)
+    r1, g1 = run(1)
+    r3, g3 = run(3)
+    assert r0 == r1 == r3
+    for a, b, c in zip(g0, g1, g3):
         assert torch.equal(a, b)
+        assert float((c - a).norm() / a.norm()) < 1e-5

@@ -38,3 +38,23 @@ for H, W, C in ((64, 35, 64), (32, 18, 128), (16, 9, 256)):
     mo, mn = to[len(to) // 2], tn[len(tn) // 2]
     fl = 2.0 * B * H * W * C * C * 9
     print('dgrad C=%-3d %3dx%-3d          %10.1f %10.1f %8.2f %10.1f %8.3f' % (C, H, W, mo, mn, mo / mn, fl / mn / 1e6, fl / mn / 1e6 / 833.0))
+print()
+print('%-28s %10s %10s %8s %10s %8s' % ('shape', 'old us', 'planes us', 'ratio', 'TF(f32eq)', 'of 833'))
+for H, W, C in ((64, 35, 64), (32, 18, 128), (16, 9, 256)):
+    x = torch.randn(B, H, W, C, device=dev)
+    dy = torch.randn(B, H, W, C, device=dev)
+    w = torch.zeros(C, 3, 3, C, device=dev)
+    xp, dp = ops.to_planes(x), ops.to_planes(dy)
+    old = lambda: we.conv_wgrad(x, dy, w, 1, 1)
+    new = lambda: we.conv_wgrad_planes(xp, dp, w, x.shape)
+    new_split = lambda: we.conv_wgrad_planes(ops.to_planes(x), dp, w, x.shape)      # including the on-demand split of x
+    for f in (old, new, new_split):
+        f(); f()
+    torch.cuda.synchronize()
+    to, tn, ts = [], [], []
+    for _ in range(rounds):
+        to.append(t_us(old)); tn.append(t_us(new)); ts.append(t_us(new_split))
+    to.sort(); tn.sort(); ts.sort()
+    mo, mn, ms = to[len(to) // 2], tn[len(tn) // 2], ts[len(ts) // 2]
+    fl = 2.0 * B * H * W * C * C * 9
+    print('wgrad C=%-3d %3dx%-3d          %10.1f %10.1f %8.2f %10.1f %8.3f   (+ split of x: %.1f us)' % (C, H, W, mo, mn, mo / mn, fl / mn / 1e6, fl / mn / 1e6 / 833.0, ms))
