@@ -312,6 +312,28 @@ def main():
             roof_conv = dict(kernel='gemm_kernel<A_IM,B_KC> (ha2g_conv2d_fwd_f32, all SE-ResNet34 forward convolutions)', bound='mfma',
                              achieved=round(ach, 2), peak=157.3, unit='TFLOP/s', frac=round(ach / 157.3, 4), launches=n,
                              mean_us=round(mean_us, 1), traffic=None)
+        # backward matrix kernels (round 3: plane-based conv data / weight gradients of trunk layers 2-4) priced against the 3-product split-bf16
+        # roofline = dense bf16 MFMA peak / 3; BatchNorm passes against HBM with their algorithmic bytes (reads of dy / x per pass + the write)
+        def mfma3(key, kernel):
+            if key not in kt:
+                return None
+            n, mean_us, _, flops = kt[key]
+            ach = flops / (n * mean_us * 1e-6) / 1e12
+            return dict(kernel=kernel, bound='mfma', achieved=round(ach, 2), peak=round(2500.0 / 3, 1), unit='TFLOP/s (fp32-equivalent: 3 bf16 MFMAs per product)',
+                        frac=round(ach / (2500.0 / 3), 4), launches=n, mean_us=round(mean_us, 1), traffic=None,
+                        counters='profiles/r03_pmc_bwd_gemm_before.txt (round-2 kernels: 15-18 VALU per MFMA, matrix pipe 19-23 % busy), profiles/r03_pmc_planes_wgrad_v1.txt')
+        roof_bwd_gemm = mfma3('conv_dgrad_planes', 'pconv_dgrad_kernel (ha2g_conv2d_dgrad_planes_f32: 3x3 data gradients of trunk layers 2-4, DMA-staged bf16 planes)')
+        roof_bwd_wgrad = mfma3('conv_wgrad_planes', 'pconv_wgrad_kernel + wide reduce (ha2g_conv2d_wgrad_planes_f32: 3x3 weight gradients of trunk layers 2-4)')
+
+        def hbm(key, kernel):
+            if key not in kt:
+                return None
+            n, mean_us, _, nbytes = kt[key]
+            ach = nbytes / (n * mean_us * 1e-6) / 1e9
+            return dict(kernel=kernel, bound='hbm', achieved=round(ach, 1), peak=8000.0, unit='GB/s', frac=round(ach / 8000.0, 4), launches=n,
+                        mean_us=round(mean_us, 1), traffic=None, note='algorithmic bytes per pass; tensors of layers 2-4 (<= 73 MB) are served by the 256 MB Infinity Cache')
+        roof_bn = hbm('bn_bwd', 'col_partial_kernel<1> + pair_final + bn_bwd_apply_kernel (ha2g_bn_bwd[_planes]_f32: BatchNorm backward, 3 launches)')
+        roof_bn_stats = hbm('bn_stats', 'col_partial_kernel<0> + bn_stats_final (ha2g_bn_stats_f32: BatchNorm forward statistics)')
         out = dict(metric='pose-frames/sec (train step) for hierarchy.yml B=128 T=34', value=round(value, 1), unit='pose-frames/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling='weak',
                    vs_baseline=None,
@@ -330,7 +352,7 @@ def main():
                                             if a.epoch > args.loss_warmup else 'warm-up phase (epoch %d)' % a.epoch),
                                global_batch=a.batch * world, parallelism='dp%d' % world,
                                word_embedding_updates='row-wise (compact gradients, lazy Adam; bit-identical to dense)' if a.sparse_embeddings else 'dense'),
-                   gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, roofline_bwd=roof_bwd, roofline_gemm=roof_gemm, roofline_conv=roof_conv, roofline_pass='separate untimed pass of %d eager steps, HIP events around each launch on its launch stream' % k_roof, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
+                   gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, roofline_bwd=roof_bwd, roofline_gemm=roof_gemm, roofline_conv=roof_conv, roofline_bwd_gemm=roof_bwd_gemm, roofline_bwd_wgrad=roof_bwd_wgrad, roofline_bn=roof_bn, roofline_bn_stats=roof_bn_stats, roofline_pass='separate untimed pass of %d eager steps, HIP events around each launch on its launch stream' % k_roof, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
         if world == 1 and not a.no_cpu_baseline and not a.expressive:
             out['cpu_baseline'] = cpu_baseline(a.epoch, a.n_words, a.n_spk)
         print(json.dumps(out))

@@ -151,9 +151,12 @@ __global__ __launch_bounds__(256) void pair_final_kernel(const double* __restric
 }
 
 // y = (x - mean) * invstd * gamma + beta ; act: 0 none, 2 leaky-relu(0.01)
+// PL = 1: y is ALSO written as the two bf16 planes of the split-bf16 product (hi = bf16(y), lo = bf16(y - hi)): it is the x operand of the
+// next convolution's plane-based weight gradient (conv_planes.hip), split once here instead of once per consumer tile and tap in the backward
+template <int PL>
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, long rows,
-                                int C, int act) {
+                                int C, int act, unsigned short* __restrict__ y_hi, unsigned short* __restrict__ y_lo) {
     const int C4 = C >> 2;
     const long total = rows * C4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -169,6 +172,12 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
             r.z = r.z > 0.f ? r.z : 0.01f * r.z; r.w = r.w > 0.f ? r.w : 0.01f * r.w;
         }
         reinterpret_cast<float4*>(y)[i] = r;
+        if (PL) {
+            uint2 h, l;
+            split2_bf16(r.x, r.y, h.x, l.x); split2_bf16(r.z, r.w, h.y, l.y);
+            reinterpret_cast<uint2*>(y_hi)[i] = h;
+            reinterpret_cast<uint2*>(y_lo)[i] = l;
+        }
     }
 }
 
@@ -330,8 +339,10 @@ __global__ __launch_bounds__(256) void image_col_kernel(const float* __restrict_
 }
 
 // out = relu(x * s[n,c] + res)
+template <int PL>
 __global__ void se_scale_add_relu_kernel(const float* __restrict__ x, const float* __restrict__ s, const float* __restrict__ res,
-                                         float* __restrict__ out, long N, int HW, int C) {
+                                         float* __restrict__ out, long N, int HW, int C, unsigned short* __restrict__ o_hi,
+                                         unsigned short* __restrict__ o_lo) {
     const int C4 = C >> 2;
     const long per = (long)HW * C4, total = N * per;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -342,6 +353,12 @@ __global__ void se_scale_add_relu_kernel(const float* __restrict__ x, const floa
         o.x = fmaxf(v.x * sc.x + r.x, 0.f); o.y = fmaxf(v.y * sc.y + r.y, 0.f);
         o.z = fmaxf(v.z * sc.z + r.z, 0.f); o.w = fmaxf(v.w * sc.w + r.w, 0.f);
         reinterpret_cast<float4*>(out)[i] = o;
+        if (PL) {
+            uint2 h, l;
+            split2_bf16(o.x, o.y, h.x, l.x); split2_bf16(o.z, o.w, h.y, l.y);
+            reinterpret_cast<uint2*>(o_hi)[i] = h;
+            reinterpret_cast<uint2*>(o_lo)[i] = l;
+        }
     }
 }
 // dpre = dout * (out > 0); dres = dpre; dx = dpre * s[n,c] + dpool[n,c]   (dpool already divided by HW)
@@ -395,9 +412,19 @@ int ha2g_bn_stats_f32(const float* x, long rows, int C, float* mean, float* invs
 int ha2g_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y,
                       long rows, int C, int act, void* stream) {
     HA2G_REQUIRE(C % 4 == 0, "bn: C %% 4");
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta,
-                       y, rows, C, act);
+    hipLaunchKernelGGL(bn_apply_kernel<0>, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta,
+                       y, rows, C, act, (unsigned short*)nullptr, (unsigned short*)nullptr);
     HA2G_CHECK_LAUNCH("bn_apply");
+    return 0;
+}
+// ha2g_bn_apply_f32 that also writes y as bf16 planes y_hi / y_lo [rows][C]
+int ha2g_bn_apply_planes_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y, void* y_hi,
+                             void* y_lo, long rows, int C, int act, void* stream) {
+    HA2G_REQUIRE(C % 4 == 0, "bn: C %% 4");
+    HA2G_REQUIRE(y_hi != nullptr && y_lo != nullptr, "bn_apply_planes: null plane");
+    hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta,
+                       y, rows, C, act, (unsigned short*)y_hi, (unsigned short*)y_lo);
+    HA2G_CHECK_LAUNCH("bn_apply_planes");
     return 0;
 }
 // y = bn(x) for x [N][HW][C] AND pooled[n][c] = mean over HW of y (the SE squeeze) in one pass over the tensor.
@@ -460,9 +487,19 @@ int ha2g_hw_mean_f32(const float* x, float* out, int N, int HW, int C, void* str
 }
 int ha2g_se_scale_add_relu_f32(const float* x, const float* s, const float* res, float* out, int N, int HW, int C, void* stream) {
     HA2G_REQUIRE(C % 4 == 0, "se: C %% 4");
-    hipLaunchKernelGGL(se_scale_add_relu_kernel, dim3(flat_grid((long)N * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, s, res,
-                       out, (long)N, HW, C);
+    hipLaunchKernelGGL(se_scale_add_relu_kernel<0>, dim3(flat_grid((long)N * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, s, res,
+                       out, (long)N, HW, C, (unsigned short*)nullptr, (unsigned short*)nullptr);
     HA2G_CHECK_LAUNCH("se_scale_add_relu");
+    return 0;
+}
+// the same, out also as bf16 planes (the next block's conv1 reads them in its weight gradient)
+int ha2g_se_scale_add_relu_planes_f32(const float* x, const float* s, const float* res, float* out, void* o_hi, void* o_lo, int N, int HW, int C,
+                                      void* stream) {
+    HA2G_REQUIRE(C % 4 == 0, "se: C %% 4");
+    HA2G_REQUIRE(o_hi != nullptr && o_lo != nullptr, "se_scale_add_relu_planes: null plane");
+    hipLaunchKernelGGL(se_scale_add_relu_kernel<1>, dim3(flat_grid((long)N * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, s, res,
+                       out, (long)N, HW, C, (unsigned short*)o_hi, (unsigned short*)o_lo);
+    HA2G_CHECK_LAUNCH("se_scale_add_relu_planes");
     return 0;
 }
 // ds[n][c] = sum_hw dout*(out>0)*x

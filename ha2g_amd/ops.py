@@ -726,8 +726,9 @@ def grouped_conv1d_tm(x, ws, bs, dil=1, pad_left=0, To=None, act=ACT_NONE):
 def bn_stats(x2, running_mean, running_var, momentum, eps):
     rows, C = x2.shape
     mean, invstd = empty(C, like=x2), empty(C, like=x2)
-    check(lib.ha2g_bn_stats_f32(x2.data_ptr(), rows, C, mean.data_ptr(), invstd.data_ptr(), _p(running_mean), _p(running_var),
-                                momentum, eps, workspace(x2.device).data_ptr(), _stream()))
+    ktimer.launch('bn_stats', lambda: check(lib.ha2g_bn_stats_f32(
+        x2.data_ptr(), rows, C, mean.data_ptr(), invstd.data_ptr(), _p(running_mean), _p(running_var), momentum, eps,
+        workspace(x2.device).data_ptr(), _stream())), 4.0 * rows * C)
     return mean, invstd
 
 
@@ -759,16 +760,19 @@ def bn_bwd(dy2, x2, mean, invstd, gamma, need_dx=True, relu_mask=False, acc=None
     dx = torch.empty_like(x2) if need_dx else None
     dgamma, dbeta = empty(C, like=x2), empty(C, like=x2)
     ag, ab = acc if acc is not None else (None, None)
+    # algorithmic HBM bytes of the backward (bench.py roofline_bn): statistics pass reads dy and x, apply pass reads them again and writes dx
+    nbytes = 4.0 * rows * C * (5 if (need_dx or planes) else 2)
     if planes:
         hi = torch.empty(rows, C, dtype=torch.bfloat16, device=x2.device)
         lo = torch.empty(rows, C, dtype=torch.bfloat16, device=x2.device)
-        check(lib.ha2g_bn_bwd_planes_f32(dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dx), hi.data_ptr(),
-                                         lo.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, C, int(relu_mask), _p(ag), _p(ab),
-                                         workspace(x2.device).data_ptr(), _stream()))
+        ktimer.launch('bn_bwd', lambda: check(lib.ha2g_bn_bwd_planes_f32(
+            dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dx), hi.data_ptr(), lo.data_ptr(),
+            dgamma.data_ptr(), dbeta.data_ptr(), rows, C, int(relu_mask), _p(ag), _p(ab), workspace(x2.device).data_ptr(), _stream())),
+            nbytes + (4.0 * rows * C if need_dx else 0.0))
         return dx, dgamma, dbeta, (hi, lo)
-    check(lib.ha2g_bn_bwd_f32(dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dx),
-                              dgamma.data_ptr(), dbeta.data_ptr(), rows, C, int(relu_mask), _p(ag), _p(ab),
-                              workspace(x2.device).data_ptr(), _stream()))
+    ktimer.launch('bn_bwd', lambda: check(lib.ha2g_bn_bwd_f32(
+        dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dx), dgamma.data_ptr(), dbeta.data_ptr(), rows, C,
+        int(relu_mask), _p(ag), _p(ab), workspace(x2.device).data_ptr(), _stream())), nbytes)
     return dx, dgamma, dbeta
 
 

@@ -81,8 +81,9 @@ def conv_dgrad_planes(dy_planes, w_ohwi, xshape, stride, pad, out=None, beta=0.0
     check(lib.ha2g_conv2d_weight_ihwo_planes(w_ohwi.data_ptr(), wh.data_ptr(), wl.data_ptr(), Cout, KH, KW, Cin, _stream()))
     if out is None:
         out = torch.empty(N, H, W, Cin, dtype=torch.float32, device=hi.device)
-    check(lib.ha2g_conv2d_dgrad_planes_f32(hi.data_ptr(), lo.data_ptr(), wh.data_ptr(), wl.data_ptr(), out.data_ptr(), N, H, W, Cin, Cout, KH, KW,
-                                           stride, pad, beta, _stream()))
+    ops.ktimer.launch('conv_dgrad_planes', lambda: check(lib.ha2g_conv2d_dgrad_planes_f32(
+        hi.data_ptr(), lo.data_ptr(), wh.data_ptr(), wl.data_ptr(), out.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad, beta, _stream())),
+        2.0 * N * H * W * Cin * KH * KW * Cout)
     return out
 
 
@@ -128,8 +129,9 @@ def conv_wgrad_planes(x_planes, dy_planes, w_ohwi, xshape, into=None):
         dw = torch.empty(Cout, KH, KW, Cin, dtype=torch.float32, device=x_planes[0].device)
     ws = workspace(x_planes[0].device)
     assert lib.ha2g_conv2d_wgrad_planes_workspace_bytes(N, H, W, Cin, Cout) <= ws.numel() * 4
-    check(lib.ha2g_conv2d_wgrad_planes_f32(x_planes[0].data_ptr(), x_planes[1].data_ptr(), dy_planes[0].data_ptr(), dy_planes[1].data_ptr(),
-                                           dw.data_ptr(), N, H, W, Cin, Cout, KH, KW, 1, 1, beta, ws.data_ptr(), ws.numel() * 4, _stream()))
+    ops.ktimer.launch('conv_wgrad_planes', lambda: check(lib.ha2g_conv2d_wgrad_planes_f32(
+        x_planes[0].data_ptr(), x_planes[1].data_ptr(), dy_planes[0].data_ptr(), dy_planes[1].data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, KH, KW,
+        1, 1, beta, ws.data_ptr(), ws.numel() * 4, _stream())), 2.0 * N * H * W * Cin * KH * KW * Cout)
     return None if into is not None else dw.permute(0, 3, 1, 2)
 
 
@@ -147,10 +149,12 @@ class _BN:
 
 _TRAINING = [True]
 _NBT_PENDING = []
+_FWD_PLANES = [False]      # this forward will be back-propagated through the plane-based weight gradients: producers also write bf16 planes
 
 
-def _bn_fwd(x, bn, pool=False):
-    """BatchNorm forward; pool=True also returns the per-image channel means of the output (the SE squeeze), fused."""
+def _bn_fwd(x, bn, pool=False, planes=False):
+    """BatchNorm forward; pool=True also returns the per-image channel means of the output (the SE squeeze), fused; planes=True appends the
+    (hi, lo) bf16 planes of the output (written by the same apply pass)."""
     x2 = _rows(x)
     if not _TRAINING[0]:                                    # module.eval(): running statistics, no update
         mean, invstd = bn.rm, ops.eltwise(ops.OP_RSQRT_EPS, bn.rv, alpha=1e-5)
@@ -161,6 +165,13 @@ def _bn_fwd(x, bn, pool=False):
     if pool:
         y, pooled = ops.bn_apply_pool(x, mean, invstd, bn.gamma, bn.beta)
         return y, mean, invstd, pooled
+    if planes:
+        y = torch.empty_like(x2)
+        hi = torch.empty(x2.shape, dtype=torch.bfloat16, device=x.device)
+        lo = torch.empty_like(hi)
+        check(lib.ha2g_bn_apply_planes_f32(x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), bn.gamma.data_ptr(), bn.beta.data_ptr(), y.data_ptr(),
+                                           hi.data_ptr(), lo.data_ptr(), x2.shape[0], x2.shape[1], ACT_NONE, _stream()))
+        return y.view(x.shape), mean, invstd, (hi, lo)
     y = ops.bn_apply(x2, mean, invstd, bn.gamma, bn.beta).view(x.shape)
     return y, mean, invstd
 
@@ -191,7 +202,9 @@ def _tap_pack(x, inverse=False, shape=None):
 
 import os as _os
 # producer-side bf16 hi / lo planes for the backward convolutions (round 3).  bit 0: data gradients (bit-identical to the round-2 kernels),
-# bit 1: weight gradients (same products, different fp32 summation order); HA2G_PLANES=0 is the round-2 path
+# bit 1: weight gradients (same products, different fp32 summation order); bit 2: the x operand of those weight gradients is written as planes by
+# the FORWARD producers (bn1's apply pass, the block's output pass) instead of being split by a streaming pass on the backward's side stream;
+# HA2G_PLANES=0 is the round-2 path
 PLANES = int(_os.environ.get('HA2G_PLANES', '3'))
 SIDE_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_WGRAD', '1') != '0'
 SIDE_FC_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_FC', '1') != '0'
@@ -246,21 +259,23 @@ class GradSink:
         else:
             self.G[name] = ops.colsum(a)
 
-    def gconv(self, name, xin, dyc, w_ohwi, stride, pad, dy_planes=None):
-        """dy_planes: the (hi, lo) planes of dyc when its producer wrote them -- the plane-based weight gradient then splits x once (a
-        streaming pass on the side stream) instead of once per consumer tile and tap."""
+    def gconv(self, name, xin, dyc, w_ohwi, stride, pad, dy_planes=None, x_planes=None):
+        """dy_planes: the (hi, lo) planes of dyc when its producer wrote them; x_planes: those of xin when the forward wrote them (else x is
+        split here, once, by a streaming pass on the side stream) -- the plane-based weight gradient reads both by DMA."""
         if dy_planes is not None and wgrad_planes_ok(xin, w_ohwi, stride, pad):
-            return self._gconv_planes(name, xin, dy_planes, w_ohwi)
+            return self._gconv_planes(name, xin, dy_planes, w_ohwi, x_planes)
         return self._gconv(name, xin, dyc, w_ohwi, stride, pad)
 
-    def _gconv_planes(self, name, xin, dy_planes, w_ohwi):
+    def _gconv_planes(self, name, xin, dy_planes, w_ohwi, x_planes=None):
         side_on = SIDE_WGRAD and ops.side.enabled and xin.is_cuda
         ctx = ops.side.section(xin.device) if side_on else ops._null()
         with ctx:
             if side_on:
                 st = torch.cuda.current_stream(xin.device)
                 xin.record_stream(st); dy_planes[0].record_stream(st); dy_planes[1].record_stream(st)
-            xp = ops.to_planes(xin)
+            if x_planes is not None and side_on:
+                x_planes[0].record_stream(st); x_planes[1].record_stream(st)
+            xp = x_planes if x_planes is not None else ops.to_planes(xin)
             r = conv_wgrad_planes(xp, dy_planes, w_ohwi, xin.shape, into=self.tgt(self.P[name]))
             if r is not None and side_on:
                 r.record_stream(torch.cuda.default_stream(xin.device))
@@ -304,13 +319,18 @@ class GradSink:
 
 # ---- one SEBasicBlock (ResNetBlocks.py:21-37,81-95): conv -> ReLU -> BN -> conv -> BN -> SE -> (+ residual) -> ReLU --------
 
-def block_fwd(x, P, b, first):
+def block_fwd(x, P, b, first, xp=None, out_planes=False):
     """x NHWC; P: name -> tensor / _BN with keys prefixed by `b`; first = stride-2 block with the 1x1 downsample branch.
-    Returns (out NHWC, saved tuple for block_bwd)."""
+    xp = (hi, lo) planes of x when the previous block wrote them; out_planes: also write this block's output as planes (the next block's
+    conv1 takes them in its weight gradient).  Returns (out NHWC, saved tuple for block_bwd, planes of out or None)."""
     stride = 2 if first else 1
     wa, wb = _ohwi(P[b + 'conv1.weight']), _ohwi(P[b + 'conv2.weight'])
     c1 = conv_fwd(x, wa, None, stride, 1, ACT_RELU)                     # relu(conv1)
-    a1, m1, s1 = _bn_fwd(c1, P[b + 'bn1'])
+    a1p = None
+    if _FWD_PLANES[0] and wgrad_planes_ok(c1, wb, 1, 1):
+        a1, m1, s1, a1p = _bn_fwd(c1, P[b + 'bn1'], planes=True)
+    else:
+        a1, m1, s1 = _bn_fwd(c1, P[b + 'bn1'])
     c2 = conv_fwd(a1, wb, None, 1, 1, ACT_NONE)
     b2, m2, s2, pooled = _bn_fwd(c2, P[b + 'bn2'], pool=True)         # bn2 + SE squeeze in one pass
     N, OH, OW, C = b2.shape
@@ -326,13 +346,19 @@ def block_fwd(x, P, b, first):
     else:
         res, cd, md, sd = x, None, None, None
     out = torch.empty_like(b2)
-    check(lib.ha2g_se_scale_add_relu_f32(b2.data_ptr(), sc.data_ptr(), res.data_ptr(), out.data_ptr(), N, OH * OW, C, _stream()))
-    return out, (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride)
+    outp = None
+    if out_planes and _FWD_PLANES[0] and wgrad_planes_ok(out, wb, 1, 1):
+        outp = (torch.empty(out.shape, dtype=torch.bfloat16, device=out.device), torch.empty(out.shape, dtype=torch.bfloat16, device=out.device))
+        check(lib.ha2g_se_scale_add_relu_planes_f32(b2.data_ptr(), sc.data_ptr(), res.data_ptr(), out.data_ptr(), outp[0].data_ptr(), outp[1].data_ptr(),
+                                                    N, OH * OW, C, _stream()))
+    else:
+        check(lib.ha2g_se_scale_add_relu_f32(b2.data_ptr(), sc.data_ptr(), res.data_ptr(), out.data_ptr(), N, OH * OW, C, _stream()))
+    return out, (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride, xp, a1p), outp
 
 
 def block_bwd(dx, saved, P, b, sink):
     """dx = d(out) NHWC -> d(x) NHWC; parameter gradients go to `sink` (GradSink)."""
-    (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride) = saved
+    (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride, xp, a1p) = saved
     N, OH, OW, C = b2.shape
     HW = OH * OW
     dout = dx.contiguous()
@@ -356,11 +382,11 @@ def block_bwd(dx, saved, P, b, sink):
     f1 = not (p1 and wgrad_planes_ok(x, wa, stride, 1))
     dc2 = sink.gbn(b + 'bn2', _rows(db2), _rows(c2), m2, s2, planes=p2, need_dx=f2)
     dc2, dc2p = ((dc2[0].view(c2.shape) if f2 else None), dc2[1]) if p2 else (dc2.view(c2.shape), None)
-    sink.gconv(b + 'conv2.weight', a1, dc2, wb, 1, 1, dy_planes=dc2p)
+    sink.gconv(b + 'conv2.weight', a1, dc2, wb, 1, 1, dy_planes=dc2p, x_planes=a1p)
     da1 = conv_dgrad_planes(dc2p, wb, a1.shape, 1, 1) if p2 else conv_dgrad(dc2, wb, a1.shape, 1, 1)
     dc1 = sink.gbn(b + 'bn1', _rows(da1), _rows(c1), m1, s1, relu_mask=True, planes=p1, need_dx=f1)
     dc1, dc1p = ((dc1[0].view(c1.shape) if f1 else None), dc1[1]) if p1 else (dc1.view(c1.shape), None)
-    sink.gconv(b + 'conv1.weight', x, dc1, wa, stride, 1, dy_planes=dc1p)
+    sink.gconv(b + 'conv1.weight', x, dc1, wa, stride, 1, dy_planes=dc1p, x_planes=xp)
     if cd is None:                                                              # identity shortcut: accumulate onto d(residual)
         if p1:
             return conv_dgrad_planes(dc1p, wa, x.shape, stride, 1, out=dres, beta=1.0)
@@ -479,11 +505,14 @@ class WavEncoderFunction(torch.autograd.Function):
         x, m, s = _bn_fwd(c0, P['bn1'])
         S['stem'] = (spec, c0, m, s)
         feats = []
+        _FWD_PLANES[0] = (PLANES & 6) == 6 and training and any(ctx.needs_input_grad)       # false under no_grad: nothing will read the planes
         for li, nblk in enumerate(LAYERS):
+            xp = None
             for j in range(nblk):
                 b = 'layer%d.%d.' % (li + 1, j)
-                x, S[b] = block_fwd(x, P, b, j == 0 and li > 0)
+                x, S[b], xp = block_fwd(x, P, b, j == 0 and li > 0, xp=xp, out_planes=j + 1 < nblk)
             feats.append(x)
+        _FWD_PLANES[0] = False
         # ---- taps ----
         tap_out = []
         for (t, C, k, r), f in zip(TAPS, feats[1:]):

@@ -179,6 +179,12 @@ int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const fl
 int ha2g_bn_bwd_planes_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx, void* dx_hi,
                            void* dx_lo, float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta,
                            float* ws, void* stream);
+/* forward producers of the x operand of the plane-based weight gradient: ha2g_bn_apply_f32 / ha2g_se_scale_add_relu_f32 that write their output
+ * a second time as bf16 hi / lo planes (model/ResNetBlocks.py:24-36: bn1's output feeds conv2, the block's output feeds the next block's conv1) */
+int ha2g_bn_apply_planes_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y, void* y_hi,
+                             void* y_lo, long rows, int C, int act, void* stream);
+int ha2g_se_scale_add_relu_planes_f32(const float* x, const float* s, const float* res, float* out, void* o_hi, void* o_lo, int N, int HW, int C,
+                                      void* stream);
 /* ---- squeeze-excite pointwise pieces (model/ResNetBlocks.py:81-95 and the residual tail :33-36) ---- */
 int ha2g_hw_mean_f32(const float* x, float* out, int N, int HW, int C, void* stream);
 int ha2g_se_scale_add_relu_f32(const float* x, const float* s, const float* res, float* out, int N, int HW, int C, void* stream);

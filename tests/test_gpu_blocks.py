@@ -33,7 +33,7 @@ def run_block(ck, name, geom, B, seed):
     x, wl = block_io(name, geom, B, seed)
     we._TRAINING[0] = True
     we._NBT_PENDING.clear()
-    out, saved = we.block_fwd(nhwc(x.to(DEV)), P, '', geom[4])
+    out, saved, _ = we.block_fwd(nhwc(x.to(DEV)), P, '', geom[4])
     sink = we.GradSink(P)
     dx = we.block_bwd(nhwc(wl.to(DEV)), saved, P, '', sink)
     sink.join(torch.device(DEV))                              # the convolution weight gradients run on the side stream

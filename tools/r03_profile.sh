@@ -7,4 +7,5 @@ rm -rf /tmp/prof_$TAG; rocprofv3 --kernel-trace -d /tmp/prof_$TAG -o kt -- pytho
 db=$(find /tmp/prof_$TAG -name "*.db" | head -1)
 python tools/rocpd_stats.py $db 90 > gpurun_out/${TAG}_kernel_stats.txt
 python tools/profile_categories.py gpurun_out/${TAG}_kernel_stats.txt 12 > gpurun_out/${TAG}_kernel_families.txt
+python tools/rocpd_queues.py $db 12 > gpurun_out/${TAG}_queues.txt
 cat gpurun_out/${TAG}_kernel_families.txt
