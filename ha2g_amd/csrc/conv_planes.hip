@@ -48,12 +48,26 @@ __global__ void weight_ihwo_planes_kernel(const float* __restrict__ w, unsigned 
     }
 }
 
+// One PARITY CLASS of output pixels.  Stride 1: a single class, all taps.  Stride 2: the output pixels (oy, ox) with (oy % 2, ox % 2) = (py, px)
+// receive contributions only from the taps with (oy + pad - kh) and (ox + pad - kw) even -- 1, 2, 2 and 4 of the nine 3x3 taps for the four
+// classes (ONE of the four classes for a 1x1 kernel) -- so each class is its own implicit GEMM over ITS taps only.  The round-2 kernels ran all
+// nine taps for every pixel with a validity mask: 4x the matrix work of a stride-2 data gradient.  The taps of a class are listed in
+// ascending order and their source offsets are affine (first tap's pixel minus ((kh - kh0) / s) rows and ((kw - kw0) / s) columns), so the k loop
+// is the stride-1 loop over a shorter tap list; the non-zero products of every output element arrive in the same order as before.
+struct PClass {
+    int py, px, OHc, OWc, M;                                     // parity, class grid, pixels of the class (over all images)
+    int ntaps, kh0, kw0;                                         // taps of the class; first valid kh / kw
+    int tap[9];                                                  // filter tap index kh * KW + kw
+    int doff[9];                                                 // source offset of the tap relative to the first one, in pixels of the dy grid (<= 0)
+};
 struct PConvP {
     const unsigned short* a_hi; const unsigned short* a_lo;      // dy planes [img][GH][GW][GC]
     const unsigned short* b_hi; const unsigned short* b_lo;      // weight planes [N][K], K = KH*KW*GC
     float* C; long ldc; float beta;
-    int M, N, K;
-    int GH, GW, GC, OH, OW, KH, KW, pad;                         // gathered tensor / output pixel grid (stride 1)
+    int N, K;
+    int GH, GW, GC, OH, OW, KH, KW, pad, stride;                 // gathered tensor (dy) / output pixel grid (dx)
+    int ncls;
+    PClass cls[4];
     int dbg;                                                     // timing ablations (ha2g_conv_planes_debug): 1 = no DMA after tile 0, 2 = no MFMA
 };
 
@@ -66,7 +80,8 @@ __device__ __forceinline__ void ptile_of_block(int& bx, int& by) {
     bx = seq / nby; by = seq - bx * nby;
 }
 
-// Data gradient of a stride-1 convolution as an implicit GEMM over planes:  dx[m][n] (+)= sum_{tap, co} dy[pix(m) - tap][co] * wt[n][tap][co].
+// Data gradient of a convolution (stride 1 or 2) as an implicit GEMM over planes:  dx[m][n] (+)= sum_{tap, co} dy[src(m, tap)][co] * wt[n][tap][co];
+// blockIdx.z = parity class (PClass).
 // BM x BN output tile, 4 waves as WM x WN, wave tile (32 MI) x (32 NI), k tile = 32 channels of one filter tap, two LDS buffers,
 // one barrier per k tile: the next tile's DMA is issued before the current tile's MFMAs and waited for after them.
 template <int BM, int BN, int WM, int WN>
@@ -85,9 +100,11 @@ __global__ __launch_bounds__(256) void pconv_dgrad_kernel(PConvP p) {
     const int wm = wave / WN, wn = wave % WN;
     int bx, by;
     ptile_of_block(bx, by);
+    const PClass& pc = p.cls[blockIdx.z];
     const int m0 = bx * BM, n0 = by * BN;
+    if (m0 >= pc.M) return;                                      // classes differ in size when H or W is odd
     const int nkc = p.GC >> 5;                                   // k tiles per filter tap
-    const int nk = p.KH * p.KW * nkc;
+    const int nk = pc.ntaps * nkc;
 
     // ---- staging state: this lane's rows (fixed for the whole k loop) ----
     const int srow = lane >> 2;                                  // row inside a 16-row piece
@@ -98,15 +115,16 @@ __global__ __launch_bounds__(256) void pconv_dgrad_kernel(PConvP p) {
         a_lc[i] = (lane & 3) ^ ((row >> 2) & 3);                  // logical 16-byte piece this lane fetches (its LDS slot is lane & 3)
         const int m = m0 + row;
         a_mask[i] = 0u; a_base[i] = 0;
-        if (m < p.M) {
-            const int ox = m % p.OW; const int t = m / p.OW; const int oy = t % p.OH; const int img = t / p.OH;
-            const int u = oy + p.pad, v = ox + p.pad;
-            a_base[i] = (((long)img * p.GH + u) * p.GW + v) * p.GC + a_lc[i] * 8;
-            for (int kh = 0; kh < p.KH; ++kh)
-                for (int kw = 0; kw < p.KW; ++kw) {
-                    const int ty = u - kh, tx = v - kw;
-                    if (ty >= 0 && tx >= 0 && ty < p.GH && tx < p.GW) a_mask[i] |= 1u << (kh * p.KW + kw);
-                }
+        if (m < pc.M) {
+            const int oxc = m % pc.OWc; const int t = m / pc.OWc; const int oyc = t % pc.OHc; const int img = t / pc.OHc;
+            const int u = oyc * p.stride + pc.py + p.pad, v = oxc * p.stride + pc.px + p.pad;
+            const int sy0 = (u - pc.kh0) / p.stride, sx0 = (v - pc.kw0) / p.stride;          // source pixel of the class's first tap (exact divisions)
+            a_base[i] = (((long)img * p.GH + sy0) * p.GW + sx0) * p.GC + a_lc[i] * 8;
+            for (int ti = 0; ti < pc.ntaps; ++ti) {
+                const int kh = pc.tap[ti] / p.KW, kw = pc.tap[ti] - kh * p.KW;
+                const int sy = (u - kh) / p.stride, sx = (v - kw) / p.stride;
+                if (u - kh >= 0 && v - kw >= 0 && sy < p.GH && sx < p.GW) a_mask[i] |= 1u << ti;
+            }
         }
     }
     long b_off[NB];
@@ -120,10 +138,9 @@ __global__ __launch_bounds__(256) void pconv_dgrad_kernel(PConvP p) {
     const unsigned short* zero = g_zero_page;
 
     auto stage = [&](int kt, int buf) {
-        const int tap = kt / nkc, c0 = (kt - tap * nkc) << 5;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
-        const long koff = c0 - ((long)kh * p.GW + kw) * p.GC;
-        const unsigned bit = 1u << tap;
+        const int ti = kt / nkc, c0 = (kt - ti * nkc) << 5;
+        const long koff = c0 + (long)pc.doff[ti] * p.GC;
+        const unsigned bit = 1u << ti;
         unsigned char* dst = smem + buf * BUF;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -134,7 +151,7 @@ __global__ __launch_bounds__(256) void pconv_dgrad_kernel(PConvP p) {
             __builtin_amdgcn_global_load_lds((gptr_t)gh, (lds_ptr_t)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)gl, (lds_ptr_t)(dst + PLANE_A + (wave + 4 * i) * 1024), 16, 0, 0);
         }
-        const long kb = (long)kt * 32;
+        const long kb = (long)pc.tap[ti] * p.GC + c0;             // k index of the weight planes: (tap, channel)
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const bool on = b_off[i] >= 0;
@@ -210,8 +227,13 @@ __global__ __launch_bounds__(256) void pconv_dgrad_kernel(PConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (row >= p.M) continue;
-                float* dst = p.C + (long)row * p.ldc + col;
+                if (row >= pc.M) continue;
+                long orow = row;                                             // stride 1: class-linear = output-linear
+                if (p.stride != 1) {
+                    const int oxc = row % pc.OWc; const int t = row / pc.OWc; const int oyc = t % pc.OHc; const int img = t / pc.OHc;
+                    orow = ((long)img * p.OH + oyc * p.stride + pc.py) * p.OW + oxc * p.stride + pc.px;
+                }
+                float* dst = p.C + orow * p.ldc + col;
                 float v = 1.0f * acc[i][j][r] + 0.f;                  // alpha = 1, no bias: the epilogue arithmetic of gemm_x3_kernel
                 if (p.beta != 0.f) v += p.beta * *dst;
                 *dst = v;
@@ -470,31 +492,57 @@ int ha2g_conv2d_weight_ihwo_planes(const float* w, void* wt_hi, void* wt_lo, int
     return 0;
 }
 
-// 1 when ha2g_conv2d_dgrad_planes_f32 serves this geometry in the current arithmetic mode (split-bf16 data gradients on, planes enabled)
+// 1 when ha2g_conv2d_dgrad_planes_f32 serves this geometry in the current arithmetic mode (split-bf16 data gradients on, planes enabled):
+// 3x3 / pad 1 or 1x1 / pad 0, stride 1 or 2, Cout % 32 == 0 (k tiles of 32 channels), Cin >= 32 and a multiple of 32
 int ha2g_conv2d_dgrad_planes_supported(int Cin, int Cout, int KH, int KW, int stride, int pad) {
-    return g_planes && gemm_split_dgrad_enabled() && stride == 1 && KH == 3 && KW == 3 && pad == 1 && Cout % 32 == 0 && Cin % 64 == 0 && Cin >= 64;
+    const bool geom = (KH == 3 && KW == 3 && pad == 1) || (KH == 1 && KW == 1 && pad == 0 && stride == 2);
+    return g_planes && gemm_split_dgrad_enabled() && geom && (stride == 1 || stride == 2) && Cout % 32 == 0 && Cin % 32 == 0 && Cin >= 32 &&
+           !(stride == 1 && Cin < 64);                              // the 32 -> 32 stride-1 layer has its direct LDS-patch kernel
 }
 
-// dx [N,H,W,Cin] = beta * dx + conv_transpose(dy, w) from the bf16 planes of dy [N,H,W,Cout] and of wt [Cin][KH][KW][Cout]
+// dx [N,H,W,Cin] = beta * dx + conv_transpose(dy, w) from the bf16 planes of dy [N,OH,OW,Cout] and of wt [Cin][KH][KW][Cout]
 // (ha2g_conv2d_weight_ihwo_planes).  Bit-identical to ha2g_conv2d_dgrad_f32 in the default arithmetic mode on the fp32 tensors the planes
-// were split from.
+// were split from.  Stride 2: pixels that no tap reaches (1x1 kernel: three of the four parity classes) are NOT written: with beta = 0 the
+// caller zero-fills dx first (ha2g_amd.wav_engine does).
 int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N, int H, int W,
                                  int Cin, int Cout, int KH, int KW, int stride, int pad, float beta, void* stream) {
     HA2G_REQUIRE(ha2g_conv2d_dgrad_planes_supported(Cin, Cout, KH, KW, stride, pad), "conv2d_dgrad_planes: unsupported geometry / mode");
+    const int OHd = (H + 2 * pad - KH) / stride + 1, OWd = (W + 2 * pad - KW) / stride + 1;      // the dy grid
     PConvP p{};
     p.a_hi = (const unsigned short*)dy_hi; p.a_lo = (const unsigned short*)dy_lo;
     p.b_hi = (const unsigned short*)wt_hi; p.b_lo = (const unsigned short*)wt_lo;
     p.C = dx; p.ldc = Cin; p.beta = beta;
-    p.M = N * H * W; p.N = Cin; p.K = KH * KW * Cout;
-    p.GH = H; p.GW = W; p.GC = Cout; p.OH = H; p.OW = W; p.KH = KH; p.KW = KW; p.pad = pad;
+    p.N = Cin; p.K = KH * KW * Cout;
+    p.GH = OHd; p.GW = OWd; p.GC = Cout; p.OH = H; p.OW = W; p.KH = KH; p.KW = KW; p.pad = pad; p.stride = stride;
     p.dbg = g_pdbg;
-    if (p.M == 0) return 0;
+    if ((long)N * H * W == 0) return 0;
+    int maxM = 0;
+    p.ncls = 0;
+    for (int py = 0; py < stride; ++py)
+        for (int px = 0; px < stride; ++px) {
+            PClass c{};
+            c.py = py; c.px = px;
+            c.OHc = (H - py + stride - 1) / stride; c.OWc = (W - px + stride - 1) / stride;
+            c.M = N * c.OHc * c.OWc;
+            c.ntaps = 0; c.kh0 = -1; c.kw0 = -1;
+            for (int kh = 0; kh < KH; ++kh)
+                for (int kw = 0; kw < KW; ++kw) {
+                    if ((py + pad - kh) % stride != 0 || (px + pad - kw) % stride != 0) continue;       // operands >= -2: C's % keeps the sign, 0 stays 0
+                    if (c.kh0 < 0) { c.kh0 = kh; c.kw0 = kw; }
+                    c.tap[c.ntaps] = kh * KW + kw;
+                    c.doff[c.ntaps] = -(((kh - c.kh0) / stride) * OWd + (kw - c.kw0) / stride);
+                    ++c.ntaps;
+                }
+            if (c.ntaps == 0 || c.M == 0) continue;
+            if (c.M > maxM) maxM = c.M;
+            p.cls[p.ncls++] = c;
+        }
     hipStream_t st = (hipStream_t)stream;
     if (Cin % 128 == 0) {
-        dim3 grid(ceil_div(p.M, 128), Cin / 128);
+        dim3 grid(ceil_div(maxM, 128), Cin / 128, p.ncls);
         hipLaunchKernelGGL((pconv_dgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, p);
-    } else {
-        dim3 grid(ceil_div(p.M, 256), Cin / 64);
+    } else {                                                        // 64 columns per tile (Cin = 32: the upper half idles)
+        dim3 grid(ceil_div(maxM, 256), ceil_div(Cin, 64), p.ncls);
         hipLaunchKernelGGL((pconv_dgrad_kernel<256, 64, 4, 1>), grid, dim3(256), 0, st, p);
     }
     HA2G_CHECK_LAUNCH("conv2d_dgrad_planes");

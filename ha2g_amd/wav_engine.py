@@ -67,7 +67,7 @@ def conv_dgrad(dy, w_ohwi, xshape, stride, pad, out=None, beta=0.0):
 
 def dgrad_planes_ok(w_ohwi, stride, pad):
     Cout, KH, KW, Cin = w_ohwi.shape
-    return bool(PLANES & 1) and bool(lib.ha2g_conv2d_dgrad_planes_supported(Cin, Cout, KH, KW, stride, pad))
+    return bool(PLANES & (1 if stride == 1 else 8)) and bool(lib.ha2g_conv2d_dgrad_planes_supported(Cin, Cout, KH, KW, stride, pad))
 
 
 def conv_dgrad_planes(dy_planes, w_ohwi, xshape, stride, pad, out=None, beta=0.0):
@@ -81,7 +81,10 @@ def conv_dgrad_planes(dy_planes, w_ohwi, xshape, stride, pad, out=None, beta=0.0
     check(lib.ha2g_conv2d_weight_ihwo_planes(w_ohwi.data_ptr(), wh.data_ptr(), wl.data_ptr(), Cout, KH, KW, Cin, _stream()))
     if out is None:
         out = torch.empty(N, H, W, Cin, dtype=torch.float32, device=hi.device)
-    ops.ktimer.launch('conv_dgrad_planes', lambda: check(lib.ha2g_conv2d_dgrad_planes_f32(
+        beta = 0.0
+    if beta == 0.0 and stride == 2 and KH == 1:
+        out.zero_()                                       # a 1x1 stride-2 kernel reaches one pixel in four: the kernel writes only those
+    ops.ktimer.launch('conv_dgrad_planes' if stride == 1 else 'conv_dgrad_planes_s2', lambda: check(lib.ha2g_conv2d_dgrad_planes_f32(
         hi.data_ptr(), lo.data_ptr(), wh.data_ptr(), wl.data_ptr(), out.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad, beta, _stream())),
         2.0 * N * H * W * Cin * KH * KW * Cout)
     return out
@@ -204,8 +207,8 @@ import os as _os
 # producer-side bf16 hi / lo planes for the backward convolutions (round 3).  bit 0: data gradients (bit-identical to the round-2 kernels),
 # bit 1: weight gradients (same products, different fp32 summation order); bit 2: the x operand of those weight gradients is written as planes by
 # the FORWARD producers (bn1's apply pass, the block's output pass) instead of being split by a streaming pass on the backward's side stream;
-# HA2G_PLANES=0 is the round-2 path
-PLANES = int(_os.environ.get('HA2G_PLANES', '3'))
+# bit 3: the stride-2 data gradients (conv1 / downsample of a layer's first block) by parity class; HA2G_PLANES=0 is the round-2 path
+PLANES = int(_os.environ.get('HA2G_PLANES', '11'))
 SIDE_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_WGRAD', '1') != '0'
 SIDE_FC_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_FC', '1') != '0'
 
@@ -391,11 +394,16 @@ def block_bwd(dx, saved, P, b, sink):
         if p1:
             return conv_dgrad_planes(dc1p, wa, x.shape, stride, 1, out=dres, beta=1.0)
         return conv_dgrad(dc1, wa, x.shape, stride, 1, out=dres, beta=1.0)
-    dxin = conv_dgrad(dc1, wa, x.shape, stride, 1)
-    dcd = sink.gbn(b + 'downsample.1', _rows(dres), _rows(cd), md, sd).view(cd.shape)
+    dxin = conv_dgrad_planes(dc1p, wa, x.shape, stride, 1) if p1 else conv_dgrad(dc1, wa, x.shape, stride, 1)
     wd = _ohwi(P[b + 'downsample.0.weight'])
+    pd = dgrad_planes_ok(wd, 2, 0)
+    dcd = sink.gbn(b + 'downsample.1', _rows(dres), _rows(cd), md, sd, planes=pd)
+    dcd, dcdp = (dcd[0].view(cd.shape), dcd[1]) if pd else (dcd.view(cd.shape), None)
     sink.gconv(b + 'downsample.0.weight', x, dcd, wd, 2, 0)
-    conv_dgrad(dcd, wd, x.shape, 2, 0, out=dxin, beta=1.0)
+    if pd:
+        conv_dgrad_planes(dcdp, wd, x.shape, 2, 0, out=dxin, beta=1.0)
+    else:
+        conv_dgrad(dcd, wd, x.shape, 2, 0, out=dxin, beta=1.0)
     return dxin
 
 

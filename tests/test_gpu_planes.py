@@ -60,11 +60,37 @@ def test_dgrad_planes_bit_identical_to_the_split_implicit_gemm(B, H, W, C):
     assert rel < 3e-5, rel
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout,k', [(4, 128, 70, 32, 64, 3), (3, 64, 35, 64, 128, 3), (5, 32, 18, 128, 256, 3), (2, 9, 7, 64, 64, 3),
+                                              (4, 128, 70, 32, 64, 1), (3, 64, 35, 64, 128, 1), (4, 32, 18, 128, 256, 1), (128, 64, 35, 64, 128, 3)])
+def test_stride2_dgrad_planes_bit_identical_to_the_implicit_gemm(B, H, W, Cin, Cout, k):
+    """The first block of layers 2-4: 3x3 / stride 2 / pad 1 (conv1) and 1x1 / stride 2 (downsample), even and odd input sizes, Cin = 32 (half a
+    column tile).  Per parity class of output pixels only the taps that reach it are run (1 / 2 / 2 / 4 of nine): same non-zero products in the
+    same order as the masked nine-tap implicit GEMM => bit-identical, at a quarter of its matrix work."""
+    torch.manual_seed(5)
+    pad = 1 if k == 3 else 0
+    OH, OW = (H + 2 * pad - k) // 2 + 1, (W + 2 * pad - k) // 2 + 1
+    dy = torch.randn(B, OH, OW, Cout, device=DEV)
+    w = torch.randn(Cout, k, k, Cin, device=DEV) * 0.05
+    assert we.dgrad_planes_ok(w, 2, pad)
+    ref = we.conv_dgrad(dy, w, (B, H, W, Cin), 2, pad)
+    got = we.conv_dgrad_planes(ops.to_planes(dy), w, (B, H, W, Cin), 2, pad)
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    base = torch.randn(B, H, W, Cin, device=DEV)
+    ref1 = we.conv_dgrad(dy, w, (B, H, W, Cin), 2, pad, out=base.clone(), beta=1.0)
+    got1 = we.conv_dgrad_planes(ops.to_planes(dy), w, (B, H, W, Cin), 2, pad, out=base.clone(), beta=1.0)
+    assert torch.equal(got1, ref1)
+    x64 = torch.nn.functional.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), stride=2, padding=pad,
+                                               output_padding=(H - ((OH - 1) * 2 - 2 * pad + k), W - ((OW - 1) * 2 - 2 * pad + k))).permute(0, 2, 3, 1)
+    rel = float((got.double() - x64).abs().max() / x64.abs().max())
+    assert rel < 3e-5, rel
+
+
 def test_planes_are_only_used_in_the_split_mode_and_can_be_switched_off():
     w = torch.zeros(64, 3, 3, 64, device=DEV)
     assert we.dgrad_planes_ok(w, 1, 1)
-    assert not we.dgrad_planes_ok(w, 2, 1)                                     # stride-2 blocks keep the implicit GEMM
+    assert we.dgrad_planes_ok(w, 2, 1) and we.dgrad_planes_ok(torch.zeros(64, 1, 1, 32, device=DEV), 2, 0)   # stride-2 blocks: parity classes
     assert not we.dgrad_planes_ok(torch.zeros(32, 3, 3, 32, device=DEV), 1, 1)  # layer1 has its direct LDS-patch kernels
+    assert not we.dgrad_planes_ok(torch.zeros(32, 3, 3, 32, device=DEV), 1, 0)  # the taps' pad-0 convolutions keep the implicit GEMM
     try:
         lib.ha2g_gemm_set_mode(0)                                              # exact-fp32 mode: no split product anywhere
         assert not we.dgrad_planes_ok(w, 1, 1)
@@ -129,8 +155,8 @@ def test_train_step_is_bitwise_unchanged_by_the_plane_data_gradients_and_close_w
         finally:
             we.PLANES = old
     r0, g0 = run(0)
-    r1, g1 = run(1)
-    r3, g3 = run(3)
+    r1, g1 = run(9)                                  # stride-1 and stride-2 data gradients
+    r3, g3 = run(11)
     assert r0 == r1 == r3
     for a, b, c in zip(g0, g1, g3):
         assert torch.equal(a, b)
