@@ -121,6 +121,7 @@ def main():
     ap.add_argument('--expressive', action='store_true', help='config_expressive/hierarchy.yml: 6 levels, 126-d pose (BASELINE config 3)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--bf16', action='store_true', help='BASELINE config 5 style: every vectorisable GEMM / convolution with plain bf16 operands (fp32 accumulate, fp32 storage / master weights); reported with dtype "bf16", never the default')
+    ap.add_argument('--fp32-storage', action='store_true', help='with --bf16: keep the audio trunk\'s activations / activation gradients in fp32 (bf16 operands only, the round-2 form of the mode) -- the "before" leg of the storage A/B')
     ap.add_argument('--launch', choices=('auto', 'graph', 'eager'), default='auto', help='what `value` times: hipGraph replays of the captured step (auto: when N = 1) or eager launches (auto: when N > 1); the eager number is always reported next to it')
     ap.add_argument('--graph', action='store_true', help='same as --launch graph')
     ap.add_argument('--no-roofline', action='store_true', help='with --primary-only: skip the per-launch HIP-event pass as well (profiling runs)')
@@ -159,6 +160,9 @@ def main():
     from ha2g_amd._lib import lib as _lib0
     default_mode = int(os.environ.get('HA2G_GEMM_MODE', '22' if a.bf16 else '6'))
     _lib0.ha2g_gemm_set_mode(default_mode)
+    from ha2g_amd import wav_engine as _we
+    b16_storage = bool(a.bf16 and not a.fp32_storage) or os.environ.get('HA2G_B16') == '1'
+    _we.set_b16(b16_storage)                                  # BASELINE config 5: bf16 activation / activation-gradient storage in the audio trunk
     P = 126 if a.expressive else 27
     args = hierarchy_args(expressive=a.expressive)            # config[_expressive]/hierarchy.yml, dropout 0.3
     tr = HierarchyTrainer(args, Vocab(a.n_words), Vocab(a.n_spk), P, dev,
@@ -334,10 +338,25 @@ def main():
                         mean_us=round(mean_us, 1), traffic=None, note='algorithmic bytes per pass; tensors of layers 2-4 (<= 73 MB) are served by the 256 MB Infinity Cache')
         roof_bn = hbm('bn_bwd', 'col_partial_kernel<1> + pair_final + bn_bwd_apply_kernel (ha2g_bn_bwd[_planes]_f32: BatchNorm backward, 3 launches)')
         roof_bn_stats = hbm('bn_stats', 'col_partial_kernel<0> + bn_stats_final (ha2g_bn_stats_f32: BatchNorm forward statistics)')
+        if b16_storage:                              # bf16-storage mode: the same passes over 2-byte tensors, bf16 single-plane matrix kernels
+            roof_bn = hbm('bn_bwd_b16', 'col_partial_kernel<1,b16> + pair_final + bn_bwd_apply_kernel<0,b16> (ha2g_bn_bwd_b16: BatchNorm backward over bf16 tensors)')
+            roof_bn_stats = hbm('bn_stats_b16', 'col_partial_kernel<0,b16> + bn_stats_final (ha2g_bn_stats_b16)')
+
+            def mfma1(key, kernel):
+                if key not in kt:
+                    return None
+                n, mean_us, _, flops = kt[key]
+                ach = flops / (n * mean_us * 1e-6) / 1e12
+                return dict(kernel=kernel, bound='mfma', achieved=round(ach, 2), peak=2500.0, unit='TFLOP/s (dense bf16)', frac=round(ach / 2500.0, 4), launches=n,
+                            mean_us=round(mean_us, 1), traffic=None)
+            roof_conv = mfma1('conv2d_fwd_b16', 'pconv_kernel<.,.,.,.,1,1> forward gather (ha2g_conv2d_fwd_b16: trunk convolutions, bf16 in / bf16 out)')
+            roof_bwd_gemm = mfma1('conv_dgrad_b16', 'pconv_kernel<.,.,.,.,1,1> (ha2g_conv2d_dgrad_b16: trunk data gradients, bf16 in / bf16 out)')
+            roof_bwd_wgrad = mfma1('conv_wgrad_b16', 'pconv_wgrad_kernel<.,1> + wide reduce (ha2g_conv2d_wgrad_b16: 3x3 weight gradients of trunk layers 2-4, single planes)')
         out = dict(metric='pose-frames/sec (train step) for hierarchy.yml B=128 T=34', value=round(value, 1), unit='pose-frames/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling='weak',
                    vs_baseline=None,
-                   dtype=('bf16 (operands; fp32 accumulate, fp32 storage and master weights)' if a.bf16 else
+                   dtype=(('bf16 (matrix operands; audio-trunk activations and activation gradients stored as bf16; fp32 accumulate, fp32 statistics, fp32 master weights and optimizer)'
+                           if b16_storage else 'bf16 (operands; fp32 accumulate, fp32 storage and master weights)') if a.bf16 else
                           'f32 (storage, accumulation, forward products: fp32 MFMA; backward products: bf16x2 split = 16-bit operand mantissa, fp32 accumulate)'),
                    data='synthetic', launch=launch, launch_note=graph_note, rccl_world=rccl_world, eager=eager,
                    matrix_core=('bf16 operands (1 MFMA per product), fp32 accumulate, fp32 storage and master weights; GRU recurrences fp32' if a.bf16 else

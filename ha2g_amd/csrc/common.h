@@ -32,6 +32,7 @@ int conv3x3_c32_x3_launch(const float* x, const float* w, float* y, int N, int H
 int gemm_split_dgrad_enabled();      // gemm.hip: ha2g_gemm_set_mode bit 2 (and not the plain-bf16 mode)
 int conv3x3_c32_wgrad_blocks(int N, int H, int W);
 int conv3x3_c32_wgrad_launch(const float* x, const float* dy, float* part, int N, int H, int W, hipStream_t st);
+int conv3x3_c32_wgrad_b16_launch(const void* x, const void* dy, float* part, int N, int H, int W, hipStream_t st);
 // internal: plane-based 3x3 weight gradient, conv_planes.hip (the wide split-K reduce that follows lives in gemm.hip)
 int pconv_wgrad_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 long pconv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout);
@@ -52,6 +53,23 @@ __device__ __forceinline__ void split2_bf16(float a, float b, unsigned& hi, unsi
     ha2g_f32x2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, ha2g_bf16x2_t));
 }
+
+// element access of the activation tensors: fp32, or bf16 (bf16-storage mode, BASELINE config 5: the tensors live in HBM as bf16 -- round to
+// nearest even on every store -- while statistics, accumulators and the arithmetic of every pass stay fp32 / double exactly as in the fp32 mode)
+typedef unsigned short b16;
+__device__ __forceinline__ float4 ld4(const float* p, long i4) { return reinterpret_cast<const float4*>(p)[i4]; }
+__device__ __forceinline__ void st4(float* p, long i4, const float4& v) { reinterpret_cast<float4*>(p)[i4] = v; }
+__device__ __forceinline__ float4 ld4(const b16* p, long i4) {
+    const uint2 w = reinterpret_cast<const uint2*>(p)[i4];
+    return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(b16* p, long i4, const float4& v) {
+    uint2 h; unsigned l;
+    split2_bf16(v.x, v.y, h.x, l); split2_bf16(v.z, v.w, h.y, l);
+    reinterpret_cast<uint2*>(p)[i4] = h;
+}
+__device__ __forceinline__ float ld1(const float* p, long i) { return p[i]; }
+__device__ __forceinline__ float ld1(const b16* p, long i) { return __uint_as_float((unsigned)p[i] << 16); }
 
 // Gate non-linearities on the hardware exp2/rcp units (v_exp_f32 / v_rcp_f32, ~1 ulp each): absolute error
 // ~2e-7 on values in (0,1) / (-1,1), far inside the 1e-4 parity budget, and ~10x fewer VALU slots than libm's

@@ -350,8 +350,12 @@ __global__ __launch_bounds__(X3Geo<C>::THREADS, 1) void conv3x3_x3_kernel(const 
 // wave order through LDS and the workgroup writes ONE partial [32][9][32]; gemm.hip's wide split-K reduce adds the partials in double.
 constexpr int WG_TP = 128, WG_NT = 256;
 
-__global__ __launch_bounds__(WG_NT, 2) void conv3x3_c32_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// T = float: fp32 tensors, split here into hi / lo planes (three MFMAs per product); T = b16 (bf16-storage mode): the tensors ARE the hi plane,
+// one MFMA per product, the lo planes stay unused.
+template <typename T>
+__global__ __launch_bounds__(WG_NT, 2) void conv3x3_c32_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                      float* __restrict__ part, int N, int H, int W, int plane_elems) {
+    constexpr bool F32 = sizeof(T) == 4;
     extern __shared__ __attribute__((aligned(16))) unsigned short wpl[];        // [x hi][x lo][dy hi][dy lo]
     typedef short s16x4_t __attribute__((ext_vector_type(4)));
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
@@ -392,14 +396,18 @@ __global__ __launch_bounds__(WG_NT, 2) void conv3x3_c32_wgrad_kernel(const float
             long g = ((long)cur.img * HW + (long)(cur.r0 - 1 + pr) * W + (px - 1)) * CH + 4 * c4;
             while (pr < cur.rows) {
                 constexpr int NS = 4;
-                float4 v[NS]; int off[NS];
+                float4 v[NS]; uint2 hv[NS]; int off[NS];
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
                     off[i] = -1;
                     v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    hv[i] = make_uint2(0u, 0u);
                     if (pr < cur.rows) {
                         const int gy = cur.r0 - 1 + pr;
-                        if (gy >= 0 && gy < H && px >= 1 && px <= W) v[i] = *reinterpret_cast<const float4*>(x + g);
+                        if (gy >= 0 && gy < H && px >= 1 && px <= W) {
+                            if constexpr (F32) v[i] = *reinterpret_cast<const float4*>(x + g);
+                            else hv[i] = *reinterpret_cast<const uint2*>(x + g);
+                        }
                         off[i] = pp * CH + 4 * c4;
                     }
                     pp += 32; px += 32; g += 32L * CH;
@@ -408,27 +416,39 @@ __global__ __launch_bounds__(WG_NT, 2) void conv3x3_c32_wgrad_kernel(const float
 #pragma unroll
                 for (int i = 0; i < NS; ++i)
                     if (off[i] >= 0) {
-                        uint2 h, l;
-                        split2(v[i].x, v[i].y, h.x, l.x); split2(v[i].z, v[i].w, h.y, l.y);
-                        *reinterpret_cast<uint2*>(xh + off[i]) = h;
-                        *reinterpret_cast<uint2*>(xl + off[i]) = l;
+                        if constexpr (F32) {
+                            uint2 h, l;
+                            split2(v[i].x, v[i].y, h.x, l.x); split2(v[i].z, v[i].w, h.y, l.y);
+                            *reinterpret_cast<uint2*>(xh + off[i]) = h;
+                            *reinterpret_cast<uint2*>(xl + off[i]) = l;
+                        } else {
+                            *reinterpret_cast<uint2*>(xh + off[i]) = hv[i];
+                        }
                     }
             }
             // dy strip: 128 pixels x 8 quads = 4 slots per thread; rows past the image end are zeros (their products vanish)
-            float4 d[4];
+            float4 d[4]; uint2 dv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int pix = (tid >> 3) + 32 * i, p = cur.p0 + pix;
                 d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p < HW) d[i] = *reinterpret_cast<const float4*>(dy + ((long)cur.img * HW + p) * CH + 4 * c4);
+                dv[i] = make_uint2(0u, 0u);
+                if (p < HW) {
+                    if constexpr (F32) d[i] = *reinterpret_cast<const float4*>(dy + ((long)cur.img * HW + p) * CH + 4 * c4);
+                    else dv[i] = *reinterpret_cast<const uint2*>(dy + ((long)cur.img * HW + p) * CH + 4 * c4);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int o = ((tid >> 3) + 32 * i) * CH + 4 * c4;
-                uint2 h, l;
-                split2(d[i].x, d[i].y, h.x, l.x); split2(d[i].z, d[i].w, h.y, l.y);
-                *reinterpret_cast<uint2*>(dh + o) = h;
-                *reinterpret_cast<uint2*>(dl + o) = l;
+                if constexpr (F32) {
+                    uint2 h, l;
+                    split2(d[i].x, d[i].y, h.x, l.x); split2(d[i].z, d[i].w, h.y, l.y);
+                    *reinterpret_cast<uint2*>(dh + o) = h;
+                    *reinterpret_cast<uint2*>(dl + o) = l;
+                } else {
+                    *reinterpret_cast<uint2*>(dh + o) = dv[i];
+                }
             }
         }
         __syncthreads();
@@ -436,7 +456,8 @@ __global__ __launch_bounds__(WG_NT, 2) void conv3x3_c32_wgrad_kernel(const float
         for (int ch = 0; ch < 2; ++ch) {
             const int pb = 32 * wave + 16 * ch + krow;                           // this lane's two tile-local pixels: pb and pb + 4
             const bf16x8_t ah = frag(dh + pb * CH + moff, dh + (pb + 4) * CH + moff);
-            const bf16x8_t al = frag(dl + pb * CH + moff, dl + (pb + 4) * CH + moff);
+            bf16x8_t al = ah;
+            if constexpr (F32) al = frag(dl + pb * CH + moff, dl + (pb + 4) * CH + moff);
             int p0 = cur.p0 + pb, p1 = p0 + 4;
             if (p0 >= HW) p0 = HW - 1;                                           // clamp: stays inside the patch; dy is zero there
             if (p1 >= HW) p1 = HW - 1;
@@ -447,9 +468,11 @@ __global__ __launch_bounds__(WG_NT, 2) void conv3x3_c32_wgrad_kernel(const float
             for (int t = 0; t < 9; ++t) {
                 const int toff = ((t / 3) * PW + (t % 3)) * CH;
                 const bf16x8_t bh = frag(xh + r0 + toff, xh + r1 + toff);
-                const bf16x8_t bl = frag(xl + r0 + toff, xl + r1 + toff);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                if constexpr (F32) {
+                    const bf16x8_t bl = frag(xl + r0 + toff, xl + r1 + toff);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                }
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
             }
         }
@@ -534,20 +557,28 @@ int conv3x3_c32_wgrad_blocks(int N, int H, int W) {
     if (hipGetDevice(&dev) == hipSuccess) { int c = 0; if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) cus = c; }
     return (int)(tiles < 2L * cus ? tiles : 2L * cus);
 }
-int conv3x3_c32_wgrad_launch(const float* x, const float* dy, float* part, int N, int H, int W, hipStream_t st) {
+template <typename T>
+static int c32_wgrad_launch_t(const T* x, const T* dy, float* part, int N, int H, int W, hipStream_t st) {
     const int rows_max = (WG_TP + W - 2) / W + 1 + 2;
     const int plane_elems = rows_max * (W + 2) * CH;
     size_t lds = ((size_t)2 * plane_elems + 2 * WG_TP * CH) * sizeof(unsigned short);
     if (lds < 9 * CH * CH * sizeof(float)) lds = 9 * CH * CH * sizeof(float);
     if (lds > 78 * 1024 || (long)H * W < WG_TP || W + 2 <= 32) return -100;           // two workgroups per CU; 32 padded pixels between a thread's slots
-    static bool attr_set = false;
+    static bool attr_set = false;                                                    // one flag per instantiation
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 78 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_wgrad_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 78 * 1024) != hipSuccess)
             return ha2g_set_error(-2, "conv3x3_c32_wgrad: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
     const int grid = conv3x3_c32_wgrad_blocks(N, H, W);
-    hipLaunchKernelGGL(conv3x3_c32_wgrad_kernel, dim3(grid), dim3(WG_NT), lds, st, x, dy, part, N, H, W, plane_elems);
+    hipLaunchKernelGGL(conv3x3_c32_wgrad_kernel<T>, dim3(grid), dim3(WG_NT), lds, st, x, dy, part, N, H, W, plane_elems);
     HA2G_CHECK_LAUNCH("conv3x3_c32_wgrad");
     return grid;
+}
+int conv3x3_c32_wgrad_launch(const float* x, const float* dy, float* part, int N, int H, int W, hipStream_t st) {
+    return c32_wgrad_launch_t<float>(x, dy, part, N, H, W, st);
+}
+// bf16 tensors (bf16-storage mode): single planes, one MFMA per product
+int conv3x3_c32_wgrad_b16_launch(const void* x, const void* dy, float* part, int N, int H, int W, hipStream_t st) {
+    return c32_wgrad_launch_t<b16>((const b16*)x, (const b16*)dy, part, N, H, W, st);
 }

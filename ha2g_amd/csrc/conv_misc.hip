@@ -9,8 +9,9 @@ namespace {
 constexpr int SC = 32;   // stem output channels
 
 // x [N][H][W], w [SC][3][3], y [N][H][W][SC] = relu(conv + bias)
+template <typename T>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, float* __restrict__ y, int N, int H, int W) {
+                                                       const float* __restrict__ bias, T* __restrict__ y, int N, int H, int W) {
     __shared__ float ws[SC * 9 + SC];
     for (int i = threadIdx.x; i < SC * 9; i += 256) ws[i] = w[i];
     if (threadIdx.x < SC) ws[SC * 9 + threadIdx.x] = bias[threadIdx.x];
@@ -37,12 +38,13 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             for (int tp = 0; tp < 9; ++tp) s += xv[tp] * ws[co * 9 + tp];
             rp[k] = fmaxf(s, 0.f);
         }
-        reinterpret_cast<float4*>(y)[i] = r;
+        st4(y, i, r);
     }
 }
 
 // partial[blk][SC][10]: taps 0..8 = dW, 9 = dbias; dy [N*H*W][SC] is the gradient w.r.t. the pre-ReLU conv output
-__global__ __launch_bounds__(256) void stem_wgrad_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_partial_kernel(const float* __restrict__ x, const T* __restrict__ dy,
                                                                  float* __restrict__ part, int N, int H, int W) {
     __shared__ float red[8][SC][10];
     const int co = threadIdx.x & 31, pl = threadIdx.x >> 5;
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_partial_kernel(const float* __
     { const long p0 = pbeg + pl; ox = (int)(p0 % W); const long t = p0 / W; oy = (int)(t % H); n = t / H; }
 #pragma unroll 4
     for (long pix = pbeg + pl; pix < pend; pix += 8) {
-        const float d = dy[pix * SC + co];
+        const float d = ld1(dy, pix * SC + co);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -116,7 +118,7 @@ extern "C" {
 int ha2g_stem_conv_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, void* stream) {
     long total = (long)N * H * W * (SC / 4);
     int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, N, H, W);
+    hipLaunchKernelGGL(stem_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, N, H, W);
     HA2G_CHECK_LAUNCH("stem_conv_fwd");
     return 0;
 }
@@ -126,9 +128,26 @@ int ha2g_stem_conv_wgrad_f32(const float* x, const float* dy, float* dw, float* 
     hipStream_t st = (hipStream_t)stream;
     long npix = (long)N * H * W;
     int nb = (int)(npix / 2048 < 1 ? 1 : (npix / 2048 > 1024 ? 1024 : npix / 2048));
-    hipLaunchKernelGGL(stem_wgrad_partial_kernel, dim3(nb), dim3(256), 0, st, x, dy, ws, N, H, W);
+    hipLaunchKernelGGL(stem_wgrad_partial_kernel<float>, dim3(nb), dim3(256), 0, st, x, dy, ws, N, H, W);
     hipLaunchKernelGGL(stem_wgrad_final_kernel, dim3(5), dim3(64), 0, st, ws, nb, dw, db, beta);
     HA2G_CHECK_LAUNCH("stem_conv_wgrad");
+    return 0;
+}
+// bf16-storage mode: the stem's output / its gradient as bf16 tensors (the spectrogram and the 32x1x3x3 weight stay fp32)
+int ha2g_stem_conv_fwd_b16(const float* x, const float* w, const float* bias, void* y, int N, int H, int W, void* stream) {
+    long total = (long)N * H * W * (SC / 4);
+    int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(stem_fwd_kernel<b16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, bias, (b16*)y, N, H, W);
+    HA2G_CHECK_LAUNCH("stem_conv_fwd_b16");
+    return 0;
+}
+int ha2g_stem_conv_wgrad_b16(const float* x, const void* dy, float* dw, float* db, int N, int H, int W, float beta, float* ws, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    long npix = (long)N * H * W;
+    int nb = (int)(npix / 2048 < 1 ? 1 : (npix / 2048 > 1024 ? 1024 : npix / 2048));
+    hipLaunchKernelGGL(stem_wgrad_partial_kernel<b16>, dim3(nb), dim3(256), 0, st, x, (const b16*)dy, ws, N, H, W);
+    hipLaunchKernelGGL(stem_wgrad_final_kernel, dim3(5), dim3(64), 0, st, ws, nb, dw, db, beta);
+    HA2G_CHECK_LAUNCH("stem_conv_wgrad_b16");
     return 0;
 }
 int ha2g_conv2d_weight_ohwi_to_ihwo_f32(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream) {

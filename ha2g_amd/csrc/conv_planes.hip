@@ -65,7 +65,8 @@ struct PConvP {
     const unsigned short* b_hi; const unsigned short* b_lo;      // weight planes [N][K], K = KH*KW*GC
     float* C; long ldc; float beta;
     int N, K;
-    int GH, GW, GC, OH, OW, KH, KW, pad, stride;                 // gathered tensor (dy) / output pixel grid (dx)
+    int GH, GW, GC, OH, OW, KH, KW, pad, stride;                 // gathered tensor (dy; forward: x) / output pixel grid (dx; forward: y)
+    int fwd, relu;                                               // forward convolution instead of the data gradient; ReLU on the bf16 output
     int ncls;
     PClass cls[4];
     int dbg;                                                     // timing ablations (ha2g_conv_planes_debug): 1 = no DMA after tile 0, 2 = no MFMA
@@ -80,19 +81,22 @@ __device__ __forceinline__ void ptile_of_block(int& bx, int& by) {
     bx = seq / nby; by = seq - bx * nby;
 }
 
-// Data gradient of a convolution (stride 1 or 2) as an implicit GEMM over planes:  dx[m][n] (+)= sum_{tap, co} dy[src(m, tap)][co] * wt[n][tap][co];
-// blockIdx.z = parity class (PClass).
+// Implicit GEMM over planes, blockIdx.z = parity class (PClass):
+//   data gradient (p.fwd = 0):  dx[m][n] (+)= sum_{tap, co} dy[src(m, tap)][co] * wt[n][tap][co]      (stride 1 or 2)
+//   forward       (p.fwd = 1):  y[m][n]   =   sum_{tap, ci} x[pix(m) * stride - pad + tap][ci] * w[n][tap][ci]   (one class: every tap)
 // BM x BN output tile, 4 waves as WM x WN, wave tile (32 MI) x (32 NI), k tile = 32 channels of one filter tap, two LDS buffers,
 // one barrier per k tile: the next tile's DMA is issued before the current tile's MFMAs and waited for after them.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void pconv_dgrad_kernel(PConvP p) {
+// NP = 2: hi + lo planes, three MFMAs per product (fp32-class, the default backward).  NP = 1: the operands ARE bf16 tensors (bf16-storage mode of
+// BASELINE config 5, `--bf16`): one plane, one MFMA.  OUT = 0: fp32 output (beta-accumulate); OUT = 1: bf16 output (optional ReLU, beta-accumulate).
+template <int BM, int BN, int WM, int WN, int NP, int OUT>
+__global__ __launch_bounds__(256) void pconv_kernel(PConvP p) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);
     constexpr int RA = BM / 16, RB = BN / 16;                    // 16-row DMA pieces (1 KiB per wave instruction) per plane
     static_assert(RA % 4 == 0 && RB % 4 == 0, "every wave stages whole row blocks");
     constexpr int NA = RA / 4, NB = RB / 4;                      // row blocks per wave, per plane
     constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;          // bytes
-    constexpr int BUF = 2 * PLANE_A + 2 * PLANE_B;
+    constexpr int BUF = NP * (PLANE_A + PLANE_B);
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -117,13 +121,22 @@ __global__ __launch_bounds__(256) void pconv_dgrad_kernel(PConvP p) {
         a_mask[i] = 0u; a_base[i] = 0;
         if (m < pc.M) {
             const int oxc = m % pc.OWc; const int t = m / pc.OWc; const int oyc = t % pc.OHc; const int img = t / pc.OHc;
-            const int u = oyc * p.stride + pc.py + p.pad, v = oxc * p.stride + pc.px + p.pad;
-            const int sy0 = (u - pc.kh0) / p.stride, sx0 = (v - pc.kw0) / p.stride;          // source pixel of the class's first tap (exact divisions)
-            a_base[i] = (((long)img * p.GH + sy0) * p.GW + sx0) * p.GC + a_lc[i] * 8;
-            for (int ti = 0; ti < pc.ntaps; ++ti) {
-                const int kh = pc.tap[ti] / p.KW, kw = pc.tap[ti] - kh * p.KW;
-                const int sy = (u - kh) / p.stride, sx = (v - kw) / p.stride;
-                if (u - kh >= 0 && v - kw >= 0 && sy < p.GH && sx < p.GW) a_mask[i] |= 1u << ti;
+            if (p.fwd) {
+                const int sy0 = oyc * p.stride - p.pad, sx0 = oxc * p.stride - p.pad;          // source pixel of tap (0, 0)
+                a_base[i] = (((long)img * p.GH + sy0) * p.GW + sx0) * p.GC + a_lc[i] * 8;
+                for (int ti = 0; ti < pc.ntaps; ++ti) {
+                    const int kh = pc.tap[ti] / p.KW, kw = pc.tap[ti] - kh * p.KW;
+                    if (sy0 + kh >= 0 && sy0 + kh < p.GH && sx0 + kw >= 0 && sx0 + kw < p.GW) a_mask[i] |= 1u << ti;
+                }
+            } else {
+                const int u = oyc * p.stride + pc.py + p.pad, v = oxc * p.stride + pc.px + p.pad;
+                const int sy0 = (u - pc.kh0) / p.stride, sx0 = (v - pc.kw0) / p.stride;      // source pixel of the class's first tap (exact divisions)
+                a_base[i] = (((long)img * p.GH + sy0) * p.GW + sx0) * p.GC + a_lc[i] * 8;
+                for (int ti = 0; ti < pc.ntaps; ++ti) {
+                    const int kh = pc.tap[ti] / p.KW, kw = pc.tap[ti] - kh * p.KW;
+                    const int sy = (u - kh) / p.stride, sx = (v - kw) / p.stride;
+                    if (u - kh >= 0 && v - kw >= 0 && sy < p.GH && sx < p.GW) a_mask[i] |= 1u << ti;
+                }
             }
         }
     }
@@ -146,19 +159,16 @@ __global__ __launch_bounds__(256) void pconv_dgrad_kernel(PConvP p) {
         for (int i = 0; i < NA; ++i) {
             const bool on = (a_mask[i] & bit) != 0u;
             const long o = a_base[i] + koff;
-            const unsigned short* gh = on ? p.a_hi + o : zero;
-            const unsigned short* gl = on ? p.a_lo + o : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)gh, (lds_ptr_t)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)gl, (lds_ptr_t)(dst + PLANE_A + (wave + 4 * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.a_hi + o : zero), (lds_ptr_t)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
+            if (NP == 2) __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.a_lo + o : zero), (lds_ptr_t)(dst + PLANE_A + (wave + 4 * i) * 1024), 16, 0, 0);
         }
         const long kb = (long)pc.tap[ti] * p.GC + c0;             // k index of the weight planes: (tap, channel)
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const bool on = b_off[i] >= 0;
-            const unsigned short* gh = on ? p.b_hi + b_off[i] + kb : zero;
-            const unsigned short* gl = on ? p.b_lo + b_off[i] + kb : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)gh, (lds_ptr_t)(dst + 2 * PLANE_A + (wave + 4 * i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)gl, (lds_ptr_t)(dst + 2 * PLANE_A + PLANE_B + (wave + 4 * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.b_hi + b_off[i] + kb : zero), (lds_ptr_t)(dst + NP * PLANE_A + (wave + 4 * i) * 1024), 16, 0, 0);
+            if (NP == 2) __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.b_lo + b_off[i] + kb : zero),
+                                                          (lds_ptr_t)(dst + NP * PLANE_A + PLANE_B + (wave + 4 * i) * 1024), 16, 0, 0);
         }
     };
 
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(256) void pconv_dgrad_kernel(PConvP p) {
         const int cur = kt & 1;
         if (kt + 1 < nk && !(p.dbg & 1)) stage(kt + 1, cur ^ 1);
         const unsigned char* ab = smem + cur * BUF + a_row_off;
-        const unsigned char* bb = smem + cur * BUF + 2 * PLANE_A + b_row_off;
+        const unsigned char* bb = smem + cur * BUF + NP * PLANE_A + b_row_off;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
             const int po = ((2 * kc + lhi) ^ sw) * 16;
@@ -188,26 +198,28 @@ __global__ __launch_bounds__(256) void pconv_dgrad_kernel(PConvP p) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 ah[i] = *reinterpret_cast<const bf16x8_t*>(ab + i * 2048 + po);
-                al[i] = *reinterpret_cast<const bf16x8_t*>(ab + PLANE_A + i * 2048 + po);
+                if (NP == 2) al[i] = *reinterpret_cast<const bf16x8_t*>(ab + PLANE_A + i * 2048 + po);
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 bh[j] = *reinterpret_cast<const bf16x8_t*>(bb + j * 2048 + po);
-                bl[j] = *reinterpret_cast<const bf16x8_t*>(bb + PLANE_B + j * 2048 + po);
+                if (NP == 2) bl[j] = *reinterpret_cast<const bf16x8_t*>(bb + PLANE_B + j * 2048 + po);
             }
             if (p.dbg & 2) {                                     // ablation: keep the fragment reads alive, skip the matrix pipe
 #pragma unroll
-                for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(ah[i]), "v"(al[i]));
+                for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(ah[i]));
 #pragma unroll
-                for (int j = 0; j < NI; ++j) asm volatile("" :: "v"(bh[j]), "v"(bl[j]));
+                for (int j = 0; j < NI; ++j) asm volatile("" :: "v"(bh[j]));
                 continue;
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    if (NP == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
@@ -223,20 +235,39 @@ __global__ __launch_bounds__(256) void pconv_dgrad_kernel(PConvP p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int col = n0 + wn * (32 * NI) + j * 32 + l31;
-            if (col >= p.N) continue;
+            if (OUT == 0 && col >= p.N) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (row >= pc.M) continue;
-                long orow = row;                                             // stride 1: class-linear = output-linear
-                if (p.stride != 1) {
+                const bool rok = row < pc.M;
+                if (OUT == 0 && !rok) continue;
+                long orow = row;                                             // stride 1 / forward: class-linear = output-linear
+                if (!p.fwd && p.stride != 1 && rok) {
                     const int oxc = row % pc.OWc; const int t = row / pc.OWc; const int oyc = t % pc.OHc; const int img = t / pc.OHc;
                     orow = ((long)img * p.OH + oyc * p.stride + pc.py) * p.OW + oxc * p.stride + pc.px;
                 }
-                float* dst = p.C + orow * p.ldc + col;
-                float v = 1.0f * acc[i][j][r] + 0.f;                  // alpha = 1, no bias: the epilogue arithmetic of gemm_x3_kernel
-                if (p.beta != 0.f) v += p.beta * *dst;
-                *dst = v;
+                if (OUT == 0) {
+                    float* dst = p.C + orow * p.ldc + col;
+                    float v = 1.0f * acc[i][j][r] + 0.f;              // alpha = 1, no bias: the epilogue arithmetic of gemm_x3_kernel
+                    if (p.beta != 0.f) v += p.beta * *dst;
+                    *dst = v;
+                } else {
+                    // bf16 output: two adjacent columns (adjacent lanes) per 4-byte store
+                    unsigned short* dstb = reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + (col & ~1);
+                    float v = acc[i][j][r];
+                    const float vn = __shfl_down(v, 1, 64);
+                    if (rok && !(l31 & 1) && col < p.N) {                   // N is even: col and col + 1 are both valid
+                        float v0 = v, v1 = vn;
+                        if (p.beta != 0.f) {
+                            const unsigned old = *reinterpret_cast<const unsigned*>(dstb);
+                            v0 += p.beta * __uint_as_float(old << 16); v1 += p.beta * __uint_as_float(old & 0xffff0000u);
+                        }
+                        if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                        unsigned h, l;
+                        split2_bf16(v0, v1, h, l);
+                        *reinterpret_cast<unsigned*>(dstb) = h;
+                    }
+                }
             }
         }
 }
@@ -277,7 +308,8 @@ constexpr int X_SUB = PW_ROWS * 64;                            // bytes of one x
 // time parked at the tile boundary with nothing else to issue from.)  Every wave issues a FIXED number of DMA instructions per tile (one
 // 16-row piece of the patch in its four sub-planes, two pieces of the dy strip): with a data-dependent count hipcc put s_waitcnt vmcnt(0) in
 // front of every fragment read, i.e. waited for the NEXT tile's DMA before computing on this one.
-template <int WT>
+// NP = 2: hi + lo planes (three MFMAs per product); NP = 1: x and dy ARE bf16 tensors (bf16-storage mode): one plane, one MFMA.
+template <int WT, int NP>
 __global__ __launch_bounds__(768) void pconv_wgrad_kernel(PWgradP p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char wsm[];
     typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -285,15 +317,15 @@ __global__ __launch_bounds__(768) void pconv_wgrad_kernel(PWgradP p) {
     typedef __attribute__((address_space(3))) s16x4_t* lds4_t;
     constexpr int NKC = WT / 16;
     constexpr int DY_SUB = ((WT + 15) / 16) * 1024;            // bytes of one dy sub-plane (WT rows of 64 bytes, in 16-row DMA pieces)
-    constexpr int DY_ALL = 4 * DY_SUB, BUF = DY_ALL + 4 * X_SUB;
-    constexpr int NDY = 4 * (WT / 16);                         // dy DMA pieces per tile: 16 (WT = 64) or 12 (WT = 48)
+    constexpr int DY_ALL = 2 * NP * DY_SUB, BUF = DY_ALL + 2 * NP * X_SUB;
+    constexpr int NDY = 2 * NP * (WT / 16);                    // dy DMA pieces per tile (plane, half, 16 pixels): 16 / 12 (NP = 2), 8 / 6 (NP = 1)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave >> 1) & 1, wn = wave & 1, kh = wave >> 2;                // corner, tap row
     const int l31 = lane & 31, lhi = lane >> 5, g4 = lane >> 4, q16 = lane & 15;
     const int krow = 8 * (g4 >> 1) + (q16 >> 2), moff = 16 * (g4 & 1) + 4 * (q16 & 3);
     const int HW = p.H * p.W, PW = p.W + 2;
-    const int ncit = p.Cin >> 6;
+    const int ncit = (p.Cin + 63) >> 6;
     const int co0 = ((int)blockIdx.y / ncit) << 6, ci0 = ((int)blockIdx.y % ncit) << 6;
     const int tiles = p.N * p.tpi;
     const int t_beg = (int)blockIdx.x * p.tiles_per_chunk;
@@ -319,10 +351,10 @@ __global__ __launch_bounds__(768) void pconv_wgrad_kernel(PWgradP p) {
         // dy strip: NDY pieces = (plane, half, 16 pixels); wave w stages pieces w and w + 12 (WT = 64; the waves past the end repeat their first)
 #pragma unroll
         for (int i = 0; i < (NDY + 11) / 12; ++i) {
-            const int q = (wave + 12 * i) < NDY ? wave + 12 * i : wave;           // = sub * (WT / 16) + piece, sub = plane * 2 + half
+            const int q = (wave + 12 * i) < NDY ? wave + 12 * i : wave % NDY;     // = sub * (WT / 16) + piece, sub = plane * 2 + half
             const int sub = q / (WT / 16), piece = q - sub * (WT / 16);
             const int pix = p0 + piece * 16 + drow;
-            const bool on = pix < HW;
+            const bool on = pix < HW && co0 + (sub & 1) * 32 < p.Cout;           // Cout = 32: the upper half is zeros
             const long o = ((long)img * HW + pix) * p.Cout + co0 + (sub & 1) * 32 + dpc * 8;
             const unsigned short* g = on ? ((sub >> 1) ? p.dy_lo : p.dy_hi) + o : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lds_ptr_t)(dst + sub * DY_SUB + piece * 1024), 16, 0, 0);
@@ -331,12 +363,15 @@ __global__ __launch_bounds__(768) void pconv_wgrad_kernel(PWgradP p) {
         {
             const int gy = r0 - 1 + ppr;
             const bool on = ppr < rows && gy >= 0 && gy < p.H && ppx >= 1 && ppx <= p.W;
+            const bool on1 = on && ci0 + 32 < p.Cin;                               // Cin = 32: the upper half is zeros
             const long o = (((long)img * p.H + gy) * p.W + (ppx - 1)) * p.Cin + ci0 + dpc * 8;
             unsigned char* d = dst + DY_ALL + wave * 1024;
             __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.x_hi + o : zero), (lds_ptr_t)(d), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.x_hi + o + 32 : zero), (lds_ptr_t)(d + X_SUB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.x_lo + o : zero), (lds_ptr_t)(d + 2 * X_SUB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.x_lo + o + 32 : zero), (lds_ptr_t)(d + 3 * X_SUB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(on1 ? p.x_hi + o + 32 : zero), (lds_ptr_t)(d + X_SUB), 16, 0, 0);
+            if (NP == 2) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.x_lo + o : zero), (lds_ptr_t)(d + 2 * X_SUB), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(on1 ? p.x_lo + o + 32 : zero), (lds_ptr_t)(d + 3 * X_SUB), 16, 0, 0);
+            }
         }
     };
 
@@ -357,7 +392,7 @@ __global__ __launch_bounds__(768) void pconv_wgrad_kernel(PWgradP p) {
         const unsigned char* a0 = base + a_lane + k0 * 64;
         const unsigned char* a1 = base + a_lane + k1 * 64;
         f.ah = frag(a0, a1);
-        f.al = frag(a0 + 2 * DY_SUB, a1 + 2 * DY_SUB);
+        if (NP == 2) f.al = frag(a0 + 2 * DY_SUB, a1 + 2 * DY_SUB);
         int q0 = p0 + k0, q1 = p0 + k1;
         if (q0 >= HW) q0 = HW - 1;                                                 // clamp: stays inside the patch; dy is zero there
         if (q1 >= HW) q1 = HW - 1;
@@ -367,16 +402,18 @@ __global__ __launch_bounds__(768) void pconv_wgrad_kernel(PWgradP p) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             f.bh[t] = frag(b0 + t * 64, b1 + t * 64);
-            f.bl[t] = frag(b0 + t * 64 + 2 * X_SUB, b1 + t * 64 + 2 * X_SUB);
+            if (NP == 2) f.bl[t] = frag(b0 + t * 64 + 2 * X_SUB, b1 + t * 64 + 2 * X_SUB);
         }
     };
     // three passes over the taps (lo*hi, hi*lo, hi*hi): consecutive MFMAs go to DIFFERENT accumulators; each accumulator still sees its
     // products in the same order
     auto mfma_set = [&](const FragSet& f) {
+        if (NP == 2) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.bh[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.bh[t], acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bl[t], acc[t], 0, 0, 0);
+            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bl[t], acc[t], 0, 0, 0);
+        }
 #pragma unroll
         for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bh[t], acc[t], 0, 0, 0);
     };
@@ -406,7 +443,7 @@ __global__ __launch_bounds__(768) void pconv_wgrad_kernel(PWgradP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            out[((long)co * 9 + kh * 3 + t) * p.Cin + ci0 + wn * 32 + l31] = acc[t][r];
+            if (co < p.Cout && ci0 + wn * 32 + l31 < p.Cin) out[((long)co * 9 + kh * 3 + t) * p.Cin + ci0 + wn * 32 + l31] = acc[t][r];
         }
 }
 
@@ -419,20 +456,22 @@ static int g_planes = 1;         // ha2g_conv_planes_enable: 0 = callers keep th
 // -100 when the geometry is not served (caller keeps the implicit GEMM), < 0 on error.
 static int pwgrad_tile(int HW) { return (HW % 64 != 0 && HW % 48 == 0) ? 48 : 64; }
 int pconv_wgrad_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
-    if (!(g_planes && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0 && (long)H * W >= 16)) return 0;
+    if (!(g_planes && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % 32 == 0 && Cout % 32 == 0 && (long)H * W >= 16)) return 0;
     const int wt = pwgrad_tile(H * W);
     return ((wt + W - 2) / W + 1 + 2) * (W + 2) <= PW_ROWS;
 }
 long pconv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
     const int wt = pwgrad_tile(H * W);
     const long tiles = (long)N * (((long)H * W + wt - 1) / wt);
-    const int npairs = (Cin / 64) * (Cout / 64);
+    const int npairs = ((Cin + 63) / 64) * ((Cout + 63) / 64);
     long nchunks = 256 / npairs < 1 ? 1 : 256 / npairs;
     if (nchunks > tiles) nchunks = tiles;
     return nchunks * (long)Cout * 9 * Cin * 4;
 }
+// x_lo == dy_lo == nullptr: bf16-storage mode (one plane)
 int pconv_wgrad_launch(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* part, int N, int H, int W, int Cin, int Cout,
                        hipStream_t st) {
+    const int np = (x_lo == nullptr && dy_lo == nullptr) ? 1 : 2;
     PWgradP p{};
     p.x_hi = (const unsigned short*)x_hi; p.x_lo = (const unsigned short*)x_lo;
     p.dy_hi = (const unsigned short*)dy_hi; p.dy_lo = (const unsigned short*)dy_lo;
@@ -440,7 +479,7 @@ int pconv_wgrad_launch(const void* x_hi, const void* x_lo, const void* dy_hi, co
     const int HW = H * W, wt = pwgrad_tile(HW);
     p.tpi = (HW + wt - 1) / wt;
     const long tiles = (long)N * p.tpi;
-    const int npairs = (Cin / 64) * (Cout / 64);
+    const int npairs = ((Cin + 63) / 64) * ((Cout + 63) / 64);
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) { int c = 0; if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) cus = c; }
     if (cus > 256) cus = 256;                                   // the workspace query assumes at most 256 chunks x pairs
@@ -451,19 +490,65 @@ int pconv_wgrad_launch(const void* x_hi, const void* x_lo, const void* dy_hi, co
     const int rows_max = (wt + W - 2) / W + 1 + 2;
     p.patch_rows = rows_max * (W + 2);
     if (p.patch_rows > PW_ROWS) return -100;                     // the patch does not fit the reserved sub-planes
-    const size_t lds = (size_t)2 * (4 * (size_t)((wt + 15) / 16) * 1024 + 4 * (size_t)X_SUB);
+    const size_t lds = (size_t)2 * (2 * np * (size_t)((wt + 15) / 16) * 1024 + 2 * np * (size_t)X_SUB);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_wgrad_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_wgrad_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_wgrad_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_wgrad_kernel<48, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_wgrad_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_wgrad_kernel<48, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
             return ha2g_set_error(-2, "pconv_wgrad: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
-    if (wt == 64) hipLaunchKernelGGL(pconv_wgrad_kernel<64>, dim3((unsigned)nchunks, npairs), dim3(768), lds, st, p);
-    else hipLaunchKernelGGL(pconv_wgrad_kernel<48>, dim3((unsigned)nchunks, npairs), dim3(768), lds, st, p);
+    const dim3 grid((unsigned)nchunks, npairs);
+    if (np == 2) {
+        if (wt == 64) hipLaunchKernelGGL((pconv_wgrad_kernel<64, 2>), grid, dim3(768), lds, st, p);
+        else hipLaunchKernelGGL((pconv_wgrad_kernel<48, 2>), grid, dim3(768), lds, st, p);
+    } else {
+        if (wt == 64) hipLaunchKernelGGL((pconv_wgrad_kernel<64, 1>), grid, dim3(768), lds, st, p);
+        else hipLaunchKernelGGL((pconv_wgrad_kernel<48, 1>), grid, dim3(768), lds, st, p);
+    }
     HA2G_CHECK_LAUNCH("pconv_wgrad");
     return (int)nchunks;
 }
+
+// parity classes of a data gradient (stride 1: one class with every tap)
+static int dgrad_classes(PConvP& p, int N, int H, int W, int KH, int KW, int stride, int pad, int OWd) {
+    int maxM = 0;
+    p.ncls = 0;
+    for (int py = 0; py < stride; ++py)
+        for (int px = 0; px < stride; ++px) {
+            PClass c{};
+            c.py = py; c.px = px;
+            c.OHc = (H - py + stride - 1) / stride; c.OWc = (W - px + stride - 1) / stride;
+            c.M = N * c.OHc * c.OWc;
+            c.ntaps = 0; c.kh0 = -1; c.kw0 = -1;
+            for (int kh = 0; kh < KH; ++kh)
+                for (int kw = 0; kw < KW; ++kw) {
+                    if ((py + pad - kh) % stride != 0 || (px + pad - kw) % stride != 0) continue;       // operands >= -2: C's % keeps the sign, 0 stays 0
+                    if (c.kh0 < 0) { c.kh0 = kh; c.kw0 = kw; }
+                    c.tap[c.ntaps] = kh * KW + kw;
+                    c.doff[c.ntaps] = -(((kh - c.kh0) / stride) * OWd + (kw - c.kw0) / stride);
+                    ++c.ntaps;
+                }
+            if (c.ntaps == 0 || c.M == 0) continue;
+            if (c.M > maxM) maxM = c.M;
+            p.cls[p.ncls++] = c;
+        }
+    return maxM;
+}
+// tile choice by the output width: 128 x 128 when N is a multiple of 128, else 256 x 64 (N = 32: the upper half of the column tile idles)
+template <int NP, int OUT>
+static void pconv_dispatch(const PConvP& p, int maxM, hipStream_t st) {
+    if (p.N % 128 == 0) {
+        dim3 grid(ceil_div(maxM, 128), p.N / 128, p.ncls);
+        hipLaunchKernelGGL((pconv_kernel<128, 128, 2, 2, NP, OUT>), grid, dim3(256), 0, st, p);
+    } else {
+        dim3 grid(ceil_div(maxM, 256), ceil_div(p.N, 64), p.ncls);
+        hipLaunchKernelGGL((pconv_kernel<256, 64, 4, 1, NP, OUT>), grid, dim3(256), 0, st, p);
+    }
+}
+
 
 extern "C" {
 
@@ -516,36 +601,57 @@ int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const voi
     p.GH = OHd; p.GW = OWd; p.GC = Cout; p.OH = H; p.OW = W; p.KH = KH; p.KW = KW; p.pad = pad; p.stride = stride;
     p.dbg = g_pdbg;
     if ((long)N * H * W == 0) return 0;
-    int maxM = 0;
-    p.ncls = 0;
-    for (int py = 0; py < stride; ++py)
-        for (int px = 0; px < stride; ++px) {
-            PClass c{};
-            c.py = py; c.px = px;
-            c.OHc = (H - py + stride - 1) / stride; c.OWc = (W - px + stride - 1) / stride;
-            c.M = N * c.OHc * c.OWc;
-            c.ntaps = 0; c.kh0 = -1; c.kw0 = -1;
-            for (int kh = 0; kh < KH; ++kh)
-                for (int kw = 0; kw < KW; ++kw) {
-                    if ((py + pad - kh) % stride != 0 || (px + pad - kw) % stride != 0) continue;       // operands >= -2: C's % keeps the sign, 0 stays 0
-                    if (c.kh0 < 0) { c.kh0 = kh; c.kw0 = kw; }
-                    c.tap[c.ntaps] = kh * KW + kw;
-                    c.doff[c.ntaps] = -(((kh - c.kh0) / stride) * OWd + (kw - c.kw0) / stride);
-                    ++c.ntaps;
-                }
-            if (c.ntaps == 0 || c.M == 0) continue;
-            if (c.M > maxM) maxM = c.M;
-            p.cls[p.ncls++] = c;
-        }
-    hipStream_t st = (hipStream_t)stream;
-    if (Cin % 128 == 0) {
-        dim3 grid(ceil_div(maxM, 128), Cin / 128, p.ncls);
-        hipLaunchKernelGGL((pconv_dgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, p);
-    } else {                                                        // 64 columns per tile (Cin = 32: the upper half idles)
-        dim3 grid(ceil_div(maxM, 256), ceil_div(Cin, 64), p.ncls);
-        hipLaunchKernelGGL((pconv_dgrad_kernel<256, 64, 4, 1>), grid, dim3(256), 0, st, p);
-    }
+    const int maxM = dgrad_classes(p, N, H, W, KH, KW, stride, pad, OWd);
+    pconv_dispatch<2, 0>(p, maxM, (hipStream_t)stream);
     HA2G_CHECK_LAUNCH("conv2d_dgrad_planes");
+    return 0;
+}
+
+// ---- bf16-storage mode (BASELINE config 5, `bench.py --bf16`): activations and the dY stream of the audio tower live in HBM as bf16; the
+//      convolutions read them as they are (one plane, one MFMA per product, fp32 accumulate) and write bf16.  3x3 / pad 1, 1x1 / pad 0,
+//      stride 1 or 2, channel counts multiples of 32.  Replaces nn.Conv2d and its autograd backward (model/ResNetBlocks.py:24-29,
+//      model/ResNetSE34V2.py:96-116) in that mode. ----
+int ha2g_conv2d_b16_supported(int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    const bool geom = (KH == 3 && KW == 3 && pad == 1) || (KH == 1 && KW == 1 && pad == 0);
+    return geom && (stride == 1 || stride == 2) && Cin % 32 == 0 && Cout % 32 == 0;
+}
+// y [N,OH,OW,Cout] (bf16) = [relu](conv(x [N,H,W,Cin] (bf16), w [Cout][KH][KW][Cin] (bf16)))
+int ha2g_conv2d_fwd_b16(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
+                        void* stream) {
+    HA2G_REQUIRE(ha2g_conv2d_b16_supported(Cin, Cout, KH, KW, stride, pad), "conv2d_fwd_b16: unsupported geometry");
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    PConvP p{};
+    p.a_hi = (const unsigned short*)x; p.b_hi = (const unsigned short*)w;
+    p.C = (float*)y; p.ldc = Cout; p.beta = 0.f; p.relu = relu; p.fwd = 1;
+    p.N = Cout; p.K = KH * KW * Cin;
+    p.GH = H; p.GW = W; p.GC = Cin; p.OH = OH; p.OW = OW; p.KH = KH; p.KW = KW; p.pad = pad; p.stride = stride;
+    p.dbg = g_pdbg;
+    PClass c{};
+    c.OHc = OH; c.OWc = OW; c.M = N * OH * OW;
+    for (int kh = 0; kh < KH; ++kh)
+        for (int kw = 0; kw < KW; ++kw) { c.tap[c.ntaps] = kh * KW + kw; c.doff[c.ntaps] = kh * W + kw; ++c.ntaps; }
+    p.ncls = 1; p.cls[0] = c;
+    if (c.M == 0) return 0;
+    pconv_dispatch<1, 1>(p, c.M, (hipStream_t)stream);
+    HA2G_CHECK_LAUNCH("conv2d_fwd_b16");
+    return 0;
+}
+// dx [N,H,W,Cin] (bf16) = beta * dx + conv_transpose(dy [N,OH,OW,Cout] (bf16), wt [Cin][KH][KW][Cout] (bf16)); stride 2 with a 1x1 kernel and
+// beta = 0: zero-fill dx first (three of four pixels are not reached)
+int ha2g_conv2d_dgrad_b16(const void* dy, const void* wt, void* dx, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                          float beta, void* stream) {
+    HA2G_REQUIRE(ha2g_conv2d_b16_supported(Cin, Cout, KH, KW, stride, pad), "conv2d_dgrad_b16: unsupported geometry");
+    const int OHd = (H + 2 * pad - KH) / stride + 1, OWd = (W + 2 * pad - KW) / stride + 1;
+    PConvP p{};
+    p.a_hi = (const unsigned short*)dy; p.b_hi = (const unsigned short*)wt;
+    p.C = (float*)dx; p.ldc = Cin; p.beta = beta;
+    p.N = Cin; p.K = KH * KW * Cout;
+    p.GH = OHd; p.GW = OWd; p.GC = Cout; p.OH = H; p.OW = W; p.KH = KH; p.KW = KW; p.pad = pad; p.stride = stride;
+    p.dbg = g_pdbg;
+    if ((long)N * H * W == 0) return 0;
+    const int maxM = dgrad_classes(p, N, H, W, KH, KW, stride, pad, OWd);
+    pconv_dispatch<1, 1>(p, maxM, (hipStream_t)stream);
+    HA2G_CHECK_LAUNCH("conv2d_dgrad_b16");
     return 0;
 }
 

@@ -1264,7 +1264,50 @@ int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int
 // Plane-based weight gradient (conv_planes.hip): x and dy arrive as bf16 hi / lo planes; one DMA-staged launch writes `chunks` dW-shaped
 // partial slabs into ws, the wide reduce adds them in double.  3x3 / stride 1 / pad 1, channels multiples of 64.
 int ha2g_conv2d_wgrad_planes_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
-    return g_split_wgrad && !g_bf16 && pconv_wgrad_supported(H, W, Cin, Cout, KH, KW, stride, pad);
+    return g_split_wgrad && !g_bf16 && Cin % 64 == 0 && Cout % 64 == 0 && pconv_wgrad_supported(H, W, Cin, Cout, KH, KW, stride, pad);
+}
+// bf16-storage mode: dw (fp32) = beta*dw + dy^T im2col(x) with x and dy bf16 tensors (one plane, one MFMA per product); 3x3 / stride 1 / pad 1,
+// channel counts multiples of 32
+static bool c32_wgrad_b16_ok(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    // conv3x3_c32_wgrad_kernel<b16>: 32 -> 32 channels, 128-pixel tiles (layer 1's 128 x 70 images do not fit the plane kernel's LDS patch)
+    if (!(Cin == 32 && Cout == 32 && KH == 3 && KW == 3 && stride == 1 && pad == 1)) return false;
+    const int rows_max = (128 + W - 2) / W + 1 + 2;
+    const long lds = ((long)2 * rows_max * (W + 2) * 32 + 2 * 128 * 32) * 2;
+    return lds <= 78 * 1024 && (long)H * W >= 128 && W + 2 > 32;
+}
+int ha2g_conv2d_wgrad_b16_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    return pconv_wgrad_supported(H, W, Cin, Cout, KH, KW, stride, pad) || c32_wgrad_b16_ok(H, W, Cin, Cout, KH, KW, stride, pad);
+}
+long ha2g_conv2d_wgrad_b16_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+    if (pconv_wgrad_supported(H, W, Cin, Cout, 3, 3, 1, 1)) return pconv_wgrad_workspace_bytes(N, H, W, Cin, Cout);
+    return (long)conv3x3_c32_wgrad_blocks(N, H, W) * Cout * 9 * Cin * 4;
+}
+int ha2g_conv2d_wgrad_b16(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                          float beta, float* ws, long ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!pconv_wgrad_supported(H, W, Cin, Cout, KH, KW, stride, pad)) {
+        HA2G_REQUIRE(c32_wgrad_b16_ok(H, W, Cin, Cout, KH, KW, stride, pad), "conv2d_wgrad_b16: unsupported geometry");
+        const long MN = (long)Cout * 9 * Cin;
+        HA2G_REQUIRE(ws && ws_bytes >= (long)conv3x3_c32_wgrad_blocks(N, H, W) * MN * 4, "conv2d_wgrad_b16: workspace too small");
+        const int nblk = conv3x3_c32_wgrad_b16_launch(x, dy, ws, N, H, W, st);
+        if (nblk < 0) return nblk == -100 ? ha2g_set_error(-1, "conv2d_wgrad_b16: the patch does not fit the LDS (W = %d)", W) : nblk;
+        ReduceOut ro{};
+        ro.groups = 1; ro.C[0] = dw;
+        hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(ceil_div(MN, 64), 1), dim3(256), 0, st, ws, nblk, MN, 9 * Cin, ro, (long)9 * Cin, 1.f, beta, 0, 0.f, Cout);
+        HA2G_CHECK_LAUNCH("conv2d_wgrad_b16 (c32) reduce");
+        return 0;
+    }
+    HA2G_REQUIRE(ws && ws_bytes >= pconv_wgrad_workspace_bytes(N, H, W, Cin, Cout), "conv2d_wgrad_b16: workspace too small");
+    const int chunks = pconv_wgrad_launch(x, nullptr, dy, nullptr, ws, N, H, W, Cin, Cout, st);
+    if (chunks == -100) return ha2g_set_error(-1, "conv2d_wgrad_b16: the patch does not fit the LDS (W = %d)", W);
+    if (chunks < 0) return chunks;
+    const long MN = (long)Cout * KH * KW * Cin;
+    ReduceOut ro{};
+    ro.groups = 1; ro.C[0] = dw;
+    hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(ceil_div(MN, 64), 1), dim3(256), 0, st, ws, chunks, MN, KH * KW * Cin, ro, (long)KH * KW * Cin, 1.f,
+                       beta, 0, 0.f, Cout);
+    HA2G_CHECK_LAUNCH("conv2d_wgrad_b16 reduce");
+    return 0;
 }
 long ha2g_conv2d_wgrad_planes_workspace_bytes(int N, int H, int W, int Cin, int Cout) { return pconv_wgrad_workspace_bytes(N, H, W, Cin, Cout); }
 int ha2g_conv2d_wgrad_planes_f32(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, int N, int H, int W, int Cin,

@@ -10,82 +10,127 @@ namespace {
 
 constexpr int NB_MAX = 1024;   // max row-chunk blocks of a partial reduction
 
-// thread layout shared by the column reductions: C4 = C/4 float4 lanes per row, 256 % C4 == 0
+// element access of the activation tensors (fp32 | bf16-storage mode): ld4 / st4 / ld1 of common.h
+
+// A thread moves 16 bytes per access: V = 4 fp32 or 8 bf16 consecutive channels (VW<T>::V); ldv / stv / ldp below.
+template <typename T> struct VW { static constexpr int V = 16 / (int)sizeof(T); };
+template <int V> struct fvec { float v[V]; };
+template <int V> struct dvec { double v[V]; };
+template <int V> __device__ __forceinline__ dvec<V> dzero() { dvec<V> r;
+#pragma unroll
+    for (int k = 0; k < V; ++k) r.v[k] = 0.0;
+    return r; }
+__device__ __forceinline__ fvec<4> ldv(const float* p, long i) {
+    const float4 w = reinterpret_cast<const float4*>(p)[i];
+    fvec<4> r; r.v[0] = w.x; r.v[1] = w.y; r.v[2] = w.z; r.v[3] = w.w; return r;
+}
+__device__ __forceinline__ fvec<8> ldv(const b16* p, long i) {
+    const uint4 w = reinterpret_cast<const uint4*>(p)[i];
+    fvec<8> r;
+    r.v[0] = __uint_as_float(w.x << 16); r.v[1] = __uint_as_float(w.x & 0xffff0000u); r.v[2] = __uint_as_float(w.y << 16); r.v[3] = __uint_as_float(w.y & 0xffff0000u);
+    r.v[4] = __uint_as_float(w.z << 16); r.v[5] = __uint_as_float(w.z & 0xffff0000u); r.v[6] = __uint_as_float(w.w << 16); r.v[7] = __uint_as_float(w.w & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ void stv(float* p, long i, const fvec<4>& r) { reinterpret_cast<float4*>(p)[i] = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]); }
+__device__ __forceinline__ void stv(b16* p, long i, const fvec<8>& r) {        // round to nearest even
+    uint4 h; unsigned l;
+    split2_bf16(r.v[0], r.v[1], h.x, l); split2_bf16(r.v[2], r.v[3], h.y, l); split2_bf16(r.v[4], r.v[5], h.z, l); split2_bf16(r.v[6], r.v[7], h.w, l);
+    reinterpret_cast<uint4*>(p)[i] = h;
+}
+// per-channel fp32 parameters of the V channels of vector lane cv
+template <int V> __device__ __forceinline__ fvec<V> ldp(const float* p, int cv) {
+    fvec<V> r;
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+        const float4 w = reinterpret_cast<const float4*>(p)[cv * (V / 4) + q];
+        r.v[4 * q] = w.x; r.v[4 * q + 1] = w.y; r.v[4 * q + 2] = w.z; r.v[4 * q + 3] = w.w;
+    }
+    return r;
+}
+// the two bf16 planes of the split-bf16 product (fp32 tensors only)
+__device__ __forceinline__ void st_planes(unsigned short* hi, unsigned short* lo, long i, const fvec<4>& r) {
+    uint2 h, l;
+    split2_bf16(r.v[0], r.v[1], h.x, l.x); split2_bf16(r.v[2], r.v[3], h.y, l.y);
+    reinterpret_cast<uint2*>(hi)[i] = h;
+    reinterpret_cast<uint2*>(lo)[i] = l;
+}
+__device__ __forceinline__ void st_planes(unsigned short*, unsigned short*, long, const fvec<8>&) {}
+
+// thread layout shared by the column reductions: CV = C / V vector lanes per row, 256 % CV == 0
 struct ColMap {
-    int c4, r0, rstep;
-    __device__ ColMap(int C4) { c4 = threadIdx.x % C4; r0 = threadIdx.x / C4; rstep = 256 / C4; }
+    int cv, r0, rstep;
+    __device__ ColMap(int CV) { cv = threadIdx.x % CV; r0 = threadIdx.x / CV; rstep = 256 / CV; }
 };
 
-struct d4 { double x, y, z, w; };
-__device__ __forceinline__ d4 d4zero() { d4 r; r.x = r.y = r.z = r.w = 0.0; return r; }
-
-// combine the per-thread double partials of threads sharing c4, write [blk][which][C] (double)
-__device__ __forceinline__ void block_col_reduce(d4 a, d4 b, int C4, double* __restrict__ part, int C, d4* lds) {
-    // lds: [2][256] d4
+// combine the per-thread double partials of threads sharing cv, write [blk][which][C] (double); lds: [2][256] dvec<V>
+template <int V>
+__device__ __forceinline__ void block_col_reduce(const dvec<V>& a, const dvec<V>& b, int CV, double* __restrict__ part, int C, dvec<V>* lds) {
     lds[threadIdx.x] = a;
     lds[256 + threadIdx.x] = b;
     __syncthreads();
-    if (threadIdx.x < C4) {
-        d4 sa = d4zero(), sb = d4zero();
-        for (int t = threadIdx.x; t < 256; t += C4) {
-            d4 x = lds[t], y = lds[256 + t];
-            sa.x += x.x; sa.y += x.y; sa.z += x.z; sa.w += x.w;
-            sb.x += y.x; sb.y += y.y; sb.z += y.z; sb.w += y.w;
+    if (threadIdx.x < CV) {
+        dvec<V> sa = dzero<V>(), sb = dzero<V>();
+        for (int t = threadIdx.x; t < 256; t += CV) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) { sa.v[k] += lds[t].v[k]; sb.v[k] += lds[256 + t].v[k]; }
         }
-        double* p0 = part + ((long)blockIdx.x * 2 + 0) * C + threadIdx.x * 4;
-        double* p1 = part + ((long)blockIdx.x * 2 + 1) * C + threadIdx.x * 4;
-        p0[0] = sa.x; p0[1] = sa.y; p0[2] = sa.z; p0[3] = sa.w;
-        p1[0] = sb.x; p1[1] = sb.y; p1[2] = sb.z; p1[3] = sb.w;
+        double* p0 = part + ((long)blockIdx.x * 2 + 0) * C + threadIdx.x * V;
+        double* p1 = part + ((long)blockIdx.x * 2 + 1) * C + threadIdx.x * V;
+#pragma unroll
+        for (int k = 0; k < V; ++k) { p0[k] = sa.v[k]; p1[k] = sb.v[k]; }
     }
 }
 
 // mode 0: (x - K, (x-K)^2) with K = row 0 (shift against cancellation); mode 1: (dy, dy * xhat).
 // Sums are carried in double (torch's CPU batch-norm accumulates in double too; the kernel is HBM-bound, the
 // fp64 adds are free) -- nearly-dead post-ReLU channels make sum(dy*xhat) cancel by 1e3..1e4.
-template <int MODE>
-__global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void col_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           long rows, int C, double* __restrict__ part) {
-    __shared__ d4 lds[512];
-    const int C4 = C >> 2;
-    ColMap m(C4);
+    constexpr int V = VW<T>::V;
+    __shared__ dvec<V> lds[512];
+    const int CV = C / V;
+    ColMap m(CV);
     const long rows_per = (rows + gridDim.x - 1) / gridDim.x;
     const long rbeg = (long)blockIdx.x * rows_per, rend = min(rows, rbeg + rows_per);
-    d4 a = d4zero(), b = d4zero();
-    float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), is4 = k4;
-    if (MODE == 0) k4 = reinterpret_cast<const float4*>(x)[m.c4];
-    else { k4 = reinterpret_cast<const float4*>(mean)[m.c4]; is4 = reinterpret_cast<const float4*>(invstd)[m.c4]; }
+    dvec<V> a = dzero<V>(), b = dzero<V>();
+    fvec<V> k4, is4;
+    if (MODE == 0) { k4 = ldv(x, m.cv); is4 = k4; }
+    else { k4 = ldp<V>(mean, m.cv); is4 = ldp<V>(invstd, m.cv); }
     // four rows per trip: the loads are issued together (one row per trip is load -> wait -> add, a single 16-byte request in flight per
     // wave: ~2.7 TB/s measured), the adds keep the row order, so the sums are bit-identical to the one-row loop's
-    auto accum = [&](const float4& v, const float4& d) {
-        if (MODE == 0) {
-            double vx = (double)v.x - k4.x, vy = (double)v.y - k4.y, vz = (double)v.z - k4.z, vw = (double)v.w - k4.w;
-            a.x += vx; a.y += vy; a.z += vz; a.w += vw;
-            b.x += vx * vx; b.y += vy * vy; b.z += vz * vz; b.w += vw * vw;
-        } else {
-            a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
-            b.x += (double)d.x * (((double)v.x - k4.x) * is4.x); b.y += (double)d.y * (((double)v.y - k4.y) * is4.y);
-            b.z += (double)d.z * (((double)v.z - k4.z) * is4.z); b.w += (double)d.w * (((double)v.w - k4.w) * is4.w);
+    auto accum = [&](const fvec<V>& v, const fvec<V>& d) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            if (MODE == 0) {
+                const double vx = (double)v.v[k] - k4.v[k];
+                a.v[k] += vx;
+                b.v[k] += vx * vx;
+            } else {
+                a.v[k] += d.v[k];
+                b.v[k] += (double)d.v[k] * (((double)v.v[k] - k4.v[k]) * is4.v[k]);
+            }
         }
     };
     long r = rbeg + m.r0;
     for (; r + 3 * m.rstep < rend; r += 4 * m.rstep) {
-        float4 v[4], d[4];
+        fvec<V> v[4], d[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            v[j] = reinterpret_cast<const float4*>(x + (r + (long)j * m.rstep) * C)[m.c4];
+            v[j] = ldv(x + (r + (long)j * m.rstep) * C, m.cv);
             d[j] = v[j];
-            if (MODE == 1) d[j] = reinterpret_cast<const float4*>(dy + (r + (long)j * m.rstep) * C)[m.c4];
+            if (MODE == 1) d[j] = ldv(dy + (r + (long)j * m.rstep) * C, m.cv);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) accum(v[j], d[j]);
     }
     for (; r < rend; r += m.rstep) {
-        float4 v = reinterpret_cast<const float4*>(x + r * C)[m.c4], d = v;
-        if (MODE == 1) d = reinterpret_cast<const float4*>(dy + r * C)[m.c4];
+        fvec<V> v = ldv(x + r * C, m.cv), d = v;
+        if (MODE == 1) d = ldv(dy + r * C, m.cv);
         accum(v, d);
     }
-    block_col_reduce(a, b, C4, part, C, lds);
+    block_col_reduce<V>(a, b, CV, part, C, lds);
 }
 
 // final reductions: one wave per column; lanes stride the block partials, fixed-order shuffle tree (deterministic)
@@ -94,8 +139,9 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ part, int nblk, long rows, int C,
-                                                             const float* __restrict__ x, float* __restrict__ mean,
+                                                             const T* __restrict__ x, float* __restrict__ mean,
                                                              float* __restrict__ invstd, float* __restrict__ rmean,
                                                              float* __restrict__ rvar, float momentum, float eps) {
     const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -117,7 +163,7 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __res
     double n = (double)rows, m1 = s1 / n;
     double var = s2 / n - m1 * m1;
     if (var < 0.0) var = 0.0;
-    double mu = (double)x[c] + m1;
+    double mu = (double)ld1(x, c) + m1;
     mean[c] = (float)mu;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     if (rmean) {
@@ -153,31 +199,26 @@ __global__ __launch_bounds__(256) void pair_final_kernel(const double* __restric
 // y = (x - mean) * invstd * gamma + beta ; act: 0 none, 2 leaky-relu(0.01)
 // PL = 1: y is ALSO written as the two bf16 planes of the split-bf16 product (hi = bf16(y), lo = bf16(y - hi)): it is the x operand of the
 // next convolution's plane-based weight gradient (conv_planes.hip), split once here instead of once per consumer tile and tap in the backward
-template <int PL>
-__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, long rows,
+template <int PL, typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, long rows,
                                 int C, int act, unsigned short* __restrict__ y_hi, unsigned short* __restrict__ y_lo) {
-    const int C4 = C >> 2;
-    const long total = rows * C4;
+    constexpr int V = VW<T>::V;
+    static_assert(!PL || V == 4, "planes are written from fp32 tensors");
+    const int CV = C / V;
+    const long total = rows * CV;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        int c4 = (int)(i % C4);
-        float4 v = reinterpret_cast<const float4*>(x)[i];
-        float4 mu = reinterpret_cast<const float4*>(mean)[c4], is = reinterpret_cast<const float4*>(invstd)[c4];
-        float4 g = reinterpret_cast<const float4*>(gamma)[c4], b = reinterpret_cast<const float4*>(beta)[c4];
-        float4 r;
-        r.x = (v.x - mu.x) * is.x * g.x + b.x; r.y = (v.y - mu.y) * is.y * g.y + b.y;
-        r.z = (v.z - mu.z) * is.z * g.z + b.z; r.w = (v.w - mu.w) * is.w * g.w + b.w;
-        if (act == 2) {
-            r.x = r.x > 0.f ? r.x : 0.01f * r.x; r.y = r.y > 0.f ? r.y : 0.01f * r.y;
-            r.z = r.z > 0.f ? r.z : 0.01f * r.z; r.w = r.w > 0.f ? r.w : 0.01f * r.w;
+        const int cv = (int)(i % CV);
+        const fvec<V> v = ldv(x, i);
+        const fvec<V> mu = ldp<V>(mean, cv), is = ldp<V>(invstd, cv), g = ldp<V>(gamma, cv), b = ldp<V>(beta, cv);
+        fvec<V> r;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            r.v[k] = (v.v[k] - mu.v[k]) * is.v[k] * g.v[k] + b.v[k];
+            if (act == 2) r.v[k] = r.v[k] > 0.f ? r.v[k] : 0.01f * r.v[k];
         }
-        reinterpret_cast<float4*>(y)[i] = r;
-        if (PL) {
-            uint2 h, l;
-            split2_bf16(r.x, r.y, h.x, l.x); split2_bf16(r.z, r.w, h.y, l.y);
-            reinterpret_cast<uint2*>(y_hi)[i] = h;
-            reinterpret_cast<uint2*>(y_lo)[i] = l;
-        }
+        stv(y, i, r);
+        if (PL) st_planes(y_hi, y_lo, i, r);
     }
 }
 
@@ -186,43 +227,49 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 // per-(image, channel) sums of y in the same pass (the separate hw-mean kernel re-read the whole tensor).  grid (chunks, N):
 // a block owns a row chunk of ONE image; per-thread double partials, block combine through LDS, one partial per
 // (image, chunk, channel); pool_final adds the chunks in ascending order (deterministic).
-__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* __restrict__ y, int HW, int C,
+                                                            const float* __restrict__ beta, T* __restrict__ y, int HW, int C,
                                                             double* __restrict__ part) {
-    __shared__ d4 lds[256];
-    const int C4 = C >> 2;
-    ColMap m(C4);
+    constexpr int V = VW<T>::V;
+    __shared__ dvec<V> lds[256];
+    const int CV = C / V;
+    ColMap m(CV);
     const int nchunk = gridDim.x;
     const int per = (HW + nchunk - 1) / nchunk;
     const int rbeg = blockIdx.x * per, rend = min(HW, rbeg + per);
     const long base = (long)blockIdx.y * HW * C;
-    const float4 mu = reinterpret_cast<const float4*>(mean)[m.c4], is = reinterpret_cast<const float4*>(invstd)[m.c4];
-    const float4 g = reinterpret_cast<const float4*>(gamma)[m.c4], b = reinterpret_cast<const float4*>(beta)[m.c4];
-    d4 a = d4zero();
-    auto row = [&](const float4& v, int r) {
-        float4 o;
-        o.x = (v.x - mu.x) * is.x * g.x + b.x; o.y = (v.y - mu.y) * is.y * g.y + b.y;
-        o.z = (v.z - mu.z) * is.z * g.z + b.z; o.w = (v.w - mu.w) * is.w * g.w + b.w;
-        reinterpret_cast<float4*>(y + base + (long)r * C)[m.c4] = o;
-        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+    const fvec<V> mu = ldp<V>(mean, m.cv), is = ldp<V>(invstd, m.cv), g = ldp<V>(gamma, m.cv), b = ldp<V>(beta, m.cv);
+    dvec<V> a = dzero<V>();
+    auto row = [&](const fvec<V>& v, int r) {
+        fvec<V> o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.v[k] = (v.v[k] - mu.v[k]) * is.v[k] * g.v[k] + b.v[k];
+        stv(y + base + (long)r * C, m.cv, o);
+#pragma unroll
+        for (int k = 0; k < V; ++k) a.v[k] += o.v[k];          // the squeeze sums the unrounded fp32 values (bf16 storage rounds only the store)
     };
     int r = rbeg + m.r0;
     for (; r + 3 * m.rstep < rend; r += 4 * m.rstep) {           // four loads in flight per wave, rows consumed in order
-        float4 v[4];
+        fvec<V> v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = reinterpret_cast<const float4*>(x + base + (long)(r + j * m.rstep) * C)[m.c4];
+        for (int j = 0; j < 4; ++j) v[j] = ldv(x + base + (long)(r + j * m.rstep) * C, m.cv);
 #pragma unroll
         for (int j = 0; j < 4; ++j) row(v[j], r + j * m.rstep);
     }
-    for (; r < rend; r += m.rstep) row(reinterpret_cast<const float4*>(x + base + (long)r * C)[m.c4], r);
+    for (; r < rend; r += m.rstep) row(ldv(x + base + (long)r * C, m.cv), r);
     lds[threadIdx.x] = a;
     __syncthreads();
-    if (threadIdx.x < C4) {
-        d4 s = d4zero();
-        for (int t = threadIdx.x; t < 256; t += C4) { d4 v = lds[t]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-        double* p = part + ((long)blockIdx.y * nchunk + blockIdx.x) * C + threadIdx.x * 4;
-        p[0] = s.x; p[1] = s.y; p[2] = s.z; p[3] = s.w;
+    if (threadIdx.x < CV) {
+        dvec<V> s = dzero<V>();
+        for (int t = threadIdx.x; t < 256; t += CV) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) s.v[k] += lds[t].v[k];
+        }
+        double* p = part + ((long)blockIdx.y * nchunk + blockIdx.x) * C + threadIdx.x * V;
+#pragma unroll
+        for (int k = 0; k < V; ++k) p[k] = s.v[k];
     }
 }
 // gate (nullable): out = sum * scale * g (1 - g) -- the SE backward's sigmoid' factor, so that no separate pointwise launch follows
@@ -242,141 +289,139 @@ __global__ void pool_final_kernel(const double* __restrict__ part, int nchunk, i
 // PL = 1: dx is ALSO (or, with dx == nullptr, ONLY) written as two bf16 planes  hi = bf16(dx), lo = bf16(dx - hi)  -- the operand format of the
 // plane-based split-bf16 consumers (conv_planes.hip): this pass is HBM-bound, the split rides in its shadow, and the convolution data /
 // weight gradients that read the tensor no longer split it once per consumer tile.
-template <int PL>
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+template <int PL, typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, float* __restrict__ dx,
+                                    const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, T* __restrict__ dx,
                                     long rows, int C, int relu_mask, unsigned short* __restrict__ dx_hi, unsigned short* __restrict__ dx_lo) {
-    const int C4 = C >> 2;
-    const long total = rows * C4;
+    constexpr int V = VW<T>::V;
+    static_assert(!PL || V == 4, "planes are written from fp32 tensors");
+    const int CV = C / V;
+    const long total = rows * CV;
     const float invn = 1.f / (float)rows;
+    const double dn = (double)invn;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        int c4 = (int)(i % C4);
-        float4 d = reinterpret_cast<const float4*>(dy)[i], v = reinterpret_cast<const float4*>(x)[i];
-        float4 mu = reinterpret_cast<const float4*>(mean)[c4], is = reinterpret_cast<const float4*>(invstd)[c4];
-        float4 g = reinterpret_cast<const float4*>(gamma)[c4];
-        float4 s1 = reinterpret_cast<const float4*>(sum_dy)[c4], s2 = reinterpret_cast<const float4*>(sum_dy_xhat)[c4];
-        float4 r;
-        const double dn = (double)invn;
-        r.x = (float)((double)g.x * is.x * ((double)d.x - s1.x * dn - ((double)v.x - mu.x) * is.x * (s2.x * dn)));
-        r.y = (float)((double)g.y * is.y * ((double)d.y - s1.y * dn - ((double)v.y - mu.y) * is.y * (s2.y * dn)));
-        r.z = (float)((double)g.z * is.z * ((double)d.z - s1.z * dn - ((double)v.z - mu.z) * is.z * (s2.z * dn)));
-        r.w = (float)((double)g.w * is.w * ((double)d.w - s1.w * dn - ((double)v.w - mu.w) * is.w * (s2.w * dn)));
-        if (relu_mask) {          // x is a ReLU output (conv -> ReLU -> BN): chain the ReLU derivative, mask = (x > 0)
-            r.x = v.x > 0.f ? r.x : 0.f; r.y = v.y > 0.f ? r.y : 0.f; r.z = v.z > 0.f ? r.z : 0.f; r.w = v.w > 0.f ? r.w : 0.f;
+        const int cv = (int)(i % CV);
+        const fvec<V> d = ldv(dy, i), v = ldv(x, i);
+        const fvec<V> mu = ldp<V>(mean, cv), is = ldp<V>(invstd, cv), g = ldp<V>(gamma, cv), s1 = ldp<V>(sum_dy, cv), s2 = ldp<V>(sum_dy_xhat, cv);
+        fvec<V> r;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            r.v[k] = (float)((double)g.v[k] * is.v[k] * ((double)d.v[k] - s1.v[k] * dn - ((double)v.v[k] - mu.v[k]) * is.v[k] * (s2.v[k] * dn)));
+            if (relu_mask) r.v[k] = v.v[k] > 0.f ? r.v[k] : 0.f;  // x is a ReLU output (conv -> ReLU -> BN): chain the ReLU derivative, mask = (x > 0)
         }
-        if (!PL || dx != nullptr) reinterpret_cast<float4*>(dx)[i] = r;
-        if (PL) {
-            uint2 h, l;
-            split2_bf16(r.x, r.y, h.x, l.x); split2_bf16(r.z, r.w, h.y, l.y);
-            reinterpret_cast<uint2*>(dx_hi)[i] = h;
-            reinterpret_cast<uint2*>(dx_lo)[i] = l;
-        }
+        if (!PL || dx != nullptr) stv(dx, i, r);
+        if (PL) st_planes(dx_hi, dx_lo, i, r);
     }
 }
 
 // ---- squeeze-excite pieces; x is [N][HW][C] -------------------------------------------------------------
 // per-image column mean (MODE 0) or per-image sum of a*b (MODE 1: ds[n,c] = sum_hw dpre*b2 with dpre = dout*(out>0))
-template <int MODE>
-__global__ __launch_bounds__(256) void image_col_kernel(const float* __restrict__ x, const float* __restrict__ dout,
-                                                        const float* __restrict__ outp, int HW, int C, float* __restrict__ res,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void image_col_kernel(const T* __restrict__ x, const T* __restrict__ dout,
+                                                        const T* __restrict__ outp, int HW, int C, float* __restrict__ res,
                                                         float scale, double* __restrict__ part, const float* __restrict__ gate) {
     // grid (nchunk, N): block (k, n) sums rows [k*per, (k+1)*per) of image n; part == nullptr (nchunk = 1): final floats to res, else
     // double partials [n][k][C] for pool_final_kernel (more blocks than images: a 128-image batch alone fills half the CUs)
-    __shared__ d4 lds[256];
-    const int C4 = C >> 2;
-    ColMap m(C4);
+    constexpr int V = VW<T>::V;
+    __shared__ dvec<V> lds[256];
+    const int CV = C / V;
+    ColMap m(CV);
     const int nchunk = gridDim.x, per = (HW + nchunk - 1) / nchunk;
     const int rbeg = blockIdx.x * per, rend = min(HW, rbeg + per);
     const long base = (long)blockIdx.y * HW * C;
-    d4 a = d4zero();
+    dvec<V> a = dzero<V>();
     // one block per image: four rows per trip so that 4 (MODE 0) / 12 (MODE 1) 16-byte loads are in flight per wave; the adds keep the row
     // order of the one-row loop (bit-identical sums)
-    auto accum = [&](const float4& v, const float4& d, const float4& o) {
-        if (MODE == 1) {
-            a.x += o.x > 0.f ? (double)v.x * d.x : 0.0; a.y += o.y > 0.f ? (double)v.y * d.y : 0.0;
-            a.z += o.z > 0.f ? (double)v.z * d.z : 0.0; a.w += o.w > 0.f ? (double)v.w * d.w : 0.0;
-        } else {
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    auto accum = [&](const fvec<V>& v, const fvec<V>& d, const fvec<V>& o) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            if (MODE == 1) a.v[k] += o.v[k] > 0.f ? (double)v.v[k] * d.v[k] : 0.0;
+            else a.v[k] += v.v[k];
         }
     };
     int r = rbeg + m.r0;
     for (; r + 3 * m.rstep < rend; r += 4 * m.rstep) {
-        float4 v[4], d[4], o[4];
+        fvec<V> v[4], d[4], o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long off = base + (long)(r + j * m.rstep) * C;
-            v[j] = reinterpret_cast<const float4*>(x + off)[m.c4];
+            v[j] = ldv(x + off, m.cv);
             d[j] = v[j]; o[j] = v[j];
-            if (MODE == 1) { d[j] = reinterpret_cast<const float4*>(dout + off)[m.c4]; o[j] = reinterpret_cast<const float4*>(outp + off)[m.c4]; }
+            if (MODE == 1) { d[j] = ldv(dout + off, m.cv); o[j] = ldv(outp + off, m.cv); }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) accum(v[j], d[j], o[j]);
     }
     for (; r < rend; r += m.rstep) {
         const long off = base + (long)r * C;
-        float4 v = reinterpret_cast<const float4*>(x + off)[m.c4], d = v, o = v;
-        if (MODE == 1) { d = reinterpret_cast<const float4*>(dout + off)[m.c4]; o = reinterpret_cast<const float4*>(outp + off)[m.c4]; }
+        fvec<V> v = ldv(x + off, m.cv), d = v, o = v;
+        if (MODE == 1) { d = ldv(dout + off, m.cv); o = ldv(outp + off, m.cv); }
         accum(v, d, o);
     }
     lds[threadIdx.x] = a;
     __syncthreads();
-    if (threadIdx.x < C4) {
-        d4 s = d4zero();
-        for (int t = threadIdx.x; t < 256; t += C4) { d4 v = lds[t]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    if (threadIdx.x < CV) {
+        dvec<V> s = dzero<V>();
+        for (int t = threadIdx.x; t < 256; t += CV) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) s.v[k] += lds[t].v[k];
+        }
         if (part) {
-            double* p = part + ((long)blockIdx.y * nchunk + blockIdx.x) * C + threadIdx.x * 4;
-            p[0] = s.x; p[1] = s.y; p[2] = s.z; p[3] = s.w;
+            double* p = part + ((long)blockIdx.y * nchunk + blockIdx.x) * C + threadIdx.x * V;
+#pragma unroll
+            for (int k = 0; k < V; ++k) p[k] = s.v[k];
         } else {
-            float4 o = make_float4((float)(s.x * scale), (float)(s.y * scale), (float)(s.z * scale), (float)(s.w * scale));
-            if (gate) {
-                const float4 g = reinterpret_cast<const float4*>(gate + (long)blockIdx.y * C)[threadIdx.x];
-                o.x = o.x * g.x * (1.f - g.x); o.y = o.y * g.y * (1.f - g.y); o.z = o.z * g.z * (1.f - g.z); o.w = o.w * g.w * (1.f - g.w);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float o = (float)(s.v[k] * scale);
+                if (gate) { const float g = gate[(long)blockIdx.y * C + threadIdx.x * V + k]; o = o * g * (1.f - g); }
+                res[(long)blockIdx.y * C + threadIdx.x * V + k] = o;
             }
-            reinterpret_cast<float4*>(res + (long)blockIdx.y * C)[threadIdx.x] = o;
         }
     }
 }
 
 // out = relu(x * s[n,c] + res)
-template <int PL>
-__global__ void se_scale_add_relu_kernel(const float* __restrict__ x, const float* __restrict__ s, const float* __restrict__ res,
-                                         float* __restrict__ out, long N, int HW, int C, unsigned short* __restrict__ o_hi,
+template <int PL, typename T>
+__global__ void se_scale_add_relu_kernel(const T* __restrict__ x, const float* __restrict__ s, const T* __restrict__ res,
+                                         T* __restrict__ out, long N, int HW, int C, unsigned short* __restrict__ o_hi,
                                          unsigned short* __restrict__ o_lo) {
-    const int C4 = C >> 2;
-    const long per = (long)HW * C4, total = N * per;
+    constexpr int V = VW<T>::V;
+    static_assert(!PL || V == 4, "planes are written from fp32 tensors");
+    const int CV = C / V;
+    const long per = (long)HW * CV, total = N * per;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        long n = i / per; int c4 = (int)(i % C4);
-        float4 v = reinterpret_cast<const float4*>(x)[i], r = reinterpret_cast<const float4*>(res)[i];
-        float4 sc = reinterpret_cast<const float4*>(s + n * C)[c4];
-        float4 o;
-        o.x = fmaxf(v.x * sc.x + r.x, 0.f); o.y = fmaxf(v.y * sc.y + r.y, 0.f);
-        o.z = fmaxf(v.z * sc.z + r.z, 0.f); o.w = fmaxf(v.w * sc.w + r.w, 0.f);
-        reinterpret_cast<float4*>(out)[i] = o;
-        if (PL) {
-            uint2 h, l;
-            split2_bf16(o.x, o.y, h.x, l.x); split2_bf16(o.z, o.w, h.y, l.y);
-            reinterpret_cast<uint2*>(o_hi)[i] = h;
-            reinterpret_cast<uint2*>(o_lo)[i] = l;
-        }
+        const long n = i / per; const int cv = (int)(i % CV);
+        const fvec<V> v = ldv(x, i), r = ldv(res, i);
+        const fvec<V> sc = ldp<V>(s + n * C, cv);
+        fvec<V> o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.v[k] = fmaxf(v.v[k] * sc.v[k] + r.v[k], 0.f);
+        stv(out, i, o);
+        if (PL) st_planes(o_hi, o_lo, i, o);
     }
 }
 // dpre = dout * (out > 0); dres = dpre; dx = dpre * s[n,c] + dpool[n,c]   (dpool already divided by HW)
-__global__ void se_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ outp, const float* __restrict__ s,
-                                    const float* __restrict__ dpool, float* __restrict__ dres, float* __restrict__ dx, long N,
+template <typename T>
+__global__ void se_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ outp, const float* __restrict__ s,
+                                    const float* __restrict__ dpool, T* __restrict__ dres, T* __restrict__ dx, long N,
                                     int HW, int C) {
-    const int C4 = C >> 2;
-    const long per = (long)HW * C4, total = N * per;
+    constexpr int V = VW<T>::V;
+    const int CV = C / V;
+    const long per = (long)HW * CV, total = N * per;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        long n = i / per; int c4 = (int)(i % C4);
-        float4 d = reinterpret_cast<const float4*>(dout)[i], o = reinterpret_cast<const float4*>(outp)[i];
-        float4 sc = reinterpret_cast<const float4*>(s + n * C)[c4], dp = reinterpret_cast<const float4*>(dpool + n * C)[c4];
-        float4 p;
-        p.x = o.x > 0.f ? d.x : 0.f; p.y = o.y > 0.f ? d.y : 0.f; p.z = o.z > 0.f ? d.z : 0.f; p.w = o.w > 0.f ? d.w : 0.f;
-        reinterpret_cast<float4*>(dres)[i] = p;
-        float4 q;
-        q.x = p.x * sc.x + dp.x; q.y = p.y * sc.y + dp.y; q.z = p.z * sc.z + dp.z; q.w = p.w * sc.w + dp.w;
-        reinterpret_cast<float4*>(dx)[i] = q;
+        const long n = i / per; const int cv = (int)(i % CV);
+        const fvec<V> d = ldv(dout, i), o = ldv(outp, i);
+        const fvec<V> sc = ldp<V>(s + n * C, cv), dp = ldp<V>(dpool + n * C, cv);
+        fvec<V> p, q;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            p.v[k] = o.v[k] > 0.f ? d.v[k] : 0.f;
+            q.v[k] = p.v[k] * sc.v[k] + dp.v[k];
+        }
+        stv(dres, i, p);
+        stv(dx, i, q);
     }
 }
 
@@ -387,7 +432,113 @@ inline int chunk_blocks(long rows) {
     return (int)b;
 }
 inline int flat_grid(long n) { long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
-inline bool okC(int C) { return C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0; }
+template <typename T> inline bool okCv(int C) { constexpr int V = VW<T>::V; return C % V == 0 && C / V <= 256 && 256 % (C / V) == 0; }
+inline bool okC(int C) { return okCv<float>(C); }
+
+
+// ---- host side, one template per pass over the element type (float | b16) ------------------------------------------------------------------
+static int pool_chunks(int N, int HW) {
+    int c = 2048 / (N < 1 ? 1 : N);                      // ~2k blocks per launch
+    int cap = HW / 64;                                   // >= 64 rows per block
+    if (c > cap) c = cap;
+    return c < 1 ? 1 : c;
+}
+template <typename T>
+int bn_stats_t(const T* x, long rows, int C, float* mean, float* invstd, float* running_mean, float* running_var, float momentum, float eps,
+               float* ws, void* stream) {
+    HA2G_REQUIRE(okCv<T>(C), "bn: unsupported channel count %d", C);
+    HA2G_REQUIRE(rows > 0, "bn: empty batch");
+    hipStream_t st = (hipStream_t)stream;
+    int nb = chunk_blocks(rows);
+    hipLaunchKernelGGL((col_partial_kernel<0, T>), dim3(nb), dim3(256), 0, st, x, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, rows, C,
+                       (double*)ws);
+    hipLaunchKernelGGL(bn_stats_final_kernel<T>, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, rows, C, x, mean, invstd, running_mean,
+                       running_var, momentum, eps);
+    HA2G_CHECK_LAUNCH("bn_stats");
+    return 0;
+}
+template <int PL, typename T>
+int bn_apply_t(const T* x, const float* mean, const float* invstd, const float* gamma, const float* beta, T* y, void* y_hi, void* y_lo, long rows,
+               int C, int act, void* stream) {
+    HA2G_REQUIRE(C % VW<T>::V == 0, "bn: C %% 4");
+    hipLaunchKernelGGL((bn_apply_kernel<PL, T>), dim3(flat_grid(rows * (C / VW<T>::V))), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, y,
+                       rows, C, act, (unsigned short*)y_hi, (unsigned short*)y_lo);
+    HA2G_CHECK_LAUNCH("bn_apply");
+    return 0;
+}
+template <typename T>
+int bn_apply_pool_t(const T* x, const float* mean, const float* invstd, const float* gamma, const float* beta, T* y, int N, int HW, int C,
+                    float* pooled, float* ws, void* stream) {
+    HA2G_REQUIRE(okCv<T>(C), "bn_apply_pool: unsupported channel count %d", C);
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = pool_chunks(N, HW);
+    hipLaunchKernelGGL(bn_apply_pool_kernel<T>, dim3(nchunk, N), dim3(256), 0, st, x, mean, invstd, gamma, beta, y, HW, C, (double*)ws);
+    hipLaunchKernelGGL(pool_final_kernel, dim3(ceil_div((long)N * C, 256)), dim3(256), 0, st, (const double*)ws, nchunk, C, (long)N * C,
+                       1.f / (float)HW, pooled, (const float*)nullptr);
+    HA2G_CHECK_LAUNCH("bn_apply_pool");
+    return 0;
+}
+template <int PL, typename T>
+int bn_bwd_t(const T* dy, const T* x, const float* mean, const float* invstd, const float* gamma, T* dx, void* dx_hi, void* dx_lo, float* dgamma,
+             float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta, float* ws, void* stream) {
+    HA2G_REQUIRE(okCv<T>(C), "bn: unsupported channel count %d", C);
+    hipStream_t st = (hipStream_t)stream;
+    int nb = chunk_blocks(rows);
+    hipLaunchKernelGGL((col_partial_kernel<1, T>), dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
+    hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, C, dbeta, dgamma, acc_dbeta, acc_dgamma);
+    if (PL || dx)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<PL, T>), dim3(flat_grid(rows * (C / VW<T>::V))), dim3(256), 0, st, dy, x, mean, invstd, gamma,
+                           (const float*)dbeta, (const float*)dgamma, dx, rows, C, relu_mask, (unsigned short*)dx_hi, (unsigned short*)dx_lo);
+    HA2G_CHECK_LAUNCH("bn_bwd");
+    return 0;
+}
+template <int PL, typename T>
+int se_scale_add_relu_t(const T* x, const float* s, const T* res, T* out, void* o_hi, void* o_lo, int N, int HW, int C, void* stream) {
+    HA2G_REQUIRE(C % VW<T>::V == 0, "se: C %% 4");
+    hipLaunchKernelGGL((se_scale_add_relu_kernel<PL, T>), dim3(flat_grid((long)N * HW * (C / VW<T>::V))), dim3(256), 0, (hipStream_t)stream, x, s, res, out,
+                       (long)N, HW, C, (unsigned short*)o_hi, (unsigned short*)o_lo);
+    HA2G_CHECK_LAUNCH("se_scale_add_relu");
+    return 0;
+}
+template <typename T>
+int se_bwd_scale_t(const T* dout, const T* out, const T* x, float* ds, int N, int HW, int C, const float* gate, float* ws, void* stream) {
+    HA2G_REQUIRE(okCv<T>(C), "se: unsupported channel count %d", C);
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = ws ? pool_chunks(N, HW) : 1;          // ws: ha2g_bn_apply_pool_workspace_floats(N, HW, C) floats, or null
+    if (nchunk > 1) {
+        hipLaunchKernelGGL((image_col_kernel<1, T>), dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, ds, 1.f, (double*)ws, (const float*)nullptr);
+        hipLaunchKernelGGL(pool_final_kernel, dim3(ceil_div((long)N * C, 256)), dim3(256), 0, st, (const double*)ws, nchunk, C, (long)N * C, 1.f, ds,
+                           gate);
+    } else {
+        hipLaunchKernelGGL((image_col_kernel<1, T>), dim3(1, N), dim3(256), 0, st, x, dout, out, HW, C, ds, 1.f, (double*)nullptr, gate);
+    }
+    HA2G_CHECK_LAUNCH("se_bwd_scale");
+    return 0;
+}
+template <typename T>
+int se_bwd_apply_t(const T* dout, const T* out, const float* s, const float* dpool, T* dres, T* dx, int N, int HW, int C, void* stream) {
+    HA2G_REQUIRE(C % VW<T>::V == 0, "se: C %% 4");
+    hipLaunchKernelGGL(se_bwd_apply_kernel<T>, dim3(flat_grid((long)N * HW * (C / VW<T>::V))), dim3(256), 0, (hipStream_t)stream, dout, out, s, dpool, dres, dx,
+                       (long)N, HW, C);
+    HA2G_CHECK_LAUNCH("se_bwd_apply");
+    return 0;
+}
+
+// bf16 <-> fp32 streams of the bf16-storage mode's boundaries (taps, tap gradients)
+__global__ void f32_to_b16_kernel(const float* __restrict__ x, b16* __restrict__ y, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) st4(y, i, ld4(x, i));
+}
+__global__ void b16_to_f32_kernel(const b16* __restrict__ x, float* __restrict__ y, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) st4(y, i, ld4(x, i));
+}
+// out = bf16(a + b): a bf16 (nullable: out = bf16(b)), b fp32
+__global__ void add_f32_to_b16_kernel(const b16* __restrict__ a, const float* __restrict__ b, b16* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 v = ld4(b, i);
+        if (a) { const float4 w = ld4(a, i); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+        st4(out, i, v);
+    }
+}
 
 }  // namespace
 
@@ -399,131 +550,117 @@ long ha2g_bn_workspace_floats(int C) { return (long)NB_MAX * 2 * C * 2; }   /* p
 // mean/invstd [C] out; running_mean/var updated in place when non-null.  x is [rows][C], C in {4,8,...,1024} with 256 % (C/4) == 0.
 int ha2g_bn_stats_f32(const float* x, long rows, int C, float* mean, float* invstd, float* running_mean, float* running_var,
                       float momentum, float eps, float* ws, void* stream) {
-    HA2G_REQUIRE(okC(C), "bn: unsupported channel count %d", C);
-    HA2G_REQUIRE(rows > 0, "bn: empty batch");
-    hipStream_t st = (hipStream_t)stream;
-    int nb = chunk_blocks(rows);
-    hipLaunchKernelGGL(col_partial_kernel<0>, dim3(nb), dim3(256), 0, st, x, nullptr, nullptr, nullptr, rows, C, (double*)ws);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, rows, C, x, mean, invstd, running_mean,
-                       running_var, momentum, eps);
-    HA2G_CHECK_LAUNCH("bn_stats");
-    return 0;
+    return bn_stats_t<float>(x, rows, C, mean, invstd, running_mean, running_var, momentum, eps, ws, stream);
 }
 int ha2g_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y,
                       long rows, int C, int act, void* stream) {
-    HA2G_REQUIRE(C % 4 == 0, "bn: C %% 4");
-    hipLaunchKernelGGL(bn_apply_kernel<0>, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta,
-                       y, rows, C, act, (unsigned short*)nullptr, (unsigned short*)nullptr);
-    HA2G_CHECK_LAUNCH("bn_apply");
-    return 0;
+    return bn_apply_t<0, float>(x, mean, invstd, gamma, beta, y, nullptr, nullptr, rows, C, act, stream);
 }
 // ha2g_bn_apply_f32 that also writes y as bf16 planes y_hi / y_lo [rows][C]
 int ha2g_bn_apply_planes_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y, void* y_hi,
                              void* y_lo, long rows, int C, int act, void* stream) {
-    HA2G_REQUIRE(C % 4 == 0, "bn: C %% 4");
     HA2G_REQUIRE(y_hi != nullptr && y_lo != nullptr, "bn_apply_planes: null plane");
-    hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta,
-                       y, rows, C, act, (unsigned short*)y_hi, (unsigned short*)y_lo);
-    HA2G_CHECK_LAUNCH("bn_apply_planes");
-    return 0;
+    return bn_apply_t<1, float>(x, mean, invstd, gamma, beta, y, y_hi, y_lo, rows, C, act, stream);
 }
 // y = bn(x) for x [N][HW][C] AND pooled[n][c] = mean over HW of y (the SE squeeze) in one pass over the tensor.
 // ws: >= ha2g_bn_apply_pool_workspace_floats(N, HW, C) floats.
-static int pool_chunks(int N, int HW) {
-    int c = 2048 / (N < 1 ? 1 : N);                      // ~2k blocks per launch
-    int cap = HW / 64;                                   // >= 64 rows per block
-    if (c > cap) c = cap;
-    return c < 1 ? 1 : c;
-}
 long ha2g_bn_apply_pool_workspace_floats(int N, int HW, int C) { return (long)N * pool_chunks(N, HW) * C * 2; }
 int ha2g_bn_apply_pool_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y,
                            int N, int HW, int C, float* pooled, float* ws, void* stream) {
-    HA2G_REQUIRE(okC(C), "bn_apply_pool: unsupported channel count %d", C);
-    hipStream_t st = (hipStream_t)stream;
-    const int nchunk = pool_chunks(N, HW);
-    hipLaunchKernelGGL(bn_apply_pool_kernel, dim3(nchunk, N), dim3(256), 0, st, x, mean, invstd, gamma, beta, y, HW, C, (double*)ws);
-    hipLaunchKernelGGL(pool_final_kernel, dim3(ceil_div((long)N * C, 256)), dim3(256), 0, st, (const double*)ws, nchunk, C, (long)N * C,
-                       1.f / (float)HW, pooled, nullptr);
-    HA2G_CHECK_LAUNCH("bn_apply_pool");
-    return 0;
+    return bn_apply_pool_t<float>(x, mean, invstd, gamma, beta, y, N, HW, C, pooled, ws, stream);
 }
 // dgamma = sum dy*xhat, dbeta = sum dy, dx as torch's batch-norm backward (train mode)
 // relu_mask = 1: x is the output of a ReLU that precedes the BatchNorm; dx then is the gradient w.r.t. the ReLU's INPUT
 int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx,
                     float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta, float* ws,
                     void* stream) {
-    HA2G_REQUIRE(okC(C), "bn: unsupported channel count %d", C);
-    hipStream_t st = (hipStream_t)stream;
-    int nb = chunk_blocks(rows);
-    hipLaunchKernelGGL(col_partial_kernel<1>, dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
-    hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, C, dbeta, dgamma, acc_dbeta, acc_dgamma);
-    if (dx)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, st, dy, x, mean, invstd, gamma, dbeta,
-                           dgamma, dx, rows, C, relu_mask, (unsigned short*)nullptr, (unsigned short*)nullptr);
-    HA2G_CHECK_LAUNCH("bn_bwd");
-    return 0;
+    return bn_bwd_t<0, float>(dy, x, mean, invstd, gamma, dx, nullptr, nullptr, dgamma, dbeta, rows, C, relu_mask, acc_dgamma, acc_dbeta, ws, stream);
 }
 // ha2g_bn_bwd_f32 whose dx goes out as bf16 planes dx_hi / dx_lo [rows][C] (and, when dx != NULL, in fp32 as well)
 int ha2g_bn_bwd_planes_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx, void* dx_hi,
                            void* dx_lo, float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta,
                            float* ws, void* stream) {
-    HA2G_REQUIRE(okC(C), "bn: unsupported channel count %d", C);
     HA2G_REQUIRE(dx_hi != nullptr && dx_lo != nullptr, "bn_bwd_planes: null plane");
-    hipStream_t st = (hipStream_t)stream;
-    int nb = chunk_blocks(rows);
-    hipLaunchKernelGGL(col_partial_kernel<1>, dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
-    hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, C, dbeta, dgamma, acc_dbeta, acc_dgamma);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(flat_grid(rows * (C / 4))), dim3(256), 0, st, dy, x, mean, invstd, gamma, dbeta, dgamma, dx,
-                       rows, C, relu_mask, (unsigned short*)dx_hi, (unsigned short*)dx_lo);
-    HA2G_CHECK_LAUNCH("bn_bwd_planes");
-    return 0;
+    return bn_bwd_t<1, float>(dy, x, mean, invstd, gamma, dx, dx_hi, dx_lo, dgamma, dbeta, rows, C, relu_mask, acc_dgamma, acc_dbeta, ws, stream);
 }
 // out[n][c] = mean over HW of x[n][hw][c]
 int ha2g_hw_mean_f32(const float* x, float* out, int N, int HW, int C, void* stream) {
     HA2G_REQUIRE(okC(C), "hw_mean: unsupported channel count %d", C);
-    hipLaunchKernelGGL(image_col_kernel<0>, dim3(1, N), dim3(256), 0, (hipStream_t)stream, x, nullptr, nullptr, HW, C, out, 1.f / (float)HW, nullptr, nullptr);
+    hipLaunchKernelGGL((image_col_kernel<0, float>), dim3(1, N), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr, (const float*)nullptr, HW, C,
+                       out, 1.f / (float)HW, (double*)nullptr, (const float*)nullptr);
     HA2G_CHECK_LAUNCH("hw_mean");
     return 0;
 }
 int ha2g_se_scale_add_relu_f32(const float* x, const float* s, const float* res, float* out, int N, int HW, int C, void* stream) {
-    HA2G_REQUIRE(C % 4 == 0, "se: C %% 4");
-    hipLaunchKernelGGL(se_scale_add_relu_kernel<0>, dim3(flat_grid((long)N * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, s, res,
-                       out, (long)N, HW, C, (unsigned short*)nullptr, (unsigned short*)nullptr);
-    HA2G_CHECK_LAUNCH("se_scale_add_relu");
-    return 0;
+    return se_scale_add_relu_t<0, float>(x, s, res, out, nullptr, nullptr, N, HW, C, stream);
 }
 // the same, out also as bf16 planes (the next block's conv1 reads them in its weight gradient)
 int ha2g_se_scale_add_relu_planes_f32(const float* x, const float* s, const float* res, float* out, void* o_hi, void* o_lo, int N, int HW, int C,
                                       void* stream) {
-    HA2G_REQUIRE(C % 4 == 0, "se: C %% 4");
     HA2G_REQUIRE(o_hi != nullptr && o_lo != nullptr, "se_scale_add_relu_planes: null plane");
-    hipLaunchKernelGGL(se_scale_add_relu_kernel<1>, dim3(flat_grid((long)N * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, s, res,
-                       out, (long)N, HW, C, (unsigned short*)o_hi, (unsigned short*)o_lo);
-    HA2G_CHECK_LAUNCH("se_scale_add_relu_planes");
-    return 0;
+    return se_scale_add_relu_t<1, float>(x, s, res, out, o_hi, o_lo, N, HW, C, stream);
 }
 // ds[n][c] = sum_hw dout*(out>0)*x
 int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, float* ds, int N, int HW, int C, const float* gate, float* ws,
                           void* stream) {
-    HA2G_REQUIRE(okC(C), "se: unsupported channel count %d", C);
-    hipStream_t st = (hipStream_t)stream;
-    const int nchunk = ws ? pool_chunks(N, HW) : 1;          // ws: ha2g_bn_apply_pool_workspace_floats(N, HW, C) floats, or null
-    if (nchunk > 1) {
-        hipLaunchKernelGGL(image_col_kernel<1>, dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, ds, 1.f, (double*)ws, (const float*)nullptr);
-        hipLaunchKernelGGL(pool_final_kernel, dim3(ceil_div((long)N * C, 256)), dim3(256), 0, st, (const double*)ws, nchunk, C, (long)N * C, 1.f, ds,
-                           gate);
-    } else {
-        hipLaunchKernelGGL(image_col_kernel<1>, dim3(1, N), dim3(256), 0, st, x, dout, out, HW, C, ds, 1.f, (double*)nullptr, gate);
-    }
-    HA2G_CHECK_LAUNCH("se_bwd_scale");
-    return 0;
+    return se_bwd_scale_t<float>(dout, out, x, ds, N, HW, C, gate, ws, stream);
 }
 int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, const float* dpool, float* dres, float* dx, int N,
                           int HW, int C, void* stream) {
-    HA2G_REQUIRE(C % 4 == 0, "se: C %% 4");
-    hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(flat_grid((long)N * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, dout, out, s,
-                       dpool, dres, dx, (long)N, HW, C);
-    HA2G_CHECK_LAUNCH("se_bwd_apply");
+    return se_bwd_apply_t<float>(dout, out, s, dpool, dres, dx, N, HW, C, stream);
+}
+
+// ---- bf16-storage mode (BASELINE config 5): the same passes over bf16 tensors.  Statistics, scales, gradients of gamma / beta and all
+// arithmetic are fp32 / double as above; only the activation / activation-gradient streams are 2 bytes per element. ------------------------------
+int ha2g_bn_stats_b16(const void* x, long rows, int C, float* mean, float* invstd, float* running_mean, float* running_var, float momentum,
+                      float eps, float* ws, void* stream) {
+    return bn_stats_t<b16>((const b16*)x, rows, C, mean, invstd, running_mean, running_var, momentum, eps, ws, stream);
+}
+int ha2g_bn_apply_b16(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, void* y, long rows, int C,
+                      int act, void* stream) {
+    return bn_apply_t<0, b16>((const b16*)x, mean, invstd, gamma, beta, (b16*)y, nullptr, nullptr, rows, C, act, stream);
+}
+int ha2g_bn_apply_pool_b16(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, void* y, int N, int HW,
+                           int C, float* pooled, float* ws, void* stream) {
+    return bn_apply_pool_t<b16>((const b16*)x, mean, invstd, gamma, beta, (b16*)y, N, HW, C, pooled, ws, stream);
+}
+int ha2g_bn_bwd_b16(const void* dy, const void* x, const float* mean, const float* invstd, const float* gamma, void* dx, float* dgamma,
+                    float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta, float* ws, void* stream) {
+    return bn_bwd_t<0, b16>((const b16*)dy, (const b16*)x, mean, invstd, gamma, (b16*)dx, nullptr, nullptr, dgamma, dbeta, rows, C, relu_mask,
+                            acc_dgamma, acc_dbeta, ws, stream);
+}
+int ha2g_se_scale_add_relu_b16(const void* x, const float* s, const void* res, void* out, int N, int HW, int C, void* stream) {
+    return se_scale_add_relu_t<0, b16>((const b16*)x, s, (const b16*)res, (b16*)out, nullptr, nullptr, N, HW, C, stream);
+}
+int ha2g_se_bwd_scale_b16(const void* dout, const void* out, const void* x, float* ds, int N, int HW, int C, const float* gate, float* ws,
+                          void* stream) {
+    return se_bwd_scale_t<b16>((const b16*)dout, (const b16*)out, (const b16*)x, ds, N, HW, C, gate, ws, stream);
+}
+int ha2g_se_bwd_apply_b16(const void* dout, const void* out, const float* s, const float* dpool, void* dres, void* dx, int N, int HW, int C,
+                          void* stream) {
+    return se_bwd_apply_t<b16>((const b16*)dout, (const b16*)out, s, dpool, (b16*)dres, (b16*)dx, N, HW, C, stream);
+}
+// y (bf16) = round-to-nearest-even(x); n % 4 == 0
+int ha2g_f32_to_b16(const float* x, void* y, long n, void* stream) {
+    HA2G_REQUIRE(n % 4 == 0, "f32_to_b16: n %% 4");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(f32_to_b16_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, (b16*)y, n / 4);
+    HA2G_CHECK_LAUNCH("f32_to_b16");
+    return 0;
+}
+int ha2g_b16_to_f32(const void* x, float* y, long n, void* stream) {
+    HA2G_REQUIRE(n % 4 == 0, "b16_to_f32: n %% 4");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(b16_to_f32_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const b16*)x, y, n / 4);
+    HA2G_CHECK_LAUNCH("b16_to_f32");
+    return 0;
+}
+// out (bf16) = bf16(a (bf16, or NULL = 0) + b (fp32)): a tap's fp32 gradient joins the trunk's bf16 gradient stream
+int ha2g_add_f32_to_b16(const void* a, const float* b, void* out, long n, void* stream) {
+    HA2G_REQUIRE(n % 4 == 0, "add_f32_to_b16: n %% 4");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(add_f32_to_b16_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const b16*)a, b, (b16*)out, n / 4);
+    HA2G_CHECK_LAUNCH("add_f32_to_b16");
     return 0;
 }
 

@@ -210,6 +210,16 @@ import os as _os
 # bit 3: the stride-2 data gradients (conv1 / downsample of a layer's first block) by parity class; HA2G_PLANES=0 is the round-2 path
 PLANES = int(_os.environ.get('HA2G_PLANES', '11'))
 SIDE_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_WGRAD', '1') != '0'
+# bf16-storage mode of the trunk (BASELINE config 5; wav_b16.py): opt-in -- HA2G_B16=1, set_b16(True) or bench.py --bf16
+B16 = [_os.environ.get('HA2G_B16', '0') == '1']
+
+
+def set_b16(on):
+    """Store the trunk's activations and activation gradients as bf16 (wav_b16.py); returns the previous setting."""
+    prev = B16[0]
+    B16[0] = bool(on)
+    return prev
+
 SIDE_FC_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_FC', '1') != '0'
 
 
@@ -506,6 +516,12 @@ class WavEncoderFunction(torch.autograd.Function):
         spec = spec.contiguous().float()
         B, H0, W0 = spec.shape
         S = {}                                            # saved activations for backward
+        ctx.b16 = B16[0]
+        if ctx.b16:
+            from . import wav_b16
+            feats16, S = wav_b16.trunk_fwd(spec, P, LAYERS, training, _NBT_PENDING)
+            feats = [None] + [wav_b16.to_f32(f) for f in feats16[1:]]      # the taps read fp32
+            return WavEncoderFunction._finish_forward(ctx, feats, S, P, vid, L, names, flat_index, tensors)
         # ---- stem: conv(1->32) + ReLU, then BN ----
         w1 = P['conv1.weight'].contiguous()
         c0 = empty(B, H0, W0, 32, like=spec)
@@ -521,6 +537,10 @@ class WavEncoderFunction(torch.autograd.Function):
                 x, S[b], xp = block_fwd(x, P, b, j == 0 and li > 0, xp=xp, out_planes=j + 1 < nblk)
             feats.append(x)
         _FWD_PLANES[0] = False
+        return WavEncoderFunction._finish_forward(ctx, feats, S, P, vid, L, names, flat_index, tensors)
+
+    @staticmethod
+    def _finish_forward(ctx, feats, S, P, vid, L, names, flat_index, tensors):
         # ---- taps ----
         tap_out = []
         for (t, C, k, r), f in zip(TAPS, feats[1:]):
@@ -554,6 +574,10 @@ class WavEncoderFunction(torch.autograd.Function):
         for ti, (t, C, k, r) in enumerate(TAPS):
             dfeat[ti + 1] = tap_bwd(df[ti], S['tap_' + t], P, t, r, sink)
         # ---- trunk backward ----
+        if ctx.b16:
+            from . import wav_b16
+            wav_b16.trunk_bwd(dfeat, S, P, LAYERS, sink)
+            return WavEncoderFunction._finish_backward(ctx, sink, dev)
         dx = None
         for li in range(len(LAYERS) - 1, -1, -1):
             if dfeat[li] is not None:
@@ -569,6 +593,11 @@ class WavEncoderFunction(torch.autograd.Function):
         check(lib.ha2g_stem_conv_wgrad_f32(spec.data_ptr(), dc0.data_ptr(), dw1.data_ptr(), dbias1.data_ptr(), Bn, H0, W0, 0.0,
                                            workspace(dev).data_ptr(), _stream()))
         G['conv1.weight'], G['conv1.bias'] = dw1, dbias1
+        return WavEncoderFunction._finish_backward(ctx, sink, dev)
+
+    @staticmethod
+    def _finish_backward(ctx, sink, dev):
+        G = sink.G
         sink.join(dev)                                   # the side stream's weight gradients are complete before autograd sees them
         # ---- scatter into the flat gradient tuple ----
         grads = [None] * ctx.n_tensors

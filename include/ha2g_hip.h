@@ -77,6 +77,38 @@ int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const voi
  * multiples of 64): every pixel of x and dy goes global -> LDS once per 64 x 64 block of dW (the nine taps share the staged patch); fp32
  * accumulation per workgroup, the workgroups' partial slabs (ws >= ..._workspace_bytes) are added in double.  Autograd's conv2d backward w.r.t.
  * the weight (model/ResNetBlocks.py:24-29). */
+/* bf16-storage mode (BASELINE config 5, bench.py --bf16): x / y / dy / dx are bf16 tensors in HBM, w bf16 [Cout][KH][KW][Cin], wt bf16
+ * [Cin][KH][KW][Cout] (= the hi plane of ha2g_conv2d_weight_ihwo_planes); fp32 accumulation; 3x3 / pad 1 or 1x1 / pad 0, stride 1 or 2,
+ * channel counts multiples of 32 (nn.Conv2d and its backward w.r.t. the input, model/ResNetBlocks.py:24-29, model/ResNetSE34V2.py:96-116) */
+int ha2g_conv2d_b16_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
+int ha2g_conv2d_fwd_b16(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
+                        void* stream);
+int ha2g_conv2d_dgrad_b16(const void* dy, const void* wt, void* dx, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                          float beta, void* stream);
+int ha2g_conv2d_wgrad_b16_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+long ha2g_conv2d_wgrad_b16_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int ha2g_conv2d_wgrad_b16(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                          float beta, float* ws, long ws_bytes, void* stream);
+/* bf16-storage mode, the HBM-bound passes of the audio tower over bf16 tensors (same arithmetic as their _f32 twins: fp32 / double statistics and
+ * accumulators, round-to-nearest-even on every activation store).  ha2g_add_f32_to_b16: out = bf16(a + b), a bf16 or NULL, b fp32. */
+int ha2g_bn_stats_b16(const void* x, long rows, int C, float* mean, float* invstd, float* running_mean, float* running_var, float momentum,
+                      float eps, float* ws, void* stream);
+int ha2g_bn_apply_b16(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, void* y, long rows, int C,
+                      int act, void* stream);
+int ha2g_bn_apply_pool_b16(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, void* y, int N, int HW,
+                           int C, float* pooled, float* ws, void* stream);
+int ha2g_bn_bwd_b16(const void* dy, const void* x, const float* mean, const float* invstd, const float* gamma, void* dx, float* dgamma,
+                    float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta, float* ws, void* stream);
+int ha2g_se_scale_add_relu_b16(const void* x, const float* s, const void* res, void* out, int N, int HW, int C, void* stream);
+int ha2g_se_bwd_scale_b16(const void* dout, const void* out, const void* x, float* ds, int N, int HW, int C, const float* gate, float* ws,
+                          void* stream);
+int ha2g_se_bwd_apply_b16(const void* dout, const void* out, const float* s, const float* dpool, void* dres, void* dx, int N, int HW, int C,
+                          void* stream);
+int ha2g_f32_to_b16(const float* x, void* y, long n, void* stream);
+int ha2g_b16_to_f32(const void* x, float* y, long n, void* stream);
+int ha2g_add_f32_to_b16(const void* a, const float* b, void* out, long n, void* stream);
+int ha2g_stem_conv_fwd_b16(const float* x, const float* w, const float* bias, void* y, int N, int H, int W, void* stream);
+int ha2g_stem_conv_wgrad_b16(const float* x, const void* dy, float* dw, float* db, int N, int H, int W, float beta, float* ws, void* stream);
 int ha2g_conv2d_wgrad_planes_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 long ha2g_conv2d_wgrad_planes_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int ha2g_conv2d_wgrad_planes_f32(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, int N, int H, int W, int Cin,

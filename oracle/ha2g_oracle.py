@@ -101,20 +101,94 @@ def text_encoder_tcn(tokens, sd, p, n_layers, drop=None):
     return F.linear(x.transpose(1, 2), sd[p + 'decoder.weight'], sd[p + 'decoder.bias'])
 
 
+class _StoreBf16(torch.autograd.Function):
+    """A tensor that the bf16-storage mode keeps in HBM as bf16: the forward value is rounded to bf16 (nearest even) where it is stored,
+    and so is the gradient that arrives at it (the activation-gradient stream is stored as bf16 as well); straight-through otherwise."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _GradBf16(torch.autograd.Function):
+    """Identity forward; the gradient arriving here is rounded to bf16 (a point where the activation-gradient stream is stored)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _WeightBf16(torch.autograd.Function):
+    """A convolution weight as the bf16 matrix kernels read it -- and any tensor stored rounded whose incoming gradient is NOT rounded at
+    this point: rounded forward, gradient untouched (weight gradients are fp32)."""
+
+    @staticmethod
+    def forward(ctx, w):
+        return w.to(torch.bfloat16).to(w.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+_BF16_STORAGE = [False]
+
+
+class bf16_storage:
+    """`with bf16_storage():` -- evaluate the audio encoder's trunk with the rounding points of ha2g_amd's bf16-storage mode (BASELINE config 5;
+    the reference has no such mode: this is the oracle *under the stated storage format*, tests/test_gpu_b16.py).  Rounded: the stem output and
+    its BatchNorm, the five stored tensors of each SEBasicBlock (ReLU(conv1), bn1, conv2, bn2, block output), the downsample conv and its
+    BatchNorm, every 3x3 / 1x1 trunk convolution weight, and the activation gradients where ha2g_amd/wav_b16.py stores them (one rounding
+    per stored gradient tensor, in its order of accumulation).  Not rounded: statistics, the SE squeeze (taken from the unrounded bn2
+    output) and gate, parameter gradients, the taps and everything after them."""
+
+    def __enter__(self):
+        self.prev = _BF16_STORAGE[0]
+        _BF16_STORAGE[0] = True
+
+    def __exit__(self, *a):
+        _BF16_STORAGE[0] = self.prev
+
+
+def _st(x):
+    return _StoreBf16.apply(x) if _BF16_STORAGE[0] else x
+
+
+def _wq(w):
+    return _WeightBf16.apply(w) if _BF16_STORAGE[0] else w
+
+
+def _gr(x):
+    return _GradBf16.apply(x) if _BF16_STORAGE[0] else x
+
+
 def se_block(x, sd, p, stride, has_down, update_bn=True):
-    """model/ResNetBlocks.py:21-37: conv -> ReLU -> BN -> conv -> BN -> SE -> (+residual) -> ReLU."""
-    out = F.conv2d(x, sd[p + 'conv1.weight'], None, stride=stride, padding=1)
-    out = batch_norm_train(torch.relu(out), sd, p + 'bn1.', update=update_bn)
-    out = F.conv2d(out, sd[p + 'conv2.weight'], None, padding=1)
-    out = batch_norm_train(out, sd, p + 'bn2.', update=update_bn)
+    """model/ResNetBlocks.py:21-37: conv -> ReLU -> BN -> conv -> BN -> SE -> (+residual) -> ReLU.  (_st / _wq are identities unless the
+    bf16-storage rounding points are switched on, see bf16_storage.)"""
+    # bf16 storage: a first block's conv1 data gradient is stored (rounded) before the downsample branch's is added onto it
+    out = F.conv2d(_gr(x) if has_down else x, _wq(sd[p + 'conv1.weight']), None, stride=stride, padding=1)
+    out = _st(batch_norm_train(_st(torch.relu(out)), sd, p + 'bn1.', update=update_bn))
+    out = _st(F.conv2d(out, _wq(sd[p + 'conv2.weight']), None, padding=1))
+    # bf16 storage: bn2's output is stored rounded, the squeeze is taken from the unrounded values of the same pass, and the gradient w.r.t.
+    # bn2's output (gate path + squeeze path) is rounded once, where it is stored
+    out = _gr(batch_norm_train(out, sd, p + 'bn2.', update=update_bn))
     y = out.mean((2, 3))                                             # ResNetBlocks.py:91-95
+    out = _wq(out)
     y = torch.relu(F.linear(y, sd[p + 'se.fc.0.weight'], sd[p + 'se.fc.0.bias']))
     y = torch.sigmoid(F.linear(y, sd[p + 'se.fc.2.weight'], sd[p + 'se.fc.2.bias']))
     out = out * y[:, :, None, None]
     if has_down:
-        x = F.conv2d(x, sd[p + 'downsample.0.weight'], None, stride=stride)
-        x = batch_norm_train(x, sd, p + 'downsample.1.', update=update_bn)
-    return torch.relu(out + x)
+        x = _st(F.conv2d(x, _wq(sd[p + 'downsample.0.weight']), None, stride=stride))
+        x = _st(batch_norm_train(x, sd, p + 'downsample.1.', update=update_bn))
+    return _st(torch.relu(out + x))
 
 
 def wav_encoder(spec, vid, sd, p, pose_level, update_bn=True):
@@ -123,13 +197,14 @@ def wav_encoder(spec, vid, sd, p, pose_level, update_bn=True):
     q = p + 'feat_extractor.'
     B = spec.shape[0]
     x = F.conv2d(spec.unsqueeze(1), sd[q + 'conv1.weight'], sd[q + 'conv1.bias'], padding=1)
-    x = batch_norm_train(torch.relu(x), sd, q + 'bn1.', update=update_bn)
+    x = _st(batch_norm_train(_st(torch.relu(x)), sd, q + 'bn1.', update=update_bn))
     feats = []
     for li, nblk in enumerate((3, 4, 6, 3)):
         for j in range(nblk):
             first = j == 0 and li > 0
             x = se_block(x, sd, '%slayer%d.%d.' % (q, li + 1, j), 2 if first else 1, first, update_bn)
         feats.append(x)
+        x = _gr(x)                 # bf16 storage: the next layer's data gradient is stored before the tap's gradient is added onto it
 
     low = wav_tap(feats[1], sd, q, 'low', 1, update_bn)
     mid = wav_tap(feats[2], sd, q, 'mid', 2, update_bn)
