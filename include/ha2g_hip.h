@@ -77,6 +77,16 @@ int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const voi
  * multiples of 64): every pixel of x and dy goes global -> LDS once per 64 x 64 block of dW (the nine taps share the staged patch); fp32
  * accumulation per workgroup, the workgroups' partial slabs (ws >= ..._workspace_bytes) are added in double.  Autograd's conv2d backward w.r.t.
  * the weight (model/ResNetBlocks.py:24-29). */
+/* Data-parallel gradient exchange without torch.distributed (csrc/comm.hip): RCCL behind plain pointers, one process per GPU.  Rank 0 fills
+ * a 128-byte id (host memory) and hands it to the other ranks; every rank calls ha2g_comm_init on its own device (collective); the flat fp32
+ * gradient buffers then go through ha2g_allreduce_bucket in place on the caller's stream (average = 1: mean over ranks).  RCCL is resolved
+ * with dlopen("librccl.so.1") at the first call -- ha2g_comm_available() = 0 when it is absent.  Replaces nn.DataParallel, scripts/train.py:133-143. */
+int ha2g_comm_available(void);
+int ha2g_comm_unique_id(void* id128);
+int ha2g_comm_init(const void* id128, int rank, int world, void** comm);
+int ha2g_comm_world(void* comm);
+int ha2g_allreduce_bucket(void* comm, float* buf, long n, int average, void* stream);
+int ha2g_comm_destroy(void* comm);
 /* bf16-storage mode (BASELINE config 5, bench.py --bf16): x / y / dy / dx are bf16 tensors in HBM, w bf16 [Cout][KH][KW][Cin], wt bf16
  * [Cin][KH][KW][Cout] (= the hi plane of ha2g_conv2d_weight_ihwo_planes); fp32 accumulation; 3x3 / pad 1 or 1x1 / pad 0, stride 1 or 2,
  * channel counts multiples of 32 (nn.Conv2d and its backward w.r.t. the input, model/ResNetBlocks.py:24-29, model/ResNetSE34V2.py:96-116) */

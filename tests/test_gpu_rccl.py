@@ -116,3 +116,35 @@ def test_single_rank_rccl_group():
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     p = subprocess.run([sys.executable, '-c', CHILD % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and 'RCCL_OK' in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+
+
+def test_c_abi_allreduce_bucket_world_size_1():
+    """The C-ABI's own collective entry points (csrc/comm.hip, for hosts without torch.distributed): id -> communicator -> in-place mean /
+    sum all-reduce of a flat gradient bucket on the caller's stream -> destroy.  One rank is all a one-GPU box allows (RCCL refuses two
+    ranks on one device); what is pinned here is the binding itself: RCCL resolved by dlopen, the handle round trip, stream ordering,
+    and that a world of one leaves the bucket bit-identical under both reductions."""
+    import ctypes
+    from ha2g_amd._lib import check, lib
+    assert lib.ha2g_comm_available() == 1
+    idb = ctypes.create_string_buffer(128)
+    check(lib.ha2g_comm_unique_id(ctypes.addressof(idb)))
+    assert any(idb.raw)
+    comm = ctypes.c_void_p()
+    torch.cuda.set_device(0)
+    check(lib.ha2g_comm_init(ctypes.addressof(idb), 0, 1, ctypes.addressof(comm)))
+    try:
+        assert comm.value and lib.ha2g_comm_world(comm.value) == 1
+        st = torch.cuda.Stream()
+        x = torch.randn((1 << 20) + 3, device='cuda:0')
+        ref = x.clone()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            x.mul_(2.0)                                                          # ordered before the collective on the same stream
+            check(lib.ha2g_allreduce_bucket(comm.value, x.data_ptr(), x.numel(), 1, st.cuda_stream))
+            check(lib.ha2g_allreduce_bucket(comm.value, x.data_ptr(), x.numel(), 0, st.cuda_stream))
+            check(lib.ha2g_allreduce_bucket(comm.value, x.data_ptr(), 0, 0, st.cuda_stream))
+        st.synchronize()
+        assert torch.equal(x, ref * 2.0)
+        assert lib.ha2g_allreduce_bucket(0, x.data_ptr(), 4, 0, st.cuda_stream) != 0    # a null communicator is an error, not a crash
+    finally:
+        check(lib.ha2g_comm_destroy(comm.value))
