@@ -142,13 +142,24 @@ def main():
                               ipc_legacy=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))), flush=True)
         return
     assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
+    # HA2G_BENCH_REHEARSAL=1: all N ranks share cuda:0 and talk over gloo (device tensors staged through the host by ha2g_amd.ddp) -- a
+    # rehearsal of this script's multi-rank control flow (rank spawn, broadcast, barriers, in-step collectives, MAX over ranks, rccl_world)
+    # on a one-GPU box, where RCCL refuses two ranks on one device.  NOT a measurement: the line says `rehearsal: true`.
+    rehearsal = os.environ.get('HA2G_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     from ha2g_amd import ops, procedural as proc
+    if rehearsal and world > 1:
+        ops.USE_GRU_CLUSTER = False                       # cluster launches of two processes on one GPU cannot both be fully co-resident
     if os.environ.get('HA2G_DEBUG_CFG'):
         from ha2g_amd._lib import lib as _l
         _l.ha2g_conv_debug_cfg(int(os.environ['HA2G_DEBUG_CFG']))
@@ -358,7 +369,7 @@ def main():
                    dtype=(('bf16 (matrix operands; audio-trunk activations and activation gradients stored as bf16; fp32 accumulate, fp32 statistics, fp32 master weights and optimizer)'
                            if b16_storage else 'bf16 (operands; fp32 accumulate, fp32 storage and master weights)') if a.bf16 else
                           'f32 (storage, accumulation, forward products: fp32 MFMA; backward products: bf16x2 split = 16-bit operand mantissa, fp32 accumulate)'),
-                   data='synthetic', launch=launch, launch_note=graph_note, rccl_world=rccl_world, eager=eager,
+                   data='synthetic', rehearsal=rehearsal, launch=launch, launch_note=graph_note, rccl_world=rccl_world, eager=eager,
                    matrix_core=('bf16 operands (1 MFMA per product), fp32 accumulate, fp32 storage and master weights; GRU recurrences fp32' if a.bf16 else
                                 'forward: fp32 MFMA; backward GEMMs/convs/BPTT: 2-piece split-bf16 (hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; 4e-6 rms-rel per GEMM vs 4e-7 for fp32 MFMA); '
                                 'the fp32-arithmetic number is exact_fp32_matrix_core'),

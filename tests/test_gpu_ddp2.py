@@ -181,3 +181,25 @@ def test_cluster_gru_beside_foreign_resident_work_completes_or_flags():
     p = subprocess.run([sys.executable, '-c', SOAK % dict(root=ROOT)], env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and 'SOAK_OK' in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
     print(p.stdout.strip().splitlines()[-1])
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """`bench.py --gpus 2` end to end -- the command the driver runs on a multi-GPU node -- rehearsed on ONE GPU (HA2G_BENCH_REHEARSAL=1:
+    both ranks on cuda:0, gloo instead of RCCL): the script spawns its two rank processes, broadcasts the parameters, runs warm-up, timed,
+    roofline, warm-up-phase and exact-fp32 legs with the in-step collectives, takes the MAX over ranks and prints ONE JSON line from rank 0
+    whose collective-observed world size is 2 and whose value is the sum over both ranks.  Not a measurement (the line says so)."""
+    import json
+    env = dict(os.environ, HA2G_BENCH_REHEARSAL='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '16',
+                        '--n-words', '300', '--n-spk', '11', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['rccl_world'] == 2 and d['rehearsal'] is True and d['launch'] == 'eager'
+    assert d['config']['global_batch'] == 32 and d['config']['parallelism'] == 'dp2'
+    assert abs(d['value'] - 2 * 16 * 34 / (d['ms_per_step'] * 1e-3)) <= 1e-3 * d['value']
+    for k in ('exact_fp32_matrix_core', 'warmup_phase', 'eager', 'roofline'):
+        assert d[k] is not None
+    assert all(v == v for v in d['last_step'].values())

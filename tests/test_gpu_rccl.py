@@ -124,6 +124,7 @@ def test_c_abi_allreduce_bucket_world_size_1():
     ranks on one device); what is pinned here is the binding itself: RCCL resolved by dlopen, the handle round trip, stream ordering,
     and that a world of one leaves the bucket bit-identical under both reductions."""
     import ctypes
+    import torch
     from ha2g_amd._lib import check, lib
     assert lib.ha2g_comm_available() == 1
     idb = ctypes.create_string_buffer(128)
