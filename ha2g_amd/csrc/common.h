@@ -30,6 +30,7 @@ int conv3x3_c32_launch(const float* x, const float* w, float* y, int N, int H, i
 int conv3x3_c32_x3_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta,
                           hipStream_t st);
 int gemm_split_dgrad_enabled();      // gemm.hip: ha2g_gemm_set_mode bit 2 (and not the plain-bf16 mode)
+extern int g_side_cus;      // conv_planes.hip: ha2g_side_cus
 int conv3x3_c32_wgrad_blocks(int N, int H, int W);
 int conv3x3_c32_wgrad_launch(const float* x, const float* dy, float* part, int N, int H, int W, hipStream_t st);
 int conv3x3_c32_wgrad_b16_launch(const void* x, const void* dy, float* part, int N, int H, int W, hipStream_t st);

@@ -555,6 +555,7 @@ int conv3x3_c32_wgrad_blocks(int N, int H, int W) {
     int cus = 256;
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) { int c = 0; if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) cus = c; }
+    if (cus > g_side_cus) cus = g_side_cus;
     return (int)(tiles < 2L * cus ? tiles : 2L * cus);
 }
 template <typename T>

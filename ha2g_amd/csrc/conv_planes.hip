@@ -84,20 +84,32 @@ __device__ __forceinline__ void ptile_of_block(int& bx, int& by) {
 // Implicit GEMM over planes, blockIdx.z = parity class (PClass):
 //   data gradient (p.fwd = 0):  dx[m][n] (+)= sum_{tap, co} dy[src(m, tap)][co] * wt[n][tap][co]      (stride 1 or 2)
 //   forward       (p.fwd = 1):  y[m][n]   =   sum_{tap, ci} x[pix(m) * stride - pad + tap][ci] * w[n][tap][ci]   (one class: every tap)
-// BM x BN output tile, 4 waves as WM x WN, wave tile (32 MI) x (32 NI), k tile = 32 channels of one filter tap, two LDS buffers,
-// one barrier per k tile: the next tile's DMA is issued before the current tile's MFMAs and waited for after them.
+// BM x BN output tile, 4 waves as WM x WN, wave tile (32 MI) x (32 NI), k tile = 32 channels of one filter tap, a RING of S LDS buffers and
+// one barrier per k tile: tile kt + S - 1 is requested right after the barrier that retires tile kt - 1's buffer, so S - 1 tiles of DMA are in
+// flight under a tile's MFMAs and the wait in front of a tile is a COUNTED `s_waitcnt vmcnt((S - 2) * loads per stage)` (every wave issues the
+// same number of DMA instructions per stage), not a drain.  S = 2 is the round-3 first version (one tile ahead; two 64 KB workgroups per
+// CU); the L2 -> LDS round trip under load (>= 1 us) is 2-3x a tile's 0.3 us of MFMAs, which is what S = 3 / 4 (one workgroup per CU) cover.
 // NP = 2: hi + lo planes, three MFMAs per product (fp32-class, the default backward).  NP = 1: the operands ARE bf16 tensors (bf16-storage mode of
 // BASELINE config 5, `--bf16`): one plane, one MFMA.  OUT = 0: fp32 output (beta-accumulate); OUT = 1: bf16 output (optional ReLU, beta-accumulate).
-template <int BM, int BN, int WM, int WN, int NP, int OUT>
+template <int N_> __device__ __forceinline__ void wait_vm_lds_barrier() {
+    // this wave's DMA older than the newest N_ instructions has landed, its LDS reads are complete; then the workgroup barrier.  The "memory"
+    // clobber keeps the compiler's LDS accesses on their side of it (a bare __builtin_amdgcn_s_barrier() does not).
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N_) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int NP, int OUT, int S>
 __global__ __launch_bounds__(256) void pconv_kernel(PConvP p) {
     static_assert(WM * WN == 4, "four waves");
+    static_assert(S >= 2 && S <= 4, "ring depth");
     constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);
     constexpr int RA = BM / 16, RB = BN / 16;                    // 16-row DMA pieces (1 KiB per wave instruction) per plane
     static_assert(RA % 4 == 0 && RB % 4 == 0, "every wave stages whole row blocks");
     constexpr int NA = RA / 4, NB = RB / 4;                      // row blocks per wave, per plane
     constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;          // bytes
     constexpr int BUF = NP * (PLANE_A + PLANE_B);
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
+    constexpr int LPS = NP * (NA + NB);                          // DMA instructions per wave and stage
+    static_assert((S - 2) * LPS <= 63, "vmcnt field");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];      // S * BUF bytes
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -184,11 +196,16 @@ __global__ __launch_bounds__(256) void pconv_kernel(PConvP p) {
     const int sw = (l31 >> 2) & 3;                               // swizzle of this lane's fragment rows (row = 32 * tile + l31)
     const int a_row_off = (wm * 32 * MI + l31) * 64, b_row_off = (wn * 32 * NI + l31) * 64;
 
-    stage(0, 0);
-    __syncthreads();                                             // with a DMA in flight the fence of __syncthreads() carries vmcnt(0): tile 0 has landed
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+        if (s < nk) stage(s, s);
+    int cur = 0, nxt = S - 1;                                    // ring slots of tile kt and of tile kt + S - 1
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk && !(p.dbg & 1)) stage(kt + 1, cur ^ 1);
+        // tile kt has landed in every wave (S - 2 newer stages may still be in flight; near the tail fewer were issued: drain) and every
+        // wave has finished reading tile kt - 1, whose slot the request below overwrites
+        if (kt + S - 2 < nk) wait_vm_lds_barrier<(S - 2) * LPS>();
+        else wait_vm_lds_barrier<0>();
+        if (kt + S - 1 < nk && !(p.dbg & 1)) stage(kt + S - 1, nxt);
         const unsigned char* ab = smem + cur * BUF + a_row_off;
         const unsigned char* bb = smem + cur * BUF + NP * PLANE_A + b_row_off;
 #pragma unroll
@@ -223,10 +240,8 @@ __global__ __launch_bounds__(256) void pconv_kernel(PConvP p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
-        // vmcnt(0) + lgkmcnt(0) + barrier: the next tile has landed in every wave and every wave's reads of this one have completed.  (A raw
-        // s_barrier is not a fence for the compiler: it sank this tile's second half of ds_reads below it.)  The MFMAs of the last k chunk
-        // are register-only and may still be scheduled past the barrier, where they overlap the next tile's address arithmetic.
-        __syncthreads();
+        cur = cur + 1 == S ? 0 : cur + 1;
+        nxt = nxt + 1 == S ? 0 : nxt + 1;
     }
 
     // ---- epilogue: C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
@@ -447,6 +462,7 @@ __global__ __launch_bounds__(768) void pconv_wgrad_kernel(PWgradP p) {
         }
 }
 
+#define HA2G_PCONV_RING_DEFAULT 2
 static int g_pdbg = 0;
 static int g_planes = 1;         // ha2g_conv_planes_enable: 0 = callers keep the round-2 kernels (A/B switch, HA2G_PLANES=0)
 
@@ -455,6 +471,8 @@ static int g_planes = 1;         // ha2g_conv_planes_enable: 0 = callers keep th
 // Partials of the plane-based weight gradient: returns the number of dW-shaped slabs written to `part` (the caller reduces them),
 // -100 when the geometry is not served (caller keeps the implicit GEMM), < 0 on error.
 static int pwgrad_tile(int HW) { return (HW % 64 != 0 && HW % 48 == 0) ? 48 : 64; }
+int g_side_cus = 256;      // persistent weight-gradient kernels (side stream) size their grids for at most this many compute units
+
 int pconv_wgrad_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     if (!(g_planes && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % 32 == 0 && Cout % 32 == 0 && (long)H * W >= 16)) return 0;
     const int wt = pwgrad_tile(H * W);
@@ -483,6 +501,7 @@ int pconv_wgrad_launch(const void* x_hi, const void* x_lo, const void* dy_hi, co
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) { int c = 0; if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) cus = c; }
     if (cus > 256) cus = 256;                                   // the workspace query assumes at most 256 chunks x pairs
+    if (cus > g_side_cus) cus = g_side_cus;                     // ha2g_side_cus: leave compute units to the main queue's kernels
     long nchunks = cus / npairs < 1 ? 1 : cus / npairs;
     if (nchunks > tiles) nchunks = tiles;
     p.tiles_per_chunk = (int)((tiles + nchunks - 1) / nchunks);
@@ -538,15 +557,35 @@ static int dgrad_classes(PConvP& p, int N, int H, int W, int KH, int KW, int str
     return maxM;
 }
 // tile choice by the output width: 128 x 128 when N is a multiple of 128, else 256 x 64 (N = 32: the upper half of the column tile idles)
-template <int NP, int OUT>
-static void pconv_dispatch(const PConvP& p, int maxM, hipStream_t st) {
-    if (p.N % 128 == 0) {
-        dim3 grid(ceil_div(maxM, 128), p.N / 128, p.ncls);
-        hipLaunchKernelGGL((pconv_kernel<128, 128, 2, 2, NP, OUT>), grid, dim3(256), 0, st, p);
-    } else {
-        dim3 grid(ceil_div(maxM, 256), ceil_div(p.N, 64), p.ncls);
-        hipLaunchKernelGGL((pconv_kernel<256, 64, 4, 1, NP, OUT>), grid, dim3(256), 0, st, p);
+static int g_ring = 0;       // ha2g_conv_planes_ring: 0 = default depth per tile shape, 2 / 3 / 4 = forced (A/B)
+
+template <int BM, int BN, int WM, int WN, int NP, int OUT, int S>
+static int pconv_launch_s(const PConvP& p, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)S * NP * (BM * 64 + BN * 64);
+    static bool attr_set = false;                                // per instantiation
+    if (!attr_set) {
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_kernel<BM, BN, WM, WN, NP, OUT, S>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ha2g_set_error(-2, "pconv: cannot raise the dynamic LDS limit to %zu bytes", lds);
+        attr_set = true;
     }
+    hipLaunchKernelGGL((pconv_kernel<BM, BN, WM, WN, NP, OUT, S>), grid, dim3(256), lds, st, p);
+    return 0;
+}
+template <int BM, int BN, int WM, int WN, int NP, int OUT>
+static int pconv_launch(const PConvP& p, dim3 grid, hipStream_t st) {
+    constexpr int per_stage = NP * (BM * 64 + BN * 64);
+    constexpr int SMAX = 160 * 1024 / per_stage >= 4 ? 4 : (160 * 1024 / per_stage >= 3 ? 3 : 2);
+    int s = g_ring ? g_ring : HA2G_PCONV_RING_DEFAULT;
+    if (s > SMAX) s = SMAX;
+    if (s >= 4) { if constexpr (SMAX >= 4) return pconv_launch_s<BM, BN, WM, WN, NP, OUT, 4>(p, grid, st); }
+    if (s == 3) { if constexpr (SMAX >= 3) return pconv_launch_s<BM, BN, WM, WN, NP, OUT, 3>(p, grid, st); }
+    return pconv_launch_s<BM, BN, WM, WN, NP, OUT, 2>(p, grid, st);
+}
+template <int NP, int OUT>
+static int pconv_dispatch(const PConvP& p, int maxM, hipStream_t st) {
+    if (p.N % 128 == 0) return pconv_launch<128, 128, 2, 2, NP, OUT>(p, dim3(ceil_div(maxM, 128), p.N / 128, p.ncls), st);
+    return pconv_launch<256, 64, 4, 1, NP, OUT>(p, dim3(ceil_div(maxM, 256), ceil_div(p.N, 64), p.ncls), st);
 }
 
 
@@ -554,6 +593,7 @@ extern "C" {
 
 void ha2g_conv_planes_enable(int on) { g_planes = on; }
 void ha2g_conv_planes_debug(int bits) { g_pdbg = bits; }
+void ha2g_conv_planes_ring(int depth) { g_ring = depth; }
 
 // fp32 -> (hi, lo) bf16 planes of the same shape; n % 4 == 0, 16-byte aligned
 int ha2g_f32_to_planes(const float* x, void* hi, void* lo, long n, void* stream) {
@@ -602,7 +642,7 @@ int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const voi
     p.dbg = g_pdbg;
     if ((long)N * H * W == 0) return 0;
     const int maxM = dgrad_classes(p, N, H, W, KH, KW, stride, pad, OWd);
-    pconv_dispatch<2, 0>(p, maxM, (hipStream_t)stream);
+    if (int rc = pconv_dispatch<2, 0>(p, maxM, (hipStream_t)stream)) return rc;
     HA2G_CHECK_LAUNCH("conv2d_dgrad_planes");
     return 0;
 }
@@ -611,6 +651,10 @@ int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const voi
 //      convolutions read them as they are (one plane, one MFMA per product, fp32 accumulate) and write bf16.  3x3 / pad 1, 1x1 / pad 0,
 //      stride 1 or 2, channel counts multiples of 32.  Replaces nn.Conv2d and its autograd backward (model/ResNetBlocks.py:24-29,
 //      model/ResNetSE34V2.py:96-116) in that mode. ----
+// Tuning knob: the persistent weight-gradient kernels of the side stream (plane kernel, direct 32-channel kernel) launch at most one (two)
+// workgroup(s) per compute unit on `n` units instead of all of them, so that the main queue's bandwidth-bound passes find free units.
+void ha2g_side_cus(int n) { g_side_cus = n < 8 ? 8 : (n > 256 ? 256 : n); }
+
 int ha2g_conv2d_b16_supported(int Cin, int Cout, int KH, int KW, int stride, int pad) {
     const bool geom = (KH == 3 && KW == 3 && pad == 1) || (KH == 1 && KW == 1 && pad == 0);
     return geom && (stride == 1 || stride == 2) && Cin % 32 == 0 && Cout % 32 == 0;
@@ -632,7 +676,7 @@ int ha2g_conv2d_fwd_b16(const void* x, const void* w, void* y, int N, int H, int
         for (int kw = 0; kw < KW; ++kw) { c.tap[c.ntaps] = kh * KW + kw; c.doff[c.ntaps] = kh * W + kw; ++c.ntaps; }
     p.ncls = 1; p.cls[0] = c;
     if (c.M == 0) return 0;
-    pconv_dispatch<1, 1>(p, c.M, (hipStream_t)stream);
+    if (int rc = pconv_dispatch<1, 1>(p, c.M, (hipStream_t)stream)) return rc;
     HA2G_CHECK_LAUNCH("conv2d_fwd_b16");
     return 0;
 }
@@ -650,7 +694,7 @@ int ha2g_conv2d_dgrad_b16(const void* dy, const void* wt, void* dx, int N, int H
     p.dbg = g_pdbg;
     if ((long)N * H * W == 0) return 0;
     const int maxM = dgrad_classes(p, N, H, W, KH, KW, stride, pad, OWd);
-    pconv_dispatch<1, 1>(p, maxM, (hipStream_t)stream);
+    if (int rc = pconv_dispatch<1, 1>(p, maxM, (hipStream_t)stream)) return rc;
     HA2G_CHECK_LAUNCH("conv2d_dgrad_b16");
     return 0;
 }

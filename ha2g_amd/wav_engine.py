@@ -211,6 +211,10 @@ import os as _os
 PLANES = int(_os.environ.get('HA2G_PLANES', '11'))
 SIDE_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_WGRAD', '1') != '0'
 # bf16-storage mode of the trunk (BASELINE config 5; wav_b16.py): opt-in -- HA2G_B16=1, set_b16(True) or bench.py --bf16
+if _os.environ.get('HA2G_PCONV_RING'):
+    lib.ha2g_conv_planes_ring(int(_os.environ['HA2G_PCONV_RING']))      # A/B: LDS ring depth of the plane convolution kernel
+if _os.environ.get('HA2G_SIDE_CUS'):
+    lib.ha2g_side_cus(int(_os.environ['HA2G_SIDE_CUS']))      # tuning: compute units the side stream's persistent weight-gradient kernels occupy
 B16 = [_os.environ.get('HA2G_B16', '0') == '1']
 
 

@@ -90,6 +90,8 @@ int ha2g_comm_destroy(void* comm);
 /* bf16-storage mode (BASELINE config 5, bench.py --bf16): x / y / dy / dx are bf16 tensors in HBM, w bf16 [Cout][KH][KW][Cin], wt bf16
  * [Cin][KH][KW][Cout] (= the hi plane of ha2g_conv2d_weight_ihwo_planes); fp32 accumulation; 3x3 / pad 1 or 1x1 / pad 0, stride 1 or 2,
  * channel counts multiples of 32 (nn.Conv2d and its backward w.r.t. the input, model/ResNetBlocks.py:24-29, model/ResNetSE34V2.py:96-116) */
+void ha2g_side_cus(int n);
+void ha2g_conv_planes_ring(int depth);   /* A/B: LDS ring depth of the plane convolution kernel (0 = default, 2..4) */
 int ha2g_conv2d_b16_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
 int ha2g_conv2d_fwd_b16(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
                         void* stream);

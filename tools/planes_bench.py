@@ -4,6 +4,7 @@ import sys
 import torch
 sys.path.insert(0, '.')
 from ha2g_amd import ops, wav_engine as we
+from ha2g_amd._lib import lib
 
 dev = torch.device('cuda:0')
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
@@ -38,6 +39,14 @@ for H, W, C in ((64, 35, 64), (32, 18, 128), (16, 9, 256)):
     mo, mn = to[len(to) // 2], tn[len(tn) // 2]
     fl = 2.0 * B * H * W * C * C * 9
     print('dgrad C=%-3d %3dx%-3d          %10.1f %10.1f %8.2f %10.1f %8.3f' % (C, H, W, mo, mn, mo / mn, fl / mn / 1e6, fl / mn / 1e6 / 833.0))
+    ref = new().clone()
+    for depth in (2, 3, 4):                                  # LDS ring depth of the plane kernel (ha2g_conv_planes_ring); 0 = default
+        lib.ha2g_conv_planes_ring(depth)
+        assert torch.equal(new(), ref), depth
+        new(); torch.cuda.synchronize()
+        ts_ = sorted(t_us(new) for _ in range(rounds))
+        print('      ring depth %d: %8.1f us' % (depth, ts_[len(ts_) // 2]))
+    lib.ha2g_conv_planes_ring(0)
 print()
 print('%-28s %10s %10s %8s %10s %8s' % ('shape', 'old us', 'planes us', 'ratio', 'TF(f32eq)', 'of 833'))
 for H, W, C in ((64, 35, 64), (32, 18, 128), (16, 9, 256)):
