@@ -225,6 +225,7 @@ def set_b16(on):
     return prev
 
 SIDE_FC_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_FC', '1') != '0'
+WGRAD_AFTER = _os.environ.get('HA2G_WGRAD_AFTER', '0') == '1'
 
 
 class GradSink:
@@ -399,16 +400,28 @@ def block_bwd(dx, saved, P, b, sink):
     f1 = not (p1 and wgrad_planes_ok(x, wa, stride, 1))
     dc2 = sink.gbn(b + 'bn2', _rows(db2), _rows(c2), m2, s2, planes=p2, need_dx=f2)
     dc2, dc2p = ((dc2[0].view(c2.shape) if f2 else None), dc2[1]) if p2 else (dc2.view(c2.shape), None)
-    sink.gconv(b + 'conv2.weight', a1, dc2, wb, 1, 1, dy_planes=dc2p, x_planes=a1p)
+    # WGRAD_AFTER: the side stream's weight gradient is forked AFTER the data gradient of the same convolution has been enqueued, so that it
+    # runs beside the bandwidth-bound BatchNorm-backward passes that follow instead of beside the (L2 -> LDS bound) data gradient
+    if not WGRAD_AFTER:
+        sink.gconv(b + 'conv2.weight', a1, dc2, wb, 1, 1, dy_planes=dc2p, x_planes=a1p)
     da1 = conv_dgrad_planes(dc2p, wb, a1.shape, 1, 1) if p2 else conv_dgrad(dc2, wb, a1.shape, 1, 1)
+    if WGRAD_AFTER:
+        sink.gconv(b + 'conv2.weight', a1, dc2, wb, 1, 1, dy_planes=dc2p, x_planes=a1p)
     dc1 = sink.gbn(b + 'bn1', _rows(da1), _rows(c1), m1, s1, relu_mask=True, planes=p1, need_dx=f1)
     dc1, dc1p = ((dc1[0].view(c1.shape) if f1 else None), dc1[1]) if p1 else (dc1.view(c1.shape), None)
-    sink.gconv(b + 'conv1.weight', x, dc1, wa, stride, 1, dy_planes=dc1p, x_planes=xp)
+    if not WGRAD_AFTER:
+        sink.gconv(b + 'conv1.weight', x, dc1, wa, stride, 1, dy_planes=dc1p, x_planes=xp)
     if cd is None:                                                              # identity shortcut: accumulate onto d(residual)
         if p1:
-            return conv_dgrad_planes(dc1p, wa, x.shape, stride, 1, out=dres, beta=1.0)
-        return conv_dgrad(dc1, wa, x.shape, stride, 1, out=dres, beta=1.0)
+            r = conv_dgrad_planes(dc1p, wa, x.shape, stride, 1, out=dres, beta=1.0)
+        else:
+            r = conv_dgrad(dc1, wa, x.shape, stride, 1, out=dres, beta=1.0)
+        if WGRAD_AFTER:
+            sink.gconv(b + 'conv1.weight', x, dc1, wa, stride, 1, dy_planes=dc1p, x_planes=xp)
+        return r
     dxin = conv_dgrad_planes(dc1p, wa, x.shape, stride, 1) if p1 else conv_dgrad(dc1, wa, x.shape, stride, 1)
+    if WGRAD_AFTER:
+        sink.gconv(b + 'conv1.weight', x, dc1, wa, stride, 1, dy_planes=dc1p, x_planes=xp)
     wd = _ohwi(P[b + 'downsample.0.weight'])
     pd = dgrad_planes_ok(wd, 2, 0)
     dcd = sink.gbn(b + 'downsample.1', _rows(dres), _rows(cd), md, sd, planes=pd)
