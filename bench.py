@@ -267,7 +267,7 @@ def main():
     # ROCm 7.0.2) -- a crash there would lose the whole line, so exactly ONE capture per process is made, the headline's.
     timed = lambda ep, n: timed_eager(ep, n)
     launch2 = 'eager'
-    ms_warm = ms_exact = float('nan')
+    ms_warm = ms_exact = ms_m2 = float('nan')
     if not a.primary_only:
         for _ in range(2):
             tr.train_iter(0, text, spec, target, vid)
@@ -276,6 +276,11 @@ def main():
         for _ in range(2):
             tr.train_iter(a.epoch, text, spec, target, vid)
         ms_exact = timed(a.epoch, a.steps)[0] / a.steps * 1e3
+        if not a.bf16:
+            _lib.ha2g_gemm_set_mode(2)                   # exact fp32 on everything that compounds (forward + data gradients); weight gradients split-bf16
+            for _ in range(2):
+                tr.train_iter(a.epoch, text, spec, target, vid)
+            ms_m2 = timed(a.epoch, a.steps)[0] / a.steps * 1e3
         _lib.ha2g_gemm_set_mode(default_mode)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -379,6 +384,8 @@ def main():
                                 'the fp32-arithmetic number is exact_fp32_matrix_core'),
                    exact_fp32_matrix_core=dict(ms_per_step=round(ms_exact, 3), value=round(a.batch * 34 * world / (ms_exact * 1e-3), 1), steps=a.steps, launch=launch2,
                                                arithmetic='every matrix product on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 (exact fp32, the reference\'s arithmetic class)'),
+                   fp32_data_path=dict(ms_per_step=round(ms_m2, 3), value=round(a.batch * 34 * world / (ms_m2 * 1e-3), 1), steps=a.steps, launch=launch2,
+                                       arithmetic='ha2g_gemm_set_mode(2): forward AND data-gradient products (everything an error can compound through) on the exact fp32 MFMA; only the weight-gradient products, which go straight to the optimizer, on the 2-piece split-bf16'),
                    warmup_phase=dict(ms_per_step=round(ms_warm, 3), value=round(a.batch * 34 * world / (ms_warm * 1e-3), 1), steps=a.steps, launch=launch2),
                    config=dict(workload='%s hierarchy train step, B=%d per GPU, T=34, %d-d pose, '
                                         'spec (128,70), n_words=%d, n_spk=%d, dropout 0.3, %s' % (
@@ -389,7 +396,15 @@ def main():
                    gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, roofline_bwd=roof_bwd, roofline_gemm=roof_gemm, roofline_conv=roof_conv, roofline_bwd_gemm=roof_bwd_gemm, roofline_bwd_wgrad=roof_bwd_wgrad, roofline_bn=roof_bn, roofline_bn_stats=roof_bn_stats, roofline_pass='separate untimed pass of %d eager steps, HIP events around each launch on its launch stream' % k_roof, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
         if world == 1 and not a.no_cpu_baseline and not a.expressive:
             out['cpu_baseline'] = cpu_baseline(a.epoch, a.n_words, a.n_spk)
-        print(json.dumps(out))
+        def _clean(o):                                   # NaN (a leg that was not run) is not JSON: null instead
+            if isinstance(o, float) and o != o:
+                return None
+            if isinstance(o, dict):
+                return {k: _clean(v) for k, v in o.items()}
+            if isinstance(o, (list, tuple)):
+                return [_clean(v) for v in o]
+            return o
+        print(json.dumps(_clean(out)))
     if world > 1:
         dist.destroy_process_group()
 
