@@ -32,10 +32,13 @@ for B in (128, 512):
         out = torch.empty(B, H, W, C, device=dev)
         fn = lambda: lib.ha2g_conv2d_dgrad_planes_f32(pl[0].data_ptr(), pl[1].data_ptr(), wh.data_ptr(), wl.data_ptr(), out.data_ptr(), B, H, W, C, C, 3, 3,
                                                       1, 1, 0.0, torch.cuda.current_stream().cuda_stream)
-        ts = []
-        for bits in (0, 1, 2, 3):
-            lib.ha2g_conv_planes_debug(bits)
-            ts.append(t_us(fn))
-        lib.ha2g_conv_planes_debug(0)
-        fl = 2.0 * B * H * W * C * C * 9
-        print('B=%-3d C=%-3d %3dx%-3d        %9.1f %9.1f %9.1f %9.1f   %.1f' % (B, C, H, W, ts[0], ts[1], ts[2], ts[3], fl / ts[0] / 1e6))
+        for ring in (2, 3, 4):                           # LDS ring depth (ha2g_conv_planes_ring)
+            lib.ha2g_conv_planes_ring(ring)
+            ts = []
+            for bits in (0, 1, 2, 3):
+                lib.ha2g_conv_planes_debug(bits)
+                ts.append(t_us(fn))
+            lib.ha2g_conv_planes_debug(0)
+            fl = 2.0 * B * H * W * C * C * 9
+            print('B=%-3d C=%-3d %3dx%-3d ring %d %9.1f %9.1f %9.1f %9.1f   %.1f' % (B, C, H, W, ring, ts[0], ts[1], ts[2], ts[3], fl / ts[0] / 1e6))
+        lib.ha2g_conv_planes_ring(0)
