@@ -98,13 +98,15 @@ template <int N_> __device__ __forceinline__ void wait_vm_lds_barrier() {
 }
 
 template <int BM, int BN, int WM, int WN, int NP, int OUT, int S>
-__global__ __launch_bounds__(256) void pconv_kernel(PConvP p) {
-    static_assert(WM * WN == 4, "four waves");
+__global__ __launch_bounds__(64 * WM * WN) void pconv_kernel(PConvP p) {
+    constexpr int NWV = WM * WN;                                 // 4 waves, or 8 (two per SIMD, twice the tile: ha2g_conv_planes_waves)
+    static_assert(NWV == 4 || NWV == 8, "four or eight waves");
     static_assert(S >= 2 && S <= 4, "ring depth");
     constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);
     constexpr int RA = BM / 16, RB = BN / 16;                    // 16-row DMA pieces (1 KiB per wave instruction) per plane
-    static_assert(RA % 4 == 0 && RB % 4 == 0, "every wave stages whole row blocks");
-    constexpr int NA = RA / 4, NB = RB / 4;                      // row blocks per wave, per plane
+    static_assert(RA % NWV == 0 && (RB % NWV == 0 || NWV % RB == 0), "every wave stages whole row blocks");
+    constexpr int NA = RA / NWV, NB = (RB + NWV - 1) / NWV;      // row blocks per wave, per plane (RB < NWV: waves rb and rb + RB stage the same
+                                                                 // block -- identical bytes to the same LDS address, every wave issues NB requests)
     constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;          // bytes
     constexpr int BUF = NP * (PLANE_A + PLANE_B);
     constexpr int LPS = NP * (NA + NB);                          // DMA instructions per wave and stage
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void pconv_kernel(PConvP p) {
     long a_base[NA]; unsigned a_mask[NA]; int a_lc[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int row = (wave + 4 * i) * 16 + srow;
+        const int row = (wave + NWV * i) * 16 + srow;
         a_lc[i] = (lane & 3) ^ ((row >> 2) & 3);                  // logical 16-byte piece this lane fetches (its LDS slot is lane & 3)
         const int m = m0 + row;
         a_mask[i] = 0u; a_base[i] = 0;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void pconv_kernel(PConvP p) {
     long b_off[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int row = (wave + 4 * i) * 16 + srow;
+        const int row = ((wave + NWV * i) % RB) * 16 + srow;
         const int lc = (lane & 3) ^ ((row >> 2) & 3);
         const int n = n0 + row;
         b_off[i] = n < p.N ? (long)n * p.K + lc * 8 : -1;
@@ -171,16 +173,17 @@ __global__ __launch_bounds__(256) void pconv_kernel(PConvP p) {
         for (int i = 0; i < NA; ++i) {
             const bool on = (a_mask[i] & bit) != 0u;
             const long o = a_base[i] + koff;
-            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.a_hi + o : zero), (lds_ptr_t)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
-            if (NP == 2) __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.a_lo + o : zero), (lds_ptr_t)(dst + PLANE_A + (wave + 4 * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.a_hi + o : zero), (lds_ptr_t)(dst + (wave + NWV * i) * 1024), 16, 0, 0);
+            if (NP == 2) __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.a_lo + o : zero), (lds_ptr_t)(dst + PLANE_A + (wave + NWV * i) * 1024), 16, 0, 0);
         }
         const long kb = (long)pc.tap[ti] * p.GC + c0;             // k index of the weight planes: (tap, channel)
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const bool on = b_off[i] >= 0;
-            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.b_hi + b_off[i] + kb : zero), (lds_ptr_t)(dst + NP * PLANE_A + (wave + 4 * i) * 1024), 16, 0, 0);
+            const int rb = (wave + NWV * i) % RB;
+            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.b_hi + b_off[i] + kb : zero), (lds_ptr_t)(dst + NP * PLANE_A + rb * 1024), 16, 0, 0);
             if (NP == 2) __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.b_lo + b_off[i] + kb : zero),
-                                                          (lds_ptr_t)(dst + NP * PLANE_A + PLANE_B + (wave + 4 * i) * 1024), 16, 0, 0);
+                                                          (lds_ptr_t)(dst + NP * PLANE_A + PLANE_B + rb * 1024), 16, 0, 0);
         }
     };
 
@@ -569,7 +572,7 @@ static int pconv_launch_s(const PConvP& p, dim3 grid, hipStream_t st) {
             return ha2g_set_error(-2, "pconv: cannot raise the dynamic LDS limit to %zu bytes", lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((pconv_kernel<BM, BN, WM, WN, NP, OUT, S>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((pconv_kernel<BM, BN, WM, WN, NP, OUT, S>), grid, dim3(64 * WM * WN), lds, st, p);
     return 0;
 }
 template <int BM, int BN, int WM, int WN, int NP, int OUT>
@@ -582,8 +585,14 @@ static int pconv_launch(const PConvP& p, dim3 grid, hipStream_t st) {
     if (s == 3) { if constexpr (SMAX >= 3) return pconv_launch_s<BM, BN, WM, WN, NP, OUT, 3>(p, grid, st); }
     return pconv_launch_s<BM, BN, WM, WN, NP, OUT, 2>(p, grid, st);
 }
+static int g_waves = 4;      // ha2g_conv_planes_waves: 8 = eight-wave workgroups with twice the tile (256 x 128 / 512 x 64), one per CU
+
 template <int NP, int OUT>
 static int pconv_dispatch(const PConvP& p, int maxM, hipStream_t st) {
+    if (g_waves == 8) {
+        if (p.N % 128 == 0) return pconv_launch<256, 128, 4, 2, NP, OUT>(p, dim3(ceil_div(maxM, 256), p.N / 128, p.ncls), st);
+        return pconv_launch<512, 64, 8, 1, NP, OUT>(p, dim3(ceil_div(maxM, 512), ceil_div(p.N, 64), p.ncls), st);
+    }
     if (p.N % 128 == 0) return pconv_launch<128, 128, 2, 2, NP, OUT>(p, dim3(ceil_div(maxM, 128), p.N / 128, p.ncls), st);
     return pconv_launch<256, 64, 4, 1, NP, OUT>(p, dim3(ceil_div(maxM, 256), ceil_div(p.N, 64), p.ncls), st);
 }
@@ -594,6 +603,7 @@ extern "C" {
 void ha2g_conv_planes_enable(int on) { g_planes = on; }
 void ha2g_conv_planes_debug(int bits) { g_pdbg = bits; }
 void ha2g_conv_planes_ring(int depth) { g_ring = depth; }
+void ha2g_conv_planes_waves(int n) { g_waves = n == 8 ? 8 : 4; }
 
 // fp32 -> (hi, lo) bf16 planes of the same shape; n % 4 == 0, 16-byte aligned
 int ha2g_f32_to_planes(const float* x, void* hi, void* lo, long n, void* stream) {

@@ -91,6 +91,7 @@ int ha2g_comm_destroy(void* comm);
  * [Cin][KH][KW][Cout] (= the hi plane of ha2g_conv2d_weight_ihwo_planes); fp32 accumulation; 3x3 / pad 1 or 1x1 / pad 0, stride 1 or 2,
  * channel counts multiples of 32 (nn.Conv2d and its backward w.r.t. the input, model/ResNetBlocks.py:24-29, model/ResNetSE34V2.py:96-116) */
 void ha2g_side_cus(int n);
+void ha2g_conv_planes_waves(int n);       /* A/B: 4 (default) or 8 waves per workgroup of the plane convolution kernel */
 void ha2g_conv_planes_ring(int depth);   /* A/B: LDS ring depth of the plane convolution kernel (0 = default, 2..4) */
 int ha2g_conv2d_b16_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
 int ha2g_conv2d_fwd_b16(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,

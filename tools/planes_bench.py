@@ -47,6 +47,12 @@ for H, W, C in ((64, 35, 64), (32, 18, 128), (16, 9, 256)):
         ts_ = sorted(t_us(new) for _ in range(rounds))
         print('      ring depth %d: %8.1f us' % (depth, ts_[len(ts_) // 2]))
     lib.ha2g_conv_planes_ring(0)
+    lib.ha2g_conv_planes_waves(8)                            # eight-wave workgroups, twice the tile
+    assert torch.equal(new(), ref), 'waves 8'
+    new(); torch.cuda.synchronize()
+    ts_ = sorted(t_us(new) for _ in range(rounds))
+    print('      8 waves     : %8.1f us' % ts_[len(ts_) // 2])
+    lib.ha2g_conv_planes_waves(4)
 print()
 print('%-28s %10s %10s %8s %10s %8s' % ('shape', 'old us', 'planes us', 'ratio', 'TF(f32eq)', 'of 833'))
 for H, W, C in ((64, 35, 64), (32, 18, 128), (16, 9, 256)):
