@@ -15,7 +15,7 @@ import torch
 
 from . import ops
 from ._lib import check, lib
-from .ops import ACT_NONE, _p, _stream, empty, workspace
+from .ops import ACT_NONE, _p, _stream, workspace
 
 BF = torch.bfloat16
 
