@@ -234,7 +234,7 @@ def main():
     # ---- headline: GPU-bound number = hipGraph replays of the captured step (N = 1); eager launches are timed next to it.  With more than one
     # rank the timed path is the eager one (RCCL collectives inside a capture have never run on this pool: an exception could be caught, a hang not).
     use_graph = a.launch == 'graph' or (a.launch == 'auto' and world == 1)
-    launch, graph_note = 'eager', None
+    launch, graph_note = 'eager', (None if world == 1 else 'N > 1 ranks are timed with eager launches (RCCL collectives are not captured); the like-for-like single-GPU number is the N = 1 line\'s eager.value, which is 2-3 % above its graph-replay value')
     dt = None
     if use_graph:
         try:
