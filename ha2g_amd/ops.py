@@ -41,7 +41,7 @@ class SideStream:
     Tensors touched by side-stream kernels must stay referenced until join()."""
 
     def __init__(self):
-        self.enabled = True
+        self.enabled = os.environ.get('HA2G_SIDE_STREAM', '1') != '0'      # 0: every weight gradient in line on the main stream (A/B)
         self._streams = {}
 
     def stream(self, device):
