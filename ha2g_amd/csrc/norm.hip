@@ -425,6 +425,42 @@ __global__ void se_bwd_apply_kernel(const T* __restrict__ dout, const T* __restr
     }
 }
 
+// Data path of the SE excitation MLP's backward in one launch (ResNetBlocks.py:84-89 under autograd): per image n
+//   dh1[n][j]   = (h1[n][j] > 0) * sum_c dsc[n][c] * w2[c][j]          (fc.2: Linear(R -> C), weight [C][R]; ReLU')
+//   dpool[n][c] = inv_hw * sum_j dh1[n][j] * w0[j][c]                   (fc.0: Linear(C -> R), weight [R][C]; the squeeze's 1 / HW)
+// C <= 256, R <= 32 (reduction 8).  Three dependent launches (GEMM, eltwise, GEMM) of a few microseconds each sat on the backward's critical path
+// per block; fixed summation order (eight strided partials per j, then ascending), no atomics.
+__global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict__ dsc, const float* __restrict__ h1, const float* __restrict__ w2,
+                                                         const float* __restrict__ w0, float* __restrict__ dh1, float* __restrict__ dpool, int C,
+                                                         int R, float inv_hw) {
+    __shared__ float sd[256];
+    __shared__ float part[8][32];
+    __shared__ float sh[32];
+    const int n = blockIdx.x, t = threadIdx.x;
+    if (t < C) sd[t] = dsc[(long)n * C + t];
+    __syncthreads();
+    const int j = t & 31, g = t >> 5;
+    float acc = 0.f;
+    if (j < R)
+        for (int c = g; c < C; c += 8) acc += sd[c] * w2[(long)c * R + j];
+    part[g][j] = acc;
+    __syncthreads();
+    if (t < R) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += part[q][t];
+        v = h1[(long)n * R + t] > 0.f ? v : 0.f;
+        dh1[(long)n * R + t] = v;
+        sh[t] = v;
+    }
+    __syncthreads();
+    if (t < C) {
+        float v = 0.f;
+        for (int q = 0; q < R; ++q) v += sh[q] * w0[(long)q * C + t];
+        dpool[(long)n * C + t] = v * inv_hw;
+    }
+}
+
 inline int chunk_blocks(long rows) {
     long b = rows / 512;
     if (b < 1) b = 1;
@@ -608,6 +644,17 @@ int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, f
 int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, const float* dpool, float* dres, float* dx, int N,
                           int HW, int C, void* stream) {
     return se_bwd_apply_t<float>(dout, out, s, dpool, dres, dx, N, HW, C, stream);
+}
+
+// dh1 [N][R], dpool [N][C] from dsc [N][C], h1 [N][R], fc.2.weight w2 [C][R], fc.0.weight w0 [R][C]; C <= 256, R <= 32
+int ha2g_se_mlp_bwd_supported(int C, int R) { return C >= 1 && C <= 256 && R >= 1 && R <= 32; }
+int ha2g_se_mlp_bwd_f32(const float* dsc, const float* h1, const float* w2, const float* w0, float* dh1, float* dpool, int N, int C, int R,
+                        float inv_hw, void* stream) {
+    HA2G_REQUIRE(ha2g_se_mlp_bwd_supported(C, R), "se_mlp_bwd: unsupported widths C = %d, R = %d", C, R);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, dsc, h1, w2, w0, dh1, dpool, C, R, inv_hw);
+    HA2G_CHECK_LAUNCH("se_mlp_bwd");
+    return 0;
 }
 
 // ---- bf16-storage mode (BASELINE config 5): the same passes over bf16 tensors.  Statistics, scales, gradients of gamma / beta and all

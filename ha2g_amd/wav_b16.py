@@ -198,9 +198,9 @@ def block_bwd(dout, saved, P, b, sink):
     check(lib.ha2g_se_bwd_scale_b16(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, sc.data_ptr(),
                                     workspace(dev).data_ptr(), _stream()))
     sink.gwb(b + 'se.fc.2.weight', b + 'se.fc.2.bias', ds, h1)
-    dh1 = ops.eltwise(ops.OP_RELU_BWD, ops.gemm(ds, P[b + 'se.fc.2.weight']), h1)
+    from .wav_engine import se_mlp_bwd
+    dh1, dpool = se_mlp_bwd(ds, h1, P[b + 'se.fc.2.weight'], P[b + 'se.fc.0.weight'], HW)
     sink.gwb(b + 'se.fc.0.weight', b + 'se.fc.0.bias', dh1, pooled)
-    dpool = ops.gemm(dh1, P[b + 'se.fc.0.weight'], alpha=1.0 / HW)
     dres, db2 = torch.empty_like(b2), torch.empty_like(b2)
     check(lib.ha2g_se_bwd_apply_b16(dout.data_ptr(), out.data_ptr(), sc.data_ptr(), dpool.data_ptr(), dres.data_ptr(), db2.data_ptr(), N, HW, C,
                                     _stream()))

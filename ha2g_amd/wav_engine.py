@@ -228,6 +228,23 @@ SIDE_FC_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_FC', '1') != '0'
 WGRAD_AFTER = _os.environ.get('HA2G_WGRAD_AFTER', '0') == '1'
 
 
+SE_MLP_FUSED = _os.environ.get('HA2G_SE_MLP_FUSED', '1') != '0'
+
+
+def se_mlp_bwd(dsc, h1, w2, w0, HW):
+    """Data path of the SE excitation MLP's backward: (dh1 [N,R], dpool [N,C]) from dsc [N,C] (gradient of the gate's pre-activation), the hidden
+    activations h1 [N,R], fc.2.weight [C,R] and fc.0.weight [R,C] -- one launch (ha2g_se_mlp_bwd_f32) instead of GEMM + ReLU' + GEMM."""
+    N, C = dsc.shape
+    R = h1.shape[1]
+    if SE_MLP_FUSED and w2.is_contiguous() and w0.is_contiguous() and lib.ha2g_se_mlp_bwd_supported(C, R):
+        dh1, dpool = torch.empty_like(h1), torch.empty_like(dsc)
+        check(lib.ha2g_se_mlp_bwd_f32(dsc.data_ptr(), h1.data_ptr(), w2.data_ptr(), w0.data_ptr(), dh1.data_ptr(), dpool.data_ptr(), N, C, R,
+                                      1.0 / HW, _stream()))
+        return dh1, dpool
+    dh1 = ops.eltwise(ops.OP_RELU_BWD, ops.gemm(dsc, w2), h1)
+    return dh1, ops.gemm(dh1, w0, alpha=1.0 / HW)
+
+
 class GradSink:
     """Where the backward kernels put parameter gradients: straight into a parameter's installed `.grad` buffer when
     there is one (beta = 1 epilogues), else into the dict G (name -> grad; BatchNorm: (dgamma, dbeta)).  The convolution weight
@@ -385,9 +402,8 @@ def block_bwd(dx, saved, P, b, sink):
                                     ops.workspace(dout.device).data_ptr(), _stream()))
     dsc = ds                                            # already times the gate's sigmoid' (folded into the reduction's final pass)
     sink.gwb(b + 'se.fc.2.weight', b + 'se.fc.2.bias', dsc, h1)
-    dh1 = ops.eltwise(ops.OP_RELU_BWD, ops.gemm(dsc, P[b + 'se.fc.2.weight']), h1)
+    dh1, dpool = se_mlp_bwd(dsc, h1, P[b + 'se.fc.2.weight'], P[b + 'se.fc.0.weight'], HW)
     sink.gwb(b + 'se.fc.0.weight', b + 'se.fc.0.bias', dh1, pooled)
-    dpool = ops.gemm(dh1, P[b + 'se.fc.0.weight'], alpha=1.0 / HW)
     dres, db2 = torch.empty_like(b2), torch.empty_like(b2)
     check(lib.ha2g_se_bwd_apply_f32(dout.data_ptr(), out.data_ptr(), sc.data_ptr(), dpool.data_ptr(), dres.data_ptr(),
                                     db2.data_ptr(), N, HW, C, _stream()))

@@ -236,6 +236,11 @@ int ha2g_se_scale_add_relu_f32(const float* x, const float* s, const float* res,
 int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, float* ds, int N, int HW, int C, const float* gate, float* ws,
                           void* stream);   /* gate (nullable) [N][C]: ds is multiplied by gate * (1 - gate), the sigmoid derivative of the SE gate; */
      /* ws: ha2g_bn_apply_pool_workspace_floats(N, HW, C) floats (row-chunked partials) or null (one block per image) */
+/* data path of the SE excitation MLP's backward (ResNetBlocks.py:84-89 under autograd) in one launch: dh1 = relu'(h1) * (dsc w2), dpool = inv_hw * dh1 w0;
+ * w2 = se.fc.2.weight [C][R], w0 = se.fc.0.weight [R][C]; C <= 256, R <= 32 */
+int ha2g_se_mlp_bwd_supported(int C, int R);
+int ha2g_se_mlp_bwd_f32(const float* dsc, const float* h1, const float* w2, const float* w0, float* dh1, float* dpool, int N, int C, int R,
+                        float inv_hw, void* stream);
 int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, const float* dpool, float* dres,
                           float* dx, int N, int HW, int C, void* stream);
 /* speaker-softmax blending of the three audio taps (model/ResNetSE34V2.py:202-212) */

@@ -340,3 +340,28 @@ def test_multi_weight_norm_equals_per_layer_launches():
         assert torch.equal(a, b)
     ref = vs[0].double() * (gs[0].double() / vs[0].double().flatten(1).norm(dim=1).view(-1, 1, 1))
     assert relerr(w_multi[0].detach(), ref.detach().cpu()) < 1e-6
+
+
+@pytest.mark.parametrize('N,C', [(128, 32), (5, 64), (17, 128), (128, 256)])
+def test_se_mlp_backward_data_path_fused(N, C):
+    """ha2g_se_mlp_bwd_f32 (one launch) vs float64 and vs the three-launch form it replaces (GEMM, ReLU', GEMM): the data path of the SE
+    excitation MLP's backward (ResNetBlocks.py:84-89 under autograd), reduction 8."""
+    from ha2g_amd import ops, wav_engine as we
+    torch.manual_seed(7)
+    R, HW = C // 8, 144
+    dsc = torch.randn(N, C, device=DEV)
+    h1 = torch.relu(torch.randn(N, R, device=DEV))
+    w2, w0 = torch.randn(C, R, device=DEV) * 0.2, torch.randn(R, C, device=DEV) * 0.2
+    dh1, dpool = we.se_mlp_bwd(dsc, h1, w2, w0, HW)
+    ref_dh1 = (dsc.double() @ w2.double()) * (h1.double() > 0)
+    ref_dpool = (ref_dh1 @ w0.double()) / HW
+    assert relerr(dh1, ref_dh1.cpu()) < 2e-6 and relerr(dpool, ref_dpool.cpu()) < 2e-6
+    old = we.SE_MLP_FUSED
+    we.SE_MLP_FUSED = False
+    try:
+        dh1_3, dpool_3 = we.se_mlp_bwd(dsc, h1, w2, w0, HW)
+    finally:
+        we.SE_MLP_FUSED = old
+    # the replaced form runs its two products on the split-bf16 inner product in the default mode (4e-6 rms per GEMM); the fused kernel is plain fp32
+    assert relerr(dh1, dh1_3.double().cpu()) < 5e-5 and relerr(dpool, dpool_3.double().cpu()) < 5e-5
+    assert torch.equal(dh1 == 0, (h1 <= 0) | (dh1 == 0))                        # masked where the hidden unit was inactive
