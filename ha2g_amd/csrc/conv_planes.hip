@@ -48,6 +48,31 @@ __global__ void weight_ihwo_planes_kernel(const float* __restrict__ w, unsigned 
     }
 }
 
+// The same for up to 48 weights in ONE launch (blockIdx.y = tensor): the tower's backward used to run one re-layout launch per convolution on
+// its critical path (29 per step), each a few microseconds of kernel and a level of the replayed graph.
+constexpr int WPB_MAX = 48;
+struct WPlanesBatch {
+    const float* w[WPB_MAX]; unsigned short* hi[WPB_MAX]; unsigned short* lo[WPB_MAX];
+    int cout[WPB_MAX], kk[WPB_MAX], cin[WPB_MAX];
+};
+__global__ void weight_ihwo_planes_multi_kernel(WPlanesBatch b) {
+    const int t = blockIdx.y;
+    const float* __restrict__ w = b.w[t];
+    unsigned* __restrict__ hi = reinterpret_cast<unsigned*>(b.hi[t]);
+    unsigned* __restrict__ lo = reinterpret_cast<unsigned*>(b.lo[t]);
+    const int Cout = b.cout[t], KK = b.kk[t], Cin = b.cin[t];
+    const long total = (long)Cout * KK * Cin / 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long e = 2 * i;
+        const int co = (int)(e % Cout); const long q = e / Cout; const int kk = (int)(q % KK); const int ci = (int)(q / KK);
+        const float x = w[((long)co * KK + kk) * Cin + ci], y = w[((long)(co + 1) * KK + kk) * Cin + ci];
+        unsigned h, l;
+        split2_bf16(x, y, h, l);
+        hi[i] = h;
+        lo[i] = l;
+    }
+}
+
 // One PARITY CLASS of output pixels.  Stride 1: a single class, all taps.  Stride 2: the output pixels (oy, ox) with (oy % 2, ox % 2) = (py, px)
 // receive contributions only from the taps with (oy + pad - kh) and (ox + pad - kw) even -- 1, 2, 2 and 4 of the nine 3x3 taps for the four
 // classes (ONE of the four classes for a 1x1 kernel) -- so each class is its own implicit GEMM over ITS taps only.  The round-2 kernels ran all
@@ -624,6 +649,26 @@ int ha2g_conv2d_weight_ihwo_planes(const float* w, void* wt_hi, void* wt_lo, int
     hipLaunchKernelGGL(weight_ihwo_planes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)wt_hi, (unsigned short*)wt_lo,
                        Cout, KH * KW, Cin);
     HA2G_CHECK_LAUNCH("weight_ihwo_planes");
+    return 0;
+}
+
+// n <= 48 weights in one launch; the arrays are HOST arrays (of device pointers / of sizes)
+int ha2g_conv2d_weight_ihwo_planes_multi(const void* const* w, void* const* wt_hi, void* const* wt_lo, const int* cout, const int* kk, const int* cin,
+                                         int n, void* stream) {
+    HA2G_REQUIRE(n >= 0 && n <= WPB_MAX, "weight_ihwo_planes_multi: %d tensors (max %d)", n, WPB_MAX);
+    if (n == 0) return 0;
+    WPlanesBatch b{};
+    long most = 0;
+    for (int i = 0; i < n; ++i) {
+        HA2G_REQUIRE(cout[i] % 2 == 0, "weight_ihwo_planes_multi: Cout %% 2");
+        b.w[i] = (const float*)w[i]; b.hi[i] = (unsigned short*)wt_hi[i]; b.lo[i] = (unsigned short*)wt_lo[i];
+        b.cout[i] = cout[i]; b.kk[i] = kk[i]; b.cin[i] = cin[i];
+        const long tot = (long)cout[i] * kk[i] * cin[i] / 2;
+        if (tot > most) most = tot;
+    }
+    const int gx = (int)((most + 255) / 256 > 512 ? 512 : (most + 255) / 256);
+    hipLaunchKernelGGL(weight_ihwo_planes_multi_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, b);
+    HA2G_CHECK_LAUNCH("weight_ihwo_planes_multi");
     return 0;
 }
 

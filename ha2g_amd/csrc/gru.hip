@@ -50,6 +50,31 @@ __global__ void gru_pack_kernel(const float* __restrict__ whh, float* __restrict
     reinterpret_cast<float4*>(pb)[(long)frag * 64 + lane] = b;
 }
 
+// the same for up to 16 weight matrices in one launch (blockIdx.y = matrix): all layers and directions of a stacked GRU are packed by one launch
+// at the start of its forward instead of two per layer on the chain between the layers' recurrences
+struct PackBatch { const float* whh[16]; float* pf[16]; float* pb[16]; };
+template <int H>
+__global__ void gru_pack_multi_kernel(PackBatch pbt) {
+    constexpr int NJT = GruCfg<H>::NJT;
+    const float* __restrict__ whh = pbt.whh[blockIdx.y];
+    float* __restrict__ pf = pbt.pf[blockIdx.y];
+    float* __restrict__ pb = pbt.pb[blockIdx.y];
+    const int frag = blockIdx.x;
+    const int c = frag % NJT, gate = (frag / NJT) % 3, a = frag / (3 * NJT);
+    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+    float4 f, b;
+    float* fp = &f.x; float* bp = &b.x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        int row = 16 * a + i, k = 16 * c + 4 * g + u;
+        fp[u] = (row < H && k < H) ? whh[(long)(gate * H + row) * H + k] : 0.f;
+        int j = 16 * c + 4 * g + u, kk = 16 * a + i;
+        bp[u] = (j < H && kk < H) ? whh[(long)(gate * H + j) * H + kk] : 0.f;
+    }
+    reinterpret_cast<float4*>(pf)[(long)frag * 64 + lane] = f;
+    reinterpret_cast<float4*>(pb)[(long)frag * 64 + lane] = b;
+}
+
 // ---- forward ------------------------------------------------------------------------------------------
 template <int H>
 __global__ __launch_bounds__(NT) void gru_fwd_kernel(const float* __restrict__ gi,      // [B][T][2][3H]
@@ -497,6 +522,14 @@ int run_pack(const float* whh, float* pf, float* pb, hipStream_t st) {
     return 0;
 }
 
+template <int H>
+int run_pack_multi(const PackBatch& b, int n, hipStream_t st) {
+    constexpr int NJT = GruCfg<H>::NJT;
+    hipLaunchKernelGGL(gru_pack_multi_kernel<H>, dim3(NJT * 3 * NJT, n), dim3(64), 0, st, b);
+    HA2G_CHECK_LAUNCH("gru_pack_multi");
+    return 0;
+}
+
 }  // namespace
 
 namespace {
@@ -532,6 +565,21 @@ int ha2g_gru_pack_whh(const float* whh, float* pf, float* pb, int H, void* strea
         case 300: return run_pack<300>(whh, pf, pb, st);
         case 64: return run_pack<64>(whh, pf, pb, st);
         case 32: return run_pack<32>(whh, pf, pb, st);
+    }
+    return ha2g_set_error(-1, "gru: hidden size %d not instantiated (300, 64, 32)", H);
+}
+
+// ha2g_gru_pack_whh for n <= 16 matrices in one launch; whh / pf / pb are HOST arrays of n device pointers
+int ha2g_gru_pack_whh_multi(const void* const* whh, void* const* pf, void* const* pb, int n, int H, void* stream) {
+    HA2G_REQUIRE(n >= 0 && n <= 16, "gru_pack_whh_multi: %d matrices (max 16)", n);
+    if (n == 0) return 0;
+    PackBatch b{};
+    for (int i = 0; i < n; ++i) { b.whh[i] = (const float*)whh[i]; b.pf[i] = (float*)pf[i]; b.pb[i] = (float*)pb[i]; }
+    hipStream_t st = (hipStream_t)stream;
+    switch (H) {
+        case 300: return run_pack_multi<300>(b, n, st);
+        case 64: return run_pack_multi<64>(b, n, st);
+        case 32: return run_pack_multi<32>(b, n, st);
     }
     return ha2g_set_error(-1, "gru: hidden size %d not instantiated (300, 64, 32)", H);
 }

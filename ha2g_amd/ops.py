@@ -872,6 +872,9 @@ def _gru_layer_fwd(gi, pk, bf, br, y, rs, B, T, H, st, device):
         check(lib.ha2g_gru_layer_fwd(gi.data_ptr(), pk.data_ptr(), bf.data_ptr(), br.data_ptr(), y.data_ptr(), _p(rs), B, T, H, st))
 
 
+PACK_MULTI = os.environ.get('HA2G_PACK_MULTI', '1') != '0'      # one W_hh pack launch per GRU stack instead of two per layer
+
+
 class BiGRUFunction(torch.autograd.Function):
     """Stacked bidirectional GRU (batch_first, h0 = 0).  forward(x, masks, H, grad_slice, *weights): weights in torch
     `_flat_weights` order (per layer, per direction: w_ih, w_hh, b_ih, b_hh); masks = tuple of pre-scaled
@@ -890,6 +893,16 @@ class BiGRUFunction(torch.autograd.Function):
         saved = []
         inp = x.contiguous()
         packs = []
+        pk_all = None
+        if PACK_MULTI and 2 * L <= 16:
+            # all layers' / directions' W_hh images from ONE launch at the start of the stack (two per layer sat between the recurrences)
+            import numpy as np
+            pk_all = torch.empty(L, 4, npk, dtype=torch.float32, device=dev)
+            wl = [weights[8 * l + 4 * d + 1].contiguous() for l in range(L) for d in range(2)]
+            wp_ = np.array([t.data_ptr() for t in wl], np.int64)
+            pf_ = np.array([pk_all[l, d].data_ptr() for l in range(L) for d in range(2)], np.int64)
+            pb_ = np.array([pk_all[l, 2 + d].data_ptr() for l in range(L) for d in range(2)], np.int64)
+            check(lib.ha2g_gru_pack_whh_multi(wp_.ctypes.data, pf_.ctypes.data, pb_.ctypes.data, 2 * L, H, st))
         for l in range(L):
             w = [t.contiguous() for t in weights[8 * l:8 * l + 8]]
             K = inp.shape[2]
@@ -899,9 +912,12 @@ class BiGRUFunction(torch.autograd.Function):
             fl = 2.0 * B * T * K * 3 * H
             ktimer.launch(tkey, lambda: gemm(x2, w[0], transb=True, out=gi[:, :3 * H], bias=w[2]), fl)
             ktimer.launch(tkey, lambda: gemm(x2, w[4], transb=True, out=gi[:, 3 * H:], bias=w[6]), fl)
-            pk = torch.empty(4, npk, dtype=torch.float32, device=dev)     # [fwd-form f, r | bwd-form f, r]
-            check(lib.ha2g_gru_pack_whh(w[1].data_ptr(), pk[0].data_ptr(), pk[2].data_ptr(), H, st))
-            check(lib.ha2g_gru_pack_whh(w[5].data_ptr(), pk[1].data_ptr(), pk[3].data_ptr(), H, st))
+            if pk_all is not None:
+                pk = pk_all[l]
+            else:
+                pk = torch.empty(4, npk, dtype=torch.float32, device=dev)     # [fwd-form f, r | bwd-form f, r]
+                check(lib.ha2g_gru_pack_whh(w[1].data_ptr(), pk[0].data_ptr(), pk[2].data_ptr(), H, st))
+                check(lib.ha2g_gru_pack_whh(w[5].data_ptr(), pk[1].data_ptr(), pk[3].data_ptr(), H, st))
             y = torch.empty(B, T, 2 * H, dtype=torch.float32, device=dev)
             rs = torch.empty(B, T, 2, 4, H, dtype=torch.float32, device=dev) if need_grad else None
             ktimer.launch('gru_layer_fwd' if (H == 300 and l > 0) else 'gru_layer_fwd_other',

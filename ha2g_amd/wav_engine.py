@@ -70,15 +70,62 @@ def dgrad_planes_ok(w_ohwi, stride, pad):
     return bool(PLANES & (1 if stride == 1 else 8)) and bool(lib.ha2g_conv2d_dgrad_planes_supported(Cin, Cout, KH, KW, stride, pad))
 
 
+def prepare_weight_planes(P):
+    """(hi, lo) bf16 planes of the transposed weight [Cin][KH][KW][Cout] of EVERY trunk convolution whose data gradient runs on the plane kernel, in
+    one launch (ha2g_conv2d_weight_ihwo_planes_multi) -> {parameter name: (hi, lo)}.  Called once at the start of the tower's backward: the
+    per-convolution re-layout launches (29 per step) leave its critical path."""
+    import numpy as np
+    items = []
+    for li, nblk in enumerate(LAYERS):
+        for j in range(nblk):
+            b = 'layer%d.%d.' % (li + 1, j)
+            first = j == 0 and li > 0
+            cands = [(b + 'conv2.weight', 1, 1), (b + 'conv1.weight', 2 if first else 1, 1)] + ([(b + 'downsample.0.weight', 2, 0)] if first else [])
+            for name, stride, pad in cands:
+                w = _ohwi(P[name])
+                if dgrad_planes_ok(w, stride, pad):
+                    items.append((name, w))
+    if not items:
+        return {}
+    dev = items[0][1].device
+    sizes = [w.numel() for _, w in items]
+    total = sum(sizes)
+    hi, lo = torch.empty(total, dtype=torch.bfloat16, device=dev), torch.empty(total, dtype=torch.bfloat16, device=dev)
+    out, off = {}, 0
+    wp, hp, lp = (np.empty(len(items), np.int64) for _ in range(3))
+    co, kk, ci = (np.empty(len(items), np.int32) for _ in range(3))
+    keep = []
+    for i, ((name, w), n) in enumerate(zip(items, sizes)):
+        Cout, KH, KW, Cin = w.shape
+        h_, l_ = hi[off:off + n].view(Cin, KH, KW, Cout), lo[off:off + n].view(Cin, KH, KW, Cout)
+        out[name] = (h_, l_)
+        wp[i], hp[i], lp[i] = w.data_ptr(), h_.data_ptr(), l_.data_ptr()
+        co[i], kk[i], ci[i] = Cout, KH * KW, Cin
+        keep.append(w)
+        off += n
+    for k0 in range(0, len(items), 48):
+        n = min(48, len(items) - k0)
+        check(lib.ha2g_conv2d_weight_ihwo_planes_multi(wp[k0:].ctypes.data, hp[k0:].ctypes.data, lp[k0:].ctypes.data, co[k0:].ctypes.data,
+                                                       kk[k0:].ctypes.data, ci[k0:].ctypes.data, n, _stream()))
+    return out
+
+
+_WPLANES = [None]      # planes prepared by prepare_weight_planes for the backward in progress (name -> (hi, lo)), looked up by weight data_ptr
+
+
 def conv_dgrad_planes(dy_planes, w_ohwi, xshape, stride, pad, out=None, beta=0.0):
     """conv_dgrad on the pre-split bf16 planes of dy (ops.bn_bwd(..., planes=True)): the weight goes through one re-layout + split launch,
     the data gradient through the DMA-staged kernel of csrc/conv_planes.hip.  Bit-identical to conv_dgrad() in the default arithmetic mode."""
     N, H, W, Cin = xshape
     Cout, KH, KW, _ = w_ohwi.shape
     hi, lo = dy_planes
-    wh = torch.empty(Cin, KH, KW, Cout, dtype=torch.bfloat16, device=hi.device)
-    wl = torch.empty_like(wh)
-    check(lib.ha2g_conv2d_weight_ihwo_planes(w_ohwi.data_ptr(), wh.data_ptr(), wl.data_ptr(), Cout, KH, KW, Cin, _stream()))
+    pre = _WPLANES[0].get(w_ohwi.data_ptr()) if _WPLANES[0] is not None else None
+    if pre is not None:
+        wh, wl = pre
+    else:
+        wh = torch.empty(Cin, KH, KW, Cout, dtype=torch.bfloat16, device=hi.device)
+        wl = torch.empty_like(wh)
+        check(lib.ha2g_conv2d_weight_ihwo_planes(w_ohwi.data_ptr(), wh.data_ptr(), wl.data_ptr(), Cout, KH, KW, Cin, _stream()))
     if out is None:
         out = torch.empty(N, H, W, Cin, dtype=torch.float32, device=hi.device)
         beta = 0.0
@@ -226,6 +273,7 @@ def set_b16(on):
 
 SIDE_FC_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_FC', '1') != '0'
 WGRAD_AFTER = _os.environ.get('HA2G_WGRAD_AFTER', '0') == '1'
+WPLANES_MULTI = _os.environ.get('HA2G_WPLANES_MULTI', '1') != '0'      # all weight planes of the tower's backward in one launch
 
 
 SE_MLP_FUSED = _os.environ.get('HA2G_SE_MLP_FUSED', '1') != '0'
@@ -607,6 +655,8 @@ class WavEncoderFunction(torch.autograd.Function):
         for ti, (t, C, k, r) in enumerate(TAPS):
             dfeat[ti + 1] = tap_bwd(df[ti], S['tap_' + t], P, t, r, sink)
         # ---- trunk backward ----
+        if WPLANES_MULTI and not ctx.b16:
+            _WPLANES[0] = {_ohwi(P[n]).data_ptr(): v for n, v in prepare_weight_planes(P).items()}
         if ctx.b16:
             from . import wav_b16
             wav_b16.trunk_bwd(dfeat, S, P, LAYERS, sink)
@@ -630,6 +680,7 @@ class WavEncoderFunction(torch.autograd.Function):
 
     @staticmethod
     def _finish_backward(ctx, sink, dev):
+        _WPLANES[0] = None
         G = sink.G
         sink.join(dev)                                   # the side stream's weight gradients are complete before autograd sees them
         # ---- scatter into the flat gradient tuple ----

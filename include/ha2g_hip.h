@@ -70,6 +70,9 @@ void ha2g_conv_planes_enable(int on);
 void ha2g_conv_planes_debug(int bits);     /* timing ablations only: 1 = no DMA after the first k tile, 2 = no MFMA (results are then meaningless) */
 int ha2g_f32_to_planes(const float* x, void* hi, void* lo, long n, void* stream);
 int ha2g_conv2d_weight_ihwo_planes(const float* w, void* wt_hi, void* wt_lo, int Cout, int KH, int KW, int Cin, void* stream);
+/* ha2g_conv2d_weight_ihwo_planes for n <= 48 weights in one launch; w / wt_hi / wt_lo / cout / kk / cin are HOST arrays of n entries */
+int ha2g_conv2d_weight_ihwo_planes_multi(const void* const* w, void* const* wt_hi, void* const* wt_lo, const int* cout, const int* kk, const int* cin,
+                                         int n, void* stream);
 int ha2g_conv2d_dgrad_planes_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
 int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N, int H, int W,
                                  int Cin, int Cout, int KH, int KW, int stride, int pad, float beta, void* stream);
@@ -169,6 +172,8 @@ int ha2g_nhwc_to_nwch_f32(const float* in, float* out, int N, int H, int W, int 
 long ha2g_gru_packed_floats(int H);           /* floats of one packed W_hh image (per direction, per form) */
 int ha2g_gru_supported_hidden(int H);         /* 300, 64, 32 are instantiated */
 int ha2g_gru_pack_whh(const float* whh, float* packed_fwd, float* packed_bwd, int H, void* stream);
+/* the same for n <= 16 matrices in one launch; whh / pf / pb are HOST arrays of n device pointers */
+int ha2g_gru_pack_whh_multi(const void* const* whh, void* const* pf, void* const* pb, int n, int H, void* stream);
 /* the layer's four bias gradients from ONE column sum (ha2g_colsum_f32) of dg [rows][2][r z n_i n_h]: d b_ih = (r,z,n_i),
  * d b_hh = (r,z,n_h); beta = 1 accumulates into the destinations */
 int ha2g_gru_bias_grads_f32(const float* colsums, float* dbih_fwd, float* dbhh_fwd, float* dbih_rev, float* dbhh_rev, int H,
