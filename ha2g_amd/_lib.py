@@ -56,7 +56,16 @@ def _load():
     return lib
 
 
+def header_abi_version(path=HEADER_PATH):
+    m = re.search(r'#define\s+HA2G_ABI_VERSION\s+(\d+)', open(path).read())
+    return int(m.group(1))
+
+
+ABI_VERSION = header_abi_version()
 _clib = _load()                      # the ctypes view: symbol check against the header, and the fallback binding
+if _clib.ha2g_abi_version() != ABI_VERSION:
+    raise ImportError('ha2g_amd: %s reports ABI %d, include/ha2g_hip.h declares %d -- stale build (make -C ha2g_amd/csrc)'
+                      % (LIB_PATH, _clib.ha2g_abi_version(), ABI_VERSION))
 
 
 class _FastLib:

@@ -64,7 +64,7 @@ CASES = {
     # TED-Expressive twin (6 levels, P=126), step only
     'expr_small': dict(B=3, hidden_size=32, n_layers=2, n_words=40, n_spk=6, seed=13, expressive=True),
     # config 3 of BASELINE.json at full width (H=300 cluster GRU, 4 layers, GRU input widths 105..207), B=4, step only.
-    # Seed 67 = the best of seeds 15..139 by ha2g_amd.testing.tcn_relu_margin (6e-7): the text encoders see integer tokens,
+    # Seed 67 = the best of seeds 15..139 by tests/ha2g_testing.tcn_relu_margin (6e-7): the text encoders see integer tokens,
     # so the reference's perturbed fp32 runs never re-roll their ReLU decisions; at seed 15 one pre-activation of g2's TCN
     # sits 7e-10 (relative) from zero and ANY other fp32 summation order flips it (1e-2 error on that layer's gradients).
     'expr_cfg1': dict(B=4, hidden_size=300, n_layers=4, n_words=60, n_spk=8, seed=67, expressive=True),

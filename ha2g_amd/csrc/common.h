@@ -55,6 +55,31 @@ __device__ __forceinline__ void split2_bf16(float a, float b, unsigned& hi, unsi
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, ha2g_bf16x2_t));
 }
 
+// The three-piece split (x = p0 + p1 + p2, each the bf16 rounding of what is left): three bf16 pieces hold all 24 mantissa bits of an fp32
+// value, and the six products p0 q0 + (p0 q1 + p1 q0) + (p0 q2 + p1 q1 + p2 q0) reproduce the fp32 product to 2^-24 -- the arithmetic class
+// of the fp32 MFMA chain (tests/test_gpu_kernels.py::test_three_piece_split_core_is_fp32_accurate).  p0 / p1 are split2_bf16's hi / lo.
+__device__ __forceinline__ void split3_bf16(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    ha2g_f32x2_t v = {a, b};
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, ha2g_bf16x2_t));
+    ha2g_f32x2_t r = {a - __uint_as_float(p0 << 16), b - __uint_as_float(p0 & 0xffff0000u)};
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, ha2g_bf16x2_t));
+    ha2g_f32x2_t q = {r[0] - __uint_as_float(p1 << 16), r[1] - __uint_as_float(p1 & 0xffff0000u)};
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(q, ha2g_bf16x2_t));
+}
+// NP pieces of two values -> out[0..NP-1] (packed {b | a} words)
+template <int NP> __device__ __forceinline__ void splitn_bf16(float a, float b, unsigned* out) {
+    if constexpr (NP == 3) split3_bf16(a, b, out[0], out[1], out[2]);
+    else if constexpr (NP == 2) split2_bf16(a, b, out[0], out[1]);
+    else { unsigned l; split2_bf16(a, b, out[0], l); }
+}
+// NP pre-split planes of one tensor: piece q lives at base + q * ps (elements).  The two-plane entry points of round 3 (hi, lo) are the case
+// ps = lo - hi, np = 2.
+struct PlaneSet { const unsigned short* p; long ps; };
+__host__ __device__ __forceinline__ const unsigned short* plane_of(const PlaneSet& s, int q) { return s.p + (long)q * s.ps; }
+
+// number of bf16 pieces of the split backward products (ha2g_gemm_set_mode bit 6): 2 = 16-bit operand mantissa, 3 = all 24 bits (fp32-class)
+int gemm_bwd_pieces();
+
 // element access of the activation tensors: fp32, or bf16 (bf16-storage mode, BASELINE config 5: the tensors live in HBM as bf16 -- round to
 // nearest even on every store -- while statistics, accumulators and the arithmetic of every pass stay fp32 / double exactly as in the fp32 mode)
 typedef unsigned short b16;

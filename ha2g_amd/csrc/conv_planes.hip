@@ -23,13 +23,15 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 // zeros: the source of every masked-out 16-byte piece (zero padding of the convolution, rows past M)
 __device__ __attribute__((aligned(64))) unsigned short g_zero_page[64];
 
-__global__ void f32_to_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, long n4) {
+// piece q of element i -> pl[q * ps + i]   (NP = 2: the hi / lo planes of round 3; NP = 3: all 24 mantissa bits, split3_bf16)
+template <int NP>
+__global__ void f32_to_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ pl, long ps, long n4) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
-        uint2 h, l;
-        split2_bf16(v.x, v.y, h.x, l.x); split2_bf16(v.z, v.w, h.y, l.y);
-        reinterpret_cast<uint2*>(hi)[i] = h;
-        reinterpret_cast<uint2*>(lo)[i] = l;
+        unsigned a[NP], b[NP];
+        splitn_bf16<NP>(v.x, v.y, a); splitn_bf16<NP>(v.z, v.w, b);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) reinterpret_cast<uint2*>(pl + q * ps)[i] = make_uint2(a[q], b[q]);
     }
 }
 
@@ -52,24 +54,23 @@ __global__ void weight_ihwo_planes_kernel(const float* __restrict__ w, unsigned 
 // its critical path (29 per step), each a few microseconds of kernel and a level of the replayed graph.
 constexpr int WPB_MAX = 48;
 struct WPlanesBatch {
-    const float* w[WPB_MAX]; unsigned short* hi[WPB_MAX]; unsigned short* lo[WPB_MAX];
+    const float* w[WPB_MAX]; unsigned short* pl[WPB_MAX]; long ps[WPB_MAX];      // piece q of tensor t at pl[t] + q * ps[t]
     int cout[WPB_MAX], kk[WPB_MAX], cin[WPB_MAX];
 };
+template <int NP>
 __global__ void weight_ihwo_planes_multi_kernel(WPlanesBatch b) {
     const int t = blockIdx.y;
     const float* __restrict__ w = b.w[t];
-    unsigned* __restrict__ hi = reinterpret_cast<unsigned*>(b.hi[t]);
-    unsigned* __restrict__ lo = reinterpret_cast<unsigned*>(b.lo[t]);
     const int Cout = b.cout[t], KK = b.kk[t], Cin = b.cin[t];
     const long total = (long)Cout * KK * Cin / 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long e = 2 * i;
         const int co = (int)(e % Cout); const long q = e / Cout; const int kk = (int)(q % KK); const int ci = (int)(q / KK);
         const float x = w[((long)co * KK + kk) * Cin + ci], y = w[((long)(co + 1) * KK + kk) * Cin + ci];
-        unsigned h, l;
-        split2_bf16(x, y, h, l);
-        hi[i] = h;
-        lo[i] = l;
+        unsigned pc[NP];
+        splitn_bf16<NP>(x, y, pc);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) reinterpret_cast<unsigned*>(b.pl[t] + k * b.ps[t])[i] = pc[k];
     }
 }
 
@@ -86,8 +87,8 @@ struct PClass {
     int doff[9];                                                 // source offset of the tap relative to the first one, in pixels of the dy grid (<= 0)
 };
 struct PConvP {
-    const unsigned short* a_hi; const unsigned short* a_lo;      // dy planes [img][GH][GW][GC]
-    const unsigned short* b_hi; const unsigned short* b_lo;      // weight planes [N][K], K = KH*KW*GC
+    PlaneSet a;                                                  // dy planes [img][GH][GW][GC] (piece q at a.p + q * a.ps)
+    PlaneSet b;                                                  // weight planes [N][K], K = KH*KW*GC
     float* C; long ldc; float beta;
     int N, K;
     int GH, GW, GC, OH, OW, KH, KW, pad, stride;                 // gathered tensor (dy; forward: x) / output pixel grid (dx; forward: y)
@@ -114,8 +115,12 @@ __device__ __forceinline__ void ptile_of_block(int& bx, int& by) {
 // flight under a tile's MFMAs and the wait in front of a tile is a COUNTED `s_waitcnt vmcnt((S - 2) * loads per stage)` (every wave issues the
 // same number of DMA instructions per stage), not a drain.  S = 2 is the round-3 first version (one tile ahead; two 64 KB workgroups per
 // CU); the L2 -> LDS round trip under load (>= 1 us) is 2-3x a tile's 0.3 us of MFMAs, which is what S = 3 / 4 (one workgroup per CU) cover.
-// NP = 2: hi + lo planes, three MFMAs per product (fp32-class, the default backward).  NP = 1: the operands ARE bf16 tensors (bf16-storage mode of
-// BASELINE config 5, `--bf16`): one plane, one MFMA.  OUT = 0: fp32 output (beta-accumulate); OUT = 1: bf16 output (optional ReLU, beta-accumulate).
+// NP = 3 (round 4, the default backward): three pieces per operand, SIX MFMAs per product, smallest products first
+//   a2 b0 + a0 b2 + a1 b1 + a1 b0 + a0 b1 + a0 b0  -- every term down to 2^-24 of the product: the arithmetic class of the fp32 MFMA chain
+//   (the reference's, train_hierarchy.py:264 loss.backward() in fp32), at 6 x 8 instead of 8 x 16 matrix-pipe passes per 32x32x16 block.
+// NP = 2: hi + lo planes, three MFMAs per product (16-bit operand mantissa: the round-3 default, now the labelled secondary mode).  NP = 1: the
+// operands ARE bf16 tensors (bf16-storage mode of BASELINE config 5, `--bf16`): one plane, one MFMA.
+// OUT = 0: fp32 output (beta-accumulate); OUT = 1: bf16 output (optional ReLU, beta-accumulate).
 template <int N_> __device__ __forceinline__ void wait_vm_lds_barrier() {
     // this wave's DMA older than the newest N_ instructions has landed, its LDS reads are complete; then the workgroup barrier.  The "memory"
     // clobber keeps the compiler's LDS accesses on their side of it (a bare __builtin_amdgcn_s_barrier() does not).
@@ -198,17 +203,19 @@ __global__ __launch_bounds__(64 * WM * WN) void pconv_kernel(PConvP p) {
         for (int i = 0; i < NA; ++i) {
             const bool on = (a_mask[i] & bit) != 0u;
             const long o = a_base[i] + koff;
-            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.a_hi + o : zero), (lds_ptr_t)(dst + (wave + NWV * i) * 1024), 16, 0, 0);
-            if (NP == 2) __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.a_lo + o : zero), (lds_ptr_t)(dst + PLANE_A + (wave + NWV * i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.a.p + q * p.a.ps + o : zero), (lds_ptr_t)(dst + q * PLANE_A + (wave + NWV * i) * 1024), 16, 0, 0);
         }
         const long kb = (long)pc.tap[ti] * p.GC + c0;             // k index of the weight planes: (tap, channel)
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const bool on = b_off[i] >= 0;
             const int rb = (wave + NWV * i) % RB;
-            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.b_hi + b_off[i] + kb : zero), (lds_ptr_t)(dst + NP * PLANE_A + rb * 1024), 16, 0, 0);
-            if (NP == 2) __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.b_lo + b_off[i] + kb : zero),
-                                                          (lds_ptr_t)(dst + NP * PLANE_A + PLANE_B + rb * 1024), 16, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.b.p + q * p.b.ps + b_off[i] + kb : zero),
+                                                 (lds_ptr_t)(dst + NP * PLANE_A + q * PLANE_B + rb * 1024), 16, 0, 0);
         }
     };
 
@@ -239,34 +246,46 @@ __global__ __launch_bounds__(64 * WM * WN) void pconv_kernel(PConvP p) {
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
             const int po = ((2 * kc + lhi) ^ sw) * 16;
-            bf16x8_t ah[MI], al[MI], bh[NI], bl[NI];
+            bf16x8_t af[NP][MI], bf[NP][NI];                     // piece q of the A / B fragments
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8_t*>(ab + i * 2048 + po);
-                if (NP == 2) al[i] = *reinterpret_cast<const bf16x8_t*>(ab + PLANE_A + i * 2048 + po);
-            }
+            for (int q = 0; q < NP; ++q) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8_t*>(bb + j * 2048 + po);
-                if (NP == 2) bl[j] = *reinterpret_cast<const bf16x8_t*>(bb + PLANE_B + j * 2048 + po);
+                for (int i = 0; i < MI; ++i) af[q][i] = *reinterpret_cast<const bf16x8_t*>(ab + q * PLANE_A + i * 2048 + po);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bf[q][j] = *reinterpret_cast<const bf16x8_t*>(bb + q * PLANE_B + j * 2048 + po);
             }
             if (p.dbg & 2) {                                     // ablation: keep the fragment reads alive, skip the matrix pipe
 #pragma unroll
-                for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(ah[i]));
+                for (int q = 0; q < NP; ++q) {
 #pragma unroll
-                for (int j = 0; j < NI; ++j) asm volatile("" :: "v"(bh[j]));
+                    for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(af[q][i]));
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) asm volatile("" :: "v"(bf[q][j]));
+                }
                 continue;
             }
+            if constexpr (NP == 3) {
+                // six products, smallest first; each pass walks ALL accumulators so that consecutive MFMAs are independent
+                constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int t = 0; t < 6; ++t)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    if (NP == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[QA[t]][i], bf[QB[t]][j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        if constexpr (NP == 2) {                 // lo * hi, hi * lo, hi * hi: the order (per accumulator) of gemm_x3_kernel<.., 2>
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 1][i], bf[0][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[NP - 1][j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
+            }
         }
         cur = cur + 1 == S ? 0 : cur + 1;
         nxt = nxt + 1 == S ? 0 : nxt + 1;
@@ -612,8 +631,17 @@ static int pconv_launch(const PConvP& p, dim3 grid, hipStream_t st) {
 }
 static int g_waves = 4;      // ha2g_conv_planes_waves: 8 = eight-wave workgroups with twice the tile (256 x 128 / 512 x 64), one per CU
 
+static int g_tile3 = 0;      // ha2g_conv_planes_tile3: tile of the three-piece kernel, 0 = default per shape, 1 = 128 x 128, 2 = 256 x 64, 3 = 128 x 64
 template <int NP, int OUT>
 static int pconv_dispatch(const PConvP& p, int maxM, hipStream_t st) {
+    if constexpr (NP == 3) {
+        // three pieces: 48 KB (128 x 128) / 60 KB (256 x 64) / 36 KB (128 x 64) per LDS stage -- the 128 x 64 tile keeps two workgroups per CU
+        int t = g_tile3 ? g_tile3 : (p.N % 128 == 0 ? 1 : 3);
+        if (t == 1 && p.N % 128 != 0) t = 3;
+        if (t == 1) return pconv_launch<128, 128, 2, 2, NP, OUT>(p, dim3(ceil_div(maxM, 128), p.N / 128, p.ncls), st);
+        if (t == 2) return pconv_launch<256, 64, 4, 1, NP, OUT>(p, dim3(ceil_div(maxM, 256), ceil_div(p.N, 64), p.ncls), st);
+        return pconv_launch<128, 64, 2, 2, NP, OUT>(p, dim3(ceil_div(maxM, 128), ceil_div(p.N, 64), p.ncls), st);
+    }
     if (g_waves == 8) {
         if (p.N % 128 == 0) return pconv_launch<256, 128, 4, 2, NP, OUT>(p, dim3(ceil_div(maxM, 256), p.N / 128, p.ncls), st);
         return pconv_launch<512, 64, 8, 1, NP, OUT>(p, dim3(ceil_div(maxM, 512), ceil_div(p.N, 64), p.ncls), st);
@@ -629,16 +657,23 @@ void ha2g_conv_planes_enable(int on) { g_planes = on; }
 void ha2g_conv_planes_debug(int bits) { g_pdbg = bits; }
 void ha2g_conv_planes_ring(int depth) { g_ring = depth; }
 void ha2g_conv_planes_waves(int n) { g_waves = n == 8 ? 8 : 4; }
+void ha2g_conv_planes_tile3(int t) { g_tile3 = (t >= 0 && t <= 3) ? t : 0; }
 
-// fp32 -> (hi, lo) bf16 planes of the same shape; n % 4 == 0, 16-byte aligned
-int ha2g_f32_to_planes(const float* x, void* hi, void* lo, long n, void* stream) {
+// fp32 -> np bf16 piece planes of the same shape (piece q at planes + q * ps elements); n % 4 == 0, 16-byte aligned, ps % 8 == 0
+int ha2g_f32_to_planes_np(const float* x, void* planes, long ps, int np, long n, void* stream) {
     HA2G_REQUIRE(n % 4 == 0, "f32_to_planes: n %% 4");
+    HA2G_REQUIRE(np == 2 || np == 3, "f32_to_planes: np = %d (2 or 3)", np);
     if (n == 0) return 0;
     const long n4 = n / 4;
     const int grid = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
-    hipLaunchKernelGGL(f32_to_planes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)hi, (unsigned short*)lo, n4);
+    if (np == 3) hipLaunchKernelGGL(f32_to_planes_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)planes, ps, n4);
+    else hipLaunchKernelGGL(f32_to_planes_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)planes, ps, n4);
     HA2G_CHECK_LAUNCH("f32_to_planes");
     return 0;
+}
+// the two-plane form of round 3: (hi, lo) = pieces 0, 1
+int ha2g_f32_to_planes(const float* x, void* hi, void* lo, long n, void* stream) {
+    return ha2g_f32_to_planes_np(x, hi, (const unsigned short*)lo - (const unsigned short*)hi, 2, n, stream);
 }
 
 // w [Cout][KH][KW][Cin] fp32 -> planes of [Cin][KH][KW][Cout] (what ha2g_conv2d_weight_ohwi_to_ihwo_f32 + a split would give)
@@ -652,24 +687,33 @@ int ha2g_conv2d_weight_ihwo_planes(const float* w, void* wt_hi, void* wt_lo, int
     return 0;
 }
 
-// n <= 48 weights in one launch; the arrays are HOST arrays (of device pointers / of sizes)
-int ha2g_conv2d_weight_ihwo_planes_multi(const void* const* w, void* const* wt_hi, void* const* wt_lo, const int* cout, const int* kk, const int* cin,
-                                         int n, void* stream) {
+// n <= 48 weights in one launch; the arrays are HOST arrays (of device pointers / of sizes); piece q of tensor i at wt[i] + q * ps[i] elements
+int ha2g_conv2d_weight_ihwo_planes_multi_np(const void* const* w, void* const* wt, const long* ps, const int* cout, const int* kk, const int* cin,
+                                            int n, int np, void* stream) {
     HA2G_REQUIRE(n >= 0 && n <= WPB_MAX, "weight_ihwo_planes_multi: %d tensors (max %d)", n, WPB_MAX);
+    HA2G_REQUIRE(np == 2 || np == 3, "weight_ihwo_planes_multi: np = %d (2 or 3)", np);
     if (n == 0) return 0;
     WPlanesBatch b{};
     long most = 0;
     for (int i = 0; i < n; ++i) {
         HA2G_REQUIRE(cout[i] % 2 == 0, "weight_ihwo_planes_multi: Cout %% 2");
-        b.w[i] = (const float*)w[i]; b.hi[i] = (unsigned short*)wt_hi[i]; b.lo[i] = (unsigned short*)wt_lo[i];
+        b.w[i] = (const float*)w[i]; b.pl[i] = (unsigned short*)wt[i]; b.ps[i] = ps[i];
         b.cout[i] = cout[i]; b.kk[i] = kk[i]; b.cin[i] = cin[i];
         const long tot = (long)cout[i] * kk[i] * cin[i] / 2;
         if (tot > most) most = tot;
     }
     const int gx = (int)((most + 255) / 256 > 512 ? 512 : (most + 255) / 256);
-    hipLaunchKernelGGL(weight_ihwo_planes_multi_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, b);
+    if (np == 3) hipLaunchKernelGGL(weight_ihwo_planes_multi_kernel<3>, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, b);
+    else hipLaunchKernelGGL(weight_ihwo_planes_multi_kernel<2>, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, b);
     HA2G_CHECK_LAUNCH("weight_ihwo_planes_multi");
     return 0;
+}
+int ha2g_conv2d_weight_ihwo_planes_multi(const void* const* w, void* const* wt_hi, void* const* wt_lo, const int* cout, const int* kk, const int* cin,
+                                         int n, void* stream) {
+    HA2G_REQUIRE(n >= 0 && n <= WPB_MAX, "weight_ihwo_planes_multi: %d tensors (max %d)", n, WPB_MAX);
+    long ps[WPB_MAX];
+    for (int i = 0; i < n; ++i) ps[i] = (const unsigned short*)wt_lo[i] - (const unsigned short*)wt_hi[i];
+    return ha2g_conv2d_weight_ihwo_planes_multi_np(w, wt_hi, ps, cout, kk, cin, n, 2, stream);
 }
 
 // 1 when ha2g_conv2d_dgrad_planes_f32 serves this geometry in the current arithmetic mode (split-bf16 data gradients on, planes enabled):
@@ -684,22 +728,30 @@ int ha2g_conv2d_dgrad_planes_supported(int Cin, int Cout, int KH, int KW, int st
 // (ha2g_conv2d_weight_ihwo_planes).  Bit-identical to ha2g_conv2d_dgrad_f32 in the default arithmetic mode on the fp32 tensors the planes
 // were split from.  Stride 2: pixels that no tap reaches (1x1 kernel: three of the four parity classes) are NOT written: with beta = 0 the
 // caller zero-fills dx first (ha2g_amd.wav_engine does).
-int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N, int H, int W,
-                                 int Cin, int Cout, int KH, int KW, int stride, int pad, float beta, void* stream) {
+// np = 2 or 3 piece planes: dy pieces at dy + q * dy_ps, transposed-weight pieces at wt + q * wt_ps (elements)
+int ha2g_conv2d_dgrad_planes_np_f32(const void* dy, long dy_ps, const void* wt, long wt_ps, int np, float* dx, int N, int H, int W,
+                                    int Cin, int Cout, int KH, int KW, int stride, int pad, float beta, void* stream) {
     HA2G_REQUIRE(ha2g_conv2d_dgrad_planes_supported(Cin, Cout, KH, KW, stride, pad), "conv2d_dgrad_planes: unsupported geometry / mode");
+    HA2G_REQUIRE(np == 2 || np == 3, "conv2d_dgrad_planes: np = %d (2 or 3)", np);
     const int OHd = (H + 2 * pad - KH) / stride + 1, OWd = (W + 2 * pad - KW) / stride + 1;      // the dy grid
     PConvP p{};
-    p.a_hi = (const unsigned short*)dy_hi; p.a_lo = (const unsigned short*)dy_lo;
-    p.b_hi = (const unsigned short*)wt_hi; p.b_lo = (const unsigned short*)wt_lo;
+    p.a = PlaneSet{(const unsigned short*)dy, dy_ps};
+    p.b = PlaneSet{(const unsigned short*)wt, wt_ps};
     p.C = dx; p.ldc = Cin; p.beta = beta;
     p.N = Cin; p.K = KH * KW * Cout;
     p.GH = OHd; p.GW = OWd; p.GC = Cout; p.OH = H; p.OW = W; p.KH = KH; p.KW = KW; p.pad = pad; p.stride = stride;
     p.dbg = g_pdbg;
     if ((long)N * H * W == 0) return 0;
     const int maxM = dgrad_classes(p, N, H, W, KH, KW, stride, pad, OWd);
-    if (int rc = pconv_dispatch<2, 0>(p, maxM, (hipStream_t)stream)) return rc;
+    if (int rc = (np == 3 ? pconv_dispatch<3, 0>(p, maxM, (hipStream_t)stream) : pconv_dispatch<2, 0>(p, maxM, (hipStream_t)stream))) return rc;
     HA2G_CHECK_LAUNCH("conv2d_dgrad_planes");
     return 0;
+}
+int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N, int H, int W,
+                                 int Cin, int Cout, int KH, int KW, int stride, int pad, float beta, void* stream) {
+    return ha2g_conv2d_dgrad_planes_np_f32(dy_hi, (const unsigned short*)dy_lo - (const unsigned short*)dy_hi, wt_hi,
+                                           (const unsigned short*)wt_lo - (const unsigned short*)wt_hi, 2, dx, N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                           beta, stream);
 }
 
 // ---- bf16-storage mode (BASELINE config 5, `bench.py --bf16`): activations and the dY stream of the audio tower live in HBM as bf16; the
@@ -720,7 +772,7 @@ int ha2g_conv2d_fwd_b16(const void* x, const void* w, void* y, int N, int H, int
     HA2G_REQUIRE(ha2g_conv2d_b16_supported(Cin, Cout, KH, KW, stride, pad), "conv2d_fwd_b16: unsupported geometry");
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     PConvP p{};
-    p.a_hi = (const unsigned short*)x; p.b_hi = (const unsigned short*)w;
+    p.a = PlaneSet{(const unsigned short*)x, 0}; p.b = PlaneSet{(const unsigned short*)w, 0};
     p.C = (float*)y; p.ldc = Cout; p.beta = 0.f; p.relu = relu; p.fwd = 1;
     p.N = Cout; p.K = KH * KW * Cin;
     p.GH = H; p.GW = W; p.GC = Cin; p.OH = OH; p.OW = OW; p.KH = KH; p.KW = KW; p.pad = pad; p.stride = stride;
@@ -742,7 +794,7 @@ int ha2g_conv2d_dgrad_b16(const void* dy, const void* wt, void* dx, int N, int H
     HA2G_REQUIRE(ha2g_conv2d_b16_supported(Cin, Cout, KH, KW, stride, pad), "conv2d_dgrad_b16: unsupported geometry");
     const int OHd = (H + 2 * pad - KH) / stride + 1, OWd = (W + 2 * pad - KW) / stride + 1;
     PConvP p{};
-    p.a_hi = (const unsigned short*)dy; p.b_hi = (const unsigned short*)wt;
+    p.a = PlaneSet{(const unsigned short*)dy, 0}; p.b = PlaneSet{(const unsigned short*)wt, 0};
     p.C = (float*)dx; p.ldc = Cin; p.beta = beta;
     p.N = Cin; p.K = KH * KW * Cout;
     p.GH = OHd; p.GW = OWd; p.GC = Cout; p.OH = H; p.OW = W; p.KH = KH; p.KW = KW; p.pad = pad; p.stride = stride;

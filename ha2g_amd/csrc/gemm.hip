@@ -186,14 +186,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     // reads form a 32x32x16 operand with no VALU at all; SPLIT = 1 rebuilt every fragment from packed {hi|lo} words with 8 ds_read_b32
     // and 8 v_perm_b32 per fragment, in every wave that needed it -- those kernels were VALU-bound.  Same hi / lo values, same MFMA
     // order: bit-identical to SPLIT = 1.  Plane row strides are = 32 (mod 64) bf16 so that the four k rows of a read hit disjoint banks.
-    constexpr bool PLANES = SPLIT == 3;
+    constexpr bool PLANES = SPLIT == 3 || SPLIT == 4;
+    constexpr int PNP = SPLIT == 4 ? 3 : 2;             // SPLIT = 4 (round 4): THREE pieces per operand, six MFMAs per product (fp32-class), same plane layout
     // A k-contiguous operand (A_KC: the dense data gradients dX = dY W) keeps [m][k] planes read with plain 16-byte loads (row stride 24
     // bf16: 16 consecutive rows hit 16 distinct 16-byte slots); its n-contiguous B goes through the transpose reads like above.
     static_assert(!PLANES || (AMODE != A_IM && BMODE != B_KC && BKT == 16), "plane staging: A_MC / A_KC with a k-slow B operand");
     constexpr int LDPA = (BM % 64 == 0) ? BM + 32 : BM, LDPB = (BN % 64 == 0) ? BN + 32 : BN;      // bf16 elements
     constexpr int LDKA = BKT + 8;                                                                  // A_KC: [m][k] plane row
     constexpr int PLA = AMODE == A_MC ? BKT * LDPA : BM * LDKA;                                    // one A plane
-    constexpr int PL_BUF = 2 * PLA + 2 * BKT * LDPB;                                               // per buffer: A hi, A lo, B hi, B lo
+    constexpr int PL_BUF = PNP * PLA + PNP * BKT * LDPB;                                           // per buffer: the A pieces, then the B pieces
     constexpr int SMEM_F32 = 2 * BKT * (LDA + LDB), SMEM_PL = (2 * PL_BUF + 1) / 2;
     __shared__ __attribute__((aligned(16))) float smem[PLANES ? (SMEM_PL > 16 * BM ? SMEM_PL : 16 * BM) : SMEM_F32];
     float* As = smem;                      // [2][BKT][LDA]
@@ -341,20 +342,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 if (!(tid + i * 256 < SA)) continue;
-                uint2 h, l;
-                split_bf16x2(ra[i].x, ra[i].y, h.x, l.x); split_bf16x2(ra[i].z, ra[i].w, h.y, l.y);
+                unsigned u[PNP], w[PNP];
+                splitn_bf16<PNP>(ra[i].x, ra[i].y, u); splitn_bf16<PNP>(ra[i].z, ra[i].w, w);
                 unsigned short* d = pl + (AMODE == A_MC ? a_r[i] * LDPA + a_c[i] : a_r[i] * LDKA + a_c[i]);    // A_KC: four consecutive k of row a_r
-                *reinterpret_cast<uint2*>(d) = h;
-                *reinterpret_cast<uint2*>(d + PLA) = l;
+#pragma unroll
+                for (int q = 0; q < PNP; ++q) *reinterpret_cast<uint2*>(d + q * PLA) = make_uint2(u[q], w[q]);
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 if (!(tid + i * 256 < SB)) continue;
-                uint2 h, l;
-                split_bf16x2(rb[i].x, rb[i].y, h.x, l.x); split_bf16x2(rb[i].z, rb[i].w, h.y, l.y);
-                unsigned short* d = pl + 2 * PLA + b_r[i] * LDPB + b_c[i];
-                *reinterpret_cast<uint2*>(d) = h;
-                *reinterpret_cast<uint2*>(d + BKT * LDPB) = l;
+                unsigned u[PNP], w[PNP];
+                splitn_bf16<PNP>(rb[i].x, rb[i].y, u); splitn_bf16<PNP>(rb[i].z, rb[i].w, w);
+                unsigned short* d = pl + PNP * PLA + b_r[i] * LDPB + b_c[i];
+#pragma unroll
+                for (int q = 0; q < PNP; ++q) *reinterpret_cast<uint2*>(d + q * BKT * LDPB) = make_uint2(u[q], w[q]);
             }
             return;
         }
@@ -417,30 +418,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
                 const s16x4_t f1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(__attribute__((address_space(3))) const unsigned short*)(ptr + 4 * ld));
                 return __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(f0, f1, 0, 1, 2, 3, 4, 5, 6, 7));
             };
-            bf16x8_t ah[MI], al[MI], bh[NI], bl[NI];
+            bf16x8_t af[PNP][MI], bf[PNP][NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                if constexpr (AMODE == A_MC) {
-                    const unsigned short* pa = pl + krow * LDPA + wm * (32 * MI) + i * 32 + moff;
-                    ah[i] = frag(pa, LDPA); al[i] = frag(pa + PLA, LDPA);
-                } else {
-                    const unsigned short* pa = pl + (wm * (32 * MI) + i * 32 + l31) * LDKA + 8 * lhi;
-                    ah[i] = *reinterpret_cast<const bf16x8_t*>(pa); al[i] = *reinterpret_cast<const bf16x8_t*>(pa + PLA);
+            for (int q = 0; q < PNP; ++q) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    if constexpr (AMODE == A_MC) {
+                        af[q][i] = frag(pl + q * PLA + krow * LDPA + wm * (32 * MI) + i * 32 + moff, LDPA);
+                    } else {
+                        af[q][i] = *reinterpret_cast<const bf16x8_t*>(pl + q * PLA + (wm * (32 * MI) + i * 32 + l31) * LDKA + 8 * lhi);
+                    }
                 }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bf[q][j] = frag(pl + PNP * PLA + q * BKT * LDPB + krow * LDPB + wn * (32 * NI) + j * 32 + moff, LDPB);
             }
+            if constexpr (PNP == 3) {                        // six products, smallest first (conv_planes.hip, pconv_kernel<.., NP = 3>)
+                constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const unsigned short* pb = pl + 2 * PLA + krow * LDPB + wn * (32 * NI) + j * 32 + moff;
-                bh[j] = frag(pb, LDPB); bl[j] = frag(pb + BKT * LDPB, LDPB);
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[QA[t]][i], bf[QB[t]][j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PNP - 1][i], bf[0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[PNP - 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+                    }
             }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
         } else if constexpr (!SPLIT) {
 #pragma unroll
             for (int kk = 0; kk < BKT / 2; ++kk) {
@@ -756,6 +766,9 @@ static int g_direct_c32 = 1;     // 32->32 channel 3x3 stride-1 forward convolut
                                  // 231 vs 312 us per convolution (-0.5 ms/step) and exact to 2e-6 vs float64, but its different fp32
                                  // summation order moves the chaotic B=4 BatchNorm case (cfg1) to 1.04x its tolerance (3x the
                                  // reference's nine-run fp32 scatter) on one of 1 000 tensors, so the implicit GEMM stays the default.
+static int g_np3 = 0;           // mode bit 6 (round 4, DEFAULT ON through ha2g_amd/_lib.py): the split backward products use THREE bf16 pieces per
+                                // operand and six MFMAs (all 24 mantissa bits: fp32-class, the reference's arithmetic) instead of two pieces / three
+                                // MFMAs (16-bit operand mantissa).  Families without a three-piece kernel run the exact fp32 MFMA in this mode.
 static int g_split_dgrad = 1;   // data-gradient GEMMs / convolutions on the split-bf16 inner product (bit 2)
 static int g_split_wgrad = 1;   // weight-gradient GEMMs / convolutions on the split-bf16 inner product (ha2g_gemm_set_mode bit 1)
 static int g_bf16 = 0;    // every vectorisable GEMM / convolution with plain bf16 operands (1 MFMA per product), fp32 accumulate: mode bit 4.
@@ -864,6 +877,12 @@ int launch(const GemmP& p, hipStream_t st) {
         if (g_bf16 && p.K >= 64 && (AMODE != A_IM || p.g.GC % 32 == 0)) {     // bf16 operands, fp32 accumulate (mode bit 4)
             hipLaunchKernelGGL((gemm_x3_kernel<MI, NI, WM, WN, AMODE, 1>), grid, dim3(256), 0, st, p);
             use_x3 = true;
+        } else if (bwd && g_split_dgrad && g_np3 && !g_x3) {
+            // fp32-class backward: the three-piece core where it serves the shape, else the exact fp32 MFMA below (never two pieces)
+            if (p.kchunk >= 64 && p.g.GC % 16 == 0 && p.N > 32) {
+                hipLaunchKernelGGL((gemm_x3_kernel<MI, NI, WM, WN, AMODE, 3>), grid, dim3(256), 0, st, p);
+                use_x3 = true;
+            }
         } else if ((g_x3 || (bwd && g_split_dgrad)) && p.K >= 64 && p.N > 32 && (AMODE != A_IM || p.g.GC % 32 == 0)) {
             hipLaunchKernelGGL((gemm_x3_kernel<MI, NI, WM, WN, AMODE, 2>), grid, dim3(256), 0, st, p);
             use_x3 = true;
@@ -881,21 +900,25 @@ int launch(const GemmP& p, hipStream_t st) {
         bool dgrad_conv = AMODE == A_IM && p.g.transposed;
         use_split = !use_x3 && p.kchunk >= 64 &&
                     ((WGRAD_SHAPE && g_split_wgrad) || ((DGRAD_DENSE || dgrad_conv) && g_split_dgrad));
+        // three-piece plane tiles that fit the 64 KB of static LDS (the widest dense tiles do not: those shapes run the exact fp32 MFMA)
+        constexpr bool P3_FITS = 2 * 2 * 3 * ((AMODE == A_MC ? 16 * ((BM % 64 == 0) ? BM + 32 : BM) : BM * 24) + 16 * ((BN % 64 == 0) ? BN + 32 : BN)) <= 65536;
         if (g_bf16 && !use_x3 && p.kchunk >= 32) {
             hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 2>), grid, dim3(256), 0, st, p);
             use_split = true;
-        } else if constexpr (WGRAD_SHAPE) {
-            if (use_split) {
-                if (g_wgrad_planes) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 3>), grid, dim3(256), 0, st, p);
-                else hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 1>), grid, dim3(256), 0, st, p);
-            }
-        } else if constexpr (DGRAD_DENSE) {
-            if (use_split) {
+        } else if constexpr (WGRAD_SHAPE || DGRAD_DENSE) {
+            if (use_split && g_np3) {
+                use_split = false;
+                if constexpr (P3_FITS) {
+                    hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 4>), grid, dim3(256), 0, st, p);
+                    use_split = true;
+                }
+            } else if (use_split) {
                 if (g_wgrad_planes) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 3>), grid, dim3(256), 0, st, p);
                 else hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 1>), grid, dim3(256), 0, st, p);
             }
         } else if constexpr (AMODE == A_IM) {
-            if (use_split) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 1>), grid, dim3(256), 0, st, p);
+            if (use_split && g_np3) use_split = false;           // packed-word two-piece core only: fp32-class mode takes the exact fp32 MFMA
+            else if (use_split) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16, 1>), grid, dim3(256), 0, st, p);
         }
     }
     if (!use_x3 && !use_split) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16>), grid, dim3(256), 0, st, p);
@@ -990,7 +1013,9 @@ int dispatch_tile(GemmP& p, long ws_floats, hipStream_t st) {
     if (VEC && AMODE == A_KC && g_tile_model && !g_bf16 && !g_x3 && !g_x6 && !g_x6_dense) {
         const TileModel& m = (BMODE == B_NC && g_split_dgrad && p.kchunk >= 64) ? kModelSplit : kModelF32;
         double bt = 1e300;
+        const bool np3_dgrad = g_np3 && BMODE == B_NC && g_split_dgrad && p.kchunk >= 64;
         for (int c = 0; c < NC; ++c) {
+            if (np3_dgrad && (c == 0 || c == 5 || c == 6)) continue;      // three-piece [m][k] planes of these tiles exceed the 64 KB of static LDS
             long tiles = (long)ceil_div(p.M, kTileBM[c]) * ceil_div(p.N, kTileBN[c]) * groups;
             long load = (tiles * p.splits + ncu - 1) / ncu;
             const bool big = kTileBM[c] * kTileBN[c] >= 128 * 96;
@@ -999,6 +1024,7 @@ int dispatch_tile(GemmP& p, long ws_floats, hipStream_t st) {
             if (t < bt) { bt = t; best = c; }
         }
     }
+    if (AMODE == A_KC && BMODE == B_NC && g_np3 && g_split_dgrad && best == 0) best = 2;      // (rule / forced-model-off path) see np3_dgrad above
     if (g_tile_force >= 0 && g_tile_force < NC) best = g_tile_force;
     if (g_splits_force > 0 && (long)groups * g_splits_force * p.M * (p.N + 1) <= ws_floats) {
         int kc = ceil_div(ceil_div(p.K, g_splits_force), 32) * 32;
@@ -1061,13 +1087,15 @@ static int pick_conv_cfg(int M, int N) {
 }
 
 int gemm_split_dgrad_enabled() { return g_split_dgrad && !g_bf16; }
+int gemm_bwd_pieces() { return g_np3 ? 3 : 2; }
 
 extern "C" {
 
 /* bit 0: forward GEMMs / convolutions on the split-bf16 core (default 0 = exact fp32: the error compounds through 34 layers
    and breaks parity); bit 1: weight gradients, bit 2: data gradients on the split-bf16 inner product (default 1: the parity
    margins of the full step are unchanged, see tools/margins.py) */
-void ha2g_gemm_set_mode(int mode) { g_x3 = mode & 1; g_split_wgrad = (mode >> 1) & 1; g_split_dgrad = (mode >> 2) & 1; g_x6 = (mode >> 3) & 1; g_bf16 = (mode >> 4) & 1; g_x6_dense = (mode >> 5) & 1; }
+void ha2g_gemm_set_mode(int mode) { g_x3 = mode & 1; g_split_wgrad = (mode >> 1) & 1; g_split_dgrad = (mode >> 2) & 1; g_x6 = (mode >> 3) & 1; g_bf16 = (mode >> 4) & 1; g_x6_dense = (mode >> 5) & 1; g_np3 = (mode >> 6) & 1; }
+int ha2g_gemm_bwd_pieces(void) { return (g_bf16 || !(g_split_wgrad || g_split_dgrad)) ? 0 : gemm_bwd_pieces(); }
 void ha2g_gemm_debug_x6_min_n(int n) { g_x6_min_n = n; }
 void ha2g_gemm_debug_tile(int cfg, int splits) { g_tile_model = cfg != -2; g_tile_force = cfg == -2 ? -1 : cfg; g_splits_force = splits; }
 void ha2g_conv_debug_direct_c32(int on) { g_direct_c32 = on & 1; g_direct_c32_dgrad = (on >> 1) & 1; g_direct_c32_x3 = !((on >> 2) & 1); g_c32_dbg = on & 0x30; }
@@ -1176,7 +1204,8 @@ int ha2g_conv2d_dgrad_f32(const float* dy, const float* wt, float* dx, int N, in
         // direct LDS-patch kernels (conv_c32.hip): split-bf16 by default like every other data gradient; fp32 form = debug bit 1
         int rc = -100;
         if (g_direct_c32_dgrad) rc = conv3x3_c32_launch(dy, wt, dx, N, H, W, 1, 0, beta, (hipStream_t)stream);
-        else if (g_split_dgrad && g_direct_c32_x3) rc = conv3x3_c32_x3_launch(dy, wt, dx, N, H, W, 1, 0, beta, (hipStream_t)stream);
+        else if (g_split_dgrad && g_direct_c32_x3 && !g_np3) rc = conv3x3_c32_x3_launch(dy, wt, dx, N, H, W, 1, 0, beta, (hipStream_t)stream);
+        else if (g_split_dgrad && g_np3 && g_direct_c32) rc = conv3x3_c32_launch(dy, wt, dx, N, H, W, 1, 0, beta, (hipStream_t)stream);     // exact fp32 direct kernel
         if (rc != -100) return rc;
     }
     GemmP p{};
@@ -1225,7 +1254,7 @@ int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int
     long need = ha2g_conv2d_wgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad);
     long MN = (long)p.M * p.N;
     hipStream_t st0 = (hipStream_t)stream;
-    if (g_direct_c32_wgrad && g_split_wgrad && !g_bf16 && Cin == 32 && Cout == 32 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && ws &&
+    if (g_direct_c32_wgrad && g_split_wgrad && !g_np3 && !g_bf16 && Cin == 32 && Cout == 32 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && ws &&
         ws_bytes >= need) {
         const int nblk = conv3x3_c32_wgrad_launch(x, dy, ws, N, H, W, st0);
         if (nblk != -100) {
@@ -1264,7 +1293,7 @@ int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int
 // Plane-based weight gradient (conv_planes.hip): x and dy arrive as bf16 hi / lo planes; one DMA-staged launch writes `chunks` dW-shaped
 // partial slabs into ws, the wide reduce adds them in double.  3x3 / stride 1 / pad 1, channels multiples of 64.
 int ha2g_conv2d_wgrad_planes_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
-    return g_split_wgrad && !g_bf16 && Cin % 64 == 0 && Cout % 64 == 0 && pconv_wgrad_supported(H, W, Cin, Cout, KH, KW, stride, pad);
+    return g_split_wgrad && !g_np3 && !g_bf16 && Cin % 64 == 0 && Cout % 64 == 0 && pconv_wgrad_supported(H, W, Cin, Cout, KH, KW, stride, pad);
 }
 // bf16-storage mode: dw (fp32) = beta*dw + dy^T im2col(x) with x and dy bf16 tensors (one plane, one MFMA per product); 3x3 / stride 1 / pad 1,
 // channel counts multiples of 32

@@ -14,7 +14,7 @@ int ha2g_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int ha2g_abi_version(void) { return 1; }
+extern "C" int ha2g_abi_version(void) { return 2; }      // 2: guarded Adam, ha2g_sparse_adam2_f32, N-piece plane entry points (*_np)
 
 namespace {
 

@@ -9,7 +9,8 @@ namespace {
 // The scalar prologue runs in double, as torch.optim.Adam's Python scalars do (1 - beta, bias corrections, lr / bc1): computed
 // in fp32, 1.f - 0.999f is off by 1.3e-5 relative and that error would sit in every second moment.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                            double lr_d, double b1_d, double b2_d, double eps_d, const int* __restrict__ step) {
+                            double lr_d, double b1_d, double b2_d, double eps_d, const int* __restrict__ step, const int* __restrict__ guard) {
+    if (guard != nullptr && *guard != 0) return;      // a flagged step (cluster-GRU hand-off time-out) must not touch parameters or moments
     const double t = (double)*step;
     const double bc1 = 1.0 - pow(b1_d, t), bc2 = 1.0 - pow(b2_d, t);
     const float step_size = (float)(lr_d / bc1), rs2 = (float)(1.0 / sqrt(bc2));
@@ -33,24 +34,31 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         p[i] -= step_size * mm / (sqrtf(vv) * rs2 + eps);
     }
 }
-__global__ void step_inc_kernel(int* step) { *step += 1; }
+__global__ void step_inc_kernel(int* step, const int* guard) { if (guard == nullptr || *guard == 0) *step += 1; }
 
 }  // namespace
 
 extern "C" {
-int ha2g_adam_step_inc(int* step, void* stream) {
-    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+// guard: optional device int32 word (the cluster-GRU error word, gru_cluster.hip); while it is non-zero the counter, the parameters and the
+// moments stay untouched, so a step whose gradients are invalid is a no-op on the optimizer state ("never trains on garbage")
+int ha2g_adam_step_inc_guarded(int* step, const int* guard, void* stream) {
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, guard);
     HA2G_CHECK_LAUNCH("adam_step_inc");
     return 0;
 }
+int ha2g_adam_step_inc(int* step, void* stream) { return ha2g_adam_step_inc_guarded(step, nullptr, stream); }
 // p, g, m, v: 16-byte aligned flat buffers of n floats; step: device int32 holding the (already incremented) step number
-int ha2g_adam_f32(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps, const int* step,
-                  void* stream) {
+int ha2g_adam_guarded_f32(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps, const int* step,
+                          const int* guard, void* stream) {
     if (n == 0) return 0;
     long gsz = (n / 4 + 255) / 256;
     int grid = (int)(gsz < 1 ? 1 : (gsz > 8192 ? 8192 : gsz));
-    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, step, guard);
     HA2G_CHECK_LAUNCH("adam");
     return 0;
+}
+int ha2g_adam_f32(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps, const int* step,
+                  void* stream) {
+    return ha2g_adam_guarded_f32(p, g, m, v, n, lr, b1, b2, eps, step, nullptr, stream);
 }
 }

@@ -53,9 +53,11 @@ __global__ void adam_scalars_kernel(const int* __restrict__ step, double lr, dou
 __global__ __launch_bounds__(128) void sparse_adam_kernel(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V, int* __restrict__ last,
                                                           const long* __restrict__ ids, const int* __restrict__ count, const float* __restrict__ vals,
                                                           const float2* __restrict__ table, const int* __restrict__ step, int C, float b1, float b2,
-                                                          float omb1, float omb2, float eps, int cap, double lr_d, double b1_d, double b2_d) {
+                                                          float omb1, float omb2, float eps, int cap, double lr_d, double b1_d, double b2_d,
+                                                          const int* __restrict__ guard) {
     const int r = blockIdx.x;
     if (r >= *count) return;
+    if (vals != nullptr && guard != nullptr && *guard != 0) return;      // flagged step: no real update (catch-ups replay VALID earlier steps and still run)
     const long row = ids[r];
     const int t = *step, t0 = last[row];
     const int zero_to = vals ? t - 1 : t;                      // last step replayed with a zero gradient
@@ -107,14 +109,24 @@ int ha2g_adam_scalars(const int* step, double lr, double b1, double b2, void* ta
     HA2G_CHECK_LAUNCH("adam_scalars");
     return 0;
 }
-int ha2g_sparse_adam_f32(float* W, float* M, float* V, int* last, const long* ids, const int* count, int max_rows, const float* vals,
-                         const void* table, const int* step, int C, double b1, double b2, double eps, int table_steps, double lr, void* stream) {
+// ABI 2: the round-3 entry point ha2g_sparse_adam_f32 had grown two parameters under an unchanged name; this is the same operation under a NEW
+// name (plus the optional guard word of ha2g_adam_guarded_f32), the old symbol keeps its round-3 signature and forwards here.  Past
+// `table_steps` the per-step scalars of replayed steps are recomputed with the CURRENT lr: exact only while lr is constant (the reference never
+// changes it, scripts/train.py:155-170).
+int ha2g_sparse_adam2_f32(float* W, float* M, float* V, int* last, const long* ids, const int* count, int max_rows, const float* vals,
+                          const void* table, const int* step, int C, double b1, double b2, double eps, int table_steps, double lr, const int* guard,
+                          void* stream) {
     if (max_rows <= 0) return 0;
     HA2G_REQUIRE(table_steps >= 1, "sparse_adam: empty scalar table");
     hipLaunchKernelGGL(sparse_adam_kernel, dim3(max_rows), dim3(128), 0, (hipStream_t)stream, W, M, V, last, ids, count, vals,
-                       (const float2*)table, step, C, (float)b1, (float)b2, (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, table_steps, lr, b1, b2);
+                       (const float2*)table, step, C, (float)b1, (float)b2, (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, table_steps, lr, b1, b2,
+                       guard);
     HA2G_CHECK_LAUNCH("sparse_adam");
     return 0;
+}
+int ha2g_sparse_adam_f32(float* W, float* M, float* V, int* last, const long* ids, const int* count, int max_rows, const float* vals,
+                         const void* table, const int* step, int C, double b1, double b2, double eps, int table_steps, double lr, void* stream) {
+    return ha2g_sparse_adam2_f32(W, M, V, last, ids, count, max_rows, vals, table, step, C, b1, b2, eps, table_steps, lr, nullptr, stream);
 }
 int ha2g_iota_ids(long* ids, int* count, int n, void* stream) {
     hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ids, count, n);

@@ -40,6 +40,19 @@ def all_reduce_(t, group=None, async_op=False):
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
+def sync_flag_(flag, group=None):
+    """MAX over ranks of a device int32 flag word (the cluster-GRU error word that guards the optimizer kernels, FusedAdam.step): either every
+    replica applies a step or none does -- a rank-local time-out must not let the replicas diverge.  One 4-byte collective."""
+    if flag is None or not active(group):
+        return
+    if _host_staged(flag, group):
+        h = flag.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        flag.copy_(h)
+        return
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+
+
 def all_gather_(outs, t, group=None):
     if _host_staged(t, group):
         hs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]

@@ -1313,9 +1313,11 @@ class SparseTable:
     def _run(self, ids, count, max_rows, vals):
         g = self.opt.param_groups[0]
         w = self.weight.data
-        check(lib.ha2g_sparse_adam_f32(w.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.last.data_ptr(), ids.data_ptr(), count.data_ptr(),
-                                       max_rows, _p(vals), self.opt.table.data_ptr(), self.opt.step_t.data_ptr(), w.shape[1],
-                                       float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), self.opt.TABLE_STEPS, float(g['lr']), _stream()))
+        guard = gru_cluster_error_tensor(w.device)          # flagged step: no real row update (see FusedAdam.step)
+        check(lib.ha2g_sparse_adam2_f32(w.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.last.data_ptr(), ids.data_ptr(), count.data_ptr(),
+                                        max_rows, _p(vals), self.opt.table.data_ptr(), self.opt.step_t.data_ptr(), w.shape[1],
+                                        float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), self.opt.TABLE_STEPS, float(g['lr']),
+                                        _p(guard), _stream()))
 
     def catch_up(self, ids, count, max_rows):
         self._run(ids, count, max_rows, None)

@@ -8,7 +8,7 @@ HBM-streaming kernel, and data-parallel gradient exchange is ONE RCCL all-reduce
 import torch
 
 from ._lib import check, lib
-from .ops import _stream
+from .ops import _stream, gru_cluster_error_tensor
 
 
 def _storage_span(p):
@@ -79,10 +79,14 @@ class FusedAdam(torch.optim.Optimizer):
                     gv.copy_(p.grad)
                 p.grad = gv
         st = _stream()
-        check(lib.ha2g_adam_step_inc(self.step_t.data_ptr(), st))
-        check(lib.ha2g_adam_f32(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
-                                self.total, float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
-                                self.step_t.data_ptr(), st))
+        # guard = the cluster-GRU error word of this device (None before the first cluster launch): while it is set the kernels below leave the
+        # step counter, parameters and moments untouched -- a step whose recurrences timed out never reaches the optimizer state
+        guard = gru_cluster_error_tensor(self.flat_p.device)
+        gp = guard.data_ptr() if guard is not None else None
+        check(lib.ha2g_adam_step_inc_guarded(self.step_t.data_ptr(), gp, st))
+        check(lib.ha2g_adam_guarded_f32(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
+                                        self.total, float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
+                                        self.step_t.data_ptr(), gp, st))
         if self.sparse_tables:
             self._host_step += 1        # informational; past TABLE_STEPS the row kernel recomputes the scalars itself (sparse.hip)
             check(lib.ha2g_adam_scalars(self.step_t.data_ptr(), float(g['lr']), float(g['betas'][0]), float(g['betas'][1]),

@@ -102,7 +102,58 @@ class HierarchyTrainer:
             names, packed = self.train_iter(epoch, in_text_padded, in_spec, target, vid_indices, return_tensors=True)
         return graph, names, packed
 
-    def train_iter(self, epoch, in_text_padded, in_spec, target, vid_indices, **kw):
+    # ---- a flagged cluster-GRU step is harmless and recoverable ----
+    # The error word of gru_cluster.hip guards every optimizer kernel ON THE DEVICE (FusedAdam.step -> ha2g_adam_guarded_f32): a step whose
+    # recurrences timed out leaves parameters, moments and step counters bit-identical.  The host learns about it from the packed loss
+    # read-back (forward launches: same call) or from the end-of-step copy of the word (BPTT launches: start of the next call).  Recovery:
+    # drain the device, restore the BatchNorm buffers the flagged forward touched, clear the word, switch this process to the single-workgroup
+    # recurrences of gru.hip (fresh launches, same process) and run the batch at hand.  cluster_retries counts the recoveries.
+    retry_on_cluster_error = True
+    cluster_retries = 0
+
+    def _bn_buffers(self):
+        return [b for m in self.modules() for k, b in m.named_buffers()
+                if k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]
+
+    def _snapshot_buffers(self):
+        bufs = self._bn_buffers()
+        snap = getattr(self, '_bn_snap', None)
+        if snap is None or len(snap) != len(bufs):
+            snap = self._bn_snap = [torch.empty_like(b) for b in bufs]
+        torch._foreach_copy_(snap, bufs)
+
+    def _recover_from_cluster_error(self, restore_buffers):
+        from . import ops
+        from .train_hierarchy import _err_watch
+        torch.cuda.synchronize(self.device)
+        _err_watch.clear()                              # copies of the word taken while it was set
+        if restore_buffers and getattr(self, '_bn_snap', None) is not None:
+            torch._foreach_copy_(self._bn_buffers(), self._bn_snap)
+        err = ops.gru_cluster_error_tensor(self.device)
+        if err is not None:
+            err.zero_()
+        ops.USE_GRU_CLUSTER = False
+        self.cluster_retries += 1
+
+    def _step(self, epoch, in_text_padded, in_spec, target, vid_indices, **kw):
         fn = train_iter_hierarchy_expressive if self.expressive else train_iter_hierarchy
         return fn(self.args, epoch, in_text_padded, in_spec, target, vid_indices, *self.gens, self.discriminator, self.audio_encoder,
                   self.text_encoder, *self.gen_opts, self.dis_opt, self.audio_opt, self.text_opt, **kw)
+
+    def train_iter(self, epoch, in_text_padded, in_spec, target, vid_indices, **kw):
+        from . import ops
+        capturing = self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
+        if not self.retry_on_cluster_error or capturing or kw.get('return_tensors') or not ops.USE_GRU_CLUSTER:
+            return self._step(epoch, in_text_padded, in_spec, target, vid_indices, **kw)
+        from .train_hierarchy import drain_cluster_errors
+        try:
+            drain_cluster_errors()                      # the PREVIOUS step's BPTT launches flagged: its update was skipped on the device
+        except ops.Ha2gClusterError:
+            self._recover_from_cluster_error(restore_buffers=False)      # that step's forward was valid: its BatchNorm statistics stay
+            return self._step(epoch, in_text_padded, in_spec, target, vid_indices, **kw)
+        self._snapshot_buffers()
+        try:
+            return self._step(epoch, in_text_padded, in_spec, target, vid_indices, **kw)
+        except ops.Ha2gClusterError:
+            self._recover_from_cluster_error(restore_buffers=True)
+            return self._step(epoch, in_text_padded, in_spec, target, vid_indices, **kw)

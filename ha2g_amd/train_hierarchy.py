@@ -131,6 +131,14 @@ _CLUSTER_MSG = ('ha2g_amd: a GRU cluster hand-off timed out (gru_cluster.hip): t
                 'the device cannot co-schedule the cluster\'s workgroups')
 
 
+def _sync_guard(dev):
+    """The optimizer kernels are predicated on the device's cluster-GRU error word (FusedAdam.step); under data parallelism the word is
+    MAX-reduced over the ranks first, so that the replicas skip (or apply) a step together."""
+    from . import ddp
+    if ddp.active():
+        ddp.sync_flag_(ops.gru_cluster_error_tensor(dev))
+
+
 def _allreduce(optimizers):
     from . import ddp
     ddp.average_module_grads_(optimizers)
@@ -239,6 +247,7 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
         dis_error = ops.dis_loss(dis_real, dis_fake)                      # ns-gan
         dis_error.backward()
         _allreduce([dis_optimizer])
+        _sync_guard(dev)                                 # data parallel: a time-out on ANY rank makes this a no-op step on EVERY rank
         dis_optimizer.step()
 
     ###########################################################################################
@@ -340,6 +349,7 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
         if w is not None:
             w.wait()
     g_opts = tuple(gen_optimizers) + (audio_optimizer, text_optimizer)
+    _sync_guard(dev)
     for o in g_opts:
         o.step()
     ops.rng.end_step()

@@ -22,6 +22,9 @@
 extern "C" {
 #endif
 
+/* Bumped whenever an exported signature changes or entry points are added that a host must not mix with an older library:
+ * ha2g_amd/_lib.py refuses to bind a library whose ha2g_abi_version() differs from this macro. */
+#define HA2G_ABI_VERSION 2
 int ha2g_abi_version(void);
 const char* ha2g_last_error(void);
 
@@ -336,6 +339,12 @@ int ha2g_adam_step_inc(int* step, void* stream);
  * in double (in fp32, 1 - 0.999 alone is off by 1.3e-5 relative), the per-element update runs in fp32 */
 int ha2g_adam_f32(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
                   const int* step, void* stream);
+/* ABI 2: the same with a GUARD word (device int32, may be NULL): while *guard != 0 the step counter, the parameters and the moments are left
+ * untouched.  The train step passes the cluster-GRU error word (ha2g_gru_layer_*_cluster's `err`), so a step whose recurrences timed out is a
+ * no-op on the optimizer state instead of an update from garbage gradients (optimizer.step() of train_hierarchy.py:131,270-274). */
+int ha2g_adam_step_inc_guarded(int* step, const int* guard, void* stream);
+int ha2g_adam_guarded_f32(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2, double eps,
+                          const int* step, const int* guard, void* stream);
 
 /* ---- sparse embedding gradients + lazy row-wise Adam (tables: model/hierarchy_net.py:31-34, optimizer train.py:155-170) ----
  * unique_tokens: tok [n] int64 -> uniq (slot 0 = the padding id 0, then distinct ids in order of first occurrence), remap [n] (slot of each
@@ -351,6 +360,12 @@ int ha2g_unique_tokens(const long* tok, int n, int* map, int* cpos, long* uniq, 
 int ha2g_adam_scalars(const int* step, double lr, double b1, double b2, void* table, int cap, void* stream);
 int ha2g_sparse_adam_f32(float* W, float* M, float* V, int* last, const long* ids, const int* count, int max_rows, const float* vals,
                          const void* table, const int* step, int C, double b1, double b2, double eps, int table_steps, double lr, void* stream);
+/* ABI 2: ha2g_sparse_adam_f32 under a new name (its signature had grown in round 3 under the old one) + the guard word of ha2g_adam_guarded_f32:
+ * a flagged step applies no real update; catch-ups (vals == NULL) replay valid earlier steps and run regardless.  Past `table_steps` replayed
+ * steps take `lr` as it is NOW: exact while lr is constant (train.py:155-170 never changes it). */
+int ha2g_sparse_adam2_f32(float* W, float* M, float* V, int* last, const long* ids, const int* count, int max_rows, const float* vals,
+                          const void* table, const int* step, int C, double b1, double b2, double eps, int table_steps, double lr, const int* guard,
+                          void* stream);
 int ha2g_iota_ids(long* ids, int* count, int n, void* stream);
 
 /* ---- log-mel front-end on the GPU: replaces the offline librosa step

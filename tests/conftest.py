@@ -7,6 +7,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+_TESTS = os.path.join(ROOT, 'tests')          # tests/ha2g_testing.py: the parity tests' shared helpers (tolerance policy, procedural state)
+if _TESTS not in sys.path:
+    sys.path.insert(1, _TESTS)
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 

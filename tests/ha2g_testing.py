@@ -13,9 +13,9 @@ the floor is never taken below the median relative floor of the same module's gr
 import numpy as np
 import torch
 
-from . import procedural as proc
-from . import schema
-from .config import FGD_CASE
+from ha2g_amd import procedural as proc
+from ha2g_amd import schema
+from ha2g_amd.config import FGD_CASE
 
 
 def state_for(case, dt=torch.float32, dims=schema.GESTURE_POSE_DIMS):
@@ -207,7 +207,7 @@ class SpeakerVocab:
 
 
 def no_dropout(m):
-    from .hierarchy_net import BiGRU, TemporalBlock
+    from ha2g_amd.hierarchy_net import BiGRU, TemporalBlock
     for sub in m.modules():
         if isinstance(sub, torch.nn.Dropout):
             sub.p = 0.0
@@ -227,8 +227,8 @@ def load_role(module, state, role):
 
 def build_modules(case, device, dims=schema.GESTURE_POSE_DIMS, state=None):
     """(args, [g1..], dis, audio, text) with procedural parameters of `case`, dropout disabled."""
-    from .config import make_args
-    from . import hierarchy_net as hn
+    from ha2g_amd.config import make_args
+    from ha2g_amd import hierarchy_net as hn
     args = make_args(case)
     spk = SpeakerVocab(case['n_spk'])
     state = state if state is not None else state_for(case, torch.float32, dims)
@@ -338,7 +338,7 @@ def block_io(name, geom, B, seed, dt=torch.float32):
 def engine_P(sd, device):
     """name -> tensor / wav_engine._BN on `device` from a flat state dict with the reference's key names
     (BatchNorm entries 'x.weight/.bias/.running_mean/.running_var/.num_batches_tracked' fold into one _BN under 'x')."""
-    from .wav_engine import _BN
+    from ha2g_amd.wav_engine import _BN
     P = {}
     for k, v in sd.items():
         if k.endswith('.running_mean'):

@@ -31,8 +31,8 @@ def test_fixture_is_a_full_return_dict(golden):
 def test_gpu_evaluate_testset_matches_reference(golden, expressive):
     from ha2g_amd.embedding_space_evaluator import EmbeddingSpaceEvaluator
     from ha2g_amd.evaluate import evaluate_testset
-    from ha2g_amd.testing import build_modules
-    from ha2g_amd.testing import fgd_ae_state as ae_state
+    from ha2g_testing import build_modules
+    from ha2g_testing import fgd_ae_state as ae_state
     from ha2g_amd import schema
     g, ec, case = golden('evalset'), EVAL_CASE, CASES['expr_small' if expressive else 'small']
     tag, P = ('evalset_expr', 126) if expressive else ('evalset', 27)

@@ -6,7 +6,7 @@ import torch
 
 from ha2g_amd import procedural as proc
 from ha2g_amd.config import FGD_CASE, hierarchy_args
-from ha2g_amd.testing import fgd_ae_state as ae_state
+from ha2g_testing import fgd_ae_state as ae_state
 
 
 def _close(got, g, key, rtol, scale=None, nm=3.0):

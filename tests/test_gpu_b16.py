@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from ha2g_amd import ops, schema, wav_b16 as wb, wav_engine as we
 from ha2g_amd._lib import check, lib
 from ha2g_amd.config import BLOCKFULL_B, BLOCKFULL_CASES, CASES
-from ha2g_amd.testing import batch_for, block_io, block_state, build_modules, engine_P, nchw, nhwc, state_for, wproc
+from ha2g_testing import batch_for, block_io, block_state, build_modules, engine_P, nchw, nhwc, state_for, wproc
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'

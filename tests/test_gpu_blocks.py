@@ -11,7 +11,7 @@ import torch
 
 from ha2g_amd import procedural as proc
 from ha2g_amd.config import BLOCK_B, BLOCK_CASES, BLOCKFULL_B, BLOCKFULL_CASES, ENC_CASE, TAPS_CASE, TAPSFULL_CASE
-from ha2g_amd.testing import (DigestChecker, block_io, block_state, build_modules, engine_P, nchw, nhwc, taps_inputs, taps_w)
+from ha2g_testing import (DigestChecker, block_io, block_state, build_modules, engine_P, nchw, nhwc, taps_inputs, taps_w)
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -133,7 +133,7 @@ def test_whole_encoder_b16(golden):
     """Whole Hierarchical_WavEncoder at B=16 through the module (one autograd node), vs the reference."""
     from ha2g_amd import hierarchy_net as hn
     from ha2g_amd.config import make_args
-    from ha2g_amd.testing import SpeakerVocab, no_dropout
+    from ha2g_testing import SpeakerVocab, no_dropout
     case = ENC_CASE
     g = golden('enc16')
     ck = DigestChecker(g, noise_mult=3.0)
@@ -164,7 +164,7 @@ def test_tower_side_stream_weight_gradients_equal_inline():
     same kernels, same operands: every parameter gradient must equal the in-line schedule bit for bit."""
     from ha2g_amd import hierarchy_net as hn, wav_engine as we
     from ha2g_amd.config import make_args
-    from ha2g_amd.testing import SpeakerVocab, no_dropout
+    from ha2g_testing import SpeakerVocab, no_dropout
     case = ENC_CASE
     args = make_args(dict(hidden_size=32, n_layers=2))
     _, spec, _, vid = proc.make_batch(case['B'], 27, 40, case['n_spk'], case['seed'])

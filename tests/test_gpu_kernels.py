@@ -1,6 +1,8 @@
 """GPU parity of individual HIP kernels (through the C-ABI) against float64 CPU restatements.
 Run on the GPU box:  python -m pytest tests -m gpu -x -q
 """
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -101,7 +103,7 @@ def test_bigru_fwd_bwd(case):
         for suf in ('', '_reverse'):
             for nm, shp in (('weight_ih', (3 * H, k)), ('weight_hh', (3 * H, H)), ('bias_ih', (3 * H,)), ('bias_hh', (3 * H,))):
                 key = 'g.%s_l%d%s' % (nm, l, suf)
-                sd[key] = rnd(shp, hash(key) % 100000, 1.0 / H ** 0.5)
+                sd[key] = rnd(shp, zlib.crc32(key.encode()) % 100000, 1.0 / H ** 0.5)      # stable across processes (str hash is salted)
                 flat.append(key)
     x = rnd((B, T, In), 7)
     wy = rnd((B, T, 2 * H), 8)
@@ -438,7 +440,7 @@ def test_dense_forward_split_leaves_the_audio_tower_bits_unchanged():
     from ha2g_amd import ops, procedural as proc
     from ha2g_amd._lib import DEFAULT_GEMM_MODE, lib
     from ha2g_amd.config import CASES
-    from ha2g_amd.testing import batch_for, build_modules
+    from ha2g_testing import batch_for, build_modules
     dev = _dev()
     case = CASES['small']
     _, _, _, aud, _ = build_modules(case, dev)

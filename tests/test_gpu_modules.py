@@ -1,12 +1,12 @@
 """GPU parity of the module mirrors (HIP forward + hand-written backward) against the reference-generated
-fixtures, with the tolerance policy of ha2g_amd/testing.py (1e-4 rel + 3x the reference's own fp32 scatter)."""
+fixtures, with the tolerance policy of tests/ha2g_testing.py (1e-4 rel + 3x the reference's own fp32 scatter)."""
 import numpy as np
 import pytest
 import torch
 
 from ha2g_amd import procedural as proc
 from ha2g_amd.config import CASES, EXPRESSIVE_SPEC, MEAN_DIR_VEC_EXPRESSIVE
-from ha2g_amd.testing import Checker, batch_for, build_modules, wproc
+from ha2g_testing import Checker, batch_for, build_modules, wproc
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'

@@ -133,7 +133,7 @@ def test_train_step_is_bitwise_unchanged_by_the_plane_data_gradients_and_close_w
     """One GAN-phase step of a trainer (full SE-ResNet34 audio tower, B = 4): plane-based DATA gradients leave every gradient bit-equal to the
     round-2 path; adding the plane-based WEIGHT gradients (another fp32 summation order of the same products) moves them by < 1e-5 of the norm."""
     from ha2g_amd.config import hierarchy_args
-    from ha2g_amd.testing import SpeakerVocab
+    from ha2g_testing import SpeakerVocab
     from ha2g_amd.train import HierarchyTrainer
     dev = torch.device(DEV)
 

@@ -221,7 +221,7 @@ def test_dropout_placement_matches_reference_sites():
     hierarchy_net.py:88,213) and that eval() draws none.  Counted through the Philox call-site counter."""
     from ha2g_amd import hierarchy_net as hn, ops
     from ha2g_amd.config import hierarchy_args
-    from ha2g_amd.testing import SpeakerVocab
+    from ha2g_testing import SpeakerVocab
     args = hierarchy_args(hidden_size=32, n_layers=2)
     dev = torch.device(DEV)
     txt = hn.TextEncoderTCN(args, 40, 300, None, dropout=args.dropout_prob).to(dev)

@@ -47,7 +47,7 @@ dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 from bench import Vocab
 from ha2g_amd import ddp, ops, procedural as proc, train_hierarchy as th
 from ha2g_amd.config import hierarchy_args
-from ha2g_amd.testing import no_dropout
+from ha2g_testing import no_dropout
 from ha2g_amd.train import HierarchyTrainer
 B = 3
 text, spec, target, vid = (torch.from_numpy(x).to(dev) for x in proc.make_batch(B, 27, 50, 7, 5))

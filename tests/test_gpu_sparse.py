@@ -99,7 +99,7 @@ def test_train_step_with_sparse_tables_equals_dense_step():
     identical loss dicts and, after sync_sparse(), bit-identical parameters."""
     from ha2g_amd import ops, procedural as proc, train_hierarchy as th
     from ha2g_amd.config import hierarchy_args
-    from ha2g_amd.testing import SpeakerVocab, no_dropout
+    from ha2g_testing import SpeakerVocab, no_dropout
     from ha2g_amd.train import HierarchyTrainer
     dev = torch.device(DEV)
 

@@ -9,7 +9,7 @@ from ha2g_amd import procedural as proc
 from ha2g_amd import train_hierarchy as th
 from ha2g_amd.config import CASES
 from ha2g_amd.optim import FusedAdam
-from ha2g_amd.testing import Checker, EpsInjector, batch_for, build_modules, named_state
+from ha2g_testing import Checker, EpsInjector, batch_for, build_modules, named_state
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -132,7 +132,7 @@ def test_training_loop_reduces_loss_and_is_deterministic():
     and two identically seeded runs are bitwise equal (no float atomics anywhere on the path)."""
     from ha2g_amd import ops
     from ha2g_amd.config import hierarchy_args
-    from ha2g_amd.testing import SpeakerVocab
+    from ha2g_testing import SpeakerVocab
     from ha2g_amd.train import HierarchyTrainer
 
     class Lang:
@@ -169,7 +169,7 @@ def test_whole_step_hipgraph_capture_matches_eager():
     three eager steps of an identically initialised trainer bit for bit."""
     from ha2g_amd import ops
     from ha2g_amd.config import hierarchy_args
-    from ha2g_amd.testing import SpeakerVocab, no_dropout
+    from ha2g_testing import SpeakerVocab, no_dropout
     from ha2g_amd.train import HierarchyTrainer
     dev = torch.device(DEV)
 
@@ -228,7 +228,7 @@ def _full_size_step(expressive, B, fuse, mode, seed=21, fuse_text=True, b16=Fals
     from ha2g_amd import ops, schema
     from ha2g_amd._lib import lib
     from ha2g_amd.config import hierarchy_args
-    from ha2g_amd.testing import SpeakerVocab, no_dropout
+    from ha2g_testing import SpeakerVocab, no_dropout
     from ha2g_amd.train import HierarchyTrainer
     dev = torch.device(DEV)
 
@@ -359,7 +359,7 @@ def test_ragged_batch_sizes_vs_oracle(B):
     GAN-phase step on the GPU against the CPU oracle run in-test on the same seeded inputs (loss dict to 1e-4 rel, like
     __graft_entry__.smoke), B = 1 included (a single sample per BatchNorm batch, a 1-element permutation)."""
     from ha2g_amd.config import make_args
-    from ha2g_amd.testing import state_for
+    from ha2g_testing import state_for
     from oracle import ha2g_oracle as O
     case = dict(CASES['small'], B=B)
     args, gens, dis, aud, txt = build_modules(case, DEV)
@@ -391,7 +391,7 @@ def test_loss_readback_is_early_and_cluster_errors_are_still_raised():
     the same call), the end-of-step word (BPTT launches) is copied asynchronously and raised by the next step / HierarchyTrainer.sync()."""
     from ha2g_amd import ops, train_hierarchy as th
     from ha2g_amd.config import hierarchy_args
-    from ha2g_amd.testing import SpeakerVocab
+    from ha2g_testing import SpeakerVocab
     from ha2g_amd.train import HierarchyTrainer
     dev = torch.device(DEV)
     args = hierarchy_args()

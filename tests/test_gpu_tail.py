@@ -18,7 +18,7 @@ from ha2g_amd import train_hierarchy as th
 from ha2g_amd._lib import DEFAULT_GEMM_MODE, lib
 from ha2g_amd.config import CASES
 from ha2g_amd.optim import FusedAdam
-from ha2g_amd.testing import EpsInjector, batch_for, build_modules
+from ha2g_testing import EpsInjector, batch_for, build_modules
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'

@@ -5,7 +5,7 @@ should cost (a few 1e-3 on the output).  Reference being restated: scripts/model
 import torch
 
 from ha2g_amd.config import BLOCK_B, BLOCK_CASES, BLOCK_SEED
-from ha2g_amd.testing import block_io, block_state
+from ha2g_testing import block_io, block_state
 from oracle import ha2g_oracle as O
 
 

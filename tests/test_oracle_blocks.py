@@ -11,7 +11,7 @@ import torch
 from ha2g_amd import procedural as proc
 from ha2g_amd import schema
 from ha2g_amd.config import BLOCK_B, BLOCK_CASES, BLOCKFULL_B, BLOCKFULL_CASES, ENC_CASE, TAPS_CASE, TAPSFULL_CASE
-from ha2g_amd.testing import DigestChecker, block_io, block_state, taps_inputs, taps_w
+from ha2g_testing import DigestChecker, block_io, block_state, taps_inputs, taps_w
 from oracle import ha2g_oracle as O
 
 DTS = [torch.float64, torch.float32]
@@ -142,7 +142,7 @@ def test_step_fixture_tcn_relu_margins():
     pre-activation within fp32 rounding of zero would be an unmeasured coin flip.  Pin the margins the step cases were
     chosen for (relative to the layer's largest pre-activation, float64)."""
     from ha2g_amd.config import CASES
-    from ha2g_amd.testing import tcn_relu_margin
+    from ha2g_testing import tcn_relu_margin
     assert tcn_relu_margin(CASES['expr_cfg1']) > 5e-7
     assert tcn_relu_margin(CASES['cfg1']) > 5e-8
     assert tcn_relu_margin(CASES['small']) > 1e-6

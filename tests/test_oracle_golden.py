@@ -14,7 +14,7 @@ import torch
 from ha2g_amd import procedural as proc
 from ha2g_amd import schema
 from ha2g_amd.config import CASES, make_args
-from ha2g_amd.testing import Checker, batch_for, leaf_params, state_for, wproc
+from ha2g_testing import Checker, batch_for, leaf_params, state_for, wproc
 from oracle import ha2g_oracle as O
 
 DTS = [torch.float64, torch.float32]

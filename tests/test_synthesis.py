@@ -7,7 +7,7 @@ import torch
 
 from ha2g_amd import procedural as proc
 from ha2g_amd.config import CASES, GESTURE_SPEC, SYNTH_CASE, make_args
-from ha2g_amd.testing import state_for
+from ha2g_testing import state_for
 
 
 class SynthLang:
@@ -61,7 +61,7 @@ def test_oracle_synthesis_matches_reference(golden, expressive):
 def test_gpu_synthesis_matches_reference(golden, expressive):
     from ha2g_amd import schema
     from ha2g_amd.synthesize import generate_gestures_hierarchy
-    from ha2g_amd.testing import build_modules
+    from ha2g_testing import build_modules
     sc, n_audio, spectro, words = _inputs()
     case = CASES['expr_small' if expressive else 'small']
     args, gens, dis, aud, txt = build_modules(case, 'cuda:0', schema.EXPRESSIVE_POSE_DIMS) if expressive else build_modules(case, 'cuda:0')

@@ -2,11 +2,11 @@
 is perturbed by one float32 ulp-scale relative noise?  (fp32 rounding acts like such a perturbation at every layer.)"""
 import sys
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from ha2g_amd import procedural as proc, train_hierarchy as th
 from ha2g_amd.config import CASES
 from ha2g_amd.optim import FusedAdam
-from ha2g_amd.testing import EpsInjector, batch_for, build_modules, named_state
+from ha2g_testing import EpsInjector, batch_for, build_modules, named_state
 DEV = 'cuda:0'
 name = sys.argv[1] if len(sys.argv) > 1 else 'cfg1'
 case = CASES[name]

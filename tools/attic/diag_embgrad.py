@@ -3,11 +3,11 @@ float64 and float32 run in-process: where does the error sit (row 0 = padding id
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from ha2g_amd import procedural as proc, schema, train_hierarchy as th
 from ha2g_amd.config import CASES, EXPRESSIVE_SPEC, make_args
 from ha2g_amd.optim import FusedAdam
-from ha2g_amd.testing import EpsInjector, batch_for, build_modules, state_for
+from ha2g_testing import EpsInjector, batch_for, build_modules, state_for
 from oracle import ha2g_oracle as O
 
 name = sys.argv[1] if len(sys.argv) > 1 else 'expr_cfg1'

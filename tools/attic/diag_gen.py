@@ -2,10 +2,10 @@
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from ha2g_amd import procedural as proc, schema
 from ha2g_amd.config import CASES
-from ha2g_amd.testing import build_modules, batch_for, state_for, wproc, leaf_params
+from ha2g_testing import build_modules, batch_for, state_for, wproc, leaf_params
 from oracle import ha2g_oracle as O
 
 DEV = 'cuda:0'

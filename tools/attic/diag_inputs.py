@@ -1,9 +1,9 @@
 import sys
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from ha2g_amd import ops, procedural as proc
 from ha2g_amd.config import CASES
-from ha2g_amd.testing import batch_for, build_modules, wproc
+from ha2g_testing import batch_for, build_modules, wproc
 DEV = 'cuda:0'
 for name in ('small', 'cfg1'):
     case = CASES[name]; g = np.load('tests/golden/%s.npz' % name)

@@ -1,9 +1,9 @@
 import sys
 import numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from ha2g_amd import procedural as proc
 from ha2g_amd.config import CASES
-from ha2g_amd.testing import batch_for, build_modules, wproc
+from ha2g_testing import batch_for, build_modules, wproc
 DEV = 'cuda:0'
 name = sys.argv[1] if len(sys.argv) > 1 else 'small'
 g = np.load('tests/golden/%s.npz' % name)

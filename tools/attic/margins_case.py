@@ -1,8 +1,8 @@
 """Worst error/tolerance ratios of a whole-step parity case per matrix-core mode: python tools/margins_case.py expr_cfg1 6 0"""
 import sys
 import numpy as np
-sys.path.insert(0, '.')
-from ha2g_amd.testing import Checker
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from ha2g_testing import Checker
 from ha2g_amd._lib import lib
 import tests.test_gpu_step as T
 

@@ -6,10 +6,10 @@ import sys
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from ha2g_amd import wav_b16 as wb, wav_engine as we
 from ha2g_amd.config import CASES
-from ha2g_amd.testing import batch_for, engine_P, state_for
+from ha2g_testing import batch_for, engine_P, state_for
 from oracle import ha2g_oracle as O
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4

@@ -4,12 +4,12 @@ computed by the HIP step in the given matrix-core modes -> gpurun_out/cfg1_audio
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from ha2g_amd import procedural as proc, train_hierarchy as th
 from ha2g_amd._lib import DEFAULT_GEMM_MODE, lib
 from ha2g_amd.config import CASES
 from ha2g_amd.optim import FusedAdam
-from ha2g_amd.testing import EpsInjector, batch_for, build_modules
+from ha2g_testing import EpsInjector, batch_for, build_modules
 
 DEV = 'cuda:0'
 case = CASES['cfg1']

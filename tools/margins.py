@@ -8,7 +8,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-from ha2g_amd.testing import Checker  # noqa: E402
+from ha2g_testing import Checker  # noqa: E402
 import test_gpu_step as ts  # noqa: E402
 
 
