@@ -169,8 +169,10 @@ def main():
     torch.manual_seed(0)
     from ha2g_amd import schema
     from ha2g_amd._lib import lib as _lib0
-    default_mode = int(os.environ.get('HA2G_GEMM_MODE', '22' if a.bf16 else '6'))
+    from ha2g_amd._lib import DEFAULT_GEMM_MODE
+    default_mode = int(os.environ['HA2G_GEMM_MODE']) if 'HA2G_GEMM_MODE' in os.environ else (22 if a.bf16 else DEFAULT_GEMM_MODE)
     _lib0.ha2g_gemm_set_mode(default_mode)
+    bwd_pieces = _lib0.ha2g_gemm_bwd_pieces()                # 3 = fp32-class backward (the default), 2 = 16-bit operand mantissa, 0 = fp32 MFMA / bf16
     from ha2g_amd import wav_engine as _we
     b16_storage = bool(a.bf16 and not a.fp32_storage) or os.environ.get('HA2G_B16') == '1'
     _we.set_b16(b16_storage)                                  # BASELINE config 5: bf16 activation / activation-gradient storage in the audio trunk
@@ -234,19 +236,23 @@ def main():
     # ---- headline: GPU-bound number = hipGraph replays of the captured step (N = 1); eager launches are timed next to it.  With more than one
     # rank the timed path is the eager one (RCCL collectives inside a capture have never run on this pool: an exception could be caught, a hang not).
     use_graph = a.launch == 'graph' or (a.launch == 'auto' and world == 1)
-    launch, graph_note = 'eager', (None if world == 1 else 'N > 1 ranks are timed with eager launches (RCCL collectives are not captured); the like-for-like single-GPU number is the N = 1 line\'s eager.value, which is 2-3 % above its graph-replay value')
-    dt = None
+    launch, graph_note = 'eager', (None if world == 1 else 'N > 1 ranks are timed with eager launches (RCCL collectives are not captured); the like-for-like single-GPU number is the N = 1 line\'s eager.ms_per_step')
+    dt = dt_graph = None
     if use_graph:
         try:
-            dt, last = timed_graph(a.epoch, a.steps)
-            launch = 'hipGraph replay'
+            dt_graph, last_graph = timed_graph(a.epoch, a.steps)
         except Exception as e:                       # fail over to the eager path, loudly, instead of losing the bench line
             graph_note = 'graph capture failed (%s: %s); value is the eager number' % (type(e).__name__, str(e)[:200])
             torch.cuda.synchronize()
     clock = dict(busy=0.0, steps=0)
     dt_eager, last_eager = timed_eager(a.epoch, a.steps, clock)
-    if dt is None:
+    # Both launch forms run the same kernels on the same data for exactly `steps` steps between barriers + device syncs; `value` is the faster of the
+    # two legs and says which (`launch`), the other one is printed beside it (`graph_replay` / `eager`).  --launch graph | eager pins the choice.
+    if dt_graph is not None and (a.launch == 'graph' or dt_graph <= dt_eager):
+        dt, last, launch = dt_graph, last_graph, 'hipGraph replay'
+    else:
         dt, last = dt_eager, last_eager
+    graph_leg = None if dt_graph is None else dict(ms_per_step=round(dt_graph / a.steps * 1e3, 3), value=round(a.batch * 34 * world / (dt_graph / a.steps), 1))
     eager = dict(ms_per_step=round(dt_eager / a.steps * 1e3, 3), value=round(a.batch * 34 * world / (dt_eager / a.steps), 1),
                  host_ms_per_step=round(clock['busy'] / max(clock['steps'], 1) * 1e3, 3),
                  note='host_ms_per_step = wall time inside train_iter minus the final wait for the loss read-back (python + autograd walk + launches)')
@@ -267,7 +273,7 @@ def main():
     # ROCm 7.0.2) -- a crash there would lose the whole line, so exactly ONE capture per process is made, the headline's.
     timed = lambda ep, n: timed_eager(ep, n)
     launch2 = 'eager'
-    ms_warm = ms_exact = ms_m2 = float('nan')
+    ms_warm = ms_exact = ms_m2 = ms_m6 = float('nan')
     if not a.primary_only:
         for _ in range(2):
             tr.train_iter(0, text, spec, target, vid)
@@ -277,10 +283,10 @@ def main():
             tr.train_iter(a.epoch, text, spec, target, vid)
         ms_exact = timed(a.epoch, a.steps)[0] / a.steps * 1e3
         if not a.bf16:
-            _lib.ha2g_gemm_set_mode(2)                   # exact fp32 on everything that compounds (forward + data gradients); weight gradients split-bf16
+            _lib.ha2g_gemm_set_mode(6)                   # the round-3 default: TWO-piece split backward (16-bit operand mantissa) -- narrower than the reference's arithmetic, labelled secondary
             for _ in range(2):
                 tr.train_iter(a.epoch, text, spec, target, vid)
-            ms_m2 = timed(a.epoch, a.steps)[0] / a.steps * 1e3
+            ms_m6 = timed(a.epoch, a.steps)[0] / a.steps * 1e3
         _lib.ha2g_gemm_set_mode(default_mode)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -321,7 +327,7 @@ def main():
         roof = gru_roof('gru_layer_fwd', 'gru_fwd_cluster_kernel (ha2g_gru_layer_fwd_cluster, H=300)', 'r03_pmc_gru_fwd.json', False)
         roof_bwd = gru_roof('gru_layer_bwd', 'gru_bwd_cluster_kernel (ha2g_gru_layer_bwd_cluster, H=300)', 'r03_pmc_gru_bwd.json', True)
         if roof_bwd is not None:     # the BPTT chain runs on the split-bf16 inner product in the default mode (3 bf16 MFMAs per product term, fp32 accumulate);
-            roof_bwd['arithmetic'] = 'fp32 MFMA' if a.bf16 else 'split-bf16 x3 (fp32-class; frac is still priced against the fp32 MFMA peak)'
+            roof_bwd['arithmetic'] = 'split-bf16 x2 (16-bit operand mantissa; frac is still priced against the fp32 MFMA peak)' if bwd_pieces == 2 else 'fp32 MFMA'
         roof_gemm = None
         if 'gemm_gi' in kt:                        # dominant dense-GEMM shape: the GRU input projections (rows x 600) . (600 x 900)^T, fp32 MFMA
             n, mean_us, _, flops = kt['gemm_gi']
@@ -343,9 +349,9 @@ def main():
                 return None
             n, mean_us, _, flops = kt[key]
             ach = flops / (n * mean_us * 1e-6) / 1e12
-            return dict(kernel=kernel, bound='mfma', achieved=round(ach, 2), peak=round(2500.0 / 3, 1), unit='TFLOP/s (fp32-equivalent: 3 bf16 MFMAs per product)',
-                        frac=round(ach / (2500.0 / 3), 4), launches=n, mean_us=round(mean_us, 1), traffic=None,
-                        counters='profiles/r03_pmc_bwd_gemm_before.txt (round-2 kernels: 15-18 VALU per MFMA, matrix pipe 19-23 % busy), profiles/r03_pmc_planes_wgrad_v1.txt')
+            nprod = 6 if bwd_pieces == 3 else 3                    # bf16 MFMAs per fp32-equivalent product
+            return dict(kernel=kernel, bound='mfma', achieved=round(ach, 2), peak=round(2500.0 / nprod, 1), unit='TFLOP/s (fp32-equivalent: %d bf16 MFMAs per product)' % nprod,
+                        frac=round(ach / (2500.0 / nprod), 4), launches=n, mean_us=round(mean_us, 1), traffic=None)
         roof_bwd_gemm = mfma3('conv_dgrad_planes', 'pconv_dgrad_kernel (ha2g_conv2d_dgrad_planes_f32: 3x3 data gradients of trunk layers 2-4, DMA-staged bf16 planes)')
         roof_bwd_wgrad = mfma3('conv_wgrad_planes', 'pconv_wgrad_kernel + wide reduce (ha2g_conv2d_wgrad_planes_f32: 3x3 weight gradients of trunk layers 2-4)')
 
@@ -377,15 +383,19 @@ def main():
                    vs_baseline=None,
                    dtype=(('bf16 (matrix operands; audio-trunk activations and activation gradients stored as bf16; fp32 accumulate, fp32 statistics, fp32 master weights and optimizer)'
                            if b16_storage else 'bf16 (operands; fp32 accumulate, fp32 storage and master weights)') if a.bf16 else
-                          'f32 (storage, accumulation, forward products: fp32 MFMA; backward products: bf16x2 split = 16-bit operand mantissa, fp32 accumulate)'),
-                   data='synthetic', rehearsal=rehearsal, launch=launch, launch_note=graph_note, rccl_world=rccl_world, eager=eager,
+                          {3: 'f32 (storage, accumulation; forward products: fp32 MFMA; backward products: bf16x3 split = all 24 operand mantissa bits, six bf16 MFMAs per product, fp32 accumulate -- or the exact fp32 MFMA where a family has no three-piece kernel)',
+                           2: 'f32 storage / accumulation, forward products fp32 MFMA; backward products: bf16x2 split = 16-bit operand mantissa (NOT fp32-class), fp32 accumulate',
+                           0: 'f32 (every product on the fp32 MFMA)'}[bwd_pieces]),
+                   data='synthetic', rehearsal=rehearsal, launch=launch, launch_note=graph_note, rccl_world=rccl_world, eager=eager, graph_replay=graph_leg,
+                   cluster_retries=tr.cluster_retries,
                    matrix_core=('bf16 operands (1 MFMA per product), fp32 accumulate, fp32 storage and master weights; GRU recurrences fp32' if a.bf16 else
-                                'forward: fp32 MFMA; backward GEMMs/convs/BPTT: 2-piece split-bf16 (hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; 4e-6 rms-rel per GEMM vs 4e-7 for fp32 MFMA); '
-                                'the fp32-arithmetic number is exact_fp32_matrix_core'),
+                                {3: 'forward: fp32 MFMA (v_mfma_f32_32x32x2_f32); backward GEMMs / convolutions: 3-piece split-bf16 (x = p0+p1+p2 holds all 24 mantissa bits; six v_mfma_f32_32x32x16_bf16 per product, smallest first, fp32 accumulate: as accurate as the fp32 MFMA chain, tests/test_gpu_np3.py); BPTT chain, direct 32-channel kernels: exact fp32 MFMA',
+                                 2: 'forward: fp32 MFMA; backward GEMMs/convs/BPTT: 2-piece split-bf16 (hi+lo, 3 bf16 MFMAs per product; 4e-6 rms-rel per GEMM vs 4e-7 for fp32 MFMA)',
+                                 0: 'fp32 MFMA everywhere'}[bwd_pieces]),
+                   two_piece_backward=dict(ms_per_step=round(ms_m6, 3), value=round(a.batch * 34 * world / (ms_m6 * 1e-3), 1) if ms_m6 == ms_m6 else None, steps=a.steps, launch=launch2,
+                                           arithmetic='ha2g_gemm_set_mode(6), the round-3 default: backward products on TWO bf16 pieces = 16-bit operand mantissa -- narrower than the reference\'s fp32 backward; a labelled secondary number, never `value`'),
                    exact_fp32_matrix_core=dict(ms_per_step=round(ms_exact, 3), value=round(a.batch * 34 * world / (ms_exact * 1e-3), 1), steps=a.steps, launch=launch2,
                                                arithmetic='every matrix product on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 (exact fp32, the reference\'s arithmetic class)'),
-                   fp32_data_path=dict(ms_per_step=round(ms_m2, 3), value=round(a.batch * 34 * world / (ms_m2 * 1e-3), 1), steps=a.steps, launch=launch2,
-                                       arithmetic='ha2g_gemm_set_mode(2): forward AND data-gradient products (everything an error can compound through) on the exact fp32 MFMA; only the weight-gradient products, which go straight to the optimizer, on the 2-piece split-bf16'),
                    warmup_phase=dict(ms_per_step=round(ms_warm, 3), value=round(a.batch * 34 * world / (ms_warm * 1e-3), 1), steps=a.steps, launch=launch2),
                    config=dict(workload='%s hierarchy train step, B=%d per GPU, T=34, %d-d pose, '
                                         'spec (128,70), n_words=%d, n_spk=%d, dropout 0.3, %s' % (

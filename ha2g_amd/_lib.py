@@ -98,7 +98,9 @@ def check(rc):
 
 # matrix-core mode (see ha2g_gemm_set_mode in include/ha2g_hip.h) and direct-convolution switches; the HA2G_GEMM_MODE / HA2G_DIRECT_C32
 # environment variables override the library defaults (tests restore THESE values after toggling modes)
-DEFAULT_GEMM_MODE = int(os.environ.get("HA2G_GEMM_MODE", "6"))
+# 70 = 64 + 6 (round 4): split backward products on THREE bf16 pieces per operand (all 24 mantissa bits, six MFMAs: fp32-class -- the reference's
+# arithmetic class), forward products on the exact fp32 MFMA.  6 = the round-3 default (two pieces: 16-bit operand mantissa), 0 = exact fp32 everywhere.
+DEFAULT_GEMM_MODE = int(os.environ.get("HA2G_GEMM_MODE", "70"))
 DEFAULT_DIRECT_C32 = int(os.environ.get("HA2G_DIRECT_C32", "1"))
 lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
 lib.ha2g_conv_debug_direct_c32(DEFAULT_DIRECT_C32)

@@ -713,7 +713,7 @@ int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs,
         unsigned host_tag0 = 0;
         const unsigned* epoch = launch_tag_base(xch, st, &host_tag0);
         const int grid = ceil_div(nclusters, 8) * 8 * G;
-        if (gemm_split_dgrad_enabled())     // data-gradient class of ha2g_gemm_set_mode: split-bf16 inner product (exact fp32 in mode 0)
+        if (gemm_split_dgrad_enabled() && gemm_bwd_pieces() == 2)     // two-piece split chain (mode 6); exact fp32 in mode 0 AND in the fp32-class default (three pieces of the resident W_hh slice do not fit the register file)
             hipLaunchKernelGGL(gru_bwd_cluster_kernel<true>, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg);
         else
             hipLaunchKernelGGL(gru_bwd_cluster_kernel<false>, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg);

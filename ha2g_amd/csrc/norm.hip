@@ -48,13 +48,22 @@ template <int V> __device__ __forceinline__ fvec<V> ldp(const float* p, int cv) 
     return r;
 }
 // the two bf16 planes of the split-bf16 product (fp32 tensors only)
-__device__ __forceinline__ void st_planes(unsigned short* hi, unsigned short* lo, long i, const fvec<4>& r) {
+// pnp = 3: three pieces (split3_bf16, all 24 mantissa bits), the third plane one plane stride (lo - hi) behind lo: equally spaced planes
+__device__ __forceinline__ void st_planes(unsigned short* hi, unsigned short* lo, int pnp, long i, const fvec<4>& r) {
+    if (pnp == 3) {
+        unsigned a[3], b[3];
+        split3_bf16(r.v[0], r.v[1], a[0], a[1], a[2]); split3_bf16(r.v[2], r.v[3], b[0], b[1], b[2]);
+        reinterpret_cast<uint2*>(hi)[i] = make_uint2(a[0], b[0]);
+        reinterpret_cast<uint2*>(lo)[i] = make_uint2(a[1], b[1]);
+        reinterpret_cast<uint2*>(lo + (lo - hi))[i] = make_uint2(a[2], b[2]);
+        return;
+    }
     uint2 h, l;
     split2_bf16(r.v[0], r.v[1], h.x, l.x); split2_bf16(r.v[2], r.v[3], h.y, l.y);
     reinterpret_cast<uint2*>(hi)[i] = h;
     reinterpret_cast<uint2*>(lo)[i] = l;
 }
-__device__ __forceinline__ void st_planes(unsigned short*, unsigned short*, long, const fvec<8>&) {}
+__device__ __forceinline__ void st_planes(unsigned short*, unsigned short*, int, long, const fvec<8>&) {}
 
 // thread layout shared by the column reductions: CV = C / V vector lanes per row, 256 % CV == 0
 struct ColMap {
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(256) void pair_final_kernel(const double* __restric
 template <int PL, typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, long rows,
-                                int C, int act, unsigned short* __restrict__ y_hi, unsigned short* __restrict__ y_lo) {
+                                int C, int act, unsigned short* __restrict__ y_hi, unsigned short* __restrict__ y_lo, int pnp) {
     constexpr int V = VW<T>::V;
     static_assert(!PL || V == 4, "planes are written from fp32 tensors");
     const int CV = C / V;
@@ -218,7 +227,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
             if (act == 2) r.v[k] = r.v[k] > 0.f ? r.v[k] : 0.01f * r.v[k];
         }
         stv(y, i, r);
-        if (PL) st_planes(y_hi, y_lo, i, r);
+        if (PL) st_planes(y_hi, y_lo, pnp, i, r);
     }
 }
 
@@ -293,7 +302,7 @@ template <int PL, typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_xhat, T* __restrict__ dx,
-                                    long rows, int C, int relu_mask, unsigned short* __restrict__ dx_hi, unsigned short* __restrict__ dx_lo) {
+                                    long rows, int C, int relu_mask, unsigned short* __restrict__ dx_hi, unsigned short* __restrict__ dx_lo, int pnp) {
     constexpr int V = VW<T>::V;
     static_assert(!PL || V == 4, "planes are written from fp32 tensors");
     const int CV = C / V;
@@ -311,7 +320,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
             if (relu_mask) r.v[k] = v.v[k] > 0.f ? r.v[k] : 0.f;  // x is a ReLU output (conv -> ReLU -> BN): chain the ReLU derivative, mask = (x > 0)
         }
         if (!PL || dx != nullptr) stv(dx, i, r);
-        if (PL) st_planes(dx_hi, dx_lo, i, r);
+        if (PL) st_planes(dx_hi, dx_lo, pnp, i, r);
     }
 }
 
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(256) void image_col_kernel(const T* __restrict__ x,
 template <int PL, typename T>
 __global__ void se_scale_add_relu_kernel(const T* __restrict__ x, const float* __restrict__ s, const T* __restrict__ res,
                                          T* __restrict__ out, long N, int HW, int C, unsigned short* __restrict__ o_hi,
-                                         unsigned short* __restrict__ o_lo) {
+                                         unsigned short* __restrict__ o_lo, int pnp) {
     constexpr int V = VW<T>::V;
     static_assert(!PL || V == 4, "planes are written from fp32 tensors");
     const int CV = C / V;
@@ -399,7 +408,7 @@ __global__ void se_scale_add_relu_kernel(const T* __restrict__ x, const float* _
 #pragma unroll
         for (int k = 0; k < V; ++k) o.v[k] = fmaxf(v.v[k] * sc.v[k] + r.v[k], 0.f);
         stv(out, i, o);
-        if (PL) st_planes(o_hi, o_lo, i, o);
+        if (PL) st_planes(o_hi, o_lo, pnp, i, o);
     }
 }
 // dpre = dout * (out > 0); dres = dpre; dx = dpre * s[n,c] + dpool[n,c]   (dpool already divided by HW)
@@ -494,11 +503,11 @@ int bn_stats_t(const T* x, long rows, int C, float* mean, float* invstd, float* 
     return 0;
 }
 template <int PL, typename T>
-int bn_apply_t(const T* x, const float* mean, const float* invstd, const float* gamma, const float* beta, T* y, void* y_hi, void* y_lo, long rows,
+int bn_apply_t(const T* x, const float* mean, const float* invstd, const float* gamma, const float* beta, T* y, void* y_hi, void* y_lo, int pnp, long rows,
                int C, int act, void* stream) {
     HA2G_REQUIRE(C % VW<T>::V == 0, "bn: C %% 4");
     hipLaunchKernelGGL((bn_apply_kernel<PL, T>), dim3(flat_grid(rows * (C / VW<T>::V))), dim3(256), 0, (hipStream_t)stream, x, mean, invstd, gamma, beta, y,
-                       rows, C, act, (unsigned short*)y_hi, (unsigned short*)y_lo);
+                       rows, C, act, (unsigned short*)y_hi, (unsigned short*)y_lo, pnp);
     HA2G_CHECK_LAUNCH("bn_apply");
     return 0;
 }
@@ -515,7 +524,7 @@ int bn_apply_pool_t(const T* x, const float* mean, const float* invstd, const fl
     return 0;
 }
 template <int PL, typename T>
-int bn_bwd_t(const T* dy, const T* x, const float* mean, const float* invstd, const float* gamma, T* dx, void* dx_hi, void* dx_lo, float* dgamma,
+int bn_bwd_t(const T* dy, const T* x, const float* mean, const float* invstd, const float* gamma, T* dx, void* dx_hi, void* dx_lo, int pnp, float* dgamma,
              float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta, float* ws, void* stream) {
     HA2G_REQUIRE(okCv<T>(C), "bn: unsupported channel count %d", C);
     hipStream_t st = (hipStream_t)stream;
@@ -524,15 +533,15 @@ int bn_bwd_t(const T* dy, const T* x, const float* mean, const float* invstd, co
     hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, C, dbeta, dgamma, acc_dbeta, acc_dgamma);
     if (PL || dx)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<PL, T>), dim3(flat_grid(rows * (C / VW<T>::V))), dim3(256), 0, st, dy, x, mean, invstd, gamma,
-                           (const float*)dbeta, (const float*)dgamma, dx, rows, C, relu_mask, (unsigned short*)dx_hi, (unsigned short*)dx_lo);
+                           (const float*)dbeta, (const float*)dgamma, dx, rows, C, relu_mask, (unsigned short*)dx_hi, (unsigned short*)dx_lo, pnp);
     HA2G_CHECK_LAUNCH("bn_bwd");
     return 0;
 }
 template <int PL, typename T>
-int se_scale_add_relu_t(const T* x, const float* s, const T* res, T* out, void* o_hi, void* o_lo, int N, int HW, int C, void* stream) {
+int se_scale_add_relu_t(const T* x, const float* s, const T* res, T* out, void* o_hi, void* o_lo, int pnp, int N, int HW, int C, void* stream) {
     HA2G_REQUIRE(C % VW<T>::V == 0, "se: C %% 4");
     hipLaunchKernelGGL((se_scale_add_relu_kernel<PL, T>), dim3(flat_grid((long)N * HW * (C / VW<T>::V))), dim3(256), 0, (hipStream_t)stream, x, s, res, out,
-                       (long)N, HW, C, (unsigned short*)o_hi, (unsigned short*)o_lo);
+                       (long)N, HW, C, (unsigned short*)o_hi, (unsigned short*)o_lo, pnp);
     HA2G_CHECK_LAUNCH("se_scale_add_relu");
     return 0;
 }
@@ -590,13 +599,19 @@ int ha2g_bn_stats_f32(const float* x, long rows, int C, float* mean, float* invs
 }
 int ha2g_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y,
                       long rows, int C, int act, void* stream) {
-    return bn_apply_t<0, float>(x, mean, invstd, gamma, beta, y, nullptr, nullptr, rows, C, act, stream);
+    return bn_apply_t<0, float>(x, mean, invstd, gamma, beta, y, nullptr, nullptr, 0, rows, C, act, stream);
 }
 // ha2g_bn_apply_f32 that also writes y as bf16 planes y_hi / y_lo [rows][C]
 int ha2g_bn_apply_planes_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y, void* y_hi,
                              void* y_lo, long rows, int C, int act, void* stream) {
     HA2G_REQUIRE(y_hi != nullptr && y_lo != nullptr, "bn_apply_planes: null plane");
-    return bn_apply_t<1, float>(x, mean, invstd, gamma, beta, y, y_hi, y_lo, rows, C, act, stream);
+    return bn_apply_t<1, float>(x, mean, invstd, gamma, beta, y, y_hi, y_lo, 2, rows, C, act, stream);
+}
+// np = 2 or 3 equally spaced piece planes: piece q at planes + q * ps (elements)
+int ha2g_bn_apply_planes_np_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y, void* planes,
+                                long ps, int np, long rows, int C, int act, void* stream) {
+    HA2G_REQUIRE(planes != nullptr && (np == 2 || np == 3), "bn_apply_planes_np: null plane / np = %d", np);
+    return bn_apply_t<1, float>(x, mean, invstd, gamma, beta, y, planes, (unsigned short*)planes + ps, np, rows, C, act, stream);
 }
 // y = bn(x) for x [N][HW][C] AND pooled[n][c] = mean over HW of y (the SE squeeze) in one pass over the tensor.
 // ws: >= ha2g_bn_apply_pool_workspace_floats(N, HW, C) floats.
@@ -610,14 +625,21 @@ int ha2g_bn_apply_pool_f32(const float* x, const float* mean, const float* invst
 int ha2g_bn_bwd_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx,
                     float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta, float* ws,
                     void* stream) {
-    return bn_bwd_t<0, float>(dy, x, mean, invstd, gamma, dx, nullptr, nullptr, dgamma, dbeta, rows, C, relu_mask, acc_dgamma, acc_dbeta, ws, stream);
+    return bn_bwd_t<0, float>(dy, x, mean, invstd, gamma, dx, nullptr, nullptr, 0, dgamma, dbeta, rows, C, relu_mask, acc_dgamma, acc_dbeta, ws, stream);
 }
 // ha2g_bn_bwd_f32 whose dx goes out as bf16 planes dx_hi / dx_lo [rows][C] (and, when dx != NULL, in fp32 as well)
 int ha2g_bn_bwd_planes_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx, void* dx_hi,
                            void* dx_lo, float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta,
                            float* ws, void* stream) {
     HA2G_REQUIRE(dx_hi != nullptr && dx_lo != nullptr, "bn_bwd_planes: null plane");
-    return bn_bwd_t<1, float>(dy, x, mean, invstd, gamma, dx, dx_hi, dx_lo, dgamma, dbeta, rows, C, relu_mask, acc_dgamma, acc_dbeta, ws, stream);
+    return bn_bwd_t<1, float>(dy, x, mean, invstd, gamma, dx, dx_hi, dx_lo, 2, dgamma, dbeta, rows, C, relu_mask, acc_dgamma, acc_dbeta, ws, stream);
+}
+int ha2g_bn_bwd_planes_np_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx, void* planes,
+                              long ps, int np, float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta,
+                              float* ws, void* stream) {
+    HA2G_REQUIRE(planes != nullptr && (np == 2 || np == 3), "bn_bwd_planes_np: null plane / np = %d", np);
+    return bn_bwd_t<1, float>(dy, x, mean, invstd, gamma, dx, planes, (unsigned short*)planes + ps, np, dgamma, dbeta, rows, C, relu_mask, acc_dgamma,
+                              acc_dbeta, ws, stream);
 }
 // out[n][c] = mean over HW of x[n][hw][c]
 int ha2g_hw_mean_f32(const float* x, float* out, int N, int HW, int C, void* stream) {
@@ -628,13 +650,18 @@ int ha2g_hw_mean_f32(const float* x, float* out, int N, int HW, int C, void* str
     return 0;
 }
 int ha2g_se_scale_add_relu_f32(const float* x, const float* s, const float* res, float* out, int N, int HW, int C, void* stream) {
-    return se_scale_add_relu_t<0, float>(x, s, res, out, nullptr, nullptr, N, HW, C, stream);
+    return se_scale_add_relu_t<0, float>(x, s, res, out, nullptr, nullptr, 0, N, HW, C, stream);
 }
 // the same, out also as bf16 planes (the next block's conv1 reads them in its weight gradient)
 int ha2g_se_scale_add_relu_planes_f32(const float* x, const float* s, const float* res, float* out, void* o_hi, void* o_lo, int N, int HW, int C,
                                       void* stream) {
     HA2G_REQUIRE(o_hi != nullptr && o_lo != nullptr, "se_scale_add_relu_planes: null plane");
-    return se_scale_add_relu_t<1, float>(x, s, res, out, o_hi, o_lo, N, HW, C, stream);
+    return se_scale_add_relu_t<1, float>(x, s, res, out, o_hi, o_lo, 2, N, HW, C, stream);
+}
+int ha2g_se_scale_add_relu_planes_np_f32(const float* x, const float* s, const float* res, float* out, void* planes, long ps, int np, int N, int HW,
+                                         int C, void* stream) {
+    HA2G_REQUIRE(planes != nullptr && (np == 2 || np == 3), "se_scale_add_relu_planes_np: null plane / np = %d", np);
+    return se_scale_add_relu_t<1, float>(x, s, res, out, planes, (unsigned short*)planes + ps, np, N, HW, C, stream);
 }
 // ds[n][c] = sum_hw dout*(out>0)*x
 int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, float* ds, int N, int HW, int C, const float* gate, float* ws,
@@ -665,7 +692,7 @@ int ha2g_bn_stats_b16(const void* x, long rows, int C, float* mean, float* invst
 }
 int ha2g_bn_apply_b16(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, void* y, long rows, int C,
                       int act, void* stream) {
-    return bn_apply_t<0, b16>((const b16*)x, mean, invstd, gamma, beta, (b16*)y, nullptr, nullptr, rows, C, act, stream);
+    return bn_apply_t<0, b16>((const b16*)x, mean, invstd, gamma, beta, (b16*)y, nullptr, nullptr, 0, rows, C, act, stream);
 }
 int ha2g_bn_apply_pool_b16(const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, void* y, int N, int HW,
                            int C, float* pooled, float* ws, void* stream) {
@@ -673,11 +700,11 @@ int ha2g_bn_apply_pool_b16(const void* x, const float* mean, const float* invstd
 }
 int ha2g_bn_bwd_b16(const void* dy, const void* x, const float* mean, const float* invstd, const float* gamma, void* dx, float* dgamma,
                     float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta, float* ws, void* stream) {
-    return bn_bwd_t<0, b16>((const b16*)dy, (const b16*)x, mean, invstd, gamma, (b16*)dx, nullptr, nullptr, dgamma, dbeta, rows, C, relu_mask,
+    return bn_bwd_t<0, b16>((const b16*)dy, (const b16*)x, mean, invstd, gamma, (b16*)dx, nullptr, nullptr, 0, dgamma, dbeta, rows, C, relu_mask,
                             acc_dgamma, acc_dbeta, ws, stream);
 }
 int ha2g_se_scale_add_relu_b16(const void* x, const float* s, const void* res, void* out, int N, int HW, int C, void* stream) {
-    return se_scale_add_relu_t<0, b16>((const b16*)x, s, (const b16*)res, (b16*)out, nullptr, nullptr, N, HW, C, stream);
+    return se_scale_add_relu_t<0, b16>((const b16*)x, s, (const b16*)res, (b16*)out, nullptr, nullptr, 0, N, HW, C, stream);
 }
 int ha2g_se_bwd_scale_b16(const void* dout, const void* out, const void* x, float* ds, int N, int HW, int C, const float* gate, float* ws,
                           void* stream) {

@@ -763,25 +763,31 @@ def bn_bwd(dy2, x2, mean, invstd, gamma, need_dx=True, relu_mask=False, acc=None
     # algorithmic HBM bytes of the backward (bench.py roofline_bn): statistics pass reads dy and x, apply pass reads them again and writes dx
     nbytes = 4.0 * rows * C * (5 if (need_dx or planes) else 2)
     if planes:
-        hi = torch.empty(rows, C, dtype=torch.bfloat16, device=x2.device)
-        lo = torch.empty(rows, C, dtype=torch.bfloat16, device=x2.device)
-        ktimer.launch('bn_bwd', lambda: check(lib.ha2g_bn_bwd_planes_f32(
-            dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dx), hi.data_ptr(), lo.data_ptr(),
+        pl = torch.empty(pieces(), rows, C, dtype=torch.bfloat16, device=x2.device)       # piece planes [np][rows][C]
+        ktimer.launch('bn_bwd', lambda: check(lib.ha2g_bn_bwd_planes_np_f32(
+            dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dx), pl.data_ptr(), pl.stride(0), pl.shape[0],
             dgamma.data_ptr(), dbeta.data_ptr(), rows, C, int(relu_mask), _p(ag), _p(ab), workspace(x2.device).data_ptr(), _stream())),
-            nbytes + (4.0 * rows * C if need_dx else 0.0))
-        return dx, dgamma, dbeta, (hi, lo)
+            nbytes + (4.0 * rows * C if need_dx else 0.0) + 2.0 * (pl.shape[0] - 2) * rows * C)
+        return dx, dgamma, dbeta, pl
     ktimer.launch('bn_bwd', lambda: check(lib.ha2g_bn_bwd_f32(
         dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dx), dgamma.data_ptr(), dbeta.data_ptr(), rows, C,
         int(relu_mask), _p(ag), _p(ab), workspace(x2.device).data_ptr(), _stream())), nbytes)
     return dx, dgamma, dbeta
 
 
-def to_planes(x):
-    """fp32 tensor -> (hi, lo) bf16 planes of the same shape: hi = bf16(x), lo = bf16(x - hi) (the operand split of the split-bf16 product)."""
+def pieces():
+    """bf16 pieces per operand of the split backward products in the current arithmetic mode (ha2g_gemm_set_mode bit 6): 3 = fp32-class
+    (x = p0 + p1 + p2, all 24 mantissa bits; the default), 2 = the round-3 hi / lo split."""
+    return 3 if lib.ha2g_gemm_bwd_pieces() == 3 else 2
+
+
+def to_planes(x, np_=None):
+    """fp32 tensor -> its bf16 piece planes, one tensor [np, *x.shape]: p0 = bf16(x), p1 = bf16(x - p0) (, p2 = bf16(x - p0 - p1)) -- the operand
+    split of the split-bf16 products; np = pieces() unless given.  With np = 2, `hi, lo = to_planes(x)` unpacks the round-3 planes."""
     x = _f32c(x)
-    hi, lo = torch.empty_like(x, dtype=torch.bfloat16), torch.empty_like(x, dtype=torch.bfloat16)
-    check(lib.ha2g_f32_to_planes(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), x.numel(), _stream()))
-    return hi, lo
+    pl = torch.empty((np_ or pieces(),) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)
+    check(lib.ha2g_f32_to_planes_np(x.data_ptr(), pl.data_ptr(), pl.stride(0), pl.shape[0], x.numel(), _stream()))
+    return pl
 
 
 class BatchNormFunction(torch.autograd.Function):

@@ -90,23 +90,24 @@ def prepare_weight_planes(P):
     dev = items[0][1].device
     sizes = [w.numel() for _, w in items]
     total = sum(sizes)
-    hi, lo = torch.empty(total, dtype=torch.bfloat16, device=dev), torch.empty(total, dtype=torch.bfloat16, device=dev)
+    npc = ops.pieces()
+    buf = torch.empty(npc, total, dtype=torch.bfloat16, device=dev)          # every weight's piece q inside plane q of ONE buffer: equal plane stride
     out, off = {}, 0
-    wp, hp, lp = (np.empty(len(items), np.int64) for _ in range(3))
+    wp, hp, ps = (np.empty(len(items), np.int64) for _ in range(3))
     co, kk, ci = (np.empty(len(items), np.int32) for _ in range(3))
     keep = []
     for i, ((name, w), n) in enumerate(zip(items, sizes)):
         Cout, KH, KW, Cin = w.shape
-        h_, l_ = hi[off:off + n].view(Cin, KH, KW, Cout), lo[off:off + n].view(Cin, KH, KW, Cout)
-        out[name] = (h_, l_)
-        wp[i], hp[i], lp[i] = w.data_ptr(), h_.data_ptr(), l_.data_ptr()
+        v = buf[:, off:off + n].view(npc, Cin, KH, KW, Cout)                  # strided view: piece q = v[q]
+        out[name] = v
+        wp[i], hp[i], ps[i] = w.data_ptr(), v.data_ptr(), v.stride(0)
         co[i], kk[i], ci[i] = Cout, KH * KW, Cin
         keep.append(w)
         off += n
     for k0 in range(0, len(items), 48):
         n = min(48, len(items) - k0)
-        check(lib.ha2g_conv2d_weight_ihwo_planes_multi(wp[k0:].ctypes.data, hp[k0:].ctypes.data, lp[k0:].ctypes.data, co[k0:].ctypes.data,
-                                                       kk[k0:].ctypes.data, ci[k0:].ctypes.data, n, _stream()))
+        check(lib.ha2g_conv2d_weight_ihwo_planes_multi_np(wp[k0:].ctypes.data, hp[k0:].ctypes.data, ps[k0:].ctypes.data, co[k0:].ctypes.data,
+                                                          kk[k0:].ctypes.data, ci[k0:].ctypes.data, n, npc, _stream()))
     return out
 
 
@@ -118,23 +119,33 @@ def conv_dgrad_planes(dy_planes, w_ohwi, xshape, stride, pad, out=None, beta=0.0
     the data gradient through the DMA-staged kernel of csrc/conv_planes.hip.  Bit-identical to conv_dgrad() in the default arithmetic mode."""
     N, H, W, Cin = xshape
     Cout, KH, KW, _ = w_ohwi.shape
-    hi, lo = dy_planes
-    pre = _WPLANES[0].get(w_ohwi.data_ptr()) if _WPLANES[0] is not None else None
-    if pre is not None:
-        wh, wl = pre
-    else:
-        wh = torch.empty(Cin, KH, KW, Cout, dtype=torch.bfloat16, device=hi.device)
-        wl = torch.empty_like(wh)
-        check(lib.ha2g_conv2d_weight_ihwo_planes(w_ohwi.data_ptr(), wh.data_ptr(), wl.data_ptr(), Cout, KH, KW, Cin, _stream()))
+    dyp = dy_planes                                       # [np, N, OH, OW, Cout] (or [np, rows, Cout]) bf16 piece planes
+    npc = dyp.shape[0]
+    wpl = _WPLANES[0].get(w_ohwi.data_ptr()) if _WPLANES[0] is not None else None
+    if wpl is None or wpl.shape[0] != npc:
+        wpl = weight_planes(w_ohwi, npc)
     if out is None:
-        out = torch.empty(N, H, W, Cin, dtype=torch.float32, device=hi.device)
+        out = torch.empty(N, H, W, Cin, dtype=torch.float32, device=dyp.device)
         beta = 0.0
     if beta == 0.0 and stride == 2 and KH == 1:
         out.zero_()                                       # a 1x1 stride-2 kernel reaches one pixel in four: the kernel writes only those
-    ops.ktimer.launch('conv_dgrad_planes' if stride == 1 else 'conv_dgrad_planes_s2', lambda: check(lib.ha2g_conv2d_dgrad_planes_f32(
-        hi.data_ptr(), lo.data_ptr(), wh.data_ptr(), wl.data_ptr(), out.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad, beta, _stream())),
+    ops.ktimer.launch('conv_dgrad_planes' if stride == 1 else 'conv_dgrad_planes_s2', lambda: check(lib.ha2g_conv2d_dgrad_planes_np_f32(
+        dyp.data_ptr(), dyp.stride(0), wpl.data_ptr(), wpl.stride(0), npc, out.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad, beta, _stream())),
         2.0 * N * H * W * Cin * KH * KW * Cout)
     return out
+
+
+def weight_planes(w_ohwi, npc):
+    """piece planes [np, Cin, KH, KW, Cout] of ONE transposed weight (the batched form is prepare_weight_planes)."""
+    import numpy as np
+    Cout, KH, KW, Cin = w_ohwi.shape
+    wpl = torch.empty(npc, Cin, KH, KW, Cout, dtype=torch.bfloat16, device=w_ohwi.device)
+    a = lambda v, dt: np.array([v], dt)
+    wp, hp, ps = a(w_ohwi.data_ptr(), np.int64), a(wpl.data_ptr(), np.int64), a(wpl.stride(0), np.int64)
+    co, kk, ci = a(Cout, np.int32), a(KH * KW, np.int32), a(Cin, np.int32)
+    check(lib.ha2g_conv2d_weight_ihwo_planes_multi_np(wp.ctypes.data, hp.ctypes.data, ps.ctypes.data, co.ctypes.data, kk.ctypes.data, ci.ctypes.data,
+                                                      1, npc, _stream()))
+    return wpl
 
 
 def conv_wgrad(x, dy, w_ohwi, stride, pad, into=None):
@@ -160,6 +171,8 @@ def conv_wgrad(x, dy, w_ohwi, stride, pad, into=None):
 
 
 def wgrad_planes_ok(x, w_ohwi, stride, pad):
+    """the plane weight-gradient kernel is a two-piece kernel: in the fp32-class (three-piece) mode the library answers 0 here and the weight
+    gradient takes the implicit GEMM with the three-piece plane tiles (gemm_kernel<.., SPLIT = 4>)"""
     Cout, KH, KW, Cin = w_ohwi.shape
     return bool(PLANES & 2) and bool(lib.ha2g_conv2d_wgrad_planes_supported(x.shape[1], x.shape[2], Cin, Cout, KH, KW, stride, pad))
 
@@ -217,11 +230,10 @@ def _bn_fwd(x, bn, pool=False, planes=False):
         return y, mean, invstd, pooled
     if planes:
         y = torch.empty_like(x2)
-        hi = torch.empty(x2.shape, dtype=torch.bfloat16, device=x.device)
-        lo = torch.empty_like(hi)
-        check(lib.ha2g_bn_apply_planes_f32(x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), bn.gamma.data_ptr(), bn.beta.data_ptr(), y.data_ptr(),
-                                           hi.data_ptr(), lo.data_ptr(), x2.shape[0], x2.shape[1], ACT_NONE, _stream()))
-        return y.view(x.shape), mean, invstd, (hi, lo)
+        pl = torch.empty((2,) + tuple(x2.shape), dtype=torch.bfloat16, device=x.device)      # the x operand of the (two-piece) plane weight gradient
+        check(lib.ha2g_bn_apply_planes_np_f32(x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), bn.gamma.data_ptr(), bn.beta.data_ptr(), y.data_ptr(),
+                                              pl.data_ptr(), pl.stride(0), 2, x2.shape[0], x2.shape[1], ACT_NONE, _stream()))
+        return y.view(x.shape), mean, invstd, pl
     y = ops.bn_apply(x2, mean, invstd, bn.gamma, bn.beta).view(x.shape)
     return y, mean, invstd
 
@@ -355,10 +367,10 @@ class GradSink:
         with ctx:
             if side_on:
                 st = torch.cuda.current_stream(xin.device)
-                xin.record_stream(st); dy_planes[0].record_stream(st); dy_planes[1].record_stream(st)
+                xin.record_stream(st); dy_planes.record_stream(st)
             if x_planes is not None and side_on:
-                x_planes[0].record_stream(st); x_planes[1].record_stream(st)
-            xp = x_planes if x_planes is not None else ops.to_planes(xin)
+                x_planes.record_stream(st)
+            xp = x_planes if x_planes is not None else ops.to_planes(xin, 2)
             r = conv_wgrad_planes(xp, dy_planes, w_ohwi, xin.shape, into=self.tgt(self.P[name]))
             if r is not None and side_on:
                 r.record_stream(torch.cuda.default_stream(xin.device))
@@ -431,9 +443,9 @@ def block_fwd(x, P, b, first, xp=None, out_planes=False):
     out = torch.empty_like(b2)
     outp = None
     if out_planes and _FWD_PLANES[0] and wgrad_planes_ok(out, wb, 1, 1):
-        outp = (torch.empty(out.shape, dtype=torch.bfloat16, device=out.device), torch.empty(out.shape, dtype=torch.bfloat16, device=out.device))
-        check(lib.ha2g_se_scale_add_relu_planes_f32(b2.data_ptr(), sc.data_ptr(), res.data_ptr(), out.data_ptr(), outp[0].data_ptr(), outp[1].data_ptr(),
-                                                    N, OH * OW, C, _stream()))
+        outp = torch.empty((2,) + tuple(out.shape), dtype=torch.bfloat16, device=out.device)
+        check(lib.ha2g_se_scale_add_relu_planes_np_f32(b2.data_ptr(), sc.data_ptr(), res.data_ptr(), out.data_ptr(), outp.data_ptr(), outp.stride(0), 2,
+                                                       N, OH * OW, C, _stream()))
     else:
         check(lib.ha2g_se_scale_add_relu_f32(b2.data_ptr(), sc.data_ptr(), res.data_ptr(), out.data_ptr(), N, OH * OW, C, _stream()))
     return out, (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride, xp, a1p), outp
@@ -638,6 +650,13 @@ class WavEncoderFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dw_ext, dlow, dmid, dhigh, *dblend):
+        try:
+            return WavEncoderFunction._backward(ctx, dw_ext, dlow, dmid, dhigh, *dblend)
+        finally:
+            _WPLANES[0] = None                           # a failed backward must not leave another step's weight planes behind
+
+    @staticmethod
+    def _backward(ctx, dw_ext, dlow, dmid, dhigh, *dblend):
         S, P, L = ctx.S, ctx.P, ctx.L
         sink = GradSink(P)
         G = sink.G
@@ -656,7 +675,9 @@ class WavEncoderFunction(torch.autograd.Function):
             dfeat[ti + 1] = tap_bwd(df[ti], S['tap_' + t], P, t, r, sink)
         # ---- trunk backward ----
         if WPLANES_MULTI and not ctx.b16:
-            _WPLANES[0] = {_ohwi(P[n]).data_ptr(): v for n, v in prepare_weight_planes(P).items()}
+            # keyed by the address of the weight's physical OHWI image -- only where that image is a VIEW of the parameter (channels_last storage):
+            # a `.contiguous()` temporary is freed at once and the caching allocator may hand its address to the next weight of the same shape
+            _WPLANES[0] = {P[n].data_ptr(): v for n, v in prepare_weight_planes(P).items() if P[n].permute(0, 2, 3, 1).is_contiguous()}
         if ctx.b16:
             from . import wav_b16
             wav_b16.trunk_bwd(dfeat, S, P, LAYERS, sink)

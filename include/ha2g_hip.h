@@ -76,6 +76,17 @@ int ha2g_conv2d_weight_ihwo_planes(const float* w, void* wt_hi, void* wt_lo, int
 /* ha2g_conv2d_weight_ihwo_planes for n <= 48 weights in one launch; w / wt_hi / wt_lo / cout / kk / cin are HOST arrays of n entries */
 int ha2g_conv2d_weight_ihwo_planes_multi(const void* const* w, void* const* wt_hi, void* const* wt_lo, const int* cout, const int* kk, const int* cin,
                                          int n, void* stream);
+/* ABI 2: the same operations on np = 2 or 3 PIECE planes, piece q of a tensor at base + q * ps elements (equally spaced planes of one
+ * allocation).  np = 3 (x = p0 + p1 + p2, all 24 mantissa bits; six MFMAs per product, smallest first) is the fp32-class form that the default
+ * backward runs (ha2g_gemm_set_mode bit 6, ha2g_gemm_bwd_pieces): the arithmetic class of the reference's loss.backward()
+ * (train_eval/train_hierarchy.py:264); the two-plane entry points above are np = 2, ps = lo - hi. */
+int ha2g_f32_to_planes_np(const float* x, void* planes, long ps, int np, long n, void* stream);
+int ha2g_conv2d_weight_ihwo_planes_multi_np(const void* const* w, void* const* wt, const long* ps, const int* cout, const int* kk, const int* cin,
+                                            int n, int np, void* stream);
+int ha2g_conv2d_dgrad_planes_np_f32(const void* dy, long dy_ps, const void* wt, long wt_ps, int np, float* dx, int N, int H, int W,
+                                    int Cin, int Cout, int KH, int KW, int stride, int pad, float beta, void* stream);
+void ha2g_conv_planes_tile3(int t);       /* A/B: tile of the three-piece plane kernel (0 = default, 1 = 128x128, 2 = 256x64, 3 = 128x64) */
+int ha2g_gemm_bwd_pieces(void);           /* 0 = backward products on the fp32 MFMA / plain bf16, 2 / 3 = bf16 pieces per operand of the split products */
 int ha2g_conv2d_dgrad_planes_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
 int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N, int H, int W,
                                  int Cin, int Cout, int KH, int KW, int stride, int pad, float beta, void* stream);
@@ -147,6 +158,11 @@ int ha2g_conv2d_wgrad_planes_f32(const void* x_hi, const void* x_lo, const void*
  *                generator head): fp32-accurate; the convolutions and the audio tower's own (narrow) GEMMs stay on the fp32 MFMA, so the tower's
  *                forward arithmetic is bit-identical with and without it (tests/test_gpu_kernels.py).  Measured slower on the whole step (60.1 vs 58.0 ms:
  *                the skinny-K projections are LDS-bound on the split kernel), kept opt-in.
+ *   bit 6 (ON by default since round 4 -- ha2g_amd/_lib.py sets mode 70 = 64 + 6): the split backward products of bits 1 / 2 use THREE bf16
+ *                pieces per operand and six MFMAs (x = p0 + p1 + p2 holds all 24 mantissa bits; products down to 2^-24 kept): fp32-class,
+ *                i.e. the arithmetic class of the reference's fp32 loss.backward() (train_hierarchy.py:264).  Kernel families without a
+ *                three-piece form (the BPTT chain, the direct 32-channel kernels, shapes the planes do not serve) run the EXACT fp32 MFMA in
+ *                this mode -- never two pieces.  Mode 6 (two pieces, 16-bit operand mantissa) survives as a labelled secondary mode.
  * 0 = exact fp32 MFMA everywhere. */
 void ha2g_gemm_set_mode(int mode);
 /* tuning aid: forward GEMMs narrower than n columns stay on the fp32 MFMA */
@@ -238,6 +254,14 @@ int ha2g_bn_apply_planes_f32(const float* x, const float* mean, const float* inv
                              void* y_lo, long rows, int C, int act, void* stream);
 int ha2g_se_scale_add_relu_planes_f32(const float* x, const float* s, const float* res, float* out, void* o_hi, void* o_lo, int N, int HW, int C,
                                       void* stream);
+/* ABI 2: the three producers above writing np = 2 or 3 equally spaced piece planes (piece q at planes + q * ps elements) */
+int ha2g_bn_bwd_planes_np_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx, void* planes,
+                              long ps, int np, float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta,
+                              float* ws, void* stream);
+int ha2g_bn_apply_planes_np_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y, void* planes,
+                                long ps, int np, long rows, int C, int act, void* stream);
+int ha2g_se_scale_add_relu_planes_np_f32(const float* x, const float* s, const float* res, float* out, void* planes, long ps, int np, int N, int HW,
+                                         int C, void* stream);
 /* ---- squeeze-excite pointwise pieces (model/ResNetBlocks.py:81-95 and the residual tail :33-36) ---- */
 int ha2g_hw_mean_f32(const float* x, float* out, int N, int HW, int C, void* stream);
 int ha2g_se_scale_add_relu_f32(const float* x, const float* s, const float* res, float* out, int N, int HW, int C, void* stream);

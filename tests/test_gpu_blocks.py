@@ -55,7 +55,7 @@ def run_block(ck, name, geom, B, seed):
     we._NBT_PENDING.clear()
 
 
-@pytest.mark.parametrize('mode', [6, 0])
+@pytest.mark.parametrize('mode', [70, 6, 0])
 @pytest.mark.parametrize('name', list(BLOCK_CASES))
 def test_se_block_strict(golden, gemm_mode, name, mode):
     gemm_mode(mode)
@@ -115,7 +115,7 @@ def run_taps(ck, case, seed):
     we._NBT_PENDING.clear()
 
 
-@pytest.mark.parametrize('mode', [6, 0])
+@pytest.mark.parametrize('mode', [70, 6, 0])
 def test_taps_and_blend_strict(golden, gemm_mode, mode):
     gemm_mode(mode)
     g = golden('blocks')

@@ -1,0 +1,140 @@
+"""The fp32-class backward of round 4 (ha2g_gemm_set_mode bit 6, the default): every split product runs on THREE bf16 pieces per operand and six
+MFMAs, x = p0 + p1 + p2 holding all 24 mantissa bits, products down to 2^-24 kept.  Each kernel family is held against float64 at the accuracy
+of the exact fp32 MFMA chain (and against that chain itself), on the shapes the train step uses.  (Replaces autograd's fp32 loss.backward(),
+train_eval/train_hierarchy.py:264; conv2d / linear backward of model/ResNetBlocks.py:24-29, model/hierarchy_net.py:87-93.)"""
+import pytest
+import torch
+
+from ha2g_amd import ops, wav_engine as we
+from ha2g_amd._lib import DEFAULT_GEMM_MODE, lib
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(autouse=True)
+def three_piece_mode():
+    lib.ha2g_gemm_set_mode(70)
+    yield
+    lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
+
+
+def test_default_mode_is_the_three_piece_backward():
+    assert DEFAULT_GEMM_MODE & 64 and lib.ha2g_gemm_bwd_pieces() == 3 and ops.pieces() == 3
+    lib.ha2g_gemm_set_mode(6)
+    assert lib.ha2g_gemm_bwd_pieces() == 2
+    lib.ha2g_gemm_set_mode(0)
+    assert lib.ha2g_gemm_bwd_pieces() == 0
+
+
+def test_three_pieces_hold_the_whole_fp32_mantissa():
+    torch.manual_seed(0)
+    x = torch.randn(1 << 16, device=DEV) * torch.logspace(-6, 6, 1 << 16, device=DEV)
+    pl = ops.to_planes(x)
+    assert pl.shape[0] == 3
+    assert torch.equal(pl[0], x.bfloat16())
+    r1 = x - pl[0].float()
+    assert torch.equal(pl[1], r1.bfloat16())
+    assert torch.equal(pl[2], (r1 - pl[1].float()).bfloat16())
+    assert torch.equal(pl[0].float() + pl[1].float() + pl[2].float(), x)          # exact: nothing of the fp32 value is lost
+
+
+def _rel(a, ref):
+    return float((a.double() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize('relu_mask', [False, True])
+def test_bn_bwd_writes_three_piece_planes(relu_mask):
+    torch.manual_seed(1)
+    rows, C = 4 * 32 * 18, 128
+    x = torch.relu(torch.randn(rows, C, device=DEV) + 0.2) if relu_mask else torch.randn(rows, C, device=DEV)
+    dy = torch.randn(rows, C, device=DEV)
+    mean, invstd = ops.bn_stats(x, None, None, 0.1, 1e-5)
+    gamma = torch.rand(C, device=DEV) + 0.5
+    dx0, dg0, db0 = ops.bn_bwd(dy, x, mean, invstd, gamma, relu_mask=relu_mask)
+    dx1, dg1, db1, pl = ops.bn_bwd(dy, x, mean, invstd, gamma, relu_mask=relu_mask, planes=True)
+    assert pl.shape[0] == 3 and torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert torch.equal(pl, ops.to_planes(dx0))
+    assert torch.equal(pl[0].float() + pl[1].float() + pl[2].float(), dx0)
+    _, _, _, pl2 = ops.bn_bwd(dy, x, mean, invstd, gamma, need_dx=False, relu_mask=relu_mask, planes=True)
+    assert torch.equal(pl2, pl)
+
+
+@pytest.mark.parametrize('tile', [0, 1, 2, 3])
+@pytest.mark.parametrize('B,H,W,C', [(4, 64, 35, 64), (3, 32, 18, 128), (5, 16, 9, 256), (1, 7, 5, 64), (128, 32, 18, 128)])
+def test_dgrad_three_piece_planes_are_fp32_class(B, H, W, C, tile):
+    """3x3 stride-1 data gradients of trunk layers 2-4 on the DMA-staged plane kernel with three pieces: as close to float64 as the exact fp32
+    MFMA kernel (mode 0) is -- 20x closer than the two-piece product -- for every tile shape of the kernel, beta = 0 and beta = 1."""
+    torch.manual_seed(2)
+    dy = torch.randn(B, H, W, C, device=DEV)
+    w = torch.randn(C, 3, 3, C, device=DEV) * 0.05
+    assert we.dgrad_planes_ok(w, 1, 1)
+    x64 = torch.nn.functional.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    lib.ha2g_conv_planes_tile3(tile)
+    try:
+        got = we.conv_dgrad_planes(ops.to_planes(dy), w, (B, H, W, C), 1, 1)
+        base = torch.randn(B, H, W, C, device=DEV)
+        got1 = we.conv_dgrad_planes(ops.to_planes(dy), w, (B, H, W, C), 1, 1, out=base.clone(), beta=1.0)
+    finally:
+        lib.ha2g_conv_planes_tile3(0)
+    lib.ha2g_gemm_set_mode(0)
+    exact = we.conv_dgrad(dy, w, (B, H, W, C), 1, 1)
+    lib.ha2g_gemm_set_mode(70)
+    e3, e32 = _rel(got, x64), _rel(exact, x64)
+    assert e3 < 1.5e-6 and e3 < 2.0 * e32 + 2e-7, (e3, e32)
+    assert _rel(got1 - base, x64) < 3e-6
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,k', [(4, 128, 70, 32, 64, 3), (3, 64, 35, 64, 128, 3), (5, 32, 18, 128, 256, 3), (2, 9, 7, 64, 64, 3),
+                                              (4, 128, 70, 32, 64, 1), (3, 64, 35, 64, 128, 1), (4, 32, 18, 128, 256, 1)])
+def test_stride2_dgrad_three_piece_planes_are_fp32_class(B, H, W, Cin, Cout, k):
+    torch.manual_seed(5)
+    pad = 1 if k == 3 else 0
+    OH, OW = (H + 2 * pad - k) // 2 + 1, (W + 2 * pad - k) // 2 + 1
+    dy = torch.randn(B, OH, OW, Cout, device=DEV)
+    w = torch.randn(Cout, k, k, Cin, device=DEV) * 0.05
+    assert we.dgrad_planes_ok(w, 2, pad)
+    got = we.conv_dgrad_planes(ops.to_planes(dy), w, (B, H, W, Cin), 2, pad)
+    x64 = torch.nn.functional.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), stride=2, padding=pad,
+                                               output_padding=(H - ((OH - 1) * 2 - 2 * pad + k), W - ((OW - 1) * 2 - 2 * pad + k))).permute(0, 2, 3, 1)
+    assert _rel(got, x64) < 1.5e-6
+
+
+@pytest.mark.parametrize('H,W,Cin,Cout,k,stride,pad', [(64, 35, 64, 64, 3, 1, 1), (32, 18, 128, 128, 3, 1, 1), (16, 9, 256, 256, 3, 1, 1), (128, 70, 32, 32, 3, 1, 1),
+                                                       (128, 70, 32, 64, 3, 2, 1), (64, 35, 64, 128, 1, 2, 0), (64, 36, 32, 32, 3, 1, 0), (63, 34, 64, 64, 2, 1, 0)])
+def test_conv_gradients_of_every_trunk_and_tap_geometry_are_fp32_class(H, W, Cin, Cout, k, stride, pad):
+    """conv_dgrad / conv_wgrad as the tower's backward calls them (whatever kernel the library dispatches in the default mode: plane kernel,
+    three-piece implicit GEMM, exact fp32 direct kernel) against float64 autograd."""
+    torch.manual_seed(6)
+    B = 3
+    x = torch.randn(B, H, W, Cin, device=DEV)
+    w = torch.randn(Cout, k, k, Cin, device=DEV) * 0.05
+    xx = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    ww = w.double().permute(0, 3, 1, 2).requires_grad_(True)
+    y = torch.nn.functional.conv2d(xx, ww, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, device=DEV, dtype=torch.float64)
+    gx, gw = torch.autograd.grad(y, [xx, ww], dy)
+    dyn = dy.float().permute(0, 2, 3, 1).contiguous()
+    dx = we.conv_dgrad(dyn, w, x.shape, stride, pad)
+    dw = we.conv_wgrad(x, dyn, w, stride, pad)
+    assert _rel(dx, gx.permute(0, 2, 3, 1)) < 2e-6
+    assert _rel(dw, gw) < 3e-6
+
+
+@pytest.mark.parametrize('M,N,K', [(4352, 900, 600), (13056, 900, 600), (4352, 900, 108), (4352, 150, 300), (4352, 300, 600), (896, 300, 64), (4352, 32, 300)])
+def test_dense_backward_products_are_fp32_class(M, N, K):
+    """dW = dY^T X and dX = dY W of the GRU projections, the generator head, the TCN and the discriminator (ops.gemm as LinearFunction.backward
+    calls it): three-piece plane tiles (gemm_kernel<.., SPLIT = 4>) or the exact fp32 MFMA where those do not serve the shape."""
+    torch.manual_seed(7)
+    dy = torch.randn(M, N, device=DEV)
+    x = torch.randn(M, K, device=DEV)
+    w = torch.randn(N, K, device=DEV) * 0.05
+    dw = ops.gemm(dy, x, transa=True)
+    dx = ops.gemm(dy, w)
+    assert _rel(dw, dy.double().t() @ x.double()) < 2e-6
+    assert _rel(dx, dy.double() @ w.double()) < 2e-6
+    lib.ha2g_gemm_set_mode(6)
+    dw2 = ops.gemm(dy, x, transa=True)
+    lib.ha2g_gemm_set_mode(70)
+    if K >= 64 and M >= 64:
+        assert _rel(dw, dy.double().t() @ x.double()) < 0.3 * _rel(dw2, dy.double().t() @ x.double()) + 1e-7      # and it is NOT the two-piece product

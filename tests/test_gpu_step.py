@@ -77,14 +77,14 @@ def test_train_step_expressive(golden, name, fuse):
         th.FUSE_CHAINS, th.randperm_source = old
 
 
-@pytest.mark.parametrize('mode', [6, 0])
+@pytest.mark.parametrize('mode', [70, 6, 0])
 @pytest.mark.parametrize('name', ['cfg2_b128', 'cfg3_b128'])
 def test_train_step_headline_size_vs_reference(golden, name, mode):
     """BASELINE configs 2 / 3 at FULL size -- B=128, T=34, H=300, 4 layers, 20 000 words, 1 371 speakers, spec (128,70); 27-d pose / the 6-level
     126-d expressive twin -- against fixtures produced by the reference's own train_iter_hierarchy[_expressive] (train_eval/train_hierarchy.py:
     71-293, train_hierarchy_expressive.py:124-483) on the same procedural parameters and batch: two consecutive steps (epoch 0, epoch 11), loss
-    dict, every tensor's gradient digest, BatchNorm running statistics, Adam-updated parameters.  mode 6 = the default arithmetic (split-bf16
-    backward products), mode 0 = every product on the fp32 MFMA.  Tolerance = Checker: 1e-4 of the tensor's scale + 3 x the reference's own
+    dict, every tensor's gradient digest, BatchNorm running statistics, Adam-updated parameters.  mode 70 = the default arithmetic (three-piece
+    split backward products: fp32-class), mode 6 = the two-piece split of round 3, mode 0 = every product on the fp32 MFMA.  Tolerance = Checker: 1e-4 of the tensor's scale + 3 x the reference's own
     measured fp32 scatter / conditioning (4 one-ulp-perturbed fp32 runs + the float64 conditioning run, tests/golden/gen_golden.py main_big)."""
     import os
     from ha2g_amd import schema
@@ -398,6 +398,7 @@ def test_loss_readback_is_early_and_cluster_errors_are_still_raised():
     class Lang:
         n_words, word_embedding_weights = 500, None
     tr = HierarchyTrainer(args, Lang(), SpeakerVocab(40), 27, dev)
+    tr.retry_on_cluster_error = False                            # this test pins the RAISING path; the recovery has its own test below
     text, spec, target, vid = (torch.from_numpy(x).to(dev) for x in proc.make_batch(16, 27, 500, 40, 5))
     a = tr.train_iter(11, text, spec, target, vid)
     tr.sync()
@@ -419,3 +420,90 @@ def test_loss_readback_is_early_and_cluster_errors_are_still_raised():
     b = tr.train_iter(11, text, spec, target, vid)
     tr.sync()
     assert set(b) == set(a)
+
+
+@pytest.mark.parametrize('sparse', [False, True])
+def test_flagged_cluster_step_leaves_the_optimizer_state_untouched_and_is_retried(sparse):
+    """VERDICT r3 item 6.  The cluster-GRU error word guards every optimizer kernel on the device (ha2g_adam_guarded_f32, ha2g_sparse_adam2_f32,
+    ha2g_adam_step_inc_guarded): a step whose recurrences timed out must leave parameters, moments and step counters BIT-IDENTICAL -- the D update
+    in the middle of the step included -- whether or not the host retries.  With the retry on (default) the same call then recovers: device
+    drained, BatchNorm buffers of the flagged forward restored, word cleared, this process switched to gru.hip's single-workgroup recurrences,
+    batch re-run; exactly ONE optimizer step is applied."""
+    from ha2g_amd import ops, train_hierarchy as th
+    from ha2g_amd.config import hierarchy_args
+    from ha2g_testing import SpeakerVocab
+    from ha2g_amd.train import HierarchyTrainer
+    dev = torch.device(DEV)
+
+    class Lang:
+        n_words, word_embedding_weights = 500, None
+    tr = HierarchyTrainer(hierarchy_args(), Lang(), SpeakerVocab(40), 27, dev, sparse_embeddings=sparse)
+    text, spec, target, vid = (torch.from_numpy(x).to(dev) for x in proc.make_batch(16, 27, 500, 40, 5))
+    opts = tr.gen_opts + [tr.audio_opt, tr.text_opt, tr.dis_opt]
+
+    def state():
+        st = [t.clone() for o in opts for t in (o.flat_p, o.flat_m, o.flat_v, o.step_t)]
+        for o in opts:
+            for tb in o.sparse_tables:
+                st += [tb.weight.data.clone(), tb.m.clone(), tb.v.clone(), tb.last.clone()]
+        return st
+
+    def bufs():
+        return [b.clone() for b in tr._bn_buffers()]
+    try:
+        assert ops.USE_GRU_CLUSTER and lib_cluster_ok()
+        a = tr.train_iter(11, text, spec, target, vid)
+        tr.sync()
+        word = ops.gru_cluster_error_tensor(dev)
+        assert word is not None and int(word.item()) == 0
+        s0, b0 = state(), bufs()
+        steps0 = [int(o.step_t.item()) for o in opts]
+        # ---- (1) no retry: the call raises, and the flagged step was a no-op on the optimizer state ----
+        tr.retry_on_cluster_error = False
+        word.fill_(1)                                            # as if a hand-off had timed out
+        with pytest.raises(ops.Ha2gClusterError):
+            tr.train_iter(11, text, spec, target, vid)
+        torch.cuda.synchronize()
+        for x, y in zip(s0, state()):
+            assert torch.equal(x, y)
+        word.zero_()
+        th._err_watch.clear()
+        torch._foreach_copy_(tr._bn_buffers(), b0)              # without the retry wrapper the flagged forward's BatchNorm statistics stay: undo by hand
+        # ---- (2) retry (default): same forced failure, the call recovers and applies exactly one step on the gru.hip recurrences ----
+        tr.retry_on_cluster_error = True
+        word.fill_(1)
+        b = tr.train_iter(11, text, spec, target, vid)
+        tr.sync()
+        assert tr.cluster_retries == 1 and not ops.USE_GRU_CLUSTER and int(word.item()) == 0
+        assert set(b) == set(a) and all(np.isfinite(v) for v in b.values())
+        assert [int(o.step_t.item()) for o in opts] == [n + 1 for n in steps0]
+        s1 = state()
+        assert not torch.equal(s0[0], s1[0])                     # the retried step DID update
+        for x, y in zip(b0, bufs()):                             # one forward's worth of running-statistics updates, not two
+            if x.dtype == torch.int64:
+                assert int(y) == int(x) + 1
+        # ---- (3) a BPTT time-out surfaces at the start of the NEXT call: that step was skipped on the device, the next batch runs ----
+        ops.USE_GRU_CLUSTER = True
+        c = tr.train_iter(11, text, spec, target, vid)
+        tr.sync()
+        s2 = state()
+        word.fill_(1)
+        th._watch_cluster_errors(dev)                            # what the end of a step with a flagged BPTT launch leaves behind
+        torch.cuda.synchronize()
+        d = tr.train_iter(11, text, spec, target, vid)
+        tr.sync()
+        assert tr.cluster_retries == 2 and not ops.USE_GRU_CLUSTER and int(word.item()) == 0 and set(d) == set(c)
+        assert [int(o.step_t.item()) for o in opts] == [n + 3 for n in steps0]
+        assert not torch.equal(s2[0], state()[0])
+    finally:
+        ops.USE_GRU_CLUSTER = True
+        w = ops.gru_cluster_error_tensor(dev)
+        if w is not None:
+            w.zero_()
+        torch.cuda.synchronize()
+        th._err_watch.clear()
+
+
+def lib_cluster_ok():
+    from ha2g_amd._lib import lib
+    return bool(lib.ha2g_gru_cluster_supported(300))

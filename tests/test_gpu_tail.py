@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-@pytest.mark.parametrize('mode', [6, 0, 14])
+@pytest.mark.parametrize('mode', [70, 6, 0, 14])
 def test_audio_gradients_within_the_reference_tail(golden, mode):
     truth, tail = golden('cfg1'), golden('cfg1_tail')
     assert int(tail['n_runs']) >= 200

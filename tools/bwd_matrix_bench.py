@@ -1,5 +1,5 @@
 """Backward matrix kernels of the train step in isolation (B = 128): the SE-ResNet's convolution data / weight gradients per trunk shape and
-the dominant dense backward GEMMs (GRU input-projection dW / dX), in the default split-bf16 mode and on the exact fp32 MFMA.
+the dominant dense backward GEMMs (GRU input-projection dW / dX), in the default three-piece (fp32-class) mode 70, the two-piece mode 6 and on the exact fp32 MFMA (mode 0).
 Prints per kernel: microseconds, fp32-equivalent TFLOP/s, fraction of the 3-product split-bf16 roofline (2.5 PF / 3 = 833 TF).
 Also the target of tools/pmc_bwd.sh (rocprofv3 PMC passes).   usage: python tools/bwd_matrix_bench.py [iters]"""
 import sys
@@ -27,7 +27,7 @@ def timeit(fn, warm=2):
 
 B = 128
 rows = []
-for mode in (6, 0):
+for mode in (70, 6, 0):
     lib.ha2g_gemm_set_mode(mode)
     for H, W, C in ((128, 70, 32), (64, 35, 64), (32, 18, 128), (16, 9, 256)):
         x = torch.randn(B, H, W, C, device=dev)
@@ -45,9 +45,10 @@ for mode in (6, 0):
         fl = 2.0 * M * N * K
         rows.append((mode, 'dense dW = dgi^T x  [%d x %d x %d] %s' % (N, K, M, name), timeit(lambda: ops.gemm(dgi, xin, transa=True)), fl))
         rows.append((mode, 'dense dX = dgi W    [%d x %d x %d] %s' % (M, K, N, name), timeit(lambda: ops.gemm(dgi, wih)), fl))
-lib.ha2g_gemm_set_mode(6)
+from ha2g_amd._lib import DEFAULT_GEMM_MODE
+lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
 print('%-4s %-66s %9s %9s %7s' % ('mode', 'kernel', 'us', 'TF(f32eq)', 'frac'))
 for mode, name, us, fl in rows:
     tf = fl / us / 1e6
-    peak = 833.0 if mode == 6 else 157.3
+    peak = {70: 416.7, 6: 833.3, 0: 157.3}[mode]                 # bf16 dense peak / MFMAs per fp32-equivalent product (6 / 3), or the fp32 MFMA peak
     print('%-4d %-66s %9.1f %9.1f %7.3f' % (mode, name, us, tf, tf / peak))

@@ -1,10 +1,11 @@
 """Timing ablations of the plane-based data-gradient kernel (ha2g_conv_planes_debug): full / no DMA / no MFMA / neither, at the trunk shapes
-(B = 128) and at 4x the pixels (tile quantisation removed).  usage: python tools/planes_ablate.py"""
+(B = 128) and at 4x the pixels (tile quantisation removed), for the two-piece (mode 6) and the three-piece (mode 70, default) kernels, every
+tile shape of the three-piece kernel and both LDS ring depths.  usage: python tools/planes_ablate.py"""
 import sys
 import torch
 sys.path.insert(0, '.')
 from ha2g_amd import ops, wav_engine as we
-from ha2g_amd._lib import lib
+from ha2g_amd._lib import DEFAULT_GEMM_MODE, lib
 
 dev = torch.device('cuda:0')
 
@@ -21,24 +22,30 @@ def t_us(fn, iters=10):
     return s.elapsed_time(e) / iters * 1e3
 
 
-print('%-26s %9s %9s %9s %9s   %s' % ('shape', 'full', 'no DMA', 'no MFMA', 'neither', 'TF(f32eq) full'))
+print('%-44s %9s %9s %9s %9s   %s' % ('shape', 'full', 'no DMA', 'no MFMA', 'neither', 'TF(f32eq) full'))
 for B in (128, 512):
     for H, W, C in ((64, 35, 64), (32, 18, 128), (16, 9, 256)):
         dy = torch.randn(B, H, W, C, device=dev)
         w = torch.randn(C, 3, 3, C, device=dev) * 0.05
-        pl = ops.to_planes(dy)
-        wh = torch.empty(C, 3, 3, C, dtype=torch.bfloat16, device=dev); wl = torch.empty_like(wh)
-        lib.ha2g_conv2d_weight_ihwo_planes(w.data_ptr(), wh.data_ptr(), wl.data_ptr(), C, 3, 3, C, 0)
         out = torch.empty(B, H, W, C, device=dev)
-        fn = lambda: lib.ha2g_conv2d_dgrad_planes_f32(pl[0].data_ptr(), pl[1].data_ptr(), wh.data_ptr(), wl.data_ptr(), out.data_ptr(), B, H, W, C, C, 3, 3,
-                                                      1, 1, 0.0, torch.cuda.current_stream().cuda_stream)
-        for ring in (2, 3, 4):                           # LDS ring depth (ha2g_conv_planes_ring)
-            lib.ha2g_conv_planes_ring(ring)
-            ts = []
-            for bits in (0, 1, 2, 3):
-                lib.ha2g_conv_planes_debug(bits)
-                ts.append(t_us(fn))
-            lib.ha2g_conv_planes_debug(0)
-            fl = 2.0 * B * H * W * C * C * 9
-            print('B=%-3d C=%-3d %3dx%-3d ring %d %9.1f %9.1f %9.1f %9.1f   %.1f' % (B, C, H, W, ring, ts[0], ts[1], ts[2], ts[3], fl / ts[0] / 1e6))
-        lib.ha2g_conv_planes_ring(0)
+        for mode, tiles in ((6, (0,)), (70, (1, 2, 3))):
+            lib.ha2g_gemm_set_mode(mode)
+            pl = ops.to_planes(dy)
+            wpl = we.weight_planes(w, pl.shape[0])
+            fn = lambda: lib.ha2g_conv2d_dgrad_planes_np_f32(pl.data_ptr(), pl.stride(0), wpl.data_ptr(), wpl.stride(0), pl.shape[0], out.data_ptr(), B, H, W,
+                                                             C, C, 3, 3, 1, 1, 0.0, torch.cuda.current_stream().cuda_stream)
+            for tile in tiles:
+                lib.ha2g_conv_planes_tile3(tile)
+                for ring in (2, 3):                           # LDS ring depth (ha2g_conv_planes_ring)
+                    lib.ha2g_conv_planes_ring(ring)
+                    ts = []
+                    for bits in (0, 1, 2, 3):
+                        lib.ha2g_conv_planes_debug(bits)
+                        ts.append(t_us(fn))
+                    lib.ha2g_conv_planes_debug(0)
+                    fl = 2.0 * B * H * W * C * C * 9
+                    print('B=%-3d C=%-3d %3dx%-3d np %d tile %d ring %d        %9.1f %9.1f %9.1f %9.1f   %.1f' % (
+                        B, C, H, W, pl.shape[0], tile, ring, ts[0], ts[1], ts[2], ts[3], fl / ts[0] / 1e6))
+            lib.ha2g_conv_planes_ring(0)
+            lib.ha2g_conv_planes_tile3(0)
+lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
