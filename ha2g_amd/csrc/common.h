@@ -39,6 +39,8 @@ int pconv_wgrad_supported(int H, int W, int Cin, int Cout, int KH, int KW, int s
 long pconv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int pconv_wgrad_launch(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* part, int N, int H, int W, int Cin, int Cout,
                        hipStream_t st);
+int pconv_wgrad_launch_np(const void* x, long x_ps, const void* dy, long dy_ps, int np, float* part, int N, int H, int W, int Cin, int Cout,
+                          hipStream_t st);
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 

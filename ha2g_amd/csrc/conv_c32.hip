@@ -217,9 +217,11 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
 }
 
-template <int C> struct X3Geo {
-    static constexpr int THREADS = C == 32 ? 512 : 256;      // 8 waves x 1 block, or 4 waves x 2 blocks of 32 pixels
-    static constexpr int MB = C == 32 ? 1 : 2;               // pixel blocks per wave
+// NP = 3 (round 4, fp32-class): three pieces, six MFMAs per product; the filter's three piece fragments are 216 registers per lane, so the
+// C = 32 kernel then runs FOUR waves (one per SIMD, 512 registers each) with two pixel blocks per wave instead of eight waves with one.
+template <int C, int NP = 2> struct X3Geo {
+    static constexpr int THREADS = (C == 32 && NP < 3) ? 512 : 256;      // 8 waves x 1 block, or 4 waves x 2 blocks of 32 pixels
+    static constexpr int MB = (C == 32 && NP < 3) ? 1 : 2;               // pixel blocks per wave
     static constexpr int NH = C / 32;                        // 32-channel output halves
     static constexpr int CHUNKS = C / 16;
     static constexpr int CSX = C + 8;                        // bf16 per pixel in a plane
@@ -227,11 +229,11 @@ template <int C> struct X3Geo {
     static constexpr int PSTEP = THREADS / QP;               // padded pixels between a thread's consecutive slots
 };
 
-template <int C>
-__global__ __launch_bounds__(X3Geo<C>::THREADS, 1) void conv3x3_x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                         float* __restrict__ y, int N, int H, int W, int flip,
-                                                                         int act, float beta, int plane_elems) {
-    using G = X3Geo<C>;
+template <int C, int NP>
+__global__ __launch_bounds__((X3Geo<C, NP>::THREADS), 1) void conv3x3_x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                               float* __restrict__ y, int N, int H, int W, int flip,
+                                                                               int act, float beta, int plane_elems) {
+    using G = X3Geo<C, NP>;
     extern __shared__ __attribute__((aligned(16))) unsigned short pl[];  // [2 planes][rows_max][W + 2][CSX]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(X3Geo<C>::THREADS, 1) void conv3x3_x3_kernel(const 
     const int nout = nh * 32 + l31;
 
     // filter -> registers: for tap t and 16-channel chunk c, lane (n = nout, half = lhi) holds channels 16c + 8*half .. +7 of row n
-    bf16x8_t bh[9][G::CHUNKS], bl[9][G::CHUNKS];
+    bf16x8_t bq[NP][9][G::CHUNKS];                                       // piece q of the filter fragments
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int tt = flip ? 8 - t : t;
@@ -251,14 +253,13 @@ __global__ __launch_bounds__(X3Geo<C>::THREADS, 1) void conv3x3_x3_kernel(const 
             const float* src = w + ((long)nout * 9 + tt) * C + 16 * c + 8 * lhi;
             const float4 u0 = *reinterpret_cast<const float4*>(src);
             const float4 u1 = *reinterpret_cast<const float4*>(src + 4);
-            uint4 h, l;
-            split2(u0.x, u0.y, h.x, l.x); split2(u0.z, u0.w, h.y, l.y); split2(u1.x, u1.y, h.z, l.z); split2(u1.z, u1.w, h.w, l.w);
-            bh[t][c] = __builtin_bit_cast(bf16x8_t, h);
-            bl[t][c] = __builtin_bit_cast(bf16x8_t, l);
+            unsigned e0[NP], e1[NP], e2[NP], e3[NP];
+            splitn_bf16<NP>(u0.x, u0.y, e0); splitn_bf16<NP>(u0.z, u0.w, e1); splitn_bf16<NP>(u1.x, u1.y, e2); splitn_bf16<NP>(u1.z, u1.w, e3);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) bq[q][t][c] = __builtin_bit_cast(bf16x8_t, make_uint4(e0[q], e1[q], e2[q], e3[q]));
         }
     }
     unsigned short* phi = pl;
-    unsigned short* plo = pl + plane_elems;
     for (long tile = blockIdx.x / G::NH; tile < tiles; tile += gridDim.x / G::NH) {
         const Tile cur = tile_of(tile, tpi, HW, W);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // previous tile's fragment reads are done
@@ -286,10 +287,10 @@ __global__ __launch_bounds__(X3Geo<C>::THREADS, 1) void conv3x3_x3_kernel(const 
 #pragma unroll
                 for (int i = 0; i < NS; ++i)
                     if (off[i] >= 0) {
-                        uint2 h, l;
-                        split2(v[i].x, v[i].y, h.x, l.x); split2(v[i].z, v[i].w, h.y, l.y);
-                        *reinterpret_cast<uint2*>(phi + off[i]) = h;
-                        *reinterpret_cast<uint2*>(plo + off[i]) = l;
+                        unsigned e0[NP], e1[NP];
+                        splitn_bf16<NP>(v[i].x, v[i].y, e0); splitn_bf16<NP>(v[i].z, v[i].w, e1);
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(phi + q * plane_elems + off[i]) = make_uint2(e0[q], e1[q]);
                     }
             }
         }
@@ -314,11 +315,18 @@ __global__ __launch_bounds__(X3Geo<C>::THREADS, 1) void conv3x3_x3_kernel(const 
             for (int c = 0; c < G::CHUNKS; ++c)
 #pragma unroll
                 for (int b = 0; b < G::MB; ++b) {
-                    const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(phi + a0[b] + toff + 16 * c);
-                    const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(plo + a0[b] + toff + 16 * c);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t][c], acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t][c], acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t][c], acc[b], 0, 0, 0);
+                    bf16x8_t aq[NP];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) aq[q] = *reinterpret_cast<const bf16x8_t*>(phi + q * plane_elems + a0[b] + toff + 16 * c);
+                    if constexpr (NP == 3) {                              // six products, smallest first (conv_planes.hip)
+                        constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                        for (int u = 0; u < 6; ++u) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[QA[u]], bq[QB[u]][t][c], acc[b], 0, 0, 0);
+                    } else {
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[1], bq[0][t][c], acc[b], 0, 0, 0);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[0], bq[1][t][c], acc[b], 0, 0, 0);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[0], bq[0][t][c], acc[b], 0, 0, 0);
+                    }
                 }
         }
         float* yout = y + (long)cur.img * HW * C;
@@ -352,11 +360,12 @@ constexpr int WG_TP = 128, WG_NT = 256;
 
 // T = float: fp32 tensors, split here into hi / lo planes (three MFMAs per product); T = b16 (bf16-storage mode): the tensors ARE the hi plane,
 // one MFMA per product, the lo planes stay unused.
-template <typename T>
-__global__ __launch_bounds__(WG_NT, 2) void conv3x3_c32_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                                     float* __restrict__ part, int N, int H, int W, int plane_elems) {
+// NP = 3 (round 4, fp32-class): three piece planes per operand (93 KB at 70-wide maps: one workgroup per CU), six MFMAs per product.
+template <typename T, int NP = 2>
+__global__ __launch_bounds__(WG_NT, (NP == 3 ? 1 : 2)) void conv3x3_c32_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                                     float* __restrict__ part, int N, int H, int W, int plane_elems) {
     constexpr bool F32 = sizeof(T) == 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned short wpl[];        // [x hi][x lo][dy hi][dy lo]
+    extern __shared__ __attribute__((aligned(16))) unsigned short wpl[];        // [x pieces][dy pieces]
     typedef short s16x4_t __attribute__((ext_vector_type(4)));
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
     typedef __attribute__((address_space(3))) s16x4_t* lds4_t;
@@ -366,9 +375,9 @@ __global__ __launch_bounds__(WG_NT, 2) void conv3x3_c32_wgrad_kernel(const T* __
     const int HW = H * W, PW = W + 2;
     const int tpi = (HW + WG_TP - 1) / WG_TP;
     const long tiles = (long)N * tpi;
-    unsigned short* xh = wpl;
+    unsigned short* xh = wpl;                                                   // piece q of x at xh + q * plane_elems
     unsigned short* xl = wpl + plane_elems;
-    unsigned short* dh = wpl + 2 * plane_elems;
+    unsigned short* dh = wpl + NP * plane_elems;                                // piece q of dy at dh + q * WG_TP * CH
     unsigned short* dl = dh + WG_TP * CH;
     auto tr = [](const unsigned short* ptr) {
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(__attribute__((address_space(3))) const unsigned short*)ptr);
@@ -417,10 +426,10 @@ __global__ __launch_bounds__(WG_NT, 2) void conv3x3_c32_wgrad_kernel(const T* __
                 for (int i = 0; i < NS; ++i)
                     if (off[i] >= 0) {
                         if constexpr (F32) {
-                            uint2 h, l;
-                            split2(v[i].x, v[i].y, h.x, l.x); split2(v[i].z, v[i].w, h.y, l.y);
-                            *reinterpret_cast<uint2*>(xh + off[i]) = h;
-                            *reinterpret_cast<uint2*>(xl + off[i]) = l;
+                            unsigned e0[NP], e1[NP];
+                            splitn_bf16<NP>(v[i].x, v[i].y, e0); splitn_bf16<NP>(v[i].z, v[i].w, e1);
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(xh + q * plane_elems + off[i]) = make_uint2(e0[q], e1[q]);
                         } else {
                             *reinterpret_cast<uint2*>(xh + off[i]) = hv[i];
                         }
@@ -442,10 +451,10 @@ __global__ __launch_bounds__(WG_NT, 2) void conv3x3_c32_wgrad_kernel(const T* __
             for (int i = 0; i < 4; ++i) {
                 const int o = ((tid >> 3) + 32 * i) * CH + 4 * c4;
                 if constexpr (F32) {
-                    uint2 h, l;
-                    split2(d[i].x, d[i].y, h.x, l.x); split2(d[i].z, d[i].w, h.y, l.y);
-                    *reinterpret_cast<uint2*>(dh + o) = h;
-                    *reinterpret_cast<uint2*>(dl + o) = l;
+                    unsigned e0[NP], e1[NP];
+                    splitn_bf16<NP>(d[i].x, d[i].y, e0); splitn_bf16<NP>(d[i].z, d[i].w, e1);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dh + q * WG_TP * CH + o) = make_uint2(e0[q], e1[q]);
                 } else {
                     *reinterpret_cast<uint2*>(dh + o) = dv[i];
                 }
@@ -456,8 +465,9 @@ __global__ __launch_bounds__(WG_NT, 2) void conv3x3_c32_wgrad_kernel(const T* __
         for (int ch = 0; ch < 2; ++ch) {
             const int pb = 32 * wave + 16 * ch + krow;                           // this lane's two tile-local pixels: pb and pb + 4
             const bf16x8_t ah = frag(dh + pb * CH + moff, dh + (pb + 4) * CH + moff);
-            bf16x8_t al = ah;
+            bf16x8_t al = ah, a2 = ah;
             if constexpr (F32) al = frag(dl + pb * CH + moff, dl + (pb + 4) * CH + moff);
+            if constexpr (F32 && NP == 3) a2 = frag(dl + WG_TP * CH + pb * CH + moff, dl + WG_TP * CH + (pb + 4) * CH + moff);
             int p0 = cur.p0 + pb, p1 = p0 + 4;
             if (p0 >= HW) p0 = HW - 1;                                           // clamp: stays inside the patch; dy is zero there
             if (p1 >= HW) p1 = HW - 1;
@@ -468,7 +478,15 @@ __global__ __launch_bounds__(WG_NT, 2) void conv3x3_c32_wgrad_kernel(const T* __
             for (int t = 0; t < 9; ++t) {
                 const int toff = ((t / 3) * PW + (t % 3)) * CH;
                 const bf16x8_t bh = frag(xh + r0 + toff, xh + r1 + toff);
-                if constexpr (F32) {
+                if constexpr (F32 && NP == 3) {                                  // six products, smallest first
+                    const bf16x8_t bl = frag(xl + r0 + toff, xl + r1 + toff);
+                    const bf16x8_t b2 = frag(xl + plane_elems + r0 + toff, xl + plane_elems + r1 + toff);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b2, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                } else if constexpr (F32) {
                     const bf16x8_t bl = frag(xl + r0 + toff, xl + r1 + toff);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
@@ -523,29 +541,32 @@ int conv3x3_c32_launch(const float* x, const float* w, float* y, int N, int H, i
 }
 
 // split-bf16 variants (used for the data gradient); C = 32 or 64 channels in and out; same contract
-template <int C>
+template <int C, int NP = 2>
 static int conv3x3_x3_launch_t(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st) {
-    using G = X3Geo<C>;
+    using G = X3Geo<C, NP>;
     const int rows_max = (TP + W - 2) / W + 1 + 2;
     const int plane_elems = rows_max * (W + 2) * G::CSX;
-    const size_t lds = (size_t)2 * plane_elems * sizeof(unsigned short);
+    const size_t lds = (size_t)NP * plane_elems * sizeof(unsigned short);
     if (lds > 150 * 1024 || (long)H * W < TP || W + 2 <= G::PSTEP) return -100;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+    static bool attr_set[64] = {false};                  // per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3_kernel<C, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
             return ha2g_set_error(-2, "conv3x3_x3: cannot raise the dynamic LDS limit");
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const long items = (long)N * (((long)H * W + TP - 1) / TP) * G::NH;
     int grid = (int)(items < 256 ? items : 256);
     grid = grid / G::NH * G::NH;                         // workgroup parity = output-channel half
     if (grid < G::NH) return -100;
-    hipLaunchKernelGGL(conv3x3_x3_kernel<C>, dim3(grid), dim3(G::THREADS), lds, st, x, w, y, N, H, W, flip, act, beta, plane_elems);
+    hipLaunchKernelGGL((conv3x3_x3_kernel<C, NP>), dim3(grid), dim3(G::THREADS), lds, st, x, w, y, N, H, W, flip, act, beta, plane_elems);
     HA2G_CHECK_LAUNCH("conv3x3_x3");
     return 0;
 }
 int conv3x3_c32_x3_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st) {
-    return conv3x3_x3_launch_t<32>(x, w, y, N, H, W, flip, act, beta, st);
+    if (gemm_bwd_pieces() == 3) return conv3x3_x3_launch_t<32, 3>(x, w, y, N, H, W, flip, act, beta, st);      // fp32-class: three pieces
+    return conv3x3_x3_launch_t<32, 2>(x, w, y, N, H, W, flip, act, beta, st);
 }
 
 // dW partials of the direct 32-channel weight gradient: returns the number of partial [32][9][32] blocks written to `part` (the caller
@@ -558,26 +579,31 @@ int conv3x3_c32_wgrad_blocks(int N, int H, int W) {
     if (cus > g_side_cus) cus = g_side_cus;
     return (int)(tiles < 2L * cus ? tiles : 2L * cus);
 }
-template <typename T>
+template <typename T, int NP = 2>
 static int c32_wgrad_launch_t(const T* x, const T* dy, float* part, int N, int H, int W, hipStream_t st) {
     const int rows_max = (WG_TP + W - 2) / W + 1 + 2;
     const int plane_elems = rows_max * (W + 2) * CH;
-    size_t lds = ((size_t)2 * plane_elems + 2 * WG_TP * CH) * sizeof(unsigned short);
+    size_t lds = ((size_t)NP * plane_elems + NP * WG_TP * CH) * sizeof(unsigned short);
     if (lds < 9 * CH * CH * sizeof(float)) lds = 9 * CH * CH * sizeof(float);
-    if (lds > 78 * 1024 || (long)H * W < WG_TP || W + 2 <= 32) return -100;           // two workgroups per CU; 32 padded pixels between a thread's slots
-    static bool attr_set = false;                                                    // one flag per instantiation
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_wgrad_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 78 * 1024) != hipSuccess)
+    constexpr int LDS_MAX = NP == 3 ? 150 * 1024 : 78 * 1024;                         // NP <= 2: two workgroups per CU; NP = 3: one
+    if (lds > LDS_MAX || (long)H * W < WG_TP || W + 2 <= 32) return -100;             // 32 padded pixels between a thread's slots
+    static bool attr_set[64] = {false};                                              // per instantiation and device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_wgrad_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess)
             return ha2g_set_error(-2, "conv3x3_c32_wgrad: cannot raise the dynamic LDS limit");
-        attr_set = true;
+        attr_set[dev] = true;
     }
-    const int grid = conv3x3_c32_wgrad_blocks(N, H, W);
-    hipLaunchKernelGGL(conv3x3_c32_wgrad_kernel<T>, dim3(grid), dim3(WG_NT), lds, st, x, dy, part, N, H, W, plane_elems);
+    int grid = conv3x3_c32_wgrad_blocks(N, H, W);
+    if (NP == 3 && grid > 256) grid = (grid + 1) / 2;                                 // one workgroup per CU
+    hipLaunchKernelGGL((conv3x3_c32_wgrad_kernel<T, NP>), dim3(grid), dim3(WG_NT), lds, st, x, dy, part, N, H, W, plane_elems);
     HA2G_CHECK_LAUNCH("conv3x3_c32_wgrad");
     return grid;
 }
 int conv3x3_c32_wgrad_launch(const float* x, const float* dy, float* part, int N, int H, int W, hipStream_t st) {
-    return c32_wgrad_launch_t<float>(x, dy, part, N, H, W, st);
+    if (gemm_bwd_pieces() == 3) return c32_wgrad_launch_t<float, 3>(x, dy, part, N, H, W, st);                  // fp32-class: three pieces
+    return c32_wgrad_launch_t<float, 2>(x, dy, part, N, H, W, st);
 }
 // bf16 tensors (bf16-storage mode): single planes, one MFMA per product
 int conv3x3_c32_wgrad_b16_launch(const void* x, const void* dy, float* part, int N, int H, int W, hipStream_t st) {

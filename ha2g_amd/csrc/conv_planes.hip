@@ -35,6 +35,23 @@ __global__ void f32_to_planes_kernel(const float* __restrict__ x, unsigned short
     }
 }
 
+// the same for up to 48 tensors in ONE launch (blockIdx.y = tensor): the forward weights of every plane-served convolution of the tower
+struct SplitBatch { const float* x[48]; unsigned short* pl[48]; long ps[48]; long n4[48]; };
+template <int NP>
+__global__ void f32_to_planes_multi_kernel(SplitBatch b) {
+    const int t = blockIdx.y;
+    const float* __restrict__ x = b.x[t];
+    unsigned short* __restrict__ pl = b.pl[t];
+    const long ps = b.ps[t], n4 = b.n4[t];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        unsigned a[NP], c[NP];
+        splitn_bf16<NP>(v.x, v.y, a); splitn_bf16<NP>(v.z, v.w, c);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) reinterpret_cast<uint2*>(pl + q * ps)[i] = make_uint2(a[q], c[q]);
+    }
+}
+
 // w [Cout][KK][Cin] fp32 (OHWI) -> planes of wt [Cin][KK][Cout]: the B operand of the data gradient, rows = input channels, k = (tap, cout)
 __global__ void weight_ihwo_planes_kernel(const float* __restrict__ w, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, int Cout,
                                           int KK, int Cin) {
@@ -311,6 +328,7 @@ __global__ __launch_bounds__(64 * WM * WN) void pconv_kernel(PConvP p) {
                 if (OUT == 0) {
                     float* dst = p.C + orow * p.ldc + col;
                     float v = 1.0f * acc[i][j][r] + 0.f;              // alpha = 1, no bias: the epilogue arithmetic of gemm_x3_kernel
+                    if (p.relu) v = fmaxf(v, 0.f);                   // forward convolutions (conv -> ReLU -> BN ordering of the reference)
                     if (p.beta != 0.f) v += p.beta * *dst;
                     *dst = v;
                 } else {
@@ -319,6 +337,256 @@ __global__ __launch_bounds__(64 * WM * WN) void pconv_kernel(PConvP p) {
                     float v = acc[i][j][r];
                     const float vn = __shfl_down(v, 1, 64);
                     if (rok && !(l31 & 1) && col < p.N) {                   // N is even: col and col + 1 are both valid
+                        float v0 = v, v1 = vn;
+                        if (p.beta != 0.f) {
+                            const unsigned old = *reinterpret_cast<const unsigned*>(dstb);
+                            v0 += p.beta * __uint_as_float(old << 16); v1 += p.beta * __uint_as_float(old & 0xffff0000u);
+                        }
+                        if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                        unsigned h, l;
+                        split2_bf16(v0, v1, h, l);
+                        *reinterpret_cast<unsigned*>(dstb) = h;
+                    }
+                }
+            }
+        }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// PING-PONG form of the plane convolution (round 4).  Counter evidence first (profiles/r04_planes_ablate_np3_v1.txt, B = 512, C = 256, three
+// pieces, 128 x 128 tile, one workgroup per CU): full 581 us, without DMA 419, without MFMA 388, neither 157 -- the three phases of a k tile
+// (fragment reads + barrier 0.48 us, DMA 0.71 us, 48 MFMAs 0.81 us) add up: with ONE wave per SIMD and a barrier per k tile nothing overlaps.
+// Here a workgroup is TWO groups of four waves (two waves per SIMD), each group owning a 128 x BN half of a 256 x BN output tile, and the
+// groups run in ANTI-PHASE: while group g issues the 48 (24) MFMAs of its k tile out of REGISTERS, group 1 - g reads ALL fragments of its next
+// k tile from LDS into registers (96 / 72 VGPRs) and then requests the tile after that by DMA.  One workgroup barrier per phase.  The matrix
+// pipe of a SIMD is therefore always fed by one of its two waves while the other one waits for LDS / issues DMA (guide: "two waves per SIMD:
+// what they share" -- the merged interval pairs matrix work with memory work).
+//   phase 2k     group 0: LOAD(k)    = fragments of tile k -> registers; request A0(k+1) and B(k+1)        group 1: COMPUTE(k-1)
+//   phase 2k+1   group 0: COMPUTE(k) = the MFMAs; then wait for its own DMA (it had the whole phase)       group 1: LOAD(k); request A1(k+1)
+// Hazards: a DMA into stage (k+1) % 2 is issued one barrier after the last fragment read of that stage (tile k-1); a tile is read one barrier
+// after its issuers' `s_waitcnt vmcnt(0)`.  B (the weights) is shared by both groups and requested by group 0 only -- group 1 reads B(k) one
+// phase later than group 0, B(k+2) replaces it one phase after that.  LDS: A 2 groups x 2 stages x NP x 8 KB + B 2 stages x NP x BN x 64 B
+// = 144 KB (BN = 128) / 120 KB (BN = 64) for three pieces.
+template <int BN, int NP, int OUT>
+__global__ __launch_bounds__(512) void pconv_pp_kernel(PConvP p) {
+    constexpr int GM = 128;                                      // rows of one group's half tile
+    constexpr int MI = 2, NI = BN / 64;                          // group = 2 x 2 waves, wave tile 64 x (BN / 2)
+    constexpr int PLANE_A = GM * 64, PLANE_B = BN * 64;          // bytes
+    constexpr int A_STAGE = NP * PLANE_A, B_STAGE = NP * PLANE_B;
+    constexpr int B_BASE = 4 * A_STAGE;                          // A: [group][stage], then B: [stage]
+    constexpr int NBW = (BN / 16) / 4;                           // B row blocks per wave of group 0 (2 / 1)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
+    int bx, by;
+    ptile_of_block(bx, by);
+    const PClass& pc = p.cls[blockIdx.z];
+    const int m0 = bx * 256 + grp * GM, n0 = by * BN;
+    if (bx * 256 >= pc.M) return;                                // whole workgroup out of range (classes differ in size)
+    const int nkc = p.GC >> 5;
+    const int nk = pc.ntaps * nkc;
+
+    // ---- staging state: this lane's two A rows (of its group's half tile) and, in group 0, its B rows ----
+    const int srow = lane >> 2;
+    long a_base[2]; unsigned a_mask[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (w4 + 4 * i) * 16 + srow;
+        const int lc = (lane & 3) ^ ((row >> 2) & 3);
+        const int m = m0 + row;
+        a_mask[i] = 0u; a_base[i] = 0;
+        if (m < pc.M) {
+            const int oxc = m % pc.OWc; const int t = m / pc.OWc; const int oyc = t % pc.OHc; const int img = t / pc.OHc;
+            if (p.fwd) {
+                const int sy0 = oyc * p.stride - p.pad, sx0 = oxc * p.stride - p.pad;
+                a_base[i] = (((long)img * p.GH + sy0) * p.GW + sx0) * p.GC + lc * 8;
+                for (int ti = 0; ti < pc.ntaps; ++ti) {
+                    const int kh = pc.tap[ti] / p.KW, kw = pc.tap[ti] - kh * p.KW;
+                    if (sy0 + kh >= 0 && sy0 + kh < p.GH && sx0 + kw >= 0 && sx0 + kw < p.GW) a_mask[i] |= 1u << ti;
+                }
+            } else {
+                const int u = oyc * p.stride + pc.py + p.pad, v = oxc * p.stride + pc.px + p.pad;
+                const int sy0 = (u - pc.kh0) / p.stride, sx0 = (v - pc.kw0) / p.stride;
+                a_base[i] = (((long)img * p.GH + sy0) * p.GW + sx0) * p.GC + lc * 8;
+                for (int ti = 0; ti < pc.ntaps; ++ti) {
+                    const int kh = pc.tap[ti] / p.KW, kw = pc.tap[ti] - kh * p.KW;
+                    const int sy = (u - kh) / p.stride, sx = (v - kw) / p.stride;
+                    if (u - kh >= 0 && v - kw >= 0 && sy < p.GH && sx < p.GW) a_mask[i] |= 1u << ti;
+                }
+            }
+        }
+    }
+    long b_off[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int row = (w4 + 4 * i) * 16 + srow;
+        const int lc = (lane & 3) ^ ((row >> 2) & 3);
+        const int n = n0 + row;
+        b_off[i] = n < p.N ? (long)n * p.K + lc * 8 : -1;
+    }
+    const unsigned short* zero = g_zero_page;
+    unsigned char* const a_lds = smem + grp * 2 * A_STAGE;      // this group's two A stages
+
+    auto stage_a = [&](int kt) {
+        const int ti = kt / nkc, c0 = (kt - ti * nkc) << 5;
+        const long koff = c0 + (long)pc.doff[ti] * p.GC;
+        const unsigned bit = 1u << ti;
+        unsigned char* dst = a_lds + (kt & 1) * A_STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool on = (a_mask[i] & bit) != 0u;
+            const long o = a_base[i] + koff;
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.a.p + q * p.a.ps + o : zero), (lds_ptr_t)(dst + q * PLANE_A + (w4 + 4 * i) * 1024), 16, 0, 0);
+        }
+    };
+    auto stage_b = [&](int kt) {
+        const int ti = kt / nkc, c0 = (kt - ti * nkc) << 5;
+        const long kb = (long)pc.tap[ti] * p.GC + c0;
+        unsigned char* dst = smem + B_BASE + (kt & 1) * B_STAGE;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const bool on = b_off[i] >= 0;
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.b.p + q * p.b.ps + b_off[i] + kb : zero), (lds_ptr_t)(dst + q * PLANE_B + (w4 + 4 * i) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int sw = (l31 >> 2) & 3;
+    const int a_row_off = (wm * 64 + l31) * 64, b_row_off = (wn * 32 * NI + l31) * 64;
+    bf16x8_t af[2][NP][MI], bf[2][NP][NI];                       // [k chunk][piece][tile]: the fragments of ONE whole k tile live in registers
+
+    auto load_frags = [&](int kt) {
+        const unsigned char* ab = a_lds + (kt & 1) * A_STAGE + a_row_off;
+        const unsigned char* bb = smem + B_BASE + (kt & 1) * B_STAGE + b_row_off;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const int po = ((2 * kc + lhi) ^ sw) * 16;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[kc][q][i] = *reinterpret_cast<const bf16x8_t*>(ab + q * PLANE_A + i * 2048 + po);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) bf[kc][q][j] = *reinterpret_cast<const bf16x8_t*>(bb + q * PLANE_B + j * 2048 + po);
+            }
+        }
+    };
+    auto compute = [&]() {
+        if (p.dbg & 2) {
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(af[kc][q][i]));
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) asm volatile("" :: "v"(bf[kc][q][j]));
+                }
+            return;
+        }
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            if constexpr (NP == 3) {
+                constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // smallest products first (pconv_kernel)
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kc][QA[t]][i], bf[kc][QB[t]][j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        if constexpr (NP == 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kc][NP - 1][i], bf[kc][0][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kc][0][i], bf[kc][NP - 1][j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kc][0][i], bf[kc][0][j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    };
+    // end of a LOAD phase: this wave's fragment reads are complete (its DMA stays in flight); end of a COMPUTE phase: its DMA has landed.
+    // (A two-tiles-ahead variant -- request tile k + 2 into the stage tile k was just read from, counted `vmcnt` -- was measured no faster and
+    // is WRONG as written: the stage is read by the group's OTHER waves too, and only a workgroup barrier orders their reads before the DMA.)
+    auto end_load = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
+    auto end_compute = [&]() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
+
+    // ---- prologue: tile 0 of everything ----
+    stage_a(0);
+    if (grp == 0) stage_b(0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const bool dma = !(p.dbg & 1);
+    if (grp == 0) {
+        for (int k = 0; k < nk; ++k) {
+            load_frags(k);                                       // phase 2k
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < nk && dma) { stage_a(k + 1); stage_b(k + 1); }
+            end_load();
+            compute();                                           // phase 2k + 1
+            __builtin_amdgcn_sched_barrier(0);
+            end_compute();
+        }
+        asm volatile("s_barrier" ::: "memory");                  // phase 2 nk: group 1's last COMPUTE
+    } else {
+        asm volatile("s_barrier" ::: "memory");                  // phase 0: group 0's first LOAD
+        for (int k = 0; k < nk; ++k) {
+            load_frags(k);                                       // phase 2k + 1
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < nk && dma) stage_a(k + 1);
+            end_load();
+            compute();                                           // phase 2k + 2
+            __builtin_amdgcn_sched_barrier(0);
+            end_compute();
+        }
+    }
+
+    // ---- epilogue (as pconv_kernel) ----
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + wn * (32 * NI) + j * 32 + l31;
+            if (OUT == 0 && col >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const bool rok = row < pc.M;
+                if (OUT == 0 && !rok) continue;
+                long orow = row;
+                if (!p.fwd && p.stride != 1 && rok) {
+                    const int oxc = row % pc.OWc; const int t = row / pc.OWc; const int oyc = t % pc.OHc; const int img = t / pc.OHc;
+                    orow = ((long)img * p.OH + oyc * p.stride + pc.py) * p.OW + oxc * p.stride + pc.px;
+                }
+                if (OUT == 0) {
+                    float* dst = p.C + orow * p.ldc + col;
+                    float v = acc[i][j][r];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.beta != 0.f) v += p.beta * *dst;
+                    *dst = v;
+                } else {
+                    unsigned short* dstb = reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + (col & ~1);
+                    float v = acc[i][j][r];
+                    const float vn = __shfl_down(v, 1, 64);
+                    if (rok && !(l31 & 1) && col < p.N) {
                         float v0 = v, v1 = vn;
                         if (p.beta != 0.f) {
                             const unsigned old = *reinterpret_cast<const unsigned*>(dstb);
@@ -377,22 +645,32 @@ __global__ __launch_bounds__(768) void pconv_wgrad_kernel(PWgradP p) {
     typedef short s16x4_t __attribute__((ext_vector_type(4)));
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
     typedef __attribute__((address_space(3))) s16x4_t* lds4_t;
+    // NP = 3 (round 4, fp32-class): three pieces per operand and six MFMAs per product.  Three x planes of a 64-channel block no longer fit twice
+    // into the LDS, so a workgroup owns a 64 (co) x 32 (ci) block of dW (ONE 32-channel half of x: CIH = 1) and the twelve waves are
+    // 2 co halves x 3 tap rows x 2 K HALVES: the waves of k half h run the 16-pixel chunks h * NKC/2 .. of every tile and write their own partial
+    // slab (the reduce adds slabs anyway) -- 36 MFMAs per wave and tile, 60 KB of DMA per tile, as many as the two-piece form has.
+    constexpr int CIH = NP == 3 ? 1 : 2;                       // 32-channel halves of x per workgroup
+    constexpr int KSP = NP == 3 ? 2 : 1;                       // k (pixel chunk) split over wave groups
     constexpr int NKC = WT / 16;
     constexpr int DY_SUB = ((WT + 15) / 16) * 1024;            // bytes of one dy sub-plane (WT rows of 64 bytes, in 16-row DMA pieces)
-    constexpr int DY_ALL = 2 * NP * DY_SUB, BUF = DY_ALL + 2 * NP * X_SUB;
-    constexpr int NDY = 2 * NP * (WT / 16);                    // dy DMA pieces per tile (plane, half, 16 pixels): 16 / 12 (NP = 2), 8 / 6 (NP = 1)
+    constexpr int DY_ALL = 2 * NP * DY_SUB, BUF = DY_ALL + CIH * NP * X_SUB;
+    constexpr int NDY = 2 * NP * (WT / 16);                    // dy DMA pieces per tile (plane, half, 16 pixels): 24 / 18 (NP = 3), 16 / 12 (NP = 2), 8 / 6 (NP = 1)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = (wave >> 1) & 1, wn = wave & 1, kh = wave >> 2;                // corner, tap row
+    // NP <= 2: wave = corner (wm, wn) + 4 * tap row.  NP = 3: wave = wm + 2 * tap row + 6 * k half, wn = 0.
+    const int wm = NP == 3 ? (wave & 1) : ((wave >> 1) & 1), wn = NP == 3 ? 0 : (wave & 1);
+    const int kh = NP == 3 ? ((wave >> 1) % 3) : (wave >> 2), khalf = NP == 3 ? wave / 6 : 0;
     const int l31 = lane & 31, lhi = lane >> 5, g4 = lane >> 4, q16 = lane & 15;
     const int krow = 8 * (g4 >> 1) + (q16 >> 2), moff = 16 * (g4 & 1) + 4 * (q16 & 3);
     const int HW = p.H * p.W, PW = p.W + 2;
-    const int ncit = (p.Cin + 63) >> 6;
-    const int co0 = ((int)blockIdx.y / ncit) << 6, ci0 = ((int)blockIdx.y % ncit) << 6;
+    constexpr int CIB = 32 * CIH;                               // ci block of a workgroup
+    const int ncit = (p.Cin + CIB - 1) / CIB;
+    const int co0 = ((int)blockIdx.y / ncit) << 6, ci0 = ((int)blockIdx.y % ncit) * CIB;
     const int tiles = p.N * p.tpi;
     const int t_beg = (int)blockIdx.x * p.tiles_per_chunk;
     const int t_end = t_beg + p.tiles_per_chunk < tiles ? t_beg + p.tiles_per_chunk : tiles;
     const unsigned short* zero = g_zero_page;
+    const long xps = p.x_lo - p.x_hi, dps = p.dy_lo - p.dy_hi;  // plane strides (elements); piece q at hi + q * stride (equally spaced planes)
 
     auto tr = [](const unsigned char* ptr) {
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(__attribute__((address_space(3))) const unsigned char*)ptr);
@@ -410,7 +688,7 @@ __global__ __launch_bounds__(768) void pconv_wgrad_kernel(PWgradP p) {
         const int pend = p0 + WT < HW ? p0 + WT : HW;
         const int r0 = p0 / p.W, rows = (pend - 1) / p.W - r0 + 3;              // + the halo row above and below
         unsigned char* dst = wsm + buf * BUF;
-        // dy strip: NDY pieces = (plane, half, 16 pixels); wave w stages pieces w and w + 12 (WT = 64; the waves past the end repeat their first)
+        // dy strip: NDY pieces = (plane, half, 16 pixels); wave w stages pieces w and w + 12 (the waves past the end repeat their first)
 #pragma unroll
         for (int i = 0; i < (NDY + 11) / 12; ++i) {
             const int q = (wave + 12 * i) < NDY ? wave + 12 * i : wave % NDY;     // = sub * (WT / 16) + piece, sub = plane * 2 + half
@@ -418,21 +696,20 @@ __global__ __launch_bounds__(768) void pconv_wgrad_kernel(PWgradP p) {
             const int pix = p0 + piece * 16 + drow;
             const bool on = pix < HW && co0 + (sub & 1) * 32 < p.Cout;           // Cout = 32: the upper half is zeros
             const long o = ((long)img * HW + pix) * p.Cout + co0 + (sub & 1) * 32 + dpc * 8;
-            const unsigned short* g = on ? ((sub >> 1) ? p.dy_lo : p.dy_hi) + o : zero;
+            const unsigned short* g = on ? p.dy_hi + (sub >> 1) * dps + o : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lds_ptr_t)(dst + sub * DY_SUB + piece * 1024), 16, 0, 0);
         }
-        // x patch: piece `wave` (16 padded pixels) in its four sub-planes; pieces past rows * PW carry zeros (never read)
+        // x patch: piece `wave` (16 padded pixels) in its CIH * NP sub-planes; pieces past rows * PW carry zeros (never read)
         {
             const int gy = r0 - 1 + ppr;
             const bool on = ppr < rows && gy >= 0 && gy < p.H && ppx >= 1 && ppx <= p.W;
             const bool on1 = on && ci0 + 32 < p.Cin;                               // Cin = 32: the upper half is zeros
             const long o = (((long)img * p.H + gy) * p.W + (ppx - 1)) * p.Cin + ci0 + dpc * 8;
             unsigned char* d = dst + DY_ALL + wave * 1024;
-            __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.x_hi + o : zero), (lds_ptr_t)(d), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(on1 ? p.x_hi + o + 32 : zero), (lds_ptr_t)(d + X_SUB), 16, 0, 0);
-            if (NP == 2) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.x_lo + o : zero), (lds_ptr_t)(d + 2 * X_SUB), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(on1 ? p.x_lo + o + 32 : zero), (lds_ptr_t)(d + 3 * X_SUB), 16, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.x_hi + q * xps + o : zero), (lds_ptr_t)(d + (q * CIH) * X_SUB), 16, 0, 0);
+                if (CIH == 2) __builtin_amdgcn_global_load_lds((gptr_t)(on1 ? p.x_hi + q * xps + o + 32 : zero), (lds_ptr_t)(d + (q * CIH + 1) * X_SUB), 16, 0, 0);
             }
         }
     };
@@ -443,9 +720,9 @@ __global__ __launch_bounds__(768) void pconv_wgrad_kernel(PWgradP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // fragment sets of one 16-pixel k chunk: the dy fragment (hi, lo) and this wave's three taps' x fragments (hi, lo).  Two sets: chunk kc + 1 is
-    // read from LDS while chunk kc's 9 MFMAs run.
-    struct FragSet { bf16x8_t ah, al, bh[3], bl[3]; };
+    // fragment sets of one 16-pixel k chunk: the dy fragment pieces and this wave's three taps' x fragment pieces.  NP <= 2: two sets (chunk
+    // kc + 1 is read from LDS while chunk kc's MFMAs run); NP = 3: one set (three waves per SIMD leave 168 registers per lane).
+    struct FragSet { bf16x8_t a[NP], b[3][NP]; };
     const int a_lane = wm * DY_SUB + 2 * moff;                                    // this wave's dy half + this lane's channel offset
     const int b_lane = DY_ALL + wn * X_SUB + 2 * moff + kh * PW * 64;             // its x half, channel offset and tap row
     auto load_set = [&](FragSet& f, int cur, int p0, int r0, int kc) {
@@ -453,8 +730,8 @@ __global__ __launch_bounds__(768) void pconv_wgrad_kernel(PWgradP p) {
         const int k0 = 16 * kc + krow, k1 = k0 + 4;                               // this lane's two tile-local pixels
         const unsigned char* a0 = base + a_lane + k0 * 64;
         const unsigned char* a1 = base + a_lane + k1 * 64;
-        f.ah = frag(a0, a1);
-        if (NP == 2) f.al = frag(a0 + 2 * DY_SUB, a1 + 2 * DY_SUB);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) f.a[q] = frag(a0 + 2 * q * DY_SUB, a1 + 2 * q * DY_SUB);
         int q0 = p0 + k0, q1 = p0 + k1;
         if (q0 >= HW) q0 = HW - 1;                                                 // clamp: stays inside the patch; dy is zero there
         if (q1 >= HW) q1 = HW - 1;
@@ -462,44 +739,60 @@ __global__ __launch_bounds__(768) void pconv_wgrad_kernel(PWgradP p) {
         const unsigned char* b0 = base + b_lane + ((y0 - r0) * PW + (q0 - y0 * p.W)) * 64;   // patch row of tap (kh, 0)
         const unsigned char* b1 = base + b_lane + ((y1 - r0) * PW + (q1 - y1 * p.W)) * 64;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            f.bh[t] = frag(b0 + t * 64, b1 + t * 64);
-            if (NP == 2) f.bl[t] = frag(b0 + t * 64 + 2 * X_SUB, b1 + t * 64 + 2 * X_SUB);
-        }
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) f.b[t][q] = frag(b0 + t * 64 + CIH * q * X_SUB, b1 + t * 64 + CIH * q * X_SUB);
     };
-    // three passes over the taps (lo*hi, hi*lo, hi*hi): consecutive MFMAs go to DIFFERENT accumulators; each accumulator still sees its
-    // products in the same order
+    // passes over the taps, smallest products first: consecutive MFMAs go to DIFFERENT accumulators; each accumulator still sees its products
+    // in the same order (NP = 2: lo*hi, hi*lo, hi*hi as in round 3; NP = 3: the six products of pconv_kernel)
     auto mfma_set = [&](const FragSet& f) {
-        if (NP == 2) {
+        if constexpr (NP == 3) {
+            constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.bh[t], acc[t], 0, 0, 0);
+            for (int u = 0; u < 6; ++u)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bl[t], acc[t], 0, 0, 0);
+                for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[QA[u]], f.b[t][QB[u]], acc[t], 0, 0, 0);
+        } else {
+            if constexpr (NP == 2) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[NP - 1], f.b[t][0], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[t][NP - 1], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[t][0], acc[t], 0, 0, 0);
         }
-#pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bh[t], acc[t], 0, 0, 0);
     };
 
     if (t_beg < t_end) stage(t_beg, 0);
-    __syncthreads();
+    wait_vm_lds_barrier<0>();            // explicit: the DMA of every wave has landed (do not lean on the compiler's alias wait)
     FragSet fs0, fs1;
+    constexpr int KC0 = NKC / KSP + (NKC % KSP);                // chunks of k half 0 (NKC = 3: 2 + 1)
+    const int kc_beg = khalf == 0 ? 0 : KC0, kc_end = (KSP == 1 || khalf == 1) ? NKC : KC0;
     for (int tile = t_beg; tile < t_end; ++tile) {
         const int cur = (tile - t_beg) & 1;
         if (tile + 1 < t_end && !(p.dbg & 1)) stage(tile + 1, cur ^ 1);
         const int p0 = (tile % p.tpi) * WT;
         const int r0 = p0 / p.W;
-        load_set(fs0, cur, p0, r0, 0);
+        if constexpr (NP == 3) {
+            for (int kc = kc_beg; kc < kc_end; ++kc) {
+                load_set(fs0, cur, p0, r0, kc);
+                mfma_set(fs0);
+            }
+        } else {
+            load_set(fs0, cur, p0, r0, 0);
 #pragma unroll
-        for (int kc = 0; kc < NKC; ++kc) {
-            FragSet& use = (kc & 1) ? fs1 : fs0;
-            FragSet& nxt = (kc & 1) ? fs0 : fs1;
-            if (kc + 1 < NKC) load_set(nxt, cur, p0, r0, kc + 1);
-            mfma_set(use);
+            for (int kc = 0; kc < NKC; ++kc) {
+                FragSet& use = (kc & 1) ? fs1 : fs0;
+                FragSet& nxt = (kc & 1) ? fs0 : fs1;
+                if (kc + 1 < NKC) load_set(nxt, cur, p0, r0, kc + 1);
+                mfma_set(use);
+            }
         }
-        __syncthreads();                 // the next tile has landed (vmcnt(0) rides on the fence) and every wave is done with this one
+        wait_vm_lds_barrier<0>();        // the next tile has landed and every wave is done with this one
     }
-    // ---- this wave's three taps of its corner of the chunk's slab: part[chunk][co][tap][ci] ----
-    float* out = p.part + (long)blockIdx.x * p.Cout * 9 * p.Cin;
+    // ---- this wave's three taps of its corner of the chunk's slab: part[chunk * KSP + k half][co][tap][ci] ----
+    float* out = p.part + ((long)blockIdx.x * KSP + khalf) * p.Cout * 9 * p.Cin;
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -525,28 +818,34 @@ int pconv_wgrad_supported(int H, int W, int Cin, int Cout, int KH, int KW, int s
     const int wt = pwgrad_tile(H * W);
     return ((wt + W - 2) / W + 1 + 2) * (W + 2) <= PW_ROWS;
 }
-long pconv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+// np = 3: a workgroup owns a 64 x 32 block (one 32-channel half of x) and writes two slabs (the two k halves of its waves)
+static int pwgrad_pairs(int Cin, int Cout, int np) { return ((Cin + (np == 3 ? 31 : 63)) / (np == 3 ? 32 : 64)) * ((Cout + 63) / 64); }
+long pconv_wgrad_workspace_bytes_np(int N, int H, int W, int Cin, int Cout, int np) {
     const int wt = pwgrad_tile(H * W);
     const long tiles = (long)N * (((long)H * W + wt - 1) / wt);
-    const int npairs = ((Cin + 63) / 64) * ((Cout + 63) / 64);
+    const int npairs = pwgrad_pairs(Cin, Cout, np);
     long nchunks = 256 / npairs < 1 ? 1 : 256 / npairs;
     if (nchunks > tiles) nchunks = tiles;
-    return nchunks * (long)Cout * 9 * Cin * 4;
+    return nchunks * (np == 3 ? 2 : 1) * (long)Cout * 9 * Cin * 4;
 }
-// x_lo == dy_lo == nullptr: bf16-storage mode (one plane)
-int pconv_wgrad_launch(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* part, int N, int H, int W, int Cin, int Cout,
-                       hipStream_t st) {
-    const int np = (x_lo == nullptr && dy_lo == nullptr) ? 1 : 2;
+long pconv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout) {          // enough for every piece count
+    const long a = pconv_wgrad_workspace_bytes_np(N, H, W, Cin, Cout, 2), b = pconv_wgrad_workspace_bytes_np(N, H, W, Cin, Cout, 3);
+    return a > b ? a : b;
+}
+// np pieces per operand: piece q of x at x + q * x_ps, of dy at dy + q * dy_ps (elements); np = 1: bf16-storage mode (the tensors themselves)
+int pconv_wgrad_launch_np(const void* x, long x_ps, const void* dy, long dy_ps, int np, float* part, int N, int H, int W, int Cin, int Cout,
+                          hipStream_t st) {
     PWgradP p{};
-    p.x_hi = (const unsigned short*)x_hi; p.x_lo = (const unsigned short*)x_lo;
-    p.dy_hi = (const unsigned short*)dy_hi; p.dy_lo = (const unsigned short*)dy_lo;
+    p.x_hi = (const unsigned short*)x; p.x_lo = p.x_hi + x_ps;
+    p.dy_hi = (const unsigned short*)dy; p.dy_lo = p.dy_hi + dy_ps;
     p.part = part; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.dbg = g_pdbg;
     const int HW = H * W, wt = pwgrad_tile(HW);
     p.tpi = (HW + wt - 1) / wt;
     const long tiles = (long)N * p.tpi;
-    const int npairs = ((Cin + 63) / 64) * ((Cout + 63) / 64);
+    const int npairs = pwgrad_pairs(Cin, Cout, np);
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) { int c = 0; if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) cus = c; }
+    if (dev < 0 || dev >= 64) dev = 0;
     if (cus > 256) cus = 256;                                   // the workspace query assumes at most 256 chunks x pairs
     if (cus > g_side_cus) cus = g_side_cus;                     // ha2g_side_cus: leave compute units to the main queue's kernels
     long nchunks = cus / npairs < 1 ? 1 : cus / npairs;
@@ -556,18 +855,23 @@ int pconv_wgrad_launch(const void* x_hi, const void* x_lo, const void* dy_hi, co
     const int rows_max = (wt + W - 2) / W + 1 + 2;
     p.patch_rows = rows_max * (W + 2);
     if (p.patch_rows > PW_ROWS) return -100;                     // the patch does not fit the reserved sub-planes
-    const size_t lds = (size_t)2 * (2 * np * (size_t)((wt + 15) / 16) * 1024 + 2 * np * (size_t)X_SUB);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_wgrad_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_wgrad_kernel<48, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_wgrad_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_wgrad_kernel<48, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
-            return ha2g_set_error(-2, "pconv_wgrad: cannot raise the dynamic LDS limit");
-        attr_set = true;
+    const int cih = np == 3 ? 1 : 2;
+    const size_t lds = (size_t)2 * (2 * np * (size_t)((wt + 15) / 16) * 1024 + cih * np * (size_t)X_SUB);
+    static bool attr_set[64] = {false};                          // per device
+    if (!attr_set[dev]) {
+        const void* fns[6] = {reinterpret_cast<const void*>(pconv_wgrad_kernel<64, 2>), reinterpret_cast<const void*>(pconv_wgrad_kernel<48, 2>),
+                              reinterpret_cast<const void*>(pconv_wgrad_kernel<64, 1>), reinterpret_cast<const void*>(pconv_wgrad_kernel<48, 1>),
+                              reinterpret_cast<const void*>(pconv_wgrad_kernel<64, 3>), reinterpret_cast<const void*>(pconv_wgrad_kernel<48, 3>)};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
+                return ha2g_set_error(-2, "pconv_wgrad: cannot raise the dynamic LDS limit");
+        attr_set[dev] = true;
     }
     const dim3 grid((unsigned)nchunks, npairs);
-    if (np == 2) {
+    if (np == 3) {
+        if (wt == 64) hipLaunchKernelGGL((pconv_wgrad_kernel<64, 3>), grid, dim3(768), lds, st, p);
+        else hipLaunchKernelGGL((pconv_wgrad_kernel<48, 3>), grid, dim3(768), lds, st, p);
+    } else if (np == 2) {
         if (wt == 64) hipLaunchKernelGGL((pconv_wgrad_kernel<64, 2>), grid, dim3(768), lds, st, p);
         else hipLaunchKernelGGL((pconv_wgrad_kernel<48, 2>), grid, dim3(768), lds, st, p);
     } else {
@@ -575,7 +879,14 @@ int pconv_wgrad_launch(const void* x_hi, const void* x_lo, const void* dy_hi, co
         else hipLaunchKernelGGL((pconv_wgrad_kernel<48, 1>), grid, dim3(768), lds, st, p);
     }
     HA2G_CHECK_LAUNCH("pconv_wgrad");
-    return (int)nchunks;
+    return (int)nchunks * (np == 3 ? 2 : 1);                     // slabs written
+}
+// x_lo == dy_lo == nullptr: bf16-storage mode (one plane)
+int pconv_wgrad_launch(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* part, int N, int H, int W, int Cin, int Cout,
+                       hipStream_t st) {
+    const int np = (x_lo == nullptr && dy_lo == nullptr) ? 1 : 2;
+    return pconv_wgrad_launch_np(x_hi, np == 1 ? 0 : (const unsigned short*)x_lo - (const unsigned short*)x_hi, dy_hi,
+                                 np == 1 ? 0 : (const unsigned short*)dy_lo - (const unsigned short*)dy_hi, np, part, N, H, W, Cin, Cout, st);
 }
 
 // parity classes of a data gradient (stride 1: one class with every tap)
@@ -631,12 +942,33 @@ static int pconv_launch(const PConvP& p, dim3 grid, hipStream_t st) {
 }
 static int g_waves = 4;      // ha2g_conv_planes_waves: 8 = eight-wave workgroups with twice the tile (256 x 128 / 512 x 64), one per CU
 
-static int g_tile3 = 0;      // ha2g_conv_planes_tile3: tile of the three-piece kernel, 0 = default per shape, 1 = 128 x 128, 2 = 256 x 64, 3 = 128 x 64
+static int g_tile3 = 0;      // ha2g_conv_planes_tile3: tile of the three-piece kernel, 0 = default per shape, 1 = 128 x 128, 2 = 256 x 64, 3 = 128 x 64,
+                             // 4 = the ping-pong kernel (256 x 128 / 256 x 64, eight waves in two anti-phase groups)
+template <int BN, int NP, int OUT>
+static int pconv_pp_launch(const PConvP& p, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)4 * NP * 128 * 64 + (size_t)2 * NP * BN * 64;
+    static bool attr_set[64] = {false};                          // per device (the attribute is per device, not per process)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_pp_kernel<BN, NP, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ha2g_set_error(-2, "pconv_pp: cannot raise the dynamic LDS limit to %zu bytes", lds);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((pconv_pp_kernel<BN, NP, OUT>), grid, dim3(512), lds, st, p);
+    return 0;
+}
 template <int NP, int OUT>
 static int pconv_dispatch(const PConvP& p, int maxM, hipStream_t st) {
     if constexpr (NP == 3) {
         // three pieces: 48 KB (128 x 128) / 60 KB (256 x 64) / 36 KB (128 x 64) per LDS stage -- the 128 x 64 tile keeps two workgroups per CU
-        int t = g_tile3 ? g_tile3 : (p.N % 128 == 0 ? 1 : 3);
+        // default: the eight-wave ping-pong kernel where the column tile is 128 wide (layers 3 / 4: 168 vs 227 us at C = 256, 194 vs 199 at C = 128,
+        // profiles/r04_bwd_matrix_bench_np3_v2.txt), the 128 x 64 tile (two workgroups per CU) for the 64-channel layer (179 vs 186 us)
+        int t = g_tile3 ? g_tile3 : (p.N % 128 == 0 ? 4 : 3);
+        if (t == 4) {
+            if (p.N % 128 == 0) return pconv_pp_launch<128, NP, OUT>(p, dim3(ceil_div(maxM, 256), p.N / 128, p.ncls), st);
+            return pconv_pp_launch<64, NP, OUT>(p, dim3(ceil_div(maxM, 256), ceil_div(p.N, 64), p.ncls), st);
+        }
         if (t == 1 && p.N % 128 != 0) t = 3;
         if (t == 1) return pconv_launch<128, 128, 2, 2, NP, OUT>(p, dim3(ceil_div(maxM, 128), p.N / 128, p.ncls), st);
         if (t == 2) return pconv_launch<256, 64, 4, 1, NP, OUT>(p, dim3(ceil_div(maxM, 256), ceil_div(p.N, 64), p.ncls), st);
@@ -657,7 +989,7 @@ void ha2g_conv_planes_enable(int on) { g_planes = on; }
 void ha2g_conv_planes_debug(int bits) { g_pdbg = bits; }
 void ha2g_conv_planes_ring(int depth) { g_ring = depth; }
 void ha2g_conv_planes_waves(int n) { g_waves = n == 8 ? 8 : 4; }
-void ha2g_conv_planes_tile3(int t) { g_tile3 = (t >= 0 && t <= 3) ? t : 0; }
+void ha2g_conv_planes_tile3(int t) { g_tile3 = (t >= 0 && t <= 4) ? t : 0; }
 
 // fp32 -> np bf16 piece planes of the same shape (piece q at planes + q * ps elements); n % 4 == 0, 16-byte aligned, ps % 8 == 0
 int ha2g_f32_to_planes_np(const float* x, void* planes, long ps, int np, long n, void* stream) {
@@ -669,6 +1001,24 @@ int ha2g_f32_to_planes_np(const float* x, void* planes, long ps, int np, long n,
     if (np == 3) hipLaunchKernelGGL(f32_to_planes_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)planes, ps, n4);
     else hipLaunchKernelGGL(f32_to_planes_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)planes, ps, n4);
     HA2G_CHECK_LAUNCH("f32_to_planes");
+    return 0;
+}
+// n <= 48 tensors in one launch; x / planes / ps / numel are HOST arrays; numel[i] % 4 == 0
+int ha2g_f32_to_planes_multi_np(const void* const* x, void* const* planes, const long* ps, const long* numel, int n, int np, void* stream) {
+    HA2G_REQUIRE(n >= 0 && n <= 48, "f32_to_planes_multi: %d tensors (max 48)", n);
+    HA2G_REQUIRE(np == 2 || np == 3, "f32_to_planes_multi: np = %d (2 or 3)", np);
+    if (n == 0) return 0;
+    SplitBatch b{};
+    long most = 0;
+    for (int i = 0; i < n; ++i) {
+        HA2G_REQUIRE(numel[i] % 4 == 0, "f32_to_planes_multi: numel %% 4");
+        b.x[i] = (const float*)x[i]; b.pl[i] = (unsigned short*)planes[i]; b.ps[i] = ps[i]; b.n4[i] = numel[i] / 4;
+        if (b.n4[i] > most) most = b.n4[i];
+    }
+    const int gx = (int)((most + 255) / 256 > 512 ? 512 : (most + 255) / 256);
+    if (np == 3) hipLaunchKernelGGL(f32_to_planes_multi_kernel<3>, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, b);
+    else hipLaunchKernelGGL(f32_to_planes_multi_kernel<2>, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, b);
+    HA2G_CHECK_LAUNCH("f32_to_planes_multi");
     return 0;
 }
 // the two-plane form of round 3: (hi, lo) = pieces 0, 1
@@ -752,6 +1102,37 @@ int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const voi
     return ha2g_conv2d_dgrad_planes_np_f32(dy_hi, (const unsigned short*)dy_lo - (const unsigned short*)dy_hi, wt_hi,
                                            (const unsigned short*)wt_lo - (const unsigned short*)wt_hi, 2, dx, N, H, W, Cin, Cout, KH, KW, stride, pad,
                                            beta, stream);
+}
+
+// ---- FORWARD convolution on three-piece planes (round 4): y [N,OH,OW,Cout] (fp32) = [relu](conv(x, w)) from the piece planes of x [N,H,W,Cin]
+//      (written by x's producer: ha2g_bn_apply_planes_np_f32 / ha2g_se_scale_add_relu_planes_np_f32) and of w [Cout][KH][KW][Cin] (OHWI,
+//      ha2g_f32_to_planes_multi_np).  Six bf16 MFMAs per product on all 24 mantissa bits of both operands = the accuracy of the fp32 MFMA
+//      chain (tests/test_gpu_np3.py), at 6 x 8 instead of 8 x 16 matrix-pipe passes.  3x3 / pad 1 or 1x1 / pad 0, stride 1 or 2, Cin % 32 == 0,
+//      Cout % 64 == 0.  Replaces nn.Conv2d forward of the SE-ResNet trunk layers 2-4 (model/ResNetBlocks.py:24-29, ResNetSE34V2.py:96-116). ----
+int ha2g_conv2d_fwd_planes_supported(int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    const bool geom = (KH == 3 && KW == 3 && pad == 1) || (KH == 1 && KW == 1 && pad == 0);
+    return g_planes && geom && (stride == 1 || stride == 2) && Cin % 32 == 0 && Cin >= 32 && Cout % 64 == 0;
+}
+int ha2g_conv2d_fwd_planes_np_f32(const void* x, long x_ps, const void* w, long w_ps, int np, float* y, int N, int H, int W, int Cin, int Cout, int KH,
+                                  int KW, int stride, int pad, int relu, void* stream) {
+    HA2G_REQUIRE(ha2g_conv2d_fwd_planes_supported(Cin, Cout, KH, KW, stride, pad), "conv2d_fwd_planes: unsupported geometry");
+    HA2G_REQUIRE(np == 3, "conv2d_fwd_planes: np = %d (the forward runs on three pieces only: fp32-class)", np);
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    PConvP p{};
+    p.a = PlaneSet{(const unsigned short*)x, x_ps}; p.b = PlaneSet{(const unsigned short*)w, w_ps};
+    p.C = y; p.ldc = Cout; p.beta = 0.f; p.relu = relu; p.fwd = 1;
+    p.N = Cout; p.K = KH * KW * Cin;
+    p.GH = H; p.GW = W; p.GC = Cin; p.OH = OH; p.OW = OW; p.KH = KH; p.KW = KW; p.pad = pad; p.stride = stride;
+    p.dbg = g_pdbg;
+    PClass c{};
+    c.OHc = OH; c.OWc = OW; c.M = N * OH * OW;
+    for (int kh = 0; kh < KH; ++kh)
+        for (int kw = 0; kw < KW; ++kw) { c.tap[c.ntaps] = kh * KW + kw; c.doff[c.ntaps] = kh * W + kw; ++c.ntaps; }
+    p.ncls = 1; p.cls[0] = c;
+    if (c.M == 0) return 0;
+    if (int rc = pconv_dispatch<3, 0>(p, c.M, (hipStream_t)stream)) return rc;
+    HA2G_CHECK_LAUNCH("conv2d_fwd_planes");
+    return 0;
 }
 
 // ---- bf16-storage mode (BASELINE config 5, `bench.py --bf16`): activations and the dY stream of the audio tower live in HBM as bf16; the

@@ -1204,8 +1204,7 @@ int ha2g_conv2d_dgrad_f32(const float* dy, const float* wt, float* dx, int N, in
         // direct LDS-patch kernels (conv_c32.hip): split-bf16 by default like every other data gradient; fp32 form = debug bit 1
         int rc = -100;
         if (g_direct_c32_dgrad) rc = conv3x3_c32_launch(dy, wt, dx, N, H, W, 1, 0, beta, (hipStream_t)stream);
-        else if (g_split_dgrad && g_direct_c32_x3 && !g_np3) rc = conv3x3_c32_x3_launch(dy, wt, dx, N, H, W, 1, 0, beta, (hipStream_t)stream);
-        else if (g_split_dgrad && g_np3 && g_direct_c32) rc = conv3x3_c32_launch(dy, wt, dx, N, H, W, 1, 0, beta, (hipStream_t)stream);     // exact fp32 direct kernel
+        else if (g_split_dgrad && g_direct_c32_x3) rc = conv3x3_c32_x3_launch(dy, wt, dx, N, H, W, 1, 0, beta, (hipStream_t)stream);      // two or three pieces by the mode
         if (rc != -100) return rc;
     }
     GemmP p{};
@@ -1254,7 +1253,7 @@ int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int
     long need = ha2g_conv2d_wgrad_workspace_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad);
     long MN = (long)p.M * p.N;
     hipStream_t st0 = (hipStream_t)stream;
-    if (g_direct_c32_wgrad && g_split_wgrad && !g_np3 && !g_bf16 && Cin == 32 && Cout == 32 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && ws &&
+    if (g_direct_c32_wgrad && g_split_wgrad && !g_bf16 && Cin == 32 && Cout == 32 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && ws &&
         ws_bytes >= need) {
         const int nblk = conv3x3_c32_wgrad_launch(x, dy, ws, N, H, W, st0);
         if (nblk != -100) {
@@ -1293,7 +1292,7 @@ int ha2g_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int
 // Plane-based weight gradient (conv_planes.hip): x and dy arrive as bf16 hi / lo planes; one DMA-staged launch writes `chunks` dW-shaped
 // partial slabs into ws, the wide reduce adds them in double.  3x3 / stride 1 / pad 1, channels multiples of 64.
 int ha2g_conv2d_wgrad_planes_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
-    return g_split_wgrad && !g_np3 && !g_bf16 && Cin % 64 == 0 && Cout % 64 == 0 && pconv_wgrad_supported(H, W, Cin, Cout, KH, KW, stride, pad);
+    return g_split_wgrad && !g_bf16 && Cin % 64 == 0 && Cout % 64 == 0 && pconv_wgrad_supported(H, W, Cin, Cout, KH, KW, stride, pad);
 }
 // bf16-storage mode: dw (fp32) = beta*dw + dy^T im2col(x) with x and dy bf16 tensors (one plane, one MFMA per product); 3x3 / stride 1 / pad 1,
 // channel counts multiples of 32
@@ -1339,6 +1338,24 @@ int ha2g_conv2d_wgrad_b16(const void* x, const void* dy, float* dw, int N, int H
     return 0;
 }
 long ha2g_conv2d_wgrad_planes_workspace_bytes(int N, int H, int W, int Cin, int Cout) { return pconv_wgrad_workspace_bytes(N, H, W, Cin, Cout); }
+// np = 2 or 3 equally spaced piece planes of x and dy (piece q at base + q * ps elements); np = 3 is the fp32-class default
+int ha2g_conv2d_wgrad_planes_np_f32(const void* x, long x_ps, const void* dy, long dy_ps, int np, float* dw, int N, int H, int W, int Cin,
+                                    int Cout, int KH, int KW, int stride, int pad, float beta, float* ws, long ws_bytes, void* stream) {
+    HA2G_REQUIRE(ha2g_conv2d_wgrad_planes_supported(H, W, Cin, Cout, KH, KW, stride, pad), "conv2d_wgrad_planes: unsupported geometry / mode");
+    HA2G_REQUIRE(np == 2 || np == 3, "conv2d_wgrad_planes: np = %d (2 or 3)", np);
+    HA2G_REQUIRE(ws && ws_bytes >= pconv_wgrad_workspace_bytes(N, H, W, Cin, Cout), "conv2d_wgrad_planes: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = pconv_wgrad_launch_np(x, x_ps, dy, dy_ps, np, ws, N, H, W, Cin, Cout, st);
+    if (chunks == -100) return ha2g_set_error(-1, "conv2d_wgrad_planes: the patch does not fit the LDS (W = %d)", W);
+    if (chunks < 0) return chunks;
+    const long MN = (long)Cout * KH * KW * Cin;
+    ReduceOut ro{};
+    ro.groups = 1; ro.C[0] = dw;
+    hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3(ceil_div(MN, 64), 1), dim3(256), 0, st, ws, chunks, MN, KH * KW * Cin, ro, (long)KH * KW * Cin, 1.f,
+                       beta, 0, 0.f, Cout);
+    HA2G_CHECK_LAUNCH("conv2d_wgrad_planes reduce");
+    return 0;
+}
 int ha2g_conv2d_wgrad_planes_f32(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, int N, int H, int W, int Cin,
                                  int Cout, int KH, int KW, int stride, int pad, float beta, float* ws, long ws_bytes, void* stream) {
     HA2G_REQUIRE(ha2g_conv2d_wgrad_planes_supported(H, W, Cin, Cout, KH, KW, stride, pad), "conv2d_wgrad_planes: unsupported geometry / mode");

@@ -171,8 +171,6 @@ def conv_wgrad(x, dy, w_ohwi, stride, pad, into=None):
 
 
 def wgrad_planes_ok(x, w_ohwi, stride, pad):
-    """the plane weight-gradient kernel is a two-piece kernel: in the fp32-class (three-piece) mode the library answers 0 here and the weight
-    gradient takes the implicit GEMM with the three-piece plane tiles (gemm_kernel<.., SPLIT = 4>)"""
     Cout, KH, KW, Cin = w_ohwi.shape
     return bool(PLANES & 2) and bool(lib.ha2g_conv2d_wgrad_planes_supported(x.shape[1], x.shape[2], Cin, Cout, KH, KW, stride, pad))
 
@@ -192,8 +190,9 @@ def conv_wgrad_planes(x_planes, dy_planes, w_ohwi, xshape, into=None):
         dw = torch.empty(Cout, KH, KW, Cin, dtype=torch.float32, device=x_planes[0].device)
     ws = workspace(x_planes[0].device)
     assert lib.ha2g_conv2d_wgrad_planes_workspace_bytes(N, H, W, Cin, Cout) <= ws.numel() * 4
-    ops.ktimer.launch('conv_wgrad_planes', lambda: check(lib.ha2g_conv2d_wgrad_planes_f32(
-        x_planes[0].data_ptr(), x_planes[1].data_ptr(), dy_planes[0].data_ptr(), dy_planes[1].data_ptr(), dw.data_ptr(), N, H, W, Cin, Cout, KH, KW,
+    assert x_planes.shape[0] == dy_planes.shape[0], 'conv_wgrad_planes: x and dy must carry the same number of pieces'
+    ops.ktimer.launch('conv_wgrad_planes', lambda: check(lib.ha2g_conv2d_wgrad_planes_np_f32(
+        x_planes.data_ptr(), x_planes.stride(0), dy_planes.data_ptr(), dy_planes.stride(0), x_planes.shape[0], dw.data_ptr(), N, H, W, Cin, Cout, KH, KW,
         1, 1, beta, ws.data_ptr(), ws.numel() * 4, _stream())), 2.0 * N * H * W * Cin * KH * KW * Cout)
     return None if into is not None else dw.permute(0, 3, 1, 2)
 
@@ -370,7 +369,7 @@ class GradSink:
                 xin.record_stream(st); dy_planes.record_stream(st)
             if x_planes is not None and side_on:
                 x_planes.record_stream(st)
-            xp = x_planes if x_planes is not None else ops.to_planes(xin, 2)
+            xp = x_planes if (x_planes is not None and x_planes.shape[0] == dy_planes.shape[0]) else ops.to_planes(xin, dy_planes.shape[0])
             r = conv_wgrad_planes(xp, dy_planes, w_ohwi, xin.shape, into=self.tgt(self.P[name]))
             if r is not None and side_on:
                 r.record_stream(torch.cuda.default_stream(xin.device))

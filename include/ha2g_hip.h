@@ -85,7 +85,16 @@ int ha2g_conv2d_weight_ihwo_planes_multi_np(const void* const* w, void* const* w
                                             int n, int np, void* stream);
 int ha2g_conv2d_dgrad_planes_np_f32(const void* dy, long dy_ps, const void* wt, long wt_ps, int np, float* dx, int N, int H, int W,
                                     int Cin, int Cout, int KH, int KW, int stride, int pad, float beta, void* stream);
-void ha2g_conv_planes_tile3(int t);       /* A/B: tile of the three-piece plane kernel (0 = default, 1 = 128x128, 2 = 256x64, 3 = 128x64) */
+int ha2g_conv2d_wgrad_planes_np_f32(const void* x, long x_ps, const void* dy, long dy_ps, int np, float* dw, int N, int H, int W, int Cin,
+                                    int Cout, int KH, int KW, int stride, int pad, float beta, float* ws, long ws_bytes, void* stream);
+/* forward convolution of trunk layers 2-4 from three-piece planes (fp32 output, optional ReLU): nn.Conv2d forward (model/ResNetBlocks.py:24-29,
+ * model/ResNetSE34V2.py:96-116) at fp32-class accuracy; x planes from the producers (ha2g_bn_apply_planes_np_f32, ha2g_se_scale_add_relu_planes_np_f32),
+ * weight planes [Cout][KH][KW][Cin] from ha2g_f32_to_planes_multi_np (n <= 48 tensors in one launch, HOST arrays) */
+int ha2g_f32_to_planes_multi_np(const void* const* x, void* const* planes, const long* ps, const long* numel, int n, int np, void* stream);
+int ha2g_conv2d_fwd_planes_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
+int ha2g_conv2d_fwd_planes_np_f32(const void* x, long x_ps, const void* w, long w_ps, int np, float* y, int N, int H, int W, int Cin, int Cout, int KH,
+                                  int KW, int stride, int pad, int relu, void* stream);
+void ha2g_conv_planes_tile3(int t);       /* A/B: tile of the three-piece plane kernel (0 = default, 1 = 128x128, 2 = 256x64, 3 = 128x64, 4 = the eight-wave ping-pong kernel 256x128 / 256x64) */
 int ha2g_gemm_bwd_pieces(void);           /* 0 = backward products on the fp32 MFMA / plain bf16, 2 / 3 = bf16 pieces per operand of the split products */
 int ha2g_conv2d_dgrad_planes_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
 int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N, int H, int W,

@@ -60,7 +60,7 @@ def test_bn_bwd_writes_three_piece_planes(relu_mask):
     assert torch.equal(pl2, pl)
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2, 3])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4])
 @pytest.mark.parametrize('B,H,W,C', [(4, 64, 35, 64), (3, 32, 18, 128), (5, 16, 9, 256), (1, 7, 5, 64), (128, 32, 18, 128)])
 def test_dgrad_three_piece_planes_are_fp32_class(B, H, W, C, tile):
     """3x3 stride-1 data gradients of trunk layers 2-4 on the DMA-staged plane kernel with three pieces: as close to float64 as the exact fp32
@@ -81,23 +81,28 @@ def test_dgrad_three_piece_planes_are_fp32_class(B, H, W, C, tile):
     exact = we.conv_dgrad(dy, w, (B, H, W, C), 1, 1)
     lib.ha2g_gemm_set_mode(70)
     e3, e32 = _rel(got, x64), _rel(exact, x64)
-    assert e3 < 1.5e-6 and e3 < 2.0 * e32 + 2e-7, (e3, e32)
-    assert _rel(got1 - base, x64) < 3e-6
+    assert e3 < 3e-6 and e3 < 1.5 * e32 + 2e-7, (e3, e32)          # K = 9 C up to 2304 terms: the fp32 chain itself sits at 1-2e-6 here
+    assert _rel(got1 - base, x64) < 5e-6
 
 
+@pytest.mark.parametrize('tile', [0, 4])
 @pytest.mark.parametrize('B,H,W,Cin,Cout,k', [(4, 128, 70, 32, 64, 3), (3, 64, 35, 64, 128, 3), (5, 32, 18, 128, 256, 3), (2, 9, 7, 64, 64, 3),
                                               (4, 128, 70, 32, 64, 1), (3, 64, 35, 64, 128, 1), (4, 32, 18, 128, 256, 1)])
-def test_stride2_dgrad_three_piece_planes_are_fp32_class(B, H, W, Cin, Cout, k):
+def test_stride2_dgrad_three_piece_planes_are_fp32_class(B, H, W, Cin, Cout, k, tile):
     torch.manual_seed(5)
     pad = 1 if k == 3 else 0
     OH, OW = (H + 2 * pad - k) // 2 + 1, (W + 2 * pad - k) // 2 + 1
     dy = torch.randn(B, OH, OW, Cout, device=DEV)
     w = torch.randn(Cout, k, k, Cin, device=DEV) * 0.05
     assert we.dgrad_planes_ok(w, 2, pad)
-    got = we.conv_dgrad_planes(ops.to_planes(dy), w, (B, H, W, Cin), 2, pad)
+    lib.ha2g_conv_planes_tile3(tile)
+    try:
+        got = we.conv_dgrad_planes(ops.to_planes(dy), w, (B, H, W, Cin), 2, pad)
+    finally:
+        lib.ha2g_conv_planes_tile3(0)
     x64 = torch.nn.functional.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), stride=2, padding=pad,
                                                output_padding=(H - ((OH - 1) * 2 - 2 * pad + k), W - ((OW - 1) * 2 - 2 * pad + k))).permute(0, 2, 3, 1)
-    assert _rel(got, x64) < 1.5e-6
+    assert _rel(got, x64) < 3e-6
 
 
 @pytest.mark.parametrize('H,W,Cin,Cout,k,stride,pad', [(64, 35, 64, 64, 3, 1, 1), (32, 18, 128, 128, 3, 1, 1), (16, 9, 256, 256, 3, 1, 1), (128, 70, 32, 32, 3, 1, 1),
@@ -136,5 +141,34 @@ def test_dense_backward_products_are_fp32_class(M, N, K):
     lib.ha2g_gemm_set_mode(6)
     dw2 = ops.gemm(dy, x, transa=True)
     lib.ha2g_gemm_set_mode(70)
-    if K >= 64 and M >= 64:
-        assert _rel(dw, dy.double().t() @ x.double()) < 0.3 * _rel(dw2, dy.double().t() @ x.double()) + 1e-7      # and it is NOT the two-piece product
+    e2 = _rel(dw2, dy.double().t() @ x.double())
+    if e2 > 2e-6:                                          # where mode 6 does run the two-piece product: the default is NOT that product
+        assert _rel(dw, dy.double().t() @ x.double()) < 0.3 * e2
+
+
+@pytest.mark.parametrize('B,H,W,C', [(4, 64, 35, 64), (3, 32, 18, 128), (5, 16, 9, 256), (2, 7, 5, 64), (1, 4, 4, 128), (128, 32, 18, 128), (16, 64, 35, 64)])
+def test_wgrad_three_piece_planes_are_fp32_class(B, H, W, C):
+    """3x3 / stride-1 / pad-1 weight gradient on the plane kernel with three pieces (64 x 32 blocks, twelve waves = 2 co halves x 3 tap rows x
+    2 k halves, two partial slabs per workgroup): every trunk width, tile-aligned and ragged pixel counts (48-pixel tiles with 2 + 1 chunks per
+    k half at 16 x 9), accumulate-into-.grad form -- against float64 autograd at the accuracy of the exact fp32 kernel."""
+    torch.manual_seed(3)
+    x = torch.randn(B, H, W, C, device=DEV)
+    dy = torch.randn(B, H, W, C, device=DEV)
+    w = torch.zeros(C, 3, 3, C, device=DEV)
+    assert we.wgrad_planes_ok(x, w, 1, 1)
+    xp, dp = ops.to_planes(x), ops.to_planes(dy)
+    assert xp.shape[0] == 3
+    got = we.conv_wgrad_planes(xp, dp, w, x.shape)             # logical OIHW
+    xx = x.double().permute(0, 3, 1, 2)
+    ww = torch.zeros(C, C, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
+    y = torch.nn.functional.conv2d(xx, ww, padding=1)
+    (gref,) = torch.autograd.grad(y, ww, dy.double().permute(0, 3, 1, 2))
+    lib.ha2g_gemm_set_mode(0)
+    exact = we.conv_wgrad(x, dy, w, 1, 1)
+    lib.ha2g_gemm_set_mode(70)
+    e3, e32 = _rel(got, gref), _rel(exact, gref)
+    assert e3 < 3e-6 and e3 < 1.5 * e32 + 3e-7, (e3, e32)
+    base = torch.randn(C, C, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)
+    tgt = base.clone(memory_format=torch.channels_last)
+    assert we.conv_wgrad_planes(xp, dp, w, x.shape, into=tgt) is None
+    assert _rel(tgt.double() - base.double(), gref) < 5e-6

@@ -38,6 +38,14 @@ for mode in (70, 6, 0):
         g = timeit(lambda: we.conv_wgrad(x, dy, w, 1, 1))
         rows.append((mode, 'conv3x3 dgrad C=%d %dx%d' % (C, H, W), d, fl))
         rows.append((mode, 'conv3x3 wgrad C=%d %dx%d' % (C, H, W), g, fl))
+        if mode and C >= 64:                                      # the plane kernels on pre-split operands (what the train step runs on layers 2-4)
+            dyp, xp = ops.to_planes(dy), ops.to_planes(x)
+            rows.append((mode, 'conv3x3 dgrad C=%d %dx%d PLANES (producer-split)' % (C, H, W), timeit(lambda: we.conv_dgrad_planes(dyp, w, x.shape, 1, 1)), fl))
+            rows.append((mode, 'conv3x3 wgrad C=%d %dx%d PLANES (producer-split)' % (C, H, W), timeit(lambda: we.conv_wgrad_planes(xp, dyp, w, x.shape)), fl))
+            if mode == 70:
+                lib.ha2g_conv_planes_tile3(4)
+                rows.append((mode, 'conv3x3 dgrad C=%d %dx%d PLANES ping-pong kernel' % (C, H, W), timeit(lambda: we.conv_dgrad_planes(dyp, w, x.shape, 1, 1)), fl))
+                lib.ha2g_conv_planes_tile3(0)
     for (M, N, K, name) in ((4352, 900, 600, 'GRU layer 1-3'), (13056, 900, 600, 'GRU fused 3-chain rows (fwd shape)')):
         dgi = torch.randn(M, N, device=dev)
         xin = torch.randn(M, K, device=dev)
