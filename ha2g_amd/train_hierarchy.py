@@ -341,10 +341,21 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
                 ddp.exchange_sparse_(tb)
         works = [ddp.average_(o.flat_g, async_op=True) if hasattr(o, 'flat_g') else ddp.average_module_grads_([o])
                  for o in gen_optimizers]
-    pairs = [(o, c.grad) for o, c in zip(enc_outs, enc_cut) if c is not o and c.grad is not None]
-    if pairs:                                            # stage 2: audio + text encoders, overlapping the collectives above
-        torch.autograd.backward([p[0] for p in pairs], [p[1] for p in pairs])
-    _allreduce((audio_optimizer, text_optimizer))
+    # stage 2: the encoders, overlapping the collectives above.  The stand-alone text encoder goes FIRST (0.5 ms of kernels) so that its bucket
+    # -- 30 MB with a dense embedding table -- is in flight under the audio tower's ~20 ms backward instead of after it.
+    pairs = [(i, o, c.grad) for i, (o, c) in enumerate(zip(enc_outs, enc_cut)) if c is not o and c.grad is not None]
+    text_pairs = [(o, g) for i, o, g in pairs if i == 4]
+    audio_pairs = [(o, g) for i, o, g in pairs if i != 4]
+    if text_pairs:
+        torch.autograd.backward([p[0] for p in text_pairs], [p[1] for p in text_pairs])
+    if ddp.active():
+        for tb in getattr(text_optimizer, 'sparse_tables', ()):
+            ddp.exchange_sparse_(tb)
+        works.append(ddp.average_(text_optimizer.flat_g, async_op=True) if hasattr(text_optimizer, 'flat_g')
+                     else ddp.average_module_grads_([text_optimizer]))
+    if audio_pairs:
+        torch.autograd.backward([p[0] for p in audio_pairs], [p[1] for p in audio_pairs])
+    _allreduce((audio_optimizer,))
     for w in works:
         if w is not None:
             w.wait()

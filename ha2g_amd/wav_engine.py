@@ -53,6 +53,61 @@ def conv_fwd(x, w_ohwi, bias, stride, pad, act):
     return y
 
 
+FWD3 = __import__('os').environ.get('HA2G_FWD_PLANES', '1') != '0'      # forward convolutions of trunk layers 2-4 on three-piece planes
+
+
+def fwd_planes_ok(w_ohwi, stride, pad):
+    """this forward convolution runs on three-piece planes (csrc/conv_planes.hip, fp32-class: six bf16 MFMAs on all 24 mantissa bits) -- only in
+    the fp32-class default mode; modes 0 / 6 keep the fp32 MFMA forward of rounds 1-3"""
+    Cout, KH, KW, Cin = w_ohwi.shape
+    return FWD3 and lib.ha2g_gemm_bwd_pieces() == 3 and bool(lib.ha2g_conv2d_fwd_planes_supported(Cin, Cout, KH, KW, stride, pad))
+
+
+def conv_fwd_planes(xp, wpl, xshape, stride, pad, act):
+    """conv_fwd on the piece planes of x [3, N, H, W, Cin] and of the OHWI weight [3, Cout, KH, KW, Cin]; act: ACT_NONE / ACT_RELU; fp32 output."""
+    N, H, W, Cin = xshape
+    _, Cout, KH, KW, _ = wpl.shape
+    OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    y = torch.empty(N, OH, OW, Cout, dtype=torch.float32, device=xp.device)
+    ops.ktimer.launch('conv2d_fwd_planes', lambda: check(lib.ha2g_conv2d_fwd_planes_np_f32(
+        xp.data_ptr(), xp.stride(0), wpl.data_ptr(), wpl.stride(0), xp.shape[0], y.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad,
+        1 if act == ACT_RELU else 0, _stream())), 2.0 * N * OH * OW * Cout * KH * KW * Cin)
+    return y
+
+
+def prepare_fwd_weight_planes(P):
+    """three-piece planes [3, Cout, KH, KW, Cin] of the OHWI weight of every trunk convolution whose FORWARD runs on planes, in one launch
+    (ha2g_f32_to_planes_multi_np) -> {parameter name: planes}"""
+    import numpy as np
+    items = []
+    for li, nblk in enumerate(LAYERS):
+        for j in range(nblk):
+            b = 'layer%d.%d.' % (li + 1, j)
+            first = j == 0 and li > 0
+            cands = [(b + 'conv1.weight', 2 if first else 1, 1), (b + 'conv2.weight', 1, 1)] + ([(b + 'downsample.0.weight', 2, 0)] if first else [])
+            for name, stride, pad in cands:
+                wp = P[name].permute(0, 2, 3, 1)
+                if wp.is_contiguous() and fwd_planes_ok(wp, stride, pad):
+                    items.append((name, wp))
+    if not items:
+        return {}
+    dev = items[0][1].device
+    total = sum(w.numel() for _, w in items)
+    buf = torch.empty(3, total, dtype=torch.bfloat16, device=dev)
+    out, off = {}, 0
+    xp_, pp_, ps_, ne_ = (np.empty(len(items), np.int64) for _ in range(4))
+    for i, (name, w) in enumerate(items):
+        n = w.numel()
+        v = buf[:, off:off + n].view(3, *w.shape)
+        out[name] = v
+        xp_[i], pp_[i], ps_[i], ne_[i] = w.data_ptr(), v.data_ptr(), v.stride(0), n
+        off += n
+    for k0 in range(0, len(items), 48):
+        n = min(48, len(items) - k0)
+        check(lib.ha2g_f32_to_planes_multi_np(xp_[k0:].ctypes.data, pp_[k0:].ctypes.data, ps_[k0:].ctypes.data, ne_[k0:].ctypes.data, n, 3, _stream()))
+    return out
+
+
 def conv_dgrad(dy, w_ohwi, xshape, stride, pad, out=None, beta=0.0):
     N, H, W, Cin = xshape
     Cout, KH, KW, _ = w_ohwi.shape
@@ -228,10 +283,11 @@ def _bn_fwd(x, bn, pool=False, planes=False):
         y, pooled = ops.bn_apply_pool(x, mean, invstd, bn.gamma, bn.beta)
         return y, mean, invstd, pooled
     if planes:
+        npc = 3 if planes == 3 else 2
         y = torch.empty_like(x2)
-        pl = torch.empty((2,) + tuple(x2.shape), dtype=torch.bfloat16, device=x.device)      # the x operand of the (two-piece) plane weight gradient
+        pl = torch.empty((npc,) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)     # the x operand of the next convolution (forward / weight gradient)
         check(lib.ha2g_bn_apply_planes_np_f32(x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), bn.gamma.data_ptr(), bn.beta.data_ptr(), y.data_ptr(),
-                                              pl.data_ptr(), pl.stride(0), 2, x2.shape[0], x2.shape[1], ACT_NONE, _stream()))
+                                              pl.data_ptr(), pl.stride(0), npc, x2.shape[0], x2.shape[1], ACT_NONE, _stream()))
         return y.view(x.shape), mean, invstd, pl
     y = ops.bn_apply(x2, mean, invstd, bn.gamma, bn.beta).view(x.shape)
     return y, mean, invstd
@@ -413,19 +469,26 @@ class GradSink:
 
 # ---- one SEBasicBlock (ResNetBlocks.py:21-37,81-95): conv -> ReLU -> BN -> conv -> BN -> SE -> (+ residual) -> ReLU --------
 
-def block_fwd(x, P, b, first, xp=None, out_planes=False):
+def block_fwd(x, P, b, first, xp=None, out_planes=0, wpl=None):
     """x NHWC; P: name -> tensor / _BN with keys prefixed by `b`; first = stride-2 block with the 1x1 downsample branch.
-    xp = (hi, lo) planes of x when the previous block wrote them; out_planes: also write this block's output as planes (the next block's
-    conv1 takes them in its weight gradient).  Returns (out NHWC, saved tuple for block_bwd, planes of out or None)."""
+    xp = piece planes of x when its producer wrote them (3 pieces: this block's convolutions of x run on them -- forward AND weight gradient;
+    2 pieces: the round-3 opt-in, weight gradient only); out_planes = pieces to write this block's output with (0 = none); wpl = forward weight
+    planes (prepare_fwd_weight_planes).  Returns (out NHWC, saved tuple for block_bwd, planes of out or None)."""
     stride = 2 if first else 1
     wa, wb = _ohwi(P[b + 'conv1.weight']), _ohwi(P[b + 'conv2.weight'])
-    c1 = conv_fwd(x, wa, None, stride, 1, ACT_RELU)                     # relu(conv1)
+    wpl = wpl or {}
+    x3 = xp is not None and xp.shape[0] == 3
+    if x3 and (b + 'conv1.weight') in wpl:
+        c1 = conv_fwd_planes(xp, wpl[b + 'conv1.weight'], x.shape, stride, 1, ACT_RELU)
+    else:
+        c1 = conv_fwd(x, wa, None, stride, 1, ACT_RELU)                 # relu(conv1)
     a1p = None
-    if _FWD_PLANES[0] and wgrad_planes_ok(c1, wb, 1, 1):
-        a1, m1, s1, a1p = _bn_fwd(c1, P[b + 'bn1'], planes=True)
+    f2 = (b + 'conv2.weight') in wpl
+    if f2 or (_FWD_PLANES[0] and wgrad_planes_ok(c1, wb, 1, 1)):
+        a1, m1, s1, a1p = _bn_fwd(c1, P[b + 'bn1'], planes=3 if f2 else 2)
     else:
         a1, m1, s1 = _bn_fwd(c1, P[b + 'bn1'])
-    c2 = conv_fwd(a1, wb, None, 1, 1, ACT_NONE)
+    c2 = conv_fwd_planes(a1p, wpl[b + 'conv2.weight'], a1.shape, 1, 1, ACT_NONE) if f2 else conv_fwd(a1, wb, None, 1, 1, ACT_NONE)
     b2, m2, s2, pooled = _bn_fwd(c2, P[b + 'bn2'], pool=True)         # bn2 + SE squeeze in one pass
     N, OH, OW, C = b2.shape
     h1 = ops.gemm(pooled, P[b + 'se.fc.0.weight'], transb=True, bias=P[b + 'se.fc.0.bias'], act=ACT_RELU)
@@ -435,16 +498,19 @@ def block_fwd(x, P, b, first, xp=None, out_planes=False):
     su = None
     if first:
         wd = _ohwi(P[b + 'downsample.0.weight'])
-        cd = conv_fwd(x, wd, None, 2, 0, ACT_NONE)
+        if x3 and (b + 'downsample.0.weight') in wpl:
+            cd = conv_fwd_planes(xp, wpl[b + 'downsample.0.weight'], x.shape, 2, 0, ACT_NONE)
+        else:
+            cd = conv_fwd(x, wd, None, 2, 0, ACT_NONE)
         res, md, sd = _bn_fwd(cd, P[b + 'downsample.1'])
     else:
         res, cd, md, sd = x, None, None, None
     out = torch.empty_like(b2)
     outp = None
-    if out_planes and _FWD_PLANES[0] and wgrad_planes_ok(out, wb, 1, 1):
-        outp = torch.empty((2,) + tuple(out.shape), dtype=torch.bfloat16, device=out.device)
-        check(lib.ha2g_se_scale_add_relu_planes_np_f32(b2.data_ptr(), sc.data_ptr(), res.data_ptr(), out.data_ptr(), outp.data_ptr(), outp.stride(0), 2,
-                                                       N, OH * OW, C, _stream()))
+    if out_planes:
+        outp = torch.empty((out_planes,) + tuple(out.shape), dtype=torch.bfloat16, device=out.device)
+        check(lib.ha2g_se_scale_add_relu_planes_np_f32(b2.data_ptr(), sc.data_ptr(), res.data_ptr(), out.data_ptr(), outp.data_ptr(), outp.stride(0),
+                                                       out_planes, N, OH * OW, C, _stream()))
     else:
         check(lib.ha2g_se_scale_add_relu_f32(b2.data_ptr(), sc.data_ptr(), res.data_ptr(), out.data_ptr(), N, OH * OW, C, _stream()))
     return out, (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride, xp, a1p), outp
@@ -622,12 +688,20 @@ class WavEncoderFunction(torch.autograd.Function):
         S['stem'] = (spec, c0, m, s)
         feats = []
         _FWD_PLANES[0] = (PLANES & 6) == 6 and training and any(ctx.needs_input_grad)       # false under no_grad: nothing will read the planes
-        for li, nblk in enumerate(LAYERS):
-            xp = None
-            for j in range(nblk):
-                b = 'layer%d.%d.' % (li + 1, j)
-                x, S[b], xp = block_fwd(x, P, b, j == 0 and li > 0, xp=xp, out_planes=j + 1 < nblk)
-            feats.append(x)
+        wpl = prepare_fwd_weight_planes(P)                  # {} unless the forward of layers 2-4 runs on three-piece planes (fp32-class default mode)
+        blocks = [('layer%d.%d.' % (li + 1, j), li, j) for li, nblk in enumerate(LAYERS) for j in range(nblk)]
+        xp = None
+        for bi, (b, li, j) in enumerate(blocks):
+            # pieces the block's output is written with: 3 when the NEXT block's convolutions of it run on planes, else the round-3 opt-in (2)
+            nxt = blocks[bi + 1][0] if bi + 1 < len(blocks) else None
+            want = 0
+            if nxt is not None and (nxt + 'conv1.weight') in wpl:
+                want = 3
+            elif nxt is not None and blocks[bi + 1][1] == li and _FWD_PLANES[0] and wgrad_planes_ok(x, _ohwi(P[b + 'conv2.weight']), 1, 1):
+                want = 2
+            x, S[b], xp = block_fwd(x, P, b, j == 0 and li > 0, xp=xp, out_planes=want, wpl=wpl)
+            if j + 1 == LAYERS[li]:
+                feats.append(x)
         _FWD_PLANES[0] = False
         return WavEncoderFunction._finish_forward(ctx, feats, S, P, vid, L, names, flat_index, tensors)
 

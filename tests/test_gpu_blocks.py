@@ -28,12 +28,21 @@ def gemm_mode():
 
 
 def run_block(ck, name, geom, B, seed):
-    from ha2g_amd import wav_engine as we
+    from ha2g_amd import ops, wav_engine as we
     P = engine_P(block_state(name, geom, seed), DEV)
     x, wl = block_io(name, geom, B, seed)
     we._TRAINING[0] = True
     we._NBT_PENDING.clear()
-    out, saved, _ = we.block_fwd(nhwc(x.to(DEV)), P, '', geom[4])
+    xin = nhwc(x.to(DEV))
+    # as the tower runs the block in the current mode: in the fp32-class default the convolutions of channels >= 64 take their input and weights as
+    # producer-written three-piece planes (forward AND weight gradient); modes 0 / 6 keep the fp32 MFMA forward
+    wpl, xp = {}, None
+    for n, stride, pad in (('conv1.weight', 2 if geom[4] else 1, 1), ('conv2.weight', 1, 1), ('downsample.0.weight', 2, 0)):
+        if n in P and we.fwd_planes_ok(we._ohwi(P[n]), stride, pad):
+            wpl[n] = ops.to_planes(we._ohwi(P[n]).contiguous(), 3)
+    if 'conv1.weight' in wpl:
+        xp = ops.to_planes(xin, 3)
+    out, saved, _ = we.block_fwd(xin, P, '', geom[4], xp=xp, wpl=wpl)
     sink = we.GradSink(P)
     dx = we.block_bwd(nhwc(wl.to(DEV)), saved, P, '', sink)
     sink.join(torch.device(DEV))                              # the convolution weight gradients run on the side stream

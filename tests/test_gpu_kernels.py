@@ -478,7 +478,15 @@ def test_dense_tile_shape_does_not_change_bits(shape):
     try:
         lib.ha2g_gemm_debug_tile(-2, 0)                                    # round 1's tile rule
         ref = ops.gemm(a, b, transa=ta, transb=tb).clone()
+        # three-piece mode, data-gradient shape (n-contiguous B): the [m][k] planes of tiles 0 / 5 / 6 exceed the 64 KB of static LDS and those tiles
+        # run the exact fp32 MFMA instead (dispatch_tile never picks them there) -- a different arithmetic by design, not a tile effect
+        skip = (0, 5, 6) if (lib.ha2g_gemm_bwd_pieces() == 3 and not ta and not tb) else ()
+        if 0 in skip:
+            lib.ha2g_gemm_debug_tile(2, 0)
+            ref = ops.gemm(a, b, transa=ta, transb=tb).clone()
         for cfg in [-1] + list(range(9)):
+            if cfg in skip:
+                continue
             lib.ha2g_gemm_debug_tile(cfg, 0)
             assert torch.equal(ops.gemm(a, b, transa=ta, transb=tb), ref), cfg
     finally:

@@ -172,3 +172,29 @@ def test_wgrad_three_piece_planes_are_fp32_class(B, H, W, C):
     tgt = base.clone(memory_format=torch.channels_last)
     assert we.conv_wgrad_planes(xp, dp, w, x.shape, into=tgt) is None
     assert _rel(tgt.double() - base.double(), gref) < 5e-6
+
+
+@pytest.mark.parametrize('tile', [0, 1, 3, 4])
+@pytest.mark.parametrize('B,H,W,Cin,Cout,k,stride,relu', [(4, 64, 35, 64, 64, 3, 1, True), (3, 32, 18, 128, 128, 3, 1, False), (5, 16, 9, 256, 256, 3, 1, True),
+                                                          (4, 128, 70, 32, 64, 3, 2, True), (3, 64, 35, 64, 128, 3, 2, True), (2, 32, 18, 128, 256, 3, 2, False),
+                                                          (4, 128, 70, 32, 64, 1, 2, False), (3, 64, 35, 64, 128, 1, 2, False), (1, 7, 5, 64, 64, 3, 1, False),
+                                                          (128, 32, 18, 128, 128, 3, 1, True)])
+def test_forward_convolution_on_three_piece_planes_is_fp32_class(B, H, W, Cin, Cout, k, stride, relu, tile):
+    """The forward convolutions of trunk layers 2-4 (nn.Conv2d of SEBasicBlock, ResNetBlocks.py:24-29; the stride-2 3x3 and 1x1 downsample of a
+    layer's first block) on producer-written three-piece planes: against float64 at the accuracy of the fp32 MFMA implicit GEMM."""
+    torch.manual_seed(8)
+    pad = 1 if k == 3 else 0
+    x = torch.randn(B, H, W, Cin, device=DEV)
+    w = torch.randn(Cout, k, k, Cin, device=DEV) * 0.05
+    assert we.fwd_planes_ok(w, stride, pad)
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    if relu:
+        ref = torch.relu(ref)
+    lib.ha2g_conv_planes_tile3(tile)
+    try:
+        got = we.conv_fwd_planes(ops.to_planes(x, 3), ops.to_planes(w, 3), x.shape, stride, pad, ops.ACT_RELU if relu else ops.ACT_NONE)
+    finally:
+        lib.ha2g_conv_planes_tile3(0)
+    exact = we.conv_fwd(x, w, None, stride, pad, ops.ACT_RELU if relu else ops.ACT_NONE)
+    e3, e32 = _rel(got, ref), _rel(exact, ref)
+    assert got.shape == exact.shape and e3 < 3e-6 and e3 < 1.5 * e32 + 2e-7, (e3, e32)

@@ -507,3 +507,74 @@ def test_flagged_cluster_step_leaves_the_optimizer_state_untouched_and_is_retrie
 def lib_cluster_ok():
     from ha2g_amd._lib import lib
     return bool(lib.ha2g_gru_cluster_supported(300))
+
+
+class _SparseGradTap:
+    """The row-wise embedding path hands compact (ids, count, rows) gradients to the optimizer and never materialises a dense .grad: for the
+    fixture comparison the tap densifies them right before SparseTable.step() consumes them (same values, scattered into a zero table)."""
+
+    def __init__(self):
+        from ha2g_amd import ops
+        self.ops, self.dense = ops, {}
+
+    def __enter__(self):
+        orig, dense = self.ops.SparseTable.step, self.dense
+
+        def step(tb):
+            if tb.pending:
+                ids, count, vals = tb.merged()
+                n = int(count.item())
+                d = torch.zeros_like(tb.weight)
+                d.index_add_(0, ids[:n], vals[:n])
+                dense[id(tb.weight)] = d
+                tb.pending = [(ids, count, vals)]
+            return orig(tb)
+        self._orig = orig
+        self.ops.SparseTable.step = step
+        return self
+
+    def __exit__(self, *a):
+        self.ops.SparseTable.step = self._orig
+
+
+@pytest.mark.parametrize('name', ['cfg1', 'cfg2_b128'])
+def test_train_step_with_row_wise_embedding_tables_vs_reference(golden, name):
+    """SURVEY 8 f2 pinned to the ORACLE: the same reference-generated step fixtures as test_train_step /
+    test_train_step_headline_size_vs_reference, with the four word-embedding tables (model/hierarchy_net.py:31-34) on the compact-gradient +
+    lazy row-wise Adam path (csrc/sparse.hip) -- loss dict, every gradient (the compact ones densified by the tap), the Adam-updated
+    parameters after sync_sparse(), BatchNorm statistics, two consecutive steps."""
+    import os
+    from ha2g_amd.config import BIG_CASES
+    from tests.conftest import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, name + '.npz')):
+        pytest.skip('fixture %s.npz not generated' % name)
+    case, g = (CASES[name] if name in CASES else BIG_CASES[name]), golden(name)
+    ck = Checker(g)
+    args, gens, dis, aud, txt = build_modules(case, DEV)
+    text, spec, target, vid = (t.to(DEV) for t in batch_for(case))
+    lr = float(args.learning_rate)
+    g_opts = [FusedAdam(m.parameters(), lr=lr, sparse=[m.text_encoder.embedding.weight]) for m in gens]
+    dis_opt = FusedAdam(dis.parameters(), lr=lr * args.discriminator_lr_weight)
+    aud_opt, txt_opt = FusedAdam(aud.parameters(), lr=lr), FusedAdam(txt.parameters(), lr=lr, sparse=[txt.embedding.weight])
+    assert all(len(o.sparse_tables) == 1 for o in g_opts + [txt_opt])
+    EpsInjector(gens, case['seed'], case['B'])
+    perm = torch.from_numpy(proc.fixed_perm(case['B'], case['seed'])).to(DEV)
+    mods = dict(g1=gens[0], g2=gens[1], g3=gens[2], dis=dis, audio=aud, text=txt)
+    tables = {'g%d.text_encoder.embedding.weight' % (i + 1): m.text_encoder.embedding.weight for i, m in enumerate(gens)}
+    tables['text.embedding.weight'] = txt.embedding.weight
+    old = th.randperm_source
+    th.randperm_source = lambda n, device: perm
+    try:
+        with _SparseGradTap() as tap:
+            for si, epoch in enumerate((0, 11)):
+                ret = th.train_iter_hierarchy(args, epoch, text, spec, target, vid, *gens, dis, aud, txt, *g_opts, dis_opt, aud_opt, txt_opt)
+                for o in g_opts + [txt_opt]:
+                    o.sync_sparse()                       # rows the step did not touch catch up with the dense Adam before they are compared
+                sd, grads = named_state(mods)
+                for k, w in tables.items():
+                    grads[k] = tap.dense[id(w)]
+                if epoch == 0:
+                    grads = {k: v for k, v in grads.items() if not k.startswith('dis.')}
+                ck.step(si, ret, grads, sd)
+    finally:
+        th.randperm_source = old
