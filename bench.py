@@ -126,6 +126,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='same as --launch graph')
     ap.add_argument('--no-roofline', action='store_true', help='with --primary-only: skip the per-launch HIP-event pass as well (profiling runs)')
     ap.add_argument('--sparse-embeddings', action='store_true', help='compact row gradients + lazy row-wise Adam for the word-embedding tables (bit-identical to the dense default; -45 %% gradient-exchange bytes under data parallelism, +0.4 ms of small kernels on one GPU)')
+    ap.add_argument('--dense-embeddings', action='store_true', help='data parallel: keep the dense word-embedding gradient all-reduce (the default under N > 1 is the row-wise exchange)')
     ap.add_argument('--dry-run', action='store_true', help='only exercise the rank launch: every rank prints its RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* and exits (no GPU)')
     ap.add_argument('--primary-only', action='store_true', help='skip the secondary timings (warm-up phase, exact-fp32 mode): for profiling')
     a = ap.parse_args()
@@ -180,7 +181,7 @@ def main():
     args = hierarchy_args(expressive=a.expressive)            # config[_expressive]/hierarchy.yml, dropout 0.3
     tr = HierarchyTrainer(args, Vocab(a.n_words), Vocab(a.n_spk), P, dev,
                           pose_dims=schema.EXPRESSIVE_POSE_DIMS if a.expressive else schema.GESTURE_POSE_DIMS,
-                          sparse_embeddings=a.sparse_embeddings)
+                          sparse_embeddings=True if a.sparse_embeddings else (False if a.dense_embeddings else None))
     if world > 1:
         tr.broadcast_parameters(0)
     ops.rng.seed(dev, 1234 + rank)
@@ -402,7 +403,7 @@ def main():
                                             'config_expressive/hierarchy.yml TED-Expressive' if a.expressive else 'config/hierarchy.yml TED-Gesture', a.batch, P, a.n_words, a.n_spk, 'GAN phase (epoch %d > loss_warmup)' % a.epoch
                                             if a.epoch > args.loss_warmup else 'warm-up phase (epoch %d)' % a.epoch),
                                global_batch=a.batch * world, parallelism='dp%d' % world,
-                               word_embedding_updates='row-wise (compact gradients, lazy Adam; bit-identical to dense)' if a.sparse_embeddings else 'dense'),
+                               word_embedding_updates='row-wise (compact gradients, lazy Adam; bit-identical to dense)' if tr.sparse_embeddings else 'dense'),
                    gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, roofline_bwd=roof_bwd, roofline_gemm=roof_gemm, roofline_conv=roof_conv, roofline_bwd_gemm=roof_bwd_gemm, roofline_bwd_wgrad=roof_bwd_wgrad, roofline_bn=roof_bn, roofline_bn_stats=roof_bn_stats, roofline_pass='separate untimed pass of %d eager steps, HIP events around each launch on its launch stream' % k_roof, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
         if world == 1 and not a.no_cpu_baseline and not a.expressive:
             out['cpu_baseline'] = cpu_baseline(a.epoch, a.n_words, a.n_spk)

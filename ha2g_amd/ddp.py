@@ -119,16 +119,48 @@ def rank_seed(base, rank=None):
     return base + rank
 
 
-def gather_sparse_rows(ids, count, rows, group=None):
+class _CountHandle:
+    """max over ranks of a device-side row count, on its way to the host (prefetch_max_count)"""
+
+    def __init__(self, host, event):
+        self.host, self.event = host, event
+
+    def value(self):
+        if self.event is not None:
+            self.event.synchronize()                       # fired during the forward: no stall in practice
+        return max(int(self.host.max().item()), 1)
+
+
+def prefetch_max_count(count, group=None):
+    """Enqueue (do not wait for) the all-gather of one int32 device count over the ranks and the copy of the result to pinned host memory."""
+    ws = dist.get_world_size(group)
+    cnt = count.to(torch.int64).reshape(1)
+    if _host_staged(cnt, group) or not cnt.is_cuda:
+        counts = [torch.empty(1, dtype=torch.int64) for _ in range(ws)]
+        dist.all_gather(counts, cnt.cpu(), group=group)
+        return _CountHandle(torch.stack(counts).reshape(-1), None)
+    out = torch.empty(ws, dtype=torch.int64, device=cnt.device)
+    dist.all_gather_into_tensor(out, cnt, group=group)       # stream-ordered on the compute stream (RCCL): no host wait
+    host = torch.empty(ws, dtype=torch.int64, pin_memory=True)
+    host.copy_(out, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return _CountHandle(host, ev)
+
+
+def gather_sparse_rows(ids, count, rows, group=None, max_count=None):
     """All-gather of compact row gradients: every rank contributes (ids [cap], device count, rows [cap, C]) of which the first
     `count` entries are valid.  Only max-over-ranks(count) rows travel (one tiny count all-gather + host read decides the size);
     entries past a rank's count come back as id 0 with a zero row, rows are pre-scaled by 1/world (mean).  -> (ids [W*mx], rows [W*mx, C]).
     Device-agnostic (RCCL on the GPUs, gloo in the CPU tests)."""
     ws = dist.get_world_size(group)
     cnt = count.to(torch.int64).reshape(1)
-    counts = [torch.empty_like(cnt) for _ in range(ws)]
-    all_gather_(counts, cnt, group)
-    mx = max(int(torch.stack(counts).max().item()), 1)       # never an empty collective
+    if max_count is not None:                              # prefetched at forward time (ops.SparseTable.prefetch_count): no host stall here
+        mx = max_count.value()
+    else:
+        counts = [torch.empty_like(cnt) for _ in range(ws)]
+        all_gather_(counts, cnt, group)
+        mx = max(int(torch.stack(counts).max().item()), 1)   # never an empty collective
     if ids.shape[0] < mx:                                  # a rank whose own list is shorter than the longest one (e.g. nothing pending)
         ids = torch.cat([ids, ids.new_zeros(mx - ids.shape[0])])
         rows = torch.cat([rows, rows.new_zeros(mx - rows.shape[0], rows.shape[1])])
@@ -150,14 +182,18 @@ def exchange_sparse_(table, group=None):
     from . import ops
     # EVERY rank takes part in the three all-gathers, whatever its local state: a rank with nothing pending (a skipped backward, a
     # non-finite-loss skip on that rank only) contributes count 0 -- an early return here would leave the other ranks' collectives hanging
+    hint = None
     if table.pending:
+        if len(table.pending) == 1 and table.count_hint is not None and table.count_hint[0] is table.pending[0][1]:
+            hint = table.count_hint[1]                     # the one pending gradient is the prefetched forward's: its max count is on the host already
         ids, count, rows = table.merged()
     else:
         w = table.weight
         ids = torch.zeros(1, dtype=torch.int64, device=w.device)
         count = torch.zeros(1, dtype=torch.int32, device=w.device)
         rows = torch.zeros(1, w.shape[1], dtype=torch.float32, device=w.device)
-    ids_all, rows_all = gather_sparse_rows(ids, count, rows, group)
+    ids_all, rows_all = gather_sparse_rows(ids, count, rows, group, max_count=hint)
+    table.count_hint = None
     table.pending = [ops.merge_rows(ids_all, rows_all, table.map)] if ids_all.numel() else []
 
 

@@ -383,6 +383,8 @@ class EmbeddingFunction(torch.autograd.Function):
             check(lib.ha2g_unique_tokens(tok.data_ptr(), n, st.map.data_ptr(), cpos.data_ptr(), uniq.data_ptr(), remap.data_ptr(), count.data_ptr(), _stream()))
             st.catch_up(uniq, count, n + 1)
             ctx.compact = (uniq, remap, count)
+            if torch.is_grad_enabled() and w.requires_grad:
+                st.prefetch_count(count)                   # data parallel: the row count leaves for the host NOW, the exchange after the backward needs it
         check(lib.ha2g_embedding_fwd_f32(tok.data_ptr(), w.data_ptr(), out.data_ptr(), tok.numel(), w.shape[1], _stream()))
         ctx.save_for_backward(tok)
         ctx.wshape = w.shape
@@ -1315,6 +1317,7 @@ class SparseTable:
         self.last = torch.zeros(V, dtype=torch.int32, device=dev)                    # optimizer step each row is up to date with
         self.map = torch.full((V,), 2 ** 31 - 1, dtype=torch.int32, device=dev)      # scratch of ha2g_unique_tokens
         self.pending = []
+        self.count_hint = None          # (device count tensor, prefetched max-over-ranks handle) of the forward whose backward is pending
 
     def _run(self, ids, count, max_rows, vals):
         g = self.opt.param_groups[0]
@@ -1327,6 +1330,16 @@ class SparseTable:
 
     def catch_up(self, ids, count, max_rows):
         self._run(ids, count, max_rows, None)
+
+    def prefetch_count(self, count):
+        """Data parallel only.  The row exchange after the backward (ddp.gather_sparse_rows) sizes its all-gathers by the MAX over ranks of the
+        number of distinct rows -- a host-side number.  The count depends on the token batch alone, so it is known at FORWARD time: the count
+        all-gather and its device -> host copy are enqueued here, a whole forward + backward ahead of their use, and the exchange then reads a
+        pinned word whose event fired long ago instead of stalling the launch queue on `.item()` (one stall per table and step before)."""
+        from . import ddp
+        self.count_hint = None
+        if ddp.active():
+            self.count_hint = (count, ddp.prefetch_max_count(count))
 
     def merged(self):
         """This step's compact gradient as ONE (ids, count, rows) list with distinct ids (several backward passes / ranks are merged

@@ -29,11 +29,16 @@ def init_model(args, lang_model, speaker_model, pose_dim, _device=None, pose_lev
 class HierarchyTrainer:
     """Everything train_epochs() builds before its batch loop (reference scripts/train.py:114-170)."""
 
-    def __init__(self, args, lang_model, speaker_model, pose_dim, device, pose_dims=(15, 21, 27), sparse_embeddings=False):
+    def __init__(self, args, lang_model, speaker_model, pose_dim, device, pose_dims=(15, 21, 27), sparse_embeddings=None):
         """sparse_embeddings: update the word-embedding tables row-wise from compact gradients (bit-identical to the dense update,
-        see ha2g_amd.optim.FusedAdam); call sync_sparse() before reading those tables outside the step (checkpoints)."""
+        see ha2g_amd.optim.FusedAdam); call sync_sparse() before reading those tables outside the step (checkpoints).  None (default) = row-wise
+        under data parallelism -- the four n_words x 300 tables are 45 % of the gradient bytes and almost all zeros, only the touched rows travel
+        (ddp.exchange_sparse_) -- dense on a single GPU, where the compaction launches cost more than the Adam traffic they save."""
+        from . import ddp
         self.args, self.device = args, device
-        self.sparse_embeddings = sparse_embeddings
+        if sparse_embeddings is None:
+            sparse_embeddings = ddp.active()
+        self.sparse_embeddings = bool(sparse_embeddings)
         self.expressive = len(pose_dims) == 6        # scripts/train_expressive.py:160-168: six generators 24/30/36/66/96/126
         _, self.discriminator, self.audio_encoder, self.text_encoder, _ = init_model(args, lang_model, speaker_model, pose_dim, device,
                                                                                      pose_level=len(pose_dims))

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
 import os, sys, torch, torch.distributed as dist
-sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r); sys.path.insert(1, %(root)r + '/tests')
 rank = int(os.environ['RANK'])
 torch.cuda.set_device(0)
 dev = torch.device('cuda', 0)
@@ -141,7 +141,7 @@ def test_two_rank_step_on_one_gpu():
 
 SOAK = r'''
 import sys, torch
-sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r); sys.path.insert(1, %(root)r + '/tests')
 dev = torch.device('cuda', 0)
 from ha2g_amd import ops
 from ha2g_amd._lib import lib, check

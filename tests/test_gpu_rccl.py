@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CHILD = r'''
 import os, sys, torch, torch.distributed as dist
-sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r); sys.path.insert(1, %(root)r + '/tests')
 torch.cuda.set_device(0)
 dev = torch.device('cuda', 0)
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
@@ -40,7 +40,7 @@ print('RCCL_OK')
 
 CHILD_FORCED = r'''
 import os, sys, torch, torch.distributed as dist
-sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r); sys.path.insert(1, %(root)r + '/tests')
 torch.cuda.set_device(0)
 dev = torch.device('cuda', 0)
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
@@ -79,10 +79,11 @@ def run(forced):
 r_plain, p_plain = run(False)
 assert not calls, calls
 r_ddp, p_ddp = run(True)
-# the in-step collective branch ran: per step 3 async all-reduces (generators, overlapping the encoders' backward) + audio +
-# text, and one for the discriminator in each GAN-phase step
+# the in-step collective branch ran: per step 4 async all-reduces (the three generators after backward stage 1, the stand-alone text encoder
+# after its own backward -- all in flight under the audio tower's backward) + the audio encoder's, and one for the discriminator in each
+# GAN-phase step
 assert len(calls) == 3 * 5 + 2, calls
-assert sum(1 for _, a in calls if a) == 9, calls
+assert sum(1 for _, a in calls if a) == 12, calls
 assert r_plain == r_ddp, (r_plain, r_ddp)
 assert torch.equal(p_plain, p_ddp)                 # a world of one: averaging is the identity, bit for bit
 dist.destroy_process_group()

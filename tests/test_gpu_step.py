@@ -19,7 +19,9 @@ DEV = 'cuda:0'
 @pytest.mark.parametrize('name', ['small', 'cfg1'])
 def test_train_step(golden, name, fuse):
     case, g = CASES[name], golden(name)
-    ck = Checker(g)
+    # cfg1 (B = 4, chaotic BatchNorm'ed tower): the audio gradients' floor is the reference's own scatter over the 200-run tail study (round 3),
+    # not the maximum over the fixture's 25 runs, which misses the heavy tail (test_gpu_tail.py)
+    ck = Checker(g, tail=golden('cfg1_tail') if name == 'cfg1' else None)
     args, gens, dis, aud, txt = build_modules(case, DEV)
     text, spec, target, vid = (t.to(DEV) for t in batch_for(case))
     lr = float(args.learning_rate)
@@ -452,6 +454,7 @@ def test_flagged_cluster_step_leaves_the_optimizer_state_untouched_and_is_retrie
         return [b.clone() for b in tr._bn_buffers()]
     try:
         assert ops.USE_GRU_CLUSTER and lib_cluster_ok()
+        binit = bufs()
         a = tr.train_iter(11, text, spec, target, vid)
         tr.sync()
         word = ops.gru_cluster_error_tensor(dev)
@@ -479,9 +482,9 @@ def test_flagged_cluster_step_leaves_the_optimizer_state_untouched_and_is_retrie
         assert [int(o.step_t.item()) for o in opts] == [n + 1 for n in steps0]
         s1 = state()
         assert not torch.equal(s0[0], s1[0])                     # the retried step DID update
-        for x, y in zip(b0, bufs()):                             # one forward's worth of running-statistics updates, not two
-            if x.dtype == torch.int64:
-                assert int(y) == int(x) + 1
+        for x0, x, y in zip(binit, b0, bufs()):                  # ONE step's worth of running-statistics updates, not two (the discriminator's
+            if x.dtype == torch.int64:                           # BatchNorms see three forwards per GAN-phase step, the tower's one)
+                assert int(y) - int(x) == int(x) - int(x0)
         # ---- (3) a BPTT time-out surfaces at the start of the NEXT call: that step was skipped on the device, the next batch runs ----
         ops.USE_GRU_CLUSTER = True
         c = tr.train_iter(11, text, spec, target, vid)
@@ -549,7 +552,7 @@ def test_train_step_with_row_wise_embedding_tables_vs_reference(golden, name):
     if not os.path.exists(os.path.join(GOLDEN, name + '.npz')):
         pytest.skip('fixture %s.npz not generated' % name)
     case, g = (CASES[name] if name in CASES else BIG_CASES[name]), golden(name)
-    ck = Checker(g)
+    ck = Checker(g, tail=golden('cfg1_tail') if name == 'cfg1' else None)
     args, gens, dis, aud, txt = build_modules(case, DEV)
     text, spec, target, vid = (t.to(DEV) for t in batch_for(case))
     lr = float(args.learning_rate)
