@@ -353,8 +353,15 @@ def main():
             nprod = 6 if bwd_pieces == 3 else 3                    # bf16 MFMAs per fp32-equivalent product
             return dict(kernel=kernel, bound='mfma', achieved=round(ach, 2), peak=round(2500.0 / nprod, 1), unit='TFLOP/s (fp32-equivalent: %d bf16 MFMAs per product)' % nprod,
                         frac=round(ach / (2500.0 / nprod), 4), launches=n, mean_us=round(mean_us, 1), traffic=None)
-        roof_bwd_gemm = mfma3('conv_dgrad_planes', 'pconv_dgrad_kernel (ha2g_conv2d_dgrad_planes_f32: 3x3 data gradients of trunk layers 2-4, DMA-staged bf16 planes)')
-        roof_bwd_wgrad = mfma3('conv_wgrad_planes', 'pconv_wgrad_kernel + wide reduce (ha2g_conv2d_wgrad_planes_f32: 3x3 weight gradients of trunk layers 2-4)')
+        roof_conv_fp32 = roof_conv                      # what still runs on the fp32 MFMA: the stem-side 32-channel layer (direct kernel) and the taps
+        if 'conv2d_fwd_planes' in kt:                   # forward convolutions of trunk layers 2-4: three-piece planes (always six MFMAs per product)
+            n, mean_us, _, flops = kt['conv2d_fwd_planes']
+            ach = flops / (n * mean_us * 1e-6) / 1e12
+            roof_conv = dict(kernel='pconv_pp_kernel / pconv_kernel<.., NP = 3> forward gather (ha2g_conv2d_fwd_planes_np_f32: forward convolutions of SE-ResNet34 layers 2-4 on producer-written three-piece planes)',
+                             bound='mfma', achieved=round(ach, 2), peak=round(2500.0 / 6, 1), unit='TFLOP/s (fp32-equivalent: 6 bf16 MFMAs per product)',
+                             frac=round(ach / (2500.0 / 6), 4), frac_of_fp32_mfma_peak=round(ach / 157.3, 4), launches=n, mean_us=round(mean_us, 1), traffic=None)
+        roof_bwd_gemm = mfma3('conv_dgrad_planes', 'pconv_pp_kernel / pconv_kernel (ha2g_conv2d_dgrad_planes_np_f32: 3x3 data gradients of trunk layers 2-4, DMA-staged bf16 piece planes)')
+        roof_bwd_wgrad = mfma3('conv_wgrad_planes', 'pconv_wgrad_kernel + wide reduce (ha2g_conv2d_wgrad_planes_np_f32: 3x3 weight gradients of trunk layers 2-4)')
 
         def hbm(key, kernel):
             if key not in kt:
@@ -404,7 +411,7 @@ def main():
                                             if a.epoch > args.loss_warmup else 'warm-up phase (epoch %d)' % a.epoch),
                                global_batch=a.batch * world, parallelism='dp%d' % world,
                                word_embedding_updates='row-wise (compact gradients, lazy Adam; bit-identical to dense)' if tr.sparse_embeddings else 'dense'),
-                   gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, roofline_bwd=roof_bwd, roofline_gemm=roof_gemm, roofline_conv=roof_conv, roofline_bwd_gemm=roof_bwd_gemm, roofline_bwd_wgrad=roof_bwd_wgrad, roofline_bn=roof_bn, roofline_bn_stats=roof_bn_stats, roofline_pass='separate untimed pass of %d eager steps, HIP events around each launch on its launch stream' % k_roof, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
+                   gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, roofline_bwd=roof_bwd, roofline_gemm=roof_gemm, roofline_conv=roof_conv, roofline_conv_fp32=roof_conv_fp32, roofline_bwd_gemm=roof_bwd_gemm, roofline_bwd_wgrad=roof_bwd_wgrad, roofline_bn=roof_bn, roofline_bn_stats=roof_bn_stats, roofline_pass='separate untimed pass of %d eager steps, HIP events around each launch on its launch stream' % k_roof, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
         if world == 1 and not a.no_cpu_baseline and not a.expressive:
             out['cpu_baseline'] = cpu_baseline(a.epoch, a.n_words, a.n_spk)
         def _clean(o):                                   # NaN (a leg that was not run) is not JSON: null instead

@@ -226,7 +226,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
             r.v[k] = (v.v[k] - mu.v[k]) * is.v[k] * g.v[k] + b.v[k];
             if (act == 2) r.v[k] = r.v[k] > 0.f ? r.v[k] : 0.01f * r.v[k];
         }
-        stv(y, i, r);
+        if (!PL || y != nullptr) stv(y, i, r);             // planes only (y == NULL): every consumer of y reads the piece planes
         if (PL) st_planes(y_hi, y_lo, pnp, i, r);
     }
 }

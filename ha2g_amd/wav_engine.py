@@ -269,7 +269,7 @@ _NBT_PENDING = []
 _FWD_PLANES = [False]      # this forward will be back-propagated through the plane-based weight gradients: producers also write bf16 planes
 
 
-def _bn_fwd(x, bn, pool=False, planes=False):
+def _bn_fwd(x, bn, pool=False, planes=False, planes_only=False):
     """BatchNorm forward; pool=True also returns the per-image channel means of the output (the SE squeeze), fused; planes=True appends the
     (hi, lo) bf16 planes of the output (written by the same apply pass)."""
     x2 = _rows(x)
@@ -284,11 +284,11 @@ def _bn_fwd(x, bn, pool=False, planes=False):
         return y, mean, invstd, pooled
     if planes:
         npc = 3 if planes == 3 else 2
-        y = torch.empty_like(x2)
+        y = torch.empty_like(x2) if not planes_only else None
         pl = torch.empty((npc,) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)     # the x operand of the next convolution (forward / weight gradient)
-        check(lib.ha2g_bn_apply_planes_np_f32(x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), bn.gamma.data_ptr(), bn.beta.data_ptr(), y.data_ptr(),
+        check(lib.ha2g_bn_apply_planes_np_f32(x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), bn.gamma.data_ptr(), bn.beta.data_ptr(), _p(y),
                                               pl.data_ptr(), pl.stride(0), npc, x2.shape[0], x2.shape[1], ACT_NONE, _stream()))
-        return y.view(x.shape), mean, invstd, pl
+        return (y.view(x.shape) if y is not None else None), mean, invstd, pl
     y = ops.bn_apply(x2, mean, invstd, bn.gamma, bn.beta).view(x.shape)
     return y, mean, invstd
 
@@ -435,6 +435,7 @@ class GradSink:
             self.G[name] = r
 
     def _gconv(self, name, xin, dyc, w_ohwi, stride, pad):
+        assert xin.dtype == torch.float32, 'GradSink._gconv: the fp32 activation was not materialised (planes-only producer) but a non-plane weight gradient needs it'
         # the convolution weight gradients only feed the optimizer: on the side stream they overlap the data-gradient chain -- MFMA work
         # beside the bandwidth-bound BatchNorm / SE passes of the main stream.  The operands are handed to the side stream's allocator
         # bookkeeping (record_stream) because the caller drops them before the join at the end of the tower's backward.
@@ -485,7 +486,12 @@ def block_fwd(x, P, b, first, xp=None, out_planes=0, wpl=None):
     a1p = None
     f2 = (b + 'conv2.weight') in wpl
     if f2 or (_FWD_PLANES[0] and wgrad_planes_ok(c1, wb, 1, 1)):
-        a1, m1, s1, a1p = _bn_fwd(c1, P[b + 'bn1'], planes=3 if f2 else 2)
+        # planes only: when conv2's forward, data gradient and weight gradient all read the three piece planes (which hold bn1's output exactly),
+        # the fp32 tensor has no reader left -- the backward of bn1 needs its INPUT c1.  a1 is then a placeholder carrying shape and device.
+        only = f2 and torch.is_grad_enabled() and dgrad_planes_ok(wb, 1, 1) and wgrad_planes_ok(c1, wb, 1, 1)
+        a1, m1, s1, a1p = _bn_fwd(c1, P[b + 'bn1'], planes=3 if f2 else 2, planes_only=only or (f2 and not torch.is_grad_enabled()))
+        if a1 is None:
+            a1 = a1p[0]                                            # bf16 piece 0: NOT the activation -- _gconv() refuses non-fp32 operands
     else:
         a1, m1, s1 = _bn_fwd(c1, P[b + 'bn1'])
     c2 = conv_fwd_planes(a1p, wpl[b + 'conv2.weight'], a1.shape, 1, 1, ACT_NONE) if f2 else conv_fwd(a1, wb, None, 1, 1, ACT_NONE)

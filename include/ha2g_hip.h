@@ -263,7 +263,8 @@ int ha2g_bn_apply_planes_f32(const float* x, const float* mean, const float* inv
                              void* y_lo, long rows, int C, int act, void* stream);
 int ha2g_se_scale_add_relu_planes_f32(const float* x, const float* s, const float* res, float* out, void* o_hi, void* o_lo, int N, int HW, int C,
                                       void* stream);
-/* ABI 2: the three producers above writing np = 2 or 3 equally spaced piece planes (piece q at planes + q * ps elements) */
+/* ABI 2: the three producers above writing np = 2 or 3 equally spaced piece planes (piece q at planes + q * ps elements); bn_apply: y may be NULL
+ * (planes only: three pieces reproduce the fp32 value exactly, and the next convolution reads nothing else) */
 int ha2g_bn_bwd_planes_np_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx, void* planes,
                               long ps, int np, float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta,
                               float* ws, void* stream);

@@ -16,7 +16,7 @@ def cat(n):
     if 'gemm_x3_kernel' in n:
         mm = re.search(r'ILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)', n)
         return 'conv dgrad (split implicit GEMM, gemm_x3)' if int(mm.group(5)) == 2 else 'dense GEMM'
-    for key, name in (('pconv_kernel', 'conv dgrad (planes, DMA-staged)'), ('pconv_wgrad', 'conv wgrad (planes, DMA-staged)'),
+    for key, name in (('pconv_kernel', 'conv fwd + dgrad (planes, DMA-staged)'), ('pconv_pp_kernel', 'conv fwd + dgrad (planes, DMA-staged)'), ('pconv_wgrad', 'conv wgrad (planes, DMA-staged)'),
                       ('weight_ihwo_planes', 'layout (shuffle/pack/permute)'), ('f32_to_planes', 'layout (shuffle/pack/permute)'),
                       ('conv3x3_c32_wgrad', 'conv 32ch direct (fwd / dgrad / wgrad)'), ('conv3x3_c32_kernel', 'conv 32ch direct (fwd / dgrad / wgrad)'),
                       ('conv3x3_x3_kernel', 'conv 32ch direct (fwd / dgrad / wgrad)'), ('pool_final', 'SE pointwise'), ('transpose_batched', 'layout (shuffle/pack/permute)'),

@@ -26,7 +26,7 @@ sys.path.insert(0, 'tools')
 
 def fam(n):
     n = re.sub(r'\(.*', '', n)
-    for key, name in (('pconv_kernel', 'conv dgrad planes'), ('pconv_wgrad', 'conv wgrad planes'), ('gemm_x3', 'conv dgrad x3'), ('conv3x3_c32', 'conv c32 direct'),
+    for key, name in (('pconv_kernel', 'conv fwd + dgrad planes'), ('pconv_pp_kernel', 'conv fwd + dgrad planes'), ('pconv_wgrad', 'conv wgrad planes'), ('gemm_x3', 'conv dgrad x3'), ('conv3x3_c32', 'conv c32 direct'),
                       ('conv3x3_x3', 'conv c32 direct'), ('gru_', 'GRU'), ('splitk', 'split-K reduce'), ('col_partial', 'BatchNorm'), ('bn_', 'BatchNorm'),
                       ('pair_final', 'BatchNorm'), ('image_col', 'SE'), ('se_', 'SE'), ('pool_final', 'SE'), ('planes', 'planes split/layout'),
                       ('adam', 'Adam'), ('eltwise', 'pointwise'), ('dropout', 'pointwise'), ('im2col', 'im2col'), ('col2im', 'im2col')):
