@@ -604,6 +604,229 @@ __global__ __launch_bounds__(512) void pconv_pp_kernel(PConvP p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
+// QUANTISATION-FREE form of the ping-pong kernel (round 4): v_mfma_f32_16x16x32_bf16 tiles, so that a group's half tile is ANY multiple of 16
+// rows.  At the headline batch the trunk's convolutions are small against the chip: layer 3 is 73 728 rows = 288 workgroup tiles of 256 rows on
+// 256 CUs -- two rounds, the second one 12 % full (56 % of the matrix pipe over the launch); layer 4 is 144 tiles (one round on 56 % of the CUs);
+// layer 2 is 1 120 tiles (4.4 -> 5 rounds).  With 2 x 16 MT rows per workgroup the tile count can be made a multiple of the CU count:
+//   layer 3: MT = 9 (288 rows) x 128 columns -> 256 workgroups, ONE full round;   layer 4: MT = 9 x 64 columns (four column tiles) -> 256;
+//   layer 2: MT = 7 (224 rows) x 64 columns -> 1 280 workgroups = five full rounds.
+// Same anti-phase schedule as pconv_pp_kernel (LOAD: every fragment of a k tile -> registers, then the next tile's DMA; COMPUTE: MFMAs out of
+// registers); the four waves of a group split the COLUMNS (each wave: all 16 MT rows x BN / 4 columns, MT x NI accumulators of four registers),
+// so the A fragments are read by all four waves (LDS bandwidth is not the bound here) and one ds_read_b128 per 16-row tile and piece is a whole
+// K = 32 fragment (lane l: row l & 15, 16-byte piece l >> 4).  LDS rows are 64 bytes; the piece a lane group touches is XOR-ed with
+// F[(row >> 2) & 3], F = {0, 3, 2, 1}: the four 16-lane groups of a ds_read_b128 ({0-3, 12-15, 20-27}, ...) then cover all 16 slots of the
+// 256-byte bank row (the 32 x 32 kernels' swizzle (row >> 2) & 3 is 2-way conflicted for this access pattern).
+template <int MT, int BN, int NP, int OUT>
+__global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
+    constexpr int GM = 16 * MT;                                  // rows of one group's half tile
+    constexpr int NI = BN / 64;                                  // 16-column tiles per wave (wave = BN / 4 columns)
+    constexpr int PLANE_A = GM * 64, PLANE_B = BN * 64;          // bytes
+    constexpr int A_STAGE = NP * PLANE_A, B_STAGE = NP * PLANE_B;
+    constexpr int B_BASE = 4 * A_STAGE;                          // A: [group][stage], then B: [stage]
+    constexpr int NTW = (MT + 3) / 4;                            // A row tiles a wave stages (tiles w4, w4 + 4, ...)
+    constexpr int NBW = (BN / 16) / 4;                           // B row blocks per wave of group 0
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;
+    int bx, by;
+    ptile_of_block(bx, by);
+    const PClass& pc = p.cls[blockIdx.z];
+    const int m0 = bx * (2 * GM) + grp * GM, n0 = by * BN;
+    if (bx * (2 * GM) >= pc.M) return;
+    const int nkc = p.GC >> 5;
+    const int nk = pc.ntaps * nkc;
+
+    // ---- staging state: this lane's row in each of the wave's A row tiles and, in group 0, B row blocks ----
+    const int srow = lane >> 2;
+    constexpr int FSW[4] = {0, 3, 2, 1};
+    const int lc8 = ((lane & 3) ^ FSW[(srow >> 2) & 3]) * 8;      // logical 16-byte piece (in elements) this lane fetches into slot lane & 3
+    unsigned a_off[NTW]; unsigned a_mask[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int tile = w4 + 4 * i;
+        const int m = m0 + tile * 16 + srow;
+        a_mask[i] = 0u; a_off[i] = 0u;
+        if (tile < MT && m < pc.M) {
+            const int oxc = m % pc.OWc; const int t = m / pc.OWc; const int oyc = t % pc.OHc; const int img = t / pc.OHc;
+            long base;
+            if (p.fwd) {
+                const int sy0 = oyc * p.stride - p.pad, sx0 = oxc * p.stride - p.pad;
+                base = (((long)img * p.GH + sy0) * p.GW + sx0) * p.GC;
+                for (int ti = 0; ti < pc.ntaps; ++ti) {
+                    const int kh = pc.tap[ti] / p.KW, kw = pc.tap[ti] - kh * p.KW;
+                    if (sy0 + kh >= 0 && sy0 + kh < p.GH && sx0 + kw >= 0 && sx0 + kw < p.GW) a_mask[i] |= 1u << ti;
+                }
+            } else {
+                const int u = oyc * p.stride + pc.py + p.pad, v = oxc * p.stride + pc.px + p.pad;
+                const int sy0 = (u - pc.kh0) / p.stride, sx0 = (v - pc.kw0) / p.stride;
+                base = (((long)img * p.GH + sy0) * p.GW + sx0) * p.GC;
+                for (int ti = 0; ti < pc.ntaps; ++ti) {
+                    const int kh = pc.tap[ti] / p.KW, kw = pc.tap[ti] - kh * p.KW;
+                    const int sy = (u - kh) / p.stride, sx = (v - kw) / p.stride;
+                    if (u - kh >= 0 && v - kw >= 0 && sy < p.GH && sx < p.GW) a_mask[i] |= 1u << ti;
+                }
+            }
+            // masked-in taps address inside the plane; the offset of tap (0, 0) may be "negative" at the border: kept modulo 2^32 and added to the
+            // (non-negative) tap offset in 32-bit arithmetic -- a plane is < 2^31 elements (host check)
+            a_off[i] = (unsigned)(base + lc8);
+        }
+    }
+    long b_off[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int n = n0 + (w4 + 4 * i) * 16 + srow;
+        b_off[i] = n < p.N ? (long)n * p.K + lc8 : -1;
+    }
+    const unsigned short* zero = g_zero_page;
+    unsigned char* const a_lds = smem + grp * 2 * A_STAGE;
+
+    auto stage_a = [&](int kt) {
+        const int ti = kt / nkc, c0 = (kt - ti * nkc) << 5;
+        const unsigned koff = (unsigned)(c0 + (long)pc.doff[ti] * p.GC);
+        const unsigned bit = 1u << ti;
+        unsigned char* dst = a_lds + (kt & 1) * A_STAGE;
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            if (w4 + 4 * i < MT) {                               // wave-uniform
+                const bool on = (a_mask[i] & bit) != 0u;
+                const unsigned o = a_off[i] + koff;
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.a.p + q * p.a.ps + o : zero), (lds_ptr_t)(dst + q * PLANE_A + (w4 + 4 * i) * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto stage_b = [&](int kt) {
+        const int ti = kt / nkc, c0 = (kt - ti * nkc) << 5;
+        const long kb = (long)pc.tap[ti] * p.GC + c0;
+        unsigned char* dst = smem + B_BASE + (kt & 1) * B_STAGE;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const bool on = b_off[i] >= 0;
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.b.p + q * p.b.ps + b_off[i] + kb : zero), (lds_ptr_t)(dst + q * PLANE_B + (w4 + 4 * i) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[MT][NI];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int l15 = lane & 15, kp = lane >> 4;
+    const int po = (kp ^ FSW[(l15 >> 2) & 3]) * 16;              // this lane's (swizzled) 16-byte piece inside a 64-byte row
+    const int a_lane = l15 * 64 + po, b_lane = (w4 * (BN / 4) + l15) * 64 + po;
+    bf16x8_t af[NP][MT], bf[NP][NI];                             // every fragment of ONE k tile
+
+    auto load_frags = [&](int kt) {
+        const unsigned char* ab = a_lds + (kt & 1) * A_STAGE + a_lane;
+        const unsigned char* bb = smem + B_BASE + (kt & 1) * B_STAGE + b_lane;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[q][j] = *reinterpret_cast<const bf16x8_t*>(bb + q * PLANE_B + j * 1024);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[q][i] = *reinterpret_cast<const bf16x8_t*>(ab + q * PLANE_A + i * 1024);
+        }
+    };
+    auto compute = [&]() {
+        if (p.dbg & 2) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(af[q][i]));
+#pragma unroll
+                for (int j = 0; j < NI; ++j) asm volatile("" :: "v"(bf[q][j]));
+            }
+            return;
+        }
+        if constexpr (NP == 3) {
+            constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // smallest products first
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[QA[t]][i], bf[QB[t]][j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    if constexpr (NP == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NP - 1][i], bf[0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[NP - 1][j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    auto end_load = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
+    auto end_compute = [&]() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
+
+    stage_a(0);
+    if (grp == 0) stage_b(0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const bool dma = !(p.dbg & 1);
+    if (grp == 0) {
+        for (int k = 0; k < nk; ++k) {
+            load_frags(k);                                       // phase 2k
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < nk && dma) { stage_a(k + 1); stage_b(k + 1); }
+            end_load();
+            compute();                                           // phase 2k + 1
+            __builtin_amdgcn_sched_barrier(0);
+            end_compute();
+        }
+        asm volatile("s_barrier" ::: "memory");
+    } else {
+        asm volatile("s_barrier" ::: "memory");
+        for (int k = 0; k < nk; ++k) {
+            load_frags(k);                                       // phase 2k + 1
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < nk && dma) stage_a(k + 1);
+            end_load();
+            compute();                                           // phase 2k + 2
+            __builtin_amdgcn_sched_barrier(0);
+            end_compute();
+        }
+    }
+
+    // ---- epilogue: C/D layout of 16x16: col = lane & 15, row = 4 (lane >> 4) + r ----
+    static_assert(OUT == 0, "fp32 output only");
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + w4 * (BN / 4) + j * 16 + l15;
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + i * 16 + 4 * kp + r;
+                if (row >= pc.M) continue;
+                long orow = row;
+                if (!p.fwd && p.stride != 1) {
+                    const int oxc = row % pc.OWc; const int t = row / pc.OWc; const int oyc = t % pc.OHc; const int img = t / pc.OHc;
+                    orow = ((long)img * p.OH + oyc * p.stride + pc.py) * p.OW + oxc * p.stride + pc.px;
+                }
+                float* dst = p.C + orow * p.ldc + col;
+                float v = acc[i][j][r];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.beta != 0.f) v += p.beta * *dst;
+                *dst = v;
+            }
+        }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
 // Weight gradient of a 3x3 / stride-1 / pad-1 convolution from planes:  dW[co][tap][ci] = sum over pixels p of dy[p][co] * x[p + tap][ci].
 // The implicit GEMM (gemm.hip, A_MC x B_IM) stages the im2col gather of x -- the same pixels nine times -- and both operands once per
 // 128-wide output tile; rocprofv3 puts it at 15 VALU per MFMA (split + gather arithmetic) and, in the step, bound by L2 -> LDS traffic beside
@@ -958,6 +1181,52 @@ static int pconv_pp_launch(const PConvP& p, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((pconv_pp_kernel<BN, NP, OUT>), grid, dim3(512), lds, st, p);
     return 0;
 }
+static int g_q_kernel = 1;   // the quantisation-free 16x16 kernel where its tile choice fills the CUs better (ha2g_conv_planes_tile3(5) forces, (6) = off)
+template <int MT, int BN, int NP>
+static int pconv_q_launch(const PConvP& p, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)4 * NP * (16 * MT) * 64 + (size_t)2 * NP * BN * 64;
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_q_kernel<MT, BN, NP, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ha2g_set_error(-2, "pconv_q: cannot raise the dynamic LDS limit to %zu bytes", lds);
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((pconv_q_kernel<MT, BN, NP, 0>), grid, dim3(512), lds, st, p);
+    return 0;
+}
+// Tile choice: rows per workgroup 2 x 16 MT (MT = 7, 8, 9) x BN columns (64 / 128) -- the combination that keeps the CUs fullest over the launch
+// (workgroups / (rounds x CUs), times the useful fraction of the padded rows), larger tiles on ties.  -100: not served (caller falls back).
+template <int NP>
+static int pconv_q_dispatch(const PConvP& p, int maxM, hipStream_t st) {
+    if (p.N % 64 != 0 || p.ncls != 1) return -100;               // stride-2 data gradients (parity classes of different sizes) keep the 32x32 kernels
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) { int c = 0; if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) cus = c; }
+    double best = -1.0; int bmt = 0, bbn = 0;
+    for (int bn = 128; bn >= 64; bn -= 64) {
+        if (p.N % bn != 0) continue;
+        for (int mt = 9; mt >= 7; --mt) {
+            const long rows = 32L * mt, tm = (maxM + rows - 1) / rows, wgs = tm * (p.N / bn);
+            const long rounds = (wgs + cus - 1) / cus;
+            double eff = (double)wgs / (double)(rounds * cus) * ((double)maxM / (double)(tm * rows));
+            eff *= (bn == 128 ? 1.0 : 0.93) * (mt == 9 ? 1.0 : (mt == 8 ? 0.985 : 0.97));        // longer COMPUTE phases amortise the per-phase overhead
+            if (eff > best + 1e-9) { best = eff; bmt = mt; bbn = bn; }
+        }
+    }
+    if (bmt == 0) return -100;
+    const dim3 grid((unsigned)((maxM + 32 * bmt - 1) / (32 * bmt)), (unsigned)(p.N / bbn), (unsigned)p.ncls);
+    if (bbn == 128) {
+        if (bmt == 9) return pconv_q_launch<9, 128, NP>(p, grid, st);
+        if (bmt == 8) return pconv_q_launch<8, 128, NP>(p, grid, st);
+        return pconv_q_launch<7, 128, NP>(p, grid, st);
+    }
+    if (bmt == 9) return pconv_q_launch<9, 64, NP>(p, grid, st);
+    if (bmt == 8) return pconv_q_launch<8, 64, NP>(p, grid, st);
+    return pconv_q_launch<7, 64, NP>(p, grid, st);
+}
+
 template <int NP, int OUT>
 static int pconv_dispatch(const PConvP& p, int maxM, hipStream_t st) {
     if constexpr (NP == 3) {
@@ -965,6 +1234,13 @@ static int pconv_dispatch(const PConvP& p, int maxM, hipStream_t st) {
         // default: the eight-wave ping-pong kernel where the column tile is 128 wide (layers 3 / 4: 168 vs 227 us at C = 256, 194 vs 199 at C = 128,
         // profiles/r04_bwd_matrix_bench_np3_v2.txt), the 128 x 64 tile (two workgroups per CU) for the 64-channel layer (179 vs 186 us)
         int t = g_tile3 ? g_tile3 : (p.N % 128 == 0 ? 4 : 3);
+        if (g_tile3 == 5 || (g_tile3 == 0 && g_q_kernel)) {
+            if constexpr (OUT == 0) {
+                int rc = pconv_q_dispatch<NP>(p, maxM, st);
+                if (rc != -100) return rc;
+            }
+            t = g_tile3 == 5 ? 4 : (p.N % 128 == 0 ? 4 : 3);
+        }
         if (t == 4) {
             if (p.N % 128 == 0) return pconv_pp_launch<128, NP, OUT>(p, dim3(ceil_div(maxM, 256), p.N / 128, p.ncls), st);
             return pconv_pp_launch<64, NP, OUT>(p, dim3(ceil_div(maxM, 256), ceil_div(p.N, 64), p.ncls), st);
@@ -989,7 +1265,7 @@ void ha2g_conv_planes_enable(int on) { g_planes = on; }
 void ha2g_conv_planes_debug(int bits) { g_pdbg = bits; }
 void ha2g_conv_planes_ring(int depth) { g_ring = depth; }
 void ha2g_conv_planes_waves(int n) { g_waves = n == 8 ? 8 : 4; }
-void ha2g_conv_planes_tile3(int t) { g_tile3 = (t >= 0 && t <= 4) ? t : 0; }
+void ha2g_conv_planes_tile3(int t) { if (t == 6) { g_q_kernel = 0; g_tile3 = 0; } else { g_q_kernel = 1; g_tile3 = (t >= 0 && t <= 5) ? t : 0; } }
 
 // fp32 -> np bf16 piece planes of the same shape (piece q at planes + q * ps elements); n % 4 == 0, 16-byte aligned, ps % 8 == 0
 int ha2g_f32_to_planes_np(const float* x, void* planes, long ps, int np, long n, void* stream) {

@@ -60,11 +60,12 @@ def test_bn_bwd_writes_three_piece_planes(relu_mask):
     assert torch.equal(pl2, pl)
 
 
-@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize('B,H,W,C', [(4, 64, 35, 64), (3, 32, 18, 128), (5, 16, 9, 256), (1, 7, 5, 64), (128, 32, 18, 128)])
 def test_dgrad_three_piece_planes_are_fp32_class(B, H, W, C, tile):
     """3x3 stride-1 data gradients of trunk layers 2-4 on the DMA-staged plane kernel with three pieces: as close to float64 as the exact fp32
-    MFMA kernel (mode 0) is -- 20x closer than the two-piece product -- for every tile shape of the kernel, beta = 0 and beta = 1."""
+    MFMA kernel (mode 0) is -- 20x closer than the two-piece product -- for every tile shape / kernel form (1-3: 32x32 tiles, 4: eight-wave ping-pong,
+    5: the quantisation-free 16x16 ping-pong kernel forced, 6: that kernel off, 0: the default choice), beta = 0 and beta = 1."""
     torch.manual_seed(2)
     dy = torch.randn(B, H, W, C, device=DEV)
     w = torch.randn(C, 3, 3, C, device=DEV) * 0.05
@@ -174,7 +175,7 @@ def test_wgrad_three_piece_planes_are_fp32_class(B, H, W, C):
     assert _rel(tgt.double() - base.double(), gref) < 5e-6
 
 
-@pytest.mark.parametrize('tile', [0, 1, 3, 4])
+@pytest.mark.parametrize('tile', [0, 1, 3, 4, 5, 6])
 @pytest.mark.parametrize('B,H,W,Cin,Cout,k,stride,relu', [(4, 64, 35, 64, 64, 3, 1, True), (3, 32, 18, 128, 128, 3, 1, False), (5, 16, 9, 256, 256, 3, 1, True),
                                                           (4, 128, 70, 32, 64, 3, 2, True), (3, 64, 35, 64, 128, 3, 2, True), (2, 32, 18, 128, 256, 3, 2, False),
                                                           (4, 128, 70, 32, 64, 1, 2, False), (3, 64, 35, 64, 128, 1, 2, False), (1, 7, 5, 64, 64, 3, 1, False),

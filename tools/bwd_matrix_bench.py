@@ -43,9 +43,13 @@ for mode in (70, 6, 0):
             rows.append((mode, 'conv3x3 dgrad C=%d %dx%d PLANES (producer-split)' % (C, H, W), timeit(lambda: we.conv_dgrad_planes(dyp, w, x.shape, 1, 1)), fl))
             rows.append((mode, 'conv3x3 wgrad C=%d %dx%d PLANES (producer-split)' % (C, H, W), timeit(lambda: we.conv_wgrad_planes(xp, dyp, w, x.shape)), fl))
             if mode == 70:
-                lib.ha2g_conv_planes_tile3(4)
-                rows.append((mode, 'conv3x3 dgrad C=%d %dx%d PLANES ping-pong kernel' % (C, H, W), timeit(lambda: we.conv_dgrad_planes(dyp, w, x.shape, 1, 1)), fl))
+                lib.ha2g_conv_planes_tile3(6)
+                rows.append((mode, 'conv3x3 dgrad C=%d %dx%d PLANES 32x32 kernels (q kernel off)' % (C, H, W), timeit(lambda: we.conv_dgrad_planes(dyp, w, x.shape, 1, 1)), fl))
                 lib.ha2g_conv_planes_tile3(0)
+                xp3, wp3 = ops.to_planes(x, 3), ops.to_planes(w, 3)
+                rows.append((mode, 'conv3x3 FORWARD C=%d %dx%d PLANES' % (C, H, W), timeit(lambda: we.conv_fwd_planes(xp3, wp3, x.shape, 1, 1, 0)), fl))
+            if mode == 0:
+                rows.append((mode, 'conv3x3 FORWARD C=%d %dx%d fp32 implicit GEMM' % (C, H, W), timeit(lambda: we.conv_fwd(x, w, None, 1, 1, 0)), fl))
     for (M, N, K, name) in ((4352, 900, 600, 'GRU layer 1-3'), (13056, 900, 600, 'GRU fused 3-chain rows (fwd shape)')):
         dgi = torch.randn(M, N, device=dev)
         xin = torch.randn(M, K, device=dev)

@@ -28,7 +28,7 @@ for B in (128, 512):
         dy = torch.randn(B, H, W, C, device=dev)
         w = torch.randn(C, 3, 3, C, device=dev) * 0.05
         out = torch.empty(B, H, W, C, device=dev)
-        for mode, tiles in ((6, (0,)), (70, (1, 3, 4))):
+        for mode, tiles in ((6, (0,)), (70, (1, 3, 4, 5))):
             lib.ha2g_gemm_set_mode(mode)
             pl = ops.to_planes(dy)
             wpl = we.weight_planes(w, pl.shape[0])
@@ -36,7 +36,7 @@ for B in (128, 512):
                                                              C, C, 3, 3, 1, 1, 0.0, torch.cuda.current_stream().cuda_stream)
             for tile in tiles:
                 lib.ha2g_conv_planes_tile3(tile)
-                for ring in ((2,) if tile == 4 else (2, 3)):      # LDS ring depth (ha2g_conv_planes_ring; the ping-pong kernel has none)
+                for ring in ((2,) if tile >= 4 else (2, 3)):      # LDS ring depth (ha2g_conv_planes_ring; the ping-pong kernel has none)
                     lib.ha2g_conv_planes_ring(ring)
                     ts = []
                     for bits in (0, 1, 2, 3):
