@@ -42,6 +42,11 @@ int pconv_wgrad_launch(const void* x_hi, const void* x_lo, const void* dy_hi, co
 int pconv_wgrad_launch_np(const void* x, long x_ps, const void* dy, long dy_ps, int np, float* part, int N, int H, int W, int Cin, int Cout,
                           hipStream_t st);
 
+// internal: dense product on the plane kernel (conv_planes.hip); the split-K reduce lives in gemm.hip
+int plane_gemm_plan(int M, int N, int ksplit, int* mt, int* bn);
+int plane_gemm_launch(const void* a, long a_ps, long lda, const void* b, long b_ps, long ldb, int M, int N, int K, float* C, long ldc, float beta,
+                      const float* bias, int act, float* ws, int ksplit, hipStream_t st);
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device helpers ----

@@ -52,6 +52,47 @@ __global__ void f32_to_planes_multi_kernel(SplitBatch b) {
     }
 }
 
+// Dense operands of the plane GEMM (plane_gemm_launch): x [rows][ldx] fp32, `cols` valid columns -> NP piece planes [rows][ldp] with zeros in
+// [cols, ldp) (ldp = cols rounded up to 32: whole k tiles) ...
+template <int NP>
+__global__ void f32_to_planes_pad_kernel(const float* __restrict__ x, long ldx, unsigned short* __restrict__ pl, long ps, long ldp, long rows, int cols) {
+    const long q4 = ldp >> 2, total = rows * q4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / q4; const int c = (int)(i - r * q4) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* src = x + r * ldx + c;
+        if (c + 3 < cols) v = *reinterpret_cast<const float4*>(src);
+        else { if (c < cols) v.x = src[0]; if (c + 1 < cols) v.y = src[1]; if (c + 2 < cols) v.z = src[2]; }
+        unsigned a[NP], b[NP];
+        splitn_bf16<NP>(v.x, v.y, a); splitn_bf16<NP>(v.z, v.w, b);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(pl + q * ps + r * ldp + c) = make_uint2(a[q], b[q]);
+    }
+}
+// ... and the TRANSPOSED form: x [rows][ldx] -> planes [cols][ldp] with element (c, r) = x[r][c], zeros in [rows, ldp) (the operands of dW = dY^T X
+// and the weight of dX = dY W arrive with k as their slow dimension).  32 x 32 tiles through LDS; grid = (ceil(ldp / 32), ceil(cols / 32)).
+template <int NP>
+__global__ __launch_bounds__(256) void f32_to_planes_t_kernel(const float* __restrict__ x, long ldx, unsigned short* __restrict__ pl, long ps, long ldp,
+                                                              long rows, int cols) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 8 rows of 32 threads
+    const long r0 = (long)blockIdx.x * 32; const int c0 = blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long r = r0 + ty + 8 * j; const int c = c0 + tx;
+        tile[ty + 8 * j][tx] = (r < rows && c < cols) ? x[r * ldx + c] : 0.f;
+    }
+    __syncthreads();
+    // output row = c0 + (thread / 8), four output columns (= input rows) r0 + 4 (thread % 8) ..: 8-byte plane stores
+    const int oc = threadIdx.x >> 3, or4 = (threadIdx.x & 7) << 2;
+    if (c0 + oc < cols && r0 + or4 < ldp) {
+        unsigned a[NP], b[NP];
+        splitn_bf16<NP>(tile[or4][oc], tile[or4 + 1][oc], a); splitn_bf16<NP>(tile[or4 + 2][oc], tile[or4 + 3][oc], b);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(pl + q * ps + (long)(c0 + oc) * ldp + r0 + or4) = make_uint2(a[q], b[q]);
+    }
+}
+
 // w [Cout][KK][Cin] fp32 (OHWI) -> planes of wt [Cin][KK][Cout]: the B operand of the data gradient, rows = input channels, k = (tap, cout)
 __global__ void weight_ihwo_planes_kernel(const float* __restrict__ w, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, int Cout,
                                           int KK, int Cin) {
@@ -113,6 +154,10 @@ struct PConvP {
     int ncls;
     PClass cls[4];
     int dbg;                                                     // timing ablations (ha2g_conv_planes_debug): 1 = no DMA after tile 0, 2 = no MFMA
+    // dense use (plane_gemm_launch: C = A B^T as a 1x1 "convolution" over M pixels; pconv_q_kernel only)
+    const float* bias; int act;                                  // epilogue: + bias[col], act 0 none / 1 relu (= relu) / 2 leaky-relu(0.01)
+    int ksplit, kt_per;                                          // split-K over blockIdx.z (ncls == 1): k tiles [z * kt_per, ..) -> raw partial slab z of ws
+    float* ws;                                                   // [ksplit][M][N]
 };
 
 // XCD-aware workgroup -> tile mapping (same rule as gemm.hip's tile_of_block: XCD x owns a contiguous eighth of the tile sequence, n fastest)
@@ -633,11 +678,14 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
     const int grp = wave >> 2, w4 = wave & 3;
     int bx, by;
     ptile_of_block(bx, by);
-    const PClass& pc = p.cls[blockIdx.z];
+    const bool ksp = p.ksplit > 1;
+    const PClass& pc = p.cls[ksp ? 0 : blockIdx.z];
     const int m0 = bx * (2 * GM) + grp * GM, n0 = by * BN;
     if (bx * (2 * GM) >= pc.M) return;
     const int nkc = p.GC >> 5;
-    const int nk = pc.ntaps * nkc;
+    const int nk_all = pc.ntaps * nkc;
+    const int kt0 = ksp ? (int)blockIdx.z * p.kt_per : 0;        // this workgroup's k tiles: [kt0, kt0 + nk)
+    const int nk = ksp ? (kt0 + p.kt_per < nk_all ? p.kt_per : nk_all - kt0) : nk_all;
 
     // ---- staging state: this lane's row in each of the wave's A row tiles and, in group 0, B row blocks ----
     const int srow = lane >> 2;
@@ -683,11 +731,12 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
     const unsigned short* zero = g_zero_page;
     unsigned char* const a_lds = smem + grp * 2 * A_STAGE;
 
-    auto stage_a = [&](int kt) {
+    auto stage_a = [&](int kl) {                                 // kl = k tile index local to this workgroup's range
+        const int kt = kt0 + kl;
         const int ti = kt / nkc, c0 = (kt - ti * nkc) << 5;
         const unsigned koff = (unsigned)(c0 + (long)pc.doff[ti] * p.GC);
         const unsigned bit = 1u << ti;
-        unsigned char* dst = a_lds + (kt & 1) * A_STAGE;
+        unsigned char* dst = a_lds + (kl & 1) * A_STAGE;
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             if (w4 + 4 * i < MT) {                               // wave-uniform
@@ -699,10 +748,11 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
             }
         }
     };
-    auto stage_b = [&](int kt) {
+    auto stage_b = [&](int kl) {
+        const int kt = kt0 + kl;
         const int ti = kt / nkc, c0 = (kt - ti * nkc) << 5;
         const long kb = (long)pc.tap[ti] * p.GC + c0;
-        unsigned char* dst = smem + B_BASE + (kt & 1) * B_STAGE;
+        unsigned char* dst = smem + B_BASE + (kl & 1) * B_STAGE;
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
             const bool on = b_off[i] >= 0;
@@ -816,9 +866,12 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
                     const int oxc = row % pc.OWc; const int t = row / pc.OWc; const int oyc = t % pc.OHc; const int img = t / pc.OHc;
                     orow = ((long)img * p.OH + oyc * p.stride + pc.py) * p.OW + oxc * p.stride + pc.px;
                 }
+                if (ksp) { p.ws[((long)blockIdx.z * pc.M + orow) * p.N + col] = acc[i][j][r]; continue; }      // raw partial: the reduce applies the epilogue
                 float* dst = p.C + orow * p.ldc + col;
                 float v = acc[i][j][r];
-                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.bias) v += p.bias[col];
+                if (p.relu || p.act == 1) v = fmaxf(v, 0.f);
+                else if (p.act == 2) v = v > 0.f ? v : 0.01f * v;
                 if (p.beta != 0.f) v += p.beta * *dst;
                 *dst = v;
             }
@@ -1199,24 +1252,31 @@ static int pconv_q_launch(const PConvP& p, dim3 grid, hipStream_t st) {
 }
 // Tile choice: rows per workgroup 2 x 16 MT (MT = 7, 8, 9) x BN columns (64 / 128) -- the combination that keeps the CUs fullest over the launch
 // (workgroups / (rounds x CUs), times the useful fraction of the padded rows), larger tiles on ties.  -100: not served (caller falls back).
-template <int NP>
-static int pconv_q_dispatch(const PConvP& p, int maxM, hipStream_t st) {
-    if (p.N % 64 != 0 || p.ncls != 1) return -100;               // stride-2 data gradients (parity classes of different sizes) keep the 32x32 kernels
+// tile plan of the q kernel for an M x N output computed in `ksplit` k slices: (MT, BN) that keeps the CUs fullest; returns the efficiency (0 = none)
+static double pconv_q_plan(int M, int N, int ksplit, int* pmt, int* pbn) {
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) { int c = 0; if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) cus = c; }
     double best = -1.0; int bmt = 0, bbn = 0;
     for (int bn = 128; bn >= 64; bn -= 64) {
-        if (p.N % bn != 0) continue;
+        const long tn = (N + bn - 1) / bn;
         for (int mt = 9; mt >= 7; --mt) {
-            const long rows = 32L * mt, tm = (maxM + rows - 1) / rows, wgs = tm * (p.N / bn);
+            const long rows = 32L * mt, tm = (M + rows - 1) / rows, wgs = tm * tn * ksplit;
             const long rounds = (wgs + cus - 1) / cus;
-            double eff = (double)wgs / (double)(rounds * cus) * ((double)maxM / (double)(tm * rows));
+            double eff = (double)wgs / (double)(rounds * cus) * ((double)M / (double)(tm * rows)) * ((double)N / (double)(tn * bn));
             eff *= (bn == 128 ? 1.0 : 0.93) * (mt == 9 ? 1.0 : (mt == 8 ? 0.985 : 0.97));        // longer COMPUTE phases amortise the per-phase overhead
             if (eff > best + 1e-9) { best = eff; bmt = mt; bbn = bn; }
         }
     }
+    *pmt = bmt; *pbn = bbn;
+    return best;
+}
+template <int NP>
+static int pconv_q_dispatch(const PConvP& p, int maxM, hipStream_t st) {
+    if (p.ncls != 1) return -100;                                // stride-2 data gradients (parity classes of different sizes) keep the 32x32 kernels
+    int bmt = 0, bbn = 0;
+    pconv_q_plan(maxM, p.N, p.ksplit > 1 ? p.ksplit : 1, &bmt, &bbn);
     if (bmt == 0) return -100;
-    const dim3 grid((unsigned)((maxM + 32 * bmt - 1) / (32 * bmt)), (unsigned)(p.N / bbn), (unsigned)p.ncls);
+    const dim3 grid((unsigned)((maxM + 32 * bmt - 1) / (32 * bmt)), (unsigned)((p.N + bbn - 1) / bbn), (unsigned)(p.ksplit > 1 ? p.ksplit : p.ncls));
     if (bbn == 128) {
         if (bmt == 9) return pconv_q_launch<9, 128, NP>(p, grid, st);
         if (bmt == 8) return pconv_q_launch<8, 128, NP>(p, grid, st);
@@ -1259,7 +1319,54 @@ static int pconv_dispatch(const PConvP& p, int maxM, hipStream_t st) {
 }
 
 
+// Dense product on the quantisation-free plane kernel: C [M][N] (fp32, row stride ldc) = act(A B^T + bias) + beta C with A = piece planes
+// [M][lda], B = piece planes [N][ldb] (three pieces each, k contiguous, zero-padded to whole 32-wide k tiles: lda, ldb >= round_up(K, 32)) -- a 1x1
+// "convolution" over M pixels with lda channels.  ksplit > 1: k slices over grid.z write raw partial slabs ws [ksplit][M][N] (the caller reduces).
+int plane_gemm_plan(int M, int N, int ksplit, int* mt, int* bn) { return pconv_q_plan(M, N, ksplit, mt, bn) > 0.0 ? 0 : -100; }
+int plane_gemm_launch(const void* a, long a_ps, long lda, const void* b, long b_ps, long ldb, int M, int N, int K, float* C, long ldc, float beta,
+                      const float* bias, int act, float* ws, int ksplit, hipStream_t st) {
+    PConvP p{};
+    p.a = PlaneSet{(const unsigned short*)a, a_ps}; p.b = PlaneSet{(const unsigned short*)b, b_ps};
+    p.C = C; p.ldc = ldc; p.beta = beta; p.fwd = 1; p.bias = bias; p.act = act;
+    p.N = N; p.K = (int)ldb;                                     // row stride of the B planes
+    const int kpad = (K + 31) / 32 * 32;
+    p.GH = 1; p.GW = M; p.GC = (int)lda; p.OH = 1; p.OW = M; p.KH = 1; p.KW = 1; p.pad = 0; p.stride = 1;
+    p.dbg = g_pdbg;
+    PClass c{};
+    c.OHc = 1; c.OWc = M; c.M = M; c.ntaps = 1; c.tap[0] = 0; c.doff[0] = 0;
+    p.ncls = 1; p.cls[0] = c;
+    // the kernel walks GC / 32 k tiles per tap: only the first kpad / 32 carry data -- hand it a class whose channel count is kpad
+    const int nkt = kpad / 32;
+    p.ksplit = ksplit > 1 ? ksplit : 1;
+    p.kt_per = (nkt + p.ksplit - 1) / p.ksplit;
+    p.ws = ws;
+    if (M == 0 || N == 0) return 0;
+    // GC is the row stride AND (>> 5) the k-tile count of the kernel: when lda > kpad the surplus tiles would multiply zeros by zeros; forbid it
+    if (lda != kpad) return ha2g_set_error(-1, "plane_gemm: lda %ld must equal K rounded up to 32 (%d)", lda, kpad);
+    if (int rc = pconv_q_dispatch<3>(p, M, st)) return rc;
+    HA2G_CHECK_LAUNCH("plane_gemm");
+    return 0;
+}
+
 extern "C" {
+
+// x [rows][ldx] fp32 -> np = 3 piece planes for the plane GEMM: transpose = 0: [rows][ldp], `cols` valid columns, zeros behind; transpose = 1:
+// [cols][ldp] holding x^T, `rows` valid columns.  ldp % 32 == 0; piece q at planes + q * ps elements.
+int ha2g_f32_to_planes_2d_np(const float* x, long ldx, long rows, int cols, void* planes, long ps, long ldp, int np, int transpose, void* stream) {
+    HA2G_REQUIRE(np == 3, "f32_to_planes_2d: np = %d (3)", np);
+    HA2G_REQUIRE(ldp % 32 == 0 && ldp >= (transpose ? rows : cols), "f32_to_planes_2d: ldp %ld", ldp);
+    if (rows == 0 || cols == 0) return 0;
+    if (!transpose) {
+        const long total = rows * (ldp / 4);
+        const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+        hipLaunchKernelGGL(f32_to_planes_pad_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (unsigned short*)planes, ps, ldp, rows, cols);
+    } else {
+        hipLaunchKernelGGL(f32_to_planes_t_kernel<3>, dim3((unsigned)(ldp / 32), (unsigned)((cols + 31) / 32)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                           (unsigned short*)planes, ps, ldp, rows, cols);
+    }
+    HA2G_CHECK_LAUNCH("f32_to_planes_2d");
+    return 0;
+}
 
 void ha2g_conv_planes_enable(int on) { g_planes = on; }
 void ha2g_conv_planes_debug(int bits) { g_pdbg = bits; }

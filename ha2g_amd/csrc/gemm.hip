@@ -1125,6 +1125,41 @@ int ha2g_gemm_f32(int transa, int transb, int M, int N, int K, float alpha, cons
     return ha2g_set_error(-1, "gemm: transa=1,transb=1 is not used on this path");
 }
 
+// Dense product on THREE-PIECE PLANES (round 4): C [M][N] = act(A B^T + bias) + beta C, A = piece planes [M][lda], B = piece planes [N][ldb]
+// (ha2g_f32_to_planes_2d_np; lda = ldb = K rounded up to 32, zero padded), on the quantisation-free plane kernel of conv_planes.hip: six bf16
+// MFMAs per product on all 24 mantissa bits = the accuracy of the fp32 MFMA GEMM, ~2x its speed on the GRU projection shapes.  Small tile grids
+// are split over k (raw slabs in ws, reduced in double by the split-K reduce).  Replaces nn.Linear / the GRU's input projections and their
+// autograd backward (model/hierarchy_net.py:87-93,144-147) where ha2g_amd.ops.gemm routes a product here.
+int ha2g_gemm_planes_np_f32(const void* a, long a_ps, long lda, const void* b, long b_ps, long ldb, int np, int M, int N, int K, float beta,
+                            float* C, long ldc, const float* bias, int act, float* ws, long ws_bytes, void* stream) {
+    HA2G_REQUIRE(np == 3, "gemm_planes: np = %d (3)", np);
+    HA2G_REQUIRE(act >= 0 && act <= 2, "gemm_planes: act %d (0 none, 1 relu, 2 leaky-relu)", act);
+    if (M == 0 || N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    // split-K when the tile grid leaves most CUs idle and k is deep enough
+    int mt = 0, bn = 0;
+    plane_gemm_plan(M, N, 1, &mt, &bn);
+    const long tiles = (long)ceil_div(M, 32 * mt) * ceil_div(N, bn);
+    const int nkt = (K + 31) / 32, ncu = cu_count();
+    int ksplit = 1;
+    if (tiles * 2 <= ncu && nkt >= 16) {
+        ksplit = (int)((ncu + tiles - 1) / tiles);
+        if (ksplit > nkt / 8) ksplit = nkt / 8;
+        while (ksplit > 1 && (long)ksplit * M * N * 4 > ws_bytes) --ksplit;
+        if (ksplit < 1) ksplit = 1;
+    }
+    if (int rc = plane_gemm_launch(a, a_ps, lda, b, b_ps, ldb, M, N, K, C, ldc, beta, bias, act, ws, ksplit, st)) return rc;
+    if (ksplit > 1) {
+        const int kt_per = (nkt + ksplit - 1) / ksplit, used = (nkt + kt_per - 1) / kt_per;      // slabs the kernel wrote (the last slices may be empty)
+        const long MN = (long)M * N;
+        ReduceOut ro{};
+        ro.groups = 1; ro.C[0] = C; ro.bias[0] = bias;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div(MN, 256), 1), dim3(256), 0, st, ws, used, MN, N, ro, ldc, 1.f, beta, act, 0.f, M);
+        HA2G_CHECK_LAUNCH("gemm_planes reduce");
+    }
+    return 0;
+}
+
 // Weight and bias gradient of a linear layer in one launch: dW[M,N] = beta*dW + dY^T X and db[M] = bias_beta*db + column sums of dY,
 // dY stored [K][M] (rows = samples), X [K][N].  The bias sums ride on the dY tiles the GEMM stages anyway (fp32 per block, double across
 // split-K partials in the reduce launch).

@@ -135,6 +135,8 @@ def gemm(a, b, transa=False, transb=False, out=None, alpha=1.0, beta=0.0, bias=N
     _chk2d(out)
     assert out.shape == (M, N)
     ws = workspace(a.device)
+    if _plane_gemm_ok(a, b, M, N, K, transa, transb, alpha, act, out):
+        return _gemm_planes(a, b, M, N, K, transa, transb, out, beta, bias, act, colsum_out, colsum_beta, ws)
     if colsum_out is not None:
         assert transa and not transb and alpha == 1.0 and bias is None and act == ACT_NONE
         assert colsum_out.shape == (M,) and colsum_out.is_contiguous() and colsum_out.dtype == torch.float32
@@ -143,6 +145,44 @@ def gemm(a, b, transa=False, transb=False, out=None, alpha=1.0, beta=0.0, bias=N
         return out
     check(lib.ha2g_gemm_f32(int(transa), int(transb), M, N, K, alpha, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
                             beta, out.data_ptr(), out.stride(0), _p(bias), act, ws.data_ptr(), ws.numel() * 4, _stream()))
+    return out
+
+
+PLANE_GEMM = os.environ.get('HA2G_PLANE_GEMM', '1') != '0'      # large dense products on three-piece planes (csrc/conv_planes.hip, pconv_q_kernel)
+# >= 4 GFLOP: the GRU input projections (both directions merged) and their backward; smaller products (generator head, TCN) lose to the operand
+# split passes (A/B on the step: 43.24 ms vs 43.58 with 0.5 GFLOP, 44.10 without the plane GEMM; profiles/r04_ab_gemm.txt)
+PLANE_GEMM_MIN_FLOP = float(os.environ.get('HA2G_PLANE_GEMM_MIN', 4e9))
+
+
+def _plane_gemm_ok(a, b, M, N, K, transa, transb, alpha, act, out):
+    """Route this product to the plane GEMM?  Only in the fp32-class default mode (three pieces = the accuracy of the fp32 MFMA GEMM), only
+    for products large enough to fill the chip (GRU input projections and their backward, the generator head), 16-byte aligned operands."""
+    if not (PLANE_GEMM and a.is_cuda and alpha == 1.0 and act in (ACT_NONE, ACT_RELU, ACT_LEAKY) and lib.ha2g_gemm_bwd_pieces() == 3):
+        return False
+    if 2.0 * M * N * K < PLANE_GEMM_MIN_FLOP or min(M, N) < 128 or K < 64:
+        return False
+    return all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 for t in (a, b))
+
+
+def _planes_2d(x, transpose):
+    """x [rows][cols] fp32 -> three-piece planes for the plane GEMM: [3][rows][Kp] (Kp = cols rounded up to 32, zero padded), or with transpose
+    [3][cols][Kp'] holding x^T (Kp' = rows rounded up to 32)"""
+    rows, cols = x.shape
+    R, Kv = (cols, rows) if transpose else (rows, cols)
+    Kp = (Kv + 31) // 32 * 32
+    pl = torch.empty(3, R, Kp, dtype=torch.bfloat16, device=x.device)
+    check(lib.ha2g_f32_to_planes_2d_np(x.data_ptr(), x.stride(0), rows, cols, pl.data_ptr(), pl.stride(0), Kp, 3, int(transpose), _stream()))
+    return pl
+
+
+def _gemm_planes(a, b, M, N, K, transa, transb, out, beta, bias, act, colsum_out, colsum_beta, ws):
+    ap = _planes_2d(a, transa)                             # [3][M][Kp]: a is [M][K], or stored [K][M]
+    bp = _planes_2d(b, not transb)                         # [3][N][Kp]: b is stored [N][K] (transb), or [K][N]
+    ktimer.launch('gemm_planes', lambda: check(lib.ha2g_gemm_planes_np_f32(
+        ap.data_ptr(), ap.stride(0), ap.shape[2], bp.data_ptr(), bp.stride(0), bp.shape[2], 3, M, N, K, beta, out.data_ptr(), out.stride(0),
+        _p(bias), act, ws.data_ptr(), ws.numel() * 4, _stream())), 2.0 * M * N * K)
+    if colsum_out is not None:                             # the layer's bias gradient (rode on the weight-gradient GEMM's dY tiles before)
+        colsum(a, out=colsum_out, beta=colsum_beta)
     return out
 
 
@@ -880,6 +920,7 @@ def _gru_layer_fwd(gi, pk, bf, br, y, rs, B, T, H, st, device):
         check(lib.ha2g_gru_layer_fwd(gi.data_ptr(), pk.data_ptr(), bf.data_ptr(), br.data_ptr(), y.data_ptr(), _p(rs), B, T, H, st))
 
 
+GRU_MERGE_DIRS = os.environ.get('HA2G_GRU_MERGE_DIRS', '1') != '0'    # both directions' input projections as one plane GEMM
 PACK_MULTI = os.environ.get('HA2G_PACK_MULTI', '1') != '0'      # one W_hh pack launch per GRU stack instead of two per layer
 
 
@@ -918,8 +959,14 @@ class BiGRUFunction(torch.autograd.Function):
             x2 = inp.view(B * T, K)
             tkey = 'gemm_gi' if (H == 300 and l > 0) else 'gemm_gi_other'
             fl = 2.0 * B * T * K * 3 * H
-            ktimer.launch(tkey, lambda: gemm(x2, w[0], transb=True, out=gi[:, :3 * H], bias=w[2]), fl)
-            ktimer.launch(tkey, lambda: gemm(x2, w[4], transb=True, out=gi[:, 3 * H:], bias=w[6]), fl)
+            if GRU_MERGE_DIRS and _plane_gemm_ok(x2, w[0], B * T, 6 * H, K, False, True, 1.0, ACT_NONE, gi) and K >= 256:
+                # both directions' input projections as ONE product [rows, K] x [6H, K]^T on the plane GEMM: twice the columns per launch fill the
+                # chip's rounds (291 -> 181 us at 13056 x 1800 x 600 incl. the operand splits, profiles/r04_plane_gemm_bench.txt)
+                wcat, bcat = torch.cat((w[0], w[4])), torch.cat((w[2], w[6]))
+                ktimer.launch(tkey, lambda: gemm(x2, wcat, transb=True, out=gi, bias=bcat), 2 * fl)
+            else:
+                ktimer.launch(tkey, lambda: gemm(x2, w[0], transb=True, out=gi[:, :3 * H], bias=w[2]), fl)
+                ktimer.launch(tkey, lambda: gemm(x2, w[4], transb=True, out=gi[:, 3 * H:], bias=w[6]), fl)
             if pk_all is not None:
                 pk = pk_all[l]
             else:

@@ -570,8 +570,13 @@ def test_grouped_gemm_matches_per_group_launches(case):
             assert float((got_cs[g].double() - refb).abs().max()) <= 2e-6 * float(a[g].double().abs().sum(0).max()), g
     if G == 1:                                                                             # degenerate group count == the plain launch, bit for bit
         one, one_cs = c0[0].clone(), (cs0[0].clone() if wgrad else None)
-        ops.gemm(a[0], b[0], transa=ta, transb=tb, out=one, beta=1.0, bias=None if bias is None else bias[0], act=act,
-                 **(dict(colsum_out=one_cs, colsum_beta=1.0) if wgrad else {}))
+        pg = ops.PLANE_GEMM
+        ops.PLANE_GEMM = False                          # the plain launch of the SAME kernel (large products otherwise take the plane GEMM)
+        try:
+            ops.gemm(a[0], b[0], transa=ta, transb=tb, out=one, beta=1.0, bias=None if bias is None else bias[0], act=act,
+                     **(dict(colsum_out=one_cs, colsum_beta=1.0) if wgrad else {}))
+        finally:
+            ops.PLANE_GEMM = pg
         assert torch.equal(one, got[0])
 
 

@@ -199,3 +199,45 @@ def test_forward_convolution_on_three_piece_planes_is_fp32_class(B, H, W, Cin, C
     exact = we.conv_fwd(x, w, None, stride, pad, ops.ACT_RELU if relu else ops.ACT_NONE)
     e3, e32 = _rel(got, ref), _rel(exact, ref)
     assert got.shape == exact.shape and e3 < 3e-6 and e3 < 1.5 * e32 + 2e-7, (e3, e32)
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb', [(13056, 900, 600, False, True), (4352, 900, 108, False, True), (4352, 600, 900, False, False),
+                                         (900, 600, 4352, True, False), (900, 108, 13056, True, False), (4352, 150, 300, False, True),
+                                         (1000, 300, 77, False, True), (4352, 300, 600, False, False), (300, 600, 4352, True, False)])
+def test_dense_products_on_three_piece_planes(M, N, K, ta, tb):
+    """ops.gemm routes large products to the plane GEMM (ha2g_gemm_planes_np_f32: K-contiguous zero-padded piece planes through
+    ha2g_f32_to_planes_2d_np -- transposing where k is an operand's slow dimension --, the quantisation-free plane kernel, split-K slabs for
+    small tile grids): every operand layout of the step (forward y = x W^T, dX = dY W, dW = dY^T X with its bias-gradient column sums),
+    K not a multiple of 32, bias / activation / accumulate epilogues -- against float64 at the accuracy of the fp32 MFMA GEMM."""
+    torch.manual_seed(9)
+    a = torch.randn((K, M) if ta else (M, K), device=DEV)
+    b = torch.randn((N, K) if tb else (K, N), device=DEV) * 0.05
+    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    old = ops.PLANE_GEMM_MIN_FLOP
+    ops.PLANE_GEMM_MIN_FLOP = 0.0
+    try:
+        assert ops._plane_gemm_ok(a, b, M, N, K, ta, tb, 1.0, ops.ACT_NONE, None) == (min(M, N) >= 128 and K >= 64)
+        got = ops.gemm(a, b, transa=ta, transb=tb)
+        ops.PLANE_GEMM = False
+        exact_mode = ops.gemm(a, b, transa=ta, transb=tb)
+        ops.PLANE_GEMM = True
+        e3, e32 = _rel(got, ref), _rel(exact_mode, ref)
+        assert e3 < 2e-6 and e3 < 3.0 * e32 + 3e-7, (e3, e32)
+        if not ta:
+            bias = torch.randn(N, device=DEV)
+            base = torch.randn(M, N, device=DEV)
+            got2 = ops.gemm(a, b, transa=ta, transb=tb, out=base.clone(), beta=1.0, bias=bias, act=ops.ACT_LEAKY)
+            v = ref + bias.double()
+            ref2 = torch.where(v > 0, v, 0.01 * v) + base.double()
+            assert _rel(got2, ref2) < 3e-6
+        else:
+            cs = torch.randn(M, device=DEV)
+            cs0 = cs.clone()
+            tgt = torch.randn(M, N, device=DEV)
+            t0 = tgt.clone()
+            ops.gemm(a, b, transa=True, out=tgt, beta=1.0, colsum_out=cs, colsum_beta=1.0)
+            assert _rel(tgt.double() - t0.double(), ref) < 3e-6
+            assert _rel(cs.double() - cs0.double(), a.double().sum(0)) < 3e-6
+    finally:
+        ops.PLANE_GEMM_MIN_FLOP = old
+        ops.PLANE_GEMM = True
