@@ -325,8 +325,8 @@ def main():
                         traffic_over_algorithmic=(round(traffic / bytes_, 3) if traffic else None), launches=n, mean_us=round(mean_us, 1),
                         batch_rows=rows, us_per_timestep=round(mean_us / T, 2), hbm_GBps_algorithmic=round(bytes_ / (mean_us * 1e-6) / 1e9, 1),
                         hbm_frac_of_8TBps=round(bytes_ / (mean_us * 1e-6) / 8e12, 4))
-        roof = gru_roof('gru_layer_fwd', 'gru_fwd_cluster_kernel (ha2g_gru_layer_fwd_cluster, H=300)', 'r03_pmc_gru_fwd.json', False)
-        roof_bwd = gru_roof('gru_layer_bwd', 'gru_bwd_cluster_kernel (ha2g_gru_layer_bwd_cluster, H=300)', 'r03_pmc_gru_bwd.json', True)
+        roof = gru_roof('gru_layer_fwd', 'gru_fwd_cluster_kernel (ha2g_gru_layer_fwd_cluster, H=300)', 'r04_pmc_gru_fwd.json', False)
+        roof_bwd = gru_roof('gru_layer_bwd', 'gru_bwd_cluster_kernel (ha2g_gru_layer_bwd_cluster, H=300)', 'r04_pmc_gru_bwd.json', True)
         if roof_bwd is not None:     # the BPTT chain runs on the split-bf16 inner product in the default mode (3 bf16 MFMAs per product term, fp32 accumulate);
             roof_bwd['arithmetic'] = 'split-bf16 x2 (16-bit operand mantissa; frac is still priced against the fp32 MFMA peak)' if bwd_pieces == 2 else 'fp32 MFMA'
         roof_gemm = None

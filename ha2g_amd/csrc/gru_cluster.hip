@@ -335,6 +335,278 @@ __global__ __launch_bounds__(NT, 1) void gru_fwd_cluster_kernel(const float* __r
 }
 
 
+// ---- THREE-PIECE forward recurrence (round 4; VERDICT r3 item 5: a structural change to the named kernel, not another analysis) ------------
+// The fp32 chain of a step is 228 v_mfma_f32_16x16x4_f32 per wave = 7 300 issue cycles = 52 % of the 5.86 us step by itself, with one wave per
+// SIMD there is nothing to overlap it with, and 0.5 of the fp32 MFMA peak was the ceiling of that design.  The only lever left was
+// fewer matrix-pipe cycles per product WITHOUT giving up fp32-class arithmetic: every fp32 value is the sum of three bf16 pieces (all 24
+// mantissa bits), and W h = sum of the six piece products down to 2^-24 -- on v_mfma_f32_16x16x32_bf16 that is 6 x 16 cycles per 16 units x 16
+// rows x 32 k instead of 8 x 32: 180 MFMAs = 2 880 cycles per wave-step, 0.39 of the fp32 chain's.
+//   * W_hh slice (16 units x 3 gates x 320 k per wave): pieces 0 and 1 live in registers as bf16 A fragments (240 per lane), piece 2 -- used by
+//     ONE of the six products -- in LDS (30 KB per wave, each lane re-reads exactly the 16 bytes it stored: no barrier, no bank conflict);
+//   * the hidden-state tile lives in LDS as three bf16 piece planes [16 rows][40 sixteen-byte slots] (slot ^= row: the 16-lane groups of a
+//     ds_read_b128 cover all 16 slots of a bank row); the split happens where a value ENTERS the tile -- the gate epilogue for the wave's own
+//     units, the poll staging for the other members' -- once per value and step, ~70 VALU per thread and step;
+//   * hand-off protocol, tags, publish order, deferred stores: unchanged (fp32 granules travel; the pieces are a local matter);
+//   * h_{t-1} of the wave's own units stays in registers (it was re-read from the fp32 tile before).
+// The result is the same function at fp32-class accuracy (x = p0 + p1 + p2 exactly; dropped terms <= 2^-24 of a product), NOT bit-identical
+// to gru.hip's fp32 chain; tests hold both against the float64 oracle (tests/test_gpu_kernels.py::test_bigru_fwd_bwd).
+constexpr int NKB = 10;                                   // 32-wide k blocks: 320 padded columns
+constexpr int H3_ROW = 768;                               // bytes per row of an h piece plane: 48 slots of 16 bytes (40 used, ^ row stays < 48)
+constexpr int H3_PLANE = 16 * H3_ROW;
+constexpr int W2_WAVE = 3 * NKB * 1024;                   // one wave's piece-2 fragments: [gate][block][64 lanes][16 B]
+constexpr int FWD3_LDS = 3 * H3_PLANE + TPW * W2_WAVE;    // 36 KB + 120 KB
+typedef __bf16 bf16x8g_t __attribute__((ext_vector_type(8)));
+
+// W_hh [3H][H] fp32 -> the three-piece A-fragment image of gru_fwd_cluster3_kernel: [tile 19][piece 3][gate 3][block 10][lane 64][8 bf16]
+// (lane = unit (l & 15) of the tile, k = 32 block + 8 (l >> 4) + e; zeros for units / columns >= H)
+__global__ void pack_whh3_kernel(const float* __restrict__ w, uint4* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;               // (tile, gate, block, lane)
+    if (idx >= NJT * 3 * NKB * 64) return;
+    const int lane = idx & 63, blk = (idx >> 6) % NKB, gate = (idx / (64 * NKB)) % 3, tile = idx / (64 * NKB * 3);
+    const int unit = 16 * tile + (lane & 15), k0 = 32 * blk + 8 * (lane >> 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (unit < H && k0 + e < H) ? w[((long)gate * H + unit) * H + k0 + e] : 0.f;
+    unsigned pc[4][3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3_bf16(v[2 * e], v[2 * e + 1], pc[e][0], pc[e][1], pc[e][2]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        out[(((long)tile * 3 + q) * 3 + gate) * NKB * 64 + blk * 64 + lane] = make_uint4(pc[0][q], pc[1][q], pc[2][q], pc[3][q]);
+}
+
+template <int Q>
+__device__ __forceinline__ void gru_fwd_member3(const float* __restrict__ gi, const uint4* __restrict__ wp3, const float* __restrict__ bhh,
+                                                float* __restrict__ y, float* __restrict__ rs, const __amdgpu_buffer_rsrc_t xr,
+                                                int* __restrict__ err, const int B, const int T, const int dir, const int b0,
+                                                const unsigned tag0, int* __restrict__ sh, const int dbg, unsigned char* __restrict__ lds) {
+    constexpr int NOWN_T = (Q == G - 1) ? NJT - TPW * (G - 1) : TPW;     // unit tiles of this member: 4 4 4 4 3
+    constexpr int P1 = (Q + 1) % G, P2 = (Q + 2) % G, P3 = (Q + 3) % G, P4 = (Q + 4) % G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lb = lane & 15, g = lane >> 4;
+    const int b = b0 + lb;
+    const bool bok = b < B;
+    const bool tile_on = wave < NOWN_T;
+    const int jt = Q * TPW + wave;
+    const int j = 16 * jt + 4 * g;                       // first of this lane's 4 hidden units
+    const bool jok = tile_on && j < H;
+    const int pr = tid >> 4, pc = (tid & 15) * 4;        // gather ownership: tile row, column inside a member's 64-column block
+
+    cluster_publish_xcd(xr, (int)(BWD_GRAN * 8), Q, tag0 + 63u);
+    // ---- this wave's slice of W_hh: pieces 0 / 1 -> registers, piece 2 -> this wave's LDS region ----
+    unsigned char* const hpl = lds;                                  // h piece planes
+    uint4* const w2 = reinterpret_cast<uint4*>(lds + 3 * H3_PLANE + wave * W2_WAVE) + lane;      // + (gate * NKB + blk) * 64
+    bf16x8g_t w0[3][NKB], w1[3][NKB];
+    {
+        const uint4* wsrc = wp3 + ((long)dir * NJT + (tile_on ? jt : 0)) * (3 * 3 * NKB * 64) + lane;
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+            for (int m = 0; m < NKB; ++m) {
+                w0[gt][m] = __builtin_bit_cast(bf16x8g_t, wsrc[((0 * 3 + gt) * NKB + m) * 64]);
+                w1[gt][m] = __builtin_bit_cast(bf16x8g_t, wsrc[((1 * 3 + gt) * NKB + m) * 64]);
+                w2[(gt * NKB + m) * 64] = wsrc[((2 * 3 + gt) * NKB + m) * 64];
+            }
+    }
+    const int fast = (dbg & 4) ? (cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh), 0) : cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh);
+    float4 br = make_float4(0.f, 0.f, 0.f, 0.f), bz = br, bn = br;
+    if (jok) {
+        br = *reinterpret_cast<const float4*>(bhh + j);
+        bz = *reinterpret_cast<const float4*>(bhh + H + j);
+        bn = *reinterpret_cast<const float4*>(bhh + 2 * H + j);
+    }
+    for (int i = tid; i < 3 * H3_PLANE / 16; i += NT) reinterpret_cast<uint4*>(hpl)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gir = zero4, giz = zero4, gin = zero4, gir_n = zero4, giz_n = zero4, gin_n = zero4;
+    float4 d_h = zero4, d_r = zero4, d_z = zero4, d_n = zero4, d_q = zero4;
+    float4 hkeep = zero4;                                 // h_{t-1} of this lane's own units (registers; the fp32 tile is gone)
+    int d_bt = -1;
+    if (jok && bok) {
+        const float* gp = gi + ((long)(b * T + (dir ? T - 1 : 0)) * 2 + dir) * 3 * H + j;
+        gir = *reinterpret_cast<const float4*>(gp);
+        giz = *reinterpret_cast<const float4*>(gp + H);
+        gin = *reinterpret_cast<const float4*>(gp + 2 * H);
+    }
+    u32x4 pa1 = {0u, 0u, 0u, 0u}, pb1 = pa1, pa2 = pa1, pb2 = pa1, pa3 = pa1, pb3 = pa1, pa4 = pa1, pb4 = pa1;
+    const long tstep = dir ? -1 : 1;
+    const float* gi_next = gi + ((long)(b * (long)T + (dir ? T - 2 : 1)) * 2 + dir) * 3 * H + j;
+    float* y_cur = y + ((long)b * T + (dir ? T - 1 : 0)) * 2 * H + dir * H + j;
+    float* rs_cur = rs ? rs + (((long)b * T + (dir ? T - 1 : 0)) * 2 + dir) * 4 * H + j : nullptr;
+    float* y_def = nullptr; float* rs_def = nullptr;
+
+    // B fragments of k block m: lane (row lb, 16-byte slot 4 m + g, ^ lb) of the three piece planes
+    const unsigned char* const hrd = hpl + lb * H3_ROW;
+    auto hfrag = [&](int q, int m) { return *reinterpret_cast<const bf16x8g_t*>(hrd + q * H3_PLANE + (((4 * m + g) ^ lb) << 4)); };
+    // four fp32 values of tile row `row`, columns k .. k + 3 (k % 4 == 0) -> the three piece planes
+    auto hstore = [&](int row, int k, float v0, float v1, float v2, float v3) {
+        unsigned a[3], c[3];
+        split3_bf16(v0, v1, a[0], a[1], a[2]); split3_bf16(v2, v3, c[0], c[1], c[2]);
+        unsigned char* d = hpl + row * H3_ROW + ((((k >> 3)) ^ row) << 4) + ((k & 4) << 1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * H3_PLANE) = make_uint2(a[q], c[q]);
+    };
+    f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
+#define HA2G_MB3(i) ((2 * Q + (i)) % NKB)
+    // chain positions I0 .. I1-1 of the member's rotated block order; the fragments of position i + 1 (three h pieces, three gates' W piece 2)
+    // are fetched before the 18 MFMAs of position i issue
+#define HA2G_FWD_CHAIN3(I0, I1)                                                                                   \
+    if ((I0) < (I1)) {                                                                                            \
+        bf16x8g_t h0_ = hfrag(0, HA2G_MB3(I0)), h1_ = hfrag(1, HA2G_MB3(I0)), h2_ = hfrag(2, HA2G_MB3(I0));       \
+        bf16x8g_t r2_ = __builtin_bit_cast(bf16x8g_t, w2[(0 * NKB + HA2G_MB3(I0)) * 64]);                         \
+        bf16x8g_t z2_ = __builtin_bit_cast(bf16x8g_t, w2[(1 * NKB + HA2G_MB3(I0)) * 64]);                         \
+        bf16x8g_t n2_ = __builtin_bit_cast(bf16x8g_t, w2[(2 * NKB + HA2G_MB3(I0)) * 64]);                         \
+        _Pragma("unroll") for (int i_ = (I0); i_ < (I1); ++i_) {                                                  \
+            bf16x8g_t h0n_ = h0_, h1n_ = h1_, h2n_ = h2_, r2n_ = r2_, z2n_ = z2_, n2n_ = n2_;                     \
+            if (i_ + 1 < (I1)) {                                                                                  \
+                h0n_ = hfrag(0, HA2G_MB3(i_ + 1)); h1n_ = hfrag(1, HA2G_MB3(i_ + 1)); h2n_ = hfrag(2, HA2G_MB3(i_ + 1)); \
+                r2n_ = __builtin_bit_cast(bf16x8g_t, w2[(0 * NKB + HA2G_MB3(i_ + 1)) * 64]);                      \
+                z2n_ = __builtin_bit_cast(bf16x8g_t, w2[(1 * NKB + HA2G_MB3(i_ + 1)) * 64]);                      \
+                n2n_ = __builtin_bit_cast(bf16x8g_t, w2[(2 * NKB + HA2G_MB3(i_ + 1)) * 64]);                      \
+            }                                                                                                     \
+            __builtin_amdgcn_sched_barrier(0x16);                                                                 \
+            const int m_ = HA2G_MB3(i_);                                                                          \
+            /* six products, smallest first, the three gates interleaved (independent accumulators) */            \
+            ar = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r2_, h0_, ar, 0, 0, 0);                                  \
+            az = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z2_, h0_, az, 0, 0, 0);                                  \
+            an = __builtin_amdgcn_mfma_f32_16x16x32_bf16(n2_, h0_, an, 0, 0, 0);                                  \
+            ar = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[0][m_], h2_, ar, 0, 0, 0);                            \
+            az = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[1][m_], h2_, az, 0, 0, 0);                            \
+            an = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[2][m_], h2_, an, 0, 0, 0);                            \
+            ar = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[0][m_], h1_, ar, 0, 0, 0);                            \
+            az = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[1][m_], h1_, az, 0, 0, 0);                            \
+            an = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[2][m_], h1_, an, 0, 0, 0);                            \
+            ar = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[0][m_], h0_, ar, 0, 0, 0);                            \
+            az = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[1][m_], h0_, az, 0, 0, 0);                            \
+            an = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[2][m_], h0_, an, 0, 0, 0);                            \
+            ar = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[0][m_], h1_, ar, 0, 0, 0);                            \
+            az = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[1][m_], h1_, az, 0, 0, 0);                            \
+            an = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[2][m_], h1_, an, 0, 0, 0);                            \
+            ar = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[0][m_], h0_, ar, 0, 0, 0);                            \
+            az = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[1][m_], h0_, az, 0, 0, 0);                            \
+            an = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[2][m_], h0_, an, 0, 0, 0);                            \
+            h0_ = h0n_; h1_ = h1n_; h2_ = h2n_; r2_ = r2n_; z2_ = z2n_; n2_ = n2n_;                                \
+        }                                                                                                         \
+    }
+#define HA2G_POLL_STAGE3(I, P)                                                                                    \
+    if (64 * (P) + pc < H) hstore(pr, 64 * (P) + pc, __uint_as_float(pa##I[0]), __uint_as_float(pa##I[2]), __uint_as_float(pb##I[0]), __uint_as_float(pb##I[2]));
+#define HA2G_POLL_WAIT_STAGE_ALL3                                                                                 \
+    {                                                                                                             \
+        for (unsigned spins_ = 0;; ++spins_) {                                                                    \
+            const bool ok_ = HA2G_POLL_OK(1, P1) && HA2G_POLL_OK(2, P2) && HA2G_POLL_OK(3, P3) && HA2G_POLL_OK(4, P4); \
+            if (__all(ok_) || (dbg & 1)) break;                                                                   \
+            if (spins_ > SPIN_LIMIT) { if (lane == 0) atomicExch(err, 1); break; }                                \
+            __builtin_amdgcn_s_sleep(1);                                                                          \
+            HA2G_POLL_ISSUE(1, P1) HA2G_POLL_ISSUE(2, P2) HA2G_POLL_ISSUE(3, P3) HA2G_POLL_ISSUE(4, P4)           \
+        }                                                                                                         \
+        HA2G_POLL_STAGE3(1, P1) HA2G_POLL_STAGE3(2, P2) HA2G_POLL_STAGE3(3, P3) HA2G_POLL_STAGE3(4, P4)           \
+    }
+#define HA2G_FWD_PREFETCH3(S)                                                                                     \
+    if ((S) + 1 < T && jok && bok) {                                                                              \
+        gir_n = *reinterpret_cast<const float4*>(gi_next);                                                        \
+        giz_n = *reinterpret_cast<const float4*>(gi_next + H);                                                    \
+        gin_n = *reinterpret_cast<const float4*>(gi_next + 2 * H);                                                \
+    }
+#define HA2G_FWD_FLUSH3                                                                                           \
+    if (d_bt >= 0) {                                                                                              \
+        *reinterpret_cast<float4*>(y_def) = d_h;                                                                  \
+        if (rs) {                                                                                                 \
+            *reinterpret_cast<float4*>(rs_def) = d_r;                                                             \
+            *reinterpret_cast<float4*>(rs_def + H) = d_z;                                                         \
+            *reinterpret_cast<float4*>(rs_def + 2 * H) = d_n;                                                     \
+            *reinterpret_cast<float4*>(rs_def + 3 * H) = d_q;                                                     \
+        }                                                                                                         \
+        d_bt = -1;                                                                                                \
+    }
+
+    for (int s = 0; s < T; ++s) {
+        ar = f32x4{0.f, 0.f, 0.f, 0.f}; az = ar; an = ar;
+        if (s == 0) {
+            HA2G_FWD_PREFETCH3(0) HA2G_FWD_FLUSH3
+            lds_barrier();
+        } else if (dbg & 2) {
+            lds_barrier();
+            if (tile_on) { HA2G_FWD_CHAIN3(0, NKB) }
+            HA2G_FWD_PREFETCH3(s) HA2G_FWD_FLUSH3
+            lds_barrier();
+        } else {
+            const unsigned tag = tag0 + (unsigned)s;
+            const int sbase = ((s - 1) & 1) * 16 * HP;
+            lds_barrier();                                                // every wave's own columns of h_s are in the planes
+            if (tile_on) { HA2G_FWD_CHAIN3(0, 2) }                         // the member's own 64 columns: two k blocks
+            HA2G_POLL_ISSUE(1, P1) HA2G_POLL_ISSUE(2, P2) HA2G_POLL_ISSUE(3, P3) HA2G_POLL_ISSUE(4, P4)
+            HA2G_FWD_PREFETCH3(s)
+            HA2G_POLL_WAIT_STAGE_ALL3
+            HA2G_FWD_FLUSH3
+            lds_barrier();
+            if (tile_on) { HA2G_FWD_CHAIN3(2, NKB) }                       // the other four members' blocks, ring order
+        }
+        float4 hn4 = zero4;
+        if (jok) {
+            if (bok) {
+                const float* hpp = &hkeep.x;
+                float* pr4 = &d_r.x; float* pz4 = &d_z.x; float* pn4 = &d_n.x; float* pq4 = &d_q.x; float* ph = &hn4.x;
+                const float* gr = &gir.x; const float* gz = &giz.x; const float* gn = &gin.x;
+                const float* cbr = &br.x; const float* cbz = &bz.x; const float* cbn = &bn.x;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float rr = sigmoidf_(gr[u] + ar[u] + cbr[u]);
+                    const float zz = sigmoidf_(gz[u] + az[u] + cbz[u]);
+                    const float qq = an[u] + cbn[u];
+                    const float nn = tanhf_(gn[u] + rr * qq);
+                    pr4[u] = rr; pz4[u] = zz; pn4[u] = nn; pq4[u] = qq;
+                    ph[u] = (1.f - zz) * nn + zz * hpp[u];
+                }
+                d_h = hn4;
+                d_bt = 1;
+                y_def = y_cur; rs_def = rs_cur;
+            }
+            if (s + 1 < T && !(dbg & 2)) {
+                const int go = (((s & 1) * 16 + lb) * HP + j) * 8;
+                const unsigned ptag = tag0 + (unsigned)(s + 1);
+                if (fast) {
+                    store_granule_pair<0>(xr, go, ptag, hn4.x, hn4.y);
+                    store_granule_pair<0>(xr, go + 16, ptag, hn4.z, hn4.w);
+                } else {
+                    store_granule_pair<16>(xr, go, ptag, hn4.x, hn4.y);
+                    store_granule_pair<16>(xr, go + 16, ptag, hn4.z, hn4.w);
+                }
+            }
+        }
+        hkeep = hn4;
+        if (tile_on) hstore(lb, j, hn4.x, hn4.y, hn4.z, hn4.w);            // own columns of h_{s+1} (zeros for padded rows / units)
+        gir = gir_n; giz = giz_n; gin = gin_n;
+        gi_next += tstep * 6 * H; y_cur += tstep * 2 * H;
+        if (rs) rs_cur += tstep * 8 * H;
+    }
+    HA2G_FWD_FLUSH3
+}
+
+__global__ __launch_bounds__(NT, 1) void gru_fwd_cluster3_kernel(const float* __restrict__ gi, const uint4* __restrict__ wp3,
+                                                                 const float* __restrict__ bhh0, const float* __restrict__ bhh1,
+                                                                 float* __restrict__ y, float* __restrict__ rs, u64* __restrict__ xch,
+                                                                 const unsigned* __restrict__ epoch, unsigned host_tag0, int* __restrict__ err, int B,
+                                                                 int T, int tile0, int nclusters, int dbg) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds3[];     // FWD3_LDS bytes + 32 for the handshake ids
+    int* sh = reinterpret_cast<int*>(lds3 + FWD3_LDS);
+    const int id = blockIdx.x, xcd = id & 7, r = id >> 3;
+    const int q = r % G, c = (r / G) * 8 + xcd;
+    if (c >= nclusters) return;
+    const int dir = c & 1, b0 = (tile0 + (c >> 1)) * 16;
+    u64* xc = xch + (long)c * CL_GRAN;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xc, 0, (int)(CL_GRAN * 8), 0x00020000);
+    const unsigned tag0 = epoch ? (0x80000000u | (*epoch << 6)) : host_tag0;
+    const float* bhh = dir ? bhh1 : bhh0;
+    switch (q) {
+        case 0: gru_fwd_member3<0>(gi, wp3, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, lds3); break;
+        case 1: gru_fwd_member3<1>(gi, wp3, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, lds3); break;
+        case 2: gru_fwd_member3<2>(gi, wp3, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, lds3); break;
+        case 3: gru_fwd_member3<3>(gi, wp3, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, lds3); break;
+        default: gru_fwd_member3<4>(gi, wp3, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, lds3); break;
+    }
+}
+
+
 // ---- backward (BPTT), cluster form -------------------------------------------------------------------------------------
 // Member q owns hidden units [64q, 64q+64).  Per step (reverse of the forward order):
 //   phase 1  gate gradients of the OWN units (one (row, 4-unit) group per thread): dg -> HBM, d gh -> LDS, dh*z kept in regs;
@@ -693,6 +965,45 @@ int ha2g_gru_layer_fwd_cluster(const float* gi, const float* wp, const float* bh
         hipLaunchKernelGGL(gru_fwd_cluster_kernel, dim3(grid), dim3(NT), 0, st, gi, wp, bhh_fwd, bhh_rev, y, rs, (u64*)xch, epoch, host_tag0, err, B, T,
                            t0, nclusters, g_dbg);
         HA2G_CHECK_LAUNCH("gru_layer_fwd_cluster");
+    }
+    return 0;
+}
+
+// ---- three-piece forward (fp32-class, the default since round 4): wp3 = both directions' three-piece W_hh images (ha2g_gru_pack_whh3,
+//      2 * ha2g_gru_packed3_bytes() bytes: direction 0 then 1); otherwise the contract of ha2g_gru_layer_fwd_cluster ----
+long ha2g_gru_packed3_bytes(void) { return (long)NJT * 3 * 3 * NKB * 64 * 16; }
+int ha2g_gru_pack_whh3(const float* w_hh, void* out, int H_, void* stream) {
+    HA2G_REQUIRE(H_ == H, "gru_pack_whh3: H=%d not instantiated (300)", H_);
+    hipLaunchKernelGGL(pack_whh3_kernel, dim3(ceil_div(NJT * 3 * NKB * 64, 256)), dim3(256), 0, (hipStream_t)stream, w_hh, (uint4*)out);
+    HA2G_CHECK_LAUNCH("gru_pack_whh3");
+    return 0;
+}
+int ha2g_gru_layer_fwd_cluster3(const float* gi, const void* wp3, const float* bhh_fwd, const float* bhh_rev, float* y, float* rs,
+                                void* xch, int* err, int B, int T, int H_, void* stream) {
+    HA2G_REQUIRE(H_ == H, "gru cluster kernel: H=%d not instantiated (300)", H_);
+    HA2G_REQUIRE(T <= MAX_STEPS, "gru cluster kernel: T=%d > %d steps", T, MAX_STEPS);
+    const int cap = device_tile_cap();
+    HA2G_REQUIRE(cap >= 1, "gru cluster kernel: the device has fewer than %d compute units", 2 * G);
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0 || T == 0) return 0;
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_cluster3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FWD3_LDS + 32) != hipSuccess)
+            return ha2g_set_error(-2, "gru_fwd_cluster3: cannot raise the dynamic LDS limit to %d bytes", FWD3_LDS + 32);
+        attr_set[dev] = true;
+    }
+    const int tiles = ceil_div(B, 16);
+    for (int t0 = 0; t0 < tiles; t0 += cap) {
+        const int nt = tiles - t0 < cap ? tiles - t0 : cap;
+        const int nclusters = nt * 2;
+        unsigned host_tag0 = 0;
+        const unsigned* epoch = launch_tag_base(xch, st, &host_tag0);
+        const int grid = ceil_div(nclusters, 8) * 8 * G;
+        hipLaunchKernelGGL(gru_fwd_cluster3_kernel, dim3(grid), dim3(NT), FWD3_LDS + 32, st, gi, (const uint4*)wp3, bhh_fwd, bhh_rev, y, rs, (u64*)xch, epoch,
+                           host_tag0, err, B, T, t0, nclusters, g_dbg);
+        HA2G_CHECK_LAUNCH("gru_layer_fwd_cluster3");
     }
     return 0;
 }

@@ -911,8 +911,22 @@ def _gru_layer_bwd(dy, y, rs, pkt, dg, hp, B, T, H, st, device):
         check(lib.ha2g_gru_layer_bwd(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pkt.data_ptr(), dg.data_ptr(), hp.data_ptr(), B, T, H, st))
 
 
-def _gru_layer_fwd(gi, pk, bf, br, y, rs, B, T, H, st, device):
-    if USE_GRU_CLUSTER and lib.ha2g_gru_cluster_supported(H) and T <= lib.ha2g_gru_cluster_max_steps():
+GRU_FWD3 = os.environ.get('HA2G_GRU_FWD3', '1') != '0'      # H = 300 forward recurrence on three bf16 pieces (fp32-class) in the default mode
+
+
+def gru_fwd3_active(H, T):
+    """the three-piece cluster forward serves this layer: cluster kernels usable and the arithmetic mode is the fp32-class default (mode 0 =
+    every product on the fp32 MFMA and mode 6 keep the fp32 chain of rounds 1-3)"""
+    return (GRU_FWD3 and USE_GRU_CLUSTER and bool(lib.ha2g_gru_cluster_supported(H)) and T <= lib.ha2g_gru_cluster_max_steps()
+            and lib.ha2g_gemm_bwd_pieces() == 3)
+
+
+def _gru_layer_fwd(gi, pk, bf, br, y, rs, B, T, H, st, device, pk3=None):
+    if pk3 is not None:
+        xch, err = _cluster_scratch(device)
+        check(lib.ha2g_gru_layer_fwd_cluster3(gi.data_ptr(), pk3.data_ptr(), bf.data_ptr(), br.data_ptr(), y.data_ptr(), _p(rs),
+                                              xch.data_ptr(), err.data_ptr(), B, T, H, st))
+    elif USE_GRU_CLUSTER and lib.ha2g_gru_cluster_supported(H) and T <= lib.ha2g_gru_cluster_max_steps():
         xch, err = _cluster_scratch(device)
         check(lib.ha2g_gru_layer_fwd_cluster(gi.data_ptr(), pk.data_ptr(), bf.data_ptr(), br.data_ptr(), y.data_ptr(), _p(rs),
                                              xch.data_ptr(), err.data_ptr(), B, T, H, st))
@@ -975,8 +989,14 @@ class BiGRUFunction(torch.autograd.Function):
                 check(lib.ha2g_gru_pack_whh(w[5].data_ptr(), pk[1].data_ptr(), pk[3].data_ptr(), H, st))
             y = torch.empty(B, T, 2 * H, dtype=torch.float32, device=dev)
             rs = torch.empty(B, T, 2, 4, H, dtype=torch.float32, device=dev) if need_grad else None
+            pk3 = None
+            if gru_fwd3_active(H, T):                      # three-piece W_hh images of both directions (bf16 A fragments)
+                n3 = lib.ha2g_gru_packed3_bytes()
+                pk3 = torch.empty(2, n3, dtype=torch.uint8, device=dev)
+                check(lib.ha2g_gru_pack_whh3(w[1].data_ptr(), pk3[0].data_ptr(), H, st))
+                check(lib.ha2g_gru_pack_whh3(w[5].data_ptr(), pk3[1].data_ptr(), H, st))
             ktimer.launch('gru_layer_fwd' if (H == 300 and l > 0) else 'gru_layer_fwd_other',
-                          lambda: _gru_layer_fwd(gi, pk, w[3], w[7], y, rs, B, T, H, st, dev), B)
+                          lambda: _gru_layer_fwd(gi, pk, w[3], w[7], y, rs, B, T, H, st, dev, pk3), B)
             saved.append((inp, y, rs))
             packs.append(pk)
             inp = y

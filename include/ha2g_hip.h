@@ -229,6 +229,14 @@ int ha2g_gru_cluster_max_steps(void);
 int ha2g_gru_cluster_supported(int H);
 int ha2g_gru_layer_fwd_cluster(const float* gi, const float* wp, const float* bhh_fwd, const float* bhh_rev, float* y,
                                float* rs, void* xch, int* err, int B, int T, int H, void* stream);
+/* ABI 2: the THREE-PIECE form of the cluster forward (round 4, the default in the fp32-class mode): the recurrent product W_hh h runs as six
+ * v_mfma_f32_16x16x32_bf16 per 32 k on three bf16 pieces of both operands (all 24 mantissa bits; fp32 accumulate) instead of eight fp32 MFMAs --
+ * 0.39 of the fp32 chain's matrix-pipe cycles at fp32-class accuracy (NOT bit-identical to ha2g_gru_layer_fwd).  wp3 = the two directions'
+ * three-piece W_hh images (ha2g_gru_pack_whh3 into direction d at byte offset d * ha2g_gru_packed3_bytes()); the rest as above. */
+long ha2g_gru_packed3_bytes(void);
+int ha2g_gru_pack_whh3(const float* w_hh, void* out, int H, void* stream);
+int ha2g_gru_layer_fwd_cluster3(const float* gi, const void* wp3, const float* bhh_fwd, const float* bhh_rev, float* y, float* rs,
+                                void* xch, int* err, int B, int T, int H, void* stream);
 int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, float* hp, void* xch,
                                int* err, int B, int T, int H, void* stream);
 /* ablation bits for tools/dbg_cluster.py: 1 no wait, 2 no exchange, 4 force the write-through publish */

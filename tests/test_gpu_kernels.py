@@ -227,14 +227,29 @@ def test_gru_cluster_matches_single_workgroup_kernel(B):
                 flat.append(rnd(shp, 100 + len(flat), 1.0 / H ** 0.5).to(dev))
     x = rnd((B, T, In), 7).to(dev)
     outs = []
-    for use in (False, True):
-        ops.USE_GRU_CLUSTER = use
+    for use, fwd3 in ((False, False), (True, False), (True, True)):
+        ops.USE_GRU_CLUSTER, old3 = use, ops.GRU_FWD3
+        ops.GRU_FWD3 = fwd3
         try:
             outs.append(ops.bigru(x, flat, H))
         finally:
-            ops.USE_GRU_CLUSTER = True
+            ops.USE_GRU_CLUSTER, ops.GRU_FWD3 = True, old3
     assert ops.gru_cluster_error(dev) == 0
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1])                   # the fp32 cluster chain == the single-workgroup fp32 chain, bit for bit
+    # the three-piece chain (round 4, the default in the fp32-class mode): the same function at fp32-class accuracy -- against float64 it is as
+    # close as the fp32 chain is (two stacked layers, 34 steps of recurrence each)
+    from oracle import ha2g_oracle as O
+    names = []
+    sd = {}
+    it = iter(flat)
+    for l in range(L):
+        for suf in ('', '_reverse'):
+            for nm in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
+                sd['g.%s_l%d%s' % (nm, l, suf)] = next(it).double().cpu()
+    y64 = O.gru_bidir(x.double().cpu(), sd, 'g.', L, H)
+    e32, e3 = relerr(outs[1], y64), relerr(outs[2], y64)
+    assert ops.gru_fwd3_active(H, T) and not torch.equal(outs[1], outs[2])
+    assert e3 < 2e-6 and e3 < 2.0 * e32 + 2e-7, (e3, e32)
 
 
 @pytest.mark.parametrize('B', [5, 40, 130])

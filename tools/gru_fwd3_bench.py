@@ -1,0 +1,53 @@
+"""The named kernel, before / after: ha2g_gru_layer_fwd_cluster (fp32 MFMA chain) vs ha2g_gru_layer_fwd_cluster3 (three-piece bf16 chain, fp32-class)
+at the train step's launch shapes (384 rows = the fused 3-chain pass, 128 rows), with the hand-off ablations of ha2g_gru_cluster_debug.
+usage: python tools/gru_fwd3_bench.py"""
+import sys
+import torch
+sys.path.insert(0, '.')
+from ha2g_amd import ops
+from ha2g_amd._lib import check, lib
+
+dev = torch.device('cuda:0')
+H, T = 300, 34
+
+
+def t_us(fn, iters=20):
+    fn(); fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+print('%-6s %-28s %10s %10s %10s %12s' % ('rows', 'variant', 'us/launch', 'us/step', 'TFLOP/s', 'of fp32 peak'))
+for B in (384, 128):
+    gi = torch.randn(B * T, 6 * H, device=dev) * 0.3
+    whh = [torch.randn(3 * H, H, device=dev) * H ** -0.5 for _ in range(2)]
+    bh = [torch.randn(3 * H, device=dev) * 0.05 for _ in range(2)]
+    npk = lib.ha2g_gru_packed_floats(H)
+    pk = torch.empty(4, npk, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for d in range(2):
+        check(lib.ha2g_gru_pack_whh(whh[d].data_ptr(), pk[d].data_ptr(), pk[2 + d].data_ptr(), H, st))
+    pk3 = torch.empty(2, lib.ha2g_gru_packed3_bytes(), dtype=torch.uint8, device=dev)
+    for d in range(2):
+        check(lib.ha2g_gru_pack_whh3(whh[d].data_ptr(), pk3[d].data_ptr(), H, st))
+    y, rs = torch.empty(B, T, 2 * H, device=dev), torch.empty(B, T, 2, 4, H, device=dev)
+    y3 = torch.empty_like(y)
+    xch, err = ops._cluster_scratch(dev)
+    f32 = lambda: check(lib.ha2g_gru_layer_fwd_cluster(gi.data_ptr(), pk.data_ptr(), bh[0].data_ptr(), bh[1].data_ptr(), y.data_ptr(), rs.data_ptr(), xch.data_ptr(), err.data_ptr(), B, T, H, st))
+    f3 = lambda: check(lib.ha2g_gru_layer_fwd_cluster3(gi.data_ptr(), pk3.data_ptr(), bh[0].data_ptr(), bh[1].data_ptr(), y3.data_ptr(), rs.data_ptr(), xch.data_ptr(), err.data_ptr(), B, T, H, st))
+    flops = 2.0 * B * T * 2 * 3 * H * H + 12.0 * B * T * 2 * H
+    for name, fn in (('fp32 chain (rounds 1-3)', f32), ('three-piece bf16 chain', f3)):
+        for dbg, dn in ((0, ''), (2, ' [no exchange]'), (1, ' [no poll wait]')):
+            lib.ha2g_gru_cluster_debug(dbg)
+            us = t_us(fn)
+            print('%-6d %-28s %10.1f %10.2f %10.1f %12.3f' % (B, name + dn, us, us / T, flops / us / 1e6, flops / us / 1e6 / 157.3))
+        lib.ha2g_gru_cluster_debug(0)
+    f32(); f3()
+    torch.cuda.synchronize()
+    print('       max |y3 - y32| / max |y32| = %.3e; err word %d' % (float((y3 - y).abs().max() / y.abs().max()), int(err.item())))
