@@ -870,9 +870,10 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
                 float* dst = p.C + orow * p.ldc + col;
                 float v = acc[i][j][r];
                 if (p.bias) v += p.bias[col];
-                if (p.relu || p.act == 1) v = fmaxf(v, 0.f);
-                else if (p.act == 2) v = v > 0.f ? v : 0.01f * v;
+                if (p.relu) v = fmaxf(v, 0.f);                   // convolution callers: relu(conv), then the accumulate (never both in practice)
                 if (p.beta != 0.f) v += p.beta * *dst;
+                if (p.act == 1) v = fmaxf(v, 0.f);               // dense callers: act(A B^T + bias + beta C), the convention of ha2g_gemm_f32
+                else if (p.act == 2) v = v > 0.f ? v : 0.01f * v;
                 *dst = v;
             }
         }

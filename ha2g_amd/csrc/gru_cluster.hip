@@ -375,6 +375,24 @@ __global__ void pack_whh3_kernel(const float* __restrict__ w, uint4* __restrict_
         out[(((long)tile * 3 + q) * 3 + gate) * NKB * 64 + blk * 64 + lane] = make_uint4(pc[0][q], pc[1][q], pc[2][q], pc[3][q]);
 }
 
+// ... and the TRANSPOSED image of gru_bwd_cluster_kernel<3>: [k tile 19][piece 3][gate 3][unit block 10][lane 64][8 bf16], lane = column
+// 16 kt + (l & 15) of W_hh, element e = unit 32 jblk + 8 (l >> 4) + e: W_hh[gate * H + unit][column] (zeros past H)
+__global__ void pack_whh3t_kernel(const float* __restrict__ w, uint4* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;               // (k tile, gate, unit block, lane)
+    if (idx >= NJT * 3 * NKB * 64) return;
+    const int lane = idx & 63, jb = (idx >> 6) % NKB, gate = (idx / (64 * NKB)) % 3, kt = idx / (64 * NKB * 3);
+    const int col = 16 * kt + (lane & 15), j0 = 32 * jb + 8 * (lane >> 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (col < H && j0 + e < H) ? w[((long)gate * H + j0 + e) * H + col] : 0.f;
+    unsigned pc[4][3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3_bf16(v[2 * e], v[2 * e + 1], pc[e][0], pc[e][1], pc[e][2]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        out[(((long)kt * 3 + q) * 3 + gate) * NKB * 64 + jb * 64 + lane] = make_uint4(pc[0][q], pc[1][q], pc[2][q], pc[3][q]);
+}
+
 template <int Q>
 __device__ __forceinline__ void gru_fwd_member3(const float* __restrict__ gi, const uint4* __restrict__ wp3, const float* __restrict__ bhh,
                                                 float* __restrict__ y, float* __restrict__ rs, const __amdgpu_buffer_rsrc_t xr,
@@ -646,12 +664,13 @@ __device__ __forceinline__ f32x4 mfma3_bf16(const float4& w, const float4& d, f3
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi_of(w), hi_of(d), acc, 0, 0, 0);
 }
 
-template <int Q, int PB, bool SPL>
+template <int Q, int PB, int AR>      // AR = 0: fp32 MFMA chain, 2: two-piece split (mode 6), 3: three-piece split (fp32-class, round 4)
 __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ rs,
                                                const float* __restrict__ wpt, float* __restrict__ dg, float* __restrict__ hpo, const __amdgpu_buffer_rsrc_t xr,
                                                int* __restrict__ err, const int B, const int T, const int dir, const int b0,
                                                const unsigned tag0, int* __restrict__ sh, const int dbg, float* __restrict__ sg,
-                                               float* __restrict__ sp) {
+                                               float* __restrict__ sp, const uint4* __restrict__ wp3t = nullptr, unsigned char* __restrict__ lds3 = nullptr) {
+    constexpr bool SPL = AR == 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lb = lane & 15, g = lane >> 4;
     constexpr int k0 = Q * 64;                              // first own unit
@@ -662,8 +681,30 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
 
     // ---- resident transposed W_hh fragments: wave w serves k-tiles w, w+4, ... ; own j-tiles 4Q..4Q+3 ----
     cluster_publish_xcd(xr, (int)(BWD_GRAN * 8), Q, tag0 + 63u);
-    float4 wf[NKW * 3 * TPW];
-    {
+    // AR = 3: the transposed slice as bf16 A fragments of v_mfma_f32_16x16x32_bf16 -- (k tile, gate, 32-unit block of the member's 64 own units):
+    // pieces 0 / 1 in registers (240 per lane), piece 2 in this wave's LDS region (30 KB; each lane re-reads the 16 bytes it stored)
+    bf16x8g_t v0[AR == 3 ? NKW : 1][3][2], v1[AR == 3 ? NKW : 1][3][2];
+    uint4* const w2 = AR == 3 ? reinterpret_cast<uint4*>(lds3 + wave * W2_WAVE) + lane : nullptr;      // + ((kk * 3 + gate) * 2 + blk) * 64
+    if constexpr (AR == 3) {
+#pragma unroll
+        for (int kk = 0; kk < NKW; ++kk)
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const int kt = wave + kk * TPW;
+                    uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0, q2 = q0;
+                    if (kt < NJT) {
+                        const uint4* src = wp3t + ((long)dir * NJT + kt) * (3 * 3 * NKB * 64) + (gate * NKB + 2 * Q + blk) * 64 + lane;
+                        q0 = src[0]; q1 = src[3 * NKB * 64]; q2 = src[2 * 3 * NKB * 64];
+                    }
+                    v0[kk][gate][blk] = __builtin_bit_cast(bf16x8g_t, q0);
+                    v1[kk][gate][blk] = __builtin_bit_cast(bf16x8g_t, q1);
+                    w2[((kk * 3 + gate) * 2 + blk) * 64] = q2;
+                }
+    }
+    float4 wf[AR == 3 ? 1 : NKW * 3 * TPW];
+    if constexpr (AR != 3) {
         const float4* base = reinterpret_cast<const float4*>(wpt) + (long)dir * (NJT * 3 * NJT) * 64 + lane;
 #pragma unroll
         for (int kk = 0; kk < NKW; ++kk)
@@ -701,11 +742,37 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
     HA2G_BWD_LOAD(0)
     lds_barrier();
 
+    // AR = 3: the six piece products (smallest first) of k tile KK x 32-unit block BLK, the three gates on independent accumulators
+#define HA2G_BWD_MFMA3(KK, BLK)                                                                                   \
+    {                                                                                                             \
+        const bf16x8g_t r2_ = __builtin_bit_cast(bf16x8g_t, w2[(((KK) * 3 + 0) * 2 + (BLK)) * 64]);               \
+        const bf16x8g_t z2_ = __builtin_bit_cast(bf16x8g_t, w2[(((KK) * 3 + 1) * 2 + (BLK)) * 64]);               \
+        const bf16x8g_t n2_ = __builtin_bit_cast(bf16x8g_t, w2[(((KK) * 3 + 2) * 2 + (BLK)) * 64]);               \
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r2_, bq[0][0][BLK], a0, 0, 0, 0);                            \
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z2_, bq[0][1][BLK], a1, 0, 0, 0);                            \
+        a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(n2_, bq[0][2][BLK], a2, 0, 0, 0);                            \
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0[KK][0][BLK], bq[2][0][BLK], a0, 0, 0, 0);                 \
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0[KK][1][BLK], bq[2][1][BLK], a1, 0, 0, 0);                 \
+        a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0[KK][2][BLK], bq[2][2][BLK], a2, 0, 0, 0);                 \
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1[KK][0][BLK], bq[1][0][BLK], a0, 0, 0, 0);                 \
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1[KK][1][BLK], bq[1][1][BLK], a1, 0, 0, 0);                 \
+        a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1[KK][2][BLK], bq[1][2][BLK], a2, 0, 0, 0);                 \
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1[KK][0][BLK], bq[0][0][BLK], a0, 0, 0, 0);                 \
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1[KK][1][BLK], bq[0][1][BLK], a1, 0, 0, 0);                 \
+        a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1[KK][2][BLK], bq[0][2][BLK], a2, 0, 0, 0);                 \
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0[KK][0][BLK], bq[1][0][BLK], a0, 0, 0, 0);                 \
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0[KK][1][BLK], bq[1][1][BLK], a1, 0, 0, 0);                 \
+        a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0[KK][2][BLK], bq[1][2][BLK], a2, 0, 0, 0);                 \
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0[KK][0][BLK], bq[0][0][BLK], a0, 0, 0, 0);                 \
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0[KK][1][BLK], bq[0][1][BLK], a1, 0, 0, 0);                 \
+        a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0[KK][2][BLK], bq[0][2][BLK], a2, 0, 0, 0);                 \
+    }
     // one k-tile (destination member KK) of the partial product; published unless it is the own block
 #define HA2G_BWD_KTILE(KK)                                                                                        \
     if (wave + (KK) * TPW < NJT) {                                                                                \
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;                                                        \
-        _Pragma("unroll") for (int jl = 0; jl < TPW; ++jl) {                                                      \
+        if constexpr (AR == 3) { HA2G_BWD_MFMA3(KK, 0) HA2G_BWD_MFMA3(KK, 1) }                                    \
+        else _Pragma("unroll") for (int jl = 0; jl < TPW; ++jl) {                                                 \
             const float* w0 = &wf[((KK) * 3 + 0) * TPW + jl].x; const float* w1 = &wf[((KK) * 3 + 1) * TPW + jl].x; \
             const float* w2 = &wf[((KK) * 3 + 2) * TPW + jl].x;                                                   \
             const float* d0 = &bop[jl].x; const float* d1 = &bop[TPW + jl].x; const float* d2 = &bop[2 * TPW + jl].x; \
@@ -768,14 +835,30 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
         lds_barrier();
         HA2G_BWD_LOAD(s + 1)                                // next step's operands: in flight during the MFMA phase
         // ---- phase 2: partial sums for all k from the own units; foreign destinations first ----
-        float4 bop[3 * TPW];
+        float4 bop[AR == 3 ? 1 : 3 * TPW];
+        bf16x8g_t bq[3][3][2];                               // AR = 3: [piece][gate][32-unit block]: lane (row lb, units 32 blk + 8 g .. + 7)
+        if constexpr (AR == 3) {
 #pragma unroll
-        for (int gate = 0; gate < 3; ++gate)
+            for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
-            for (int jl = 0; jl < TPW; ++jl) {
-                const float4 v = *reinterpret_cast<const float4*>(&sg[lb * LDG + gate * 64 + 16 * jl + 4 * g]);
-                bop[gate * TPW + jl] = SPL ? split_pack4(v) : v;
-            }
+                for (int blk = 0; blk < 2; ++blk) {
+                    const float4 x0 = *reinterpret_cast<const float4*>(&sg[lb * LDG + gate * 64 + 32 * blk + 8 * g]);
+                    const float4 x1 = *reinterpret_cast<const float4*>(&sg[lb * LDG + gate * 64 + 32 * blk + 8 * g + 4]);
+                    unsigned e0[3], e1[3], e2[3], e3[3];
+                    split3_bf16(x0.x, x0.y, e0[0], e0[1], e0[2]); split3_bf16(x0.z, x0.w, e1[0], e1[1], e1[2]);
+                    split3_bf16(x1.x, x1.y, e2[0], e2[1], e2[2]); split3_bf16(x1.z, x1.w, e3[0], e3[1], e3[2]);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) bq[q][gate][blk] = __builtin_bit_cast(bf16x8g_t, make_uint4(e0[q], e1[q], e2[q], e3[q]));
+                }
+        } else {
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+                for (int jl = 0; jl < TPW; ++jl) {
+                    const float4 v = *reinterpret_cast<const float4*>(&sg[lb * LDG + gate * 64 + 16 * jl + 4 * g]);
+                    bop[gate * TPW + jl] = SPL ? split_pack4(v) : v;
+                }
+        }
         const unsigned tag = tag0 + (unsigned)(s + 1);
         HA2G_BWD_KTILE((Q + 1) % G)
         HA2G_BWD_KTILE((Q + 2) % G)
@@ -793,6 +876,11 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
         for (int src = 0; src < G; ++src) { gx0[src] = u32x4{0u, 0u, 0u, 0u}; gx1[src] = gx0[src]; }
         if (wave + Q * TPW < NJT) {
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+            if constexpr (AR == 3) {
+                HA2G_BWD_MFMA3(Q, 0)
+                HA2G_BWD_GATHER_ISSUE                          // the gather loads travel under the second block's 18 MFMAs
+                HA2G_BWD_MFMA3(Q, 1)
+            } else
 #pragma unroll
             for (int jl = 0; jl < TPW; ++jl) {
                 const float* w0 = &wf[(Q * 3 + 0) * TPW + jl].x; const float* w1 = &wf[(Q * 3 + 1) * TPW + jl].x;
@@ -850,7 +938,7 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
     }
 }
 
-template <bool SPL>
+template <int AR>
 __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __restrict__ dy,      // [B][T][2H]
                                                                 const float* __restrict__ y,       // [B][T][2H]
                                                                 const float* __restrict__ rs,      // [B][T][2][4][H]
@@ -858,7 +946,9 @@ __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __r
                                                                 float* __restrict__ dg,            // [B][T][2][4H]
                                                                 float* __restrict__ hpo,           // [B][T][2H] h_prev per step (nullable)
                                                                 u64* __restrict__ xch, const unsigned* __restrict__ epoch, unsigned host_tag0,
-                                                                int* __restrict__ err, int B, int T, int tile0, int nclusters, int dbg) {
+                                                                int* __restrict__ err, int B, int T, int tile0, int nclusters, int dbg,
+                                                                const uint4* __restrict__ wp3t) {  // AR = 3: three-piece transposed images
+    extern __shared__ __attribute__((aligned(1024))) unsigned char bwd_lds3[];                    // AR = 3: TPW * W2_WAVE bytes (piece 2 of W)
     __shared__ __attribute__((aligned(16))) float sg[16 * LDG];
     __shared__ __attribute__((aligned(16))) float sp[16 * LDP];
     __shared__ int sh[8];
@@ -869,7 +959,7 @@ __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __r
     u64* xc = xch + (long)c * CL_GRAN;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xc, 0, (int)(CL_GRAN * 8), 0x00020000);
     const unsigned tag0 = epoch ? (0x80000000u | (*epoch << 6)) : host_tag0;
-#define HA2G_BWD_CALL(QQ, PP) gru_bwd_member<QQ, PP, SPL>(dy, y, rs, wpt, dg, hpo, xr, err, B, T, dir, b0, tag0, sh, dbg, sg, sp)
+#define HA2G_BWD_CALL(QQ, PP) gru_bwd_member<QQ, PP, AR>(dy, y, rs, wpt, dg, hpo, xr, err, B, T, dir, b0, tag0, sh, dbg, sg, sp, wp3t, bwd_lds3)
 #define HA2G_BWD_SWITCH(PP)                                                                                       \
     switch (q) {                                                                                                  \
         case 0: HA2G_BWD_CALL(0, PP); break; case 1: HA2G_BWD_CALL(1, PP); break; case 2: HA2G_BWD_CALL(2, PP); break; \
@@ -1009,9 +1099,19 @@ int ha2g_gru_layer_fwd_cluster3(const float* gi, const void* wp3, const float* b
 }
 
 // BPTT counterpart (same contract as ha2g_gru_layer_bwd, H = 300 only); wpt = packed backward images of both directions.
-int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, float* hp, void* xch, int* err,
-                               int B, int T, int H_, void* stream) {
+static int gru_bwd_cluster_launch(const float* dy, const float* y, const float* rs, const float* wpt, const void* wp3t, float* dg, float* hp, void* xch,
+                                  int* err, int B, int T, int H_, void* stream) {
     HA2G_REQUIRE(H_ == H, "gru cluster kernel: H=%d not instantiated (300)", H_);
+    if (wp3t != nullptr) {
+        static bool attr_set[64] = {false};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!attr_set[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_cluster_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, TPW * W2_WAVE) != hipSuccess)
+                return ha2g_set_error(-2, "gru_bwd_cluster3: cannot raise the dynamic LDS limit to %d bytes", TPW * W2_WAVE);
+            attr_set[dev] = true;
+        }
+    }
     HA2G_REQUIRE(T <= MAX_STEPS, "gru cluster kernel: T=%d > %d steps", T, MAX_STEPS);
     const int cap = device_tile_cap();
     HA2G_REQUIRE(cap >= 1, "gru cluster kernel: the device has fewer than %d compute units", 2 * G);
@@ -1024,13 +1124,32 @@ int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs,
         unsigned host_tag0 = 0;
         const unsigned* epoch = launch_tag_base(xch, st, &host_tag0);
         const int grid = ceil_div(nclusters, 8) * 8 * G;
-        if (gemm_split_dgrad_enabled() && gemm_bwd_pieces() == 2)     // two-piece split chain (mode 6); exact fp32 in mode 0 AND in the fp32-class default (three pieces of the resident W_hh slice do not fit the register file)
-            hipLaunchKernelGGL(gru_bwd_cluster_kernel<true>, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg);
+        if (wp3t != nullptr)
+            hipLaunchKernelGGL(gru_bwd_cluster_kernel<3>, dim3(grid), dim3(NT), TPW * W2_WAVE, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg, (const uint4*)wp3t);
+        else if (gemm_split_dgrad_enabled() && gemm_bwd_pieces() == 2)     // two-piece split chain (mode 6); exact fp32 in mode 0
+            hipLaunchKernelGGL(gru_bwd_cluster_kernel<2>, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg, (const uint4*)nullptr);
         else
-            hipLaunchKernelGGL(gru_bwd_cluster_kernel<false>, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg);
+            hipLaunchKernelGGL(gru_bwd_cluster_kernel<0>, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg, (const uint4*)nullptr);
         HA2G_CHECK_LAUNCH("gru_layer_bwd_cluster");
     }
     return 0;
+}
+int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, float* hp, void* xch, int* err,
+                               int B, int T, int H_, void* stream) {
+    return gru_bwd_cluster_launch(dy, y, rs, wpt, nullptr, dg, hp, xch, err, B, T, H_, stream);
+}
+// three-piece BPTT chain (fp32-class, the default since round 4): wp3t = both directions' transposed three-piece W_hh images
+// (ha2g_gru_pack_whh3t, direction d at byte offset d * ha2g_gru_packed3_bytes())
+int ha2g_gru_pack_whh3t(const float* w_hh, void* out, int H_, void* stream) {
+    HA2G_REQUIRE(H_ == H, "gru_pack_whh3t: H=%d not instantiated (300)", H_);
+    hipLaunchKernelGGL(pack_whh3t_kernel, dim3(ceil_div(NJT * 3 * NKB * 64, 256)), dim3(256), 0, (hipStream_t)stream, w_hh, (uint4*)out);
+    HA2G_CHECK_LAUNCH("gru_pack_whh3t");
+    return 0;
+}
+int ha2g_gru_layer_bwd_cluster3(const float* dy, const float* y, const float* rs, const void* wp3t, float* dg, float* hp, void* xch, int* err,
+                                int B, int T, int H_, void* stream) {
+    HA2G_REQUIRE(wp3t != nullptr, "gru_layer_bwd_cluster3: null weight image");
+    return gru_bwd_cluster_launch(dy, y, rs, nullptr, wp3t, dg, hp, xch, err, B, T, H_, stream);
 }
 
 }  // extern "C"

@@ -902,8 +902,12 @@ class Ha2gClusterError(RuntimeError):
     pass
 
 
-def _gru_layer_bwd(dy, y, rs, pkt, dg, hp, B, T, H, st, device):
-    if USE_GRU_CLUSTER and lib.ha2g_gru_cluster_supported(H) and T <= lib.ha2g_gru_cluster_max_steps():
+def _gru_layer_bwd(dy, y, rs, pkt, dg, hp, B, T, H, st, device, pk3t=None):
+    if pk3t is not None:
+        xch, err = _cluster_scratch(device)
+        check(lib.ha2g_gru_layer_bwd_cluster3(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pk3t.data_ptr(), dg.data_ptr(), hp.data_ptr(), xch.data_ptr(),
+                                              err.data_ptr(), B, T, H, st))
+    elif USE_GRU_CLUSTER and lib.ha2g_gru_cluster_supported(H) and T <= lib.ha2g_gru_cluster_max_steps():
         xch, err = _cluster_scratch(device)
         check(lib.ha2g_gru_layer_bwd_cluster(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pkt.data_ptr(), dg.data_ptr(), hp.data_ptr(), xch.data_ptr(),
                                              err.data_ptr(), B, T, H, st))
@@ -1032,8 +1036,14 @@ class BiGRUFunction(torch.autograd.Function):
             dg = torch.empty(B * T, 8 * H, dtype=torch.float32, device=dev)        # [dir][r z n hn]
             # h_prev per direction (forward dir: y[t-1], reverse dir: y[t+1], zero at the sequence ends) is written by the BPTT kernel
             hp = torch.empty(B, T, 2 * H, dtype=torch.float32, device=dev)
+            pk3t = None
+            if gru_fwd3_active(H, T):                      # the BPTT chain on three pieces too: transposed W_hh images of both directions
+                n3 = lib.ha2g_gru_packed3_bytes()
+                pk3t = torch.empty(2, n3, dtype=torch.uint8, device=dev)
+                check(lib.ha2g_gru_pack_whh3t(w[1].data_ptr(), pk3t[0].data_ptr(), H, st))
+                check(lib.ha2g_gru_pack_whh3t(w[5].data_ptr(), pk3t[1].data_ptr(), H, st))
             ktimer.launch('gru_layer_bwd' if H == 300 else 'gru_layer_bwd_other',
-                          lambda: _gru_layer_bwd(dy, y, rs, ctx.packs[l][2], dg, hp, B, T, H, st, dev), B)
+                          lambda: _gru_layer_bwd(dy, y, rs, ctx.packs[l][2], dg, hp, B, T, H, st, dev, pk3t), B)
             K = inp.shape[2]
             x2 = inp.view(B * T, K)
             hp2 = hp.view(B * T, 2 * H)

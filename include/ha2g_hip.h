@@ -237,6 +237,10 @@ long ha2g_gru_packed3_bytes(void);
 int ha2g_gru_pack_whh3(const float* w_hh, void* out, int H, void* stream);
 int ha2g_gru_layer_fwd_cluster3(const float* gi, const void* wp3, const float* bhh_fwd, const float* bhh_rev, float* y, float* rs,
                                 void* xch, int* err, int B, int T, int H, void* stream);
+/* the BPTT twin on three pieces: wp3t = the transposed images (ha2g_gru_pack_whh3t); contract of ha2g_gru_layer_bwd_cluster otherwise */
+int ha2g_gru_pack_whh3t(const float* w_hh, void* out, int H, void* stream);
+int ha2g_gru_layer_bwd_cluster3(const float* dy, const float* y, const float* rs, const void* wp3t, float* dg, float* hp, void* xch, int* err,
+                                int B, int T, int H, void* stream);
 int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, float* hp, void* xch,
                                int* err, int B, int T, int H, void* stream);
 /* ablation bits for tools/dbg_cluster.py: 1 no wait, 2 no exchange, 4 force the write-through publish */

@@ -267,18 +267,20 @@ def test_gru_cluster_backward_matches(B):
     x0 = rnd((B, T, In), 9).to(dev)
     wy = rnd((B, T, 2 * H), 10).to(dev)
     res = []
-    for use in (False, True):
-        ops.USE_GRU_CLUSTER = use
+    for use, fwd3 in ((False, False), (True, False), (True, True)):       # gru.hip / fp32 cluster chains / three-piece cluster chains (round 4)
+        ops.USE_GRU_CLUSTER, old3 = use, ops.GRU_FWD3
+        ops.GRU_FWD3 = fwd3
         try:
             x = x0.clone().requires_grad_(True)
             flat = [w.clone().requires_grad_(True) for w in ws]
             yy = ops.bigru(x, flat, H)
             res.append(torch.autograd.grad((yy * wy).sum(), [x] + flat))
         finally:
-            ops.USE_GRU_CLUSTER = True
+            ops.USE_GRU_CLUSTER, ops.GRU_FWD3 = True, old3
     assert ops.gru_cluster_error(dev) == 0
-    for a, b in zip(*res):
+    for a, b, c in zip(*res):
         assert relerr(a, b.cpu()) < 2e-5
+        assert relerr(c, b.cpu()) < 2e-5                     # fp32-class: the same closeness to the fp32 chains as they have to each other
 
 
 def test_split_bf16_core_opt_in():

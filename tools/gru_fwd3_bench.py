@@ -51,3 +51,20 @@ for B in (384, 128):
     f32(); f3()
     torch.cuda.synchronize()
     print('       max |y3 - y32| / max |y32| = %.3e; err word %d' % (float((y3 - y).abs().max() / y.abs().max()), int(err.item())))
+    # ---- BPTT twin on the same rows ----
+    dy = torch.randn(B, T, 2 * H, device=dev) * 0.1
+    dg, hp, dg3 = torch.empty(B * T, 8 * H, device=dev), torch.empty(B, T, 2 * H, device=dev), torch.empty(B * T, 8 * H, device=dev)
+    pk3t = torch.empty(2, lib.ha2g_gru_packed3_bytes(), dtype=torch.uint8, device=dev)
+    for d in range(2):
+        check(lib.ha2g_gru_pack_whh3t(whh[d].data_ptr(), pk3t[d].data_ptr(), H, st))
+    lib.ha2g_gemm_set_mode(0)
+    b32 = lambda: check(lib.ha2g_gru_layer_bwd_cluster(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pk[2].data_ptr(), dg.data_ptr(), hp.data_ptr(), xch.data_ptr(), err.data_ptr(), B, T, H, st))
+    b3 = lambda: check(lib.ha2g_gru_layer_bwd_cluster3(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pk3t.data_ptr(), dg3.data_ptr(), hp.data_ptr(), xch.data_ptr(), err.data_ptr(), B, T, H, st))
+    for name, fn in (('BPTT fp32 chain', b32), ('BPTT three-piece chain', b3)):
+        us = t_us(fn)
+        print('%-6d %-28s %10.1f %10.2f %10.1f %12.3f' % (B, name, us, us / T, flops / us / 1e6, flops / us / 1e6 / 157.3))
+    b32(); b3()
+    torch.cuda.synchronize()
+    print('       max |dg3 - dg32| / max |dg32| = %.3e; err word %d' % (float((dg3 - dg).abs().max() / dg.abs().max()), int(err.item())))
+    from ha2g_amd._lib import DEFAULT_GEMM_MODE
+    lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
