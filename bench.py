@@ -303,7 +303,7 @@ def main():
         import hashlib
         src_sha = hashlib.sha256(open(os.path.join(ROOT, 'ha2g_amd', 'csrc', 'gru_cluster.hip'), 'rb').read()).hexdigest()
 
-        def gru_roof(key, kernel, pmc_name, bwd):
+        def gru_roof(key, kernel, pmc_name, bwd, three):
             if key not in kt:
                 return None
             n, mean_us, rows = kt[key][:3]                                     # rows = batch rows per launch
@@ -320,15 +320,24 @@ def main():
                 if pm.get('batch_rows') == rows:
                     traffic, tsrc = pm['hbm_bytes_per_launch'], 'profiles/%s (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)' % pmc_name
                     stale = pm.get('source_sha256') != src_sha     # the kernel source changed since the counters were collected
-            return dict(kernel=kernel, bound='mfma', achieved=round(ach, 3), peak=157.3, unit='TFLOP/s', frac=round(ach / 157.3, 4),
+            # three-piece chains execute 6 bf16 MFMA products per fp32-equivalent product: their roofline is the dense bf16 peak / 6 (the same
+            # convention as roofline_conv); the fraction of the fp32 MFMA peak -- what the fp32 form of the same kernel is priced against -- rides along
+            peak = round(2500.0 / 6, 1) if three else 157.3
+            return dict(kernel=kernel, bound='mfma', achieved=round(ach, 3), peak=peak,
+                        unit='TFLOP/s (fp32-equivalent: 6 bf16 MFMAs per product)' if three else 'TFLOP/s', frac=round(ach / peak, 4),
+                        frac_of_fp32_mfma_peak=round(ach / 157.3, 4),
+                        arithmetic='three-piece bf16 split of W_hh and h, fp32 accumulate (fp32-class: all 24 mantissa bits)' if three else 'fp32 MFMA',
                         traffic=traffic, traffic_source=tsrc, traffic_stale=stale, algorithmic_bytes=bytes_,
                         traffic_over_algorithmic=(round(traffic / bytes_, 3) if traffic else None), launches=n, mean_us=round(mean_us, 1),
                         batch_rows=rows, us_per_timestep=round(mean_us / T, 2), hbm_GBps_algorithmic=round(bytes_ / (mean_us * 1e-6) / 1e9, 1),
                         hbm_frac_of_8TBps=round(bytes_ / (mean_us * 1e-6) / 8e12, 4))
-        roof = gru_roof('gru_layer_fwd', 'gru_fwd_cluster_kernel (ha2g_gru_layer_fwd_cluster, H=300)', 'r04_pmc_gru_fwd.json', False)
-        roof_bwd = gru_roof('gru_layer_bwd', 'gru_bwd_cluster_kernel (ha2g_gru_layer_bwd_cluster, H=300)', 'r04_pmc_gru_bwd.json', True)
-        if roof_bwd is not None:     # the BPTT chain runs on the split-bf16 inner product in the default mode (3 bf16 MFMAs per product term, fp32 accumulate);
-            roof_bwd['arithmetic'] = 'split-bf16 x2 (16-bit operand mantissa; frac is still priced against the fp32 MFMA peak)' if bwd_pieces == 2 else 'fp32 MFMA'
+        three = ops.gru_fwd3_active(H, T)                  # default mode: both recurrent chains on three bf16 pieces (gru_fwd_cluster3_kernel, gru_bwd_cluster_kernel<3>)
+        roof = gru_roof('gru_layer_fwd', ('gru_fwd_cluster3_kernel (ha2g_gru_layer_fwd_cluster3, H=300)' if three else
+                                          'gru_fwd_cluster_kernel (ha2g_gru_layer_fwd_cluster, H=300)'), 'r04_pmc_gru_fwd.json', False, three)
+        roof_bwd = gru_roof('gru_layer_bwd', ('gru_bwd_cluster_kernel<3> (ha2g_gru_layer_bwd_cluster3, H=300)' if three else
+                                              'gru_bwd_cluster_kernel (ha2g_gru_layer_bwd_cluster, H=300)'), 'r04_pmc_gru_bwd.json', True, three)
+        if roof_bwd is not None and not three and bwd_pieces == 2:     # mode 6: the BPTT chain on the two-piece split (3 bf16 MFMAs per product term, fp32 accumulate)
+            roof_bwd['arithmetic'] = 'split-bf16 x2 (16-bit operand mantissa; frac is still priced against the fp32 MFMA peak)'
         roof_gemm = None
         if 'gemm_gi' in kt:                        # dominant dense-GEMM shape: the GRU input projections (rows x 600) . (600 x 900)^T, fp32 MFMA
             n, mean_us, _, flops = kt['gemm_gi']

@@ -16,7 +16,9 @@ def cat(n):
     if 'gemm_x3_kernel' in n:
         mm = re.search(r'ILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)', n)
         return 'conv dgrad (split implicit GEMM, gemm_x3)' if int(mm.group(5)) == 2 else 'dense GEMM'
-    for key, name in (('pconv_kernel', 'conv fwd + dgrad (planes, DMA-staged)'), ('pconv_pp_kernel', 'conv fwd + dgrad (planes, DMA-staged)'), ('pconv_wgrad', 'conv wgrad (planes, DMA-staged)'),
+    for key, name in (('pconv_q_kernel', 'plane kernel (conv fwd / dgrad + large dense products, 16x16x32)'), ('pack_whh', 'layout (shuffle/pack/permute)'),
+                      ('se_mlp', 'SE pointwise'), ('gen_concat', 'pointwise (act bwd, adds, masks)'), ('step_inc', 'Adam'),
+                      ('pconv_kernel', 'conv fwd + dgrad (planes, DMA-staged)'), ('pconv_pp_kernel', 'conv fwd + dgrad (planes, DMA-staged)'), ('pconv_wgrad', 'conv wgrad (planes, DMA-staged)'),
                       ('weight_ihwo_planes', 'layout (shuffle/pack/permute)'), ('f32_to_planes', 'layout (shuffle/pack/permute)'),
                       ('conv3x3_c32_wgrad', 'conv 32ch direct (fwd / dgrad / wgrad)'), ('conv3x3_c32_kernel', 'conv 32ch direct (fwd / dgrad / wgrad)'),
                       ('conv3x3_x3_kernel', 'conv 32ch direct (fwd / dgrad / wgrad)'), ('pool_final', 'SE pointwise'), ('transpose_batched', 'layout (shuffle/pack/permute)'),
