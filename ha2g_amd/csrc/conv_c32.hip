@@ -525,11 +525,13 @@ int conv3x3_c32_launch(const float* x, const float* w, float* y, int N, int H, i
     const int patch_floats = rows_max * (W + 2) * CS;
     const size_t lds = (size_t)2 * patch_floats * sizeof(float);
     if (lds > 150 * 1024 || (long)H * W < TP || rows_max * (W + 2) * 8 > 8 * NT || W + 2 <= 64) return -100;   // one workgroup per CU, 8 slots per thread
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {false};                  // per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
             return ha2g_set_error(-2, "conv3x3_c32: cannot raise the dynamic LDS limit");
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const long tiles = (long)N * (((long)H * W + TP - 1) / TP);
     const int grid = (int)(tiles < 256 ? tiles : 256);

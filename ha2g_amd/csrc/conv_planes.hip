@@ -156,6 +156,7 @@ struct PConvP {
     int dbg;                                                     // timing ablations (ha2g_conv_planes_debug): 1 = no DMA after tile 0, 2 = no MFMA
     // dense use (plane_gemm_launch: C = A B^T as a 1x1 "convolution" over M pixels; pconv_q_kernel only)
     const float* bias; int act;                                  // epilogue: + bias[col], act 0 none / 1 relu (= relu) / 2 leaky-relu(0.01)
+    int kmaj;                                                    // pconv_q_kernel: 1 = channel-major k order (default), 0 = tap-major (ha2g_conv_planes_korder)
     int ksplit, kt_per;                                          // split-K over blockIdx.z (ncls == 1): k tiles [z * kt_per, ..) -> raw partial slab z of ws
     float* ws;                                                   // [ksplit][M][N]
 };
@@ -731,9 +732,19 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
     const unsigned short* zero = g_zero_page;
     unsigned char* const a_lds = smem + grp * 2 * A_STAGE;
 
+    // k tile -> (tap, first channel).  Split products walk the k axis CHANNEL-major -- the nine taps of one 32-channel slice back to back: a tap
+    // re-reads the pixels of the previous one shifted by a pixel or a row, so the re-read now follows within one k tile and hits the XCD's L2.
+    // Tap-major (all channels of tap 0, then tap 1, ...) put 4-8 k tiles of every workgroup of the XCD between them: at C = 128 the PMC showed
+    // 470 MB fetched past L2 per launch for 57 MB of operands (profiles/r04_pmc_step_bytes_b128_before_korder.txt).  The one-piece kernel of the
+    // bf16-storage mode keeps the tap-major order (its fixtures are pinned to that summation order).
+    auto k_of = [&](int kt, int& ti, int& c0) {
+        if (NP >= 2 && p.kmaj) { const int cc = kt / pc.ntaps; ti = kt - cc * pc.ntaps; c0 = cc << 5; }
+        else { ti = kt / nkc; c0 = (kt - ti * nkc) << 5; }
+    };
     auto stage_a = [&](int kl) {                                 // kl = k tile index local to this workgroup's range
         const int kt = kt0 + kl;
-        const int ti = kt / nkc, c0 = (kt - ti * nkc) << 5;
+        int ti, c0;
+        k_of(kt, ti, c0);
         const unsigned koff = (unsigned)(c0 + (long)pc.doff[ti] * p.GC);
         const unsigned bit = 1u << ti;
         unsigned char* dst = a_lds + (kl & 1) * A_STAGE;
@@ -750,7 +761,8 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
     };
     auto stage_b = [&](int kl) {
         const int kt = kt0 + kl;
-        const int ti = kt / nkc, c0 = (kt - ti * nkc) << 5;
+        int ti, c0;
+        k_of(kt, ti, c0);
         const long kb = (long)pc.tap[ti] * p.GC + c0;
         unsigned char* dst = smem + B_BASE + (kl & 1) * B_STAGE;
 #pragma unroll
@@ -1197,12 +1209,14 @@ static int g_ring = 0;       // ha2g_conv_planes_ring: 0 = default depth per til
 template <int BM, int BN, int WM, int WN, int NP, int OUT, int S>
 static int pconv_launch_s(const PConvP& p, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)S * NP * (BM * 64 + BN * 64);
-    static bool attr_set = false;                                // per instantiation
-    if (!attr_set) {
+    static bool attr_set[64] = {false};                          // per instantiation and per device (the attribute belongs to the device's code object)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
         if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_kernel<BM, BN, WM, WN, NP, OUT, S>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ha2g_set_error(-2, "pconv: cannot raise the dynamic LDS limit to %zu bytes", lds);
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL((pconv_kernel<BM, BN, WM, WN, NP, OUT, S>), grid, dim3(64 * WM * WN), lds, st, p);
     return 0;
@@ -1235,6 +1249,7 @@ static int pconv_pp_launch(const PConvP& p, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((pconv_pp_kernel<BN, NP, OUT>), grid, dim3(512), lds, st, p);
     return 0;
 }
+static int g_kmaj = 1;       // k order of the q kernel's split products: 1 = channel-major (the nine taps of a 32-channel slice back to back), 0 = tap-major
 static int g_q_kernel = 1;   // the quantisation-free 16x16 kernel where its tile choice fills the CUs better (ha2g_conv_planes_tile3(5) forces, (6) = off)
 template <int MT, int BN, int NP>
 static int pconv_q_launch(const PConvP& p, dim3 grid, hipStream_t st) {
@@ -1272,7 +1287,9 @@ static double pconv_q_plan(int M, int N, int ksplit, int* pmt, int* pbn) {
     return best;
 }
 template <int NP>
-static int pconv_q_dispatch(const PConvP& p, int maxM, hipStream_t st) {
+static int pconv_q_dispatch(const PConvP& p_in, int maxM, hipStream_t st) {
+    PConvP p = p_in;
+    p.kmaj = g_kmaj;
     if (p.ncls != 1) return -100;                                // stride-2 data gradients (parity classes of different sizes) keep the 32x32 kernels
     int bmt = 0, bbn = 0;
     pconv_q_plan(maxM, p.N, p.ksplit > 1 ? p.ksplit : 1, &bmt, &bbn);
@@ -1373,6 +1390,7 @@ void ha2g_conv_planes_enable(int on) { g_planes = on; }
 void ha2g_conv_planes_debug(int bits) { g_pdbg = bits; }
 void ha2g_conv_planes_ring(int depth) { g_ring = depth; }
 void ha2g_conv_planes_waves(int n) { g_waves = n == 8 ? 8 : 4; }
+void ha2g_conv_planes_korder(int channel_major) { g_kmaj = channel_major ? 1 : 0; }
 void ha2g_conv_planes_tile3(int t) { if (t == 6) { g_q_kernel = 0; g_tile3 = 0; } else { g_q_kernel = 1; g_tile3 = (t >= 0 && t <= 5) ? t : 0; } }
 
 // fp32 -> np bf16 piece planes of the same shape (piece q at planes + q * ps elements); n % 4 == 0, 16-byte aligned, ps % 8 == 0

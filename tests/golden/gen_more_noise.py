@@ -7,6 +7,7 @@ deviation from the STORED float64 truth and raises `@noise` where a new run devi
 only grow, and only by what the reference itself does.  Container-only (imports /root/reference through gen_golden.py).
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_more_noise.py cfg3_b128 [NEXTRA=8] [first draw=5]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_more_noise.py enc16 60 9        (the B=16 whole-encoder fixture: 9 runs so far)
 """
 import os
 import sys
@@ -23,7 +24,7 @@ from ha2g_amd.config import BIG_CASES  # noqa: E402
 name = sys.argv[1]
 nextra = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-case = BIG_CASES[name]
+case = BIG_CASES.get(name)                               # None: one of gen_golden.EXTRA's well-conditioned fixtures (enc16, blocks, ...)
 path = os.path.join(HERE, name + '.npz')
 fix = dict(np.load(path))
 grown = 0
@@ -31,7 +32,11 @@ for i in range(nextra):
     G.PERTURB_DRAW = first + i
     o = {}
     t0 = time.time()
-    G.step_goldens(case, o, torch.float32, expressive=bool(case.get('expressive')), perturb=6e-8, perturb_text=True)
+    if case is not None:
+        G.step_goldens(case, o, torch.float32, expressive=bool(case.get('expressive')), perturb=6e-8, perturb_text=True)
+    else:
+        for fn in G.EXTRA[name]:
+            fn(o, torch.float32, perturb=6e-8)
     n = 0
     for k, v in o.items():
         if k not in fix or k + '@noise' not in fix:
@@ -43,6 +48,6 @@ for i in range(nextra):
     grown += n
     print('draw %d: %.0f s, %d of %d noise floors raised' % (first + i, time.time() - t0, n, len(o)), flush=True)
     np.savez_compressed(path, **fix)                      # after every run: an interrupted study keeps what it has measured
-fix['noise_runs'] = np.float64(float(fix.get('noise_runs', 5)) + nextra)
+fix['noise_runs'] = np.float64(float(fix.get('noise_runs', 5 if case is not None else 9)) + nextra)
 np.savez_compressed(path, **fix)
 print('wrote', path, '(%d floors raised in total)' % grown)

@@ -233,3 +233,41 @@ def test_sparse_row_gather_with_an_idle_rank(tmp_path):
     out = str(tmp_path / 'spe.pt')
     mp.spawn(_sparse_empty_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert torch.load(out)['ok']
+
+
+def _flag_worker(rank, world, port, out):
+    """Round 4: ddp.sync_flag_ (MAX of the cluster-GRU error word: every replica skips a flagged step, or none does) and the touched-row count that is
+    exchanged one step ahead (ddp.prefetch_max_count -> gather_sparse_rows(max_count=...): same result as the count exchange inside the gather)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ha2g_amd import ddp
+    res = {}
+    for name, mine in (('none', 0), ('rank1_only', 7 if rank == 1 else 0), ('both', 3 + rank)):
+        flag = torch.tensor([mine], dtype=torch.int32)
+        ddp.sync_flag_(flag)
+        res[name] = int(flag.item())
+    ddp.sync_flag_(None)                                     # no error word on this device: a no-op, not a collective
+    # prefetched maximum of the per-rank row counts, then the gather sized by it
+    cap, C = 9, 4
+    g = torch.Generator().manual_seed(5 + rank)
+    n = 3 if rank == 0 else 6
+    ids = torch.zeros(cap, dtype=torch.int64); ids[:n] = torch.randperm(50, generator=g)[:n] + 1
+    rows = torch.zeros(cap, C); rows[:n] = torch.randn(n, C, generator=g)
+    count = torch.tensor(n, dtype=torch.int32)
+    h = ddp.prefetch_max_count(count)
+    res['max_count'] = h.value()
+    a_ids, a_rows = ddp.gather_sparse_rows(ids, count, rows, max_count=h)
+    b_ids, b_rows = ddp.gather_sparse_rows(ids, count, rows)
+    res['same'] = bool(torch.equal(a_ids, b_ids) and torch.equal(a_rows, b_rows))
+    res['shape'] = tuple(a_ids.shape)
+    torch.save(res, out + '.r%d' % rank)
+    dist.destroy_process_group()
+
+
+def test_error_flag_and_prefetched_row_count_two_ranks(tmp_path):
+    out = str(tmp_path / 'flag.pt')
+    mp.spawn(_flag_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + '.r0'), torch.load(out + '.r1')
+    assert r0 == r1                                          # both replicas see the same flags and the same gathered rows
+    assert r0['none'] == 0 and r0['rank1_only'] == 7 and r0['both'] == 4
+    assert r0['max_count'] == 6 and r0['shape'] == (12,) and r0['same']

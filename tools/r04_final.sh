@@ -26,5 +26,10 @@ print('${f}', d['ms_per_step'], d['value'], d['launch'], 'eager', d['eager']['ms
       'roof', d['roofline']['frac'] if d['roofline'] else None, d['roofline'].get('traffic_stale') if d['roofline'] else None)
 PY
 done
+python tools/bwd_matrix_bench.py 2>/dev/null | grep -E "^(mode|70|6 |0 )" > gpurun_out/r04_bwd_matrix_bench.txt
+python tools/planes_ablate.py 2>/dev/null | grep -E "^(shape|B=)" > gpurun_out/r04_planes_ablate.txt
+python tools/gru_fwd3_bench.py 2>/dev/null | grep -vE "Warn|amdgpu" > gpurun_out/r04_gru_fwd3_bench.txt
+python tools/korder_check.py 2>/dev/null | grep Cin > gpurun_out/r04_korder_check.txt
+bash tools/pmc_q.sh r04 > /dev/null 2>&1
 cat gpurun_out/r04_bench_b128_kernel_families.txt
 cat gpurun_out/r04_bench_b128_queues.txt
