@@ -143,6 +143,8 @@ struct PClass {
     int ntaps, kh0, kw0;                                         // taps of the class; first valid kh / kw
     int tap[9];                                                  // filter tap index kh * KW + kw
     int doff[9];                                                 // source offset of the tap relative to the first one, in pixels of the dy grid (<= 0)
+    unsigned char khs[12], kws[12];                              // pconv_q_kernel: (kh, kw) of each tap (host-filled: no division by KW per tap and lane)
+    unsigned mg_ow, mg_oh;                                       // pconv_q_kernel: ceil(2^32 / OWc), ceil(2^32 / OHc) (0 when the divisor is 1): fast_div
 };
 struct PConvP {
     PlaneSet a;                                                  // dy planes [img][GH][GW][GC] (piece q at a.p + q * a.ps)
@@ -156,12 +158,21 @@ struct PConvP {
     int dbg;                                                     // timing ablations (ha2g_conv_planes_debug): 1 = no DMA after tile 0, 2 = no MFMA
     // dense use (plane_gemm_launch: C = A B^T as a 1x1 "convolution" over M pixels; pconv_q_kernel only)
     const float* bias; int act;                                  // epilogue: + bias[col], act 0 none / 1 relu (= relu) / 2 leaky-relu(0.01)
+    int vec;                                                     // pconv_q_kernel: 16-byte output stores allowed (N % 4 == 0, ldc % 4 == 0, aligned pointers)
+    int buf, a_bytes, b_bytes;                                   // pconv_q_kernel: buffer-addressed DMA (ha2g_conv_planes_bufaddr) and the byte size of one piece plane of A / B
     int kmaj;                                                    // pconv_q_kernel: 1 = channel-major k order (default), 0 = tap-major (ha2g_conv_planes_korder)
     int ksplit, kt_per;                                          // split-K over blockIdx.z (ncls == 1): k tiles [z * kt_per, ..) -> raw partial slab z of ws
     float* ws;                                                   // [ksplit][M][N]
 };
 
 // XCD-aware workgroup -> tile mapping (same rule as gemm.hip's tile_of_block: XCD x owns a contiguous eighth of the tile sequence, n fastest)
+// m / d for 0 <= m < 2^31 with mg = ceil(2^32 / d) (0 for d = 1): the estimate umulhi(m, mg) is the quotient or one more; one correction makes it exact
+__device__ __forceinline__ int fast_div(int m, int d, unsigned mg) {
+    if (mg == 0u) return m;
+    int q = (int)__umulhi((unsigned)m, mg);
+    if (q * d > m) --q;
+    return q;
+}
 __device__ __forceinline__ void ptile_of_block(int& bx, int& by) {
     const int nbx = gridDim.x, nby = gridDim.y, total = nbx * nby;
     const int lin = blockIdx.y * nbx + blockIdx.x;
@@ -699,23 +710,26 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
         const int m = m0 + tile * 16 + srow;
         a_mask[i] = 0u; a_off[i] = 0u;
         if (tile < MT && m < pc.M) {
-            const int oxc = m % pc.OWc; const int t = m / pc.OWc; const int oyc = t % pc.OHc; const int img = t / pc.OHc;
+            // (the first version divided by OWc / OHc / KW / stride per row and tap here: ~2 000 instructions per lane, 36 of the 162 us of a
+            //  64-channel launch went into launch + prologue -- tools/planes_ablate.py, columns "no k loop")
+            const int t = fast_div(m, pc.OWc, pc.mg_ow), oxc = m - t * pc.OWc;
+            const int img = fast_div(t, pc.OHc, pc.mg_oh), oyc = t - img * pc.OHc;
             long base;
             if (p.fwd) {
                 const int sy0 = oyc * p.stride - p.pad, sx0 = oxc * p.stride - p.pad;
                 base = (((long)img * p.GH + sy0) * p.GW + sx0) * p.GC;
                 for (int ti = 0; ti < pc.ntaps; ++ti) {
-                    const int kh = pc.tap[ti] / p.KW, kw = pc.tap[ti] - kh * p.KW;
+                    const int kh = pc.khs[ti], kw = pc.kws[ti];
                     if (sy0 + kh >= 0 && sy0 + kh < p.GH && sx0 + kw >= 0 && sx0 + kw < p.GW) a_mask[i] |= 1u << ti;
                 }
-            } else {
+            } else {                                             // data gradient (stride 1, or the single live parity class of a stride-2 1x1 convolution)
+                const int sh = p.stride >> 1;                    // stride 1 / 2: u - kh is a multiple of the stride for every tap of the class
                 const int u = oyc * p.stride + pc.py + p.pad, v = oxc * p.stride + pc.px + p.pad;
-                const int sy0 = (u - pc.kh0) / p.stride, sx0 = (v - pc.kw0) / p.stride;
+                const int sy0 = (u - pc.kh0) >> sh, sx0 = (v - pc.kw0) >> sh;
                 base = (((long)img * p.GH + sy0) * p.GW + sx0) * p.GC;
                 for (int ti = 0; ti < pc.ntaps; ++ti) {
-                    const int kh = pc.tap[ti] / p.KW, kw = pc.tap[ti] - kh * p.KW;
-                    const int sy = (u - kh) / p.stride, sx = (v - kw) / p.stride;
-                    if (u - kh >= 0 && v - kw >= 0 && sy < p.GH && sx < p.GW) a_mask[i] |= 1u << ti;
+                    const int dy_ = u - pc.khs[ti], dx_ = v - pc.kws[ti];
+                    if (dy_ >= 0 && dx_ >= 0 && (dy_ >> sh) < p.GH && (dx_ >> sh) < p.GW) a_mask[i] |= 1u << ti;
                 }
             }
             // masked-in taps address inside the plane; the offset of tap (0, 0) may be "negative" at the border: kept modulo 2^32 and added to the
@@ -737,40 +751,63 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
     // Tap-major (all channels of tap 0, then tap 1, ...) put 4-8 k tiles of every workgroup of the XCD between them: at C = 128 the PMC showed
     // 470 MB fetched past L2 per launch for 57 MB of operands (profiles/r04_pmc_step_bytes_b128_before_korder.txt).  The one-piece kernel of the
     // bf16-storage mode keeps the tap-major order (its fixtures are pinned to that summation order).
-    auto k_of = [&](int kt, int& ti, int& c0) {
-        if (NP >= 2 && p.kmaj) { const int cc = kt / pc.ntaps; ti = kt - cc * pc.ntaps; c0 = cc << 5; }
-        else { ti = kt / nkc; c0 = (kt - ti * nkc) << 5; }
+    // The k tiles are staged strictly in order (0, 1, 2, ... of this workgroup's range), so (tap, channel slice) is a CURSOR advanced once per tile -- the
+    // first version recomputed it by an integer division per staging call: ~35 SALU + 15 VALU each, in the phase that bounds the kernel -- and the
+    // tap's table entries (kernel arguments: scalar loads) are fetched one tile ahead.
+    const bool cmaj = NP >= 2 && p.kmaj;
+    int s_ti, s_cc;
+    if (cmaj) { s_cc = kt0 / pc.ntaps; s_ti = kt0 - s_cc * pc.ntaps; } else { s_ti = kt0 / nkc; s_cc = kt0 - s_ti * nkc; }
+    int s_doff = pc.doff[s_ti], s_tap = pc.tap[s_ti];
+    auto next_k = [&]() {
+        if (cmaj) { if (++s_ti == pc.ntaps) { s_ti = 0; ++s_cc; } }
+        else { if (++s_cc == nkc) { s_cc = 0; ++s_ti; } }
+        s_doff = pc.doff[s_ti]; s_tap = pc.tap[s_ti];           // past the last tile: an unused entry of the same struct
     };
+    // Buffer-addressed DMA (p.buf, default): one buffer resource per piece plane (SGPRs), the lane's address is a 32-bit byte offset inside the plane,
+    // and padding is an offset past the end -- the load returns zeros (tools/probe/buffer_lds_probe.hip) -- instead of a per-lane 64-bit select
+    // between the plane and the zero page for every piece: 3 VALU per row tile and k tile instead of ~8 per DMA instruction.
+    // (the resources are wave-uniform SGPR quads built at the use site: loop-invariant, the compiler keeps them in SGPRs)
+    constexpr unsigned OOB = 0xfffffff0u;
     auto stage_a = [&](int kl) {                                 // kl = k tile index local to this workgroup's range
-        const int kt = kt0 + kl;
-        int ti, c0;
-        k_of(kt, ti, c0);
-        const unsigned koff = (unsigned)(c0 + (long)pc.doff[ti] * p.GC);
-        const unsigned bit = 1u << ti;
+        const unsigned koff = (unsigned)((s_cc << 5) + (long)s_doff * p.GC);
+        const unsigned bit = 1u << s_ti;
         unsigned char* dst = a_lds + (kl & 1) * A_STAGE;
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             if (w4 + 4 * i < MT) {                               // wave-uniform
                 const bool on = (a_mask[i] & bit) != 0u;
                 const unsigned o = a_off[i] + koff;
+                if (p.buf) {
+                    const unsigned vo = on ? o << 1 : OOB;
 #pragma unroll
-                for (int q = 0; q < NP; ++q)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.a.p + q * p.a.ps + o : zero), (lds_ptr_t)(dst + q * PLANE_A + (w4 + 4 * i) * 1024), 16, 0, 0);
+                    for (int q = 0; q < NP; ++q)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)(p.a.p + q * p.a.ps), 0, p.a_bytes, 0x00020000),
+                                                                 (lds_ptr_t)(dst + q * PLANE_A + (w4 + 4 * i) * 1024), 16, (int)vo, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.a.p + q * p.a.ps + o : zero), (lds_ptr_t)(dst + q * PLANE_A + (w4 + 4 * i) * 1024), 16, 0, 0);
+                }
             }
         }
     };
     auto stage_b = [&](int kl) {
-        const int kt = kt0 + kl;
-        int ti, c0;
-        k_of(kt, ti, c0);
-        const long kb = (long)pc.tap[ti] * p.GC + c0;
+        const long kb = (long)s_tap * p.GC + (s_cc << 5);
         unsigned char* dst = smem + B_BASE + (kl & 1) * B_STAGE;
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
             const bool on = b_off[i] >= 0;
+            if (p.buf) {
+                const unsigned vo = on ? (unsigned)(b_off[i] + kb) << 1 : OOB;
 #pragma unroll
-            for (int q = 0; q < NP; ++q)
-                __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.b.p + q * p.b.ps + b_off[i] + kb : zero), (lds_ptr_t)(dst + q * PLANE_B + (w4 + 4 * i) * 1024), 16, 0, 0);
+                for (int q = 0; q < NP; ++q)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)(p.b.p + q * p.b.ps), 0, p.b_bytes, 0x00020000),
+                                                             (lds_ptr_t)(dst + q * PLANE_B + (w4 + 4 * i) * 1024), 16, (int)vo, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(on ? p.b.p + q * p.b.ps + b_off[i] + kb : zero), (lds_ptr_t)(dst + q * PLANE_B + (w4 + 4 * i) * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -815,17 +852,17 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[QA[t]][i], bf[QB[t]][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[QB[t]][j], af[QA[t]][i], acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     if constexpr (NP == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NP - 1][i], bf[0][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[NP - 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][j], af[NP - 1][i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[NP - 1][j], af[0][i], acc[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0][j], af[0][i], acc[i][j], 0, 0, 0);
                 }
         }
     };
@@ -834,14 +871,16 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
 
     stage_a(0);
     if (grp == 0) stage_b(0);
+    next_k();
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     const bool dma = !(p.dbg & 1);
+    const int nkr = (p.dbg & 4) ? 0 : nk;                        // ablation bit 2: skip the k loop (launch + prologue + epilogue remain)
     if (grp == 0) {
-        for (int k = 0; k < nk; ++k) {
+        for (int k = 0; k < nkr; ++k) {
             load_frags(k);                                       // phase 2k
             __builtin_amdgcn_sched_barrier(0);
-            if (k + 1 < nk && dma) { stage_a(k + 1); stage_b(k + 1); }
+            if (k + 1 < nk && dma) { stage_a(k + 1); stage_b(k + 1); next_k(); }
             end_load();
             compute();                                           // phase 2k + 1
             __builtin_amdgcn_sched_barrier(0);
@@ -850,10 +889,10 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
         asm volatile("s_barrier" ::: "memory");
     } else {
         asm volatile("s_barrier" ::: "memory");
-        for (int k = 0; k < nk; ++k) {
+        for (int k = 0; k < nkr; ++k) {
             load_frags(k);                                       // phase 2k + 1
             __builtin_amdgcn_sched_barrier(0);
-            if (k + 1 < nk && dma) stage_a(k + 1);
+            if (k + 1 < nk && dma) { stage_a(k + 1); next_k(); }
             end_load();
             compute();                                           // phase 2k + 2
             __builtin_amdgcn_sched_barrier(0);
@@ -861,38 +900,64 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
         }
     }
 
-    // ---- epilogue: C/D layout of 16x16: col = lane & 15, row = 4 (lane >> 4) + r ----
+    // ---- epilogue.  The MFMAs take the WEIGHT fragment as their first operand: D = W X^T, so a lane's four accumulator registers are four consecutive
+    //      output CHANNELS (4 (lane >> 4) + r) of one pixel (lane & 15) -- one 16-byte store per 16x16 tile and lane instead of four 4-byte stores
+    //      to four different rows (the output stores were 27 of the 162 us of a 64-channel launch: tools/planes_ablate.py, "no stores"). ----
     static_assert(OUT == 0, "fp32 output only");
+    if (p.dbg & 8) return;                                       // ablation bit 3: no output stores
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
+        const int row = m0 + i * 16 + l15;
+        if (row >= pc.M) continue;
+        long orow = row;                                         // forward / stride-1 data gradient: output pixel = GEMM row
+        if (!p.fwd && p.stride != 1) {                           // the live parity class of a stride-2 1x1 data gradient: its pixels inside the full grid
+            const int t = fast_div(row, pc.OWc, pc.mg_ow), oxc = row - t * pc.OWc;
+            const int img = fast_div(t, pc.OHc, pc.mg_oh), oyc = t - img * pc.OHc;
+            orow = ((long)img * p.OH + oyc * p.stride + pc.py) * p.OW + oxc * p.stride + pc.px;
+        }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int col = n0 + w4 * (BN / 4) + j * 16 + l15;
-            if (col >= p.N) continue;
+            const int col0 = n0 + w4 * (BN / 4) + j * 16 + 4 * kp;
+            if (col0 >= p.N) continue;
+            f32x4_t v = acc[i][j];
+            if (ksp) {                                           // raw partial: the reduce applies the epilogue
+                float* d = p.ws + ((long)blockIdx.z * pc.M + orow) * p.N + col0;
+                if (p.vec) *reinterpret_cast<f32x4_t*>(d) = v;
+                else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + i * 16 + 4 * kp + r;
-                if (row >= pc.M) continue;
-                long orow = row;
-                if (!p.fwd && p.stride != 1) {
-                    const int oxc = row % pc.OWc; const int t = row / pc.OWc; const int oyc = t % pc.OHc; const int img = t / pc.OHc;
-                    orow = ((long)img * p.OH + oyc * p.stride + pc.py) * p.OW + oxc * p.stride + pc.px;
+                    for (int r = 0; r < 4; ++r) if (col0 + r < p.N) d[r] = v[r];
                 }
-                if (ksp) { p.ws[((long)blockIdx.z * pc.M + orow) * p.N + col] = acc[i][j][r]; continue; }      // raw partial: the reduce applies the epilogue
-                float* dst = p.C + orow * p.ldc + col;
-                float v = acc[i][j][r];
-                if (p.bias) v += p.bias[col];
-                if (p.relu) v = fmaxf(v, 0.f);                   // convolution callers: relu(conv), then the accumulate (never both in practice)
-                if (p.beta != 0.f) v += p.beta * *dst;
-                if (p.act == 1) v = fmaxf(v, 0.f);               // dense callers: act(A B^T + bias + beta C), the convention of ha2g_gemm_f32
-                else if (p.act == 2) v = v > 0.f ? v : 0.01f * v;
-                *dst = v;
+                continue;
+            }
+            float* dst = p.C + orow * p.ldc + col0;
+            if (p.vec) {
+                if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + col0);
+                if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }   // convolution callers: relu(conv)
+                if (p.beta != 0.f) v += p.beta * *reinterpret_cast<const f32x4_t*>(dst);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                    // dense callers: act(A B^T + bias + beta C), the convention of ha2g_gemm_f32
+                    if (p.act == 1) v[r] = fmaxf(v[r], 0.f);
+                    else if (p.act == 2) v[r] = v[r] > 0.f ? v[r] : 0.01f * v[r];
+                }
+                *reinterpret_cast<f32x4_t*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (col0 + r >= p.N) continue;
+                    float x = v[r];
+                    if (p.bias) x += p.bias[col0 + r];
+                    if (p.relu) x = fmaxf(x, 0.f);
+                    if (p.beta != 0.f) x += p.beta * dst[r];
+                    if (p.act == 1) x = fmaxf(x, 0.f);
+                    else if (p.act == 2) x = x > 0.f ? x : 0.01f * x;
+                    dst[r] = x;
+                }
             }
         }
+    }
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------------------
 // Weight gradient of a 3x3 / stride-1 / pad-1 convolution from planes:  dW[co][tap][ci] = sum over pixels p of dy[p][co] * x[p + tap][ci].
 // The implicit GEMM (gemm.hip, A_MC x B_IM) stages the im2col gather of x -- the same pixels nine times -- and both operands once per
 // 128-wide output tile; rocprofv3 puts it at 15 VALU per MFMA (split + gather arithmetic) and, in the step, bound by L2 -> LDS traffic beside
@@ -1249,6 +1314,7 @@ static int pconv_pp_launch(const PConvP& p, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((pconv_pp_kernel<BN, NP, OUT>), grid, dim3(512), lds, st, p);
     return 0;
 }
+static int g_qbuf = 1;       // buffer-addressed DMA in the q kernel (ha2g_conv_planes_bufaddr(0) = flat addresses + zero page, A/B)
 static int g_kmaj = 1;       // k order of the q kernel's split products: 1 = channel-major (the nine taps of a 32-channel slice back to back), 0 = tap-major
 static int g_q_kernel = 1;   // the quantisation-free 16x16 kernel where its tile choice fills the CUs better (ha2g_conv_planes_tile3(5) forces, (6) = off)
 template <int MT, int BN, int NP>
@@ -1286,10 +1352,27 @@ static double pconv_q_plan(int M, int N, int ksplit, int* pmt, int* pbn) {
     *pmt = bmt; *pbn = bbn;
     return best;
 }
+// element counts of one piece plane of A / B -> byte sizes for the q kernel's buffer resources (0 = too large for 32-bit byte offsets: flat path)
+static void set_plane_bytes(PConvP& p, long a_elems, long b_elems) {
+    const long lim = (1L << 30) - 64;
+    p.a_bytes = (a_elems > 0 && a_elems < lim) ? (int)(a_elems * 2) : 0;
+    p.b_bytes = (b_elems > 0 && b_elems < lim) ? (int)(b_elems * 2) : 0;
+}
 template <int NP>
 static int pconv_q_dispatch(const PConvP& p_in, int maxM, hipStream_t st) {
     PConvP p = p_in;
     p.kmaj = g_kmaj;
+    // buffer addressing needs 32-bit byte offsets inside a plane and the element counts of the planes (a: GH x GW x GC per image x images; b: N x K);
+    // callers that know them set a_bytes / b_bytes, otherwise (0) the flat-address path runs
+    p.buf = (g_qbuf && p.a_bytes > 0 && p.b_bytes > 0) ? 1 : 0;
+    {
+        PClass& c = p.cls[0];
+        for (int t = 0; t < c.ntaps && t < 9; ++t) { c.khs[t] = (unsigned char)(c.tap[t] / p.KW); c.kws[t] = (unsigned char)(c.tap[t] % p.KW); }
+        c.mg_ow = c.OWc > 1 ? (unsigned)(((1ULL << 32) + (unsigned)c.OWc - 1) / (unsigned)c.OWc) : 0u;
+        c.mg_oh = c.OHc > 1 ? (unsigned)(((1ULL << 32) + (unsigned)c.OHc - 1) / (unsigned)c.OHc) : 0u;
+    }
+    const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    p.vec = (p.N % 4 == 0 && p.ldc % 4 == 0 && al16(p.C) && (!p.bias || al16(p.bias)) && (p.ksplit <= 1 || al16(p.ws))) ? 1 : 0;
     if (p.ncls != 1) return -100;                                // stride-2 data gradients (parity classes of different sizes) keep the 32x32 kernels
     int bmt = 0, bbn = 0;
     pconv_q_plan(maxM, p.N, p.ksplit > 1 ? p.ksplit : 1, &bmt, &bbn);
@@ -1361,6 +1444,7 @@ int plane_gemm_launch(const void* a, long a_ps, long lda, const void* b, long b_
     if (M == 0 || N == 0) return 0;
     // GC is the row stride AND (>> 5) the k-tile count of the kernel: when lda > kpad the surplus tiles would multiply zeros by zeros; forbid it
     if (lda != kpad) return ha2g_set_error(-1, "plane_gemm: lda %ld must equal K rounded up to 32 (%d)", lda, kpad);
+    set_plane_bytes(p, (long)M * lda, (long)N * ldb);
     if (int rc = pconv_q_dispatch<3>(p, M, st)) return rc;
     HA2G_CHECK_LAUNCH("plane_gemm");
     return 0;
@@ -1390,6 +1474,7 @@ void ha2g_conv_planes_enable(int on) { g_planes = on; }
 void ha2g_conv_planes_debug(int bits) { g_pdbg = bits; }
 void ha2g_conv_planes_ring(int depth) { g_ring = depth; }
 void ha2g_conv_planes_waves(int n) { g_waves = n == 8 ? 8 : 4; }
+void ha2g_conv_planes_bufaddr(int on) { g_qbuf = on ? 1 : 0; }
 void ha2g_conv_planes_korder(int channel_major) { g_kmaj = channel_major ? 1 : 0; }
 void ha2g_conv_planes_tile3(int t) { if (t == 6) { g_q_kernel = 0; g_tile3 = 0; } else { g_q_kernel = 1; g_tile3 = (t >= 0 && t <= 5) ? t : 0; } }
 
@@ -1495,6 +1580,7 @@ int ha2g_conv2d_dgrad_planes_np_f32(const void* dy, long dy_ps, const void* wt, 
     p.dbg = g_pdbg;
     if ((long)N * H * W == 0) return 0;
     const int maxM = dgrad_classes(p, N, H, W, KH, KW, stride, pad, OWd);
+    set_plane_bytes(p, (long)N * OHd * OWd * Cout, (long)Cin * KH * KW * Cout);
     if (int rc = (np == 3 ? pconv_dispatch<3, 0>(p, maxM, (hipStream_t)stream) : pconv_dispatch<2, 0>(p, maxM, (hipStream_t)stream))) return rc;
     HA2G_CHECK_LAUNCH("conv2d_dgrad_planes");
     return 0;
@@ -1532,6 +1618,7 @@ int ha2g_conv2d_fwd_planes_np_f32(const void* x, long x_ps, const void* w, long 
         for (int kw = 0; kw < KW; ++kw) { c.tap[c.ntaps] = kh * KW + kw; c.doff[c.ntaps] = kh * W + kw; ++c.ntaps; }
     p.ncls = 1; p.cls[0] = c;
     if (c.M == 0) return 0;
+    set_plane_bytes(p, (long)N * H * W * Cin, (long)Cout * KH * KW * Cin);
     if (int rc = pconv_dispatch<3, 0>(p, c.M, (hipStream_t)stream)) return rc;
     HA2G_CHECK_LAUNCH("conv2d_fwd_planes");
     return 0;

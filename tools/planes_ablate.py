@@ -22,7 +22,7 @@ def t_us(fn, iters=10):
     return s.elapsed_time(e) / iters * 1e3
 
 
-print('%-44s %9s %9s %9s %9s   %s' % ('shape', 'full', 'no DMA', 'no MFMA', 'neither', 'TF(f32eq) full'))
+print('%-44s %9s %9s %9s %9s   %s   %s' % ('shape', 'full', 'no DMA', 'no MFMA', 'neither', 'TF(f32eq) full', '[q kernel: no k loop | no k loop, no stores | no stores]'))
 for B in (128, 512):
     for H, W, C in ((64, 35, 64), (32, 18, 128), (16, 9, 256)):
         dy = torch.randn(B, H, W, C, device=dev)
@@ -42,10 +42,17 @@ for B in (128, 512):
                     for bits in (0, 1, 2, 3):
                         lib.ha2g_conv_planes_debug(bits)
                         ts.append(t_us(fn))
+                    extra = ''
+                    if tile == 5:                         # q kernel: per-launch fixed costs (bit 2 = skip the k loop, bit 3 = skip the output stores)
+                        ex = []
+                        for bits in (4, 12, 8):
+                            lib.ha2g_conv_planes_debug(bits)
+                            ex.append(t_us(fn))
+                        extra = '   [%.1f | %.1f | %.1f]' % tuple(ex)
                     lib.ha2g_conv_planes_debug(0)
                     fl = 2.0 * B * H * W * C * C * 9
-                    print('B=%-3d C=%-3d %3dx%-3d np %d tile %d ring %d        %9.1f %9.1f %9.1f %9.1f   %.1f' % (
-                        B, C, H, W, pl.shape[0], tile, ring, ts[0], ts[1], ts[2], ts[3], fl / ts[0] / 1e6))
+                    print('B=%-3d C=%-3d %3dx%-3d np %d tile %d ring %d        %9.1f %9.1f %9.1f %9.1f   %.1f%s' % (
+                        B, C, H, W, pl.shape[0], tile, ring, ts[0], ts[1], ts[2], ts[3], fl / ts[0] / 1e6, extra))
             lib.ha2g_conv_planes_ring(0)
             lib.ha2g_conv_planes_tile3(0)
 lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
