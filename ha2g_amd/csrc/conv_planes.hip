@@ -878,9 +878,16 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
     const int nkr = (p.dbg & 4) ? 0 : nk;                        // ablation bit 2: skip the k loop (launch + prologue + epilogue remain)
     if (grp == 0) {
         for (int k = 0; k < nkr; ++k) {
-            load_frags(k);                                       // phase 2k
+            if (p.dbg & 16) {                                    // A/B: the first form (fragment reads, then the next tile's DMA)
+                load_frags(k);                                   // phase 2k
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < nk && dma) { stage_a(k + 1); stage_b(k + 1); next_k(); }
+            } else {                                             // the next tile's DMA FIRST: its stage was retired a phase ago, and every cycle of flight counts
+                if (k + 1 < nk && dma) { stage_a(k + 1); stage_b(k + 1); next_k(); }
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(k);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if (k + 1 < nk && dma) { stage_a(k + 1); stage_b(k + 1); next_k(); }
             end_load();
             compute();                                           // phase 2k + 1
             __builtin_amdgcn_sched_barrier(0);
@@ -890,9 +897,16 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
     } else {
         asm volatile("s_barrier" ::: "memory");
         for (int k = 0; k < nkr; ++k) {
-            load_frags(k);                                       // phase 2k + 1
+            if (p.dbg & 16) {
+                load_frags(k);                                   // phase 2k + 1
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < nk && dma) { stage_a(k + 1); next_k(); }
+            } else {
+                if (k + 1 < nk && dma) { stage_a(k + 1); next_k(); }
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(k);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if (k + 1 < nk && dma) { stage_a(k + 1); next_k(); }
             end_load();
             compute();                                           // phase 2k + 2
             __builtin_amdgcn_sched_barrier(0);
