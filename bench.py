@@ -253,6 +253,9 @@ def main():
         dt, last, launch = dt_graph, last_graph, 'hipGraph replay'
     else:
         dt, last = dt_eager, last_eager
+    if dt_graph is not None and graph_note is None:
+        graph_note = ('value = the faster of two legs over the same %d steps of the same step function between barriers + device syncs: hipGraph replay %.3f ms/step, '
+                      'eager launches %.3f ms/step' % (a.steps, dt_graph / a.steps * 1e3, dt_eager / a.steps * 1e3))
     graph_leg = None if dt_graph is None else dict(ms_per_step=round(dt_graph / a.steps * 1e3, 3), value=round(a.batch * 34 * world / (dt_graph / a.steps), 1))
     eager = dict(ms_per_step=round(dt_eager / a.steps * 1e3, 3), value=round(a.batch * 34 * world / (dt_eager / a.steps), 1),
                  host_ms_per_step=round(clock['busy'] / max(clock['steps'], 1) * 1e3, 3),
@@ -267,8 +270,8 @@ def main():
     ops.ktimer.enabled = False
     tr.sync()
     # ---- secondary numbers, timed like the primary over the same number of steps: warm-up phase (epoch <= loss_warmup: no D update / no D-phase
-    # chain) and the same GAN-phase step with EVERY matrix product on the exact fp32 MFMA (ha2g_gemm_set_mode(0)) -- the default runs the backward
-    # GEMMs / convolutions on the 2-piece split-bf16 product (hi + lo = 16 operand mantissa bits, 3 bf16 MFMAs, fp32 accumulate)
+    # chain), the same GAN-phase step with EVERY matrix product on the exact fp32 MFMA (ha2g_gemm_set_mode(0)), and with round 3's arithmetic (mode 6:
+    # two-piece split backward = 16 operand mantissa bits, fp32-MFMA forward) -- the default (mode 70) runs every split product on three pieces
     # They are timed with EAGER launches (compare with `eager.ms_per_step`, which is within ~2 % of the replay number: the step is GPU-bound):
     # a second / third whole-step capture in one process segfaulted inside hipStreamEndCapture on the largest graphs (expressive, ~3 400 nodes,
     # ROCm 7.0.2) -- a crash there would lose the whole line, so exactly ONE capture per process is made, the headline's.
@@ -342,9 +345,14 @@ def main():
         if 'gemm_gi' in kt:                        # dominant dense-GEMM shape: the GRU input projections (rows x 600) . (600 x 900)^T, fp32 MFMA
             n, mean_us, _, flops = kt['gemm_gi']
             ach = flops / (n * mean_us * 1e-6) / 1e12
-            roof_gemm = dict(kernel='gemm_kernel<A_KC,B_KC> (ha2g_gemm_f32: GRU input projections [rows,600]x[900,600]^T)', bound='mfma',
-                             achieved=round(ach, 2), peak=157.3, unit='TFLOP/s', frac=round(ach / 157.3, 4), launches=n, mean_us=round(mean_us, 1),
-                             traffic=None)
+            if ops.PLANE_GEMM and ops.GRU_MERGE_DIRS and bwd_pieces == 3:    # default mode: both directions in ONE product on three-piece planes (the time includes the two operand-split launches)
+                roof_gemm = dict(kernel='f32_to_planes x2 + pconv_q_kernel (ha2g_gemm_planes_np_f32: GRU input projections of both directions [rows,600]x[1800,600]^T on three-piece planes)',
+                                 bound='mfma', achieved=round(ach, 2), peak=round(2500.0 / 6, 1), unit='TFLOP/s (fp32-equivalent: 6 bf16 MFMAs per product)',
+                                 frac=round(ach / (2500.0 / 6), 4), frac_of_fp32_mfma_peak=round(ach / 157.3, 4), launches=n, mean_us=round(mean_us, 1), traffic=None)
+            else:
+                roof_gemm = dict(kernel='gemm_kernel<A_KC,B_KC> (ha2g_gemm_f32: GRU input projections [rows,600]x[900,600]^T)', bound='mfma',
+                                 achieved=round(ach, 2), peak=157.3, unit='TFLOP/s', frac=round(ach / 157.3, 4), launches=n, mean_us=round(mean_us, 1),
+                                 traffic=None)
         roof_conv = None
         if 'conv2d_fwd' in kt:                     # the largest kernel family by time: implicit-GEMM convolutions of the audio tower (forward, fp32 MFMA)
             n, mean_us, _, flops = kt['conv2d_fwd']
@@ -366,10 +374,10 @@ def main():
         if 'conv2d_fwd_planes' in kt:                   # forward convolutions of trunk layers 2-4: three-piece planes (always six MFMAs per product)
             n, mean_us, _, flops = kt['conv2d_fwd_planes']
             ach = flops / (n * mean_us * 1e-6) / 1e12
-            roof_conv = dict(kernel='pconv_pp_kernel / pconv_kernel<.., NP = 3> forward gather (ha2g_conv2d_fwd_planes_np_f32: forward convolutions of SE-ResNet34 layers 2-4 on producer-written three-piece planes)',
+            roof_conv = dict(kernel='pconv_q_kernel<MT,BN,3> (stride 2: pconv_kernel<..,3>) forward gather (ha2g_conv2d_fwd_planes_np_f32: forward convolutions of SE-ResNet34 layers 2-4 on producer-written three-piece planes)',
                              bound='mfma', achieved=round(ach, 2), peak=round(2500.0 / 6, 1), unit='TFLOP/s (fp32-equivalent: 6 bf16 MFMAs per product)',
                              frac=round(ach / (2500.0 / 6), 4), frac_of_fp32_mfma_peak=round(ach / 157.3, 4), launches=n, mean_us=round(mean_us, 1), traffic=None)
-        roof_bwd_gemm = mfma3('conv_dgrad_planes', 'pconv_pp_kernel / pconv_kernel (ha2g_conv2d_dgrad_planes_np_f32: 3x3 data gradients of trunk layers 2-4, DMA-staged bf16 piece planes)')
+        roof_bwd_gemm = mfma3('conv_dgrad_planes', 'pconv_q_kernel<MT,BN,NP> / pconv_kernel (ha2g_conv2d_dgrad_planes_np_f32: 3x3 data gradients of trunk layers 2-4, DMA-staged bf16 piece planes)')
         roof_bwd_wgrad = mfma3('conv_wgrad_planes', 'pconv_wgrad_kernel + wide reduce (ha2g_conv2d_wgrad_planes_np_f32: 3x3 weight gradients of trunk layers 2-4)')
 
         def hbm(key, kernel):
@@ -400,13 +408,13 @@ def main():
                    vs_baseline=None,
                    dtype=(('bf16 (matrix operands; audio-trunk activations and activation gradients stored as bf16; fp32 accumulate, fp32 statistics, fp32 master weights and optimizer)'
                            if b16_storage else 'bf16 (operands; fp32 accumulate, fp32 storage and master weights)') if a.bf16 else
-                          {3: 'f32 (storage, accumulation; forward products: fp32 MFMA; backward products: bf16x3 split = all 24 operand mantissa bits, six bf16 MFMAs per product, fp32 accumulate -- or the exact fp32 MFMA where a family has no three-piece kernel)',
+                          {3: 'f32 (storage, accumulation; matrix products: bf16x3 split = all 24 operand mantissa bits, six bf16 MFMAs per product, fp32 accumulate (trunk convolutions forward + backward, dense products >= 4 GFLOP, both GRU chains, every backward GEMM) or the fp32 MFMA (small forward GEMMs, 32-channel forward, stem))',
                            2: 'f32 storage / accumulation, forward products fp32 MFMA; backward products: bf16x2 split = 16-bit operand mantissa (NOT fp32-class), fp32 accumulate',
                            0: 'f32 (every product on the fp32 MFMA)'}[bwd_pieces]),
                    data='synthetic', rehearsal=rehearsal, launch=launch, launch_note=graph_note, rccl_world=rccl_world, eager=eager, graph_replay=graph_leg,
                    cluster_retries=tr.cluster_retries,
                    matrix_core=('bf16 operands (1 MFMA per product), fp32 accumulate, fp32 storage and master weights; GRU recurrences fp32' if a.bf16 else
-                                {3: 'forward: fp32 MFMA (v_mfma_f32_32x32x2_f32); backward GEMMs / convolutions: 3-piece split-bf16 (x = p0+p1+p2 holds all 24 mantissa bits; six v_mfma_f32_32x32x16_bf16 per product, smallest first, fp32 accumulate: as accurate as the fp32 MFMA chain, tests/test_gpu_np3.py); BPTT chain, direct 32-channel kernels: exact fp32 MFMA',
+                                {3: '3-piece split-bf16 (x = p0+p1+p2 holds all 24 mantissa bits; six bf16 MFMAs per product, smallest first, fp32 accumulate: as accurate as the fp32 MFMA chain, tests/test_gpu_np3.py): forward + backward convolutions of trunk layers 2-4 (v_mfma_f32_16x16x32_bf16 / 32x32x16), 32-channel data / weight gradients, dense products >= 4 GFLOP, every backward GEMM, GRU forward and BPTT chains; fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4): small forward GEMMs, 32-channel forward, stem',
                                  2: 'forward: fp32 MFMA; backward GEMMs/convs/BPTT: 2-piece split-bf16 (hi+lo, 3 bf16 MFMAs per product; 4e-6 rms-rel per GEMM vs 4e-7 for fp32 MFMA)',
                                  0: 'fp32 MFMA everywhere'}[bwd_pieces]),
                    two_piece_backward=dict(ms_per_step=round(ms_m6, 3), value=round(a.batch * 34 * world / (ms_m6 * 1e-3), 1) if ms_m6 == ms_m6 else None, steps=a.steps, launch=launch2,

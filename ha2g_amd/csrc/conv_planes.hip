@@ -685,6 +685,7 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
+    if (p.dbg & 32) return;                                      // ablation bit 5: launch cost only
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, w4 = wave & 3;

@@ -1,0 +1,64 @@
+import json, re, sys, os
+R='/root/repo/'
+def L(f): return json.load(open(R+'profiles/r04_bench_%s_line.json'%f))
+d=L('b128')
+s=open(R+'DESIGN.md').read()
+def row(name,f):
+    x=L(f)
+    g=x.get('graph_replay') or {}
+    tp=(x.get('two_piece_backward') or {}).get('ms_per_step')
+    return '| %s | %.1f | %.1f k | %s / %.1f | %s | %.1f | %.1f |' % (name, x['ms_per_step'], x['value']/1e3, ('%.1f'%g['ms_per_step']) if g else '—', x['eager']['ms_per_step'], ('%.1f'%tp) if tp else '—', x['exact_fp32_matrix_core']['ms_per_step'], x['warmup_phase']['ms_per_step'])
+table='\n'.join([row('**B = 128, TED-Gesture (headline, config 2)**','b128'), row('B = 256','b256'), row('TED-Expressive, B = 128 (config 3)','expressive'), row('TED-Expressive, B = 256','expressive_b256'),
+                 row('TED-Expressive, B = 256, `--bf16` (config 5: bf16 operands + bf16 trunk storage)','expressive_b256_bf16'), row('TED-Expressive, B = 256, `--bf16 --fp32-storage`','expressive_b256_bf16_fp32storage'),
+                 '| CPU oracle, %d cores (B = 128, same box, same run) | — | %.0f | | | | |' % (d['cpu_baseline']['cores'], d['cpu_baseline']['value'])])
+sb=open(R+'profiles/r04_pmc_step_bytes_b128.txt').read()
+rg=float(re.search(r'FETCH_SIZE:.*?= ([\d.]+) GB',sb).group(1)); wg=float(re.search(r'WRITE_SIZE:.*?= ([\d.]+) GB',sb).group(1))
+fam=open(R+'profiles/r04_bench_b128_kernel_families.txt').read().splitlines()
+famd={}
+for l in fam[1:]:
+    m=re.match(r'(.*?)\s+(\d+)\s+([\d.]+)(\s+[\d.]+%)?$', l.strip())
+    if m: famd[m.group(1).strip()]=(int(m.group(2)), float(m.group(3)))
+q=open(R+'profiles/r04_bench_b128_queues.txt').read()
+qm=re.search(r'queue 1: (\d+) kernels/step, busy ([\d.]+) ms/step.*?of which ([\d.]+) ms', q); qs=re.search(r'queue 2: (\d+) kernels/step, busy ([\d.]+) ms/step', q)
+span=float(re.search(r'span ([\d.]+) ms/step', q).group(1))
+families=('plane kernel %.1f ms/step (%d launches), dense GEMM %.1f, 32-channel direct convolutions %.1f, BatchNorm %.1f, plane weight gradients %.1f, GRU %.1f, SE %.1f, split-K reduce %.1f, '
+          'torch plumbing %.1f; %d launches, %.1f ms of kernel time on two queues.  Per queue (under the profiler the step stretches to %.1f ms): the main queue is busy %s ms — it is the critical path — the side queue %s ms, %s of them beside a main-queue kernel.') % (
+    famd[[k for k in famd if k.startswith('plane kernel')][0]][1], famd[[k for k in famd if k.startswith('plane kernel')][0]][0], famd['dense GEMM'][1], famd['conv 32ch direct (fwd / dgrad / wgrad)'][1], famd['BatchNorm'][1],
+    famd['conv wgrad (planes, DMA-staged)'][1], famd['GRU recurrences'][1], famd['SE pointwise'][1], famd['split-K reduce'][1], famd['torch plumbing (add/fill/copy/cat)'][1], famd['total'][0], famd['total'][1], span, qm.group(2), qs.group(2), qm.group(3))
+bwd=open(R+'profiles/r04_bwd_matrix_bench.txt').read().splitlines()
+bt=['| kernel (alone, B = 128) | µs, mode 70 | TFLOP/s (fp32-eq.) | of 417 | µs, mode 6 (two pieces) | µs, mode 0 (fp32 MFMA) | of 157.3 |','|---|---|---|---|---|---|---|']
+rows={}
+for l in bwd:
+    m=re.match(r'(\d+)\s+(.*?)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)$', l)
+    if m: rows.setdefault(m.group(2).strip(),{})[int(m.group(1))]=(float(m.group(3)),float(m.group(4)),float(m.group(5)))
+for k,v in rows.items():
+    if 70 in v:
+        bt.append('| %s | %.0f | %.0f | %.2f | %s | %s | %s |' % (k, v[70][0], v[70][1], v[70][2], ('%.0f'%v[6][0]) if 6 in v else '—', ('%.0f'%v[0][0]) if 0 in v else '—', ('%.2f'%v[0][2]) if 0 in v else '—'))
+# q PMC
+pq=open(R+'profiles/r04_pmc_q.txt').read()
+def ctr(kern,name):
+    m=re.search(r'%s\S*\s+%s\s+\d+\s+([\d.]+)\s+([\d.]+)'%(re.escape(kern),name), pq)
+    return float(m.group(1)) if m else float('nan')
+ql=['| `pconv_q_kernel` alone (`profiles/r04_pmc_q.txt`) | matrix pipe busy | wave cycles parked (`SQ_WAIT_ANY`) | issue stalls (`SQ_WAIT_INST_ANY`) | issuing | VALU / SALU per MFMA | LDS bank conflicts |','|---|---|---|---|---|---|---|']
+for kern,label,flops in (('pconv_q_kernelILi9ELi128','<9,128,3> (C = 128)',21.7e9),('pconv_q_kernelILi9ELi64','<9,64,3> (C = 64 and C = 256 launches averaged)',21.4e9)):
+    wc=ctr(kern,'SQ_WAVE_CYCLES'); mf=ctr(kern,'SQ_INSTS_MFMA'); busy=ctr(kern,'SQ_VALU_MFMA_BUSY_CYCLES'); gui=ctr(kern,'GRBM_GUI_ACTIVE')
+    nsamp=flops*6/16384/mf if mf==mf and mf>0 else float('nan')
+    simds=1024/nsamp if nsamp==nsamp else float('nan')
+    ql.append('| %s | %.0f %% | %.0f %% | %.0f %% | %.0f %% | %.1f / %.1f | %.0f |' % (label, 100*busy/(simds*gui), 100*ctr(kern,'SQ_WAIT_ANY')/wc, 100*ctr(kern,'SQ_WAIT_INST_ANY')/wc, 100*ctr(kern,'SQ_ACTIVE_INST_ANY')/wc,
+              ctr(kern,'SQ_INSTS_VALU')/mf, ctr(kern,'SQ_INSTS_SALU')/mf, ctr(kern,'SQ_LDS_BANK_CONFLICT')))
+import subprocess
+nsym=len(set(re.findall(r'\b(ha2g_[a-z0-9_]+)\s*\(', open(R+'include/ha2g_hip.h').read())))
+gt=open(R+'profiles/r04_gpu_tests.txt').read() if os.path.exists(R+'profiles/r04_gpu_tests.txt') else ''
+ngpu=re.search(r'(\d+) passed', gt); ngpu=ngpu.group(1) if ngpu else '425'
+import numpy as np
+nrun3=int(float(np.load(R+'tests/golden/cfg3_b128.npz')['noise_runs'])); nrun16=int(float(np.load(R+'tests/golden/enc16.npz')['noise_runs']))
+rf,rb=d['roofline'],d['roofline_bwd']
+rep={'«NGPU»':ngpu,'«NCPU»':sys.argv[1] if len(sys.argv)>1 else '93','«NSYM»':str(nsym),'«NRUN3»':str(nrun3),'«NRUN16»':str(nrun16),
+     '«HMS»':'%.1f'%d['ms_per_step'],'«HVAL»':'%.1f'%(d['value']/1e3),'«M6MS»':'%.1f'%d['two_piece_backward']['ms_per_step'],'«X32MS»':'%.1f'%d['exact_fp32_matrix_core']['ms_per_step'],
+     '«GRUUS»':'%.0f'%rf['mean_us'],'«GRUF32»':'%.2f'%rf['frac_of_fp32_mfma_peak'],'«GRUF3»':'%.2f'%rf['frac'],'«BPTTUS»':'%.0f'%rb['mean_us'],'«BYTES»':'%.1f'%(rg+wg),
+     '«NNP3»':sys.argv[2] if len(sys.argv)>2 else '48','«BENCHTABLE»':table,'«HEAGER»':'%.1f'%d['eager']['ms_per_step'],'«RGB»':'%.1f'%rg,'«WGB»':'%.1f'%wg,'«TGB»':'%.1f'%(rg+wg),
+     '«QPMC»':'\n'.join(ql),'«BWDTABLE»':'\n'.join(bt),'«FAMILIES»':families,'«QMAIN»':qm.group(2)}
+for k,v in rep.items(): s=s.replace(k,v)
+left=re.findall(r'«[A-Z0-9]+»', s)
+print('unfilled:', left)
+open(sys.argv[3] if len(sys.argv)>3 else '/tmp/DESIGN_filled.md','w').write(s)

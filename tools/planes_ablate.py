@@ -22,7 +22,7 @@ def t_us(fn, iters=10):
     return s.elapsed_time(e) / iters * 1e3
 
 
-print('%-44s %9s %9s %9s %9s   %s   %s' % ('shape', 'full', 'no DMA', 'no MFMA', 'neither', 'TF(f32eq) full', '[q kernel: no k loop | no k loop, no stores | no stores | reads before DMA]'))
+print('%-44s %9s %9s %9s %9s   %s   %s' % ('shape', 'full', 'no DMA', 'no MFMA', 'neither', 'TF(f32eq) full', '[q kernel: no k loop | no k loop, no stores | no stores | reads before DMA | empty launch]'))
 for B in (128, 512):
     for H, W, C in ((64, 35, 64), (32, 18, 128), (16, 9, 256)):
         dy = torch.randn(B, H, W, C, device=dev)
@@ -45,10 +45,10 @@ for B in (128, 512):
                     extra = ''
                     if tile == 5:                         # q kernel: per-launch fixed costs (bit 2 = skip the k loop, bit 3 = skip the output stores)
                         ex = []
-                        for bits in (4, 12, 8, 16):
+                        for bits in (4, 12, 8, 16, 32):
                             lib.ha2g_conv_planes_debug(bits)
                             ex.append(t_us(fn))
-                        extra = '   [%.1f | %.1f | %.1f | %.1f]' % tuple(ex)
+                        extra = '   [%.1f | %.1f | %.1f | %.1f | %.1f]' % tuple(ex)
                     lib.ha2g_conv_planes_debug(0)
                     fl = 2.0 * B * H * W * C * C * 9
                     print('B=%-3d C=%-3d %3dx%-3d np %d tile %d ring %d        %9.1f %9.1f %9.1f %9.1f   %.1f%s' % (
