@@ -59,6 +59,11 @@ rep={'«NGPU»':ngpu,'«NCPU»':sys.argv[1] if len(sys.argv)>1 else '93','«NSYM
      '«NNP3»':sys.argv[2] if len(sys.argv)>2 else '48','«BENCHTABLE»':table,'«HEAGER»':'%.1f'%d['eager']['ms_per_step'],'«RGB»':'%.1f'%rg,'«WGB»':'%.1f'%wg,'«TGB»':'%.1f'%(rg+wg),
      '«QPMC»':'\n'.join(ql),'«BWDTABLE»':'\n'.join(bt),'«FAMILIES»':families,'«QMAIN»':qm.group(2)}
 for k,v in rep.items(): s=s.replace(k,v)
+rd=open(R+'README.md').read()
+rep2=dict(rep); rep2.update({'«V256»':'%.1f'%(L('b256')['value']/1e3),'«VEXP»':'%.1f'%(L('expressive')['value']/1e3),'«VBF16»':'%.1f'%(L('expressive_b256_bf16')['value']/1e3),'«CPUV»':'%.0f'%d['cpu_baseline']['value']})
+for k,v in rep2.items(): rd=rd.replace(k,v)
+if '--write' in sys.argv: open(R+'README.md','w').write(rd)
+print('README unfilled:', re.findall(r'«[A-Z0-9]+»', rd))
 left=re.findall(r'«[A-Z0-9]+»', s)
 print('unfilled:', left)
-open(sys.argv[3] if len(sys.argv)>3 else '/tmp/DESIGN_filled.md','w').write(s)
+open(R+'DESIGN.md' if '--write' in sys.argv else '/tmp/DESIGN_filled.md','w').write(s)
