@@ -128,6 +128,7 @@ def main():
     ap.add_argument('--sparse-embeddings', action='store_true', help='compact row gradients + lazy row-wise Adam for the word-embedding tables (bit-identical to the dense default; -45 %% gradient-exchange bytes under data parallelism, +0.4 ms of small kernels on one GPU)')
     ap.add_argument('--dense-embeddings', action='store_true', help='data parallel: keep the dense word-embedding gradient all-reduce (the default under N > 1 is the row-wise exchange)')
     ap.add_argument('--dry-run', action='store_true', help='only exercise the rank launch: every rank prints its RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* and exits (no GPU)')
+    ap.add_argument('--host-profile', action='store_true', help='cProfile of `--steps` eager steps after the warm-up (where the host time of a step goes): prints the top functions and exits, no JSON line')
     ap.add_argument('--primary-only', action='store_true', help='skip the secondary timings (warm-up phase, exact-fp32 mode): for profiling')
     a = ap.parse_args()
     if a.graph:
@@ -234,6 +235,44 @@ def main():
 
     for _ in range(a.warmup):
         tr.train_iter(a.epoch, text, spec, target, vid)
+    if a.host_profile:
+        import cProfile, pstats, inspect
+        # host time per autograd Function (forward and backward; the backward runs on the engine's thread, which cProfile does not see)
+        from ha2g_amd import hierarchy_net as _hn, wav_engine as _we
+        acc = {}
+
+        def _wrap(cls, name):
+            fn = getattr(cls, name)
+
+            def timed_fn(*x, **k):
+                t_ = time.perf_counter()
+                try:
+                    return fn(*x, **k)
+                finally:
+                    e = acc.setdefault('%s.%s' % (cls.__name__, name), [0, 0.0])
+                    e[0] += 1; e[1] += time.perf_counter() - t_
+            setattr(cls, name, staticmethod(timed_fn))
+        for mod in (ops, _hn, _we):
+            for _, cls in inspect.getmembers(mod, inspect.isclass):
+                if issubclass(cls, torch.autograd.Function) and cls is not torch.autograd.Function and cls.__module__ == mod.__name__:
+                    _wrap(cls, 'forward'); _wrap(cls, 'backward')
+        sync()
+        pr = cProfile.Profile()
+        t0 = time.perf_counter()
+        pr.enable()
+        for _ in range(a.steps):
+            tr.train_iter(a.epoch, text, spec, target, vid)
+        pr.disable()
+        t1 = time.perf_counter()
+        sync()
+        print('host wall per step (python running under the profiler, GPU queued behind): %.1f ms; %d steps' % ((t1 - t0) / a.steps * 1e3, a.steps))
+        print('host time inside autograd Functions (inclusive of nested Functions), ms per step:')
+        for k_, (n_, t_) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:40]:
+            print('  %-44s %6d calls/step %8.3f ms/step' % (k_, n_ // a.steps, t_ / a.steps * 1e3))
+        for key in ('tottime', 'cumtime'):
+            st = pstats.Stats(pr)
+            st.sort_stats(key).print_stats(45)
+        return
     # ---- headline: GPU-bound number = hipGraph replays of the captured step (N = 1); eager launches are timed next to it.  With more than one
     # rank the timed path is the eager one (RCCL collectives inside a capture have never run on this pool: an exception could be caught, a hang not).
     use_graph = a.launch == 'graph' or (a.launch == 'auto' and world == 1)

@@ -17,14 +17,20 @@ _WS_BYTES = 160 << 20
 _ws = {}
 
 
+# The raw handle of the current stream straight from the C layer: `torch.cuda.current_stream().cuda_stream` builds a Stream object through four python
+# frames per call -- 680 calls per forward and as many per backward, 8 ms of a 35 ms host step (bench.py --host-profile, profiles/r04_host_profile.txt).
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_device = torch._C._cuda_getDevice
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _raw_stream(_cur_device())
 
 
 def workspace(device):
     """One persistent scratch buffer per (device, stream) (split-K partials, reduction partials).  Kernels of one stream
     run in order, so they can share it; the weight-gradient side stream gets its own.  Allocated once, outside capture."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.type, device.index, _raw_stream(device.index if device.index is not None else _cur_device()))
     if key not in _ws:
         _ws[key] = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
     return _ws[key]
@@ -157,9 +163,9 @@ PLANE_GEMM_MIN_FLOP = float(os.environ.get('HA2G_PLANE_GEMM_MIN', 4e9))
 def _plane_gemm_ok(a, b, M, N, K, transa, transb, alpha, act, out):
     """Route this product to the plane GEMM?  Only in the fp32-class default mode (three pieces = the accuracy of the fp32 MFMA GEMM), only
     for products large enough to fill the chip (GRU input projections and their backward, the generator head), 16-byte aligned operands."""
-    if not (PLANE_GEMM and a.is_cuda and alpha == 1.0 and act in (ACT_NONE, ACT_RELU, ACT_LEAKY) and lib.ha2g_gemm_bwd_pieces() == 3):
+    if 2.0 * M * N * K < PLANE_GEMM_MIN_FLOP or min(M, N) < 128 or K < 64:      # first: almost every product of a step is below the threshold (host time)
         return False
-    if 2.0 * M * N * K < PLANE_GEMM_MIN_FLOP or min(M, N) < 128 or K < 64:
+    if not (PLANE_GEMM and a.is_cuda and alpha == 1.0 and act in (ACT_NONE, ACT_RELU, ACT_LEAKY) and lib.ha2g_gemm_bwd_pieces() == 3):
         return False
     return all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 for t in (a, b))
 
