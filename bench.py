@@ -239,16 +239,24 @@ def main():
         import cProfile, pstats, inspect
         # host time per autograd Function (forward and backward; the backward runs on the engine's thread, which cProfile does not see)
         from ha2g_amd import hierarchy_net as _hn, wav_engine as _we
-        acc = {}
+        acc, deep_prof = {}, {}
 
         def _wrap(cls, name):
             fn = getattr(cls, name)
 
+            deep = name == 'backward' and cls.__name__ in ('WavEncoderFunction', 'BiGRUFunction')     # the engine thread's two biggest: own cProfile
+
             def timed_fn(*x, **k):
                 t_ = time.perf_counter()
+                pr_ = None
+                if deep:
+                    pr_ = deep_prof.setdefault(cls.__name__, cProfile.Profile())
+                    pr_.enable()
                 try:
                     return fn(*x, **k)
                 finally:
+                    if pr_ is not None:
+                        pr_.disable()
                     e = acc.setdefault('%s.%s' % (cls.__name__, name), [0, 0.0])
                     e[0] += 1; e[1] += time.perf_counter() - t_
             setattr(cls, name, staticmethod(timed_fn))
@@ -269,6 +277,9 @@ def main():
         print('host time inside autograd Functions (inclusive of nested Functions), ms per step:')
         for k_, (n_, t_) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:40]:
             print('  %-44s %6d calls/step %8.3f ms/step' % (k_, n_ // a.steps, t_ / a.steps * 1e3))
+        for nm, p_ in deep_prof.items():
+            print('---- inside %s.backward (engine thread), all %d steps ----' % (nm, a.steps))
+            pstats.Stats(p_).sort_stats('tottime').print_stats(28)
         for key in ('tottime', 'cumtime'):
             st = pstats.Stats(pr)
             st.sort_stats(key).print_stats(45)

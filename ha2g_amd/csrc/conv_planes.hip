@@ -1329,6 +1329,7 @@ static int pconv_pp_launch(const PConvP& p, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((pconv_pp_kernel<BN, NP, OUT>), grid, dim3(512), lds, st, p);
     return 0;
 }
+static int g_q_classes = 1;  // stride-2 data gradients (up to four parity classes over grid.z) on the q kernel too (ha2g_conv_planes_tile3(7) = the 32x32 kernels, A/B)
 static int g_qbuf = 1;       // buffer-addressed DMA in the q kernel (ha2g_conv_planes_bufaddr(0) = flat addresses + zero page, A/B)
 static int g_kmaj = 1;       // k order of the q kernel's split products: 1 = channel-major (the nine taps of a 32-channel slice back to back), 0 = tap-major
 static int g_q_kernel = 1;   // the quantisation-free 16x16 kernel where its tile choice fills the CUs better (ha2g_conv_planes_tile3(5) forces, (6) = off)
@@ -1380,15 +1381,15 @@ static int pconv_q_dispatch(const PConvP& p_in, int maxM, hipStream_t st) {
     // buffer addressing needs 32-bit byte offsets inside a plane and the element counts of the planes (a: GH x GW x GC per image x images; b: N x K);
     // callers that know them set a_bytes / b_bytes, otherwise (0) the flat-address path runs
     p.buf = (g_qbuf && p.a_bytes > 0 && p.b_bytes > 0) ? 1 : 0;
-    {
-        PClass& c = p.cls[0];
+    for (int ci = 0; ci < p.ncls; ++ci) {
+        PClass& c = p.cls[ci];
         for (int t = 0; t < c.ntaps && t < 9; ++t) { c.khs[t] = (unsigned char)(c.tap[t] / p.KW); c.kws[t] = (unsigned char)(c.tap[t] % p.KW); }
         c.mg_ow = c.OWc > 1 ? (unsigned)(((1ULL << 32) + (unsigned)c.OWc - 1) / (unsigned)c.OWc) : 0u;
         c.mg_oh = c.OHc > 1 ? (unsigned)(((1ULL << 32) + (unsigned)c.OHc - 1) / (unsigned)c.OHc) : 0u;
     }
     const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     p.vec = (p.N % 4 == 0 && p.ldc % 4 == 0 && al16(p.C) && (!p.bias || al16(p.bias)) && (p.ksplit <= 1 || al16(p.ws))) ? 1 : 0;
-    if (p.ncls != 1) return -100;                                // stride-2 data gradients (parity classes of different sizes) keep the 32x32 kernels
+    if (p.ncls != 1 && (p.ksplit > 1 || !g_q_classes)) return -100;      // grid.z is the parity class OR the k slice
     int bmt = 0, bbn = 0;
     pconv_q_plan(maxM, p.N, p.ksplit > 1 ? p.ksplit : 1, &bmt, &bbn);
     if (bmt == 0) return -100;
@@ -1491,7 +1492,12 @@ void ha2g_conv_planes_ring(int depth) { g_ring = depth; }
 void ha2g_conv_planes_waves(int n) { g_waves = n == 8 ? 8 : 4; }
 void ha2g_conv_planes_bufaddr(int on) { g_qbuf = on ? 1 : 0; }
 void ha2g_conv_planes_korder(int channel_major) { g_kmaj = channel_major ? 1 : 0; }
-void ha2g_conv_planes_tile3(int t) { if (t == 6) { g_q_kernel = 0; g_tile3 = 0; } else { g_q_kernel = 1; g_tile3 = (t >= 0 && t <= 5) ? t : 0; } }
+void ha2g_conv_planes_tile3(int t) {
+    g_q_classes = 1;
+    if (t == 7) { g_q_classes = 0; g_q_kernel = 1; g_tile3 = 0; }
+    else if (t == 6) { g_q_kernel = 0; g_tile3 = 0; }
+    else { g_q_kernel = 1; g_tile3 = (t >= 0 && t <= 5) ? t : 0; }
+}
 
 // fp32 -> np bf16 piece planes of the same shape (piece q at planes + q * ps elements); n % 4 == 0, 16-byte aligned, ps % 8 == 0
 int ha2g_f32_to_planes_np(const float* x, void* planes, long ps, int np, long n, void* stream) {

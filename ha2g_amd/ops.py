@@ -27,6 +27,23 @@ def _stream():
     return _raw_stream(_cur_device())
 
 
+_stream_objs = {}
+_NO_STREAM_CACHE = os.environ.get('HA2G_NO_STREAM_CACHE', '0') != '0'      # A/B
+
+
+def cur_stream(device=None):
+    """torch.cuda.current_stream(device) without building a new Stream object per call: the objects are cached by raw handle (a step makes ~900 such
+    lookups for wait_stream / record_stream bookkeeping)."""
+    if _NO_STREAM_CACHE:
+        return torch.cuda.current_stream(device)
+    idx = device.index if (device is not None and device.index is not None) else _cur_device()
+    raw = _raw_stream(idx)
+    so = _stream_objs.get((idx, raw))
+    if so is None:
+        so = _stream_objs[(idx, raw)] = torch.cuda.current_stream(idx)
+    return so
+
+
 def workspace(device):
     """One persistent scratch buffer per (device, stream) (split-K partials, reduction partials).  Kernels of one stream
     run in order, so they can share it; the weight-gradient side stream gets its own.  Allocated once, outside capture."""
@@ -61,12 +78,12 @@ class SideStream:
         if not self.enabled:
             return contextlib.nullcontext()
         s = self.stream(device)
-        s.wait_stream(torch.cuda.current_stream(device))
+        s.wait_stream(cur_stream(device))
         return torch.cuda.stream(s)
 
     def join(self, device):
         if self.enabled:
-            torch.cuda.current_stream(device).wait_stream(self.stream(device))
+            cur_stream(device).wait_stream(self.stream(device))
 
 
 side = SideStream()
@@ -209,18 +226,25 @@ def gemm_grouped(a, b, transa=False, transb=False, out=None, alpha=1.0, beta=0.0
     A, Bm = parts(a, 2), parts(b, 2)
     G = len(A)
     assert len(Bm) == G and 1 <= G <= 8
-    for t in A + Bm:
-        _chk2d(t)
-    M, K = (A[0].shape[1], A[0].shape[0]) if transa else A[0].shape
-    Kb, N = (Bm[0].shape[1], Bm[0].shape[0]) if transb else Bm[0].shape
+    a0, b0 = A[0], Bm[0]
+    _chk2d(a0); _chk2d(b0)
+    sha, shb, lda, ldb = a0.shape, b0.shape, a0.stride(0), b0.stride(0)
+    for i in range(1, G):                                  # one pass (this wrapper runs 60+ times per step: host time)
+        ta, tb = A[i], Bm[i]
+        assert ta.shape == sha and ta.stride() == (lda, 1) and tb.shape == shb and tb.stride() == (ldb, 1) and ta.dtype == tb.dtype == torch.float32, \
+            'gemm_grouped: every group must have the shape, row stride and dtype of group 0'
+    M, K = (sha[1], sha[0]) if transa else sha
+    Kb, N = (shb[1], shb[0]) if transb else shb
     assert K == Kb
-    assert all(t.shape == A[0].shape and t.stride(0) == A[0].stride(0) for t in A) and all(t.shape == Bm[0].shape and t.stride(0) == Bm[0].stride(0) for t in Bm)
     ret = out
     if out is None:
         assert beta == 0.0
-        ret = out = torch.empty(G, M, N, dtype=torch.float32, device=A[0].device)
+        ret = out = torch.empty(G, M, N, dtype=torch.float32, device=a0.device)
     C = parts(out, 2)
-    assert len(C) == G and all(t.shape == (M, N) and t.stride(0) == C[0].stride(0) and t.stride(1) == 1 for t in C)
+    ldc = C[0].stride(0)
+    assert len(C) == G
+    for t in C:
+        assert t.shape == (M, N) and t.stride() == (ldc, 1)
     bias_l = parts(bias, 1)
     cs_l = parts(colsum_out, 1)
     if cs_l is not None:
@@ -228,8 +252,8 @@ def gemm_grouped(a, b, transa=False, transb=False, out=None, alpha=1.0, beta=0.0
     ws = workspace(A[0].device)
     keep = (_ptr_array(A), _ptr_array(Bm), _ptr_array(C), _ptr_array(bias_l) if bias_l is not None else None,
             _ptr_array(cs_l) if cs_l is not None else None)
-    check(lib.ha2g_gemm_grouped_f32(G, int(transa), int(transb), M, N, K, alpha, keep[0], A[0].stride(0), keep[1], Bm[0].stride(0), beta,
-                                    keep[2], C[0].stride(0), keep[3], act, keep[4], colsum_beta, ws.data_ptr(), ws.numel() * 4, _stream()))
+    check(lib.ha2g_gemm_grouped_f32(G, int(transa), int(transb), M, N, K, alpha, keep[0], lda, keep[1], ldb, beta,
+                                    keep[2], ldc, keep[3], act, keep[4], colsum_beta, ws.data_ptr(), ws.numel() * 4, _stream()))
     return ret
 
 

@@ -5,6 +5,7 @@ import torch
 
 from .hierarchy_net import (Hierarchical_ConvDiscriminator, Hierarchical_PoseGenerator, Hierarchical_WavEncoder,
                             TextEncoderTCN)
+from . import ops
 from .optim import FusedAdam
 from .train_hierarchy import train_iter_hierarchy, train_iter_hierarchy_expressive
 
@@ -94,11 +95,11 @@ class HierarchyTrainer:
         `graph.replay()` runs the step (fresh dropout masks / noise per replay, device-side Adam counters), `packed` then holds
         the logged scalars in `names` order.  Update the input tensors in place to feed new batches."""
         s = torch.cuda.Stream(self.device)
-        s.wait_stream(torch.cuda.current_stream(self.device))
+        s.wait_stream(ops.cur_stream(self.device))
         with torch.cuda.stream(s):                   # allocations / workspaces of the capture stream are created outside capture
             for _ in range(warmup):
                 self.train_iter(epoch, in_text_padded, in_spec, target, vid_indices, return_tensors=True)
-        torch.cuda.current_stream(self.device).wait_stream(s)
+        ops.cur_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
         from .train_hierarchy import drain_cluster_errors
         drain_cluster_errors(block=True)             # error words of earlier eager steps are looked at (and raised) BEFORE the capture starts

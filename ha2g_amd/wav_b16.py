@@ -90,7 +90,7 @@ def gconv(sink, name, x, dy, w_ohwi, stride, pad):
     side_on = we.SIDE_WGRAD and ops.side.enabled and x.is_cuda
     with (ops.side.section(dev) if side_on else ops._null()):
         if side_on:
-            st = torch.cuda.current_stream(dev)
+            st = ops.cur_stream(dev)
             x.record_stream(st); dy.record_stream(st)
         into = sink.tgt(sink.P[name])
         if lib.ha2g_conv2d_wgrad_b16_supported(H, W, Cin, Cout, KH, KW, stride, pad):

@@ -383,7 +383,7 @@ class GradSink:
     def gwb(self, wname, bname, a, b_):                   # dW (+)= a^T b_ and db (+)= column sums of a, one launch (ha2g_gemm_wgrad_bias_f32)
         if SIDE_FC_WGRAD and SIDE_WGRAD and ops.side.enabled and a.is_cuda:
             with ops.side.section(a.device):              # off the data-gradient chain, like the convolution weight gradients
-                st = torch.cuda.current_stream(a.device)
+                st = ops.cur_stream(a.device)
                 a.record_stream(st); b_.record_stream(st)
                 self._gwb(wname, bname, a, b_)
             self.forked = True
@@ -421,7 +421,7 @@ class GradSink:
         ctx = ops.side.section(xin.device) if side_on else ops._null()
         with ctx:
             if side_on:
-                st = torch.cuda.current_stream(xin.device)
+                st = ops.cur_stream(xin.device)
                 xin.record_stream(st); dy_planes.record_stream(st)
             if x_planes is not None and side_on:
                 x_planes.record_stream(st)
@@ -441,7 +441,7 @@ class GradSink:
         # bookkeeping (record_stream) because the caller drops them before the join at the end of the tower's backward.
         if SIDE_WGRAD and ops.side.enabled and xin.is_cuda:
             with ops.side.section(xin.device):
-                st = torch.cuda.current_stream(xin.device)
+                st = ops.cur_stream(xin.device)
                 xin.record_stream(st); dyc.record_stream(st)
                 r = conv_wgrad(xin, dyc, w_ohwi, stride, pad, into=self.tgt(self.P[name]))
                 if r is not None:

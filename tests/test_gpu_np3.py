@@ -86,7 +86,7 @@ def test_dgrad_three_piece_planes_are_fp32_class(B, H, W, C, tile):
     assert _rel(got1 - base, x64) < 5e-6
 
 
-@pytest.mark.parametrize('tile', [0, 4])
+@pytest.mark.parametrize('tile', [0, 4, 7])      # 0 = default (q kernel, the parity classes over grid.z), 4 / 7 = the 32x32 kernels
 @pytest.mark.parametrize('B,H,W,Cin,Cout,k', [(4, 128, 70, 32, 64, 3), (3, 64, 35, 64, 128, 3), (5, 32, 18, 128, 256, 3), (2, 9, 7, 64, 64, 3),
                                               (4, 128, 70, 32, 64, 1), (3, 64, 35, 64, 128, 1), (4, 32, 18, 128, 256, 1)])
 def test_stride2_dgrad_three_piece_planes_are_fp32_class(B, H, W, Cin, Cout, k, tile):
