@@ -105,6 +105,8 @@ DEFAULT_DIRECT_C32 = int(os.environ.get("HA2G_DIRECT_C32", "1"))
 lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
 if os.environ.get("HA2G_PLANES_DEBUG") is not None:  # A/B and ablation bits of the plane kernels (ha2g_conv_planes_debug)
     lib.ha2g_conv_planes_debug(int(os.environ["HA2G_PLANES_DEBUG"]))
+if os.environ.get("HA2G_C32_PREFETCH") is not None:  # A/B: prefetching form of the 32-channel three-piece direct convolution (1 = default)
+    lib.ha2g_conv_c32_prefetch(int(os.environ["HA2G_C32_PREFETCH"]))
 if os.environ.get("HA2G_TILE3") is not None:        # A/B: tile / kernel form of the three-piece plane kernels (ha2g_conv_planes_tile3)
     lib.ha2g_conv_planes_tile3(int(os.environ["HA2G_TILE3"]))
 if os.environ.get("HA2G_QBUF") is not None:         # A/B: buffer-addressed DMA in the plane kernel (1 = default)

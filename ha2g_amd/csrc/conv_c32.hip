@@ -348,6 +348,298 @@ __global__ __launch_bounds__((X3Geo<C, NP>::THREADS), 1) void conv3x3_x3_kernel(
 }
 
 
+// ---- PREFETCHING form of conv3x3_x3_kernel<32, 3> (round 4).  The first form fills its single patch buffer (global loads -> split -> LDS), then
+// runs the tile's 216 MFMAs per wave, then stores, tile after tile: with one wave per SIMD nothing hides the ~2 us of load latency and the ~1 us of
+// split + LDS writes of each of a workgroup's 17.5 tiles (262 us per launch for 51 us of matrix work).  Here the NEXT tile's global loads are issued
+// into registers (16 float4 per thread: the whole 7-row patch) BEFORE the current tile's MFMAs and stores, and are split / written to LDS after the
+// barrier that retires the current patch -- the load latency runs under the matrix phase.  Same values, same MFMA order: bit-identical results. ----
+__global__ __launch_bounds__(256, 1) void conv3x3_x3p_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H,
+                                                             int W, int flip, int act, float beta, int plane_elems) {
+    using G = X3Geo<32, 3>;
+    constexpr int NP = 3, C = 32, NSF = 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned short pl[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int HW = H * W, PW = W + 2;
+    const int tpi = (HW + TP - 1) / TP;
+    const long tiles = (long)N * tpi;
+    const int nout = l31;
+
+    bf16x8_t bq[NP][9][G::CHUNKS];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tt = flip ? 8 - t : t;
+#pragma unroll
+        for (int c = 0; c < G::CHUNKS; ++c) {
+            const float* src = w + ((long)nout * 9 + tt) * C + 16 * c + 8 * lhi;
+            const float4 u0 = *reinterpret_cast<const float4*>(src);
+            const float4 u1 = *reinterpret_cast<const float4*>(src + 4);
+            unsigned e0[NP], e1[NP], e2[NP], e3[NP];
+            splitn_bf16<NP>(u0.x, u0.y, e0); splitn_bf16<NP>(u0.z, u0.w, e1); splitn_bf16<NP>(u1.x, u1.y, e2); splitn_bf16<NP>(u1.z, u1.w, e3);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) bq[q][t][c] = __builtin_bit_cast(bf16x8_t, make_uint4(e0[q], e1[q], e2[q], e3[q]));
+        }
+    }
+    unsigned short* phi = pl;
+    float4 pv[NSF]; int poff[NSF];                           // the NEXT tile's patch slots of this thread, in flight / waiting for the barrier
+    const int c4 = tid % G::QP, pp0 = tid / G::QP;
+    auto issue = [&](const Tile& t) {
+        int pp = pp0;
+        int pr = pp / PW, px = pp - pr * PW;
+        long g = ((long)t.img * HW + (long)(t.r0 - 1 + pr) * W + (px - 1)) * C + 4 * c4;
+#pragma unroll
+        for (int i = 0; i < NSF; ++i) {
+            poff[i] = -1;
+            pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pr < t.rows) {
+                const int gy = t.r0 - 1 + pr;
+                if (gy >= 0 && gy < H && px >= 1 && px <= W) pv[i] = *reinterpret_cast<const float4*>(x + g);
+                poff[i] = pp * G::CSX + 4 * c4;
+            }
+            pp += G::PSTEP; px += G::PSTEP; g += (long)G::PSTEP * C;
+            if (px >= PW) { px -= PW; ++pr; g -= 2 * C; }        // PSTEP < PW (host check): at most one row wrap per slot
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NSF; ++i)
+            if (poff[i] >= 0) {
+                unsigned e0[NP], e1[NP];
+                splitn_bf16<NP>(pv[i].x, pv[i].y, e0); splitn_bf16<NP>(pv[i].z, pv[i].w, e1);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(phi + q * plane_elems + poff[i]) = make_uint2(e0[q], e1[q]);
+            }
+    };
+    const int dbg = act >> 8;                               // timing ablations (ha2g_conv_c32_prefetch(1 | bits << 1)): 1 no MFMA, 2 no LDS fill, 4 no stores, 8 no loads
+    long tile = blockIdx.x;
+    if (tile >= tiles) return;
+    Tile cur = tile_of(tile, tpi, HW, W);
+    issue(cur);
+    commit();
+    __syncthreads();
+    for (;;) {
+        const long ntile = tile + gridDim.x;
+        const bool has_next = ntile < tiles;
+        Tile nxt = cur;
+        if (has_next) { nxt = tile_of(ntile, tpi, HW, W); if (!(dbg & 8)) issue(nxt); }
+        int a0[G::MB];
+#pragma unroll
+        for (int b = 0; b < G::MB; ++b) {
+            int p = cur.p0 + 32 * (G::MB * wave + b) + l31;
+            if (p >= HW) p = HW - 1;                                     // clamp: stays inside the patch, result discarded
+            const int py = p / W, px = p - py * W;
+            a0[b] = ((py - cur.r0) * PW + px) * G::CSX + 8 * lhi;
+        }
+        f32x16 acc[G::MB];
+#pragma unroll
+        for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        if (!(dbg & 1))
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * PW + (t % 3)) * G::CSX;
+#pragma unroll
+            for (int c = 0; c < G::CHUNKS; ++c) {
+                // the two pixel blocks' chains INTERLEAVED: six back-to-back MFMAs on one accumulator each wait out the previous one's latency
+                // (the first form ran them block after block); alternating the blocks keeps two independent chains in the pipe.  Per accumulator
+                // the order of the products is unchanged.
+                bf16x8_t aq[G::MB][NP];
+#pragma unroll
+                for (int b = 0; b < G::MB; ++b)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) aq[b][q] = *reinterpret_cast<const bf16x8_t*>(phi + q * plane_elems + a0[b] + toff + 16 * c);
+                constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+#pragma unroll
+                    for (int b = 0; b < G::MB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[b][QA[u]], bq[QB[u]][t][c], acc[b], 0, 0, 0);
+            }
+        }
+        float* yout = y + (long)cur.img * HW * C;
+        if (!(dbg & 4))
+#pragma unroll
+        for (int b = 0; b < G::MB; ++b) {
+            const int pb0 = cur.p0 + 32 * (G::MB * wave + b);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pp = pb0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (pp >= HW) continue;
+                float v = acc[b][r];
+                float* d = yout + (long)pp * C + nout;
+                if (beta != 0.f) v += beta * *d;
+                if ((act & 15) == 1) v = fmaxf(v, 0.f);
+                *d = v;
+            }
+        }
+        if (!has_next) break;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done reading the current patch
+        if (!(dbg & 2)) commit();                                         // the prefetched tile: split + LDS writes (its loads landed under the MFMAs)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // patch complete (LDS only: the output stores keep draining)
+        tile = ntile; cur = nxt;
+    }
+}
+
+
+// ---- ANTI-PHASE form (round 4): conv3x3_c32pp_kernel.  tools/c32_ablate.py on the prefetching form: matrix phase 94 us, output stores 36, global loads 30,
+// split + LDS fill 26 -- and they ADD UP (182 us): with one wave per SIMD nothing runs beside the matrix pipe.  Here a workgroup is two groups of four
+// waves (wave w and w + 4 share a SIMD) that work on their OWN 128-pixel tiles in opposite phases: while one group's 216 MFMAs per wave run, the other
+// stores its finished tile, splits / writes its next patch from registers and issues the loads of the tile after that; one workgroup barrier per phase.
+// To fit two waves per SIMD a wave owns 64 pixels x 16 output channels on v_mfma_f32_16x16x32_bf16 (108 filter registers instead of 216); the weight
+// fragment is the first operand (D = W X^T), so a lane holds four consecutive output channels of one pixel: one 16-byte store per 16 x 16 tile.
+// Patch: [piece][padded pixel][32 channels] bf16, 64 bytes per pixel, 16-byte slots XOR-ed with (pixel >> 2) & 3 (conflict-free ds_read_b128 for any
+// tap shift).  Products and their order per accumulator = the other three-piece kernels (six per k block, smallest first). ----
+constexpr int TPH = 128;                                     // pixels of a group's tile
+__device__ __forceinline__ int fast_div_c32(int m, int d, unsigned mg) {
+    int q = (int)__umulhi((unsigned)m, mg);                   // mg = ceil(2^32 / d), d >= 2: the quotient or one more
+    if (q * d > m) --q;
+    return q;
+}
+__global__ __launch_bounds__(512, 1) void conv3x3_c32pp_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H,
+                                                               int W, int flip, int act, float beta, int plane_elems, unsigned mgW) {
+    constexpr int NP = 3, C = 32, NSF = 12;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(1024))) unsigned short ppl[];          // [group][piece][plane_elems]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3, ph = w4 & 1, chh = w4 >> 1;
+    const int l15 = lane & 15, kp = lane >> 4;
+    const int gt = tid & 255;                                // thread index inside the group
+    const int HW = H * W, PW = W + 2;
+    const int tpi = (HW + TPH - 1) / TPH;
+    const long tiles = (long)N * tpi;
+    unsigned short* const pg = ppl + (long)grp * NP * plane_elems;
+
+    // filter -> registers: lane (channel chh * 16 + l15, k piece kp) holds input channels 8 kp .. + 7 of every tap, as three pieces
+    bf16x8_t bq[NP][9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tt = flip ? 8 - t : t;
+        const float* src = w + ((long)(chh * 16 + l15) * 9 + tt) * C + 8 * kp;
+        const float4 u0 = *reinterpret_cast<const float4*>(src);
+        const float4 u1 = *reinterpret_cast<const float4*>(src + 4);
+        unsigned e0[NP], e1[NP], e2[NP], e3[NP];
+        splitn_bf16<NP>(u0.x, u0.y, e0); splitn_bf16<NP>(u0.z, u0.w, e1); splitn_bf16<NP>(u1.x, u1.y, e2); splitn_bf16<NP>(u1.z, u1.w, e3);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) bq[q][t] = __builtin_bit_cast(bf16x8_t, make_uint4(e0[q], e1[q], e2[q], e3[q]));
+    }
+
+    auto tile_at = [&](long t) {
+        Tile r;
+        r.img = (int)(t / tpi); r.p0 = (int)(t - (long)r.img * tpi) * TPH;
+        const int pend = min(r.p0 + TPH, HW);
+        r.r0 = fast_div_c32(r.p0, W, mgW);
+        r.rows = fast_div_c32(pend - 1, W, mgW) - r.r0 + 3;
+        return r;
+    };
+    // patch slots of this thread: padded pixel (source numbering, rows of PW pixels) pp0 + 32 i, channel quad c4 (4 fp32 = 8 bytes of a piece plane)
+    const int c4 = gt & 7, pp0 = gt >> 3;
+    const int pr0 = pp0 / PW, px0 = pp0 - pr0 * PW;
+    float4 pv[NSF]; unsigned pmask = 0u;                     // the next tile's slots in flight; bit i = slot i lies inside the patch
+    auto issue = [&](const Tile& t) {
+        int pr = pr0, px = px0;
+        long g = ((long)t.img * HW + (long)(t.r0 - 1 + pr) * W + (px - 1)) * C + 4 * c4;
+        pmask = 0u;
+#pragma unroll
+        for (int i = 0; i < NSF; ++i) {
+            pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pr < t.rows) {
+                const int gy = t.r0 - 1 + pr;
+                if (gy >= 0 && gy < H && px >= 1 && px <= W) pv[i] = *reinterpret_cast<const float4*>(x + g);
+                pmask |= 1u << i;
+            }
+            px += 32; g += 32L * C;
+            if (px >= PW) { px -= PW; ++pr; g -= 2 * C; }        // 32 < PW (host check): at most one row wrap per slot
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NSF; ++i)
+            if (pmask & (1u << i)) {
+                const int pp = pp0 + 32 * i;
+                const int off = pp * 32 + ((((c4 >> 1) ^ ((pp >> 2) & 3)) << 3) | ((c4 & 1) << 2));      // element offset: swizzled 16-byte slot + half
+                unsigned e0[NP], e1[NP];
+                splitn_bf16<NP>(pv[i].x, pv[i].y, e0); splitn_bf16<NP>(pv[i].z, pv[i].w, e1);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(pg + q * plane_elems + off) = make_uint2(e0[q], e1[q]);
+            }
+    };
+    f32x4_t acc[4];
+    auto matrix = [&](const Tile& t) {
+        int ppb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int p = t.p0 + ph * 64 + i * 16 + l15;
+            if (p >= HW) p = HW - 1;                         // clamp: stays inside the patch, result discarded
+            const int py = fast_div_c32(p, W, mgW), px = p - py * W;
+            ppb[i] = (py - t.r0) * PW + px;
+            acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};          // (pixel piece, filter piece), smallest products first
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int toff = (tp / 3) * PW + (tp % 3);
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {                 // two row tiles at a time: two independent accumulator chains, 24 fragment registers
+                bf16x8_t aq[2][NP];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int pp = ppb[2 * ip + j] + toff;
+                    const int eo = pp * 32 + ((kp ^ ((pp >> 2) & 3)) << 3);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) aq[j][q] = *reinterpret_cast<const bf16x8_t*>(pg + q * plane_elems + eo);
+                }
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[2 * ip + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[QB[u]][tp], aq[j][QA[u]], acc[2 * ip + j], 0, 0, 0);
+            }
+        }
+    };
+    auto store = [&](const Tile& t) {
+        float* yout = y + (long)t.img * HW * C + chh * 16 + 4 * kp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = t.p0 + ph * 64 + i * 16 + l15;
+            if (p >= HW) continue;
+            f32x4_t v = acc[i];
+            f32x4_t* d = reinterpret_cast<f32x4_t*>(yout + (long)p * C);
+            if (beta != 0.f) v += beta * *d;
+            if ((act & 15) == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            *d = v;
+        }
+    };
+
+    // this group's tiles: 2 blockIdx.x + grp, then every 2 gridDim.x; both groups run the same number of rounds (the barriers are workgroup-wide)
+    const long stride = 2L * gridDim.x;
+    const long first = 2L * blockIdx.x + grp;
+    const long n_rounds = (tiles - 2L * blockIdx.x + stride - 1) / stride;           // rounds of group 0 (>= those of group 1)
+    Tile cur = tile_at(first < tiles ? first : 0), nxt = cur;
+    bool v_cur = first < tiles, v_nxt = first + stride < tiles;
+    if (v_cur) { issue(cur); commit(); }
+    if (v_nxt) { nxt = tile_at(first + stride); issue(nxt); }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (grp == 1) asm volatile("s_barrier" ::: "memory");                            // half a round behind group 0
+    const int dbg = act >> 8;                               // timing ablations (ha2g_conv_c32_prefetch bits 1-4): 1 no MFMA, 2 no LDS fill, 4 no stores, 8 no loads
+    for (long k = 0; k < n_rounds; ++k) {
+        if (v_cur && !(dbg & 1)) matrix(cur);                                         // MATRIX phase
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // OTHER phase: next patch from registers FIRST (its loads are the oldest outstanding memory operations: a counted vmcnt suffices -- behind the
+        // stores the wait would be for the stores' write acknowledgements), then this tile's stores, then the loads of the tile after the next
+        const Tile done = cur; const bool v_done = v_cur;
+        cur = nxt; v_cur = v_nxt;
+        if (v_cur && !(dbg & 2)) commit();
+        if (v_done && !(dbg & 4)) store(done);
+        const long t2 = first + (k + 2) * stride;
+        v_nxt = t2 < tiles;
+        if (v_nxt) { nxt = tile_at(t2); if (!(dbg & 8)) issue(nxt); }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");
+}
+
+
 // ---- direct weight gradient, 32 -> 32 channels, 3x3 / stride 1 / pad 1 (split-bf16) ---------------------------------------------------
 // dW[co][tap][ci] = sum over pixels of dy[p][co] * x[p + tap][ci].  The implicit GEMM stages the im2col gather of x -- the same patch nine
 // times, for only 32 rows of reuse -- and is bound by that staging (237 us at B = 128).  Here a tile is 128 consecutive pixels of one image:
@@ -566,7 +858,62 @@ static int conv3x3_x3_launch_t(const float* x, const float* w, float* y, int N, 
     HA2G_CHECK_LAUNCH("conv3x3_x3");
     return 0;
 }
+static int g_x3_prefetch = 1;       // conv3x3_x3p_kernel where its 16 slots per thread hold the patch (ha2g_conv_c32_prefetch(0): the first form, A/B)
+static int g_x3p_dbg = 0;
+static int g_c32pp = 1;             // the anti-phase kernel conv3x3_c32pp_kernel (ha2g_conv_c32_prefetch bit 5 clears it: A/B)
+extern "C" void ha2g_conv_c32_prefetch(int on) { g_x3_prefetch = on & 1; g_x3p_dbg = (on >> 1) & 15; g_c32pp = !((on >> 5) & 1); }
+static int conv3x3_x3p_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st) {
+    using G = X3Geo<32, 3>;
+    const int rows_max = (TP + W - 2) / W + 1 + 2;
+    const int plane_elems = rows_max * (W + 2) * G::CSX;
+    const size_t lds = (size_t)3 * plane_elems * sizeof(unsigned short);
+    if (lds > 150 * 1024 || (long)H * W < TP || W + 2 <= G::PSTEP) return -100;
+    if ((long)rows_max * (W + 2) * G::QP > 16L * G::THREADS) return -100;          // the patch must fit the 16 prefetch slots per thread
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_x3p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return ha2g_set_error(-2, "conv3x3_x3p: cannot raise the dynamic LDS limit");
+        attr_set[dev] = true;
+    }
+    const long items = (long)N * (((long)H * W + TP - 1) / TP);
+    const int grid = (int)(items < 256 ? items : 256);
+    hipLaunchKernelGGL(conv3x3_x3p_kernel, dim3(grid), dim3(G::THREADS), lds, st, x, w, y, N, H, W, flip, (act & 255) | (g_x3p_dbg << 8), beta, plane_elems);
+    HA2G_CHECK_LAUNCH("conv3x3_x3p");
+    return 0;
+}
+static int conv3x3_c32pp_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st) {
+    const int rows_max = (TPH + W - 2) / W + 1 + 2;
+    const int plane_elems = rows_max * (W + 2) * 32;
+    const size_t lds = (size_t)2 * 3 * plane_elems * sizeof(unsigned short);
+    if (lds > 156 * 1024 || (long)H * W < TPH || W + 2 <= 32 || W < 2) return -100;
+    if ((long)rows_max * (W + 2) * 8 > 12L * 256) return -100;                       // the patch must fit the 12 prefetch slots per thread
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+            return ha2g_set_error(-2, "conv3x3_c32pp: cannot raise the dynamic LDS limit");
+        attr_set[dev] = true;
+    }
+    const long tiles = (long)N * (((long)H * W + TPH - 1) / TPH);
+    const long pairs = (tiles + 1) / 2;
+    const int grid = (int)(pairs < 256 ? pairs : 256);
+    const unsigned mgW = (unsigned)(((1ULL << 32) + (unsigned)W - 1) / (unsigned)W);
+    hipLaunchKernelGGL(conv3x3_c32pp_kernel, dim3(grid), dim3(512), lds, st, x, w, y, N, H, W, flip, (act & 255) | (g_x3p_dbg << 8), beta, plane_elems, mgW);
+    HA2G_CHECK_LAUNCH("conv3x3_c32pp");
+    return 0;
+}
 int conv3x3_c32_x3_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st) {
+    if (gemm_bwd_pieces() == 3 && g_c32pp) {
+        const int rc = conv3x3_c32pp_launch(x, w, y, N, H, W, flip, act, beta, st);
+        if (rc != -100) return rc;
+    }
+    if (gemm_bwd_pieces() == 3 && g_x3_prefetch) {
+        const int rc = conv3x3_x3p_launch(x, w, y, N, H, W, flip, act, beta, st);
+        if (rc != -100) return rc;
+    }
     if (gemm_bwd_pieces() == 3) return conv3x3_x3_launch_t<32, 3>(x, w, y, N, H, W, flip, act, beta, st);      // fp32-class: three pieces
     return conv3x3_x3_launch_t<32, 2>(x, w, y, N, H, W, flip, act, beta, st);
 }

@@ -760,6 +760,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmP p) {
 }
 
 static int g_c32_dbg = 0;
+static int g_c32_fwd3 = 1;      // layer-1 forward on the three-piece direct kernel in the default mode (ha2g_conv_debug_direct_c32 bit 6 clears it)
 static int g_direct_c32_dgrad = 0;
 static int g_direct_c32_x3 = 1;  // data gradient of the 32->32 channel 3x3 convolutions on the split-bf16 direct kernel (debug bit 2 = off)
 static int g_direct_c32 = 1;     // 32->32 channel 3x3 stride-1 forward convolutions on the direct LDS-patch kernel (conv_c32.hip): DEFAULT since it is bit-identical to the implicit GEMM (round 2: same k pairing and order).
@@ -1098,7 +1099,7 @@ void ha2g_gemm_set_mode(int mode) { g_x3 = mode & 1; g_split_wgrad = (mode >> 1)
 int ha2g_gemm_bwd_pieces(void) { return (g_bf16 || !(g_split_wgrad || g_split_dgrad)) ? 0 : gemm_bwd_pieces(); }
 void ha2g_gemm_debug_x6_min_n(int n) { g_x6_min_n = n; }
 void ha2g_gemm_debug_tile(int cfg, int splits) { g_tile_model = cfg != -2; g_tile_force = cfg == -2 ? -1 : cfg; g_splits_force = splits; }
-void ha2g_conv_debug_direct_c32(int on) { g_direct_c32 = on & 1; g_direct_c32_dgrad = (on >> 1) & 1; g_direct_c32_x3 = !((on >> 2) & 1); g_c32_dbg = on & 0x30; }
+void ha2g_conv_debug_direct_c32(int on) { g_direct_c32 = on & 1; g_direct_c32_dgrad = (on >> 1) & 1; g_direct_c32_x3 = !((on >> 2) & 1); g_c32_dbg = on & 0x30; g_c32_fwd3 = !((on >> 6) & 1); }
 void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 40000) g_direct_c32_wgrad = cfg - 40000; else if (cfg >= 30000) g_wgrad_planes = cfg - 30000; else if (cfg >= 20000) g_wgrad_wide = cfg - 20000; else if (cfg >= 10000) g_wgrad_blocks = cfg - 10000; else if (cfg >= 1000) g_split_tiles = cfg - 1000; else g_conv_cfg = cfg; }   /* 1000+n: split-K tile threshold n; 10000+n: wgrad block target n */
 
 // Dense GEMM, row-major.  transa/transb follow BLAS meaning on row-major storage:
@@ -1215,6 +1216,12 @@ int ha2g_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float
     HA2G_REQUIRE(KH * KW <= 32, "conv2d_fwd: at most 32 filter taps");
     int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
     if (g_direct_c32 && Cin == 32 && Cout == 32 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && bias == nullptr && act <= 1) {
+        // fp32-class default mode: the layer-1 forward on three pieces as well (anti-phase direct kernel, conv_c32.hip: 160 vs 230 us); modes 0 / 6 and
+        // shapes it does not serve keep the fp32 direct kernel that is bit-identical to the implicit GEMM
+        if (g_np3 && g_c32_fwd3) {
+            int rc = conv3x3_c32_x3_launch(x, w, y, N, H, W, 0, act, 0.f, (hipStream_t)stream);
+            if (rc != -100) return rc;
+        }
         int rc = conv3x3_c32_launch(x, w, y, N, H, W, 0, act | g_c32_dbg, 0.f, (hipStream_t)stream);
         if (rc != -100) return rc;
     }

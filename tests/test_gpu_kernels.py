@@ -378,7 +378,9 @@ def test_direct_conv3x3_c32(shape):
     try:
         # 3: fp32 direct kernel for forward and data gradient; 0: forward implicit GEMM, data gradient on the split-bf16 direct kernel
         # (the default is 1: direct forward + split-bf16 direct data gradient); 4: everything on the implicit GEMM
-        for mode in (3, 0, 4):
+        # 67 = 3 + bit 6: the fp32 direct forward kernel also in the default (three-piece) arithmetic mode, where 3 sends the forward to the three-piece
+        # anti-phase kernel (conv3x3_c32pp_kernel) like the data gradient
+        for mode in (3, 67, 0, 4):
             lib.ha2g_conv_debug_direct_c32(mode)
             y = we.conv_fwd(xg, wg, None, 1, 1, we.ACT_RELU)
             acc = base.permute(0, 2, 3, 1).contiguous().to(dev)
@@ -386,12 +388,12 @@ def test_direct_conv3x3_c32(shape):
             outs[mode] = (y.permute(0, 3, 1, 2), dx.permute(0, 3, 1, 2))
     finally:
         lib.ha2g_conv_debug_direct_c32(__import__('ha2g_amd._lib', fromlist=['x']).DEFAULT_DIRECT_C32)
-    for mode in (3, 0, 4):
+    for mode in (3, 67, 0, 4):
         assert relerr(outs[mode][0], ref_y) < 2e-6, mode
         # split-bf16 data gradients: ~4e-6 rms; the direct kernels need W + 2 > 64, narrower maps fall back to the split GEMM
         assert relerr(outs[mode][1], ref_dx) < (2e-6 if (mode == 3 and W > 62) else 2e-5), mode
     # the direct forward kernel feeds every accumulator the implicit GEMM's MFMA chain (same k pairs, same order): bit-identical outputs
-    assert torch.equal(outs[3][0], outs[4][0])
+    assert torch.equal(outs[67][0], outs[4][0])
 
 
 def test_plain_bf16_mode_is_bf16_accurate():
