@@ -410,9 +410,14 @@ def main():
         if 'conv2d_fwd' in kt:                     # the largest kernel family by time: implicit-GEMM convolutions of the audio tower (forward, fp32 MFMA)
             n, mean_us, _, flops = kt['conv2d_fwd']
             ach = flops / (n * mean_us * 1e-6) / 1e12
-            roof_conv = dict(kernel='gemm_kernel<A_IM,B_KC> (ha2g_conv2d_fwd_f32, all SE-ResNet34 forward convolutions)', bound='mfma',
-                             achieved=round(ach, 2), peak=157.3, unit='TFLOP/s', frac=round(ach / 157.3, 4), launches=n,
-                             mean_us=round(mean_us, 1), traffic=None)
+            if bwd_pieces == 3:      # default mode: what ha2g_conv2d_fwd_f32 still serves is the 32-channel layer on the three-piece anti-phase direct kernel + the taps (fp32 implicit GEMM)
+                roof_conv = dict(kernel='conv3x3_c32pp_kernel (three-piece direct kernel: the six 32-channel forward convolutions of layer 1) + gemm_kernel<A_IM,B_KC> for the tap convolutions (ha2g_conv2d_fwd_f32)',
+                                 bound='mfma', achieved=round(ach, 2), peak=round(2500.0 / 6, 1), unit='TFLOP/s (fp32-equivalent: 6 bf16 MFMAs per product)',
+                                 frac=round(ach / (2500.0 / 6), 4), frac_of_fp32_mfma_peak=round(ach / 157.3, 4), launches=n, mean_us=round(mean_us, 1), traffic=None)
+            else:
+                roof_conv = dict(kernel='gemm_kernel<A_IM,B_KC> / conv3x3_c32_kernel (ha2g_conv2d_fwd_f32, SE-ResNet34 forward convolutions on the fp32 MFMA)', bound='mfma',
+                                 achieved=round(ach, 2), peak=157.3, unit='TFLOP/s', frac=round(ach / 157.3, 4), launches=n,
+                                 mean_us=round(mean_us, 1), traffic=None)
         # backward matrix kernels (round 3: plane-based conv data / weight gradients of trunk layers 2-4) priced against the 3-product split-bf16
         # roofline = dense bf16 MFMA peak / 3; BatchNorm passes against HBM with their algorithmic bytes (reads of dy / x per pass + the write)
         def mfma3(key, kernel):
@@ -423,7 +428,7 @@ def main():
             nprod = 6 if bwd_pieces == 3 else 3                    # bf16 MFMAs per fp32-equivalent product
             return dict(kernel=kernel, bound='mfma', achieved=round(ach, 2), peak=round(2500.0 / nprod, 1), unit='TFLOP/s (fp32-equivalent: %d bf16 MFMAs per product)' % nprod,
                         frac=round(ach / (2500.0 / nprod), 4), launches=n, mean_us=round(mean_us, 1), traffic=None)
-        roof_conv_fp32 = roof_conv                      # what still runs on the fp32 MFMA: the stem-side 32-channel layer (direct kernel) and the taps
+        roof_conv_fp32 = roof_conv                      # ha2g_conv2d_fwd_f32's callers: the 32-channel layer (three-piece direct kernel in the default mode) and the taps
         if 'conv2d_fwd_planes' in kt:                   # forward convolutions of trunk layers 2-4: three-piece planes (always six MFMAs per product)
             n, mean_us, _, flops = kt['conv2d_fwd_planes']
             ach = flops / (n * mean_us * 1e-6) / 1e12
@@ -461,13 +466,13 @@ def main():
                    vs_baseline=None,
                    dtype=(('bf16 (matrix operands; audio-trunk activations and activation gradients stored as bf16; fp32 accumulate, fp32 statistics, fp32 master weights and optimizer)'
                            if b16_storage else 'bf16 (operands; fp32 accumulate, fp32 storage and master weights)') if a.bf16 else
-                          {3: 'f32 (storage, accumulation; matrix products: bf16x3 split = all 24 operand mantissa bits, six bf16 MFMAs per product, fp32 accumulate (trunk convolutions forward + backward, dense products >= 4 GFLOP, both GRU chains, every backward GEMM) or the fp32 MFMA (small forward GEMMs, 32-channel forward, stem))',
+                          {3: 'f32 (storage, accumulation; matrix products: bf16x3 split = all 24 operand mantissa bits, six bf16 MFMAs per product, fp32 accumulate (trunk convolutions forward + backward, dense products >= 4 GFLOP, both GRU chains, every backward GEMM) or the fp32 MFMA (small forward GEMMs, tap convolutions, stem))',
                            2: 'f32 storage / accumulation, forward products fp32 MFMA; backward products: bf16x2 split = 16-bit operand mantissa (NOT fp32-class), fp32 accumulate',
                            0: 'f32 (every product on the fp32 MFMA)'}[bwd_pieces]),
                    data='synthetic', rehearsal=rehearsal, launch=launch, launch_note=graph_note, rccl_world=rccl_world, eager=eager, graph_replay=graph_leg,
                    cluster_retries=tr.cluster_retries,
                    matrix_core=('bf16 operands (1 MFMA per product), fp32 accumulate, fp32 storage and master weights; GRU recurrences fp32' if a.bf16 else
-                                {3: '3-piece split-bf16 (x = p0+p1+p2 holds all 24 mantissa bits; six bf16 MFMAs per product, smallest first, fp32 accumulate: as accurate as the fp32 MFMA chain, tests/test_gpu_np3.py): forward + backward convolutions of trunk layers 2-4 (v_mfma_f32_16x16x32_bf16 / 32x32x16), 32-channel data / weight gradients, dense products >= 4 GFLOP, every backward GEMM, GRU forward and BPTT chains; fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4): small forward GEMMs, 32-channel forward, stem',
+                                {3: '3-piece split-bf16 (x = p0+p1+p2 holds all 24 mantissa bits; six bf16 MFMAs per product, smallest first, fp32 accumulate: as accurate as the fp32 MFMA chain, tests/test_gpu_np3.py): forward + backward convolutions of trunk layers 1-4 (v_mfma_f32_16x16x32_bf16 / 32x32x16), dense products >= 4 GFLOP, every backward GEMM, GRU forward and BPTT chains; fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4): small forward GEMMs, tap convolutions, stem',
                                  2: 'forward: fp32 MFMA; backward GEMMs/convs/BPTT: 2-piece split-bf16 (hi+lo, 3 bf16 MFMAs per product; 4e-6 rms-rel per GEMM vs 4e-7 for fp32 MFMA)',
                                  0: 'fp32 MFMA everywhere'}[bwd_pieces]),
                    two_piece_backward=dict(ms_per_step=round(ms_m6, 3), value=round(a.batch * 34 * world / (ms_m6 * 1e-3), 1) if ms_m6 == ms_m6 else None, steps=a.steps, launch=launch2,

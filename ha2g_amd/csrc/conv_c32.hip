@@ -502,16 +502,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c32pp_kernel(const float* __re
     extern __shared__ __attribute__((aligned(1024))) unsigned short ppl[];          // [group][piece][plane_elems]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, w4 = wave & 3, ph = w4 & 1, chh = w4 >> 1;
+    // groups by wave parity (A/B bit 14 of act: by wave >> 2): the same within the scatter of repeated runs (155-165 us either way, tools/c32_ablate.py)
+    const bool by_half = (act >> 14) & 1;
+    const int grp = by_half ? (wave >> 2) : (wave & 1), w4 = by_half ? (wave & 3) : (wave >> 1), ph = w4 & 1, chh = w4 >> 1;
     const int l15 = lane & 15, kp = lane >> 4;
-    const int gt = tid & 255;                                // thread index inside the group
+    const int gt = w4 * 64 + lane;                           // thread index inside the group
     const int HW = H * W, PW = W + 2;
     const int tpi = (HW + TPH - 1) / TPH;
     const long tiles = (long)N * tpi;
     unsigned short* const pg = ppl + (long)grp * NP * plane_elems;
 
-    // filter -> registers: lane (channel chh * 16 + l15, k piece kp) holds input channels 8 kp .. + 7 of every tap, as three pieces
-    bf16x8_t bq[NP][9];
+    // filter: lane (channel chh * 16 + l15, k piece kp) holds input channels 8 kp .. + 7 of every tap -- pieces 0 / 1 in registers (72), piece 2 (one
+    // of the six products per tap) in LDS behind the patches: 36 registers less, which is what lets FOUR accumulator chains run interleaved (a
+    // dependent v_mfma_f32_16x16x32_bf16 waits ~60 cycles: with two chains the matrix phase ran at 29 cycles per MFMA, tools/c32_ablate.py)
+    bf16x8_t bq[2][9];
+    unsigned short* const fl2 = ppl + 2L * NP * plane_elems;                        // [channel half][tap][lane][8]
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int tt = flip ? 8 - t : t;
@@ -521,7 +526,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c32pp_kernel(const float* __re
         unsigned e0[NP], e1[NP], e2[NP], e3[NP];
         splitn_bf16<NP>(u0.x, u0.y, e0); splitn_bf16<NP>(u0.z, u0.w, e1); splitn_bf16<NP>(u1.x, u1.y, e2); splitn_bf16<NP>(u1.z, u1.w, e3);
 #pragma unroll
-        for (int q = 0; q < NP; ++q) bq[q][t] = __builtin_bit_cast(bf16x8_t, make_uint4(e0[q], e1[q], e2[q], e3[q]));
+        for (int q = 0; q < 2; ++q) bq[q][t] = __builtin_bit_cast(bf16x8_t, make_uint4(e0[q], e1[q], e2[q], e3[q]));
+        if (grp == 0 && ph == 0) *reinterpret_cast<uint4*>(fl2 + ((chh * 9 + t) * 64 + lane) * 8) = make_uint4(e0[2], e1[2], e2[2], e3[2]);
     }
 
     auto tile_at = [&](long t) {
@@ -579,22 +585,24 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c32pp_kernel(const float* __re
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
             const int toff = (tp / 3) * PW + (tp % 3);
+            const bf16x8_t b2 = *reinterpret_cast<const bf16x8_t*>(fl2 + ((chh * 9 + tp) * 64 + lane) * 8);
+            bf16x8_t aq[4][NP];
 #pragma unroll
-            for (int ip = 0; ip < 2; ++ip) {                 // two row tiles at a time: two independent accumulator chains, 24 fragment registers
-                bf16x8_t aq[2][NP];
+            for (int i = 0; i < 4; ++i) {
+                const int pp = ppb[i] + toff;
+                const int eo = pp * 32 + ((kp ^ ((pp >> 2) & 3)) << 3);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int pp = ppb[2 * ip + j] + toff;
-                    const int eo = pp * 32 + ((kp ^ ((pp >> 2) & 3)) << 3);
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) aq[j][q] = *reinterpret_cast<const bf16x8_t*>(pg + q * plane_elems + eo);
-                }
-#pragma unroll
-                for (int u = 0; u < 6; ++u)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[2 * ip + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[QB[u]][tp], aq[j][QA[u]], acc[2 * ip + j], 0, 0, 0);
+                for (int q = 0; q < NP; ++q) aq[i][q] = *reinterpret_cast<const bf16x8_t*>(pg + q * plane_elems + eo);
             }
+            // pin the schedule: left alone, hipcc re-orders the 24 MFMAs of a tap for register pressure until dependent ones sit back to back
+            // (s_nop 5 between them) and waits lgkmcnt(0) in front of single MFMAs -- 34 cycles per MFMA instead of 16
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)                  // four independent chains; per accumulator the products keep their order
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(QB[u] == 2 ? b2 : bq[QB[u] & 1][tp], aq[i][QA[u]], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto store = [&](const Tile& t) {
@@ -861,7 +869,7 @@ static int conv3x3_x3_launch_t(const float* x, const float* w, float* y, int N, 
 static int g_x3_prefetch = 1;       // conv3x3_x3p_kernel where its 16 slots per thread hold the patch (ha2g_conv_c32_prefetch(0): the first form, A/B)
 static int g_x3p_dbg = 0;
 static int g_c32pp = 1;             // the anti-phase kernel conv3x3_c32pp_kernel (ha2g_conv_c32_prefetch bit 5 clears it: A/B)
-extern "C" void ha2g_conv_c32_prefetch(int on) { g_x3_prefetch = on & 1; g_x3p_dbg = (on >> 1) & 15; g_c32pp = !((on >> 5) & 1); }
+extern "C" void ha2g_conv_c32_prefetch(int on) { g_x3_prefetch = on & 1; g_x3p_dbg = ((on >> 1) & 15) | (((on >> 6) & 3) << 4) | (((on >> 8) & 1) << 6); g_c32pp = !((on >> 5) & 1); }
 static int conv3x3_x3p_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st) {
     using G = X3Geo<32, 3>;
     const int rows_max = (TP + W - 2) / W + 1 + 2;
@@ -886,14 +894,14 @@ static int conv3x3_x3p_launch(const float* x, const float* w, float* y, int N, i
 static int conv3x3_c32pp_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st) {
     const int rows_max = (TPH + W - 2) / W + 1 + 2;
     const int plane_elems = rows_max * (W + 2) * 32;
-    const size_t lds = (size_t)2 * 3 * plane_elems * sizeof(unsigned short);
-    if (lds > 156 * 1024 || (long)H * W < TPH || W + 2 <= 32 || W < 2) return -100;
+    const size_t lds = (size_t)2 * 3 * plane_elems * sizeof(unsigned short) + 2 * 9 * 64 * 16;      // two groups' patches + the filter's third piece
+    if (lds > 158 * 1024 || (long)H * W < TPH || W + 2 <= 32 || W < 2) return -100;
     if ((long)rows_max * (W + 2) * 8 > 12L * 256) return -100;                       // the patch must fit the 12 prefetch slots per thread
     static bool attr_set[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)
             return ha2g_set_error(-2, "conv3x3_c32pp: cannot raise the dynamic LDS limit");
         attr_set[dev] = true;
     }
