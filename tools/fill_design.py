@@ -57,7 +57,7 @@ rep={'«NGPU»':ngpu,'«NCPU»':sys.argv[1] if len(sys.argv)>1 else '93','«NSYM
      '«HMS»':'%.1f'%d['ms_per_step'],'«HVAL»':'%.1f'%(d['value']/1e3),'«M6MS»':'%.1f'%d['two_piece_backward']['ms_per_step'],'«X32MS»':'%.1f'%d['exact_fp32_matrix_core']['ms_per_step'],
      '«GRUUS»':'%.0f'%rf['mean_us'],'«GRUF32»':'%.2f'%rf['frac_of_fp32_mfma_peak'],'«GRUF3»':'%.2f'%rf['frac'],'«BPTTUS»':'%.0f'%rb['mean_us'],'«BYTES»':'%.1f'%(rg+wg),
      '«NNP3»':sys.argv[2] if len(sys.argv)>2 else '48','«BENCHTABLE»':table,'«HEAGER»':'%.1f'%d['eager']['ms_per_step'],'«RGB»':'%.1f'%rg,'«WGB»':'%.1f'%wg,'«TGB»':'%.1f'%(rg+wg),
-     '«QPMC»':'\n'.join(ql),'«BWDTABLE»':'\n'.join(bt),'«FAMILIES»':families,'«QMAIN»':qm.group(2)}
+     '«QPMC»':'\n'.join(ql),'«BWDTABLE»':'\n'.join(bt),'«FAMILIES»':families,'«QFAM»':'%.1f'%famd[[k for k in famd if k.startswith('plane kernel')][0]][1],'«QMAIN»':qm.group(2)}
 for k,v in rep.items(): s=s.replace(k,v)
 rd=open(R+'README.md').read()
 rep2=dict(rep); rep2.update({'«V256»':'%.1f'%(L('b256')['value']/1e3),'«VEXP»':'%.1f'%(L('expressive')['value']/1e3),'«VBF16»':'%.1f'%(L('expressive_b256_bf16')['value']/1e3),'«CPUV»':'%.0f'%d['cpu_baseline']['value']})

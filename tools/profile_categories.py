@@ -20,7 +20,7 @@ def cat(n):
                       ('se_mlp', 'SE pointwise'), ('gen_concat', 'pointwise (act bwd, adds, masks)'), ('step_inc', 'Adam'),
                       ('pconv_kernel', 'conv fwd + dgrad (planes, DMA-staged)'), ('pconv_pp_kernel', 'conv fwd + dgrad (planes, DMA-staged)'), ('pconv_wgrad', 'conv wgrad (planes, DMA-staged)'),
                       ('weight_ihwo_planes', 'layout (shuffle/pack/permute)'), ('f32_to_planes', 'layout (shuffle/pack/permute)'),
-                      ('conv3x3_c32_wgrad', 'conv 32ch direct (fwd / dgrad / wgrad)'), ('conv3x3_c32_kernel', 'conv 32ch direct (fwd / dgrad / wgrad)'),
+                      ('conv3x3_c32_wgrad', 'conv 32ch direct (fwd / dgrad / wgrad)'), ('conv3x3_c32pp', 'conv 32ch direct (fwd / dgrad / wgrad)'), ('conv3x3_x3p', 'conv 32ch direct (fwd / dgrad / wgrad)'), ('conv3x3_c32_kernel', 'conv 32ch direct (fwd / dgrad / wgrad)'),
                       ('conv3x3_x3_kernel', 'conv 32ch direct (fwd / dgrad / wgrad)'), ('pool_final', 'SE pointwise'), ('transpose_batched', 'layout (shuffle/pack/permute)'),
                       ('gru_', 'GRU recurrences'), ('splitk', 'split-K reduce'), ('colsum', 'bias-grad column sums'),
                       ('col_partial', 'BatchNorm'), ('bn_', 'BatchNorm'), ('pair_final', 'BatchNorm'),
