@@ -502,8 +502,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c32pp_kernel(const float* __re
     extern __shared__ __attribute__((aligned(1024))) unsigned short ppl[];          // [group][piece][plane_elems]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // groups by wave parity (A/B bit 14 of act: by wave >> 2): the same within the scatter of repeated runs (155-165 us either way, tools/c32_ablate.py)
-    const bool by_half = (act >> 14) & 1;
+    // groups by wave >> 2: wave w and w + 4 share a SIMD, so each SIMD holds one wave of EACH group and its matrix pipe alternates between them
+    // (A/B bit 14 of act: groups by wave parity = both waves of a SIMD in the same phase: 177 vs 145 us, tools/c32_ablate.py)
+    const bool by_half = !((act >> 14) & 1);
     const int grp = by_half ? (wave >> 2) : (wave & 1), w4 = by_half ? (wave & 3) : (wave >> 1), ph = w4 & 1, chh = w4 >> 1;
     const int l15 = lane & 15, kp = lane >> 4;
     const int gt = w4 * 64 + lane;                           // thread index inside the group
@@ -582,27 +583,36 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c32pp_kernel(const float* __re
             acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
         constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};          // (pixel piece, filter piece), smallest products first
-#pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
+        // 18 half steps (tap, pair of row tiles), software-pipelined over two fragment sets: while the 12 MFMAs of one pair run, the fragments of the
+        // pair after the next one are in flight -- a tap's reads used to be issued right in front of its MFMAs (their ~200 cycles of LDS latency per tap
+        // were in nobody's shadow: 34 cycles per MFMA)
+        bf16x8_t aq[2][2][NP];                               // [set = pair][row tile of the pair][piece]
+        auto load = [&](int tp, int pr_) {
             const int toff = (tp / 3) * PW + (tp % 3);
-            const bf16x8_t b2 = *reinterpret_cast<const bf16x8_t*>(fl2 + ((chh * 9 + tp) * 64 + lane) * 8);
-            bf16x8_t aq[4][NP];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int pp = ppb[i] + toff;
+            for (int j = 0; j < 2; ++j) {
+                const int pp = ppb[2 * pr_ + j] + toff;
                 const int eo = pp * 32 + ((kp ^ ((pp >> 2) & 3)) << 3);
 #pragma unroll
-                for (int q = 0; q < NP; ++q) aq[i][q] = *reinterpret_cast<const bf16x8_t*>(pg + q * plane_elems + eo);
+                for (int q = 0; q < NP; ++q) aq[pr_][j][q] = *reinterpret_cast<const bf16x8_t*>(pg + q * plane_elems + eo);
             }
-            // pin the schedule: left alone, hipcc re-orders the 24 MFMAs of a tap for register pressure until dependent ones sit back to back
-            // (s_nop 5 between them) and waits lgkmcnt(0) in front of single MFMAs -- 34 cycles per MFMA instead of 16
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        load(0, 0);
+        load(0, 1);
 #pragma unroll
-            for (int u = 0; u < 6; ++u)
+        for (int tp = 0; tp < 9; ++tp) {
+            const bf16x8_t b2 = *reinterpret_cast<const bf16x8_t*>(fl2 + ((chh * 9 + tp) * 64 + lane) * 8);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)                  // four independent chains; per accumulator the products keep their order
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(QB[u] == 2 ? b2 : bq[QB[u] & 1][tp], aq[i][QA[u]], acc[i], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int pr_ = 0; pr_ < 2; ++pr_) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[2 * pr_ + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(QB[u] == 2 ? b2 : bq[QB[u] & 1][tp], aq[pr_][j][QA[u]], acc[2 * pr_ + j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tp + 1 < 9) load(tp + 1, pr_);           // this pair's set is free again: the next tap's fragments of the same pair
+            }
         }
     };
     auto store = [&](const Tile& t) {

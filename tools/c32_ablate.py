@@ -28,7 +28,7 @@ def t_us(iters=20):
 
 for label, form, bits in (('first form (single buffer, conv3x3_x3_kernel<32,3>)', 'x3', 0), ('prefetching form (conv3x3_x3p_kernel)', 'x3p', 0),
                           ('anti-phase form (conv3x3_c32pp_kernel)', 'pp', 0), ('  no MFMA', 'pp', 1), ('  no LDS fill (split + writes)', 'pp', 2), ('  no stores', 'pp', 4),
-                          ('  no loads', 'pp', 8), ('  no MFMA, no stores', 'pp', 5), ('  nothing but the barriers', 'pp', 15), ('  only MFMA (no fill, stores, loads)', 'pp', 14), ('anti-phase form, groups by wave >> 2 instead of wave parity', 'pp', 256), ('  only MFMA', 'pp', 256 | 14)):
+                          ('  no loads', 'pp', 8), ('  no MFMA, no stores', 'pp', 5), ('  nothing but the barriers', 'pp', 15), ('  only MFMA (no fill, stores, loads)', 'pp', 14), ('anti-phase form, groups by wave parity instead of wave >> 2', 'pp', 256), ('  only MFMA', 'pp', 256 | 14)):
     lib.ha2g_conv_c32_prefetch({'x3': 32, 'x3p': 33, 'pp': 1}[form] | ((bits & 15) << 1) | (256 if bits & 256 else 0))
     print('%-52s %8.1f us' % (label, t_us()))
 lib.ha2g_conv_c32_prefetch(1)
