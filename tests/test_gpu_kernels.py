@@ -357,11 +357,12 @@ def test_log_mel_frontend():
     assert one.dtype == torch.float16 and tuple(one.shape) == (128, 71)
 
 
-@pytest.mark.parametrize('shape', [(3, 20, 14), (2, 128, 70), (1, 16, 16), (2, 9, 37)])
+@pytest.mark.parametrize('shape', [(3, 20, 14), (2, 128, 70), (1, 16, 16), (2, 9, 37), (3, 17, 66), (1, 2, 78), (5, 12, 31)])
 def test_direct_conv3x3_c32(shape):
     """The direct LDS-patch kernel for the 32->32 channel 3x3 convolutions (layer1 of the audio tower; conv_c32.hip), forward
     (+ReLU) and data gradient (accumulating), against float64 torch and against the implicit-GEMM path it replaces.  Shapes:
-    ragged last tile, the real 128x70 map, exactly one tile, a width that makes tiles straddle many rows."""
+    ragged last tile, the real 128x70 map, exactly one tile, a width that makes tiles straddle many rows; round 4 (anti-phase kernel, two groups of
+    four waves on alternating 128-pixel tiles): an odd number of tiles (one group idles in the last round), the widest and a narrow map it serves."""
     import torch.nn.functional as F
     from ha2g_amd import wav_engine as we
     from ha2g_amd._lib import lib
