@@ -242,3 +242,33 @@ def test_dense_products_on_three_piece_planes(M, N, K, ta, tb):
     finally:
         ops.PLANE_GEMM_MIN_FLOP = old
         ops.PLANE_GEMM = True
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 70), (3, 9, 37)])
+def test_c32_three_piece_kernel_forms_are_fp32_class(shape):
+    """The three forms of the 32-channel three-piece direct convolution (conv_c32.hip): anti-phase (default, 16x16x32 tiles), prefetching and first form
+    (32x32x16 tiles) -- forward with ReLU and accumulating data gradient against float64; the two 32x32x16 forms run the same MFMA chain: bit-identical."""
+    import torch.nn.functional as F
+    N, H, W = shape
+    g = torch.Generator().manual_seed(11 + shape[2])
+    x = torch.randn(N, 32, H, W, generator=g)
+    w = torch.randn(32, 32, 3, 3, generator=g) * 0.08
+    dy = torch.randn(N, 32, H, W, generator=g)
+    base = torch.randn(N, 32, H, W, generator=g)
+    xg, dyg, wg = (t.permute(0, 2, 3, 1).contiguous().to(DEV) for t in (x, dy, w))
+    ref_y = F.relu(F.conv2d(x.double(), w.double(), padding=1))
+    ref_dx = base.double() + F.conv_transpose2d(dy.double(), w.double(), padding=1)
+    outs = {}
+    try:
+        for form, sw in (('anti-phase', 1), ('prefetch', 33), ('first', 32)):
+            lib.ha2g_conv_c32_prefetch(sw)
+            y = we.conv_fwd(xg, wg, None, 1, 1, we.ACT_RELU)
+            acc = base.permute(0, 2, 3, 1).contiguous().to(DEV)
+            dx = we.conv_dgrad(dyg, wg, (N, H, W, 32), 1, 1, out=acc, beta=1.0)
+            outs[form] = (y.permute(0, 3, 1, 2).double().cpu(), dx.permute(0, 3, 1, 2).double().cpu())
+    finally:
+        lib.ha2g_conv_c32_prefetch(1)
+    for form, (y, dx) in outs.items():
+        assert float((y - ref_y).abs().max() / ref_y.abs().max()) < 3e-6, form
+        assert float((dx - ref_dx).abs().max() / ref_dx.abs().max()) < 3e-6, form
+    assert torch.equal(outs['prefetch'][0], outs['first'][0]) and torch.equal(outs['prefetch'][1], outs['first'][1])
