@@ -98,8 +98,10 @@ def check(rc):
 
 # matrix-core mode (see ha2g_gemm_set_mode in include/ha2g_hip.h) and direct-convolution switches; the HA2G_GEMM_MODE / HA2G_DIRECT_C32
 # environment variables override the library defaults (tests restore THESE values after toggling modes)
-# 70 = 64 + 6 (round 4): split backward products on THREE bf16 pieces per operand (all 24 mantissa bits, six MFMAs: fp32-class -- the reference's
-# arithmetic class), forward products on the exact fp32 MFMA.  6 = the round-3 default (two pieces: 16-bit operand mantissa), 0 = exact fp32 everywhere.
+# 70 = 64 + 6 (round 4): every split product -- the trunk's forward AND backward convolutions, the dense products >= 4 GFLOP, both GRU chains, every
+# backward GEMM -- on THREE bf16 pieces per operand (all 24 mantissa bits, six MFMAs: fp32-class, the reference's arithmetic class); the small forward
+# GEMMs, the tap convolutions and the stem stay on the fp32 MFMA.  6 = the round-3 default (two-piece backward: 16-bit operand mantissa, fp32-MFMA
+# forward), 0 = exact fp32 MFMA everywhere.
 DEFAULT_GEMM_MODE = int(os.environ.get("HA2G_GEMM_MODE", "70"))
 DEFAULT_DIRECT_C32 = int(os.environ.get("HA2G_DIRECT_C32", "1"))
 lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)

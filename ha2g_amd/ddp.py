@@ -180,12 +180,16 @@ def exchange_sparse_(table, group=None):
     if not active(group):
         return
     from . import ops
-    # EVERY rank takes part in the three all-gathers, whatever its local state: a rank with nothing pending (a skipped backward, a
-    # non-finite-loss skip on that rank only) contributes count 0 -- an early return here would leave the other ranks' collectives hanging
-    hint = None
+    # EVERY rank takes part in the same sequence of collectives, whatever its local state: a rank with nothing pending (a skipped backward, a
+    # non-finite-loss skip on that rank only) contributes count 0 -- an early return here would leave the other ranks' collectives hanging.
+    # Whether the prefetched max count replaces the in-line count all-gather is decided from RANK-SYMMETRIC state only: exactly one count
+    # collective was issued since the last exchange (every rank ran that one forward, so every rank holds its handle -- with or without a
+    # pending gradient: the handle's maximum bounds every rank's count of that forward).  Anything else takes the in-line exchange everywhere.
+    hint = table.count_hint[1] if (table.n_prefetch == 1 and table.count_hint is not None) else None
     if table.pending:
-        if len(table.pending) == 1 and table.count_hint is not None and table.count_hint[0] is table.pending[0][1]:
-            hint = table.count_hint[1]                     # the one pending gradient is the prefetched forward's: its max count is on the host already
+        if hint is not None and not (len(table.pending) == 1 and table.count_hint[0] is table.pending[0][1]):
+            raise RuntimeError('ha2g_amd.ddp.exchange_sparse_: one forward was prefetched but the pending gradient is not that forward\'s '
+                               '(%d pending): the prefetched row count does not bound it' % len(table.pending))
         ids, count, rows = table.merged()
     else:
         w = table.weight
@@ -193,7 +197,7 @@ def exchange_sparse_(table, group=None):
         count = torch.zeros(1, dtype=torch.int32, device=w.device)
         rows = torch.zeros(1, w.shape[1], dtype=torch.float32, device=w.device)
     ids_all, rows_all = gather_sparse_rows(ids, count, rows, group, max_count=hint)
-    table.count_hint = None
+    table.count_hint, table.n_prefetch = None, 0
     table.pending = [ops.merge_rows(ids_all, rows_all, table.map)] if ids_all.numel() else []
 
 

@@ -1425,6 +1425,7 @@ class SparseTable:
         self.map = torch.full((V,), 2 ** 31 - 1, dtype=torch.int32, device=dev)      # scratch of ha2g_unique_tokens
         self.pending = []
         self.count_hint = None          # (device count tensor, prefetched max-over-ranks handle) of the forward whose backward is pending
+        self.n_prefetch = 0             # count collectives issued since the last exchange -- equal on every rank (every rank runs every forward)
 
     def _run(self, ids, count, max_rows, vals):
         g = self.opt.param_groups[0]
@@ -1447,6 +1448,7 @@ class SparseTable:
         self.count_hint = None
         if ddp.active():
             self.count_hint = (count, ddp.prefetch_max_count(count))
+            self.n_prefetch += 1
 
     def merged(self):
         """This step's compact gradient as ONE (ids, count, rows) list with distinct ids (several backward passes / ranks are merged

@@ -64,14 +64,32 @@ class HierarchyTrainer:
     def sync(self):
         """Waits for the device and raises if a cluster-GRU hand-off of an earlier step timed out.  train_iter returns as soon as the
         step's losses have reached the host (they exist before the backward); the backward / optimizer kernels may still be running."""
-        import torch
+        from . import ops
         from .train_hierarchy import drain_cluster_errors
         torch.cuda.synchronize(self.device)
-        drain_cluster_errors(block=True)
+        try:
+            drain_cluster_errors(block=True)
+        except ops.Ha2gClusterError:
+            # with the retry on, a flag found HERE (the device is drained: the word is final and, under data parallelism, equal on every rank
+            # -- sync() is called by all ranks at the same point) is handled like one found at the next step: the flagged updates were skipped on
+            # the device, switch to gru.hip and go on.  The BatchNorm statistics of the flagged forward stay (no snapshot is guaranteed to predate it)
+            if not self.retry_on_cluster_error:
+                raise
+            self._recover_from_cluster_error(restore_buffers=False)
 
     def sync_sparse(self):
         for o in self.gen_opts + [self.text_opt]:
             o.sync_sparse()
+
+    def state_dict(self):
+        """The reference's checkpoint payload (scripts/train.py:202-243: gen_dict_1..L, dis_dict, audio_dict, text_dict) with every table current:
+        row-wise embedding tables are updated lazily, so the rows a step did not touch are brought up to date first (sync_sparse) -- reading
+        module.state_dict() directly under `sparse_embeddings` returns stale rows."""
+        self.sync()
+        self.sync_sparse()
+        out = {'gen_dict_%d' % (i + 1): g.state_dict() for i, g in enumerate(self.gens)}
+        out.update(dis_dict=self.discriminator.state_dict(), audio_dict=self.audio_encoder.state_dict(), text_dict=self.text_encoder.state_dict())
+        return out
 
     def broadcast_parameters(self, src=0):
         """DDP start-up: every rank adopts rank `src`'s parameters and buffers."""
@@ -151,30 +169,45 @@ class HierarchyTrainer:
     def _bn_buffers(self):
         return [b for m in self.modules() for k, b in m.named_buffers() if k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]
 
-    def _snapshot_buffers(self):
+    def _snapshot_buffers(self, slot=0):
+        """slot: the data-parallel path keeps the snapshots of the last three steps (a flagged step is noticed two calls later)"""
         if self._bn_snap is None:
-            self._bn_snap = tuple(torch.empty_like(t) if t is not None else None for t in (self._bn_flat, self._bn_cnt))
-        for dst, src in zip(self._bn_snap, (self._bn_flat, self._bn_cnt)):
+            self._bn_snap = {}
+        if slot not in self._bn_snap:
+            self._bn_snap[slot] = tuple(torch.empty_like(t) if t is not None else None for t in (self._bn_flat, self._bn_cnt))
+        for src, name in ((self._bn_flat, 'running statistics'), (self._bn_cnt, 'num_batches_tracked')):
+            if src is not None:
+                # the module buffers must still be the views of the flat tensor installed by _flatten_bn_buffers: a later module.to(dtype) or an
+                # assign-style load_state_dict re-binds them, and the snapshot / restore would then silently do nothing
+                first = next(b for b in self._bn_buffers() if b.dtype == src.dtype)
+                assert first.data_ptr() == src.data_ptr(), 'HierarchyTrainer: the BatchNorm %s no longer alias the flat snapshot buffer ' \
+                    '(module.to(dtype) / load_state_dict(assign=True) after construction?): call _flatten_bn_buffers() again' % name
+        for dst, src in zip(self._bn_snap[slot], (self._bn_flat, self._bn_cnt)):
             if src is not None:
                 dst.copy_(src)
 
-    def _restore_buffers(self):
-        for dst, src in zip((self._bn_flat, self._bn_cnt), self._bn_snap):
+    def _restore_buffers(self, slot=0):
+        for dst, src in zip((self._bn_flat, self._bn_cnt), self._bn_snap[slot]):
             if dst is not None:
                 dst.copy_(src)
 
-    def _recover_from_cluster_error(self, restore_buffers):
+    def _recover_from_cluster_error(self, restore_buffers, slot=0):
         from . import ops
         from .train_hierarchy import _err_watch
         torch.cuda.synchronize(self.device)
         _err_watch.clear()                              # copies of the word taken while it was set
-        if restore_buffers and getattr(self, '_bn_snap', None) is not None:
-            self._restore_buffers()
+        if restore_buffers and self._bn_snap and slot in self._bn_snap:
+            self._restore_buffers(slot)
         err = ops.gru_cluster_error_tensor(self.device)
         if err is not None:
             err.zero_()
         ops.USE_GRU_CLUSTER = False
         self.cluster_retries += 1
+        if self.cluster_retries > self.max_cluster_retries:
+            raise ops.Ha2gClusterError('ha2g_amd: %d cluster-GRU recoveries in this process (max_cluster_retries = %d): the fallback recurrences '
+                                       'do not use the cluster protocol, so something else sets the error word' % (self.cluster_retries, self.max_cluster_retries))
+
+    max_cluster_retries = 3      # a process switches to gru.hip at its FIRST recovery: more than a couple means the word is being set by something else
 
     def _step(self, epoch, in_text_padded, in_spec, target, vid_indices, **kw):
         fn = train_iter_hierarchy_expressive if self.expressive else train_iter_hierarchy
@@ -182,10 +215,12 @@ class HierarchyTrainer:
                   self.text_encoder, *self.gen_opts, self.dis_opt, self.audio_opt, self.text_opt, **kw)
 
     def train_iter(self, epoch, in_text_padded, in_spec, target, vid_indices, **kw):
-        from . import ops
+        from . import ddp, ops
         capturing = self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
-        if not self.retry_on_cluster_error or capturing or kw.get('return_tensors') or not ops.USE_GRU_CLUSTER:
+        if not self.retry_on_cluster_error or capturing or kw.get('return_tensors'):
             return self._step(epoch, in_text_padded, in_spec, target, vid_indices, **kw)
+        if ddp.active():
+            return self._train_iter_ddp(epoch, in_text_padded, in_spec, target, vid_indices, **kw)
         from .train_hierarchy import drain_cluster_errors
         try:
             drain_cluster_errors()                      # the PREVIOUS step's BPTT launches flagged: its update was skipped on the device
@@ -198,3 +233,24 @@ class HierarchyTrainer:
         except ops.Ha2gClusterError:
             self._recover_from_cluster_error(restore_buffers=True)
             return self._step(epoch, in_text_padded, in_spec, target, vid_indices, **kw)
+
+    _ddp_call = 0
+
+    def _train_iter_ddp(self, epoch, in_text_padded, in_spec, target, vid_indices, **kw):
+        """Data parallel: the recovery is COLLECTIVE.  The step issues all-reduces / all-gathers, so a rank may neither raise nor
+        re-run a step on its own.  Every rank therefore decides from the same information at the same call: the end-of-step error words --
+        MAX-reduced over the ranks inside each step before the optimizer kernels read them -- examined with a fixed lag of one call
+        (train_hierarchy.drain_cluster_errors_lagged).  A step flagged on ANY rank was a no-op for the optimizer state on EVERY rank, and so
+        was the step after it (the word is sticky until cleared here); at the call that notices it all ranks restore the BatchNorm statistics
+        to what they were before the first flagged step, clear the word, switch to the gru.hip recurrences and run the batch at hand.  The
+        two flagged batches are dropped (their loss dicts may hold garbage on the rank that timed out).  The rank-local forward-time word is not
+        part of the loss read-back in this mode (train_hierarchy._train_iter), so nothing raises on one rank only."""
+        from .train_hierarchy import drain_cluster_errors_lagged
+        k = self._ddp_call
+        self._ddp_call = k + 1
+        if drain_cluster_errors_lagged(raise_=False):
+            # the copies looked at belong to the calls <= k - 2; the sticky word makes every call from the first flagged one onwards a no-op, and the
+            # oldest snapshot still held (taken before call k - 2) predates the first of them that this drain can have seen for the first time
+            self._recover_from_cluster_error(restore_buffers=True, slot=(k - 2) % 3 if k >= 2 else 0)
+        self._snapshot_buffers(slot=k % 3)
+        return self._step(epoch, in_text_padded, in_spec, target, vid_indices, **kw)

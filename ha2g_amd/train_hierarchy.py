@@ -114,17 +114,30 @@ def _watch_cluster_errors(dev):
     _err_watch.append((ev, word, dev))
 
 
-def drain_cluster_errors(block=False):
+def drain_cluster_errors(block=False, keep_last=0, raise_=True):
     """Looks at the end-of-step error words whose copies have completed (block=True: waits for all of them) and raises
-    Ha2gClusterError when one is set.  Called at the start of every train step and by HierarchyTrainer.sync()."""
+    Ha2gClusterError when one is set (raise_=False: returns True instead).  Called at the start of every train step and by
+    HierarchyTrainer.sync().  keep_last=n leaves the n most recent copies alone: see drain_cluster_errors_lagged."""
     bad = False
-    while _err_watch and (block or _err_watch[0][0].query()):
+    while len(_err_watch) > keep_last and (block or _err_watch[0][0].query()):
         ev, word, dev = _err_watch.pop(0)
         ev.synchronize()
         bad = bad or int(word[0]) != 0
         _err_free.append(word)
-    if bad:
+    if bad and raise_:
         raise ops.Ha2gClusterError(_CLUSTER_MSG)
+    return bad
+
+
+def drain_cluster_errors_lagged(raise_=True):
+    """The data-parallel form.  Ranks issue collectives inside the step, so they must notice a flagged step AT THE SAME CALL -- a non-blocking
+    `event.query()` (drain_cluster_errors) may fire on one rank a call earlier than on its peer, and a rank that retries while the others move
+    on leaves their all-reduces unmatched.  Rule: at the start of step k + 1 look at the end-of-step words of the steps <= k - 1, blocking.  Those
+    copies ARE complete by then -- train_iter(k) returned only after step k's loss read-back (recorded behind the whole of step k - 1 on the
+    compute stream) had fired -- so the wait costs nothing and the host's run-ahead into step k's backward is untouched; step k's own word
+    is left for the next call.  The words themselves are rank-symmetric: every step MAX-reduces the word over the ranks (_sync_guard) before its
+    end-of-step copy.  Same words, same call => every rank takes the same decision."""
+    return drain_cluster_errors(block=True, keep_last=1, raise_=raise_)
 
 
 _CLUSTER_MSG = ('ha2g_amd: a GRU cluster hand-off timed out (gru_cluster.hip): that step\'s GRU outputs and gradients are invalid -- '
@@ -173,7 +186,9 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
     B = target.shape[0]
     t_host0 = time.perf_counter() if host_clock is not None else 0.0
     if not (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
-        drain_cluster_errors()                           # BPTT time-outs of earlier steps whose read-back has arrived (never inside a capture)
+        # time-outs of earlier steps whose read-back has arrived (never inside a capture); data parallel: the rank-symmetric lagged form
+        from . import ddp as _ddp
+        (drain_cluster_errors_lagged if _ddp.active() else drain_cluster_errors)()
     ops.rng.begin_step()
     L = len(gens)
     consts = _consts(spec, args, dev)
@@ -320,8 +335,12 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
         names.append('-c_neg'); vals.append(text_low_pos.detach())
     if args.loss_physical_weight > 0.0:
         names.append('phy'); vals.append(physical_loss.detach())
+    from . import ddp
     err = ops.gru_cluster_error_tensor(dev)
-    if err is not None:                                  # cluster-GRU hand-off time-out flag (forward launches so far) rides along
+    if err is not None and not (ddp.active() and not return_tensors):
+        # cluster-GRU hand-off time-out flag (forward launches so far) rides along.  NOT under data parallelism: at this point the word is
+        # rank-local, and a rank that raised here would leave its peers' collectives of this very step unmatched -- there the flag surfaces
+        # through the end-of-step word, which every rank reads after the MAX-reduce (drain_cluster_errors_lagged)
         names.append('_cluster_err'); vals.append(err[0].to(torch.float32))
     packed = torch.stack(vals)
     readback = None
@@ -332,7 +351,6 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
         ev.record()
         readback = (host, ev)
 
-    from . import ddp
     loss.backward()                                      # stage 1: losses, discriminator, generators (down to the cut)
     works = []
     if ddp.active():

@@ -225,9 +225,11 @@ def conv_wgrad(x, dy, w_ohwi, stride, pad, into=None):
     return None if into is not None else dw.permute(0, 3, 1, 2)
 
 
-def wgrad_planes_ok(x, w_ohwi, stride, pad):
+def wgrad_planes_ok(x, w_ohwi, stride, pad, hw=None):
+    """x: the convolution's NHWC input (or hw = (H, W) of it when the tensor does not exist yet)"""
     Cout, KH, KW, Cin = w_ohwi.shape
-    return bool(PLANES & 2) and bool(lib.ha2g_conv2d_wgrad_planes_supported(x.shape[1], x.shape[2], Cin, Cout, KH, KW, stride, pad))
+    H, W = hw if hw is not None else (x.shape[1], x.shape[2])
+    return bool(PLANES & 2) and bool(lib.ha2g_conv2d_wgrad_planes_supported(H, W, Cin, Cout, KH, KW, stride, pad))
 
 
 def conv_wgrad_planes(x_planes, dy_planes, w_ohwi, xshape, into=None):
@@ -267,6 +269,9 @@ class _BN:
 _TRAINING = [True]
 _NBT_PENDING = []
 _FWD_PLANES = [False]      # this forward will be back-propagated through the plane-based weight gradients: producers also write bf16 planes
+# this forward will be back-propagated at all.  torch.is_grad_enabled() cannot tell: inside autograd.Function.forward it is always False.
+# WavEncoderFunction.forward sets it from `training and any(ctx.needs_input_grad)`; direct block_fwd() callers (tests, tools) back-propagate.
+_WILL_BWD = [True]
 
 
 def _bn_fwd(x, bn, pool=False, planes=False, planes_only=False):
@@ -488,8 +493,11 @@ def block_fwd(x, P, b, first, xp=None, out_planes=0, wpl=None):
     if f2 or (_FWD_PLANES[0] and wgrad_planes_ok(c1, wb, 1, 1)):
         # planes only: when conv2's forward, data gradient and weight gradient all read the three piece planes (which hold bn1's output exactly),
         # the fp32 tensor has no reader left -- the backward of bn1 needs its INPUT c1.  a1 is then a placeholder carrying shape and device.
-        only = f2 and torch.is_grad_enabled() and dgrad_planes_ok(wb, 1, 1) and wgrad_planes_ok(c1, wb, 1, 1)
-        a1, m1, s1, a1p = _bn_fwd(c1, P[b + 'bn1'], planes=3 if f2 else 2, planes_only=only or (f2 and not torch.is_grad_enabled()))
+        # With a backward ahead that holds only if BOTH backward convolutions of conv2 run on planes (a spectrogram longer than 72 frames makes
+        # W >= 37 and the plane weight gradient unsupported; HA2G_PLANES may switch either off): otherwise the fp32 tensor is materialised too.
+        bwd_on_planes = dgrad_planes_ok(wb, 1, 1) and wgrad_planes_ok(c1, wb, 1, 1)
+        only = f2 and (not _WILL_BWD[0] or bwd_on_planes)
+        a1, m1, s1, a1p = _bn_fwd(c1, P[b + 'bn1'], planes=3 if f2 else 2, planes_only=only)
         if a1 is None:
             a1 = a1p[0]                                            # bf16 piece 0: NOT the activation -- _gconv() refuses non-fp32 operands
     else:
@@ -653,6 +661,29 @@ def blend_bwd(dw_ext, dblend, df, saved, feats, P, L, sink):
     sink.G['speaker_embedding.0.weight'] = demb
 
 
+SAVED_TAP = [None]      # diagnostics: a list here receives the saved-activation dict S of every fp32-storage forward (relu_pattern_of reads it)
+
+
+def block_relu_pattern(saved, prefix=''):
+    """The ReLU decisions one block_fwd() took, from its saved tuple: {prefix + 'c1' | 'se' | 'out': bool tensor, NCHW / [N, R]} -- the key
+    names of oracle.ha2g_oracle.relu_pattern (the test-side float64 oracle is linearised at this pattern)."""
+    c1, h1, out = saved[1], saved[10], saved[16]
+    return {prefix + 'c1': (c1 > 0).permute(0, 3, 1, 2), prefix + 'se': h1 > 0, prefix + 'out': (out > 0).permute(0, 3, 1, 2)}
+
+
+def relu_pattern_of(S, prefix=''):
+    """All ReLU decisions of one forward of the tower (fp32 storage): stem, every block, the three taps; keys as oracle.ha2g_oracle.relu_pattern
+    with the blocks' keys prefixed by `prefix` (the oracle's state-dict prefix, e.g. 'audio.feat_extractor.')."""
+    m = {'stem': (S['stem'][1] > 0).permute(0, 3, 1, 2)}
+    for li, nblk in enumerate(LAYERS):
+        for j in range(nblk):
+            b = 'layer%d.%d.' % (li + 1, j)
+            m.update(block_relu_pattern(S[b], prefix + b))
+    for t, _, _, _ in TAPS:
+        m['tap_' + t] = (S['tap_' + t][2] > 0).permute(0, 3, 1, 2)
+    return m
+
+
 class WavEncoderFunction(torch.autograd.Function):
     """apply(spec [B,128,W], vid [B], pose_level, names, bufs, *tensors) -> (weight, low, mid, high, blend_0..L-1).
     `tensors` follow param_names(): a BatchNorm entry contributes 2 tensors (gamma, beta); its buffers
@@ -693,7 +724,8 @@ class WavEncoderFunction(torch.autograd.Function):
         x, m, s = _bn_fwd(c0, P['bn1'])
         S['stem'] = (spec, c0, m, s)
         feats = []
-        _FWD_PLANES[0] = (PLANES & 6) == 6 and training and any(ctx.needs_input_grad)       # false under no_grad: nothing will read the planes
+        _WILL_BWD[0] = bool(training and any(ctx.needs_input_grad))                        # false under no_grad / eval
+        _FWD_PLANES[0] = (PLANES & 6) == 6 and _WILL_BWD[0]                                # false under no_grad: nothing will read the planes
         wpl = prepare_fwd_weight_planes(P)                  # {} unless the forward of layers 2-4 runs on three-piece planes (fp32-class default mode)
         blocks = [('layer%d.%d.' % (li + 1, j), li, j) for li, nblk in enumerate(LAYERS) for j in range(nblk)]
         xp = None
@@ -703,12 +735,16 @@ class WavEncoderFunction(torch.autograd.Function):
             want = 0
             if nxt is not None and (nxt + 'conv1.weight') in wpl:
                 want = 3
-            elif nxt is not None and blocks[bi + 1][1] == li and _FWD_PLANES[0] and wgrad_planes_ok(x, _ohwi(P[b + 'conv2.weight']), 1, 1):
-                want = 2
+            elif nxt is not None and blocks[bi + 1][1] == li and _FWD_PLANES[0]:
+                # the reader is the NEXT block's conv1 weight gradient (stride 1, same layer): judge ITS geometry -- this block's OUTPUT, which is
+                # half the input's size when this block is the layer's stride-2 block
+                oh, ow = ((x.shape[1] + 1) // 2, (x.shape[2] + 1) // 2) if (j == 0 and li > 0) else (x.shape[1], x.shape[2])
+                if wgrad_planes_ok(None, _ohwi(P[nxt + 'conv1.weight']), 1, 1, hw=(oh, ow)):
+                    want = 2
             x, S[b], xp = block_fwd(x, P, b, j == 0 and li > 0, xp=xp, out_planes=want, wpl=wpl)
             if j + 1 == LAYERS[li]:
                 feats.append(x)
-        _FWD_PLANES[0] = False
+        _FWD_PLANES[0], _WILL_BWD[0] = False, True
         return WavEncoderFunction._finish_forward(ctx, feats, S, P, vid, L, names, flat_index, tensors)
 
     @staticmethod
@@ -724,6 +760,8 @@ class WavEncoderFunction(torch.autograd.Function):
             _NBT_PENDING.clear()
         wsm, blend, S['spk'] = blend_fwd(vid, low, mid, high, P, L)
         S['feats'] = (low, mid, high)
+        if SAVED_TAP[0] is not None and not ctx.b16:
+            SAVED_TAP[0].append(S)
         ctx.S, ctx.P, ctx.L, ctx.names, ctx.flat_index, ctx.n_tensors = S, P, L, names, flat_index, len(tensors)
         return (wsm, low, mid, high) + tuple(blend[i] for i in range(L))
 

@@ -158,6 +158,38 @@ class bf16_storage:
         _BF16_STORAGE[0] = self.prev
 
 
+_RELU_SITES = [None, None]          # [masks to impose (site -> bool tensor) or None, dict to record the oracle's own decisions into or None]
+
+
+class relu_pattern:
+    """`with relu_pattern(masks=m):` -- evaluate the audio encoder with every ReLU decision IMPOSED: relu(x) becomes x * m[site] at the
+    sites named below.  That is the reference's network linearised at a given activation pattern: where the pattern is the one an fp32
+    implementation's forward actually took, its backward can be held to the float64 result at 1e-4 without the ReLU-flip scatter that
+    two fp32 runs of the reference itself show (tests/test_gpu_linearised.py).  `record={}` collects the oracle's own decisions (x > 0),
+    so that imposing them reproduces the plain oracle exactly (tests/test_oracle_blocks.py).  Sites (tensors NCHW / [N, R]):
+    'stem', '<block>c1' (ReLU(conv1), ResNetBlocks.py:24-25), '<block>se' (SELayer's hidden ReLU, :86), '<block>out' (the block's
+    final ReLU, :36), 'tap_low' / 'tap_mid' / 'tap_high' (ResNetSE34V2.py:158,168,179)."""
+
+    def __init__(self, masks=None, record=None):
+        self.new = [masks, record]
+
+    def __enter__(self):
+        self.prev = list(_RELU_SITES)
+        _RELU_SITES[:] = self.new
+
+    def __exit__(self, *a):
+        _RELU_SITES[:] = self.prev
+
+
+def _relu(x, site):
+    masks, record = _RELU_SITES
+    if record is not None:
+        record[site] = (x > 0).detach()
+    if masks is not None and site in masks:
+        return x * masks[site].to(x.dtype)
+    return torch.relu(x)
+
+
 def _st(x):
     return _StoreBf16.apply(x) if _BF16_STORAGE[0] else x
 
@@ -175,20 +207,20 @@ def se_block(x, sd, p, stride, has_down, update_bn=True):
     bf16-storage rounding points are switched on, see bf16_storage.)"""
     # bf16 storage: a first block's conv1 data gradient is stored (rounded) before the downsample branch's is added onto it
     out = F.conv2d(_gr(x) if has_down else x, _wq(sd[p + 'conv1.weight']), None, stride=stride, padding=1)
-    out = _st(batch_norm_train(_st(torch.relu(out)), sd, p + 'bn1.', update=update_bn))
+    out = _st(batch_norm_train(_st(_relu(out, p + 'c1')), sd, p + 'bn1.', update=update_bn))
     out = _st(F.conv2d(out, _wq(sd[p + 'conv2.weight']), None, padding=1))
     # bf16 storage: bn2's output is stored rounded, the squeeze is taken from the unrounded values of the same pass, and the gradient w.r.t.
     # bn2's output (gate path + squeeze path) is rounded once, where it is stored
     out = _gr(batch_norm_train(out, sd, p + 'bn2.', update=update_bn))
     y = out.mean((2, 3))                                             # ResNetBlocks.py:91-95
     out = _wq(out)
-    y = torch.relu(F.linear(y, sd[p + 'se.fc.0.weight'], sd[p + 'se.fc.0.bias']))
+    y = _relu(F.linear(y, sd[p + 'se.fc.0.weight'], sd[p + 'se.fc.0.bias']), p + 'se')
     y = torch.sigmoid(F.linear(y, sd[p + 'se.fc.2.weight'], sd[p + 'se.fc.2.bias']))
     out = out * y[:, :, None, None]
     if has_down:
         x = _st(F.conv2d(x, _wq(sd[p + 'downsample.0.weight']), None, stride=stride))
         x = _st(batch_norm_train(x, sd, p + 'downsample.1.', update=update_bn))
-    return _st(torch.relu(out + x))
+    return _st(_relu(out + x, p + 'out'))
 
 
 def wav_encoder(spec, vid, sd, p, pose_level, update_bn=True):
@@ -197,7 +229,7 @@ def wav_encoder(spec, vid, sd, p, pose_level, update_bn=True):
     q = p + 'feat_extractor.'
     B = spec.shape[0]
     x = F.conv2d(spec.unsqueeze(1), sd[q + 'conv1.weight'], sd[q + 'conv1.bias'], padding=1)
-    x = _st(batch_norm_train(_st(torch.relu(x)), sd, q + 'bn1.', update=update_bn))
+    x = _st(batch_norm_train(_st(_relu(x, 'stem')), sd, q + 'bn1.', update=update_bn))
     feats = []
     for li, nblk in enumerate((3, 4, 6, 3)):
         for j in range(nblk):
@@ -220,7 +252,7 @@ def wav_tap(f, sd, q, name, shuffle, update_bn=True):
     if shuffle > 1:
         f = F.pixel_shuffle(f, shuffle)
     f = F.conv2d(f, sd[q + 'conv_%s.weight' % name], sd[q + 'conv_%s.bias' % name])
-    f = batch_norm_train(torch.relu(f), sd, q + 'bn_%s.' % name, update=update_bn)
+    f = batch_norm_train(_relu(f, 'tap_' + name), sd, q + 'bn_%s.' % name, update=update_bn)
     f = f.reshape(B, -1, f.shape[-1]).transpose(1, 2)            # (B, W, C*H)
     return F.linear(f, sd[q + 'fc_%s.weight' % name], sd[q + 'fc_%s.bias' % name])
 

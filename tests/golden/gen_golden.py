@@ -196,8 +196,9 @@ def module_goldens(case, out, dt, perturb=0.0):
         out['eval/gen/out'] = o.double().numpy()
 
 
-def step_goldens(case, out, dt, expressive=False, perturb=0.0, perturb_text=False):
-    """Two consecutive train steps (epoch 0 = warm-up phase, epoch 11 = GAN phase) through the reference.
+def step_goldens(case, out, dt, expressive=False, perturb=0.0, perturb_text=False, epochs=(0, 11)):
+    """Consecutive train steps through the reference: by default two (epoch 0 = warm-up phase, then epoch 11 = GAN phase);
+    epochs=(11,) = ONE GAN-phase step from fresh state (the `*_gan` fixtures: the phase bench.py times, checked strictly as step 0).
     perturb_text: the perturbed runs also move the word-embedding tables by `perturb` (one fp32 ulp) -- the tokens are integers,
     so nothing else would re-roll the text encoders' rounding / ReLU decisions (BIG_CASES)."""
     pose_dims = (24, 30, 36, 66, 96, 126) if expressive else (15, 21, 27)
@@ -225,7 +226,7 @@ def step_goldens(case, out, dt, expressive=False, perturb=0.0, perturb_text=Fals
     mods = {('g%d' % (i + 1)): g for i, g in enumerate(gens)}
     mods.update(dis=dis, audio=aud, text=txt)
     try:
-        for si, epoch in enumerate((0, 11)):
+        for si, epoch in enumerate(epochs):
             if expressive:
                 ret = ref_expr.train_iter_hierarchy_expressive(args, epoch, text_t, spec_t, tgt_t, vid_t, *gens, dis, aud,
                                                                txt, *opts, dis_opt, aud_opt, txt_opt)
@@ -708,9 +709,41 @@ def main_big(only):
         write_fixture(name, runs, NPERT)
 
 
+GAN_CASES = {'cfg1_gan': 'cfg1', 'expr_cfg1_gan': 'expr_cfg1', 'cfg2_b128_gan': 'cfg2_b128', 'cfg3_b128_gan': 'cfg3_b128'}
+
+
+def main_gan(only):
+    """`*_gan` fixtures (round 5): the FIRST step of a fresh state is a GAN-phase step (epoch 11 > loss_warmup) -- D phase
+    (train_hierarchy.py:93-131), gen_error into the generators (:179-180, :233-234), D's .grad = its own loss's gradient + what
+    the generators' loss.backward() adds through the updated D (:264), six Adam updates (:270-274) -- so that phase's gradients
+    are element-checked by the strict step-0 policy instead of the loose second-step one.  Same cases / seeds / procedural
+    state as the two-step fixtures they are named after.  Only generated when named on the command line."""
+    global PERTURB_DRAW
+    from ha2g_amd.config import BIG_CASES
+    import time
+    for name, base in GAN_CASES.items():
+        if name not in only:
+            continue
+        big = base in BIG_CASES
+        case = BIG_CASES[base] if big else CASES[base]
+        print('case', name, case, flush=True)
+        NPERT = int(os.environ.get('HA2G_GAN_NPERT', 8 if big else 24))
+        plan = [('f64', torch.float64, 0.0, 0), ('f32', torch.float32, 0.0, 0), ('cond', torch.float64, 6e-8, 0)]
+        plan += [('f32p%d' % i, torch.float32, 6e-8, i + 1) for i in range(NPERT)]
+        runs = {}
+        for tag, dt, pert, draw in plan:
+            PERTURB_DRAW = draw
+            o = runs[tag] = {}
+            t0 = time.time()
+            step_goldens(case, o, dt, expressive=bool(case.get('expressive')), perturb=pert, perturb_text=big, epochs=(11,))
+            print('   run', tag, 'done in %.0f s' % (time.time() - t0), flush=True)
+        write_fixture(name, runs, NPERT)
+
+
 def main():
     only = sys.argv[1:]
     main_big(only)
+    main_gan(only)
     main_extra(only)
     main_extra32(only)
     for name, case in CASES.items():

@@ -467,3 +467,27 @@ def fgd_ae_state(dt=torch.float32, P=27):
         t = torch.from_numpy(np.asarray(v)).reshape(shp)
         sd[k] = t.to(dt) if t.is_floating_point() else t
     return sd
+
+
+def tolerance_profile(g, prefix='step0/grad/', rtol=1e-4, tail=None):
+    """What Checker.digest will ALLOW on every gradient digest under `prefix` of fixture `g`, as a fraction of the tensor's scale -- a property of
+    the fixture and the tolerance policy alone (no implementation involved).  -> {module: (share of comparisons whose relative tolerance exceeds
+    2e-4, median relative tolerance, count)} plus the same under 'all'.  tests/test_tolerance_freeze.py pins these numbers: any change to the
+    Checker that loosens a comparison shows up as a grown share and fails (the checker is frozen)."""
+    ck = Checker(g, tail=tail, rtol=rtol)
+    per = {}
+    for k in g.files:
+        if not (k.startswith(prefix) and k.endswith('/sample')) or '.net.' in k:
+            continue
+        key = k[:-7]
+        ref = g[k]
+        rn = float(g[key + '/norm'])
+        n_el = max(ref.size, 1)
+        # Checker.digest's elementwise branch (the norm of the full tensor is not stored with its element count: use the sample's own scale rule)
+        scale = max(np.abs(ref).max(), 1e-30)
+        gfl = ck._group_rel_floor(k)
+        tol = ck._tol(k, scale) + ck.nm * gfl * scale + ck.rtol * ck._group_stats(k)[1]
+        mod = key[len(prefix):].split('.')[0]
+        per.setdefault(mod, []).append(tol / scale)
+        per.setdefault('all', []).append(tol / scale)
+    return {m: (float(np.mean(np.asarray(v) > 2e-4)), float(np.median(v)), len(v)) for m, v in per.items()}

@@ -271,3 +271,59 @@ def test_error_flag_and_prefetched_row_count_two_ranks(tmp_path):
     assert r0 == r1                                          # both replicas see the same flags and the same gathered rows
     assert r0['none'] == 0 and r0['rank1_only'] == 7 and r0['both'] == 4
     assert r0['max_count'] == 6 and r0['shape'] == (12,) and r0['same']
+
+
+class _FakeTable:
+    """what ddp.exchange_sparse_ touches of ops.SparseTable (the real one needs the device for its compaction kernels)"""
+
+    def __init__(self, C):
+        self.weight = torch.zeros(50, C)
+        self.map = None
+        self.pending, self.count_hint, self.n_prefetch = [], None, 0
+
+    def merged(self):
+        assert len(self.pending) == 1
+        return self.pending[0]
+
+
+def _exchange_worker(rank, world, port, out):
+    """ddp.exchange_sparse_ with a prefetched count AND an idle rank.  Rank 1 ran the forward (it holds the prefetched handle) but has
+    nothing pending (a skipped backward): both ranks must take the SAME sequence of collectives -- the handle path, two all-gathers -- or the
+    1-element count all-gather of one rank pairs with the id all-gather of the other (hang / size mismatch; this worker has a timeout)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ha2g_amd import ddp, ops
+    calls = []
+    orig_ag = ddp.all_gather_
+    ddp.all_gather_ = lambda outs, t, group=None: (calls.append(tuple(t.shape)), orig_ag(outs, t, group))[1]
+    ops.merge_rows = lambda ids, rows, m: (ids, torch.tensor([ids.numel()], dtype=torch.int32), rows)      # identity stand-in for the device compaction
+    C, cap = 4, 9
+    res = {}
+    for case, n_prefetch in (('hint', 1), ('two_forwards', 2)):
+        tb = _FakeTable(C)
+        n = 5 if rank == 0 else 3
+        ids = torch.zeros(cap, dtype=torch.int64); ids[:n] = torch.arange(1, n + 1) + 10 * rank
+        rows = torch.zeros(cap, C); rows[:n] = 1.0 + rank
+        count = torch.tensor(n, dtype=torch.int32)
+        for _ in range(n_prefetch):                             # every rank runs every forward: the count collectives are symmetric
+            tb.count_hint = (count, ddp.prefetch_max_count(count))
+            tb.n_prefetch += 1
+        if rank == 0:
+            tb.pending = [(ids, count, rows)]                   # rank 1: idle (nothing pending), but it holds the handle
+        calls.clear()
+        ddp.exchange_sparse_(tb)
+        res[case] = dict(calls=list(calls), n_ids=int(tb.pending[0][0].numel()), state=(tb.count_hint, tb.n_prefetch),
+                         rows_sum=float(tb.pending[0][2].sum()))
+    torch.save(res, out + '.r%d' % rank)
+    dist.destroy_process_group()
+
+
+def test_sparse_exchange_with_prefetched_count_and_an_idle_rank(tmp_path):
+    out = str(tmp_path / 'xchg.pt')
+    mp.spawn(_exchange_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + '.r0'), torch.load(out + '.r1')
+    assert r0 == r1                                              # same collectives, same merged result on both ranks
+    assert [len(c) for c in r0['hint']['calls']] == [1, 2]       # ids [mx], rows [mx, C]: NO count all-gather on either rank
+    assert r0['hint']['calls'][0] == (5,) and r0['hint']['n_ids'] == 10 and r0['hint']['rows_sum'] == 5 * 4 * 0.5
+    assert r0['two_forwards']['calls'][0] == (1,) and len(r0['two_forwards']['calls']) == 3     # in-line count exchange everywhere
+    assert r0['hint']['state'] == (None, 0)

@@ -195,3 +195,43 @@ def test_tower_side_stream_weight_gradients_equal_inline():
     assert set(grads[True]) == set(grads[False]) and len(grads[True]) > 100
     for k in grads[True]:
         assert torch.equal(grads[True][k], grads[False][k]), k
+
+
+@pytest.mark.parametrize('variant', ['long_spectrogram', 'planes_off', 'dgrad_planes_only'])
+def test_default_mode_tower_when_conv2_backward_cannot_run_on_planes(gemm_mode, variant):
+    """ADVICE r4 (wav_engine.block_fwd): in the default mode conv2's forward reads bn1's output as three-piece planes and the fp32 tensor is
+    dropped -- which is only right when conv2's data AND weight gradient read planes too.  A spectrogram longer than 72 frames (layer 2 then has
+    W >= 37: the plane weight gradient does not serve it; T = 62 is SURVEY M5's legal neighbour of config 5's T = 64) or an HA2G_PLANES setting
+    that switches either off must fall back to materialising the fp32 tensor instead of dying in GradSink._gconv.  Forward + backward in mode 70
+    against mode 0 under the same setting: outputs to 1e-4, the whole gradient at cosine > 0.999 (B = 2: flip-level differences are expected)."""
+    from ha2g_amd import hierarchy_net as hn, wav_engine as we
+    from ha2g_amd.config import make_args
+    from ha2g_testing import SpeakerVocab, no_dropout
+    W0 = 126 if variant == 'long_spectrogram' else 70
+    planes = {'long_spectrogram': we.PLANES, 'planes_off': 0, 'dgrad_planes_only': 9}[variant]
+    args = make_args(dict(hidden_size=32, n_layers=2))
+    g = torch.Generator().manual_seed(3)
+    spec = (torch.rand(2, 128, W0, generator=g) * -80.0).to(DEV)
+    vid = torch.tensor([1, 5], device=DEV)
+    res = {}
+    old = we.PLANES
+    we.PLANES = planes
+    try:
+        for mode in (70, 0):
+            gemm_mode(mode)
+            aud = hn.Hierarchical_WavEncoder(args, SpeakerVocab(8), 3, 32)
+            proc.fill_module(aud, 14, 'audio.')
+            aud = no_dropout(aud).to(DEV)
+            w, lo, mid, hi, blend = aud(spec, vid)
+            assert lo.shape == (2, W0 // 2 - 1, 32) and mid.shape == lo.shape and hi.shape == lo.shape
+            (sum((bl * bl).sum() for bl in blend) + (hi * lo).sum() + w.sum()).backward()
+            torch.cuda.synchronize()
+            res[mode] = (torch.cat([t.reshape(-1) for t in (w, lo, mid, hi)]).detach().clone(),
+                         torch.cat([p_.grad.reshape(-1) for p_ in aud.parameters()]).clone())
+    finally:
+        we.PLANES = old
+    o70, g70 = res[70]
+    o0, g0 = res[0]
+    assert float((o70 - o0).abs().max() / o0.abs().max()) < 1e-4
+    cos = float(torch.dot(g70, g0) / (g70.norm() * g0.norm()))
+    assert torch.isfinite(g70).all() and cos > 0.999, cos

@@ -105,6 +105,48 @@ assert torch.equal(fs[0], fs[1]), 'replicas diverged (sparse tables)'
 assert rets_s == rets, (rets_s, rets)
 bad = [k for k in p_dense if not torch.equal(p_dense[k], p_sparse[k])]
 assert not bad, ('sparse vs dense data-parallel parameters differ', bad[:5])
+del tr
+
+# 4. ADVICE r4: a cluster-GRU time-out on ONE rank is recovered from COLLECTIVELY (HierarchyTrainer._train_iter_ddp): the flag is MAX-reduced
+#    inside the step, both replicas skip the flagged updates, both notice the flag at the same later call, restore their BatchNorm
+#    statistics, switch to the fallback recurrences and go on -- no rank raises or re-runs a step on its own (unmatched collectives = hang)
+tr = make(); tr.broadcast_parameters(0); seed_draws()
+ops.USE_GRU_CLUSTER = True                         # H = 32 never takes the cluster kernels; the switch only records the fallback decision
+word = ops._cluster_scratch(dev)[1]                # the error word exists on every rank (as it does after the first cluster launch)
+def snap(tr):
+    return (torch.cat([o.flat_p for o in tr.gen_opts + [tr.audio_opt, tr.text_opt, tr.dis_opt]]).clone(),
+            torch.cat([b.reshape(-1).double() for b in tr._bn_buffers()]).clone(), [int(o.step_t.item()) for o in tr.gen_opts + [tr.dis_opt]])
+for _ in range(2):
+    tr.train_iter(11, text, spec, target, vid)     # calls 0, 1: clean
+tr.sync()
+p0, b0, s0 = snap(tr)
+if rank == 1:
+    word.fill_(1)                                  # as if a hand-off of THIS rank timed out during call 2
+for _ in range(2):
+    tr.train_iter(11, text, spec, target, vid)     # calls 2, 3: flagged on every rank after the in-step MAX-reduce -> optimizer no-ops
+torch.cuda.synchronize()
+assert tr.cluster_retries == 0                     # not noticed yet: the end-of-step words are examined with a fixed lag, the same on every rank
+p1, b1, s1 = snap(tr)
+assert torch.equal(p0, p1) and s0 == s1, 'a flagged data-parallel step changed parameters / step counters'
+assert not torch.equal(b0, b1)                     # ... while its forwards did touch the BatchNorm statistics
+assert int(word.item()) == 1                       # rank 0 holds the flag too: it came through ddp.sync_flag_
+r4 = tr.train_iter(11, text, spec, target, vid)    # call 4: every rank recovers here and runs the batch
+tr.sync()
+assert tr.cluster_retries == 1 and not ops.USE_GRU_CLUSTER and int(word.item()) == 0
+p2, b2, s2 = snap(tr)
+assert s2 == [n + 1 for n in s0] and not torch.equal(p2, p0)          # exactly ONE update since the snapshot
+assert all(v == v for v in r4.values())
+fl = gather(p2)
+assert torch.equal(fl[0], fl[1]), 'replicas diverged across the collective recovery'
+# BatchNorm buffers: restored to the state before the first flagged call, then ONE step's updates (num_batches_tracked is among them)
+ref_tr_cnt = [int(b) for b in tr._bn_buffers() if b.dtype == torch.int64]
+tr2 = make(); tr2.broadcast_parameters(0)
+for _ in range(3):
+    tr2.train_iter(11, text, spec, target, vid)
+tr2.sync()
+assert ref_tr_cnt == [int(b) for b in tr2._bn_buffers() if b.dtype == torch.int64]     # as after three effective steps
+tr2.train_iter(11, text, spec, target, vid); tr2.sync()
+assert tr2.cluster_retries == 0
 dist.destroy_process_group()
 print('DDP2_OK rank %%d' %% rank)
 '''
@@ -121,7 +163,8 @@ def _free_port():
 def test_two_rank_step_on_one_gpu():
     """3 data-parallel steps, 2 ranks: replicas stay bit-identical (dense and sparse embedding tables, which also agree with each other bit for
     bit), the averaged gradient of step 1 equals the mean of the two single-rank gradients (1e-6), batches / dropout masks / BatchNorm running
-    statistics are rank-local, sync_bn_stats() makes the latter identical."""
+    statistics are rank-local, sync_bn_stats() makes the latter identical; a cluster-GRU time-out injected on ONE rank is recovered from by BOTH
+    ranks at the same call (flagged updates skipped everywhere, BatchNorm statistics restored, replicas still bit-identical)."""
     port = _free_port()
     procs = []
     for r in range(2):

@@ -128,6 +128,69 @@ def test_train_step_headline_size_vs_reference(golden, name, mode):
     print('%s mode %d: worst relative deviation from the reference %.2e' % (name, mode, ck.worst))
 
 
+def _margins_by_module(start):
+    """worst error / tolerance ratio per module over the comparisons Checker made since index `start` of its log"""
+    worst = {}
+    for m, key in Checker.margins[start:]:
+        parts = key.split('/')
+        mod = parts[2].split('.')[0] if len(parts) > 2 and parts[1] in ('grad', 'param', 'buf') else parts[1]
+        tag = '%s:%s' % (parts[1], mod)
+        if m > worst.get(tag, (0.0, ''))[0]:
+            worst[tag] = (m, key)
+    return worst
+
+
+@pytest.mark.parametrize('mode', [70, 0])
+@pytest.mark.parametrize('name', ['cfg1_gan', 'expr_cfg1_gan', 'cfg2_b128_gan', 'cfg3_b128_gan'])
+def test_gan_phase_first_step_vs_reference(golden, name, mode):
+    """the phase bench.py times, checked STRICTLY.  The fixture's only step is a GAN-phase step (epoch 11) from fresh state, run
+    by the reference's own train_iter_hierarchy[_expressive] (train_eval/train_hierarchy.py:93-131 D phase, :179-180 + :233-234 gen_error into the
+    generators, :264 loss.backward() adding into D's .grad through the UPDATED D, :270-274 Adam x5; expressive: train_hierarchy_expressive.py:
+    146-196, 284-285, 340, 451-459) -- so the loss dict, every element-digest of every gradient (D's accumulated gradient included), the
+    BatchNorm buffers and the Adam-updated parameters go through Checker._step's step-0 policy (1e-4 of scale + 3 x the reference's own fp32
+    scatter), not the loss-dict-and-norms policy the second step of the two-step fixtures gets."""
+    import os
+    from ha2g_amd import ops, schema
+    from ha2g_amd._lib import DEFAULT_GEMM_MODE, lib
+    from ha2g_amd.config import BIG_CASES
+    from tests.conftest import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, name + '.npz')):
+        pytest.skip('fixture %s.npz not generated (tests/golden/gen_golden.py %s)' % (name, name))
+    base = name[:-4]
+    case, g = (CASES[base] if base in CASES else BIG_CASES[base]), golden(name)
+    expressive = bool(case.get('expressive'))
+    dims = schema.EXPRESSIVE_POSE_DIMS if expressive else schema.GESTURE_POSE_DIMS
+    ck = Checker(g)
+    args, gens, dis, aud, txt = build_modules(case, DEV, dims)
+    text, spec, target, vid = (t.to(DEV) for t in batch_for(case, P=dims[-1]))
+    lr = float(args.learning_rate)
+    g_opts = [FusedAdam(m.parameters(), lr=lr) for m in gens]
+    dis_opt = FusedAdam(dis.parameters(), lr=lr * args.discriminator_lr_weight)
+    aud_opt, txt_opt = FusedAdam(aud.parameters(), lr=lr), FusedAdam(txt.parameters(), lr=lr)
+    EpsInjector(gens, case['seed'], case['B'])
+    perm = torch.from_numpy(proc.fixed_perm(case['B'], case['seed'])).to(DEV)
+    mods = {'g%d' % (i + 1): m for i, m in enumerate(gens)}
+    mods.update(dis=dis, audio=aud, text=txt)
+    fn = th.train_iter_hierarchy_expressive if expressive else th.train_iter_hierarchy
+    old = th.randperm_source
+    th.randperm_source = lambda n, device: perm
+    lib.ha2g_gemm_set_mode(mode)
+    start = len(Checker.margins)
+    try:
+        ret = fn(args, 11, text, spec, target, vid, *gens, dis, aud, txt, *g_opts, dis_opt, aud_opt, txt_opt)
+        sd, grads = named_state(mods)
+        assert any(k.startswith('dis.') for k in grads)                       # D's gradients ARE part of this comparison
+        ck.step(0, ret, grads, sd)
+    finally:
+        th.randperm_source = old
+        lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
+        w = _margins_by_module(start)
+        print('%s mode %d: worst error/tolerance per module: %s' % (name, mode, ', '.join(
+            '%s %.2f' % (k, v[0]) for k, v in sorted(w.items()) if k.startswith('grad:'))))
+    assert ops.gru_cluster_error(torch.device(DEV)) == 0
+    assert {'grad:dis'} | {'grad:g%d' % (i + 1) for i in range(len(gens))} <= set(w)
+
+
 def test_training_loop_reduces_loss_and_is_deterministic():
     """A few real optimisation steps (dropout on, default init, HierarchyTrainer = the reference's train_epochs set-up):
     losses stay finite, the regression loss falls on a fixed batch, memory does not grow, no GRU hand-off times out,

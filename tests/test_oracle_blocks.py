@@ -146,3 +146,31 @@ def test_step_fixture_tcn_relu_margins():
     assert tcn_relu_margin(CASES['expr_cfg1']) > 5e-7
     assert tcn_relu_margin(CASES['cfg1']) > 5e-8
     assert tcn_relu_margin(CASES['small']) > 1e-6
+
+
+def test_imposing_the_oracles_own_relu_pattern_reproduces_it():
+    """oracle.relu_pattern (the linearisation the GPU-side 1e-4 pins of the tower's backward use, tests/test_gpu_linearised.py): with the
+    decisions the float64 oracle itself took imposed as masks, outputs and every gradient are those of the plain oracle -- and with ONE decision
+    flipped they are not (the masks are really what the backward goes through)."""
+    name, geom = 'l2d', BLOCK_CASES['l2d']
+    dt = torch.float64
+
+    def run(masks=None, record=None):
+        sd = block_state(name, geom, 2100, dt)
+        x, wl = block_io(name, geom, BLOCK_B, 2100, dt)
+        x.requires_grad_(True)
+        ps = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not k.endswith(('running_mean', 'running_var'))]
+        with O.relu_pattern(masks=masks, record=record):
+            y = O.se_block(x, {('b.' + k): v for k, v in sd.items()}, 'b.', 2, True)
+        return [y.detach()] + [g for g in torch.autograd.grad((y * wl).sum(), [x] + ps)]
+
+    rec = {}
+    plain = run(record=rec)
+    assert sorted(rec) == ['b.c1', 'b.out', 'b.se'] and all(m.dtype == torch.bool for m in rec.values())
+    imposed = run(masks=rec)
+    for a, b in zip(plain, imposed):
+        assert torch.equal(a, b)
+    flipped = {k: v.clone() for k, v in rec.items()}
+    flipped['b.c1'].view(-1)[7] ^= True
+    other = run(masks=flipped)
+    assert any(not torch.equal(a, b) for a, b in zip(plain[1:], other[1:]))

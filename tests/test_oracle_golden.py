@@ -172,3 +172,22 @@ def test_eval_mode_inference(golden, name, dt):
         pre[:, :4, -1] = 1
         o, *_ = O.pose_generator(pre, text, blend[2], vid, sd, 'g3.', case['n_layers'], case['hidden_size'], eps)
         ck.close(o, 'eval/gen/out')
+
+
+@pytest.mark.parametrize('dt', DTS)
+@pytest.mark.parametrize('name', ['cfg1_gan', 'expr_cfg1_gan'])
+def test_gan_phase_first_step(golden, name, dt):
+    """The `*_gan` fixtures: ONE GAN-phase step (epoch 11) from fresh state run by the reference -- the oracle's D phase, gen_error path, D-gradient
+    accumulation through the updated D and the six (nine) Adam updates under the strict step-0 policy (1e-9 in float64)."""
+    from ha2g_amd.config import EXPRESSIVE_SPEC
+    case, g = CASES[name[:-4]], golden(name)
+    expressive = bool(case.get('expressive'))
+    ck = Checker(g, dt)
+    sd = state_for(case, dt, schema.EXPRESSIVE_POSE_DIMS if expressive else schema.GESTURE_POSE_DIMS)
+    text, spec, target, vid = batch_for(case, dt, P=126 if expressive else 27)
+    tr = O.OracleTrainer(sd, make_args(case), EXPRESSIVE_SPEC if expressive else None)
+    es = proc.EpsStream(case['seed'])
+    perm = torch.from_numpy(proc.fixed_perm(case['B'], case['seed']))
+    ret = tr.train_iter(11, text, spec, target, vid, lambda shp: torch.from_numpy(es(shp)).to(dt), perm)
+    assert 'gen' in ret and 'dis' in ret and any(k.startswith('dis.') for k in tr.grads)
+    ck.step(0, ret, tr.grads, sd)
