@@ -13,6 +13,7 @@
 // the 16-lane groups of a ds_read_b128 (guide, LDS section) touch 16 distinct 16-byte slots: conflict-free fragment reads.  The DMA writes
 // LDS lane-linearly (wave-uniform base + lane * 16), so the swizzle is applied to the per-lane SOURCE address (guide 5.4 rule 21).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -973,6 +974,228 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// PATCH-RESIDENT form of the q kernel (round 5): pconv_r_kernel -- 3x3 / stride 1 / pad 1, forward or data gradient, three pieces.
+// What bounded the q kernel on the trunk's 3x3 convolutions was not the matrix pipe but the LDS-DMA path: every k tile (one tap of one 32-channel
+// slice) re-stages its shifted A tile, i.e. every pixel travels L2 -> LDS NINE times per slice, and B once per workgroup: 1.21 GB / 0.74 GB /
+// 1.25 GB of DMA per launch at C = 64 / 128 / 256 -- at the ~8 TB/s the DMA path delivers chip-wide that IS the 143 / 94 / 116 us the launches
+// took (matrix floor: 52 us each).  Here a group's A operand is the PATCH of its tile -- the tile's image rows plus a one-pixel halo, one 32-channel
+// slice, three pieces -- staged ONCE per slice; the nine taps read their fragments from it at shifted addresses (as conv3x3_c32pp_kernel does).
+// A traffic drops by 9 x (tile pixels / patch pixels) = 4-7x; B is staged per k tile exactly as before.
+//   * a GROUP tile is GM = 16 MT consecutive pixels of ONE image (MT = 7: 112 = 1/20 of a 64x35 image; MT = 9: 144 = 1/4 of 32x18, all of 16x9);
+//     workgroup = two group tiles in anti-phase (LOAD: fragments of a k tile -> registers + the next k tile's B; COMPUTE: MFMAs out of registers);
+//   * patch rows are PW = W + 8 pixels wide (1 left pad, 7 right): a 16-pixel fragment that wraps around an image row then continues 8 patch
+//     pixels further on, which the bank pattern cannot tell from a consecutive run -- with the slot swizzle  s ^ 2 ((pixel >> 2) & 1)  and the
+//     fragment columns permuted (columns {0-3, 12-15} = pixels 0-7, columns 4-11 = pixels 8-15; see conv3x3_c32pp_kernel) every ds_read_b128 of
+//     every tap is conflict-free (enumerated for the three trunk geometries; W + 2 leaves 1.4-1.9x the conflict-free cycles);
+//   * the patch of the next slice is requested at the head of the COMPUTE phase of a slice's last tap (its reads ended with that tap's LOAD): one
+//     single-buffered patch per group is all that fits beside the B ring (2 x 52-61 KB + 24-48 KB);
+//   * same k order (channel-major, taps ascending), same six products smallest first, same accumulators as the q kernel => BIT-IDENTICAL output
+//     (tests/test_gpu_planes.py asserts torch.equal against the q kernel on every trunk geometry, forward and data gradient).
+struct RGeo {
+    int gpi;                  // group tiles per image
+    int ntiles;               // group tiles in all (images x gpi)
+    int PW, patch_px;         // patch row length (W + 8), patch pixels reserved per piece (multiple of 16)
+    int nchunks;              // 16-pixel DMA chunks of a patch (patch_px / 16)
+    unsigned mgW, mgPW, mg_gpi;
+    int toff64[9];            // byte offset of each tap's source pixel inside the patch (host-filled ints: scalar loads -- a byte table indexed at run
+                              // time became global_load_ubyte + s_waitcnt vmcnt(0) at the head of every LOAD phase, i.e. a wait for the weight loads)
+};
+template <int MT, int BN, int PPX>
+__global__ __launch_bounds__(512) void pconv_r_kernel(PConvP p, RGeo g) {
+    constexpr int NP = 3;
+    constexpr int GM = 16 * MT;
+    constexpr int NI = BN / 64;
+    constexpr int PLANE_A = PPX * 64, A_GRP = NP * PLANE_A;      // bytes; multiples of 512 (the fragment address trick below relies on it)
+    static_assert(PLANE_A % 512 == 0 && 2 * PLANE_A < 65536, "piece offsets are ds_read immediates");
+    constexpr int NCW = (PPX / 16 + 3) / 4;                      // DMA chunks of the patch a wave issues at most
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;
+    int bx, by;
+    ptile_of_block(bx, by);
+    const PClass& pc = p.cls[0];
+    const int n0 = by * BN;
+    const int W = p.GW, H = p.GH, HW = H * W, PW = g.PW;
+    // this group's tile (clamped past the end: the group still takes part in every barrier, its stores are skipped)
+    int gt = 2 * bx + grp;
+    const bool live = gt < g.ntiles;
+    if (!live) gt = g.ntiles - 1;
+    const int img = fast_div(gt, g.gpi, g.mg_gpi);
+    const int tp0 = (gt - img * g.gpi) * GM;                      // first pixel of the tile inside its image
+    const int tend = tp0 + GM < HW ? tp0 + GM : HW;
+    const int r0 = fast_div(tp0, W, g.mgW);                       // first image row of the tile; the patch starts one row above, one column left
+    const int nkc = p.GC >> 5;
+
+    // ---- patch DMA: chunk c = 16 patch pixels x 64 bytes of one piece; lane -> (pixel c * 16 + lane / 4, PHYSICAL slot lane & 3), fetched from the
+    //      logical slot  phys ^ sw(pixel)  of the source pixel (the swizzle is applied to the source address: the LDS side of a DMA is lane-linear)
+    constexpr unsigned OOB = 0xfffffff0u;
+    unsigned poff[NCW];
+#pragma unroll
+    for (int i = 0; i < NCW; ++i) {
+        const int c = w4 + 4 * i;
+        poff[i] = OOB;
+        if (c < g.nchunks) {
+            const int q = c * 16 + (lane >> 2);
+            const int pr = fast_div(q, PW, g.mgPW), pcx = q - pr * PW;
+            const int y = r0 - 1 + pr, x = pcx - 1;
+            const int slot = (lane & 3) ^ ((q >> 1) & 2);
+            if (y >= 0 && y < H && x >= 0 && x < W) poff[i] = (unsigned)(((((long)img * H + y) * W + x) * p.GC + slot * 8) * 2);
+        }
+    }
+    unsigned char* const a_lds = smem + grp * A_GRP;
+    auto stage_patch = [&](int cc) {
+        const unsigned coff = (unsigned)(cc << 6);               // 32 channels = 64 bytes
+#pragma unroll
+        for (int i = 0; i < NCW; ++i) {
+            const int c = w4 + 4 * i;
+            if (c < g.nchunks) {                                 // wave-uniform
+                const unsigned vo = poff[i] == OOB ? OOB : poff[i] + coff;
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)(p.a.p + q * p.a.ps), 0, p.a_bytes, 0x00020000),
+                                                             (lds_ptr_t)(a_lds + q * PLANE_A + c * 1024), 16, (int)vo, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x4_t acc[MT][NI];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int l15 = lane & 15, kp = lane >> 4;
+    const int pxo = l15 < 4 ? l15 : (l15 < 12 ? l15 + 4 : l15 - 8);          // fragment column -> pixel of its 16-pixel row tile (bank pattern, see above)
+    // ---- B: the weight fragments go global -> registers DIRECTLY (round 5, second form).  Through LDS they cost group 0 three to six LDS-DMA
+    //      instructions per k tile in its LOAD phase -- ~220 cycles EACH in that phase (tools/r_kernel_ablate.py: the phase grew from 1 000 to 2 300
+    //      cycles and bounded the kernel at C = 128) -- plus a two-stage LDS ring and the fragment reads.  A lane's fragment of column n, k chunk kp is
+    //      16 contiguous bytes of row n of the [N][K] weight planes: one buffer_load_dwordx4 per (piece, column tile) with a per-lane constant offset
+    //      and the k tile's (tap, slice) offset in an SGPR; the loads are issued at the head of the LOAD phase and land under its fragment reads.
+    unsigned boff[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + w4 * (BN / 4) + j * 16 + l15;
+        boff[j] = n < p.N ? (unsigned)(((long)n * p.K + kp * 8) * 2) : OOB;
+    }
+    // byte address (in LDS, relative to 0) of this lane's 16 bytes of its pixel of row tile i at tap offset 0, BEFORE the slot swizzle:
+    //   v = a_lds + pp * 64 + kp * 16;   the swizzled address is  v ^ ((v >> 3) & 32)  -- bit 8 of v is bit 2 of the patch pixel pp (a_lds and the
+    //   piece planes are multiples of 512 bytes), bit 5 is the high bit of the slot: slot ^ 2 ((pp >> 2) & 1) without recomputing pp
+    int vb[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int pix = tp0 + i * 16 + pxo;
+        if (pix >= tend) pix = tend - 1;                          // clamp: inside the patch, result discarded
+        const int oy = fast_div(pix, W, g.mgW), ox = pix - oy * W;
+        vb[i] = grp * A_GRP + ((oy - r0) * PW + ox) * 64 + kp * 16;
+    }
+    bf16x8_t af[NP][MT], bfb[2][NP][NI];                        // the weight fragments of TWO k tiles: the next one's are in flight a whole k tile ahead
+
+    auto load_b = [&](auto SET, int ti, int cc) {
+        constexpr int sb = decltype(SET)::value;
+        const int kb2 = (pc.tap[ti] * p.GC + (cc << 5)) * 2;     // bytes
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)(p.b.p + q * p.b.ps), 0, p.b_bytes, 0x00020000),
+                                                                        (int)boff[j], kb2, 0);
+                bfb[sb][q][j] = __builtin_bit_cast(bf16x8_t, v);
+            }
+    };
+    auto load_frags = [&](int ti) {
+        const int toff64 = g.toff64[ti];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int v = vb[i] + toff64;
+            const unsigned char* ab = smem + (v ^ ((v >> 3) & 32));
+#pragma unroll
+            for (int q = 0; q < NP; ++q) af[q][i] = *reinterpret_cast<const bf16x8_t*>(ab + q * PLANE_A);
+        }
+    };
+    auto compute = [&](auto SET) {
+        constexpr int sb = decltype(SET)::value;
+        if (p.dbg & 2) {                                         // ablation bit 1 (ha2g_conv_planes_debug): no MFMA -- the fragments stay live
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(af[q][i]));
+#pragma unroll
+                for (int j = 0; j < NI; ++j) asm volatile("" :: "v"(bfb[sb][q][j]));
+            }
+            return;
+        }
+        constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};          // smallest products first
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfb[sb][QB[t]][j], af[QA[t]][i], acc[i][j], 0, 0, 0);
+    };
+    auto end_load = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
+    auto end_compute = [&]() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
+
+    if (p.dbg & 32) return;                                      // ablation bit 5: launch cost only
+    const int nk = (p.dbg & 4) ? 0 : pc.ntaps * nkc;             // ablation bit 2: no k loop (launch + prologue + epilogue remain)
+    const bool dma = !(p.dbg & 1);                               // ablation bit 0: no DMA / weight loads after the prologue's
+    stage_patch(0);
+    load_b(std::integral_constant<int, 0>{}, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) asm volatile("s_barrier" ::: "memory");        // half a period behind group 0
+    int ti = 0, cc = 0;
+    auto step = [&](auto CUR, int k) {
+        constexpr int cur = decltype(CUR)::value;
+        // LOAD phase: the NEXT k tile's weight fragments first -- a whole k tile (LOAD + COMPUTE + LOAD) ahead of their first use: an L2 round trip
+        // under load is longer than one LOAD phase (the first form of this loader fetched the CURRENT tile's fragments here and waited for them)
+        int tn = ti + 1, cn = cc;
+        if (tn == pc.ntaps) { tn = 0; ++cn; }
+        if (k + 1 < nk && dma) load_b(std::integral_constant<int, 1 - cur>{}, tn, cn);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(ti);
+        __builtin_amdgcn_sched_barrier(0);
+        end_load();
+        const bool last_tap = ti + 1 == pc.ntaps;
+        if (last_tap && cc + 1 < nkc && dma) stage_patch(cc + 1);                       // COMPUTE phase: the patch is dead (its last reads ended with this LOAD)
+        __builtin_amdgcn_sched_barrier(0);
+        compute(CUR);
+        __builtin_amdgcn_sched_barrier(0);
+        end_compute();
+        ti = tn; cc = cn;
+    };
+    for (int k = 0; k < nk; k += 2) {
+        step(std::integral_constant<int, 0>{}, k);
+        if (k + 1 < nk) step(std::integral_constant<int, 1>{}, k + 1);
+    }
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");
+
+    // ---- epilogue: D = W X^T, a lane holds four consecutive output channels of one pixel -> one 16-byte store per 16x16 tile (as the q kernel) ----
+    if (!live || (p.dbg & 8)) return;                            // ablation bit 3: no output stores
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int pix = tp0 + i * 16 + pxo;
+        if (pix >= tend) continue;
+        const long orow = (long)img * HW + pix;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col0 = n0 + w4 * (BN / 4) + j * 16 + 4 * kp;
+            if (col0 >= p.N) continue;
+            f32x4_t v = acc[i][j];
+            float* dst = p.C + orow * p.ldc + col0;
+            if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (p.beta != 0.f) v += p.beta * *reinterpret_cast<const f32x4_t*>(dst);
+            *reinterpret_cast<f32x4_t*>(dst) = v;
+        }
+    }
+}
+
 // Weight gradient of a 3x3 / stride-1 / pad-1 convolution from planes:  dW[co][tap][ci] = sum over pixels p of dy[p][co] * x[p + tap][ci].
 // The implicit GEMM (gemm.hip, A_MC x B_IM) stages the im2col gather of x -- the same pixels nine times -- and both operands once per
 // 128-wide output tile; rocprofv3 puts it at 15 VALU per MFMA (split + gather arithmetic) and, in the step, bound by L2 -> LDS traffic beside
@@ -1374,6 +1597,77 @@ static void set_plane_bytes(PConvP& p, long a_elems, long b_elems) {
     p.a_bytes = (a_elems > 0 && a_elems < lim) ? (int)(a_elems * 2) : 0;
     p.b_bytes = (b_elems > 0 && b_elems < lim) ? (int)(b_elems * 2) : 0;
 }
+static int g_r_kernel = 1;   // patch-resident kernel for the 3x3 / stride-1 trunk convolutions (ha2g_conv_planes_tile3(8) = off: the q kernel, A/B)
+template <int MT, int BN, int PPX>
+static int pconv_r_launch(const PConvP& p, const RGeo& g, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * 3 * PPX * 64;
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_r_kernel<MT, BN, PPX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ha2g_set_error(-2, "pconv_r: cannot raise the dynamic LDS limit");
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((pconv_r_kernel<MT, BN, PPX>), grid, dim3(512), lds, st, p, g);
+    return 0;
+}
+// -100: geometry not served (the caller keeps the q kernel): 3x3 / stride 1 / pad 1 with one class of nine taps, N a multiple of 64 with aligned
+// vector stores, no bias / activation epilogue (the convolution callers pass relu only), the two patches inside the reserved LDS planes
+static int pconv_r_dispatch(const PConvP& p_in, int imgs, hipStream_t st) {
+    PConvP p = p_in;
+    const PClass& c0 = p.cls[0];
+    if (!g_r_kernel || p.ncls != 1 || c0.ntaps != 9 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.ksplit > 1 || p.bias || p.act) return -100;
+    if (p.GH != p.OH || p.GW != p.OW || p.GC % 32 != 0 || p.N % 64 != 0 || p.a_bytes <= 0 || p.b_bytes <= 0) return -100;
+    const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    if (!(p.ldc % 4 == 0 && al16(p.C))) return -100;
+    const int H = p.GH, W = p.GW, HW = H * W;
+    if (W < 2 || HW < 16) return -100;
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) { int c = 0; if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) cus = c; }
+    // tile choice: rows per group 16 MT (MT = 7 or 9) x BN columns -- the combination that keeps the CUs fullest (as pconv_q_plan), among those whose
+    // patch fits one of the two reserved plane sizes (272 / 320 patch pixels)
+    double best = -1.0; int bmt = 0, bbn = 0; RGeo bg{};
+    for (int bn = 128; bn >= 64; bn -= 64) {
+        if (p.N % bn != 0) continue;
+        for (int mt = 9; mt >= 7; mt -= 2) {
+            const int gm = 16 * mt, gpi = (HW + gm - 1) / gm;
+            int rows_max = 1;
+            for (int t = 0; t < gpi; ++t) {
+                const int a = t * gm, b = (a + gm < HW ? a + gm : HW) - 1;
+                const int r = b / W - a / W + 1;
+                if (r > rows_max) rows_max = r;
+            }
+            RGeo g{};
+            g.gpi = gpi; g.ntiles = imgs * gpi; g.PW = W + 8;
+            const int need = (rows_max + 2) * g.PW;
+            if (need > 320) continue;
+            g.patch_px = need <= 272 ? 272 : 320;
+            g.nchunks = (need + 15) / 16;
+            const long wgs = (long)((g.ntiles + 1) / 2) * (p.N / bn), rounds = (wgs + cus - 1) / cus;
+            double eff = (double)wgs / (double)(rounds * cus) * ((double)HW / (double)(gpi * gm));
+            eff *= (bn == 128 ? 1.0 : 0.93) * (mt == 9 ? 1.0 : 0.97);
+            if (eff > best + 1e-9) { best = eff; bmt = mt; bbn = bn; bg = g; }
+        }
+    }
+    if (bmt == 0) return -100;
+    bg.mgW = (unsigned)(((1ULL << 32) + (unsigned)W - 1) / (unsigned)W);
+    bg.mgPW = (unsigned)(((1ULL << 32) + (unsigned)bg.PW - 1) / (unsigned)bg.PW);
+    bg.mg_gpi = bg.gpi > 1 ? (unsigned)(((1ULL << 32) + (unsigned)bg.gpi - 1) / (unsigned)bg.gpi) : 0u;
+    for (int t = 0; t < 9; ++t) {                                // forward: source pixel (oy - 1 + kh, ox - 1 + kw); data gradient: (oy + 1 - kh, ox + 1 - kw)
+        const int kh = c0.tap[t] / 3, kw = c0.tap[t] % 3;
+        bg.toff64[t] = (p.fwd ? kh * bg.PW + kw : (2 - kh) * bg.PW + (2 - kw)) * 64;
+    }
+    const dim3 grid((unsigned)((bg.ntiles + 1) / 2), (unsigned)(p.N / bbn), 1);
+    const bool big = bg.patch_px == 320;
+    if (bbn == 128) {
+        if (bmt == 9) return big ? pconv_r_launch<9, 128, 320>(p, bg, grid, st) : pconv_r_launch<9, 128, 272>(p, bg, grid, st);
+        return big ? pconv_r_launch<7, 128, 320>(p, bg, grid, st) : pconv_r_launch<7, 128, 272>(p, bg, grid, st);
+    }
+    if (bmt == 9) return big ? pconv_r_launch<9, 64, 320>(p, bg, grid, st) : pconv_r_launch<9, 64, 272>(p, bg, grid, st);
+    return big ? pconv_r_launch<7, 64, 320>(p, bg, grid, st) : pconv_r_launch<7, 64, 272>(p, bg, grid, st);
+}
+
 template <int NP>
 static int pconv_q_dispatch(const PConvP& p_in, int maxM, hipStream_t st) {
     PConvP p = p_in;
@@ -1413,7 +1707,9 @@ static int pconv_dispatch(const PConvP& p, int maxM, hipStream_t st) {
         int t = g_tile3 ? g_tile3 : (p.N % 128 == 0 ? 4 : 3);
         if (g_tile3 == 5 || (g_tile3 == 0 && g_q_kernel)) {
             if constexpr (OUT == 0) {
-                int rc = pconv_q_dispatch<NP>(p, maxM, st);
+                int rc = g_tile3 == 0 ? pconv_r_dispatch(p, p.cls[0].OHc > 0 && p.cls[0].OWc > 0 ? p.cls[0].M / (p.cls[0].OHc * p.cls[0].OWc) : 0, st) : -100;
+                if (rc != -100) return rc;
+                rc = pconv_q_dispatch<NP>(p, maxM, st);
                 if (rc != -100) return rc;
             }
             t = g_tile3 == 5 ? 4 : (p.N % 128 == 0 ? 4 : 3);
@@ -1494,6 +1790,8 @@ void ha2g_conv_planes_bufaddr(int on) { g_qbuf = on ? 1 : 0; }
 void ha2g_conv_planes_korder(int channel_major) { g_kmaj = channel_major ? 1 : 0; }
 void ha2g_conv_planes_tile3(int t) {
     g_q_classes = 1;
+    g_r_kernel = 1;
+    if (t == 8) { g_r_kernel = 0; t = 0; }                        // the q kernel for the 3x3 / stride-1 convolutions too (round 4's default; A/B)
     if (t == 7) { g_q_classes = 0; g_q_kernel = 1; g_tile3 = 0; }
     else if (t == 6) { g_q_kernel = 0; g_tile3 = 0; }
     else { g_q_kernel = 1; g_tile3 = (t >= 0 && t <= 5) ? t : 0; }

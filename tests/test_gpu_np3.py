@@ -272,3 +272,40 @@ def test_c32_three_piece_kernel_forms_are_fp32_class(shape):
         assert float((y - ref_y).abs().max() / ref_y.abs().max()) < 3e-6, form
         assert float((dx - ref_dx).abs().max() / ref_dx.abs().max()) < 3e-6, form
     assert torch.equal(outs['prefetch'][0], outs['first'][0]) and torch.equal(outs['prefetch'][1], outs['first'][1])
+
+
+@pytest.mark.parametrize('B,H,W,C,Cout', [(4, 64, 35, 64, 64), (3, 64, 35, 64, 64), (4, 32, 18, 128, 128), (5, 16, 9, 256, 256), (2, 13, 11, 64, 128),
+                                          (1, 7, 5, 64, 64), (7, 16, 9, 256, 256), (2, 64, 63, 64, 64), (128, 32, 18, 128, 128)])
+def test_patch_resident_kernel_is_bit_identical_to_the_q_kernel(B, H, W, C, Cout):
+    """pconv_r_kernel (round 5: the tile's patch staged once per 32-channel slice, the nine taps read it at shifted addresses) against pconv_q_kernel
+    (every tap's A tile re-staged): same k order, same six products smallest first, same accumulators => torch.equal -- forward (with and without the
+    fused ReLU) and data gradient (beta = 0 and accumulate), the three trunk geometries, odd image counts (an idle second group), images that are
+    not a whole number of tiles, a 63-wide layer-2 image (the T = 62 spectrogram) -- and against float64 at the three-piece bound."""
+    from ha2g_amd import wav_engine as we
+    torch.manual_seed(11)
+    x = torch.randn(B, H, W, C, device=DEV)
+    w = torch.randn(Cout, 3, 3, C, device=DEV) * 0.05                          # OHWI
+    xp, wp = ops.to_planes(x, 3), ops.to_planes(w.contiguous(), 3)
+    dy = torch.randn(B, H, W, Cout, device=DEV)
+    dyp = ops.to_planes(dy, 3)
+    base = torch.randn(B, H, W, C, device=DEV)
+
+    def run():
+        y0 = we.conv_fwd_planes(xp, wp, x.shape, 1, 1, we.ACT_NONE)
+        y1 = we.conv_fwd_planes(xp, wp, x.shape, 1, 1, we.ACT_RELU)
+        d0 = we.conv_dgrad_planes(dyp, w, (B, H, W, C), 1, 1)
+        d1 = we.conv_dgrad_planes(dyp, w, (B, H, W, C), 1, 1, out=base.clone(), beta=1.0)
+        torch.cuda.synchronize()
+        return y0, y1, d0, d1
+    try:
+        lib.ha2g_conv_planes_tile3(8)                                          # the q kernel
+        ref = run()
+    finally:
+        lib.ha2g_conv_planes_tile3(0)
+    got = run()                                                                # default: the patch-resident kernel where it serves the geometry
+    for a, b_, name in zip(got, ref, ('fwd', 'fwd+relu', 'dgrad', 'dgrad beta=1')):
+        assert torch.equal(a, b_), (name, float((a - b_).abs().max()))
+    y64 = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    assert float((got[0].double() - y64).abs().max() / y64.abs().max()) < 3e-6
+    d64 = torch.nn.functional.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    assert float((got[2].double() - d64).abs().max() / d64.abs().max()) < 3e-6

@@ -13,7 +13,7 @@ dx = torch.empty(B, H, W, C, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 
 
-def t_us(iters=20):
+def t_us(iters=60):
     fn = lambda: check(lib.ha2g_conv2d_dgrad_f32(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), B, H, W, C, C, 3, 3, 1, 1, 0.0, st))
     fn(); fn()
     torch.cuda.synchronize()
@@ -30,5 +30,8 @@ for label, form, bits in (('first form (single buffer, conv3x3_x3_kernel<32,3>)'
                           ('anti-phase form (conv3x3_c32pp_kernel)', 'pp', 0), ('  no MFMA', 'pp', 1), ('  no LDS fill (split + writes)', 'pp', 2), ('  no stores', 'pp', 4),
                           ('  no loads', 'pp', 8), ('  no MFMA, no stores', 'pp', 5), ('  nothing but the barriers', 'pp', 15), ('  only MFMA (no fill, stores, loads)', 'pp', 14), ('anti-phase form, groups by wave parity instead of wave >> 2', 'pp', 256), ('  only MFMA', 'pp', 256 | 14)):
     lib.ha2g_conv_c32_prefetch({'x3': 32, 'x3p': 33, 'pp': 1}[form] | ((bits & 15) << 1) | (256 if bits & 256 else 0))
+    print('%-52s %8.1f us' % (label, t_us()))
+for label, sw in (('anti-phase form again (after the ablations: clocks settled)', 1), ('anti-phase form again', 1)):
+    lib.ha2g_conv_c32_prefetch(sw)
     print('%-52s %8.1f us' % (label, t_us()))
 lib.ha2g_conv_c32_prefetch(1)
