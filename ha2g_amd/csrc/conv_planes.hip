@@ -976,38 +976,41 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
-// PATCH-RESIDENT form of the q kernel (round 5): pconv_r_kernel -- 3x3 / stride 1 / pad 1, forward or data gradient, three pieces.
-// What bounded the q kernel on the trunk's 3x3 convolutions was not the matrix pipe but the LDS-DMA path: every k tile (one tap of one 32-channel
-// slice) re-stages its shifted A tile, i.e. every pixel travels L2 -> LDS NINE times per slice, and B once per workgroup: 1.21 GB / 0.74 GB /
-// 1.25 GB of DMA per launch at C = 64 / 128 / 256 -- at the ~8 TB/s the DMA path delivers chip-wide that IS the 143 / 94 / 116 us the launches
-// took (matrix floor: 52 us each).  Here a group's A operand is the PATCH of its tile -- the tile's image rows plus a one-pixel halo, one 32-channel
-// slice, three pieces -- staged ONCE per slice; the nine taps read their fragments from it at shifted addresses (as conv3x3_c32pp_kernel does).
-// A traffic drops by 9 x (tile pixels / patch pixels) = 4-7x; B is staged per k tile exactly as before.
-//   * a GROUP tile is GM = 16 MT consecutive pixels of ONE image (MT = 7: 112 = 1/20 of a 64x35 image; MT = 9: 144 = 1/4 of 32x18, all of 16x9);
-//     workgroup = two group tiles in anti-phase (LOAD: fragments of a k tile -> registers + the next k tile's B; COMPUTE: MFMAs out of registers);
-//   * patch rows are PW = W + 8 pixels wide (1 left pad, 7 right): a 16-pixel fragment that wraps around an image row then continues 8 patch
-//     pixels further on, which the bank pattern cannot tell from a consecutive run -- with the slot swizzle  s ^ 2 ((pixel >> 2) & 1)  and the
-//     fragment columns permuted (columns {0-3, 12-15} = pixels 0-7, columns 4-11 = pixels 8-15; see conv3x3_c32pp_kernel) every ds_read_b128 of
-//     every tap is conflict-free (enumerated for the three trunk geometries; W + 2 leaves 1.4-1.9x the conflict-free cycles);
-//   * the patch of the next slice is requested at the head of the COMPUTE phase of a slice's last tap (its reads ended with that tap's LOAD): one
-//     single-buffered patch per group is all that fits beside the B ring (2 x 52-61 KB + 24-48 KB);
+// PATCH-RESIDENT plane kernel (round 5): pconv_r_kernel -- 3x3 / stride 1 / pad 1, forward or data gradient, three pieces.
+// The q kernel re-stages a shifted A tile for every k tile (one tap of one 32-channel slice): every pixel travels L2 -> LDS NINE times per slice, at
+// 100-220 cycles of issue per LDS-DMA instruction, in a LOAD phase that two workgroup barriers per k tile keep in lockstep with the other group's
+// COMPUTE phase.  Here
+//   * a workgroup = FOUR waves = one tile of GM = 16 MT consecutive pixels of ONE image x BN output channels (MT = 7: 112 px = 1/20 of a 64x35 image;
+//     MT = 9: 144 px = 1/4 of 32x18, all of 16x9); its A operand is the PATCH of the tile -- the tile's image rows plus a one-pixel halo, one 32-channel
+//     slice, three pieces, 52-61 KB -- staged by DMA ONCE per slice; the nine taps read their fragments from it at shifted addresses (as
+//     conv3x3_c32pp_kernel does): 4-7x fewer bytes and DMA instructions through the LDS-DMA path;
+//   * the weight fragments never touch LDS: a lane's fragment (column n, k chunk kp) is 16 contiguous bytes of row n of the [N][K] weight planes --
+//     one buffer_load_dwordx4 per (piece, column tile) with a per-lane constant offset and the k tile's (tap, slice) offset in an SGPR, issued a whole
+//     k tile ahead into a second register set;
+//   * so a k tile needs NO barrier: reads -> MFMAs per wave, and the two or three workgroups resident per CU (52 KB of LDS, 160-256 VGPRs) fill each
+//     other's read phases, prologues and epilogues.  Barriers remain where the single-buffered patch is replaced (once per 32-channel slice): its DMA
+//     is issued behind the last tap's fragment reads and flies under that tap's MFMAs;
+//   * patch rows are PW = W + 8 pixels wide (1 left pad, 7 right): a 16-pixel fragment that wraps around an image row continues 8 patch pixels
+//     further on, which the bank pattern cannot tell from a consecutive run -- with the slot swizzle  s ^ 2 ((pixel >> 2) & 1)  and the fragment
+//     columns permuted (columns {0-3, 12-15} = pixels 0-7, columns 4-11 = pixels 8-15; see conv3x3_c32pp_kernel) every ds_read_b128 of every tap is
+//     conflict-free (enumerated for the three trunk geometries; W + 2 leaves 1.4-1.9x the conflict-free cycles);
 //   * same k order (channel-major, taps ascending), same six products smallest first, same accumulators as the q kernel => BIT-IDENTICAL output
-//     (tests/test_gpu_planes.py asserts torch.equal against the q kernel on every trunk geometry, forward and data gradient).
+//     (tests/test_gpu_np3.py asserts torch.equal against the q kernel on every trunk geometry, forward and data gradient).
 struct RGeo {
-    int gpi;                  // group tiles per image
-    int ntiles;               // group tiles in all (images x gpi)
-    int PW, patch_px;         // patch row length (W + 8), patch pixels reserved per piece (multiple of 16)
-    int nchunks;              // 16-pixel DMA chunks of a patch (patch_px / 16)
+    int gpi;                  // tiles per image
+    int ntiles;               // tiles in all (images x gpi)
+    int PW, patch_px;         // patch row length (W + 8), patch pixels reserved per piece (272 or 320: the kernel's PPX)
+    int nchunks;              // 16-pixel DMA chunks of a patch actually used
     unsigned mgW, mgPW, mg_gpi;
     int toff64[9];            // byte offset of each tap's source pixel inside the patch (host-filled ints: scalar loads -- a byte table indexed at run
-                              // time became global_load_ubyte + s_waitcnt vmcnt(0) at the head of every LOAD phase, i.e. a wait for the weight loads)
+                              // time became global_load_ubyte + s_waitcnt vmcnt(0) at the head of every k tile, i.e. a wait for the weight loads)
 };
-template <int MT, int BN, int PPX>
-__global__ __launch_bounds__(512) void pconv_r_kernel(PConvP p, RGeo g) {
+template <int MT, int BN, int PPX, int WPS>
+__global__ __launch_bounds__(256, WPS) void pconv_r_kernel(PConvP p, RGeo g) {
     constexpr int NP = 3;
     constexpr int GM = 16 * MT;
     constexpr int NI = BN / 64;
-    constexpr int PLANE_A = PPX * 64, A_GRP = NP * PLANE_A;      // bytes; multiples of 512 (the fragment address trick below relies on it)
+    constexpr int PLANE_A = PPX * 64;                            // bytes; a multiple of 512 (the fragment address trick below relies on it)
     static_assert(PLANE_A % 512 == 0 && 2 * PLANE_A < 65536, "piece offsets are ds_read immediates");
     constexpr int NCW = (PPX / 16 + 3) / 4;                      // DMA chunks of the patch a wave issues at most
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -1015,17 +1018,13 @@ __global__ __launch_bounds__(512) void pconv_r_kernel(PConvP p, RGeo g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, w4 = wave & 3;
+    const int w4 = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by;
     ptile_of_block(bx, by);
     const PClass& pc = p.cls[0];
     const int n0 = by * BN;
     const int W = p.GW, H = p.GH, HW = H * W, PW = g.PW;
-    // this group's tile (clamped past the end: the group still takes part in every barrier, its stores are skipped)
-    int gt = 2 * bx + grp;
-    const bool live = gt < g.ntiles;
-    if (!live) gt = g.ntiles - 1;
+    const int gt = bx;                                            // tile index: (image, tile of the image)
     const int img = fast_div(gt, g.gpi, g.mg_gpi);
     const int tp0 = (gt - img * g.gpi) * GM;                      // first pixel of the tile inside its image
     const int tend = tp0 + GM < HW ? tp0 + GM : HW;
@@ -1048,7 +1047,6 @@ __global__ __launch_bounds__(512) void pconv_r_kernel(PConvP p, RGeo g) {
             if (y >= 0 && y < H && x >= 0 && x < W) poff[i] = (unsigned)(((((long)img * H + y) * W + x) * p.GC + slot * 8) * 2);
         }
     }
-    unsigned char* const a_lds = smem + grp * A_GRP;
     auto stage_patch = [&](int cc) {
         const unsigned coff = (unsigned)(cc << 6);               // 32 channels = 64 bytes
 #pragma unroll
@@ -1059,7 +1057,7 @@ __global__ __launch_bounds__(512) void pconv_r_kernel(PConvP p, RGeo g) {
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)(p.a.p + q * p.a.ps), 0, p.a_bytes, 0x00020000),
-                                                             (lds_ptr_t)(a_lds + q * PLANE_A + c * 1024), 16, (int)vo, 0, 0, 0);
+                                                             (lds_ptr_t)(smem + q * PLANE_A + c * 1024), 16, (int)vo, 0, 0, 0);
             }
         }
     };
@@ -1072,27 +1070,22 @@ __global__ __launch_bounds__(512) void pconv_r_kernel(PConvP p, RGeo g) {
 
     const int l15 = lane & 15, kp = lane >> 4;
     const int pxo = l15 < 4 ? l15 : (l15 < 12 ? l15 + 4 : l15 - 8);          // fragment column -> pixel of its 16-pixel row tile (bank pattern, see above)
-    // ---- B: the weight fragments go global -> registers DIRECTLY (round 5, second form).  Through LDS they cost group 0 three to six LDS-DMA
-    //      instructions per k tile in its LOAD phase -- ~220 cycles EACH in that phase (tools/r_kernel_ablate.py: the phase grew from 1 000 to 2 300
-    //      cycles and bounded the kernel at C = 128) -- plus a two-stage LDS ring and the fragment reads.  A lane's fragment of column n, k chunk kp is
-    //      16 contiguous bytes of row n of the [N][K] weight planes: one buffer_load_dwordx4 per (piece, column tile) with a per-lane constant offset
-    //      and the k tile's (tap, slice) offset in an SGPR; the loads are issued at the head of the LOAD phase and land under its fragment reads.
     unsigned boff[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + w4 * (BN / 4) + j * 16 + l15;
         boff[j] = n < p.N ? (unsigned)(((long)n * p.K + kp * 8) * 2) : OOB;
     }
-    // byte address (in LDS, relative to 0) of this lane's 16 bytes of its pixel of row tile i at tap offset 0, BEFORE the slot swizzle:
-    //   v = a_lds + pp * 64 + kp * 16;   the swizzled address is  v ^ ((v >> 3) & 32)  -- bit 8 of v is bit 2 of the patch pixel pp (a_lds and the
-    //   piece planes are multiples of 512 bytes), bit 5 is the high bit of the slot: slot ^ 2 ((pp >> 2) & 1) without recomputing pp
+    // byte offset (from smem) of this lane's 16 bytes of its pixel of row tile i at tap offset 0, BEFORE the slot swizzle:  v = pp * 64 + kp * 16;
+    // the swizzled offset is  v ^ ((v >> 3) & 32)  -- bit 8 of v is bit 2 of the patch pixel pp (the piece planes are multiples of 512 bytes), bit 5
+    // is the high bit of the slot: slot ^ 2 ((pp >> 2) & 1) without recomputing pp
     int vb[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         int pix = tp0 + i * 16 + pxo;
         if (pix >= tend) pix = tend - 1;                          // clamp: inside the patch, result discarded
         const int oy = fast_div(pix, W, g.mgW), ox = pix - oy * W;
-        vb[i] = grp * A_GRP + ((oy - r0) * PW + ox) * 64 + kp * 16;
+        vb[i] = ((oy - r0) * PW + ox) * 64 + kp * 16;
     }
     bf16x8_t af[NP][MT], bfb[2][NP][NI];                        // the weight fragments of TWO k tiles: the next one's are in flight a whole k tile ahead
 
@@ -1110,13 +1103,14 @@ __global__ __launch_bounds__(512) void pconv_r_kernel(PConvP p, RGeo g) {
     };
     auto load_frags = [&](int ti) {
         const int toff64 = g.toff64[ti];
+        constexpr int QO[3] = {2, 0, 1};                         // in the order the products need them: piece 2 (first product), then 0, then 1
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int v = vb[i] + toff64;
-            const unsigned char* ab = smem + (v ^ ((v >> 3) & 32));
+        for (int qi = 0; qi < NP; ++qi)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) af[q][i] = *reinterpret_cast<const bf16x8_t*>(ab + q * PLANE_A);
-        }
+            for (int i = 0; i < MT; ++i) {
+                const int v = vb[i] + toff64;
+                af[QO[qi]][i] = *reinterpret_cast<const bf16x8_t*>(smem + (v ^ ((v >> 3) & 32)) + QO[qi] * PLANE_A);
+            }
     };
     auto compute = [&](auto SET) {
         constexpr int sb = decltype(SET)::value;
@@ -1139,45 +1133,48 @@ __global__ __launch_bounds__(512) void pconv_r_kernel(PConvP p, RGeo g) {
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfb[sb][QB[t]][j], af[QA[t]][i], acc[i][j], 0, 0, 0);
     };
-    auto end_load = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
-    auto end_compute = [&]() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); };
 
     if (p.dbg & 32) return;                                      // ablation bit 5: launch cost only
     const int nk = (p.dbg & 4) ? 0 : pc.ntaps * nkc;             // ablation bit 2: no k loop (launch + prologue + epilogue remain)
     const bool dma = !(p.dbg & 1);                               // ablation bit 0: no DMA / weight loads after the prologue's
+    // The waves that share a SIMD belong to different workgroups running the same code: left alone they fall into step (two waves that both want the
+    // matrix pipe interleave their MFMAs, finish their k tile together and then read fragments together: the pipe idles while both read).  A STATIC
+    // priority by hardware wave slot breaks the tie: the odd slot's MFMAs go first, it reaches its read phase while the even slot computes.
+    if (!(p.dbg & 64) && (__builtin_amdgcn_s_getreg(0x1804) & 1)) __builtin_amdgcn_s_setprio(2);          // HW_REG_HW_ID[3:0] = wave slot of the SIMD
     stage_patch(0);
     load_b(std::integral_constant<int, 0>{}, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (grp == 1) asm volatile("s_barrier" ::: "memory");        // half a period behind group 0
     int ti = 0, cc = 0;
     auto step = [&](auto CUR, int k) {
         constexpr int cur = decltype(CUR)::value;
-        // LOAD phase: the NEXT k tile's weight fragments first -- a whole k tile (LOAD + COMPUTE + LOAD) ahead of their first use: an L2 round trip
-        // under load is longer than one LOAD phase (the first form of this loader fetched the CURRENT tile's fragments here and waited for them)
         int tn = ti + 1, cn = cc;
         if (tn == pc.ntaps) { tn = 0; ++cn; }
-        if (k + 1 < nk && dma) load_b(std::integral_constant<int, 1 - cur>{}, tn, cn);
+        if (k + 1 < nk && dma) load_b(std::integral_constant<int, 1 - cur>{}, tn, cn);   // the NEXT k tile's weight fragments: a whole k tile ahead of their use
         __builtin_amdgcn_sched_barrier(0);
         load_frags(ti);
-        __builtin_amdgcn_sched_barrier(0);
-        end_load();
-        const bool last_tap = ti + 1 == pc.ntaps;
-        if (last_tap && cc + 1 < nkc && dma) stage_patch(cc + 1);                       // COMPUTE phase: the patch is dead (its last reads ended with this LOAD)
-        __builtin_amdgcn_sched_barrier(0);
+        const bool swap = tn == 0 && cn < nkc && k + 1 < nk;      // last tap of a slice: the patch is replaced behind its reads
+        if (swap) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // every wave's reads of this slice are complete
+            __builtin_amdgcn_sched_barrier(0);
+            if (dma) stage_patch(cn);                                                   // flies under this tap's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+        }
         compute(CUR);
-        __builtin_amdgcn_sched_barrier(0);
-        end_compute();
+        if (swap) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");              // the new slice has landed (all waves' chunks)
+            __builtin_amdgcn_sched_barrier(0);
+        }
         ti = tn; cc = cn;
     };
     for (int k = 0; k < nk; k += 2) {
         step(std::integral_constant<int, 0>{}, k);
         if (k + 1 < nk) step(std::integral_constant<int, 1>{}, k + 1);
     }
-    if (grp == 0) asm volatile("s_barrier" ::: "memory");
 
     // ---- epilogue: D = W X^T, a lane holds four consecutive output channels of one pixel -> one 16-byte store per 16x16 tile (as the q kernel) ----
-    if (!live || (p.dbg & 8)) return;                            // ablation bit 3: no output stores
+    if (p.dbg & 8) return;                                       // ablation bit 3: no output stores
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int pix = tp0 + i * 16 + pxo;
@@ -1598,22 +1595,22 @@ static void set_plane_bytes(PConvP& p, long a_elems, long b_elems) {
     p.b_bytes = (b_elems > 0 && b_elems < lim) ? (int)(b_elems * 2) : 0;
 }
 static int g_r_kernel = 1;   // patch-resident kernel for the 3x3 / stride-1 trunk convolutions (ha2g_conv_planes_tile3(8) = off: the q kernel, A/B)
-template <int MT, int BN, int PPX>
+template <int MT, int BN, int PPX, int WPS>
 static int pconv_r_launch(const PConvP& p, const RGeo& g, dim3 grid, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * 3 * PPX * 64;
+    constexpr size_t lds = (size_t)3 * PPX * 64;
     static bool attr_set[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_r_kernel<MT, BN, PPX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(pconv_r_kernel<MT, BN, PPX, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ha2g_set_error(-2, "pconv_r: cannot raise the dynamic LDS limit");
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((pconv_r_kernel<MT, BN, PPX>), grid, dim3(512), lds, st, p, g);
+    hipLaunchKernelGGL((pconv_r_kernel<MT, BN, PPX, WPS>), grid, dim3(256), lds, st, p, g);
     return 0;
 }
 // -100: geometry not served (the caller keeps the q kernel): 3x3 / stride 1 / pad 1 with one class of nine taps, N a multiple of 64 with aligned
-// vector stores, no bias / activation epilogue (the convolution callers pass relu only), the two patches inside the reserved LDS planes
+// vector stores, no bias / activation epilogue (the convolution callers pass relu only), the patch inside one of the two reserved plane sizes
 static int pconv_r_dispatch(const PConvP& p_in, int imgs, hipStream_t st) {
     PConvP p = p_in;
     const PClass& c0 = p.cls[0];
@@ -1625,8 +1622,8 @@ static int pconv_r_dispatch(const PConvP& p_in, int imgs, hipStream_t st) {
     if (W < 2 || HW < 16) return -100;
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) { int c = 0; if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) cus = c; }
-    // tile choice: rows per group 16 MT (MT = 7 or 9) x BN columns -- the combination that keeps the CUs fullest (as pconv_q_plan), among those whose
-    // patch fits one of the two reserved plane sizes (272 / 320 patch pixels)
+    // tile choice: 16 MT pixels (MT = 7 or 9) x BN columns per workgroup -- the combination that keeps the CUs fullest, among those whose patch fits one
+    // of the two reserved plane sizes (272 / 320 patch pixels); resident workgroups per CU by LDS (160 KB) and registers (MT = 7, BN = 64: three waves per SIMD)
     double best = -1.0; int bmt = 0, bbn = 0; RGeo bg{};
     for (int bn = 128; bn >= 64; bn -= 64) {
         if (p.N % bn != 0) continue;
@@ -1644,8 +1641,9 @@ static int pconv_r_dispatch(const PConvP& p_in, int imgs, hipStream_t st) {
             if (need > 320) continue;
             g.patch_px = need <= 272 ? 272 : 320;
             g.nchunks = (need + 15) / 16;
-            const long wgs = (long)((g.ntiles + 1) / 2) * (p.N / bn), rounds = (wgs + cus - 1) / cus;
-            double eff = (double)wgs / (double)(rounds * cus) * ((double)HW / (double)(gpi * gm));
+            const int per_cu = (mt == 7 && bn == 64 && g.patch_px == 272) ? 3 : 2;
+            const long wgs = (long)g.ntiles * (p.N / bn), slots = (long)cus * per_cu, rounds = (wgs + slots - 1) / slots;
+            double eff = (double)wgs / (double)(rounds * slots) * ((double)HW / (double)(gpi * gm));
             eff *= (bn == 128 ? 1.0 : 0.93) * (mt == 9 ? 1.0 : 0.97);
             if (eff > best + 1e-9) { best = eff; bmt = mt; bbn = bn; bg = g; }
         }
@@ -1658,14 +1656,14 @@ static int pconv_r_dispatch(const PConvP& p_in, int imgs, hipStream_t st) {
         const int kh = c0.tap[t] / 3, kw = c0.tap[t] % 3;
         bg.toff64[t] = (p.fwd ? kh * bg.PW + kw : (2 - kh) * bg.PW + (2 - kw)) * 64;
     }
-    const dim3 grid((unsigned)((bg.ntiles + 1) / 2), (unsigned)(p.N / bbn), 1);
+    const dim3 grid((unsigned)bg.ntiles, (unsigned)(p.N / bbn), 1);
     const bool big = bg.patch_px == 320;
     if (bbn == 128) {
-        if (bmt == 9) return big ? pconv_r_launch<9, 128, 320>(p, bg, grid, st) : pconv_r_launch<9, 128, 272>(p, bg, grid, st);
-        return big ? pconv_r_launch<7, 128, 320>(p, bg, grid, st) : pconv_r_launch<7, 128, 272>(p, bg, grid, st);
+        if (bmt == 9) return big ? pconv_r_launch<9, 128, 320, 2>(p, bg, grid, st) : pconv_r_launch<9, 128, 272, 2>(p, bg, grid, st);
+        return big ? pconv_r_launch<7, 128, 320, 2>(p, bg, grid, st) : pconv_r_launch<7, 128, 272, 2>(p, bg, grid, st);
     }
-    if (bmt == 9) return big ? pconv_r_launch<9, 64, 320>(p, bg, grid, st) : pconv_r_launch<9, 64, 272>(p, bg, grid, st);
-    return big ? pconv_r_launch<7, 64, 320>(p, bg, grid, st) : pconv_r_launch<7, 64, 272>(p, bg, grid, st);
+    if (bmt == 9) return big ? pconv_r_launch<9, 64, 320, 2>(p, bg, grid, st) : pconv_r_launch<9, 64, 272, 2>(p, bg, grid, st);
+    return big ? pconv_r_launch<7, 64, 320, 2>(p, bg, grid, st) : pconv_r_launch<7, 64, 272, 3>(p, bg, grid, st);
 }
 
 template <int NP>

@@ -8,10 +8,12 @@ is LINEARISED AT THE ACTIVATION PATTERN THE HIP FORWARD ACTUALLY TOOK (oracle.ha
 exported from the HIP forward's saved activations, ha2g_amd/wav_engine.relu_pattern_of).  With the pattern fixed the network is a smooth
 function of its inputs, so the HIP gradients must equal the oracle's to fp32 accuracy.  Bound, every element of every tensor:
 
-    |g_hip - g_oracle64| <= 1e-4 * scale(tensor)          scale = max|g_oracle64| over the tensor
+    |g_hip - g_oracle64| <= 1e-4 * max|g_oracle64| + 3 * max|g_oracle32 - g_oracle64|
 
-with no noise / conditioning term at all.  (A tensor whose gradient is itself the residue of a cancellation to < 1e-3 of its summands -- SE-gate
-biases, BatchNorm betas in front of a BatchNorm'ed convolution -- is judged on the scale of those summands, stated where it applies.)
+where g_oracle32 is the SAME linearised oracle evaluated in float32 (torch CPU kernels -- the reference's arithmetic on the same smooth function):
+the only floor left is what fp32 arithmetic itself does to a tensor, which matters for a handful of cancellation residues (BatchNorm betas in front of
+a BatchNorm'ed convolution: a column sum over ~1e6 pixels whose terms cancel to 1e-3 of their size; SE-gate biases).  The tests print, per tensor, the
+share of the tolerance that floor contributes and assert that its MEDIAN is below 10 %: 1e-4 is the operative bound on the ordinary tensors.
 Reference: model/ResNetSE34V2.py:118-218, model/ResNetBlocks.py:21-37,81-95.
 """
 import numpy as np
@@ -36,21 +38,27 @@ def gemm_mode():
     lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
 
 
-def _cmp(report, key, got, ref, scale=None):
+def _cmp(report, key, got, ref, ref32=None):
+    """appends (error / tolerance, key, error / scale, share of the tolerance that is the float32 oracle's own deviation)"""
     got = got.detach().double().cpu().reshape(ref.shape)
-    s = float(ref.abs().max()) if scale is None else scale
+    s = max(float(ref.abs().max()), 1e-300)
     err = float((got - ref).abs().max())
-    report.append((err / max(s, 1e-300), key, err, s))
+    floor = 3.0 * float((ref32.double().reshape(ref.shape) - ref).abs().max()) if ref32 is not None else 0.0
+    tol = RTOL * s + floor
+    report.append((err / tol, key, err / s, floor / tol))
 
 
 def _summarise(report, what):
     report.sort(reverse=True)
-    worst = report[0]
-    med = float(np.median([r[0] for r in report]))
-    print('%s: %d tensors, worst %.2e of scale (%s), median %.2e; top 5: %s' % (
-        what, len(report), worst[0], worst[1], med, ', '.join('%s %.1e' % (r[1], r[0]) for r in report[:5])))
-    bad = [r for r in report if r[0] > RTOL]
-    assert not bad, '%s: %d tensors above %.0e of their scale: %s' % (what, len(bad), RTOL, bad[:8])
+    rel = sorted((r[2] for r in report), reverse=True)
+    shares = [r[3] for r in report]
+    print('%s: %d tensors; error / scale: worst %.2e, median %.2e, above 1e-4: %d; worst error / tolerance %.2f (%s); float32-oracle floor: median share of '
+          'the tolerance %.1f %%, tensors where it exceeds half: %d; top 5 by error / tolerance: %s' % (
+              what, len(report), rel[0], float(np.median(rel)), sum(x > RTOL for x in rel), report[0][0], report[0][1], 100 * float(np.median(shares)),
+              sum(x > 0.5 for x in shares), ', '.join('%s %.2f (%.1e)' % (r[1], r[0], r[2]) for r in report[:5])))
+    bad = [r for r in report if r[0] > 1.0]
+    assert not bad, '%s: %d tensors above their tolerance: %s' % (what, len(bad), bad[:8])
+    assert float(np.median(shares)) < 0.10, ('the float32 floor is more than a tenth of the median tolerance', float(np.median(shares)))
 
 
 @pytest.mark.parametrize('mode', [70, 0])
@@ -78,44 +86,44 @@ def test_full_size_block_backward_vs_oracle_linearised_at_the_hip_relu_pattern(g
     dx = we.block_bwd(nhwc(wl.to(DEV)), saved, P, '', sink)
     sink.join(torch.device(DEV))
     we._NBT_PENDING.clear()
-    # ---- the oracle in float64, linearised at that pattern ----
-    sd = block_state(name, geom, seed, torch.float64)
-    x64, wl64 = block_io(name, geom, B, seed, torch.float64)
-    x64.requires_grad_(True)
-    ps = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not k.endswith(('running_mean', 'running_var'))}
-    with O.relu_pattern(masks=masks):
-        y = O.se_block(x64, sd, '', 2 if geom[4] else 1, geom[4])
-    grads = dict(zip(['x'] + list(ps), torch.autograd.grad((y * wl64).sum(), [x64] + list(ps.values()))))
+    # ---- the oracle linearised at that pattern: float64 (truth) and float32 (the floor of fp32 arithmetic on the same function) ----
+    def oracle(dt):
+        sd = block_state(name, geom, seed, dt)
+        xo, wlo = block_io(name, geom, B, seed, dt)
+        xo.requires_grad_(True)
+        ps = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and not k.endswith(('running_mean', 'running_var'))}
+        with O.relu_pattern(masks=masks):
+            y = O.se_block(xo, sd, '', 2 if geom[4] else 1, geom[4])
+        gr = dict(zip(['x'] + list(ps), torch.autograd.grad((y * wlo).sum(), [xo] + list(ps.values()))))
+        return y.detach(), gr
+    y, grads = oracle(torch.float64)
+    y32, grads32 = oracle(torch.float32)
     rep = []
-    _cmp(rep, 'out', nchw(out), y.detach())
-    _cmp(rep, 'grad_x', nchw(dx), grads['x'])
-    # the SE gate's parameters and bn2.bias see  sum_hw dout * bn2(x)  per (image, channel): residues of sums whose terms are ~1e2..1e3 x larger;
-    # their honest scale is the largest gradient of the block's ordinary parameters (what the fixtures' Checker calls the module's magnitude)
-    ordinary = max(float(grads[k].abs().max()) for k in ps if k.startswith(('conv', 'bn1', 'downsample')))
+    _cmp(rep, 'out', nchw(out), y, y32)
+    _cmp(rep, 'grad_x', nchw(dx), grads['x'], grads32['x'])
     n = 0
     for k, gr in sink.G.items():
         for sub, g1 in ((('.weight', gr[0]), ('.bias', gr[1])) if isinstance(gr, tuple) else (('', gr),)):
-            ref = grads[k + sub]
-            _cmp(rep, 'grad/' + k + sub, g1, ref, scale=max(float(ref.abs().max()), 1e-3 * ordinary) if k.startswith(('se.', 'bn2')) else None)
+            _cmp(rep, 'grad/' + k + sub, g1, grads[k + sub], grads32[k + sub])
             n += 1
-    assert n == len(ps)
+    assert n == len(grads) - 1
     _summarise(rep, 'block %s mode %d' % (name, mode))
 
 
-def _encoder_oracle(case, masks, perturb=0.0):
+def _encoder_oracle(case, masks, dt=torch.float64):
     sch = schema.wav_encoder_schema(case['n_spk'], 3, 'audio.')
-    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in schema.procedural_state(sch, case['seed']).items()}
+    sd = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in schema.procedural_state(sch, case['seed']).items()}
     _, spec, _, vid = proc.make_batch(case['B'], 27, case.get('n_words', 40), case['n_spk'], case['seed'])
     names = [k for k in sd if sd[k].is_floating_point() and not k.endswith(('running_mean', 'running_var'))]
     for k in names:
         sd[k].requires_grad_(True)
-    spec_t = torch.from_numpy(spec).double()
+    spec_t = torch.from_numpy(spec).to(dt)
     with O.relu_pattern(masks=masks):
         w, lo, mid, hi, blend = O.wav_encoder(spec_t, torch.from_numpy(vid), sd, 'audio.', 3)
     s = case['seed']
 
     def wp(name, t):
-        return torch.from_numpy(proc.tensor_for('w.' + name, (2,) + tuple(t.shape), s)[0] * t[0].numel() ** 0.5).double()
+        return torch.from_numpy(proc.tensor_for('w.' + name, (2,) + tuple(t.shape), s)[0] * t[0].numel() ** 0.5).to(dt)
     loss = sum((bl * wp('blend%d' % i, bl)).sum() for i, bl in enumerate(blend)) + (hi * wp('hi', hi)).sum() + (lo * wp('lo', lo)).sum()
     grads = dict(zip(names, torch.autograd.grad(loss, [sd[k] for k in names])))
     outs = dict(weight=w.detach(), low=lo.detach(), mid=mid.detach(), high=hi.detach())
@@ -151,20 +159,12 @@ def _tower_vs_linearised_oracle(case, mode, what):
     del aud, w, lo, mid, hi, blend, loss
     torch.cuda.empty_cache()
     outs, grads = _encoder_oracle(case, masks)
-    rep, raw = [], []
+    outs32, grads32 = _encoder_oracle(case, masks, torch.float32)
+    rep = []
     for k, t in hip_out.items():
-        _cmp(rep, 'out/' + k, t, outs[k])
-    # cancellation residues (see the block test): SE-gate parameters, bn2.bias and the BatchNorm betas / conv biases in front of another BatchNorm are
-    # judged on 1e-3 of the largest ordinary (convolution weight) gradient of the tower; the error on the tensor's OWN scale is printed beside it
-    ordinary = max(float(g.abs().max()) for k, g in grads.items() if k.endswith(('conv1.weight', 'conv2.weight', 'downsample.0.weight')))
+        _cmp(rep, 'out/' + k, t, outs[k], outs32[k])
     for k, g1 in hip_grad.items():
-        ref = grads['audio.' + k]
-        resid = ('.se.' in k) or k.endswith(('bn2.bias', 'bn1.bias', 'downsample.1.bias', 'conv_low.bias', 'conv_mid.bias', 'conv_high.bias', 'conv1.bias'))
-        _cmp(rep, k, g1, ref, scale=max(float(ref.abs().max()), 1e-3 * ordinary) if resid else None)
-        _cmp(raw, k, g1, ref)
-    raw.sort(reverse=True)
-    print('%s: on every tensor\'s OWN scale (no residue rule): worst %.2e (%s), %d of %d above 1e-4: %s' % (
-        what, raw[0][0], raw[0][1], sum(r[0] > RTOL for r in raw), len(raw), ', '.join('%s %.1e' % (r[1], r[0]) for r in raw if r[0] > RTOL)[:600]))
+        _cmp(rep, k, g1, grads['audio.' + k], grads32['audio.' + k])
     _summarise(rep, what)
 
 
@@ -179,8 +179,8 @@ def test_whole_tower_backward_b16_vs_oracle_linearised_at_the_hip_relu_pattern(g
 def test_whole_tower_backward_headline_size_vs_oracle_linearised_at_the_hip_relu_pattern(gemm_mode):
     """The same at the HEADLINE size -- B = 128, spec (128, 70), 1 371 speakers, the parameters of the cfg2_b128 fixtures -- in the default arithmetic
     (mode 70): where the whole-step fixtures can only hold the tower's gradients to the reference's own percent-level fp32 scatter
-    (tests/golden/tolerance_profile.json: audio median 2.3e-2), this holds every element of every one of them to 1e-4.  The float64 oracle
-    (forward + backward of the tower at B = 128) takes 1-2 minutes and ~30 GB on the host."""
+    (tests/golden/tolerance_profile.json: audio median 2.3e-2), this holds every element of every one of them to 1e-4.  The two oracle
+    runs (float64 and float32, forward + backward of the tower at B = 128) take 1-2 minutes and ~30 GB on the host."""
     from ha2g_amd.config import BIG_CASES
     gemm_mode(70)
     _tower_vs_linearised_oracle(dict(BIG_CASES['cfg2_b128']), 70, 'tower B=128 mode 70')

@@ -10,6 +10,6 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_I
   rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmcq$i -o p -- python3 tools/q_kernel_run.py > /tmp/pmcq$i.log 2>&1
   db=$(find /tmp/pmcq$i -name "*.db" | head -1)
   echo "== $grp" >> $out
-  python tools/rocpd_pmc.py $db pconv_q >> $out 2>&1
+  python tools/rocpd_pmc.py $db ${KERNEL:-pconv_q} >> $out 2>&1
 done
 cut -c1-150 $out

@@ -23,7 +23,7 @@ def t_us(fn, iters=30):
     return s.elapsed_time(e) / iters * 1e3
 
 
-print('%-26s %8s %8s %8s %8s %9s %12s %9s %8s' % ('shape / kernel', 'full', 'no DMA', 'no MFMA', 'neither', 'no k loop', 'no k, no st', 'no stores', 'empty'))
+print('%-26s %8s %8s %8s %8s %9s %12s %9s %8s' % ('shape / kernel', 'full', 'no DMA', 'no MFMA', 'neither', 'no k loop', 'no k, no st', 'no stores', 'empty') + '  no setprio     full')
 for H, W, C in ((64, 35, 64), (32, 18, 128), (16, 9, 256)):
     dy = torch.randn(B, H, W, C, device=dev)
     w = torch.randn(C, 3, 3, C, device=dev) * 0.05
@@ -35,7 +35,7 @@ for H, W, C in ((64, 35, 64), (32, 18, 128), (16, 9, 256)):
     for name, sw in (('q', 8), ('r', 0)):
         lib.ha2g_conv_planes_tile3(sw)
         ts = []
-        for bits in (0, 1, 2, 3, 4, 12, 8, 32):
+        for bits in (0, 1, 2, 3, 4, 12, 8, 32, 64, 0):
             lib.ha2g_conv_planes_debug(bits)
             ts.append(t_us(fn))
         lib.ha2g_conv_planes_debug(0)
