@@ -122,7 +122,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--bf16', action='store_true', help='BASELINE config 5 style: every vectorisable GEMM / convolution with plain bf16 operands (fp32 accumulate, fp32 storage / master weights); reported with dtype "bf16", never the default')
     ap.add_argument('--fp32-storage', action='store_true', help='with --bf16: keep the audio trunk\'s activations / activation gradients in fp32 (bf16 operands only, the round-2 form of the mode) -- the "before" leg of the storage A/B')
-    ap.add_argument('--launch', choices=('auto', 'graph', 'eager'), default='auto', help='what `value` times: hipGraph replays of the captured step (auto: when N = 1) or eager launches (auto: when N > 1); the eager number is always reported next to it')
+    ap.add_argument('--launch', choices=('auto', 'graph', 'eager'), default='auto', help='what `value` times.  auto = eager: EAGER launches are the documented default launch form of the step (the form every N uses; the hipGraph replay of the same step is timed beside it at N = 1 and printed as `graph_replay`, never folded into `value`); graph: `value` = hipGraph replays')
+    ap.add_argument('--n-poses', type=int, default=34, help='frames per window.  34 = the reference (parity).  62 = the legal neighbour of BASELINE config 5\'s T = 64 (SURVEY M5: the three audio taps agree only for T = 2 mod 4; T = 64 cannot exist with the reference modules): spectrogram width 126, discriminator out2 = Linear(56, 1) -- a PERFORMANCE-ONLY leg, no reference twin')
+    ap.add_argument('--max-cluster-retries', type=int, default=1, help='fail (exit 3, no JSON line) when more cluster-GRU recoveries than this happened during the run: each one costs a whole step and switches the process to the slower single-workgroup recurrences, so a line above the bound does not measure the default path')
     ap.add_argument('--graph', action='store_true', help='same as --launch graph')
     ap.add_argument('--no-roofline', action='store_true', help='with --primary-only: skip the per-launch HIP-event pass as well (profiling runs)')
     ap.add_argument('--sparse-embeddings', action='store_true', help='compact row gradients + lazy row-wise Adam for the word-embedding tables (bit-identical to the dense default; -45 %% gradient-exchange bytes under data parallelism, +0.4 ms of small kernels on one GPU)')
@@ -179,14 +181,17 @@ def main():
     b16_storage = bool(a.bf16 and not a.fp32_storage) or os.environ.get('HA2G_B16') == '1'
     _we.set_b16(b16_storage)                                  # BASELINE config 5: bf16 activation / activation-gradient storage in the audio trunk
     P = 126 if a.expressive else 27
-    args = hierarchy_args(expressive=a.expressive)            # config[_expressive]/hierarchy.yml, dropout 0.3
+    T = a.n_poses
+    assert T % 4 == 2, '--n-poses must be 2 mod 4 (the three audio taps yield W/2-1, 2*ceil(W/4)-2, 4*ceil(W/8)-2 frames: equal only then; SURVEY M5)'
+    spec_w = 2 * (T + 1)                                      # 34 -> 70, 62 -> 126
+    args = hierarchy_args(expressive=a.expressive, n_poses=T) # config[_expressive]/hierarchy.yml, dropout 0.3
     tr = HierarchyTrainer(args, Vocab(a.n_words), Vocab(a.n_spk), P, dev,
                           pose_dims=schema.EXPRESSIVE_POSE_DIMS if a.expressive else schema.GESTURE_POSE_DIMS,
                           sparse_embeddings=True if a.sparse_embeddings else (False if a.dense_embeddings else None))
     if world > 1:
         tr.broadcast_parameters(0)
     ops.rng.seed(dev, 1234 + rank)
-    text, spec, target, vid = (torch.from_numpy(x).to(dev) for x in proc.make_batch(a.batch, P, a.n_words, a.n_spk, 1234 + rank))
+    text, spec, target, vid = (torch.from_numpy(x).to(dev) for x in proc.make_batch(a.batch, P, a.n_words, a.n_spk, 1234 + rank, T=T, W=spec_w))
 
     def sync():
         if world > 1:
@@ -287,7 +292,7 @@ def main():
     # ---- headline: GPU-bound number = hipGraph replays of the captured step (N = 1); eager launches are timed next to it.  With more than one
     # rank the timed path is the eager one (RCCL collectives inside a capture have never run on this pool: an exception could be caught, a hang not).
     use_graph = a.launch == 'graph' or (a.launch == 'auto' and world == 1)
-    launch, graph_note = 'eager', (None if world == 1 else 'N > 1 ranks are timed with eager launches (RCCL collectives are not captured); the like-for-like single-GPU number is the N = 1 line\'s eager.ms_per_step')
+    launch, graph_note = 'eager', None
     dt = dt_graph = None
     if use_graph:
         try:
@@ -299,18 +304,21 @@ def main():
         for _ in range(2):                           # the eager leg is timed (at B = 256 the first eager steps after a capture otherwise pay hipMalloc: 132 vs 74 ms)
             tr.train_iter(a.epoch, text, spec, target, vid)
     clock = dict(busy=0.0, steps=0)
+    th.comm_clock = [] if world > 1 else None
     dt_eager, last_eager = timed_eager(a.epoch, a.steps, clock)
-    # Both launch forms run the same kernels on the same data for exactly `steps` steps between barriers + device syncs; `value` is the faster of the
-    # two legs and says which (`launch`), the other one is printed beside it (`graph_replay` / `eager`).  --launch graph | eager pins the choice.
-    if dt_graph is not None and (a.launch == 'graph' or dt_graph <= dt_eager):
+    comm_events, th.comm_clock = th.comm_clock, None
+    # Two labelled legs over the same kernels, the same data and exactly `steps` steps between barriers + device syncs: `eager` (the default launch form:
+    # what a training loop runs and what every N > 1 rank runs) and, at N = 1, `graph_replay` (the whole step captured into one hipGraph).  `value` is the
+    # DEFAULT form's number -- eager -- unless --launch graph asks for the replay; it is never the minimum of the two.
+    if dt_graph is not None and a.launch == 'graph':
         dt, last, launch = dt_graph, last_graph, 'hipGraph replay'
     else:
         dt, last = dt_eager, last_eager
     if dt_graph is not None and graph_note is None:
-        graph_note = ('value = the faster of two legs over the same %d steps of the same step function between barriers + device syncs: hipGraph replay %.3f ms/step, '
-                      'eager launches %.3f ms/step' % (a.steps, dt_graph / a.steps * 1e3, dt_eager / a.steps * 1e3))
-    graph_leg = None if dt_graph is None else dict(ms_per_step=round(dt_graph / a.steps * 1e3, 3), value=round(a.batch * 34 * world / (dt_graph / a.steps), 1))
-    eager = dict(ms_per_step=round(dt_eager / a.steps * 1e3, 3), value=round(a.batch * 34 * world / (dt_eager / a.steps), 1),
+        graph_note = ('value = the %s leg; both legs run the same %d steps of the same step function between barriers + device syncs: eager launches %.3f ms/step, '
+                      'hipGraph replay %.3f ms/step' % ('hipGraph replay' if a.launch == 'graph' else 'eager (default launch form)', a.steps, dt_eager / a.steps * 1e3, dt_graph / a.steps * 1e3))
+    graph_leg = None if dt_graph is None else dict(ms_per_step=round(dt_graph / a.steps * 1e3, 3), value=round(a.batch * T * world / (dt_graph / a.steps), 1))
+    eager = dict(ms_per_step=round(dt_eager / a.steps * 1e3, 3), value=round(a.batch * T * world / (dt_eager / a.steps), 1),
                  host_ms_per_step=round(clock['busy'] / max(clock['steps'], 1) * 1e3, 3),
                  note='host_ms_per_step = wall time inside train_iter minus the final wait for the loss read-back (python + autograd walk + launches)')
     # ---- roofline leg: a SEPARATE, untimed pass of eager steps with HIP events around the individual launches (on their launch stream)
@@ -345,16 +353,31 @@ def main():
                 tr.train_iter(a.epoch, text, spec, target, vid)
             ms_m6 = timed(a.epoch, a.steps)[0] / a.steps * 1e3
         _lib.ha2g_gemm_set_mode(default_mode)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64)
+    per_rank = None
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        def reduce_host(t, op):                          # a few doubles: staged through the host (works over RCCL and over the rehearsal's gloo alike)
+            if rehearsal:
+                dist.all_reduce(t, op=op)
+                return t
+            d_ = t.to(dev)
+            dist.all_reduce(d_, op=op)
+            return d_.cpu()
+        mine = torch.zeros(world, 3, dtype=torch.float64)    # per rank: ms/step of the timed leg, exposed gradient exchange ms/step, host ms/step
+        exposed = float(np.mean([s_.elapsed_time(e_) for s_, e_ in comm_events])) if comm_events else float('nan')
+        mine[rank] = torch.tensor([dt / a.steps * 1e3, exposed, clock['busy'] / max(clock['steps'], 1) * 1e3], dtype=torch.float64)
+        per_rank = reduce_host(mine, dist.ReduceOp.SUM).tolist()
+        tmax = reduce_host(tmax, dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms = dt / a.steps * 1e3
-    value = a.batch * 34 * world / (dt / a.steps)
+    value = a.batch * T * world / (dt / a.steps)
 
+    if tr.cluster_retries > a.max_cluster_retries:
+        sys.stderr.write('bench.py: %d cluster-GRU recoveries (> --max-cluster-retries %d): the run did not measure the default path -- no line printed\n' % (tr.cluster_retries, a.max_cluster_retries))
+        sys.exit(3)
     if rank == 0:
         # ---- roofline of the named kernel: bi-GRU layer forward (ha2g_gru_layer_fwd_cluster, H=300, layers 1..3: in = 600) and its BPTT twin ----
-        H, T = args.hidden_size, 34
+        H = args.hidden_size
         kt = ops.ktimer.summary()
         import hashlib
         src_sha = hashlib.sha256(open(os.path.join(ROOT, 'ha2g_amd', 'csrc', 'gru_cluster.hip'), 'rb').read()).hexdigest()
@@ -432,10 +455,10 @@ def main():
         if 'conv2d_fwd_planes' in kt:                   # forward convolutions of trunk layers 2-4: three-piece planes (always six MFMAs per product)
             n, mean_us, _, flops = kt['conv2d_fwd_planes']
             ach = flops / (n * mean_us * 1e-6) / 1e12
-            roof_conv = dict(kernel='pconv_q_kernel<MT,BN,3> (stride 2: pconv_kernel<..,3>) forward gather (ha2g_conv2d_fwd_planes_np_f32: forward convolutions of SE-ResNet34 layers 2-4 on producer-written three-piece planes)',
+            roof_conv = dict(kernel='pconv_r_kernel<MT,BN,PPX> (3x3 stride 1: patch-resident plane kernel; 1x1 / stride 2: pconv_q_kernel) forward gather (ha2g_conv2d_fwd_planes_np_f32: forward convolutions of SE-ResNet34 layers 2-4 on producer-written three-piece planes)',
                              bound='mfma', achieved=round(ach, 2), peak=round(2500.0 / 6, 1), unit='TFLOP/s (fp32-equivalent: 6 bf16 MFMAs per product)',
                              frac=round(ach / (2500.0 / 6), 4), frac_of_fp32_mfma_peak=round(ach / 157.3, 4), launches=n, mean_us=round(mean_us, 1), traffic=None)
-        roof_bwd_gemm = mfma3('conv_dgrad_planes', 'pconv_q_kernel<MT,BN,NP> / pconv_kernel (ha2g_conv2d_dgrad_planes_np_f32: 3x3 data gradients of trunk layers 2-4, DMA-staged bf16 piece planes)')
+        roof_bwd_gemm = mfma3('conv_dgrad_planes', 'pconv_r_kernel<MT,BN,PPX> (ha2g_conv2d_dgrad_planes_np_f32: 3x3 stride-1 data gradients of trunk layers 2-4, patch-resident three-piece planes)')
         roof_bwd_wgrad = mfma3('conv_wgrad_planes', 'pconv_wgrad_kernel + wide reduce (ha2g_conv2d_wgrad_planes_np_f32: 3x3 weight gradients of trunk layers 2-4)')
 
         def hbm(key, kernel):
@@ -461,7 +484,7 @@ def main():
             roof_conv = mfma1('conv2d_fwd_b16', 'pconv_kernel<.,.,.,.,1,1> forward gather (ha2g_conv2d_fwd_b16: trunk convolutions, bf16 in / bf16 out)')
             roof_bwd_gemm = mfma1('conv_dgrad_b16', 'pconv_kernel<.,.,.,.,1,1> (ha2g_conv2d_dgrad_b16: trunk data gradients, bf16 in / bf16 out)')
             roof_bwd_wgrad = mfma1('conv_wgrad_b16', 'pconv_wgrad_kernel<.,1> + wide reduce (ha2g_conv2d_wgrad_b16: 3x3 weight gradients of trunk layers 2-4, single planes)')
-        out = dict(metric='pose-frames/sec (train step) for hierarchy.yml B=128 T=34', value=round(value, 1), unit='pose-frames/s',
+        out = dict(metric='pose-frames/sec (train step) for hierarchy.yml B=128 T=34' if T == 34 else 'pose-frames/sec (train step), T=%d performance-only window' % T, value=round(value, 1), unit='pose-frames/s',
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling='weak',
                    vs_baseline=None,
                    dtype=(('bf16 (matrix operands; audio-trunk activations and activation gradients stored as bf16; fp32 accumulate, fp32 statistics, fp32 master weights and optimizer)'
@@ -471,18 +494,26 @@ def main():
                            0: 'f32 (every product on the fp32 MFMA)'}[bwd_pieces]),
                    data='synthetic', rehearsal=rehearsal, launch=launch, launch_note=graph_note, rccl_world=rccl_world, eager=eager, graph_replay=graph_leg,
                    cluster_retries=tr.cluster_retries,
+                   per_rank=(None if per_rank is None else dict(
+                       ms_per_step=[round(r[0], 3) for r in per_rank], ms_per_step_min=round(min(r[0] for r in per_rank), 3), ms_per_step_max=round(max(r[0] for r in per_rank), 3),
+                       exposed_comm_ms=[round(r[1], 3) for r in per_rank], exposed_comm_ms_max=round(max(r[1] for r in per_rank), 3),
+                       host_ms_per_step=[round(r[2], 3) for r in per_rank],
+                       note='exposed_comm_ms = HIP-event time from behind the last backward kernel (audio tower) to the first optimizer kernel: the gradient exchange NOT hidden '
+                            'under the backward (the audio bucket by design + what is left of the generators\' / text encoder\'s asynchronous buckets + the error-word MAX-reduce)')),
                    matrix_core=('bf16 operands (1 MFMA per product), fp32 accumulate, fp32 storage and master weights; GRU recurrences fp32' if a.bf16 else
                                 {3: '3-piece split-bf16 (x = p0+p1+p2 holds all 24 mantissa bits; six bf16 MFMAs per product, smallest first, fp32 accumulate: as accurate as the fp32 MFMA chain, tests/test_gpu_np3.py): forward + backward convolutions of trunk layers 1-4 (v_mfma_f32_16x16x32_bf16 / 32x32x16), dense products >= 4 GFLOP, every backward GEMM, GRU forward and BPTT chains; fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4): small forward GEMMs, tap convolutions, stem',
                                  2: 'forward: fp32 MFMA; backward GEMMs/convs/BPTT: 2-piece split-bf16 (hi+lo, 3 bf16 MFMAs per product; 4e-6 rms-rel per GEMM vs 4e-7 for fp32 MFMA)',
                                  0: 'fp32 MFMA everywhere'}[bwd_pieces]),
-                   two_piece_backward=dict(ms_per_step=round(ms_m6, 3), value=round(a.batch * 34 * world / (ms_m6 * 1e-3), 1) if ms_m6 == ms_m6 else None, steps=a.steps, launch=launch2,
+                   two_piece_backward=dict(ms_per_step=round(ms_m6, 3), value=round(a.batch * T * world / (ms_m6 * 1e-3), 1) if ms_m6 == ms_m6 else None, steps=a.steps, launch=launch2,
                                            arithmetic='ha2g_gemm_set_mode(6), the round-3 default: backward products on TWO bf16 pieces = 16-bit operand mantissa -- narrower than the reference\'s fp32 backward; a labelled secondary number, never `value`'),
-                   exact_fp32_matrix_core=dict(ms_per_step=round(ms_exact, 3), value=round(a.batch * 34 * world / (ms_exact * 1e-3), 1), steps=a.steps, launch=launch2,
+                   exact_fp32_matrix_core=dict(ms_per_step=round(ms_exact, 3), value=round(a.batch * T * world / (ms_exact * 1e-3), 1), steps=a.steps, launch=launch2,
                                                arithmetic='every matrix product on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 (exact fp32, the reference\'s arithmetic class)'),
-                   warmup_phase=dict(ms_per_step=round(ms_warm, 3), value=round(a.batch * 34 * world / (ms_warm * 1e-3), 1), steps=a.steps, launch=launch2),
-                   config=dict(workload='%s hierarchy train step, B=%d per GPU, T=34, %d-d pose, '
-                                        'spec (128,70), n_words=%d, n_spk=%d, dropout 0.3, %s' % (
-                                            'config_expressive/hierarchy.yml TED-Expressive' if a.expressive else 'config/hierarchy.yml TED-Gesture', a.batch, P, a.n_words, a.n_spk, 'GAN phase (epoch %d > loss_warmup)' % a.epoch
+                   warmup_phase=dict(ms_per_step=round(ms_warm, 3), value=round(a.batch * T * world / (ms_warm * 1e-3), 1), steps=a.steps, launch=launch2),
+                   config=dict(workload='%s hierarchy train step, B=%d per GPU, T=%d%s, %d-d pose, '
+                                        'spec (128,%d), n_words=%d, n_spk=%d, dropout 0.3, %s' % (
+                                            'config_expressive/hierarchy.yml TED-Expressive' if a.expressive else 'config/hierarchy.yml TED-Gesture', a.batch, T,
+                                            '' if T == 34 else ' (PERFORMANCE-ONLY window: BASELINE config 5 asks for T = 64, which the reference modules cannot produce -- SURVEY M5; T = 62 is the legal neighbour, discriminator out2 resized to Linear(%d, 1); parity holds at T = 34 only)' % (T - 6),
+                                            P, spec_w, a.n_words, a.n_spk, 'GAN phase (epoch %d > loss_warmup)' % a.epoch
                                             if a.epoch > args.loss_warmup else 'warm-up phase (epoch %d)' % a.epoch),
                                global_batch=a.batch * world, parallelism='dp%d' % world,
                                word_embedding_updates='row-wise (compact gradients, lazy Adam; bit-identical to dense)' if tr.sparse_embeddings else 'dense'),

@@ -1010,6 +1010,7 @@ const unsigned* launch_tag_base(void* xch, hipStream_t st, unsigned* host_tag0) 
     return nullptr;
 }
 
+static int g_tile_cap = 0;          // ha2g_gru_cluster_tile_cap: upper bound on the 16-row tiles of one launch (0 = what the device holds)
 int device_tile_cap() {
     static int cap[64] = {0};
     int dev = 0;
@@ -1020,7 +1021,8 @@ int device_tile_cap() {
         int t = cus / (2 * G);
         cap[dev] = t > MAX_TILES ? MAX_TILES : (t < 1 ? -1 : t);
     }
-    return cap[dev] < 0 ? 0 : cap[dev];
+    const int c = cap[dev] < 0 ? 0 : cap[dev];
+    return (g_tile_cap > 0 && g_tile_cap < c) ? g_tile_cap : c;
 }
 
 }  // namespace
@@ -1029,6 +1031,9 @@ static int g_dbg = 0;
 extern "C" {
 
 void ha2g_gru_cluster_debug(int m) { g_dbg = m; }
+/* every workgroup of a cluster launch must be co-resident: a process that SHARES its device (two ranks on one GPU, a co-resident service) caps the tiles
+ * per launch at its share of the compute units / 10 (0 = the whole device, the default); larger batches take more launches */
+void ha2g_gru_cluster_tile_cap(int tiles) { g_tile_cap = tiles > 0 ? tiles : 0; }
 /* exchange granules of 48 clusters + the device-side launch epoch (last 64 bytes); must be zero-initialised ONCE by the caller */
 long ha2g_gru_cluster_workspace_bytes(void) { return XCH_BYTES + 64; }
 int ha2g_gru_cluster_max_steps(void) { return MAX_STEPS; }

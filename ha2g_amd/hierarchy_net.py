@@ -366,7 +366,9 @@ class _Conv1dParams(nn.Module):
 
 
 class Hierarchical_ConvDiscriminator(nn.Module):
-    def __init__(self, input_size):
+    def __init__(self, input_size, n_frames=34):
+        """n_frames: the reference hard-codes the 34-frame window (out2 = Linear(28, 1), model/hierarchy_net.py:216); other window lengths (SURVEY M5:
+        T = 62 is the legal neighbour of BASELINE config 5's T = 64) size out2 as Linear(n_frames - 6, 1) -- performance runs only, no reference twin."""
         super().__init__()
         self.input_size = input_size
         self.hidden_size = 64
@@ -374,7 +376,7 @@ class Hierarchical_ConvDiscriminator(nn.Module):
                                       _Conv1dParams(16, 8, 3), BatchNormParams(8), _Marker(), _Conv1dParams(8, 8, 3))
         self.gru = BiGRU(8, self.hidden_size, 4, dropout=0.3)
         self.out = Linear(self.hidden_size, 1)
-        self.out2 = Linear(28, 1)
+        self.out2 = Linear(n_frames - 6, 1)
         self.do_flatten_parameters = False
 
     def _features(self, poses):

@@ -18,7 +18,7 @@ def init_model(args, lang_model, speaker_model, pose_dim, _device=None, pose_lev
         generator = Hierarchical_PoseGenerator(args, n_words=lang_model.n_words, word_embed_size=args.wordembed_dim,
                                                word_embeddings=lang_model.word_embedding_weights, z_obj=speaker_model,
                                                pose_dim=pose_dim)
-        discriminator = Hierarchical_ConvDiscriminator(pose_dim)
+        discriminator = Hierarchical_ConvDiscriminator(pose_dim, n_frames=int(getattr(args, 'n_poses', 34)))
         audio_encoder = Hierarchical_WavEncoder(args, z_obj=speaker_model, pose_level=pose_level, nOut=32)
         text_encoder = TextEncoderTCN(args, lang_model.n_words, args.wordembed_dim,
                                       pre_trained_embedding=lang_model.word_embedding_weights, dropout=args.dropout_prob)

@@ -90,6 +90,8 @@ def _grouped_text_features(gens, in_text):
 
 _pinned_bufs = {}
 host_clock = None        # bench.py: {'busy': s, 'steps': n} -- host time spent inside train_iter excluding the final wait for the loss read-back
+comm_clock = None        # bench.py (N > 1): list of (event behind the last backward kernel, event in front of the first optimizer kernel) per step --
+                         # the time between them is the EXPOSED gradient exchange: the audio tower's bucket (last by design) + whatever is left of the others
 _err_watch = []          # (event, pinned int32 word, device): end-of-step copies of the cluster error word not yet looked at
 _err_free = []
 
@@ -373,12 +375,20 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
                      else ddp.average_module_grads_([text_optimizer]))
     if audio_pairs:
         torch.autograd.backward([p[0] for p in audio_pairs], [p[1] for p in audio_pairs])
+    ev_bwd_done = None
+    if comm_clock is not None and dev.type == 'cuda':
+        ev_bwd_done = torch.cuda.Event(enable_timing=True)
+        ev_bwd_done.record()
     _allreduce((audio_optimizer,))
     for w in works:
         if w is not None:
             w.wait()
     g_opts = tuple(gen_optimizers) + (audio_optimizer, text_optimizer)
     _sync_guard(dev)
+    if ev_bwd_done is not None:
+        ev_opt = torch.cuda.Event(enable_timing=True)
+        ev_opt.record()
+        comm_clock.append((ev_bwd_done, ev_opt))
     for o in g_opts:
         o.step()
     ops.rng.end_step()

@@ -24,7 +24,7 @@ extern "C" {
 
 /* Bumped whenever an exported signature changes or entry points are added that a host must not mix with an older library:
  * ha2g_amd/_lib.py refuses to bind a library whose ha2g_abi_version() differs from this macro. */
-#define HA2G_ABI_VERSION 2
+#define HA2G_ABI_VERSION 3
 int ha2g_abi_version(void);
 const char* ha2g_last_error(void);
 
@@ -248,6 +248,8 @@ int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs,
                                int* err, int B, int T, int H, void* stream);
 /* ablation bits for tools/dbg_cluster.py: 1 no wait, 2 no exchange, 4 force the write-through publish */
 void ha2g_gru_cluster_debug(int mode);
+/* ABI 3 (round 5): a process that shares its device caps the 16-row tiles of one cluster launch at its share of compute units / 10 (0 = whole device) */
+void ha2g_gru_cluster_tile_cap(int tiles);
 /* test aid: `blocks` (1..256) workgroups that each hold one compute unit's whole LDS for `microseconds` on `stream` -- a stand-in for a foreign
  * kernel (an RCCL collective of the data-parallel step, scripts/train.py:133-143 replaced by ha2g_amd/ddp.py) that is resident while a cluster
  * GRU launch needs its workgroups co-resident; the launch must then complete or set its error word, never hang.  sink: any device int. */

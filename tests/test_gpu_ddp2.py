@@ -147,6 +147,26 @@ tr2.sync()
 assert ref_tr_cnt == [int(b) for b in tr2._bn_buffers() if b.dtype == torch.int64]     # as after three effective steps
 tr2.train_iter(11, text, spec, target, vid); tr2.sync()
 assert tr2.cluster_retries == 0
+del tr, tr2
+
+# 5. VERDICT r4 item 6c: the CLUSTER GRU on (H = 300: gru_cluster.hip forward + BPTT, 10 co-resident workgroups per launch and rank) under data
+#    parallelism: two processes' cluster launches, the in-step collectives and the side-stream kernels share one device.  Each rank caps its launches
+#    at half the device (ha2g_gru_cluster_tile_cap): what a process that shares its GPU must do.
+from ha2g_amd._lib import lib
+assert lib.ha2g_gru_cluster_supported(300)
+lib.ha2g_gru_cluster_tile_cap(12)
+ops.USE_GRU_CLUSTER = True
+word.zero_(); torch.cuda.synchronize()
+torch.manual_seed(5)
+trc = HierarchyTrainer(hierarchy_args(), Vocab(60), Vocab(9), 27, dev)           # hidden_size 300, 4 layers: the cluster kernels
+trc.broadcast_parameters(0); seed_draws()
+rc = [trc.train_iter(e, text, spec, target, vid) for e in (0, 11, 11)]
+trc.sync()
+assert ops.gru_cluster_error(dev) == 0 and trc.cluster_retries == 0 and ops.USE_GRU_CLUSTER
+assert all(v == v and abs(v) < 1e6 for r_ in rc for v in r_.values()), rc
+flc = gather(torch.cat([o.flat_p for o in trc.gen_opts + [trc.audio_opt, trc.text_opt, trc.dis_opt]]))
+assert torch.equal(flc[0], flc[1]), 'replicas diverged with the cluster GRU on'
+lib.ha2g_gru_cluster_tile_cap(0)
 dist.destroy_process_group()
 print('DDP2_OK rank %%d' %% rank)
 '''

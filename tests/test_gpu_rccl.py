@@ -91,13 +91,70 @@ print('RCCL_FORCED_OK')
 '''
 
 
+CHILD_GRAPH = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r); sys.path.insert(1, %(root)r + '/tests')
+torch.cuda.set_device(0)
+dev = torch.device('cuda', 0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+from bench import Vocab
+from ha2g_amd import ddp, ops, procedural as proc, train_hierarchy as th
+from ha2g_amd.config import hierarchy_args
+from ha2g_testing import no_dropout
+from ha2g_amd.train import HierarchyTrainer
+B = 3
+text, spec, target, vid = (torch.from_numpy(x).to(dev) for x in proc.make_batch(B, 27, 50, 7, 5))
+eps_const = torch.from_numpy(proc.tensor_for('in.eps', (3 * B, 16), 11)).to(dev)
+perm = torch.from_numpy(proc.fixed_perm(B, 11)).to(dev)
+th.randperm_source = lambda n, device: perm
+ddp.FORCE_ACTIVE = True                            # the in-step collectives run (a world of one: the identity, through RCCL)
+def make():
+    torch.manual_seed(5)
+    ops.rng.seed(dev, 77)
+    tr = HierarchyTrainer(hierarchy_args(hidden_size=32, n_layers=2), Vocab(50), Vocab(7), 27, dev, sparse_embeddings=False)
+    for m in tr.modules():
+        no_dropout(m)
+    for g in tr.gens:
+        g.eps_source = lambda shape, device: eps_const[:shape[0]]
+    tr.broadcast_parameters(0)
+    return tr
+tr_e = make()
+eager = []
+for _ in range(5):
+    names, packed = tr_e.train_iter(11, text, spec, target, vid, return_tensors=True)
+    eager.append(packed.clone())
+torch.cuda.synchronize()
+tr_g = make()
+graph, gnames, gpacked = tr_g.capture_step(11, text, spec, target, vid)     # 2 warm-up steps, then ONE captured step WITH its RCCL all-reduces
+replays = []
+for _ in range(2):
+    graph.replay()
+    replays.append(gpacked.clone())
+torch.cuda.synchronize()
+assert gnames == names
+for got, ref in zip(replays, eager[2:4]):
+    assert torch.equal(got, ref), (got.tolist(), ref.tolist())
+pe = torch.cat([o.flat_p for o in tr_e.gen_opts + [tr_e.audio_opt, tr_e.text_opt, tr_e.dis_opt]])
+tr_e2 = make()
+for _ in range(4):
+    tr_e2.train_iter(11, text, spec, target, vid, return_tensors=True)
+torch.cuda.synchronize()
+pg = torch.cat([o.flat_p for o in tr_g.gen_opts + [tr_g.audio_opt, tr_g.text_opt, tr_g.dis_opt]])
+p4 = torch.cat([o.flat_p for o in tr_e2.gen_opts + [tr_e2.audio_opt, tr_e2.text_opt, tr_e2.dis_opt]])
+assert torch.equal(pg, p4)                         # 2 warm-up + 2 replayed steps == 4 eager steps, every parameter, bit for bit
+ddp.FORCE_ACTIVE = False
+dist.destroy_process_group()
+print('RCCL_GRAPH_OK')
+'''
+
+
 def _run_child(code):
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-    return subprocess.run([sys.executable, '-c', code % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=900)
+    return subprocess.run([sys.executable, '-c', code % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=420)
 
 
 def test_in_step_collective_branch_equals_plain_step():
@@ -150,3 +207,13 @@ def test_c_abi_allreduce_bucket_world_size_1():
         assert lib.ha2g_allreduce_bucket(0, x.data_ptr(), 4, 0, st.cuda_stream) != 0    # a null communicator is an error, not a crash
     finally:
         check(lib.ha2g_comm_destroy(comm.value))
+
+
+def test_whole_step_with_its_rccl_collectives_captures_into_a_hipgraph():
+    """the data-parallel step -- D all-reduce inside the D phase, the generators' / text encoder's asynchronous all-reduces under
+    the audio tower's backward, the audio bucket, the error-word MAX-reduce -- captured into ONE hipGraph in a world of one rank (ddp.FORCE_ACTIVE;
+    dense embedding tables: the row-wise exchange reads a count on the host) and replayed: losses and every parameter equal the eager data-parallel
+    steps bit for bit.  N > 1 ranks are then no longer bound to the eager host path (bench.py --launch graph).  Child process with a hard time limit:
+    a collective inside a capture that hung would otherwise hang the suite."""
+    p = _run_child(CHILD_GRAPH)
+    assert p.returncode == 0 and 'RCCL_GRAPH_OK' in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
