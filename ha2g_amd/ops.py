@@ -13,7 +13,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 (OP_ADD, OP_MUL, OP_ADD_RELU, OP_RELU_BWD, OP_LEAKY_BWD, OP_SIGMOID_BWD, OP_ELU, OP_ELU_BWD, OP_REPARAM,
  OP_REPARAM_BWD_LOGVAR, OP_AXPBY, OP_LEAKY, OP_RELU, OP_SCALE, OP_MUL_SCALAR, OP_SIGMOID, OP_SIGMOID_BWD_PRE, OP_RSQRT_EPS, OP_LEAKY_A) = range(19)
 
-_WS_BYTES = 160 << 20
+_WS_BYTES = 320 << 20      # per (device, stream) scratch: sized for the largest reduction of the path (contrastive pair block + split-K partials at N = 256 x 62 rows)
 _ws = {}
 
 
