@@ -164,9 +164,6 @@ def main():
     from ha2g_amd import ops, procedural as proc
     if rehearsal and world > 1:
         ops.USE_GRU_CLUSTER = False                       # cluster launches of two processes on one GPU cannot both be fully co-resident
-    if os.environ.get('HA2G_DEBUG_CFG'):
-        from ha2g_amd._lib import lib as _l
-        _l.ha2g_conv_debug_cfg(int(os.environ['HA2G_DEBUG_CFG']))
     from ha2g_amd.config import hierarchy_args
     from ha2g_amd.train import HierarchyTrainer
 
@@ -178,7 +175,7 @@ def main():
     _lib0.ha2g_gemm_set_mode(default_mode)
     bwd_pieces = _lib0.ha2g_gemm_bwd_pieces()                # 3 = fp32-class backward (the default), 2 = 16-bit operand mantissa, 0 = fp32 MFMA / bf16
     from ha2g_amd import wav_engine as _we
-    b16_storage = bool(a.bf16 and not a.fp32_storage) or os.environ.get('HA2G_B16') == '1'
+    b16_storage = bool(a.bf16 and not a.fp32_storage)
     _we.set_b16(b16_storage)                                  # BASELINE config 5: bf16 activation / activation-gradient storage in the audio trunk
     P = 126 if a.expressive else 27
     T = a.n_poses
@@ -412,9 +409,9 @@ def main():
                         hbm_frac_of_8TBps=round(bytes_ / (mean_us * 1e-6) / 8e12, 4))
         three = ops.gru_fwd3_active(H, T)                  # default mode: both recurrent chains on three bf16 pieces (gru_fwd_cluster3_kernel, gru_bwd_cluster_kernel<3>)
         roof = gru_roof('gru_layer_fwd', ('gru_fwd_cluster3_kernel (ha2g_gru_layer_fwd_cluster3, H=300)' if three else
-                                          'gru_fwd_cluster_kernel (ha2g_gru_layer_fwd_cluster, H=300)'), 'r04_pmc_gru_fwd.json', False, three)
+                                          'gru_fwd_cluster_kernel (ha2g_gru_layer_fwd_cluster, H=300)'), 'r05_pmc_gru_fwd.json', False, three)
         roof_bwd = gru_roof('gru_layer_bwd', ('gru_bwd_cluster_kernel<3> (ha2g_gru_layer_bwd_cluster3, H=300)' if three else
-                                              'gru_bwd_cluster_kernel (ha2g_gru_layer_bwd_cluster, H=300)'), 'r04_pmc_gru_bwd.json', True, three)
+                                              'gru_bwd_cluster_kernel (ha2g_gru_layer_bwd_cluster, H=300)'), 'r05_pmc_gru_bwd.json', True, three)
         if roof_bwd is not None and not three and bwd_pieces == 2:     # mode 6: the BPTT chain on the two-piece split (3 bf16 MFMAs per product term, fp32 accumulate)
             roof_bwd['arithmetic'] = 'split-bf16 x2 (16-bit operand mantissa; frac is still priced against the fp32 MFMA peak)'
         roof_gemm = None

@@ -96,26 +96,16 @@ def check(rc):
     if rc != 0:
         raise Ha2gError('ha2g kernel call failed (%d): %s' % (rc, lib.ha2g_last_error().decode()))
 
-# matrix-core mode (see ha2g_gemm_set_mode in include/ha2g_hip.h) and direct-convolution switches; the HA2G_GEMM_MODE / HA2G_DIRECT_C32
-# environment variables override the library defaults (tests restore THESE values after toggling modes)
+# matrix-core mode (see ha2g_gemm_set_mode in include/ha2g_hip.h); the HA2G_GEMM_MODE environment variable overrides the default (tests restore
+# THIS value after toggling modes).  The A/B switches of closed experiments are no longer read from the environment: tools and tests call the
+# library's debug entry points (ha2g_conv_planes_tile3 / _debug / _korder, ha2g_conv_c32_prefetch, ha2g_gemm_debug_tile, ...) directly.
 # 70 = 64 + 6 (round 4): every split product -- the trunk's forward AND backward convolutions, the dense products >= 4 GFLOP, both GRU chains, every
 # backward GEMM -- on THREE bf16 pieces per operand (all 24 mantissa bits, six MFMAs: fp32-class, the reference's arithmetic class); the small forward
 # GEMMs, the tap convolutions and the stem stay on the fp32 MFMA.  6 = the round-3 default (two-piece backward: 16-bit operand mantissa, fp32-MFMA
 # forward), 0 = exact fp32 MFMA everywhere.
 DEFAULT_GEMM_MODE = int(os.environ.get("HA2G_GEMM_MODE", "70"))
-DEFAULT_DIRECT_C32 = int(os.environ.get("HA2G_DIRECT_C32", "1"))
+DEFAULT_DIRECT_C32 = 1
 lib.ha2g_gemm_set_mode(DEFAULT_GEMM_MODE)
-if os.environ.get("HA2G_PLANES_DEBUG") is not None:  # A/B and ablation bits of the plane kernels (ha2g_conv_planes_debug)
-    lib.ha2g_conv_planes_debug(int(os.environ["HA2G_PLANES_DEBUG"]))
-if os.environ.get("HA2G_C32_PREFETCH") is not None:  # A/B: prefetching form of the 32-channel three-piece direct convolution (1 = default)
-    lib.ha2g_conv_c32_prefetch(int(os.environ["HA2G_C32_PREFETCH"]))
-if os.environ.get("HA2G_TILE3") is not None:        # A/B: tile / kernel form of the three-piece plane kernels (ha2g_conv_planes_tile3)
+if os.environ.get("HA2G_TILE3") is not None:        # step-level A/B of the plane kernels' form (ha2g_conv_planes_tile3: 8 = the q kernel instead of the patch-resident one)
     lib.ha2g_conv_planes_tile3(int(os.environ["HA2G_TILE3"]))
-if os.environ.get("HA2G_QBUF") is not None:         # A/B: buffer-addressed DMA in the plane kernel (1 = default)
-    lib.ha2g_conv_planes_bufaddr(int(os.environ["HA2G_QBUF"]))
-if os.environ.get("HA2G_KORDER") is not None:       # A/B: k order of the plane kernel (1 = channel-major, the default; 0 = tap-major)
-    lib.ha2g_conv_planes_korder(int(os.environ["HA2G_KORDER"]))
 lib.ha2g_conv_debug_direct_c32(DEFAULT_DIRECT_C32)
-# dense tile rule (tuning aid): HA2G_GEMM_TILE=-2 selects round 1's tile rule, 0..8 forces one tile shape (bit-identical results either way)
-if "HA2G_GEMM_TILE" in os.environ:
-    lib.ha2g_gemm_debug_tile(int(os.environ["HA2G_GEMM_TILE"]), 0)

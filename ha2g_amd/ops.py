@@ -28,7 +28,7 @@ def _stream():
 
 
 _stream_objs = {}
-_NO_STREAM_CACHE = os.environ.get('HA2G_NO_STREAM_CACHE', '0') != '0'      # A/B
+_NO_STREAM_CACHE = False      # True: build a torch Stream object per call (the round-3 host path; A/B from python)
 
 
 def cur_stream(device=None):
@@ -171,10 +171,10 @@ def gemm(a, b, transa=False, transb=False, out=None, alpha=1.0, beta=0.0, bias=N
     return out
 
 
-PLANE_GEMM = os.environ.get('HA2G_PLANE_GEMM', '1') != '0'      # large dense products on three-piece planes (csrc/conv_planes.hip, pconv_q_kernel)
+PLANE_GEMM = True      # large dense products on three-piece planes (csrc/conv_planes.hip, pconv_q_kernel)
 # >= 4 GFLOP: the GRU input projections (both directions merged) and their backward; smaller products (generator head, TCN) lose to the operand
 # split passes (A/B on the step: 43.24 ms vs 43.58 with 0.5 GFLOP, 44.10 without the plane GEMM; profiles/r04_ab_gemm.txt)
-PLANE_GEMM_MIN_FLOP = float(os.environ.get('HA2G_PLANE_GEMM_MIN', 4e9))
+PLANE_GEMM_MIN_FLOP = 4e9
 
 
 def _plane_gemm_ok(a, b, M, N, K, transa, transb, alpha, act, out):
@@ -367,8 +367,8 @@ DIRECT_GRAD = True     # accumulate weight gradients straight into an existing `
                        # returning a temporary that autograd then adds with its own kernel (one at::add per parameter)
 
 
-GROUP_GRU_WGRAD = os.environ.get("HA2G_GROUP_GRU_WGRAD", "1") != "0"   # the two directions' weight gradients of a GRU layer as grouped launches
-FUSE_BIAS_GRAD = os.environ.get("HA2G_FUSE_BIAS_GRAD", "1") != "0"     # Linear / Conv1d: bias gradient = column sums taken by the weight-gradient GEMM (ha2g_gemm_wgrad_bias_f32)
+GROUP_GRU_WGRAD = True   # the two directions' weight gradients of a GRU layer as grouped launches
+FUSE_BIAS_GRAD = True     # Linear / Conv1d: bias gradient = column sums taken by the weight-gradient GEMM (ha2g_gemm_wgrad_bias_f32)
 
 
 def _grad_target(param):
@@ -945,7 +945,7 @@ def _gru_layer_bwd(dy, y, rs, pkt, dg, hp, B, T, H, st, device, pk3t=None):
         check(lib.ha2g_gru_layer_bwd(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pkt.data_ptr(), dg.data_ptr(), hp.data_ptr(), B, T, H, st))
 
 
-GRU_FWD3 = os.environ.get('HA2G_GRU_FWD3', '1') != '0'      # H = 300 forward recurrence on three bf16 pieces (fp32-class) in the default mode
+GRU_FWD3 = True      # H = 300 forward recurrence on three bf16 pieces (fp32-class) in the default mode
 
 
 def gru_fwd3_active(H, T):
@@ -968,8 +968,8 @@ def _gru_layer_fwd(gi, pk, bf, br, y, rs, B, T, H, st, device, pk3=None):
         check(lib.ha2g_gru_layer_fwd(gi.data_ptr(), pk.data_ptr(), bf.data_ptr(), br.data_ptr(), y.data_ptr(), _p(rs), B, T, H, st))
 
 
-GRU_MERGE_DIRS = os.environ.get('HA2G_GRU_MERGE_DIRS', '1') != '0'    # both directions' input projections as one plane GEMM
-PACK_MULTI = os.environ.get('HA2G_PACK_MULTI', '1') != '0'      # one W_hh pack launch per GRU stack instead of two per layer
+GRU_MERGE_DIRS = True    # both directions' input projections as one plane GEMM
+PACK_MULTI = True      # one W_hh pack launch per GRU stack instead of two per layer
 
 
 class BiGRUFunction(torch.autograd.Function):

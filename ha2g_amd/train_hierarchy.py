@@ -57,7 +57,7 @@ def _chain(spec, args, gens, targets, in_text, blend, vids, tables):
     return outs, last[0], last[1], last[2]
 
 
-FUSE_TEXT = os.environ.get('HA2G_FUSE_TEXT', '1') != '0'     # the generators' text encoders as grouped launches (hierarchy_net.grouped_text_encoders)
+FUSE_TEXT = True     # the generators' text encoders as grouped launches (hierarchy_net.grouped_text_encoders)
 
 
 def _grouped_text_features(gens, in_text):

@@ -53,7 +53,7 @@ def conv_fwd(x, w_ohwi, bias, stride, pad, act):
     return y
 
 
-FWD3 = __import__('os').environ.get('HA2G_FWD_PLANES', '1') != '0'      # forward convolutions of trunk layers 2-4 on three-piece planes
+FWD3 = True      # forward convolutions of trunk layers 2-4 on three-piece planes
 
 
 def fwd_planes_ok(w_ohwi, stride, pad):
@@ -328,13 +328,9 @@ import os as _os
 # the FORWARD producers (bn1's apply pass, the block's output pass) instead of being split by a streaming pass on the backward's side stream;
 # bit 3: the stride-2 data gradients (conv1 / downsample of a layer's first block) by parity class; HA2G_PLANES=0 is the round-2 path
 PLANES = int(_os.environ.get('HA2G_PLANES', '11'))
-SIDE_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_WGRAD', '1') != '0'
-# bf16-storage mode of the trunk (BASELINE config 5; wav_b16.py): opt-in -- HA2G_B16=1, set_b16(True) or bench.py --bf16
-if _os.environ.get('HA2G_PCONV_RING'):
-    lib.ha2g_conv_planes_ring(int(_os.environ['HA2G_PCONV_RING']))      # A/B: LDS ring depth of the plane convolution kernel
-if _os.environ.get('HA2G_SIDE_CUS'):
-    lib.ha2g_side_cus(int(_os.environ['HA2G_SIDE_CUS']))      # tuning: compute units the side stream's persistent weight-gradient kernels occupy
-B16 = [_os.environ.get('HA2G_B16', '0') == '1']
+SIDE_WGRAD = True            # the tower's convolution weight gradients on ops.side's stream (False: in line; same kernels, bit-identical -- tested)
+# bf16-storage mode of the trunk (BASELINE config 5; wav_b16.py): opt-in -- set_b16(True) or bench.py --bf16
+B16 = [False]
 
 
 def set_b16(on):
@@ -343,12 +339,12 @@ def set_b16(on):
     B16[0] = bool(on)
     return prev
 
-SIDE_FC_WGRAD = _os.environ.get('HA2G_TOWER_SIDE_FC', '1') != '0'
-WGRAD_AFTER = _os.environ.get('HA2G_WGRAD_AFTER', '0') == '1'
-WPLANES_MULTI = _os.environ.get('HA2G_WPLANES_MULTI', '1') != '0'      # all weight planes of the tower's backward in one launch
+SIDE_FC_WGRAD = True
+WGRAD_AFTER = False          # fork a convolution's weight gradient AFTER its data gradient was enqueued (round 3 A/B: the contention only moves)
+WPLANES_MULTI = True      # all weight planes of the tower's backward in one launch
 
 
-SE_MLP_FUSED = _os.environ.get('HA2G_SE_MLP_FUSED', '1') != '0'
+SE_MLP_FUSED = True
 
 
 def se_mlp_bwd(dsc, h1, w2, w0, HW):

@@ -1,7 +1,7 @@
 # Whole-step HBM bytes of the headline configuration (B = 128 TED-Gesture, GAN phase): PMC FETCH_SIZE / WRITE_SIZE, one counter per run,
-# kernel-trace only -> gpurun_out/${TAG}_pmc_step_bytes_b128.txt      usage: bash tools/r04_step_bytes.sh [TAG] [extra bench.py flags]
+# kernel-trace only -> gpurun_out/${TAG}_pmc_step_bytes_b128.txt      usage: bash tools/step_bytes.sh [TAG] [extra bench.py flags]
 export TMPDIR=/tmp
-TAG=${1:-r04}; shift
+TAG=${1:-r05}; shift
 W=2; K=4
 out=$PWD/gpurun_out/${TAG}_pmc_step_bytes_b128.txt; : > $out
 for ctr in FETCH_SIZE WRITE_SIZE; do
