@@ -8,6 +8,7 @@ only grow, and only by what the reference itself does.  Container-only (imports 
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_more_noise.py cfg3_b128 [NEXTRA=8] [first draw=5]
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_more_noise.py enc16 60 9        (the B=16 whole-encoder fixture: 9 runs so far)
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_more_noise.py cfg3_b128_gan 32 9 (round 5: the GAN-phase-first fixtures start with 9 runs)
 """
 import os
 import sys
@@ -24,7 +25,8 @@ from ha2g_amd.config import BIG_CASES  # noqa: E402
 name = sys.argv[1]
 nextra = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-case = BIG_CASES.get(name)                               # None: one of gen_golden.EXTRA's well-conditioned fixtures (enc16, blocks, ...)
+gan = name.endswith('_gan')                              # the GAN-phase-first fixtures (gen_golden.main_gan): one step at epoch 11 from fresh state
+case = BIG_CASES.get(name[:-4] if gan else name)         # None: one of gen_golden.EXTRA's well-conditioned fixtures (enc16, blocks, ...)
 path = os.path.join(HERE, name + '.npz')
 fix = dict(np.load(path))
 grown = 0
@@ -33,7 +35,7 @@ for i in range(nextra):
     o = {}
     t0 = time.time()
     if case is not None:
-        G.step_goldens(case, o, torch.float32, expressive=bool(case.get('expressive')), perturb=6e-8, perturb_text=True)
+        G.step_goldens(case, o, torch.float32, expressive=bool(case.get('expressive')), perturb=6e-8, perturb_text=True, epochs=(11,) if gan else (0, 11))
     else:
         for fn in G.EXTRA[name]:
             fn(o, torch.float32, perturb=6e-8)
