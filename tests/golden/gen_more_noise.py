@@ -50,6 +50,6 @@ for i in range(nextra):
     grown += n
     print('draw %d: %.0f s, %d of %d noise floors raised' % (first + i, time.time() - t0, n, len(o)), flush=True)
     np.savez_compressed(path, **fix)                      # after every run: an interrupted study keeps what it has measured
-fix['noise_runs'] = np.float64(float(fix.get('noise_runs', 5 if case is not None else 9)) + nextra)
+fix['noise_runs'] = np.float64(float(fix.get('noise_runs', (9 if gan else 5) if case is not None else 9)) + nextra)
 np.savez_compressed(path, **fix)
 print('wrote', path, '(%d floors raised in total)' % grown)
