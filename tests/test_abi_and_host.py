@@ -131,3 +131,9 @@ def test_fastcall_binding_covers_the_header_and_converts_like_ctypes():
         fc.ha2g_gemm_f32(0, 1, 0)
     with pytest.raises(TypeError):
         fc.ha2g_gemm_f32(0, 1, 0, 0, 0, 1.0, 'x', 0, None, 0, 0, None, 0, None, 0, None, 0, None)
+
+
+def test_graft_entry_build_passes_on_the_tree_as_it_is():
+    """The driver's "does it build" hook: make (a no-op when the objects are current), import of the oracle and the package, ABI version check."""
+    import __graft_entry__ as g
+    g.build()
