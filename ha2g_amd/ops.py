@@ -89,6 +89,15 @@ class SideStream:
 side = SideStream()
 
 
+ACT_TAP = [None]      # diagnostics: a list here receives (kind, y > 0) for every ReLU / LeakyReLU applied by an autograd Function below, in call order
+                      # (tests/test_gpu_linearised.py linearises the float64 oracle at exactly this activation pattern)
+
+
+def _tap_act(kind, y, act):
+    if ACT_TAP[0] is not None and act in (ACT_RELU, ACT_LEAKY):
+        ACT_TAP[0].append((kind, (y > 0)))
+
+
 class KernelTimer:
     """HIP-event timing of selected kernel launches on the stream they are launched on (bench.py's roofline leg)."""
 
@@ -390,6 +399,7 @@ class LinearFunction(torch.autograd.Function):
         w_in = w
         w = w.contiguous()
         y = gemm(x2, w, transb=True, bias=b, act=act)
+        _tap_act('linear', y, act)
         ctx.act = act
         ctx.xshape = x.shape
         ctx.has_b = b is not None
@@ -506,6 +516,7 @@ class AddReluFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
         y = eltwise(OP_ADD_RELU, a.contiguous(), b.contiguous())
+        _tap_act('add_relu', y, ACT_RELU)
         ctx.save_for_backward(y)
         return y
 
@@ -656,6 +667,7 @@ class Conv1dFunction(torch.autograd.Function):
         col = torch.empty(B * To, C * k, dtype=torch.float32, device=x.device)
         check(lib.ha2g_im2col1d_f32(x.data_ptr(), col.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
         y = gemm(col, w.view(cout, C * k), transb=True, bias=b, act=act)
+        _tap_act('conv1d', y.view(B, To, cout), act)
         ctx.geom = (B, T, C, k, dil, pad_left, To, act)
         ctx.has_b = b is not None
         ctx.save_for_backward(col, w, y if act != ACT_NONE else None)
@@ -713,6 +725,7 @@ class GroupedLinearFunction(torch.autograd.Function):
         x = _f32c(x.contiguous())
         wc = [w.contiguous() for w in ws]
         y = gemm_grouped(x, wc, transb=True, bias=bs if has_b else None, act=act)
+        _tap_act('grouped_linear', y, act)
         ctx.act, ctx.G, ctx.has_b = act, G, has_b
         ctx.refs = (ws, bs)
         ctx.save_for_backward(x, y if act != ACT_NONE else None, *wc)
@@ -871,6 +884,7 @@ class BatchNormFunction(torch.autograd.Function):
         x2 = x.view(-1, x.shape[-1])
         mean, invstd = bn_stats(x2, running_mean, running_var, momentum, eps)
         y = bn_apply(x2, mean, invstd, gamma, beta, act)
+        _tap_act('batch_norm', y.view(x.shape), act)
         ctx.act = act
         ctx.save_for_backward(x2, mean, invstd, gamma, y if act != ACT_NONE else None)
         return y.view(x.shape)

@@ -92,12 +92,12 @@ def text_encoder_tcn(tokens, sd, p, n_layers, drop=None):
             q = '%stcn.network.%d.%s.' % (p, i, c)
             w = weight_norm(sd[q + 'weight_g'], sd[q + 'weight_v'])
             y = F.conv1d(F.pad(y, (dil, 0)), w, sd[q + 'bias'], dilation=dil)   # left pad == pad+chomp
-            y = torch.relu(y)
+            y = _act(y, 0.0, True)
             if drop:
                 y = y * drop[(i, j)]
         if (p + 'tcn.network.%d.downsample.weight' % i) in sd:
             res = F.conv1d(res, sd[p + 'tcn.network.%d.downsample.weight' % i], sd[p + 'tcn.network.%d.downsample.bias' % i])
-        x = torch.relu(y + res)
+        x = _act(y + res, 0.0, True)
     return F.linear(x.transpose(1, 2), sd[p + 'decoder.weight'], sd[p + 'decoder.bias'])
 
 
@@ -188,6 +188,44 @@ def _relu(x, site):
     if masks is not None and site in masks:
         return x * masks[site].to(x.dtype)
     return torch.relu(x)
+
+
+_ACT_SEQ = [None, None]             # [iterator over masks to impose, list to record into] for the activations OUTSIDE the audio tower, in call order
+
+
+class act_sequence:
+    """`with act_sequence(masks=[m0, m1, ...]):` -- the ReLU / LeakyReLU decisions of the text encoders (model/tcn.py:21-29,43-46), the generators' head
+    (model/hierarchy_net.py:91) and the discriminator (model/hierarchy_net.py:200-206) imposed in CALL ORDER (the k-th such activation evaluated takes
+    the k-th mask; time-major [B, T, C] masks are transposed to the oracle's [B, C, T] where the site says so): relu(x) -> x * m, leaky(x) -> x * (m + 0.01 (1 - m)).
+    With relu_pattern (the tower's sites, by name) this linearises the WHOLE train step at a given activation pattern.  `record=[]` collects the
+    oracle's own decisions in the same order and layout convention."""
+
+    def __init__(self, masks=None, record=None):
+        self.new = [iter(masks) if masks is not None else None, record]
+
+    def __enter__(self):
+        self.prev = list(_ACT_SEQ)
+        _ACT_SEQ[:] = self.new
+
+    def __exit__(self, *a):
+        left = 0 if _ACT_SEQ[0] is None else sum(1 for _ in _ACT_SEQ[0])
+        _ACT_SEQ[:] = self.prev
+        assert left == 0, 'act_sequence: %d masks were not consumed (the call order of the two sides differs)' % left
+
+
+def _act(x, slope, time_major_mask):
+    """relu (slope 0) / leaky_relu at one sequence site; x in the oracle's layout, the mask in the other side's when time_major_mask"""
+    it, record = _ACT_SEQ
+    if record is not None:
+        m = (x > 0).detach()
+        record.append(m.transpose(1, 2).contiguous() if time_major_mask else m)
+    if it is not None:
+        m = next(it)
+        if time_major_mask:
+            m = m.reshape(x.shape[0], x.shape[2], x.shape[1]).transpose(1, 2)
+        m = m.reshape(x.shape).to(x.dtype)
+        return x * (m + slope * (1 - m)) if slope else x * m
+    return F.leaky_relu(x, slope) if slope else torch.relu(x)
 
 
 def _st(x):
@@ -282,7 +320,7 @@ def pose_generator(pre_seq, tokens, audio_feat, vid, sd, p, n_layers, H, eps, dr
     y = gru_bidir(x, sd, p + 'gru.', n_layers, H, drop['gru'] if drop else None)
     y = y[:, :, :H] + y[:, :, H:]
     y = F.linear(y, sd[p + 'out.0.weight'], sd[p + 'out.0.bias'])
-    y = F.leaky_relu(y, 0.01)
+    y = _act(y, 0.01, False)
     y = F.linear(y, sd[p + 'out.2.weight'], sd[p + 'out.2.bias'])
     return y, zc, mu, logvar
 
@@ -292,9 +330,9 @@ def conv_discriminator(poses, sd, p, update_bn=True, gru_masks=None):
     4 layers) -> direction sum -> Linear(64,1) per frame -> Linear(T-6,1) -> sigmoid."""
     x = poses.transpose(1, 2)
     x = F.conv1d(x, sd[p + 'pre_conv.0.weight'], sd[p + 'pre_conv.0.bias'])
-    x = F.leaky_relu(batch_norm_train(x, sd, p + 'pre_conv.1.', update=update_bn), 0.01)
+    x = _act(batch_norm_train(x, sd, p + 'pre_conv.1.', update=update_bn), 0.01, True)
     x = F.conv1d(x, sd[p + 'pre_conv.3.weight'], sd[p + 'pre_conv.3.bias'])
-    x = F.leaky_relu(batch_norm_train(x, sd, p + 'pre_conv.4.', update=update_bn), 0.01)
+    x = _act(batch_norm_train(x, sd, p + 'pre_conv.4.', update=update_bn), 0.01, True)
     x = F.conv1d(x, sd[p + 'pre_conv.6.weight'], sd[p + 'pre_conv.6.bias']).transpose(1, 2)
     y = gru_bidir(x, sd, p + 'gru.', 4, 64, gru_masks)
     y = y[:, :, :64] + y[:, :, 64:]

@@ -191,3 +191,28 @@ def test_gan_phase_first_step(golden, name, dt):
     ret = tr.train_iter(11, text, spec, target, vid, lambda shp: torch.from_numpy(es(shp)).to(dt), perm)
     assert 'gen' in ret and 'dis' in ret and any(k.startswith('dis.') for k in tr.grads)
     ck.step(0, ret, tr.grads, sd)
+
+
+def test_imposing_the_oracles_own_activation_sequence_reproduces_the_step():
+    """oracle.act_sequence + relu_pattern (the whole-step linearisation of tests/test_gpu_linearised.py): with the decisions the float64 oracle itself took
+    imposed -- the tower's by name, the text encoders' / heads' / discriminator's in call order -- a GAN-phase step gives the same losses and gradients."""
+    case = CASES['small']
+    dt = torch.float64
+    text, spec, target, vid = batch_for(case, dt)
+    perm = torch.from_numpy(proc.fixed_perm(case['B'], case['seed']))
+
+    def run(masks=None, seq=None, rec_m=None, rec_s=None):
+        sd = state_for(case, dt)
+        tr = O.OracleTrainer(sd, make_args(case))
+        es = proc.EpsStream(case['seed'])
+        with O.relu_pattern(masks=masks, record=rec_m), O.act_sequence(masks=seq, record=rec_s):
+            ret = tr.train_iter(11, text, spec, target, vid, lambda shp: torch.from_numpy(es(shp)).to(dt), perm)
+        return ret, tr.grads
+    rec_m, rec_s = {}, []
+    r0, g0 = run(rec_m=rec_m, rec_s=rec_s)
+    # per generator call: 2 layers x (2 conv ReLUs + 1 residual ReLU) in its text encoder + 1 head LeakyReLU; 9 generator calls, 1 stand-alone encoder, 3 D calls x 2
+    assert len(rec_s) == 6 + 9 * 7 + 3 * 2 and len(rec_m) == 1 + 16 * 3 + 3
+    r1, g1 = run(masks=rec_m, seq=rec_s)
+    assert r0.keys() == r1.keys() and all(abs(r0[k] - r1[k]) <= 1e-12 * max(1.0, abs(r0[k])) for k in r0)
+    for k in g0:
+        assert torch.allclose(g0[k], g1[k], rtol=1e-12, atol=1e-14), k
