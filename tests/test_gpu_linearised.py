@@ -269,3 +269,12 @@ def test_whole_gan_phase_step_vs_oracle_linearised_at_the_hip_activation_pattern
     from ha2g_amd.config import CASES
     case = CASES[name]
     _whole_step_vs_linearised_oracle(case, bool(case.get('expressive')), 'GAN-phase step %s' % name)
+
+
+def test_whole_gan_phase_step_headline_size_vs_oracle_linearised_at_the_hip_activation_pattern():
+    """The same at the HEADLINE configuration (BASELINE config 2: B = 128, T = 34, H = 300, 4 layers, 20 000 words, 1 371 speakers, spec (128, 70); the
+    parameters and batch of the cfg2_b128 fixtures): where the reference-generated fixture can hold the generators to 1e-3 and the tower to percent (its own
+    fp32 runs flip kinks), this holds every element of every gradient of the GAN-phase step the benchmark times to 1e-4 + the float32 oracle's floor.  The two
+    oracle steps (float64, float32) take ~40 GB and a few minutes of host time."""
+    from ha2g_amd.config import BIG_CASES
+    _whole_step_vs_linearised_oracle(dict(BIG_CASES['cfg2_b128']), False, 'GAN-phase step cfg2_b128')
