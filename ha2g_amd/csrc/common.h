@@ -121,6 +121,28 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Reduce-scatter over the 16 lanes of a row (lanes sharing lane >> 4): every lane brings NV (16 or 8) doubles; on return v[0] of lane r (= lane & 15)
+// is the sum over the row's 16 lanes of value index r & (NV - 1) (NV = 8: both halves of the row hold the same eight sums).  A fixed exchange tree
+// (partners lane ^ 8, ^ 4, ^ 2, ^ 1; a + b is commutative, so both partners compute the same bits): deterministic.  15 (NV = 16) / 15 (NV = 8)
+// double exchanges instead of NV x 4 for a plain butterfly.
+template <int NV> __device__ __forceinline__ void row16_reduce_scatter(double (&v)[NV], int lane) {
+    static_assert(NV == 16 || NV == 8, "row16_reduce_scatter: 8 or 16 values");
+    if constexpr (NV == 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += __shfl_xor(v[k], 8, 64);
+    }
+    constexpr int TOP = NV == 16 ? 8 : 4;
+#pragma unroll
+    for (int m = TOP, n = NV / 2; m >= 1; m >>= 1, n >>= 1) {
+        const bool up = (lane & m) != 0;                    // lanes with the bit set keep the upper half of the values
+#pragma unroll
+        for (int k = 0; k < n; ++k) {
+            const double send = up ? v[k] : v[k + n], keep = up ? v[k + n] : v[k];
+            v[k] = keep + __shfl_xor(send, m, 64);
+        }
+    }
+}
+
 // block-wide sum for blocks of up to 1024 threads; `red` is >= 16 floats of LDS. All threads get the sum.
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);

@@ -164,6 +164,9 @@ struct PConvP {
     int kmaj;                                                    // pconv_q_kernel: 1 = channel-major k order (default), 0 = tap-major (ha2g_conv_planes_korder)
     int ksplit, kt_per;                                          // split-K over blockIdx.z (ncls == 1): k tiles [z * kt_per, ..) -> raw partial slab z of ws
     float* ws;                                                   // [ksplit][M][N]
+    // BatchNorm statistics of the stored output from the epilogue (pconv_r_kernel, forward): per row tile and channel the sum and the sum of
+    // squares (double) -> stat[(which * N + channel) * stat_nblk + tile]; null = none.  norm.hip's bn_stats_final_kernel adds the tiles in order.
+    double* stat; int stat_nblk;
 };
 
 // XCD-aware workgroup -> tile mapping (same rule as gemm.hip's tile_of_block: XCD x owns a contiguous eighth of the tile sequence, n fastest)
@@ -971,6 +974,33 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
             }
         }
     }
+    // BatchNorm statistics of the stored output (see pconv_r_kernel's epilogue; forward convolutions only: relu is the only epilogue term): block
+    // 2 bx + group of stat_nblk = 2 gridDim.x
+    if (p.stat != nullptr) {
+        constexpr int NV = NI * 8;
+        double sv[NV];
+        bool live[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) live[i] = m0 + i * 16 + l15 < pc.M;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    float v = acc[i][j][u];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    v = live[i] ? v : 0.f;
+                    s1 += v; s2 = fmaf(v, v, s2);
+                }
+                sv[(j * 4 + u) * 2] = (double)s1; sv[(j * 4 + u) * 2 + 1] = (double)s2;
+            }
+        row16_reduce_scatter<NV>(sv, lane);
+        const int idx = l15 & (NV - 1);
+        const int ch = n0 + w4 * (BN / 4) + (idx >> 3) * 16 + 4 * kp + ((idx >> 1) & 3);
+        if ((NV == 16 || l15 < 8) && ch < p.N) p.stat[((long)(idx & 1) * p.N + ch) * p.stat_nblk + 2 * bx + grp] = sv[0];
+    }
 }
 
 
@@ -1190,6 +1220,35 @@ __global__ __launch_bounds__(256, WPS) void pconv_r_kernel(PConvP p, RGeo g) {
             if (p.beta != 0.f) v += p.beta * *reinterpret_cast<const f32x4_t*>(dst);
             *reinterpret_cast<f32x4_t*>(dst) = v;
         }
+    }
+    // ---- BatchNorm statistics of the tile (forward, the BatchNorm that follows the convolution: ResNetBlocks.py:24-29): the separate column pass
+    //      over the output (norm.hip col_partial_kernel<0>, 0.9 ms of the step's main queue) re-read what this epilogue holds in registers.
+    //      Per lane the column sums of its MT <= 9 pixels (fp32: nine terms), then in double: a reduce-scatter over the 16 pixel lanes, one double per
+    //      (channel, which) and tile; the tiles are added in double by bn_stats_final_kernel.  (All-double lane sums cost 5.5 us per launch.)
+    if (p.stat != nullptr) {
+        constexpr int NV = NI * 8;
+        double sv[NV];
+        bool live[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) live[i] = tp0 + i * 16 + pxo < tend;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    float v = acc[i][j][u];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    v = live[i] ? v : 0.f;
+                    s1 += v; s2 = fmaf(v, v, s2);
+                }
+                sv[(j * 4 + u) * 2] = (double)s1; sv[(j * 4 + u) * 2 + 1] = (double)s2;
+            }
+        row16_reduce_scatter<NV>(sv, lane);
+        const int idx = l15 & (NV - 1);
+        const int ch = n0 + w4 * (BN / 4) + (idx >> 3) * 16 + 4 * kp + ((idx >> 1) & 3);
+        if ((NV == 16 || l15 < 8) && ch < p.N) p.stat[((long)(idx & 1) * p.N + ch) * p.stat_nblk + gt] = sv[0];
     }
 }
 
@@ -1611,6 +1670,9 @@ static int pconv_r_launch(const PConvP& p, const RGeo& g, dim3 grid, hipStream_t
 }
 // -100: geometry not served (the caller keeps the q kernel): 3x3 / stride 1 / pad 1 with one class of nine taps, N a multiple of 64 with aligned
 // vector stores, no bias / activation epilogue (the convolution callers pass relu only), the patch inside one of the two reserved plane sizes
+// tile plan of the patch-resident kernel for a 3x3 / stride-1 / pad-1 convolution of `imgs` images of H x W pixels with N output channels:
+// false = geometry not served.  Depends on the geometry and the device's CU count only (ha2g_conv2d_fwd_planes_stat_blocks reports its tile count).
+static bool pconv_r_plan(int imgs, int H, int W, int N, int& bmt, int& bbn, RGeo& bg);
 static int pconv_r_dispatch(const PConvP& p_in, int imgs, hipStream_t st) {
     PConvP p = p_in;
     const PClass& c0 = p.cls[0];
@@ -1618,13 +1680,32 @@ static int pconv_r_dispatch(const PConvP& p_in, int imgs, hipStream_t st) {
     if (p.GH != p.OH || p.GW != p.OW || p.GC % 32 != 0 || p.N % 64 != 0 || p.a_bytes <= 0 || p.b_bytes <= 0) return -100;
     const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     if (!(p.ldc % 4 == 0 && al16(p.C))) return -100;
-    const int H = p.GH, W = p.GW, HW = H * W;
-    if (W < 2 || HW < 16) return -100;
+    int bmt = 0, bbn = 0; RGeo bg{};
+    if (!pconv_r_plan(imgs, p.GH, p.GW, p.N, bmt, bbn, bg)) return -100;
+    if (p.stat != nullptr && p.stat_nblk != bg.ntiles) return ha2g_set_error(-1, "conv2d_fwd_planes: statistics buffer sized for %d row tiles, the kernel writes %d", p.stat_nblk, bg.ntiles);
+    for (int t = 0; t < 9; ++t) {                                // forward: source pixel (oy - 1 + kh, ox - 1 + kw); data gradient: (oy + 1 - kh, ox + 1 - kw)
+        const int kh = c0.tap[t] / 3, kw = c0.tap[t] % 3;
+        bg.toff64[t] = (p.fwd ? kh * bg.PW + kw : (2 - kh) * bg.PW + (2 - kw)) * 64;
+    }
+    const dim3 grid((unsigned)bg.ntiles, (unsigned)(p.N / bbn), 1);
+    const bool big = bg.patch_px == 320;
+    if (bbn == 128) {
+        if (bmt == 9) return big ? pconv_r_launch<9, 128, 320, 2>(p, bg, grid, st) : pconv_r_launch<9, 128, 272, 2>(p, bg, grid, st);
+        return big ? pconv_r_launch<7, 128, 320, 2>(p, bg, grid, st) : pconv_r_launch<7, 128, 272, 2>(p, bg, grid, st);
+    }
+    if (bmt == 9) return big ? pconv_r_launch<9, 64, 320, 2>(p, bg, grid, st) : pconv_r_launch<9, 64, 272, 2>(p, bg, grid, st);
+    return big ? pconv_r_launch<7, 64, 320, 2>(p, bg, grid, st) : pconv_r_launch<7, 64, 272, 3>(p, bg, grid, st);
+}
+static bool pconv_r_plan(int imgs, int H, int W, int N, int& bmt, int& bbn, RGeo& bg) {
+    const int HW = H * W;
+    bmt = bbn = 0;
+    if (W < 2 || HW < 16 || N % 64 != 0 || imgs <= 0) return false;
+    struct { int N; } p{N};
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) { int c = 0; if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) cus = c; }
     // tile choice: 16 MT pixels (MT = 7 or 9) x BN columns per workgroup -- the combination that keeps the CUs fullest, among those whose patch fits one
     // of the two reserved plane sizes (272 / 320 patch pixels); resident workgroups per CU by LDS (160 KB) and registers (MT = 7, BN = 64: three waves per SIMD)
-    double best = -1.0; int bmt = 0, bbn = 0; RGeo bg{};
+    double best = -1.0;
     for (int bn = 128; bn >= 64; bn -= 64) {
         if (p.N % bn != 0) continue;
         for (int mt = 9; mt >= 7; mt -= 2) {
@@ -1648,22 +1729,11 @@ static int pconv_r_dispatch(const PConvP& p_in, int imgs, hipStream_t st) {
             if (eff > best + 1e-9) { best = eff; bmt = mt; bbn = bn; bg = g; }
         }
     }
-    if (bmt == 0) return -100;
+    if (bmt == 0) return false;
     bg.mgW = (unsigned)(((1ULL << 32) + (unsigned)W - 1) / (unsigned)W);
     bg.mgPW = (unsigned)(((1ULL << 32) + (unsigned)bg.PW - 1) / (unsigned)bg.PW);
     bg.mg_gpi = bg.gpi > 1 ? (unsigned)(((1ULL << 32) + (unsigned)bg.gpi - 1) / (unsigned)bg.gpi) : 0u;
-    for (int t = 0; t < 9; ++t) {                                // forward: source pixel (oy - 1 + kh, ox - 1 + kw); data gradient: (oy + 1 - kh, ox + 1 - kw)
-        const int kh = c0.tap[t] / 3, kw = c0.tap[t] % 3;
-        bg.toff64[t] = (p.fwd ? kh * bg.PW + kw : (2 - kh) * bg.PW + (2 - kw)) * 64;
-    }
-    const dim3 grid((unsigned)bg.ntiles, (unsigned)(p.N / bbn), 1);
-    const bool big = bg.patch_px == 320;
-    if (bbn == 128) {
-        if (bmt == 9) return big ? pconv_r_launch<9, 128, 320, 2>(p, bg, grid, st) : pconv_r_launch<9, 128, 272, 2>(p, bg, grid, st);
-        return big ? pconv_r_launch<7, 128, 320, 2>(p, bg, grid, st) : pconv_r_launch<7, 128, 272, 2>(p, bg, grid, st);
-    }
-    if (bmt == 9) return big ? pconv_r_launch<9, 64, 320, 2>(p, bg, grid, st) : pconv_r_launch<9, 64, 272, 2>(p, bg, grid, st);
-    return big ? pconv_r_launch<7, 64, 320, 2>(p, bg, grid, st) : pconv_r_launch<7, 64, 272, 3>(p, bg, grid, st);
+    return true;
 }
 
 template <int NP>
@@ -1686,6 +1756,8 @@ static int pconv_q_dispatch(const PConvP& p_in, int maxM, hipStream_t st) {
     pconv_q_plan(maxM, p.N, p.ksplit > 1 ? p.ksplit : 1, &bmt, &bbn);
     if (bmt == 0) return -100;
     const dim3 grid((unsigned)((maxM + 32 * bmt - 1) / (32 * bmt)), (unsigned)((p.N + bbn - 1) / bbn), (unsigned)(p.ksplit > 1 ? p.ksplit : p.ncls));
+    if (p.stat != nullptr && !(p.fwd && p.vec && p.ncls == 1 && p.ksplit <= 1 && !p.bias && !p.act && p.beta == 0.f && p.stat_nblk == 2 * (int)grid.x))
+        return ha2g_set_error(-1, "conv2d_fwd_planes: statistics buffer sized for %d row blocks, the q kernel writes %d", p.stat_nblk, 2 * (int)grid.x);
     if (bbn == 128) {
         if (bmt == 9) return pconv_q_launch<9, 128, NP>(p, grid, st);
         if (bmt == 8) return pconv_q_launch<8, 128, NP>(p, grid, st);
@@ -1918,8 +1990,37 @@ int ha2g_conv2d_fwd_planes_supported(int Cin, int Cout, int KH, int KW, int stri
     const bool geom = (KH == 3 && KW == 3 && pad == 1) || (KH == 1 && KW == 1 && pad == 0);
     return g_planes && geom && (stride == 1 || stride == 2) && Cin % 32 == 0 && Cin >= 32 && Cout % 64 == 0;
 }
+// Row tiles per channel of the BatchNorm statistics this forward convolution can leave behind (ha2g_conv2d_fwd_planes_np_stats_f32): the tile
+// count of the patch-resident kernel when it serves the geometry (3x3 / stride 1 / pad 1) in the current configuration, else 0 (the caller runs
+// ha2g_bn_stats_f32 on the output).  Host arithmetic only.
+int ha2g_conv2d_fwd_planes_stat_blocks(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (!ha2g_conv2d_fwd_planes_supported(Cin, Cout, KH, KW, stride, pad)) return 0;
+    if (!(g_tile3 == 0 && g_q_kernel)) return 0;
+    int bmt = 0, bbn = 0; RGeo g{};
+    if (g_r_kernel && KH == 3 && KW == 3 && stride == 1 && pad == 1 && pconv_r_plan(N, H, W, Cout, bmt, bbn, g)) return g.ntiles;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;     // the q kernel: two row groups per workgroup
+    const long M = (long)N * OH * OW;
+    if (M <= 0 || M > 0x7fffffffL) return 0;
+    pconv_q_plan((int)M, Cout, 1, &bmt, &bbn);
+    return bmt ? 2 * (int)((M + 32 * bmt - 1) / (32 * bmt)) : 0;
+}
+static int conv2d_fwd_planes_impl(const void* x, long x_ps, const void* w, long w_ps, int np, float* y, int N, int H, int W, int Cin, int Cout, int KH,
+                                  int KW, int stride, int pad, int relu, double* stat, int stat_nblk, void* stream);
 int ha2g_conv2d_fwd_planes_np_f32(const void* x, long x_ps, const void* w, long w_ps, int np, float* y, int N, int H, int W, int Cin, int Cout, int KH,
                                   int KW, int stride, int pad, int relu, void* stream) {
+    return conv2d_fwd_planes_impl(x, x_ps, w, w_ps, np, y, N, H, W, Cin, Cout, KH, KW, stride, pad, relu, nullptr, 0, stream);
+}
+// ... and the statistics of the BatchNorm that follows (conv -> [ReLU] -> BatchNorm, ResNetBlocks.py:24-29,81-83) from the same launch:
+// stat_part [2][Cout][stat_nblk] doubles receives per row tile the sum and the sum of squares of the STORED output (after the ReLU);
+// stat_nblk = ha2g_conv2d_fwd_planes_stat_blocks(...) > 0.  ha2g_bn_stats_finalize_f32 turns them into mean / invstd / running statistics.
+int ha2g_conv2d_fwd_planes_np_stats_f32(const void* x, long x_ps, const void* w, long w_ps, int np, float* y, int N, int H, int W, int Cin, int Cout,
+                                        int KH, int KW, int stride, int pad, int relu, void* stat_part, int stat_nblk, void* stream) {
+    HA2G_REQUIRE(stat_part != nullptr && stat_nblk > 0 && stat_nblk == ha2g_conv2d_fwd_planes_stat_blocks(N, H, W, Cin, Cout, KH, KW, stride, pad),
+                 "conv2d_fwd_planes_stats: stat_nblk = %d is not what ha2g_conv2d_fwd_planes_stat_blocks reports for this geometry", stat_nblk);
+    return conv2d_fwd_planes_impl(x, x_ps, w, w_ps, np, y, N, H, W, Cin, Cout, KH, KW, stride, pad, relu, (double*)stat_part, stat_nblk, stream);
+}
+static int conv2d_fwd_planes_impl(const void* x, long x_ps, const void* w, long w_ps, int np, float* y, int N, int H, int W, int Cin, int Cout, int KH,
+                                  int KW, int stride, int pad, int relu, double* stat, int stat_nblk, void* stream) {
     HA2G_REQUIRE(ha2g_conv2d_fwd_planes_supported(Cin, Cout, KH, KW, stride, pad), "conv2d_fwd_planes: unsupported geometry");
     HA2G_REQUIRE(np == 3, "conv2d_fwd_planes: np = %d (the forward runs on three pieces only: fp32-class)", np);
     const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
@@ -1934,6 +2035,7 @@ int ha2g_conv2d_fwd_planes_np_f32(const void* x, long x_ps, const void* w, long 
     for (int kh = 0; kh < KH; ++kh)
         for (int kw = 0; kw < KW; ++kw) { c.tap[c.ntaps] = kh * KW + kw; c.doff[c.ntaps] = kh * W + kw; ++c.ntaps; }
     p.ncls = 1; p.cls[0] = c;
+    p.stat = stat; p.stat_nblk = stat_nblk;
     if (c.M == 0) return 0;
     set_plane_bytes(p, (long)N * H * W * Cin, (long)Cout * KH * KW * Cin);
     if (int rc = pconv_dispatch<3, 0>(p, c.M, (hipStream_t)stream)) return rc;

@@ -637,6 +637,8 @@ __global__ __launch_bounds__(NT, 1) void gru_fwd_cluster3_kernel(const float* __
 //            carry' = dh*z + sum_src partial_src.   The carry never leaves the owning thread's registers.
 constexpr int LDG = 3 * 64 + 4;      // LDS row stride of the own d gh tile [16][3][64]
 constexpr int LDP = 64 + 4;
+constexpr int G3_GATE = 16 * 128, G3_PIECE = 3 * G3_GATE;     // AR = 3: bytes of one (piece, gate) plane of the own gate-gradient tile / of one piece
+constexpr int BWD3_LDS = TPW * W2_WAVE + 3 * G3_PIECE;        // dynamic LDS of gru_bwd_cluster_kernel<3>: piece 2 of W + the gate-gradient piece planes
 constexpr int NKW = (NJT + TPW - 1) / TPW;             // k-tiles per wave (5): wave w serves k-tiles w, w+4, ... = one per member
 
 // ---- split-bf16 BPTT (ha2g_gemm_set_mode bit 2, the data-gradient class) ------------------------------------------------------------------
@@ -664,7 +666,9 @@ __device__ __forceinline__ f32x4 mfma3_bf16(const float4& w, const float4& d, f3
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi_of(w), hi_of(d), acc, 0, 0, 0);
 }
 
-template <int Q, int PB, int AR>      // AR = 0: fp32 MFMA chain, 2: two-piece split (mode 6), 3: three-piece split (fp32-class, round 4)
+// ABL: the timing ablations of ha2g_gru_cluster_debug bits 8 .. 64 are compiled in (a second instantiation: the branches cost the product kernel
+// 150 -> 178 us when they sat in it)
+template <int Q, int PB, int AR, bool ABL>      // AR = 0: fp32 MFMA chain, 2: two-piece split (mode 6), 3: three-piece split (fp32-class, round 4)
 __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ rs,
                                                const float* __restrict__ wpt, float* __restrict__ dg, float* __restrict__ hpo, const __amdgpu_buffer_rsrc_t xr,
                                                int* __restrict__ err, const int B, const int T, const int dir, const int b0,
@@ -685,6 +689,7 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
     // pieces 0 / 1 in registers (240 per lane), piece 2 in this wave's LDS region (30 KB; each lane re-reads the 16 bytes it stored)
     bf16x8g_t v0[AR == 3 ? NKW : 1][3][2], v1[AR == 3 ? NKW : 1][3][2];
     uint4* const w2 = AR == 3 ? reinterpret_cast<uint4*>(lds3 + wave * W2_WAVE) + lane : nullptr;      // + ((kk * 3 + gate) * 2 + blk) * 64
+    unsigned char* const gpl = AR == 3 ? lds3 + TPW * W2_WAVE : nullptr;     // piece planes of the own gate gradients: [piece][gate][row 16][64 units bf16 = 8 slots of 16 B, slot ^= row >> 1]
     if constexpr (AR == 3) {
 #pragma unroll
         for (int kk = 0; kk < NKW; ++kk)
@@ -719,7 +724,7 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
                 }
     }
     const int fast = (dbg & 4) ? (cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh), 0) : cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh);
-    for (int i = tid; i < 16 * LDG; i += NT) sg[i] = 0.f;
+    if constexpr (AR != 3) for (int i = tid; i < 16 * LDG; i += NT) sg[i] = 0.f;
     for (int i = tid; i < 16 * LDP; i += NT) sp[i] = 0.f;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 carry = zero4;
@@ -727,7 +732,7 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
     // operands of the step whose gate gradients run next (prefetched during the previous step's MFMA phase)
     float4 n_dy = zero4, n_r = zero4, n_z = zero4, n_n = zero4, n_q = zero4, n_hp = zero4;
 #define HA2G_BWD_LOAD(S)                                                                                          \
-    if (own_ok && (S) < T) {                                                                                      \
+    if (own_ok && (S) < T && !(ABL && (dbg & 64) && (S) > 1)) {                                                          \
         const int t_ = dir ? (S) : T - 1 - (S);                                                                   \
         const int tp_ = dir ? t_ + 1 : t_ - 1;                                                                    \
         const long bt_ = (long)bo * T + t_;                                                                       \
@@ -740,6 +745,24 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
         n_hp = (tp_ >= 0 && tp_ < T) ? *reinterpret_cast<const float4*>(y + ((long)bo * T + tp_) * 2 * H + dir * H + jo) : zero4; \
     }
     HA2G_BWD_LOAD(0)
+    // AR = 3: operands TWO steps ahead (m_*), issued right after a step's gather has completed: the polls of the next gather are then issued a
+    // whole MFMA phase behind them (vmcnt retires in order: a poll queued right behind six HBM loads waited for HBM, 0.4 us of the step alone and
+    // more beside the side queue's GEMMs)
+    float4 m_dy = zero4, m_r = zero4, m_z = zero4, m_n = zero4, m_q = zero4, m_hp = zero4;
+#define HA2G_BWD_LOAD2(S)                                                                                         \
+    if (own_ok && (S) < T && !(ABL && (dbg & 64) && (S) > 1)) {                                                   \
+        const int t_ = dir ? (S) : T - 1 - (S);                                                                   \
+        const int tp_ = dir ? t_ + 1 : t_ - 1;                                                                    \
+        const long bt_ = (long)bo * T + t_;                                                                       \
+        m_dy = *reinterpret_cast<const float4*>(dy + bt_ * 2 * H + dir * H + jo);                                 \
+        const float* rp_ = rs + (bt_ * 2 + dir) * 4 * H + jo;                                                     \
+        m_r = *reinterpret_cast<const float4*>(rp_);                                                              \
+        m_z = *reinterpret_cast<const float4*>(rp_ + H);                                                          \
+        m_n = *reinterpret_cast<const float4*>(rp_ + 2 * H);                                                      \
+        m_q = *reinterpret_cast<const float4*>(rp_ + 3 * H);                                                      \
+        m_hp = (tp_ >= 0 && tp_ < T) ? *reinterpret_cast<const float4*>(y + ((long)bo * T + tp_) * 2 * H + dir * H + jo) : zero4; \
+    }
+    if constexpr (AR == 3) { HA2G_BWD_LOAD2(1) }
     lds_barrier();
 
     // AR = 3: the six piece products (smallest first) of k tile KK x 32-unit block BLK, the three gates on independent accumulators
@@ -771,7 +794,7 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
 #define HA2G_BWD_KTILE(KK)                                                                                        \
     if (wave + (KK) * TPW < NJT) {                                                                                \
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;                                                        \
-        if constexpr (AR == 3) { HA2G_BWD_MFMA3(KK, 0) HA2G_BWD_MFMA3(KK, 1) }                                    \
+        if constexpr (AR == 3) { if (!(ABL && (dbg & 16))) { HA2G_BWD_MFMA3(KK, 0) HA2G_BWD_MFMA3(KK, 1) } }         \
         else _Pragma("unroll") for (int jl = 0; jl < TPW; ++jl) {                                                 \
             const float* w0 = &wf[((KK) * 3 + 0) * TPW + jl].x; const float* w1 = &wf[((KK) * 3 + 1) * TPW + jl].x; \
             const float* w2 = &wf[((KK) * 3 + 2) * TPW + jl].x;                                                   \
@@ -821,35 +844,46 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
                 o_q[u] = a_n * pr[u];
                 o_c[u] = dh * pz[u];
             }
+            if (!(ABL && (dbg & 32))) {
             float* gp = dg + (bt * 2 + dir) * 4 * H + jo;
             *reinterpret_cast<float4*>(gp) = dar;
             *reinterpret_cast<float4*>(gp + H) = daz;
             *reinterpret_cast<float4*>(gp + 2 * H) = dan;
             *reinterpret_cast<float4*>(gp + 3 * H) = dghn;
             if (hpo) *reinterpret_cast<float4*>(hpo + bt * 2 * H + dir * H + jo) = n_hp;      // h_prev of this step: the dW_hh GEMM's operand
+            }
         }
         if (s + 1 == T) break;                              // the carry out of the last step is never used (h0 is constant)
-        *reinterpret_cast<float4*>(&sg[bb * LDG + jl4]) = dar;
-        *reinterpret_cast<float4*>(&sg[bb * LDG + 64 + jl4]) = daz;
-        *reinterpret_cast<float4*>(&sg[bb * LDG + 128 + jl4]) = dghn;
+        if constexpr (AR == 3) {
+            // the three gates' gradients enter the LDS tile as bf16 piece planes: split ONCE here by the thread that computed them (every wave of
+            // phase 2 split the whole fp32 tile again before: 24 split3 pairs per lane and step, 0.6 us of the 4.4 us step)
+            auto gstore = [&](int gate, const float4& v) {
+                unsigned a[3], c[3];
+                if (ABL && (dbg & 8)) { a[0] = a[1] = a[2] = __float_as_uint(v.x); c[0] = c[1] = c[2] = __float_as_uint(v.z); }
+                else { split3_bf16(v.x, v.y, a[0], a[1], a[2]); split3_bf16(v.z, v.w, c[0], c[1], c[2]); }
+                unsigned char* d = gpl + gate * G3_GATE + bb * 128 + (((jl4 >> 3) ^ (bb >> 1)) << 4) + ((jl4 & 4) << 1);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(d + q * G3_PIECE) = make_uint2(a[q], c[q]);
+            };
+            gstore(0, dar); gstore(1, daz); gstore(2, dghn);
+        } else {
+            *reinterpret_cast<float4*>(&sg[bb * LDG + jl4]) = dar;
+            *reinterpret_cast<float4*>(&sg[bb * LDG + 64 + jl4]) = daz;
+            *reinterpret_cast<float4*>(&sg[bb * LDG + 128 + jl4]) = dghn;
+        }
         lds_barrier();
-        HA2G_BWD_LOAD(s + 1)                                // next step's operands: in flight during the MFMA phase
+        if constexpr (AR != 3) { HA2G_BWD_LOAD(s + 1) }      // next step's operands: in flight during the MFMA phase
         // ---- phase 2: partial sums for all k from the own units; foreign destinations first ----
         float4 bop[AR == 3 ? 1 : 3 * TPW];
         bf16x8g_t bq[3][3][2];                               // AR = 3: [piece][gate][32-unit block]: lane (row lb, units 32 blk + 8 g .. + 7)
         if constexpr (AR == 3) {
 #pragma unroll
-            for (int gate = 0; gate < 3; ++gate)
+            for (int q = 0; q < 3; ++q)
 #pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {
-                    const float4 x0 = *reinterpret_cast<const float4*>(&sg[lb * LDG + gate * 64 + 32 * blk + 8 * g]);
-                    const float4 x1 = *reinterpret_cast<const float4*>(&sg[lb * LDG + gate * 64 + 32 * blk + 8 * g + 4]);
-                    unsigned e0[3], e1[3], e2[3], e3[3];
-                    split3_bf16(x0.x, x0.y, e0[0], e0[1], e0[2]); split3_bf16(x0.z, x0.w, e1[0], e1[1], e1[2]);
-                    split3_bf16(x1.x, x1.y, e2[0], e2[1], e2[2]); split3_bf16(x1.z, x1.w, e3[0], e3[1], e3[2]);
+                for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) bq[q][gate][blk] = __builtin_bit_cast(bf16x8g_t, make_uint4(e0[q], e1[q], e2[q], e3[q]));
-                }
+                    for (int blk = 0; blk < 2; ++blk)
+                        bq[q][gate][blk] = *reinterpret_cast<const bf16x8g_t*>(gpl + q * G3_PIECE + gate * G3_GATE + lb * 128 + (((4 * blk + g) ^ (lb >> 1)) << 4));
         } else {
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate)
@@ -877,9 +911,9 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
         if (wave + Q * TPW < NJT) {
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
             if constexpr (AR == 3) {
-                HA2G_BWD_MFMA3(Q, 0)
+                if (!(ABL && (dbg & 16))) { HA2G_BWD_MFMA3(Q, 0) }
                 HA2G_BWD_GATHER_ISSUE                          // the gather loads travel under the second block's 18 MFMAs
-                HA2G_BWD_MFMA3(Q, 1)
+                if (!(ABL && (dbg & 16))) { HA2G_BWD_MFMA3(Q, 1) }
             } else
 #pragma unroll
             for (int jl = 0; jl < TPW; ++jl) {
@@ -935,10 +969,14 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
             carry.x += p.x; carry.y += p.y; carry.z += p.z; carry.w += p.w;
         }
         if (!own_ok) carry = zero4;
+        if constexpr (AR == 3) {
+            n_dy = m_dy; n_r = m_r; n_z = m_z; n_n = m_n; n_q = m_q; n_hp = m_hp;
+            HA2G_BWD_LOAD2(s + 2)
+        }
     }
 }
 
-template <int AR>
+template <int AR, bool ABL = false>
 __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __restrict__ dy,      // [B][T][2H]
                                                                 const float* __restrict__ y,       // [B][T][2H]
                                                                 const float* __restrict__ rs,      // [B][T][2][4][H]
@@ -948,8 +986,8 @@ __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __r
                                                                 u64* __restrict__ xch, const unsigned* __restrict__ epoch, unsigned host_tag0,
                                                                 int* __restrict__ err, int B, int T, int tile0, int nclusters, int dbg,
                                                                 const uint4* __restrict__ wp3t) {  // AR = 3: three-piece transposed images
-    extern __shared__ __attribute__((aligned(1024))) unsigned char bwd_lds3[];                    // AR = 3: TPW * W2_WAVE bytes (piece 2 of W)
-    __shared__ __attribute__((aligned(16))) float sg[16 * LDG];
+    extern __shared__ __attribute__((aligned(1024))) unsigned char bwd_lds3[];                    // AR = 3: BWD3_LDS bytes (piece 2 of W, gate-gradient piece planes)
+    __shared__ __attribute__((aligned(16))) float sg[AR == 3 ? 4 : 16 * LDG];                      // AR = 3: the gate-gradient tile lives in the dynamic region as piece planes
     __shared__ __attribute__((aligned(16))) float sp[16 * LDP];
     __shared__ int sh[8];
     const int id = blockIdx.x, xcd = id & 7, r = id >> 3;
@@ -959,7 +997,7 @@ __global__ __launch_bounds__(NT, 1) void gru_bwd_cluster_kernel(const float* __r
     u64* xc = xch + (long)c * CL_GRAN;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xc, 0, (int)(CL_GRAN * 8), 0x00020000);
     const unsigned tag0 = epoch ? (0x80000000u | (*epoch << 6)) : host_tag0;
-#define HA2G_BWD_CALL(QQ, PP) gru_bwd_member<QQ, PP, AR>(dy, y, rs, wpt, dg, hpo, xr, err, B, T, dir, b0, tag0, sh, dbg, sg, sp, wp3t, bwd_lds3)
+#define HA2G_BWD_CALL(QQ, PP) gru_bwd_member<QQ, PP, AR, ABL>(dy, y, rs, wpt, dg, hpo, xr, err, B, T, dir, b0, tag0, sh, dbg, sg, sp, wp3t, bwd_lds3)
 #define HA2G_BWD_SWITCH(PP)                                                                                       \
     switch (q) {                                                                                                  \
         case 0: HA2G_BWD_CALL(0, PP); break; case 1: HA2G_BWD_CALL(1, PP); break; case 2: HA2G_BWD_CALL(2, PP); break; \
@@ -1112,8 +1150,9 @@ static int gru_bwd_cluster_launch(const float* dy, const float* y, const float* 
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
         if (!attr_set[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_cluster_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, TPW * W2_WAVE) != hipSuccess)
-                return ha2g_set_error(-2, "gru_bwd_cluster3: cannot raise the dynamic LDS limit to %d bytes", TPW * W2_WAVE);
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_cluster_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD3_LDS) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_cluster_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD3_LDS) != hipSuccess)
+                return ha2g_set_error(-2, "gru_bwd_cluster3: cannot raise the dynamic LDS limit to %d bytes", BWD3_LDS);
             attr_set[dev] = true;
         }
     }
@@ -1129,8 +1168,10 @@ static int gru_bwd_cluster_launch(const float* dy, const float* y, const float* 
         unsigned host_tag0 = 0;
         const unsigned* epoch = launch_tag_base(xch, st, &host_tag0);
         const int grid = ceil_div(nclusters, 8) * 8 * G;
-        if (wp3t != nullptr)
-            hipLaunchKernelGGL(gru_bwd_cluster_kernel<3>, dim3(grid), dim3(NT), TPW * W2_WAVE, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg, (const uint4*)wp3t);
+        if (wp3t != nullptr && (g_dbg & ~7))                    // timing ablations (bits 8 .. 64): the instantiation that carries their branches
+            hipLaunchKernelGGL((gru_bwd_cluster_kernel<3, true>), dim3(grid), dim3(NT), BWD3_LDS, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg, (const uint4*)wp3t);
+        else if (wp3t != nullptr)
+            hipLaunchKernelGGL((gru_bwd_cluster_kernel<3, false>), dim3(grid), dim3(NT), BWD3_LDS, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg, (const uint4*)wp3t);
         else if (gemm_split_dgrad_enabled() && gemm_bwd_pieces() == 2)     // two-piece split chain (mode 6); exact fp32 in mode 0
             hipLaunchKernelGGL(gru_bwd_cluster_kernel<2>, dim3(grid), dim3(NT), 0, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg, (const uint4*)nullptr);
         else

@@ -14,7 +14,7 @@ int ha2g_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int ha2g_abi_version(void) { return 3; }      // 2: guarded Adam, ha2g_sparse_adam2_f32, N-piece plane entry points (*_np); 3: ha2g_gru_cluster_tile_cap
+extern "C" int ha2g_abi_version(void) { return 4; }      // 2: guarded Adam, ha2g_sparse_adam2_f32, N-piece plane entry points (*_np); 3: ha2g_gru_cluster_tile_cap; 4: BatchNorm statistics from the forward convolution's epilogue
 
 namespace {
 

@@ -152,31 +152,41 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// one BLOCK per column: wave w adds the partials b = 64 j + lane of its quarter [w nq, (w + 1) nq) of the blocks (four loads per trip in flight), a
+// fixed shuffle tree per wave, the four wave sums added in wave order by thread 0: deterministic.  (One wave per column read a convolution
+// epilogue's 2 560 tile sums in 8.8 us.)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ part, int nblk, long rows, int C,
                                                              const T* __restrict__ x, float* __restrict__ mean,
                                                              float* __restrict__ invstd, float* __restrict__ rmean,
                                                              float* __restrict__ rvar, float momentum, float eps) {
-    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    __shared__ double red[8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.x;
+    const int nq = (nblk + 3) >> 2, b0 = w * nq, b1 = min(nblk, b0 + nq);
+    const double* p1 = part + (long)c * nblk;
+    const double* p2 = part + ((long)C + c) * nblk;
     double s1 = 0.0, s2 = 0.0;
-    {   // partials in fixed order, four pairs of loads per trip in flight
-        int b = lane;
-        for (; b + 192 < nblk; b += 256) {
-            double p1[4], p2[4];
+    {
+        int b = b0 + lane;
+        for (; b + 192 < b1; b += 256) {
+            double q1[4], q2[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { p1[j] = part[(long)c * nblk + b + 64 * j]; p2[j] = part[((long)C + c) * nblk + b + 64 * j]; }
+            for (int j = 0; j < 4; ++j) { q1[j] = p1[b + 64 * j]; q2[j] = p2[b + 64 * j]; }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { s1 += p1[j]; s2 += p2[j]; }
+            for (int j = 0; j < 4; ++j) { s1 += q1[j]; s2 += q2[j]; }
         }
-        for (; b < nblk; b += 64) { s1 += part[(long)c * nblk + b]; s2 += part[((long)C + c) * nblk + b]; }
+        for (; b < b1; b += 64) { s1 += p1[b]; s2 += p2[b]; }
     }
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-    if (lane != 0) return;
+    if (lane == 0) { red[w] = s1; red[4 + w] = s2; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    s1 = ((red[0] + red[1]) + red[2]) + red[3];
+    s2 = ((red[4] + red[5]) + red[6]) + red[7];
     double n = (double)rows, m1 = s1 / n;
     double var = s2 / n - m1 * m1;
     if (var < 0.0) var = 0.0;
-    double mu = (double)ld1(x, c) + m1;
+    double mu = (x != nullptr ? (double)ld1(x, c) : 0.0) + m1;      // x == null: unshifted partial sums (a convolution epilogue's)
     mean[c] = (float)mu;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     if (rmean) {
@@ -501,7 +511,7 @@ int bn_stats_t(const T* x, long rows, int C, float* mean, float* invstd, float* 
     int nb = chunk_blocks(rows);
     hipLaunchKernelGGL((col_partial_kernel<0, T>), dim3(nb), dim3(256), 0, st, x, (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, rows, C,
                        (double*)ws);
-    hipLaunchKernelGGL(bn_stats_final_kernel<T>, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, rows, C, x, mean, invstd, running_mean,
+    hipLaunchKernelGGL(bn_stats_final_kernel<T>, dim3(C), dim3(256), 0, st, (const double*)ws, nb, rows, C, x, mean, invstd, running_mean,
                        running_var, momentum, eps);
     HA2G_CHECK_LAUNCH("bn_stats");
     return 0;
@@ -597,6 +607,17 @@ extern "C" {
 long ha2g_bn_workspace_floats(int C) { return (long)NB_MAX * 2 * C * 2; }   /* partials are doubles */
 
 // mean/invstd [C] out; running_mean/var updated in place when non-null.  x is [rows][C], C in {4,8,...,1024} with 256 % (C/4) == 0.
+// mean / invstd / running statistics from per-block partial sums [2][C][nblk] (sum, sum of squares; doubles) that a producer's epilogue left
+// behind (ha2g_conv2d_fwd_planes_np_stats_f32): the second half of ha2g_bn_stats_f32 without its pass over the tensor.  nn.BatchNorm2d in training
+// mode (ResNetBlocks.py:27-28,34): biased variance for the normalisation, unbiased for running_var, momentum 0.1.
+int ha2g_bn_stats_finalize_f32(const void* part, int nblk, long rows, int C, float* mean, float* invstd, float* running_mean, float* running_var,
+                               float momentum, float eps, void* stream) {
+    HA2G_REQUIRE(part != nullptr && nblk > 0 && rows > 0 && C > 0, "bn_stats_finalize: empty input");
+    hipLaunchKernelGGL(bn_stats_final_kernel<float>, dim3(C), dim3(256), 0, (hipStream_t)stream, (const double*)part, nblk, rows, C,
+                       (const float*)nullptr, mean, invstd, running_mean, running_var, momentum, eps);
+    HA2G_CHECK_LAUNCH("bn_stats_finalize");
+    return 0;
+}
 int ha2g_bn_stats_f32(const float* x, long rows, int C, float* mean, float* invstd, float* running_mean, float* running_var,
                       float momentum, float eps, float* ws, void* stream) {
     return bn_stats_t<float>(x, rows, C, mean, invstd, running_mean, running_var, momentum, eps, ws, stream);

@@ -817,6 +817,15 @@ def bn_stats(x2, running_mean, running_var, momentum, eps):
     return mean, invstd
 
 
+def bn_stats_finalize(part, nblk, rows, C, running_mean, running_var, momentum, eps):
+    """mean / invstd (+ running statistics) from the per-block sums [2, C, nblk] (float64) a convolution's epilogue wrote
+    (ha2g_conv2d_fwd_planes_np_stats_f32): bn_stats without its pass over the tensor."""
+    mean, invstd = torch.empty(C, dtype=torch.float32, device=part.device), torch.empty(C, dtype=torch.float32, device=part.device)
+    ktimer.launch('bn_stats_finalize', lambda: check(lib.ha2g_bn_stats_finalize_f32(
+        part.data_ptr(), nblk, rows, C, mean.data_ptr(), invstd.data_ptr(), _p(running_mean), _p(running_var), momentum, eps, _stream())), 0)
+    return mean, invstd
+
+
 def bn_apply(x2, mean, invstd, gamma, beta, act=ACT_NONE, out=None):
     rows, C = x2.shape
     if out is None:

@@ -63,16 +63,33 @@ def fwd_planes_ok(w_ohwi, stride, pad):
     return FWD3 and lib.ha2g_gemm_bwd_pieces() == 3 and bool(lib.ha2g_conv2d_fwd_planes_supported(Cin, Cout, KH, KW, stride, pad))
 
 
-def conv_fwd_planes(xp, wpl, xshape, stride, pad, act):
-    """conv_fwd on the piece planes of x [3, N, H, W, Cin] and of the OHWI weight [3, Cout, KH, KW, Cin]; act: ACT_NONE / ACT_RELU; fp32 output."""
+CONV_BN_STATS = True      # the statistics of the BatchNorm behind a forward plane convolution come out of the convolution's epilogue (no column pass)
+_stat_blocks = {}
+
+
+def conv_fwd_planes(xp, wpl, xshape, stride, pad, act, stats=False):
+    """conv_fwd on the piece planes of x [3, N, H, W, Cin] and of the OHWI weight [3, Cout, KH, KW, Cin]; act: ACT_NONE / ACT_RELU; fp32 output.
+    stats=True: returns (y, st) with st = (partial sums [2, Cout, nblk] float64, nblk) of y for ops.bn_stats_finalize when this geometry's kernel
+    carries the statistics epilogue, else st = None."""
     N, H, W, Cin = xshape
     _, Cout, KH, KW, _ = wpl.shape
     OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     y = torch.empty(N, OH, OW, Cout, dtype=torch.float32, device=xp.device)
+    if stats:
+        key = (N, H, W, Cin, Cout, KH, KW, stride, pad)
+        nblk = _stat_blocks.get(key)
+        if nblk is None:
+            nblk = _stat_blocks[key] = int(lib.ha2g_conv2d_fwd_planes_stat_blocks(*key)) if CONV_BN_STATS else 0
+        if nblk > 0:
+            part = torch.empty(2, Cout, nblk, dtype=torch.float64, device=xp.device)
+            ops.ktimer.launch('conv2d_fwd_planes', lambda: check(lib.ha2g_conv2d_fwd_planes_np_stats_f32(
+                xp.data_ptr(), xp.stride(0), wpl.data_ptr(), wpl.stride(0), xp.shape[0], y.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                1 if act == ACT_RELU else 0, part.data_ptr(), nblk, _stream())), 2.0 * N * OH * OW * Cout * KH * KW * Cin)
+            return y, (part, nblk)
     ops.ktimer.launch('conv2d_fwd_planes', lambda: check(lib.ha2g_conv2d_fwd_planes_np_f32(
         xp.data_ptr(), xp.stride(0), wpl.data_ptr(), wpl.stride(0), xp.shape[0], y.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad,
         1 if act == ACT_RELU else 0, _stream())), 2.0 * N * OH * OW * Cout * KH * KW * Cin)
-    return y
+    return (y, None) if stats else y
 
 
 def prepare_fwd_weight_planes(P):
@@ -274,14 +291,17 @@ _FWD_PLANES = [False]      # this forward will be back-propagated through the pl
 _WILL_BWD = [True]
 
 
-def _bn_fwd(x, bn, pool=False, planes=False, planes_only=False):
+def _bn_fwd(x, bn, pool=False, planes=False, planes_only=False, stats=None):
     """BatchNorm forward; pool=True also returns the per-image channel means of the output (the SE squeeze), fused; planes=True appends the
-    (hi, lo) bf16 planes of the output (written by the same apply pass)."""
+    (hi, lo) bf16 planes of the output (written by the same apply pass); stats = the partial sums x's producer left behind (conv_fwd_planes)."""
     x2 = _rows(x)
     if not _TRAINING[0]:                                    # module.eval(): running statistics, no update
         mean, invstd = bn.rm, ops.eltwise(ops.OP_RSQRT_EPS, bn.rv, alpha=1e-5)
     else:
-        mean, invstd = ops.bn_stats(x2, bn.rm, bn.rv, 0.1, 1e-5)
+        if stats is not None:
+            mean, invstd = ops.bn_stats_finalize(stats[0], stats[1], x2.shape[0], x2.shape[1], bn.rm, bn.rv, 0.1, 1e-5)
+        else:
+            mean, invstd = ops.bn_stats(x2, bn.rm, bn.rv, 0.1, 1e-5)
         if bn.nbt is not None:
             _NBT_PENDING.append(bn.nbt)                    # num_batches_tracked += 1, batched into one launch per forward
     if pool:
@@ -480,8 +500,11 @@ def block_fwd(x, P, b, first, xp=None, out_planes=0, wpl=None):
     wa, wb = _ohwi(P[b + 'conv1.weight']), _ohwi(P[b + 'conv2.weight'])
     wpl = wpl or {}
     x3 = xp is not None and xp.shape[0] == 3
+    st1 = st2 = None
     if x3 and (b + 'conv1.weight') in wpl:
-        c1 = conv_fwd_planes(xp, wpl[b + 'conv1.weight'], x.shape, stride, 1, ACT_RELU)
+        c1 = conv_fwd_planes(xp, wpl[b + 'conv1.weight'], x.shape, stride, 1, ACT_RELU, stats=_TRAINING[0])
+        if _TRAINING[0]:
+            c1, st1 = c1
     else:
         c1 = conv_fwd(x, wa, None, stride, 1, ACT_RELU)                 # relu(conv1)
     a1p = None
@@ -493,13 +516,18 @@ def block_fwd(x, P, b, first, xp=None, out_planes=0, wpl=None):
         # W >= 37 and the plane weight gradient unsupported; HA2G_PLANES may switch either off): otherwise the fp32 tensor is materialised too.
         bwd_on_planes = dgrad_planes_ok(wb, 1, 1) and wgrad_planes_ok(c1, wb, 1, 1)
         only = f2 and (not _WILL_BWD[0] or bwd_on_planes)
-        a1, m1, s1, a1p = _bn_fwd(c1, P[b + 'bn1'], planes=3 if f2 else 2, planes_only=only)
+        a1, m1, s1, a1p = _bn_fwd(c1, P[b + 'bn1'], planes=3 if f2 else 2, planes_only=only, stats=st1)
         if a1 is None:
             a1 = a1p[0]                                            # bf16 piece 0: NOT the activation -- _gconv() refuses non-fp32 operands
     else:
-        a1, m1, s1 = _bn_fwd(c1, P[b + 'bn1'])
-    c2 = conv_fwd_planes(a1p, wpl[b + 'conv2.weight'], a1.shape, 1, 1, ACT_NONE) if f2 else conv_fwd(a1, wb, None, 1, 1, ACT_NONE)
-    b2, m2, s2, pooled = _bn_fwd(c2, P[b + 'bn2'], pool=True)         # bn2 + SE squeeze in one pass
+        a1, m1, s1 = _bn_fwd(c1, P[b + 'bn1'], stats=st1)
+    if f2:
+        c2 = conv_fwd_planes(a1p, wpl[b + 'conv2.weight'], a1.shape, 1, 1, ACT_NONE, stats=_TRAINING[0])
+        if _TRAINING[0]:
+            c2, st2 = c2
+    else:
+        c2 = conv_fwd(a1, wb, None, 1, 1, ACT_NONE)
+    b2, m2, s2, pooled = _bn_fwd(c2, P[b + 'bn2'], pool=True, stats=st2)         # bn2 + SE squeeze in one pass
     N, OH, OW, C = b2.shape
     h1 = ops.gemm(pooled, P[b + 'se.fc.0.weight'], transb=True, bias=P[b + 'se.fc.0.bias'], act=ACT_RELU)
     # the gate straight out of the GEMM's sigmoid epilogue (the same 1 / (1 + expf(-v)) on the same v as a separate pointwise launch:
@@ -508,11 +536,14 @@ def block_fwd(x, P, b, first, xp=None, out_planes=0, wpl=None):
     su = None
     if first:
         wd = _ohwi(P[b + 'downsample.0.weight'])
+        std = None
         if x3 and (b + 'downsample.0.weight') in wpl:
-            cd = conv_fwd_planes(xp, wpl[b + 'downsample.0.weight'], x.shape, 2, 0, ACT_NONE)
+            cd = conv_fwd_planes(xp, wpl[b + 'downsample.0.weight'], x.shape, 2, 0, ACT_NONE, stats=_TRAINING[0])
+            if _TRAINING[0]:
+                cd, std = cd
         else:
             cd = conv_fwd(x, wd, None, 2, 0, ACT_NONE)
-        res, md, sd = _bn_fwd(cd, P[b + 'downsample.1'])
+        res, md, sd = _bn_fwd(cd, P[b + 'downsample.1'], stats=std)
     else:
         res, cd, md, sd = x, None, None, None
     out = torch.empty_like(b2)

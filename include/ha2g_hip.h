@@ -24,7 +24,7 @@ extern "C" {
 
 /* Bumped whenever an exported signature changes or entry points are added that a host must not mix with an older library:
  * ha2g_amd/_lib.py refuses to bind a library whose ha2g_abi_version() differs from this macro. */
-#define HA2G_ABI_VERSION 3
+#define HA2G_ABI_VERSION 4
 int ha2g_abi_version(void);
 const char* ha2g_last_error(void);
 
@@ -94,6 +94,13 @@ int ha2g_f32_to_planes_multi_np(const void* const* x, void* const* planes, const
 int ha2g_conv2d_fwd_planes_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
 int ha2g_conv2d_fwd_planes_np_f32(const void* x, long x_ps, const void* w, long w_ps, int np, float* y, int N, int H, int W, int Cin, int Cout, int KH,
                                   int KW, int stride, int pad, int relu, void* stream);
+/* ... with the statistics of the BatchNorm that follows (conv -> [ReLU] -> BatchNorm, model/ResNetBlocks.py:24-29) left behind by the same launch:
+ * stat_part [2][Cout][stat_nblk] doubles = per row tile the sum and the sum of squares of the stored output; stat_nblk =
+ * ha2g_conv2d_fwd_planes_stat_blocks(...) (0: this geometry's kernel has no statistics epilogue -- run ha2g_bn_stats_f32 on y instead);
+ * ha2g_bn_stats_finalize_f32 turns the partial sums into mean / invstd / running statistics (ABI 4) */
+int ha2g_conv2d_fwd_planes_stat_blocks(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int ha2g_conv2d_fwd_planes_np_stats_f32(const void* x, long x_ps, const void* w, long w_ps, int np, float* y, int N, int H, int W, int Cin, int Cout,
+                                        int KH, int KW, int stride, int pad, int relu, void* stat_part, int stat_nblk, void* stream);
 /* dense products on three-piece planes (nn.Linear / GRU input projections and their backward, model/hierarchy_net.py:87-93,144-147):
  * ha2g_f32_to_planes_2d_np splits a 2-D fp32 operand into K-contiguous, zero-padded piece planes (transpose = 1: the planes hold x^T);
  * ha2g_gemm_planes_np_f32: C [M][N] = act(A B^T + bias) + beta C from the planes of A [M][lda] and B [N][ldb], lda = ldb = K rounded up to 32 */
@@ -264,6 +271,9 @@ int ha2g_gru_layer_bwd(const float* dy, const float* y, const float* rs, const f
 long ha2g_bn_workspace_floats(int C);
 int ha2g_bn_stats_f32(const float* x, long rows, int C, float* mean, float* invstd, float* running_mean,
                       float* running_var, float momentum, float eps, float* ws, void* stream);
+/* the second half of ha2g_bn_stats_f32 on partial sums [2][C][nblk] (doubles: sum, sum of squares per block) a producer's epilogue wrote */
+int ha2g_bn_stats_finalize_f32(const void* part, int nblk, long rows, int C, float* mean, float* invstd, float* running_mean,
+                               float* running_var, float momentum, float eps, void* stream);
 int ha2g_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                       float* y, long rows, int C, int act, void* stream);
 /* BatchNorm apply fused with the SE squeeze that follows bn2 (model/ResNetBlocks.py:29-36,81-83): y = bn(x) for x [N][HW][C]

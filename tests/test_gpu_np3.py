@@ -309,3 +309,66 @@ def test_patch_resident_kernel_is_bit_identical_to_the_q_kernel(B, H, W, C, Cout
     assert float((got[0].double() - y64).abs().max() / y64.abs().max()) < 3e-6
     d64 = torch.nn.functional.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
     assert float((got[2].double() - d64).abs().max() / d64.abs().max()) < 3e-6
+
+
+@pytest.mark.parametrize('relu', [False, True])
+@pytest.mark.parametrize('B,H,W,C,Cout,k,stride', [(4, 64, 35, 64, 64, 3, 1), (3, 64, 35, 64, 64, 3, 1), (4, 32, 18, 128, 128, 3, 1), (5, 16, 9, 256, 256, 3, 1),
+                                                   (2, 13, 11, 64, 128, 3, 1), (1, 7, 5, 64, 64, 3, 1), (2, 64, 63, 64, 64, 3, 1), (128, 32, 18, 128, 128, 3, 1),
+                                                   (4, 64, 35, 32, 64, 3, 2), (4, 64, 35, 32, 64, 1, 2), (3, 32, 18, 64, 128, 3, 2), (5, 16, 9, 128, 256, 1, 2),
+                                                   (128, 64, 35, 32, 64, 1, 2)])
+def test_batchnorm_statistics_from_the_convolution_epilogue(B, H, W, C, Cout, k, stride, relu):
+    """ha2g_conv2d_fwd_planes_np_stats_f32: the forward plane convolution leaves per-tile column sums of its stored output behind and
+    ha2g_bn_stats_finalize_f32 turns them into the BatchNorm's mean / invstd / running statistics (conv -> [ReLU] -> BN, ResNetBlocks.py:24-29):
+    (a) the output is the bits of the plain launch, (b) mean / var agree with float64 statistics of that output to 1e-6 of the channel scale -- the
+    accuracy of the separate column pass (ha2g_bn_stats_f32), which is run beside it -- (c) the running statistics receive the same update.
+    3x3 / stride 1: the patch-resident kernel's epilogue; stride 2, 1x1 and the 63-wide image: the q kernel's."""
+    from ha2g_amd import wav_engine as we
+    torch.manual_seed(5)
+    pad = 1 if k == 3 else 0
+    x = torch.randn(B, H, W, C, device=DEV)
+    w = torch.randn(Cout, k, k, C, device=DEV) * 0.05
+    xp, wp = ops.to_planes(x, 3), ops.to_planes(w.contiguous(), 3)
+    act = we.ACT_RELU if relu else we.ACT_NONE
+    y0 = we.conv_fwd_planes(xp, wp, x.shape, stride, pad, act)
+    y1, st = we.conv_fwd_planes(xp, wp, x.shape, stride, pad, act, stats=True)
+    nblk = lib.ha2g_conv2d_fwd_planes_stat_blocks(B, H, W, C, Cout, k, k, stride, pad)
+    assert st is not None and st[1] == nblk > 0
+    assert torch.equal(y0, y1)
+    rows = y0.numel() // Cout
+    rm0, rv0 = torch.randn(Cout, device=DEV), torch.rand(Cout, device=DEV) + 0.5
+    rm_a, rv_a, rm_b, rv_b = rm0.clone(), rv0.clone(), rm0.clone(), rv0.clone()
+    mean_a, inv_a = ops.bn_stats_finalize(st[0], st[1], rows, Cout, rm_a, rv_a, 0.1, 1e-5)
+    mean_b, inv_b = ops.bn_stats(y0.view(rows, Cout), rm_b, rv_b, 0.1, 1e-5)
+    y64 = y0.double().view(rows, Cout)
+    m64, v64 = y64.mean(0), y64.var(0, unbiased=False)
+    scale = float(y64.abs().max())
+    for got in (mean_a, mean_b):
+        assert float((got.double() - m64).abs().max()) < 1e-6 * scale, float((got.double() - m64).abs().max()) / scale
+    i64 = 1.0 / torch.sqrt(v64 + 1e-5)
+    for got in (inv_a, inv_b):
+        assert float(((got.double() - i64) / i64).abs().max()) < 2e-6, float(((got.double() - i64) / i64).abs().max())
+    assert float((rm_a - rm_b).abs().max()) < 1e-6 * scale and float(((rv_a - rv_b) / rv_b).abs().max()) < 2e-6
+    # the partial sums themselves: every tile's sums add up to the column sums
+    # (a lane adds its <= 9 pixels in fp32 before the double reduction: 9 roundings of 6e-8 relative to the terms)
+    s64 = st[0].sum(2)
+    e1 = float(((s64[0] - y64.sum(0)).abs() / y64.abs().sum(0).clamp_min(1e-30)).max())
+    e2 = float(((s64[1] - (y64 * y64).sum(0)).abs() / (y64 * y64).sum(0).clamp_min(1e-30)).max())
+    assert e1 < 1e-6 and e2 < 1e-6, (e1, e2)
+
+
+def test_convolution_epilogue_statistics_are_off_where_the_kernel_cannot_write_them():
+    """the eight-wave ping-pong form of the plane kernel (ha2g_conv_planes_tile3(4), an A/B form) has no statistics epilogue: the query reports 0
+    blocks and the caller keeps the column pass; asking for statistics with a block count the geometry does not have is an error, not a silent skip."""
+    try:
+        lib.ha2g_conv_planes_tile3(4)
+        assert lib.ha2g_conv2d_fwd_planes_stat_blocks(4, 64, 35, 64, 64, 3, 3, 1, 1) == 0
+    finally:
+        lib.ha2g_conv_planes_tile3(0)
+    x = torch.randn(2, 16, 9, 64, device=DEV)
+    w = torch.randn(64, 3, 3, 64, device=DEV)
+    xp, wp = ops.to_planes(x, 3), ops.to_planes(w, 3)
+    y = torch.empty(2, 16, 9, 64, device=DEV)
+    part = torch.empty(2, 64, 7, dtype=torch.float64, device=DEV)
+    rc = lib.ha2g_conv2d_fwd_planes_np_stats_f32(xp.data_ptr(), xp.stride(0), wp.data_ptr(), wp.stride(0), 3, y.data_ptr(), 2, 16, 9, 64, 64, 3, 3, 1, 1, 0,
+                                                 part.data_ptr(), 7, torch.cuda.current_stream().cuda_stream)
+    assert rc != 0

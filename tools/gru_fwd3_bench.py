@@ -61,8 +61,36 @@ for B in (384, 128):
     b32 = lambda: check(lib.ha2g_gru_layer_bwd_cluster(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pk[2].data_ptr(), dg.data_ptr(), hp.data_ptr(), xch.data_ptr(), err.data_ptr(), B, T, H, st))
     b3 = lambda: check(lib.ha2g_gru_layer_bwd_cluster3(dy.data_ptr(), y.data_ptr(), rs.data_ptr(), pk3t.data_ptr(), dg3.data_ptr(), hp.data_ptr(), xch.data_ptr(), err.data_ptr(), B, T, H, st))
     for name, fn in (('BPTT fp32 chain', b32), ('BPTT three-piece chain', b3)):
-        us = t_us(fn)
-        print('%-6d %-28s %10.1f %10.2f %10.1f %12.3f' % (B, name, us, us / T, flops / us / 1e6, flops / us / 1e6 / 157.3))
+        abl = ((0, ''),) if fn is b32 else ((0, ''), (2, ' [no exchange]'), (1, ' [no poll wait]'), (8, ' [no split]'), (16, ' [no MFMA]'), (32, ' [no dg stores]'),
+                                            (64, ' [no operand loads]'), (96, ' [no HBM traffic]'), (2 + 8 + 16 + 96, ' [phase 1 + barriers only]'))
+        for dbg, dn in abl:
+            lib.ha2g_gru_cluster_debug(dbg)
+            us = t_us(fn)
+            print('%-6d %-28s %10.1f %10.2f %10.1f %12.3f' % (B, name + dn, us, us / T, flops / us / 1e6, flops / us / 1e6 / 157.3))
+        lib.ha2g_gru_cluster_debug(0)
+    # the same launch beside a stream of weight-gradient-shaped products on a second queue (what the train step's side queue does to it)
+    ga, gb = torch.randn(B * T, 900, device=dev), torch.randn(B * T, 600, device=dev)
+    gout = torch.empty(900, 600, device=dev)
+    s2 = torch.cuda.Stream(dev)
+    def contended(fn, iters=10):
+        fn(); torch.cuda.synchronize()
+        with torch.cuda.stream(s2):
+            for _ in range(iters * 6):
+                ops.gemm(ga, gb, transa=True, out=gout)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / iters * 1e3
+    for dbg, dn in ((0, ''), (2, ' [no exchange]'), (32, ' [no dg stores]'), (64, ' [no operand loads]'), (96, ' [no HBM traffic]')):
+        lib.ha2g_gru_cluster_debug(dbg)
+        us = contended(b3)
+        print('%-6d %-28s %10.1f %10.2f   beside dW GEMMs on a second queue' % (B, 'BPTT three-piece' + dn, us, us / T))
+    lib.ha2g_gru_cluster_debug(0)
+    us = contended(f3)
+    print('%-6d %-28s %10.1f %10.2f   beside dW GEMMs on a second queue' % (B, 'forward three-piece', us, us / T))
     b32(); b3()
     torch.cuda.synchronize()
     print('       max |dg3 - dg32| / max |dg32| = %.3e; err word %d' % (float((dg3 - dg).abs().max() / dg.abs().max()), int(err.item())))
