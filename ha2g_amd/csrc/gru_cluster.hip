@@ -625,6 +625,11 @@ __global__ __launch_bounds__(NT, 1) void gru_fwd_cluster3_kernel(const float* __
 }
 
 
+// timing probe of the BPTT step (ha2g_gru_cluster_debug bit 7, ablation instantiation only): wave 0 of every member of cluster 0 adds the shader-clock
+// cycles between eight points of the step loop into g_bwd_prof[member][phase]; ha2g_gru_cluster_prof copies the table out
+__device__ unsigned long long g_bwd_prof[G * 16];
+#define HA2G_PROF(K) if (ABL && prof) { const long long t_ = (long long)__builtin_readcyclecounter(); pacc[K] += t_ - tlast; tlast = t_; }
+
 // ---- backward (BPTT), cluster form -------------------------------------------------------------------------------------
 // Member q owns hidden units [64q, 64q+64).  Per step (reverse of the forward order):
 //   phase 1  gate gradients of the OWN units (one (row, 4-unit) group per thread): dg -> HBM, d gh -> LDS, dh*z kept in regs;
@@ -728,6 +733,8 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
     for (int i = tid; i < 16 * LDP; i += NT) sp[i] = 0.f;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 carry = zero4;
+    const bool prof = ABL && (dbg & 128) && blockIdx.x < 8 * G && (blockIdx.x & 7) == 0 && wave == 0;      // cluster 0 (xcd 0, r < G)
+    long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 
     // operands of the step whose gate gradients run next (prefetched during the previous step's MFMA phase)
     float4 n_dy = zero4, n_r = zero4, n_z = zero4, n_n = zero4, n_q = zero4, n_hp = zero4;
@@ -749,20 +756,27 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
     // whole MFMA phase behind them (vmcnt retires in order: a poll queued right behind six HBM loads waited for HBM, 0.4 us of the step alone and
     // more beside the side queue's GEMMs)
     float4 m_dy = zero4, m_r = zero4, m_z = zero4, m_n = zero4, m_q = zero4, m_hp = zero4;
+    // running pointers of this thread's operands (step S of the time loop is time t = dir ? S : T - 1 - S: every tensor advances by a constant per
+    // step; the per-step 64-bit index arithmetic of the first form was 550 + 300 cycles of the 9 500-cycle step, tools/gru_fwd3_bench.py probe)
+    const long st2 = (dir ? 2L : -2L) * H, st8 = (dir ? 8L : -8L) * H;
+    const long bt0 = (long)bo * T + (dir ? 0 : T - 1);
+    const float* ld_dy = dy + (bt0 * 2 + dir) * H + jo + st2;              // operands of step 1 (HA2G_BWD_LOAD2 advances them)
+    const float* ld_rs = rs + (bt0 * 2 + dir) * 4 * H + jo + st8;
+    const float* ld_y = y + (bt0 * 2 + dir) * H + jo + 2 * st2;            // h_prev of step S = y at step S + 1 (zero behind the last step)
+    int ld_s = 1;
 #define HA2G_BWD_LOAD2(S)                                                                                         \
-    if (own_ok && (S) < T && !(ABL && (dbg & 64) && (S) > 1)) {                                                   \
-        const int t_ = dir ? (S) : T - 1 - (S);                                                                   \
-        const int tp_ = dir ? t_ + 1 : t_ - 1;                                                                    \
-        const long bt_ = (long)bo * T + t_;                                                                       \
-        m_dy = *reinterpret_cast<const float4*>(dy + bt_ * 2 * H + dir * H + jo);                                 \
-        const float* rp_ = rs + (bt_ * 2 + dir) * 4 * H + jo;                                                     \
-        m_r = *reinterpret_cast<const float4*>(rp_);                                                              \
-        m_z = *reinterpret_cast<const float4*>(rp_ + H);                                                          \
-        m_n = *reinterpret_cast<const float4*>(rp_ + 2 * H);                                                      \
-        m_q = *reinterpret_cast<const float4*>(rp_ + 3 * H);                                                      \
-        m_hp = (tp_ >= 0 && tp_ < T) ? *reinterpret_cast<const float4*>(y + ((long)bo * T + tp_) * 2 * H + dir * H + jo) : zero4; \
-    }
+    if (own_ok && ld_s < T && !(ABL && (dbg & 64) && ld_s > 1)) {                                                 \
+        m_dy = *reinterpret_cast<const float4*>(ld_dy);                                                           \
+        m_r = *reinterpret_cast<const float4*>(ld_rs);                                                            \
+        m_z = *reinterpret_cast<const float4*>(ld_rs + H);                                                        \
+        m_n = *reinterpret_cast<const float4*>(ld_rs + 2 * H);                                                    \
+        m_q = *reinterpret_cast<const float4*>(ld_rs + 3 * H);                                                    \
+        m_hp = ld_s + 1 < T ? *reinterpret_cast<const float4*>(ld_y) : zero4;                                     \
+    }                                                                                                             \
+    ld_dy += st2; ld_rs += st8; ld_y += st2; ++ld_s;
     if constexpr (AR == 3) { HA2G_BWD_LOAD2(1) }
+    float* st_dg = dg + (bt0 * 2 + dir) * 4 * H + jo;                      // this step's dg / h_prev rows
+    float* st_hp = hpo ? hpo + (bt0 * 2 + dir) * H + jo : nullptr;
     lds_barrier();
 
     // AR = 3: the six piece products (smallest first) of k tile KK x 32-unit block BLK, the three gates on independent accumulators
@@ -824,6 +838,7 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
 
     for (int s = 0; s < T; ++s) {
         const int t = dir ? s : T - 1 - s;
+        if (ABL && prof) tlast = (long long)__builtin_readcyclecounter();
         // ---- phase 1 ----
         float4 dar = zero4, daz = zero4, dghn = zero4, dhz = zero4;
         if (own_ok) {
@@ -845,15 +860,17 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
                 o_c[u] = dh * pz[u];
             }
             if (!(ABL && (dbg & 32))) {
-            float* gp = dg + (bt * 2 + dir) * 4 * H + jo;
+            float* gp = AR == 3 ? st_dg : dg + (bt * 2 + dir) * 4 * H + jo;
             *reinterpret_cast<float4*>(gp) = dar;
             *reinterpret_cast<float4*>(gp + H) = daz;
             *reinterpret_cast<float4*>(gp + 2 * H) = dan;
             *reinterpret_cast<float4*>(gp + 3 * H) = dghn;
-            if (hpo) *reinterpret_cast<float4*>(hpo + bt * 2 * H + dir * H + jo) = n_hp;      // h_prev of this step: the dW_hh GEMM's operand
+            if (hpo) *reinterpret_cast<float4*>(AR == 3 ? st_hp : hpo + bt * 2 * H + dir * H + jo) = n_hp;      // h_prev of this step: the dW_hh GEMM's operand
             }
         }
+        if constexpr (AR == 3) { st_dg += st8; st_hp += st2; }
         if (s + 1 == T) break;                              // the carry out of the last step is never used (h0 is constant)
+        HA2G_PROF(0)                                        // 0: gate gradients + dg stores issued
         if constexpr (AR == 3) {
             // the three gates' gradients enter the LDS tile as bf16 piece planes: split ONCE here by the thread that computed them (every wave of
             // phase 2 split the whole fp32 tile again before: 24 split3 pairs per lane and step, 0.6 us of the 4.4 us step)
@@ -871,7 +888,9 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
             *reinterpret_cast<float4*>(&sg[bb * LDG + 64 + jl4]) = daz;
             *reinterpret_cast<float4*>(&sg[bb * LDG + 128 + jl4]) = dghn;
         }
+        HA2G_PROF(1)                                        // 1: split + LDS writes
         lds_barrier();
+        HA2G_PROF(2)                                        // 2: barrier A
         if constexpr (AR != 3) { HA2G_BWD_LOAD(s + 1) }      // next step's operands: in flight during the MFMA phase
         // ---- phase 2: partial sums for all k from the own units; foreign destinations first ----
         float4 bop[AR == 3 ? 1 : 3 * TPW];
@@ -894,10 +913,13 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
                 }
         }
         const unsigned tag = tag0 + (unsigned)(s + 1);
+        // (one straight run of the four foreign tiles' 144 MFMAs with the publishes batched behind it was tried: 160 vs 146 us per launch -- eight
+        //  stores in one burst put every receiver's LAST partial behind six others; tile by tile the first three drain under later MFMAs)
         HA2G_BWD_KTILE((Q + 1) % G)
         HA2G_BWD_KTILE((Q + 2) % G)
         HA2G_BWD_KTILE((Q + 3) % G)
         HA2G_BWD_KTILE((Q + 4) % G)
+        HA2G_PROF(3)                                        // 3: fragment reads + four foreign k tiles + publishes
         // own block last: the four foreign blocks are travelling; the gather loads are issued after PB of its 4 j-tiles
         u32x4 gx0[G], gx1[G];                                // statically indexed only (member Q's slot stays unused)
 #define HA2G_BWD_GATHER_ISSUE                                                                                     \
@@ -912,7 +934,8 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
             if constexpr (AR == 3) {
                 if (!(ABL && (dbg & 16))) { HA2G_BWD_MFMA3(Q, 0) }
-                HA2G_BWD_GATHER_ISSUE                          // the gather loads travel under the second block's 18 MFMAs
+                HA2G_BWD_GATHER_ISSUE                          // the gather loads travel under the second block's 18 MFMAs (issued after the own tile
+                                                               // or after the barrier instead: the same step time -- the wait is for the data, not for a poll round)
                 if (!(ABL && (dbg & 16))) { HA2G_BWD_MFMA3(Q, 1) }
             } else
 #pragma unroll
@@ -939,7 +962,9 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
         } else {
             HA2G_BWD_GATHER_ISSUE
         }
+        HA2G_PROF(4)                                        // 4: own k tile + gather issue
         lds_barrier();
+        HA2G_PROF(5)                                        // 5: barrier B
         // ---- gather: carry' = dh*z + sum over members (ascending) of their partial for my 4 units ----
         float4 part[G];
         const float4 own_part = *reinterpret_cast<const float4*>(&sp[bb * LDP + jl4]);
@@ -969,10 +994,17 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
             carry.x += p.x; carry.y += p.y; carry.z += p.z; carry.w += p.w;
         }
         if (!own_ok) carry = zero4;
+        HA2G_PROF(6)                                        // 6: poll wait + carry sum
         if constexpr (AR == 3) {
             n_dy = m_dy; n_r = m_r; n_z = m_z; n_n = m_n; n_q = m_q; n_hp = m_hp;
             HA2G_BWD_LOAD2(s + 2)
         }
+        HA2G_PROF(7)                                        // 7: operand hand-over (waits for the loads issued a step ago) + next loads issued
+    }
+    if (ABL && prof && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g_bwd_prof[Q * 16 + k] = (unsigned long long)pacc[k];
+        g_bwd_prof[Q * 16 + 8] = (unsigned long long)(T - 1);
     }
 }
 
@@ -1069,6 +1101,10 @@ static int g_dbg = 0;
 extern "C" {
 
 void ha2g_gru_cluster_debug(int m) { g_dbg = m; }
+// the BPTT step probe's table (debug bit 7): out[member 5][16] = cycles per phase summed over the steps of the last probed launch, [8] = steps
+int ha2g_gru_cluster_prof(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_prof), sizeof(unsigned long long) * G * 16) == hipSuccess ? 0 : ha2g_set_error(-2, "gru_cluster_prof: copy failed");
+}
 /* every workgroup of a cluster launch must be co-resident: a process that SHARES its device (two ranks on one GPU, a co-resident service) caps the tiles
  * per launch at its share of the compute units / 10 (0 = the whole device, the default); larger batches take more launches */
 void ha2g_gru_cluster_tile_cap(int tiles) { g_tile_cap = tiles > 0 ? tiles : 0; }

@@ -255,6 +255,9 @@ int ha2g_gru_layer_bwd_cluster(const float* dy, const float* y, const float* rs,
                                int* err, int B, int T, int H, void* stream);
 /* ablation bits for tools/dbg_cluster.py: 1 no wait, 2 no exchange, 4 force the write-through publish */
 void ha2g_gru_cluster_debug(int mode);
+/* timing probe of the BPTT step loop (debug bit 7 of ha2g_gru_cluster_debug, tools/gru_fwd3_bench.py): out[5 members][16] = shader-clock cycles per
+ * phase of wave 0 of cluster 0, summed over the steps of the last probed launch; [m][8] = the number of steps.  HOST pointer. */
+int ha2g_gru_cluster_prof(unsigned long long* out);
 /* ABI 3 (round 5): a process that shares its device caps the 16-row tiles of one cluster launch at its share of compute units / 10 (0 = whole device) */
 void ha2g_gru_cluster_tile_cap(int tiles);
 /* test aid: `blocks` (1..256) workgroups that each hold one compute unit's whole LDS for `microseconds` on `stream` -- a stand-in for a foreign

@@ -68,6 +68,24 @@ for B in (384, 128):
             us = t_us(fn)
             print('%-6d %-28s %10.1f %10.2f %10.1f %12.3f' % (B, name + dn, us, us / T, flops / us / 1e6, flops / us / 1e6 / 157.3))
         lib.ha2g_gru_cluster_debug(0)
+    # where a BPTT step goes: shader-clock cycles between eight points of the step loop, wave 0 of the five members of cluster 0 (debug bit 7)
+    import numpy as np
+    names = ['gate gradients + dg stores', 'split3 + LDS writes', 'barrier A', 'fragment reads + 4 foreign k tiles', 'own k tile + gather issue', 'barrier B',
+             'poll wait + carry', 'operand hand-over + loads']
+    for dbg, dn in ((128, ''), (128 + 2, ' [no exchange]')):
+        lib.ha2g_gru_cluster_debug(dbg)
+        us = t_us(b3, iters=5)
+        tab = np.zeros(5 * 16, np.uint64)
+        check(lib.ha2g_gru_cluster_prof(tab.ctypes.data))
+        tab = tab.reshape(5, 16).astype(np.float64)
+        steps = tab[0, 8]
+        tot = tab[:, :8].sum(1) / steps
+        print('%-6d BPTT step probe%s: %.1f us / launch (probed), cycles per step and member (0..4), mean:' % (B, dn, us))
+        for k, nm in enumerate(names):
+            print('         %-36s %s   %7.0f' % (nm, ' '.join('%6.0f' % (tab[m, k] / steps) for m in range(5)), tab[:, k].mean() / steps))
+        print('         %-36s %s   %7.0f  (= %.2f us per step at %.2f GHz if the probed launch took its time in the loop)' % (
+            'sum', ' '.join('%6.0f' % v for v in tot), tot.mean(), us / T, tot.mean() / (us / T) / 1e3))
+    lib.ha2g_gru_cluster_debug(0)
     # the same launch beside a stream of weight-gradient-shaped products on a second queue (what the train step's side queue does to it)
     ga, gb = torch.randn(B * T, 900, device=dev), torch.randn(B * T, 600, device=dev)
     gout = torch.empty(900, 600, device=dev)
