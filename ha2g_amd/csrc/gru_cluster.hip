@@ -33,6 +33,7 @@
 // caller then uses gru.hip) on a device or partition with fewer than 2 G compute units.
 #include "common.h"
 #include <mutex>
+#include <type_traits>
 #include <unordered_map>
 
 namespace {
@@ -677,9 +678,10 @@ template <int Q, int PB, int AR, bool ABL>      // AR = 0: fp32 MFMA chain, 2: t
 __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ rs,
                                                const float* __restrict__ wpt, float* __restrict__ dg, float* __restrict__ hpo, const __amdgpu_buffer_rsrc_t xr,
                                                int* __restrict__ err, const int B, const int T, const int dir, const int b0,
-                                               const unsigned tag0, int* __restrict__ sh, const int dbg, float* __restrict__ sg,
+                                               const unsigned tag0, int* __restrict__ sh, const int dbg_in, float* __restrict__ sg,
                                                float* __restrict__ sp, const uint4* __restrict__ wp3t = nullptr, unsigned char* __restrict__ lds3 = nullptr) {
     constexpr bool SPL = AR == 2;
+    const int dbg = (AR == 3 && !ABL) ? 0 : dbg_in;          // the three-piece product kernel carries NO debug branch (the host launches the ABL instantiation for any debug bit)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lb = lane & 15, g = lane >> 4;
     constexpr int k0 = Q * 64;                              // first own unit
@@ -728,7 +730,12 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
                     wf[(kk * 3 + gate) * TPW + jl] = SPL ? split_pack4(v) : v;
                 }
     }
-    const int fast = (dbg & 4) ? (cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh), 0) : cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh);
+    const int fast_rt = (dbg & 4) ? (cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh), 0) : cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh);
+    // AR = 3: the step loop is instantiated for both placements (publish = plain store / write-through store) so that the publishes carry no branch and
+    // can sit INSIDE the next tile's MFMA run
+    auto body = [&](auto FASTC) {
+    const int fast = FASTC;
+    constexpr bool FAST = std::is_same<decltype(FASTC), std::true_type>::value;
     if constexpr (AR != 3) for (int i = tid; i < 16 * LDG; i += NT) sg[i] = 0.f;
     for (int i = tid; i < 16 * LDP; i += NT) sp[i] = 0.f;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -913,12 +920,35 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
                 }
         }
         const unsigned tag = tag0 + (unsigned)(s + 1);
-        // (one straight run of the four foreign tiles' 144 MFMAs with the publishes batched behind it was tried: 160 vs 146 us per launch -- eight
-        //  stores in one burst put every receiver's LAST partial behind six others; tile by tile the first three drain under later MFMAs)
-        HA2G_BWD_KTILE((Q + 1) % G)
-        HA2G_BWD_KTILE((Q + 2) % G)
-        HA2G_BWD_KTILE((Q + 3) % G)
-        HA2G_BWD_KTILE((Q + 4) % G)
+        if constexpr (AR == 3) {
+            // The four foreign k tiles as one branch-free run of 144 MFMAs (a wave whose tile lies behind the 19th multiplies its zero weight fragments
+            // and its publish is dropped by the buffer's range check; the placement is a template constant): tile i's three gate accumulators are
+            // added and PUBLISHED between the two halves of tile i + 1, under its MFMAs; only the last tile's publish stands alone, right behind its
+            // last MFMA -- every receiver waits for it.  (Tile by tile behind `if (tile exists)` and a two-way store branch the phase took 4 350 cycles
+            // for 2 304 of MFMA issue; all four publishes batched behind the run was slower still, 160 vs 146 us: the critical partial queued behind
+            // six others.)
+            const int kl = 16 * wave + 4 * g;
+            auto pub = [&](auto KKC, const f32x4& pv) {
+                constexpr int KK = decltype(KKC)::value;
+                if (ABL && (dbg & 2)) return;
+                const int go = wave + KK * TPW < NJT ? (((((s & 1) * G + KK) * G + Q) * 16 + lb) * 64 + kl) * 8 : 0x7ffffff0;
+                store_granule_pair<FAST ? 0 : 16>(xr, go, tag, pv[0], pv[1]);
+                store_granule_pair<FAST ? 0 : 16>(xr, go + 16, tag, pv[2], pv[3]);
+            };
+            constexpr int K1 = (Q + 1) % G, K2 = (Q + 2) % G, K3 = (Q + 3) % G, K4 = (Q + 4) % G;
+            const bool mm = !(ABL && (dbg & 16));
+            f32x4 pa, pb;
+            { f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0; if (mm) { HA2G_BWD_MFMA3(K1, 0) HA2G_BWD_MFMA3(K1, 1) } pa = a0 + a1 + a2; }
+            { f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0; if (mm) { HA2G_BWD_MFMA3(K2, 0) } pub(std::integral_constant<int, K1>{}, pa); if (mm) { HA2G_BWD_MFMA3(K2, 1) } pb = a0 + a1 + a2; }
+            { f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0; if (mm) { HA2G_BWD_MFMA3(K3, 0) } pub(std::integral_constant<int, K2>{}, pb); if (mm) { HA2G_BWD_MFMA3(K3, 1) } pa = a0 + a1 + a2; }
+            { f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0; if (mm) { HA2G_BWD_MFMA3(K4, 0) } pub(std::integral_constant<int, K3>{}, pa); if (mm) { HA2G_BWD_MFMA3(K4, 1) } pb = a0 + a1 + a2; }
+            pub(std::integral_constant<int, K4>{}, pb);
+        } else {
+            HA2G_BWD_KTILE((Q + 1) % G)
+            HA2G_BWD_KTILE((Q + 2) % G)
+            HA2G_BWD_KTILE((Q + 3) % G)
+            HA2G_BWD_KTILE((Q + 4) % G)
+        }
         HA2G_PROF(3)                                        // 3: fragment reads + four foreign k tiles + publishes
         // own block last: the four foreign blocks are travelling; the gather loads are issued after PB of its 4 j-tiles
         u32x4 gx0[G], gx1[G];                                // statically indexed only (member Q's slot stays unused)
@@ -1006,6 +1036,9 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
         for (int k = 0; k < 8; ++k) g_bwd_prof[Q * 16 + k] = (unsigned long long)pacc[k];
         g_bwd_prof[Q * 16 + 8] = (unsigned long long)(T - 1);
     }
+    };
+    if constexpr (AR == 3) { if (fast_rt) body(std::true_type{}); else body(std::false_type{}); }
+    else body(fast_rt);
 }
 
 template <int AR, bool ABL = false>
@@ -1204,7 +1237,7 @@ static int gru_bwd_cluster_launch(const float* dy, const float* y, const float* 
         unsigned host_tag0 = 0;
         const unsigned* epoch = launch_tag_base(xch, st, &host_tag0);
         const int grid = ceil_div(nclusters, 8) * 8 * G;
-        if (wp3t != nullptr && (g_dbg & ~7))                    // timing ablations (bits 8 .. 64): the instantiation that carries their branches
+        if (wp3t != nullptr && g_dbg != 0)                      // any debug bit: the instantiation that carries the debug branches (the product kernel has none)
             hipLaunchKernelGGL((gru_bwd_cluster_kernel<3, true>), dim3(grid), dim3(NT), BWD3_LDS, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg, (const uint4*)wp3t);
         else if (wp3t != nullptr)
             hipLaunchKernelGGL((gru_bwd_cluster_kernel<3, false>), dim3(grid), dim3(NT), BWD3_LDS, st, dy, y, rs, wpt, dg, hp, (u64*)xch, epoch, host_tag0, err, B, T, t0, nclusters, g_dbg, (const uint4*)wp3t);
