@@ -34,6 +34,8 @@ python tools/r_kernel_bench.py 2>/dev/null | grep -vE "Warn|amdgpu" > gpurun_out
 python tools/r_kernel_ablate.py 2>/dev/null | grep -vE "Warn|amdgpu" > gpurun_out/r05_r_kernel_ablate.txt
 python tools/c32_ablate.py 2>/dev/null | grep -vE "Warn|amdgpu" > gpurun_out/r05_c32_ablate.txt
 python tools/gru_fwd3_bench.py 2>/dev/null | grep -vE "Warn|amdgpu" > gpurun_out/r05_gru_fwd3_bench.txt
+python tools/gru_fastpath_ab.py 2>/dev/null | tail -4 > gpurun_out/r05_gru_fastpath_ab.txt
+python tools/gemm_census.py > gpurun_out/r05_gemm_census.txt 2>/dev/null
 KERNEL=pconv_r bash tools/pmc_q.sh r05r > /dev/null 2>&1
 bash tools/pmc_c32.sh r05 > /dev/null 2>&1
 bash tools/step_bytes.sh r05 > /dev/null 2>&1
