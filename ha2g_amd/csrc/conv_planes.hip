@@ -2004,6 +2004,13 @@ int ha2g_conv2d_fwd_planes_stat_blocks(int N, int H, int W, int Cin, int Cout, i
     pconv_q_plan((int)M, Cout, 1, &bmt, &bbn);
     return bmt ? 2 * (int)((M + 32 * bmt - 1) / (32 * bmt)) : 0;
 }
+// > 0: the statistics blocks are tiles INSIDE one image (the patch-resident kernel), that many per image in image order -- per-image column sums
+// (the SE squeeze, ha2g_bn_pool_from_partials_f32) are sums of consecutive blocks; 0: they are not (the q kernel's row groups straddle images) or none
+int ha2g_conv2d_fwd_planes_stat_tiles_per_image(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (!ha2g_conv2d_fwd_planes_supported(Cin, Cout, KH, KW, stride, pad) || !(g_tile3 == 0 && g_q_kernel)) return 0;
+    int bmt = 0, bbn = 0; RGeo g{};
+    return (g_r_kernel && KH == 3 && KW == 3 && stride == 1 && pad == 1 && pconv_r_plan(N, H, W, Cout, bmt, bbn, g)) ? g.gpi : 0;
+}
 static int conv2d_fwd_planes_impl(const void* x, long x_ps, const void* w, long w_ps, int np, float* y, int N, int H, int W, int Cin, int Cout, int KH,
                                   int KW, int stride, int pad, int relu, double* stat, int stat_nblk, void* stream);
 int ha2g_conv2d_fwd_planes_np_f32(const void* x, long x_ps, const void* w, long w_ps, int np, float* y, int N, int H, int W, int Cin, int Cout, int KH,

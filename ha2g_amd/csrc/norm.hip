@@ -308,6 +308,20 @@ __global__ void pool_final_kernel(const double* __restrict__ part, int nchunk, i
     out[i] = v;
 }
 
+// SE squeeze of a BatchNorm's output from the per-tile column sums of its INPUT (a convolution epilogue's, tiles inside one image):
+// pooled[n][c] = (sum of image n's tiles / HW - mean) invstd gamma + beta -- the mean of an affine map is the affine map of the mean
+__global__ void pool_from_partials_kernel(const double* __restrict__ part, int nblk, int gpi, int C, long NC, double inv_hw,
+                                          const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                          const float* __restrict__ beta, float* __restrict__ pooled) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= NC) return;
+    const long n = i / C; const int c = (int)(i - n * C);
+    const double* p = part + (long)c * nblk + n * gpi;
+    double s = 0.0;
+    for (int k = 0; k < gpi; ++k) s += p[k];
+    pooled[i] = (float)((s * inv_hw - (double)mean[c]) * (double)invstd[c] * (double)gamma[c] + (double)beta[c]);
+}
+
 // dx = gamma * invstd * (dy - sum_dy/N - xhat * sum_dy_xhat/N)
 // PL = 1: dx is ALSO (or, with dx == nullptr, ONLY) written as two bf16 planes  hi = bf16(dx), lo = bf16(dx - hi)  -- the operand format of the
 // plane-based split-bf16 consumers (conv_planes.hip): this pass is HBM-bound, the split rides in its shadow, and the convolution data /
@@ -340,10 +354,13 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
 
 // ---- squeeze-excite pieces; x is [N][HW][C] -------------------------------------------------------------
 // per-image column mean (MODE 0) or per-image sum of a*b (MODE 1: ds[n,c] = sum_hw dpre*b2 with dpre = dout*(out>0))
-template <int MODE, typename T>
+// AFF (MODE 1): x is the INPUT of the BatchNorm whose output the sum needs -- b2 = (x - mean) invstd gamma + beta is recomputed per element with
+// bn_apply_pool_kernel's own expression (the same bits), so that the BatchNorm's output need not exist in memory (block_fwd's statistics path)
+struct BnAff { const float* mean; const float* invstd; const float* gamma; const float* beta; };
+template <int MODE, typename T, bool AFF = false>
 __global__ __launch_bounds__(256) void image_col_kernel(const T* __restrict__ x, const T* __restrict__ dout,
                                                         const T* __restrict__ outp, int HW, int C, float* __restrict__ res,
-                                                        float scale, double* __restrict__ part, const float* __restrict__ gate) {
+                                                        float scale, double* __restrict__ part, const float* __restrict__ gate, BnAff aff = BnAff{}) {
     // grid (nchunk, N): block (k, n) sums rows [k*per, (k+1)*per) of image n; part == nullptr (nchunk = 1): final floats to res, else
     // double partials [n][k][C] for pool_final_kernel (more blocks than images: a 128-image batch alone fills half the CUs)
     constexpr int V = VW<T>::V;
@@ -354,13 +371,17 @@ __global__ __launch_bounds__(256) void image_col_kernel(const T* __restrict__ x,
     const int rbeg = blockIdx.x * per, rend = min(HW, rbeg + per);
     const long base = (long)blockIdx.y * HW * C;
     dvec<V> a = dzero<V>();
+    fvec<V> mu, is, g, b;
+    if (AFF) { mu = ldp<V>(aff.mean, m.cv); is = ldp<V>(aff.invstd, m.cv); g = ldp<V>(aff.gamma, m.cv); b = ldp<V>(aff.beta, m.cv); }
     // one block per image: four rows per trip so that 4 (MODE 0) / 12 (MODE 1) 16-byte loads are in flight per wave; the adds keep the row
     // order of the one-row loop (bit-identical sums)
     auto accum = [&](const fvec<V>& v, const fvec<V>& d, const fvec<V>& o) {
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            if (MODE == 1) a.v[k] += o.v[k] > 0.f ? (double)v.v[k] * d.v[k] : 0.0;
-            else a.v[k] += v.v[k];
+            float vk = v.v[k];
+            if (AFF) vk = (vk - mu.v[k]) * is.v[k] * g.v[k] + b.v[k];
+            if (MODE == 1) a.v[k] += o.v[k] > 0.f ? (double)vk * d.v[k] : 0.0;
+            else a.v[k] += vk;
         }
     };
     int r = rbeg + m.r0;
@@ -406,18 +427,24 @@ __global__ __launch_bounds__(256) void image_col_kernel(const T* __restrict__ x,
 }
 
 // out = relu(x * s[n,c] + res)
-template <int PL, typename T>
+template <int PL, typename T, bool AFF = false>
 __global__ void se_scale_add_relu_kernel(const T* __restrict__ x, const float* __restrict__ s, const T* __restrict__ res,
                                          T* __restrict__ out, long N, int HW, int C, unsigned short* __restrict__ o_hi,
-                                         unsigned short* __restrict__ o_lo, int pnp) {
+                                         unsigned short* __restrict__ o_lo, int pnp, BnAff aff = BnAff{}) {
     constexpr int V = VW<T>::V;
     static_assert(!PL || V == 4, "planes are written from fp32 tensors");
     const int CV = C / V;
     const long per = (long)HW * CV, total = N * per;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long n = i / per; const int cv = (int)(i % CV);
-        const fvec<V> v = ldv(x, i), r = ldv(res, i);
+        fvec<V> v = ldv(x, i);
+        const fvec<V> r = ldv(res, i);
         const fvec<V> sc = ldp<V>(s + n * C, cv);
+        if (AFF) {                                          // x is the BatchNorm's INPUT: its output with bn_apply_pool_kernel's expression (the same bits)
+            const fvec<V> mu = ldp<V>(aff.mean, cv), is = ldp<V>(aff.invstd, cv), g = ldp<V>(aff.gamma, cv), b = ldp<V>(aff.beta, cv);
+#pragma unroll
+            for (int k = 0; k < V; ++k) v.v[k] = (v.v[k] - mu.v[k]) * is.v[k] * g.v[k] + b.v[k];
+        }
         fvec<V> o;
 #pragma unroll
         for (int k = 0; k < V; ++k) o.v[k] = fmaxf(v.v[k] * sc.v[k] + r.v[k], 0.f);
@@ -552,18 +579,34 @@ int bn_bwd_t(const T* dy, const T* x, const float* mean, const float* invstd, co
     return 0;
 }
 template <int PL, typename T>
-int se_scale_add_relu_t(const T* x, const float* s, const T* res, T* out, void* o_hi, void* o_lo, int pnp, int N, int HW, int C, void* stream) {
+int se_scale_add_relu_t(const T* x, const float* s, const T* res, T* out, void* o_hi, void* o_lo, int pnp, int N, int HW, int C, void* stream,
+                        const BnAff* aff = nullptr) {
     HA2G_REQUIRE(C % VW<T>::V == 0, "se: C %% 4");
+    if (aff)
+        hipLaunchKernelGGL((se_scale_add_relu_kernel<PL, T, true>), dim3(flat_grid((long)N * HW * (C / VW<T>::V))), dim3(256), 0, (hipStream_t)stream, x, s, res,
+                           out, (long)N, HW, C, (unsigned short*)o_hi, (unsigned short*)o_lo, pnp, *aff);
+    else
     hipLaunchKernelGGL((se_scale_add_relu_kernel<PL, T>), dim3(flat_grid((long)N * HW * (C / VW<T>::V))), dim3(256), 0, (hipStream_t)stream, x, s, res, out,
-                       (long)N, HW, C, (unsigned short*)o_hi, (unsigned short*)o_lo, pnp);
+                       (long)N, HW, C, (unsigned short*)o_hi, (unsigned short*)o_lo, pnp, BnAff{});
     HA2G_CHECK_LAUNCH("se_scale_add_relu");
     return 0;
 }
 template <typename T>
-int se_bwd_scale_t(const T* dout, const T* out, const T* x, float* ds, int N, int HW, int C, const float* gate, float* ws, void* stream) {
+int se_bwd_scale_t(const T* dout, const T* out, const T* x, float* ds, int N, int HW, int C, const float* gate, float* ws, void* stream,
+                   const BnAff* aff = nullptr) {
     HA2G_REQUIRE(okCv<T>(C), "se: unsupported channel count %d", C);
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = ws ? pool_chunks(N, HW) : 1;          // ws: ha2g_bn_apply_pool_workspace_floats(N, HW, C) floats, or null
+    if (aff) {
+        if (nchunk > 1) {
+            hipLaunchKernelGGL((image_col_kernel<1, T, true>), dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, ds, 1.f, (double*)ws, (const float*)nullptr, *aff);
+            hipLaunchKernelGGL(pool_final_kernel, dim3(ceil_div((long)N * C, 256)), dim3(256), 0, st, (const double*)ws, nchunk, C, (long)N * C, 1.f, ds, gate);
+        } else {
+            hipLaunchKernelGGL((image_col_kernel<1, T, true>), dim3(1, N), dim3(256), 0, st, x, dout, out, HW, C, ds, 1.f, (double*)nullptr, gate, *aff);
+        }
+        HA2G_CHECK_LAUNCH("se_bwd_scale_bn");
+        return 0;
+    }
     if (nchunk > 1) {
         hipLaunchKernelGGL((image_col_kernel<1, T>), dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, ds, 1.f, (double*)ws, (const float*)nullptr);
         hipLaunchKernelGGL(pool_final_kernel, dim3(ceil_div((long)N * C, 256)), dim3(256), 0, st, (const double*)ws, nchunk, C, (long)N * C, 1.f, ds,
@@ -687,6 +730,31 @@ int ha2g_se_scale_add_relu_planes_np_f32(const float* x, const float* s, const f
                                          int C, void* stream) {
     HA2G_REQUIRE(planes != nullptr && (np == 2 || np == 3), "se_scale_add_relu_planes_np: null plane / np = %d", np);
     return se_scale_add_relu_t<1, float>(x, s, res, out, planes, (unsigned short*)planes + ps, np, N, HW, C, stream);
+}
+// The SE tail of a block whose bn2 statistics came out of conv2's epilogue (ResNetBlocks.py:29-36,81-95): bn2's output b2 is never materialised.
+//   ha2g_bn_pool_from_partials_f32: the squeeze mean_hw b2 from the per-tile column sums of c2 (stat_part of ha2g_conv2d_fwd_planes_np_stats_f32 when its
+//     tiles lie inside one image: nblk = N * tiles per image, ha2g_conv2d_fwd_planes_stat_tiles_per_image > 0);
+//   ha2g_se_bn_scale_add_relu_np_f32: out = relu(bn2(c2) * s + res) (+ np piece planes of out, np = 0: none) -- bn2(c2) with ha2g_bn_apply_pool_f32's expression;
+//   ha2g_se_bwd_scale_bn_f32: ds[n][c] = sum_hw dout (out > 0) bn2(c2), the gate's sigmoid' folded in as in ha2g_se_bwd_scale_f32.
+int ha2g_bn_pool_from_partials_f32(const void* part, int nblk, int N, int HW, int C, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, float* pooled, void* stream) {
+    HA2G_REQUIRE(part != nullptr && N > 0 && nblk > 0 && nblk % N == 0 && HW > 0, "bn_pool_from_partials: %d blocks do not split over %d images", nblk, N);
+    hipLaunchKernelGGL(pool_from_partials_kernel, dim3(ceil_div((long)N * C, 256)), dim3(256), 0, (hipStream_t)stream, (const double*)part, nblk, nblk / N, C,
+                       (long)N * C, 1.0 / (double)HW, mean, invstd, gamma, beta, pooled);
+    HA2G_CHECK_LAUNCH("bn_pool_from_partials");
+    return 0;
+}
+int ha2g_se_bn_scale_add_relu_np_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* s,
+                                     const float* res, float* out, void* planes, long ps, int np, int N, int HW, int C, void* stream) {
+    HA2G_REQUIRE(np == 0 || (planes != nullptr && (np == 2 || np == 3)), "se_bn_scale_add_relu_np: null plane / np = %d", np);
+    const BnAff aff{mean, invstd, gamma, beta};
+    if (np == 0) return se_scale_add_relu_t<0, float>(x, s, res, out, nullptr, nullptr, 0, N, HW, C, stream, &aff);
+    return se_scale_add_relu_t<1, float>(x, s, res, out, planes, (unsigned short*)planes + ps, np, N, HW, C, stream, &aff);
+}
+int ha2g_se_bwd_scale_bn_f32(const float* dout, const float* out, const float* x, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, float* ds, int N, int HW, int C, const float* gate, float* ws, void* stream) {
+    const BnAff aff{mean, invstd, gamma, beta};
+    return se_bwd_scale_t<float>(dout, out, x, ds, N, HW, C, gate, ws, stream, &aff);
 }
 // ds[n][c] = sum_hw dout*(out>0)*x
 int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, float* ds, int N, int HW, int C, const float* gate, float* ws,

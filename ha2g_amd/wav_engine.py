@@ -63,6 +63,20 @@ def fwd_planes_ok(w_ohwi, stride, pad):
     return FWD3 and lib.ha2g_gemm_bwd_pieces() == 3 and bool(lib.ha2g_conv2d_fwd_planes_supported(Cin, Cout, KH, KW, stride, pad))
 
 
+SE_FROM_STATS = True      # ... and, where the epilogue's tiles lie inside one image, the SE squeeze too: bn2's output is never materialised (block_fwd)
+_tpi = {}
+
+
+def _tiles_per_image(xshape, w_ohwi):
+    key = tuple(xshape) + tuple(w_ohwi.shape)
+    v = _tpi.get(key)
+    if v is None:
+        N, H, W, Cin = xshape
+        Cout, KH, KW, _ = w_ohwi.shape
+        v = _tpi[key] = int(lib.ha2g_conv2d_fwd_planes_stat_tiles_per_image(N, H, W, Cin, Cout, KH, KW, 1, 1))
+    return v
+
+
 CONV_BN_STATS = True      # the statistics of the BatchNorm behind a forward plane convolution come out of the convolution's epilogue (no column pass)
 _stat_blocks = {}
 
@@ -527,8 +541,20 @@ def block_fwd(x, P, b, first, xp=None, out_planes=0, wpl=None):
             c2, st2 = c2
     else:
         c2 = conv_fwd(a1, wb, None, 1, 1, ACT_NONE)
-    b2, m2, s2, pooled = _bn_fwd(c2, P[b + 'bn2'], pool=True, stats=st2)         # bn2 + SE squeeze in one pass
-    N, OH, OW, C = b2.shape
+    bn2 = P[b + 'bn2']
+    N, OH, OW, C = c2.shape
+    if st2 is not None and SE_FROM_STATS and _tiles_per_image(a1.shape, wb) > 0:
+        # conv2's epilogue left per-tile column sums of c2 behind, tiles inside one image: bn2's statistics AND the SE squeeze come from them
+        # (the mean of an affine map is the affine map of the mean), the tail below applies bn2 on the fly -- b2 is never written or re-read
+        m2, s2 = ops.bn_stats_finalize(st2[0], st2[1], N * OH * OW, C, bn2.rm, bn2.rv, 0.1, 1e-5)
+        if bn2.nbt is not None:
+            _NBT_PENDING.append(bn2.nbt)
+        pooled = torch.empty(N, C, dtype=torch.float32, device=c2.device)
+        check(lib.ha2g_bn_pool_from_partials_f32(st2[0].data_ptr(), st2[1], N, OH * OW, C, m2.data_ptr(), s2.data_ptr(), bn2.gamma.data_ptr(),
+                                                 bn2.beta.data_ptr(), pooled.data_ptr(), _stream()))
+        b2 = None
+    else:
+        b2, m2, s2, pooled = _bn_fwd(c2, bn2, pool=True, stats=st2)      # bn2 + SE squeeze in one pass
     h1 = ops.gemm(pooled, P[b + 'se.fc.0.weight'], transb=True, bias=P[b + 'se.fc.0.bias'], act=ACT_RELU)
     # the gate straight out of the GEMM's sigmoid epilogue (the same 1 / (1 + expf(-v)) on the same v as a separate pointwise launch:
     # bit-identical forward); the backward takes sigma' = s (1 - s) from the stored gate
@@ -546,10 +572,15 @@ def block_fwd(x, P, b, first, xp=None, out_planes=0, wpl=None):
         res, md, sd = _bn_fwd(cd, P[b + 'downsample.1'], stats=std)
     else:
         res, cd, md, sd = x, None, None, None
-    out = torch.empty_like(b2)
+    out = torch.empty_like(c2)
     outp = None
     if out_planes:
         outp = torch.empty((out_planes,) + tuple(out.shape), dtype=torch.bfloat16, device=out.device)
+    if b2 is None:
+        check(lib.ha2g_se_bn_scale_add_relu_np_f32(c2.data_ptr(), m2.data_ptr(), s2.data_ptr(), bn2.gamma.data_ptr(), bn2.beta.data_ptr(), sc.data_ptr(),
+                                                   res.data_ptr(), out.data_ptr(), _p(outp), outp.stride(0) if outp is not None else 0, out_planes or 0,
+                                                   N, OH * OW, C, _stream()))
+    elif out_planes:
         check(lib.ha2g_se_scale_add_relu_planes_np_f32(b2.data_ptr(), sc.data_ptr(), res.data_ptr(), out.data_ptr(), outp.data_ptr(), outp.stride(0),
                                                        out_planes, N, OH * OW, C, _stream()))
     else:
@@ -560,17 +591,22 @@ def block_fwd(x, P, b, first, xp=None, out_planes=0, wpl=None):
 def block_bwd(dx, saved, P, b, sink):
     """dx = d(out) NHWC -> d(x) NHWC; parameter gradients go to `sink` (GradSink)."""
     (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride, xp, a1p) = saved
-    N, OH, OW, C = b2.shape
+    N, OH, OW, C = c2.shape
     HW = OH * OW
     dout = dx.contiguous()
-    ds = empty(N, C, like=b2)
-    check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, sc.data_ptr(),
-                                    ops.workspace(dout.device).data_ptr(), _stream()))
+    ds = empty(N, C, like=c2)
+    if b2 is None:                                      # the forward never wrote bn2's output: recomputed per element from c2 (the same bits)
+        bn2 = P[b + 'bn2']
+        check(lib.ha2g_se_bwd_scale_bn_f32(dout.data_ptr(), out.data_ptr(), c2.data_ptr(), m2.data_ptr(), s2.data_ptr(), bn2.gamma.data_ptr(),
+                                           bn2.beta.data_ptr(), ds.data_ptr(), N, HW, C, sc.data_ptr(), ops.workspace(dout.device).data_ptr(), _stream()))
+    else:
+        check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, sc.data_ptr(),
+                                        ops.workspace(dout.device).data_ptr(), _stream()))
     dsc = ds                                            # already times the gate's sigmoid' (folded into the reduction's final pass)
     sink.gwb(b + 'se.fc.2.weight', b + 'se.fc.2.bias', dsc, h1)
     dh1, dpool = se_mlp_bwd(dsc, h1, P[b + 'se.fc.2.weight'], P[b + 'se.fc.0.weight'], HW)
     sink.gwb(b + 'se.fc.0.weight', b + 'se.fc.0.bias', dh1, pooled)
-    dres, db2 = torch.empty_like(b2), torch.empty_like(b2)
+    dres, db2 = torch.empty_like(c2), torch.empty_like(c2)
     check(lib.ha2g_se_bwd_apply_f32(dout.data_ptr(), out.data_ptr(), sc.data_ptr(), dpool.data_ptr(), dres.data_ptr(),
                                     db2.data_ptr(), N, HW, C, _stream()))
     wb = _ohwi(P[b + 'conv2.weight'])

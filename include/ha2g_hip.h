@@ -99,6 +99,7 @@ int ha2g_conv2d_fwd_planes_np_f32(const void* x, long x_ps, const void* w, long 
  * ha2g_conv2d_fwd_planes_stat_blocks(...) (0: this geometry's kernel has no statistics epilogue -- run ha2g_bn_stats_f32 on y instead);
  * ha2g_bn_stats_finalize_f32 turns the partial sums into mean / invstd / running statistics (ABI 4) */
 int ha2g_conv2d_fwd_planes_stat_blocks(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int ha2g_conv2d_fwd_planes_stat_tiles_per_image(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);   /* > 0: blocks = tiles inside one image, that many per image */
 int ha2g_conv2d_fwd_planes_np_stats_f32(const void* x, long x_ps, const void* w, long w_ps, int np, float* y, int N, int H, int W, int Cin, int Cout,
                                         int KH, int KW, int stride, int pad, int relu, void* stat_part, int stat_nblk, void* stream);
 /* dense products on three-piece planes (nn.Linear / GRU input projections and their backward, model/hierarchy_net.py:87-93,144-147):
@@ -311,6 +312,15 @@ int ha2g_se_scale_add_relu_planes_np_f32(const float* x, const float* s, const f
 /* ---- squeeze-excite pointwise pieces (model/ResNetBlocks.py:81-95 and the residual tail :33-36) ---- */
 int ha2g_hw_mean_f32(const float* x, float* out, int N, int HW, int C, void* stream);
 int ha2g_se_scale_add_relu_f32(const float* x, const float* s, const float* res, float* out, int N, int HW, int C, void* stream);
+/* SE tail of a block whose bn2 statistics came out of conv2's epilogue (model/ResNetBlocks.py:29-36,81-95): bn2's output is never materialised.
+ * pooled = the squeeze from the per-tile column sums of c2 (tiles inside one image); out = relu(bn2(c2) * s + res) (+ np piece planes, np = 0: none);
+ * ds = sum_hw dout (out > 0) bn2(c2) -- bn2(c2) recomputed per element with ha2g_bn_apply_pool_f32's expression (the same bits) */
+int ha2g_bn_pool_from_partials_f32(const void* part, int nblk, int N, int HW, int C, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, float* pooled, void* stream);
+int ha2g_se_bn_scale_add_relu_np_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* s,
+                                     const float* res, float* out, void* planes, long ps, int np, int N, int HW, int C, void* stream);
+int ha2g_se_bwd_scale_bn_f32(const float* dout, const float* out, const float* x, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, float* ds, int N, int HW, int C, const float* gate, float* ws, void* stream);
 int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, float* ds, int N, int HW, int C, const float* gate, float* ws,
                           void* stream);   /* gate (nullable) [N][C]: ds is multiplied by gate * (1 - gate), the sigmoid derivative of the SE gate; */
      /* ws: ha2g_bn_apply_pool_workspace_floats(N, HW, C) floats (row-chunked partials) or null (one block per image) */

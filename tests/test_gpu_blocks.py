@@ -235,3 +235,44 @@ def test_default_mode_tower_when_conv2_backward_cannot_run_on_planes(gemm_mode, 
     assert float((o70 - o0).abs().max() / o0.abs().max()) < 1e-4
     cos = float(torch.dot(g70, g0) / (g70.norm() * g0.norm()))
     assert torch.isfinite(g70).all() and cos > 0.999, cos
+
+
+@pytest.mark.parametrize('name', ['l2', 'l3d', 'l3', 'l4'])
+def test_se_tail_without_materialised_bn2_output(name):
+    """Where conv2's epilogue leaves per-tile column sums behind (tiles inside one image), block_fwd takes bn2's statistics AND the SE squeeze from
+    them and applies bn2 on the fly in the tail passes: bn2's output is never written (saved slot None).  Same block, same inputs, against the path
+    that materialises it (wav_engine.SE_FROM_STATS = False): the squeeze differs only by the rounding of a mean (1e-6 of the output / gradient scale
+    bounds everything downstream), and both are held to the reference fixtures by test_se_block_full_size."""
+    from ha2g_amd import ops, wav_engine as we
+    geom = BLOCKFULL_CASES[name]
+    P = engine_P(block_state(name, geom, 31), DEV)
+    x, wl = block_io(name, geom, BLOCKFULL_B, 31)
+    xin, dout = nhwc(x.to(DEV)), nhwc(wl.to(DEV))
+    wpl = {}
+    for n, stride, pad in (('conv1.weight', 2 if geom[4] else 1, 1), ('conv2.weight', 1, 1), ('downsample.0.weight', 2, 0)):
+        if n in P and we.fwd_planes_ok(we._ohwi(P[n]), stride, pad):
+            wpl[n] = ops.to_planes(we._ohwi(P[n]).contiguous(), 3)
+    assert 'conv2.weight' in wpl
+    xp = ops.to_planes(xin, 3) if 'conv1.weight' in wpl else None
+    res = {}
+    try:
+        for on in (True, False):
+            we.SE_FROM_STATS = on
+            we._TRAINING[0] = True
+            we._NBT_PENDING.clear()
+            Pc = {k: (v.clone() if torch.is_tensor(v) else we._BN(v.gamma, v.beta, v.rm.clone(), v.rv.clone(), None)) for k, v in P.items()}
+            out, saved, _ = we.block_fwd(xin, Pc, '', geom[4], xp=xp, wpl=wpl)
+            assert (saved[8] is None) == on, name
+            sink = we.GradSink(Pc)
+            dx = we.block_bwd(dout, saved, Pc, '', sink)
+            sink.join(torch.device(DEV))
+            g = {}
+            for k, gr in sink.G.items():
+                for j, t in enumerate(gr if isinstance(gr, tuple) else (gr,)):
+                    g['%s/%d' % (k, j)] = t.double()
+            res[on] = dict(out=out.double(), dx=dx.double(), rm=Pc['bn2'].rm.double(), rv=Pc['bn2'].rv.double(), **g)
+    finally:
+        we.SE_FROM_STATS = True
+    for k in res[True]:
+        a, b_ = res[True][k], res[False][k]
+        assert float((a - b_).abs().max()) <= 2e-6 * float(b_.abs().max()) + 1e-12, (name, k, float((a - b_).abs().max()), float(b_.abs().max()))
