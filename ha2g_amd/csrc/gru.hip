@@ -241,11 +241,11 @@ __global__ __launch_bounds__(NT) void gru_bwd_kernel(const float* __restrict__ d
                     o_q[u] = a_n * pr[u];
                     o_c[u] = dh * pz[u];
                 }
-                float* gp = dg + (bt * 2 + dir) * 4 * H + j;
+                float* gp = dg + bt * 8 * H + dir * 3 * H + j;              // dg row: [d gi (r z n) fwd][d gi (r z n) rev][d gh_n fwd][d gh_n rev]
                 *reinterpret_cast<float4*>(gp) = dar;
                 *reinterpret_cast<float4*>(gp + H) = daz;
                 *reinterpret_cast<float4*>(gp + 2 * H) = dan;
-                *reinterpret_cast<float4*>(gp + 3 * H) = dghn;
+                *reinterpret_cast<float4*>(dg + bt * 8 * H + 6 * H + dir * H + j) = dghn;
                 if (hpo) *reinterpret_cast<float4*>(hpo + bt * 2 * H + dir * H + j) = hp4;
             }
             *reinterpret_cast<float4*>(&sg[bb * LDG + j]) = dar;
@@ -469,11 +469,11 @@ __global__ __launch_bounds__(64 * GruCfg<H>::NJT) void gru_bwd_small_kernel(cons
                     o_q[u] = a_n * pr[u];
                     o_c[u] = dh * pz[u];
                 }
-                float* gp = dg + (bt * 2 + dir) * 4 * H + j;
+                float* gp = dg + bt * 8 * H + dir * 3 * H + j;              // dg row: [d gi (r z n) fwd][d gi (r z n) rev][d gh_n fwd][d gh_n rev]
                 *reinterpret_cast<float4*>(gp) = dar;
                 *reinterpret_cast<float4*>(gp + H) = daz;
                 *reinterpret_cast<float4*>(gp + 2 * H) = dan;
-                *reinterpret_cast<float4*>(gp + 3 * H) = dghn;
+                *reinterpret_cast<float4*>(dg + bt * 8 * H + 6 * H + dir * H + j) = dghn;
                 if (hpo) *reinterpret_cast<float4*>(hpo + bt * 2 * H + dir * H + j) = n_hp;
             }
             *reinterpret_cast<float4*>(&sg[bb * LDG + j]) = dar;
@@ -533,16 +533,16 @@ int run_pack_multi(const PackBatch& b, int n, hipStream_t st) {
 }  // namespace
 
 namespace {
-// Bias gradients of one bidirectional layer from ONE column sum of the gate-gradient buffer dg [rows][2 dirs][r z n_i n_h]:
+// Bias gradients of one bidirectional layer from ONE column sum of the gate-gradient buffer dg [rows][(r z n_i) fwd | (r z n_i) rev | n_h fwd | n_h rev]:
 //   d b_ih = (r, z, n_i)      d b_hh = (r, z, n_h)      (nn.GRU keeps b_ih and b_hh separate; r and z gradients coincide)
 __global__ void gru_bias_grads_kernel(const float* __restrict__ cs, float* __restrict__ bih0, float* __restrict__ bhh0,
                                       float* __restrict__ bih1, float* __restrict__ bhh1, int H, float beta) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= 6 * H) return;
     const int d = i / (3 * H), j = i % (3 * H);
-    const float* t = cs + 4 * H * d;
+    const float* t = cs + 3 * H * d;
     float* bi = d ? bih1 : bih0; float* bh = d ? bhh1 : bhh0;
-    const float vi = t[j], vh = j < 2 * H ? t[j] : t[j + H];
+    const float vi = t[j], vh = j < 2 * H ? t[j] : cs[6 * H + H * d + (j - 2 * H)];
     bi[j] = (beta != 0.f ? beta * bi[j] : 0.f) + vi;
     bh[j] = (beta != 0.f ? beta * bh[j] : 0.f) + vh;
 }

@@ -782,7 +782,7 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
     }                                                                                                             \
     ld_dy += st2; ld_rs += st8; ld_y += st2; ++ld_s;
     if constexpr (AR == 3) { HA2G_BWD_LOAD2(1) }
-    float* st_dg = dg + (bt0 * 2 + dir) * 4 * H + jo;                      // this step's dg / h_prev rows
+    float* st_dg = dg + bt0 * 8 * H + dir * 3 * H + jo;                    // this step's dg / h_prev rows
     float* st_hp = hpo ? hpo + (bt0 * 2 + dir) * H + jo : nullptr;
     lds_barrier();
 
@@ -867,11 +867,11 @@ __device__ __forceinline__ void gru_bwd_member(const float* __restrict__ dy, con
                 o_c[u] = dh * pz[u];
             }
             if (!(ABL && (dbg & 32))) {
-            float* gp = AR == 3 ? st_dg : dg + (bt * 2 + dir) * 4 * H + jo;
+            float* gp = AR == 3 ? st_dg : dg + bt * 8 * H + dir * 3 * H + jo;       // dg row: [d gi (r z n) fwd][d gi (r z n) rev][d gh_n fwd][d gh_n rev]
             *reinterpret_cast<float4*>(gp) = dar;
             *reinterpret_cast<float4*>(gp + H) = daz;
             *reinterpret_cast<float4*>(gp + 2 * H) = dan;
-            *reinterpret_cast<float4*>(gp + 3 * H) = dghn;
+            *reinterpret_cast<float4*>(gp + (6 - 2 * dir) * H) = dghn;                 // = row + 6H + dir H
             if (hpo) *reinterpret_cast<float4*>(AR == 3 ? st_hp : hpo + bt * 2 * H + dir * H + jo) = n_hp;      // h_prev of this step: the dW_hh GEMM's operand
             }
         }

@@ -1013,6 +1013,7 @@ class BiGRUFunction(torch.autograd.Function):
         saved = []
         inp = x.contiguous()
         packs = []
+        wcats = [None] * L
         pk_all = None
         if PACK_MULTI and 2 * L <= 16:
             # all layers' / directions' W_hh images from ONE launch at the start of the stack (two per layer sat between the recurrences)
@@ -1035,6 +1036,7 @@ class BiGRUFunction(torch.autograd.Function):
                 # chip's rounds (291 -> 181 us at 13056 x 1800 x 600 incl. the operand splits, profiles/r04_plane_gemm_bench.txt)
                 wcat, bcat = torch.cat((w[0], w[4])), torch.cat((w[2], w[6]))
                 ktimer.launch(tkey, lambda: gemm(x2, wcat, transb=True, out=gi, bias=bcat), 2 * fl)
+                wcats[l] = wcat                            # [6H, K]: the backward's dX = dg[:, :6H] @ wcat is one product too
             else:
                 ktimer.launch(tkey, lambda: gemm(x2, w[0], transb=True, out=gi[:, :3 * H], bias=w[2]), fl)
                 ktimer.launch(tkey, lambda: gemm(x2, w[4], transb=True, out=gi[:, 3 * H:], bias=w[6]), fl)
@@ -1062,6 +1064,7 @@ class BiGRUFunction(torch.autograd.Function):
         ctx.H, ctx.L, ctx.masks, ctx.grad_slice = H, L, masks, grad_slice
         ctx.saved_bufs = saved
         ctx.packs = packs
+        ctx.wcats = wcats
         ctx.save_for_backward(*weights)
         return inp
 
@@ -1086,7 +1089,7 @@ class BiGRUFunction(torch.autograd.Function):
             w = weights[8 * l:8 * l + 8]
             if masks is not None and l < L - 1 and masks[l] is not None:
                 dy = eltwise(OP_MUL, dy, masks[l][sl])
-            dg = torch.empty(B * T, 8 * H, dtype=torch.float32, device=dev)        # [dir][r z n hn]
+            dg = torch.empty(B * T, 8 * H, dtype=torch.float32, device=dev)        # [(r z n) fwd | (r z n) rev | hn fwd | hn rev]
             # h_prev per direction (forward dir: y[t-1], reverse dir: y[t+1], zero at the sequence ends) is written by the BPTT kernel
             hp = torch.empty(B, T, 2 * H, dtype=torch.float32, device=dev)
             pk3t = None
@@ -1111,8 +1114,8 @@ class BiGRUFunction(torch.autograd.Function):
                 if FUSE_BIAS_GRAD and GROUP_GRU_WGRAD and all(t is not None for tg in tgs for t in tg):
                     # every target is an installed .grad buffer: the two directions' weight-gradient GEMMs have one shape each -> three grouped
                     # launches (dW_ih, dW_hh rows r z, dW_hh rows n) instead of six, bias gradients riding on them
-                    A = [[dg[:, 4 * H * d:4 * H * d + 3 * H] for d in range(2)], [dg[:, 4 * H * d:4 * H * d + 2 * H] for d in range(2)],
-                         [dg[:, 4 * H * d + 3 * H:4 * H * d + 4 * H] for d in range(2)]]
+                    A = [[dg[:, 3 * H * d:3 * H * d + 3 * H] for d in range(2)], [dg[:, 3 * H * d:3 * H * d + 2 * H] for d in range(2)],
+                         [dg[:, 6 * H + H * d:6 * H + H * (d + 1)] for d in range(2)]]
                     Bm = [[x2, x2], [hp2[:, d * H:(d + 1) * H] for d in range(2)], [hp2[:, d * H:(d + 1) * H] for d in range(2)]]
                     Cm = [[tgs[d][0] for d in range(2)], [tgs[d][1][:2 * H] for d in range(2)], [tgs[d][1][2 * H:] for d in range(2)]]
                     cs = [[tgs[d][2] for d in range(2)], [tgs[d][3][:2 * H] for d in range(2)], [tgs[d][3][2 * H:] for d in range(2)]]
@@ -1121,7 +1124,7 @@ class BiGRUFunction(torch.autograd.Function):
                     fused_b += [True, True]
                 else:
                     for d in range(2):
-                        o = 4 * H * d
+                        o = 3 * H * d
                         dgi = dg[:, o:o + 3 * H]
                         tg = tgs[d]
                         # bias gradients ride on the weight-gradient launches when every target is an installed .grad buffer:
@@ -1137,7 +1140,7 @@ class BiGRUFunction(torch.autograd.Function):
                         dwhh = tg[1] if tg[1] is not None else torch.empty(3 * H, H, dtype=torch.float32, device=dev)
                         hpd = hp2[:, d * H:(d + 1) * H]
                         gemm(dg[:, o:o + 2 * H], hpd, transa=True, out=dwhh[:2 * H], beta=bt, **cs3[1])    # rows r,z
-                        gemm(dg[:, o + 3 * H:o + 4 * H], hpd, transa=True, out=dwhh[2 * H:], beta=bt, **cs3[2])  # rows n (d gh_n)
+                        gemm(dg[:, 6 * H + H * d:6 * H + H * (d + 1)], hpd, transa=True, out=dwhh[2 * H:], beta=bt, **cs3[2])  # rows n (d gh_n)
                         if tg[1] is None:
                             grads[8 * l + 4 * d + 1] = dwhh
                 if not all(fused_b[-2:]):
@@ -1153,16 +1156,18 @@ class BiGRUFunction(torch.autograd.Function):
                     if not direct:
                         for d in range(2):
                             grads[8 * l + 4 * d + 2], grads[8 * l + 4 * d + 3] = outs[d]
-            if need_dx:
-                for d in range(2):                                                  # critical path: dX (+)= dgi W_ih
-                    gemm(dg[:, 4 * H * d:4 * H * d + 3 * H], w[4 * d], out=dx, beta=float(d))
+            if need_dx and ctx.wcats[l] is not None:                                # critical path: dX = [dgi fwd | dgi rev] [W_ih; W_ih_reverse], ONE product
+                gemm(dg[:, :6 * H], ctx.wcats[l], out=dx)                           # (two products of K = 3H with an accumulate pass before: 2 x 121 us in the step)
+            elif need_dx:
+                for d in range(2):                                                  # dX (+)= dgi W_ih
+                    gemm(dg[:, 3 * H * d:3 * H * d + 3 * H], w[4 * d], out=dx, beta=float(d))
             dy = dx.view(B, T, K) if need_dx else None
         side.join(dev)
         if dy is not None and B != Bfull:
             full = torch.zeros(Bfull, T, dy.shape[2], dtype=torch.float32, device=dev)
             full[sl] = dy
             dy = full
-        ctx.saved_bufs = None
+        ctx.saved_bufs = ctx.wcats = None
         return (dy, None, None, None) + tuple(grads)
 
 

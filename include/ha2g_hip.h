@@ -219,7 +219,7 @@ int ha2g_gru_supported_hidden(int H);         /* 300, 64, 32 are instantiated */
 int ha2g_gru_pack_whh(const float* whh, float* packed_fwd, float* packed_bwd, int H, void* stream);
 /* the same for n <= 16 matrices in one launch; whh / pf / pb are HOST arrays of n device pointers */
 int ha2g_gru_pack_whh_multi(const void* const* whh, void* const* pf, void* const* pb, int n, int H, void* stream);
-/* the layer's four bias gradients from ONE column sum (ha2g_colsum_f32) of dg [rows][2][r z n_i n_h]: d b_ih = (r,z,n_i),
+/* the layer's four bias gradients from ONE column sum (ha2g_colsum_f32) of dg [rows][(r z n_i) fwd | (r z n_i) rev | n_h fwd | n_h rev]: d b_ih = (r,z,n_i),
  * d b_hh = (r,z,n_h); beta = 1 accumulates into the destinations */
 int ha2g_gru_bias_grads_f32(const float* colsums, float* dbih_fwd, float* dbhh_fwd, float* dbih_rev, float* dbhh_rev, int H,
                             float beta, void* stream);
@@ -265,7 +265,8 @@ void ha2g_gru_cluster_tile_cap(int tiles);
  * kernel (an RCCL collective of the data-parallel step, scripts/train.py:133-143 replaced by ha2g_amd/ddp.py) that is resident while a cluster
  * GRU launch needs its workgroups co-resident; the launch must then complete or set its error word, never hang.  sink: any device int. */
 int ha2g_debug_occupy(int blocks, long microseconds, int* sink, void* stream);
-/* dg [B][T][2][4H] = (d gi_r, d gi_z, d gi_n, d gh_n); wpt = packed_bwd images (dir 0, dir 1); hp (nullable) [B][T][2H] receives
+/* dg [B][T][8H], a row = [d gi (r z n) of the forward direction | d gi (r z n) of the reverse direction | d gh_n forward | d gh_n reverse]: both
+ * directions' input-gate gradients are contiguous, so dX = dg[:, :6H] [W_ih; W_ih_reverse] is ONE product (d gh = (d gi_r, d gi_z, d gh_n)); wpt = packed_bwd images (dir 0, dir 1); hp (nullable) [B][T][2H] receives
  * the h_prev each step used (y shifted by one step per direction, zero at the sequence ends) = the dW_hh GEMM's operand */
 int ha2g_gru_layer_bwd(const float* dy, const float* y, const float* rs, const float* wpt, float* dg, float* hp, int B, int T,
                        int H, void* stream);
