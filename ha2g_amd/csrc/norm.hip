@@ -767,6 +767,56 @@ int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, c
 }
 
 // dh1 [N][R], dpool [N][C] from dsc [N][C], h1 [N][R], fc.2.weight w2 [C][R], fc.0.weight w0 [R][C]; C <= 256, R <= 32
+// FORWARD of the SE excitation MLP in one launch (ResNetBlocks.py:84-89): per image n
+//   pooled[n][c] = the squeeze -- given, or taken from the per-tile column sums of bn2's INPUT as in pool_from_partials_kernel
+//   h1[n][j]     = relu(b0[j] + sum_c pooled[n][c] w0[j][c])            (fc.0: Linear(C -> R), weight [R][C])
+//   sc[n][c]     = sigmoid(b2[c] + sum_j h1[n][j] w2[c][j])             (fc.2: Linear(R -> C), weight [C][R]; the gate)
+// Two GEMM launches of a few microseconds (+ the squeeze kernel) sat between conv2 and the block's tail on the forward's critical path, per block.
+// Fixed summation order (eight strided partials per j, then ascending; ascending over j), no atomics.
+__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict__ pooled_in, const double* __restrict__ part, int nblk, int gpi,
+                                                         double inv_hw, BnAff aff, const float* __restrict__ w0, const float* __restrict__ b0,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ pooled_out,
+                                                         float* __restrict__ h1, float* __restrict__ sc, int C, int R) {
+    __shared__ float sp[256];
+    __shared__ float part8[8][32];
+    __shared__ float sh[32];
+    const int n = blockIdx.x, t = threadIdx.x;
+    if (t < C) {
+        float v;
+        if (part != nullptr) {
+            const double* p = part + (long)t * nblk + (long)n * gpi;
+            double s = 0.0;
+            for (int k = 0; k < gpi; ++k) s += p[k];
+            v = (float)((s * inv_hw - (double)aff.mean[t]) * (double)aff.invstd[t] * (double)aff.gamma[t] + (double)aff.beta[t]);
+            pooled_out[(long)n * C + t] = v;
+        } else {
+            v = pooled_in[(long)n * C + t];
+        }
+        sp[t] = v;
+    }
+    __syncthreads();
+    const int j = t & 31, g = t >> 5;
+    float acc = 0.f;
+    if (j < R)
+        for (int c = g; c < C; c += 8) acc += sp[c] * w0[(long)j * C + c];
+    part8[g][j] = acc;
+    __syncthreads();
+    if (t < R) {
+        float v = b0[t];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += part8[q][t];
+        v = fmaxf(v, 0.f);
+        h1[(long)n * R + t] = v;
+        sh[t] = v;
+    }
+    __syncthreads();
+    if (t < C) {
+        float v = b2[t];
+        for (int q = 0; q < R; ++q) v += sh[q] * w2[(long)t * R + q];
+        sc[(long)n * C + t] = 1.0f / (1.0f + expf(-v));
+    }
+}
+
 int ha2g_se_mlp_bwd_supported(int C, int R) { return C >= 1 && C <= 256 && R >= 1 && R <= 32; }
 int ha2g_se_mlp_bwd_f32(const float* dsc, const float* h1, const float* w2, const float* w0, float* dh1, float* dpool, int N, int C, int R,
                         float inv_hw, void* stream) {
@@ -774,6 +824,22 @@ int ha2g_se_mlp_bwd_f32(const float* dsc, const float* h1, const float* w2, cons
     if (N == 0) return 0;
     hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, dsc, h1, w2, w0, dh1, dpool, C, R, inv_hw);
     HA2G_CHECK_LAUNCH("se_mlp_bwd");
+    return 0;
+}
+
+// Exactly one of pooled_in [N][C] / stat_part (with nblk = N * tiles per image, HW and bn2's mean / invstd / gamma / beta; pooled_out receives the
+// squeeze) is given.  h1 [N][R] and sc [N][C] are outputs.
+int ha2g_se_mlp_fwd_f32(const float* pooled_in, const void* stat_part, int nblk, int HW, const float* mean, const float* invstd, const float* gamma,
+                        const float* beta, const float* w0, const float* b0, const float* w2, const float* b2, float* pooled_out, float* h1,
+                        float* sc, int N, int C, int R, void* stream) {
+    HA2G_REQUIRE(ha2g_se_mlp_bwd_supported(C, R), "se_mlp_fwd: unsupported widths C = %d, R = %d", C, R);
+    HA2G_REQUIRE((pooled_in != nullptr) != (stat_part != nullptr), "se_mlp_fwd: exactly one of pooled_in / stat_part");
+    HA2G_REQUIRE(stat_part == nullptr || (N > 0 && nblk > 0 && nblk % N == 0 && HW > 0 && pooled_out != nullptr && mean && invstd && gamma && beta),
+                 "se_mlp_fwd: %d statistics blocks do not split over %d images / null BatchNorm parameter", nblk, N);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, pooled_in, (const double*)stat_part, nblk, stat_part ? nblk / N : 0,
+                       HW > 0 ? 1.0 / (double)HW : 0.0, BnAff{mean, invstd, gamma, beta}, w0, b0, w2, b2, pooled_out, h1, sc, C, R);
+    HA2G_CHECK_LAUNCH("se_mlp_fwd");
     return 0;
 }
 

@@ -543,6 +543,10 @@ def block_fwd(x, P, b, first, xp=None, out_planes=0, wpl=None):
         c2 = conv_fwd(a1, wb, None, 1, 1, ACT_NONE)
     bn2 = P[b + 'bn2']
     N, OH, OW, C = c2.shape
+    w0, b0, w2, b2_ = (P[b + n] for n in ('se.fc.0.weight', 'se.fc.0.bias', 'se.fc.2.weight', 'se.fc.2.bias'))
+    R = w0.shape[0]
+    mlp1 = SE_MLP_FUSED and w0.is_contiguous() and w2.is_contiguous() and bool(lib.ha2g_se_mlp_bwd_supported(C, R))      # the excitation MLP in one launch
+    h1 = sc = None
     if st2 is not None and SE_FROM_STATS and _tiles_per_image(a1.shape, wb) > 0:
         # conv2's epilogue left per-tile column sums of c2 behind, tiles inside one image: bn2's statistics AND the SE squeeze come from them
         # (the mean of an affine map is the affine map of the mean), the tail below applies bn2 on the fly -- b2 is never written or re-read
@@ -550,15 +554,25 @@ def block_fwd(x, P, b, first, xp=None, out_planes=0, wpl=None):
         if bn2.nbt is not None:
             _NBT_PENDING.append(bn2.nbt)
         pooled = torch.empty(N, C, dtype=torch.float32, device=c2.device)
-        check(lib.ha2g_bn_pool_from_partials_f32(st2[0].data_ptr(), st2[1], N, OH * OW, C, m2.data_ptr(), s2.data_ptr(), bn2.gamma.data_ptr(),
-                                                 bn2.beta.data_ptr(), pooled.data_ptr(), _stream()))
+        if mlp1:                                               # squeeze + fc.0 + ReLU + fc.2 + sigmoid: one launch
+            h1, sc = torch.empty(N, R, dtype=torch.float32, device=c2.device), torch.empty(N, C, dtype=torch.float32, device=c2.device)
+            check(lib.ha2g_se_mlp_fwd_f32(None, st2[0].data_ptr(), st2[1], OH * OW, m2.data_ptr(), s2.data_ptr(), bn2.gamma.data_ptr(), bn2.beta.data_ptr(),
+                                          w0.data_ptr(), b0.data_ptr(), w2.data_ptr(), b2_.data_ptr(), pooled.data_ptr(), h1.data_ptr(), sc.data_ptr(),
+                                          N, C, R, _stream()))
+        else:
+            check(lib.ha2g_bn_pool_from_partials_f32(st2[0].data_ptr(), st2[1], N, OH * OW, C, m2.data_ptr(), s2.data_ptr(), bn2.gamma.data_ptr(),
+                                                     bn2.beta.data_ptr(), pooled.data_ptr(), _stream()))
         b2 = None
     else:
         b2, m2, s2, pooled = _bn_fwd(c2, bn2, pool=True, stats=st2)      # bn2 + SE squeeze in one pass
-    h1 = ops.gemm(pooled, P[b + 'se.fc.0.weight'], transb=True, bias=P[b + 'se.fc.0.bias'], act=ACT_RELU)
-    # the gate straight out of the GEMM's sigmoid epilogue (the same 1 / (1 + expf(-v)) on the same v as a separate pointwise launch:
-    # bit-identical forward); the backward takes sigma' = s (1 - s) from the stored gate
-    sc = ops.gemm(h1, P[b + 'se.fc.2.weight'], transb=True, bias=P[b + 'se.fc.2.bias'], act=ACT_SIGMOID)
+        if mlp1:
+            h1, sc = torch.empty(N, R, dtype=torch.float32, device=c2.device), torch.empty(N, C, dtype=torch.float32, device=c2.device)
+            check(lib.ha2g_se_mlp_fwd_f32(pooled.data_ptr(), None, 0, 0, None, None, None, None, w0.data_ptr(), b0.data_ptr(), w2.data_ptr(), b2_.data_ptr(),
+                                          None, h1.data_ptr(), sc.data_ptr(), N, C, R, _stream()))
+    if h1 is None:
+        h1 = ops.gemm(pooled, w0, transb=True, bias=b0, act=ACT_RELU)
+        # the gate straight out of the GEMM's sigmoid epilogue; the backward takes sigma' = s (1 - s) from the stored gate
+        sc = ops.gemm(h1, w2, transb=True, bias=b2_, act=ACT_SIGMOID)
     su = None
     if first:
         wd = _ohwi(P[b + 'downsample.0.weight'])

@@ -327,6 +327,12 @@ int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, f
      /* ws: ha2g_bn_apply_pool_workspace_floats(N, HW, C) floats (row-chunked partials) or null (one block per image) */
 /* data path of the SE excitation MLP's backward (ResNetBlocks.py:84-89 under autograd) in one launch: dh1 = relu'(h1) * (dsc w2), dpool = inv_hw * dh1 w0;
  * w2 = se.fc.2.weight [C][R], w0 = se.fc.0.weight [R][C]; C <= 256, R <= 32 */
+/* forward of the SE excitation MLP in one launch (model/ResNetBlocks.py:84-89): h1 = relu(fc.0(pooled)), sc = sigmoid(fc.2(h1)); the squeeze
+ * `pooled` is given (pooled_in) or taken from the per-tile column sums of bn2's input (stat_part: see ha2g_bn_pool_from_partials_f32; pooled_out
+ * receives it).  Widths as ha2g_se_mlp_bwd_supported. */
+int ha2g_se_mlp_fwd_f32(const float* pooled_in, const void* stat_part, int nblk, int HW, const float* mean, const float* invstd, const float* gamma,
+                        const float* beta, const float* w0, const float* b0, const float* w2, const float* b2, float* pooled_out, float* h1,
+                        float* sc, int N, int C, int R, void* stream);
 int ha2g_se_mlp_bwd_supported(int C, int R);
 int ha2g_se_mlp_bwd_f32(const float* dsc, const float* h1, const float* w2, const float* w0, float* dh1, float* dpool, int N, int C, int R,
                         float inv_hw, void* stream);

@@ -365,3 +365,39 @@ def test_se_mlp_backward_data_path_fused(N, C):
     # the replaced form runs its two products on the split-bf16 inner product in the default mode (4e-6 rms per GEMM); the fused kernel is plain fp32
     assert relerr(dh1, dh1_3.double().cpu()) < 5e-5 and relerr(dpool, dpool_3.double().cpu()) < 5e-5
     assert torch.equal(dh1 == 0, (h1 <= 0) | (dh1 == 0))                        # masked where the hidden unit was inactive
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,C,HW,gpi', [(5, 64, 2240, 20), (3, 128, 576, 4), (7, 256, 144, 1)])
+def test_se_excitation_mlp_forward_in_one_launch(N, C, HW, gpi):
+    """ha2g_se_mlp_fwd_f32 (squeeze -> fc.0 -> ReLU -> fc.2 -> sigmoid, model/ResNetBlocks.py:84-89) against float64, from a given squeeze and from
+    per-tile column sums of bn2's input (tiles inside one image, gpi per image)."""
+    from ha2g_amd._lib import check, lib
+    from ha2g_amd.ops import _stream
+    torch.manual_seed(N * C)
+    R = C // 8
+    dev = DEV
+    w0, b0 = torch.randn(R, C, device=dev) * C ** -0.5, torch.randn(R, device=dev) * 0.1
+    w2, b2 = torch.randn(C, R, device=dev) * R ** -0.5, torch.randn(C, device=dev) * 0.1
+    part = torch.randn(2, C, N * gpi, dtype=torch.float64, device=dev) * HW / gpi
+    mean, invstd = torch.randn(C, device=dev), torch.rand(C, device=dev) + 0.5
+    gamma, beta = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1
+    sums = part[0].view(C, N, gpi).sum(2).t()                                              # [N, C]
+    pooled64 = (sums / HW - mean.double()) * invstd.double() * gamma.double() + beta.double()
+    h64 = torch.relu(pooled64 @ w0.double().t() + b0.double())
+    s64 = torch.sigmoid(h64 @ w2.double().t() + b2.double())
+    pooled, h1, sc = torch.empty(N, C, device=dev), torch.empty(N, R, device=dev), torch.empty(N, C, device=dev)
+    st = _stream()
+    check(lib.ha2g_se_mlp_fwd_f32(None, part.data_ptr(), N * gpi, HW, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), w0.data_ptr(),
+                                  b0.data_ptr(), w2.data_ptr(), b2.data_ptr(), pooled.data_ptr(), h1.data_ptr(), sc.data_ptr(), N, C, R, st))
+    assert float((pooled.double() - pooled64).abs().max()) < 1e-6 * float(pooled64.abs().max())
+    assert float((h1.double() - h64).abs().max()) < 2e-6 * float(h64.abs().max() + 1)
+    assert float((sc.double() - s64).abs().max()) < 2e-6
+    h1b, scb = torch.empty_like(h1), torch.empty_like(sc)
+    check(lib.ha2g_se_mlp_fwd_f32(pooled.data_ptr(), None, 0, 0, None, None, None, None, w0.data_ptr(), b0.data_ptr(), w2.data_ptr(), b2.data_ptr(), None,
+                                  h1b.data_ptr(), scb.data_ptr(), N, C, R, st))
+    assert torch.equal(h1b, h1) and torch.equal(scb, sc)
+    pooled_b = torch.empty_like(pooled)
+    check(lib.ha2g_bn_pool_from_partials_f32(part.data_ptr(), N * gpi, N, HW, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                             pooled_b.data_ptr(), st))
+    assert torch.equal(pooled_b, pooled)
