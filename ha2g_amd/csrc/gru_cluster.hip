@@ -360,7 +360,7 @@ typedef __bf16 bf16x8g_t __attribute__((ext_vector_type(8)));
 
 // W_hh [3H][H] fp32 -> the three-piece A-fragment image of gru_fwd_cluster3_kernel: [tile 19][piece 3][gate 3][block 10][lane 64][8 bf16]
 // (lane = unit (l & 15) of the tile, k = 32 block + 8 (l >> 4) + e; zeros for units / columns >= H)
-__global__ void pack_whh3_kernel(const float* __restrict__ w, uint4* __restrict__ out) {
+__device__ __forceinline__ void pack_whh3_body(const float* __restrict__ w, uint4* __restrict__ out) {
     const int idx = blockIdx.x * 256 + threadIdx.x;               // (tile, gate, block, lane)
     if (idx >= NJT * 3 * NKB * 64) return;
     const int lane = idx & 63, blk = (idx >> 6) % NKB, gate = (idx / (64 * NKB)) % 3, tile = idx / (64 * NKB * 3);
@@ -378,7 +378,7 @@ __global__ void pack_whh3_kernel(const float* __restrict__ w, uint4* __restrict_
 
 // ... and the TRANSPOSED image of gru_bwd_cluster_kernel<3>: [k tile 19][piece 3][gate 3][unit block 10][lane 64][8 bf16], lane = column
 // 16 kt + (l & 15) of W_hh, element e = unit 32 jblk + 8 (l >> 4) + e: W_hh[gate * H + unit][column] (zeros past H)
-__global__ void pack_whh3t_kernel(const float* __restrict__ w, uint4* __restrict__ out) {
+__device__ __forceinline__ void pack_whh3t_body(const float* __restrict__ w, uint4* __restrict__ out) {
     const int idx = blockIdx.x * 256 + threadIdx.x;               // (k tile, gate, unit block, lane)
     if (idx >= NJT * 3 * NKB * 64) return;
     const int lane = idx & 63, jb = (idx >> 6) % NKB, gate = (idx / (64 * NKB)) % 3, kt = idx / (64 * NKB * 3);
@@ -392,6 +392,15 @@ __global__ void pack_whh3t_kernel(const float* __restrict__ w, uint4* __restrict
 #pragma unroll
     for (int q = 0; q < 3; ++q)
         out[(((long)kt * 3 + q) * 3 + gate) * NKB * 64 + jb * 64 + lane] = make_uint4(pc[0][q], pc[1][q], pc[2][q], pc[3][q]);
+}
+
+__global__ void pack_whh3_kernel(const float* __restrict__ w, uint4* __restrict__ out) { pack_whh3_body(w, out); }
+__global__ void pack_whh3t_kernel(const float* __restrict__ w, uint4* __restrict__ out) { pack_whh3t_body(w, out); }
+// n <= 16 matrices in one launch (blockIdx.y = matrix): a four-layer stack packed its eight W_hh images with eight launches in front of the recurrences
+struct Pack3Batch { const float* w[16]; uint4* out[16]; };
+template <bool TR> __global__ void pack_whh3_multi_kernel(Pack3Batch b) {
+    if (TR) pack_whh3t_body(b.w[blockIdx.y], b.out[blockIdx.y]);
+    else pack_whh3_body(b.w[blockIdx.y], b.out[blockIdx.y]);
 }
 
 template <int Q>
@@ -1178,6 +1187,19 @@ int ha2g_gru_pack_whh3(const float* w_hh, void* out, int H_, void* stream) {
     HA2G_REQUIRE(H_ == H, "gru_pack_whh3: H=%d not instantiated (300)", H_);
     hipLaunchKernelGGL(pack_whh3_kernel, dim3(ceil_div(NJT * 3 * NKB * 64, 256)), dim3(256), 0, (hipStream_t)stream, w_hh, (uint4*)out);
     HA2G_CHECK_LAUNCH("gru_pack_whh3");
+    return 0;
+}
+// ha2g_gru_pack_whh3 (transposed = 0) / ha2g_gru_pack_whh3t (transposed = 1) for n <= 16 matrices in one launch; w / out are HOST arrays of n device pointers
+int ha2g_gru_pack_whh3_multi(const void* const* w, void* const* out, int n, int H_, int transposed, void* stream) {
+    HA2G_REQUIRE(H_ == H, "gru_pack_whh3_multi: H=%d not instantiated (300)", H_);
+    HA2G_REQUIRE(n >= 0 && n <= 16, "gru_pack_whh3_multi: %d matrices (max 16)", n);
+    if (n == 0) return 0;
+    Pack3Batch b{};
+    for (int i = 0; i < n; ++i) { b.w[i] = (const float*)w[i]; b.out[i] = (uint4*)out[i]; }
+    const dim3 grid(ceil_div(NJT * 3 * NKB * 64, 256), n);
+    if (transposed) hipLaunchKernelGGL(pack_whh3_multi_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, b);
+    else hipLaunchKernelGGL(pack_whh3_multi_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, b);
+    HA2G_CHECK_LAUNCH("gru_pack_whh3_multi");
     return 0;
 }
 int ha2g_gru_layer_fwd_cluster3(const float* gi, const void* wp3, const float* bhh_fwd, const float* bhh_rev, float* y, float* rs,

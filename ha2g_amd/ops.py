@@ -995,6 +995,18 @@ GRU_MERGE_DIRS = True    # both directions' input projections as one plane GEMM
 PACK_MULTI = True      # one W_hh pack launch per GRU stack instead of two per layer
 
 
+def _pack3_multi(whh, L, H, transposed, dev, st):
+    """[L, 2, packed3 bytes]: the three-piece images (ha2g_gru_pack_whh3 / _whh3t) of the 2 L recurrent matrices from ONE launch"""
+    import numpy as np
+    n3 = lib.ha2g_gru_packed3_bytes()
+    out = torch.empty(L, 2, n3, dtype=torch.uint8, device=dev)
+    wl = [t.contiguous() for t in whh]
+    wp_ = np.array([t.data_ptr() for t in wl], np.int64)
+    op_ = np.array([out[l, d].data_ptr() for l in range(L) for d in range(2)], np.int64)
+    check(lib.ha2g_gru_pack_whh3_multi(wp_.ctypes.data, op_.ctypes.data, 2 * L, H, int(transposed), st))
+    return out
+
+
 class BiGRUFunction(torch.autograd.Function):
     """Stacked bidirectional GRU (batch_first, h0 = 0).  forward(x, masks, H, grad_slice, *weights): weights in torch
     `_flat_weights` order (per layer, per direction: w_ih, w_hh, b_ih, b_hh); masks = tuple of pre-scaled
@@ -1024,6 +1036,10 @@ class BiGRUFunction(torch.autograd.Function):
             pf_ = np.array([pk_all[l, d].data_ptr() for l in range(L) for d in range(2)], np.int64)
             pb_ = np.array([pk_all[l, 2 + d].data_ptr() for l in range(L) for d in range(2)], np.int64)
             check(lib.ha2g_gru_pack_whh_multi(wp_.ctypes.data, pf_.ctypes.data, pb_.ctypes.data, 2 * L, H, st))
+        pk3_all = None
+        if PACK_MULTI and 2 * L <= 16 and gru_fwd3_active(H, T):
+            # ... and their three-piece images (bf16 A fragments of the cluster kernel) likewise: one launch instead of two per layer
+            pk3_all = _pack3_multi([weights[8 * l + 4 * d + 1] for l in range(L) for d in range(2)], L, H, False, dev, st)
         for l in range(L):
             w = [t.contiguous() for t in weights[8 * l:8 * l + 8]]
             K = inp.shape[2]
@@ -1049,7 +1065,9 @@ class BiGRUFunction(torch.autograd.Function):
             y = torch.empty(B, T, 2 * H, dtype=torch.float32, device=dev)
             rs = torch.empty(B, T, 2, 4, H, dtype=torch.float32, device=dev) if need_grad else None
             pk3 = None
-            if gru_fwd3_active(H, T):                      # three-piece W_hh images of both directions (bf16 A fragments)
+            if pk3_all is not None:
+                pk3 = pk3_all[l]
+            elif gru_fwd3_active(H, T):                    # three-piece W_hh images of both directions (bf16 A fragments)
                 n3 = lib.ha2g_gru_packed3_bytes()
                 pk3 = torch.empty(2, n3, dtype=torch.uint8, device=dev)
                 check(lib.ha2g_gru_pack_whh3(w[1].data_ptr(), pk3[0].data_ptr(), H, st))
@@ -1084,6 +1102,9 @@ class BiGRUFunction(torch.autograd.Function):
         grads = [None] * (8 * L)
         keep = []
         fused_b = []
+        pk3t_all = None
+        if PACK_MULTI and 2 * L <= 16 and gru_fwd3_active(H, T):      # the transposed three-piece W_hh images of every layer: one launch
+            pk3t_all = _pack3_multi([weights[8 * l + 4 * d + 1] for l in range(L) for d in range(2)], L, H, True, dev, st)
         for l in range(L - 1, -1, -1):
             inp, y, rs = (t[sl] for t in ctx.saved_bufs[l])
             w = weights[8 * l:8 * l + 8]
@@ -1093,7 +1114,9 @@ class BiGRUFunction(torch.autograd.Function):
             # h_prev per direction (forward dir: y[t-1], reverse dir: y[t+1], zero at the sequence ends) is written by the BPTT kernel
             hp = torch.empty(B, T, 2 * H, dtype=torch.float32, device=dev)
             pk3t = None
-            if gru_fwd3_active(H, T):                      # the BPTT chain on three pieces too: transposed W_hh images of both directions
+            if pk3t_all is not None:
+                pk3t = pk3t_all[l]
+            elif gru_fwd3_active(H, T):                    # the BPTT chain on three pieces too: transposed W_hh images of both directions
                 n3 = lib.ha2g_gru_packed3_bytes()
                 pk3t = torch.empty(2, n3, dtype=torch.uint8, device=dev)
                 check(lib.ha2g_gru_pack_whh3t(w[1].data_ptr(), pk3t[0].data_ptr(), H, st))

@@ -246,6 +246,8 @@ int ha2g_gru_layer_fwd_cluster(const float* gi, const float* wp, const float* bh
  * three-piece W_hh images (ha2g_gru_pack_whh3 into direction d at byte offset d * ha2g_gru_packed3_bytes()); the rest as above. */
 long ha2g_gru_packed3_bytes(void);
 int ha2g_gru_pack_whh3(const float* w_hh, void* out, int H, void* stream);
+/* ha2g_gru_pack_whh3 (transposed = 0) / ha2g_gru_pack_whh3t (1) for n <= 16 matrices in one launch; w / out: HOST arrays of n device pointers */
+int ha2g_gru_pack_whh3_multi(const void* const* w, void* const* out, int n, int H, int transposed, void* stream);
 int ha2g_gru_layer_fwd_cluster3(const float* gi, const void* wp3, const float* bhh_fwd, const float* bhh_rev, float* y, float* rs,
                                 void* xch, int* err, int B, int T, int H, void* stream);
 /* the BPTT twin on three pieces: wp3t = the transposed images (ha2g_gru_pack_whh3t); contract of ha2g_gru_layer_bwd_cluster otherwise */
