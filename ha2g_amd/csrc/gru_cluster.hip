@@ -403,11 +403,12 @@ template <bool TR> __global__ void pack_whh3_multi_kernel(Pack3Batch b) {
     else pack_whh3_body(b.w[blockIdx.y], b.out[blockIdx.y]);
 }
 
-template <int Q>
+template <int Q, bool ABL>
 __device__ __forceinline__ void gru_fwd_member3(const float* __restrict__ gi, const uint4* __restrict__ wp3, const float* __restrict__ bhh,
                                                 float* __restrict__ y, float* __restrict__ rs, const __amdgpu_buffer_rsrc_t xr,
                                                 int* __restrict__ err, const int B, const int T, const int dir, const int b0,
-                                                const unsigned tag0, int* __restrict__ sh, const int dbg, unsigned char* __restrict__ lds) {
+                                                const unsigned tag0, int* __restrict__ sh, const int dbg_in, unsigned char* __restrict__ lds) {
+    const int dbg = ABL ? dbg_in : 0;                     // the product kernel carries no debug branch (as gru_bwd_member: the host launches the ABL instantiation for any debug bit)
     constexpr int NOWN_T = (Q == G - 1) ? NJT - TPW * (G - 1) : TPW;     // unit tiles of this member: 4 4 4 4 3
     constexpr int P1 = (Q + 1) % G, P2 = (Q + 2) % G, P3 = (Q + 3) % G, P4 = (Q + 4) % G;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -436,7 +437,9 @@ __device__ __forceinline__ void gru_fwd_member3(const float* __restrict__ gi, co
                 w2[(gt * NKB + m) * 64] = wsrc[((2 * 3 + gt) * NKB + m) * 64];
             }
     }
-    const int fast = (dbg & 4) ? (cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh), 0) : cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh);
+    const int fast_rt = (dbg & 4) ? (cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh), 0) : cluster_same_xcd(xr, (int)(BWD_GRAN * 8), tag0 + 63u, err, sh);
+    auto body = [&](auto FASTC) {                        // the step loop per hand-off placement: the publish carries no branch
+    constexpr bool FAST = std::is_same<decltype(FASTC), std::true_type>::value;
     float4 br = make_float4(0.f, 0.f, 0.f, 0.f), bz = br, bn = br;
     if (jok) {
         br = *reinterpret_cast<const float4*>(bhh + j);
@@ -592,13 +595,8 @@ __device__ __forceinline__ void gru_fwd_member3(const float* __restrict__ gi, co
             if (s + 1 < T && !(dbg & 2)) {
                 const int go = (((s & 1) * 16 + lb) * HP + j) * 8;
                 const unsigned ptag = tag0 + (unsigned)(s + 1);
-                if (fast) {
-                    store_granule_pair<0>(xr, go, ptag, hn4.x, hn4.y);
-                    store_granule_pair<0>(xr, go + 16, ptag, hn4.z, hn4.w);
-                } else {
-                    store_granule_pair<16>(xr, go, ptag, hn4.x, hn4.y);
-                    store_granule_pair<16>(xr, go + 16, ptag, hn4.z, hn4.w);
-                }
+                store_granule_pair<FAST ? 0 : 16>(xr, go, ptag, hn4.x, hn4.y);
+                store_granule_pair<FAST ? 0 : 16>(xr, go + 16, ptag, hn4.z, hn4.w);
             }
         }
         hkeep = hn4;
@@ -608,8 +606,11 @@ __device__ __forceinline__ void gru_fwd_member3(const float* __restrict__ gi, co
         if (rs) rs_cur += tstep * 8 * H;
     }
     HA2G_FWD_FLUSH3
+    };
+    if (fast_rt) body(std::true_type{}); else body(std::false_type{});
 }
 
+template <bool ABL>
 __global__ __launch_bounds__(NT, 1) void gru_fwd_cluster3_kernel(const float* __restrict__ gi, const uint4* __restrict__ wp3,
                                                                  const float* __restrict__ bhh0, const float* __restrict__ bhh1,
                                                                  float* __restrict__ y, float* __restrict__ rs, u64* __restrict__ xch,
@@ -626,11 +627,11 @@ __global__ __launch_bounds__(NT, 1) void gru_fwd_cluster3_kernel(const float* __
     const unsigned tag0 = epoch ? (0x80000000u | (*epoch << 6)) : host_tag0;
     const float* bhh = dir ? bhh1 : bhh0;
     switch (q) {
-        case 0: gru_fwd_member3<0>(gi, wp3, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, lds3); break;
-        case 1: gru_fwd_member3<1>(gi, wp3, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, lds3); break;
-        case 2: gru_fwd_member3<2>(gi, wp3, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, lds3); break;
-        case 3: gru_fwd_member3<3>(gi, wp3, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, lds3); break;
-        default: gru_fwd_member3<4>(gi, wp3, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, lds3); break;
+        case 0: gru_fwd_member3<0, ABL>(gi, wp3, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, lds3); break;
+        case 1: gru_fwd_member3<1, ABL>(gi, wp3, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, lds3); break;
+        case 2: gru_fwd_member3<2, ABL>(gi, wp3, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, lds3); break;
+        case 3: gru_fwd_member3<3, ABL>(gi, wp3, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, lds3); break;
+        default: gru_fwd_member3<4, ABL>(gi, wp3, bhh, y, rs, xr, err, B, T, dir, b0, tag0, sh, dbg, lds3); break;
     }
 }
 
@@ -1214,7 +1215,8 @@ int ha2g_gru_layer_fwd_cluster3(const float* gi, const void* wp3, const float* b
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_cluster3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FWD3_LDS + 32) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_cluster3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FWD3_LDS + 32) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_cluster3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FWD3_LDS + 32) != hipSuccess)
             return ha2g_set_error(-2, "gru_fwd_cluster3: cannot raise the dynamic LDS limit to %d bytes", FWD3_LDS + 32);
         attr_set[dev] = true;
     }
@@ -1225,8 +1227,12 @@ int ha2g_gru_layer_fwd_cluster3(const float* gi, const void* wp3, const float* b
         unsigned host_tag0 = 0;
         const unsigned* epoch = launch_tag_base(xch, st, &host_tag0);
         const int grid = ceil_div(nclusters, 8) * 8 * G;
-        hipLaunchKernelGGL(gru_fwd_cluster3_kernel, dim3(grid), dim3(NT), FWD3_LDS + 32, st, gi, (const uint4*)wp3, bhh_fwd, bhh_rev, y, rs, (u64*)xch, epoch,
-                           host_tag0, err, B, T, t0, nclusters, g_dbg);
+        if (g_dbg != 0)                                         // any debug bit: the instantiation that carries the debug branches
+            hipLaunchKernelGGL(gru_fwd_cluster3_kernel<true>, dim3(grid), dim3(NT), FWD3_LDS + 32, st, gi, (const uint4*)wp3, bhh_fwd, bhh_rev, y, rs, (u64*)xch,
+                               epoch, host_tag0, err, B, T, t0, nclusters, g_dbg);
+        else
+            hipLaunchKernelGGL(gru_fwd_cluster3_kernel<false>, dim3(grid), dim3(NT), FWD3_LDS + 32, st, gi, (const uint4*)wp3, bhh_fwd, bhh_rev, y, rs, (u64*)xch,
+                               epoch, host_tag0, err, B, T, t0, nclusters, 0);
         HA2G_CHECK_LAUNCH("gru_layer_fwd_cluster3");
     }
     return 0;
