@@ -64,22 +64,15 @@ def fwd_planes_ok(w_ohwi, stride, pad):
 
 
 SE_FROM_STATS = True      # ... and, where the epilogue's tiles lie inside one image, the SE squeeze too: bn2's output is never materialised (block_fwd)
-_tpi = {}
-
-
 def _tiles_per_image(xshape, w_ohwi):
-    key = tuple(xshape) + tuple(w_ohwi.shape)
-    v = _tpi.get(key)
-    if v is None:
-        N, H, W, Cin = xshape
-        Cout, KH, KW, _ = w_ohwi.shape
-        v = _tpi[key] = int(lib.ha2g_conv2d_fwd_planes_stat_tiles_per_image(N, H, W, Cin, Cout, KH, KW, 1, 1))
-    return v
+    """> 0: conv2's statistics blocks are tiles inside one image, that many per image (asked per call: host arithmetic, and the answer follows the
+    library's kernel-selection switches)"""
+    N, H, W, Cin = xshape
+    Cout, KH, KW, _ = w_ohwi.shape
+    return int(lib.ha2g_conv2d_fwd_planes_stat_tiles_per_image(N, H, W, Cin, Cout, KH, KW, 1, 1))
 
 
 CONV_BN_STATS = True      # the statistics of the BatchNorm behind a forward plane convolution come out of the convolution's epilogue (no column pass)
-_stat_blocks = {}
-
 
 def conv_fwd_planes(xp, wpl, xshape, stride, pad, act, stats=False):
     """conv_fwd on the piece planes of x [3, N, H, W, Cin] and of the OHWI weight [3, Cout, KH, KW, Cin]; act: ACT_NONE / ACT_RELU; fp32 output.
@@ -90,10 +83,8 @@ def conv_fwd_planes(xp, wpl, xshape, stride, pad, act, stats=False):
     OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     y = torch.empty(N, OH, OW, Cout, dtype=torch.float32, device=xp.device)
     if stats:
-        key = (N, H, W, Cin, Cout, KH, KW, stride, pad)
-        nblk = _stat_blocks.get(key)
-        if nblk is None:
-            nblk = _stat_blocks[key] = int(lib.ha2g_conv2d_fwd_planes_stat_blocks(*key)) if CONV_BN_STATS else 0
+        # asked per call (host arithmetic): the answer follows the library's kernel-selection switches (ha2g_conv_planes_tile3)
+        nblk = int(lib.ha2g_conv2d_fwd_planes_stat_blocks(N, H, W, Cin, Cout, KH, KW, stride, pad)) if CONV_BN_STATS else 0
         if nblk > 0:
             part = torch.empty(2, Cout, nblk, dtype=torch.float64, device=xp.device)
             ops.ktimer.launch('conv2d_fwd_planes', lambda: check(lib.ha2g_conv2d_fwd_planes_np_stats_f32(
