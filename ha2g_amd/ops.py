@@ -66,6 +66,7 @@ class SideStream:
     def __init__(self):
         self.enabled = os.environ.get('HA2G_SIDE_STREAM', '1') != '0'      # 0: every weight gradient in line on the main stream (A/B)
         self._streams = {}
+        self._deferred = {}
 
     def stream(self, device):
         key = (device.type, device.index)
@@ -84,6 +85,18 @@ class SideStream:
     def join(self, device):
         if self.enabled:
             cur_stream(device).wait_stream(self.stream(device))
+            self._deferred.pop((device.type, device.index), None)
+
+    def defer(self, device, keep):
+        """Instead of join(): the side-stream work enqueued so far only ACCUMULATES into installed .grad buffers (nothing the main stream reads before the
+        optimizer / the gradient exchange), so the main stream does not wait here; `keep` stays referenced until flush() / the next join().  The
+        caller of backward() owes a flush() before anything on the main stream touches those buffers (train_hierarchy._train_iter does)."""
+        if self.enabled:
+            self._deferred.setdefault((device.type, device.index), []).append(keep)
+
+    def flush(self, device):
+        if self.enabled and self._deferred.get((device.type, device.index)):
+            self.join(device)
 
 
 side = SideStream()
@@ -184,6 +197,7 @@ PLANE_GEMM = True      # large dense products on three-piece planes (csrc/conv_p
 # >= 4 GFLOP: the GRU input projections (both directions merged) and their backward; smaller products (generator head, TCN) lose to the operand
 # split passes (A/B on the step: 43.24 ms vs 43.58 with 0.5 GFLOP, 44.10 without the plane GEMM; profiles/r04_ab_gemm.txt)
 PLANE_GEMM_MIN_FLOP = 4e9
+DEFER_JOIN = True       # BiGRU backward: no main-stream wait for in-place weight gradients (SideStream.defer / flush)
 
 
 def _plane_gemm_ok(a, b, M, N, K, transa, transb, alpha, act, out):
@@ -1185,7 +1199,12 @@ class BiGRUFunction(torch.autograd.Function):
                 for d in range(2):                                                  # dX (+)= dgi W_ih
                     gemm(dg[:, 3 * H * d:3 * H * d + 3 * H], w[4 * d], out=dx, beta=float(d))
             dy = dx.view(B, T, K) if need_dx else None
-        side.join(dev)
+        if DEFER_JOIN and fused_b and all(fused_b) and all(g is None for g in grads):
+            # every weight / bias gradient of the stack accumulated in place into installed .grad buffers: the main stream need not wait for the side
+            # queue here (5 joins of ~75 us per step) -- the step flushes before the gradient exchange / the optimizer
+            side.defer(dev, keep)
+        else:
+            side.join(dev)
         if dy is not None and B != Bfull:
             full = torch.zeros(Bfull, T, dy.shape[2], dtype=torch.float32, device=dev)
             full[sl] = dy

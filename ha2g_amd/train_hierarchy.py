@@ -263,6 +263,7 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
             dis_fake = discriminator(out_dir_vec_d.detach(), in_text_padded)
         dis_error = ops.dis_loss(dis_real, dis_fake)                      # ns-gan
         dis_error.backward()
+        ops.side.flush(dev)                              # deferred side-stream weight gradients (ops.SideStream.defer) before D's optimizer
         _allreduce([dis_optimizer])
         _sync_guard(dev)                                 # data parallel: a time-out on ANY rank makes this a no-op step on EVERY rank
         dis_optimizer.step()
@@ -354,6 +355,7 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
         readback = (host, ev)
 
     loss.backward()                                      # stage 1: losses, discriminator, generators (down to the cut)
+    ops.side.flush(dev)                                  # ... their deferred side-stream weight gradients before the exchange / stage 2 / the optimizers
     works = []
     if ddp.active():
         for o in gen_optimizers:
