@@ -67,6 +67,7 @@ class SideStream:
         self.enabled = os.environ.get('HA2G_SIDE_STREAM', '1') != '0'      # 0: every weight gradient in line on the main stream (A/B)
         self._streams = {}
         self._deferred = {}
+        self.allow_defer = False          # set by a caller that flushes before it touches the gradient buffers (train_hierarchy._train_iter)
 
     def stream(self, device):
         key = (device.type, device.index)
@@ -90,7 +91,8 @@ class SideStream:
     def defer(self, device, keep):
         """Instead of join(): the side-stream work enqueued so far only ACCUMULATES into installed .grad buffers (nothing the main stream reads before the
         optimizer / the gradient exchange), so the main stream does not wait here; `keep` stays referenced until flush() / the next join().  The
-        caller of backward() owes a flush() before anything on the main stream touches those buffers (train_hierarchy._train_iter does)."""
+        caller of backward() owes a flush() before anything on the main stream touches those buffers: only a caller that sets `allow_defer`
+        (train_hierarchy._train_iter) gets this -- a plain `loss.backward(); optimizer.step()` at the reference's call sites keeps the joins."""
         if self.enabled:
             self._deferred.setdefault((device.type, device.index), []).append(keep)
 
@@ -109,6 +111,15 @@ ACT_TAP = [None]      # diagnostics: a list here receives (kind, y > 0) for ever
 def _tap_act(kind, y, act):
     if ACT_TAP[0] is not None and act in (ACT_RELU, ACT_LEAKY):
         ACT_TAP[0].append((kind, (y > 0)))
+
+
+def _join_or_defer(device, in_place, keep):
+    """End of a backward function's side-stream section: when every weight / bias gradient went straight into an installed .grad buffer (nothing is
+    handed to autograd, whose accumulation would run on the main stream) the main stream does not wait (SideStream.defer), else it joins."""
+    if DEFER_JOIN and side.allow_defer and in_place:
+        side.defer(device, keep)
+    else:
+        side.join(device)
 
 
 class KernelTimer:
@@ -451,7 +462,7 @@ class LinearFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = gemm(dy2, w).view(ctx.xshape)
         if big:
-            side.join(dy2.device)
+            _join_or_defer(dy2.device, dw is None and db is None, (dy2, x2))
         return dx, dw, db, None
 
 
@@ -716,7 +727,7 @@ class Conv1dFunction(torch.autograd.Function):
             dcol = gemm(dy2, w.view(cout, C * k))
             dx = torch.empty(B, T, C, dtype=torch.float32, device=dy.device)
             check(lib.ha2g_col2im1d_f32(dcol.data_ptr(), dx.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
-        side.join(dy2.device)
+        _join_or_defer(dy2.device, dw is None and db is None, (dy2, col))
         return dx, dw, db, None, None, None, None
 
 
@@ -776,7 +787,7 @@ class GroupedLinearFunction(torch.autograd.Function):
                     dbs[g] = colsum(dy2[g])
         if ctx.needs_input_grad[0]:
             dx = gemm_grouped(dy2, wc)
-        side.join(dy2.device)
+        _join_or_defer(dy2.device, all(t is None for t in dws) and all(t is None for t in dbs), (dy2, x))
         return (dx, None, None) + tuple(dws) + tuple(dbs)
 
 
@@ -1199,7 +1210,7 @@ class BiGRUFunction(torch.autograd.Function):
                 for d in range(2):                                                  # dX (+)= dgi W_ih
                     gemm(dg[:, 3 * H * d:3 * H * d + 3 * H], w[4 * d], out=dx, beta=float(d))
             dy = dx.view(B, T, K) if need_dx else None
-        if DEFER_JOIN and fused_b and all(fused_b) and all(g is None for g in grads):
+        if DEFER_JOIN and side.allow_defer and fused_b and all(fused_b) and all(g is None for g in grads):
             # every weight / bias gradient of the stack accumulated in place into installed .grad buffers: the main stream need not wait for the side
             # queue here (5 joins of ~75 us per step) -- the step flushes before the gradient exchange / the optimizer
             side.defer(dev, keep)

@@ -183,6 +183,20 @@ def train_iter_hierarchy_expressive(args, epoch, in_text_padded, in_spec, target
 
 def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices, gens, discriminator, audio_encoder, text_encoder,
                 gen_optimizers, dis_optimizer, audio_optimizer, text_optimizer, return_tensors=False):
+    # Inside the step the backward functions may leave their in-place weight gradients running on the side stream (ops.SideStream.defer): every
+    # backward() below is followed by a flush() before the gradient exchange / the optimizers touch the buffers.
+    prev, ops.side.allow_defer = ops.side.allow_defer, True
+    try:
+        return _train_iter_impl(spec, args, epoch, in_text_padded, in_spec, target, vid_indices, gens, discriminator, audio_encoder, text_encoder,
+                                gen_optimizers, dis_optimizer, audio_optimizer, text_optimizer, return_tensors)
+    finally:
+        ops.side.allow_defer = prev
+        if target.is_cuda:
+            ops.side.flush(target.device)
+
+
+def _train_iter_impl(spec, args, epoch, in_text_padded, in_spec, target, vid_indices, gens, discriminator, audio_encoder, text_encoder,
+                     gen_optimizers, dis_optimizer, audio_optimizer, text_optimizer, return_tensors=False):
     warm_up_epochs = args.loss_warmup
     dev = target.device
     B = target.shape[0]
@@ -370,6 +384,7 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
     audio_pairs = [(o, g) for i, o, g in pairs if i != 4]
     if text_pairs:
         torch.autograd.backward([p[0] for p in text_pairs], [p[1] for p in text_pairs])
+        ops.side.flush(dev)
     if ddp.active():
         for tb in getattr(text_optimizer, 'sparse_tables', ()):
             ddp.exchange_sparse_(tb)
@@ -377,6 +392,7 @@ def _train_iter(spec, args, epoch, in_text_padded, in_spec, target, vid_indices,
                      else ddp.average_module_grads_([text_optimizer]))
     if audio_pairs:
         torch.autograd.backward([p[0] for p in audio_pairs], [p[1] for p in audio_pairs])
+        ops.side.flush(dev)
     ev_bwd_done = None
     if comm_clock is not None and dev.type == 'cuda':
         ev_bwd_done = torch.cuda.Event(enable_timing=True)

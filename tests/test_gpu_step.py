@@ -721,3 +721,50 @@ def test_whole_step_gradient_is_the_directional_derivative_with_dropout_on(div_r
         if div_reg and nm in ('g3', 'audio'):
             continue
         assert abs(fd - gn) <= 0.01 * gn, report                 # measured: 0.03-0.4 %
+
+
+def test_deferred_side_stream_joins_change_no_bit():
+    """Inside the train step the backward functions whose weight gradients accumulate in place on the side stream do not make the main stream wait
+    (ops.SideStream.defer; the step flushes before the exchange / the optimizers).  Only synchronisation points move, so three steps with and without
+    the deferral (ops.DEFER_JOIN) must agree bit for bit -- losses, every parameter, the gradient buffers --; and outside the step (a plain
+    backward() at the reference's call sites) nothing is deferred."""
+    from ha2g_amd import ops
+    from ha2g_amd.config import hierarchy_args
+    from ha2g_testing import SpeakerVocab
+    from ha2g_amd.train import HierarchyTrainer
+
+    class Lang:
+        n_words, word_embedding_weights = 300, None
+
+    dev = torch.device(DEV)
+    batch = [torch.from_numpy(x).to(DEV) for x in proc.make_batch(16, 27, 300, 20, 5)]
+
+    def run(defer):
+        old = ops.DEFER_JOIN
+        ops.DEFER_JOIN = defer
+        try:
+            torch.manual_seed(3)
+            ops.rng.seed(dev, 99)
+            tr = HierarchyTrainer(hierarchy_args(), Lang(), SpeakerVocab(20), 27, dev)
+            hist = [tr.train_iter(11, *batch) for _ in range(3)]
+            torch.cuda.synchronize()
+            opts = list(tr.gen_opts) + [tr.dis_opt, tr.audio_opt, tr.text_opt]
+            return hist, [o.flat_p.clone() for o in opts], [o.flat_g.clone() for o in opts]
+        finally:
+            ops.DEFER_JOIN = old
+
+    h1, p1, g1 = run(True)
+    assert not ops.side._deferred.get((dev.type, dev.index))          # flushed at the end of every step
+    h0, p0, g0 = run(False)
+    assert h1 == h0
+    assert all(torch.equal(a, b_) for a, b_ in zip(p1, p0)) and all(torch.equal(a, b_) for a, b_ in zip(g1, g0))
+    # outside the step: allow_defer is off, a Linear backward with an installed .grad buffer joins
+    assert ops.side.allow_defer is False
+    lin = torch.nn.Linear(64, 32).to(dev)
+    lin.weight.grad = torch.zeros_like(lin.weight); lin.bias.grad = torch.zeros_like(lin.bias)
+    x = torch.randn(2048, 64, device=dev, requires_grad=True)
+    y = ops.linear(x, lin.weight, lin.bias)
+    y.sum().backward()
+    assert not ops.side._deferred.get((dev.type, dev.index))
+    ref = torch.ones(2048, 32, device=dev).t() @ x.detach()
+    assert float((lin.weight.grad - ref).abs().max()) < 1e-3 * float(ref.abs().max())
