@@ -113,6 +113,22 @@ def _tap_act(kind, y, act):
         ACT_TAP[0].append((kind, (y > 0)))
 
 
+def _count_grad_use(w):
+    """Forward-time bookkeeping for deferred joins: how many gradient-carrying uses a NON-LEAF weight (a weight-normalised convolution weight) has.
+    With exactly one, the dW a backward function returns goes to one consumer only -- the weight-norm backward, which runs on the side stream too --
+    and autograd has nothing to add on the main stream."""
+    if torch.is_grad_enabled() and w is not None and w.requires_grad and not w.is_leaf:
+        base = w._base if w._base is not None else w
+        base._ha2g_grad_uses = getattr(base, '_ha2g_grad_uses', 0) + 1
+
+
+def _single_use_nonleaf(w):
+    if w is None or w.is_leaf or not (DEFER_JOIN and side.allow_defer):
+        return False
+    base = w._base if w._base is not None else w
+    return getattr(base, '_ha2g_grad_uses', 0) == 1
+
+
 def _join_or_defer(device, in_place, keep):
     """End of a backward function's side-stream section: when every weight / bias gradient went straight into an installed .grad buffer (nothing is
     handed to autograd, whose accumulation would run on the main stream) the main stream does not wait (SideStream.defer), else it joins."""
@@ -617,12 +633,18 @@ class WeightNormFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dw):
         g, v, norm = ctx.saved_tensors
-        dw = dw.contiguous()
         tg, tv = _grad_target(ctx.refs[0]), _grad_target(ctx.refs[1])
         if tg is not None and tv is not None and tg.is_contiguous() and tv.is_contiguous():     # straight into the flat .grad buffers
-            check(lib.ha2g_weight_norm_bwd_f32(dw.data_ptr(), g.data_ptr(), v.data_ptr(), norm.data_ptr(), tg.data_ptr(), tv.data_ptr(),
-                                               v.shape[0], v[0].numel(), 1.0, _stream()))
+            # on the SIDE stream: dw may still be in flight there (a convolution backward that did not join, _single_use_nonleaf), and the result
+            # only feeds the optimizer
+            with side.section(dw.device):
+                dw = dw.contiguous()
+                check(lib.ha2g_weight_norm_bwd_f32(dw.data_ptr(), g.data_ptr(), v.data_ptr(), norm.data_ptr(), tg.data_ptr(), tv.data_ptr(),
+                                                   v.shape[0], v[0].numel(), 1.0, _stream()))
+            _join_or_defer(dw.device, True, (dw, g, v, norm))
             return None, None
+        side.flush(dw.device)
+        dw = dw.contiguous()
         dg, dv = torch.empty_like(g), torch.empty_like(v)
         check(lib.ha2g_weight_norm_bwd_f32(dw.data_ptr(), g.data_ptr(), v.data_ptr(), norm.data_ptr(), dg.data_ptr(), dv.data_ptr(),
                                            v.shape[0], v[0].numel(), 0.0, _stream()))
@@ -656,15 +678,20 @@ class MultiWeightNormFunction(torch.autograd.Function):
         norms, *gv = ctx.saved_tensors
         gs, vs = gv[:n], gv[n:]
         cout, rl = vs[0].shape[0], vs[0][0].numel()
-        dws = [(d.contiguous() if d is not None else torch.zeros_like(vs[i])) for i, d in enumerate(dws)]
+        dev = vs[0].device
         tg = [_grad_target(t) for t in ctx.refs[0]]
         tv = [_grad_target(t) for t in ctx.refs[1]]
         direct = all(t is not None and t.is_contiguous() for t in tg + tv)
         if not direct:
+            side.flush(dev)                                  # the dws may still be in flight on the side stream: this branch runs on the main stream
             tg, tv = [torch.empty_like(g) for g in gs], [torch.empty_like(v) for v in vs]
-        check(lib.ha2g_weight_norm_multi_bwd_f32(n, _ptr_array(dws), _ptr_array(gs), _ptr_array(vs), _ptr_array([norms[i] for i in range(n)]),
-                                                 _ptr_array(tg), _ptr_array(tv), cout, rl, 1.0 if direct else 0.0, _stream()))
+        # direct: on the SIDE stream (the dws were produced there, possibly without a join: _single_use_nonleaf), in place into the .grad buffers
+        with (side.section(dev) if direct else _null()):
+            dws = [(d.contiguous() if d is not None else torch.zeros_like(vs[i])) for i, d in enumerate(dws)]
+            check(lib.ha2g_weight_norm_multi_bwd_f32(n, _ptr_array(dws), _ptr_array(gs), _ptr_array(vs), _ptr_array([norms[i] for i in range(n)]),
+                                                     _ptr_array(tg), _ptr_array(tv), cout, rl, 1.0 if direct else 0.0, _stream()))
         if direct:
+            _join_or_defer(dev, True, (dws, norms, gs, vs))
             return (None,) * (1 + 2 * n)
         return (None,) + tuple(tg) + tuple(tv)
 
@@ -727,13 +754,14 @@ class Conv1dFunction(torch.autograd.Function):
             dcol = gemm(dy2, w.view(cout, C * k))
             dx = torch.empty(B, T, C, dtype=torch.float32, device=dy.device)
             check(lib.ha2g_col2im1d_f32(dcol.data_ptr(), dx.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
-        _join_or_defer(dy2.device, dw is None and db is None, (dy2, col))
+        _join_or_defer(dy2.device, (dw is None or _single_use_nonleaf(ctx.refs[0])) and db is None, (dy2, col, dw))
         return dx, dw, db, None, None, None, None
 
 
 def conv1d_tm(x, w, b, dil=1, pad_left=0, To=None, act=ACT_NONE):
     if To is None:
         To = x.shape[1] + pad_left - (w.shape[2] - 1) * dil
+    _count_grad_use(w)
     return Conv1dFunction.apply(x, w, b, dil, pad_left, To, act)
 
 # ------------------------------------------------------------------------------------------------
@@ -787,12 +815,14 @@ class GroupedLinearFunction(torch.autograd.Function):
                     dbs[g] = colsum(dy2[g])
         if ctx.needs_input_grad[0]:
             dx = gemm_grouped(dy2, wc)
-        _join_or_defer(dy2.device, all(t is None for t in dws) and all(t is None for t in dbs), (dy2, x))
+        _join_or_defer(dy2.device, all(t is None or _single_use_nonleaf(w) for t, w in zip(dws, ws)) and all(t is None for t in dbs), (dy2, x, dws))
         return (dx, None, None) + tuple(dws) + tuple(dbs)
 
 
 def grouped_linear(x, ws, bs=None, act=ACT_NONE):
     G = len(ws)
+    for w in ws:
+        _count_grad_use(w)                                 # (here, not in forward(): autograd runs forward() with gradients disabled)
     return GroupedLinearFunction.apply(x, act, G, *ws, *(bs if bs is not None else [None] * G))
 
 

@@ -401,3 +401,40 @@ def test_se_excitation_mlp_forward_in_one_launch(N, C, HW, gpi):
     check(lib.ha2g_bn_pool_from_partials_f32(part.data_ptr(), N * gpi, N, HW, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                              pooled_b.data_ptr(), st))
     assert torch.equal(pooled_b, pooled)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('uses', [1, 2])
+def test_weight_norm_convolution_gradients_with_deferred_joins(uses):
+    """Inside the train step (SideStream.allow_defer) a convolution backward may hand the dW of a weight-normalised weight to the weight-norm
+    backward WITHOUT making the main stream wait: both run on the side stream -- but only when the weight has exactly ONE gradient-carrying use
+    (ops._count_grad_use): with two, autograd adds the two dW tensors on the main stream, so the functions must join.  Both cases against torch."""
+    from ha2g_amd import ops
+    dev = torch.device(DEV)
+    torch.manual_seed(uses)
+    g = torch.nn.Parameter(torch.rand(48, 1, 1, device=dev) + 0.5)
+    v = torch.nn.Parameter(torch.randn(48, 32, 2, device=dev))
+    g.grad, v.grad = torch.zeros_like(g), torch.zeros_like(v)              # installed buffers: the in-place path
+    xs = [torch.randn(64, 34, 32, device=dev) for _ in range(uses)]
+    prev, ops.side.allow_defer = ops.side.allow_defer, True
+    try:
+        w = ops.weight_norm(g, v)
+        ys = [ops.conv1d_tm(x, w, None, dil=2, pad_left=2, To=34) for x in xs]
+        assert getattr(w, '_ha2g_grad_uses', 0) == uses
+        sum((y * y).sum() for y in ys).backward()
+        pending = bool(ops.side._deferred.get((dev.type, dev.index)))
+        ops.side.flush(dev)
+    finally:
+        ops.side.allow_defer = prev
+    assert pending                                                          # the weight-norm backward itself defers (in-place targets)
+    torch.cuda.synchronize()
+    g2, v2 = g.detach().clone().requires_grad_(True), v.detach().clone().requires_grad_(True)
+    w2 = g2 * v2 / v2.flatten(1).norm(dim=1).view(-1, 1, 1)
+    tot = 0
+    for x in xs:
+        xp = torch.nn.functional.pad(x.transpose(1, 2), (2, 0))
+        y = torch.nn.functional.conv1d(xp, w2, dilation=2).transpose(1, 2)
+        tot = tot + (y * y).sum()
+    tot.backward()
+    assert float((g.grad - g2.grad).abs().max()) < 2e-4 * float(g2.grad.abs().max())
+    assert float((v.grad - v2.grad).abs().max()) < 2e-4 * float(v2.grad.abs().max())
