@@ -148,10 +148,12 @@ def prefetch_max_count(count, group=None):
     return _CountHandle(host, ev)
 
 
-def gather_sparse_rows(ids, count, rows, group=None, max_count=None):
+def gather_sparse_rows(ids, count, rows, group=None, max_count=None, flag=None):
     """All-gather of compact row gradients: every rank contributes (ids [cap], device count, rows [cap, C]) of which the first
     `count` entries are valid.  Only max-over-ranks(count) rows travel (one tiny count all-gather + host read decides the size);
     entries past a rank's count come back as id 0 with a zero row, rows are pre-scaled by 1/world (mean).  -> (ids [W*mx], rows [W*mx, C]).
+    flag (an int, 0 = fine): a rank-local error word that rides as one extra element of the id all-gather -- no collective of its own -- and
+    comes back MAX-reduced over the ranks as a third result (a 0-d tensor on the ids' device): every rank learns that SOME rank was in trouble.
     Device-agnostic (RCCL on the GPUs, gloo in the CPU tests)."""
     ws = dist.get_world_size(group)
     cnt = count.to(torch.int64).reshape(1)
@@ -166,12 +168,35 @@ def gather_sparse_rows(ids, count, rows, group=None, max_count=None):
         rows = torch.cat([rows, rows.new_zeros(mx - rows.shape[0], rows.shape[1])])
     valid = torch.arange(mx, device=ids.device) < cnt
     ids_s = torch.where(valid, ids[:mx], torch.zeros_like(ids[:mx])).contiguous()
+    if flag is not None:
+        ids_s = torch.cat([ids_s, ids_s.new_full((1,), int(flag))])
     rows_s = (rows[:mx] * valid.unsqueeze(1) * (1.0 / ws)).contiguous()
     ids_all = [torch.empty_like(ids_s) for _ in range(ws)]
     rows_all = [torch.empty_like(rows_s) for _ in range(ws)]
     all_gather_(ids_all, ids_s, group)
     all_gather_(rows_all, rows_s, group)
+    if flag is not None:
+        worst = torch.stack([t[-1] for t in ids_all]).max()
+        return torch.cat([t[:-1] for t in ids_all]), torch.cat(rows_all), worst
     return torch.cat(ids_all), torch.cat(rows_all)
+
+
+_MISMATCH_MSG = ('ha2g_amd.ddp.exchange_sparse_: on some rank one forward was prefetched but the pending gradient was not that forward\'s: the '
+                 'prefetched row count did not bound it and the previous exchange of this table dropped rows')
+
+
+def _raise_if_flagged(table):
+    """The flag of the PREVIOUS exchange of this table (MAX over ranks, so identical everywhere), looked at with a lag of one exchange: by then its
+    copy has long landed, and every rank raises at the same call -- none is left waiting inside a collective for a peer that raised alone."""
+    w = getattr(table, '_xflag', None)
+    if w is None:
+        return
+    table._xflag = None
+    ev, word = w
+    if ev is not None:
+        ev.synchronize()
+    if int(word.reshape(-1)[0]) != 0:
+        raise RuntimeError(_MISMATCH_MSG)
 
 
 def exchange_sparse_(table, group=None):
@@ -185,18 +210,31 @@ def exchange_sparse_(table, group=None):
     # Whether the prefetched max count replaces the in-line count all-gather is decided from RANK-SYMMETRIC state only: exactly one count
     # collective was issued since the last exchange (every rank ran that one forward, so every rank holds its handle -- with or without a
     # pending gradient: the handle's maximum bounds every rank's count of that forward).  Anything else takes the in-line exchange everywhere.
+    _raise_if_flagged(table)
     hint = table.count_hint[1] if (table.n_prefetch == 1 and table.count_hint is not None) else None
+    bad = 0
     if table.pending:
         if hint is not None and not (len(table.pending) == 1 and table.count_hint[0] is table.pending[0][1]):
-            raise RuntimeError('ha2g_amd.ddp.exchange_sparse_: one forward was prefetched but the pending gradient is not that forward\'s '
-                               '(%d pending): the prefetched row count does not bound it' % len(table.pending))
+            # one forward was prefetched but the pending gradient is not that forward's: the prefetched count does not bound it.  `table.pending` is
+            # RANK-LOCAL (a peer whose backward was skipped holds nothing and sees no mismatch), so raising here would leave the peers waiting in
+            # the all-gathers below.  The collectives are completed -- rows past the hint are dropped -- with the error riding in the id
+            # all-gather, and EVERY rank raises together at this table's next exchange (_raise_if_flagged).
+            bad = 1
         ids, count, rows = table.merged()
     else:
         w = table.weight
         ids = torch.zeros(1, dtype=torch.int64, device=w.device)
         count = torch.zeros(1, dtype=torch.int32, device=w.device)
         rows = torch.zeros(1, w.shape[1], dtype=torch.float32, device=w.device)
-    ids_all, rows_all = gather_sparse_rows(ids, count, rows, group, max_count=hint)
+    ids_all, rows_all, worst = gather_sparse_rows(ids, count, rows, group, max_count=hint, flag=bad)
+    if worst.is_cuda:
+        word = torch.empty(1, dtype=torch.int64, pin_memory=True)
+        word.copy_(worst.reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        table._xflag = (ev, word)
+    else:
+        table._xflag = (None, worst)
     table.count_hint, table.n_prefetch = None, 0
     table.pending = [ops.merge_rows(ids_all, rows_all, table.map)] if ids_all.numel() else []
 

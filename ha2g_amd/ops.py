@@ -67,6 +67,7 @@ class SideStream:
         self.enabled = os.environ.get('HA2G_SIDE_STREAM', '1') != '0'      # 0: every weight gradient in line on the main stream (A/B)
         self._streams = {}
         self._deferred = {}
+        self._targets = {}                # device -> data_ptrs of the .grad buffers deferred side-stream work is still accumulating into (None in the set: unknown)
         self.allow_defer = False          # set by a caller that flushes before it touches the gradient buffers (train_hierarchy._train_iter)
 
     def stream(self, device):
@@ -87,14 +88,29 @@ class SideStream:
         if self.enabled:
             cur_stream(device).wait_stream(self.stream(device))
             self._deferred.pop((device.type, device.index), None)
+            self._targets.pop((device.type, device.index), None)
 
-    def defer(self, device, keep):
+    def defer(self, device, keep, targets=None):
         """Instead of join(): the side-stream work enqueued so far only ACCUMULATES into installed .grad buffers (nothing the main stream reads before the
         optimizer / the gradient exchange), so the main stream does not wait here; `keep` stays referenced until flush() / the next join().  The
         caller of backward() owes a flush() before anything on the main stream touches those buffers: only a caller that sets `allow_defer`
         (train_hierarchy._train_iter) gets this -- a plain `loss.backward(); optimizer.step()` at the reference's call sites keeps the joins."""
         if self.enabled:
-            self._deferred.setdefault((device.type, device.index), []).append(keep)
+            key = (device.type, device.index)
+            self._deferred.setdefault(key, []).append(keep)
+            ptrs = self._targets.setdefault(key, set())
+            if targets is None:
+                ptrs.add(None)                                   # a site that does not name its targets: any main-stream touch flushes
+            else:
+                ptrs.update(t.data_ptr() for t in targets if t is not None)
+
+    def touch(self, device, *tensors):
+        """Call before MAIN-stream work reads or accumulates into gradient buffers (a small Linear's in-place dW +=, an embedding backward, a gradient
+        handed back to autograd's AccumulateGrad): if deferred side-stream work is still accumulating into one of them, the main stream joins first --
+        two unordered read-modify-writes of one buffer would race silently."""
+        ptrs = self._targets.get((device.type, device.index))
+        if self.enabled and ptrs and (None in ptrs or any(t is not None and t.data_ptr() in ptrs for t in tensors)):
+            self.join(device)
 
     def flush(self, device):
         if self.enabled and self._deferred.get((device.type, device.index)):
@@ -129,11 +145,12 @@ def _single_use_nonleaf(w):
     return getattr(base, '_ha2g_grad_uses', 0) == 1
 
 
-def _join_or_defer(device, in_place, keep):
+def _join_or_defer(device, in_place, keep, targets=None):
     """End of a backward function's side-stream section: when every weight / bias gradient went straight into an installed .grad buffer (nothing is
-    handed to autograd, whose accumulation would run on the main stream) the main stream does not wait (SideStream.defer), else it joins."""
+    handed to autograd, whose accumulation would run on the main stream) the main stream does not wait (SideStream.defer), else it joins.
+    targets: the .grad buffers the section accumulates into (SideStream.touch orders later main-stream accumulations into the same buffers)."""
     if DEFER_JOIN and side.allow_defer and in_place:
-        side.defer(device, keep)
+        side.defer(device, keep, targets)
     else:
         side.join(device)
 
@@ -457,9 +474,14 @@ class LinearFunction(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dx = dw = db = None
         big = dy2.shape[0] >= 1024                       # tiny layers: the fork/join costs more than it hides
+        tgt = None
         with (side.section(dy2.device) if big else _null()):
             want_b = ctx.has_b and ctx.needs_input_grad[2]
             tb = _grad_target(ctx.bias_ref) if (want_b and ctx.bias_ref is not None) else None
+            if not big and dy2.is_cuda:
+                # main-stream accumulation: ordered behind deferred side-stream accumulations into the same buffers (the same Linear applied at a big
+                # row count earlier in this backward)
+                side.touch(dy2.device, tb, _grad_target(ctx.wref) if ctx.needs_input_grad[1] else None)
             fuse_b = want_b and ctx.needs_input_grad[1] and FUSE_BIAS_GRAD        # bias gradient from the weight-gradient launch
             if fuse_b and tb is None:
                 db = torch.empty(dy2.shape[1], dtype=torch.float32, device=dy2.device)
@@ -478,11 +500,12 @@ class LinearFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = gemm(dy2, w).view(ctx.xshape)
         if big:
-            _join_or_defer(dy2.device, dw is None and db is None, (dy2, x2))
+            _join_or_defer(dy2.device, dw is None and db is None, (dy2, x2), (tgt, tb))
         return dx, dw, db, None
 
 
 def linear(x, w, b=None, act=ACT_NONE):
+    _count_grad_use(w)
     return LinearFunction.apply(x, w, b, act)
 
 
@@ -525,6 +548,8 @@ class EmbeddingFunction(torch.autograd.Function):
             return None, None
         tgt = _grad_target(ctx.wref)
         direct = tgt is not None and tgt.is_contiguous()
+        if direct and dy.is_cuda:
+            side.touch(dy.device, tgt)
         dw = tgt if direct else torch.zeros(ctx.wshape, dtype=torch.float32, device=dy.device)
         check(lib.ha2g_embedding_bwd_f32(tok.data_ptr(), dy.data_ptr(), dw.data_ptr(), tok.numel(), ctx.wshape[1], 0,
                                          workspace(dy.device).data_ptr(), _stream()))          # the kernel accumulates (dW +=)
@@ -641,7 +666,7 @@ class WeightNormFunction(torch.autograd.Function):
                 dw = dw.contiguous()
                 check(lib.ha2g_weight_norm_bwd_f32(dw.data_ptr(), g.data_ptr(), v.data_ptr(), norm.data_ptr(), tg.data_ptr(), tv.data_ptr(),
                                                    v.shape[0], v[0].numel(), 1.0, _stream()))
-            _join_or_defer(dw.device, True, (dw, g, v, norm))
+            _join_or_defer(dw.device, True, (dw, g, v, norm), (tg, tv))
             return None, None
         side.flush(dw.device)
         dw = dw.contiguous()
@@ -691,7 +716,7 @@ class MultiWeightNormFunction(torch.autograd.Function):
             check(lib.ha2g_weight_norm_multi_bwd_f32(n, _ptr_array(dws), _ptr_array(gs), _ptr_array(vs), _ptr_array([norms[i] for i in range(n)]),
                                                      _ptr_array(tg), _ptr_array(tv), cout, rl, 1.0 if direct else 0.0, _stream()))
         if direct:
-            _join_or_defer(dev, True, (dws, norms, gs, vs))
+            _join_or_defer(dev, True, (dws, norms, gs, vs), tg + tv)
             return (None,) * (1 + 2 * n)
         return (None,) + tuple(tg) + tuple(tv)
 
@@ -731,7 +756,7 @@ class Conv1dFunction(torch.autograd.Function):
         B, T, C, k, dil, pad_left, To, act = ctx.geom
         cout = w.shape[0]
         dy2 = act_bwd(dy.reshape(B * To, cout), y, act)
-        dx = dw = db = None
+        dx = dw = db = tw = None
         with side.section(dy2.device):
             want_b = ctx.has_b and ctx.needs_input_grad[2]
             tb = _grad_target(ctx.refs[1]) if want_b else None
@@ -754,7 +779,7 @@ class Conv1dFunction(torch.autograd.Function):
             dcol = gemm(dy2, w.view(cout, C * k))
             dx = torch.empty(B, T, C, dtype=torch.float32, device=dy.device)
             check(lib.ha2g_col2im1d_f32(dcol.data_ptr(), dx.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
-        _join_or_defer(dy2.device, (dw is None or _single_use_nonleaf(ctx.refs[0])) and db is None, (dy2, col, dw))
+        _join_or_defer(dy2.device, (dw is None or _single_use_nonleaf(ctx.refs[0])) and db is None, (dy2, col, dw), (tw, tb))
         return dx, dw, db, None, None, None, None
 
 
@@ -793,6 +818,7 @@ class GroupedLinearFunction(torch.autograd.Function):
         N, K = wc[0].shape
         dx = None
         dws, dbs = [None] * G, [None] * G
+        targets = []
         need_w, need_b = ctx.needs_input_grad[3], ctx.has_b and ctx.needs_input_grad[3 + G]
         with side.section(dy2.device):
             if need_w:
@@ -810,12 +836,13 @@ class GroupedLinearFunction(torch.autograd.Function):
                     dws = [out[g].view(ws[g].shape) for g in range(G)]
                 gemm_grouped(dy2, x, transa=True, out=out, beta=1.0 if direct_w else 0.0,
                              colsum_out=tb if need_b else None, colsum_beta=1.0 if direct_b else 0.0)
+                targets = (list(tw) if direct_w else []) + (list(tb) if direct_b else [])
             elif need_b:
                 for g in range(G):
                     dbs[g] = colsum(dy2[g])
         if ctx.needs_input_grad[0]:
             dx = gemm_grouped(dy2, wc)
-        _join_or_defer(dy2.device, all(t is None or _single_use_nonleaf(w) for t, w in zip(dws, ws)) and all(t is None for t in dbs), (dy2, x, dws))
+        _join_or_defer(dy2.device, all(t is None or _single_use_nonleaf(w) for t, w in zip(dws, ws)) and all(t is None for t in dbs), (dy2, x, dws), targets)
         return (dx, None, None) + tuple(dws) + tuple(dbs)
 
 
@@ -1243,7 +1270,7 @@ class BiGRUFunction(torch.autograd.Function):
         if DEFER_JOIN and side.allow_defer and fused_b and all(fused_b) and all(g is None for g in grads):
             # every weight / bias gradient of the stack accumulated in place into installed .grad buffers: the main stream need not wait for the side
             # queue here (5 joins of ~75 us per step) -- the step flushes before the gradient exchange / the optimizer
-            side.defer(dev, keep)
+            side.defer(dev, keep, [_grad_target(p_) for p_ in weights])
         else:
             side.join(dev)
         if dy is not None and B != Bfull:

@@ -792,27 +792,30 @@ class WavEncoderFunction(torch.autograd.Function):
         x, m, s = _bn_fwd(c0, P['bn1'])
         S['stem'] = (spec, c0, m, s)
         feats = []
-        _WILL_BWD[0] = bool(training and any(ctx.needs_input_grad))                        # false under no_grad / eval
+        # a backward will follow iff some input needs a gradient (false under no_grad); train / eval mode only governs the BatchNorm statistics
+        _WILL_BWD[0] = bool(any(ctx.needs_input_grad))
         _FWD_PLANES[0] = (PLANES & 6) == 6 and _WILL_BWD[0]                                # false under no_grad: nothing will read the planes
-        wpl = prepare_fwd_weight_planes(P)                  # {} unless the forward of layers 2-4 runs on three-piece planes (fp32-class default mode)
-        blocks = [('layer%d.%d.' % (li + 1, j), li, j) for li, nblk in enumerate(LAYERS) for j in range(nblk)]
-        xp = None
-        for bi, (b, li, j) in enumerate(blocks):
-            # pieces the block's output is written with: 3 when the NEXT block's convolutions of it run on planes, else the round-3 opt-in (2)
-            nxt = blocks[bi + 1][0] if bi + 1 < len(blocks) else None
-            want = 0
-            if nxt is not None and (nxt + 'conv1.weight') in wpl:
-                want = 3
-            elif nxt is not None and blocks[bi + 1][1] == li and _FWD_PLANES[0]:
-                # the reader is the NEXT block's conv1 weight gradient (stride 1, same layer): judge ITS geometry -- this block's OUTPUT, which is
-                # half the input's size when this block is the layer's stride-2 block
-                oh, ow = ((x.shape[1] + 1) // 2, (x.shape[2] + 1) // 2) if (j == 0 and li > 0) else (x.shape[1], x.shape[2])
-                if wgrad_planes_ok(None, _ohwi(P[nxt + 'conv1.weight']), 1, 1, hw=(oh, ow)):
-                    want = 2
-            x, S[b], xp = block_fwd(x, P, b, j == 0 and li > 0, xp=xp, out_planes=want, wpl=wpl)
-            if j + 1 == LAYERS[li]:
-                feats.append(x)
-        _FWD_PLANES[0], _WILL_BWD[0] = False, True
+        try:                                                # the two flags are module globals: restored whatever block_fwd raises (OOM, check())
+            wpl = prepare_fwd_weight_planes(P)                  # {} unless the forward of layers 2-4 runs on three-piece planes (fp32-class default mode)
+            blocks = [('layer%d.%d.' % (li + 1, j), li, j) for li, nblk in enumerate(LAYERS) for j in range(nblk)]
+            xp = None
+            for bi, (b, li, j) in enumerate(blocks):
+                # pieces the block's output is written with: 3 when the NEXT block's convolutions of it run on planes, else the round-3 opt-in (2)
+                nxt = blocks[bi + 1][0] if bi + 1 < len(blocks) else None
+                want = 0
+                if nxt is not None and (nxt + 'conv1.weight') in wpl:
+                    want = 3
+                elif nxt is not None and blocks[bi + 1][1] == li and _FWD_PLANES[0]:
+                    # the reader is the NEXT block's conv1 weight gradient (stride 1, same layer): judge ITS geometry -- this block's OUTPUT, which is
+                    # half the input's size when this block is the layer's stride-2 block
+                    oh, ow = ((x.shape[1] + 1) // 2, (x.shape[2] + 1) // 2) if (j == 0 and li > 0) else (x.shape[1], x.shape[2])
+                    if wgrad_planes_ok(None, _ohwi(P[nxt + 'conv1.weight']), 1, 1, hw=(oh, ow)):
+                        want = 2
+                x, S[b], xp = block_fwd(x, P, b, j == 0 and li > 0, xp=xp, out_planes=want, wpl=wpl)
+                if j + 1 == LAYERS[li]:
+                    feats.append(x)
+        finally:
+            _FWD_PLANES[0], _WILL_BWD[0] = False, True
         return WavEncoderFunction._finish_forward(ctx, feats, S, P, vid, L, names, flat_index, tensors)
 
     @staticmethod

@@ -299,7 +299,7 @@ def _exchange_worker(rank, world, port, out):
     ops.merge_rows = lambda ids, rows, m: (ids, torch.tensor([ids.numel()], dtype=torch.int32), rows)      # identity stand-in for the device compaction
     C, cap = 4, 9
     res = {}
-    for case, n_prefetch in (('hint', 1), ('two_forwards', 2)):
+    for case, n_prefetch in (('hint', 1), ('two_forwards', 2), ('mismatch', 1)):
         tb = _FakeTable(C)
         n = 5 if rank == 0 else 3
         ids = torch.zeros(cap, dtype=torch.int64); ids[:n] = torch.arange(1, n + 1) + 10 * rank
@@ -310,10 +310,21 @@ def _exchange_worker(rank, world, port, out):
             tb.n_prefetch += 1
         if rank == 0:
             tb.pending = [(ids, count, rows)]                   # rank 1: idle (nothing pending), but it holds the handle
+        if case == 'mismatch' and rank == 0:
+            # rank 0's pending gradient is NOT the prefetched forward's (another count tensor); rank 1 is idle and cannot see that.
+            # Nobody raises alone inside the collectives: both complete this exchange and BOTH raise at the table's next one.
+            tb.pending = [(ids, count.clone(), rows)]
         calls.clear()
         ddp.exchange_sparse_(tb)
         res[case] = dict(calls=list(calls), n_ids=int(tb.pending[0][0].numel()), state=(tb.count_hint, tb.n_prefetch),
                          rows_sum=float(tb.pending[0][2].sum()))
+        if case == 'mismatch':
+            tb.pending = []
+            try:
+                ddp.exchange_sparse_(tb)
+                res['mismatch_raised'] = False
+            except RuntimeError as e:
+                res['mismatch_raised'] = 'dropped rows' in str(e)
     torch.save(res, out + '.r%d' % rank)
     dist.destroy_process_group()
 
@@ -323,7 +334,8 @@ def test_sparse_exchange_with_prefetched_count_and_an_idle_rank(tmp_path):
     mp.spawn(_exchange_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     r0, r1 = torch.load(out + '.r0'), torch.load(out + '.r1')
     assert r0 == r1                                              # same collectives, same merged result on both ranks
-    assert [len(c) for c in r0['hint']['calls']] == [1, 2]       # ids [mx], rows [mx, C]: NO count all-gather on either rank
-    assert r0['hint']['calls'][0] == (5,) and r0['hint']['n_ids'] == 10 and r0['hint']['rows_sum'] == 5 * 4 * 0.5
+    assert [len(c) for c in r0['hint']['calls']] == [1, 2]       # ids [mx + 1 flag word], rows [mx, C]: NO count all-gather on either rank
+    assert r0['hint']['calls'][0] == (6,) and r0['hint']['n_ids'] == 10 and r0['hint']['rows_sum'] == 5 * 4 * 0.5
+    assert r0['mismatch']['calls'] == r0['hint']['calls'] and r0['mismatch_raised'] is True and r1['mismatch_raised'] is True
     assert r0['two_forwards']['calls'][0] == (1,) and len(r0['two_forwards']['calls']) == 3     # in-line count exchange everywhere
     assert r0['hint']['state'] == (None, 0)

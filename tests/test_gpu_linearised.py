@@ -198,14 +198,14 @@ def test_whole_tower_backward_headline_size_vs_oracle_linearised_at_the_hip_relu
     _tower_vs_linearised_oracle(dict(BIG_CASES['cfg2_b128']), 70, 'tower B=128 mode 70')
 
 
-def _whole_step_vs_linearised_oracle(case, expressive, what):
-    """One GAN-phase step (epoch 11, fresh state) on the HIP path in the reference's literal schedule (three separate generator passes, every generator
-    running its own text encoder: the activation CALL ORDER is then the reference's), with every ReLU / LeakyReLU decision recorded; the float64 oracle
-    linearised at that pattern; the loss dict and EVERY element of every gradient of every module (D's accumulated gradient included) compared."""
+def _hip_gan_phase_step(case, expressive, fused):
+    """One GAN-phase step (epoch 11, fresh procedural state) on the HIP path with every ReLU / LeakyReLU decision recorded.  fused=False: the reference's
+    literal schedule (three separate generator passes, every generator running its own text encoder -- the activation CALL ORDER is then the
+    reference's); fused=True: the DEFAULT schedule, the one bench.py times (3B-row fused chains, grouped text encoders, D on real + fake in one pass).
+    Returns (loss dict, [mask, ...] in call order on the device, the tower's masks by site name, {name: gradient})."""
     from ha2g_amd import ops, schema, train_hierarchy as th, wav_engine as we
-    from ha2g_amd.config import EXPRESSIVE_SPEC, make_args
     from ha2g_amd.optim import FusedAdam
-    from ha2g_testing import EpsInjector, batch_for, build_modules, named_state, state_for
+    from ha2g_testing import EpsInjector, batch_for, build_modules, named_state
     dims = schema.EXPRESSIVE_POSE_DIMS if expressive else schema.GESTURE_POSE_DIMS
     args, gens, dis, aud, txt = build_modules(case, DEV, dims)
     text, spec, target, vid = batch_for(case, P=dims[-1])
@@ -219,7 +219,7 @@ def _whole_step_vs_linearised_oracle(case, expressive, what):
     mods.update(dis=dis, audio=aud, text=txt)
     fn = th.train_iter_hierarchy_expressive if expressive else th.train_iter_hierarchy
     old = th.FUSE_CHAINS, th.FUSE_TEXT, th.randperm_source
-    th.FUSE_CHAINS, th.FUSE_TEXT, th.randperm_source = False, False, (lambda n, device: perm.to(device))
+    th.FUSE_CHAINS, th.FUSE_TEXT, th.randperm_source = fused, fused, (lambda n, device: perm.to(device))
     ops.ACT_TAP[0], we.SAVED_TAP[0] = [], []
     try:
         ret = fn(args, 11, text.to(DEV), spec.to(DEV), target.to(DEV), vid.to(DEV), *gens, dis, aud, txt, *g_opts, dis_opt, aud_opt, txt_opt)
@@ -228,10 +228,82 @@ def _whole_step_vs_linearised_oracle(case, expressive, what):
         th.FUSE_CHAINS, th.FUSE_TEXT, th.randperm_source = old
         ops.ACT_TAP[0], we.SAVED_TAP[0] = None, None
     torch.cuda.synchronize()
+    assert ops.gru_cluster_error(torch.device(DEV)) == 0
     tower = {k: v.cpu() for k, v in we.relu_pattern_of(S, 'audio.feat_extractor.').items()}
-    seq = [m.cpu() for _, m in taps]
     _, grads = named_state(mods)
     hip_grads = {k: v.detach().double().cpu() for k, v in grads.items()}
+    return ret, [m for _, m in taps], tower, hip_grads
+
+
+def _reference_call_order(lit, fus, what):
+    """The fused schedule evaluates the same activation sites as the reference's literal schedule, but over stacked row blocks (3B-row chains, [G, ...]
+    grouped encoders, real + fake through D at once) and in its own call order.  Every literal mask (B rows of one site) is one CONTIGUOUS chunk of one
+    fused mask; this finds it BY CONTENT (the decisions at a site are a ~50 % dense random pattern: an unrelated chunk differs in about half its elements,
+    the right one in none, or in the handful of elements whose pre-activation sits within rounding of zero) and returns the fused run's OWN decisions
+    re-cut into the reference's call order -- what the call-order oracle needs to be linearised at the fused forward's pattern.  Asserts that the
+    assignment is a bijection (every chunk of every fused mask used exactly once) and that matched chunks differ in < 1e-4 of their elements."""
+    chunks = {}                                    # numel -> list of (fused index, chunk index, flat bool view)
+    sizes = sorted({m.numel() for m in lit})
+    for fi, m in enumerate(fus):
+        flat = m.reshape(-1)
+        cands = [sz for sz in sizes if flat.numel() % sz == 0]
+        assert cands, ('fused tap %d of %d elements matches no literal size' % (fi, flat.numel()), sizes)
+        for sz in cands:                                                              # sites of different width can share a multiple: offer every cut
+            for ci in range(flat.numel() // sz):
+                chunks.setdefault(sz, []).append((fi, ci, flat[ci * sz:(ci + 1) * sz]))
+    used, out, worst, flips = set(), [], 0.0, 0
+    for li, m in enumerate(lit):
+        flat = m.reshape(-1)
+        n = flat.numel()
+        probe = flat[:65536]
+        best = None
+        for fi, ci, c in chunks[n]:
+            if (fi, n, ci) in used:
+                continue
+            d = int((c[:probe.numel()] ^ probe).sum())
+            if best is None or d < best[0]:
+                best = (d, fi, ci, c)
+        assert best is not None, ('no fused chunk left for literal tap', li, n)
+        _, fi, ci, c = best
+        d = int((c ^ flat).sum())
+        assert d <= max(1e-4 * n, 2), ('%s: literal tap %d has no fused twin: closest chunk (fused tap %d, chunk %d) differs in %d of %d decisions' % (what, li, fi, ci, d, n))
+        used.add((fi, n, ci))
+        flips += d
+        worst = max(worst, d / n)
+        out.append(c.reshape(m.shape).cpu())
+    # bijection: the elements handed to the oracle are exactly the elements the fused run decided
+    assert sum(m.numel() for m in out) == sum(m.numel() for m in fus), (sum(m.numel() for m in out), sum(m.numel() for m in fus))
+    per_fused = {}
+    for fi, n, ci in used:
+        per_fused[fi] = per_fused.get(fi, 0) + n
+    assert all(per_fused.get(fi, 0) == m.numel() for fi, m in enumerate(fus)), 'a fused mask was cut at two different chunk sizes or left partly unused'
+    print('%s: %d literal activation calls found in %d fused calls; decisions that differ between the two HIP schedules: %d (worst site: %.1e of its elements)'
+          % (what, len(lit), len(fus), flips, worst))
+    return out
+
+
+def _whole_step_vs_linearised_oracle(case, expressive, what, fused=False):
+    """One GAN-phase step on the HIP path with every ReLU / LeakyReLU decision recorded; the float64 oracle linearised at that pattern; the loss dict and
+    EVERY element of every gradient of every module (D's accumulated gradient included) compared.  fused=False checks the literal schedule; fused=True
+    checks the DEFAULT schedule -- the literal run is then used only to learn the reference's call order (_reference_call_order), the pattern imposed on
+    the oracle and the gradients compared are the fused run's."""
+    from ha2g_amd import schema
+    from ha2g_amd.config import EXPRESSIVE_SPEC, make_args
+    from ha2g_testing import batch_for, state_for
+    dims = schema.EXPRESSIVE_POSE_DIMS if expressive else schema.GESTURE_POSE_DIMS
+    text, spec, target, vid = batch_for(case, P=dims[-1])
+    perm = torch.from_numpy(proc.fixed_perm(case['B'], case['seed']))
+    ret, lit, tower, hip_grads = _hip_gan_phase_step(case, expressive, False)
+    if fused:
+        del tower, hip_grads
+        torch.cuda.empty_cache()
+        ret, fus, tower, hip_grads = _hip_gan_phase_step(case, expressive, True)
+        seq = _reference_call_order(lit, fus, what)
+        del fus
+    else:
+        seq = [m.cpu() for m in lit]
+    del lit
+    torch.cuda.empty_cache()
 
     def oracle(dt):
         sd = state_for(case, dt, dims)
@@ -278,3 +350,20 @@ def test_whole_gan_phase_step_headline_size_vs_oracle_linearised_at_the_hip_acti
     oracle steps (float64, float32) take ~40 GB and a few minutes of host time."""
     from ha2g_amd.config import BIG_CASES
     _whole_step_vs_linearised_oracle(dict(BIG_CASES['cfg2_b128']), False, 'GAN-phase step cfg2_b128')
+
+
+@pytest.mark.parametrize('name', ['cfg1', 'expr_cfg1'])
+def test_default_fused_schedule_gan_phase_step_vs_oracle_linearised_at_its_own_activation_pattern(name):
+    """the schedule bench.py times -- fused 3B-row chains, grouped text encoders, D on real + fake in one pass, mode 70 --
+    element-checked against the float64 oracle DIRECTLY: its own activation decisions, re-cut into the reference's call order, are imposed on the oracle and
+    every element of every gradient is held to 1e-4 + the float32 oracle's floor.  Full width, B = 4 (three and six generators)."""
+    from ha2g_amd.config import CASES
+    case = CASES[name]
+    _whole_step_vs_linearised_oracle(case, bool(case.get('expressive')), 'fused GAN-phase step %s' % name, fused=True)
+
+
+def test_default_fused_schedule_gan_phase_step_headline_size_vs_oracle_linearised_at_its_own_activation_pattern():
+    """The same at the HEADLINE configuration (cfg2_b128: B = 128, T = 34, H = 300, 4 layers, 20 000 words, 1 371 speakers, spec (128, 70)): the exact
+    configuration, schedule and arithmetic mode of the benchmark line (dropout aside), every gradient element at 1e-4 against float64."""
+    from ha2g_amd.config import BIG_CASES
+    _whole_step_vs_linearised_oracle(dict(BIG_CASES['cfg2_b128']), False, 'fused GAN-phase step cfg2_b128', fused=True)

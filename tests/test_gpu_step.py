@@ -288,8 +288,9 @@ def test_whole_step_hipgraph_capture_matches_eager():
     assert ops.gru_cluster_error(dev) == 0
 
 
-def _full_size_step(expressive, B, fuse, mode, seed=21, fuse_text=True, b16=False):
-    """One GAN-phase step of a freshly built full-size trainer with every random draw pinned; returns (loss dict, flat grads)."""
+def _full_size_step(expressive, B, fuse, mode, seed=21, fuse_text=True, b16=False, per_tensor=False):
+    """One GAN-phase step of a freshly built full-size trainer with every random draw pinned; returns (loss dict, flat grads) -- with
+    per_tensor, (loss dict, {'<module>.<parameter>': gradient}) over every parameter of the generators, the audio tower, the text encoder and D."""
     from ha2g_amd import ops, schema
     from ha2g_amd._lib import lib
     from ha2g_amd.config import hierarchy_args
@@ -336,55 +337,82 @@ def _full_size_step(expressive, B, fuse, mode, seed=21, fuse_text=True, b16=Fals
         lib.ha2g_gemm_set_mode(__import__('ha2g_amd._lib', fromlist=['x']).DEFAULT_GEMM_MODE)
         wav_engine.set_b16(prev_b16)
     names = ['g%d' % (i + 1) for i in range(len(tr.gens))] + ['audio', 'text']
-    grads = {n: o.flat_g.clone() for n, o in zip(names, tr.gen_opts + [tr.audio_opt, tr.text_opt])}
+    if per_tensor:
+        mods = dict(zip(names + ['dis'], tr.gens + [tr.audio_encoder, tr.text_encoder, tr.discriminator]))
+        grads = {k: v.detach().clone() for k, v in named_state(mods)[1].items()}
+    else:
+        grads = {n: o.flat_g.clone() for n, o in zip(names, tr.gen_opts + [tr.audio_opt, tr.text_opt])}
     assert ops.gru_cluster_error(dev) == 0
     del tr
     torch.cuda.empty_cache()
     return ret, grads
 
 
+def _elementwise_bridge(what, g_a, g_b, rtol):
+    """max|a - b| <= rtol * max|b| for EVERY parameter tensor; prints the worst ratio (max|a - b| / max|b|) per module."""
+    assert sorted(g_a) == sorted(g_b) and len(g_a) > 100
+    worst, bad = {}, []
+    for k, b in g_b.items():
+        scale = float(b.abs().max())
+        err = float((g_a[k] - b).abs().max())
+        r = err / scale if scale > 0 else (0.0 if err == 0 else float('inf'))
+        m = k.split('.')[0]
+        if r >= worst.get(m, (-1.0, ''))[0]:
+            worst[m] = (r, k)
+        if r > rtol:
+            bad.append((k, r))
+    print('%s: worst max|d| / max|g| per module: %s' % (what, ', '.join('%s %.2e (%s)' % (m, r, k) for m, (r, k) in sorted(worst.items()))))
+    assert not bad, (what, rtol, sorted(bad, key=lambda kv: -kv[1])[:8])
+
+
 @pytest.mark.parametrize('expressive', [False, True])
 def test_full_size_schedule_and_precision_invariants(expressive):
     """BASELINE's full-size configurations (config 2: B=128, T=34, 27-d pose; config 3: the 6-level 126-d expressive twin; spec
     (128,70), 20 000 words, 1 371 speakers, H=300, 4 layers), beside the reference fixtures of this size (cfg2_b128 / cfg3_b128,
-    test_train_step_headline_size_vs_reference): size-independent invariants of the step, with the random draws pinned:
-      * the fused 3-chain schedule and the literal three-pass schedule of the reference give the same loss terms and the
-        same gradient for every module;
-      * the default matrix-core mode (split-bf16 backward GEMMs / convolutions) and the exact-fp32 mode give identical
-        losses (the forward is untouched) and gradients that agree to 1e-4 of each module's gradient norm;
+    test_train_step_headline_size_vs_reference): size-independent invariants of the step, with the random draws pinned, IN THE DEFAULT
+    ARITHMETIC (mode 70: three-piece split products, what bench.py times) and in mode 0 (every product on the fp32 MFMA):
+      * the fused 3-chain schedule (the default, what bench.py times) and the literal three-pass schedule of the reference give the same
+        loss terms and, PER PARAMETER TENSOR AND ELEMENT-WISE, the same gradient: max|fused - literal| <= 1e-5 max|g| for every one of the
+        ~480 (690) tensors, D's accumulated gradient included.  This is the bridge from the benchmarked schedule to
+        tests/test_gpu_linearised.py, which pins the literal schedule (and, since round 6, the fused one directly) to the float64 oracle
+        element by element at 1e-4;
+      * the default mode and the exact-fp32 mode give the same losses to 2e-5 and gradients that agree to 1e-4 of each module's gradient
+        norm (two different roundings of the same products: kink flips in the heads / TCNs keep this one at the norm level);
       * running the same step twice from the same state is bitwise reproducible."""
     B = 128
-    r_f, g_f = _full_size_step(expressive, B, True, 6)
-    r_l, g_l = _full_size_step(expressive, B, False, 6)
+    for mode in (70, 0):
+        r_f, g_f = _full_size_step(expressive, B, True, mode, per_tensor=True)
+        r_l, g_l = _full_size_step(expressive, B, False, mode, per_tensor=True)
+        for k in r_f:                                                                          # schedules agree
+            assert abs(r_f[k] - r_l[k]) <= 2e-5 * max(abs(r_l[k]), 1e-3), (mode, k, r_f[k], r_l[k])
+        _elementwise_bridge('fused vs literal schedule, mode %d, %s' % (mode, 'expressive' if expressive else 'gesture'), g_f, g_l, 1e-5)
+    del g_f, g_l
+    r_f, g_f = _full_size_step(expressive, B, True, 70)
     r_x, g_x = _full_size_step(expressive, B, True, 0)
-    r_f2, g_f2 = _full_size_step(expressive, B, True, 6)
+    r_f2, g_f2 = _full_size_step(expressive, B, True, 70)
     assert r_f == r_f2 and all(torch.equal(g_f[k], g_f2[k]) for k in g_f)                      # reproducible
-    for k in r_f:                                                                              # schedules agree
-        assert abs(r_f[k] - r_l[k]) <= 2e-5 * max(abs(r_l[k]), 1e-3), (k, r_f[k], r_l[k])
-    for k in g_f:
-        d = float((g_f[k] - g_l[k]).norm() / g_l[k].norm())
-        assert d < 2e-4, ('fused vs literal', k, d)
     for k in r_f:                                                                              # precision modes agree
         if k not in ('dis',):
-            assert abs(r_f[k] - r_x[k]) <= 1e-6 * max(abs(r_x[k]), 1e-3), (k, r_f[k], r_x[k])
+            assert abs(r_f[k] - r_x[k]) <= 2e-5 * max(abs(r_x[k]), 1e-3), (k, r_f[k], r_x[k])
     for k in g_f:
         d = float((g_f[k] - g_x[k]).norm() / g_x[k].norm())
-        assert d < 1e-4, ('split-bf16 vs fp32 backward', k, d)
+        assert d < 1e-4, ('three-piece vs fp32 products', k, d)
 
 
 @pytest.mark.parametrize('expressive,fuse', [(False, True), (False, False), (True, True)])
 def test_grouped_text_encoders_match_the_per_generator_encoders(expressive, fuse):
     """The generators' text encoders evaluated in lockstep as grouped launches (hierarchy_net.grouped_text_encoders, the default) against
-    each generator running its own encoder inside its forward (the reference's structure): same loss terms, same gradients for every module,
-    under the fused-chain and the literal schedule, three and six generators."""
+    each generator running its own encoder inside its forward (the reference's structure): same loss terms and, per parameter tensor and
+    element-wise (1e-5 of the tensor's largest element), the same gradients for every module -- under the fused-chain and the literal
+    schedule, three and six generators, in the default arithmetic (mode 70) and on the fp32 MFMA (mode 0)."""
     B = 128
-    r_g, g_g = _full_size_step(expressive, B, fuse, 6, fuse_text=True)
-    r_s, g_s = _full_size_step(expressive, B, fuse, 6, fuse_text=False)
-    for k in r_g:
-        assert abs(r_g[k] - r_s[k]) <= 2e-5 * max(abs(r_s[k]), 1e-3), (k, r_g[k], r_s[k])
-    for k in g_g:
-        d = float((g_g[k] - g_s[k]).norm() / g_s[k].norm())
-        assert d < 2e-4, ('grouped vs per-generator text encoders', k, d)
+    for mode in (70, 0):
+        r_g, g_g = _full_size_step(expressive, B, fuse, mode, fuse_text=True, per_tensor=True)
+        r_s, g_s = _full_size_step(expressive, B, fuse, mode, fuse_text=False, per_tensor=True)
+        for k in r_g:
+            assert abs(r_g[k] - r_s[k]) <= 2e-5 * max(abs(r_s[k]), 1e-3), (mode, k, r_g[k], r_s[k])
+        _elementwise_bridge('grouped vs per-generator text encoders, mode %d, fuse=%s, %s' % (mode, fuse, 'expressive' if expressive else 'gesture'),
+                            g_g, g_s, 1e-5)
 
 
 def test_config5_bf16_step_b256():
@@ -768,3 +796,56 @@ def test_deferred_side_stream_joins_change_no_bit():
     assert not ops.side._deferred.get((dev.type, dev.index))
     ref = torch.ones(2048, 32, device=dev).t() @ x.detach()
     assert float((lin.weight.grad - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+
+
+def test_one_linear_at_a_big_and_a_small_row_count_under_deferred_joins():
+    """under `allow_defer` a Linear applied at >= 1024 rows accumulates dW on the side stream without a join, and the SAME Linear applied
+    at < 1024 rows accumulates on the main stream straight into the same .grad buffer: two unordered read-modify-writes.  SideStream.touch orders the
+    main-stream accumulation behind the deferred one (the buffers deferred work writes are tracked by address).  Repeated 20 times with a long side-stream
+    kernel queued in front so that a missing ordering shows: the result must equal the joined run bit for bit every time, and a weight-normalised weight
+    that is ALSO used by a Linear is counted as two uses (its convolution's dW is then joined, not deferred)."""
+    from ha2g_amd import ops
+    dev = torch.device(DEV)
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(256, 192).to(dev)
+    xb = torch.randn(8192, 256, device=dev)
+    xs = torch.randn(96, 256, device=dev)
+    big_a, big_b = torch.randn(4096, 4096, device=dev), torch.randn(4096, 4096, device=dev)
+
+    def run(defer):
+        lin.weight.grad = torch.zeros_like(lin.weight); lin.bias.grad = torch.zeros_like(lin.bias)
+        prev = ops.side.allow_defer
+        ops.side.allow_defer = defer
+        try:
+            with ops.side.section(dev):                    # something long in front of the side-stream accumulation
+                for _ in range(4):
+                    ops.gemm(big_a, big_b)
+            ops.side.join(dev)
+            with ops.side.section(dev):
+                for _ in range(4):
+                    ops.gemm(big_a, big_b)
+            yb = ops.linear(xb, lin.weight, lin.bias)
+            ys = ops.linear(xs, lin.weight, lin.bias)
+            (yb.sum() * 0.5 + (ys * ys).sum()).backward()
+            deferred = bool(ops.side._deferred.get((dev.type, dev.index)))
+            ops.side.flush(dev)
+        finally:
+            ops.side.allow_defer = prev
+        torch.cuda.synchronize()
+        return lin.weight.grad.clone(), lin.bias.grad.clone(), deferred
+    w0, b0, d0 = run(False)
+    assert not d0
+    ref = (torch.full((8192, 192), 0.5, device=dev).t() @ xb) + (2 * ops.linear(xs, lin.weight, lin.bias).detach()).t() @ xs
+    assert float((w0 - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    for _ in range(20):
+        w1, b1, _ = run(True)
+        assert torch.equal(w1, w0) and torch.equal(b1, b0)
+    # a weight-normalised weight used by a convolution AND by a Linear: two counted uses -> the convolution's dW joins
+    g = torch.nn.Parameter(torch.rand(32, 1, 1, device=dev) + 0.5)
+    v = torch.nn.Parameter(torch.randn(32, 16, 2, device=dev))
+    w = ops.weight_norm(g, v)
+    x = torch.randn(64, 34, 16, device=dev)
+    ops.conv1d_tm(x, w, None, pad_left=1)
+    ops.linear(torch.randn(8, 32, device=dev), w.view(32, 32))
+    base = w._base if w._base is not None else w
+    assert getattr(base, '_ha2g_grad_uses', 0) == 2 and not ops._single_use_nonleaf(w)
