@@ -45,7 +45,66 @@ int pconv_wgrad_launch_np(const void* x, long x_ps, const void* dy, long dy_ps, 
 // internal: dense product on the plane kernel (conv_planes.hip); the split-K reduce lives in gemm.hip
 int plane_gemm_plan(int M, int N, int ksplit, int* mt, int* bn);
 int plane_gemm_launch(const void* a, long a_ps, long lda, const void* b, long b_ps, long ldb, int M, int N, int K, float* C, long ldc, float beta,
-                      const float* bias, int act, float* ws, int ksplit, hipStream_t st);
+                      const float* bias, int act, float* ws, int ksplit, int* tickets, hipStream_t st);
+
+// ---- in-kernel split-K reduction (round 6): arrival tickets -------------------------------------------------------------------------------
+// A split-K launch used to leave `splits` raw partial slabs in the workspace for a SECOND launch (splitk_reduce[_wide]_kernel) to add up: 157
+// extra launches, 2.5 ms of kernel time and 1.5 GB of re-read per train step, and an HBM burst that doubled whatever main-queue kernel ran beside
+// it (profiles/r05_queue_overlap.txt).  With a ticket buffer registered for the launch stream (ha2g_splitk_set_tickets) the k slices of an
+// output tile instead take a ticket when their slab is written; the LAST arriver adds the slabs IN SLICE ORDER (double accumulation, exactly
+// the reduce kernel's arithmetic: no float atomics, bitwise reproducible whatever the arrival order), applies the epilogue and stores the tile.
+// Hand-off (MI355X guide, persistent-kernel forms): plain slab stores -> __syncthreads() (drains vmcnt) -> one lane: agent-scope release
+// (buffer_wbl2 sc1) + explicit s_waitcnt vmcnt(0) -> relaxed agent atomic on the ticket; the last arriver: agent-scope acquire (buffer_inv sc1)
+// -> __syncthreads() -> plain loads.  The last arriver re-zeroes its ticket: the buffer is zero between launches (graph-replay safe).
+#define HA2G_SPLITK_TICKETS 16384
+int* splitk_tickets_for(hipStream_t st);        // misc.hip: the buffer registered for (current device, stream), or nullptr
+// every thread of the workgroup calls it after its slab stores; returns true in every thread of the last-arriving workgroup of `ticket`
+__device__ __forceinline__ bool splitk_last_arriver(int* __restrict__ ticket, int nslices, int* __restrict__ sh) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == nslices - 1;
+        if (last) {
+            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        *sh = last;
+    }
+    __syncthreads();
+    return *sh != 0;
+}
+// sum over z = 0 .. n-1 of p[z * stride] accumulated in double IN THAT ORDER (eight loads in flight): the arithmetic of splitk_reduce_kernel
+__device__ __forceinline__ double splitk_ordered_sum(const float* __restrict__ p, long stride, int n) {
+    double sd = 0.0;
+    int z = 0;
+    for (; z + 7 < n; z += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[(long)(z + j) * stride];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sd += (double)v[j];
+    }
+    for (; z < n; ++z) sd += (double)p[(long)z * stride];
+    return sd;
+}
+// the same for four consecutive floats (16-byte aligned)
+__device__ __forceinline__ void splitk_ordered_sum4(const float* __restrict__ p, long stride, int n, double* __restrict__ sd) {
+    sd[0] = sd[1] = sd[2] = sd[3] = 0.0;
+    int z = 0;
+    for (; z + 3 < n; z += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(p + (long)(z + j) * stride);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sd[0] += (double)v[j][0]; sd[1] += (double)v[j][1]; sd[2] += (double)v[j][2]; sd[3] += (double)v[j][3]; }
+    }
+    for (; z < n; ++z) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + (long)z * stride);
+        sd[0] += (double)v[0]; sd[1] += (double)v[1]; sd[2] += (double)v[2]; sd[3] += (double)v[3];
+    }
+}
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -164,6 +164,7 @@ struct PConvP {
     int kmaj;                                                    // pconv_q_kernel: 1 = channel-major k order (default), 0 = tap-major (ha2g_conv_planes_korder)
     int ksplit, kt_per;                                          // split-K over blockIdx.z (ncls == 1): k tiles [z * kt_per, ..) -> raw partial slab z of ws
     float* ws;                                                   // [ksplit][M][N]
+    int* tickets;                                                // dense use with ksplit > 1: in-kernel reduction (common.h: splitk_last_arriver), one ticket per output tile; null = the caller reduces
     // BatchNorm statistics of the stored output from the epilogue (pconv_r_kernel, forward): per row tile and channel the sum and the sum of
     // squares (double) -> stat[(which * N + channel) * stat_nblk + tile]; null = none.  norm.hip's bn_stats_final_kernel adds the tiles in order.
     double* stat; int stat_nblk;
@@ -971,6 +972,39 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
                     else if (p.act == 2) x = x > 0.f ? x : 0.01f * x;
                     dst[r] = x;
                 }
+            }
+        }
+    }
+    // in-kernel split-K reduction (dense use only: output row = GEMM row): the last of this tile's k slices to arrive adds the ksplit raw slabs in slice
+    // order, in double (the arithmetic of splitk_reduce_kernel), applies bias / beta / activation and stores the 2 GM x BN tile
+    if (ksp && p.tickets != nullptr) {
+        int* sh = reinterpret_cast<int*>(smem);
+        if (splitk_last_arriver(p.tickets + (long)by * gridDim.x + bx, (int)gridDim.z, sh)) {
+            const long MN = (long)pc.M * p.N;
+            const int r0 = bx * (2 * GM);
+            for (int idx = tid; idx < 2 * GM * (BN / 4); idx += 512) {
+                const int row = r0 + idx / (BN / 4), col = n0 + (idx % (BN / 4)) * 4;
+                if (row >= pc.M || col >= p.N) continue;
+                const int nv = p.N - col < 4 ? p.N - col : 4;
+                const float* src = p.ws + (long)row * p.N + col;
+                double sd[4] = {0.0, 0.0, 0.0, 0.0};
+                if (p.vec) splitk_ordered_sum4(src, MN, (int)gridDim.z, sd);
+                else for (int c = 0; c < nv; ++c) sd[c] = splitk_ordered_sum(src + c, MN, (int)gridDim.z);
+                float* dst = p.C + (long)row * p.ldc + col;
+                f32x4_t v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float x = 0.f;
+                    if (c < nv) {
+                        x = (float)sd[c] + (p.bias ? p.bias[col + c] : 0.f);
+                        if (p.beta != 0.f) x += p.beta * dst[c];
+                        if (p.act == 1) x = fmaxf(x, 0.f);
+                        else if (p.act == 2) x = x > 0.f ? x : 0.01f * x;
+                    }
+                    v[c] = x;
+                }
+                if (p.vec) *reinterpret_cast<f32x4_t*>(dst) = v;
+                else for (int c = 0; c < nv; ++c) dst[c] = v[c];
             }
         }
     }
@@ -1804,7 +1838,7 @@ static int pconv_dispatch(const PConvP& p, int maxM, hipStream_t st) {
 // "convolution" over M pixels with lda channels.  ksplit > 1: k slices over grid.z write raw partial slabs ws [ksplit][M][N] (the caller reduces).
 int plane_gemm_plan(int M, int N, int ksplit, int* mt, int* bn) { return pconv_q_plan(M, N, ksplit, mt, bn) > 0.0 ? 0 : -100; }
 int plane_gemm_launch(const void* a, long a_ps, long lda, const void* b, long b_ps, long ldb, int M, int N, int K, float* C, long ldc, float beta,
-                      const float* bias, int act, float* ws, int ksplit, hipStream_t st) {
+                      const float* bias, int act, float* ws, int ksplit, int* tickets, hipStream_t st) {
     PConvP p{};
     p.a = PlaneSet{(const unsigned short*)a, a_ps}; p.b = PlaneSet{(const unsigned short*)b, b_ps};
     p.C = C; p.ldc = ldc; p.beta = beta; p.fwd = 1; p.bias = bias; p.act = act;
@@ -1820,6 +1854,7 @@ int plane_gemm_launch(const void* a, long a_ps, long lda, const void* b, long b_
     p.ksplit = ksplit > 1 ? ksplit : 1;
     p.kt_per = (nkt + p.ksplit - 1) / p.ksplit;
     p.ws = ws;
+    p.tickets = p.ksplit > 1 ? tickets : nullptr;                // in-kernel reduction of the k slices (the caller checked the tile count against the ticket buffer)
     if (M == 0 || N == 0) return 0;
     // GC is the row stride AND (>> 5) the k-tile count of the kernel: when lda > kpad the surplus tiles would multiply zeros by zeros; forbid it
     if (lda != kpad) return ha2g_set_error(-1, "plane_gemm: lda %ld must equal K rounded up to 32 (%d)", lda, kpad);

@@ -49,6 +49,8 @@ struct GemmP {
     // (stacked operands: base + g * stride, or separate tensors); split-K slabs [group][split][M][N], then the bias partials [group][split][M].
     int groups;
     const float* Ag[8]; const float* Bg[8]; float* Cg[8]; const float* biasg[8]; float* csumg[8];
+    // in-kernel split-K reduction (common.h): one arrival ticket per (group, output tile); null = the caller launches splitk_reduce_kernel
+    int* tickets;
 };
 
 
@@ -57,6 +59,48 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 2) return v > 0.f ? v : 0.01f * v;
     if (act == 3) return 1.0f / (1.0f + expf(-v));
     return v;
+}
+
+// The last-arriving k slice of an output tile (splitk_last_arriver) adds the `splits` raw slabs of rows [m0, m0 + BM) x columns [n0, n0 + BN) in
+// slice order -- double accumulation, then alpha / bias / beta / activation: element for element the arithmetic of splitk_reduce_kernel --
+// and, on the weight-gradient shape, the bias-gradient partials of its rows (the by == 0 tile).
+template <int BM, int BN>
+__device__ __forceinline__ void splitk_finish_tile(const GemmP& p, const float* __restrict__ gws, const float* __restrict__ gwsb, float* __restrict__ gC,
+                                                   const float* __restrict__ gbias, float* __restrict__ gcsum, bool csum_on, int m0, int n0) {
+    const long gMN = (long)p.M * p.N;
+    const bool vec = (p.N & 3) == 0 && ((reinterpret_cast<uintptr_t>(gws) & 15) == 0);
+    const bool vecc = vec && (p.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(gC) & 15) == 0);
+    for (int idx = threadIdx.x; idx < BM * (BN / 4); idx += blockDim.x) {
+        const int row = m0 + idx / (BN / 4), col = n0 + (idx % (BN / 4)) * 4;
+        if (row >= p.M || col >= p.N) continue;
+        double sd[4];
+        int nv = p.N - col < 4 ? p.N - col : 4;
+        const float* src = gws + (long)row * p.N + col;
+        if (vec) splitk_ordered_sum4(src, gMN, p.splits, sd);
+        else for (int c = 0; c < nv; ++c) sd[c] = splitk_ordered_sum(src + c, gMN, p.splits);
+        float* dst = gC + (long)row * p.ldc + col;
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float x = 0.f;
+            if (c < nv) {
+                x = p.alpha * (float)sd[c] + (gbias ? gbias[col + c] : 0.f);
+                if (p.beta != 0.f) x += p.beta * dst[c];
+                x = apply_act(x, p.act);
+            }
+            v[c] = x;
+        }
+        if (vecc) *reinterpret_cast<f32x4*>(dst) = v;
+        else for (int c = 0; c < nv; ++c) dst[c] = v[c];
+    }
+    if (csum_on) {
+        for (int r = threadIdx.x; r < BM; r += blockDim.x) {
+            const int m = m0 + r;
+            if (m >= p.M) continue;
+            const double sd = splitk_ordered_sum(gwsb + m, p.M, p.splits);
+            gcsum[m] = (p.csum_beta != 0.f ? p.csum_beta * gcsum[m] : 0.f) + (float)sd;
+        }
+    }
 }
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -547,6 +591,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
             }
         }
     }
+    if (partial && p.tickets != nullptr) {                // in-kernel reduction: the last of this tile's k slices to arrive finishes the tile
+        int* sh = reinterpret_cast<int*>(smem);
+        if (splitk_last_arriver(p.tickets + ((long)grp * gridDim.y + tl.by) * gridDim.x + tl.bx, p.splits, sh))
+            splitk_finish_tile<BM, BN>(p, gws, gwsb, gC, gbias, gcsum, AMODE == A_MC && csum_on, m0, n0);
+    }
 }
 
 
@@ -757,6 +806,11 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmP p) {
                 *dst = v;
             }
         }
+    if (partial && p.tickets != nullptr) {                // in-kernel split-K reduction (see gemm_kernel)
+        int* sh = reinterpret_cast<int*>(smem);
+        if (splitk_last_arriver(p.tickets + (long)tl.by * gridDim.x + tl.bx, p.splits, sh))
+            splitk_finish_tile<BM, BN>(p, p.ws, nullptr, p.C, p.bias, nullptr, false, m0, n0);
+    }
 }
 
 static int g_c32_dbg = 0;
@@ -789,6 +843,8 @@ static int g_direct_c32_wgrad = 1;  // 32 -> 32 channel 3x3 weight gradients on 
 static int g_wgrad_planes = 1;      // weight-gradient shapes: bf16 planes + transpose reads (SPLIT = 3) instead of packed words (SPLIT = 1); bit-identical
 static int g_wgrad_wide = 1;        // Cout <= 32 weight gradients: one 32 x 384 tile spans all 9*Cin columns (dy tile staged once instead of 3 times)
 static int g_wgrad_blocks = 0;      // 0 = per-shape default (see ha2g_conv2d_wgrad_workspace_bytes); else forced target
+static int g_plane_ksplit_model = 1, g_plane_ksplit_force = 0;   // ha2g_gemm_debug_plane_ksplit
+static long g_inkernel_bytes = 3L << 19;   // ha2g_gemm_debug_inkernel_bytes
 static int g_split_tiles = 192;   // swept on the full step: <=100 is 5-30 % slower, >=192 flat
 
 // sum of p[z * stride] for z = z0, z0 + step, ... < n, accumulated in double IN THAT ORDER; eight loads are issued before the first add (the
@@ -863,10 +919,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* ws
 }
 
 template <int MI, int NI, int WM, int WN, int AMODE, int BMODE, bool VEC>
-int launch(const GemmP& p, hipStream_t st) {
+int launch(const GemmP& p_in, hipStream_t st) {
     constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
+    GemmP p = p_in;
     const int groups = p.groups > 1 ? p.groups : 1;
     dim3 grid(ceil_div(p.M, BM), ceil_div(p.N, BN), p.splits * groups);
+    p.tickets = nullptr;
+    // in-kernel reduction where ONE workgroup can add a tile's slabs in a few microseconds (it reads at ~70 GB/s: <= 1.5 MB); hundreds of slabs over a
+    // small output (implicit-GEMM convolution weight gradients) keep the chip-wide reduce launch below
+    if (p.splits > 1 && (long)grid.x * grid.y * groups <= HA2G_SPLITK_TICKETS && (long)p.splits * BM * BN * 4 <= g_inkernel_bytes) p.tickets = splitk_tickets_for(st);
     // tile depth BKT = 16.  (BKT = 32 was measured 5-20 % slower on MI355X: fewer resident blocks per CU, more staging
     // registers; the template parameter stays for future tuning.)
     constexpr bool X3_SHAPE = (AMODE == A_KC || AMODE == A_IM) && BMODE == B_KC && VEC;
@@ -924,7 +985,7 @@ int launch(const GemmP& p, hipStream_t st) {
     }
     if (!use_x3 && !use_split) hipLaunchKernelGGL((gemm_kernel<MI, NI, WM, WN, AMODE, BMODE, VEC, 16>), grid, dim3(256), 0, st, p);
     HA2G_CHECK_LAUNCH("gemm");
-    if (p.splits > 1) {
+    if (p.splits > 1 && p.tickets == nullptr) {
         long MN = (long)p.M * p.N;
         ReduceOut ro{};
         ro.groups = groups;
@@ -1098,6 +1159,8 @@ extern "C" {
 void ha2g_gemm_set_mode(int mode) { g_x3 = mode & 1; g_split_wgrad = (mode >> 1) & 1; g_split_dgrad = (mode >> 2) & 1; g_x6 = (mode >> 3) & 1; g_bf16 = (mode >> 4) & 1; g_x6_dense = (mode >> 5) & 1; g_np3 = (mode >> 6) & 1; }
 int ha2g_gemm_bwd_pieces(void) { return (g_bf16 || !(g_split_wgrad || g_split_dgrad)) ? 0 : gemm_bwd_pieces(); }
 void ha2g_gemm_debug_x6_min_n(int n) { g_x6_min_n = n; }
+void ha2g_gemm_debug_inkernel_bytes(long n) { g_inkernel_bytes = n; }
+void ha2g_gemm_debug_plane_ksplit(int model, int force) { g_plane_ksplit_model = model; g_plane_ksplit_force = force; }
 void ha2g_gemm_debug_tile(int cfg, int splits) { g_tile_model = cfg != -2; g_tile_force = cfg == -2 ? -1 : cfg; g_splits_force = splits; }
 void ha2g_conv_debug_direct_c32(int on) { g_direct_c32 = on & 1; g_direct_c32_dgrad = (on >> 1) & 1; g_direct_c32_x3 = !((on >> 2) & 1); g_c32_dbg = on & 0x30; g_c32_fwd3 = !((on >> 6) & 1); }
 void ha2g_conv_debug_cfg(int cfg) { if (cfg >= 40000) g_direct_c32_wgrad = cfg - 40000; else if (cfg >= 30000) g_wgrad_planes = cfg - 30000; else if (cfg >= 20000) g_wgrad_wide = cfg - 20000; else if (cfg >= 10000) g_wgrad_blocks = cfg - 10000; else if (cfg >= 1000) g_split_tiles = cfg - 1000; else g_conv_cfg = cfg; }   /* 1000+n: split-K tile threshold n; 10000+n: wgrad block target n */
@@ -1137,20 +1200,43 @@ int ha2g_gemm_planes_np_f32(const void* a, long a_ps, long lda, const void* b, l
     HA2G_REQUIRE(act >= 0 && act <= 2, "gemm_planes: act %d (0 none, 1 relu, 2 leaky-relu)", act);
     if (M == 0 || N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    // split-K when the tile grid leaves most CUs idle and k is deep enough
-    int mt = 0, bn = 0;
-    plane_gemm_plan(M, N, 1, &mt, &bn);
-    const long tiles = (long)ceil_div(M, 32 * mt) * ceil_div(N, bn);
     const int nkt = (K + 31) / 32, ncu = cu_count();
-    int ksplit = 1;
-    if (tiles * 2 <= ncu && nkt >= 16) {
-        ksplit = (int)((ncu + tiles - 1) / tiles);
-        if (ksplit > nkt / 8) ksplit = nkt / 8;
-        while (ksplit > 1 && (long)ksplit * M * N * 4 > ws_bytes) --ksplit;
-        if (ksplit < 1) ksplit = 1;
+    int ksplit = 1, mt = 0, bn = 0;
+    int* tickets = splitk_tickets_for(st);
+    if (g_plane_ksplit_model && tickets != nullptr) {
+        // Split-K by a time model of the q kernel (round 6).  One workgroup takes ~2.4 us per 32-deep k tile whatever its tile shape (its LOAD phase --
+        // the A tile's LDS-DMA -- bounds a k tile, so a 64-column tile is not faster than a 128-column one) plus ~6 us of prologue / epilogue, and a
+        // launch lasts rounds x that: the GRU dX product [4352 x 600] x K = 1800 ran ONE round of 170 workgroups x 57 k tiles (150-166 us = 0.11 of the
+        // roofline); three k slices of 19 tiles on 240 workgroups of 288 x 128 are one round of a third the depth.  The k slices are
+        // added in the kernel by each tile's last arriver (~70 GB/s per workgroup): + 4 us + slab bytes / 70 GB/s.
+        double best = 1e300;
+        for (int ks = 1; ks <= 8 && (ks == 1 || ks <= nkt / 8); ++ks) {
+            if ((long)ks * M * N * 4 > ws_bytes && ks > 1) break;
+            int cmt = 0, cbn = 0;
+            if (plane_gemm_plan(M, N, ks, &cmt, &cbn) != 0) continue;
+            const long tiles = (long)ceil_div(M, 32 * cmt) * ceil_div(N, cbn);
+            if (ks > 1 && tiles > HA2G_SPLITK_TICKETS) continue;
+            const long rounds = (tiles * ks + ncu - 1) / ncu;
+            const int kt_per = (nkt + ks - 1) / ks;
+            double t = (double)rounds * (kt_per * 2.4 + 6.0);
+            if (ks > 1) t += 4.0 + (double)ks * (32.0 * cmt * cbn * 4.0) / 70e3;
+            if (t < best - 1e-9) { best = t; ksplit = ks; mt = cmt; bn = cbn; }
+        }
+    } else {
+        // round 4-5 rule: split-K when the tile grid leaves most CUs idle and k is deep enough (raw slabs, reduced by a second launch)
+        tickets = nullptr;
+        plane_gemm_plan(M, N, 1, &mt, &bn);
+        const long tiles = (long)ceil_div(M, 32 * mt) * ceil_div(N, bn);
+        if (tiles * 2 <= ncu && nkt >= 16) {
+            ksplit = (int)((ncu + tiles - 1) / tiles);
+            if (ksplit > nkt / 8) ksplit = nkt / 8;
+            while (ksplit > 1 && (long)ksplit * M * N * 4 > ws_bytes) --ksplit;
+            if (ksplit < 1) ksplit = 1;
+        }
     }
-    if (int rc = plane_gemm_launch(a, a_ps, lda, b, b_ps, ldb, M, N, K, C, ldc, beta, bias, act, ws, ksplit, st)) return rc;
-    if (ksplit > 1) {
+    if (g_plane_ksplit_force > 0 && g_plane_ksplit_force <= nkt / 2 && (long)g_plane_ksplit_force * M * N * 4 <= ws_bytes) ksplit = g_plane_ksplit_force;
+    if (int rc = plane_gemm_launch(a, a_ps, lda, b, b_ps, ldb, M, N, K, C, ldc, beta, bias, act, ws, ksplit, tickets, st)) return rc;
+    if (ksplit > 1 && tickets == nullptr) {
         const int kt_per = (nkt + ksplit - 1) / ksplit, used = (nkt + kt_per - 1) / kt_per;      // slabs the kernel wrote (the last slices may be empty)
         const long MN = (long)M * N;
         ReduceOut ro{};

@@ -14,7 +14,34 @@ int ha2g_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int ha2g_abi_version(void) { return 4; }      // 2: guarded Adam, ha2g_sparse_adam2_f32, N-piece plane entry points (*_np); 3: ha2g_gru_cluster_tile_cap; 4: BatchNorm statistics from the forward convolution's epilogue
+extern "C" int ha2g_abi_version(void) { return 5; }      // 2: guarded Adam, ha2g_sparse_adam2_f32, N-piece plane entry points (*_np); 3: ha2g_gru_cluster_tile_cap; 4: BatchNorm statistics from the forward convolution's epilogue; 5: ha2g_splitk_set_tickets (in-kernel split-K reduction)
+
+// ---- split-K arrival tickets per (device, stream): see common.h ----
+#include <mutex>
+#include <map>
+static std::mutex g_tk_mu;
+static std::map<std::pair<int, void*>, int*> g_tk;
+static int g_tk_on = 1;
+int* splitk_tickets_for(hipStream_t st) {
+    if (!g_tk_on) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_tk_mu);
+    auto it = g_tk.find({dev, (void*)st});
+    return it == g_tk.end() ? nullptr : it->second;
+}
+// tickets: HA2G_SPLITK_TICKETS (16384) ints of device memory, ZEROED by the caller, owned by the caller, used by every split-K launch on `stream`
+// of the current device from now on (nullptr: unregister -> those launches use the separate reduce launch again)
+extern "C" int ha2g_splitk_set_tickets(void* tickets, long n_ints, void* stream) {
+    HA2G_REQUIRE(tickets == nullptr || n_ints >= HA2G_SPLITK_TICKETS, "splitk_set_tickets: %ld ticket words (< %d)", n_ints, HA2G_SPLITK_TICKETS);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return ha2g_set_error(-2, "splitk_set_tickets: no current device");
+    std::lock_guard<std::mutex> lk(g_tk_mu);
+    if (tickets) g_tk[{dev, stream}] = (int*)tickets; else g_tk.erase({dev, stream});
+    return 0;
+}
+extern "C" int ha2g_splitk_ticket_words(void) { return HA2G_SPLITK_TICKETS; }
+extern "C" void ha2g_splitk_in_kernel(int on) { g_tk_on = on; }      // A/B: 0 = every split-K launch followed by its reduce launch (round 5)
 
 namespace {
 

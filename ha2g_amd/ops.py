@@ -15,6 +15,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 
 _WS_BYTES = 320 << 20      # per (device, stream) scratch: sized for the largest reduction of the path (contrastive pair block + split-K partials at N = 256 x 62 rows)
 _ws = {}
+_tickets = {}
 
 
 # The raw handle of the current stream straight from the C layer: `torch.cuda.current_stream().cuda_stream` builds a Stream object through four python
@@ -47,9 +48,17 @@ def cur_stream(device=None):
 def workspace(device):
     """One persistent scratch buffer per (device, stream) (split-K partials, reduction partials).  Kernels of one stream
     run in order, so they can share it; the weight-gradient side stream gets its own.  Allocated once, outside capture."""
-    key = (device.type, device.index, _raw_stream(device.index if device.index is not None else _cur_device()))
+    raw = _raw_stream(device.index if device.index is not None else _cur_device())
+    key = (device.type, device.index, raw)
     if key not in _ws:
         _ws[key] = torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=device)
+        if device.type == 'cuda':
+            # the stream's split-K arrival tickets (include/ha2g_hip.h, ABI 5): zeroed once, registered with the library for this stream -- its
+            # split-K launches then add their slabs in the kernel (last arriver per tile) instead of a second reduce launch
+            tk = torch.zeros(lib.ha2g_splitk_ticket_words(), dtype=torch.int32, device=device)
+            with torch.cuda.device(device):
+                check(lib.ha2g_splitk_set_tickets(tk.data_ptr(), tk.numel(), raw))
+            _tickets[key] = tk
     return _ws[key]
 
 

@@ -24,7 +24,7 @@ extern "C" {
 
 /* Bumped whenever an exported signature changes or entry points are added that a host must not mix with an older library:
  * ha2g_amd/_lib.py refuses to bind a library whose ha2g_abi_version() differs from this macro. */
-#define HA2G_ABI_VERSION 4
+#define HA2G_ABI_VERSION 5
 int ha2g_abi_version(void);
 const char* ha2g_last_error(void);
 
@@ -191,6 +191,22 @@ int ha2g_conv2d_wgrad_planes_f32(const void* x_hi, const void* x_lo, const void*
  *                this mode -- never two pieces.  Mode 6 (two pieces, 16-bit operand mantissa) survives as a labelled secondary mode.
  * 0 = exact fp32 MFMA everywhere. */
 void ha2g_gemm_set_mode(int mode);
+/* ---- in-kernel split-K reduction (ABI 5) -------------------------------------------------------------------------------------------------
+ * A split-K launch (small tile grids: weight gradients dW = dY^T X of nn.Linear / nn.GRU / the TCN convolutions, the GRU's dX product; the
+ * reference's addmm backward, model/hierarchy_net.py:87-93,144-147, model/tcn.py:19-31) leaves `splits` raw slabs in `ws`.  With a ticket buffer
+ * registered for the launch stream the slices of an output tile take a ticket and the LAST arriver adds the slabs in slice order (double
+ * accumulation: the arithmetic of the reduce launch it replaces; no float atomics, bitwise reproducible) inside the same launch.
+ * ha2g_splitk_set_tickets: `tickets` = ha2g_splitk_ticket_words() ints of device memory, ZEROED once by the caller and never written by it again
+ * (the kernels leave them zero); applies to every split-K launch on `stream` of the current device from then on; tickets = NULL unregisters
+ * (a second reduce launch per split-K launch, as before ABI 5).  One buffer per stream: kernels of one stream run in order.
+ * ha2g_splitk_in_kernel(0): A/B switch -- ignore the registered buffers. */
+int ha2g_splitk_set_tickets(void* tickets, long n_ints, void* stream);
+int ha2g_splitk_ticket_words(void);
+void ha2g_splitk_in_kernel(int on);
+/* tuning aids: the largest number of slab bytes one workgroup adds in the kernel (larger tiles x splits keep the reduce launch; default 1.5 MB);
+ * the plane GEMM's split-K rule (model = 1: time model + in-kernel reduction, 0: the round-5 rule; force > 0: that many k slices) */
+void ha2g_gemm_debug_inkernel_bytes(long n);
+void ha2g_gemm_debug_plane_ksplit(int model, int force);
 /* tuning aid: forward GEMMs narrower than n columns stay on the fp32 MFMA */
 void ha2g_gemm_debug_x6_min_n(int n);
 /* tuning aid (tools/gemm_tile_sweep.py): force the dense tile shape (0-8, see kTileBM/kTileBN in csrc/gemm.hip; -1 = default rule,

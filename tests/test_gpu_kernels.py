@@ -688,3 +688,73 @@ def test_direct_c32_weight_gradient(shape):
     base = acc.clone()
     we.conv_wgrad(x, dy, w0, 1, 1, into=acc)
     assert float((acc.double() - (base.double() + ref)).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [  # (G, M, N, K, transa, transb, bias / csum, act, beta)
+    (1, 900, 600, 4352, True, False, True, 0, 1.0),       # GRU dW_ih: 7 k slices, fused bias gradient, accumulate into .grad
+    (2, 900, 600, 4352, True, False, True, 0, 1.0),       # ... both directions grouped
+    (3, 300, 600, 4352, True, False, True, 0, 0.0),       # TCN dW grouped: 12 slices
+    (1, 150, 300, 4352, True, False, False, 0, 0.0),      # 34 slices over 6 tiles ("wide" reduce before)
+    (1, 129, 77, 1000, True, False, True, 0, 1.0),        # ragged: scalar paths of the in-kernel reduction
+    (1, 96, 40, 2048, False, True, True, 2, 1.0),         # forward shape with bias + leaky-relu + beta through the slabs
+    (1, 64, 200, 1536, False, False, False, 1, 0.0),      # data-gradient shape, relu
+    (1, 4352, 600, 1800, False, False, False, 0, 0.0),    # GRU dX: the plane GEMM (three k slices of the q kernel, reduced by the tile's last arriver)
+    (1, 4352, 600, 1800, False, False, False, 0, 1.0),
+    (1, 1024, 384, 2560, False, True, True, 2, 1.0),      # plane GEMM, transb, bias + leaky-relu + beta
+])
+def test_split_k_reduced_in_the_kernel_by_the_last_arriver(case):
+    """Round 6: a split-K launch whose stream has arrival tickets registered (ops.workspace does that) adds its slabs IN THE KERNEL -- the last k slice of
+    an output tile to arrive sums them in slice order, in double -- instead of leaving them to splitk_reduce[_wide]_kernel.  Same arithmetic, element for
+    element: the result is BIT-IDENTICAL to the two-launch form (ha2g_splitk_in_kernel(0)), equal to float64 at the split-product bound, bitwise stable
+    over 25 repetitions (arrival order varies, summation order does not; the tickets re-zero themselves), with the fused bias gradient reduced alike."""
+    from ha2g_amd import ops
+    from ha2g_amd._lib import lib
+    G, M, N, K, ta, tb, extra, act, beta = case
+    gen = torch.Generator(device='cuda:0').manual_seed(M * 31 + N * 7 + K + G)
+    A = [torch.randn((K, M) if ta else (M, K), device='cuda:0', generator=gen) for _ in range(G)]
+    Bm = [torch.randn((N, K) if tb else (K, N), device='cuda:0', generator=gen) for _ in range(G)]
+    C0 = [torch.randn(M, N, device='cuda:0', generator=gen) for _ in range(G)]
+    wgrad = ta and not tb
+    bias = [torch.randn(N, device='cuda:0', generator=gen) for _ in range(G)] if (extra and not wgrad) else None
+    cs0 = [torch.randn(M, device='cuda:0', generator=gen) for _ in range(G)] if (extra and wgrad) else None
+
+    def run():
+        out = [c.clone() for c in C0]
+        cs = [c.clone() for c in cs0] if cs0 is not None else None
+        kw = dict(transa=ta, transb=tb, beta=beta, act=act)
+        if G == 1:
+            ops.gemm(A[0], Bm[0], out=out[0], bias=None if bias is None else bias[0], **kw,
+                     **(dict(colsum_out=cs[0], colsum_beta=1.0) if cs is not None else {}))
+        else:
+            ops.gemm_grouped(A, Bm, out=out, bias=bias, colsum_out=cs, colsum_beta=1.0, **kw)
+        torch.cuda.synchronize()
+        return out, cs
+    ops.workspace(torch.device('cuda:0'))                     # registers the tickets of this stream
+    lib.ha2g_splitk_in_kernel(0)
+    try:
+        ref, ref_cs = run()
+    finally:
+        lib.ha2g_splitk_in_kernel(1)
+    got, got_cs = run()
+    plane = G == 1 and 2.0 * M * N * K >= ops.PLANE_GEMM_MIN_FLOP and min(M, N) >= 128      # the plane GEMM also re-plans its k slices: fp32-level agreement
+    for g in range(G):
+        if plane:
+            assert float((got[g] - ref[g]).abs().max()) <= 2e-6 * float(ref[g].abs().max())
+        else:
+            assert torch.equal(got[g], ref[g]), (g, float((got[g] - ref[g]).abs().max()))
+        if cs0 is not None:
+            assert torch.equal(got_cs[g], ref_cs[g])
+        r64 = A[g].double().t() @ Bm[g].double() if ta else A[g].double() @ (Bm[g].double().t() if tb else Bm[g].double())
+        r64 = r64 + (bias[g].double() if bias is not None else 0.0) + beta * C0[g].double()
+        if act == 1:
+            r64 = r64.clamp_min(0)
+        elif act == 2:
+            r64 = torch.where(r64 > 0, r64, 0.01 * r64)
+        assert float((got[g].double() - r64).abs().max()) <= 3e-5 * float(r64.abs().max())
+    for _ in range(25):
+        again, again_cs = run()
+        assert all(torch.equal(a, b) for a, b in zip(again, got))
+        assert cs0 is None or all(torch.equal(a, b) for a, b in zip(again_cs, got_cs))
+    tk = ops._tickets[('cuda', 0, ops._raw_stream(0))]
+    assert int(tk.abs().sum()) == 0                            # every ticket is back at zero
