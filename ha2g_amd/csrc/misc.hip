@@ -21,7 +21,7 @@ extern "C" int ha2g_abi_version(void) { return 5; }      // 2: guarded Adam, ha2
 #include <map>
 static std::mutex g_tk_mu;
 static std::map<std::pair<int, void*>, int*> g_tk;
-static int g_tk_on = 1;
+static int g_tk_on = 0;       // OFF by default: measured slower than the reduce launch on this path (profiles/r06_splitk_inkernel.txt)
 int* splitk_tickets_for(hipStream_t st) {
     if (!g_tk_on) return nullptr;
     int dev = 0;
@@ -41,7 +41,7 @@ extern "C" int ha2g_splitk_set_tickets(void* tickets, long n_ints, void* stream)
     return 0;
 }
 extern "C" int ha2g_splitk_ticket_words(void) { return HA2G_SPLITK_TICKETS; }
-extern "C" void ha2g_splitk_in_kernel(int on) { g_tk_on = on; }      // A/B: 0 = every split-K launch followed by its reduce launch (round 5)
+extern "C" void ha2g_splitk_in_kernel(int on) { g_tk_on = on; }      // 1 = add the slabs in the kernel where a ticket buffer is registered; 0 (default) = the reduce launch
 
 namespace {
 

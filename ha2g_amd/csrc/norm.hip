@@ -511,6 +511,31 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
     }
 }
 
+// Weight and bias gradients of the SE excitation MLP in ONE launch (round 6; ResNetBlocks.py:84-89 under autograd):
+//   dW2[c][j] += sum_n dsc[n][c] h1[n][j],  db2[c] += sum_n dsc[n][c]          (fc.2: Linear(R -> C), weight [C][R])
+//   dW0[j][c] += sum_n dh1[n][j] pooled[n][c],  db0[j] += sum_n dh1[n][j]      (fc.0: Linear(C -> R), weight [R][C])
+// Before: two generic weight-gradient GEMM launches per block (M, N <= 256, K = batch: < 1 MFLOP each, 33-94 us apiece in the step = 1.7 ms per
+// step over the 16 blocks, profiles/r05_gemm_census.txt).  Block = 8 channels x 32 hidden units, thread (c, j) walks the batch in ascending order
+// (fixed order, fp32: 128 terms); no atomics.
+__global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* __restrict__ dsc, const float* __restrict__ h1, const float* __restrict__ dh1,
+                                                           const float* __restrict__ pooled, float* __restrict__ dw2, float* __restrict__ db2,
+                                                           float* __restrict__ dw0, float* __restrict__ db0, int N, int C, int R) {
+    const int t = threadIdx.x, j = t & 31, c = blockIdx.x * 8 + (t >> 5);
+    const bool on = c < C && j < R;
+    float a2 = 0.f, a0 = 0.f, b2 = 0.f, b0 = 0.f;
+    if (c < C) {
+        for (int n = 0; n < N; ++n) {
+            const float d = dsc[(long)n * C + c], pl = pooled[(long)n * C + c];
+            const float h = j < R ? h1[(long)n * R + j] : 0.f, g = j < R ? dh1[(long)n * R + j] : 0.f;
+            a2 = fmaf(d, h, a2); a0 = fmaf(g, pl, a0);
+            b2 += d; b0 += g;
+        }
+    }
+    if (on) { dw2[(long)c * R + j] += a2; dw0[(long)j * C + c] += a0; }
+    if (c < C && j == 0) db2[c] += b2;
+    if (blockIdx.x == 0 && t < 32 && j < R) db0[j] += b0;          // channel 0's threads: b0 does not depend on c
+}
+
 inline int chunk_blocks(long rows) {
     long b = rows / 512;
     if (b < 1) b = 1;
@@ -824,6 +849,15 @@ int ha2g_se_mlp_bwd_f32(const float* dsc, const float* h1, const float* w2, cons
     if (N == 0) return 0;
     hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, dsc, h1, w2, w0, dh1, dpool, C, R, inv_hw);
     HA2G_CHECK_LAUNCH("se_mlp_bwd");
+    return 0;
+}
+
+int ha2g_se_mlp_wgrad_f32(const float* dsc, const float* h1, const float* dh1, const float* pooled, float* dw2, float* db2, float* dw0, float* db0,
+                          int N, int C, int R, void* stream) {
+    HA2G_REQUIRE(ha2g_se_mlp_bwd_supported(C, R), "se_mlp_wgrad: unsupported widths C = %d, R = %d", C, R);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, dsc, h1, dh1, pooled, dw2, db2, dw0, db0, N, C, R);
+    HA2G_CHECK_LAUNCH("se_mlp_wgrad");
     return 0;
 }
 

@@ -294,6 +294,7 @@ _FWD_PLANES = [False]      # this forward will be back-propagated through the pl
 # this forward will be back-propagated at all.  torch.is_grad_enabled() cannot tell: inside autograd.Function.forward it is always False.
 # WavEncoderFunction.forward sets it from `training and any(ctx.needs_input_grad)`; direct block_fwd() callers (tests, tools) back-propagate.
 _WILL_BWD = [True]
+SE_WGRAD_FUSED = True      # the SE excitation MLP's four parameter gradients in one launch (GradSink.gse)
 
 
 def _bn_fwd(x, bn, pool=False, planes=False, planes_only=False, stats=None):
@@ -415,6 +416,28 @@ class GradSink:
             self.forked = True
         else:
             self._gwb(wname, bname, a, b_)
+
+    def gse(self, b, dsc, h1, dh1, pooled):
+        """the four parameter gradients of a block's SE excitation MLP: ONE launch (ha2g_se_mlp_wgrad_f32) on the side stream when all four accumulate into
+        installed .grad buffers, else the two generic weight-gradient GEMMs"""
+        names = [b + 'se.fc.2.weight', b + 'se.fc.2.bias', b + 'se.fc.0.weight', b + 'se.fc.0.bias']
+        tg = [self.tgt(self.P[n]) for n in names]
+        N, C = dsc.shape
+        R = h1.shape[1]
+        if not (SE_WGRAD_FUSED and all(t is not None and t.is_contiguous() for t in tg) and dsc.is_cuda and lib.ha2g_se_mlp_bwd_supported(C, R)):
+            self.gwb(names[0], names[1], dsc, h1)
+            self.gwb(names[2], names[3], dh1, pooled)
+            return
+        side_on = SIDE_FC_WGRAD and SIDE_WGRAD and ops.side.enabled
+        with (ops.side.section(dsc.device) if side_on else ops._null()):
+            if side_on:
+                st = ops.cur_stream(dsc.device)
+                for t in (dsc, h1, dh1, pooled):
+                    t.record_stream(st)
+            check(lib.ha2g_se_mlp_wgrad_f32(dsc.data_ptr(), h1.data_ptr(), dh1.data_ptr(), pooled.data_ptr(), tg[0].data_ptr(), tg[1].data_ptr(),
+                                            tg[2].data_ptr(), tg[3].data_ptr(), N, C, R, _stream()))
+        if side_on:
+            self.forked = True
 
     def _gwb(self, wname, bname, a, b_):
         tw, tb = self.tgt(self.P[wname]), self.tgt(self.P[bname])
@@ -608,9 +631,8 @@ def block_bwd(dx, saved, P, b, sink):
         check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, sc.data_ptr(),
                                         ops.workspace(dout.device).data_ptr(), _stream()))
     dsc = ds                                            # already times the gate's sigmoid' (folded into the reduction's final pass)
-    sink.gwb(b + 'se.fc.2.weight', b + 'se.fc.2.bias', dsc, h1)
     dh1, dpool = se_mlp_bwd(dsc, h1, P[b + 'se.fc.2.weight'], P[b + 'se.fc.0.weight'], HW)
-    sink.gwb(b + 'se.fc.0.weight', b + 'se.fc.0.bias', dh1, pooled)
+    sink.gse(b, dsc, h1, dh1, pooled)
     dres, db2 = torch.empty_like(c2), torch.empty_like(c2)
     check(lib.ha2g_se_bwd_apply_f32(dout.data_ptr(), out.data_ptr(), sc.data_ptr(), dpool.data_ptr(), dres.data_ptr(),
                                     db2.data_ptr(), N, HW, C, _stream()))

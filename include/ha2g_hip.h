@@ -354,6 +354,11 @@ int ha2g_se_mlp_fwd_f32(const float* pooled_in, const void* stat_part, int nblk,
 int ha2g_se_mlp_bwd_supported(int C, int R);
 int ha2g_se_mlp_bwd_f32(const float* dsc, const float* h1, const float* w2, const float* w0, float* dh1, float* dpool, int N, int C, int R,
                         float inv_hw, void* stream);
+/* weight and bias gradients of the SE excitation MLP, ACCUMULATED into their gradient buffers, in one launch (ABI 5; autograd's addmm backward + sum(0)
+ * of the two nn.Linear of model/ResNetBlocks.py:84-89): dw2 [C][R] += dsc^T h1, db2 [C] += column sums of dsc, dw0 [R][C] += dh1^T pooled, db0 [R] += column
+ * sums of dh1; dsc [N][C], h1 / dh1 [N][R], pooled [N][C].  Replaces two ha2g_gemm_wgrad_bias_f32 launches per block. */
+int ha2g_se_mlp_wgrad_f32(const float* dsc, const float* h1, const float* dh1, const float* pooled, float* dw2, float* db2, float* dw0, float* db0,
+                          int N, int C, int R, void* stream);
 int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, const float* dpool, float* dres,
                           float* dx, int N, int HW, int C, void* stream);
 /* speaker-softmax blending of the three audio taps (model/ResNetSE34V2.py:202-212) */

@@ -704,10 +704,11 @@ def test_direct_c32_weight_gradient(shape):
     (1, 1024, 384, 2560, False, True, True, 2, 1.0),      # plane GEMM, transb, bias + leaky-relu + beta
 ])
 def test_split_k_reduced_in_the_kernel_by_the_last_arriver(case):
-    """Round 6: a split-K launch whose stream has arrival tickets registered (ops.workspace does that) adds its slabs IN THE KERNEL -- the last k slice of
-    an output tile to arrive sums them in slice order, in double -- instead of leaving them to splitk_reduce[_wide]_kernel.  Same arithmetic, element for
-    element: the result is BIT-IDENTICAL to the two-launch form (ha2g_splitk_in_kernel(0)), equal to float64 at the split-product bound, bitwise stable
-    over 25 repetitions (arrival order varies, summation order does not; the tickets re-zero themselves), with the fused bias gradient reduced alike."""
+    """Round 6 (built, measured, NOT the default: profiles/r06_splitk_inkernel.txt): with ha2g_splitk_in_kernel(1) a split-K launch whose
+    stream has arrival tickets registered (ops.workspace does that) adds its slabs IN THE KERNEL -- the last k slice of an output tile to arrive sums them
+    in slice order, in double -- instead of leaving them to splitk_reduce[_wide]_kernel.  Same arithmetic, element for element: the result is BIT-IDENTICAL
+    to the two-launch form (the default), equal to float64 at the split-product bound, bitwise stable over 25 repetitions (arrival order varies, summation
+    order does not; the tickets re-zero themselves), with the fused bias gradient reduced alike."""
     from ha2g_amd import ops
     from ha2g_amd._lib import lib
     G, M, N, K, ta, tb, extra, act, beta = case
@@ -731,12 +732,16 @@ def test_split_k_reduced_in_the_kernel_by_the_last_arriver(case):
         torch.cuda.synchronize()
         return out, cs
     ops.workspace(torch.device('cuda:0'))                     # registers the tickets of this stream
-    lib.ha2g_splitk_in_kernel(0)
+    ref, ref_cs = run()                                       # default: the two-launch form
+    lib.ha2g_splitk_in_kernel(1)
     try:
-        ref, ref_cs = run()
+        got, got_cs = run()
+        for _ in range(25):
+            again, again_cs = run()
+            assert all(torch.equal(a, b) for a, b in zip(again, got))
+            assert cs0 is None or all(torch.equal(a, b) for a, b in zip(again_cs, got_cs))
     finally:
-        lib.ha2g_splitk_in_kernel(1)
-    got, got_cs = run()
+        lib.ha2g_splitk_in_kernel(0)
     plane = G == 1 and 2.0 * M * N * K >= ops.PLANE_GEMM_MIN_FLOP and min(M, N) >= 128      # the plane GEMM also re-plans its k slices: fp32-level agreement
     for g in range(G):
         if plane:
@@ -752,9 +757,26 @@ def test_split_k_reduced_in_the_kernel_by_the_last_arriver(case):
         elif act == 2:
             r64 = torch.where(r64 > 0, r64, 0.01 * r64)
         assert float((got[g].double() - r64).abs().max()) <= 3e-5 * float(r64.abs().max())
-    for _ in range(25):
-        again, again_cs = run()
-        assert all(torch.equal(a, b) for a, b in zip(again, got))
-        assert cs0 is None or all(torch.equal(a, b) for a, b in zip(again_cs, got_cs))
     tk = ops._tickets[('cuda', 0, ops._raw_stream(0))]
     assert int(tk.abs().sum()) == 0                            # every ticket is back at zero
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,C,R', [(128, 32, 4), (128, 64, 8), (128, 128, 16), (128, 256, 32), (5, 48, 6)])
+def test_se_mlp_parameter_gradients_in_one_launch(N, C, R):
+    """ha2g_se_mlp_wgrad_f32 (round 6): dW / db of the SE excitation MLP's two Linear layers (model/ResNetBlocks.py:84-89), accumulated into existing
+    buffers, against float64; and through GradSink.gse == the two generic weight-gradient GEMMs it replaces at fp32 level."""
+    from ha2g_amd._lib import check, lib
+    from ha2g_amd.ops import _stream
+    g = torch.Generator(device='cuda:0').manual_seed(N * 1000 + C)
+    dsc, pooled = torch.randn(N, C, device='cuda:0', generator=g), torch.randn(N, C, device='cuda:0', generator=g)
+    h1, dh1 = torch.randn(N, R, device='cuda:0', generator=g).clamp_min(0), torch.randn(N, R, device='cuda:0', generator=g)
+    init = [torch.randn(C, R, device='cuda:0', generator=g), torch.randn(C, device='cuda:0', generator=g),
+            torch.randn(R, C, device='cuda:0', generator=g), torch.randn(R, device='cuda:0', generator=g)]
+    out = [t.clone() for t in init]
+    check(lib.ha2g_se_mlp_wgrad_f32(dsc.data_ptr(), h1.data_ptr(), dh1.data_ptr(), pooled.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                    out[2].data_ptr(), out[3].data_ptr(), N, C, R, _stream()))
+    ref = [init[0].double() + dsc.double().t() @ h1.double(), init[1].double() + dsc.double().sum(0),
+           init[2].double() + dh1.double().t() @ pooled.double(), init[3].double() + dh1.double().sum(0)]
+    for o, r in zip(out, ref):
+        assert float((o.double() - r).abs().max()) <= 2e-6 * max(float(r.abs().max()), 1.0) * (N ** 0.5)

@@ -350,24 +350,29 @@ def _full_size_step(expressive, B, fuse, mode, seed=21, fuse_text=True, b16=Fals
 
 def _elementwise_bridge(what, g_a, g_b, rtol):
     """max|a - b| <= rtol * max|b| for EVERY parameter tensor; prints the worst ratio (max|a - b| / max|b|) per module.  A gradient that is ZERO by
-    construction (a convolution bias in front of a BatchNorm: pure rounding residue, 1e-7 of its neighbours) has no scale of its own to be relative
-    to: a tensor's scale is floored at 1e-4 of the median tensor scale of its module."""
+    construction (a convolution bias in front of a BatchNorm -- D's pre_conv.0 / pre_conv.3: pure rounding residue, below 1e-5 of its module's median
+    tensor scale) has no scale of its own to be relative to: it is held absolutely, at rtol x that median scale."""
     assert sorted(g_a) == sorted(g_b) and len(g_a) > 100
     scales = {}
     for k, b in g_b.items():
         scales.setdefault(k.split('.')[0], []).append(float(b.abs().max()))
-    floor = {m: 1e-4 * float(np.median(v)) for m, v in scales.items()}
-    worst, bad = {}, []
+    med = {m: float(np.median(v)) for m, v in scales.items()}
+    worst, bad, residues = {}, [], []
     for k, b in g_b.items():
         m = k.split('.')[0]
-        scale = max(float(b.abs().max()), floor[m])
+        scale = float(b.abs().max())
+        if scale < 1e-5 * med[m]:
+            residues.append(k)
+            scale = med[m]
         err = float((g_a[k] - b).abs().max())
         r = err / scale if scale > 0 else (0.0 if err == 0 else float('inf'))
         if r >= worst.get(m, (-1.0, ''))[0]:
             worst[m] = (r, k)
         if r > rtol:
             bad.append((k, r))
-    print('%s: worst max|d| / max|g| per module: %s' % (what, ', '.join('%s %.2e (%s)' % (m, r, k) for m, (r, k) in sorted(worst.items()))))
+    assert len(residues) <= 4, residues
+    print('%s: worst max|d| / max|g| per module: %s; held absolutely (zero by construction): %s' % (
+        what, ', '.join('%s %.2e (%s)' % (m, r, k) for m, (r, k) in sorted(worst.items())), residues))
     assert not bad, (what, rtol, sorted(bad, key=lambda kv: -kv[1])[:8])
 
 
