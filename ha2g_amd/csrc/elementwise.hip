@@ -282,8 +282,12 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
 }
 // mask[i] = keep ? 1/(1-p) : 0 ; out = x * mask.  state = {seed, step} lives in device memory so a captured
 // hipGraph draws fresh masks on every replay; `stream_id` separates call sites within a step.
+// mode (round 6, the TCN blocks' dropouts fused with their neighbours; same mask for the same (state, stream_id, element)):
+//   0: out = x * mask                          1: out = relu(x * mask + b)   (dropout + residual add + ReLU, model/tcn.py:44-46 after :29)
+//   2: out = b > 0 ? x * mask : 0              (backward: the dropout's backward and the ReLU' of the convolution in front of it, b = its output)
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ out, float* __restrict__ mask, long n, float p,
-                               const unsigned long long* __restrict__ state, unsigned stream_id, int vec) {
+                               const unsigned long long* __restrict__ state, unsigned stream_id, int vec, const float* __restrict__ b = nullptr,
+                               int mode = 0) {
     const unsigned long long seed = state[0], step = state[1];
     const float scale = 1.f / (1.f - p);
     const long n4 = (n + 3) >> 2;
@@ -300,7 +304,13 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
             if (mask) reinterpret_cast<float4*>(mask)[i] = make_float4(m[0], m[1], m[2], m[3]);
             if (out) {
                 const float4 v = reinterpret_cast<const float4*>(x)[i];
-                reinterpret_cast<float4*>(out)[i] = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+                float4 o = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+                if (mode != 0) {
+                    const float4 w = reinterpret_cast<const float4*>(b)[i];
+                    if (mode == 1) o = make_float4(fmaxf(o.x + w.x, 0.f), fmaxf(o.y + w.y, 0.f), fmaxf(o.z + w.z, 0.f), fmaxf(o.w + w.w, 0.f));
+                    else o = make_float4(w.x > 0.f ? o.x : 0.f, w.y > 0.f ? o.y : 0.f, w.z > 0.f ? o.z : 0.f, w.w > 0.f ? o.w : 0.f);
+                }
+                reinterpret_cast<float4*>(out)[i] = o;
             }
         } else {
 #pragma unroll
@@ -308,7 +318,12 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
                 long e = i * 4 + j;
                 if (e < n) {
                     if (mask) mask[e] = m[j];
-                    if (out) out[e] = x[e] * m[j];
+                    if (out) {
+                        float o = x[e] * m[j];
+                        if (mode == 1) o = fmaxf(o + b[e], 0.f);
+                        else if (mode == 2) o = b[e] > 0.f ? o : 0.f;
+                        out[e] = o;
+                    }
                 }
             }
         }
@@ -510,6 +525,18 @@ int ha2g_dropout_f32(const float* x, float* out, float* mask, long n, float p, c
     hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n, 4)), dim3(EB), 0, (hipStream_t)stream, x, out, mask, n, p,
                        (const unsigned long long*)state, stream_id, vec);
     HA2G_CHECK_LAUNCH("dropout");
+    return 0;
+}
+// mode 1: out = relu(x * mask + b); mode 2: out = b > 0 ? x * mask : 0 (see dropout_kernel); the mask is the one ha2g_dropout_f32 draws for the same
+// (state, stream_id, element)
+int ha2g_dropout_fused_f32(const float* x, const float* b, float* out, long n, float p, const void* state, unsigned stream_id, int mode, void* stream) {
+    if (n == 0) return 0;
+    HA2G_REQUIRE(p >= 0.f && p < 1.f, "dropout_fused: p=%f out of range", p);
+    HA2G_REQUIRE((mode == 1 || mode == 2) && x && b && out, "dropout_fused: mode %d (1, 2) / null operand", mode);
+    const int vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n, 4)), dim3(EB), 0, (hipStream_t)stream, x, out, (float*)nullptr, n, p,
+                       (const unsigned long long*)state, stream_id, vec, b, mode);
+    HA2G_CHECK_LAUNCH("dropout_fused");
     return 0;
 }
 int ha2g_dirsum_f32(const float* y, float* out, long rows, int H, int inverse, void* stream) {

@@ -99,12 +99,17 @@ class TemporalBlock(nn.Module):
         computed all of the network's weight norms in one launch."""
         d = self.dilation
         y = x
+        spec = None
         for ci, conv in enumerate((self.conv1, self.conv2)):
             w = ws[ci] if ws is not None else ops.weight_norm(conv.weight_g, conv.weight_v)
-            y = ops.conv1d_tm(y, w, conv.bias, dil=d, pad_left=d * (w.shape[2] - 1), To=x.shape[1], act=ACT_RELU)
-            y = ops.dropout(y, self.p, self.training)
+            # the block's two dropouts ride on their neighbours (ops.DropSpec): conv1's is applied by a launch of its own, its backward shares one launch with
+            # conv1's ReLU'; conv2's is applied by the residual add + ReLU below
+            spec = ops.make_drop(self.p, self.training, x.device, deferred=ci == 1) if x.is_cuda else None
+            y = ops.conv1d_tm(y, w, conv.bias, dil=d, pad_left=d * (w.shape[2] - 1), To=x.shape[1], act=ACT_RELU, drop=spec)
+            if spec is None:
+                y = ops.dropout(y, self.p, self.training)
         res = x if self.downsample is None else ops.conv1d_tm(x, self.downsample.weight, self.downsample.bias)
-        return ops.add_relu(y, res)
+        return ops.add_relu(y, res, drop=spec)
 
 
 class TemporalConvNet(nn.Module):
@@ -195,13 +200,16 @@ def grouped_text_encoders(encs, in_text, wn=None):
         blocks = [e.tcn.network[lvl] for e in encs]
         d, p = blocks[0].dilation, blocks[0].p
         y = x
+        spec = None
         for ci, name in enumerate(('conv1', 'conv2')):
             convs = [getattr(b, name) for b in blocks]
             ws = wn[lvl][ci]
+            spec = ops.make_drop(p, e0.training, x.device, deferred=ci == 1)       # see TemporalBlock.forward
             y = ops.grouped_conv1d_tm(y.view(G, B, T, y.shape[2]), ws, [c.bias for c in convs], dil=d, pad_left=d * (ws[0].shape[2] - 1), To=T,
-                                      act=ACT_RELU).view(G * B, T, -1)
-            y = ops.dropout(y, p, e0.training)
-        x = ops.add_relu(y, x)
+                                      act=ACT_RELU, drop=spec).view(G * B, T, -1)
+            if spec is None:
+                y = ops.dropout(y, p, e0.training)
+        x = ops.add_relu(y, x, drop=spec)
     out = ops.grouped_linear(x.view(G, B * T, x.shape[2]), [e.decoder.weight for e in encs], [e.decoder.bias for e in encs])
     return out.view(G, B, T, -1)
 

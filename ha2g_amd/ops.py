@@ -421,6 +421,44 @@ def dropout(x, p, training):
     return DropoutFunction.apply(x, p)
 
 
+class DropSpec:
+    """A dropout attached to the op in front of / behind it (round 6: the TCN blocks' dropouts, model/tcn.py:21-31, fused with their neighbours).
+    conv1d_tm / grouped_linear(..., act=ACT_RELU, drop=spec): y = dropout(relu(conv)) -- the forward applies the mask unless spec.deferred (then the CONSUMER
+    does: add_relu(y, res, drop=spec) = relu(mask * y + res) in one launch, and hands back the gradient w.r.t. the masked value); the backward applies
+    dropout' and ReLU' in ONE launch (ha2g_dropout_fused_f32 mode 2) instead of two.  The mask is the one ops.dropout draws for the same call id."""
+    __slots__ = ('p', 'call', 'token', 'deferred')
+
+    def __init__(self, p, call, token, deferred):
+        self.p, self.call, self.token, self.deferred = p, call, token, deferred
+
+
+FUSE_TCN_DROPOUT = True
+
+
+def make_drop(p, training, device, deferred=False):
+    if not training or p <= 0.0 or not FUSE_TCN_DROPOUT:
+        return None
+    if rng.state is None or rng.state.device != device:
+        rng.seed(device, 0x5EED)
+    return DropSpec(p, rng.next_id(), rng.step_token, deferred)
+
+
+def _drop_apply(y, spec):
+    out = torch.empty_like(y)
+    check(lib.ha2g_dropout_f32(y.data_ptr(), out.data_ptr(), None, y.numel(), spec.p, rng.state.data_ptr(), spec.call, _stream()))
+    return out
+
+
+def _drop_relu_bwd(dy, y, spec):
+    """d(pre-activation) = (y > 0) * mask * dy: the dropout's backward and the ReLU' of the op in front of it, one launch"""
+    if spec.token != rng.step_token:
+        raise RuntimeError('ha2g_amd dropout: backward after the RNG step advanced (rng.end_step()): the mask cannot be re-drawn')
+    dy = _f32c(dy.contiguous())
+    out = torch.empty_like(dy)
+    check(lib.ha2g_dropout_fused_f32(dy.data_ptr(), y.data_ptr(), out.data_ptr(), dy.numel(), spec.p, rng.state.data_ptr(), spec.call, 2, _stream()))
+    return out
+
+
 def dropout_mask(shape, p, device):
     """Pre-scaled keep mask only (used for the GRU inter-layer dropout)."""
     if rng.state is None or rng.state.device != device:
@@ -589,8 +627,13 @@ def elu(x):
 
 class AddReluFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b):
-        y = eltwise(OP_ADD_RELU, a.contiguous(), b.contiguous())
+    def forward(ctx, a, b, drop=None):
+        a, b = _f32c(a.contiguous()), _f32c(b.contiguous())
+        if drop is not None:                               # relu(mask * a + b): a's producer left its dropout to this launch (DropSpec.deferred)
+            y = torch.empty_like(a)
+            check(lib.ha2g_dropout_fused_f32(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), drop.p, rng.state.data_ptr(), drop.call, 1, _stream()))
+        else:
+            y = eltwise(OP_ADD_RELU, a, b)
         _tap_act('add_relu', y, ACT_RELU)
         ctx.save_for_backward(y)
         return y
@@ -598,11 +641,12 @@ class AddReluFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         g = eltwise(OP_RELU_BWD, dy.contiguous(), ctx.saved_tensors[0])
-        return g, g
+        return g, g, None                                  # with a deferred dropout: the gradient w.r.t. the MASKED a -- its producer's backward applies the mask
 
 
-def add_relu(a, b):
-    return AddReluFunction.apply(a, b)
+def add_relu(a, b, drop=None):
+    assert drop is None or drop.deferred
+    return AddReluFunction.apply(a, b, drop)
 
 
 class ReparamFunction(torch.autograd.Function):
@@ -744,7 +788,7 @@ class Conv1dFunction(torch.autograd.Function):
     out[b,t] = sum_kk W[:,:,kk] x[b, t - pad_left + kk*dil]."""
 
     @staticmethod
-    def forward(ctx, x, w, b, dil, pad_left, To, act):
+    def forward(ctx, x, w, b, dil, pad_left, To, act, drop=None):
         x = _f32c(x.contiguous())
         ctx.refs = (w, b)
         w = w.contiguous()
@@ -756,15 +800,17 @@ class Conv1dFunction(torch.autograd.Function):
         _tap_act('conv1d', y.view(B, To, cout), act)
         ctx.geom = (B, T, C, k, dil, pad_left, To, act)
         ctx.has_b = b is not None
+        ctx.drop = drop
         ctx.save_for_backward(col, w, y if act != ACT_NONE else None)
-        return y.view(B, To, cout)
+        out = _drop_apply(y, drop) if (drop is not None and not drop.deferred) else y      # DropSpec: dropout(relu(conv)), see there
+        return out.view(B, To, cout)
 
     @staticmethod
     def backward(ctx, dy):
         col, w, y = ctx.saved_tensors
         B, T, C, k, dil, pad_left, To, act = ctx.geom
         cout = w.shape[0]
-        dy2 = act_bwd(dy.reshape(B * To, cout), y, act)
+        dy2 = _drop_relu_bwd(dy.reshape(B * To, cout), y, ctx.drop) if ctx.drop is not None else act_bwd(dy.reshape(B * To, cout), y, act)
         dx = dw = db = tw = None
         with side.section(dy2.device):
             want_b = ctx.has_b and ctx.needs_input_grad[2]
@@ -789,14 +835,15 @@ class Conv1dFunction(torch.autograd.Function):
             dx = torch.empty(B, T, C, dtype=torch.float32, device=dy.device)
             check(lib.ha2g_col2im1d_f32(dcol.data_ptr(), dx.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
         _join_or_defer(dy2.device, (dw is None or _single_use_nonleaf(ctx.refs[0])) and db is None, (dy2, col, dw), (tw, tb))
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv1d_tm(x, w, b, dil=1, pad_left=0, To=None, act=ACT_NONE):
+def conv1d_tm(x, w, b, dil=1, pad_left=0, To=None, act=ACT_NONE, drop=None):
     if To is None:
         To = x.shape[1] + pad_left - (w.shape[2] - 1) * dil
+    assert drop is None or act == ACT_RELU
     _count_grad_use(w)
-    return Conv1dFunction.apply(x, w, b, dil, pad_left, To, act)
+    return Conv1dFunction.apply(x, w, b, dil, pad_left, To, act, drop)
 
 # ------------------------------------------------------------------------------------------------
 # grouped layers: the same layer of G networks (own weights) as one launch per GEMM (ha2g_gemm_grouped_f32)
@@ -806,29 +853,29 @@ class GroupedLinearFunction(torch.autograd.Function):
     """y[g] = act(x[g] W_g^T + b_g); x [G, R, K] stacked, W_g [N, K] and b_g [N] separate tensors (G parameters of G modules)."""
 
     @staticmethod
-    def forward(ctx, x, act, G, *wb):
+    def forward(ctx, x, act, G, drop, *wb):
         ws, bs = list(wb[:G]), list(wb[G:])
         has_b = bs[0] is not None
         x = _f32c(x.contiguous())
         wc = [w.contiguous() for w in ws]
         y = gemm_grouped(x, wc, transb=True, bias=bs if has_b else None, act=act)
         _tap_act('grouped_linear', y, act)
-        ctx.act, ctx.G, ctx.has_b = act, G, has_b
+        ctx.act, ctx.G, ctx.has_b, ctx.drop = act, G, has_b, drop
         ctx.refs = (ws, bs)
         ctx.save_for_backward(x, y if act != ACT_NONE else None, *wc)
-        return y
+        return _drop_apply(y, drop) if (drop is not None and not drop.deferred) else y      # DropSpec: dropout(relu(.)), see there
 
     @staticmethod
     def backward(ctx, dy):
         x, y, *wc = ctx.saved_tensors
         G = ctx.G
         ws, bs = ctx.refs
-        dy2 = act_bwd(dy, y, ctx.act)
+        dy2 = _drop_relu_bwd(dy, y, ctx.drop) if ctx.drop is not None else act_bwd(dy, y, ctx.act)
         N, K = wc[0].shape
         dx = None
         dws, dbs = [None] * G, [None] * G
         targets = []
-        need_w, need_b = ctx.needs_input_grad[3], ctx.has_b and ctx.needs_input_grad[3 + G]
+        need_w, need_b = ctx.needs_input_grad[4], ctx.has_b and ctx.needs_input_grad[4 + G]
         with side.section(dy2.device):
             if need_w:
                 tw = [_grad_target(w) for w in ws]
@@ -852,14 +899,15 @@ class GroupedLinearFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = gemm_grouped(dy2, wc)
         _join_or_defer(dy2.device, all(t is None or _single_use_nonleaf(w) for t, w in zip(dws, ws)) and all(t is None for t in dbs), (dy2, x, dws), targets)
-        return (dx, None, None) + tuple(dws) + tuple(dbs)
+        return (dx, None, None, None) + tuple(dws) + tuple(dbs)
 
 
-def grouped_linear(x, ws, bs=None, act=ACT_NONE):
+def grouped_linear(x, ws, bs=None, act=ACT_NONE, drop=None):
     G = len(ws)
+    assert drop is None or act == ACT_RELU
     for w in ws:
         _count_grad_use(w)                                 # (here, not in forward(): autograd runs forward() with gradients disabled)
-    return GroupedLinearFunction.apply(x, act, G, *ws, *(bs if bs is not None else [None] * G))
+    return GroupedLinearFunction.apply(x, act, G, drop, *ws, *(bs if bs is not None else [None] * G))
 
 
 class Im2col1dFunction(torch.autograd.Function):
@@ -883,14 +931,14 @@ class Im2col1dFunction(torch.autograd.Function):
         return dx, None, None, None, None
 
 
-def grouped_conv1d_tm(x, ws, bs, dil=1, pad_left=0, To=None, act=ACT_NONE):
+def grouped_conv1d_tm(x, ws, bs, dil=1, pad_left=0, To=None, act=ACT_NONE, drop=None):
     """x [G, B, T, C] (the inputs of G same-shape convolutions), ws: G weights [Cout, C, k], bs: G biases -> [G, B, To, Cout]."""
     G, B, T, C = x.shape
     cout, _, k = ws[0].shape
     if To is None:
         To = T + pad_left - (k - 1) * dil
     col = Im2col1dFunction.apply(x.reshape(G * B, T, C), k, dil, pad_left, To)
-    y = grouped_linear(col.view(G, B * To, C * k), [w.reshape(cout, C * k) for w in ws], bs, act)
+    y = grouped_linear(col.view(G, B * To, C * k), [w.reshape(cout, C * k) for w in ws], bs, act, drop)
     return y.view(G, B, To, cout)
 
 

@@ -394,6 +394,10 @@ int ha2g_eltwise_f32(int op, const float* a, const float* b, const float* c, flo
 int ha2g_dirsum_f32(const float* y, float* out, long rows, int H, int inverse, void* stream);
 /* Philox4x32-10 dropout; state = device uint64[2] {seed, step}; out and/or mask (pre-scaled keep mask) may be null */
 int ha2g_dropout_f32(const float* x, float* out, float* mask, long n, float p, const void* state, unsigned stream_id, void* stream);
+/* the same dropout fused with its neighbour in a TCN block (ABI 5; model/tcn.py:21-31,44-46): mode 1: out = relu(x * mask + b) (dropout -> + residual -> ReLU);
+ * mode 2: out = b > 0 ? x * mask : 0 (backward: dropout' then the ReLU' of the convolution in front of it, b = that convolution's output).  The mask is the
+ * one ha2g_dropout_f32 draws for the same (state, stream_id, element). */
+int ha2g_dropout_fused_f32(const float* x, const float* b, float* out, long n, float p, const void* state, unsigned stream_id, int mode, void* stream);
 int ha2g_rng_advance(void* state, void* stream);
 
 /* ---- generator input pack + hierarchy scatter (train_eval/train_hierarchy.py:153-169, expressive :163-212;

@@ -438,3 +438,51 @@ def test_weight_norm_convolution_gradients_with_deferred_joins(uses):
     tot.backward()
     assert float((g.grad - g2.grad).abs().max()) < 2e-4 * float(g2.grad.abs().max())
     assert float((v.grad - v2.grad).abs().max()) < 2e-4 * float(v2.grad.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('grouped', [False, True])
+def test_tcn_block_dropouts_fused_with_their_neighbours_change_no_bit(grouped):
+    """Round 6: the two dropouts of a TemporalBlock (model/tcn.py:21-31) ride on their neighbours -- conv1's backward shares one launch with conv1's ReLU'
+    (ha2g_dropout_fused_f32 mode 2), conv2's forward is applied by the residual add + ReLU (mode 1) and its backward by conv2's -- and draw the masks the
+    stand-alone dropout launches drew (same call ids, same element indices): output and every gradient are BIT-IDENTICAL to the unfused block
+    (ops.FUSE_TCN_DROPOUT = False), for the per-module block and for the generators' grouped encoders."""
+    from ha2g_amd import hierarchy_net as hn, ops
+    from ha2g_amd.config import hierarchy_args
+    dev = torch.device(DEV)
+    torch.manual_seed(4)
+    if not grouped:
+        blk = hn.TemporalBlock(300, 300, 2, 1, 4, 4, dropout=0.3).to(dev).train()
+        x0 = torch.randn(9, 34, 300, device=dev)
+        params = list(blk.parameters())
+
+        def run():
+            x = x0.clone().requires_grad_(True)
+            y = blk(x)
+            g = torch.autograd.grad((y * y).sum(), [x] + params)
+            return [y.detach()] + [t.detach() for t in g]
+    else:
+        args = hierarchy_args()
+        encs = [hn.TextEncoderTCN(args, 50, 300, dropout=0.3).to(dev).train() for _ in range(3)]
+        tok = torch.randint(0, 50, (7, 34), device=dev)
+        params = [p for e in encs for p in e.parameters()]
+
+        def run():
+            y = hn.grouped_text_encoders(encs, tok)
+            g = torch.autograd.grad((y * y).sum(), params, allow_unused=True)
+            return [y.detach()] + [t.detach() for t in g if t is not None]
+    outs = {}
+    for fuse in (True, False):
+        old = ops.FUSE_TCN_DROPOUT
+        ops.FUSE_TCN_DROPOUT = fuse
+        try:
+            ops.rng.seed(dev, 77)
+            ops.rng.begin_step()
+            outs[fuse] = run()
+            torch.cuda.synchronize()
+        finally:
+            ops.FUSE_TCN_DROPOUT = old
+    assert len(outs[True]) == len(outs[False]) > 5
+    assert float(outs[True][0].abs().max()) > 0 and float((outs[True][0] == 0).float().mean()) > 0.2      # dropout + ReLU really zero things
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a, b)

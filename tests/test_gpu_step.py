@@ -417,17 +417,26 @@ def test_full_size_schedule_and_precision_invariants(expressive):
 @pytest.mark.parametrize('expressive,fuse', [(False, True), (False, False), (True, True)])
 def test_grouped_text_encoders_match_the_per_generator_encoders(expressive, fuse):
     """The generators' text encoders evaluated in lockstep as grouped launches (hierarchy_net.grouped_text_encoders, the default) against
-    each generator running its own encoder inside its forward (the reference's structure): same loss terms and, per parameter tensor and
-    element-wise (1e-5 of the tensor's largest element), the same gradients for every module -- under the fused-chain and the literal
-    schedule, three and six generators, in the default arithmetic (mode 70) and on the fp32 MFMA (mode 0)."""
+    each generator running its own encoder inside its forward (the reference's structure): same loss terms, and the same gradients for every
+    module -- under the fused-chain and the literal schedule, three and six generators, in the default arithmetic (mode 70) and on the fp32 MFMA
+    (mode 0).  Unlike the fused-chain bridge above, the two sides run DIFFERENT launches of the same products (a grouped tile grid against three
+    single ones, other split-K counts): the forwards agree to fp32 rounding, not bit for bit, so a handful of ReLU / LeakyReLU decisions flip and a
+    gradient tensor moves by ~1e-3 of its largest element.  Held per module at 5e-4 of the flat gradient norm and per tensor, element-wise, at
+    1e-2; the element-wise pin of the grouped form itself is tests/test_gpu_linearised.py::test_default_fused_schedule_* (1e-4 against float64)."""
     B = 128
     for mode in (70, 0):
         r_g, g_g = _full_size_step(expressive, B, fuse, mode, fuse_text=True, per_tensor=True)
         r_s, g_s = _full_size_step(expressive, B, fuse, mode, fuse_text=False, per_tensor=True)
         for k in r_g:
             assert abs(r_g[k] - r_s[k]) <= 2e-5 * max(abs(r_s[k]), 1e-3), (mode, k, r_g[k], r_s[k])
-        _elementwise_bridge('grouped vs per-generator text encoders, mode %d, fuse=%s, %s' % (mode, fuse, 'expressive' if expressive else 'gesture'),
-                            g_g, g_s, 1e-5)
+        what = 'grouped vs per-generator text encoders, mode %d, fuse=%s, %s' % (mode, fuse, 'expressive' if expressive else 'gesture')
+        _elementwise_bridge(what, g_g, g_s, 1e-2)
+        mods = sorted({k.split('.')[0] for k in g_s})
+        for m in mods:
+            a = torch.cat([g_g[k].reshape(-1) for k in sorted(g_s) if k.split('.')[0] == m])
+            b = torch.cat([g_s[k].reshape(-1) for k in sorted(g_s) if k.split('.')[0] == m])
+            d = float((a - b).norm() / b.norm())
+            assert d < 5e-4, (what, m, d)
 
 
 def test_config5_bf16_step_b256():
