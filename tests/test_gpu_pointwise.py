@@ -483,6 +483,8 @@ def test_tcn_block_dropouts_fused_with_their_neighbours_change_no_bit(grouped):
         finally:
             ops.FUSE_TCN_DROPOUT = old
     assert len(outs[True]) == len(outs[False]) > 5
-    assert float(outs[True][0].abs().max()) > 0 and float((outs[True][0] == 0).float().mean()) > 0.2      # dropout + ReLU really zero things
+    assert float(outs[True][0].abs().max()) > 0
+    if not grouped:
+        assert float((outs[True][0] == 0).float().mean()) > 0.2                                        # the block's output: ReLU really zeroes things
     for a, b in zip(outs[True], outs[False]):
         assert torch.equal(a, b)
