@@ -705,10 +705,16 @@ constexpr int WG_TP = 128, WG_NT = 256;
 // T = float: fp32 tensors, split here into hi / lo planes (three MFMAs per product); T = b16 (bf16-storage mode): the tensors ARE the hi plane,
 // one MFMA per product, the lo planes stay unused.
 // NP = 3 (round 4, fp32-class): three piece planes per operand (93 KB at 70-wide maps: one workgroup per CU), six MFMAs per product.
-template <typename T, int NP = 2>
+// PF (round 6, fp32 / three pieces only): the NEXT tile's x patch and dy strip are loaded into registers (12 + 4 sixteen-byte slots per thread, branch-free
+// buffer loads: padding = an out-of-range offset, which returns zeros) BEFORE this tile's MFMA phase and split / written to LDS behind it -- the first form
+// loaded, waited, split, wrote and only then computed: 2.6 us of exposed load latency against 1.4 us of MFMAs per tile.  The side queue is the saturated
+// one during the tower's backward (10.7 of 12.1 ms, profiles/r06_*), and beside this kernel bn_bwd_apply ran 18 -> 107 us and the 32-channel data
+// gradient 152 -> 273 us: its duration is main-queue time.  Same values, same summation order: bit-identical partials.
+template <typename T, int NP = 2, bool PF = false>
 __global__ __launch_bounds__(WG_NT, (NP == 3 ? 1 : 2)) void conv3x3_c32_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                                      float* __restrict__ part, int N, int H, int W, int plane_elems) {
     constexpr bool F32 = sizeof(T) == 4;
+    static_assert(!PF || (F32 && NP == 3), "the prefetching form serves the fp32 three-piece mode");
     extern __shared__ __attribute__((aligned(16))) unsigned short wpl[];        // [x pieces][dy pieces]
     typedef short s16x4_t __attribute__((ext_vector_type(4)));
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
@@ -735,6 +741,116 @@ __global__ __launch_bounds__(WG_NT, (NP == 3 ? 1 : 2)) void conv3x3_c32_wgrad_ke
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // one tile's MFMA phase out of the LDS planes (both forms)
+    auto mfma_tile = [&](const Tile& cur) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int pb = 32 * wave + 16 * ch + krow;                           // this lane's two tile-local pixels: pb and pb + 4
+            const bf16x8_t ah = frag(dh + pb * CH + moff, dh + (pb + 4) * CH + moff);
+            bf16x8_t al = ah, a2 = ah;
+            if constexpr (F32) al = frag(dl + pb * CH + moff, dl + (pb + 4) * CH + moff);
+            if constexpr (F32 && NP == 3) a2 = frag(dl + WG_TP * CH + pb * CH + moff, dl + WG_TP * CH + (pb + 4) * CH + moff);
+            int p0 = cur.p0 + pb, p1 = p0 + 4;
+            if (p0 >= HW) p0 = HW - 1;                                           // clamp: stays inside the patch; dy is zero there
+            if (p1 >= HW) p1 = HW - 1;
+            const int y0 = p0 / W, y1 = p1 / W;
+            const int r0 = ((y0 - cur.r0) * PW + (p0 - y0 * W)) * CH + moff;     // tap (0,0) = the pixel above-left (halo included)
+            const int r1 = ((y1 - cur.r0) * PW + (p1 - y1 * W)) * CH + moff;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int toff = ((t / 3) * PW + (t % 3)) * CH;
+                const bf16x8_t bh = frag(xh + r0 + toff, xh + r1 + toff);
+                if constexpr (F32 && NP == 3) {                                  // six products, smallest first
+                    const bf16x8_t bl = frag(xl + r0 + toff, xl + r1 + toff);
+                    const bf16x8_t b2 = frag(xl + plane_elems + r0 + toff, xl + plane_elems + r1 + toff);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b2, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                } else if constexpr (F32) {
+                    const bf16x8_t bl = frag(xl + r0 + toff, xl + r1 + toff);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+            }
+        }
+    };
+    auto tile_geom = [&](long tile) {
+        Tile t;
+        t.img = (int)(tile / tpi); t.p0 = (int)(tile % tpi) * WG_TP;
+        const int pend = min(t.p0 + WG_TP, HW);
+        t.r0 = t.p0 / W;
+        t.rows = (pend - 1) / W - t.r0 + 3;
+        return t;
+    };
+    if constexpr (PF) {
+        constexpr int XS = 12;                                                   // x patch slots per thread (host: rows_max * PW * 8 <= XS * 256)
+        constexpr unsigned OOB = 0xfffffff0u;
+        const int c4 = tid & 7;
+        // slot i of this thread = padded pixel (tid >> 3) + 32 i of the patch: its patch row / byte offset relative to the patch origin (row r0 - 1,
+        // column 0) depend on PW only
+        int s_pr[XS], s_rel[XS];
+#pragma unroll
+        for (int i = 0; i < XS; ++i) {
+            const int pp = (tid >> 3) + 32 * i, pr = pp / PW, px = pp - pr * PW;
+            s_pr[i] = pr;
+            s_rel[i] = (px >= 1 && px <= W) ? ((pr * W + (px - 1)) * CH + 4 * c4) * 4 : -1;
+        }
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((long)N * HW * CH * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((long)N * HW * CH * 4), 0x00020000);
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        f4_t xv[XS], dv[4];
+        auto issue = [&](const Tile& t) {
+            const long base = ((long)t.img * HW + (long)(t.r0 - 1) * W) * CH * 4;       // may be negative for the first image's top halo: those slots are masked
+#pragma unroll
+            for (int i = 0; i < XS; ++i) {
+                const int gy = t.r0 - 1 + s_pr[i];
+                const bool on = s_pr[i] < t.rows && gy >= 0 && gy < H && s_rel[i] >= 0;
+                const unsigned off = on ? (unsigned)(base + s_rel[i]) : OOB;
+                xv[i] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = t.p0 + (tid >> 3) + 32 * i;
+                const unsigned off = p < HW ? (unsigned)((((long)t.img * HW + p) * CH + 4 * c4) * 4) : OOB;
+                dv[i] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(dr, (int)off, 0, 0));
+            }
+        };
+        auto commit = [&](const Tile& t) {
+#pragma unroll
+            for (int i = 0; i < XS; ++i) {
+                if (s_pr[i] < t.rows) {                                          // rows of the patch: pixels outside the image carry the zeros the load returned
+                    const int off = ((tid >> 3) + 32 * i) * CH + 4 * c4;
+                    unsigned e0[NP], e1[NP];
+                    splitn_bf16<NP>(xv[i][0], xv[i][1], e0); splitn_bf16<NP>(xv[i][2], xv[i][3], e1);
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(xh + q * plane_elems + off) = make_uint2(e0[q], e1[q]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = ((tid >> 3) + 32 * i) * CH + 4 * c4;
+                unsigned e0[NP], e1[NP];
+                splitn_bf16<NP>(dv[i][0], dv[i][1], e0); splitn_bf16<NP>(dv[i][2], dv[i][3], e1);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dh + q * WG_TP * CH + o) = make_uint2(e0[q], e1[q]);
+            }
+        };
+        long tile = blockIdx.x;
+        Tile cur{}, nxt{};
+        if (tile < tiles) { cur = tile_geom(tile); issue(cur); }
+        for (; tile < tiles; tile += gridDim.x) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the previous tile's fragment reads are done
+            commit(cur);                                                         // waits for this tile's loads (they flew under the previous MFMA phase)
+            __syncthreads();
+            const long next = tile + gridDim.x;
+            if (next < tiles) { nxt = tile_geom(next); issue(nxt); }
+            mfma_tile(cur);
+            cur = nxt;
+        }
+    } else
     for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         Tile cur;
         cur.img = (int)(tile / tpi); cur.p0 = (int)(tile % tpi) * WG_TP;
@@ -805,39 +921,7 @@ __global__ __launch_bounds__(WG_NT, (NP == 3 ? 1 : 2)) void conv3x3_c32_wgrad_ke
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            const int pb = 32 * wave + 16 * ch + krow;                           // this lane's two tile-local pixels: pb and pb + 4
-            const bf16x8_t ah = frag(dh + pb * CH + moff, dh + (pb + 4) * CH + moff);
-            bf16x8_t al = ah, a2 = ah;
-            if constexpr (F32) al = frag(dl + pb * CH + moff, dl + (pb + 4) * CH + moff);
-            if constexpr (F32 && NP == 3) a2 = frag(dl + WG_TP * CH + pb * CH + moff, dl + WG_TP * CH + (pb + 4) * CH + moff);
-            int p0 = cur.p0 + pb, p1 = p0 + 4;
-            if (p0 >= HW) p0 = HW - 1;                                           // clamp: stays inside the patch; dy is zero there
-            if (p1 >= HW) p1 = HW - 1;
-            const int y0 = p0 / W, y1 = p1 / W;
-            const int r0 = ((y0 - cur.r0) * PW + (p0 - y0 * W)) * CH + moff;     // tap (0,0) = the pixel above-left (halo included)
-            const int r1 = ((y1 - cur.r0) * PW + (p1 - y1 * W)) * CH + moff;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int toff = ((t / 3) * PW + (t % 3)) * CH;
-                const bf16x8_t bh = frag(xh + r0 + toff, xh + r1 + toff);
-                if constexpr (F32 && NP == 3) {                                  // six products, smallest first
-                    const bf16x8_t bl = frag(xl + r0 + toff, xl + r1 + toff);
-                    const bf16x8_t b2 = frag(xl + plane_elems + r0 + toff, xl + plane_elems + r1 + toff);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b2, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-                } else if constexpr (F32) {
-                    const bf16x8_t bl = frag(xl + r0 + toff, xl + r1 + toff);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-                }
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
-            }
-        }
+        mfma_tile(cur);
     }
     // ---- the four waves' accumulators, added in wave order through LDS; one partial [co][tap][ci] per workgroup ----
     __syncthreads();
@@ -978,6 +1062,8 @@ int conv3x3_c32_wgrad_blocks(int N, int H, int W) {
     if (cus > g_side_cus) cus = g_side_cus;
     return (int)(tiles < 2L * cus ? tiles : 2L * cus);
 }
+static int g_c32_wgrad_pf = 1;      // ha2g_conv_c32_wgrad_prefetch: the register-prefetching form of the fp32 three-piece weight gradient (A/B)
+extern "C" void ha2g_conv_c32_wgrad_prefetch(int on) { g_c32_wgrad_pf = on; }
 template <typename T, int NP = 2>
 static int c32_wgrad_launch_t(const T* x, const T* dy, float* part, int N, int H, int W, hipStream_t st) {
     const int rows_max = (WG_TP + W - 2) / W + 1 + 2;
@@ -989,13 +1075,25 @@ static int c32_wgrad_launch_t(const T* x, const T* dy, float* part, int N, int H
     static bool attr_set[64] = {false};                                              // per instantiation and device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    constexpr bool CAN_PF = sizeof(T) == 4 && NP == 3;
     if (!attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_wgrad_kernel<T, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess)
             return ha2g_set_error(-2, "conv3x3_c32_wgrad: cannot raise the dynamic LDS limit");
+        if constexpr (CAN_PF)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_wgrad_kernel<T, NP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess)
+                return ha2g_set_error(-2, "conv3x3_c32_wgrad: cannot raise the dynamic LDS limit");
         attr_set[dev] = true;
     }
     int grid = conv3x3_c32_wgrad_blocks(N, H, W);
     if (NP == 3 && grid > 256) grid = (grid + 1) / 2;                                 // one workgroup per CU
+    if constexpr (CAN_PF) {
+        // the prefetching form: the patch in 12 register slots per thread, tensors inside one 2 GB buffer resource
+        if (g_c32_wgrad_pf && rows_max * (W + 2) <= 12 * 32 && (long)N * H * W * CH * 4 < (1L << 31)) {
+            hipLaunchKernelGGL((conv3x3_c32_wgrad_kernel<T, NP, true>), dim3(grid), dim3(WG_NT), lds, st, x, dy, part, N, H, W, plane_elems);
+            HA2G_CHECK_LAUNCH("conv3x3_c32_wgrad (prefetching)");
+            return grid;
+        }
+    }
     hipLaunchKernelGGL((conv3x3_c32_wgrad_kernel<T, NP>), dim3(grid), dim3(WG_NT), lds, st, x, dy, part, N, H, W, plane_elems);
     HA2G_CHECK_LAUNCH("conv3x3_c32_wgrad");
     return grid;

@@ -108,6 +108,7 @@ int ha2g_conv2d_fwd_planes_np_stats_f32(const void* x, long x_ps, const void* w,
 int ha2g_f32_to_planes_2d_np(const float* x, long ldx, long rows, int cols, void* planes, long ps, long ldp, int np, int transpose, void* stream);
 int ha2g_gemm_planes_np_f32(const void* a, long a_ps, long lda, const void* b, long b_ps, long ldb, int np, int M, int N, int K, float beta,
                             float* C, long ldc, const float* bias, int act, float* ws, long ws_bytes, void* stream);
+void ha2g_conv_c32_wgrad_prefetch(int on);   /* A/B (ABI 5): the 32-channel three-piece weight gradient with the next tile's operands prefetched into registers (1, default; bit-identical) */
 void ha2g_conv_c32_prefetch(int on);             /* A/B: the 32-channel three-piece direct convolution with the next tile's loads prefetched into registers (1, default) or the single-buffered first form (0) */
 void ha2g_conv_planes_bufaddr(int on);          /* A/B: the plane kernel's DMA through buffer resources (1, default: padding = out-of-range offsets) or flat addresses + zero page (0) */
 void ha2g_conv_planes_korder(int channel_major);  /* A/B: k order of the plane kernel's split products: 1 (default) = the nine taps of a 32-channel slice back to back (the re-read pixels hit L2), 0 = tap-major */

@@ -780,3 +780,30 @@ def test_se_mlp_parameter_gradients_in_one_launch(N, C, R):
            init[2].double() + dh1.double().t() @ pooled.double(), init[3].double() + dh1.double().sum(0)]
     for o, r in zip(out, ref):
         assert float((o.double() - r).abs().max()) <= 2e-6 * max(float(r.abs().max()), 1.0) * (N ** 0.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('geom', [(4, 128, 70), (3, 64, 35), (2, 40, 37), (5, 128, 70)])
+def test_c32_weight_gradient_prefetching_form_is_bit_identical(geom):
+    """Round 6: the 32-channel three-piece weight gradient (layer 1 of the tower, side queue) loads the NEXT tile's patch and dy strip into registers in front
+    of this tile's MFMA phase (ha2g_conv_c32_wgrad_prefetch(1), the default) -- same values, same summation order: BIT-IDENTICAL to the first form, and equal
+    to float64 at the three-piece bound."""
+    from ha2g_amd import wav_engine as we
+    from ha2g_amd._lib import lib
+    N, H, W = geom
+    g = torch.Generator(device='cuda:0').manual_seed(N * 100 + W)
+    x = torch.randn(N, H, W, 32, device='cuda:0', generator=g)
+    dy = torch.randn(N, H, W, 32, device='cuda:0', generator=g)
+    w = torch.randn(32, 3, 3, 32, device='cuda:0', generator=g)
+    out = {}
+    for pf in (1, 0):
+        lib.ha2g_conv_c32_wgrad_prefetch(pf)
+        try:
+            out[pf] = we.conv_wgrad(x, dy, w, 1, 1).clone()
+            torch.cuda.synchronize()
+        finally:
+            lib.ha2g_conv_c32_wgrad_prefetch(1)
+    assert torch.equal(out[1], out[0])
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (32, 32, 3, 3), dy.permute(0, 3, 1, 2).double(), padding=1)     # [co][ci][kh][kw]
+    assert out[1].shape == ref.shape
+    assert float((out[1].double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
