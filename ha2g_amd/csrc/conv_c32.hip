@@ -710,11 +710,14 @@ constexpr int WG_TP = 128, WG_NT = 256;
 // loaded, waited, split, wrote and only then computed: 2.6 us of exposed load latency against 1.4 us of MFMAs per tile.  The side queue is the saturated
 // one during the tower's backward (10.7 of 12.1 ms, profiles/r06_*), and beside this kernel bn_bwd_apply ran 18 -> 107 us and the 32-channel data
 // gradient 152 -> 273 us: its duration is main-queue time.  Same values, same summation order: bit-identical partials.
-template <typename T, int NP = 2, bool PF = false>
+// TPX = pixels per tile: 128, or 256 in the prefetching form where the LDS holds it (70-wide maps: 142.5 KB) -- a 256-pixel tile spans 3.7 image rows + 2 halo
+// rows (1.6x its pixels) where a 128-pixel tile spans 1.8 + 2 (2.4x): 21 % fewer bytes loaded per pixel
+template <typename T, int NP = 2, bool PF = false, int TPX = 128>
 __global__ __launch_bounds__(WG_NT, (NP == 3 ? 1 : 2)) void conv3x3_c32_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                                      float* __restrict__ part, int N, int H, int W, int plane_elems) {
     constexpr bool F32 = sizeof(T) == 4;
     static_assert(!PF || (F32 && NP == 3), "the prefetching form serves the fp32 three-piece mode");
+    static_assert(TPX == 128 || (PF && TPX == 256), "256-pixel tiles: prefetching form only");
     extern __shared__ __attribute__((aligned(16))) unsigned short wpl[];        // [x pieces][dy pieces]
     typedef short s16x4_t __attribute__((ext_vector_type(4)));
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
@@ -723,12 +726,12 @@ __global__ __launch_bounds__(WG_NT, (NP == 3 ? 1 : 2)) void conv3x3_c32_wgrad_ke
     const int l31 = lane & 31, lhi = lane >> 5, g4 = lane >> 4, q16 = lane & 15;
     const int krow = 8 * (g4 >> 1) + (q16 >> 2), moff = 16 * (g4 & 1) + 4 * (q16 & 3);
     const int HW = H * W, PW = W + 2;
-    const int tpi = (HW + WG_TP - 1) / WG_TP;
+    const int tpi = (HW + TPX - 1) / TPX;
     const long tiles = (long)N * tpi;
     unsigned short* xh = wpl;                                                   // piece q of x at xh + q * plane_elems
     unsigned short* xl = wpl + plane_elems;
-    unsigned short* dh = wpl + NP * plane_elems;                                // piece q of dy at dh + q * WG_TP * CH
-    unsigned short* dl = dh + WG_TP * CH;
+    unsigned short* dh = wpl + NP * plane_elems;                                // piece q of dy at dh + q * TPX * CH
+    unsigned short* dl = dh + TPX * CH;
     auto tr = [](const unsigned short* ptr) {
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(__attribute__((address_space(3))) const unsigned short*)ptr);
     };
@@ -744,12 +747,12 @@ __global__ __launch_bounds__(WG_NT, (NP == 3 ? 1 : 2)) void conv3x3_c32_wgrad_ke
     // one tile's MFMA phase out of the LDS planes (both forms)
     auto mfma_tile = [&](const Tile& cur) {
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            const int pb = 32 * wave + 16 * ch + krow;                           // this lane's two tile-local pixels: pb and pb + 4
+        for (int ch = 0; ch < TPX / 64; ++ch) {
+            const int pb = (TPX / 4) * wave + 16 * ch + krow;                           // this lane's two tile-local pixels: pb and pb + 4
             const bf16x8_t ah = frag(dh + pb * CH + moff, dh + (pb + 4) * CH + moff);
             bf16x8_t al = ah, a2 = ah;
             if constexpr (F32) al = frag(dl + pb * CH + moff, dl + (pb + 4) * CH + moff);
-            if constexpr (F32 && NP == 3) a2 = frag(dl + WG_TP * CH + pb * CH + moff, dl + WG_TP * CH + (pb + 4) * CH + moff);
+            if constexpr (F32 && NP == 3) a2 = frag(dl + TPX * CH + pb * CH + moff, dl + TPX * CH + (pb + 4) * CH + moff);
             int p0 = cur.p0 + pb, p1 = p0 + 4;
             if (p0 >= HW) p0 = HW - 1;                                           // clamp: stays inside the patch; dy is zero there
             if (p1 >= HW) p1 = HW - 1;
@@ -779,14 +782,14 @@ __global__ __launch_bounds__(WG_NT, (NP == 3 ? 1 : 2)) void conv3x3_c32_wgrad_ke
     };
     auto tile_geom = [&](long tile) {
         Tile t;
-        t.img = (int)(tile / tpi); t.p0 = (int)(tile % tpi) * WG_TP;
-        const int pend = min(t.p0 + WG_TP, HW);
+        t.img = (int)(tile / tpi); t.p0 = (int)(tile % tpi) * TPX;
+        const int pend = min(t.p0 + TPX, HW);
         t.r0 = t.p0 / W;
         t.rows = (pend - 1) / W - t.r0 + 3;
         return t;
     };
     if constexpr (PF) {
-        constexpr int XS = 12;                                                   // x patch slots per thread (host: rows_max * PW * 8 <= XS * 256)
+        constexpr int XS = TPX == 256 ? 16 : 12, DS = TPX / 32;                  // x patch / dy strip slots per thread (host: rows_max * PW <= 32 XS)
         constexpr unsigned OOB = 0xfffffff0u;
         const int c4 = tid & 7;
         // slot i of this thread = padded pixel (tid >> 3) + 32 i of the patch: its patch row / byte offset relative to the patch origin (row r0 - 1,
@@ -801,7 +804,7 @@ __global__ __launch_bounds__(WG_NT, (NP == 3 ? 1 : 2)) void conv3x3_c32_wgrad_ke
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((long)N * HW * CH * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((long)N * HW * CH * 4), 0x00020000);
         typedef float f4_t __attribute__((ext_vector_type(4)));
-        f4_t xv[XS], dv[4];
+        f4_t xv[XS], dv[DS];
         auto issue = [&](const Tile& t) {
             const long base = ((long)t.img * HW + (long)(t.r0 - 1) * W) * CH * 4;       // may be negative for the first image's top halo: those slots are masked
 #pragma unroll
@@ -812,7 +815,7 @@ __global__ __launch_bounds__(WG_NT, (NP == 3 ? 1 : 2)) void conv3x3_c32_wgrad_ke
                 xv[i] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < DS; ++i) {
                 const int p = t.p0 + (tid >> 3) + 32 * i;
                 const unsigned off = p < HW ? (unsigned)((((long)t.img * HW + p) * CH + 4 * c4) * 4) : OOB;
                 dv[i] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(dr, (int)off, 0, 0));
@@ -830,12 +833,12 @@ __global__ __launch_bounds__(WG_NT, (NP == 3 ? 1 : 2)) void conv3x3_c32_wgrad_ke
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < DS; ++i) {
                 const int o = ((tid >> 3) + 32 * i) * CH + 4 * c4;
                 unsigned e0[NP], e1[NP];
                 splitn_bf16<NP>(dv[i][0], dv[i][1], e0); splitn_bf16<NP>(dv[i][2], dv[i][3], e1);
 #pragma unroll
-                for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dh + q * WG_TP * CH + o) = make_uint2(e0[q], e1[q]);
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dh + q * TPX * CH + o) = make_uint2(e0[q], e1[q]);
             }
         };
         long tile = blockIdx.x;
@@ -853,8 +856,8 @@ __global__ __launch_bounds__(WG_NT, (NP == 3 ? 1 : 2)) void conv3x3_c32_wgrad_ke
     } else
     for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         Tile cur;
-        cur.img = (int)(tile / tpi); cur.p0 = (int)(tile % tpi) * WG_TP;
-        const int pend = min(cur.p0 + WG_TP, HW);
+        cur.img = (int)(tile / tpi); cur.p0 = (int)(tile % tpi) * TPX;
+        const int pend = min(cur.p0 + TPX, HW);
         cur.r0 = cur.p0 / W;
         cur.rows = (pend - 1) / W - cur.r0 + 3;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // the previous tile's fragment reads are done
@@ -914,7 +917,7 @@ __global__ __launch_bounds__(WG_NT, (NP == 3 ? 1 : 2)) void conv3x3_c32_wgrad_ke
                     unsigned e0[NP], e1[NP];
                     splitn_bf16<NP>(d[i].x, d[i].y, e0); splitn_bf16<NP>(d[i].z, d[i].w, e1);
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dh + q * WG_TP * CH + o) = make_uint2(e0[q], e1[q]);
+                    for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(dh + q * TPX * CH + o) = make_uint2(e0[q], e1[q]);
                 } else {
                     *reinterpret_cast<uint2*>(dh + o) = dv[i];
                 }
@@ -1062,7 +1065,7 @@ int conv3x3_c32_wgrad_blocks(int N, int H, int W) {
     if (cus > g_side_cus) cus = g_side_cus;
     return (int)(tiles < 2L * cus ? tiles : 2L * cus);
 }
-static int g_c32_wgrad_pf = 1;      // ha2g_conv_c32_wgrad_prefetch: the register-prefetching form of the fp32 three-piece weight gradient (A/B)
+static int g_c32_wgrad_pf = 2;      // ha2g_conv_c32_wgrad_prefetch: 0 = first form, 1 = register-prefetching form, 2 (default) = + 256-pixel tiles where they fit
 extern "C" void ha2g_conv_c32_wgrad_prefetch(int on) { g_c32_wgrad_pf = on; }
 template <typename T, int NP = 2>
 static int c32_wgrad_launch_t(const T* x, const T* dy, float* part, int N, int H, int W, hipStream_t st) {
@@ -1087,7 +1090,23 @@ static int c32_wgrad_launch_t(const T* x, const T* dy, float* part, int N, int H
     int grid = conv3x3_c32_wgrad_blocks(N, H, W);
     if (NP == 3 && grid > 256) grid = (grid + 1) / 2;                                 // one workgroup per CU
     if constexpr (CAN_PF) {
-        // the prefetching form: the patch in 12 register slots per thread, tensors inside one 2 GB buffer resource
+        // the prefetching form: the patch in 12 (16) register slots per thread, tensors inside one 2 GB buffer resource; 256-pixel tiles where they fit the LDS
+        const int rows2 = (256 + W - 2) / W + 1 + 2, pe2 = rows2 * (W + 2) * CH;
+        const size_t lds2 = ((size_t)NP * pe2 + NP * 256 * CH) * sizeof(unsigned short);
+        if (g_c32_wgrad_pf >= 2 && rows2 * (W + 2) <= 16 * 32 && lds2 <= (size_t)LDS_MAX && (long)H * W >= 256 && (long)N * H * W * CH * 4 < (1L << 31)) {
+            static bool attr2[64] = {false};
+            if (!attr2[dev]) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_wgrad_kernel<T, NP, true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess)
+                    return ha2g_set_error(-2, "conv3x3_c32_wgrad: cannot raise the dynamic LDS limit");
+                attr2[dev] = true;
+            }
+            const long tiles2 = (long)N * (((long)H * W + 255) / 256);
+            int grid2 = grid;
+            if (grid2 > tiles2) grid2 = (int)tiles2;
+            hipLaunchKernelGGL((conv3x3_c32_wgrad_kernel<T, NP, true, 256>), dim3(grid2), dim3(WG_NT), lds2, st, x, dy, part, N, H, W, pe2);
+            HA2G_CHECK_LAUNCH("conv3x3_c32_wgrad (prefetching, 256-pixel tiles)");
+            return grid2;
+        }
         if (g_c32_wgrad_pf && rows_max * (W + 2) <= 12 * 32 && (long)N * H * W * CH * 4 < (1L << 31)) {
             hipLaunchKernelGGL((conv3x3_c32_wgrad_kernel<T, NP, true>), dim3(grid), dim3(WG_NT), lds, st, x, dy, part, N, H, W, plane_elems);
             HA2G_CHECK_LAUNCH("conv3x3_c32_wgrad (prefetching)");

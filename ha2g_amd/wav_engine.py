@@ -294,6 +294,8 @@ _FWD_PLANES = [False]      # this forward will be back-propagated through the pl
 # this forward will be back-propagated at all.  torch.is_grad_enabled() cannot tell: inside autograd.Function.forward it is always False.
 # WavEncoderFunction.forward sets it from `training and any(ctx.needs_input_grad)`; direct block_fwd() callers (tests, tools) back-propagate.
 _WILL_BWD = [True]
+JOIN_DGRAD = 0             # round-6 experiment: 1 = the main stream waits for the side queue after every data gradient of the tower's backward (the
+                           # BatchNorm / SE passes then run with no weight gradient beside them); 0 = one join at the end
 SE_WGRAD_FUSED = True      # the SE excitation MLP's four parameter gradients in one launch (GradSink.gse)
 
 
@@ -652,6 +654,8 @@ def block_bwd(dx, saved, P, b, sink):
     da1 = conv_dgrad_planes(dc2p, wb, a1.shape, 1, 1) if p2 else conv_dgrad(dc2, wb, a1.shape, 1, 1)
     if WGRAD_AFTER:
         sink.gconv(b + 'conv2.weight', a1, dc2, wb, 1, 1, dy_planes=dc2p, x_planes=a1p)
+    if JOIN_DGRAD:
+        ops.side.join(dx.device)
     dc1 = sink.gbn(b + 'bn1', _rows(da1), _rows(c1), m1, s1, relu_mask=True, planes=p1, need_dx=f1)
     dc1, dc1p = ((dc1[0].view(c1.shape) if f1 else None), dc1[1]) if p1 else (dc1.view(c1.shape), None)
     if not WGRAD_AFTER:
@@ -663,6 +667,8 @@ def block_bwd(dx, saved, P, b, sink):
             r = conv_dgrad(dc1, wa, x.shape, stride, 1, out=dres, beta=1.0)
         if WGRAD_AFTER:
             sink.gconv(b + 'conv1.weight', x, dc1, wa, stride, 1, dy_planes=dc1p, x_planes=xp)
+        if JOIN_DGRAD:
+            ops.side.join(dx.device)
         return r
     dxin = conv_dgrad_planes(dc1p, wa, x.shape, stride, 1) if p1 else conv_dgrad(dc1, wa, x.shape, stride, 1)
     if WGRAD_AFTER:
@@ -676,6 +682,8 @@ def block_bwd(dx, saved, P, b, sink):
         conv_dgrad_planes(dcdp, wd, x.shape, 2, 0, out=dxin, beta=1.0)
     else:
         conv_dgrad(dcd, wd, x.shape, 2, 0, out=dxin, beta=1.0)
+    if JOIN_DGRAD:
+        ops.side.join(dx.device)
     return dxin
 
 
