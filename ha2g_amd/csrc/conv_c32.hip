@@ -1065,7 +1065,7 @@ int conv3x3_c32_wgrad_blocks(int N, int H, int W) {
     if (cus > g_side_cus) cus = g_side_cus;
     return (int)(tiles < 2L * cus ? tiles : 2L * cus);
 }
-static int g_c32_wgrad_pf = 2;      // ha2g_conv_c32_wgrad_prefetch: 0 = first form, 1 = register-prefetching form, 2 (default) = + 256-pixel tiles where they fit
+static int g_c32_wgrad_pf = 1;      // ha2g_conv_c32_wgrad_prefetch: 0 = first form, 1 (default) = register-prefetching form, 2 = + 256-pixel tiles where they fit (no gain in the step: 36.16 vs 36.20 ms)
 extern "C" void ha2g_conv_c32_wgrad_prefetch(int on) { g_c32_wgrad_pf = on; }
 template <typename T, int NP = 2>
 static int c32_wgrad_launch_t(const T* x, const T* dy, float* part, int N, int H, int W, hipStream_t st) {

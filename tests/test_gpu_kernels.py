@@ -786,7 +786,7 @@ def test_se_mlp_parameter_gradients_in_one_launch(N, C, R):
 @pytest.mark.parametrize('geom', [(4, 128, 70), (3, 64, 35), (2, 40, 37), (5, 128, 70)])
 def test_c32_weight_gradient_prefetching_form_is_bit_identical(geom):
     """Round 6: the 32-channel three-piece weight gradient (layer 1 of the tower, side queue) loads the NEXT tile's patch and dy strip into registers in front
-    of this tile's MFMA phase (ha2g_conv_c32_wgrad_prefetch(1)) -- same values, same summation order: BIT-IDENTICAL to the first form; the default (2) also
+    of this tile's MFMA phase (ha2g_conv_c32_wgrad_prefetch(1)) -- same values, same summation order: BIT-IDENTICAL to the first form; mode 2 also
     uses 256-pixel tiles where the LDS holds them (fewer halo bytes per pixel; another, fixed tile order).  Both equal float64 at the three-piece bound."""
     from ha2g_amd import wav_engine as we
     from ha2g_amd._lib import lib
@@ -796,7 +796,7 @@ def test_c32_weight_gradient_prefetching_form_is_bit_identical(geom):
     dy = torch.randn(N, H, W, 32, device='cuda:0', generator=g)
     w = torch.randn(32, 3, 3, 32, device='cuda:0', generator=g)
     out = {}
-    for pf in (2, 1, 0):                                      # 2 = the default: prefetching + 256-pixel tiles where the LDS holds them (another tile order)
+    for pf in (2, 1, 0):                                      # 1 = the default; 2 = + 256-pixel tiles where the LDS holds them (another tile order; no gain in the step)
         lib.ha2g_conv_c32_wgrad_prefetch(pf)
         try:
             out[pf] = we.conv_wgrad(x, dy, w, 1, 1).clone()
@@ -804,7 +804,7 @@ def test_c32_weight_gradient_prefetching_form_is_bit_identical(geom):
             assert torch.equal(again, out[pf])
             torch.cuda.synchronize()
         finally:
-            lib.ha2g_conv_c32_wgrad_prefetch(2)
+            lib.ha2g_conv_c32_wgrad_prefetch(1)
     assert torch.equal(out[1], out[0])
     ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (32, 32, 3, 3), dy.permute(0, 3, 1, 2).double(), padding=1)     # [co][ci][kh][kw]
     assert out[1].shape == ref.shape
