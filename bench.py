@@ -409,9 +409,9 @@ def main():
                         hbm_frac_of_8TBps=round(bytes_ / (mean_us * 1e-6) / 8e12, 4))
         three = ops.gru_fwd3_active(H, T)                  # default mode: both recurrent chains on three bf16 pieces (gru_fwd_cluster3_kernel, gru_bwd_cluster_kernel<3>)
         roof = gru_roof('gru_layer_fwd', ('gru_fwd_cluster3_kernel (ha2g_gru_layer_fwd_cluster3, H=300)' if three else
-                                          'gru_fwd_cluster_kernel (ha2g_gru_layer_fwd_cluster, H=300)'), 'r05_pmc_gru_fwd.json', False, three)
+                                          'gru_fwd_cluster_kernel (ha2g_gru_layer_fwd_cluster, H=300)'), 'r06_pmc_gru_fwd.json', False, three)
         roof_bwd = gru_roof('gru_layer_bwd', ('gru_bwd_cluster_kernel<3> (ha2g_gru_layer_bwd_cluster3, H=300)' if three else
-                                              'gru_bwd_cluster_kernel (ha2g_gru_layer_bwd_cluster, H=300)'), 'r05_pmc_gru_bwd.json', True, three)
+                                              'gru_bwd_cluster_kernel (ha2g_gru_layer_bwd_cluster, H=300)'), 'r06_pmc_gru_bwd.json', True, three)
         if roof_bwd is not None and not three and bwd_pieces == 2:     # mode 6: the BPTT chain on the two-piece split (3 bf16 MFMAs per product term, fp32 accumulate)
             roof_bwd['arithmetic'] = 'split-bf16 x2 (16-bit operand mantissa; frac is still priced against the fp32 MFMA peak)'
         roof_gemm = None

@@ -1241,6 +1241,7 @@ class BiGRUFunction(torch.autograd.Function):
         grads = [None] * (8 * L)
         keep = []
         fused_b = []
+        all_tgs = []                                       # the .grad buffers the side-stream sections below accumulate into (SideStream.touch)
         pk3t_all = None
         if PACK_MULTI and 2 * L <= 16 and gru_fwd3_active(H, T):      # the transposed three-piece W_hh images of every layer: one launch
             pk3t_all = _pack3_multi([weights[8 * l + 4 * d + 1] for l in range(L) for d in range(2)], L, H, True, dev, st)
@@ -1273,6 +1274,7 @@ class BiGRUFunction(torch.autograd.Function):
                 for d in range(2):
                     tg = [_grad_target(w[4 * d + i]) for i in range(4)]
                     tgs.append([t if (t is not None and t.is_contiguous()) else None for t in tg])
+                all_tgs += tgs
                 if FUSE_BIAS_GRAD and GROUP_GRU_WGRAD and all(t is not None for tg in tgs for t in tg):
                     # every target is an installed .grad buffer: the two directions' weight-gradient GEMMs have one shape each -> three grouped
                     # launches (dW_ih, dW_hh rows r z, dW_hh rows n) instead of six, bias gradients riding on them
@@ -1327,7 +1329,7 @@ class BiGRUFunction(torch.autograd.Function):
         if DEFER_JOIN and side.allow_defer and fused_b and all(fused_b) and all(g is None for g in grads):
             # every weight / bias gradient of the stack accumulated in place into installed .grad buffers: the main stream need not wait for the side
             # queue here (5 joins of ~75 us per step) -- the step flushes before the gradient exchange / the optimizer
-            side.defer(dev, keep, [_grad_target(p_) for p_ in weights])
+            side.defer(dev, keep, [t for tg in all_tgs for t in tg])
         else:
             side.join(dev)
         if dy is not None and B != Bfull:

@@ -90,8 +90,18 @@ def _grouped_text_features(gens, in_text):
 
 _pinned_bufs = {}
 host_clock = None        # bench.py: {'busy': s, 'steps': n} -- host time spent inside train_iter excluding the final wait for the loss read-back
+phase_clock = None       # tools/phase_spans.py: a list -> (label, GPU event on the compute stream, host perf_counter) at the step's phase boundaries
 comm_clock = None        # bench.py (N > 1): list of (event behind the last backward kernel, event in front of the first optimizer kernel) per step --
                          # the time between them is the EXPOSED gradient exchange: the audio tower's bucket (last by design) + whatever is left of the others
+
+
+def _phase(label):
+    if phase_clock is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        phase_clock.append((label, ev, time.perf_counter()))
+
+
 _err_watch = []          # (event, pinned int32 word, device): end-of-step copies of the cluster error word not yet looked at
 _err_free = []
 
@@ -209,8 +219,11 @@ def _train_iter_impl(spec, args, epoch, in_text_padded, in_spec, target, vid_ind
     L = len(gens)
     consts = _consts(spec, args, dev)
 
+    _phase('start')
     weight, feat_low, feat_mid, feat_high, linear_blend_feat = audio_encoder(in_spec, vid_indices)
+    _phase('audio tower forward')
     text_feat = text_encoder(in_text_padded)
+    _phase('text encoder forward')
     # Cut the autograd graph at the encoders' outputs: the backward runs in two stages (generators + losses, then the
     # encoders), so that under data parallelism the generators' gradient all-reduce is in flight while the audio tower --
     # the longest part of the backward -- is still back-propagating (BASELINE north_star: "all-reduce overlapped with
@@ -260,6 +273,7 @@ def _train_iter_impl(spec, args, epoch, in_text_padded, in_spec, target, vid_ind
             sl = slice(i * B, (i + 1) * B)
             fused[b] = ([o[sl] for o in outs_all], z_all[sl], mu_all[sl], lv_all[sl])
 
+    _phase('generator chains forward (fused rows)')
     ###########################################################################################
     # train D   (reference :93-131)
     dis_error = None
@@ -282,6 +296,7 @@ def _train_iter_impl(spec, args, epoch, in_text_padded, in_spec, target, vid_ind
         _sync_guard(dev)                                 # data parallel: a time-out on ANY rank makes this a no-op step on EVERY rank
         dis_optimizer.step()
 
+    _phase('D phase (forward, backward, Adam)')
     ###########################################################################################
     # train G   (reference :135-274)
     for o in tuple(gen_optimizers) + (audio_optimizer, text_optimizer):
@@ -368,8 +383,10 @@ def _train_iter_impl(spec, args, epoch, in_text_padded, in_spec, target, vid_ind
         ev.record()
         readback = (host, ev)
 
+    _phase('losses, D(fake), loss assembly')
     loss.backward()                                      # stage 1: losses, discriminator, generators (down to the cut)
     ops.side.flush(dev)                                  # ... their deferred side-stream weight gradients before the exchange / stage 2 / the optimizers
+    _phase('backward stage 1 (losses, D, generators incl. BPTT)')
     works = []
     if ddp.active():
         for o in gen_optimizers:
@@ -385,6 +402,7 @@ def _train_iter_impl(spec, args, epoch, in_text_padded, in_spec, target, vid_ind
     if text_pairs:
         torch.autograd.backward([p[0] for p in text_pairs], [p[1] for p in text_pairs])
         ops.side.flush(dev)
+    _phase('text encoder backward')
     if ddp.active():
         for tb in getattr(text_optimizer, 'sparse_tables', ()):
             ddp.exchange_sparse_(tb)
@@ -393,6 +411,7 @@ def _train_iter_impl(spec, args, epoch, in_text_padded, in_spec, target, vid_ind
     if audio_pairs:
         torch.autograd.backward([p[0] for p in audio_pairs], [p[1] for p in audio_pairs])
         ops.side.flush(dev)
+    _phase('audio tower backward')
     ev_bwd_done = None
     if comm_clock is not None and dev.type == 'cuda':
         ev_bwd_done = torch.cuda.Event(enable_timing=True)
@@ -410,6 +429,7 @@ def _train_iter_impl(spec, args, epoch, in_text_padded, in_spec, target, vid_ind
     for o in g_opts:
         o.step()
     ops.rng.end_step()
+    _phase('optimizers')
 
     if return_tensors:                                   # graph-captured steps read the packed buffer after replay
         err = ops.gru_cluster_error_tensor(dev)

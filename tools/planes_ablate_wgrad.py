@@ -1,4 +1,4 @@
-"""Timing ablation of the plane-based weight-gradient kernel: full vs no DMA after the first tile (ha2g_conv_planes_debug(1)); B = 128."""
+"""Timing ablation of the three-piece plane-based weight-gradient kernel (+ its wide reduce): full vs no DMA after the first tile (ha2g_conv_planes_debug(1)); B = 128."""
 import sys
 import torch
 sys.path.insert(0, '.')
@@ -25,7 +25,7 @@ print('%-24s %9s %9s' % ('shape', 'full', 'no DMA'))
 for H, W, C in ((64, 35, 64), (32, 18, 128), (16, 9, 256)):
     x = torch.randn(B, H, W, C, device=dev); dy = torch.randn(B, H, W, C, device=dev)
     w = torch.zeros(C, 3, 3, C, device=dev)
-    xp, dp = ops.to_planes(x), ops.to_planes(dy)
+    xp, dp = ops.to_planes(x, 3), ops.to_planes(dy, 3)
     fn = lambda: we.conv_wgrad_planes(xp, dp, w, x.shape)
     ts = []
     for bits in (0, 1):
