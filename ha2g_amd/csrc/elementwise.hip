@@ -287,12 +287,13 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
 //   2: out = b > 0 ? x * mask : 0              (backward: the dropout's backward and the ReLU' of the convolution in front of it, b = its output)
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ out, float* __restrict__ mask, long n, float p,
                                const unsigned long long* __restrict__ state, unsigned stream_id, int vec, const float* __restrict__ b = nullptr,
-                               int mode = 0) {
+                               int mode = 0, long off4 = 0) {
     const unsigned long long seed = state[0], step = state[1];
     const float scale = 1.f / (1.f - p);
     const long n4 = (n + 3) >> 2;
     for (long i = (long)blockIdx.x * EB + threadIdx.x; i < n4; i += (long)gridDim.x * EB) {
-        uint32_t c0 = (uint32_t)i, c1 = (uint32_t)(i >> 32) ^ stream_id, c2 = (uint32_t)step, c3 = (uint32_t)(step >> 32);
+        const long ic = i + off4;                          // off4: this launch covers elements [4 off4, 4 off4 + n) of the tensor the mask is defined on (a row slice)
+        uint32_t c0 = (uint32_t)ic, c1 = (uint32_t)(ic >> 32) ^ stream_id, c2 = (uint32_t)step, c3 = (uint32_t)(step >> 32);
         uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
         for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
@@ -537,6 +538,18 @@ int ha2g_dropout_fused_f32(const float* x, const float* b, float* out, long n, f
     hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n, 4)), dim3(EB), 0, (hipStream_t)stream, x, out, (float*)nullptr, n, p,
                        (const unsigned long long*)state, stream_id, vec, b, mode);
     HA2G_CHECK_LAUNCH("dropout_fused");
+    return 0;
+}
+// out = x * mask over the elements [elem_offset, elem_offset + n) of the tensor the mask of (state, stream_id) is defined on: the backward of a dropout
+// whose gradient arrives for a ROW SLICE only (the GRU's inter-layer dropout under the fused chains: 128 of 384 rows carry gradient)
+int ha2g_dropout_slice_f32(const float* x, float* out, long n, long elem_offset, float p, const void* state, unsigned stream_id, void* stream) {
+    if (n == 0) return 0;
+    HA2G_REQUIRE(p >= 0.f && p < 1.f, "dropout_slice: p=%f out of range", p);
+    HA2G_REQUIRE(elem_offset >= 0 && elem_offset % 4 == 0, "dropout_slice: offset %ld must be a non-negative multiple of 4", elem_offset);
+    const int vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n, 4)), dim3(EB), 0, (hipStream_t)stream, x, out, (float*)nullptr, n, p,
+                       (const unsigned long long*)state, stream_id, vec, (const float*)nullptr, 0, elem_offset / 4);
+    HA2G_CHECK_LAUNCH("dropout_slice");
     return 0;
 }
 int ha2g_dirsum_f32(const float* y, float* out, long rows, int H, int inverse, void* stream) {

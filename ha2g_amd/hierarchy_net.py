@@ -243,8 +243,11 @@ class BiGRU(nn.Module):
         assert hidden is None, 'h0 is always zero on this path'
         masks = None
         if self.training and self.dropout > 0 and self.num_layers > 1:
-            masks = [ops.dropout_mask((x.shape[0], x.shape[1], 2 * self.hidden_size), self.dropout, x.device)
-                     for _ in range(self.num_layers - 1)]
+            if ops.GRU_MASK_SPEC and x.is_cuda:
+                masks = [ops.gru_drop_spec(self.dropout, x.device) for _ in range(self.num_layers - 1)]
+            else:
+                masks = [ops.dropout_mask((x.shape[0], x.shape[1], 2 * self.hidden_size), self.dropout, x.device)
+                         for _ in range(self.num_layers - 1)]
         y = ops.bigru(x, [getattr(self, n) for n in self._names], self.hidden_size, masks, self.grad_slice)
         return y, None
 

@@ -459,6 +459,17 @@ def _drop_relu_bwd(dy, y, spec):
     return out
 
 
+GRU_MASK_SPEC = True      # the GRU's inter-layer dropouts as specs (mask re-drawn where it is applied: one launch forward, one backward, no mask tensor)
+
+
+def gru_drop_spec(p, device):
+    """nn.GRU's inter-layer dropout (model/hierarchy_net.py:87) without a mask tensor: BiGRUFunction applies dropout(y) in ONE launch per layer (a mask
+    launch + a multiply, 31 MB written and re-read per layer at 384 rows before) and re-draws the mask over the gradient-carrying row slice in the backward"""
+    if rng.state is None or rng.state.device != device:
+        rng.seed(device, 0x5EED)
+    return DropSpec(p, rng.next_id(), rng.step_token, False)
+
+
 def dropout_mask(shape, p, device):
     """Pre-scaled keep mask only (used for the GRU inter-layer dropout)."""
     if rng.state is None or rng.state.device != device:
@@ -1217,7 +1228,7 @@ class BiGRUFunction(torch.autograd.Function):
             packs.append(pk)
             inp = y
             if masks is not None and l < L - 1 and masks[l] is not None:
-                inp = eltwise(OP_MUL, y, masks[l])
+                inp = _drop_apply(y, masks[l]) if isinstance(masks[l], DropSpec) else eltwise(OP_MUL, y, masks[l])
         ctx.H, ctx.L, ctx.masks, ctx.grad_slice = H, L, masks, grad_slice
         ctx.saved_bufs = saved
         ctx.packs = packs
@@ -1249,7 +1260,17 @@ class BiGRUFunction(torch.autograd.Function):
             inp, y, rs = (t[sl] for t in ctx.saved_bufs[l])
             w = weights[8 * l:8 * l + 8]
             if masks is not None and l < L - 1 and masks[l] is not None:
-                dy = eltwise(OP_MUL, dy, masks[l][sl])
+                if isinstance(masks[l], DropSpec):         # the mask of rows [sl] re-drawn: element offset of the slice inside the [Bfull, T, 2H] tensor
+                    spec = masks[l]
+                    if spec.token != rng.step_token:
+                        raise RuntimeError('ha2g_amd dropout: backward after the RNG step advanced (rng.end_step()): the mask cannot be re-drawn')
+                    dyc = dy.contiguous()
+                    out = torch.empty_like(dyc)
+                    off = (sl.start or 0) * T * 2 * H
+                    check(lib.ha2g_dropout_slice_f32(dyc.data_ptr(), out.data_ptr(), dyc.numel(), off, spec.p, rng.state.data_ptr(), spec.call, st))
+                    dy = out
+                else:
+                    dy = eltwise(OP_MUL, dy, masks[l][sl])
             dg = torch.empty(B * T, 8 * H, dtype=torch.float32, device=dev)        # [(r z n) fwd | (r z n) rev | hn fwd | hn rev]
             # h_prev per direction (forward dir: y[t-1], reverse dir: y[t+1], zero at the sequence ends) is written by the BPTT kernel
             hp = torch.empty(B, T, 2 * H, dtype=torch.float32, device=dev)

@@ -399,6 +399,9 @@ int ha2g_dropout_f32(const float* x, float* out, float* mask, long n, float p, c
  * mode 2: out = b > 0 ? x * mask : 0 (backward: dropout' then the ReLU' of the convolution in front of it, b = that convolution's output).  The mask is the
  * one ha2g_dropout_f32 draws for the same (state, stream_id, element). */
 int ha2g_dropout_fused_f32(const float* x, const float* b, float* out, long n, float p, const void* state, unsigned stream_id, int mode, void* stream);
+/* out = x * mask over elements [elem_offset, elem_offset + n) of the tensor the mask of (state, stream_id) is defined on (ABI 5): the backward of the GRU's
+ * inter-layer dropout (nn.GRU(dropout=...), model/hierarchy_net.py:87) when only a row slice carries gradient; elem_offset % 4 == 0 */
+int ha2g_dropout_slice_f32(const float* x, float* out, long n, long elem_offset, float p, const void* state, unsigned stream_id, void* stream);
 int ha2g_rng_advance(void* state, void* stream);
 
 /* ---- generator input pack + hierarchy scatter (train_eval/train_hierarchy.py:153-169, expressive :163-212;

@@ -488,3 +488,38 @@ def test_tcn_block_dropouts_fused_with_their_neighbours_change_no_bit(grouped):
         assert float((outs[True][0] == 0).float().mean()) > 0.2                                        # the block's output: ReLU really zeroes things
     for a, b in zip(outs[True], outs[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('grad_slice', [None, (32, 16)])
+def test_gru_inter_layer_dropout_without_a_mask_tensor_changes_no_bit(grad_slice):
+    """Round 6: nn.GRU's inter-layer dropout (model/hierarchy_net.py:87) as a spec (ops.gru_drop_spec) -- dropout(y) in one launch per layer instead of a
+    mask launch + a multiply, the backward re-draws the mask over the gradient-carrying row slice (ha2g_dropout_slice_f32) -- against the mask-tensor form
+    (ops.GRU_MASK_SPEC = False): same call ids, same element indices, so output and every gradient are BIT-IDENTICAL; with and without the fused chains'
+    row slice."""
+    from ha2g_amd import hierarchy_net as hn, ops
+    dev = torch.device(DEV)
+    torch.manual_seed(11)
+    gru = hn.BiGRU(48, 300, 3, dropout=0.3).to(dev).train()
+    x0 = torch.randn(48, 34, 48, device=dev)
+    params = list(gru.parameters())
+    outs = {}
+    for spec in (True, False):
+        old = ops.GRU_MASK_SPEC
+        ops.GRU_MASK_SPEC = spec
+        gru.grad_slice = grad_slice
+        try:
+            ops.rng.seed(dev, 5)
+            ops.rng.begin_step()
+            x = x0.clone().requires_grad_(True)
+            y, _ = gru(x)
+            g = torch.autograd.grad((y * y).sum(), [x] + params)
+            outs[spec] = [y.detach()] + [t.detach() for t in g]
+            torch.cuda.synchronize()
+        finally:
+            ops.GRU_MASK_SPEC = old
+            gru.grad_slice = None
+    assert ops.gru_cluster_error(dev) == 0
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a, b)
+    assert float(outs[True][1].abs().max()) > 0
