@@ -216,7 +216,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // Compute units of the current device (256 on an unpartitioned MI355X; fewer under CPX/DPX partitioning), queried ONCE per device and translation
 // unit: the tile / split heuristics run per launch and hipDeviceGetAttribute is a driver call (~100 queries per train step before).
-static inline int ha2g_cu_count() {
+static inline int hw_cu_count() {
     static int n[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;

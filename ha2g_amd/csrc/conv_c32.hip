@@ -1061,7 +1061,7 @@ int conv3x3_c32_x3_launch(const float* x, const float* w, float* y, int N, int H
 // reduces them), -100 when the shape does not fit (caller falls back to the implicit GEMM), < 0 on error.
 int conv3x3_c32_wgrad_blocks(int N, int H, int W) {
     const long tiles = (long)N * (((long)H * W + WG_TP - 1) / WG_TP);
-    int cus = ha2g_cu_count();
+    int cus = hw_cu_count();
     if (cus > g_side_cus) cus = g_side_cus;
     return (int)(tiles < 2L * cus ? tiles : 2L * cus);
 }

@@ -1543,7 +1543,7 @@ int pconv_wgrad_launch_np(const void* x, long x_ps, const void* dy, long dy_ps, 
     p.tpi = (HW + wt - 1) / wt;
     const long tiles = (long)N * p.tpi;
     const int npairs = pwgrad_pairs(Cin, Cout, np);
-    int cus = ha2g_cu_count(), dev = 0;
+    int cus = hw_cu_count(), dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (cus > 256) cus = 256;                                   // the workspace query assumes at most 256 chunks x pairs
     if (cus > g_side_cus) cus = g_side_cus;                     // ha2g_side_cus: leave compute units to the main queue's kernels
@@ -1682,7 +1682,7 @@ static int pconv_q_launch(const PConvP& p, dim3 grid, hipStream_t st) {
 // (workgroups / (rounds x CUs), times the useful fraction of the padded rows), larger tiles on ties.  -100: not served (caller falls back).
 // tile plan of the q kernel for an M x N output computed in `ksplit` k slices: (MT, BN) that keeps the CUs fullest; returns the efficiency (0 = none)
 static double pconv_q_plan(int M, int N, int ksplit, int* pmt, int* pbn) {
-    const int cus = ha2g_cu_count();
+    const int cus = hw_cu_count();
     double best = -1.0; int bmt = 0, bbn = 0;
     for (int bn = 128; bn >= 64; bn -= 64) {
         const long tn = (N + bn - 1) / bn;
@@ -1751,7 +1751,7 @@ static bool pconv_r_plan(int imgs, int H, int W, int N, int& bmt, int& bbn, RGeo
     bmt = bbn = 0;
     if (W < 2 || HW < 16 || N % 64 != 0 || imgs <= 0) return false;
     struct { int N; } p{N};
-    const int cus = ha2g_cu_count();
+    const int cus = hw_cu_count();
     // tile choice: 16 MT pixels (MT = 7 or 9) x BN columns per workgroup -- the combination that keeps the CUs fullest, among those whose patch fits one
     // of the two reserved plane sizes (272 / 320 patch pixels); resident workgroups per CU by LDS (160 KB) and registers (MT = 7, BN = 64: three waves per SIMD)
     double best = -1.0;

@@ -97,7 +97,7 @@ __device__ __forceinline__ void block_col_reduce(const dvec<V>& a, const dvec<V>
 // mode 0: (x - K, (x-K)^2) with K = row 0 (shift against cancellation); mode 1: (dy, dy * xhat).
 // Sums are carried in double (torch's CPU batch-norm accumulates in double too; the kernel is HBM-bound, the
 // fp64 adds are free) -- nearly-dead post-ReLU channels make sum(dy*xhat) cancel by 1e3..1e4.
-template <int MODE, typename T>
+template <int MODE, typename T, int RPT = 4>
 __global__ __launch_bounds__(256) void col_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           long rows, int C, double* __restrict__ part) {
@@ -127,16 +127,16 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const T* __restrict__ 
         }
     };
     long r = rbeg + m.r0;
-    for (; r + 3 * m.rstep < rend; r += 4 * m.rstep) {
-        fvec<V> v[4], d[4];
+    for (; r + (RPT - 1) * m.rstep < rend; r += RPT * m.rstep) {
+        fvec<V> v[RPT], d[RPT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < RPT; ++j) {
             v[j] = ldv(x + (r + (long)j * m.rstep) * C, m.cv);
             d[j] = v[j];
             if (MODE == 1) d[j] = ldv(dy + (r + (long)j * m.rstep) * C, m.cv);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accum(v[j], d[j]);
+        for (int j = 0; j < RPT; ++j) accum(v[j], d[j]);
     }
     for (; r < rend; r += m.rstep) {
         fvec<V> v = ldv(x + r * C, m.cv), d = v;
@@ -572,6 +572,7 @@ __global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* __restri
     if (blockIdx.x == 0 && t < 32 && j < R) db0[j] += b0;          // channel 0's threads: b0 does not depend on c
 }
 
+static int g_colp_rpt = 4;          // rows per trip of the BatchNorm-backward statistics pass (ha2g_bn_debug_rows_per_trip: A/B of the loads in flight per wave)
 inline int chunk_blocks(long rows) {
     long b = rows / 512;
     if (b < 1) b = 1;
@@ -631,7 +632,9 @@ int bn_bwd_t(const T* dy, const T* x, const float* mean, const float* invstd, co
     HA2G_REQUIRE(okCv<T>(C), "bn: unsupported channel count %d", C);
     hipStream_t st = (hipStream_t)stream;
     int nb = chunk_blocks(rows);
-    hipLaunchKernelGGL((col_partial_kernel<1, T>), dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
+    if (g_colp_rpt == 8) hipLaunchKernelGGL((col_partial_kernel<1, T, 8>), dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
+    else if (g_colp_rpt == 2) hipLaunchKernelGGL((col_partial_kernel<1, T, 2>), dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
+    else hipLaunchKernelGGL((col_partial_kernel<1, T>), dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
     hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, C, dbeta, dgamma, acc_dbeta, acc_dgamma);
     if (PL || dx)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<PL, T>), dim3(flat_grid(rows * (C / VW<T>::V))), dim3(256), 0, st, dy, x, mean, invstd, gamma,
@@ -878,6 +881,7 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict
     }
 }
 
+void ha2g_bn_debug_rows_per_trip(int n) { g_colp_rpt = n; }
 int ha2g_se_mlp_bwd_supported(int C, int R) { return C >= 1 && C <= 256 && R >= 1 && R <= 32; }
 int ha2g_se_mlp_bwd_f32(const float* dsc, const float* h1, const float* w2, const float* w0, float* dh1, float* dpool, int N, int C, int R,
                         float inv_hw, void* stream) {

@@ -352,6 +352,7 @@ int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, f
 int ha2g_se_mlp_fwd_f32(const float* pooled_in, const void* stat_part, int nblk, int HW, const float* mean, const float* invstd, const float* gamma,
                         const float* beta, const float* w0, const float* b0, const float* w2, const float* b2, float* pooled_out, float* h1,
                         float* sc, int N, int C, int R, void* stream);
+void ha2g_bn_debug_rows_per_trip(int n);     /* A/B (ABI 5): rows per trip (2, 4 = default, 8) of the BatchNorm-backward statistics pass; bit-identical sums */
 int ha2g_se_mlp_bwd_supported(int C, int R);
 int ha2g_se_mlp_bwd_f32(const float* dsc, const float* h1, const float* w2, const float* w0, float* dh1, float* dpool, int N, int C, int R,
                         float inv_hw, void* stream);
