@@ -1020,15 +1020,24 @@ __global__ __launch_bounds__(512) void pconv_q_kernel(PConvP p) {
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                // SHIFTED lane sums: the fp32 part runs on v - K, K = the lane's first pixel of this channel, so its rounding is relative to
+                // the channel's SPREAD, not to its mean -- raw sums of squares lose (1 + mean^2 / var) x 5e-7 of the variance when the finalize pass
+                // forms s2 / n - mean^2 (a channel with |mean| = 30 sigma: 5e-4).  Back to raw sums in double: S1 = s1 + n K, S2 = s2 + K (2 s1 + n K).
+                float kf = acc[0][j][u];
+                if (p.relu) kf = fmaxf(kf, 0.f);
+                kf = live[0] ? kf : 0.f;
                 float s1 = 0.f, s2 = 0.f;
+                int nl = 0;
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     float v = acc[i][j][u];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    v = live[i] ? v : 0.f;
+                    v = live[i] ? v - kf : 0.f;
+                    nl += live[i] ? 1 : 0;
                     s1 += v; s2 = fmaf(v, v, s2);
                 }
-                sv[(j * 4 + u) * 2] = (double)s1; sv[(j * 4 + u) * 2 + 1] = (double)s2;
+                const double kd = (double)kf, nk = (double)nl * kd;
+                sv[(j * 4 + u) * 2] = (double)s1 + nk; sv[(j * 4 + u) * 2 + 1] = (double)s2 + kd * (2.0 * (double)s1 + nk);
             }
         row16_reduce_scatter<NV>(sv, lane);
         const int idx = l15 & (NV - 1);
@@ -1258,7 +1267,8 @@ __global__ __launch_bounds__(256, WPS) void pconv_r_kernel(PConvP p, RGeo g) {
     // ---- BatchNorm statistics of the tile (forward, the BatchNorm that follows the convolution: ResNetBlocks.py:24-29): the separate column pass
     //      over the output (norm.hip col_partial_kernel<0>, 0.9 ms of the step's main queue) re-read what this epilogue holds in registers.
     //      Per lane the column sums of its MT <= 9 pixels (fp32: nine terms), then in double: a reduce-scatter over the 16 pixel lanes, one double per
-    //      (channel, which) and tile; the tiles are added in double by bn_stats_final_kernel.  (All-double lane sums cost 5.5 us per launch.)
+    //      (channel, which) and tile; the tiles are added in double by bn_stats_final_kernel.  (All-double lane sums cost 5.5 us per launch; the lane
+    //      sums are shifted instead, see below.)
     if (p.stat != nullptr) {
         constexpr int NV = NI * 8;
         double sv[NV];
@@ -1269,15 +1279,24 @@ __global__ __launch_bounds__(256, WPS) void pconv_r_kernel(PConvP p, RGeo g) {
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                // SHIFTED lane sums: the fp32 part runs on v - K, K = the lane's first pixel of this channel, so its rounding is relative to
+                // the channel's SPREAD, not to its mean -- raw sums of squares lose (1 + mean^2 / var) x 5e-7 of the variance when the finalize pass
+                // forms s2 / n - mean^2 (a channel with |mean| = 30 sigma: 5e-4).  Back to raw sums in double: S1 = s1 + n K, S2 = s2 + K (2 s1 + n K).
+                float kf = acc[0][j][u];
+                if (p.relu) kf = fmaxf(kf, 0.f);
+                kf = live[0] ? kf : 0.f;
                 float s1 = 0.f, s2 = 0.f;
+                int nl = 0;
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     float v = acc[i][j][u];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    v = live[i] ? v : 0.f;
+                    v = live[i] ? v - kf : 0.f;
+                    nl += live[i] ? 1 : 0;
                     s1 += v; s2 = fmaf(v, v, s2);
                 }
-                sv[(j * 4 + u) * 2] = (double)s1; sv[(j * 4 + u) * 2 + 1] = (double)s2;
+                const double kd = (double)kf, nk = (double)nl * kd;
+                sv[(j * 4 + u) * 2] = (double)s1 + nk; sv[(j * 4 + u) * 2 + 1] = (double)s2 + kd * (2.0 * (double)s1 + nk);
             }
         row16_reduce_scatter<NV>(sv, lane);
         const int idx = l15 & (NV - 1);

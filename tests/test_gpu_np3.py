@@ -356,6 +356,34 @@ def test_batchnorm_statistics_from_the_convolution_epilogue(B, H, W, C, Cout, k,
     assert e1 < 1e-6 and e2 < 1e-6, (e1, e2)
 
 
+@pytest.mark.parametrize('geom', [(4, 32, 18, 64, 64, 3, 1), (3, 64, 35, 32, 64, 3, 2)])
+def test_epilogue_statistics_of_a_channel_whose_mean_dwarfs_its_spread(geom):
+    """the convolution epilogue's lane sums are SHIFTED (v - K, K = the lane's first pixel) before squaring, so a channel with |mean| >> sigma --
+    here 300 sigma: a convolution whose input carries a large constant -- keeps its variance: invstd from ha2g_bn_stats_finalize_f32 equals the float64
+    statistics of the stored output, and the separate column pass (shifted sums in double), at 2e-6.  (Raw fp32 sums of squares lose
+    (1 + mean^2 / var) x 5e-7 of the variance in s2 / n - mean^2: ~5 % here.)  Patch-resident kernel and q kernel (stride 2)."""
+    from ha2g_amd import wav_engine as we
+    B, H, W, C, Cout, k, stride = geom
+    torch.manual_seed(7)
+    x = torch.randn(B, H, W, C, device=DEV) * 0.01 + 3.0             # sum over 9 C taps of ~3 w: a large per-channel constant, a small spread
+    w = torch.randn(Cout, k, k, C, device=DEV) * 0.05 + 0.02
+    xp, wp = ops.to_planes(x, 3), ops.to_planes(w.contiguous(), 3)
+    y, st = we.conv_fwd_planes(xp, wp, x.shape, stride, 1, we.ACT_NONE, stats=True)
+    rows = y.numel() // Cout
+    # the interior only defines the regime (zero padding makes the border pixels differ): check the ratio on the stored output itself
+    y64 = y.double().view(rows, Cout)
+    m64, v64 = y64.mean(0), y64.var(0, unbiased=False)
+    assert float((m64.abs() / v64.sqrt()).median()) > 3.0
+    rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    mean_a, inv_a = ops.bn_stats_finalize(st[0], st[1], rows, Cout, rm.clone(), rv.clone(), 0.1, 1e-5)
+    mean_b, inv_b = ops.bn_stats(y.view(rows, Cout), rm.clone(), rv.clone(), 0.1, 1e-5)
+    i64 = 1.0 / torch.sqrt(v64 + 1e-5)
+    for got in (inv_a, inv_b):
+        assert float(((got.double() - i64) / i64).abs().max()) < 2e-6, float(((got.double() - i64) / i64).abs().max())
+    for got in (mean_a, mean_b):
+        assert float(((got.double() - m64) / m64.abs().clamp_min(1e-3)).abs().max()) < 1e-6
+
+
 def test_convolution_epilogue_statistics_are_off_where_the_kernel_cannot_write_them():
     """the eight-wave ping-pong form of the plane kernel (ha2g_conv_planes_tile3(4), an A/B form) has no statistics epilogue: the query reports 0
     blocks and the caller keeps the column pass; asking for statistics with a block count the geometry does not have is an error, not a silent skip."""
