@@ -165,6 +165,7 @@ class HierarchyTrainer:
                 sub._buffers['num_batches_tracked'] = cnt[i]
             self._bn_cnt = cnt
         self._bn_snap = None
+        self._alias_probe = {}
 
     def _bn_buffers(self):
         return [b for m in self.modules() for k, b in m.named_buffers() if k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]
@@ -178,8 +179,14 @@ class HierarchyTrainer:
         for src, name in ((self._bn_flat, 'running statistics'), (self._bn_cnt, 'num_batches_tracked')):
             if src is not None:
                 # the module buffers must still be the views of the flat tensor installed by _flatten_bn_buffers: a later module.to(dtype) or an
-                # assign-style load_state_dict re-binds them, and the snapshot / restore would then silently do nothing
-                first = next(b for b in self._bn_buffers() if b.dtype == src.dtype)
+                # assign-style load_state_dict re-binds them, and the snapshot / restore would then silently do nothing.  The probe buffer is looked
+                # up once per flat tensor (walking every module twice per step was host time); the check itself stays per step.
+                probe = self._alias_probe.get(name)
+                if probe is None or probe[2] is not src:          # (owning module, attribute): the module's CURRENT buffer is fetched every step
+                    probe = self._alias_probe[name] = next((m, k, src) for mod in self.modules() for m in mod.modules()
+                                                           for k, b in m.named_buffers(recurse=False)
+                                                           if k in ('running_mean', 'running_var', 'num_batches_tracked') and b.dtype == src.dtype)
+                first = getattr(probe[0], probe[1])
                 assert first.data_ptr() == src.data_ptr(), 'HierarchyTrainer: the BatchNorm %s no longer alias the flat snapshot buffer ' \
                     '(module.to(dtype) / load_state_dict(assign=True) after construction?): call _flatten_bn_buffers() again' % name
         for dst, src in zip(self._bn_snap[slot], (self._bn_flat, self._bn_cnt)):
@@ -193,9 +200,10 @@ class HierarchyTrainer:
 
     def _recover_from_cluster_error(self, restore_buffers, slot=0):
         from . import ops
-        from .train_hierarchy import _err_watch
+        from .train_hierarchy import _err_free, _err_watch
         torch.cuda.synchronize(self.device)
-        _err_watch.clear()                              # copies of the word taken while it was set
+        _err_free.extend(w for _, w, _ in _err_watch)   # copies of the word taken while it was set: dropped, their pinned words go back to the pool
+        _err_watch.clear()
         if restore_buffers and self._bn_snap and slot in self._bn_snap:
             self._restore_buffers(slot)
         err = ops.gru_cluster_error_tensor(self.device)
