@@ -873,3 +873,29 @@ def test_one_linear_at_a_big_and_a_small_row_count_under_deferred_joins():
     ops.linear(torch.randn(8, 32, device=dev), w.view(32, 32))
     base = w._base if w._base is not None else w
     assert getattr(base, '_ha2g_grad_uses', 0) == 2 and not ops._single_use_nonleaf(w)
+
+
+def test_batchnorm_snapshot_notices_rebound_buffers():
+    """HierarchyTrainer snapshots the BatchNorm running statistics before every step through ONE flat tensor the module buffers are views of (the retry
+    after a cluster-GRU time-out restores from it).  A module.to(dtype) / assign-style load_state_dict re-binds the buffers: the snapshot would then
+    silently protect nothing -- the per-step check (the owning module's CURRENT buffer against the flat tensor; its location is looked up once)
+    must still fire."""
+    from ha2g_amd.config import hierarchy_args
+    from ha2g_testing import SpeakerVocab
+    from ha2g_amd.train import HierarchyTrainer
+
+    class Lang:
+        n_words, word_embedding_weights = 300, None
+
+    dev = torch.device(DEV)
+    tr = HierarchyTrainer(hierarchy_args(), Lang(), SpeakerVocab(20), 27, dev)
+    tr._snapshot_buffers()
+    tr._snapshot_buffers()                                    # second call: the cached location
+    bn = next(m for m in tr.audio_encoder.modules() if isinstance(getattr(m, 'running_mean', None), torch.Tensor))
+    bn.running_mean = bn.running_mean.clone()                 # what module.to(dtype) / load_state_dict(assign=True) do
+    first = tr._alias_probe['running statistics']
+    if getattr(first[0], first[1]).data_ptr() == tr._bn_flat.data_ptr():
+        # the re-bound buffer is not the probed one: re-bind the probed buffer as well (the check guards the FIRST view of the flat tensor)
+        setattr(first[0], first[1], getattr(first[0], first[1]).clone())
+    with pytest.raises(AssertionError, match='no longer alias'):
+        tr._snapshot_buffers()
