@@ -94,6 +94,54 @@ __global__ __launch_bounds__(256) void f32_to_planes_t_kernel(const float* __res
     }
 }
 
+// Round 6: up to 16 of those 2-D splits in ONE launch (blockIdx.z = job), each into its own window of a shared plane buffer -- the B operands of a GRU
+// stack's merged input projections [W_ih; W_ih_reverse] (rows 0..3H-1 / 3H..6H-1 of a [6H][Kp] plane set) and of its dX products (the transposed form:
+// columns 0..3H-1 / 3H..6H-1 of a [K][round_up(6H, 32)] plane set) were a torch.cat + a split launch per layer.
+// Job: x [rows][ldx] -> planes window at pl (piece q at pl + q * ps), row stride ldp.  tr = 0: `cols` valid columns, zeros in [cols, wcols);
+// tr = 1: element (c, r) = x[r][c] for c < cols, r < rows, zeros in [rows, wcols) (wcols = the window's width in elements, a multiple of 4).
+struct Split2dJobs { const float* x[16]; unsigned short* pl[16]; long ldx[16]; int rows[16], cols[16], wcols[16]; long ps, ldp; int tr; };
+template <int NP>
+__global__ __launch_bounds__(256) void f32_to_planes_2d_multi_kernel(Split2dJobs jb) {
+    const int j = blockIdx.z;
+    const float* __restrict__ x = jb.x[j];
+    unsigned short* __restrict__ pl = jb.pl[j];
+    const long ldx = jb.ldx[j], ps = jb.ps, ldp = jb.ldp;
+    const int rows = jb.rows[j], cols = jb.cols[j], wcols = jb.wcols[j];
+    if (!jb.tr) {
+        const int q4 = wcols >> 2;
+        const long total = (long)rows * q4;
+        for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < total; i += (long)gridDim.x * gridDim.y * 256) {
+            const long r = i / q4; const int c = (int)(i - r * q4) << 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* src = x + r * ldx + c;
+            if (c + 3 < cols) v = *reinterpret_cast<const float4*>(src);
+            else { if (c < cols) v.x = src[0]; if (c + 1 < cols) v.y = src[1]; if (c + 2 < cols) v.z = src[2]; }
+            unsigned a[NP], b[NP];
+            splitn_bf16<NP>(v.x, v.y, a); splitn_bf16<NP>(v.z, v.w, b);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(pl + q * ps + r * ldp + c) = make_uint2(a[q], b[q]);
+        }
+        return;
+    }
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long r0 = (long)blockIdx.x * 32; const int c0 = blockIdx.y * 32;
+    if (r0 >= wcols || c0 >= cols) return;                       // (block-uniform)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long r = r0 + ty + 8 * k; const int c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < rows && c < cols) ? x[r * ldx + c] : 0.f;
+    }
+    __syncthreads();
+    const int oc = threadIdx.x >> 3, or4 = (threadIdx.x & 7) << 2;
+    if (c0 + oc < cols && r0 + or4 < wcols) {
+        unsigned a[NP], b[NP];
+        splitn_bf16<NP>(tile[or4][oc], tile[or4 + 1][oc], a); splitn_bf16<NP>(tile[or4 + 2][oc], tile[or4 + 3][oc], b);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2*>(pl + q * ps + (long)(c0 + oc) * ldp + r0 + or4) = make_uint2(a[q], b[q]);
+    }
+}
+
 // w [Cout][KK][Cin] fp32 (OHWI) -> planes of wt [Cin][KK][Cout]: the B operand of the data gradient, rows = input channels, k = (tap, cout)
 __global__ void weight_ihwo_planes_kernel(const float* __restrict__ w, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, int Cout,
                                           int KK, int Cin) {
@@ -1918,6 +1966,32 @@ int ha2g_f32_to_planes_2d_np(const float* x, long ldx, long rows, int cols, void
                            (unsigned short*)planes, ps, ldp, rows, cols);
     }
     HA2G_CHECK_LAUNCH("f32_to_planes_2d");
+    return 0;
+}
+
+// n <= 16 two-dimensional splits in one launch (HOST arrays of device pointers / sizes); see f32_to_planes_2d_multi_kernel.  Every job writes a window of
+// the same plane set: piece q of job i at planes[i] + q * ps, row stride ldp.  transpose = 0: window = rows[i] x wcols[i]; 1: cols[i] x wcols[i].
+int ha2g_f32_to_planes_2d_multi_np(const void* const* x, const long* ldx, const int* rows, const int* cols, void* const* planes, const int* wcols, long ps, long ldp,
+                                   int n, int np, int transpose, void* stream) {
+    HA2G_REQUIRE(np == 3, "f32_to_planes_2d_multi: np = %d (3)", np);
+    HA2G_REQUIRE(n >= 0 && n <= 16, "f32_to_planes_2d_multi: %d jobs (max 16)", n);
+    if (n == 0) return 0;
+    Split2dJobs jb{};
+    jb.ps = ps; jb.ldp = ldp; jb.tr = transpose ? 1 : 0;
+    long most_r = 0; int most_c = 0;
+    for (int i = 0; i < n; ++i) {
+        HA2G_REQUIRE(wcols[i] % 4 == 0 && wcols[i] <= ldp && wcols[i] >= (transpose ? rows[i] : cols[i]), "f32_to_planes_2d_multi: window of %d columns", wcols[i]);
+        HA2G_REQUIRE(((uintptr_t)planes[i] & 7) == 0 && ldp % 4 == 0 && ps % 4 == 0, "f32_to_planes_2d_multi: plane windows must be 8-byte aligned");
+        jb.x[i] = (const float*)x[i]; jb.pl[i] = (unsigned short*)planes[i]; jb.ldx[i] = ldx[i]; jb.rows[i] = rows[i]; jb.cols[i] = cols[i]; jb.wcols[i] = wcols[i];
+        const long work = transpose ? wcols[i] : (long)rows[i] * (wcols[i] / 4);
+        if (work > most_r) most_r = work;
+        if (cols[i] > most_c) most_c = cols[i];
+    }
+    dim3 grid;
+    if (transpose) grid = dim3((unsigned)((most_r + 31) / 32), (unsigned)((most_c + 31) / 32), (unsigned)n);
+    else { const long b = (most_r + 255) / 256; grid = dim3((unsigned)(b > 1024 ? 1024 : (b < 1 ? 1 : b)), 1, (unsigned)n); }
+    hipLaunchKernelGGL(f32_to_planes_2d_multi_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, jb);
+    HA2G_CHECK_LAUNCH("f32_to_planes_2d_multi");
     return 0;
 }
 

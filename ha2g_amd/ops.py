@@ -285,6 +285,33 @@ def _gemm_planes(a, b, M, N, K, transa, transb, out, beta, bias, act, colsum_out
     return out
 
 
+def _gemm_planes_pre(a, bp, M, N, K, out, beta=0.0, bias=None, act=ACT_NONE):
+    """_gemm_planes with the B operand ALREADY split: bp [3][N][Kp] piece planes of the [N][K] operand (K contiguous, zero padded to Kp = K rounded up to
+    32) -- built for a whole GRU stack by one split2d_multi launch.  a [M][K] fp32 is split here."""
+    ap = _planes_2d(a, False)
+    assert ap.shape[2] == bp.shape[2] and bp.shape[1] == N
+    ws = workspace(a.device)
+    ktimer.launch('gemm_planes', lambda: check(lib.ha2g_gemm_planes_np_f32(
+        ap.data_ptr(), ap.stride(0), ap.shape[2], bp.data_ptr(), bp.stride(0), bp.shape[2], 3, M, N, K, beta, out.data_ptr(), out.stride(0),
+        _p(bias), act, ws.data_ptr(), ws.numel() * 4, _stream())), 2.0 * M * N * K)
+    return out
+
+
+def split2d_multi(mats, windows, ps, ldp, wcols, transpose):
+    """ha2g_f32_to_planes_2d_multi_np: mats = 2-D fp32 tensors (unit inner stride), windows = data pointers (ints) of their windows inside ONE plane set
+    (piece stride ps, row stride ldp elements), wcols = window widths"""
+    import numpy as np
+    n = len(mats)
+    xp = np.array([m.data_ptr() for m in mats], np.int64)
+    ld = np.array([m.stride(0) for m in mats], np.int64)
+    rows = np.array([m.shape[0] for m in mats], np.int32)
+    cols = np.array([m.shape[1] for m in mats], np.int32)
+    wp = np.array(windows, np.int64)
+    wc = np.array(wcols, np.int32)
+    check(lib.ha2g_f32_to_planes_2d_multi_np(xp.ctypes.data, ld.ctypes.data, rows.ctypes.data, cols.ctypes.data, wp.ctypes.data, wc.ctypes.data, ps, ldp,
+                                             n, 3, int(transpose), _stream()))
+
+
 def _ptr_array(tensors):
     import ctypes
     return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
@@ -1142,6 +1169,7 @@ def _gru_layer_fwd(gi, pk, bf, br, y, rs, B, T, H, st, device, pk3=None):
 
 
 GRU_MERGE_DIRS = True    # both directions' input projections as one plane GEMM
+GRU_STACK_PREP = True    # ... whose weight operands are split for the whole stack in one launch (forward: [6H][K] planes, backward: their transposes)
 PACK_MULTI = True      # one W_hh pack launch per GRU stack instead of two per layer
 
 
@@ -1190,6 +1218,18 @@ class BiGRUFunction(torch.autograd.Function):
         if PACK_MULTI and 2 * L <= 16 and gru_fwd3_active(H, T):
             # ... and their three-piece images (bf16 A fragments of the cluster kernel) likewise: one launch instead of two per layer
             pk3_all = _pack3_multi([weights[8 * l + 4 * d + 1] for l in range(L) for d in range(2)], L, H, False, dev, st)
+        # layers 1 .. L-1 (input = 2H columns): the merged operands [W_ih; W_ih_reverse] of ALL of them as piece planes from ONE launch, their merged biases
+        # from one cat (a cat of the weights, a cat of the biases and a split launch per layer before: round 6)
+        wih_planes = bcat_all = None
+        Kp2 = (2 * H + 31) // 32 * 32
+        if (GRU_STACK_PREP and GRU_MERGE_DIRS and L > 1 and dev.type == 'cuda' and 2 * H >= 256 and 2.0 * B * T * 6 * H * 2 * H >= PLANE_GEMM_MIN_FLOP
+                and PLANE_GEMM and lib.ha2g_gemm_bwd_pieces() == 3 and 2 * (L - 1) <= 16
+                and all(weights[8 * l + 4 * d].is_contiguous() and weights[8 * l + 4 * d].data_ptr() % 16 == 0 for l in range(1, L) for d in range(2))):
+            wih_planes = torch.empty(L - 1, 3, 6 * H, Kp2, dtype=torch.bfloat16, device=dev)
+            mats = [weights[8 * l + 4 * d] for l in range(1, L) for d in range(2)]
+            wins = [wih_planes[l - 1, 0, 3 * H * d].data_ptr() for l in range(1, L) for d in range(2)]
+            split2d_multi(mats, wins, wih_planes.stride(1), Kp2, [Kp2] * len(mats), False)
+            bcat_all = torch.cat([weights[8 * l + 4 * d + 2] for l in range(1, L) for d in range(2)]).view(L - 1, 6 * H)
         for l in range(L):
             w = [t.contiguous() for t in weights[8 * l:8 * l + 8]]
             K = inp.shape[2]
@@ -1197,7 +1237,10 @@ class BiGRUFunction(torch.autograd.Function):
             x2 = inp.view(B * T, K)
             tkey = 'gemm_gi' if (H == 300 and l > 0) else 'gemm_gi_other'
             fl = 2.0 * B * T * K * 3 * H
-            if GRU_MERGE_DIRS and _plane_gemm_ok(x2, w[0], B * T, 6 * H, K, False, True, 1.0, ACT_NONE, gi) and K >= 256:
+            if wih_planes is not None and l > 0 and K == 2 * H and x2.data_ptr() % 16 == 0:
+                ktimer.launch(tkey, lambda: _gemm_planes_pre(x2, wih_planes[l - 1], B * T, 6 * H, K, gi, bias=bcat_all[l - 1]), 2 * fl)
+                wcats[l] = 'planes'                        # the backward builds the transposed planes of the stack in one launch too
+            elif GRU_MERGE_DIRS and _plane_gemm_ok(x2, w[0], B * T, 6 * H, K, False, True, 1.0, ACT_NONE, gi) and K >= 256:
                 # both directions' input projections as ONE product [rows, K] x [6H, K]^T on the plane GEMM: twice the columns per launch fill the
                 # chip's rounds (291 -> 181 us at 13056 x 1800 x 600 incl. the operand splits, profiles/r04_plane_gemm_bench.txt)
                 wcat, bcat = torch.cat((w[0], w[4])), torch.cat((w[2], w[6]))
@@ -1253,6 +1296,14 @@ class BiGRUFunction(torch.autograd.Function):
         keep = []
         fused_b = []
         all_tgs = []                                       # the .grad buffers the side-stream sections below accumulate into (SideStream.touch)
+        wih_t_planes = None
+        if any(isinstance(c, str) for c in ctx.wcats):
+            # dX = dg[:, :6H] @ [W_ih; W_ih_reverse]: the B operand's planes hold its transpose [K][6H -> Kp6]; both directions of every layer >= 1 from one launch
+            Kp6 = (6 * H + 31) // 32 * 32
+            wih_t_planes = torch.empty(L - 1, 3, 2 * H, Kp6, dtype=torch.bfloat16, device=dev)
+            mats = [weights[8 * l + 4 * d] for l in range(1, L) for d in range(2)]
+            wins = [wih_t_planes[l - 1, 0, 0, 3 * H * d].data_ptr() for l in range(1, L) for d in range(2)]
+            split2d_multi(mats, wins, wih_t_planes.stride(1), Kp6, [3 * H if d == 0 else Kp6 - 3 * H for l in range(1, L) for d in range(2)], True)
         pk3t_all = None
         if PACK_MULTI and 2 * L <= 16 and gru_fwd3_active(H, T):      # the transposed three-piece W_hh images of every layer: one launch
             pk3t_all = _pack3_multi([weights[8 * l + 4 * d + 1] for l in range(L) for d in range(2)], L, H, True, dev, st)
@@ -1341,7 +1392,9 @@ class BiGRUFunction(torch.autograd.Function):
                     if not direct:
                         for d in range(2):
                             grads[8 * l + 4 * d + 2], grads[8 * l + 4 * d + 3] = outs[d]
-            if need_dx and ctx.wcats[l] is not None:                                # critical path: dX = [dgi fwd | dgi rev] [W_ih; W_ih_reverse], ONE product
+            if need_dx and isinstance(ctx.wcats[l], str):
+                _gemm_planes_pre(dg[:, :6 * H], wih_t_planes[l - 1], B * T, K, 6 * H, dx)
+            elif need_dx and ctx.wcats[l] is not None:                              # critical path: dX = [dgi fwd | dgi rev] [W_ih; W_ih_reverse], ONE product
                 gemm(dg[:, :6 * H], ctx.wcats[l], out=dx)                           # (two products of K = 3H with an accumulate pass before: 2 x 121 us in the step)
             elif need_dx:
                 for d in range(2):                                                  # dX (+)= dgi W_ih

@@ -106,6 +106,12 @@ int ha2g_conv2d_fwd_planes_np_stats_f32(const void* x, long x_ps, const void* w,
  * ha2g_f32_to_planes_2d_np splits a 2-D fp32 operand into K-contiguous, zero-padded piece planes (transpose = 1: the planes hold x^T);
  * ha2g_gemm_planes_np_f32: C [M][N] = act(A B^T + bias) + beta C from the planes of A [M][lda] and B [N][ldb], lda = ldb = K rounded up to 32 */
 int ha2g_f32_to_planes_2d_np(const float* x, long ldx, long rows, int cols, void* planes, long ps, long ldp, int np, int transpose, void* stream);
+/* n <= 16 of those splits in one launch, each into its own window of ONE plane set (ABI 5): job i splits x[i] [rows[i]][ldx[i]] (cols[i] valid columns) into the
+ * window at planes[i] (piece q at planes[i] + q * ps elements, row stride ldp): transpose = 0 -> rows[i] x wcols[i] with zeros in [cols[i], wcols[i]);
+ * transpose = 1 -> cols[i] x wcols[i] holding x^T with zeros in [rows[i], wcols[i]).  The arrays are HOST arrays.  Builds the merged operands
+ * [W_ih; W_ih_reverse] of every layer of an nn.GRU stack (model/hierarchy_net.py:87) without a torch.cat + split per layer. */
+int ha2g_f32_to_planes_2d_multi_np(const void* const* x, const long* ldx, const int* rows, const int* cols, void* const* planes, const int* wcols, long ps, long ldp,
+                                   int n, int np, int transpose, void* stream);
 int ha2g_gemm_planes_np_f32(const void* a, long a_ps, long lda, const void* b, long b_ps, long ldb, int np, int M, int N, int K, float beta,
                             float* C, long ldc, const float* bias, int act, float* ws, long ws_bytes, void* stream);
 void ha2g_conv_c32_wgrad_prefetch(int on);   /* A/B (ABI 5): the 32-channel three-piece weight gradient with the next tile's operands prefetched into registers (1, default; bit-identical) */

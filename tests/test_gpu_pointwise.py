@@ -523,3 +523,32 @@ def test_gru_inter_layer_dropout_without_a_mask_tensor_changes_no_bit(grad_slice
     for a, b in zip(outs[True], outs[False]):
         assert torch.equal(a, b)
     assert float(outs[True][1].abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_gru_stack_weight_operands_split_in_one_launch_change_no_bit():
+    """Round 6: the merged input-projection operands [W_ih; W_ih_reverse] of layers 1 .. L-1 of an nn.GRU stack (model/hierarchy_net.py:87) are split into piece
+    planes by ONE launch for the whole stack (forward: [6H][K] planes; backward, for dX: their transposes, both directions side by side) instead of a
+    torch.cat + a split per layer: the same plane values, so the output and every gradient are BIT-IDENTICAL to the per-layer form (ops.GRU_STACK_PREP = False).
+    64 x 34 rows: the plane GEMM serves the projections."""
+    from ha2g_amd import hierarchy_net as hn, ops
+    dev = torch.device(DEV)
+    torch.manual_seed(3)
+    gru = hn.BiGRU(107, 300, 4, dropout=0.0).to(dev).train()
+    x0 = torch.randn(64, 34, 107, device=dev)
+    params = list(gru.parameters())
+    outs = {}
+    for prep in (True, False):
+        old = ops.GRU_STACK_PREP
+        ops.GRU_STACK_PREP = prep
+        try:
+            x = x0.clone().requires_grad_(True)
+            y, _ = gru(x)
+            g = torch.autograd.grad((y * torch.sin(y)).sum(), [x] + params)
+            outs[prep] = [y.detach()] + [t.detach() for t in g]
+            torch.cuda.synchronize()
+        finally:
+            ops.GRU_STACK_PREP = old
+    assert ops.gru_cluster_error(dev) == 0
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a, b)
