@@ -216,6 +216,9 @@ struct PConvP {
     // BatchNorm statistics of the stored output from the epilogue (pconv_r_kernel, forward): per row tile and channel the sum and the sum of
     // squares (double) -> stat[(which * N + channel) * stat_nblk + tile]; null = none.  norm.hip's bn_stats_final_kernel adds the tiles in order.
     double* stat; int stat_nblk;
+    // round 6, data gradient on the patch-resident kernel: the tile sums are those of the BatchNorm BACKWARD this gradient feeds -- sum of dy and of
+    // dy * xhat, xhat = (bsx - bsmean) * bsinv, bsx = the BatchNorm's input [pixels][N] (the layout of the output) -- instead of the forward sums
+    const float* bsx; const float* bsmean; const float* bsinv;
 };
 
 // XCD-aware workgroup -> tile mapping (same rule as gemm.hip's tile_of_block: XCD x owns a contiguous eighth of the tile sequence, n fastest)
@@ -1317,6 +1320,40 @@ __global__ __launch_bounds__(256, WPS) void pconv_r_kernel(PConvP p, RGeo g) {
     //      Per lane the column sums of its MT <= 9 pixels (fp32: nine terms), then in double: a reduce-scatter over the 16 pixel lanes, one double per
     //      (channel, which) and tile; the tiles are added in double by bn_stats_final_kernel.  (All-double lane sums cost 5.5 us per launch; the lane
     //      sums are shifted instead, see below.)
+    if (p.stat != nullptr && p.bsx != nullptr) {
+        // BatchNorm-BACKWARD statistics of the gradient this launch produces (bn1 behind conv2's data gradient, ResNetBlocks.py:24-29 under autograd): the
+        // column pass col_partial_kernel<1> re-read dy (what this epilogue holds in registers) and the BatchNorm's input; here only the input tile is
+        // read.  Lane sums in double, the arithmetic of that pass ((double) x - mean) * invstd -- sum(dy * xhat) cancels by 1e3..1e4 on nearly dead
+        // channels --, then the same reduce-scatter and tile layout as the forward sums: norm.hip's pair_final_kernel adds the tiles in order.
+        constexpr int NV = NI * 8;
+        double sv[NV];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col0 = n0 + w4 * (BN / 4) + j * 16 + 4 * kp;
+            f32x4_t m4 = {0.f, 0.f, 0.f, 0.f}, i4 = m4;
+            if (col0 < p.N) { m4 = *reinterpret_cast<const f32x4_t*>(p.bsmean + col0); i4 = *reinterpret_cast<const f32x4_t*>(p.bsinv + col0); }
+            double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int pix = tp0 + i * 16 + pxo;
+                if (pix < tend && col0 < p.N) {
+                    const f32x4_t xv = *reinterpret_cast<const f32x4_t*>(p.bsx + ((long)img * HW + pix) * p.ldc + col0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double d = (double)acc[i][j][u];
+                        s1[u] += d;
+                        s2[u] += d * (((double)xv[u] - (double)m4[u]) * (double)i4[u]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { sv[(j * 4 + u) * 2] = s1[u]; sv[(j * 4 + u) * 2 + 1] = s2[u]; }
+        }
+        row16_reduce_scatter<NV>(sv, lane);
+        const int idx = l15 & (NV - 1);
+        const int ch = n0 + w4 * (BN / 4) + (idx >> 3) * 16 + 4 * kp + ((idx >> 1) & 3);
+        if ((NV == 16 || l15 < 8) && ch < p.N) p.stat[((long)(idx & 1) * p.N + ch) * p.stat_nblk + gt] = sv[0];
+    } else
     if (p.stat != nullptr) {
         constexpr int NV = NI * 8;
         double sv[NV];
@@ -1872,6 +1909,7 @@ static int pconv_q_dispatch(const PConvP& p_in, int maxM, hipStream_t st) {
     pconv_q_plan(maxM, p.N, p.ksplit > 1 ? p.ksplit : 1, &bmt, &bbn);
     if (bmt == 0) return -100;
     const dim3 grid((unsigned)((maxM + 32 * bmt - 1) / (32 * bmt)), (unsigned)((p.N + bbn - 1) / bbn), (unsigned)(p.ksplit > 1 ? p.ksplit : p.ncls));
+    if (p.stat != nullptr && p.bsx != nullptr) return ha2g_set_error(-1, "conv2d_dgrad_planes_bnstats: the geometry is not served by the patch-resident kernel");
     if (p.stat != nullptr && !(p.fwd && p.vec && p.ncls == 1 && p.ksplit <= 1 && !p.bias && !p.act && p.beta == 0.f && p.stat_nblk == 2 * (int)grid.x))
         return ha2g_set_error(-1, "conv2d_fwd_planes: statistics buffer sized for %d row blocks, the q kernel writes %d", p.stat_nblk, 2 * (int)grid.x);
     if (bbn == 128) {
@@ -2122,6 +2160,42 @@ int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const voi
     return ha2g_conv2d_dgrad_planes_np_f32(dy_hi, (const unsigned short*)dy_lo - (const unsigned short*)dy_hi, wt_hi,
                                            (const unsigned short*)wt_lo - (const unsigned short*)wt_hi, 2, dx, N, H, W, Cin, Cout, KH, KW, stride, pad,
                                            beta, stream);
+}
+
+// Round 6: the data gradient of a 3x3 / stride-1 / pad-1 convolution whose OUTPUT is the dy of a BatchNorm backward (conv2's data gradient feeds bn1,
+// model/ResNetBlocks.py:24-29 under autograd) leaves that backward's tile sums behind: stat_part [2][Cin][stat_nblk] doubles = per row tile the sums of
+// dx and of dx * xhat, xhat = (x_bn - mean) * invstd with x_bn [N,H,W,Cin] the BatchNorm's input.  ha2g_bn_bwd_planes_np_partials_f32 finishes them:
+// the column pass over dx and x_bn (col_partial_kernel<1>) is not run.  stat_nblk = ha2g_conv2d_dgrad_planes_stat_blocks(...) > 0: the geometry is
+// served by the patch-resident kernel in the current configuration (else the caller keeps the column pass).
+int ha2g_conv2d_dgrad_planes_stat_blocks(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (!ha2g_conv2d_dgrad_planes_supported(Cin, Cout, KH, KW, stride, pad)) return 0;
+    if (!(g_tile3 == 0 && g_q_kernel && g_r_kernel && gemm_bwd_pieces() == 3)) return 0;
+    if (!(KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cout % 32 == 0 && Cin % 64 == 0)) return 0;
+    int bmt = 0, bbn = 0; RGeo g{};
+    return pconv_r_plan(N, H, W, Cin, bmt, bbn, g) ? g.ntiles : 0;
+}
+int ha2g_conv2d_dgrad_planes_np_bnstats_f32(const void* dy, long dy_ps, const void* wt, long wt_ps, int np, float* dx, int N, int H, int W, int Cin, int Cout,
+                                            int KH, int KW, int stride, int pad, const float* x_bn, const float* mean, const float* invstd, void* stat_part,
+                                            int stat_nblk, void* stream) {
+    HA2G_REQUIRE(np == 3, "conv2d_dgrad_planes_bnstats: np = %d (3)", np);
+    HA2G_REQUIRE(x_bn && mean && invstd && stat_part, "conv2d_dgrad_planes_bnstats: null operand");
+    HA2G_REQUIRE(stat_nblk > 0 && stat_nblk == ha2g_conv2d_dgrad_planes_stat_blocks(N, H, W, Cin, Cout, KH, KW, stride, pad),
+                 "conv2d_dgrad_planes_bnstats: stat_nblk = %d is not what ha2g_conv2d_dgrad_planes_stat_blocks reports for this geometry", stat_nblk);
+    HA2G_REQUIRE((((uintptr_t)x_bn | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)dx) & 15) == 0, "conv2d_dgrad_planes_bnstats: 16-byte aligned operands");
+    PConvP p{};
+    p.a = PlaneSet{(const unsigned short*)dy, dy_ps};
+    p.b = PlaneSet{(const unsigned short*)wt, wt_ps};
+    p.C = dx; p.ldc = Cin; p.beta = 0.f;
+    p.N = Cin; p.K = KH * KW * Cout;
+    p.GH = H; p.GW = W; p.GC = Cout; p.OH = H; p.OW = W; p.KH = KH; p.KW = KW; p.pad = pad; p.stride = stride;
+    p.dbg = g_pdbg;
+    p.stat = (double*)stat_part; p.stat_nblk = stat_nblk; p.bsx = x_bn; p.bsmean = mean; p.bsinv = invstd;
+    if ((long)N * H * W == 0) return 0;
+    const int maxM = dgrad_classes(p, N, H, W, KH, KW, stride, pad, W);
+    set_plane_bytes(p, (long)N * H * W * Cout, (long)Cin * KH * KW * Cout);
+    if (int rc = pconv_dispatch<3, 0>(p, maxM, (hipStream_t)stream)) return rc;
+    HA2G_CHECK_LAUNCH("conv2d_dgrad_planes_bnstats");
+    return 0;
 }
 
 // ---- FORWARD convolution on three-piece planes (round 4): y [N,OH,OW,Cout] (fp32) = [relu](conv(x, w)) from the piece planes of x [N,H,W,Cin]

@@ -773,6 +773,26 @@ int ha2g_bn_bwd_planes_np_f32(const float* dy, const float* x, const float* mean
     return bn_bwd_t<1, float>(dy, x, mean, invstd, gamma, dx, planes, (unsigned short*)planes + ps, np, dgamma, dbeta, rows, C, relu_mask, acc_dgamma,
                               acc_dbeta, ws, stream);
 }
+// BatchNorm backward whose statistics pass already happened: stat_part [2][C][stat_nblk] doubles = tile sums of dy and of dy * xhat left behind by the
+// producer of dy (ha2g_conv2d_dgrad_planes_np_bnstats_f32).  pair_final adds the tiles in order (-> dbeta, dgamma, accumulated into acc_* when given), then
+// the apply pass as in ha2g_bn_bwd_planes_np_f32 (planes may be NULL: fp32 dx only).
+int ha2g_bn_bwd_planes_np_partials_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx, void* planes,
+                                       long ps, int np, float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta,
+                                       const void* stat_part, int stat_nblk, void* stream) {
+    HA2G_REQUIRE(okCv<float>(C), "bn: unsupported channel count %d", C);
+    HA2G_REQUIRE(stat_part != nullptr && stat_nblk > 0, "bn_bwd_partials: no partial sums");
+    HA2G_REQUIRE(planes == nullptr || np == 2 || np == 3, "bn_bwd_partials: np = %d", np);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)stat_part, stat_nblk, C, dbeta, dgamma, acc_dbeta, acc_dgamma);
+    if (planes != nullptr)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1, float>), dim3(flat_grid(rows * (C / 4))), dim3(256), 0, st, dy, x, mean, invstd, gamma, (const float*)dbeta,
+                           (const float*)dgamma, dx, rows, C, relu_mask, (unsigned short*)planes, (unsigned short*)planes + ps, np);
+    else if (dx != nullptr)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<0, float>), dim3(flat_grid(rows * (C / 4))), dim3(256), 0, st, dy, x, mean, invstd, gamma, (const float*)dbeta,
+                           (const float*)dgamma, dx, rows, C, relu_mask, (unsigned short*)nullptr, (unsigned short*)nullptr, 0);
+    HA2G_CHECK_LAUNCH("bn_bwd_partials");
+    return 0;
+}
 // out[n][c] = mean over HW of x[n][hw][c]
 int ha2g_hw_mean_f32(const float* x, float* out, int N, int HW, int C, void* stream) {
     HA2G_REQUIRE(okC(C), "hw_mean: unsupported channel count %d", C);

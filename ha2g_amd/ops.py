@@ -1023,14 +1023,23 @@ def bn_apply_pool(x, mean, invstd, gamma, beta):
     return y, pooled
 
 
-def bn_bwd(dy2, x2, mean, invstd, gamma, need_dx=True, relu_mask=False, acc=None, planes=False):
+def bn_bwd(dy2, x2, mean, invstd, gamma, need_dx=True, relu_mask=False, acc=None, planes=False, partials=None):
     """acc = (gamma.grad, beta.grad) buffers to accumulate into directly (the returned dgamma/dbeta are the fresh sums).
     planes: dx is also written as (hi, lo) bf16 planes for the plane-based split-bf16 consumers (csrc/conv_planes.hip) and the return value
-    grows to (dx, dgamma, dbeta, (hi, lo)); with need_dx=False ONLY the planes are written (dx is None)."""
+    grows to (dx, dgamma, dbeta, (hi, lo)); with need_dx=False ONLY the planes are written (dx is None).
+    partials = (stat_part [2, C, nblk] float64, nblk): the tile sums of (dy, dy * xhat) the producer of dy left behind (round 6): no column pass."""
     rows, C = x2.shape
     dx = torch.empty_like(x2) if need_dx else None
     dgamma, dbeta = empty(C, like=x2), empty(C, like=x2)
     ag, ab = acc if acc is not None else (None, None)
+    if partials is not None:
+        part, nblk = partials
+        pl = torch.empty(pieces(), rows, C, dtype=torch.bfloat16, device=x2.device) if planes else None
+        nb_ = 4.0 * rows * C * 3 + (2.0 * pl.shape[0] * rows * C if planes else 0.0)
+        ktimer.launch('bn_bwd_partials', lambda: check(lib.ha2g_bn_bwd_planes_np_partials_f32(
+            dy2.data_ptr(), x2.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), _p(dx), _p(pl), pl.stride(0) if planes else 0,
+            pl.shape[0] if planes else 0, dgamma.data_ptr(), dbeta.data_ptr(), rows, C, int(relu_mask), _p(ag), _p(ab), part.data_ptr(), nblk, _stream())), nb_)
+        return (dx, dgamma, dbeta, pl) if planes else (dx, dgamma, dbeta)
     # algorithmic HBM bytes of the backward (bench.py roofline_bn): statistics pass reads dy and x, apply pass reads them again and writes dx
     nbytes = 4.0 * rows * C * (5 if (need_dx or planes) else 2)
     if planes:

@@ -191,9 +191,23 @@ def prepare_weight_planes(P):
 _WPLANES = [None]      # planes prepared by prepare_weight_planes for the backward in progress (name -> (hi, lo)), looked up by weight data_ptr
 
 
-def conv_dgrad_planes(dy_planes, w_ohwi, xshape, stride, pad, out=None, beta=0.0):
+BN_BWD_EPILOGUE = True      # bn1's backward statistics out of the epilogue of conv2's data gradient (round 6)
+
+
+def dgrad_bnstats_blocks(w_ohwi, xshape, stride, pad):
+    """tiles per channel the data gradient's epilogue would write for the BatchNorm backward that consumes it; 0 = not served (keep the column pass)"""
+    N, H, W, Cin = xshape
+    Cout, KH, KW, _ = w_ohwi.shape
+    if not BN_BWD_EPILOGUE:
+        return 0
+    return int(lib.ha2g_conv2d_dgrad_planes_stat_blocks(N, H, W, Cin, Cout, KH, KW, stride, pad))
+
+
+def conv_dgrad_planes(dy_planes, w_ohwi, xshape, stride, pad, out=None, beta=0.0, bnstats=None):
     """conv_dgrad on the pre-split bf16 planes of dy (ops.bn_bwd(..., planes=True)): the weight goes through one re-layout + split launch,
-    the data gradient through the DMA-staged kernel of csrc/conv_planes.hip.  Bit-identical to conv_dgrad() in the default arithmetic mode."""
+    the data gradient through the DMA-staged kernel of csrc/conv_planes.hip.  Bit-identical to conv_dgrad() in the default arithmetic mode.
+    bnstats = (x_bn, mean, invstd, nblk): the output is the dy of that BatchNorm's backward and nblk = dgrad_bnstats_blocks(...) > 0 -- the epilogue
+    also leaves the backward's tile sums behind; returns (out, (stat_part [2, Cin, nblk] float64, nblk)) for ops.bn_bwd(..., partials=...)."""
     N, H, W, Cin = xshape
     Cout, KH, KW, _ = w_ohwi.shape
     dyp = dy_planes                                       # [np, N, OH, OW, Cout] (or [np, rows, Cout]) bf16 piece planes
@@ -204,6 +218,14 @@ def conv_dgrad_planes(dy_planes, w_ohwi, xshape, stride, pad, out=None, beta=0.0
     if out is None:
         out = torch.empty(N, H, W, Cin, dtype=torch.float32, device=dyp.device)
         beta = 0.0
+    if bnstats is not None:
+        x_bn, mean, invstd, nblk = bnstats
+        assert beta == 0.0 and npc == 3 and x_bn.is_contiguous() and tuple(x_bn.shape) == (N, H, W, Cin)
+        part = torch.empty(2, Cin, nblk, dtype=torch.float64, device=dyp.device)
+        ops.ktimer.launch('conv_dgrad_planes', lambda: check(lib.ha2g_conv2d_dgrad_planes_np_bnstats_f32(
+            dyp.data_ptr(), dyp.stride(0), wpl.data_ptr(), wpl.stride(0), npc, out.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad,
+            x_bn.data_ptr(), mean.data_ptr(), invstd.data_ptr(), part.data_ptr(), nblk, _stream())), 2.0 * N * H * W * Cin * KH * KW * Cout)
+        return out, (part, nblk)
     if beta == 0.0 and stride == 2 and KH == 1:
         out.zero_()                                       # a 1x1 stride-2 kernel reaches one pixel in four: the kernel writes only those
     ops.ktimer.launch('conv_dgrad_planes' if stride == 1 else 'conv_dgrad_planes_s2', lambda: check(lib.ha2g_conv2d_dgrad_planes_np_f32(
@@ -508,12 +530,13 @@ class GradSink:
             ops.side.join(device)
             self.forked = False
 
-    def gbn(self, name, dy2, x2, mean, invstd, relu_mask=False, planes=False, need_dx=True):
-        """planes=True: -> (dx fp32 or None (need_dx=False: every consumer reads the planes), (hi, lo) bf16 planes of dx)"""
+    def gbn(self, name, dy2, x2, mean, invstd, relu_mask=False, planes=False, need_dx=True, partials=None):
+        """planes=True: -> (dx fp32 or None (need_dx=False: every consumer reads the planes), (hi, lo) bf16 planes of dx).
+        partials = (stat_part, nblk): the statistics pass already happened in dy's producer (conv_dgrad_planes(..., bnstats=...))"""
         bn = self.P[name]
         tg_, tb_ = self.tgt(bn.gamma), self.tgt(bn.beta)
         acc = (tg_, tb_) if (tg_ is not None and tb_ is not None) else None
-        r = ops.bn_bwd(dy2, x2, mean, invstd, bn.gamma, need_dx=need_dx or not planes, relu_mask=relu_mask, acc=acc, planes=planes)
+        r = ops.bn_bwd(dy2, x2, mean, invstd, bn.gamma, need_dx=need_dx or not planes, relu_mask=relu_mask, acc=acc, planes=planes, partials=partials)
         if acc is None:
             self.G[name] = (r[1], r[2])
         return (r[0], r[3]) if planes else r[0]
@@ -651,12 +674,18 @@ def block_bwd(dx, saved, P, b, sink):
     # runs beside the bandwidth-bound BatchNorm-backward passes that follow instead of beside the (L2 -> LDS bound) data gradient
     if not WGRAD_AFTER:
         sink.gconv(b + 'conv2.weight', a1, dc2, wb, 1, 1, dy_planes=dc2p, x_planes=a1p)
-    da1 = conv_dgrad_planes(dc2p, wb, a1.shape, 1, 1) if p2 else conv_dgrad(dc2, wb, a1.shape, 1, 1)
+    st1 = None
+    nb1 = dgrad_bnstats_blocks(wb, c1.shape, 1, 1) if (p2 and dc2p.shape[0] == 3 and c1.dtype == torch.float32 and c1.is_contiguous()) else 0
+    if nb1 > 0:
+        # conv2's data gradient IS bn1's dy: its epilogue leaves bn1's backward sums behind, the column pass over (dy, c1) is not run
+        da1, st1 = conv_dgrad_planes(dc2p, wb, a1.shape, 1, 1, bnstats=(c1, m1, s1, nb1))
+    else:
+        da1 = conv_dgrad_planes(dc2p, wb, a1.shape, 1, 1) if p2 else conv_dgrad(dc2, wb, a1.shape, 1, 1)
     if WGRAD_AFTER:
         sink.gconv(b + 'conv2.weight', a1, dc2, wb, 1, 1, dy_planes=dc2p, x_planes=a1p)
     if JOIN_DGRAD:
         ops.side.join(dx.device)
-    dc1 = sink.gbn(b + 'bn1', _rows(da1), _rows(c1), m1, s1, relu_mask=True, planes=p1, need_dx=f1)
+    dc1 = sink.gbn(b + 'bn1', _rows(da1), _rows(c1), m1, s1, relu_mask=True, planes=p1, need_dx=f1, partials=st1)
     dc1, dc1p = ((dc1[0].view(c1.shape) if f1 else None), dc1[1]) if p1 else (dc1.view(c1.shape), None)
     if not WGRAD_AFTER:
         sink.gconv(b + 'conv1.weight', x, dc1, wa, stride, 1, dy_planes=dc1p, x_planes=xp)

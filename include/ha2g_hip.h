@@ -331,6 +331,18 @@ int ha2g_se_scale_add_relu_planes_f32(const float* x, const float* s, const floa
 int ha2g_bn_bwd_planes_np_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx, void* planes,
                               long ps, int np, float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta,
                               float* ws, void* stream);
+/* ABI 5: BatchNorm-backward statistics out of the epilogue of the data gradient that produces the BatchNorm's dy (conv2's data gradient -> bn1,
+ * model/ResNetBlocks.py:24-29 under autograd's backward, train_hierarchy.py:264).  ha2g_conv2d_dgrad_planes_stat_blocks: tiles per channel the launch
+ * writes (0 = not served: keep ha2g_bn_bwd_planes_np_f32); ha2g_conv2d_dgrad_planes_np_bnstats_f32: the data gradient (beta = 0) + stat_part
+ * [2][Cin][stat_nblk] doubles = tile sums of dx and dx * xhat (x_bn = the BatchNorm's input [N,H,W,Cin], its mean / invstd);
+ * ha2g_bn_bwd_planes_np_partials_f32: dgamma / dbeta from those tiles + the apply pass -- no column pass over dx and x_bn. */
+int ha2g_conv2d_dgrad_planes_stat_blocks(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int ha2g_conv2d_dgrad_planes_np_bnstats_f32(const void* dy, long dy_ps, const void* wt, long wt_ps, int np, float* dx, int N, int H, int W, int Cin, int Cout,
+                                            int KH, int KW, int stride, int pad, const float* x_bn, const float* mean, const float* invstd, void* stat_part,
+                                            int stat_nblk, void* stream);
+int ha2g_bn_bwd_planes_np_partials_f32(const float* dy, const float* x, const float* mean, const float* invstd, const float* gamma, float* dx, void* planes,
+                                       long ps, int np, float* dgamma, float* dbeta, long rows, int C, int relu_mask, float* acc_dgamma, float* acc_dbeta,
+                                       const void* stat_part, int stat_nblk, void* stream);
 int ha2g_bn_apply_planes_np_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float* y, void* planes,
                                 long ps, int np, long rows, int C, int act, void* stream);
 int ha2g_se_scale_add_relu_planes_np_f32(const float* x, const float* s, const float* res, float* out, void* planes, long ps, int np, int N, int HW,

@@ -276,3 +276,49 @@ def test_se_tail_without_materialised_bn2_output(name):
     for k in res[True]:
         a, b_ = res[True][k], res[False][k]
         assert float((a - b_).abs().max()) <= 2e-6 * float(b_.abs().max()) + 1e-12, (name, k, float((a - b_).abs().max()), float(b_.abs().max()))
+
+
+@pytest.mark.parametrize('name', ['l2', 'l3d', 'l3', 'l4'])
+def test_bn1_backward_statistics_from_the_data_gradient_epilogue(name):
+    """Round 6: conv2's data gradient (patch-resident kernel) IS bn1's dy, so its epilogue leaves bn1's backward sums -- sum(dy), sum(dy * xhat), lane sums in
+    double, tiles added in order by pair_final -- and the column pass over (dy, c1) is not run (wav_engine.BN_BWD_EPILOGUE).  Same block, same inputs,
+    against the column-pass form: bn1's gamma / beta gradients agree to 1e-6 of their scale (another summation order of the same doubles), everything
+    downstream of bn1's backward -- dx, conv1's weight gradient -- likewise; what lies upstream (bn2, SE, conv2) is bit-identical.  Both forms are held
+    to the reference fixtures by test_se_block_full_size and, element-wise, by tests/test_gpu_linearised.py."""
+    from ha2g_amd import ops, wav_engine as we
+    geom = BLOCKFULL_CASES[name]
+    P = engine_P(block_state(name, geom, 37), DEV)
+    x, wl = block_io(name, geom, BLOCKFULL_B, 37)
+    xin, dout = nhwc(x.to(DEV)), nhwc(wl.to(DEV))
+    wpl = {}
+    for n, stride, pad in (('conv1.weight', 2 if geom[4] else 1, 1), ('conv2.weight', 1, 1), ('downsample.0.weight', 2, 0)):
+        if n in P and we.fwd_planes_ok(we._ohwi(P[n]), stride, pad):
+            wpl[n] = ops.to_planes(we._ohwi(P[n]).contiguous(), 3)
+    xp = ops.to_planes(xin, 3) if 'conv1.weight' in wpl else None
+    c2w = we._ohwi(P['conv2.weight'])
+    res, used = {}, {}
+    try:
+        for on in (True, False):
+            we.BN_BWD_EPILOGUE = on
+            we._TRAINING[0] = True
+            we._NBT_PENDING.clear()
+            Pc = {k: (v.clone() if torch.is_tensor(v) else we._BN(v.gamma, v.beta, v.rm.clone(), v.rv.clone(), None)) for k, v in P.items()}
+            out, saved, _ = we.block_fwd(xin, Pc, '', geom[4], xp=xp, wpl=wpl)
+            used[on] = we.dgrad_bnstats_blocks(c2w, saved[1].shape, 1, 1)
+            sink = we.GradSink(Pc)
+            dx = we.block_bwd(dout, saved, Pc, '', sink)
+            sink.join(torch.device(DEV))
+            g = {}
+            for k, gr in sink.G.items():
+                for j, t in enumerate(gr if isinstance(gr, tuple) else (gr,)):
+                    g['%s/%d' % (k, j)] = t.double()
+            res[on] = dict(dx=dx.double(), **g)
+    finally:
+        we.BN_BWD_EPILOGUE = True
+    assert used[True] > 0 and used[False] == 0, (name, used)                  # the epilogue form really ran
+    for k in res[True]:
+        a, b_ = res[True][k], res[False][k]
+        if k.startswith(('bn2', 'se.', 'conv2')):
+            assert torch.equal(a, b_), (name, k)
+        else:
+            assert float((a - b_).abs().max()) <= 2e-6 * float(b_.abs().max()) + 1e-12, (name, k, float((a - b_).abs().max()), float(b_.abs().max()))
