@@ -421,8 +421,8 @@ def test_grouped_text_encoders_match_the_per_generator_encoders(expressive, fuse
     module -- under the fused-chain and the literal schedule, three and six generators, in the default arithmetic (mode 70) and on the fp32 MFMA
     (mode 0).  Unlike the fused-chain bridge above, the two sides run DIFFERENT launches of the same products (a grouped tile grid against three
     single ones, other split-K counts): the forwards agree to fp32 rounding, not bit for bit, so a handful of ReLU / LeakyReLU decisions flip and a
-    gradient tensor moves by ~1e-3 of its largest element.  Held per module at 5e-4 of the flat gradient norm and per tensor, element-wise, at
-    1e-2; the element-wise pin of the grouped form itself is tests/test_gpu_linearised.py::test_default_fused_schedule_* (1e-4 against float64)."""
+    gradient tensor moves by ~1e-3 of its largest element (a row of an embedding table: 1e-2).  Held per module at 5e-4 of the flat gradient norm and per
+    tensor, element-wise, at 3e-2; the element-wise pin of the grouped form itself is tests/test_gpu_linearised.py::test_default_fused_schedule_* (1e-4 against float64)."""
     B = 128
     for mode in (70, 0):
         r_g, g_g = _full_size_step(expressive, B, fuse, mode, fuse_text=True, per_tensor=True)
@@ -430,7 +430,7 @@ def test_grouped_text_encoders_match_the_per_generator_encoders(expressive, fuse
         for k in r_g:
             assert abs(r_g[k] - r_s[k]) <= 2e-5 * max(abs(r_s[k]), 1e-3), (mode, k, r_g[k], r_s[k])
         what = 'grouped vs per-generator text encoders, mode %d, fuse=%s, %s' % (mode, fuse, 'expressive' if expressive else 'gesture')
-        _elementwise_bridge(what, g_g, g_s, 1e-2)
+        _elementwise_bridge(what, g_g, g_s, 3e-2)
         mods = sorted({k.split('.')[0] for k in g_s})
         for m in mods:
             a = torch.cat([g_g[k].reshape(-1) for k in sorted(g_s) if k.split('.')[0] == m])
