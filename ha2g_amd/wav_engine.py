@@ -191,7 +191,9 @@ def prepare_weight_planes(P):
 _WPLANES = [None]      # planes prepared by prepare_weight_planes for the backward in progress (name -> (hi, lo)), looked up by weight data_ptr
 
 
-BN_BWD_EPILOGUE = True      # bn1's backward statistics out of the epilogue of conv2's data gradient (round 6)
+BN_BWD_EPILOGUE = False     # bn1's backward statistics out of the epilogue of conv2's data gradient (round 6): built, tested, NOT the default --
+                            # the step is 0.3 ms SLOWER with it (36.14 vs 35.84 ms: the double-precision epilogue of the MFMA kernel costs more than the
+                            # column pass it removes), DESIGN 8.1
 
 
 def dgrad_bnstats_blocks(w_ohwi, xshape, stride, pad):
