@@ -480,14 +480,30 @@ __global__ void se_bwd_apply_kernel(const T* __restrict__ dout, const T* __restr
 //   dpool[n][c] = inv_hw * sum_j dh1[n][j] * w0[j][c]                   (fc.0: Linear(C -> R), weight [R][C]; the squeeze's 1 / HW)
 // C <= 256, R <= 32 (reduction 8).  Three dependent launches (GEMM, eltwise, GEMM) of a few microseconds each sat on the backward's critical path
 // per block; fixed summation order (eight strided partials per j, then ascending), no atomics.
+// dpart (round 6, nullable): dsc is not given but still the chunk sums of the SE-backward reduction pass (image_col_kernel<1>: [n][nchunk][C] doubles); this
+// kernel finishes them as pool_final_kernel did -- chunks added in order, cast, times the gate's sigmoid' -- and writes dsc out (the SE weight gradient reads
+// it): one launch less per block, the same bits.
 __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict__ dsc, const float* __restrict__ h1, const float* __restrict__ w2,
                                                          const float* __restrict__ w0, float* __restrict__ dh1, float* __restrict__ dpool, int C,
-                                                         int R, float inv_hw) {
+                                                         int R, float inv_hw, const double* __restrict__ dpart = nullptr, int nchunk = 0,
+                                                         const float* __restrict__ gate = nullptr, float* __restrict__ dsc_out = nullptr) {
     __shared__ float sd[256];
     __shared__ float part[8][32];
     __shared__ float sh[32];
     const int n = blockIdx.x, t = threadIdx.x;
-    if (t < C) sd[t] = dsc[(long)n * C + t];
+    if (t < C) {
+        float v;
+        if (dpart != nullptr) {
+            double sm = 0.0;
+            for (int k = 0; k < nchunk; ++k) sm += dpart[((long)n * nchunk + k) * C + t];
+            v = (float)(sm * 1.f);
+            if (gate) { const float g = gate[(long)n * C + t]; v = v * g * (1.f - g); }
+            dsc_out[(long)n * C + t] = v;
+        } else {
+            v = dsc[(long)n * C + t];
+        }
+        sd[t] = v;
+    }
     __syncthreads();
     const int j = t & 31, g = t >> 5;
     float acc = 0.f;
@@ -844,6 +860,28 @@ int ha2g_se_bwd_scale_bn_f32(const float* dout, const float* out, const float* x
 int ha2g_se_bwd_scale_f32(const float* dout, const float* out, const float* x, float* ds, int N, int HW, int C, const float* gate, float* ws,
                           void* stream) {
     return se_bwd_scale_t<float>(dout, out, x, ds, N, HW, C, gate, ws, stream);
+}
+// ha2g_se_bwd_scale[_bn]_f32 + ha2g_se_mlp_bwd_f32 with the reduction's final pass folded into the MLP launch (round 6): ds [N][C] is still written (the
+// excitation MLP's weight gradient reads it).  mean == NULL: x is bn2's materialised output; else bn2 is applied on the fly to its input x.
+int ha2g_se_bwd_scale_mlp_f32(const float* dout, const float* out, const float* x, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, float* ds, int N, int HW, int C, const float* gate, float* ws, const float* h1, const float* w2,
+                              const float* w0, float* dh1, float* dpool, int R, void* stream) {
+    HA2G_REQUIRE(okCv<float>(C), "se: unsupported channel count %d", C);
+    HA2G_REQUIRE(C >= 1 && C <= 256 && R >= 1 && R <= 32, "se_bwd_scale_mlp: unsupported widths C = %d, R = %d", C, R);
+    HA2G_REQUIRE(ws != nullptr && gate != nullptr, "se_bwd_scale_mlp: null workspace / gate");
+    if (N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = pool_chunks(N, HW);
+    if (mean != nullptr) {
+        const BnAff aff{mean, invstd, gamma, beta};
+        hipLaunchKernelGGL((image_col_kernel<1, float, true>), dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, ds, 1.f, (double*)ws, (const float*)nullptr, aff);
+    } else {
+        hipLaunchKernelGGL((image_col_kernel<1, float>), dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, ds, 1.f, (double*)ws, (const float*)nullptr);
+    }
+    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(N), dim3(256), 0, st, (const float*)nullptr, h1, w2, w0, dh1, dpool, C, R, 1.f / (float)HW, (const double*)ws, nchunk,
+                       gate, ds);
+    HA2G_CHECK_LAUNCH("se_bwd_scale_mlp");
+    return 0;
 }
 int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, const float* dpool, float* dres, float* dx, int N,
                           int HW, int C, void* stream) {

@@ -320,6 +320,7 @@ _FWD_PLANES = [False]      # this forward will be back-propagated through the pl
 _WILL_BWD = [True]
 JOIN_DGRAD = 0             # round-6 experiment: 1 = the main stream waits for the side queue after every data gradient of the tower's backward (the
                            # BatchNorm / SE passes then run with no weight gradient beside them); 0 = one join at the end
+SE_BWD_FOLD = True         # the SE backward's reduction finishes inside the excitation MLP's backward launch (round 6: -16 launches, same bits)
 SE_WGRAD_FUSED = True      # the SE excitation MLP's four parameter gradients in one launch (GradSink.gse)
 
 
@@ -650,15 +651,28 @@ def block_bwd(dx, saved, P, b, sink):
     HW = OH * OW
     dout = dx.contiguous()
     ds = empty(N, C, like=c2)
-    if b2 is None:                                      # the forward never wrote bn2's output: recomputed per element from c2 (the same bits)
-        bn2 = P[b + 'bn2']
-        check(lib.ha2g_se_bwd_scale_bn_f32(dout.data_ptr(), out.data_ptr(), c2.data_ptr(), m2.data_ptr(), s2.data_ptr(), bn2.gamma.data_ptr(),
-                                           bn2.beta.data_ptr(), ds.data_ptr(), N, HW, C, sc.data_ptr(), ops.workspace(dout.device).data_ptr(), _stream()))
+    w2_, w0_ = P[b + 'se.fc.2.weight'], P[b + 'se.fc.0.weight']
+    if SE_BWD_FOLD and SE_MLP_FUSED and w2_.is_contiguous() and w0_.is_contiguous() and lib.ha2g_se_mlp_bwd_supported(C, h1.shape[1]):
+        # reduction pass + (its final pass inside) the excitation MLP's backward: two launches instead of three, the same bits
+        dh1, dpool = torch.empty_like(h1), torch.empty_like(ds)
+        bn2 = P[b + 'bn2'] if b2 is None else None
+        xsrc = c2 if b2 is None else b2
+        check(lib.ha2g_se_bwd_scale_mlp_f32(dout.data_ptr(), out.data_ptr(), xsrc.data_ptr(), _p(m2 if bn2 is not None else None),
+                                            _p(s2 if bn2 is not None else None), _p(bn2.gamma if bn2 is not None else None),
+                                            _p(bn2.beta if bn2 is not None else None), ds.data_ptr(), N, HW, C, sc.data_ptr(),
+                                            ops.workspace(dout.device).data_ptr(), h1.data_ptr(), w2_.data_ptr(), w0_.data_ptr(), dh1.data_ptr(), dpool.data_ptr(),
+                                            h1.shape[1], _stream()))
+        dsc = ds
     else:
-        check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, sc.data_ptr(),
-                                        ops.workspace(dout.device).data_ptr(), _stream()))
-    dsc = ds                                            # already times the gate's sigmoid' (folded into the reduction's final pass)
-    dh1, dpool = se_mlp_bwd(dsc, h1, P[b + 'se.fc.2.weight'], P[b + 'se.fc.0.weight'], HW)
+        if b2 is None:                                      # the forward never wrote bn2's output: recomputed per element from c2 (the same bits)
+            bn2 = P[b + 'bn2']
+            check(lib.ha2g_se_bwd_scale_bn_f32(dout.data_ptr(), out.data_ptr(), c2.data_ptr(), m2.data_ptr(), s2.data_ptr(), bn2.gamma.data_ptr(),
+                                               bn2.beta.data_ptr(), ds.data_ptr(), N, HW, C, sc.data_ptr(), ops.workspace(dout.device).data_ptr(), _stream()))
+        else:
+            check(lib.ha2g_se_bwd_scale_f32(dout.data_ptr(), out.data_ptr(), b2.data_ptr(), ds.data_ptr(), N, HW, C, sc.data_ptr(),
+                                            ops.workspace(dout.device).data_ptr(), _stream()))
+        dsc = ds                                            # already times the gate's sigmoid' (folded into the reduction's final pass)
+        dh1, dpool = se_mlp_bwd(dsc, h1, w2_, w0_, HW)
     sink.gse(b, dsc, h1, dh1, pooled)
     dres, db2 = torch.empty_like(c2), torch.empty_like(c2)
     check(lib.ha2g_se_bwd_apply_f32(dout.data_ptr(), out.data_ptr(), sc.data_ptr(), dpool.data_ptr(), dres.data_ptr(),

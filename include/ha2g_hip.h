@@ -379,6 +379,11 @@ int ha2g_se_mlp_bwd_f32(const float* dsc, const float* h1, const float* w2, cons
  * sums of dh1; dsc [N][C], h1 / dh1 [N][R], pooled [N][C].  Replaces two ha2g_gemm_wgrad_bias_f32 launches per block. */
 int ha2g_se_mlp_wgrad_f32(const float* dsc, const float* h1, const float* dh1, const float* pooled, float* dw2, float* db2, float* dw0, float* db0,
                           int N, int C, int R, void* stream);
+/* ABI 5: ha2g_se_bwd_scale[_bn]_f32 + ha2g_se_mlp_bwd_f32 as two launches instead of three (the reduction's final pass runs inside the MLP launch; ds is
+ * still written).  mean == NULL: x = bn2's output; else x = bn2's input and bn2 is applied on the fly (mean / invstd / gamma / beta). */
+int ha2g_se_bwd_scale_mlp_f32(const float* dout, const float* out, const float* x, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, float* ds, int N, int HW, int C, const float* gate, float* ws, const float* h1, const float* w2,
+                              const float* w0, float* dh1, float* dpool, int R, void* stream);
 int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, const float* dpool, float* dres,
                           float* dx, int N, int HW, int C, void* stream);
 /* speaker-softmax blending of the three audio taps (model/ResNetSE34V2.py:202-212) */

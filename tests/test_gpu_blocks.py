@@ -322,3 +322,40 @@ def test_bn1_backward_statistics_from_the_data_gradient_epilogue(name):
             assert torch.equal(a, b_), (name, k)
         else:
             assert float((a - b_).abs().max()) <= 2e-6 * float(b_.abs().max()) + 1e-12, (name, k, float((a - b_).abs().max()), float(b_.abs().max()))
+
+
+@pytest.mark.parametrize('name', ['l1', 'l2', 'l3d', 'l4'])
+def test_se_backward_reduction_finished_inside_the_mlp_launch_changes_no_bit(name):
+    """Round 6: the SE backward's per-image reduction (dout * relu' * bn2(c2) summed over the pixels, in chunks) is finished -- chunks added in order, cast,
+    times the gate's sigmoid' -- inside the excitation MLP's backward launch instead of a pool_final launch of its own (wav_engine.SE_BWD_FOLD): every output
+    of the block's backward is BIT-IDENTICAL."""
+    from ha2g_amd import ops, wav_engine as we
+    geom = BLOCKFULL_CASES[name]
+    P = engine_P(block_state(name, geom, 41), DEV)
+    x, wl = block_io(name, geom, BLOCKFULL_B, 41)
+    xin, dout = nhwc(x.to(DEV)), nhwc(wl.to(DEV))
+    wpl = {}
+    for n, stride, pad in (('conv1.weight', 2 if geom[4] else 1, 1), ('conv2.weight', 1, 1), ('downsample.0.weight', 2, 0)):
+        if n in P and we.fwd_planes_ok(we._ohwi(P[n]), stride, pad):
+            wpl[n] = ops.to_planes(we._ohwi(P[n]).contiguous(), 3)
+    xp = ops.to_planes(xin, 3) if 'conv1.weight' in wpl else None
+    res = {}
+    try:
+        for on in (True, False):
+            we.SE_BWD_FOLD = on
+            we._TRAINING[0] = True
+            we._NBT_PENDING.clear()
+            Pc = {k: (v.clone() if torch.is_tensor(v) else we._BN(v.gamma, v.beta, v.rm.clone(), v.rv.clone(), None)) for k, v in P.items()}
+            out, saved, _ = we.block_fwd(xin, Pc, '', geom[4], xp=xp, wpl=wpl)
+            sink = we.GradSink(Pc)
+            dx = we.block_bwd(dout, saved, Pc, '', sink)
+            sink.join(torch.device(DEV))
+            g = {}
+            for k, gr in sink.G.items():
+                for j, t in enumerate(gr if isinstance(gr, tuple) else (gr,)):
+                    g['%s/%d' % (k, j)] = t.clone()
+            res[on] = dict(dx=dx.clone(), **g)
+    finally:
+        we.SE_BWD_FOLD = True
+    for k in res[True]:
+        assert torch.equal(res[True][k], res[False][k]), (name, k)
