@@ -330,6 +330,46 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
         }
     }
 }
+// dropout_kernel's keep factors of elements [4 ic, 4 ic + 4) (the same mask for the same (state, stream_id, element))
+__device__ __forceinline__ void philox_mask4(long ic, unsigned long long seed, unsigned long long step, unsigned stream_id, float p, float scale, float* m) {
+    uint32_t c0 = (uint32_t)ic, c1 = (uint32_t)(ic >> 32) ^ stream_id, c2 = (uint32_t)step, c3 = (uint32_t)(step >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    const uint32_t rr[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = ((rr[j] >> 8) * (1.0f / 16777216.0f)) >= p ? scale : 0.f;
+}
+// im2col1d_k2_kernel of dropout(x) without the dropped tensor (round 6; model/tcn.py:21-31: conv1 -> ReLU -> dropout -> conv2): the mask of ha2g_dropout_f32
+// for the same (state, stream_id) over x's elements is re-drawn for both taps of an output row (a launch and 2 x |x| bytes less per convolution)
+__global__ void im2col1d_k2_drop_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int T, int C4, int dil, int pad_left, int To, float p,
+                                        const unsigned long long* __restrict__ state, unsigned stream_id) {
+    const unsigned long long seed = state[0], step = state[1];
+    const float scale = 1.f / (1.f - p);
+    const long total = (long)B * To * C4;
+    for (long i = (long)blockIdx.x * EB + threadIdx.x; i < total; i += (long)gridDim.x * EB) {
+        const int c4 = (int)(i % C4); const long r = i / C4; const int t = (int)(r % To); const long b = r / To;
+        const int t0 = t - pad_left, t1 = t0 + dil;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), v = a;
+        if (t0 >= 0 && t0 < T) {
+            const long ic = (b * T + t0) * C4 + c4;
+            float m[4];
+            philox_mask4(ic, seed, step, stream_id, p, scale, m);
+            a = reinterpret_cast<const float4*>(x)[ic];
+            a = make_float4(a.x * m[0], a.y * m[1], a.z * m[2], a.w * m[3]);
+        }
+        if (t1 >= 0 && t1 < T) {
+            const long ic = (b * T + t1) * C4 + c4;
+            float m[4];
+            philox_mask4(ic, seed, step, stream_id, p, scale, m);
+            v = reinterpret_cast<const float4*>(x)[ic];
+            v = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+        }
+        float4* d = reinterpret_cast<float4*>(col) + (r * C4 + c4) * 2;
+        d[0] = make_float4(a.x, v.x, a.y, v.y);
+        d[1] = make_float4(a.z, v.z, a.w, v.w);
+    }
+}
 __global__ void rng_advance_kernel(unsigned long long* state) { state[1] += 1ull; }
 
 // ---------------------------------------------------------------- pixel shuffle (NHWC) ----------------
@@ -464,6 +504,19 @@ int ha2g_im2col1d_f32(const float* x, float* col, int B, int T, int C, int k, in
     }
     hipLaunchKernelGGL(im2col1d_kernel, dim3(grid_for(total)), dim3(EB), 0, (hipStream_t)stream, x, col, B, T, C, k, dil, pad_left, To);
     HA2G_CHECK_LAUNCH("im2col1d");
+    return 0;
+}
+int ha2g_im2col1d_drop_supported(int C, int k) { return k == 2 && C % 4 == 0; }
+int ha2g_im2col1d_drop_f32(const float* x, float* col, int B, int T, int C, int k, int dil, int pad_left, int To, float p, const void* rng_state,
+                           unsigned stream_id, void* stream) {
+    HA2G_REQUIRE(ha2g_im2col1d_drop_supported(C, k), "im2col1d_drop: k = %d, C = %d (k = 2, C %% 4 == 0)", k, C);
+    HA2G_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)col & 15) == 0, "im2col1d_drop: 16-byte aligned buffers");
+    HA2G_REQUIRE(p >= 0.f && p < 1.f && rng_state != nullptr, "im2col1d_drop: p = %f / null state", (double)p);
+    const long total = (long)B * To * C * k;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(im2col1d_k2_drop_kernel, dim3(grid_for(total / 8)), dim3(EB), 0, (hipStream_t)stream, x, col, B, T, C / 4, dil, pad_left, To, p,
+                       (const unsigned long long*)rng_state, stream_id);
+    HA2G_CHECK_LAUNCH("im2col1d_k2_drop");
     return 0;
 }
 int ha2g_col2im1d_f32(const float* dcol, float* dx, int B, int T, int C, int k, int dil, int pad_left, int To, void* stream) {

@@ -14,7 +14,7 @@ int ha2g_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int ha2g_abi_version(void) { return 5; }      // 2: guarded Adam, ha2g_sparse_adam2_f32, N-piece plane entry points (*_np); 3: ha2g_gru_cluster_tile_cap; 4: BatchNorm statistics from the forward convolution's epilogue; 5: ha2g_splitk_set_tickets (in-kernel split-K reduction)
+extern "C" int ha2g_abi_version(void) { return 6; }      // 2: guarded Adam, ha2g_sparse_adam2_f32, N-piece plane entry points (*_np); 3: ha2g_gru_cluster_tile_cap; 4: BatchNorm statistics from the forward convolution's epilogue; 5: ha2g_splitk_set_tickets (in-kernel split-K reduction); 6: ha2g_se_bn_bwd_* (SE + bn2 backward in two passes)
 
 // ---- split-K arrival tickets per (device, stream): see common.h ----
 #include <mutex>
@@ -67,6 +67,40 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     __syncthreads();
     if (w == 0 && c < cols) part[(long)blockIdx.y * cols + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
+// narrow matrices (cols <= 1024, cols / 4 divides 256, 16-byte aligned rows): 16-byte loads, 256 / (cols / 4) rows per trip and four trips in flight --
+// the 64-lane form above keeps cols of 64 lanes busy with 4-byte loads (the audio taps' bias gradients, 16 / 32 / 64 columns x 0.3-1.2 M rows:
+// 48-71 us each on the main queue of the tower's backward).  Same partial layout, fixed order.
+__global__ __launch_bounds__(256) void colsum_partial_v4_kernel(const float* __restrict__ X, long ld, long rows, int cols, double* __restrict__ part) {
+    __shared__ double sh[256][4];
+    const int CV = cols >> 2, cv = threadIdx.x % CV, r0 = threadIdx.x / CV, rstep = 256 / CV;
+    const long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long rbeg = (long)blockIdx.x * per, rend = min(rows, rbeg + per);
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    long r = rbeg + r0;
+    for (; r + 3L * rstep < rend; r += 4L * rstep) {
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(X + (r + (long)j * rstep) * ld + cv * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[0] += (double)v[j][0]; a[1] += (double)v[j][1]; a[2] += (double)v[j][2]; a[3] += (double)v[j][3]; }
+    }
+    for (; r < rend; r += rstep) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(X + r * ld + cv * 4);
+        a[0] += (double)v[0]; a[1] += (double)v[1]; a[2] += (double)v[2]; a[3] += (double)v[3];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sh[threadIdx.x][k] = a[k];
+    __syncthreads();
+    if (threadIdx.x < CV) {
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int t = threadIdx.x; t < 256; t += CV) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s4[k] += sh[t][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[(long)blockIdx.x * cols + threadIdx.x * 4 + k] = s4[k];
+    }
+}
 // one wave per column: lanes stride the row-chunk partials, fixed xor tree
 __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ part, int nchunk, int cols, float* __restrict__ out,
                                                            float beta) {
@@ -87,6 +121,14 @@ extern "C" int ha2g_colsum_f32(const float* X, long ld, long rows, int cols, flo
     if (cols <= 0) return 0;
     HA2G_REQUIRE(ws != nullptr, "colsum: workspace required");
     hipStream_t st = (hipStream_t)stream;
+    if (cols % 4 == 0 && cols <= 1024 && 256 % (cols / 4) == 0 && ld % 4 == 0 && ((uintptr_t)X & 15) == 0 && rows >= 4096) {
+        long want = rows / 256;
+        const int nchunk = (int)(want > CS_MAXCHUNK ? CS_MAXCHUNK : want);
+        hipLaunchKernelGGL(colsum_partial_v4_kernel, dim3(nchunk), dim3(256), 0, st, X, ld, rows, cols, (double*)ws);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 4)), dim3(256), 0, st, (const double*)ws, nchunk, cols, out, beta);
+        HA2G_CHECK_LAUNCH("colsum");
+        return 0;
+    }
     int cchunks = ceil_div(cols, 64);
     long want = rows / 64;                                // >= 64 rows per block
     int nchunk = (int)(want < 1 ? 1 : (want > CS_MAXCHUNK ? CS_MAXCHUNK : want));

@@ -545,6 +545,162 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
     }
 }
 
+// ---- SE backward + bn2 backward WITHOUT the gradient tensor between them (round 6, second half) ------------------------------------------------
+// Block tail (ResNetBlocks.py:30-37): z = bn2(c2); out = relu(z * s[n,c] + residual), s = SE gate of mean_hw z.  With dpre = dout * (out > 0):
+//   dz[n,hw,c] = dpre * s[n,c] + dpool[n,c]                 (dpool = the squeeze's gradient, already / HW)
+// and bn2's backward needs sum dz and sum dz * xhat per channel.  Both follow from PER-IMAGE sums over hw that the SE reduction pass can take
+// while it reads (dout, out, c2) anyway:  A1 = sum dpre, A2 = sum dpre * xhat, A3 = sum xhat  (xhat = (c2 - mean) invstd):
+//   SE:  sum_hw dpre * z  = gamma A2 + beta A1           (z = gamma xhat + beta)
+//   bn2: sum_hw dz        = s A1 + HW dpool,   sum_hw dz * xhat = s A2 + dpool A3
+// so the pass that WROTE dz (se_bwd_apply) and the column pass that READ it back with c2 (col_partial<1>) disappear: two passes over three tensors
+// (reduce, apply) instead of four over nine tensor reads.  All sums in double, fixed order (chunks ascending, images ascending): deterministic.
+__global__ __launch_bounds__(256) void se_bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dout, const float* __restrict__ outp,
+                                                           int HW, int C, double* __restrict__ part, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd) {
+    // grid (nchunk, N): block (k, n) sums rows [k * per, (k + 1) * per) of image n -> part [n][k][3][C]
+    __shared__ dvec<4> lds[3][256];
+    const int CV = C / 4;
+    ColMap m(CV);
+    const int nchunk = gridDim.x, per = (HW + nchunk - 1) / nchunk;
+    const int rbeg = blockIdx.x * per, rend = min(HW, rbeg + per);
+    const long base = (long)blockIdx.y * HW * C;
+    dvec<4> a1 = dzero<4>(), a2 = dzero<4>(), a3 = dzero<4>();
+    const fvec<4> mu = ldp<4>(mean, m.cv), is = ldp<4>(invstd, m.cv);
+    auto accum = [&](const fvec<4>& v, const fvec<4>& d, const fvec<4>& o) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double xh = ((double)v.v[k] - mu.v[k]) * is.v[k];          // col_partial_kernel<1>'s xhat
+            const double dp = o.v[k] > 0.f ? (double)d.v[k] : 0.0;
+            a1.v[k] += dp; a2.v[k] += dp * xh; a3.v[k] += xh;
+        }
+    };
+    int r = rbeg + m.r0;
+    for (; r + 3 * m.rstep < rend; r += 4 * m.rstep) {                        // twelve 16-byte loads in flight per thread
+        fvec<4> v[4], d[4], o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long off = base + (long)(r + j * m.rstep) * C;
+            v[j] = ldv(x + off, m.cv); d[j] = ldv(dout + off, m.cv); o[j] = ldv(outp + off, m.cv);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accum(v[j], d[j], o[j]);
+    }
+    for (; r < rend; r += m.rstep) {
+        const long off = base + (long)r * C;
+        accum(ldv(x + off, m.cv), ldv(dout + off, m.cv), ldv(outp + off, m.cv));
+    }
+    lds[0][threadIdx.x] = a1; lds[1][threadIdx.x] = a2; lds[2][threadIdx.x] = a3;
+    __syncthreads();
+    if (threadIdx.x < CV) {
+        double* p = part + ((long)blockIdx.y * nchunk + blockIdx.x) * 3 * C + threadIdx.x * 4;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            dvec<4> sacc = dzero<4>();
+            for (int t = threadIdx.x; t < 256; t += CV) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sacc.v[k] += lds[q][t].v[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p[(long)q * C + k] = sacc.v[k];
+        }
+    }
+}
+// se_mlp_bwd_kernel fed by se_bn_reduce_kernel's chunk sums; also leaves bn2's per-image statistics behind: stat [2][C][N] doubles (pair_final_kernel's
+// layout with "blocks" = images): stat[c][n] = sum_hw dz, stat[C + c][n] = sum_hw dz * xhat of image n.
+__global__ __launch_bounds__(256) void se_bn_mlp_bwd_kernel(const float* __restrict__ h1, const float* __restrict__ w2, const float* __restrict__ w0,
+                                                            float* __restrict__ dh1, float* __restrict__ dpool, int C, int R, int HW, int N,
+                                                            const double* __restrict__ dpart, int nchunk, const float* __restrict__ gate,
+                                                            float* __restrict__ dsc_out, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            double* __restrict__ stat) {
+    __shared__ float sd[256];
+    __shared__ float part[8][32];
+    __shared__ float sh[32];
+    const int n = blockIdx.x, t = threadIdx.x;
+    double A1 = 0.0, A2 = 0.0, A3 = 0.0;
+    float gt = 0.f;
+    if (t < C) {
+        for (int k = 0; k < nchunk; ++k) {
+            const double* p = dpart + ((long)n * nchunk + k) * 3 * C + t;
+            A1 += p[0]; A2 += p[C]; A3 += p[2 * C];
+        }
+        float v = (float)((double)gamma[t] * A2 + (double)beta[t] * A1);      // sum_hw dpre * z
+        gt = gate[(long)n * C + t];
+        v = v * gt * (1.f - gt);
+        dsc_out[(long)n * C + t] = v;
+        sd[t] = v;
+    }
+    __syncthreads();
+    const int j = t & 31, g = t >> 5;
+    float acc = 0.f;
+    if (j < R) {
+        int c = g;
+        for (; c + 56 < C; c += 64) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = w2[(long)(c + 8 * u) * R + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += sd[c + 8 * u] * wv[u];
+        }
+        for (; c < C; c += 8) acc += sd[c] * w2[(long)c * R + j];
+    }
+    part[g][j] = acc;
+    __syncthreads();
+    if (t < R) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += part[q][t];
+        v = h1[(long)n * R + t] > 0.f ? v : 0.f;
+        dh1[(long)n * R + t] = v;
+        sh[t] = v;
+    }
+    __syncthreads();
+    if (t < C) {
+        float v = 0.f;
+        int q = 0;
+        for (; q + 7 < R; q += 8) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = w0[(long)(q + u) * C + t];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += sh[q + u] * wv[u];
+        }
+        for (; q < R; ++q) v += sh[q] * w0[(long)q * C + t];
+        const float dp = v * (1.f / (float)HW);
+        dpool[(long)n * C + t] = dp;
+        stat[(long)t * N + n] = (double)gt * A1 + (double)HW * (double)dp;
+        stat[((long)C + t) * N + n] = (double)gt * A2 + (double)dp * A3;
+    }
+}
+// dpre = dout * (out > 0); dres = dpre; dz = dpre * s[n,c] + dpool[n,c] (se_bwd_apply_kernel's expression, never stored);
+// dx = gamma invstd (dz - sum_dz / M - xhat sum_dz_xhat / M) (bn_bwd_apply_kernel's expression), as fp32 and / or piece planes
+template <int PL>
+__global__ void se_bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ outp, const float* __restrict__ x,
+                                       const float* __restrict__ s, const float* __restrict__ dpool, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ sum_dy,
+                                       const float* __restrict__ sum_dy_xhat, float* __restrict__ dres, float* __restrict__ dx, long N, int HW, int C,
+                                       unsigned short* __restrict__ dx_hi, unsigned short* __restrict__ dx_lo, int pnp) {
+    const int CV = C / 4;
+    const long per = (long)HW * CV, total = N * per;
+    const float invn = 1.f / (float)(N * HW);
+    const double dn = (double)invn;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / per; const int cv = (int)(i % CV);
+        const fvec<4> d = ldv(dout, i), o = ldv(outp, i), v = ldv(x, i);
+        const fvec<4> sc = ldp<4>(s + n * C, cv), dp = ldp<4>(dpool + n * C, cv);
+        const fvec<4> mu = ldp<4>(mean, cv), is = ldp<4>(invstd, cv), g = ldp<4>(gamma, cv), s1 = ldp<4>(sum_dy, cv), s2 = ldp<4>(sum_dy_xhat, cv);
+        fvec<4> p, r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            p.v[k] = o.v[k] > 0.f ? d.v[k] : 0.f;
+            const float q = p.v[k] * sc.v[k] + dp.v[k];
+            r.v[k] = (float)((double)g.v[k] * is.v[k] * ((double)q - s1.v[k] * dn - ((double)v.v[k] - mu.v[k]) * is.v[k] * (s2.v[k] * dn)));
+        }
+        stv(dres, i, p);
+        if (!PL || dx != nullptr) stv(dx, i, r);
+        if (PL) st_planes(dx_hi, dx_lo, pnp, i, r);
+    }
+}
+
 // Weight and bias gradients of the SE excitation MLP in ONE launch (round 6; ResNetBlocks.py:84-89 under autograd):
 //   dW2[c][j] += sum_n dsc[n][c] h1[n][j],  db2[c] += sum_n dsc[n][c]          (fc.2: Linear(R -> C), weight [C][R])
 //   dW0[j][c] += sum_n dh1[n][j] pooled[n][c],  db0[j] += sum_n dh1[n][j]      (fc.0: Linear(C -> R), weight [R][C])
@@ -886,6 +1042,49 @@ int ha2g_se_bwd_scale_mlp_f32(const float* dout, const float* out, const float* 
 int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, const float* dpool, float* dres, float* dx, int N,
                           int HW, int C, void* stream) {
     return se_bwd_apply_t<float>(dout, out, s, dpool, dres, dx, N, HW, C, stream);
+}
+
+// ---- SE backward + bn2 backward in two passes (round 6; see se_bn_reduce_kernel) ----
+// floats of workspace ha2g_se_bn_bwd_reduce_mlp_f32 needs
+long ha2g_se_bn_bwd_workspace_floats(int N, int HW, int C) { return (long)N * pool_chunks(N, HW) * 3 * C * 2; }
+// Reduction pass + excitation MLP backward.  x = bn2's INPUT (conv2's output) [N][HW][C], mean / invstd / gamma / beta = bn2's; gate = the SE gate [N][C];
+// writes ds [N][C] (the MLP's weight gradient reads it), dh1 [N][R], dpool [N][C] (already / HW) and stat [2][C][N] doubles: bn2's per-image backward sums.
+int ha2g_se_bn_bwd_reduce_mlp_f32(const float* dout, const float* out, const float* x, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, float* ds, int N, int HW, int C, const float* gate, float* ws, const float* h1, const float* w2,
+                                  const float* w0, float* dh1, float* dpool, int R, double* stat, void* stream) {
+    HA2G_REQUIRE(okCv<float>(C), "se_bn_bwd: unsupported channel count %d", C);
+    HA2G_REQUIRE(C >= 1 && C <= 256 && R >= 1 && R <= 32, "se_bn_bwd: unsupported widths C = %d, R = %d", C, R);
+    HA2G_REQUIRE(ws != nullptr && gate != nullptr && stat != nullptr && mean != nullptr && invstd != nullptr && gamma != nullptr && beta != nullptr,
+                 "se_bn_bwd: null workspace / gate / statistics / BatchNorm parameter");
+    if (N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = pool_chunks(N, HW);
+    hipLaunchKernelGGL(se_bn_reduce_kernel, dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, (double*)ws, mean, invstd);
+    hipLaunchKernelGGL(se_bn_mlp_bwd_kernel, dim3(N), dim3(256), 0, st, h1, w2, w0, dh1, dpool, C, R, HW, N, (const double*)ws, nchunk, gate, ds, gamma, beta, stat);
+    HA2G_CHECK_LAUNCH("se_bn_bwd_reduce_mlp");
+    return 0;
+}
+// Apply pass: dres = dout * (out > 0) (the residual branch's gradient) and bn2's data gradient dx (fp32, nullable when planes are given) and / or its
+// np piece planes (planes, piece stride ps elements; null: fp32 only); dgamma / dbeta [C] = bn2's parameter gradients (fresh sums; acc_*: also added there).
+int ha2g_se_bn_bwd_apply_np_f32(const float* dout, const float* out, const float* x, const float* s, const float* dpool, const float* mean,
+                                const float* invstd, const float* gamma, float* dres, float* dx, void* planes, long ps, int np, float* dgamma, float* dbeta,
+                                float* acc_dgamma, float* acc_dbeta, const double* stat, int N, int HW, int C, void* stream) {
+    HA2G_REQUIRE(okCv<float>(C), "se_bn_bwd: unsupported channel count %d", C);
+    HA2G_REQUIRE(planes == nullptr || np == 2 || np == 3, "se_bn_bwd_apply: np = %d", np);
+    HA2G_REQUIRE(planes != nullptr || dx != nullptr, "se_bn_bwd_apply: no output");
+    HA2G_REQUIRE(dres != nullptr && stat != nullptr && dgamma != nullptr && dbeta != nullptr, "se_bn_bwd_apply: null buffer");
+    if (N == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, stat, N, C, dbeta, dgamma, acc_dbeta, acc_dgamma);
+    const dim3 grid(flat_grid((long)N * HW * (C / 4)));
+    if (planes != nullptr)
+        hipLaunchKernelGGL(se_bn_bwd_apply_kernel<1>, grid, dim3(256), 0, st, dout, out, x, s, dpool, mean, invstd, gamma, (const float*)dbeta, (const float*)dgamma,
+                           dres, dx, (long)N, HW, C, (unsigned short*)planes, (unsigned short*)planes + ps, np);
+    else
+        hipLaunchKernelGGL(se_bn_bwd_apply_kernel<0>, grid, dim3(256), 0, st, dout, out, x, s, dpool, mean, invstd, gamma, (const float*)dbeta, (const float*)dgamma,
+                           dres, dx, (long)N, HW, C, (unsigned short*)nullptr, (unsigned short*)nullptr, 0);
+    HA2G_CHECK_LAUNCH("se_bn_bwd_apply");
+    return 0;
 }
 
 // dh1 [N][R], dpool [N][C] from dsc [N][C], h1 [N][R], fc.2.weight w2 [C][R], fc.0.weight w0 [R][C]; C <= 256, R <= 32

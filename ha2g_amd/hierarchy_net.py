@@ -99,13 +99,16 @@ class TemporalBlock(nn.Module):
         computed all of the network's weight norms in one launch."""
         d = self.dilation
         y = x
-        spec = None
+        spec = prev = None
         for ci, conv in enumerate((self.conv1, self.conv2)):
             w = ws[ci] if ws is not None else ops.weight_norm(conv.weight_g, conv.weight_v)
-            # the block's two dropouts ride on their neighbours (ops.DropSpec): conv1's is applied by a launch of its own, its backward shares one launch with
-            # conv1's ReLU'; conv2's is applied by the residual add + ReLU below
-            spec = ops.make_drop(self.p, self.training, x.device, deferred=ci == 1) if x.is_cuda else None
-            y = ops.conv1d_tm(y, w, conv.bias, dil=d, pad_left=d * (w.shape[2] - 1), To=x.shape[1], act=ACT_RELU, drop=spec)
+            # the block's two dropouts ride on their neighbours (ops.DropSpec): conv1's is applied by conv2's im2col (k = 2, C % 4 == 0; else by a launch of its
+            # own), its backward shares one launch with conv1's ReLU'; conv2's is applied by the residual add + ReLU below
+            defer = ci == 1 or ops.im2col_drop_ok(w.shape[0], self.conv2.weight_v.shape[2])
+            spec = ops.make_drop(self.p, self.training, x.device, deferred=defer) if x.is_cuda else None
+            y = ops.conv1d_tm(y, w, conv.bias, dil=d, pad_left=d * (w.shape[2] - 1), To=x.shape[1], act=ACT_RELU, drop=spec,
+                              in_drop=prev if (prev is not None and prev.deferred) else None)
+            prev = spec
             if spec is None:
                 y = ops.dropout(y, self.p, self.training)
         res = x if self.downsample is None else ops.conv1d_tm(x, self.downsample.weight, self.downsample.bias)
@@ -200,13 +203,15 @@ def grouped_text_encoders(encs, in_text, wn=None):
         blocks = [e.tcn.network[lvl] for e in encs]
         d, p = blocks[0].dilation, blocks[0].p
         y = x
-        spec = None
+        spec = prev = None
         for ci, name in enumerate(('conv1', 'conv2')):
             convs = [getattr(b, name) for b in blocks]
             ws = wn[lvl][ci]
-            spec = ops.make_drop(p, e0.training, x.device, deferred=ci == 1)       # see TemporalBlock.forward
+            defer = ci == 1 or ops.im2col_drop_ok(ws[0].shape[0], wn[lvl][1][0].shape[2])
+            spec = ops.make_drop(p, e0.training, x.device, deferred=defer)       # see TemporalBlock.forward
             y = ops.grouped_conv1d_tm(y.view(G, B, T, y.shape[2]), ws, [c.bias for c in convs], dil=d, pad_left=d * (ws[0].shape[2] - 1), To=T,
-                                      act=ACT_RELU, drop=spec).view(G * B, T, -1)
+                                      act=ACT_RELU, drop=spec, in_drop=prev if (prev is not None and prev.deferred) else None).view(G * B, T, -1)
+            prev = spec
             if spec is None:
                 y = ops.dropout(y, p, e0.training)
         x = ops.add_relu(y, x, drop=spec)

@@ -460,6 +460,7 @@ class DropSpec:
 
 
 FUSE_TCN_DROPOUT = True
+FUSE_IM2COL_DROPOUT = True      # a deferred DropSpec handed to the NEXT convolution (conv1d_tm / grouped_conv1d_tm in_drop=spec): its im2col applies the mask
 
 
 def make_drop(p, training, device, deferred=False):
@@ -468,6 +469,20 @@ def make_drop(p, training, device, deferred=False):
     if rng.state is None or rng.state.device != device:
         rng.seed(device, 0x5EED)
     return DropSpec(p, rng.next_id(), rng.step_token, deferred)
+
+
+def im2col_drop_ok(C, k):
+    """can the convolution that consumes dropout(y) (y [.., C], kernel k) apply the mask in its im2col?"""
+    return bool(FUSE_TCN_DROPOUT and FUSE_IM2COL_DROPOUT and lib.ha2g_im2col1d_drop_supported(C, k))
+
+
+def _im2col(x, col, B, T, C, k, dil, pad_left, To, in_drop):
+    if in_drop is None:
+        check(lib.ha2g_im2col1d_f32(x.data_ptr(), col.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
+    else:
+        if in_drop.token != rng.step_token:
+            raise RuntimeError('ha2g_amd dropout: a DropSpec of an earlier RNG step')
+        check(lib.ha2g_im2col1d_drop_f32(x.data_ptr(), col.data_ptr(), B, T, C, k, dil, pad_left, To, in_drop.p, rng.state.data_ptr(), in_drop.call, _stream()))
 
 
 def _drop_apply(y, spec):
@@ -826,14 +841,14 @@ class Conv1dFunction(torch.autograd.Function):
     out[b,t] = sum_kk W[:,:,kk] x[b, t - pad_left + kk*dil]."""
 
     @staticmethod
-    def forward(ctx, x, w, b, dil, pad_left, To, act, drop=None):
+    def forward(ctx, x, w, b, dil, pad_left, To, act, drop=None, in_drop=None):
         x = _f32c(x.contiguous())
         ctx.refs = (w, b)
         w = w.contiguous()
         B, T, C = x.shape
         cout, _, k = w.shape
         col = torch.empty(B * To, C * k, dtype=torch.float32, device=x.device)
-        check(lib.ha2g_im2col1d_f32(x.data_ptr(), col.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
+        _im2col(x, col, B, T, C, k, dil, pad_left, To, in_drop)      # in_drop: x is the UNMASKED output of the op in front, whose deferred dropout is applied here
         y = gemm(col, w.view(cout, C * k), transb=True, bias=b, act=act)
         _tap_act('conv1d', y.view(B, To, cout), act)
         ctx.geom = (B, T, C, k, dil, pad_left, To, act)
@@ -873,15 +888,18 @@ class Conv1dFunction(torch.autograd.Function):
             dx = torch.empty(B, T, C, dtype=torch.float32, device=dy.device)
             check(lib.ha2g_col2im1d_f32(dcol.data_ptr(), dx.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
         _join_or_defer(dy2.device, (dw is None or _single_use_nonleaf(ctx.refs[0])) and db is None, (dy2, col, dw), (tw, tb))
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv1d_tm(x, w, b, dil=1, pad_left=0, To=None, act=ACT_NONE, drop=None):
+def conv1d_tm(x, w, b, dil=1, pad_left=0, To=None, act=ACT_NONE, drop=None, in_drop=None):
+    """in_drop: the deferred DropSpec of the op that produced x -- this convolution's im2col applies the mask (the gradient handed back is the one w.r.t. the
+    masked value, as add_relu(.., drop=spec) does)"""
     if To is None:
         To = x.shape[1] + pad_left - (w.shape[2] - 1) * dil
     assert drop is None or act == ACT_RELU
+    assert in_drop is None or (in_drop.deferred and im2col_drop_ok(x.shape[2], w.shape[2]))
     _count_grad_use(w)
-    return Conv1dFunction.apply(x, w, b, dil, pad_left, To, act, drop)
+    return Conv1dFunction.apply(x, w, b, dil, pad_left, To, act, drop, in_drop)
 
 # ------------------------------------------------------------------------------------------------
 # grouped layers: the same layer of G networks (own weights) as one launch per GEMM (ha2g_gemm_grouped_f32)
@@ -952,11 +970,11 @@ class Im2col1dFunction(torch.autograd.Function):
     """x [B, T, C] -> columns [B*To, C*k] of a dilated causal 1-D convolution (the GEMM operand of Conv1dFunction); backward = col2im."""
 
     @staticmethod
-    def forward(ctx, x, k, dil, pad_left, To):
+    def forward(ctx, x, k, dil, pad_left, To, in_drop=None):
         x = _f32c(x.contiguous())
         B, T, C = x.shape
         col = torch.empty(B * To, C * k, dtype=torch.float32, device=x.device)
-        check(lib.ha2g_im2col1d_f32(x.data_ptr(), col.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
+        _im2col(x, col, B, T, C, k, dil, pad_left, To, in_drop)
         ctx.geom = (B, T, C, k, dil, pad_left, To)
         return col
 
@@ -966,16 +984,17 @@ class Im2col1dFunction(torch.autograd.Function):
         dcol = dcol.contiguous()
         dx = torch.empty(B, T, C, dtype=torch.float32, device=dcol.device)
         check(lib.ha2g_col2im1d_f32(dcol.data_ptr(), dx.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
-def grouped_conv1d_tm(x, ws, bs, dil=1, pad_left=0, To=None, act=ACT_NONE, drop=None):
+def grouped_conv1d_tm(x, ws, bs, dil=1, pad_left=0, To=None, act=ACT_NONE, drop=None, in_drop=None):
     """x [G, B, T, C] (the inputs of G same-shape convolutions), ws: G weights [Cout, C, k], bs: G biases -> [G, B, To, Cout]."""
     G, B, T, C = x.shape
     cout, _, k = ws[0].shape
     if To is None:
         To = T + pad_left - (k - 1) * dil
-    col = Im2col1dFunction.apply(x.reshape(G * B, T, C), k, dil, pad_left, To)
+    assert in_drop is None or (in_drop.deferred and im2col_drop_ok(C, k))
+    col = Im2col1dFunction.apply(x.reshape(G * B, T, C), k, dil, pad_left, To, in_drop)
     y = grouped_linear(col.view(G, B * To, C * k), [w.reshape(cout, C * k) for w in ws], bs, act, drop)
     return y.view(G, B, To, cout)
 

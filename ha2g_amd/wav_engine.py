@@ -321,6 +321,7 @@ _WILL_BWD = [True]
 JOIN_DGRAD = 0             # round-6 experiment: 1 = the main stream waits for the side queue after every data gradient of the tower's backward (the
                            # BatchNorm / SE passes then run with no weight gradient beside them); 0 = one join at the end
 SE_BWD_FOLD = True         # the SE backward's reduction finishes inside the excitation MLP's backward launch (round 6: -16 launches, same bits)
+SE_BN2_FUSED = True    # SE backward + bn2 backward in two passes, bn2's dy never stored (ha2g_se_bn_bwd_*; A/B switch)
 SE_WGRAD_FUSED = True      # the SE excitation MLP's four parameter gradients in one launch (GradSink.gse)
 
 
@@ -533,6 +534,26 @@ class GradSink:
             ops.side.join(device)
             self.forked = False
 
+    def gbn_se(self, name, dout, out, x, sc, dpool, mean, invstd, dres, stat, planes=False, need_dx=True):
+        """bn2's backward fused with the SE apply pass (ha2g_se_bn_bwd_apply_np_f32): dres <- dout * (out > 0); -> (dx fp32 NHWC or None, piece planes or
+        None) of bn2's data gradient; gamma / beta gradients go where gbn() puts them.  stat = the per-image sums ha2g_se_bn_bwd_reduce_mlp_f32 left."""
+        bn = self.P[name]
+        N, OH, OW, C = x.shape
+        tg_, tb_ = self.tgt(bn.gamma), self.tgt(bn.beta)
+        acc = (tg_, tb_) if (tg_ is not None and tb_ is not None) else None
+        need_dx = need_dx or not planes
+        dxo = torch.empty_like(x) if need_dx else None
+        pl = torch.empty(ops.pieces(), N * OH * OW, C, dtype=torch.bfloat16, device=x.device) if planes else None
+        dgamma, dbeta = empty(C, like=x), empty(C, like=x)
+        nb_ = 4.0 * x.numel() * (4 + (1 if need_dx else 0)) + (2.0 * pl.shape[0] * x.numel() if planes else 0.0)
+        ops.ktimer.launch('se_bn_bwd_apply', lambda: check(lib.ha2g_se_bn_bwd_apply_np_f32(
+            dout.data_ptr(), out.data_ptr(), x.data_ptr(), sc.data_ptr(), dpool.data_ptr(), mean.data_ptr(), invstd.data_ptr(), bn.gamma.data_ptr(),
+            dres.data_ptr(), _p(dxo), _p(pl), pl.stride(0) if planes else 0, pl.shape[0] if planes else 0, dgamma.data_ptr(), dbeta.data_ptr(),
+            _p(acc[0] if acc else None), _p(acc[1] if acc else None), stat.data_ptr(), N, OH * OW, C, _stream())), nb_)
+        if acc is None:
+            self.G[name] = (dgamma, dbeta)
+        return dxo, pl
+
     def gbn(self, name, dy2, x2, mean, invstd, relu_mask=False, planes=False, need_dx=True, partials=None):
         """planes=True: -> (dx fp32 or None (need_dx=False: every consumer reads the planes), (hi, lo) bf16 planes of dx).
         partials = (stat_part, nblk): the statistics pass already happened in dy's producer (conv_dgrad_planes(..., bnstats=...))"""
@@ -652,7 +673,27 @@ def block_bwd(dx, saved, P, b, sink):
     dout = dx.contiguous()
     ds = empty(N, C, like=c2)
     w2_, w0_ = P[b + 'se.fc.2.weight'], P[b + 'se.fc.0.weight']
-    if SE_BWD_FOLD and SE_MLP_FUSED and w2_.is_contiguous() and w0_.is_contiguous() and lib.ha2g_se_mlp_bwd_supported(C, h1.shape[1]):
+    wb = _ohwi(P[b + 'conv2.weight'])
+    wa = _ohwi(P[b + 'conv1.weight'])
+    p2, p1 = dgrad_planes_ok(wb, 1, 1), dgrad_planes_ok(wa, stride, 1)
+    f2 = not (p2 and wgrad_planes_ok(a1, wb, 1, 1))                           # someone still reads the fp32 tensor
+    f1 = not (p1 and wgrad_planes_ok(x, wa, stride, 1))
+    fused_tail = (SE_BN2_FUSED and SE_MLP_FUSED and c2.dtype == torch.float32 and c2.is_contiguous() and w2_.is_contiguous() and w0_.is_contiguous()
+                  and lib.ha2g_se_mlp_bwd_supported(C, h1.shape[1]))
+    if fused_tail:
+        # SE backward + bn2 backward in two passes over (dout, out, c2): bn2's dy is never stored, its statistics come from the SE reduction's per-image sums
+        bn2 = P[b + 'bn2']
+        ws = ops.workspace(dout.device)
+        assert lib.ha2g_se_bn_bwd_workspace_floats(N, HW, C) <= ws.numel()
+        dh1, dpool = torch.empty_like(h1), torch.empty_like(ds)
+        stat = torch.empty(2 * C * N, dtype=torch.float64, device=dout.device)
+        check(lib.ha2g_se_bn_bwd_reduce_mlp_f32(dout.data_ptr(), out.data_ptr(), c2.data_ptr(), m2.data_ptr(), s2.data_ptr(), bn2.gamma.data_ptr(),
+                                                bn2.beta.data_ptr(), ds.data_ptr(), N, HW, C, sc.data_ptr(), ws.data_ptr(), h1.data_ptr(), w2_.data_ptr(),
+                                                w0_.data_ptr(), dh1.data_ptr(), dpool.data_ptr(), h1.shape[1], stat.data_ptr(), _stream()))
+        sink.gse(b, ds, h1, dh1, pooled)
+        dres = torch.empty_like(c2)
+        dc2, dc2p = sink.gbn_se(b + 'bn2', dout, out, c2, sc, dpool, m2, s2, dres, stat, planes=p2, need_dx=f2)
+    elif SE_BWD_FOLD and SE_MLP_FUSED and w2_.is_contiguous() and w0_.is_contiguous() and lib.ha2g_se_mlp_bwd_supported(C, h1.shape[1]):
         # reduction pass + (its final pass inside) the excitation MLP's backward: two launches instead of three, the same bits
         dh1, dpool = torch.empty_like(h1), torch.empty_like(ds)
         bn2 = P[b + 'bn2'] if b2 is None else None
@@ -673,19 +714,15 @@ def block_bwd(dx, saved, P, b, sink):
                                             ops.workspace(dout.device).data_ptr(), _stream()))
         dsc = ds                                            # already times the gate's sigmoid' (folded into the reduction's final pass)
         dh1, dpool = se_mlp_bwd(dsc, h1, w2_, w0_, HW)
-    sink.gse(b, dsc, h1, dh1, pooled)
-    dres, db2 = torch.empty_like(c2), torch.empty_like(c2)
-    check(lib.ha2g_se_bwd_apply_f32(dout.data_ptr(), out.data_ptr(), sc.data_ptr(), dpool.data_ptr(), dres.data_ptr(),
-                                    db2.data_ptr(), N, HW, C, _stream()))
-    wb = _ohwi(P[b + 'conv2.weight'])
-    wa = _ohwi(P[b + 'conv1.weight'])
-    # the BatchNorm-backward apply pass is the PRODUCER of the convolutions' dy: where the plane-based data gradient serves the geometry it
-    # also writes dy as bf16 hi / lo planes (same values the consumer tiles used to split out of the fp32 tensor, once instead of per tile)
-    p2, p1 = dgrad_planes_ok(wb, 1, 1), dgrad_planes_ok(wa, stride, 1)
-    f2 = not (p2 and wgrad_planes_ok(a1, wb, 1, 1))                           # someone still reads the fp32 tensor
-    f1 = not (p1 and wgrad_planes_ok(x, wa, stride, 1))
-    dc2 = sink.gbn(b + 'bn2', _rows(db2), _rows(c2), m2, s2, planes=p2, need_dx=f2)
-    dc2, dc2p = ((dc2[0].view(c2.shape) if f2 else None), dc2[1]) if p2 else (dc2.view(c2.shape), None)
+    if not fused_tail:
+        sink.gse(b, dsc, h1, dh1, pooled)
+        dres, db2 = torch.empty_like(c2), torch.empty_like(c2)
+        check(lib.ha2g_se_bwd_apply_f32(dout.data_ptr(), out.data_ptr(), sc.data_ptr(), dpool.data_ptr(), dres.data_ptr(),
+                                        db2.data_ptr(), N, HW, C, _stream()))
+        # the BatchNorm-backward apply pass is the PRODUCER of the convolutions' dy: where the plane-based data gradient serves the geometry it
+        # also writes dy as bf16 hi / lo planes (same values the consumer tiles used to split out of the fp32 tensor, once instead of per tile)
+        dc2 = sink.gbn(b + 'bn2', _rows(db2), _rows(c2), m2, s2, planes=p2, need_dx=f2)
+        dc2, dc2p = ((dc2[0].view(c2.shape) if f2 else None), dc2[1]) if p2 else (dc2.view(c2.shape), None)
     # WGRAD_AFTER: the side stream's weight gradient is forked AFTER the data gradient of the same convolution has been enqueued, so that it
     # runs beside the bandwidth-bound BatchNorm-backward passes that follow instead of beside the (L2 -> LDS bound) data gradient
     if not WGRAD_AFTER:

@@ -24,7 +24,7 @@ extern "C" {
 
 /* Bumped whenever an exported signature changes or entry points are added that a host must not mix with an older library:
  * ha2g_amd/_lib.py refuses to bind a library whose ha2g_abi_version() differs from this macro. */
-#define HA2G_ABI_VERSION 5
+#define HA2G_ABI_VERSION 6
 int ha2g_abi_version(void);
 const char* ha2g_last_error(void);
 
@@ -386,6 +386,20 @@ int ha2g_se_bwd_scale_mlp_f32(const float* dout, const float* out, const float* 
                               const float* w0, float* dh1, float* dpool, int R, void* stream);
 int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, const float* dpool, float* dres,
                           float* dx, int N, int HW, int C, void* stream);
+/* ABI 6: the SE backward and bn2's backward of a block (model/ResNetBlocks.py:30-37 under autograd) without the gradient tensor between them.  With
+ * dpre = dout * (out > 0), bn2's dy is dz = dpre * s[n,c] + dpool[n,c]; its column sums follow from per-image sums the SE reduction pass takes anyway
+ * (sum dpre, sum dpre * xhat, sum xhat), so ha2g_se_bwd_apply_f32's write of dz and ha2g_bn_bwd*'s statistics pass over (dz, x) are not run.
+ * reduce_mlp: x = bn2's INPUT [N][HW][C], mean / invstd / gamma / beta = bn2's, gate = the SE gate [N][C], ws >= ha2g_se_bn_bwd_workspace_floats floats;
+ *   writes ds [N][C], dh1 [N][R], dpool [N][C] (already / HW) as ha2g_se_bwd_scale_mlp_f32 does, and stat [2][C][N] doubles (bn2's per-image sums).
+ * apply: dres = dpre; bn2's data gradient as fp32 (dx, nullable when planes != NULL) and / or np (2 | 3) bf16 piece planes (piece stride ps elements);
+ *   dgamma / dbeta [C] = bn2's parameter gradients, also ADDED to acc_dgamma / acc_dbeta when those are not NULL. */
+long ha2g_se_bn_bwd_workspace_floats(int N, int HW, int C);
+int ha2g_se_bn_bwd_reduce_mlp_f32(const float* dout, const float* out, const float* x, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, float* ds, int N, int HW, int C, const float* gate, float* ws, const float* h1, const float* w2,
+                                  const float* w0, float* dh1, float* dpool, int R, double* stat, void* stream);
+int ha2g_se_bn_bwd_apply_np_f32(const float* dout, const float* out, const float* x, const float* s, const float* dpool, const float* mean,
+                                const float* invstd, const float* gamma, float* dres, float* dx, void* planes, long ps, int np, float* dgamma, float* dbeta,
+                                float* acc_dgamma, float* acc_dbeta, const double* stat, int N, int HW, int C, void* stream);
 /* speaker-softmax blending of the three audio taps (model/ResNetSE34V2.py:202-212) */
 int ha2g_blend_fwd_f32(const float* logits, const float* f0, const float* f1, const float* f2, float* w, float* blend,
                        int B, int L, int TF, void* stream);
@@ -426,6 +440,11 @@ int ha2g_dropout_fused_f32(const float* x, const float* b, float* out, long n, f
 /* out = x * mask over elements [elem_offset, elem_offset + n) of the tensor the mask of (state, stream_id) is defined on (ABI 5): the backward of the GRU's
  * inter-layer dropout (nn.GRU(dropout=...), model/hierarchy_net.py:87) when only a row slice carries gradient; elem_offset % 4 == 0 */
 int ha2g_dropout_slice_f32(const float* x, float* out, long n, long elem_offset, float p, const void* state, unsigned stream_id, void* stream);
+/* ABI 6: ha2g_im2col1d_f32 of dropout(x) without the dropped tensor (model/tcn.py:21-31: conv1 -> ReLU -> dropout -> conv2's columns): the mask
+ * ha2g_dropout_f32 draws for (state, stream_id) over x [B][T][C] is re-drawn for both taps.  k = 2 and C % 4 == 0 only (ha2g_im2col1d_drop_supported). */
+int ha2g_im2col1d_drop_supported(int C, int k);
+int ha2g_im2col1d_drop_f32(const float* x, float* col, int B, int T, int C, int k, int dil, int pad_left, int To, float p, const void* state,
+                           unsigned stream_id, void* stream);
 int ha2g_rng_advance(void* state, void* stream);
 
 /* ---- generator input pack + hierarchy scatter (train_eval/train_hierarchy.py:153-169, expressive :163-212;

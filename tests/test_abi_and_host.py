@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
                   if f.endswith('.hip'))
     exported = set(re.findall(r'\b(ha2g_[a-z0-9_]+)\s*\(', src)) - {'ha2g_set_error'}
     assert exported <= set(protos) | {'ha2g_last_error'}, exported - set(protos)
-    assert _lib.lib.ha2g_abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.lib.ha2g_abi_version() == _lib.ABI_VERSION == 6
     assert _lib.lib.ha2g_gru_supported_hidden(300) == 1 and _lib.lib.ha2g_gru_supported_hidden(123) == 0
     assert _lib.lib.ha2g_gru_packed_floats(300) == 19 * 3 * 19 * 256
 

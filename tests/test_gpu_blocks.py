@@ -341,6 +341,7 @@ def test_se_backward_reduction_finished_inside_the_mlp_launch_changes_no_bit(nam
     xp = ops.to_planes(xin, 3) if 'conv1.weight' in wpl else None
     res = {}
     try:
+        we.SE_BN2_FUSED = False                           # the two-pass tail (below) replaces both forms
         for on in (True, False):
             we.SE_BWD_FOLD = on
             we._TRAINING[0] = True
@@ -357,5 +358,50 @@ def test_se_backward_reduction_finished_inside_the_mlp_launch_changes_no_bit(nam
             res[on] = dict(dx=dx.clone(), **g)
     finally:
         we.SE_BWD_FOLD = True
+        we.SE_BN2_FUSED = True
     for k in res[True]:
         assert torch.equal(res[True][k], res[False][k]), (name, k)
+
+
+@pytest.mark.parametrize('name', ['l1', 'l2', 'l3d', 'l4'])
+def test_se_and_bn2_backward_in_two_passes_match_the_four_pass_form(name):
+    """Round 6: bn2's dy = dout * relu' * s + dpool is never stored (wav_engine.SE_BN2_FUSED): its column sums come from the per-image sums of the SE
+    reduction pass (ha2g_se_bn_bwd_reduce_mlp_f32), the apply pass forms it on the fly (ha2g_se_bn_bwd_apply_np_f32).  Same mathematics, other summation
+    order (double sums throughout): every output of the block's backward agrees with the four-pass form to a few float ulps of its largest element.
+    (Both forms are held to the float64 oracle at 1e-4 by test_block_backward_* above.)"""
+    from ha2g_amd import ops, wav_engine as we
+    geom = BLOCKFULL_CASES[name]
+    P = engine_P(block_state(name, geom, 43), DEV)
+    x, wl = block_io(name, geom, BLOCKFULL_B, 43)
+    xin, dout = nhwc(x.to(DEV)), nhwc(wl.to(DEV))
+    wpl = {}
+    for n, stride, pad in (('conv1.weight', 2 if geom[4] else 1, 1), ('conv2.weight', 1, 1), ('downsample.0.weight', 2, 0)):
+        if n in P and we.fwd_planes_ok(we._ohwi(P[n]), stride, pad):
+            wpl[n] = ops.to_planes(we._ohwi(P[n]).contiguous(), 3)
+    xp = ops.to_planes(xin, 3) if 'conv1.weight' in wpl else None
+    res = {}
+    try:
+        for on in (True, False):
+            we.SE_BN2_FUSED = on
+            we._TRAINING[0] = True
+            we._NBT_PENDING.clear()
+            Pc = {k: (v.clone() if torch.is_tensor(v) else we._BN(v.gamma, v.beta, v.rm.clone(), v.rv.clone(), None)) for k, v in P.items()}
+            out, saved, _ = we.block_fwd(xin, Pc, '', geom[4], xp=xp, wpl=wpl)
+            sink = we.GradSink(Pc)
+            dx = we.block_bwd(dout, saved, Pc, '', sink)
+            sink.join(torch.device(DEV))
+            g = {}
+            for k, gr in sink.G.items():
+                for j, t in enumerate(gr if isinstance(gr, tuple) else (gr,)):
+                    g['%s/%d' % (k, j)] = t.clone()
+            res[on] = dict(dx=dx.clone(), **g)
+    finally:
+        we.SE_BN2_FUSED = True
+    assert set(res[True]) == set(res[False])
+    worst = 0.0
+    for k in res[True]:
+        a, b_ = res[True][k].double(), res[False][k].double()
+        err, ref = float((a - b_).abs().max()), float(b_.abs().max())
+        worst = max(worst, err / (ref + 1e-30))
+        assert err <= 2e-5 * ref + 1e-12, (name, k, err, ref)
+    print('two-pass SE + bn2 backward vs four-pass, %s: worst max|d| / max|ref| = %.2e' % (name, worst))

@@ -472,22 +472,26 @@ def test_tcn_block_dropouts_fused_with_their_neighbours_change_no_bit(grouped):
             g = torch.autograd.grad((y * y).sum(), params, allow_unused=True)
             return [y.detach()] + [t.detach() for t in g if t is not None]
     outs = {}
-    for fuse in (True, False):
-        old = ops.FUSE_TCN_DROPOUT
-        ops.FUSE_TCN_DROPOUT = fuse
+    # (neighbour fusion, conv1's dropout applied by conv2's im2col -- ha2g_im2col1d_drop_f32, the second half of round 6)
+    for fuse in ((True, True), (True, False), (False, False)):
+        old = ops.FUSE_TCN_DROPOUT, ops.FUSE_IM2COL_DROPOUT
+        ops.FUSE_TCN_DROPOUT, ops.FUSE_IM2COL_DROPOUT = fuse
         try:
             ops.rng.seed(dev, 77)
             ops.rng.begin_step()
             outs[fuse] = run()
             torch.cuda.synchronize()
         finally:
-            ops.FUSE_TCN_DROPOUT = old
-    assert len(outs[True]) == len(outs[False]) > 5
-    assert float(outs[True][0].abs().max()) > 0
+            ops.FUSE_TCN_DROPOUT, ops.FUSE_IM2COL_DROPOUT = old
+    ref = outs[(False, False)]
+    assert len(ref) > 5
+    assert float(ref[0].abs().max()) > 0
     if not grouped:
-        assert float((outs[True][0] == 0).float().mean()) > 0.2                                        # the block's output: ReLU really zeroes things
-    for a, b in zip(outs[True], outs[False]):
-        assert torch.equal(a, b)
+        assert float((ref[0] == 0).float().mean()) > 0.2                                        # the block's output: ReLU really zeroes things
+    for fuse in ((True, True), (True, False)):
+        assert len(outs[fuse]) == len(ref)
+        for a, b in zip(outs[fuse], ref):
+            assert torch.equal(a, b), fuse
 
 
 @pytest.mark.gpu
@@ -552,3 +556,21 @@ def test_gru_stack_weight_operands_split_in_one_launch_change_no_bit():
     assert ops.gru_cluster_error(dev) == 0
     for a, b in zip(outs[True], outs[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('rows,cols,ld', [(300000, 16, 16), (123457, 32, 32), (70001, 64, 64), (9000, 64, 80), (5000, 300, 300), (4096, 256, 256), (700, 64, 64), (4099, 1024, 1024)])
+def test_column_sums_narrow_and_wide_forms_against_float64(rows, cols, ld):
+    """ha2g_colsum_f32 (bias gradients; model/ResNetSE34V2.py:157-185's tap convolutions have 16 / 32 / 64 output channels): the 16-byte-load form for narrow
+    contiguous matrices (round 6) and the 64-lane form, both against a float64 sum at 1e-6 of sum |x|; beta accumulates; repeated calls are bit-identical."""
+    from ha2g_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    buf = (torch.randn(rows, ld, generator=g) + 0.3).to(DEV)
+    x = buf[:, :cols]
+    ref = x.double().sum(0)
+    scale = x.double().abs().sum(0)
+    got = ops.colsum(x)
+    assert float(((got.double() - ref).abs() / scale).max()) < 1e-6
+    assert torch.equal(got, ops.colsum(x))
+    acc = torch.full((cols,), 2.0, device=DEV)
+    ops.colsum(x, out=acc, beta=0.5)
+    assert float(((acc.double() - (ref + 1.0)).abs() / (scale + 1.0)).max()) < 1e-6
