@@ -146,6 +146,50 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const T* __restrict__ 
     block_col_reduce<V>(a, b, CV, part, C, lds);
 }
 
+// Per-IMAGE column sums (x, x^2) of x [N][HW][C] (round 6): grid (nchunk, N), block (k, n) = rows [k per, (k + 1) per) of image n -> part [2][C][N nchunk]
+// doubles, block index n nchunk + k: the layout (and the "tiles inside one image" property) of a convolution epilogue's statistics, so that
+// bn_stats_final_kernel (x == null: unshifted sums) AND the SE squeeze (se_mlp_fwd_kernel) read them -- layer 1's 32-channel convolutions have no
+// statistics epilogue, and its bn2 output was written by one pass and re-read by the next only to be pooled and scaled.  Unshifted squares in double: the
+// variance loses log2(mean^2 / var) of 53 bits.
+__global__ __launch_bounds__(256) void bn_image_partial_kernel(const float* __restrict__ x, int HW, int C, double* __restrict__ part) {
+    __shared__ dvec<4> lds[512];
+    const int CV = C / 4;
+    ColMap m(CV);
+    const int nchunk = gridDim.x, per = (HW + nchunk - 1) / nchunk;
+    const int rbeg = blockIdx.x * per, rend = min(HW, rbeg + per);
+    const float* xb = x + (long)blockIdx.y * HW * C;
+    dvec<4> a = dzero<4>(), b = dzero<4>();
+    auto accum = [&](const fvec<4>& v) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const double vx = (double)v.v[k]; a.v[k] += vx; b.v[k] += vx * vx; }
+    };
+    int r = rbeg + m.r0;
+    for (; r + 3 * m.rstep < rend; r += 4 * m.rstep) {
+        fvec<4> v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ldv(xb + (long)(r + j * m.rstep) * C, m.cv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accum(v[j]);
+    }
+    for (; r < rend; r += m.rstep) accum(ldv(xb + (long)r * C, m.cv));
+    lds[threadIdx.x] = a;
+    lds[256 + threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x < CV) {
+        dvec<4> sa = dzero<4>(), sb = dzero<4>();
+        for (int t = threadIdx.x; t < 256; t += CV) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sa.v[k] += lds[t].v[k]; sb.v[k] += lds[256 + t].v[k]; }
+        }
+        const long nb = (long)gridDim.x * gridDim.y, blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            part[((long)(threadIdx.x * 4 + k)) * nb + blk] = sa.v[k];
+            part[((long)C + threadIdx.x * 4 + k) * nb + blk] = sb.v[k];
+        }
+    }
+}
+
 // final reductions: one wave per column; lanes stride the block partials, fixed-order shuffle tree (deterministic)
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -1044,6 +1088,17 @@ int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, c
     return se_bwd_apply_t<float>(dout, out, s, dpool, dres, dx, N, HW, C, stream);
 }
 
+// per-image statistics partials of x [N][HW][C] for ha2g_bn_stats_finalize_f32 + ha2g_se_mlp_fwd_f32 (see bn_image_partial_kernel): part [2][C][nblk] doubles
+// with nblk = N * ha2g_bn_image_partial_chunks(N, HW)
+int ha2g_bn_image_partial_chunks(int N, int HW) { return pool_chunks(N, HW); }
+int ha2g_bn_image_partials_f32(const float* x, int N, int HW, int C, double* part, void* stream) {
+    HA2G_REQUIRE(okCv<float>(C), "bn_image_partials: unsupported channel count %d", C);
+    HA2G_REQUIRE(part != nullptr && x != nullptr && N >= 0 && HW > 0, "bn_image_partials: null buffer / empty image");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(bn_image_partial_kernel, dim3(pool_chunks(N, HW), N), dim3(256), 0, (hipStream_t)stream, x, HW, C, part);
+    HA2G_CHECK_LAUNCH("bn_image_partials");
+    return 0;
+}
 // ---- SE backward + bn2 backward in two passes (round 6; see se_bn_reduce_kernel) ----
 // floats of workspace ha2g_se_bn_bwd_reduce_mlp_f32 needs
 long ha2g_se_bn_bwd_workspace_floats(int N, int HW, int C) { return (long)N * pool_chunks(N, HW) * 3 * C * 2; }

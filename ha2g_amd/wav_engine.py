@@ -63,6 +63,7 @@ def fwd_planes_ok(w_ohwi, stride, pad):
     return FWD3 and lib.ha2g_gemm_bwd_pieces() == 3 and bool(lib.ha2g_conv2d_fwd_planes_supported(Cin, Cout, KH, KW, stride, pad))
 
 
+IMAGE_STATS = True        # layer 1 (no statistics epilogue): bn2's statistics and the SE squeeze from ONE per-image column pass over conv2's output (round 6)
 SE_FROM_STATS = True      # ... and, where the epilogue's tiles lie inside one image, the SE squeeze too: bn2's output is never materialised (block_fwd)
 def _tiles_per_image(xshape, w_ohwi):
     """> 0: conv2's statistics blocks are tiles inside one image, that many per image (asked per call: host arithmetic, and the answer follows the
@@ -610,7 +611,15 @@ def block_fwd(x, P, b, first, xp=None, out_planes=0, wpl=None):
     R = w0.shape[0]
     mlp1 = SE_MLP_FUSED and w0.is_contiguous() and w2.is_contiguous() and bool(lib.ha2g_se_mlp_bwd_supported(C, R))      # the excitation MLP in one launch
     h1 = sc = None
-    if st2 is not None and SE_FROM_STATS and _tiles_per_image(a1.shape, wb) > 0:
+    img_parts = False
+    if (st2 is None and IMAGE_STATS and SE_FROM_STATS and _TRAINING[0] and mlp1 and c2.dtype == torch.float32 and c2.is_contiguous() and c2.is_cuda
+            and C % 4 == 0 and 256 % (C // 4) == 0):
+        # no statistics epilogue (layer 1's 32-channel convolutions): one per-image column pass over c2 serves bn2's statistics AND the SE squeeze
+        nblk = N * int(lib.ha2g_bn_image_partial_chunks(N, OH * OW))
+        part = torch.empty(2 * C * nblk, dtype=torch.float64, device=c2.device)
+        check(lib.ha2g_bn_image_partials_f32(c2.data_ptr(), N, OH * OW, C, part.data_ptr(), _stream()))
+        st2, img_parts = (part, nblk), True
+    if st2 is not None and SE_FROM_STATS and (img_parts or _tiles_per_image(a1.shape, wb) > 0):
         # conv2's epilogue left per-tile column sums of c2 behind, tiles inside one image: bn2's statistics AND the SE squeeze come from them
         # (the mean of an affine map is the affine map of the mean), the tail below applies bn2 on the fly -- b2 is never written or re-read
         m2, s2 = ops.bn_stats_finalize(st2[0], st2[1], N * OH * OW, C, bn2.rm, bn2.rv, 0.1, 1e-5)

@@ -393,6 +393,11 @@ int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, c
  *   writes ds [N][C], dh1 [N][R], dpool [N][C] (already / HW) as ha2g_se_bwd_scale_mlp_f32 does, and stat [2][C][N] doubles (bn2's per-image sums).
  * apply: dres = dpre; bn2's data gradient as fp32 (dx, nullable when planes != NULL) and / or np (2 | 3) bf16 piece planes (piece stride ps elements);
  *   dgamma / dbeta [C] = bn2's parameter gradients, also ADDED to acc_dgamma / acc_dbeta when those are not NULL. */
+/* ABI 6: per-IMAGE statistics partials of x [N][HW][C] (sum x, sum x^2; doubles [2][C][nblk], nblk = N * ha2g_bn_image_partial_chunks(N, HW), the blocks of
+ * an image consecutive): what a plane convolution's statistics epilogue leaves behind, for a tensor whose producer has none (layer 1's 32-channel
+ * convolutions) -- ha2g_bn_stats_finalize_f32 and ha2g_se_mlp_fwd_f32 (the SE squeeze) read them, bn2's output is then never materialised. */
+int ha2g_bn_image_partial_chunks(int N, int HW);
+int ha2g_bn_image_partials_f32(const float* x, int N, int HW, int C, double* part, void* stream);
 long ha2g_se_bn_bwd_workspace_floats(int N, int HW, int C);
 int ha2g_se_bn_bwd_reduce_mlp_f32(const float* dout, const float* out, const float* x, const float* mean, const float* invstd, const float* gamma,
                                   const float* beta, float* ds, int N, int HW, int C, const float* gate, float* ws, const float* h1, const float* w2,

@@ -405,3 +405,41 @@ def test_se_and_bn2_backward_in_two_passes_match_the_four_pass_form(name):
         worst = max(worst, err / (ref + 1e-30))
         assert err <= 2e-5 * ref + 1e-12, (name, k, err, ref)
     print('two-pass SE + bn2 backward vs four-pass, %s: worst max|d| / max|ref| = %.2e' % (name, worst))
+
+
+@pytest.mark.parametrize('name', ['l1', 'l2'])
+def test_bn2_statistics_and_se_squeeze_from_one_per_image_pass(name):
+    """Round 6: where conv2 has no statistics epilogue (layer 1's 32-channel kernels; 'l2' here with the forward planes off), ONE per-image column pass
+    over conv2's output (ha2g_bn_image_partials_f32) serves bn2's batch statistics and the SE squeeze, and the block's tail applies bn2 on the fly --
+    bn2's output is never written (wav_engine.IMAGE_STATS).  Against the form that materialises it: statistics, running statistics, gate, output and the
+    whole backward agree to float rounding."""
+    from ha2g_amd import ops, wav_engine as we
+    geom = BLOCKFULL_CASES[name]
+    P = engine_P(block_state(name, geom, 47), DEV)
+    x, wl = block_io(name, geom, BLOCKFULL_B, 47)
+    xin, dout = nhwc(x.to(DEV)), nhwc(wl.to(DEV))
+    res = {}
+    try:
+        for on in (True, False):
+            we.IMAGE_STATS = on
+            we._TRAINING[0] = True
+            we._NBT_PENDING.clear()
+            Pc = {k: (v.clone() if torch.is_tensor(v) else we._BN(v.gamma, v.beta, v.rm.clone(), v.rv.clone(), None)) for k, v in P.items()}
+            out, saved, _ = we.block_fwd(xin, Pc, '', geom[4])
+            assert (saved[8] is None) == on                      # bn2's output exists only in the materialising form
+            sink = we.GradSink(Pc)
+            dx = we.block_bwd(dout, saved, Pc, '', sink)
+            sink.join(torch.device(DEV))
+            g = {}
+            for k, gr in sink.G.items():
+                for j, t in enumerate(gr if isinstance(gr, tuple) else (gr,)):
+                    g['%s/%d' % (k, j)] = t.clone()
+            res[on] = dict(out=out.clone(), m2=saved[6].clone(), s2=saved[7].clone(), pooled=saved[9].clone(), gate=saved[11].clone(),
+                           rm=Pc['bn2'].rm.clone(), rv=Pc['bn2'].rv.clone(), dx=dx.clone(), **g)
+    finally:
+        we.IMAGE_STATS = True
+    assert set(res[True]) == set(res[False])
+    for k in res[True]:
+        a, b_ = res[True][k].double(), res[False][k].double()
+        err, ref = float((a - b_).abs().max()), float(b_.abs().max())
+        assert err <= 2e-5 * ref + 1e-12, (name, k, err, ref)
