@@ -501,6 +501,8 @@ def _drop_relu_bwd(dy, y, spec):
     return out
 
 
+DX_FIRST = False          # the same order in the TCN convolutions' and the grouped layers' backward: measured, no gain (34.16 vs 34.12 ms), off
+GRU_DX_FIRST = True       # BiGRU backward: a layer's dX product is enqueued before its weight-gradient products fork to the side queue (A/B switch)
 GRU_MASK_SPEC = True      # the GRU's inter-layer dropouts as specs (mask re-drawn where it is applied: one launch forward, one backward, no mask tensor)
 
 
@@ -575,6 +577,8 @@ class LinearFunction(torch.autograd.Function):
         dx = dw = db = None
         big = dy2.shape[0] >= 1024                       # tiny layers: the fork/join costs more than it hides
         tgt = None
+        if DX_FIRST and big and ctx.needs_input_grad[0]:
+            dx = gemm(dy2, w).view(ctx.xshape)
         with (side.section(dy2.device) if big else _null()):
             want_b = ctx.has_b and ctx.needs_input_grad[2]
             tb = _grad_target(ctx.bias_ref) if (want_b and ctx.bias_ref is not None) else None
@@ -597,7 +601,7 @@ class LinearFunction(torch.autograd.Function):
                     colsum(dy2, out=tb, beta=1.0)
                 else:
                     db = colsum(dy2)
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and dx is None:
             dx = gemm(dy2, w).view(ctx.xshape)
         if big:
             _join_or_defer(dy2.device, dw is None and db is None, (dy2, x2), (tgt, tb))
@@ -865,6 +869,7 @@ class Conv1dFunction(torch.autograd.Function):
         cout = w.shape[0]
         dy2 = _drop_relu_bwd(dy.reshape(B * To, cout), y, ctx.drop) if ctx.drop is not None else act_bwd(dy.reshape(B * To, cout), y, act)
         dx = dw = db = tw = None
+        dcol = gemm(dy2, w.view(cout, C * k)) if (DX_FIRST and ctx.needs_input_grad[0]) else None      # DX_FIRST: see there
         with side.section(dy2.device):
             want_b = ctx.has_b and ctx.needs_input_grad[2]
             tb = _grad_target(ctx.refs[1]) if want_b else None
@@ -884,7 +889,8 @@ class Conv1dFunction(torch.autograd.Function):
                 else:
                     db = colsum(dy2)
         if ctx.needs_input_grad[0]:
-            dcol = gemm(dy2, w.view(cout, C * k))
+            if dcol is None:
+                dcol = gemm(dy2, w.view(cout, C * k))
             dx = torch.empty(B, T, C, dtype=torch.float32, device=dy.device)
             check(lib.ha2g_col2im1d_f32(dcol.data_ptr(), dx.data_ptr(), B, T, C, k, dil, pad_left, To, _stream()))
         _join_or_defer(dy2.device, (dw is None or _single_use_nonleaf(ctx.refs[0])) and db is None, (dy2, col, dw), (tw, tb))
@@ -932,6 +938,8 @@ class GroupedLinearFunction(torch.autograd.Function):
         dws, dbs = [None] * G, [None] * G
         targets = []
         need_w, need_b = ctx.needs_input_grad[4], ctx.has_b and ctx.needs_input_grad[4 + G]
+        if DX_FIRST and ctx.needs_input_grad[0]:
+            dx = gemm_grouped(dy2, wc)
         with side.section(dy2.device):
             if need_w:
                 tw = [_grad_target(w) for w in ws]
@@ -952,7 +960,7 @@ class GroupedLinearFunction(torch.autograd.Function):
             elif need_b:
                 for g in range(G):
                     dbs[g] = colsum(dy2[g])
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and dx is None:
             dx = gemm_grouped(dy2, wc)
         _join_or_defer(dy2.device, all(t is None or _single_use_nonleaf(w) for t, w in zip(dws, ws)) and all(t is None for t in dbs), (dy2, x, dws), targets)
         return (dx, None, None, None) + tuple(dws) + tuple(dbs)
@@ -1369,6 +1377,19 @@ class BiGRUFunction(torch.autograd.Function):
             need_dx = l > 0 or ctx.needs_input_grad[0]
             dx = torch.empty(B * T, K, dtype=torch.float32, device=dev) if need_dx else None
             keep.append((dg, hp, x2, y, dy))                                        # side-stream readers: alive until join
+
+            def data_gradient():
+                if need_dx and isinstance(ctx.wcats[l], str):
+                    _gemm_planes_pre(dg[:, :6 * H], wih_t_planes[l - 1], B * T, K, 6 * H, dx)
+                elif need_dx and ctx.wcats[l] is not None:                          # critical path: dX = [dgi fwd | dgi rev] [W_ih; W_ih_reverse], ONE product
+                    gemm(dg[:, :6 * H], ctx.wcats[l], out=dx)                       # (two products of K = 3H with an accumulate pass before: 2 x 121 us in the step)
+                elif need_dx:
+                    for d in range(2):                                              # dX (+)= dgi W_ih
+                        gemm(dg[:, 3 * H * d:3 * H * d + 3 * H], w[4 * d], out=dx, beta=float(d))
+            if GRU_DX_FIRST:
+                # the layer's data gradient is enqueued BEFORE the side queue forks: the weight-gradient products then start when dX is done and run beside
+                # the next layer's recurrence (80 workgroups, latency-bound) instead of beside the product the recurrence is waiting for
+                data_gradient()
             with side.section(dev):                                                 # weight / bias gradients: off the critical path
                 tgs = []
                 for d in range(2):
@@ -1420,13 +1441,8 @@ class BiGRUFunction(torch.autograd.Function):
                     if not direct:
                         for d in range(2):
                             grads[8 * l + 4 * d + 2], grads[8 * l + 4 * d + 3] = outs[d]
-            if need_dx and isinstance(ctx.wcats[l], str):
-                _gemm_planes_pre(dg[:, :6 * H], wih_t_planes[l - 1], B * T, K, 6 * H, dx)
-            elif need_dx and ctx.wcats[l] is not None:                              # critical path: dX = [dgi fwd | dgi rev] [W_ih; W_ih_reverse], ONE product
-                gemm(dg[:, :6 * H], ctx.wcats[l], out=dx)                           # (two products of K = 3H with an accumulate pass before: 2 x 121 us in the step)
-            elif need_dx:
-                for d in range(2):                                                  # dX (+)= dgi W_ih
-                    gemm(dg[:, 3 * H * d:3 * H * d + 3 * H], w[4 * d], out=dx, beta=float(d))
+            if not GRU_DX_FIRST:
+                data_gradient()
             dy = dx.view(B, T, K) if need_dx else None
         if DEFER_JOIN and side.allow_defer and fused_b and all(fused_b) and all(g is None for g in grads):
             # every weight / bias gradient of the stack accumulated in place into installed .grad buffers: the main stream need not wait for the side
