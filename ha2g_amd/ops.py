@@ -360,6 +360,19 @@ def gemm_grouped(a, b, transa=False, transb=False, out=None, alpha=1.0, beta=0.0
     return ret
 
 
+def gemm_grouped_raw(dev, G, transa, transb, M, N, K, pa, lda, pb, ldb, pc, ldc, beta=0.0, pcs=None, cs_beta=0.0, alpha=1.0, pbias=None, act=ACT_NONE):
+    """gemm_grouped on raw device addresses (lists of G ints: fp32 operands with unit inner stride, row strides lda / ldb / ldc in elements) -- for callers
+    that address column / row blocks of buffers they own (BiGRUFunction.backward: 22 slice views per layer were host time on the host-bound phase of the
+    step).  The CALLER keeps the buffers alive and vouches for shapes; nothing is checked here beyond the group count."""
+    import ctypes
+    assert 1 <= G <= 8 and len(pa) == len(pb) == len(pc) == G
+    arr = ctypes.c_void_p * G
+    ws = workspace(dev)
+    keep = (arr(*pa), arr(*pb), arr(*pc), arr(*pbias) if pbias is not None else None, arr(*pcs) if pcs is not None else None)
+    check(lib.ha2g_gemm_grouped_f32(G, int(transa), int(transb), M, N, K, alpha, keep[0], lda, keep[1], ldb, beta, keep[2], ldc, keep[3], act, keep[4], cs_beta,
+                                    ws.data_ptr(), ws.numel() * 4, _stream()))
+
+
 def colsum(x, out=None, beta=0.0):
     _chk2d(x)
     if out is None:
@@ -1399,13 +1412,16 @@ class BiGRUFunction(torch.autograd.Function):
                 if FUSE_BIAS_GRAD and GROUP_GRU_WGRAD and all(t is not None for tg in tgs for t in tg):
                     # every target is an installed .grad buffer: the two directions' weight-gradient GEMMs have one shape each -> three grouped
                     # launches (dW_ih, dW_hh rows r z, dW_hh rows n) instead of six, bias gradients riding on them
-                    A = [[dg[:, 3 * H * d:3 * H * d + 3 * H] for d in range(2)], [dg[:, 3 * H * d:3 * H * d + 2 * H] for d in range(2)],
-                         [dg[:, 6 * H + H * d:6 * H + H * (d + 1)] for d in range(2)]]
-                    Bm = [[x2, x2], [hp2[:, d * H:(d + 1) * H] for d in range(2)], [hp2[:, d * H:(d + 1) * H] for d in range(2)]]
-                    Cm = [[tgs[d][0] for d in range(2)], [tgs[d][1][:2 * H] for d in range(2)], [tgs[d][1][2 * H:] for d in range(2)]]
-                    cs = [[tgs[d][2] for d in range(2)], [tgs[d][3][:2 * H] for d in range(2)], [tgs[d][3][2 * H:] for d in range(2)]]
-                    for i in range(3):
-                        gemm_grouped(A[i], Bm[i], transa=True, out=Cm[i], beta=1.0, colsum_out=cs[i], colsum_beta=1.0)
+                    # (raw addresses of the column / row blocks: no slice views -- this backward is on the host-bound stretch of the step)
+                    assert x2.stride() == (K, 1) and all(tgs[d][0].shape == (3 * H, K) and tgs[d][1].shape == (3 * H, H) for d in range(2))
+                    pdg, px, ph = dg.data_ptr(), x2.data_ptr(), hp2.data_ptr()
+                    pw = [[tgs[d][i].data_ptr() for i in range(4)] for d in range(2)]
+                    gemm_grouped_raw(dev, 2, True, False, 3 * H, K, B * T, [pdg + 12 * H * d for d in range(2)], 8 * H, [px, px], K,
+                                     [pw[d][0] for d in range(2)], K, 1.0, [pw[d][2] for d in range(2)], 1.0)
+                    gemm_grouped_raw(dev, 2, True, False, 2 * H, H, B * T, [pdg + 12 * H * d for d in range(2)], 8 * H, [ph + 4 * H * d for d in range(2)], 2 * H,
+                                     [pw[d][1] for d in range(2)], H, 1.0, [pw[d][3] for d in range(2)], 1.0)
+                    gemm_grouped_raw(dev, 2, True, False, H, H, B * T, [pdg + 4 * (6 * H + H * d) for d in range(2)], 8 * H, [ph + 4 * H * d for d in range(2)], 2 * H,
+                                     [pw[d][1] + 8 * H * H for d in range(2)], H, 1.0, [pw[d][3] + 8 * H for d in range(2)], 1.0)
                     fused_b += [True, True]
                 else:
                     for d in range(2):

@@ -1,8 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-rm -f gpurun_out/r06b_ab4.txt
-for i in 1 2 3; do
-python tools/ab_call.py "pass" >> gpurun_out/r06b_ab4.txt 2>&1
-python tools/ab_call.py "ops.DX_FIRST=False" >> gpurun_out/r06b_ab4.txt 2>&1
-done
-grep -v amdgpu.ids gpurun_out/r06b_ab4.txt
+timeout 1200 python -m pytest tests -x -q -m gpu -k "gru or GRU or bigru" 2>&1 | tail -4 > gpurun_out/r06c_tests3.txt
+python tools/phase_spans.py 2>&1 | grep -v amdgpu > gpurun_out/r06c_phase_spans2.txt
+cat gpurun_out/r06c_tests3.txt gpurun_out/r06c_phase_spans2.txt
