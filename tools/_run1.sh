@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -x -q -m gpu -k "gru or GRU or bigru" 2>&1 | tail -4 > gpurun_out/r06c_tests3.txt
-python tools/phase_spans.py 2>&1 | grep -v amdgpu > gpurun_out/r06c_phase_spans2.txt
-cat gpurun_out/r06c_tests3.txt gpurun_out/r06c_phase_spans2.txt
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 > gpurun_out/r06c_tests_full.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 >> gpurun_out/r06c_tests_full.txt
+cat gpurun_out/r06c_tests_full.txt
