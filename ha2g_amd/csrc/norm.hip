@@ -474,7 +474,9 @@ __global__ __launch_bounds__(256) void image_col_kernel(const T* __restrict__ x,
 template <int PL, typename T, bool AFF = false>
 __global__ void se_scale_add_relu_kernel(const T* __restrict__ x, const float* __restrict__ s, const T* __restrict__ res,
                                          T* __restrict__ out, long N, int HW, int C, unsigned short* __restrict__ o_hi,
-                                         unsigned short* __restrict__ o_lo, int pnp, BnAff aff = BnAff{}) {
+                                         unsigned short* __restrict__ o_lo, int pnp, BnAff aff = BnAff{}, unsigned* __restrict__ mbits = nullptr) {
+    // mbits (fp32, C % 32 == 0; nullable): the ReLU decisions (out > 0) as four bits per 16-byte vector, eight vectors per 32-bit word (word i >> 3, nibble
+    // i & 7 of vector index i) -- the block's backward reads 1 / 32 of the bytes of `out` for its mask (round 6)
     constexpr int V = VW<T>::V;
     static_assert(!PL || V == 4, "planes are written from fp32 tensors");
     const int CV = C / V;
@@ -494,8 +496,18 @@ __global__ void se_scale_add_relu_kernel(const T* __restrict__ x, const float* _
         for (int k = 0; k < V; ++k) o.v[k] = fmaxf(v.v[k] * sc.v[k] + r.v[k], 0.f);
         stv(out, i, o);
         if (PL) st_planes(o_hi, o_lo, pnp, i, o);
+        if constexpr (V == 4) {
+            if (mbits != nullptr) {                         // total % 8 == 0 and a wave's vectors are consecutive: groups of eight lanes are whole
+                unsigned nib = (o.v[0] > 0.f ? 1u : 0u) | (o.v[1] > 0.f ? 2u : 0u) | (o.v[2] > 0.f ? 4u : 0u) | (o.v[3] > 0.f ? 8u : 0u);
+                unsigned w = nib << (4 * (threadIdx.x & 7));
+                w |= __shfl_xor(w, 1, 64); w |= __shfl_xor(w, 2, 64); w |= __shfl_xor(w, 4, 64);
+                if ((threadIdx.x & 7) == 0) mbits[i >> 3] = w;
+            }
+        }
     }
 }
+// the four ReLU decisions of vector i from se_scale_add_relu_kernel's bit words
+__device__ __forceinline__ unsigned relu_bits(const unsigned* __restrict__ mbits, long i) { return (mbits[i >> 3] >> (4 * (int)(i & 7))) & 15u; }
 // dpre = dout * (out > 0); dres = dpre; dx = dpre * s[n,c] + dpool[n,c]   (dpool already divided by HW)
 template <typename T>
 __global__ void se_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ outp, const float* __restrict__ s,
@@ -598,9 +610,10 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
 //   bn2: sum_hw dz        = s A1 + HW dpool,   sum_hw dz * xhat = s A2 + dpool A3
 // so the pass that WROTE dz (se_bwd_apply) and the column pass that READ it back with c2 (col_partial<1>) disappear: two passes over three tensors
 // (reduce, apply) instead of four over nine tensor reads.  All sums in double, fixed order (chunks ascending, images ascending): deterministic.
+template <bool BITS>
 __global__ __launch_bounds__(256) void se_bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dout, const float* __restrict__ outp,
                                                            int HW, int C, double* __restrict__ part, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd) {
+                                                           const float* __restrict__ invstd, const unsigned* __restrict__ mbits) {
     // grid (nchunk, N): block (k, n) sums rows [k * per, (k + 1) * per) of image n -> part [n][k][3][C]
     __shared__ dvec<4> lds[3][256];
     const int CV = C / 4;
@@ -610,28 +623,35 @@ __global__ __launch_bounds__(256) void se_bn_reduce_kernel(const float* __restri
     const long base = (long)blockIdx.y * HW * C;
     dvec<4> a1 = dzero<4>(), a2 = dzero<4>(), a3 = dzero<4>();
     const fvec<4> mu = ldp<4>(mean, m.cv), is = ldp<4>(invstd, m.cv);
-    auto accum = [&](const fvec<4>& v, const fvec<4>& d, const fvec<4>& o) {
+    // the ReLU decisions: (out > 0) read from the block's output, or BITS: from se_scale_add_relu_kernel's bit words (a 32nd of the bytes)
+    auto accum = [&](const fvec<4>& v, const fvec<4>& d, unsigned bits) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const double xh = ((double)v.v[k] - mu.v[k]) * is.v[k];          // col_partial_kernel<1>'s xhat
-            const double dp = o.v[k] > 0.f ? (double)d.v[k] : 0.0;
+            const double dp = ((bits >> k) & 1u) ? (double)d.v[k] : 0.0;
             a1.v[k] += dp; a2.v[k] += dp * xh; a3.v[k] += xh;
         }
     };
+    auto decisions = [&](long off) -> unsigned {
+        if (BITS) return relu_bits(mbits, (off >> 2) + m.cv);
+        const fvec<4> o = ldv(outp + off, m.cv);
+        return (o.v[0] > 0.f ? 1u : 0u) | (o.v[1] > 0.f ? 2u : 0u) | (o.v[2] > 0.f ? 4u : 0u) | (o.v[3] > 0.f ? 8u : 0u);
+    };
     int r = rbeg + m.r0;
-    for (; r + 3 * m.rstep < rend; r += 4 * m.rstep) {                        // twelve 16-byte loads in flight per thread
-        fvec<4> v[4], d[4], o[4];
+    for (; r + 3 * m.rstep < rend; r += 4 * m.rstep) {                        // twelve (BITS: eight + four 4-byte) loads in flight per thread
+        fvec<4> v[4], d[4];
+        unsigned bt[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long off = base + (long)(r + j * m.rstep) * C;
-            v[j] = ldv(x + off, m.cv); d[j] = ldv(dout + off, m.cv); o[j] = ldv(outp + off, m.cv);
+            v[j] = ldv(x + off, m.cv); d[j] = ldv(dout + off, m.cv); bt[j] = decisions(off);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accum(v[j], d[j], o[j]);
+        for (int j = 0; j < 4; ++j) accum(v[j], d[j], bt[j]);
     }
     for (; r < rend; r += m.rstep) {
         const long off = base + (long)r * C;
-        accum(ldv(x + off, m.cv), ldv(dout + off, m.cv), ldv(outp + off, m.cv));
+        accum(ldv(x + off, m.cv), ldv(dout + off, m.cv), decisions(off));
     }
     lds[0][threadIdx.x] = a1; lds[1][threadIdx.x] = a2; lds[2][threadIdx.x] = a3;
     __syncthreads();
@@ -717,25 +737,28 @@ __global__ __launch_bounds__(256) void se_bn_mlp_bwd_kernel(const float* __restr
 }
 // dpre = dout * (out > 0); dres = dpre; dz = dpre * s[n,c] + dpool[n,c] (se_bwd_apply_kernel's expression, never stored);
 // dx = gamma invstd (dz - sum_dz / M - xhat sum_dz_xhat / M) (bn_bwd_apply_kernel's expression), as fp32 and / or piece planes
-template <int PL>
+template <int PL, bool BITS>
 __global__ void se_bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ outp, const float* __restrict__ x,
                                        const float* __restrict__ s, const float* __restrict__ dpool, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ sum_dy,
                                        const float* __restrict__ sum_dy_xhat, float* __restrict__ dres, float* __restrict__ dx, long N, int HW, int C,
-                                       unsigned short* __restrict__ dx_hi, unsigned short* __restrict__ dx_lo, int pnp) {
+                                       unsigned short* __restrict__ dx_hi, unsigned short* __restrict__ dx_lo, int pnp, const unsigned* __restrict__ mbits) {
     const int CV = C / 4;
     const long per = (long)HW * CV, total = N * per;
     const float invn = 1.f / (float)(N * HW);
     const double dn = (double)invn;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long n = i / per; const int cv = (int)(i % CV);
-        const fvec<4> d = ldv(dout, i), o = ldv(outp, i), v = ldv(x, i);
+        const fvec<4> d = ldv(dout, i), v = ldv(x, i);
+        unsigned bits;
+        if (BITS) bits = relu_bits(mbits, i);
+        else { const fvec<4> o = ldv(outp, i); bits = (o.v[0] > 0.f ? 1u : 0u) | (o.v[1] > 0.f ? 2u : 0u) | (o.v[2] > 0.f ? 4u : 0u) | (o.v[3] > 0.f ? 8u : 0u); }
         const fvec<4> sc = ldp<4>(s + n * C, cv), dp = ldp<4>(dpool + n * C, cv);
         const fvec<4> mu = ldp<4>(mean, cv), is = ldp<4>(invstd, cv), g = ldp<4>(gamma, cv), s1 = ldp<4>(sum_dy, cv), s2 = ldp<4>(sum_dy_xhat, cv);
         fvec<4> p, r;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            p.v[k] = o.v[k] > 0.f ? d.v[k] : 0.f;
+            p.v[k] = ((bits >> k) & 1u) ? d.v[k] : 0.f;
             const float q = p.v[k] * sc.v[k] + dp.v[k];
             r.v[k] = (float)((double)g.v[k] * is.v[k] * ((double)q - s1.v[k] * dn - ((double)v.v[k] - mu.v[k]) * is.v[k] * (s2.v[k] * dn)));
         }
@@ -860,11 +883,12 @@ int bn_bwd_t(const T* dy, const T* x, const float* mean, const float* invstd, co
 }
 template <int PL, typename T>
 int se_scale_add_relu_t(const T* x, const float* s, const T* res, T* out, void* o_hi, void* o_lo, int pnp, int N, int HW, int C, void* stream,
-                        const BnAff* aff = nullptr) {
+                        const BnAff* aff = nullptr, unsigned* mbits = nullptr) {
     HA2G_REQUIRE(C % VW<T>::V == 0, "se: C %% 4");
+    HA2G_REQUIRE(mbits == nullptr || (aff != nullptr && sizeof(T) == 4 && C % 32 == 0), "se: the decision bits need fp32 storage, C %% 32 == 0 and the on-the-fly bn2 form");
     if (aff)
         hipLaunchKernelGGL((se_scale_add_relu_kernel<PL, T, true>), dim3(flat_grid((long)N * HW * (C / VW<T>::V))), dim3(256), 0, (hipStream_t)stream, x, s, res,
-                           out, (long)N, HW, C, (unsigned short*)o_hi, (unsigned short*)o_lo, pnp, *aff);
+                           out, (long)N, HW, C, (unsigned short*)o_hi, (unsigned short*)o_lo, pnp, *aff, mbits);
     else
     hipLaunchKernelGGL((se_scale_add_relu_kernel<PL, T>), dim3(flat_grid((long)N * HW * (C / VW<T>::V))), dim3(256), 0, (hipStream_t)stream, x, s, res, out,
                        (long)N, HW, C, (unsigned short*)o_hi, (unsigned short*)o_lo, pnp, BnAff{});
@@ -1051,6 +1075,15 @@ int ha2g_se_bn_scale_add_relu_np_f32(const float* x, const float* mean, const fl
     if (np == 0) return se_scale_add_relu_t<0, float>(x, s, res, out, nullptr, nullptr, 0, N, HW, C, stream, &aff);
     return se_scale_add_relu_t<1, float>(x, s, res, out, planes, (unsigned short*)planes + ps, np, N, HW, C, stream, &aff);
 }
+// ... and leaves the ReLU decisions (out > 0) behind as bits: mask_bits = N * HW * C / 32 32-bit words (C % 32 == 0), for ha2g_se_bn_bwd_*'s mask_bits
+int ha2g_se_bn_scale_add_relu_mask_np_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* s,
+                                          const float* res, float* out, void* planes, long ps, int np, int N, int HW, int C, void* mask_bits, void* stream) {
+    HA2G_REQUIRE(np == 0 || (planes != nullptr && (np == 2 || np == 3)), "se_bn_scale_add_relu_mask_np: null plane / np = %d", np);
+    HA2G_REQUIRE(mask_bits != nullptr, "se_bn_scale_add_relu_mask_np: null bit buffer");
+    const BnAff aff{mean, invstd, gamma, beta};
+    if (np == 0) return se_scale_add_relu_t<0, float>(x, s, res, out, nullptr, nullptr, 0, N, HW, C, stream, &aff, (unsigned*)mask_bits);
+    return se_scale_add_relu_t<1, float>(x, s, res, out, planes, (unsigned short*)planes + ps, np, N, HW, C, stream, &aff, (unsigned*)mask_bits);
+}
 int ha2g_se_bwd_scale_bn_f32(const float* dout, const float* out, const float* x, const float* mean, const float* invstd, const float* gamma,
                              const float* beta, float* ds, int N, int HW, int C, const float* gate, float* ws, void* stream) {
     const BnAff aff{mean, invstd, gamma, beta};
@@ -1106,15 +1139,19 @@ long ha2g_se_bn_bwd_workspace_floats(int N, int HW, int C) { return (long)N * po
 // writes ds [N][C] (the MLP's weight gradient reads it), dh1 [N][R], dpool [N][C] (already / HW) and stat [2][C][N] doubles: bn2's per-image backward sums.
 int ha2g_se_bn_bwd_reduce_mlp_f32(const float* dout, const float* out, const float* x, const float* mean, const float* invstd, const float* gamma,
                                   const float* beta, float* ds, int N, int HW, int C, const float* gate, float* ws, const float* h1, const float* w2,
-                                  const float* w0, float* dh1, float* dpool, int R, double* stat, void* stream) {
+                                  const float* w0, float* dh1, float* dpool, int R, double* stat, const void* mask_bits, void* stream) {
     HA2G_REQUIRE(okCv<float>(C), "se_bn_bwd: unsupported channel count %d", C);
+    HA2G_REQUIRE(mask_bits == nullptr ? out != nullptr : C % 32 == 0, "se_bn_bwd: the ReLU decisions come from `out` or from mask_bits (C %% 32 == 0)");
     HA2G_REQUIRE(C >= 1 && C <= 256 && R >= 1 && R <= 32, "se_bn_bwd: unsupported widths C = %d, R = %d", C, R);
     HA2G_REQUIRE(ws != nullptr && gate != nullptr && stat != nullptr && mean != nullptr && invstd != nullptr && gamma != nullptr && beta != nullptr,
                  "se_bn_bwd: null workspace / gate / statistics / BatchNorm parameter");
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = pool_chunks(N, HW);
-    hipLaunchKernelGGL(se_bn_reduce_kernel, dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, (double*)ws, mean, invstd);
+    if (mask_bits != nullptr)
+        hipLaunchKernelGGL(se_bn_reduce_kernel<true>, dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, (double*)ws, mean, invstd, (const unsigned*)mask_bits);
+    else
+        hipLaunchKernelGGL(se_bn_reduce_kernel<false>, dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, (double*)ws, mean, invstd, (const unsigned*)nullptr);
     hipLaunchKernelGGL(se_bn_mlp_bwd_kernel, dim3(N), dim3(256), 0, st, h1, w2, w0, dh1, dpool, C, R, HW, N, (const double*)ws, nchunk, gate, ds, gamma, beta, stat);
     HA2G_CHECK_LAUNCH("se_bn_bwd_reduce_mlp");
     return 0;
@@ -1123,8 +1160,9 @@ int ha2g_se_bn_bwd_reduce_mlp_f32(const float* dout, const float* out, const flo
 // np piece planes (planes, piece stride ps elements; null: fp32 only); dgamma / dbeta [C] = bn2's parameter gradients (fresh sums; acc_*: also added there).
 int ha2g_se_bn_bwd_apply_np_f32(const float* dout, const float* out, const float* x, const float* s, const float* dpool, const float* mean,
                                 const float* invstd, const float* gamma, float* dres, float* dx, void* planes, long ps, int np, float* dgamma, float* dbeta,
-                                float* acc_dgamma, float* acc_dbeta, const double* stat, int N, int HW, int C, void* stream) {
+                                float* acc_dgamma, float* acc_dbeta, const double* stat, int N, int HW, int C, const void* mask_bits, void* stream) {
     HA2G_REQUIRE(okCv<float>(C), "se_bn_bwd: unsupported channel count %d", C);
+    HA2G_REQUIRE(mask_bits == nullptr ? out != nullptr : C % 32 == 0, "se_bn_bwd_apply: the ReLU decisions come from `out` or from mask_bits (C %% 32 == 0)");
     HA2G_REQUIRE(planes == nullptr || np == 2 || np == 3, "se_bn_bwd_apply: np = %d", np);
     HA2G_REQUIRE(planes != nullptr || dx != nullptr, "se_bn_bwd_apply: no output");
     HA2G_REQUIRE(dres != nullptr && stat != nullptr && dgamma != nullptr && dbeta != nullptr, "se_bn_bwd_apply: null buffer");
@@ -1132,12 +1170,13 @@ int ha2g_se_bn_bwd_apply_np_f32(const float* dout, const float* out, const float
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, stat, N, C, dbeta, dgamma, acc_dbeta, acc_dgamma);
     const dim3 grid(flat_grid((long)N * HW * (C / 4)));
-    if (planes != nullptr)
-        hipLaunchKernelGGL(se_bn_bwd_apply_kernel<1>, grid, dim3(256), 0, st, dout, out, x, s, dpool, mean, invstd, gamma, (const float*)dbeta, (const float*)dgamma,
-                           dres, dx, (long)N, HW, C, (unsigned short*)planes, (unsigned short*)planes + ps, np);
-    else
-        hipLaunchKernelGGL(se_bn_bwd_apply_kernel<0>, grid, dim3(256), 0, st, dout, out, x, s, dpool, mean, invstd, gamma, (const float*)dbeta, (const float*)dgamma,
-                           dres, dx, (long)N, HW, C, (unsigned short*)nullptr, (unsigned short*)nullptr, 0);
+    const unsigned* mb = (const unsigned*)mask_bits;
+    unsigned short* ph = (unsigned short*)planes;
+#define HA2G_SEBN_APPLY(PL, BITS) hipLaunchKernelGGL((se_bn_bwd_apply_kernel<PL, BITS>), grid, dim3(256), 0, st, dout, out, x, s, dpool, mean, invstd, gamma, \
+        (const float*)dbeta, (const float*)dgamma, dres, dx, (long)N, HW, C, ph, ph ? ph + ps : ph, planes ? np : 0, mb)
+    if (planes != nullptr) { if (mb) HA2G_SEBN_APPLY(1, true); else HA2G_SEBN_APPLY(1, false); }
+    else { if (mb) HA2G_SEBN_APPLY(0, true); else HA2G_SEBN_APPLY(0, false); }
+#undef HA2G_SEBN_APPLY
     HA2G_CHECK_LAUNCH("se_bn_bwd_apply");
     return 0;
 }

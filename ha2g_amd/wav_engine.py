@@ -63,6 +63,7 @@ def fwd_planes_ok(w_ohwi, stride, pad):
     return FWD3 and lib.ha2g_gemm_bwd_pieces() == 3 and bool(lib.ha2g_conv2d_fwd_planes_supported(Cin, Cout, KH, KW, stride, pad))
 
 
+RELU_BITS = True          # the blocks' ReLU decisions (out > 0) as bits for the two-pass backward tail: 1 / 32 of the bytes of `out`, read twice per block (round 6)
 IMAGE_STATS = True        # layer 1 (no statistics epilogue): bn2's statistics and the SE squeeze from ONE per-image column pass over conv2's output (round 6)
 SE_FROM_STATS = True      # ... and, where the epilogue's tiles lie inside one image, the SE squeeze too: bn2's output is never materialised (block_fwd)
 def _tiles_per_image(xshape, w_ohwi):
@@ -535,7 +536,7 @@ class GradSink:
             ops.side.join(device)
             self.forked = False
 
-    def gbn_se(self, name, dout, out, x, sc, dpool, mean, invstd, dres, stat, planes=False, need_dx=True):
+    def gbn_se(self, name, dout, out, x, sc, dpool, mean, invstd, dres, stat, planes=False, need_dx=True, mask_bits=None):
         """bn2's backward fused with the SE apply pass (ha2g_se_bn_bwd_apply_np_f32): dres <- dout * (out > 0); -> (dx fp32 NHWC or None, piece planes or
         None) of bn2's data gradient; gamma / beta gradients go where gbn() puts them.  stat = the per-image sums ha2g_se_bn_bwd_reduce_mlp_f32 left."""
         bn = self.P[name]
@@ -550,7 +551,7 @@ class GradSink:
         ops.ktimer.launch('se_bn_bwd_apply', lambda: check(lib.ha2g_se_bn_bwd_apply_np_f32(
             dout.data_ptr(), out.data_ptr(), x.data_ptr(), sc.data_ptr(), dpool.data_ptr(), mean.data_ptr(), invstd.data_ptr(), bn.gamma.data_ptr(),
             dres.data_ptr(), _p(dxo), _p(pl), pl.stride(0) if planes else 0, pl.shape[0] if planes else 0, dgamma.data_ptr(), dbeta.data_ptr(),
-            _p(acc[0] if acc else None), _p(acc[1] if acc else None), stat.data_ptr(), N, OH * OW, C, _stream())), nb_)
+            _p(acc[0] if acc else None), _p(acc[1] if acc else None), stat.data_ptr(), N, OH * OW, C, _p(mask_bits), _stream())), nb_)
         if acc is None:
             self.G[name] = (dgamma, dbeta)
         return dxo, pl
@@ -662,7 +663,14 @@ def block_fwd(x, P, b, first, xp=None, out_planes=0, wpl=None):
     outp = None
     if out_planes:
         outp = torch.empty((out_planes,) + tuple(out.shape), dtype=torch.bfloat16, device=out.device)
-    if b2 is None:
+    mb = None
+    if b2 is None and RELU_BITS and SE_BN2_FUSED and _TRAINING[0] and _WILL_BWD[0] and C % 32 == 0 and c2.dtype == torch.float32:
+        # the block's ReLU decisions as bits: its backward (two passes, block_bwd) reads them instead of `out`
+        mb = torch.empty(c2.numel() // 32, dtype=torch.int32, device=c2.device)
+        check(lib.ha2g_se_bn_scale_add_relu_mask_np_f32(c2.data_ptr(), m2.data_ptr(), s2.data_ptr(), bn2.gamma.data_ptr(), bn2.beta.data_ptr(), sc.data_ptr(),
+                                                        res.data_ptr(), out.data_ptr(), _p(outp), outp.stride(0) if outp is not None else 0, out_planes or 0,
+                                                        N, OH * OW, C, mb.data_ptr(), _stream()))
+    elif b2 is None:
         check(lib.ha2g_se_bn_scale_add_relu_np_f32(c2.data_ptr(), m2.data_ptr(), s2.data_ptr(), bn2.gamma.data_ptr(), bn2.beta.data_ptr(), sc.data_ptr(),
                                                    res.data_ptr(), out.data_ptr(), _p(outp), outp.stride(0) if outp is not None else 0, out_planes or 0,
                                                    N, OH * OW, C, _stream()))
@@ -671,12 +679,12 @@ def block_fwd(x, P, b, first, xp=None, out_planes=0, wpl=None):
                                                        out_planes, N, OH * OW, C, _stream()))
     else:
         check(lib.ha2g_se_scale_add_relu_f32(b2.data_ptr(), sc.data_ptr(), res.data_ptr(), out.data_ptr(), N, OH * OW, C, _stream()))
-    return out, (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride, xp, a1p), outp
+    return out, (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride, xp, a1p, mb), outp
 
 
 def block_bwd(dx, saved, P, b, sink):
     """dx = d(out) NHWC -> d(x) NHWC; parameter gradients go to `sink` (GradSink)."""
-    (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride, xp, a1p) = saved
+    (x, c1, m1, s1, a1, c2, m2, s2, b2, pooled, h1, sc, su, cd, md, sd, out, stride, xp, a1p, mb) = saved
     N, OH, OW, C = c2.shape
     HW = OH * OW
     dout = dx.contiguous()
@@ -698,10 +706,10 @@ def block_bwd(dx, saved, P, b, sink):
         stat = torch.empty(2 * C * N, dtype=torch.float64, device=dout.device)
         check(lib.ha2g_se_bn_bwd_reduce_mlp_f32(dout.data_ptr(), out.data_ptr(), c2.data_ptr(), m2.data_ptr(), s2.data_ptr(), bn2.gamma.data_ptr(),
                                                 bn2.beta.data_ptr(), ds.data_ptr(), N, HW, C, sc.data_ptr(), ws.data_ptr(), h1.data_ptr(), w2_.data_ptr(),
-                                                w0_.data_ptr(), dh1.data_ptr(), dpool.data_ptr(), h1.shape[1], stat.data_ptr(), _stream()))
+                                                w0_.data_ptr(), dh1.data_ptr(), dpool.data_ptr(), h1.shape[1], stat.data_ptr(), _p(mb), _stream()))
         sink.gse(b, ds, h1, dh1, pooled)
         dres = torch.empty_like(c2)
-        dc2, dc2p = sink.gbn_se(b + 'bn2', dout, out, c2, sc, dpool, m2, s2, dres, stat, planes=p2, need_dx=f2)
+        dc2, dc2p = sink.gbn_se(b + 'bn2', dout, out, c2, sc, dpool, m2, s2, dres, stat, planes=p2, need_dx=f2, mask_bits=mb)
     elif SE_BWD_FOLD and SE_MLP_FUSED and w2_.is_contiguous() and w0_.is_contiguous() and lib.ha2g_se_mlp_bwd_supported(C, h1.shape[1]):
         # reduction pass + (its final pass inside) the excitation MLP's backward: two launches instead of three, the same bits
         dh1, dpool = torch.empty_like(h1), torch.empty_like(ds)

@@ -392,7 +392,8 @@ int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, c
  * reduce_mlp: x = bn2's INPUT [N][HW][C], mean / invstd / gamma / beta = bn2's, gate = the SE gate [N][C], ws >= ha2g_se_bn_bwd_workspace_floats floats;
  *   writes ds [N][C], dh1 [N][R], dpool [N][C] (already / HW) as ha2g_se_bwd_scale_mlp_f32 does, and stat [2][C][N] doubles (bn2's per-image sums).
  * apply: dres = dpre; bn2's data gradient as fp32 (dx, nullable when planes != NULL) and / or np (2 | 3) bf16 piece planes (piece stride ps elements);
- *   dgamma / dbeta [C] = bn2's parameter gradients, also ADDED to acc_dgamma / acc_dbeta when those are not NULL. */
+ *   dgamma / dbeta [C] = bn2's parameter gradients, also ADDED to acc_dgamma / acc_dbeta when those are not NULL.
+ * mask_bits (both; nullable): the ReLU decisions as ha2g_se_bn_scale_add_relu_mask_np_f32 wrote them. */
 /* ABI 6: per-IMAGE statistics partials of x [N][HW][C] (sum x, sum x^2; doubles [2][C][nblk], nblk = N * ha2g_bn_image_partial_chunks(N, HW), the blocks of
  * an image consecutive): what a plane convolution's statistics epilogue leaves behind, for a tensor whose producer has none (layer 1's 32-channel
  * convolutions) -- ha2g_bn_stats_finalize_f32 and ha2g_se_mlp_fwd_f32 (the SE squeeze) read them, bn2's output is then never materialised. */
@@ -401,10 +402,15 @@ int ha2g_bn_image_partials_f32(const float* x, int N, int HW, int C, double* par
 long ha2g_se_bn_bwd_workspace_floats(int N, int HW, int C);
 int ha2g_se_bn_bwd_reduce_mlp_f32(const float* dout, const float* out, const float* x, const float* mean, const float* invstd, const float* gamma,
                                   const float* beta, float* ds, int N, int HW, int C, const float* gate, float* ws, const float* h1, const float* w2,
-                                  const float* w0, float* dh1, float* dpool, int R, double* stat, void* stream);
+                                  const float* w0, float* dh1, float* dpool, int R, double* stat, const void* mask_bits, void* stream);
 int ha2g_se_bn_bwd_apply_np_f32(const float* dout, const float* out, const float* x, const float* s, const float* dpool, const float* mean,
                                 const float* invstd, const float* gamma, float* dres, float* dx, void* planes, long ps, int np, float* dgamma, float* dbeta,
-                                float* acc_dgamma, float* acc_dbeta, const double* stat, int N, int HW, int C, void* stream);
+                                float* acc_dgamma, float* acc_dbeta, const double* stat, int N, int HW, int C, const void* mask_bits, void* stream);
+/* ha2g_se_bn_scale_add_relu_np_f32 that also leaves the block's ReLU decisions (out > 0) behind as bits: mask_bits = N * HW * C / 32 32-bit words, four bits
+ * per 16-byte vector, eight vectors per word (C % 32 == 0).  ha2g_se_bn_bwd_reduce_mlp_f32 / _apply_np_f32 with mask_bits != NULL read them instead of
+ * `out` (which may then be NULL): a 32nd of the bytes, twice per block. */
+int ha2g_se_bn_scale_add_relu_mask_np_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* s,
+                                          const float* res, float* out, void* planes, long ps, int np, int N, int HW, int C, void* mask_bits, void* stream);
 /* speaker-softmax blending of the three audio taps (model/ResNetSE34V2.py:202-212) */
 int ha2g_blend_fwd_f32(const float* logits, const float* f0, const float* f1, const float* f2, float* w, float* blend,
                        int B, int L, int TF, void* stream);

@@ -443,3 +443,47 @@ def test_bn2_statistics_and_se_squeeze_from_one_per_image_pass(name):
         a, b_ = res[True][k].double(), res[False][k].double()
         err, ref = float((a - b_).abs().max()), float(b_.abs().max())
         assert err <= 2e-5 * ref + 1e-12, (name, k, err, ref)
+
+
+@pytest.mark.parametrize('name', ['l1', 'l2', 'l3d', 'l4'])
+def test_relu_decisions_as_bits_change_no_bit_of_the_backward(name):
+    """Round 6: the block's tail leaves its ReLU decisions (out > 0) behind as four bits per 16-byte vector (ha2g_se_bn_scale_add_relu_mask_np_f32) and the
+    two passes of the block's backward read those instead of `out` (wav_engine.RELU_BITS: a 32nd of the bytes, twice per block): output and every gradient
+    are BIT-IDENTICAL to the form that re-reads the output tensor; and the bits are the decisions."""
+    from ha2g_amd import ops, wav_engine as we
+    geom = BLOCKFULL_CASES[name]
+    P = engine_P(block_state(name, geom, 53), DEV)
+    x, wl = block_io(name, geom, BLOCKFULL_B, 53)
+    xin, dout = nhwc(x.to(DEV)), nhwc(wl.to(DEV))
+    wpl = {}
+    for n, stride, pad in (('conv1.weight', 2 if geom[4] else 1, 1), ('conv2.weight', 1, 1), ('downsample.0.weight', 2, 0)):
+        if n in P and we.fwd_planes_ok(we._ohwi(P[n]), stride, pad):
+            wpl[n] = ops.to_planes(we._ohwi(P[n]).contiguous(), 3)
+    xp = ops.to_planes(xin, 3) if 'conv1.weight' in wpl else None
+    res = {}
+    try:
+        for on in (True, False):
+            we.RELU_BITS = on
+            we._TRAINING[0] = True
+            we._WILL_BWD[0] = True
+            we._NBT_PENDING.clear()
+            Pc = {k: (v.clone() if torch.is_tensor(v) else we._BN(v.gamma, v.beta, v.rm.clone(), v.rv.clone(), None)) for k, v in P.items()}
+            out, saved, _ = we.block_fwd(xin, Pc, '', geom[4], xp=xp, wpl=wpl)
+            assert (saved[20] is not None) == on
+            if on:                                               # word i >> 3, nibble i & 7 of vector i; bit k = element 4 i + k
+                w = saved[20].to(torch.int64) & 0xffffffff
+                bits = ((w.view(-1, 1) >> torch.arange(32, device=w.device)) & 1).view(-1).bool()
+                assert torch.equal(bits, (out > 0).view(-1))
+            sink = we.GradSink(Pc)
+            dx = we.block_bwd(dout, saved, Pc, '', sink)
+            sink.join(torch.device(DEV))
+            g = {}
+            for k, gr in sink.G.items():
+                for j, t in enumerate(gr if isinstance(gr, tuple) else (gr,)):
+                    g['%s/%d' % (k, j)] = t.clone()
+            res[on] = dict(out=out.clone(), dx=dx.clone(), **g)
+    finally:
+        we.RELU_BITS = True
+    assert set(res[True]) == set(res[False])
+    for k in res[True]:
+        assert torch.equal(res[True][k], res[False][k]), (name, k)

@@ -54,14 +54,30 @@ def _cmp(report, key, got, ref, ref32=None):
     err = float((got - ref).abs().max())
     floor = 3.0 * float((ref32.double().reshape(ref.shape) - ref).abs().max()) if ref32 is not None else 0.0
     tol = RTOL * s + floor
-    report.append((err / tol, key, err / s, floor / tol, s))
+    report.append((err / tol, key, err / s, floor / tol, s, err))
+
+
+def _hold_zero_tensors_absolutely(report):
+    """see _summarise; idempotent; returns the median gradient scale"""
+    med_scale = float(np.median([r[4] for r in report]))
+    mod_scale = {}
+    for r in report:
+        mod_scale.setdefault(r[1].split('.')[0], []).append(r[4])
+    for i, r in enumerate(report):
+        if r[4] <= 1e-9 * med_scale:
+            tol0 = RTOL * float(np.median(mod_scale[r[1].split('.')[0]]))
+            report[i] = (r[5] / tol0, r[1], r[2], 0.0, r[4], r[5])
+    return med_scale
 
 
 def _summarise(report, what):
+    # a gradient that is ZERO by construction (a convolution bias in front of a BatchNorm: ~1e-16 in float64) has no scale to be relative to, and what any
+    # fp32 implementation computes for it is the sum of its inputs' rounding errors -- ONE draw of a noise whose sign and size change with any 1e-7
+    # perturbation upstream (the float32 oracle's own value is another single draw: three times it was the bound until a reordered summation in the tower
+    # moved dis.pre_conv.3.bias from below to 1.6 x above it).  Such a tensor is held ABSOLUTELY to 1e-4 of the median gradient scale of its module (the
+    # update it causes is below every other parameter's tolerance) and left out of the error / scale statistics.
+    med_scale = _hold_zero_tensors_absolutely(report)
     report.sort(reverse=True)
-    # a gradient that is ZERO by construction (a convolution bias in front of a BatchNorm: ~1e-16 in float64) has no scale to be relative to: it is held
-    # by the absolute float32 floor alone and left out of the error / scale statistics
-    med_scale = float(np.median([r[4] for r in report]))
     rel = sorted((r[2] for r in report if r[4] > 1e-9 * med_scale), reverse=True)
     shares = [r[3] for r in report]
     print('%s: %d tensors; error / scale: worst %.2e, median %.2e, above 1e-4: %d; worst error / tolerance %.2f (%s); float32-oracle floor: median share of '
@@ -324,6 +340,7 @@ def _whole_step_vs_linearised_oracle(case, expressive, what, fused=False):
             continue
         _cmp(rep, k, hip_grads[k], ref, g32[k])
     assert len(rep) > 400 and any(r[1].startswith('dis.') for r in rep)
+    _hold_zero_tensors_absolutely(rep)
     by_mod = {}
     for r in rep:
         m = r[1].split('.')[0]

@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 > gpurun_out/r06c_tests_full.txt
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 >> gpurun_out/r06c_tests_full.txt
-cat gpurun_out/r06c_tests_full.txt
+timeout 900 python -m pytest tests/test_gpu_blocks.py -x -q -m gpu -k "relu_decisions" 2>&1 | tail -12
