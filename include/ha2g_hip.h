@@ -228,6 +228,7 @@ void ha2g_conv_debug_direct_c32(int on);
 void ha2g_conv_debug_cfg(int cfg);   /* tile-shape override for tools/conv_bench.py (-1 = heuristic) */
 /* stem Conv2d(1->32, 3x3, pad 1) + bias + ReLU (model/ResNetSE34V2.py:27,127-128); x [N,H,W], y [N,H,W,32] */
 int ha2g_stem_conv_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, void* stream);
+/* dw [32][3][3], db [32] (= beta * old + gradient); dy = gradient w.r.t. the pre-ReLU output; ws >= 4096 * 320 floats of scratch */
 int ha2g_stem_conv_wgrad_f32(const float* x, const float* dy, float* dw, float* db, int N, int H, int W, float beta,
                              float* ws, void* stream);
 /* NHWC PixelShuffle(r) (model/ResNetSE34V2.py:166-167,177-178); inverse=1 routes the gradient back */
