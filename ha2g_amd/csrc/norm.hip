@@ -811,6 +811,53 @@ __global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const float* __restri
     if (blockIdx.x == 0 && t < 32 && j < R) db0[j] += b0;          // channel 0's threads: b0 does not depend on c
 }
 
+// se_mlp_wgrad_kernel for up to 16 blocks of the tower in ONE launch (round 6): sixteen launches of 4-32 workgroups sat on the side queue of the tower's
+// backward at 52 us each (alone: 17) between the persistent weight-gradient kernels; their operands ([N][C], [N][R]) are small enough to keep until the
+// trunk's backward is enqueued.  Same arithmetic and order per block.
+struct SeWgradJobs {
+    const float* dsc[16]; const float* h1[16]; const float* dh1[16]; const float* pooled[16];
+    float* dw2[16]; float* db2[16]; float* dw0[16]; float* db0[16];
+    int C[16], R[16], start[17];
+};
+__global__ __launch_bounds__(256) void se_mlp_wgrad_multi_kernel(SeWgradJobs jb, int njobs, int N) {
+    constexpr int NB = 64;
+    __shared__ float s_d[NB][8], s_p[NB][8], s_h[NB][32], s_g[NB][32];
+    int q = 0;
+    while (q + 1 < njobs && (int)blockIdx.x >= jb.start[q + 1]) ++q;
+    const float* __restrict__ dsc = jb.dsc[q]; const float* __restrict__ h1 = jb.h1[q]; const float* __restrict__ dh1 = jb.dh1[q];
+    const float* __restrict__ pooled = jb.pooled[q];
+    const int C = jb.C[q], R = jb.R[q];
+    const int t = threadIdx.x, j = t & 31, cl = t >> 5, c0 = ((int)blockIdx.x - jb.start[q]) * 8, c = c0 + cl;
+    const bool on = c < C && j < R;
+    float a2 = 0.f, a0 = 0.f, b2 = 0.f, b0 = 0.f;
+    for (int n0 = 0; n0 < N; n0 += NB) {
+        const int nb = N - n0 < NB ? N - n0 : NB;
+        for (int i = t; i < NB * 8; i += 256) {
+            const int n = i >> 3, cc = i & 7;
+            const bool ok = n < nb && c0 + cc < C;
+            s_d[n][cc] = ok ? dsc[(long)(n0 + n) * C + c0 + cc] : 0.f;
+            s_p[n][cc] = ok ? pooled[(long)(n0 + n) * C + c0 + cc] : 0.f;
+        }
+        for (int i = t; i < NB * 32; i += 256) {
+            const int n = i >> 5, jj = i & 31;
+            const bool ok = n < nb && jj < R;
+            s_h[n][jj] = ok ? h1[(long)(n0 + n) * R + jj] : 0.f;
+            s_g[n][jj] = ok ? dh1[(long)(n0 + n) * R + jj] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int n = 0; n < NB; ++n) {
+            const float d = s_d[n][cl], pl = s_p[n][cl], h = s_h[n][j], g = s_g[n][j];
+            a2 = fmaf(d, h, a2); a0 = fmaf(g, pl, a0);
+            b2 += d; b0 += g;
+        }
+        __syncthreads();
+    }
+    if (on) { jb.dw2[q][(long)c * R + j] += a2; jb.dw0[q][(long)j * C + c] += a0; }
+    if (c < C && j == 0) jb.db2[q][c] += b2;
+    if ((int)blockIdx.x == jb.start[q] && t < 32 && j < R) jb.db0[q][j] += b0;
+}
+
 static int g_colp_rpt = 4;          // rows per trip of the BatchNorm-backward statistics pass (ha2g_bn_debug_rows_per_trip: A/B of the loads in flight per wave)
 inline int chunk_blocks(long rows) {
     long b = rows / 512;
@@ -1130,6 +1177,25 @@ int ha2g_bn_image_partials_f32(const float* x, int N, int HW, int C, double* par
     if (N == 0) return 0;
     hipLaunchKernelGGL(bn_image_partial_kernel, dim3(pool_chunks(N, HW), N), dim3(256), 0, (hipStream_t)stream, x, HW, C, part);
     HA2G_CHECK_LAUNCH("bn_image_partials");
+    return 0;
+}
+// ha2g_se_mlp_wgrad_f32 for n <= 16 blocks in one launch: HOST arrays of n device pointers / widths; every job's batch is N images
+int ha2g_se_mlp_wgrad_multi_f32(int n, const void* const* dsc, const void* const* h1, const void* const* dh1, const void* const* pooled, void* const* dw2,
+                                void* const* db2, void* const* dw0, void* const* db0, const int* C, const int* R, int N, void* stream) {
+    HA2G_REQUIRE(n >= 0 && n <= 16, "se_mlp_wgrad_multi: %d jobs (max 16)", n);
+    if (n == 0 || N == 0) return 0;
+    SeWgradJobs jb{};
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        HA2G_REQUIRE(C[i] >= 1 && C[i] <= 256 && R[i] >= 1 && R[i] <= 32, "se_mlp_wgrad_multi: unsupported widths C = %d, R = %d", C[i], R[i]);
+        jb.dsc[i] = (const float*)dsc[i]; jb.h1[i] = (const float*)h1[i]; jb.dh1[i] = (const float*)dh1[i]; jb.pooled[i] = (const float*)pooled[i];
+        jb.dw2[i] = (float*)dw2[i]; jb.db2[i] = (float*)db2[i]; jb.dw0[i] = (float*)dw0[i]; jb.db0[i] = (float*)db0[i];
+        jb.C[i] = C[i]; jb.R[i] = R[i]; jb.start[i] = total;
+        total += ceil_div(C[i], 8);
+    }
+    jb.start[n] = total;
+    hipLaunchKernelGGL(se_mlp_wgrad_multi_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, jb, n, N);
+    HA2G_CHECK_LAUNCH("se_mlp_wgrad_multi");
     return 0;
 }
 // ---- SE backward + bn2 backward in two passes (round 6; see se_bn_reduce_kernel) ----

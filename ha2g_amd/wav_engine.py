@@ -324,6 +324,7 @@ JOIN_DGRAD = 0             # round-6 experiment: 1 = the main stream waits for t
                            # BatchNorm / SE passes then run with no weight gradient beside them); 0 = one join at the end
 SE_BWD_FOLD = True         # the SE backward's reduction finishes inside the excitation MLP's backward launch (round 6: -16 launches, same bits)
 SE_BN2_FUSED = True    # SE backward + bn2 backward in two passes, bn2's dy never stored (ha2g_se_bn_bwd_*; A/B switch)
+SE_WGRAD_BATCH = True      # ... of all blocks of the tower in ONE launch after its backward is enqueued (GradSink.flush_se; round 6)
 SE_WGRAD_FUSED = True      # the SE excitation MLP's four parameter gradients in one launch (GradSink.gse)
 
 
@@ -459,6 +460,14 @@ class GradSink:
             self.gwb(names[2], names[3], dh1, pooled)
             return
         side_on = SIDE_FC_WGRAD and SIDE_WGRAD and ops.side.enabled
+        if SE_WGRAD_BATCH:
+            # kept until the trunk's backward is enqueued: one launch for all blocks (flush_se, from join())
+            if not hasattr(self, 'se_jobs'):
+                self.se_jobs = []
+            if self.se_jobs and (self.se_jobs[0][0].shape[0] != N or len(self.se_jobs) == 16):
+                self.flush_se()
+            self.se_jobs.append((dsc, h1, dh1, pooled, tg))
+            return
         with (ops.side.section(dsc.device) if side_on else ops._null()):
             if side_on:
                 st = ops.cur_stream(dsc.device)
@@ -531,7 +540,33 @@ class GradSink:
         if r is not None:
             self.G[name] = r
 
+    def flush_se(self):
+        """the SE excitation MLPs' parameter gradients gse() collected: ONE launch (ha2g_se_mlp_wgrad_multi_f32), on the side stream when that is on"""
+        jobs = getattr(self, 'se_jobs', None)
+        if not jobs:
+            return
+        import numpy as np
+        self.se_jobs = []
+        dev = jobs[0][0].device
+        n = len(jobs)
+        ptr = np.empty((8, n), np.int64)
+        Cs, Rs = np.empty(n, np.int32), np.empty(n, np.int32)
+        for i, (dsc, h1, dh1, pooled, tg) in enumerate(jobs):
+            ptr[:, i] = (dsc.data_ptr(), h1.data_ptr(), dh1.data_ptr(), pooled.data_ptr(), tg[0].data_ptr(), tg[1].data_ptr(), tg[2].data_ptr(), tg[3].data_ptr())
+            Cs[i], Rs[i] = dsc.shape[1], h1.shape[1]
+        side_on = SIDE_FC_WGRAD and SIDE_WGRAD and ops.side.enabled
+        with (ops.side.section(dev) if side_on else ops._null()):
+            if side_on:
+                st = ops.cur_stream(dev)
+                for job in jobs:
+                    for t in job[:4]:
+                        t.record_stream(st)
+            check(lib.ha2g_se_mlp_wgrad_multi_f32(n, *(ptr[k].ctypes.data for k in range(8)), Cs.ctypes.data, Rs.ctypes.data, jobs[0][0].shape[0], _stream()))
+        if side_on:
+            self.forked = True
+
     def join(self, device):
+        self.flush_se()
         if getattr(self, 'forked', False):
             ops.side.join(device)
             self.forked = False

@@ -380,6 +380,10 @@ int ha2g_se_mlp_bwd_f32(const float* dsc, const float* h1, const float* w2, cons
  * sums of dh1; dsc [N][C], h1 / dh1 [N][R], pooled [N][C].  Replaces two ha2g_gemm_wgrad_bias_f32 launches per block. */
 int ha2g_se_mlp_wgrad_f32(const float* dsc, const float* h1, const float* dh1, const float* pooled, float* dw2, float* db2, float* dw0, float* db0,
                           int N, int C, int R, void* stream);
+/* ABI 6: ha2g_se_mlp_wgrad_f32 of n <= 16 blocks in ONE launch (HOST arrays of n device pointers / widths; every block's batch is N images): the tower's
+ * sixteen SE layers after its backward is enqueued instead of sixteen small launches between the convolutions' weight gradients. */
+int ha2g_se_mlp_wgrad_multi_f32(int n, const void* const* dsc, const void* const* h1, const void* const* dh1, const void* const* pooled, void* const* dw2,
+                                void* const* db2, void* const* dw0, void* const* db0, const int* C, const int* R, int N, void* stream);
 /* ABI 5: ha2g_se_bwd_scale[_bn]_f32 + ha2g_se_mlp_bwd_f32 as two launches instead of three (the reduction's final pass runs inside the MLP launch; ds is
  * still written).  mean == NULL: x = bn2's output; else x = bn2's input and bn2 is applied on the fly (mean / invstd / gamma / beta). */
 int ha2g_se_bwd_scale_mlp_f32(const float* dout, const float* out, const float* x, const float* mean, const float* invstd, const float* gamma,

@@ -783,6 +783,41 @@ def test_se_mlp_parameter_gradients_in_one_launch(N, C, R):
 
 
 @pytest.mark.gpu
+def test_se_mlp_parameter_gradients_of_sixteen_blocks_in_one_launch_are_bit_identical():
+    """ha2g_se_mlp_wgrad_multi_f32 (round 6): the tower's sixteen SE layers (widths 32 / 64 / 128 / 256, reduction 8) in one launch == sixteen
+    ha2g_se_mlp_wgrad_f32 launches, bit for bit; through GradSink.gse / flush_se as the step calls it."""
+    import numpy as np
+    from ha2g_amd._lib import check, lib
+    from ha2g_amd.ops import _stream
+    N = 24
+    g = torch.Generator(device='cuda:0').manual_seed(5)
+    widths = [32] * 3 + [64] * 4 + [128] * 6 + [256] * 3
+    jobs, one, multi = [], [], []
+    for C in widths:
+        R = C // 8
+        dsc, pooled = torch.randn(N, C, device='cuda:0', generator=g), torch.randn(N, C, device='cuda:0', generator=g)
+        h1, dh1 = torch.randn(N, R, device='cuda:0', generator=g).clamp_min(0), torch.randn(N, R, device='cuda:0', generator=g)
+        init = [torch.randn(C, R, device='cuda:0', generator=g), torch.randn(C, device='cuda:0', generator=g),
+                torch.randn(R, C, device='cuda:0', generator=g), torch.randn(R, device='cuda:0', generator=g)]
+        jobs.append((dsc, h1, dh1, pooled))
+        one.append([t.clone() for t in init])
+        multi.append([t.clone() for t in init])
+    for (dsc, h1, dh1, pooled), o in zip(jobs, one):
+        check(lib.ha2g_se_mlp_wgrad_f32(dsc.data_ptr(), h1.data_ptr(), dh1.data_ptr(), pooled.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
+                                        o[3].data_ptr(), N, dsc.shape[1], h1.shape[1], _stream()))
+    n = len(jobs)
+    ptr = np.empty((8, n), np.int64)
+    for i, (job, o) in enumerate(zip(jobs, multi)):
+        ptr[:, i] = [t.data_ptr() for t in job] + [t.data_ptr() for t in o]
+    Cs, Rs = np.array(widths, np.int32), np.array([c // 8 for c in widths], np.int32)
+    check(lib.ha2g_se_mlp_wgrad_multi_f32(n, *(ptr[k].ctypes.data for k in range(8)), Cs.ctypes.data, Rs.ctypes.data, N, _stream()))
+    for a, b in zip(one, multi):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert lib.ha2g_se_mlp_wgrad_multi_f32(17, *(ptr[k].ctypes.data for k in range(8)), Cs.ctypes.data, Rs.ctypes.data, N, _stream()) != 0      # > 16 jobs: refused
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('geom', [(4, 128, 70), (3, 64, 35), (2, 40, 37), (5, 128, 70)])
 def test_c32_weight_gradient_prefetching_form_is_bit_identical(geom):
     """Round 6: the 32-channel three-piece weight gradient (layer 1 of the tower, side queue) loads the NEXT tile's patch and dy strip into registers in front
