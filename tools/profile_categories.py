@@ -17,7 +17,7 @@ def cat(n):
         mm = re.search(r'ILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)', n)
         return 'conv dgrad (split implicit GEMM, gemm_x3)' if int(mm.group(5)) == 2 else 'dense GEMM'
     for key, name in (('pconv_r_kernel', 'patch-resident plane kernel (3x3 stride-1 conv fwd / dgrad of layers 2-4)'), ('pconv_q_kernel', 'plane kernel (1x1 / stride-2 convs + large dense products, 16x16x32)'), ('pack_whh', 'layout (shuffle/pack/permute)'),
-                      ('se_mlp', 'SE pointwise'), ('gen_concat', 'pointwise (act bwd, adds, masks)'), ('step_inc', 'Adam'),
+                      ('se_bn_', 'SE + bn2 backward in two passes (round 6)'), ('se_mlp', 'SE pointwise'), ('gen_concat', 'pointwise (act bwd, adds, masks)'), ('step_inc', 'Adam'),
                       ('pconv_kernel', 'conv fwd + dgrad (planes, DMA-staged)'), ('pconv_pp_kernel', 'conv fwd + dgrad (planes, DMA-staged)'), ('pconv_wgrad', 'conv wgrad (planes, DMA-staged)'),
                       ('weight_ihwo_planes', 'layout (shuffle/pack/permute)'), ('f32_to_planes', 'layout (shuffle/pack/permute)'),
                       ('conv3x3_c32_wgrad', 'conv 32ch direct (fwd / dgrad / wgrad)'), ('conv3x3_c32pp', 'conv 32ch direct (fwd / dgrad / wgrad)'), ('conv3x3_x3p', 'conv 32ch direct (fwd / dgrad / wgrad)'), ('conv3x3_c32_kernel', 'conv 32ch direct (fwd / dgrad / wgrad)'),
