@@ -466,6 +466,8 @@ def main():
             return dict(kernel=kernel, bound='hbm', achieved=round(ach, 1), peak=8000.0, unit='GB/s', frac=round(ach / 8000.0, 4), launches=n,
                         mean_us=round(mean_us, 1), traffic=None, note='algorithmic bytes per pass; tensors of layers 2-4 (<= 73 MB) are served by the 256 MB Infinity Cache')
         roof_bn = hbm('bn_bwd', 'col_partial_kernel<1> + pair_final + bn_bwd_apply_kernel (ha2g_bn_bwd[_planes]_f32: BatchNorm backward, 3 launches)')
+        roof_se_bn = hbm('se_bn_bwd_apply', 'pair_final + se_bn_bwd_apply_kernel (ha2g_se_bn_bwd_apply_np_f32: SE tail + bn2 backward, apply pass of the two-pass form)')
+        roof_se_bn_reduce = hbm('se_bn_bwd_reduce', 'se_bn_reduce_kernel + se_bn_mlp_bwd_kernel (ha2g_se_bn_bwd_reduce_mlp_f32: reduction pass of the two-pass form + the excitation MLP backward)')
         roof_bn_stats = hbm('bn_stats', 'col_partial_kernel<0> + bn_stats_final (ha2g_bn_stats_f32: BatchNorm forward statistics)')
         if b16_storage:                              # bf16-storage mode: the same passes over 2-byte tensors, bf16 single-plane matrix kernels
             roof_bn = hbm('bn_bwd_b16', 'col_partial_kernel<1,b16> + pair_final + bn_bwd_apply_kernel<0,b16> (ha2g_bn_bwd_b16: BatchNorm backward over bf16 tensors)')
@@ -514,7 +516,7 @@ def main():
                                             if a.epoch > args.loss_warmup else 'warm-up phase (epoch %d)' % a.epoch),
                                global_batch=a.batch * world, parallelism='dp%d' % world,
                                word_embedding_updates='row-wise (compact gradients, lazy Adam; bit-identical to dense)' if tr.sparse_embeddings else 'dense'),
-                   gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, roofline_bwd=roof_bwd, roofline_gemm=roof_gemm, roofline_conv=roof_conv, roofline_conv_fp32=roof_conv_fp32, roofline_bwd_gemm=roof_bwd_gemm, roofline_bwd_wgrad=roof_bwd_wgrad, roofline_bn=roof_bn, roofline_bn_stats=roof_bn_stats, roofline_pass='separate untimed pass of %d eager steps, HIP events around each launch on its launch stream' % k_roof, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
+                   gru_cluster_handoff_timeouts=ops.gru_cluster_error(dev), roofline=roof, roofline_bwd=roof_bwd, roofline_gemm=roof_gemm, roofline_conv=roof_conv, roofline_conv_fp32=roof_conv_fp32, roofline_bwd_gemm=roof_bwd_gemm, roofline_bwd_wgrad=roof_bwd_wgrad, roofline_bn=roof_bn, roofline_bn_stats=roof_bn_stats, roofline_se_bn=roof_se_bn, roofline_se_bn_reduce=roof_se_bn_reduce, roofline_pass='separate untimed pass of %d eager steps, HIP events around each launch on its launch stream' % k_roof, kernel_times_us={k: [v[0], round(v[1], 1)] for k, v in kt.items()}, last_step=last)
         if world == 1 and not a.no_cpu_baseline and not a.expressive:
             out['cpu_baseline'] = cpu_baseline(a.epoch, a.n_words, a.n_spk)
         def _clean(o):                                   # NaN (a leg that was not run) is not JSON: null instead

@@ -582,7 +582,8 @@ class GradSink:
         dxo = torch.empty_like(x) if need_dx else None
         pl = torch.empty(ops.pieces(), N * OH * OW, C, dtype=torch.bfloat16, device=x.device) if planes else None
         dgamma, dbeta = empty(C, like=x), empty(C, like=x)
-        nb_ = 4.0 * x.numel() * (4 + (1 if need_dx else 0)) + (2.0 * pl.shape[0] * x.numel() if planes else 0.0)
+        # algorithmic HBM bytes (bench.py roofline_se_bn): reads dout and x (+ the decision bits or `out`), writes dres (+ dx) (+ the piece planes)
+        nb_ = 4.0 * x.numel() * (3 + (1.0 / 32 if mask_bits is not None else 1) + (1 if need_dx else 0)) + (2.0 * pl.shape[0] * x.numel() if planes else 0.0)
         ops.ktimer.launch('se_bn_bwd_apply', lambda: check(lib.ha2g_se_bn_bwd_apply_np_f32(
             dout.data_ptr(), out.data_ptr(), x.data_ptr(), sc.data_ptr(), dpool.data_ptr(), mean.data_ptr(), invstd.data_ptr(), bn.gamma.data_ptr(),
             dres.data_ptr(), _p(dxo), _p(pl), pl.stride(0) if planes else 0, pl.shape[0] if planes else 0, dgamma.data_ptr(), dbeta.data_ptr(),
@@ -739,9 +740,10 @@ def block_bwd(dx, saved, P, b, sink):
         assert lib.ha2g_se_bn_bwd_workspace_floats(N, HW, C) <= ws.numel()
         dh1, dpool = torch.empty_like(h1), torch.empty_like(ds)
         stat = torch.empty(2 * C * N, dtype=torch.float64, device=dout.device)
-        check(lib.ha2g_se_bn_bwd_reduce_mlp_f32(dout.data_ptr(), out.data_ptr(), c2.data_ptr(), m2.data_ptr(), s2.data_ptr(), bn2.gamma.data_ptr(),
-                                                bn2.beta.data_ptr(), ds.data_ptr(), N, HW, C, sc.data_ptr(), ws.data_ptr(), h1.data_ptr(), w2_.data_ptr(),
-                                                w0_.data_ptr(), dh1.data_ptr(), dpool.data_ptr(), h1.shape[1], stat.data_ptr(), _p(mb), _stream()))
+        ops.ktimer.launch('se_bn_bwd_reduce', lambda: check(lib.ha2g_se_bn_bwd_reduce_mlp_f32(
+            dout.data_ptr(), out.data_ptr(), c2.data_ptr(), m2.data_ptr(), s2.data_ptr(), bn2.gamma.data_ptr(), bn2.beta.data_ptr(), ds.data_ptr(), N, HW, C,
+            sc.data_ptr(), ws.data_ptr(), h1.data_ptr(), w2_.data_ptr(), w0_.data_ptr(), dh1.data_ptr(), dpool.data_ptr(), h1.shape[1], stat.data_ptr(), _p(mb),
+            _stream())), 4.0 * c2.numel() * (2 + (1.0 / 32 if mb is not None else 1)))
         sink.gse(b, ds, h1, dh1, pooled)
         dres = torch.empty_like(c2)
         dc2, dc2p = sink.gbn_se(b + 'bn2', dout, out, c2, sc, dpool, m2, s2, dres, stat, planes=p2, need_dx=f2, mask_bits=mb)
