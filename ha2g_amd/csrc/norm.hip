@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
 //   bn2: sum_hw dz        = s A1 + HW dpool,   sum_hw dz * xhat = s A2 + dpool A3
 // so the pass that WROTE dz (se_bwd_apply) and the column pass that READ it back with c2 (col_partial<1>) disappear: two passes over three tensors
 // (reduce, apply) instead of four over nine tensor reads.  All sums in double, fixed order (chunks ascending, images ascending): deterministic.
-template <bool BITS>
+template <bool BITS, int RPT = 4>
 __global__ __launch_bounds__(256) void se_bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dout, const float* __restrict__ outp,
                                                            int HW, int C, double* __restrict__ part, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const unsigned* __restrict__ mbits) {
@@ -638,16 +638,16 @@ __global__ __launch_bounds__(256) void se_bn_reduce_kernel(const float* __restri
         return (o.v[0] > 0.f ? 1u : 0u) | (o.v[1] > 0.f ? 2u : 0u) | (o.v[2] > 0.f ? 4u : 0u) | (o.v[3] > 0.f ? 8u : 0u);
     };
     int r = rbeg + m.r0;
-    for (; r + 3 * m.rstep < rend; r += 4 * m.rstep) {                        // twelve (BITS: eight + four 4-byte) loads in flight per thread
-        fvec<4> v[4], d[4];
-        unsigned bt[4];
+    for (; r + (RPT - 1) * m.rstep < rend; r += RPT * m.rstep) {              // RPT = 4: twelve (BITS: eight + four 4-byte) loads in flight per thread
+        fvec<4> v[RPT], d[RPT];
+        unsigned bt[RPT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < RPT; ++j) {
             const long off = base + (long)(r + j * m.rstep) * C;
             v[j] = ldv(x + off, m.cv); d[j] = ldv(dout + off, m.cv); bt[j] = decisions(off);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) accum(v[j], d[j], bt[j]);
+        for (int j = 0; j < RPT; ++j) accum(v[j], d[j], bt[j]);
     }
     for (; r < rend; r += m.rstep) {
         const long off = base + (long)r * C;
@@ -1199,6 +1199,9 @@ int ha2g_se_mlp_wgrad_multi_f32(int n, const void* const* dsc, const void* const
     return 0;
 }
 // ---- SE backward + bn2 backward in two passes (round 6; see se_bn_reduce_kernel) ----
+static int g_sebn_rpt = 4, g_sebn_chunk_shift = 0;
+// A/B of the reduction pass: rows per trip (4 | 2: 126 | fewer registers per wave) and chunks per image halved `chunk_shift` times (longer loops per block)
+void ha2g_se_bn_debug(int rpt, int chunk_shift) { g_sebn_rpt = rpt == 2 ? 2 : 4; g_sebn_chunk_shift = chunk_shift < 0 ? 0 : (chunk_shift > 4 ? 4 : chunk_shift); }
 // floats of workspace ha2g_se_bn_bwd_reduce_mlp_f32 needs
 long ha2g_se_bn_bwd_workspace_floats(int N, int HW, int C) { return (long)N * pool_chunks(N, HW) * 3 * C * 2; }
 // Reduction pass + excitation MLP backward.  x = bn2's INPUT (conv2's output) [N][HW][C], mean / invstd / gamma / beta = bn2's; gate = the SE gate [N][C];
@@ -1213,8 +1216,11 @@ int ha2g_se_bn_bwd_reduce_mlp_f32(const float* dout, const float* out, const flo
                  "se_bn_bwd: null workspace / gate / statistics / BatchNorm parameter");
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const int nchunk = pool_chunks(N, HW);
-    if (mask_bits != nullptr)
+    int nchunk = pool_chunks(N, HW) >> g_sebn_chunk_shift;
+    if (nchunk < 1) nchunk = 1;
+    if (mask_bits != nullptr && g_sebn_rpt == 2)
+        hipLaunchKernelGGL((se_bn_reduce_kernel<true, 2>), dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, (double*)ws, mean, invstd, (const unsigned*)mask_bits);
+    else if (mask_bits != nullptr)
         hipLaunchKernelGGL(se_bn_reduce_kernel<true>, dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, (double*)ws, mean, invstd, (const unsigned*)mask_bits);
     else
         hipLaunchKernelGGL(se_bn_reduce_kernel<false>, dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, (double*)ws, mean, invstd, (const unsigned*)nullptr);

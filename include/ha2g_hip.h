@@ -405,6 +405,7 @@ int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, c
 int ha2g_bn_image_partial_chunks(int N, int HW);
 int ha2g_bn_image_partials_f32(const float* x, int N, int HW, int C, double* part, void* stream);
 long ha2g_se_bn_bwd_workspace_floats(int N, int HW, int C);
+void ha2g_se_bn_debug(int rows_per_trip, int chunk_shift);   /* A/B of the reduction pass (4 | 2 rows of loads in flight; chunks per image >> chunk_shift); default (4, 0) */
 int ha2g_se_bn_bwd_reduce_mlp_f32(const float* dout, const float* out, const float* x, const float* mean, const float* invstd, const float* gamma,
                                   const float* beta, float* ds, int N, int HW, int C, const float* gate, float* ws, const float* h1, const float* w2,
                                   const float* w0, float* dh1, float* dpool, int R, double* stat, const void* mask_bits, void* stream);
