@@ -1234,6 +1234,93 @@ def _pack3_multi(whh, L, H, transposed, dev, st):
     return out
 
 
+GRU_PREFETCH = False      # (measured: 34.66 / 34.77 / 34.49 with, 34.71 / 34.48 / 34.23 ms without -- nothing; off)  the weight images a GRU stack's forward AND backward need (W_hh packs, W_ih piece planes and their transposes) prepared at the start
+                          # of the step on the side stream, beside the audio tower's forward (prefetch_gru; A/B switch)
+_GRU_PREP = {}            # data_ptr of weight_hh_l0 -> _GruPrep of the CURRENT step (rng.step_token)
+
+
+class _GruPrep:
+    __slots__ = ('token', 'H', 'L', 'T', 'rows', 'fwd', 'bwd')
+
+
+def _gru_prep_fwd(weights, H, L, T, rows, dev, st):
+    """(pk_all, pk3_all, wih_planes, bcat_all): what BiGRUFunction.forward builds from the weights alone before its first product"""
+    npk = lib.ha2g_gru_packed_floats(H)
+    pk_all = None
+    if PACK_MULTI and 2 * L <= 16:
+        # all layers' / directions' W_hh images from ONE launch at the start of the stack (two per layer sat between the recurrences)
+        import numpy as np
+        pk_all = torch.empty(L, 4, npk, dtype=torch.float32, device=dev)
+        wl = [weights[8 * l + 4 * d + 1].contiguous() for l in range(L) for d in range(2)]
+        wp_ = np.array([t.data_ptr() for t in wl], np.int64)
+        pf_ = np.array([pk_all[l, d].data_ptr() for l in range(L) for d in range(2)], np.int64)
+        pb_ = np.array([pk_all[l, 2 + d].data_ptr() for l in range(L) for d in range(2)], np.int64)
+        check(lib.ha2g_gru_pack_whh_multi(wp_.ctypes.data, pf_.ctypes.data, pb_.ctypes.data, 2 * L, H, st))
+    pk3_all = None
+    if PACK_MULTI and 2 * L <= 16 and gru_fwd3_active(H, T):
+        # ... and their three-piece images (bf16 A fragments of the cluster kernel) likewise: one launch instead of two per layer
+        pk3_all = _pack3_multi([weights[8 * l + 4 * d + 1] for l in range(L) for d in range(2)], L, H, False, dev, st)
+    # layers 1 .. L-1 (input = 2H columns): the merged operands [W_ih; W_ih_reverse] of ALL of them as piece planes from ONE launch, their merged biases
+    # from one cat (a cat of the weights, a cat of the biases and a split launch per layer before: round 6)
+    wih_planes = bcat_all = None
+    Kp2 = (2 * H + 31) // 32 * 32
+    if (GRU_STACK_PREP and GRU_MERGE_DIRS and L > 1 and dev.type == 'cuda' and 2 * H >= 256 and 2.0 * rows * 6 * H * 2 * H >= PLANE_GEMM_MIN_FLOP
+            and PLANE_GEMM and lib.ha2g_gemm_bwd_pieces() == 3 and 2 * (L - 1) <= 16
+            and all(weights[8 * l + 4 * d].is_contiguous() and weights[8 * l + 4 * d].data_ptr() % 16 == 0 for l in range(1, L) for d in range(2))):
+        wih_planes = torch.empty(L - 1, 3, 6 * H, Kp2, dtype=torch.bfloat16, device=dev)
+        mats = [weights[8 * l + 4 * d] for l in range(1, L) for d in range(2)]
+        wins = [wih_planes[l - 1, 0, 3 * H * d].data_ptr() for l in range(1, L) for d in range(2)]
+        split2d_multi(mats, wins, wih_planes.stride(1), Kp2, [Kp2] * len(mats), False)
+        bcat_all = torch.cat([weights[8 * l + 4 * d + 2] for l in range(1, L) for d in range(2)]).view(L - 1, 6 * H)
+    return pk_all, pk3_all, wih_planes, bcat_all
+
+
+def _gru_prep_bwd(weights, H, L, T, dev, st, planes):
+    """(wih_t_planes, pk3t_all): what BiGRUFunction.backward builds from the weights alone; planes = the forward ran layers >= 1 on piece planes"""
+    wih_t_planes = None
+    if planes:
+        # dX = dg[:, :6H] @ [W_ih; W_ih_reverse]: the B operand's planes hold its transpose [K][6H -> Kp6]; both directions of every layer >= 1 from one launch
+        Kp6 = (6 * H + 31) // 32 * 32
+        wih_t_planes = torch.empty(L - 1, 3, 2 * H, Kp6, dtype=torch.bfloat16, device=dev)
+        mats = [weights[8 * l + 4 * d] for l in range(1, L) for d in range(2)]
+        wins = [wih_t_planes[l - 1, 0, 0, 3 * H * d].data_ptr() for l in range(1, L) for d in range(2)]
+        split2d_multi(mats, wins, wih_t_planes.stride(1), Kp6, [3 * H if d == 0 else Kp6 - 3 * H for l in range(1, L) for d in range(2)], True)
+    pk3t_all = None
+    if PACK_MULTI and 2 * L <= 16 and gru_fwd3_active(H, T):      # the transposed three-piece W_hh images of every layer: one launch
+        pk3t_all = _pack3_multi([weights[8 * l + 4 * d + 1] for l in range(L) for d in range(2)], L, H, True, dev, st)
+    return wih_t_planes, pk3t_all
+
+
+def prefetch_gru(weights, H, T, rows, consumer_stream=None):
+    """Prepare the weight images of one GRU stack for THIS step's forward (at `rows` = B * T rows) and backward; call inside side.section() at the start of
+    the step (the weights do not change until the optimizers run) and side.join() before the stack's forward.  A forward whose shapes differ, or a later
+    step, does not find the entry and prepares in line as before."""
+    weights = list(weights)
+    L = len(weights) // 8
+    dev = weights[0].device
+    st = _stream()
+    p = _GruPrep()
+    p.token, p.H, p.L, p.T, p.rows = rng.step_token, H, L, T, rows
+    p.fwd = _gru_prep_fwd(weights, H, L, T, rows, dev, st)
+    p.bwd = _gru_prep_bwd(weights, H, L, T, dev, st, p.fwd[2] is not None)
+    if consumer_stream is not None:                       # allocated under the side stream, read by the consumer's: the caching allocator must know
+        for t in p.fwd + p.bwd:
+            if t is not None:
+                t.record_stream(consumer_stream)
+    _GRU_PREP[weights[1].data_ptr()] = p
+
+
+def _gru_prep_lookup(weights, H, L, T, rows, dev):
+    p = _GRU_PREP.get(weights[1].data_ptr()) if (GRU_PREFETCH and _GRU_PREP) else None
+    if p is None or p.token != rng.step_token or (p.H, p.L, p.T) != (H, L, T) or (rows is not None and p.rows != rows):
+        return None
+    return p
+
+
+def gru_prep_clear():
+    _GRU_PREP.clear()
+
+
 class BiGRUFunction(torch.autograd.Function):
     """Stacked bidirectional GRU (batch_first, h0 = 0).  forward(x, masks, H, grad_slice, *weights): weights in torch
     `_flat_weights` order (per layer, per direction: w_ih, w_hh, b_ih, b_hh); masks = tuple of pre-scaled
@@ -1253,32 +1340,11 @@ class BiGRUFunction(torch.autograd.Function):
         inp = x.contiguous()
         packs = []
         wcats = [None] * L
-        pk_all = None
-        if PACK_MULTI and 2 * L <= 16:
-            # all layers' / directions' W_hh images from ONE launch at the start of the stack (two per layer sat between the recurrences)
-            import numpy as np
-            pk_all = torch.empty(L, 4, npk, dtype=torch.float32, device=dev)
-            wl = [weights[8 * l + 4 * d + 1].contiguous() for l in range(L) for d in range(2)]
-            wp_ = np.array([t.data_ptr() for t in wl], np.int64)
-            pf_ = np.array([pk_all[l, d].data_ptr() for l in range(L) for d in range(2)], np.int64)
-            pb_ = np.array([pk_all[l, 2 + d].data_ptr() for l in range(L) for d in range(2)], np.int64)
-            check(lib.ha2g_gru_pack_whh_multi(wp_.ctypes.data, pf_.ctypes.data, pb_.ctypes.data, 2 * L, H, st))
-        pk3_all = None
-        if PACK_MULTI and 2 * L <= 16 and gru_fwd3_active(H, T):
-            # ... and their three-piece images (bf16 A fragments of the cluster kernel) likewise: one launch instead of two per layer
-            pk3_all = _pack3_multi([weights[8 * l + 4 * d + 1] for l in range(L) for d in range(2)], L, H, False, dev, st)
-        # layers 1 .. L-1 (input = 2H columns): the merged operands [W_ih; W_ih_reverse] of ALL of them as piece planes from ONE launch, their merged biases
-        # from one cat (a cat of the weights, a cat of the biases and a split launch per layer before: round 6)
-        wih_planes = bcat_all = None
-        Kp2 = (2 * H + 31) // 32 * 32
-        if (GRU_STACK_PREP and GRU_MERGE_DIRS and L > 1 and dev.type == 'cuda' and 2 * H >= 256 and 2.0 * B * T * 6 * H * 2 * H >= PLANE_GEMM_MIN_FLOP
-                and PLANE_GEMM and lib.ha2g_gemm_bwd_pieces() == 3 and 2 * (L - 1) <= 16
-                and all(weights[8 * l + 4 * d].is_contiguous() and weights[8 * l + 4 * d].data_ptr() % 16 == 0 for l in range(1, L) for d in range(2))):
-            wih_planes = torch.empty(L - 1, 3, 6 * H, Kp2, dtype=torch.bfloat16, device=dev)
-            mats = [weights[8 * l + 4 * d] for l in range(1, L) for d in range(2)]
-            wins = [wih_planes[l - 1, 0, 3 * H * d].data_ptr() for l in range(1, L) for d in range(2)]
-            split2d_multi(mats, wins, wih_planes.stride(1), Kp2, [Kp2] * len(mats), False)
-            bcat_all = torch.cat([weights[8 * l + 4 * d + 2] for l in range(1, L) for d in range(2)]).view(L - 1, 6 * H)
+        pre = _gru_prep_lookup(weights, H, L, T, B * T, dev)
+        if pre is not None:                               # prepared on the side stream while the audio tower ran (prefetch_gru, round 6)
+            pk_all, pk3_all, wih_planes, bcat_all = pre.fwd
+        else:
+            pk_all, pk3_all, wih_planes, bcat_all = _gru_prep_fwd(weights, H, L, T, B * T, dev, st)
         for l in range(L):
             w = [t.contiguous() for t in weights[8 * l:8 * l + 8]]
             K = inp.shape[2]
@@ -1345,17 +1411,12 @@ class BiGRUFunction(torch.autograd.Function):
         keep = []
         fused_b = []
         all_tgs = []                                       # the .grad buffers the side-stream sections below accumulate into (SideStream.touch)
-        wih_t_planes = None
-        if any(isinstance(c, str) for c in ctx.wcats):
-            # dX = dg[:, :6H] @ [W_ih; W_ih_reverse]: the B operand's planes hold its transpose [K][6H -> Kp6]; both directions of every layer >= 1 from one launch
-            Kp6 = (6 * H + 31) // 32 * 32
-            wih_t_planes = torch.empty(L - 1, 3, 2 * H, Kp6, dtype=torch.bfloat16, device=dev)
-            mats = [weights[8 * l + 4 * d] for l in range(1, L) for d in range(2)]
-            wins = [wih_t_planes[l - 1, 0, 0, 3 * H * d].data_ptr() for l in range(1, L) for d in range(2)]
-            split2d_multi(mats, wins, wih_t_planes.stride(1), Kp6, [3 * H if d == 0 else Kp6 - 3 * H for l in range(1, L) for d in range(2)], True)
-        pk3t_all = None
-        if PACK_MULTI and 2 * L <= 16 and gru_fwd3_active(H, T):      # the transposed three-piece W_hh images of every layer: one launch
-            pk3t_all = _pack3_multi([weights[8 * l + 4 * d + 1] for l in range(L) for d in range(2)], L, H, True, dev, st)
+        need_planes = any(isinstance(c, str) for c in ctx.wcats)
+        pre = _gru_prep_lookup(weights, H, L, T, None, dev)
+        if pre is not None and (pre.bwd[0] is not None) == need_planes:
+            wih_t_planes, pk3t_all = pre.bwd                  # prepared at the start of the step (prefetch_gru)
+        else:
+            wih_t_planes, pk3t_all = _gru_prep_bwd(weights, H, L, T, dev, st, need_planes)
         for l in range(L - 1, -1, -1):
             inp, y, rs = (t[sl] for t in ctx.saved_bufs[l])
             w = weights[8 * l:8 * l + 8]
