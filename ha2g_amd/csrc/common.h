@@ -28,7 +28,8 @@ int ha2g_set_error(int code, const char* fmt, ...);
 int conv3x3_c32_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta,
                               hipStream_t st);
 int conv3x3_c32_x3_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta,
-                          hipStream_t st);
+                          hipStream_t st, const float* rsd = nullptr, const unsigned* rbits = nullptr);
+int conv3x3_c32pp_serves(int H, int W);
 int gemm_split_dgrad_enabled();      // gemm.hip: ha2g_gemm_set_mode bit 2 (and not the plain-bf16 mode)
 extern int g_side_cus;      // conv_planes.hip: ha2g_side_cus
 int conv3x3_c32_wgrad_blocks(int N, int H, int W);

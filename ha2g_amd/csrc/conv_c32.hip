@@ -496,7 +496,8 @@ __device__ __forceinline__ int fast_div_c32(int m, int d, unsigned mg) {
     return q;
 }
 __global__ __launch_bounds__(512, 1) void conv3x3_c32pp_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H,
-                                                               int W, int flip, int act, float beta, int plane_elems, unsigned mgW) {
+                                                               int W, int flip, int act, float beta, int plane_elems, unsigned mgW,
+                                                               const float* __restrict__ rsd, const unsigned* __restrict__ rbits) {
     constexpr int NP = 3, C = 32, NSF = 12;
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(1024))) unsigned short ppl[];          // [group][piece][plane_elems]
@@ -658,6 +659,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c32pp_kernel(const float* __re
             f32x4_t v = acc[i];
             f32x4_t* d = reinterpret_cast<f32x4_t*>(yout + (long)p * C);
             if (beta != 0.f) v += beta * *d;
+            if (rsd != nullptr) {
+                // masked residual (round 6; the block's identity shortcut under autograd, ResNetBlocks.py:34-36): y = conv + (out > 0 ? dout : 0) with the
+                // decisions from the forward tail's bit words -- what "beta = 1 onto dres" added, without dres ever being written
+                const long e = (yout - y) + (long)p * C;
+                const f32x4_t dd = *reinterpret_cast<const f32x4_t*>(rsd + e);
+                const long vi = e >> 2;
+                const unsigned b = (rbits[vi >> 3] >> (4 * (int)(vi & 7))) & 15u;
+                v[0] += (b & 1u) ? dd[0] : 0.f; v[1] += (b & 2u) ? dd[1] : 0.f; v[2] += (b & 4u) ? dd[2] : 0.f; v[3] += (b & 8u) ? dd[3] : 0.f;
+            }
             if ((act & 15) == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
             *d = v;
         }
@@ -1022,7 +1032,18 @@ static int conv3x3_x3p_launch(const float* x, const float* w, float* y, int N, i
     HA2G_CHECK_LAUNCH("conv3x3_x3p");
     return 0;
 }
-static int conv3x3_c32pp_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st) {
+// does the anti-phase kernel serve an H x W image (in the current mode)?  (gemm.hip: ha2g_conv2d_dgrad_resid_supported)
+int conv3x3_c32pp_serves(int H, int W) {
+    if (W < 2) return 0;
+    const int rows_max = (TPH + W - 2) / W + 1 + 2;
+    const int plane_elems = rows_max * (W + 2) * 32;
+    const size_t lds = (size_t)2 * 3 * plane_elems * sizeof(unsigned short) + 2 * 9 * 64 * 16;
+    if (lds > 158 * 1024 || (long)H * W < TPH || W + 2 <= 32) return 0;
+    if ((long)rows_max * (W + 2) * 8 > 12L * 256) return 0;
+    return gemm_bwd_pieces() == 3 && g_c32pp;
+}
+static int conv3x3_c32pp_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st,
+                                const float* rsd = nullptr, const unsigned* rbits = nullptr) {
     const int rows_max = (TPH + W - 2) / W + 1 + 2;
     const int plane_elems = rows_max * (W + 2) * 32;
     const size_t lds = (size_t)2 * 3 * plane_elems * sizeof(unsigned short) + 2 * 9 * 64 * 16;      // two groups' patches + the filter's third piece
@@ -1040,15 +1061,18 @@ static int conv3x3_c32pp_launch(const float* x, const float* w, float* y, int N,
     const long pairs = (tiles + 1) / 2;
     const int grid = (int)(pairs < 256 ? pairs : 256);
     const unsigned mgW = (unsigned)(((1ULL << 32) + (unsigned)W - 1) / (unsigned)W);
-    hipLaunchKernelGGL(conv3x3_c32pp_kernel, dim3(grid), dim3(512), lds, st, x, w, y, N, H, W, flip, (act & 255) | (g_x3p_dbg << 8), beta, plane_elems, mgW);
+    hipLaunchKernelGGL(conv3x3_c32pp_kernel, dim3(grid), dim3(512), lds, st, x, w, y, N, H, W, flip, (act & 255) | (g_x3p_dbg << 8), beta, plane_elems, mgW,
+                       rsd, rbits);
     HA2G_CHECK_LAUNCH("conv3x3_c32pp");
     return 0;
 }
-int conv3x3_c32_x3_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st) {
+int conv3x3_c32_x3_launch(const float* x, const float* w, float* y, int N, int H, int W, int flip, int act, float beta, hipStream_t st, const float* rsd,
+                          const unsigned* rbits) {
     if (gemm_bwd_pieces() == 3 && g_c32pp) {
-        const int rc = conv3x3_c32pp_launch(x, w, y, N, H, W, flip, act, beta, st);
+        const int rc = conv3x3_c32pp_launch(x, w, y, N, H, W, flip, act, beta, st, rsd, rbits);
         if (rc != -100) return rc;
     }
+    if (rsd != nullptr) return -100;                         // the masked-residual epilogue exists in the anti-phase kernel only
     if (gemm_bwd_pieces() == 3 && g_x3_prefetch) {
         const int rc = conv3x3_x3p_launch(x, w, y, N, H, W, flip, act, beta, st);
         if (rc != -100) return rc;

@@ -199,6 +199,7 @@ struct PConvP {
     PlaneSet a;                                                  // dy planes [img][GH][GW][GC] (piece q at a.p + q * a.ps)
     PlaneSet b;                                                  // weight planes [N][K], K = KH*KW*GC
     float* C; long ldc; float beta;
+    const float* rsd; const unsigned* rsd_bits;      // masked residual of the patch-resident kernel's epilogue (ha2g_conv2d_dgrad_planes_np_resid_f32), or null
     int N, K;
     int GH, GW, GC, OH, OW, KH, KW, pad, stride;                 // gathered tensor (dy; forward: x) / output pixel grid (dx; forward: y)
     int fwd, relu;                                               // forward convolution instead of the data gradient; ReLU on the bf16 output
@@ -1312,6 +1313,14 @@ __global__ __launch_bounds__(256, WPS) void pconv_r_kernel(PConvP p, RGeo g) {
             float* dst = p.C + orow * p.ldc + col0;
             if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
             if (p.beta != 0.f) v += p.beta * *reinterpret_cast<const f32x4_t*>(dst);
+            if (p.rsd != nullptr) {
+                // masked residual (round 6; the identity shortcut under autograd, ResNetBlocks.py:34-36): + (out > 0 ? dout : 0), decisions from the forward
+                // tail's bit words -- what "beta = 1 onto dres" added, without dres ever being written
+                const long e = orow * p.ldc + col0, vi = e >> 2;
+                const f32x4_t dd = *reinterpret_cast<const f32x4_t*>(p.rsd + e);
+                const unsigned b = (p.rsd_bits[vi >> 3] >> (4 * (int)(vi & 7))) & 15u;
+                v[0] += (b & 1u) ? dd[0] : 0.f; v[1] += (b & 2u) ? dd[1] : 0.f; v[2] += (b & 4u) ? dd[2] : 0.f; v[3] += (b & 8u) ? dd[3] : 0.f;
+            }
             *reinterpret_cast<f32x4_t*>(dst) = v;
         }
     }
@@ -1933,6 +1942,7 @@ static int pconv_dispatch(const PConvP& p, int maxM, hipStream_t st) {
             if constexpr (OUT == 0) {
                 int rc = g_tile3 == 0 ? pconv_r_dispatch(p, p.cls[0].OHc > 0 && p.cls[0].OWc > 0 ? p.cls[0].M / (p.cls[0].OHc * p.cls[0].OWc) : 0, st) : -100;
                 if (rc != -100) return rc;
+                if (p.rsd != nullptr) return ha2g_set_error(-1, "conv2d_dgrad_planes_resid: the geometry is not served by the patch-resident kernel");
                 rc = pconv_q_dispatch<NP>(p, maxM, st);
                 if (rc != -100) return rc;
             }
@@ -2153,6 +2163,35 @@ int ha2g_conv2d_dgrad_planes_np_f32(const void* dy, long dy_ps, const void* wt, 
     set_plane_bytes(p, (long)N * OHd * OWd * Cout, (long)Cin * KH * KW * Cout);
     if (int rc = (np == 3 ? pconv_dispatch<3, 0>(p, maxM, (hipStream_t)stream) : pconv_dispatch<2, 0>(p, maxM, (hipStream_t)stream))) return rc;
     HA2G_CHECK_LAUNCH("conv2d_dgrad_planes");
+    return 0;
+}
+// ... + (decision bit ? resid : 0) in the epilogue instead of beta = 1 onto a materialised dres = dout * (out > 0) (round 6): resid [N,H,W,Cin] fp32,
+// resid_bits = ha2g_se_bn_scale_add_relu_mask_np_f32's words over the same tensor.  Patch-resident kernel only: ha2g_conv2d_dgrad_planes_resid_supported.
+int ha2g_conv2d_dgrad_planes_resid_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (!ha2g_conv2d_dgrad_planes_supported(Cin, Cout, KH, KW, stride, pad)) return 0;
+    if (!(g_tile3 == 0 && g_q_kernel && g_r_kernel && gemm_bwd_pieces() == 3)) return 0;
+    if (!(KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cout % 32 == 0 && Cin % 64 == 0)) return 0;
+    int bmt = 0, bbn = 0; RGeo g{};
+    return pconv_r_plan(N, H, W, Cin, bmt, bbn, g) ? 1 : 0;
+}
+int ha2g_conv2d_dgrad_planes_np_resid_f32(const void* dy, long dy_ps, const void* wt, long wt_ps, int np, float* dx, int N, int H, int W, int Cin, int Cout,
+                                          int KH, int KW, int stride, int pad, const float* resid, const void* resid_bits, void* stream) {
+    HA2G_REQUIRE(np == 3, "conv2d_dgrad_planes_resid: np = %d (3)", np);
+    HA2G_REQUIRE(ha2g_conv2d_dgrad_planes_resid_supported(N, H, W, Cin, Cout, KH, KW, stride, pad), "conv2d_dgrad_planes_resid: unsupported geometry / mode");
+    HA2G_REQUIRE(resid != nullptr && resid_bits != nullptr && dx != resid && (((uintptr_t)resid | (uintptr_t)dx) & 15) == 0,
+                 "conv2d_dgrad_planes_resid: null / misaligned residual, or dx aliases it");
+    PConvP p{};
+    p.a = PlaneSet{(const unsigned short*)dy, dy_ps};
+    p.b = PlaneSet{(const unsigned short*)wt, wt_ps};
+    p.C = dx; p.ldc = Cin; p.beta = 0.f; p.rsd = resid; p.rsd_bits = (const unsigned*)resid_bits;
+    p.N = Cin; p.K = KH * KW * Cout;
+    p.GH = H; p.GW = W; p.GC = Cout; p.OH = H; p.OW = W; p.KH = KH; p.KW = KW; p.pad = pad; p.stride = stride;
+    p.dbg = g_pdbg;
+    if ((long)N * H * W == 0) return 0;
+    const int maxM = dgrad_classes(p, N, H, W, KH, KW, stride, pad, W);
+    set_plane_bytes(p, (long)N * H * W * Cout, (long)Cin * KH * KW * Cout);
+    if (int rc = pconv_dispatch<3, 0>(p, maxM, (hipStream_t)stream)) return rc;
+    HA2G_CHECK_LAUNCH("conv2d_dgrad_planes_resid");
     return 0;
 }
 int ha2g_conv2d_dgrad_planes_f32(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N, int H, int W,

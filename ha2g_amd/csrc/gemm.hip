@@ -1348,6 +1348,22 @@ int ha2g_conv2d_dgrad_f32(const float* dy, const float* wt, float* dx, int N, in
     return launch_conv_cfg<A_IM, B_KC>(cfg, p, st);
 }
 
+// dx = conv_transpose(dy, w) + (decision bit ? resid : 0): the data gradient of a block's conv1 with the identity shortcut's gradient added in the epilogue
+// (round 6: what beta = 1 onto a materialised dres = dout * (out > 0) did).  32 -> 32 channels, 3x3, stride 1 on the anti-phase direct kernel only
+// (ha2g_conv2d_dgrad_resid_supported); resid [N,H,W,32] fp32, resid_bits = ha2g_se_bn_scale_add_relu_mask_np_f32's words over the same tensor.
+int ha2g_conv2d_dgrad_resid_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    return Cin == 32 && Cout == 32 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !g_direct_c32_dgrad && g_split_dgrad && g_direct_c32_x3 &&
+           gemm_bwd_pieces() == 3 && conv3x3_c32pp_serves(H, W);
+}
+int ha2g_conv2d_dgrad_resid_f32(const float* dy, const float* wt, float* dx, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                const float* resid, const void* resid_bits, void* stream) {
+    HA2G_REQUIRE(ha2g_conv2d_dgrad_resid_supported(H, W, Cin, Cout, KH, KW, stride, pad), "conv2d_dgrad_resid: unsupported geometry / mode");
+    HA2G_REQUIRE(resid != nullptr && resid_bits != nullptr && dx != resid, "conv2d_dgrad_resid: null residual / bits, or dx aliases the residual");
+    const int rc = conv3x3_c32_x3_launch(dy, wt, dx, N, H, W, 1, 0, 0.f, (hipStream_t)stream, resid, (const unsigned*)resid_bits);
+    if (rc == -100) return ha2g_set_error(-1, "conv2d_dgrad_resid: the anti-phase 32-channel kernel does not serve H = %d, W = %d", H, W);
+    return rc;
+}
+
 // Weight gradient: dw [Cout][KH][KW][Cin] (+)= dy^T * im2col(x); K = N*OH*OW output pixels, split over grid.z.
 // ws must hold splits*Cout*KH*KW*Cin floats (query with ha2g_conv2d_wgrad_workspace_bytes).
 long ha2g_conv2d_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {

@@ -762,7 +762,7 @@ __global__ void se_bn_bwd_apply_kernel(const float* __restrict__ dout, const flo
             const float q = p.v[k] * sc.v[k] + dp.v[k];
             r.v[k] = (float)((double)g.v[k] * is.v[k] * ((double)q - s1.v[k] * dn - ((double)v.v[k] - mu.v[k]) * is.v[k] * (s2.v[k] * dn)));
         }
-        stv(dres, i, p);
+        if (dres != nullptr) stv(dres, i, p);               // null: the consumer adds the masked residual itself (ha2g_conv2d_dgrad_*resid*)
         if (!PL || dx != nullptr) stv(dx, i, r);
         if (PL) st_planes(dx_hi, dx_lo, pnp, i, r);
     }
@@ -1237,7 +1237,8 @@ int ha2g_se_bn_bwd_apply_np_f32(const float* dout, const float* out, const float
     HA2G_REQUIRE(mask_bits == nullptr ? out != nullptr : C % 32 == 0, "se_bn_bwd_apply: the ReLU decisions come from `out` or from mask_bits (C %% 32 == 0)");
     HA2G_REQUIRE(planes == nullptr || np == 2 || np == 3, "se_bn_bwd_apply: np = %d", np);
     HA2G_REQUIRE(planes != nullptr || dx != nullptr, "se_bn_bwd_apply: no output");
-    HA2G_REQUIRE(dres != nullptr && stat != nullptr && dgamma != nullptr && dbeta != nullptr, "se_bn_bwd_apply: null buffer");
+    HA2G_REQUIRE(stat != nullptr && dgamma != nullptr && dbeta != nullptr, "se_bn_bwd_apply: null buffer");
+    HA2G_REQUIRE(dres != nullptr || mask_bits != nullptr, "se_bn_bwd_apply: dres may be omitted only where the consumer holds the decision bits");
     if (N == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, stat, N, C, dbeta, dgamma, acc_dbeta, acc_dgamma);

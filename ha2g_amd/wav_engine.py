@@ -63,6 +63,7 @@ def fwd_planes_ok(w_ohwi, stride, pad):
     return FWD3 and lib.ha2g_gemm_bwd_pieces() == 3 and bool(lib.ha2g_conv2d_fwd_planes_supported(Cin, Cout, KH, KW, stride, pad))
 
 
+RESID_EPILOGUE = True     # identity-shortcut blocks: conv1's data gradient adds the masked residual in its epilogue, dres = dout * (out > 0) is never written (round 6)
 RELU_BITS = True          # the blocks' ReLU decisions (out > 0) as bits for the two-pass backward tail: 1 / 32 of the bytes of `out`, read twice per block (round 6)
 IMAGE_STATS = True        # layer 1 (no statistics epilogue): bn2's statistics and the SE squeeze from ONE per-image column pass over conv2's output (round 6)
 SE_FROM_STATS = True      # ... and, where the epilogue's tiles lie inside one image, the SE squeeze too: bn2's output is never materialised (block_fwd)
@@ -132,11 +133,18 @@ def prepare_fwd_weight_planes(P):
     return out
 
 
-def conv_dgrad(dy, w_ohwi, xshape, stride, pad, out=None, beta=0.0):
+def conv_dgrad(dy, w_ohwi, xshape, stride, pad, out=None, beta=0.0, resid=None):
+    """resid = (dout, decision bits): out = the data gradient + (bit ? dout : 0) (ha2g_conv2d_dgrad_resid_f32; the caller checked *_resid_supported)"""
     N, H, W, Cin = xshape
     Cout, KH, KW, _ = w_ohwi.shape
     wt = empty(Cin, KH, KW, Cout, like=dy)
     check(lib.ha2g_conv2d_weight_ohwi_to_ihwo_f32(w_ohwi.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, _stream()))
+    if resid is not None:
+        assert out is None
+        out = empty(N, H, W, Cin, like=dy)
+        check(lib.ha2g_conv2d_dgrad_resid_f32(dy.data_ptr(), wt.data_ptr(), out.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad, resid[0].data_ptr(),
+                                              resid[1].data_ptr(), _stream()))
+        return out
     if out is None:
         out = empty(N, H, W, Cin, like=dy)
     check(lib.ha2g_conv2d_dgrad_f32(dy.data_ptr(), wt.data_ptr(), out.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad, beta,
@@ -207,7 +215,7 @@ def dgrad_bnstats_blocks(w_ohwi, xshape, stride, pad):
     return int(lib.ha2g_conv2d_dgrad_planes_stat_blocks(N, H, W, Cin, Cout, KH, KW, stride, pad))
 
 
-def conv_dgrad_planes(dy_planes, w_ohwi, xshape, stride, pad, out=None, beta=0.0, bnstats=None):
+def conv_dgrad_planes(dy_planes, w_ohwi, xshape, stride, pad, out=None, beta=0.0, bnstats=None, resid=None):
     """conv_dgrad on the pre-split bf16 planes of dy (ops.bn_bwd(..., planes=True)): the weight goes through one re-layout + split launch,
     the data gradient through the DMA-staged kernel of csrc/conv_planes.hip.  Bit-identical to conv_dgrad() in the default arithmetic mode.
     bnstats = (x_bn, mean, invstd, nblk): the output is the dy of that BatchNorm's backward and nblk = dgrad_bnstats_blocks(...) > 0 -- the epilogue
@@ -219,6 +227,13 @@ def conv_dgrad_planes(dy_planes, w_ohwi, xshape, stride, pad, out=None, beta=0.0
     wpl = _WPLANES[0].get(w_ohwi.data_ptr()) if _WPLANES[0] is not None else None
     if wpl is None or wpl.shape[0] != npc:
         wpl = weight_planes(w_ohwi, npc)
+    if resid is not None:                                 # (dout, decision bits): + (bit ? dout : 0) in the epilogue (the caller checked *_resid_supported)
+        assert out is None and bnstats is None and npc == 3
+        out = torch.empty(N, H, W, Cin, dtype=torch.float32, device=dyp.device)
+        ops.ktimer.launch('conv_dgrad_planes', lambda: check(lib.ha2g_conv2d_dgrad_planes_np_resid_f32(
+            dyp.data_ptr(), dyp.stride(0), wpl.data_ptr(), wpl.stride(0), npc, out.data_ptr(), N, H, W, Cin, Cout, KH, KW, stride, pad,
+            resid[0].data_ptr(), resid[1].data_ptr(), _stream())), 2.0 * N * H * W * Cin * KH * KW * Cout)
+        return out
     if out is None:
         out = torch.empty(N, H, W, Cin, dtype=torch.float32, device=dyp.device)
         beta = 0.0
@@ -583,10 +598,11 @@ class GradSink:
         pl = torch.empty(ops.pieces(), N * OH * OW, C, dtype=torch.bfloat16, device=x.device) if planes else None
         dgamma, dbeta = empty(C, like=x), empty(C, like=x)
         # algorithmic HBM bytes (bench.py roofline_se_bn): reads dout and x (+ the decision bits or `out`), writes dres (+ dx) (+ the piece planes)
-        nb_ = 4.0 * x.numel() * (3 + (1.0 / 32 if mask_bits is not None else 1) + (1 if need_dx else 0)) + (2.0 * pl.shape[0] * x.numel() if planes else 0.0)
+        nb_ = 4.0 * x.numel() * (2 + (1 if dres is not None else 0) + (1.0 / 32 if mask_bits is not None else 1) + (1 if need_dx else 0)) + (
+            2.0 * pl.shape[0] * x.numel() if planes else 0.0)
         ops.ktimer.launch('se_bn_bwd_apply', lambda: check(lib.ha2g_se_bn_bwd_apply_np_f32(
             dout.data_ptr(), out.data_ptr(), x.data_ptr(), sc.data_ptr(), dpool.data_ptr(), mean.data_ptr(), invstd.data_ptr(), bn.gamma.data_ptr(),
-            dres.data_ptr(), _p(dxo), _p(pl), pl.stride(0) if planes else 0, pl.shape[0] if planes else 0, dgamma.data_ptr(), dbeta.data_ptr(),
+            _p(dres), _p(dxo), _p(pl), pl.stride(0) if planes else 0, pl.shape[0] if planes else 0, dgamma.data_ptr(), dbeta.data_ptr(),
             _p(acc[0] if acc else None), _p(acc[1] if acc else None), stat.data_ptr(), N, OH * OW, C, _p(mask_bits), _stream())), nb_)
         if acc is None:
             self.G[name] = (dgamma, dbeta)
@@ -745,7 +761,16 @@ def block_bwd(dx, saved, P, b, sink):
             sc.data_ptr(), ws.data_ptr(), h1.data_ptr(), w2_.data_ptr(), w0_.data_ptr(), dh1.data_ptr(), dpool.data_ptr(), h1.shape[1], stat.data_ptr(), _p(mb),
             _stream())), 4.0 * c2.numel() * (2 + (1.0 / 32 if mb is not None else 1)))
         sink.gse(b, ds, h1, dh1, pooled)
-        dres = torch.empty_like(c2)
+        # identity shortcut + decision bits: conv1's data gradient adds the masked residual (dout where out > 0) in its epilogue -- dres is not written
+        resid = None
+        if RESID_EPILOGUE and mb is not None and cd is None and stride == 1 and x.shape == c2.shape:
+            Nx, Hx, Wx, Cx = x.shape
+            if p1:
+                if lib.ha2g_conv2d_dgrad_planes_resid_supported(Nx, Hx, Wx, Cx, wa.shape[0], 3, 3, 1, 1) and ops.pieces() == 3:
+                    resid = (dout, mb)
+            elif lib.ha2g_conv2d_dgrad_resid_supported(Hx, Wx, Cx, wa.shape[0], wa.shape[1], wa.shape[2], 1, 1):
+                resid = (dout, mb)
+        dres = torch.empty_like(c2) if resid is None else None
         dc2, dc2p = sink.gbn_se(b + 'bn2', dout, out, c2, sc, dpool, m2, s2, dres, stat, planes=p2, need_dx=f2, mask_bits=mb)
     elif SE_BWD_FOLD and SE_MLP_FUSED and w2_.is_contiguous() and w0_.is_contiguous() and lib.ha2g_se_mlp_bwd_supported(C, h1.shape[1]):
         # reduction pass + (its final pass inside) the excitation MLP's backward: two launches instead of three, the same bits
@@ -797,10 +822,11 @@ def block_bwd(dx, saved, P, b, sink):
     if not WGRAD_AFTER:
         sink.gconv(b + 'conv1.weight', x, dc1, wa, stride, 1, dy_planes=dc1p, x_planes=xp)
     if cd is None:                                                              # identity shortcut: accumulate onto d(residual)
+        rs_ = resid if fused_tail else None
         if p1:
-            r = conv_dgrad_planes(dc1p, wa, x.shape, stride, 1, out=dres, beta=1.0)
+            r = conv_dgrad_planes(dc1p, wa, x.shape, stride, 1, out=dres, beta=1.0, resid=rs_)
         else:
-            r = conv_dgrad(dc1, wa, x.shape, stride, 1, out=dres, beta=1.0)
+            r = conv_dgrad(dc1, wa, x.shape, stride, 1, out=dres, beta=1.0, resid=rs_)
         if WGRAD_AFTER:
             sink.gconv(b + 'conv1.weight', x, dc1, wa, stride, 1, dy_planes=dc1p, x_planes=xp)
         if JOIN_DGRAD:

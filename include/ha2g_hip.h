@@ -404,6 +404,16 @@ int ha2g_se_bwd_apply_f32(const float* dout, const float* out, const float* s, c
  * convolutions) -- ha2g_bn_stats_finalize_f32 and ha2g_se_mlp_fwd_f32 (the SE squeeze) read them, bn2's output is then never materialised. */
 int ha2g_bn_image_partial_chunks(int N, int HW);
 int ha2g_bn_image_partials_f32(const float* x, int N, int HW, int C, double* part, void* stream);
+/* ABI 6: the data gradient of a block's conv1 (3x3, stride 1; model/ResNetBlocks.py:21-37 under autograd) with the identity shortcut's gradient added in the
+ * epilogue: dx = conv_transpose(dy, w) + (decision bit ? resid : 0), resid = the gradient of the block's output, resid_bits = the ReLU decisions
+ * ha2g_se_bn_scale_add_relu_mask_np_f32 left -- what beta = 1 onto a materialised dres = resid * (out > 0) computed, bit for bit, without writing dres
+ * (ha2g_se_bn_bwd_apply_np_f32 then takes dres = NULL).  *_planes_*: layers 2-4 on the patch-resident plane kernel; the other: layer 1 (32 channels). */
+int ha2g_conv2d_dgrad_planes_resid_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int ha2g_conv2d_dgrad_planes_np_resid_f32(const void* dy, long dy_ps, const void* wt, long wt_ps, int np, float* dx, int N, int H, int W, int Cin, int Cout,
+                                          int KH, int KW, int stride, int pad, const float* resid, const void* resid_bits, void* stream);
+int ha2g_conv2d_dgrad_resid_supported(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int ha2g_conv2d_dgrad_resid_f32(const float* dy, const float* wt, float* dx, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                const float* resid, const void* resid_bits, void* stream);
 long ha2g_se_bn_bwd_workspace_floats(int N, int HW, int C);
 void ha2g_se_bn_debug(int rows_per_trip, int chunk_shift);   /* A/B of the reduction pass (4 | 2 rows of loads in flight; chunks per image >> chunk_shift); default (4, 0) */
 int ha2g_se_bn_bwd_reduce_mlp_f32(const float* dout, const float* out, const float* x, const float* mean, const float* invstd, const float* gamma,

@@ -487,3 +487,43 @@ def test_relu_decisions_as_bits_change_no_bit_of_the_backward(name):
     assert set(res[True]) == set(res[False])
     for k in res[True]:
         assert torch.equal(res[True][k], res[False][k]), (name, k)
+
+
+@pytest.mark.parametrize('name', ['l1', 'l2', 'l3d', 'l4'])
+def test_masked_residual_in_the_data_gradient_epilogue_changes_no_bit(name):
+    """Round 6: in a block with the identity shortcut, conv1's data gradient adds the shortcut's gradient -- dout where the block's output was positive, the
+    decisions from the forward's bit words -- in its epilogue (ha2g_conv2d_dgrad_planes_np_resid_f32 / ha2g_conv2d_dgrad_resid_f32) instead of accumulating
+    with beta = 1 onto a tensor dres = dout * (out > 0) that the SE / bn2 apply pass wrote (wav_engine.RESID_EPILOGUE): one tensor write less per block,
+    every output BIT-IDENTICAL.  ('l3d' has the downsample branch: its bn needs dres, nothing changes there.)"""
+    from ha2g_amd import ops, wav_engine as we
+    geom = BLOCKFULL_CASES[name]
+    P = engine_P(block_state(name, geom, 59), DEV)
+    x, wl = block_io(name, geom, BLOCKFULL_B, 59)
+    xin, dout = nhwc(x.to(DEV)), nhwc(wl.to(DEV))
+    wpl = {}
+    for n, stride, pad in (('conv1.weight', 2 if geom[4] else 1, 1), ('conv2.weight', 1, 1), ('downsample.0.weight', 2, 0)):
+        if n in P and we.fwd_planes_ok(we._ohwi(P[n]), stride, pad):
+            wpl[n] = ops.to_planes(we._ohwi(P[n]).contiguous(), 3)
+    xp = ops.to_planes(xin, 3) if 'conv1.weight' in wpl else None
+    res = {}
+    try:
+        for on in (True, False):
+            we.RESID_EPILOGUE = on
+            we._TRAINING[0] = True
+            we._WILL_BWD[0] = True
+            we._NBT_PENDING.clear()
+            Pc = {k: (v.clone() if torch.is_tensor(v) else we._BN(v.gamma, v.beta, v.rm.clone(), v.rv.clone(), None)) for k, v in P.items()}
+            out, saved, _ = we.block_fwd(xin, Pc, '', geom[4], xp=xp, wpl=wpl)
+            sink = we.GradSink(Pc)
+            dx = we.block_bwd(dout, saved, Pc, '', sink)
+            sink.join(torch.device(DEV))
+            g = {}
+            for k, gr in sink.G.items():
+                for j, t in enumerate(gr if isinstance(gr, tuple) else (gr,)):
+                    g['%s/%d' % (k, j)] = t.clone()
+            res[on] = dict(dx=dx.clone(), **g)
+    finally:
+        we.RESID_EPILOGUE = True
+    assert set(res[True]) == set(res[False])
+    for k in res[True]:
+        assert torch.equal(res[True][k], res[False][k]), (name, k)
