@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_partial_kernel(const float* __
     }
 }
 // one wave per element: lanes stride the block partials (four loads in flight), double sums, a fixed xor tree (deterministic).  Round 6: the partial pass
-// ran 908 blocks of 2 048 pixels -- 3.5 waves per SIMD walking 64 dependent batches of loads: 197 us for 245 MB on the main queue at the end of the tower's
+// ran 908 blocks of 2 048 pixels -- 3.5 waves per SIMD walking 64 dependent batches of loads: 197 us for 147 MB on the main queue at the end of the tower's
 // backward; 4 096 blocks of ~450 pixels stream it.
 __global__ __launch_bounds__(256) void stem_wgrad_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dw, float* __restrict__ db,
                                                                float beta) {
