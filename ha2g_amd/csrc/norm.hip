@@ -94,15 +94,55 @@ __device__ __forceinline__ void block_col_reduce(const dvec<V>& a, const dvec<V>
     }
 }
 
+// The same for narrow tensors (CV = C / V <= 16 lanes per row, i.e. C <= 64 fp32 channels) with 1 / 8 of the LDS (round 6): the partials of the lanes of a
+// wave that share cv (lane % CV) are first added by xor-shuffles over the lane bits above CV (a fixed tree), then one dvec per (wave, cv) goes through LDS.
+// Why: beside a persistent weight-gradient workgroup (120-156 KB of the CU's 160 KB of LDS) a 16-24 KB reduction buffer allows ONE workgroup of a
+// statistics pass per CU (or none); 2-3 KB allows as many as the registers do.  Deterministic; another summation order than block_col_reduce.
+__device__ __forceinline__ double shfl_xor_d(double v, int o) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl_xor((int)(b & 0xffffffffLL), o, 64), hi = __shfl_xor((int)(b >> 32), o, 64);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int V>
+__device__ __forceinline__ dvec<V> wave_cv_sum(dvec<V> a, int CV) {
+    for (int o = CV; o < 64; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) a.v[k] += shfl_xor_d(a.v[k], o);
+    }
+    return a;
+}
+// lds: [2][4][16] dvec<V>
+template <int V>
+__device__ __forceinline__ void block_col_reduce_small(dvec<V> a, dvec<V> b, int CV, double* __restrict__ part, int C, dvec<V>* lds) {
+    a = wave_cv_sum<V>(a, CV); b = wave_cv_sum<V>(b, CV);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < CV) { lds[w * 16 + lane] = a; lds[64 + w * 16 + lane] = b; }
+    __syncthreads();
+    if (threadIdx.x < CV) {
+        dvec<V> sa = dzero<V>(), sb = dzero<V>();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) { sa.v[k] += lds[q * 16 + threadIdx.x].v[k]; sb.v[k] += lds[64 + q * 16 + threadIdx.x].v[k]; }
+        }
+        const long nb = gridDim.x;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            part[((long)(threadIdx.x * V + k)) * nb + blockIdx.x] = sa.v[k];
+            part[((long)C + threadIdx.x * V + k) * nb + blockIdx.x] = sb.v[k];
+        }
+    }
+}
+
 // mode 0: (x - K, (x-K)^2) with K = row 0 (shift against cancellation); mode 1: (dy, dy * xhat).
 // Sums are carried in double (torch's CPU batch-norm accumulates in double too; the kernel is HBM-bound, the
 // fp64 adds are free) -- nearly-dead post-ReLU channels make sum(dy*xhat) cancel by 1e3..1e4.
-template <int MODE, typename T, int RPT = 4>
+template <int MODE, typename T, int RPT = 4, int SMALL = 0>
 __global__ __launch_bounds__(256) void col_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           long rows, int C, double* __restrict__ part) {
     constexpr int V = VW<T>::V;
-    __shared__ dvec<V> lds[512];
+    __shared__ dvec<V> lds[SMALL == 2 ? 1 : (SMALL == 1 ? 128 : 512)];
     const int CV = C / V;
     ColMap m(CV);
     const long rows_per = (rows + gridDim.x - 1) / gridDim.x;
@@ -143,7 +183,21 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const T* __restrict__ 
         if (MODE == 1) d = ldv(dy + r * C, m.cv);
         accum(v, d);
     }
-    block_col_reduce<V>(a, b, CV, part, C, lds);
+    if constexpr (SMALL == 2) {
+        // no LDS at all: every WAVE leaves its own partial (block index 4 blockIdx + wave of 4 gridDim blocks) -- a statistics pass then fits beside a
+        // persistent plane weight-gradient workgroup (156 of the CU's 160 KB of LDS), where no LDS-using workgroup can be resident
+        a = wave_cv_sum<V>(a, CV); b = wave_cv_sum<V>(b, CV);
+        const int lane = threadIdx.x & 63;
+        if (lane < CV) {
+            const long nb = 4L * gridDim.x, blk = 4L * blockIdx.x + (threadIdx.x >> 6);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                part[((long)(lane * V + k)) * nb + blk] = a.v[k];
+                part[((long)C + lane * V + k) * nb + blk] = b.v[k];
+            }
+        }
+    } else if constexpr (SMALL == 1) block_col_reduce_small<V>(a, b, CV, part, C, lds);
+    else block_col_reduce<V>(a, b, CV, part, C, lds);
 }
 
 // Per-IMAGE column sums (x, x^2) of x [N][HW][C] (round 6): grid (nchunk, N), block (k, n) = rows [k per, (k + 1) per) of image n -> part [2][C][N nchunk]
@@ -610,12 +664,12 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
 //   bn2: sum_hw dz        = s A1 + HW dpool,   sum_hw dz * xhat = s A2 + dpool A3
 // so the pass that WROTE dz (se_bwd_apply) and the column pass that READ it back with c2 (col_partial<1>) disappear: two passes over three tensors
 // (reduce, apply) instead of four over nine tensor reads.  All sums in double, fixed order (chunks ascending, images ascending): deterministic.
-template <bool BITS, int RPT = 4>
+template <bool BITS, int RPT = 4, int SMALL = 0>
 __global__ __launch_bounds__(256) void se_bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dout, const float* __restrict__ outp,
                                                            int HW, int C, double* __restrict__ part, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const unsigned* __restrict__ mbits) {
     // grid (nchunk, N): block (k, n) sums rows [k * per, (k + 1) * per) of image n -> part [n][k][3][C]
-    __shared__ dvec<4> lds[3][256];
+    __shared__ dvec<4> lds[3][SMALL == 2 ? 1 : (SMALL == 1 ? 64 : 256)];
     const int CV = C / 4;
     ColMap m(CV);
     const int nchunk = gridDim.x, per = (HW + nchunk - 1) / nchunk;
@@ -652,6 +706,37 @@ __global__ __launch_bounds__(256) void se_bn_reduce_kernel(const float* __restri
     for (; r < rend; r += m.rstep) {
         const long off = base + (long)r * C;
         accum(ldv(x + off, m.cv), ldv(dout + off, m.cv), decisions(off));
+    }
+    if constexpr (SMALL == 2) {                              // no LDS: one partial per WAVE, chunk index 4 k + wave of 4 nchunk (see col_partial_kernel)
+        a1 = wave_cv_sum<4>(a1, CV); a2 = wave_cv_sum<4>(a2, CV); a3 = wave_cv_sum<4>(a3, CV);
+        const int lane = threadIdx.x & 63;
+        if (lane < CV) {
+            double* p = part + (((long)blockIdx.y * nchunk + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 3 * C + lane * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { p[k] = a1.v[k]; p[(long)C + k] = a2.v[k]; p[2L * C + k] = a3.v[k]; }
+        }
+        return;
+    }
+    if constexpr (SMALL == 1) {                              // CV <= 16: shuffle pre-reduction, one dvec per (wave, cv) through LDS (block_col_reduce_small)
+        a1 = wave_cv_sum<4>(a1, CV); a2 = wave_cv_sum<4>(a2, CV); a3 = wave_cv_sum<4>(a3, CV);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane < CV) { lds[0][w * 16 + lane] = a1; lds[1][w * 16 + lane] = a2; lds[2][w * 16 + lane] = a3; }
+        __syncthreads();
+        if (threadIdx.x < CV) {
+            double* p = part + ((long)blockIdx.y * nchunk + blockIdx.x) * 3 * C + threadIdx.x * 4;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                dvec<4> sacc = dzero<4>();
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sacc.v[k] += lds[q][wv * 16 + threadIdx.x].v[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) p[(long)q * C + k] = sacc.v[k];
+            }
+        }
+        return;
     }
     lds[0][threadIdx.x] = a1; lds[1][threadIdx.x] = a2; lds[2][threadIdx.x] = a3;
     __syncthreads();
@@ -858,6 +943,7 @@ __global__ __launch_bounds__(256) void se_mlp_wgrad_multi_kernel(SeWgradJobs jb,
     if ((int)blockIdx.x == jb.start[q] && t < 32 && j < R) jb.db0[q][j] += b0;
 }
 
+static int g_small_lds = 2;         // narrow tensors (C <= 64): the backward statistics passes with shuffle pre-reduction and 2-3 KB of LDS (ha2g_bn_debug_small_lds: A/B)
 static int g_colp_rpt = 4;          // rows per trip of the BatchNorm-backward statistics pass (ha2g_bn_debug_rows_per_trip: A/B of the loads in flight per wave)
 inline int chunk_blocks(long rows) {
     long b = rows / 512;
@@ -918,10 +1004,16 @@ int bn_bwd_t(const T* dy, const T* x, const float* mean, const float* invstd, co
     HA2G_REQUIRE(okCv<T>(C), "bn: unsupported channel count %d", C);
     hipStream_t st = (hipStream_t)stream;
     int nb = chunk_blocks(rows);
-    if (g_colp_rpt == 8) hipLaunchKernelGGL((col_partial_kernel<1, T, 8>), dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
+    int nfin = nb;
+    if (g_small_lds && sizeof(T) == 4 && C / VW<T>::V <= (g_small_lds == 3 ? 16 : 8))       // C = 32 (mode 3: C <= 64): the small-LDS form (see block_col_reduce_small)
+        hipLaunchKernelGGL((col_partial_kernel<1, T, 2, 1>), dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
+    else if (g_small_lds == 1 && sizeof(T) == 4 && C / VW<T>::V <= 64) {      // wider (cv == lane needs C / 4 <= 64): one partial per WAVE, no LDS
+        hipLaunchKernelGGL((col_partial_kernel<1, T, 2, 2>), dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
+        nfin = 4 * nb;
+    } else if (g_colp_rpt == 8) hipLaunchKernelGGL((col_partial_kernel<1, T, 8>), dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
     else if (g_colp_rpt == 2) hipLaunchKernelGGL((col_partial_kernel<1, T, 2>), dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
     else hipLaunchKernelGGL((col_partial_kernel<1, T>), dim3(nb), dim3(256), 0, st, x, dy, mean, invstd, rows, C, (double*)ws);
-    hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nb, C, dbeta, dgamma, acc_dbeta, acc_dgamma);
+    hipLaunchKernelGGL(pair_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const double*)ws, nfin, C, dbeta, dgamma, acc_dbeta, acc_dgamma);
     if (PL || dx)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<PL, T>), dim3(flat_grid(rows * (C / VW<T>::V))), dim3(256), 0, st, dy, x, mean, invstd, gamma,
                            (const float*)dbeta, (const float*)dgamma, dx, rows, C, relu_mask, (unsigned short*)dx_hi, (unsigned short*)dx_lo, pnp);
@@ -1201,9 +1293,10 @@ int ha2g_se_mlp_wgrad_multi_f32(int n, const void* const* dsc, const void* const
 // ---- SE backward + bn2 backward in two passes (round 6; see se_bn_reduce_kernel) ----
 static int g_sebn_rpt = 4, g_sebn_chunk_shift = 0;
 // A/B of the reduction pass: rows per trip (4 | 2: 126 | fewer registers per wave) and chunks per image halved `chunk_shift` times (longer loops per block)
+void ha2g_bn_debug_small_lds(int on) { g_small_lds = on < 0 ? 0 : (on > 3 ? 3 : on); }      // 0 classic; 1 = C = 32 small LDS, wider: LDS-free; 2 (default) = C = 32 only; 3 = C <= 64
 void ha2g_se_bn_debug(int rpt, int chunk_shift) { g_sebn_rpt = rpt == 2 ? 2 : 4; g_sebn_chunk_shift = chunk_shift < 0 ? 0 : (chunk_shift > 4 ? 4 : chunk_shift); }
 // floats of workspace ha2g_se_bn_bwd_reduce_mlp_f32 needs
-long ha2g_se_bn_bwd_workspace_floats(int N, int HW, int C) { return (long)N * pool_chunks(N, HW) * 3 * C * 2; }
+long ha2g_se_bn_bwd_workspace_floats(int N, int HW, int C) { return (long)N * pool_chunks(N, HW) * 4 * 3 * C * 2; }      // (one partial per wave in the LDS-free form)
 // Reduction pass + excitation MLP backward.  x = bn2's INPUT (conv2's output) [N][HW][C], mean / invstd / gamma / beta = bn2's; gate = the SE gate [N][C];
 // writes ds [N][C] (the MLP's weight gradient reads it), dh1 [N][R], dpool [N][C] (already / HW) and stat [2][C][N] doubles: bn2's per-image backward sums.
 int ha2g_se_bn_bwd_reduce_mlp_f32(const float* dout, const float* out, const float* x, const float* mean, const float* invstd, const float* gamma,
@@ -1218,13 +1311,19 @@ int ha2g_se_bn_bwd_reduce_mlp_f32(const float* dout, const float* out, const flo
     hipStream_t st = (hipStream_t)stream;
     int nchunk = pool_chunks(N, HW) >> g_sebn_chunk_shift;
     if (nchunk < 1) nchunk = 1;
-    if (mask_bits != nullptr && g_sebn_rpt == 2)
+    int nfin = nchunk;
+    if (mask_bits != nullptr && g_small_lds && C / 4 <= (g_small_lds == 3 ? 16 : 8))
+        hipLaunchKernelGGL((se_bn_reduce_kernel<true, 2, 1>), dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, (double*)ws, mean, invstd, (const unsigned*)mask_bits);
+    else if (mask_bits != nullptr && g_small_lds == 1 && C / 4 <= 64) {
+        hipLaunchKernelGGL((se_bn_reduce_kernel<true, 2, 2>), dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, (double*)ws, mean, invstd, (const unsigned*)mask_bits);
+        nfin = 4 * nchunk;
+    } else if (mask_bits != nullptr && g_sebn_rpt == 2)
         hipLaunchKernelGGL((se_bn_reduce_kernel<true, 2>), dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, (double*)ws, mean, invstd, (const unsigned*)mask_bits);
     else if (mask_bits != nullptr)
         hipLaunchKernelGGL(se_bn_reduce_kernel<true>, dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, (double*)ws, mean, invstd, (const unsigned*)mask_bits);
     else
         hipLaunchKernelGGL(se_bn_reduce_kernel<false>, dim3(nchunk, N), dim3(256), 0, st, x, dout, out, HW, C, (double*)ws, mean, invstd, (const unsigned*)nullptr);
-    hipLaunchKernelGGL(se_bn_mlp_bwd_kernel, dim3(N), dim3(256), 0, st, h1, w2, w0, dh1, dpool, C, R, HW, N, (const double*)ws, nchunk, gate, ds, gamma, beta, stat);
+    hipLaunchKernelGGL(se_bn_mlp_bwd_kernel, dim3(N), dim3(256), 0, st, h1, w2, w0, dh1, dpool, C, R, HW, N, (const double*)ws, nfin, gate, ds, gamma, beta, stat);
     HA2G_CHECK_LAUNCH("se_bn_bwd_reduce_mlp");
     return 0;
 }

@@ -415,6 +415,7 @@ int ha2g_conv2d_dgrad_resid_supported(int H, int W, int Cin, int Cout, int KH, i
 int ha2g_conv2d_dgrad_resid_f32(const float* dy, const float* wt, float* dx, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                 const float* resid, const void* resid_bits, void* stream);
 long ha2g_se_bn_bwd_workspace_floats(int N, int HW, int C);
+void ha2g_bn_debug_small_lds(int on);   /* the backward statistics passes' reduction: 0 = through 16-24 KB of LDS; 1 (default) = C = 32: shuffles + 4-6 KB, wider: one partial per wave, no LDS; 2 = the small form for C = 32 only.  A/B */
 void ha2g_se_bn_debug(int rows_per_trip, int chunk_shift);   /* A/B of the reduction pass (4 | 2 rows of loads in flight; chunks per image >> chunk_shift); default (4, 0) */
 int ha2g_se_bn_bwd_reduce_mlp_f32(const float* dout, const float* out, const float* x, const float* mean, const float* invstd, const float* gamma,
                                   const float* beta, float* ds, int N, int HW, int C, const float* gate, float* ws, const float* h1, const float* w2,
