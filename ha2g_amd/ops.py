@@ -429,6 +429,22 @@ class Rng:
 rng = Rng()
 
 
+DROP_TAP = [None]     # diagnostics: a list here receives (call id, p, shape) of every dropout APPLIED in a forward (tests/test_gpu_linearised.py re-draws the masks
+                      # of a step from a copy of rng.state and hands them to the float64 oracle: the step with dropout ON against the oracle with the same masks)
+
+
+def _tap_drop(call, p, shape):
+    if DROP_TAP[0] is not None:
+        DROP_TAP[0].append((int(call), float(p), tuple(int(d) for d in shape)))
+
+
+def redraw_mask(state, call, p, shape):
+    """the pre-scaled keep mask ha2g_dropout_f32 draws for (state = a uint64[2] {seed, step} device tensor, call id) over a tensor of `shape`"""
+    mask = torch.empty(shape, dtype=torch.float32, device=state.device)
+    check(lib.ha2g_dropout_f32(0, 0, mask.data_ptr(), mask.numel(), p, state.data_ptr(), call, _stream()))
+    return mask
+
+
 class DropoutFunction(torch.autograd.Function):
     """out = x * mask, mask = keep / (1 - p) drawn from the device-resident Philox state keyed by (seed, step, call id, element).  The mask is
     NOT stored: the backward re-draws it by running the same kernel on dy with the same call id (the state only advances at the end of the
@@ -443,6 +459,7 @@ class DropoutFunction(torch.autograd.Function):
         out = torch.empty_like(x)
         ctx.p, ctx.call, ctx.step_token = p, rng.next_id(), rng.step_token
         check(lib.ha2g_dropout_f32(x.data_ptr(), out.data_ptr(), None, x.numel(), p, rng.state.data_ptr(), ctx.call, _stream()))
+        _tap_drop(ctx.call, p, x.shape)
         return out
 
     @staticmethod
@@ -496,11 +513,13 @@ def _im2col(x, col, B, T, C, k, dil, pad_left, To, in_drop):
         if in_drop.token != rng.step_token:
             raise RuntimeError('ha2g_amd dropout: a DropSpec of an earlier RNG step')
         check(lib.ha2g_im2col1d_drop_f32(x.data_ptr(), col.data_ptr(), B, T, C, k, dil, pad_left, To, in_drop.p, rng.state.data_ptr(), in_drop.call, _stream()))
+        _tap_drop(in_drop.call, in_drop.p, x.shape)
 
 
 def _drop_apply(y, spec):
     out = torch.empty_like(y)
     check(lib.ha2g_dropout_f32(y.data_ptr(), out.data_ptr(), None, y.numel(), spec.p, rng.state.data_ptr(), spec.call, _stream()))
+    _tap_drop(spec.call, spec.p, y.shape)
     return out
 
 
@@ -702,6 +721,7 @@ class AddReluFunction(torch.autograd.Function):
         if drop is not None:                               # relu(mask * a + b): a's producer left its dropout to this launch (DropSpec.deferred)
             y = torch.empty_like(a)
             check(lib.ha2g_dropout_fused_f32(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), drop.p, rng.state.data_ptr(), drop.call, 1, _stream()))
+            _tap_drop(drop.call, drop.p, a.shape)
         else:
             y = eltwise(OP_ADD_RELU, a, b)
         _tap_act('add_relu', y, ACT_RELU)

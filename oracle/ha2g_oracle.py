@@ -37,6 +37,41 @@ def batch_norm_train(x, sd, p, momentum=0.1, eps=1e-5, update=True):
     return F.batch_norm(x, rm, rv, sd[p + 'weight'], sd[p + 'bias'], True, momentum, eps)
 
 
+_DROP_SEQ = [None]                  # iterator over pre-scaled dropout masks in the reference's call order, or None (drop_sequence)
+
+
+class drop_sequence:
+    """`with drop_sequence(masks=[m0, m1, ...]):` -- dropout ON with GIVEN masks: every dropout of the text encoders (embedding, the two per TCN block:
+    model/tcn.py:21-31), of nn.GRU between layers (model/hierarchy_net.py:87, :217) consumes the next mask, in the order the reference calls them
+    (time-major [B, T, C] masks are transposed to [B, C, T] at the TCN sites).  tests/test_gpu_linearised.py feeds the masks the HIP step drew."""
+
+    def __init__(self, masks):
+        self.new = iter(masks)
+
+    def __enter__(self):
+        self.old = _DROP_SEQ[0]
+        _DROP_SEQ[0] = self.new
+        return self
+
+    def __exit__(self, *exc):
+        it = _DROP_SEQ[0]
+        _DROP_SEQ[0] = self.old
+        if exc[0] is None:
+            left = sum(1 for _ in it)
+            assert left == 0, 'drop_sequence: %d masks were not consumed (the call order of the two sides differs)' % left
+
+
+def _next_drop(x, time_major_mask=False):
+    """x times the next mask of the sequence (None active: x unchanged)"""
+    if _DROP_SEQ[0] is None:
+        return x
+    m = next(_DROP_SEQ[0])
+    if time_major_mask:
+        m = m.transpose(1, 2)
+    assert tuple(m.shape) == tuple(x.shape), ('drop_sequence: mask of shape %s at a site of shape %s' % (tuple(m.shape), tuple(x.shape)))
+    return x * m.to(x.dtype)
+
+
 def gru_bidir(x, sd, p, n_layers, H, masks=None):
     """Stacked bidirectional GRU, batch_first, h0 = 0 (torch.nn.GRU semantics).
     gates ordered (r,z,n); n = tanh(gi_n + r*(W_hn h + b_hn)); h' = (1-z)*n + z*h.
@@ -63,6 +98,8 @@ def gru_bidir(x, sd, p, n_layers, H, masks=None):
         inp = torch.cat(outs, 2)
         if masks is not None and l < n_layers - 1:
             inp = inp * masks[l]
+        elif l < n_layers - 1:
+            inp = _next_drop(inp)
     return inp
 
 
@@ -83,6 +120,8 @@ def text_encoder_tcn(tokens, sd, p, n_layers, drop=None):
     x = F.embedding(tokens, sd[p + 'embedding.weight'])
     if drop:
         x = x * drop['emb']
+    else:
+        x = _next_drop(x)
     x = x.transpose(1, 2)                                            # (B, C, T)
     for i in range(n_layers):
         dil = 2 ** i
@@ -95,6 +134,8 @@ def text_encoder_tcn(tokens, sd, p, n_layers, drop=None):
             y = _act(y, 0.0, True)
             if drop:
                 y = y * drop[(i, j)]
+            else:
+                y = _next_drop(y, True)
         if (p + 'tcn.network.%d.downsample.weight' % i) in sd:
             res = F.conv1d(res, sd[p + 'tcn.network.%d.downsample.weight' % i], sd[p + 'tcn.network.%d.downsample.bias' % i])
         x = _act(y + res, 0.0, True)

@@ -255,11 +255,24 @@ def load_role(module, state, role):
     return module
 
 
-def build_modules(case, device, dims=schema.GESTURE_POSE_DIMS, state=None):
-    """(args, [g1..], dis, audio, text) with procedural parameters of `case`, dropout disabled."""
+def build_modules(case, device, dims=schema.GESTURE_POSE_DIMS, state=None, keep_dropout=False):
+    """(args, [g1..], dis, audio, text) with procedural parameters of `case`, dropout disabled (keep_dropout: left as the modules define it)."""
+    global no_dropout
+    _nd = no_dropout
+    if keep_dropout:
+        no_dropout = lambda m: m
+    try:
+        return _build_modules(case, device, dims, state, 0.3 if keep_dropout else None)
+    finally:
+        no_dropout = _nd
+
+
+def _build_modules(case, device, dims, state, dropout_prob=None):
     from ha2g_amd.config import make_args
     from ha2g_amd import hierarchy_net as hn
     args = make_args(case)
+    if dropout_prob is not None:
+        args.dropout_prob = dropout_prob                     # config/hierarchy.yml's value (the parity cases build with 0)
     spk = SpeakerVocab(case['n_spk'])
     state = state if state is not None else state_for(case, torch.float32, dims)
     gens = []

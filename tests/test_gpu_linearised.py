@@ -214,16 +214,17 @@ def test_whole_tower_backward_headline_size_vs_oracle_linearised_at_the_hip_relu
     _tower_vs_linearised_oracle(dict(BIG_CASES['cfg2_b128']), 70, 'tower B=128 mode 70')
 
 
-def _hip_gan_phase_step(case, expressive, fused):
+def _hip_gan_phase_step(case, expressive, fused, dropout=False):
     """One GAN-phase step (epoch 11, fresh procedural state) on the HIP path with every ReLU / LeakyReLU decision recorded.  fused=False: the reference's
     literal schedule (three separate generator passes, every generator running its own text encoder -- the activation CALL ORDER is then the
     reference's); fused=True: the DEFAULT schedule, the one bench.py times (3B-row fused chains, grouped text encoders, D on real + fake in one pass).
-    Returns (loss dict, [mask, ...] in call order on the device, the tower's masks by site name, {name: gradient})."""
+    Returns (loss dict, [mask, ...] in call order on the device, the tower's masks by site name, {name: gradient}); with dropout=True (the modules'
+    dropouts ON, as benchmarked) a fifth element: the pre-scaled dropout masks the step drew, in call order, re-drawn from a copy of the RNG state."""
     from ha2g_amd import ops, schema, train_hierarchy as th, wav_engine as we
     from ha2g_amd.optim import FusedAdam
     from ha2g_testing import EpsInjector, batch_for, build_modules, named_state
     dims = schema.EXPRESSIVE_POSE_DIMS if expressive else schema.GESTURE_POSE_DIMS
-    args, gens, dis, aud, txt = build_modules(case, DEV, dims)
+    args, gens, dis, aud, txt = build_modules(case, DEV, dims, keep_dropout=dropout)
     text, spec, target, vid = batch_for(case, P=dims[-1])
     lr = float(args.learning_rate)
     g_opts = [FusedAdam(m.parameters(), lr=lr) for m in gens]
@@ -237,21 +238,76 @@ def _hip_gan_phase_step(case, expressive, fused):
     old = th.FUSE_CHAINS, th.FUSE_TEXT, th.randperm_source
     th.FUSE_CHAINS, th.FUSE_TEXT, th.randperm_source = fused, fused, (lambda n, device: perm.to(device))
     ops.ACT_TAP[0], we.SAVED_TAP[0] = [], []
+    state0 = None
+    if dropout:
+        ops.rng.seed(torch.device(DEV), 0xD0 + case['seed'])
+        state0 = ops.rng.state.clone()                         # {seed, step} of THIS step: the masks are a function of (state, call id, element)
+        ops.DROP_TAP[0] = []
     try:
         ret = fn(args, 11, text.to(DEV), spec.to(DEV), target.to(DEV), vid.to(DEV), *gens, dis, aud, txt, *g_opts, dis_opt, aud_opt, txt_opt)
         taps, S = ops.ACT_TAP[0], we.SAVED_TAP[0][0]
+        dtaps = ops.DROP_TAP[0]
     finally:
         th.FUSE_CHAINS, th.FUSE_TEXT, th.randperm_source = old
-        ops.ACT_TAP[0], we.SAVED_TAP[0] = None, None
+        ops.ACT_TAP[0], we.SAVED_TAP[0], ops.DROP_TAP[0] = None, None, None
     torch.cuda.synchronize()
     assert ops.gru_cluster_error(torch.device(DEV)) == 0
     tower = {k: v.cpu() for k, v in we.relu_pattern_of(S, 'audio.feat_extractor.').items()}
     _, grads = named_state(mods)
     hip_grads = {k: v.detach().double().cpu() for k, v in grads.items()}
+    if dropout:
+        dtaps = sorted(dtaps)
+        assert len(dtaps) > 20 and len({c for c, _, _ in dtaps}) == len(dtaps), 'every dropout of the step is applied exactly once in its forward'
+        drops = [ops.redraw_mask(state0, c, p_, shp).cpu() for c, p_, shp in dtaps]
+        kept = float(np.mean([float((m > 0).float().mean()) for m in drops]))
+        assert 0.6 < kept < 0.95, kept                          # the masks are real (p = 0.1 .. 0.3)
+        meta = dict(B=case['B'], L=len(gens), n_text=1 + 2 * len(txt.tcn.network), n_gru=gens[0].gru.num_layers - 1, n_dgru=dis.gru.num_layers - 1)
+        return ret, [m for _, m in taps], tower, hip_grads, drops, meta
     return ret, [m for _, m in taps], tower, hip_grads
 
 
-def _reference_call_order(lit, fus, what):
+def _fused_drops_in_reference_order(F, meta):
+    """The dropout masks of a FUSED GAN-phase step (call-id order) re-cut into the reference's call order.  The fused step draws ONE mask per stacked call:
+    [stand-alone text encoder: n_text] [grouped generator text encoders over the no-gradient row blocks (dis, rand): n_text masks of [G * 2B, T, C], rows
+    (generator, block, sample)] [the same over the main block: [G * B, T, C]] [per generator: n_gru masks of [3B, T, 2H], row blocks in the PHYSICAL order
+    dis, rand, main (train_hierarchy._train_iter_impl: the gradient-carrying block last)] [D(real | fake) in one pass: n_dgru masks of [2B, T', 128]]
+    [D(fake) of the generator loss: n_dgru].  The reference (and the oracle) call: text encoder; the D-phase chain g1..gL (each: its text encoder, its GRU);
+    D(real); D(fake); the main chain; D(fake); the random-speaker chain.  Every shape is asserted."""
+    B, L, nt, ng, nd = meta['B'], meta['L'], meta['n_text'], meta['n_gru'], meta['n_dgru']
+    assert len(F) == nt + 2 * nt + L * ng + 2 * nd, (len(F), nt, ng, nd, L)
+    o_txt, o_a, o_b, o_gru, o_pair, o_fake = 0, nt, 2 * nt, 3 * nt, 3 * nt + L * ng, 3 * nt + L * ng + nd
+    for s_ in range(nt):
+        assert F[o_txt + s_].shape[0] == B and F[o_a + s_].shape[0] == L * 2 * B and F[o_b + s_].shape[0] == L * B, (s_, F[o_a + s_].shape, F[o_b + s_].shape)
+    for g in range(L):
+        for l in range(ng):
+            assert F[o_gru + g * ng + l].shape[0] == 3 * B
+    for l in range(nd):
+        assert F[o_pair + l].shape[0] == 2 * B and F[o_fake + l].shape[0] == B
+    phys = ['dis', 'rand', 'main']
+    nograd = ['dis', 'rand']
+
+    def gen(g, c):
+        if c == 'main':
+            text = [F[o_b + s_][g * B:(g + 1) * B] for s_ in range(nt)]
+        else:
+            i = nograd.index(c)
+            text = [F[o_a + s_][(g * 2 + i) * B:(g * 2 + i + 1) * B] for s_ in range(nt)]
+        i = phys.index(c)
+        return text + [F[o_gru + g * ng + l][i * B:(i + 1) * B] for l in range(ng)]
+    out = list(F[o_txt:o_txt + nt])
+    for g in range(L):
+        out += gen(g, 'dis')
+    out += [F[o_pair + l][:B] for l in range(nd)] + [F[o_pair + l][B:] for l in range(nd)]
+    for g in range(L):
+        out += gen(g, 'main')
+    out += list(F[o_fake:o_fake + nd])
+    for g in range(L):
+        out += gen(g, 'rand')
+    assert sum(m.numel() for m in out) == sum(m.numel() for m in F)
+    return [m.contiguous() for m in out]
+
+
+def _reference_call_order(lit, fus, what, mapping_out=None):
     """The fused schedule evaluates the same activation sites as the reference's literal schedule, but over stacked row blocks (3B-row chains, [G, ...]
     grouped encoders, real + fake through D at once) and in its own call order.  Every literal mask (B rows of one site) is one CONTIGUOUS chunk of one
     fused mask; this finds it BY CONTENT (the decisions at a site are a ~50 % dense random pattern: an unrelated chunk differs in about half its elements,
@@ -287,6 +343,8 @@ def _reference_call_order(lit, fus, what):
         flips += d
         worst = max(worst, d / n)
         out.append(c.reshape(m.shape).cpu())
+        if mapping_out is not None:
+            mapping_out.append((fi, ci, n, tuple(m.shape)))
     # bijection: the elements handed to the oracle are exactly the elements the fused run decided
     assert sum(m.numel() for m in out) == sum(m.numel() for m in fus), (sum(m.numel() for m in out), sum(m.numel() for m in fus))
     per_fused = {}
@@ -298,7 +356,7 @@ def _reference_call_order(lit, fus, what):
     return out
 
 
-def _whole_step_vs_linearised_oracle(case, expressive, what, fused=False):
+def _whole_step_vs_linearised_oracle(case, expressive, what, fused=False, dropout=False):
     """One GAN-phase step on the HIP path with every ReLU / LeakyReLU decision recorded; the float64 oracle linearised at that pattern; the loss dict and
     EVERY element of every gradient of every module (D's accumulated gradient included) compared.  fused=False checks the literal schedule; fused=True
     checks the DEFAULT schedule -- the literal run is then used only to learn the reference's call order (_reference_call_order), the pattern imposed on
@@ -309,8 +367,51 @@ def _whole_step_vs_linearised_oracle(case, expressive, what, fused=False):
     dims = schema.EXPRESSIVE_POSE_DIMS if expressive else schema.GESTURE_POSE_DIMS
     text, spec, target, vid = batch_for(case, P=dims[-1])
     perm = torch.from_numpy(proc.fixed_perm(case['B'], case['seed']))
-    ret, lit, tower, hip_grads = _hip_gan_phase_step(case, expressive, False)
-    if fused:
+    drops = None
+    if dropout and fused:
+        # the cut of the fused activation taps into the reference's call order is STRUCTURAL: learnt by content from a dropout-off pair of runs (a literal and
+        # a fused one draw different masks, their patterns cannot be matched), then applied to the dropout-on fused run's taps
+        assert not expressive
+        _, lit, _, _ = _hip_gan_phase_step(case, expressive, False)
+        _, fus0, _, _ = _hip_gan_phase_step(case, expressive, True)
+        mapping = []
+        _reference_call_order(lit, fus0, what + ' (dropout off: the cut)', mapping)
+        shapes0 = [tuple(m.shape) for m in fus0]
+        # With dropout OFF a generator's text encoder computes the SAME activations in the three chains (same text, same weights): the content match cannot
+        # tell its three literal calls apart, any assignment was right -- with dropout ON the three differ.  Those ties are resolved by structure: the
+        # grouped encoders run the no-gradient blocks [dis | rand] in one call (the larger fused tap, chunks in that order) and the main block in another.
+        import hashlib
+        groups = {}
+        for j, m in enumerate(lit):
+            groups.setdefault((tuple(m.shape), hashlib.sha1(m.cpu().numpy().tobytes()).hexdigest()), []).append(j)
+        n_ties = 0
+        for js in groups.values():
+            if len(js) == 1:
+                continue
+            assert len(js) == 3, ('identical activation calls that are not the three chains of one text-encoder site', js)
+            ch = [mapping[j] for j in js]                         # (fused tap, chunk, numel, shape) of the calls dis, main, rand (the reference's order)
+            big = max(fus0[c[0]].numel() for c in ch)
+            part_a = sorted(c for c in ch if fus0[c[0]].numel() == big)
+            part_b = [c for c in ch if fus0[c[0]].numel() != big]
+            assert len(part_a) == 2 and len(part_b) == 1 and part_a[0][0] == part_a[1][0], ch
+            mapping[js[0]], mapping[js[1]], mapping[js[2]] = part_a[0], part_b[0], part_a[1]
+            n_ties += 1
+        print('%s: %d tied text-encoder sites resolved by structure' % (what, n_ties))
+        del lit, fus0
+        torch.cuda.empty_cache()
+        ret, fus, tower, hip_grads, drops_f, meta = _hip_gan_phase_step(case, expressive, True, dropout=True)
+        assert [tuple(m.shape) for m in fus] == shapes0, 'the fused step records the same activation sites with its dropouts on'
+        seq = [fus[fi].reshape(-1)[ci * n:(ci + 1) * n].reshape(shp).cpu() for fi, ci, n, shp in mapping]
+        drops = _fused_drops_in_reference_order(drops_f, meta)
+        del fus, drops_f
+        lit = None
+    elif dropout:
+        ret, lit, tower, hip_grads, drops, _ = _hip_gan_phase_step(case, expressive, False, dropout=True)
+    else:
+        ret, lit, tower, hip_grads = _hip_gan_phase_step(case, expressive, False)
+    if dropout and fused:
+        pass
+    elif fused:
         del tower, hip_grads
         torch.cuda.empty_cache()
         ret, fus, tower, hip_grads = _hip_gan_phase_step(case, expressive, True)
@@ -325,7 +426,8 @@ def _whole_step_vs_linearised_oracle(case, expressive, what, fused=False):
         sd = state_for(case, dt, dims)
         tr = O.OracleTrainer(sd, make_args(case), EXPRESSIVE_SPEC if expressive else None)
         es = proc.EpsStream(case['seed'])
-        with O.relu_pattern(masks=tower), O.act_sequence(masks=seq):
+        import contextlib
+        with O.relu_pattern(masks=tower), O.act_sequence(masks=seq), (O.drop_sequence(masks=drops) if drops is not None else contextlib.nullcontext()):
             r = tr.train_iter(11, text, spec.to(dt), target.to(dt), vid, lambda shp: torch.from_numpy(es(shp)).to(dt), perm)
         return r, tr.grads
     r64, g64 = oracle(torch.float64)
@@ -384,3 +486,28 @@ def test_default_fused_schedule_gan_phase_step_headline_size_vs_oracle_linearise
     configuration, schedule and arithmetic mode of the benchmark line (dropout aside), every gradient element at 1e-4 against float64."""
     from ha2g_amd.config import BIG_CASES
     _whole_step_vs_linearised_oracle(dict(BIG_CASES['cfg2_b128']), False, 'fused GAN-phase step cfg2_b128', fused=True)
+
+
+@pytest.mark.parametrize('name', ['cfg1', 'cfg2_b128'])
+def test_gan_phase_step_with_dropout_on_vs_oracle_with_the_same_masks(name):
+    """The step AS BENCHMARKED has its dropouts on (embedding 0.1?, TCN blocks, nn.GRU's inter-layer 0.2 / 0.3): until round 6 that arithmetic had a
+    self-consistency check only (directional derivative, tests/test_gpu_step.py).  Here the HIP step (literal schedule, default arithmetic mode 70) runs
+    with every dropout ON; the pre-scaled masks it drew -- a function of (RNG state, call id, element index), re-drawn after the step from a copy of the
+    state with ha2g_dropout_f32's mask output -- are handed to the float64 oracle in the reference's call order (oracle.drop_sequence), together with the
+    HIP run's activation pattern; the loss dict and EVERY element of every gradient are held to 1e-4 (+ the float32 oracle's floor).  This also checks the
+    fused dropout forms against an independent implementation: conv1's mask applied by conv2's im2col, conv2's by the residual add, the GRU's without a
+    mask tensor, every backward re-drawing its mask.  cfg2_b128 = the headline configuration."""
+    from ha2g_amd.config import BIG_CASES, CASES
+    case = dict(BIG_CASES[name]) if name in BIG_CASES else dict(CASES[name])
+    _whole_step_vs_linearised_oracle(case, False, 'GAN-phase step %s, dropout ON' % name, dropout=True)
+
+
+@pytest.mark.parametrize('name', ['cfg1', 'cfg2_b128'])
+def test_default_fused_schedule_with_dropout_on_vs_oracle_with_the_same_masks(name):
+    """... and the same for the schedule, arithmetic AND dropout setting of the benchmark line: the DEFAULT fused step (3B-row chains, grouped text encoders
+    in their row-split form, D on real + fake in one pass, mode 70) with every dropout ON, against the float64 oracle that multiplies by the very masks the
+    fused step drew -- re-cut from its stacked calls into the reference's call order (_fused_drops_in_reference_order) -- and is linearised at the fused
+    run's own activation pattern: loss dict and every element of every gradient at 1e-4 (+ the float32 oracle's floor).  cfg2_b128 = the headline size."""
+    from ha2g_amd.config import BIG_CASES, CASES
+    case = dict(BIG_CASES[name]) if name in BIG_CASES else dict(CASES[name])
+    _whole_step_vs_linearised_oracle(case, False, 'GAN-phase step %s, default fused schedule, dropout ON' % name, fused=True, dropout=True)
