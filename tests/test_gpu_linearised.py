@@ -371,7 +371,6 @@ def _whole_step_vs_linearised_oracle(case, expressive, what, fused=False, dropou
     if dropout and fused:
         # the cut of the fused activation taps into the reference's call order is STRUCTURAL: learnt by content from a dropout-off pair of runs (a literal and
         # a fused one draw different masks, their patterns cannot be matched), then applied to the dropout-on fused run's taps
-        assert not expressive
         _, lit, _, _ = _hip_gan_phase_step(case, expressive, False)
         _, fus0, _, _ = _hip_gan_phase_step(case, expressive, True)
         mapping = []
@@ -488,7 +487,7 @@ def test_default_fused_schedule_gan_phase_step_headline_size_vs_oracle_linearise
     _whole_step_vs_linearised_oracle(dict(BIG_CASES['cfg2_b128']), False, 'fused GAN-phase step cfg2_b128', fused=True)
 
 
-@pytest.mark.parametrize('name', ['cfg1', 'cfg2_b128'])
+@pytest.mark.parametrize('name', ['cfg1', 'expr_cfg1', 'cfg2_b128'])
 def test_gan_phase_step_with_dropout_on_vs_oracle_with_the_same_masks(name):
     """The step AS BENCHMARKED has its dropouts on (embedding 0.1?, TCN blocks, nn.GRU's inter-layer 0.2 / 0.3): until round 6 that arithmetic had a
     self-consistency check only (directional derivative, tests/test_gpu_step.py).  Here the HIP step (literal schedule, default arithmetic mode 70) runs
@@ -499,10 +498,10 @@ def test_gan_phase_step_with_dropout_on_vs_oracle_with_the_same_masks(name):
     mask tensor, every backward re-drawing its mask.  cfg2_b128 = the headline configuration."""
     from ha2g_amd.config import BIG_CASES, CASES
     case = dict(BIG_CASES[name]) if name in BIG_CASES else dict(CASES[name])
-    _whole_step_vs_linearised_oracle(case, False, 'GAN-phase step %s, dropout ON' % name, dropout=True)
+    _whole_step_vs_linearised_oracle(case, bool(case.get('expressive')), 'GAN-phase step %s, dropout ON' % name, dropout=True)
 
 
-@pytest.mark.parametrize('name', ['cfg1', 'cfg2_b128'])
+@pytest.mark.parametrize('name', ['cfg1', 'expr_cfg1', 'cfg2_b128'])
 def test_default_fused_schedule_with_dropout_on_vs_oracle_with_the_same_masks(name):
     """... and the same for the schedule, arithmetic AND dropout setting of the benchmark line: the DEFAULT fused step (3B-row chains, grouped text encoders
     in their row-split form, D on real + fake in one pass, mode 70) with every dropout ON, against the float64 oracle that multiplies by the very masks the
@@ -510,4 +509,4 @@ def test_default_fused_schedule_with_dropout_on_vs_oracle_with_the_same_masks(na
     run's own activation pattern: loss dict and every element of every gradient at 1e-4 (+ the float32 oracle's floor).  cfg2_b128 = the headline size."""
     from ha2g_amd.config import BIG_CASES, CASES
     case = dict(BIG_CASES[name]) if name in BIG_CASES else dict(CASES[name])
-    _whole_step_vs_linearised_oracle(case, False, 'GAN-phase step %s, default fused schedule, dropout ON' % name, fused=True, dropout=True)
+    _whole_step_vs_linearised_oracle(case, bool(case.get('expressive')), 'GAN-phase step %s, default fused schedule, dropout ON' % name, fused=True, dropout=True)
