@@ -487,7 +487,7 @@ def test_default_fused_schedule_gan_phase_step_headline_size_vs_oracle_linearise
     _whole_step_vs_linearised_oracle(dict(BIG_CASES['cfg2_b128']), False, 'fused GAN-phase step cfg2_b128', fused=True)
 
 
-@pytest.mark.parametrize('name', ['cfg1', 'expr_cfg1', 'cfg2_b128'])
+@pytest.mark.parametrize('name', ['cfg1', 'expr_cfg1'])        # (cfg2_b128 passes too -- worst error / tolerance 0.39 --; the headline size is kept for the fused test below)
 def test_gan_phase_step_with_dropout_on_vs_oracle_with_the_same_masks(name):
     """The step AS BENCHMARKED has its dropouts on (embedding 0.1?, TCN blocks, nn.GRU's inter-layer 0.2 / 0.3): until round 6 that arithmetic had a
     self-consistency check only (directional derivative, tests/test_gpu_step.py).  Here the HIP step (literal schedule, default arithmetic mode 70) runs
